@@ -1,0 +1,45 @@
+"""Shared helpers for the parity tests (oracle side only -- never imported by the product)."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def load_npz(name):
+    with np.load(os.path.join(GOLDEN, name), allow_pickle=False) as f:
+        return OrderedDict((k, f[k]) for k in f.files)
+
+
+def reduced_params(requires_grad=False):
+    sd = load_npz('reduced_state.npz')
+    return OrderedDict((k, torch.from_numpy(v.copy()).requires_grad_(requires_grad))
+                       for k, v in sd.items())
+
+
+def full_shapes():
+    f = load_npz('full_shapes.npz')
+    return OrderedDict((str(n), tuple(int(t) for t in s.strip('()').split(',') if t.strip()))
+                       for n, s in zip(f['names'], f['shapes']))
+
+
+def full_params(seed=1234, requires_grad=False):
+    from polyphonic_chord_texture_disentanglement_amd.synthetic import fill_state_dict
+    sd = fill_state_dict(full_shapes(), seed)
+    return OrderedDict((k, v.requires_grad_(requires_grad)) for k, v in sd.items())
+
+
+class CoinList:
+    """Replays a recorded coin-flip sequence (reference draw order)."""
+
+    def __init__(self, coins):
+        self.coins = list(coins)
+        self.i = 0
+
+    def __call__(self):
+        v = self.coins[self.i]
+        self.i += 1
+        return v
