@@ -1,0 +1,51 @@
+// common.hpp -- shared host/device helpers for the ptvae HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define PTV_OK 0
+#define PTV_ERR_ARG (-1)
+#define PTV_ERR_LAUNCH (-2)
+
+#define PTV_PREC_F32 0
+#define PTV_PREC_BF16 1
+
+// every entry point ends with this: report launch-configuration errors as a status code, never throw
+#define PTV_CHECK_LAUNCH()                                                          \
+  do {                                                                              \
+    hipError_t e__ = hipGetLastError();                                             \
+    if (e__ != hipSuccess) {                                                        \
+      fprintf(stderr, "[ptvae_hip] %s:%d launch failed: %s\n", __FILE__, __LINE__,  \
+              hipGetErrorString(e__));                                              \
+      return PTV_ERR_LAUNCH;                                                        \
+    }                                                                               \
+  } while (0)
+
+#define PTV_TRY(expr)                 \
+  do {                                \
+    int rc__ = (expr);                \
+    if (rc__ != PTV_OK) return rc__;  \
+  } while (0)
+
+namespace ptv {
+
+// accurate (ocml) transcendentals: the epilogues are a negligible share of the step and the fp32
+// parity path must track the CPU reference through 50+ recurrent steps
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace ptv

@@ -1,0 +1,132 @@
+// gemm.hip -- plain dense products on the MFMA core: Linear forward (NT), dX (NN), dW (TN, split-K).
+// C-ABI entry: ptv_gemm (include/ptvae_hip.h).
+#include <type_traits>
+#include "common.hpp"
+#include "gemm_core.hpp"
+#include "../../include/ptvae_hip.h"
+
+namespace ptv {
+
+// C[m,n] = act(alpha*acc + bias[n]) (+ C[m,n] when accumulate); atomic adds when split-K
+struct EpiPlain {
+  struct Params {
+    float* C; long ldc;
+    const float* bias;
+    float alpha;
+    int accumulate;   // C += ...
+    int act;          // 0 none, 1 exp
+    int atomic;       // split-K partial sums: atomicAdd into C (C pre-initialised)
+  };
+  template <int FM, int FN, int NG>
+  static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], int m0, int n0, int M, int N) {
+    const int lane = threadIdx.x & 63;
+    const bool vec = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
+    const bool use_bias = p.bias != nullptr && blockIdx.z == 0;
+#pragma unroll
+    for (int i = 0; i < FM; i++) {
+      const int m = m0 + i * 16 + (lane & 15);
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < FN; j++) {
+        const int n = n0 + j * 16 + (lane >> 4) * 4;
+        if (n >= N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          v[e] = p.alpha * acc[i][j][e];
+          if (use_bias && n + e < N) v[e] += p.bias[n + e];
+          if (p.act == 1) v[e] = expf(v[e]);
+        }
+        float* c = p.C + (long)m * p.ldc + n;
+        if (p.atomic) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) if (n + e < N) atomicAdd(c + e, v[e]);
+        } else if (vec && n + 3 < N) {
+          float4 o = make_float4(v[0], v[1], v[2], v[3]);
+          if (p.accumulate) { float4 q = *reinterpret_cast<float4*>(c); o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
+          *reinterpret_cast<float4*>(c) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) if (n + e < N) c[e] = p.accumulate ? c[e] + v[e] : v[e];
+        }
+      }
+    }
+  }
+};
+
+template <class CT, int BM, int BN, int WGM, int WGN, bool KA, bool KB>
+__global__ __launch_bounds__(NTHREADS) void gemm_plain_kernel(GemmArgs g, EpiPlain::Params ep) {
+  gemm_body<CT, BM, BN, WGM, WGN, 1, KA, KB, EpiPlain>(g, ep);
+}
+
+__global__ void fill_rows_kernel(float* C, long ldc, int M, int N, float v) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)M * N;
+  for (; i < total; i += (long)gridDim.x * blockDim.x) C[(i / N) * ldc + (i % N)] = v;
+}
+
+template <class CT, int BM, int BN, bool KA, bool KB>
+static void launch_plain(const GemmArgs& g, const EpiPlain::Params& ep, int splits, hipStream_t s) {
+  dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), splits);
+  hipLaunchKernelGGL((gemm_plain_kernel<CT, BM, BN, 2, 2, KA, KB>), grid, dim3(NTHREADS), 0, s, g, ep);
+}
+
+template <class CT>
+static int gemm_dispatch(int transA, int transB, GemmArgs g, EpiPlain::Params ep, int splitk, hipStream_t s) {
+  // tile choice: 128x128 when it still yields >= ~1 block per CU, else 64x64
+  const long blocks_big = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
+  const bool big = blocks_big >= 192;
+  const int bm = big ? 128 : 64;
+  long blocks = (long)cdiv(g.M, bm) * cdiv(g.N, bm);
+  int splits = 1;
+  if (splitk > 0) splits = splitk;
+  else if (splitk == 0 && blocks < 256 && g.K >= 8 * CT::BK && ep.act == 0) {
+    splits = (int)((512 + blocks - 1) / blocks);
+    int maxs = g.K / (4 * CT::BK);
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+  }
+  int kper = g.K;
+  if (splits > 1) {
+    kper = cdiv(cdiv(g.K, splits), CT::BK) * CT::BK;
+    splits = cdiv(g.K, kper);
+  }
+  g.k_per_split = kper;
+  if (splits > 1) {
+    ep.atomic = 1;
+    if (!ep.accumulate) {
+      long total = (long)g.M * g.N;
+      int nb = (int)((total + 255) / 256); if (nb > 2048) nb = 2048;
+      hipLaunchKernelGGL(fill_rows_kernel, dim3(nb), dim3(256), 0, s, ep.C, ep.ldc, g.M, g.N, 0.f);
+    }
+  }
+#define PTV_LAUNCH(KA, KB)                                              \
+  do {                                                                  \
+    if (big) launch_plain<CT, 128, 128, KA, KB>(g, ep, splits, s);      \
+    else launch_plain<CT, 64, 64, KA, KB>(g, ep, splits, s);            \
+  } while (0)
+  if (!transA && !transB) PTV_LAUNCH(false, false);
+  else if (!transA && transB) PTV_LAUNCH(false, true);
+  else if (transA && transB) PTV_LAUNCH(true, true);
+  else PTV_LAUNCH(true, false);
+#undef PTV_LAUNCH
+  return PTV_OK;
+}
+
+}  // namespace ptv
+
+extern "C" int ptv_gemm(int prec, int transA, int transB, int M, int N, int K,
+                        const float* A, long lda, const float* B, long ldb,
+                        float* C, long ldc, const float* bias, float alpha,
+                        int accumulate, int act, int splitk, void* stream) {
+  if (M < 0 || N < 0 || K < 0 || !A || !B || !C) return PTV_ERR_ARG;
+  if (M == 0 || N == 0) return PTV_OK;
+  ptv::GemmArgs g{A, lda, B, ldb, M, N, K, K, 0};
+  ptv::EpiPlain::Params ep{C, ldc, bias, alpha, accumulate, act, 0};
+  hipStream_t s = (hipStream_t)stream;
+  int rc = (prec == PTV_PREC_BF16) ? ptv::gemm_dispatch<ptv::BF16>(transA, transB, g, ep, splitk, s)
+                                   : ptv::gemm_dispatch<ptv::F32>(transA, transB, g, ep, splitk, s);
+  if (rc != PTV_OK) return rc;
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}

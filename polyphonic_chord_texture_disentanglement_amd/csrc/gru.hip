@@ -1,0 +1,235 @@
+// gru.hip -- fused GRU cell kernels (forward step and BPTT step) on the MFMA core, and the
+// sequence drivers that launch one step kernel per recurrent step on a caller-supplied stream.
+//
+// Follows torch.nn.GRU cell semantics used by every recurrent layer of the reference
+// (ptvae.py:14,39,103,262-286):
+//   r = s(gi_r + W_hr h + b_hr)  z = s(gi_z + W_hz h + b_hz)  n = tanh(gi_n + r*(W_hn h + b_hn))
+//   h' = (1-z)*n + z*h            (gi = W_i x + b_i is produced by a batched input-side GEMM)
+#include <type_traits>
+#include "common.hpp"
+#include "gemm_core.hpp"
+#include "../../include/ptvae_hip.h"
+
+namespace ptv {
+
+// ---------------------------------------------------------------------------------------------
+// forward step epilogue: acc[.][g*FN+fn] = (h_prev . W_h{g}^T) for unit j of gate g
+// ---------------------------------------------------------------------------------------------
+struct EpiGruFwd {
+  struct Params {
+    const float* hprev; long ld_hprev;
+    const float* gi; long ld_gi;        // [M, 3H] input-side pre-activations (b_ih included)
+    const float* gi2; long ld_gi2;      // optional second addend (e.g. per-step token part), may be null
+    const float* bhh;                   // [3H]
+    float* hout; long ld_hout;
+    float* gates; long plane;           // saved (r, z, n, hn) as 4 planes [M,H]; null = do not save
+    const int* lengths; int t;          // packed-sequence mask: row m is updated iff t < lengths[m]
+    int H;
+  };
+  template <int FM, int FN, int NG>
+  static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], int m0, int j0, int M, int H) {
+    static_assert(NG == 3, "GRU epilogue needs the three gates");
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < FM; i++) {
+      const int m = m0 + i * 16 + (lane & 15);
+      if (m >= M) continue;
+      const bool live = p.lengths == nullptr || p.t < p.lengths[m];
+#pragma unroll
+      for (int f = 0; f < FN; f++) {
+        const int j = j0 + f * 16 + (lane >> 4) * 4;
+        if (j >= H) continue;
+        // H is a multiple of 4 for every GRU on the path (host checks) -> 16-byte accesses
+        const float4 gr = *reinterpret_cast<const float4*>(p.gi + (long)m * p.ld_gi + j);
+        const float4 gz = *reinterpret_cast<const float4*>(p.gi + (long)m * p.ld_gi + H + j);
+        const float4 gn = *reinterpret_cast<const float4*>(p.gi + (long)m * p.ld_gi + 2 * H + j);
+        float4 hr = make_float4(0, 0, 0, 0), hz = hr, hn2 = hr;
+        if (p.gi2) {
+          hr = *reinterpret_cast<const float4*>(p.gi2 + (long)m * p.ld_gi2 + j);
+          hz = *reinterpret_cast<const float4*>(p.gi2 + (long)m * p.ld_gi2 + H + j);
+          hn2 = *reinterpret_cast<const float4*>(p.gi2 + (long)m * p.ld_gi2 + 2 * H + j);
+        }
+        const float4 br = *reinterpret_cast<const float4*>(p.bhh + j);
+        const float4 bz = *reinterpret_cast<const float4*>(p.bhh + H + j);
+        const float4 bn = *reinterpret_cast<const float4*>(p.bhh + 2 * H + j);
+        const float4 hp = *reinterpret_cast<const float4*>(p.hprev + (long)m * p.ld_hprev + j);
+        const float gir[4] = {gr.x + hr.x, gr.y + hr.y, gr.z + hr.z, gr.w + hr.w};
+        const float giz[4] = {gz.x + hz.x, gz.y + hz.y, gz.z + hz.z, gz.w + hz.w};
+        const float gin[4] = {gn.x + hn2.x, gn.y + hn2.y, gn.z + hn2.z, gn.w + hn2.w};
+        const float bR[4] = {br.x, br.y, br.z, br.w}, bZ[4] = {bz.x, bz.y, bz.z, bz.w}, bN[4] = {bn.x, bn.y, bn.z, bn.w};
+        const float hP[4] = {hp.x, hp.y, hp.z, hp.w};
+        float r[4], z[4], n[4], hn[4], h[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          r[e] = sigmoidf_(gir[e] + acc[i][0 * FN + f][e] + bR[e]);
+          z[e] = sigmoidf_(giz[e] + acc[i][1 * FN + f][e] + bZ[e]);
+          hn[e] = acc[i][2 * FN + f][e] + bN[e];
+          n[e] = tanhf_(gin[e] + r[e] * hn[e]);
+          if (!live) { r[e] = 0.f; z[e] = 1.f; n[e] = 0.f; }     // masked row: h' = h, zero gate grads
+          h[e] = (1.0f - z[e]) * n[e] + z[e] * hP[e];
+        }
+        *reinterpret_cast<float4*>(p.hout + (long)m * p.ld_hout + j) = make_float4(h[0], h[1], h[2], h[3]);
+        if (p.gates) {
+          float* gs = p.gates + (long)m * H + j;
+          *reinterpret_cast<float4*>(gs + 0 * p.plane) = make_float4(r[0], r[1], r[2], r[3]);
+          *reinterpret_cast<float4*>(gs + 1 * p.plane) = make_float4(z[0], z[1], z[2], z[3]);
+          *reinterpret_cast<float4*>(gs + 2 * p.plane) = make_float4(n[0], n[1], n[2], n[3]);
+          *reinterpret_cast<float4*>(gs + 3 * p.plane) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+        }
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// BPTT step epilogue: acc = dgh_{s+1} . W_hh  (grad reaching h_{s+1}... see gru_seq_bwd)
+// ---------------------------------------------------------------------------------------------
+struct EpiGruBwd {
+  struct Params {
+    const float* dhz_next;              // [M,H] dh (x) z carried from the later step, null at the last step
+    const float* dh_ext; long ld_ext;   // [M,H] gradient arriving at this step's output from outside, may be null
+    const float* dh_ext2; long ld_ext2; // second external addend (e.g. final-state grad), may be null
+    const float* gates; long plane;     // saved r,z,n,hn of this step
+    const float* hprev; long ld_hprev;
+    float* dgi; float* dgh;             // [M,3H] each
+    float* dhz;                         // [M,H] out: dh (x) z
+    int H;
+  };
+  template <int FM, int FN, int NG>
+  static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], int m0, int j0, int M, int H) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < FM; i++) {
+      const int m = m0 + i * 16 + (lane & 15);
+      if (m >= M) continue;
+#pragma unroll
+      for (int f = 0; f < FN; f++) {
+        const int j = j0 + f * 16 + (lane >> 4) * 4;
+        if (j >= H) continue;
+        float dh[4] = {acc[i][f][0], acc[i][f][1], acc[i][f][2], acc[i][f][3]};
+        if (p.dhz_next) { const float4 q = *reinterpret_cast<const float4*>(p.dhz_next + (long)m * H + j); dh[0] += q.x; dh[1] += q.y; dh[2] += q.z; dh[3] += q.w; }
+        if (p.dh_ext) { const float4 q = *reinterpret_cast<const float4*>(p.dh_ext + (long)m * p.ld_ext + j); dh[0] += q.x; dh[1] += q.y; dh[2] += q.z; dh[3] += q.w; }
+        if (p.dh_ext2) { const float4 q = *reinterpret_cast<const float4*>(p.dh_ext2 + (long)m * p.ld_ext2 + j); dh[0] += q.x; dh[1] += q.y; dh[2] += q.z; dh[3] += q.w; }
+        const float* gs = p.gates + (long)m * H + j;
+        const float4 r4 = *reinterpret_cast<const float4*>(gs + 0 * p.plane);
+        const float4 z4 = *reinterpret_cast<const float4*>(gs + 1 * p.plane);
+        const float4 n4 = *reinterpret_cast<const float4*>(gs + 2 * p.plane);
+        const float4 q4 = *reinterpret_cast<const float4*>(gs + 3 * p.plane);
+        const float4 hp4 = *reinterpret_cast<const float4*>(p.hprev + (long)m * p.ld_hprev + j);
+        const float r[4] = {r4.x, r4.y, r4.z, r4.w}, z[4] = {z4.x, z4.y, z4.z, z4.w}, n[4] = {n4.x, n4.y, n4.z, n4.w};
+        const float hn[4] = {q4.x, q4.y, q4.z, q4.w}, hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+        float dr[4], dz[4], dn[4], dnr[4], dhz[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          dn[e] = dh[e] * (1.0f - z[e]) * (1.0f - n[e] * n[e]);
+          dz[e] = dh[e] * (hp[e] - n[e]) * z[e] * (1.0f - z[e]);
+          dr[e] = dn[e] * hn[e] * r[e] * (1.0f - r[e]);
+          dnr[e] = dn[e] * r[e];
+          dhz[e] = dh[e] * z[e];
+        }
+        float* gi = p.dgi + (long)m * 3 * H + j;
+        float* gh = p.dgh + (long)m * 3 * H + j;
+        const float4 vr = make_float4(dr[0], dr[1], dr[2], dr[3]), vz = make_float4(dz[0], dz[1], dz[2], dz[3]);
+        *reinterpret_cast<float4*>(gi) = vr;
+        *reinterpret_cast<float4*>(gi + H) = vz;
+        *reinterpret_cast<float4*>(gi + 2 * H) = make_float4(dn[0], dn[1], dn[2], dn[3]);
+        *reinterpret_cast<float4*>(gh) = vr;
+        *reinterpret_cast<float4*>(gh + H) = vz;
+        *reinterpret_cast<float4*>(gh + 2 * H) = make_float4(dnr[0], dnr[1], dnr[2], dnr[3]);
+        *reinterpret_cast<float4*>(p.dhz + (long)m * H + j) = make_float4(dhz[0], dhz[1], dhz[2], dhz[3]);
+      }
+    }
+  }
+};
+
+template <class CT, int BM, int BJ>
+__global__ __launch_bounds__(NTHREADS) void gru_fwd_step_kernel(GemmArgs g, EpiGruFwd::Params ep) {
+  gemm_body<CT, BM, BJ, 2, 2, 3, false, false, EpiGruFwd>(g, ep);
+}
+template <class CT, int BM, int BN>
+__global__ __launch_bounds__(NTHREADS) void gru_bwd_step_kernel(GemmArgs g, EpiGruBwd::Params ep) {
+  gemm_body<CT, BM, BN, 2, 2, 1, false, true, EpiGruBwd>(g, ep);
+}
+
+template <class CT>
+static void launch_fwd_step(const GemmArgs& g, const EpiGruFwd::Params& ep, hipStream_t s) {
+  // units per block 64 (x3 gates) with 128 rows when that still fills the chip, else 32 x 64
+  const long blocks_big = (long)cdiv(g.M, 128) * cdiv(g.N, 64);
+  if (blocks_big >= 192) {
+    hipLaunchKernelGGL((gru_fwd_step_kernel<CT, 128, 64>), dim3(cdiv(g.N, 64), cdiv(g.M, 128)), dim3(NTHREADS), 0, s, g, ep);
+  } else {
+    hipLaunchKernelGGL((gru_fwd_step_kernel<CT, 64, 32>), dim3(cdiv(g.N, 32), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
+  }
+}
+template <class CT>
+static void launch_bwd_step(const GemmArgs& g, const EpiGruBwd::Params& ep, hipStream_t s) {
+  const long blocks_big = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
+  if (blocks_big >= 192) {
+    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 128, 128>), dim3(cdiv(g.N, 128), cdiv(g.M, 128)), dim3(NTHREADS), 0, s, g, ep);
+  } else {
+    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 64, 64>), dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
+  }
+}
+
+}  // namespace ptv
+
+using namespace ptv;
+
+extern "C" int ptv_gru_seq_fwd(int prec, int M, int H, int T,
+                               const float* gi, long gi_step_stride, long gi_ld,
+                               const float* gi2, long gi2_step_stride, long gi2_ld,
+                               const float* w_hh, const float* b_hh,
+                               float* hall, float* gates,
+                               const int* lengths, int reverse, void* stream) {
+  if (M <= 0 || H <= 0 || T <= 0 || (H & 3) || !gi || !w_hh || !b_hh || !hall) return PTV_ERR_ARG;
+  if ((gi_ld & 3) || (gi_step_stride & 3) || (gi2 && ((gi2_ld & 3) || (gi2_step_stride & 3)))) return PTV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const long MH = (long)M * H;
+  for (int step = 0; step < T; step++) {
+    const int t = reverse ? T - 1 - step : step;
+    GemmArgs g{hall + step * MH, H, w_hh, H, M, H, H, H, (long)H};
+    EpiGruFwd::Params ep{hall + step * MH, H,
+                         gi + t * gi_step_stride, gi_ld,
+                         gi2 ? gi2 + t * gi2_step_stride : nullptr, gi2_ld,
+                         b_hh, hall + (step + 1) * MH, H,
+                         gates ? gates + (long)step * 4 * MH : nullptr, MH,
+                         lengths, t, H};
+    if (prec == PTV_PREC_BF16) launch_fwd_step<BF16>(g, ep, s); else launch_fwd_step<F32>(g, ep, s);
+  }
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
+                               const float* hall, const float* gates, const float* w_hh,
+                               const float* dh_ext, long ext_step_stride, long ext_ld,
+                               const float* dh_last, long last_ld,
+                               float* dgi, float* dgh, float* dhz, float* dh0,
+                               int reverse, void* stream) {
+  if (M <= 0 || H <= 0 || T <= 0 || (H & 3) || !hall || !gates || !w_hh || !dgi || !dgh || !dhz) return PTV_ERR_ARG;
+  if (dh_ext && ((ext_ld & 3) || (ext_step_stride & 3))) return PTV_ERR_ARG;
+  if (dh_last && (last_ld & 3)) return PTV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const long MH = (long)M * H, M3H = 3 * MH;
+  for (int step = T - 1; step >= 0; step--) {
+    const int t = reverse ? T - 1 - step : step;
+    const bool last = step == T - 1;
+    // dh_{step+1} = dgh_{step+1} . W_hh (K = 3H; K = 0 at the last step) + dhz_{step+1} + external grads
+    GemmArgs g{last ? dgh : dgh + (long)(step + 1) * M3H, 3L * H, w_hh, H, M, H, last ? 0 : 3 * H, last ? 0 : 3 * H, 0};
+    EpiGruBwd::Params ep{last ? nullptr : dhz + ((step + 1) & 1) * MH,
+                         dh_ext ? dh_ext + (long)step * ext_step_stride : nullptr, ext_ld,
+                         last ? dh_last : nullptr, last_ld,
+                         gates + (long)step * 4 * MH, MH,
+                         hall + (long)step * MH, H,
+                         dgi + (long)t * M3H, dgh + (long)step * M3H,
+                         dhz + (step & 1) * MH, H};
+    if (prec == PTV_PREC_BF16) launch_bwd_step<BF16>(g, ep, s); else launch_bwd_step<F32>(g, ep, s);
+  }
+  PTV_CHECK_LAUNCH();
+  if (dh0) {
+    // dh0 = dhz_0 + dgh_0 . W_hh
+    hipMemcpyAsync(dh0, dhz, MH * sizeof(float), hipMemcpyDeviceToDevice, s);
+    PTV_TRY(ptv_gemm(prec, 0, 1, M, H, 3 * H, dgh, 3L * H, w_hh, H, dh0, H, nullptr, 1.0f, 1, 0, -1, stream));
+  }
+  return PTV_OK;
+}
