@@ -53,17 +53,21 @@ int ptv_gemm(int prec, int transA, int transB, int M, int N, int K,
  *   lengths[M] or NULL: packed-sequence masking (row m updated at time t iff t < lengths[m]),
  *                 the pack_padded_sequence semantics of ptvae.py:446-453,480-486
  *   reverse: processing step s consumes time index t = T-1-s (the *_reverse direction)
+ *   gi_idx[M] or NULL: row m reads gi row gi_idx[m] instead of m (the duration GRU's input is a
+ *                 one-hot token, so W_i x + b_i is a 2-row table indexed by the previous argmax)
  */
 int ptv_gru_seq_fwd(int prec, int M, int H, int T,
                     const float* gi, long gi_step_stride, long gi_ld,
                     const float* gi2, long gi2_step_stride, long gi2_ld,
                     const float* w_hh, const float* b_hh,
                     float* hall, float* gates,
-                    const int* lengths, int reverse, void* stream);
+                    const int* lengths, int reverse, const int* gi_idx, void* stream);
 
 /* BPTT through ptv_gru_seq_fwd (replaces autograd through the same call sites).
  *   dh_ext [T] x [M,H]  gradient arriving at the state after processing step s (may be NULL)
  *   dh_last [M,H]       gradient arriving at the final state only (may be NULL)
+ *   lr_a/lr_b           optional low-rank external gradient: dh_s += lr_a_s[M,k] . lr_b[k,H]
+ *                       (the 2-wide dur_out_linear feeding back into the duration GRU state)
  *   dgi [T][M][3H] (indexed by TIME t), dgh [T][M][3H] (indexed by processing step s)
  *   dhz scratch [2][M][H];  dh0 [M,H] gradient w.r.t. the initial state (may be NULL)
  * Weight gradients follow with ptv_gemm(transA=1,transB=1): dW_hh += dgh^T.hall[0:T], dW_ih += dgi^T.x
@@ -72,8 +76,89 @@ int ptv_gru_seq_bwd(int prec, int M, int H, int T,
                     const float* hall, const float* gates, const float* w_hh,
                     const float* dh_ext, long ext_step_stride, long ext_ld,
                     const float* dh_last, long last_ld,
+                    const float* lr_a, long lr_step_stride, long lr_lda, int lr_k, const float* lr_b,
                     float* dgi, float* dgh, float* dhz, float* dh0,
                     int reverse, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Streaming helpers (layout shuffles and reductions that torch would do with cat/transpose/sum).
+ */
+/* dst[r*ldd + c] = (accumulate ? dst : 0) + alpha*src[r*lds + c]   (lds = 0 broadcasts one row) */
+int ptv_copy2d(float* dst, long ldd, const float* src, long lds, long rows, int cols, float alpha,
+               int accumulate, void* stream);
+/* [D0,D1,W] -> [D1,D0,W]  (batch-major API tensors <-> step-major internal layout) */
+int ptv_transpose01(float* dst, const float* src, int D0, int D1, int W, void* stream);
+/* out[i] = (accumulate ? out[i] : 0) + sum_t in[t*stride + i] */
+int ptv_sum_steps(float* out, const float* in, long n, int T, long stride, int accumulate, void* stream);
+/* out[g*N + n] += sum over rows r with (sel ? sel[r] : 0) == g of A[r*lda + n]   (bias gradients;
+ * with sel: the duration GRU's W_ih gradient, whose inputs are one-hot tokens) */
+int ptv_colsum(float* out, const float* A, long lda, long rows, int N, const int* sel, int G, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Note embedding as a gather: PtvaeDecoder.emb_x (ptvae.py:531-535) = get_len_index_tensor
+ * (ptvae.py:292-297) + index_tensor_to_multihot_tensor (ptvae.py:299-313) + note_embedding Linear.
+ *   x [B,32,16,6] int64 -> emb STEP-MAJOR [16][32][B][E], lengths [32][B] int32 (lengths may be NULL)
+ * bwd: dW[E,135] += demb^T . multihot, dbias[E] += colsum(demb)  (LDS-privatised, one atomic flush/block)
+ */
+int ptv_embed_fwd(const long* x, const float* W, const float* bias, float* emb, int* lengths, int B, int E, void* stream);
+int ptv_embed_bwd(const long* x, const float* demb, float* dW, float* dbias, int B, int E, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * TextureEncoder front end (ptvae.py:95-99,112-114): Conv2d(1,C,(4,12),stride(4,1)) + ReLU +
+ * MaxPool2d((1,4)) fused; pr_mat [B,32,128] -> pooled [B,C,8,29].  bwd recomputes the conv and
+ * accumulates dW[C,48], dbias[C] (pr_mat is an input: no dX).
+ */
+int ptv_txt_conv_relu_pool_fwd(const float* pr_mat, const float* w, const float* bias, float* pooled, int B, int C, void* stream);
+int ptv_txt_conv_relu_pool_bwd(const float* pr_mat, const float* w, const float* bias, const float* dpooled,
+                               float* dw, float* dbias, int B, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * reparameterize(): get_zs_from_dists / Normal.rsample (amc_dl/torch_plus/train_utils.py:33-34)
+ *   z[b*ldz + j] = mu + sd*eps (eps NULL -> z = mu); kl_sum += sum(-log sd + (sd^2+mu^2)/2 - 1/2)
+ * bwd: dmu = dz + klw*mu + dmu_ext ; dsd = dz*eps + klw*(sd - 1/sd) + dsd_ext ; dlv = dsd*sd
+ *      (lv = log sd is the linear_var output, ptvae.py:27,120); any of dz/eps/ext may be NULL;
+ *      mul_sd = 0 returns dsd itself in `dlv`.
+ */
+int ptv_reparam_kl_fwd(const float* mu, const float* sd, const float* eps, float* z, long ldz, float* kl_sum, int B, int Z, void* stream);
+int ptv_reparam_kl_bwd(const float* mu, const float* sd, const float* eps, const float* dz, long lddz,
+                       const float* dmu_ext, const float* dsd_ext, float klw, int mul_sd, float* dmu, float* dlv, int B, int Z, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Losses: DisentangleVAE.loss_function (model.py:57-68), PtvaeDecoder.recon_loss (ptvae.py:498-511),
+ * chord_loss (model.py:70-83), kl_loss (model.py:85-90) + kl_with_normal (train_utils.py:45-49).
+ *   targets: int32 arrays in the row order of the logits (step_major = 1: [15][32][B], else [B][32][15];
+ *            chord: [8][B] or [B][8]); counts[0/1] += number of non-ignored pitch / duration targets
+ *   ptv_ce_fwd: nll_sum += sum over non-ignored rows of -log softmax(logits)[target]
+ *   ptv_ce_bwd: dlogits = gscale[0] * (softmax - onehot), 0 on ignored rows (gscale is a DEVICE scalar)
+ *   ptv_loss_finalize: 7 sums + 2 counts -> the 11 scalars in train.py:54-55 order
+ *   ptv_loss_bwd_scales: upstream grads of the 11 scalars -> 7 per-component scale factors (device)
+ */
+int ptv_pianotree_targets(const long* x, int B, int step_major, int* pitch_t, int* dur_t, int* counts, void* stream);
+int ptv_chord_targets(const float* c, int B, int step_major, int* root_t, int* chroma_t, int* bass_t, void* stream);
+int ptv_ce_fwd(const float* logits, long ld, const int* targets, long rows, int C, int ignore_index, float* nll_sum, void* stream);
+int ptv_ce_bwd(const float* logits, long ld, const int* targets, long rows, int C, int ignore_index, const float* gscale,
+               float* dlogits, long ldd, void* stream);
+int ptv_kl_fwd(const float* mu, const float* sd, long n, float* kl_sum, void* stream);
+int ptv_kl_bwd(const float* mu, const float* sd, long n, const float* gscale, float* dmu, float* dsd, void* stream);
+int ptv_loss_finalize(const float* sums, const int* counts, float beta, float w0, float w1, float n_kl, float n_root,
+                      float n_chroma, float* out11, void* stream);
+int ptv_loss_bwd_scales(const float* gout11, const int* counts, float beta, float w0, float w1, float n_kl, float n_root,
+                        float n_chroma, float* gs7, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Duration head (ptvae.py:361-367): dur_out[r*ld_out + 0..1] = dur_out_linear(h[r]); idx[r] = argmax
+ * (force_idx, if given, overrides the argmax: replay mode for parity checks).
+ */
+int ptv_dur_out_token(const float* h, int H, const float* w_out, const float* b_out, float* dur_out, long ld_out,
+                      int* idx, const int* force_idx, long rows, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * clip_grad_norm_ (module.py:142-143) + torch.optim.Adam.step (train.py:50, scheduler.py:69-74) over
+ * flat fp32 buffers: sumsq = |g|^2 (device scalar), then p,m,v updated with g*gscale clipped to `clip`.
+ */
+int ptv_grad_sumsq(const float* g, long n, float* sumsq, void* stream);
+int ptv_clip_adam_step(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float gscale, float clip,
+                       float lr, float beta1, float beta2, float eps, int step, void* stream);
 
 #ifdef __cplusplus
 }

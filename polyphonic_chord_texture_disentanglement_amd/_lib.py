@@ -17,21 +17,36 @@ _PREC = {'fp32': PREC_F32, 'f32': PREC_F32, 'bf16': PREC_BF16, 0: 0, 1: 1}
 
 _lib = None
 
-c_f = ctypes.c_void_p       # float* (device)
-c_i = ctypes.c_int
-c_l = ctypes.c_long
-c_fl = ctypes.c_float
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'ptvae_hip.h')
 
-_SIGNATURES = {
-    'ptv_arch': (ctypes.c_char_p, []),
-    'ptv_abi_version': (c_i, []),
-    'ptv_gemm': (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_l, c_f, c_l, c_f, c_l, c_f, c_fl,
-                       c_i, c_i, c_i, c_f]),
-    'ptv_gru_seq_fwd': (c_i, [c_i, c_i, c_i, c_i, c_f, c_l, c_l, c_f, c_l, c_l, c_f, c_f, c_f, c_f,
-                              c_f, c_i, c_f]),
-    'ptv_gru_seq_bwd': (c_i, [c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_l, c_l, c_f, c_l,
-                              c_f, c_f, c_f, c_f, c_i, c_f]),
-}
+
+def _parse_header(path):
+    """Build the ctypes signature table from include/ptvae_hip.h (the single source of truth)."""
+    import re
+    src = open(path).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    sigs = {}
+    for m in re.finditer(r'(const char\*|int)\s+(ptv_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;', src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        argtypes = []
+        if args and args != 'void':
+            for a in args.split(','):
+                a = ' '.join(a.split())
+                if '*' in a:
+                    argtypes.append(ctypes.c_void_p)
+                elif a.startswith('long '):
+                    argtypes.append(ctypes.c_long)
+                elif a.startswith('int '):
+                    argtypes.append(ctypes.c_int)
+                elif a.startswith('float '):
+                    argtypes.append(ctypes.c_float)
+                else:
+                    raise RuntimeError('unparsed argument %r of %s' % (a, name))
+        sigs[name] = (ctypes.c_char_p if ret.startswith('const char') else ctypes.c_int, argtypes)
+    return sigs
+
+
+_SIGNATURES = _parse_header(HEADER_PATH)
 
 
 def exported_symbols():

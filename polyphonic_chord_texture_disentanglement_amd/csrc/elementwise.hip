@@ -1,0 +1,240 @@
+// elementwise.hip -- the HBM-bound kernels of the train step: layout shuffles, reductions over
+// rows / steps, note-embedding gather + its gradient, reparameterisation + KL.
+// All are simple streaming kernels: coalesced 4-byte/16-byte accesses, grid-stride loops,
+// wave-shuffle + LDS reductions, one atomic per block where a cross-block sum is needed.
+#include "common.hpp"
+#include "../../include/ptvae_hip.h"
+
+namespace ptv {
+
+static inline int grid_for(long n, int block = 256, int cap = 4096) {
+  long b = (n + block - 1) / block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// dst[r*ldd + c] = (accumulate ? dst : 0) + alpha * src[r*lds + c]      (lds may be 0: row broadcast)
+__global__ void copy2d_kernel(float* dst, long ldd, const float* src, long lds, long rows, int cols, float alpha, int accumulate) {
+  long total = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / cols; int c = (int)(i % cols);
+    float v = alpha * src[r * lds + c];
+    float* d = dst + r * ldd + c;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
+// [D0, D1, W] -> [D1, D0, W]
+__global__ void transpose01_kernel(float* dst, const float* src, int D0, int D1, int W) {
+  long total = (long)D0 * D1 * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int w = (int)(i % W); long r = i / W; int d0 = (int)(r % D0); int d1 = (int)(r / D0);
+    dst[i] = src[((long)d0 * D1 + d1) * W + w];
+  }
+}
+
+// out[i] = (accumulate? out[i] : 0) + sum_t in[t*stride + i]
+__global__ void sum_steps_kernel(float* out, const float* in, long n, int T, long stride, int accumulate) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float s = accumulate ? out[i] : 0.f;
+    for (int t = 0; t < T; t++) s += in[t * stride + i];
+    out[i] = s;
+  }
+}
+
+// out[g*N + n] += sum_{rows r with (sel ? sel[r] : 0) == g} A[r*lda + n]       (block partial + atomics)
+// block = 256 threads = 64 columns x 4 row lanes
+__global__ void colsum_kernel(float* out, const float* A, long lda, long rows, int N, const int* sel, int G) {
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cx;
+  const long rows_per_block = (rows + gridDim.y - 1) / gridDim.y;
+  const long r0 = blockIdx.y * rows_per_block;
+  const long r1 = min(rows, r0 + rows_per_block);
+  for (int g = 0; g < G; g++) {
+    float s = 0.f;
+    if (n < N) {
+      for (long r = r0 + ry; r < r1; r += 4) {
+        if (sel == nullptr || sel[r] == g) s += A[r * lda + n];
+      }
+    }
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && n < N) {
+      float t = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+      if (t != 0.f) atomicAdd(out + (long)g * N + n, t);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// note embedding as a gather (ptvae.py:299-313 builds a dense multi-hot and multiplies by the
+// 135 x E weight; one-hot . W is a column gather + 5 duration columns)
+//   x [B,32,16,6] int64 -> emb step-major [16][32][B][E], lengths [32][B] int32
+// ---------------------------------------------------------------------------------------------
+__global__ void embed_fwd_kernel(const long* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                                 float* __restrict__ emb, int B, int E) {
+  extern __shared__ __attribute__((aligned(16))) float wt[];     // [135][E] transposed weight
+  for (int i = threadIdx.x; i < 135 * E; i += blockDim.x) { int e = i % E, p = i / E; wt[i] = W[e * 135 + p]; }
+  __syncthreads();
+  const long notes = (long)B * 512;
+  const int per = blockDim.x / E > 0 ? blockDim.x / E : 1;       // notes in flight per block
+  const int e = threadIdx.x % E, sub = threadIdx.x / E;
+  if (sub >= per) return;
+  for (long i = (long)blockIdx.x * per + sub; i < notes; i += (long)gridDim.x * per) {
+    // i indexes the OUTPUT row (n, t, b)
+    const int b = (int)(i % B); const long q = i / B; const int t = (int)(q % 32), n = (int)(q / 32);
+    const long* xr = x + (((long)b * 32 + t) * 16 + n) * 6;
+    const int p = (int)xr[0];
+    float v = bias[e];
+    if (p < 130) v += wt[p * E + e];
+#pragma unroll
+    for (int d = 0; d < 5; d++) v += wt[(130 + d) * E + e] * (float)xr[1 + d];
+    emb[i * E + e] = v;
+  }
+}
+
+__global__ void lengths_kernel(const long* __restrict__ x, int* __restrict__ lengths, int B) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;       // output index t*B + b
+  if (i >= (long)B * 32) return;
+  int b = (int)(i % B), t = (int)(i / B);
+  const long* xr = x + ((long)b * 32 + t) * 16 * 6;
+  int pad = 0;
+  for (int n = 0; n < 16; n++) pad += (xr[n * 6] == 130);
+  lengths[i] = 16 - pad;
+}
+
+// dW[e, p] += sum_notes demb[note, e] * multihot[note, p];  dbias[e] += sum demb
+__global__ void embed_bwd_kernel(const long* __restrict__ x, const float* __restrict__ demb, float* __restrict__ dW,
+                                 float* __restrict__ dbias, int B, int E) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];    // [136][E]: 135 columns + bias
+  for (int i = threadIdx.x; i < 136 * E; i += blockDim.x) acc[i] = 0.f;
+  __syncthreads();
+  const long notes = (long)B * 512;
+  const int per = blockDim.x / E > 0 ? blockDim.x / E : 1;
+  const int e = threadIdx.x % E, sub = threadIdx.x / E;
+  if (sub < per) {
+    for (long i = (long)blockIdx.x * per + sub; i < notes; i += (long)gridDim.x * per) {
+      const int b = (int)(i % B); const long q = i / B; const int t = (int)(q % 32), n = (int)(q / 32);
+      const long* xr = x + (((long)b * 32 + t) * 16 + n) * 6;
+      const float g = demb[i * E + e];
+      const int p = (int)xr[0];
+      if (p < 130) atomicAdd(&acc[p * E + e], g);
+#pragma unroll
+      for (int d = 0; d < 5; d++) { float dv = (float)xr[1 + d]; if (dv != 0.f) atomicAdd(&acc[(130 + d) * E + e], g * dv); }
+      atomicAdd(&acc[135 * E + e], g);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 136 * E; i += blockDim.x) {
+    float v = acc[i];
+    if (v == 0.f) continue;
+    int ee = i % E, p = i / E;
+    if (p < 135) atomicAdd(dW + ee * 135 + p, v); else atomicAdd(dbias + ee, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// reparameterisation + KL (train_utils.py:33-34,45-49):  z = mu + std*eps ; kl = mean(-log std + (std^2+mu^2)/2 - 1/2)
+// ---------------------------------------------------------------------------------------------
+__global__ void reparam_kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ sd, const float* __restrict__ eps,
+                                      float* __restrict__ z, long ldz, float* __restrict__ kl_sum, int B, int Z) {
+  __shared__ float red[4];
+  long total = (long)B * Z;
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int b = (int)(i / Z), j = (int)(i % Z);
+    float m = mu[i], d = sd[i];
+    z[(long)b * ldz + j] = m + d * (eps ? eps[i] : 0.f);
+    s += -logf(d) + (d * d + m * m) * 0.5f - 0.5f;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(kl_sum, red[0] + red[1] + red[2] + red[3]);
+}
+
+// dmu = dz + klw*mu ; dlv = (dz*eps + klw*(std - 1/std)) * std      (lv = log std is the Linear output)
+__global__ void reparam_kl_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ sd, const float* __restrict__ eps,
+                                      const float* __restrict__ dz, long lddz, const float* __restrict__ dmu_ext,
+                                      const float* __restrict__ dsd_ext, float klw, int mul_sd,
+                                      float* __restrict__ dmu, float* __restrict__ dlv, int B, int Z) {
+  long total = (long)B * Z;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int b = (int)(i / Z), j = (int)(i % Z);
+    float m = mu[i], d = sd[i];
+    float g = dz ? dz[(long)b * lddz + j] : 0.f;
+    float gm = g + klw * m + (dmu_ext ? dmu_ext[i] : 0.f);
+    float gs = g * (eps ? eps[i] : 0.f) + klw * (d - 1.0f / d) + (dsd_ext ? dsd_ext[i] : 0.f);
+    dmu[i] = gm;
+    dlv[i] = mul_sd ? gs * d : gs;
+  }
+}
+
+}  // namespace ptv
+
+using namespace ptv;
+
+extern "C" int ptv_copy2d(float* dst, long ldd, const float* src, long lds, long rows, int cols, float alpha, int accumulate, void* stream) {
+  if (!dst || !src || rows < 0 || cols < 0) return PTV_ERR_ARG;
+  if (rows == 0 || cols == 0) return PTV_OK;
+  hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, dst, ldd, src, lds, rows, cols, alpha, accumulate);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_transpose01(float* dst, const float* src, int D0, int D1, int W, void* stream) {
+  if (!dst || !src || D0 <= 0 || D1 <= 0 || W <= 0) return PTV_ERR_ARG;
+  hipLaunchKernelGGL(transpose01_kernel, dim3(grid_for((long)D0 * D1 * W)), dim3(256), 0, (hipStream_t)stream, dst, src, D0, D1, W);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_sum_steps(float* out, const float* in, long n, int T, long stride, int accumulate, void* stream) {
+  if (!out || !in || n <= 0 || T <= 0) return PTV_ERR_ARG;
+  hipLaunchKernelGGL(sum_steps_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, in, n, T, stride, accumulate);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_colsum(float* out, const float* A, long lda, long rows, int N, const int* sel, int G, void* stream) {
+  if (!out || !A || rows < 0 || N <= 0 || G <= 0) return PTV_ERR_ARG;
+  if (rows == 0) return PTV_OK;
+  int gy = (int)((rows + 511) / 512); if (gy > 512) gy = 512; if (gy < 1) gy = 1;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), gy), dim3(256), 0, (hipStream_t)stream, out, A, lda, rows, N, sel, G);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_embed_fwd(const long* x, const float* W, const float* bias, float* emb, int* lengths, int B, int E, void* stream) {
+  if (!x || !W || !bias || !emb || B <= 0 || E <= 0 || E > 256) return PTV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for((long)B * 512, 2, 1024)), dim3(256), 135 * E * sizeof(float), s, x, W, bias, emb, B, E);
+  if (lengths) hipLaunchKernelGGL(lengths_kernel, dim3(cdiv((long)B * 32, 256)), dim3(256), 0, s, x, lengths, B);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_embed_bwd(const long* x, const float* demb, float* dW, float* dbias, int B, int E, void* stream) {
+  if (!x || !demb || !dW || !dbias || B <= 0 || E <= 0 || E > 256) return PTV_ERR_ARG;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((long)B * 512, 2 * 64, 512)), dim3(256), 136 * E * sizeof(float), (hipStream_t)stream, x, demb, dW, dbias, B, E);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_reparam_kl_fwd(const float* mu, const float* sd, const float* eps, float* z, long ldz, float* kl_sum, int B, int Z, void* stream) {
+  if (!mu || !sd || !z || !kl_sum || B <= 0 || Z <= 0) return PTV_ERR_ARG;
+  hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(grid_for((long)B * Z, 256, 256)), dim3(256), 0, (hipStream_t)stream, mu, sd, eps, z, ldz, kl_sum, B, Z);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_reparam_kl_bwd(const float* mu, const float* sd, const float* eps, const float* dz, long lddz,
+                                  const float* dmu_ext, const float* dsd_ext, float klw, int mul_sd, float* dmu, float* dlv, int B, int Z, void* stream) {
+  if (!mu || !sd || !dmu || !dlv || B <= 0 || Z <= 0) return PTV_ERR_ARG;
+  hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3(grid_for((long)B * Z)), dim3(256), 0, (hipStream_t)stream, mu, sd, eps, dz, lddz, dmu_ext, dsd_ext, klw, mul_sd, dmu, dlv, B, Z);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}

@@ -24,6 +24,7 @@ struct EpiGruFwd {
     float* hout; long ld_hout;
     float* gates; long plane;           // saved (r, z, n, hn) as 4 planes [M,H]; null = do not save
     const int* lengths; int t;          // packed-sequence mask: row m is updated iff t < lengths[m]
+    const int* gi_idx;                  // optional: row m reads gi row gi_idx[m] (token-indexed gate table)
     int H;
   };
   template <int FM, int FN, int NG>
@@ -40,9 +41,10 @@ struct EpiGruFwd {
         const int j = j0 + f * 16 + (lane >> 4) * 4;
         if (j >= H) continue;
         // H is a multiple of 4 for every GRU on the path (host checks) -> 16-byte accesses
-        const float4 gr = *reinterpret_cast<const float4*>(p.gi + (long)m * p.ld_gi + j);
-        const float4 gz = *reinterpret_cast<const float4*>(p.gi + (long)m * p.ld_gi + H + j);
-        const float4 gn = *reinterpret_cast<const float4*>(p.gi + (long)m * p.ld_gi + 2 * H + j);
+        const long gm = p.gi_idx ? p.gi_idx[m] : m;
+        const float4 gr = *reinterpret_cast<const float4*>(p.gi + gm * p.ld_gi + j);
+        const float4 gz = *reinterpret_cast<const float4*>(p.gi + gm * p.ld_gi + H + j);
+        const float4 gn = *reinterpret_cast<const float4*>(p.gi + gm * p.ld_gi + 2 * H + j);
         float4 hr = make_float4(0, 0, 0, 0), hz = hr, hn2 = hr;
         if (p.gi2) {
           hr = *reinterpret_cast<const float4*>(p.gi2 + (long)m * p.ld_gi2 + j);
@@ -89,6 +91,7 @@ struct EpiGruBwd {
     const float* dhz_next;              // [M,H] dh (x) z carried from the later step, null at the last step
     const float* dh_ext; long ld_ext;   // [M,H] gradient arriving at this step's output from outside, may be null
     const float* dh_ext2; long ld_ext2; // second external addend (e.g. final-state grad), may be null
+    const float* lr_a; long lr_lda; int lr_k; const float* lr_b;   // optional low-rank addend: dh += lr_a[m, 0:k] . lr_b[k, H]
     const float* gates; long plane;     // saved r,z,n,hn of this step
     const float* hprev; long ld_hprev;
     float* dgi; float* dgh;             // [M,3H] each
@@ -110,6 +113,13 @@ struct EpiGruBwd {
         if (p.dhz_next) { const float4 q = *reinterpret_cast<const float4*>(p.dhz_next + (long)m * H + j); dh[0] += q.x; dh[1] += q.y; dh[2] += q.z; dh[3] += q.w; }
         if (p.dh_ext) { const float4 q = *reinterpret_cast<const float4*>(p.dh_ext + (long)m * p.ld_ext + j); dh[0] += q.x; dh[1] += q.y; dh[2] += q.z; dh[3] += q.w; }
         if (p.dh_ext2) { const float4 q = *reinterpret_cast<const float4*>(p.dh_ext2 + (long)m * p.ld_ext2 + j); dh[0] += q.x; dh[1] += q.y; dh[2] += q.z; dh[3] += q.w; }
+        if (p.lr_a) {
+          for (int k = 0; k < p.lr_k; k++) {
+            const float a = p.lr_a[(long)m * p.lr_lda + k];
+            const float4 q = *reinterpret_cast<const float4*>(p.lr_b + (long)k * H + j);
+            dh[0] += a * q.x; dh[1] += a * q.y; dh[2] += a * q.z; dh[3] += a * q.w;
+          }
+        }
         const float* gs = p.gates + (long)m * H + j;
         const float4 r4 = *reinterpret_cast<const float4*>(gs + 0 * p.plane);
         const float4 z4 = *reinterpret_cast<const float4*>(gs + 1 * p.plane);
@@ -180,7 +190,7 @@ extern "C" int ptv_gru_seq_fwd(int prec, int M, int H, int T,
                                const float* gi2, long gi2_step_stride, long gi2_ld,
                                const float* w_hh, const float* b_hh,
                                float* hall, float* gates,
-                               const int* lengths, int reverse, void* stream) {
+                               const int* lengths, int reverse, const int* gi_idx, void* stream) {
   if (M <= 0 || H <= 0 || T <= 0 || (H & 3) || !gi || !w_hh || !b_hh || !hall) return PTV_ERR_ARG;
   if ((gi_ld & 3) || (gi_step_stride & 3) || (gi2 && ((gi2_ld & 3) || (gi2_step_stride & 3)))) return PTV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -193,7 +203,7 @@ extern "C" int ptv_gru_seq_fwd(int prec, int M, int H, int T,
                          gi2 ? gi2 + t * gi2_step_stride : nullptr, gi2_ld,
                          b_hh, hall + (step + 1) * MH, H,
                          gates ? gates + (long)step * 4 * MH : nullptr, MH,
-                         lengths, t, H};
+                         lengths, t, gi_idx, H};
     if (prec == PTV_PREC_BF16) launch_fwd_step<BF16>(g, ep, s); else launch_fwd_step<F32>(g, ep, s);
   }
   PTV_CHECK_LAUNCH();
@@ -204,6 +214,7 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
                                const float* hall, const float* gates, const float* w_hh,
                                const float* dh_ext, long ext_step_stride, long ext_ld,
                                const float* dh_last, long last_ld,
+                               const float* lr_a, long lr_step_stride, long lr_lda, int lr_k, const float* lr_b,
                                float* dgi, float* dgh, float* dhz, float* dh0,
                                int reverse, void* stream) {
   if (M <= 0 || H <= 0 || T <= 0 || (H & 3) || !hall || !gates || !w_hh || !dgi || !dgh || !dhz) return PTV_ERR_ARG;
@@ -219,6 +230,7 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
     EpiGruBwd::Params ep{last ? nullptr : dhz + ((step + 1) & 1) * MH,
                          dh_ext ? dh_ext + (long)step * ext_step_stride : nullptr, ext_ld,
                          last ? dh_last : nullptr, last_ld,
+                         lr_a ? lr_a + (long)step * lr_step_stride : nullptr, lr_lda, lr_k, lr_b,
                          gates + (long)step * 4 * MH, MH,
                          hall + (long)step * MH, H,
                          dgi + (long)t * M3H, dgh + (long)step * M3H,
@@ -228,7 +240,7 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
   PTV_CHECK_LAUNCH();
   if (dh0) {
     // dh0 = dhz_0 + dgh_0 . W_hh
-    hipMemcpyAsync(dh0, dhz, MH * sizeof(float), hipMemcpyDeviceToDevice, s);
+    if (hipMemcpyAsync(dh0, dhz, MH * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return PTV_ERR_LAUNCH;
     PTV_TRY(ptv_gemm(prec, 0, 1, M, H, 3 * H, dgh, 3L * H, w_hh, H, dh0, H, nullptr, 1.0f, 1, 0, -1, stream));
   }
   return PTV_OK;

@@ -1,0 +1,252 @@
+// loss.hip -- reconstruction / KL / chord losses of DisentangleVAE.loss_function (model.py:57-90,
+// ptvae.py:498-511) and their gradients w.r.t. the logits and the posterior parameters.
+//   pl = CE(pitch logits, x[:,:,1:,0], ignore 130)      dl = CE(dur logits, x[:,:,1:,1:], ignore 2)
+//   kl_x = mean_{B x Z}(-log s + (s^2+m^2)/2 - 1/2)     root/chroma/bass = plain CE
+//   loss = w0*pl + w1*dl + beta*(kl_chd+kl_rhy) + root + chroma + bass
+// Row layouts: logits may be batch-major [B,32,15,*] (API tensors) or step-major [15,32,B,*]
+// (the decoder's internal layout); targets are materialised once per step in the same order.
+#include "common.hpp"
+#include "../../include/ptvae_hip.h"
+
+namespace ptv {
+
+// sums:   0 pitch nll, 1 dur nll, 2 kl_chd, 3 kl_rhy, 4 root nll, 5 chroma nll, 6 bass nll
+// counts: 0 valid pitch targets, 1 valid dur targets
+
+__global__ void pianotree_targets_kernel(const long* __restrict__ x, int B, int step_major,
+                                         int* __restrict__ pitch_t, int* __restrict__ dur_t, int* __restrict__ counts) {
+  __shared__ int red[2][4];
+  const long rows = (long)B * 480;
+  int cp = 0, cd = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (long)gridDim.x * blockDim.x) {
+    int b, t, n;
+    if (step_major) { b = (int)(i % B); long q = i / B; t = (int)(q % 32); n = (int)(q / 32); }
+    else { n = (int)(i % 15); long q = i / 15; t = (int)(q % 32); b = (int)(q / 32); }
+    const long* xr = x + (((long)b * 32 + t) * 16 + n + 1) * 6;
+    int p = (int)xr[0];
+    pitch_t[i] = p;
+    cp += (p != 130);
+#pragma unroll
+    for (int d = 0; d < 5; d++) { int v = (int)xr[1 + d]; dur_t[i * 5 + d] = v; cd += (v != 2); }
+  }
+  for (int o = 32; o > 0; o >>= 1) { cp += __shfl_xor(cp, o, 64); cd += __shfl_xor(cd, o, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = cp; red[1][threadIdx.x >> 6] = cd; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(counts + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(counts + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+// c [B,8,36] -> root/bass argmax targets [8B], chroma targets [8B*12]   (model.py:72-74)
+__global__ void chord_targets_kernel(const float* __restrict__ c, int B, int step_major,
+                                     int* __restrict__ root_t, int* __restrict__ chroma_t, int* __restrict__ bass_t) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * 8) return;
+  int b, t;
+  if (step_major) { b = (int)(i % B); t = (int)(i / B); } else { t = (int)(i % 8); b = (int)(i / 8); }
+  const float* cr = c + ((long)b * 8 + t) * 36;
+  int ar = 0, ab = 0; float mr = cr[0], mb = cr[24];
+  for (int k = 1; k < 12; k++) { if (cr[k] > mr) { mr = cr[k]; ar = k; } if (cr[24 + k] > mb) { mb = cr[24 + k]; ab = k; } }
+  root_t[i] = ar; bass_t[i] = ab;
+  for (int k = 0; k < 12; k++) chroma_t[i * 12 + k] = (int)cr[12 + k];
+}
+
+// one wave per row, C <= 256
+template <bool BWD>
+__global__ void ce_wave_kernel(const float* __restrict__ logits, long ld, const int* __restrict__ tgt, long rows, int C, int ignore,
+                               float* __restrict__ nll_sum, const float* __restrict__ gscale, float* __restrict__ dlogits, long ldd) {
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float local = 0.f;
+  const float gs = BWD ? gscale[0] : 0.f;
+  for (long r = (long)blockIdx.x * 4 + w; r < rows; r += (long)gridDim.x * 4) {
+    const float* lr = logits + r * ld;
+    const int t = tgt[r];
+    float v[4]; float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { int c = lane + 64 * k; v[k] = c < C ? lr[c] : -INFINITY; m = fmaxf(m, v[k]); }
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { int c = lane + 64 * k; if (c < C) s += expf(v[k] - m); }
+    s = wave_sum(s);
+    const bool valid = t != ignore;
+    if (!BWD) {
+      if (valid && lane == 0) local += -(lr[t] - m - logf(s));
+    } else {
+      float* dr = dlogits + r * ldd;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        int c = lane + 64 * k;
+        if (c < C) dr[c] = valid ? gs * (expf(v[k] - m) / s - (c == t ? 1.f : 0.f)) : 0.f;
+      }
+    }
+  }
+  if (!BWD) {
+    if (lane == 0) red[w] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) { float t = red[0] + red[1] + red[2] + red[3]; if (t != 0.f) atomicAdd(nll_sum, t); }
+  }
+}
+
+// one thread per row, C <= 16 (duration bits C=2, chord heads C=12 / 2)
+template <bool BWD>
+__global__ void ce_small_kernel(const float* __restrict__ logits, long ld, const int* __restrict__ tgt, long rows, int C, int ignore,
+                                float* __restrict__ nll_sum, const float* __restrict__ gscale, float* __restrict__ dlogits, long ldd) {
+  __shared__ float red[4];
+  float local = 0.f;
+  const float gs = BWD ? gscale[0] : 0.f;
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
+    const float* lr = logits + r * ld;
+    const int t = tgt[r];
+    float v[16]; float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { v[k] = k < C ? lr[k] : -INFINITY; m = fmaxf(m, v[k]); }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) if (k < C) s += expf(v[k] - m);
+    const bool valid = t != ignore;
+    if (!BWD) {
+      if (valid) {
+        float vt = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) if (k == t) vt = v[k];
+        local += -(vt - m - logf(s));
+      }
+    } else {
+      float* dr = dlogits + r * ldd;
+#pragma unroll
+      for (int k = 0; k < 16; k++) if (k < C) dr[k] = valid ? gs * (expf(v[k] - m) / s - (k == t ? 1.f : 0.f)) : 0.f;
+    }
+  }
+  if (!BWD) {
+    local = wave_sum(local);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) { float t = red[0] + red[1] + red[2] + red[3]; if (t != 0.f) atomicAdd(nll_sum, t); }
+  }
+}
+
+__global__ void kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ sd, long n, float* __restrict__ kl_sum) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float m = mu[i], d = sd[i];
+    s += -logf(d) + (d * d + m * m) * 0.5f - 0.5f;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(kl_sum, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void kl_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ sd, long n, const float* __restrict__ gscale,
+                              float* __restrict__ dmu, float* __restrict__ dsd) {
+  const float gs = gscale[0];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float m = mu[i], d = sd[i];
+    dmu[i] = gs * m;
+    dsd[i] = gs * (d - 1.0f / d);
+  }
+}
+
+// out: loss, recon, pl, dl, kl, kl_chd, kl_rhy, chord, root, chroma, bass   (train.py:54-55 order)
+__global__ void loss_finalize_kernel(const float* __restrict__ sums, const int* __restrict__ counts, float beta, float w0, float w1,
+                                     float n_kl, float n_root, float n_chroma, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float pl = sums[0] / (float)counts[0];
+  float dl = sums[1] / (float)counts[1];
+  float klc = sums[2] / n_kl, klr = sums[3] / n_kl;
+  float root = sums[4] / n_root, chroma = sums[5] / n_chroma, bass = sums[6] / n_root;
+  float recon = w0 * pl + w1 * dl;
+  float kl = klc + klr;
+  float chord = root + chroma + bass;
+  out[0] = recon + beta * kl + chord;
+  out[1] = recon; out[2] = pl; out[3] = dl; out[4] = kl; out[5] = klc; out[6] = klr;
+  out[7] = chord; out[8] = root; out[9] = chroma; out[10] = bass;
+}
+
+// upstream grads of the 11 outputs (null entries = 0) -> per-component scale factors gs[7]
+__global__ void loss_bwd_scales_kernel(const float* __restrict__ g, const int* __restrict__ counts, float beta, float w0, float w1,
+                                       float n_kl, float n_root, float n_chroma, float* __restrict__ gs) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float g_recon = g[0] + g[1];
+  gs[0] = (g_recon * w0 + g[2]) / (float)counts[0];
+  gs[1] = (g_recon * w1 + g[3]) / (float)counts[1];
+  float g_kl = g[0] * beta + g[4];
+  gs[2] = (g_kl + g[5]) / n_kl;
+  gs[3] = (g_kl + g[6]) / n_kl;
+  float g_chord = g[0] + g[7];
+  gs[4] = (g_chord + g[8]) / n_root;
+  gs[5] = (g_chord + g[9]) / n_chroma;
+  gs[6] = (g_chord + g[10]) / n_root;
+}
+
+static inline int grid_rows(long n, int per_block, int cap = 8192) {
+  long b = (n + per_block - 1) / per_block; if (b > cap) b = cap; if (b < 1) b = 1; return (int)b;
+}
+
+}  // namespace ptv
+
+using namespace ptv;
+
+extern "C" int ptv_pianotree_targets(const long* x, int B, int step_major, int* pitch_t, int* dur_t, int* counts, void* stream) {
+  if (!x || !pitch_t || !dur_t || !counts || B <= 0) return PTV_ERR_ARG;
+  hipLaunchKernelGGL(pianotree_targets_kernel, dim3(grid_rows((long)B * 480, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, B, step_major, pitch_t, dur_t, counts);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_chord_targets(const float* c, int B, int step_major, int* root_t, int* chroma_t, int* bass_t, void* stream) {
+  if (!c || !root_t || !chroma_t || !bass_t || B <= 0) return PTV_ERR_ARG;
+  hipLaunchKernelGGL(chord_targets_kernel, dim3(cdiv((long)B * 8, 256)), dim3(256), 0, (hipStream_t)stream, c, B, step_major, root_t, chroma_t, bass_t);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_ce_fwd(const float* logits, long ld, const int* targets, long rows, int C, int ignore_index, float* nll_sum, void* stream) {
+  if (!logits || !targets || !nll_sum || rows <= 0 || C <= 0 || C > 256) return PTV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (C <= 16) hipLaunchKernelGGL((ce_small_kernel<false>), dim3(grid_rows(rows, 256, 2048)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nll_sum, nullptr, nullptr, 0L);
+  else hipLaunchKernelGGL((ce_wave_kernel<false>), dim3(grid_rows(rows, 4, 16384)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nll_sum, nullptr, nullptr, 0L);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_ce_bwd(const float* logits, long ld, const int* targets, long rows, int C, int ignore_index, const float* gscale, float* dlogits, long ldd, void* stream) {
+  if (!logits || !targets || !gscale || !dlogits || rows <= 0 || C <= 0 || C > 256) return PTV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (C <= 16) hipLaunchKernelGGL((ce_small_kernel<true>), dim3(grid_rows(rows, 256, 2048)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nullptr, gscale, dlogits, ldd);
+  else hipLaunchKernelGGL((ce_wave_kernel<true>), dim3(grid_rows(rows, 4, 16384)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nullptr, gscale, dlogits, ldd);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_kl_fwd(const float* mu, const float* sd, long n, float* kl_sum, void* stream) {
+  if (!mu || !sd || !kl_sum || n <= 0) return PTV_ERR_ARG;
+  hipLaunchKernelGGL(kl_fwd_kernel, dim3(grid_rows(n, 256, 256)), dim3(256), 0, (hipStream_t)stream, mu, sd, n, kl_sum);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_kl_bwd(const float* mu, const float* sd, long n, const float* gscale, float* dmu, float* dsd, void* stream) {
+  if (!mu || !sd || !gscale || !dmu || !dsd || n <= 0) return PTV_ERR_ARG;
+  hipLaunchKernelGGL(kl_bwd_kernel, dim3(grid_rows(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, mu, sd, n, gscale, dmu, dsd);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_loss_finalize(const float* sums, const int* counts, float beta, float w0, float w1, float n_kl, float n_root, float n_chroma, float* out11, void* stream) {
+  if (!sums || !counts || !out11) return PTV_ERR_ARG;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, counts, beta, w0, w1, n_kl, n_root, n_chroma, out11);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_loss_bwd_scales(const float* gout11, const int* counts, float beta, float w0, float w1, float n_kl, float n_root, float n_chroma, float* gs7, void* stream) {
+  if (!gout11 || !counts || !gs7) return PTV_ERR_ARG;
+  hipLaunchKernelGGL(loss_bwd_scales_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gout11, counts, beta, w0, w1, n_kl, n_root, n_chroma, gs7);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}

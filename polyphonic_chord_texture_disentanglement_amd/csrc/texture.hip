@@ -1,0 +1,125 @@
+// texture.hip -- TextureEncoder front end (ptvae.py:95-99,112-114):
+//   Conv2d(1, C, kernel (4,12), stride (4,1)) -> ReLU -> MaxPool2d((1,4)) over pr_mat [B,32,128],
+// fused into one kernel: the [B,32,128] piano-roll is read once (coalesced, 4 rows of 128 floats
+// per beat staged in LDS), the [B,C,8,117] conv map never exists in HBM.
+// Output pooled [B,C,8,29]; its raw reinterpretation as [B*8, C*29/... ] rows of 290 (the
+// reference's .view(bs, 8, -1), ptvae.py:114) is done by the caller with a plain pointer cast.
+#include "common.hpp"
+#include "../../include/ptvae_hip.h"
+
+namespace ptv {
+
+constexpr int TX_MAXC = 16;
+
+// one block iteration = one (b, beat); thread -> (ch, pp)
+__global__ void txt_conv_fwd_kernel(const float* __restrict__ pr, const float* __restrict__ w, const float* __restrict__ bias,
+                                    float* __restrict__ pooled, int B, int C) {
+  __shared__ float rows[4][128];
+  __shared__ float ws[TX_MAXC * 48 + TX_MAXC];
+  for (int i = threadIdx.x; i < C * 48; i += blockDim.x) ws[i] = w[i];
+  for (int i = threadIdx.x; i < C; i += blockDim.x) ws[C * 48 + i] = bias[i];
+  const int nout = C * 29;
+  for (long it = blockIdx.x; it < (long)B * 8; it += gridDim.x) {
+    const int b = (int)(it / 8), beat = (int)(it % 8);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) rows[i >> 7][i & 127] = pr[((long)b * 32 + beat * 4) * 128 + i];
+    __syncthreads();
+    for (int o = threadIdx.x; o < nout; o += blockDim.x) {
+      const int ch = o / 29, pp = o % 29;
+      const float* wc = ws + ch * 48;
+      float best = 0.f;                       // ReLU floor: max(relu(v_q)) = max(0, max v_q)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int p0 = pp * 4 + q;
+        float v = ws[C * 48 + ch];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 12; j++) v += wc[i * 12 + j] * rows[i][p0 + j];
+        best = fmaxf(best, v);
+      }
+      pooled[(((long)b * C + ch) * 8 + beat) * 29 + pp] = best;
+    }
+  }
+}
+
+// dW[ch,i,j] += sum dpool * [conv>0 at the arg-max q] * pr ; dbias likewise.  Conv is recomputed.
+__global__ void txt_conv_bwd_kernel(const float* __restrict__ pr, const float* __restrict__ w, const float* __restrict__ bias,
+                                    const float* __restrict__ dpooled, float* __restrict__ dw, float* __restrict__ dbias, int B, int C) {
+  __shared__ float rows[4][128];
+  __shared__ float ws[TX_MAXC * 48 + TX_MAXC];
+  __shared__ float acc[TX_MAXC * 49];
+  for (int i = threadIdx.x; i < C * 48; i += blockDim.x) ws[i] = w[i];
+  for (int i = threadIdx.x; i < C; i += blockDim.x) ws[C * 48 + i] = bias[i];
+  for (int i = threadIdx.x; i < C * 49; i += blockDim.x) acc[i] = 0.f;
+  const int nout = C * 29;
+  // thread o = threadIdx.x (< nout) keeps a private gradient for its channel across all iterations
+  float g[49];
+#pragma unroll
+  for (int k = 0; k < 49; k++) g[k] = 0.f;
+  const int o = threadIdx.x;
+  const int ch = o / 29, pp = o % 29;
+  for (long it = blockIdx.x; it < (long)B * 8; it += gridDim.x) {
+    const int b = (int)(it / 8), beat = (int)(it % 8);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) rows[i >> 7][i & 127] = pr[((long)b * 32 + beat * 4) * 128 + i];
+    __syncthreads();
+    if (o < nout) {
+      const float* wc = ws + ch * 48;
+      float best = 0.f; int bq = -1;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int p0 = pp * 4 + q;
+        float v = ws[C * 48 + ch];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 12; j++) v += wc[i * 12 + j] * rows[i][p0 + j];
+        if (v > best) { best = v; bq = q; }      // first max wins ties, as MaxPool2d does
+      }
+      if (bq >= 0) {
+        const float d = dpooled[(((long)b * C + ch) * 8 + beat) * 29 + pp];
+        const int p0 = pp * 4 + bq;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 12; j++) g[i * 12 + j] += d * rows[i][p0 + j];
+        g[48] += d;
+      }
+    }
+  }
+  __syncthreads();
+  if (o < nout) {
+#pragma unroll
+    for (int k = 0; k < 49; k++) if (g[k] != 0.f) atomicAdd(&acc[ch * 49 + k], g[k]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * 49; i += blockDim.x) {
+    float v = acc[i];
+    if (v == 0.f) continue;
+    int c2 = i / 49, k = i % 49;
+    if (k < 48) atomicAdd(dw + c2 * 48 + k, v); else atomicAdd(dbias + c2, v);
+  }
+}
+
+}  // namespace ptv
+
+using namespace ptv;
+
+extern "C" int ptv_txt_conv_relu_pool_fwd(const float* pr_mat, const float* w, const float* bias, float* pooled, int B, int C, void* stream) {
+  if (!pr_mat || !w || !bias || !pooled || B <= 0 || C <= 0 || C > TX_MAXC) return PTV_ERR_ARG;
+  int grid = B * 8 < 2048 ? B * 8 : 2048;
+  hipLaunchKernelGGL(txt_conv_fwd_kernel, dim3(grid), dim3(320), 0, (hipStream_t)stream, pr_mat, w, bias, pooled, B, C);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_txt_conv_relu_pool_bwd(const float* pr_mat, const float* w, const float* bias, const float* dpooled,
+                                          float* dw, float* dbias, int B, int C, void* stream) {
+  if (!pr_mat || !w || !bias || !dpooled || !dw || !dbias || B <= 0 || C <= 0 || C > TX_MAXC) return PTV_ERR_ARG;
+  int nthreads = ((C * 29 + 63) / 64) * 64;       // one thread per (ch, pp)
+  int grid = B * 8 < 512 ? B * 8 : 512;
+  hipLaunchKernelGGL(txt_conv_bwd_kernel, dim3(grid), dim3(nthreads), 0, (hipStream_t)stream, pr_mat, w, bias, dpooled, dw, dbias, B, C);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}

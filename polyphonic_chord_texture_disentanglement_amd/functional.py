@@ -1,0 +1,864 @@
+"""torch.autograd glue over the HIP library: one autograd.Function per block of the train step.
+
+Every forward/backward body below is a sequence of C-ABI calls (`_lib.call`) on raw device
+pointers; torch supplies memory, streams and the autograd graph only.  Internal activations are
+STEP-MAJOR ([step][row][feature]) so that every recurrent step and every weight-gradient product
+sees one contiguous matrix; API tensors are converted at the boundary (Transpose01).
+
+Reference call sites are cited per function (paths are into /root/reference).
+"""
+import torch
+
+from ._lib import call, prec_code, ptr, stream_ptr
+
+F32 = torch.float32
+
+
+def _empty(*shape, dev):
+    return torch.empty(*shape, device=dev, dtype=F32)
+
+
+def _zeros(*shape, dev):
+    return torch.zeros(*shape, device=dev, dtype=F32)
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
+    return t.stride(0)
+
+
+def gemm(a, b, out=None, *, ta=False, tb=False, bias=None, alpha=1.0, acc=False, act=0, prec=0, splitk=0):
+    """out[M,N] = act(alpha * op(a) . op(b)^T + bias) (+ out);  see ptv_gemm in include/ptvae_hip.h."""
+    M, K = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
+    N, Kb = (b.shape[1], b.shape[0]) if tb else (b.shape[0], b.shape[1])
+    assert K == Kb, (a.shape, b.shape, ta, tb)
+    if out is None:
+        assert not acc
+        out = _empty(M, N, dev=a.device)
+    assert tuple(out.shape) == (M, N), (out.shape, M, N)
+    call('ptv_gemm', prec, int(ta), int(tb), M, N, K, ptr(a), _ld(a), ptr(b), _ld(b), ptr(out), _ld(out),
+         ptr(bias), float(alpha), int(acc), int(act), int(splitk), stream_ptr())
+    return out
+
+
+def copy2d(dst, src, *, alpha=1.0, acc=False, rows=None, cols=None, lds=None):
+    rows = dst.shape[0] if rows is None else rows
+    cols = dst.shape[1] if cols is None else cols
+    call('ptv_copy2d', ptr(dst), _ld(dst), ptr(src), (_ld(src) if lds is None else lds), rows, cols,
+         float(alpha), int(acc), stream_ptr())
+    return dst
+
+
+def colsum(out, a, sel=None, groups=1):
+    """out[g, n] += sum_{rows with sel==g} a[row, n]"""
+    call('ptv_colsum', ptr(out), ptr(a), _ld(a), a.shape[0], a.shape[1], ptr(sel), groups, stream_ptr())
+    return out
+
+
+def sum_steps(x3, out=None, acc=False):
+    T = x3.shape[0]
+    n = x3[0].numel()
+    assert x3.is_contiguous()
+    if out is None:
+        out = _empty(*x3.shape[1:], dev=x3.device)
+    call('ptv_sum_steps', ptr(out), ptr(x3), n, T, n, int(acc), stream_ptr())
+    return out
+
+
+def transpose01(x):
+    D0, D1 = x.shape[0], x.shape[1]
+    W = x[0, 0].numel()
+    x = x.contiguous()
+    out = torch.empty((D1, D0) + tuple(x.shape[2:]), device=x.device, dtype=F32)
+    call('ptv_transpose01', ptr(out), ptr(x), D0, D1, W, stream_ptr())
+    return out
+
+
+def gru_fwd(prec, gi, gi_step, gi_ld, w_hh, b_hh, hall, gates, *, gi2=None, gi2_step=0, gi2_ld=0, lengths=None,
+            reverse=False, gi_idx=None, T=None):
+    T1, M, H = hall.shape
+    T = T1 - 1 if T is None else T
+    call('ptv_gru_seq_fwd', prec, M, H, T, ptr(gi), gi_step, gi_ld, ptr(gi2), gi2_step, gi2_ld, ptr(w_hh),
+         ptr(b_hh), ptr(hall), ptr(gates), ptr(lengths), int(reverse), ptr(gi_idx), stream_ptr())
+
+
+def gru_bwd(prec, hall, gates, w_hh, *, dh_ext=None, dh_last=None, lr=None, reverse=False, need_dh0=True):
+    """-> dgi [T,M,3H] (time order), dgh [T,M,3H] (processing order), dh0 [M,H] or None"""
+    T1, M, H = hall.shape
+    T = T1 - 1
+    dev = hall.device
+    dgi = _empty(T, M, 3 * H, dev=dev)
+    dgh = _empty(T, M, 3 * H, dev=dev)
+    dhz = _empty(2, M, H, dev=dev)
+    dh0 = _empty(M, H, dev=dev) if need_dh0 else None
+    ext = (ptr(dh_ext), dh_ext.stride(0), dh_ext.stride(1)) if dh_ext is not None else (None, 0, 0)
+    last = (ptr(dh_last), dh_last.stride(0)) if dh_last is not None else (None, 0)
+    lra = (ptr(lr[0]), lr[1], lr[2], lr[3], ptr(lr[4])) if lr is not None else (None, 0, 0, 0, None)
+    call('ptv_gru_seq_bwd', prec, M, H, T, ptr(hall), ptr(gates), ptr(w_hh), *ext, *last, *lra, ptr(dgi),
+         ptr(dgh), ptr(dhz), ptr(dh0), int(reverse), stream_ptr())
+    return dgi, dgh, dh0
+
+
+def _gbuf(p):
+    """zero-initialised gradient buffer for parameter p (weight-gradient kernels accumulate)."""
+    return torch.zeros_like(p, memory_format=torch.contiguous_format)
+
+
+def _as2d(t):
+    return t.view(1, -1) if t.dim() == 1 else t
+
+
+# =============================================================================================
+# nn.Linear  (x . W^T + b)
+# =============================================================================================
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2, w, b, prec):
+        y = gemm(x2, w, bias=b, prec=prec)
+        ctx.save_for_backward(x2, w)
+        ctx.prec = prec
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        prec = ctx.prec
+        dy = dy.contiguous()
+        dx = gemm(dy, w, tb=True, prec=prec) if ctx.needs_input_grad[0] else None
+        dw = gemm(dy, x2, _gbuf(w), ta=True, tb=True, acc=True, prec=prec)
+        db = colsum(_zeros(1, w.shape[0], dev=w.device), dy).view(-1) if ctx.has_bias else None
+        return dx, dw, db, None
+
+
+# =============================================================================================
+# Transpose01: batch-major API tensors <-> step-major internals
+# =============================================================================================
+class Transpose01Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return transpose01(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return transpose01(dy)
+
+
+# =============================================================================================
+# PtvaeDecoder.emb_x  (ptvae.py:531-535)
+# =============================================================================================
+class EmbedFn(torch.autograd.Function):
+    """x [B,32,16,6] int64 -> (emb step-major [16,32,B,E], lengths int32 [32*B])"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        B = x.shape[0]
+        E = w.shape[0]
+        x = x.contiguous()
+        emb = _empty(16, 32, B, E, dev=w.device)
+        lengths = torch.empty(32 * B, device=w.device, dtype=torch.int32)
+        call('ptv_embed_fwd', ptr(x), ptr(w), ptr(b), ptr(emb), ptr(lengths), B, E, stream_ptr())
+        ctx.save_for_backward(x, w)
+        ctx.mark_non_differentiable(lengths)
+        return emb, lengths
+
+    @staticmethod
+    def backward(ctx, demb, _dl):
+        x, w = ctx.saved_tensors
+        B, E = x.shape[0], w.shape[0]
+        dw = _gbuf(w)
+        db = _zeros(E, dev=w.device)
+        call('ptv_embed_bwd', ptr(x), ptr(demb.contiguous()), ptr(dw), ptr(db), B, E, stream_ptr())
+        return None, dw, db
+
+
+# =============================================================================================
+# bidirectional GRU, final states only  (RnnEncoder / TextureEncoder / dec_notes_emb_gru)
+# =============================================================================================
+def _bigru_forward(prec, x3, lengths, w):
+    """x3 [T,M,I] step-major.  w = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r).
+    Returns out [M,2H] and the saved state for backward."""
+    T, M, I = x3.shape
+    H = w[1].shape[1]
+    dev = x3.device
+    xf = x3.reshape(T * M, I)
+    saved = []
+    out = _empty(M, 2 * H, dev=dev)
+    for d in range(2):
+        w_ih, w_hh, b_ih, b_hh = w[4 * d: 4 * d + 4]
+        gi = gemm(xf, w_ih, bias=b_ih, prec=prec)                      # [T*M, 3H]
+        hall = _empty(T + 1, M, H, dev=dev)
+        hall[0].zero_()
+        gates = _empty(T, 4, M, H, dev=dev)
+        gru_fwd(prec, gi, M * 3 * H, 3 * H, w_hh, b_hh, hall, gates, lengths=lengths, reverse=bool(d))
+        copy2d(out[:, d * H:(d + 1) * H], hall[T])
+        saved.append((hall, gates))
+    return out, saved
+
+
+def _bigru_backward(prec, x3, w, saved, dout, need_dx):
+    T, M, I = x3.shape
+    H = w[1].shape[1]
+    xf = x3.reshape(T * M, I)
+    grads = []
+    dx = None
+    for d in range(2):
+        w_ih, w_hh, b_ih, b_hh = w[4 * d: 4 * d + 4]
+        hall, gates = saved[d]
+        dgi, dgh, _ = gru_bwd(prec, hall, gates, w_hh, dh_last=dout[:, d * H:(d + 1) * H], reverse=bool(d),
+                              need_dh0=False)
+        dgi2, dgh2 = dgi.view(T * M, 3 * H), dgh.view(T * M, 3 * H)
+        dw_ih = gemm(dgi2, xf, _gbuf(w_ih), ta=True, tb=True, acc=True, prec=prec)
+        dw_hh = gemm(dgh2, hall[:T].view(T * M, H), _gbuf(w_hh), ta=True, tb=True, acc=True, prec=prec)
+        db_ih = colsum(_zeros(1, 3 * H, dev=xf.device), dgi2).view(-1)
+        db_hh = colsum(_zeros(1, 3 * H, dev=xf.device), dgh2).view(-1)
+        grads += [dw_ih, dw_hh, db_ih, db_hh]
+        if need_dx:
+            if dx is None:
+                dx = gemm(dgi2, w_ih, tb=True, prec=prec)
+            else:
+                gemm(dgi2, w_ih, dx, tb=True, acc=True, prec=prec)
+    return grads, (dx.view(T, M, I) if dx is not None else None)
+
+
+class BiGruFinalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x3, lengths, prec, *w):
+        x3 = x3.contiguous()
+        out, saved = _bigru_forward(prec, x3, lengths, w)
+        ctx.save_for_backward(x3, *w)
+        ctx.saved_state = saved
+        ctx.prec = prec
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x3, *w = ctx.saved_tensors
+        grads, dx = _bigru_backward(ctx.prec, x3, w, ctx.saved_state, dout.contiguous(), ctx.needs_input_grad[0])
+        ctx.saved_state = None
+        return (dx, None, None) + tuple(grads)
+
+
+# =============================================================================================
+# encoder heads: mu = linear_mu(h), std = exp(linear_var(h))   (ptvae.py:26-28, 119-121)
+# =============================================================================================
+class EncoderHeadsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, w_mu, b_mu, w_var, b_var, prec):
+        mu = gemm(h, w_mu, bias=b_mu, prec=prec)
+        sd = gemm(h, w_var, bias=b_var, act=1, prec=prec)
+        ctx.save_for_backward(h, w_mu, w_var, mu, sd)
+        ctx.prec = prec
+        return mu, sd
+
+    @staticmethod
+    def backward(ctx, dmu, dsd):
+        h, w_mu, w_var, mu, sd = ctx.saved_tensors
+        prec = ctx.prec
+        B, Z = mu.shape
+        dev = h.device
+        dmu = None if dmu is None else dmu.contiguous()
+        dsd = None if dsd is None else dsd.contiguous()
+        gmu, glv = _empty(B, Z, dev=dev), _empty(B, Z, dev=dev)
+        call('ptv_reparam_kl_bwd', ptr(mu), ptr(sd), None, None, 0, ptr(dmu), ptr(dsd), 0.0, 1, ptr(gmu), ptr(glv),
+             B, Z, stream_ptr())
+        dh = gemm(gmu, w_mu, tb=True, prec=prec)
+        gemm(glv, w_var, dh, tb=True, acc=True, prec=prec)
+        dw_mu = gemm(gmu, h, _gbuf(w_mu), ta=True, tb=True, acc=True, prec=prec)
+        dw_var = gemm(glv, h, _gbuf(w_var), ta=True, tb=True, acc=True, prec=prec)
+        db_mu = colsum(_zeros(1, Z, dev=dev), gmu).view(-1)
+        db_var = colsum(_zeros(1, Z, dev=dev), glv).view(-1)
+        return dh, dw_mu, db_mu, dw_var, db_var, None
+
+
+# =============================================================================================
+# reparameterize: z = mu + std * eps   (train_utils.py:33-34)
+# =============================================================================================
+class ReparamFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, sd, eps):
+        B, Z = mu.shape
+        z = _empty(B, Z, dev=mu.device)
+        scratch = _zeros(1, dev=mu.device)
+        call('ptv_reparam_kl_fwd', ptr(mu.contiguous()), ptr(sd.contiguous()), ptr(eps), ptr(z), Z, ptr(scratch), B, Z,
+             stream_ptr())
+        ctx.save_for_backward(mu, sd, eps)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        mu, sd, eps = ctx.saved_tensors
+        B, Z = mu.shape
+        dz = dz.contiguous()
+        dmu, dsd = _empty(B, Z, dev=mu.device), _empty(B, Z, dev=mu.device)
+        call('ptv_reparam_kl_bwd', ptr(mu), ptr(sd), ptr(eps), ptr(dz), Z, None, None, 0.0, 0, ptr(dmu), ptr(dsd), B, Z,
+             stream_ptr())
+        return dmu, dsd, None
+
+
+# =============================================================================================
+# TextureEncoder front end: conv + relu + maxpool   (ptvae.py:95-99,112-114)
+# =============================================================================================
+class TextureFrontFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pr_mat, w, b):
+        B, C = pr_mat.shape[0], w.shape[0]
+        pr_mat = pr_mat.contiguous()
+        pooled = _empty(B, C, 8, 29, dev=w.device)
+        call('ptv_txt_conv_relu_pool_fwd', ptr(pr_mat), ptr(w), ptr(b), ptr(pooled), B, C, stream_ptr())
+        ctx.save_for_backward(pr_mat, w, b)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        pr_mat, w, b = ctx.saved_tensors
+        dw, db = _gbuf(w), _gbuf(b)
+        call('ptv_txt_conv_relu_pool_bwd', ptr(pr_mat), ptr(w), ptr(b), ptr(dpooled.contiguous()), ptr(dw), ptr(db),
+             pr_mat.shape[0], w.shape[0], stream_ptr())
+        return None, dw, db
+
+
+# =============================================================================================
+# PtvaeDecoder, teacher-forced (tfr1 = tfr2 = 1): restructured from 2912 dependent cells to
+# 32 + 15 + 5 sequential steps.  ptvae.py:336-496.
+# =============================================================================================
+DEC_PARAM_NAMES = [
+    'dec_init_input', 'dur_sos_token',
+    'z2dec_hid_linear.weight', 'z2dec_hid_linear.bias', 'z2dec_in_linear.weight', 'z2dec_in_linear.bias',
+    'dec_notes_emb_gru.weight_ih_l0', 'dec_notes_emb_gru.weight_hh_l0', 'dec_notes_emb_gru.bias_ih_l0',
+    'dec_notes_emb_gru.bias_hh_l0', 'dec_notes_emb_gru.weight_ih_l0_reverse', 'dec_notes_emb_gru.weight_hh_l0_reverse',
+    'dec_notes_emb_gru.bias_ih_l0_reverse', 'dec_notes_emb_gru.bias_hh_l0_reverse',
+    'dec_time_gru.weight_ih_l0', 'dec_time_gru.weight_hh_l0', 'dec_time_gru.bias_ih_l0', 'dec_time_gru.bias_hh_l0',
+    'dec_time_to_notes_hid.weight', 'dec_time_to_notes_hid.bias',
+    'dec_notes_gru.weight_ih_l0', 'dec_notes_gru.weight_hh_l0', 'dec_notes_gru.bias_ih_l0', 'dec_notes_gru.bias_hh_l0',
+    'pitch_out_linear.weight', 'pitch_out_linear.bias',
+    'dec_dur_gru.weight_ih_l0', 'dec_dur_gru.weight_hh_l0', 'dec_dur_gru.bias_ih_l0', 'dec_dur_gru.bias_hh_l0',
+    'dur_hid_linear.weight', 'dur_hid_linear.bias', 'dur_out_linear.weight', 'dur_out_linear.bias',
+]
+
+_CONST = {}
+
+
+def _onehot2x5(dev):
+    key = ('oh25', str(dev))
+    if key not in _CONST:
+        t = torch.zeros(2, 5, device=dev, dtype=F32)
+        t[0, 0] = 1.0
+        t[1, 1] = 1.0
+        _CONST[key] = t
+    return _CONST[key]
+
+
+def _eye2(dev):
+    key = ('eye2', str(dev))
+    if key not in _CONST:
+        _CONST[key] = torch.eye(2, device=dev, dtype=F32)
+    return _CONST[key]
+
+
+class DecoderTFFn(torch.autograd.Function):
+    """(z [B,Zs], emb step-major [16,32,B,E], lengths int32 [32B], force_dur_idx or None, *params)
+    -> pitch logits step-major [15,32,B,130], dur logits [15*32*B, 5, 2]"""
+
+    @staticmethod
+    def forward(ctx, z, emb, lengths, force_dur, prec, *params):
+        P = dict(zip(DEC_PARAM_NAMES, params))
+        dev = z.device
+        z = z.contiguous()
+        B = z.shape[0]
+        R = 32 * B
+        E = emb.shape[-1]
+        He = P['dec_notes_emb_gru.weight_hh_l0'].shape[1]
+        Ht = P['dec_time_gru.weight_hh_l0'].shape[1]
+        Hn = P['dec_notes_gru.weight_hh_l0'].shape[1]
+        Hd = P['dec_dur_gru.weight_hh_l0'].shape[1]
+        NP = P['pitch_out_linear.weight'].shape[0]              # 130
+        S = ctx                                                  # stash everything on ctx
+
+        # --- z -> initial time state, z_in  (ptvae.py:435-437)
+        NS = _empty(33, B, Ht, dev=dev)
+        gemm(z, P['z2dec_hid_linear.weight'], NS[0], bias=P['z2dec_hid_linear.bias'], prec=prec)
+        z_in = gemm(z, P['z2dec_in_linear.weight'], bias=P['z2dec_in_linear.bias'], prec=prec)
+
+        # --- ground-truth note summaries: packed bi-GRU final states (ptvae.py:446-453)
+        emb3 = emb.view(16, R, E)
+        w_emb = [P['dec_notes_emb_gru.' + n] for n in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0',
+                                                        'weight_ih_l0_reverse', 'weight_hh_l0_reverse',
+                                                        'bias_ih_l0_reverse', 'bias_hh_l0_reverse')]
+        xs, emb_saved = _bigru_forward(prec, emb3, lengths, w_emb)             # [R, 2He], rows (t, b)
+
+        # --- time GRU inputs: token_t = [init ; xs[t-1]], z_in broadcast over t  (ptvae.py:457-462,476-478)
+        TOKS = _empty(33, B, 2 * He, dev=dev)
+        copy2d(TOKS[0], P['dec_init_input'].view(1, -1), lds=0)
+        copy2d(TOKS[1:].view(R, 2 * He), xs)
+        w_ih_t = P['dec_time_gru.weight_ih_l0']
+        gi_t = gemm(TOKS[:32].view(R, 2 * He), w_ih_t[:, :2 * He], prec=prec)  # [32*B, 3Ht]
+        zg = gemm(z_in, w_ih_t[:, 2 * He:], bias=P['dec_time_gru.bias_ih_l0'], prec=prec)
+        gates_t = _empty(32, 4, B, Ht, dev=dev)
+        gru_fwd(prec, gi_t, B * 3 * Ht, 3 * Ht, P['dec_time_gru.weight_hh_l0'], P['dec_time_gru.bias_hh_l0'], NS,
+                gates_t, gi2=zg, gi2_step=0, gi2_ld=3 * Ht)
+        NSf = NS[1:].view(R, Ht)                                               # notes_summary rows (t, b)
+
+        # --- notes GRU: h0 = dec_time_to_notes_hid(ns); input [ns | token], ns part hoisted (ptvae.py:374-398)
+        HN = _empty(16, R, Hn, dev=dev)
+        gemm(NSf, P['dec_time_to_notes_hid.weight'], HN[0], bias=P['dec_time_to_notes_hid.bias'], prec=prec)
+        w_ih_n = P['dec_notes_gru.weight_ih_l0']
+        GC = gemm(NSf, w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec)          # [R, 3Hn]
+        GT = gemm(emb3[:15].view(15 * R, E), w_ih_n[:, Ht:], prec=prec)                        # [15R, 3Hn]
+        gates_n = _empty(15, 4, R, Hn, dev=dev)
+        gru_fwd(prec, GT, R * 3 * Hn, 3 * Hn, P['dec_notes_gru.weight_hh_l0'], P['dec_notes_gru.bias_hh_l0'], HN,
+                gates_n, gi2=GC, gi2_step=0, gi2_ld=3 * Hn)
+        NSUM = HN[1:].view(15 * R, Hn)
+
+        # --- pitch head + duration GRU initial state (ptvae.py:343-352)
+        M = 15 * R
+        pitch = gemm(NSUM, P['pitch_out_linear.weight'], bias=P['pitch_out_linear.bias'], prec=prec)   # [M,130]
+        w_dh = P['dur_hid_linear.weight']
+        HD = _empty(6, M, Hd, dev=dev)
+        gemm(NSUM, w_dh[:, :Hn], HD[0], bias=P['dur_hid_linear.bias'], prec=prec)
+        gemm(pitch, w_dh[:, Hn:], HD[0], acc=True, prec=prec)
+
+        # --- 5-step duration GRU with argmax feedback (ptvae.py:353-367)
+        w_ih_d, b_ih_d = P['dec_dur_gru.weight_ih_l0'], P['dec_dur_gru.bias_ih_l0']
+        tab0 = gemm(P['dur_sos_token'].view(1, -1), w_ih_d, bias=b_ih_d, prec=0)       # [1, 3Hd]  (tiny: exact)
+        tab = gemm(_onehot2x5(dev), w_ih_d, bias=b_ih_d, prec=0)                       # [2, 3Hd]
+        gates_d = _empty(5, 4, M, Hd, dev=dev)
+        dur = _empty(M, 5, 2, dev=dev)
+        idx = torch.empty(5, M, device=dev, dtype=torch.int32)
+        dur2 = dur.view(M, 10)
+        for d in range(5):
+            gi, gi_ld, gi_idx = (tab0, 0, None) if d == 0 else (tab, 3 * Hd, idx[d - 1])
+            gru_fwd(prec, gi, 0, gi_ld, P['dec_dur_gru.weight_hh_l0'], P['dec_dur_gru.bias_hh_l0'], HD[d:d + 2],
+                    gates_d[d], gi_idx=gi_idx, T=1)
+            call('ptv_dur_out_token', ptr(HD[d + 1]), Hd, ptr(P['dur_out_linear.weight']), ptr(P['dur_out_linear.bias']),
+                 ptr(dur2[:, 2 * d:]), 10, ptr(idx[d]), ptr(force_dur[d]) if force_dur is not None else None, M,
+                 stream_ptr())
+
+        S.save_for_backward(z, emb, *params)
+        S.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in, emb_saved=emb_saved,
+                    TOKS=TOKS, gates_t=gates_t, HN=HN, gates_n=gates_n, pitch=pitch, HD=HD, gates_d=gates_d, idx=idx,
+                    lengths=lengths)
+        S.mark_non_differentiable(idx)
+        return pitch.view(15, 32, B, NP), dur, idx
+
+    @staticmethod
+    def backward(ctx, dpitch, ddur, _didx):
+        z, emb, *params = ctx.saved_tensors
+        P = dict(zip(DEC_PARAM_NAMES, params))
+        st = ctx.st
+        ctx.st = None
+        B, R, E, He, Ht, Hn, Hd, NP, prec = (st[k] for k in ('B', 'R', 'E', 'He', 'Ht', 'Hn', 'Hd', 'NP', 'prec'))
+        dev = z.device
+        M = 15 * R
+        G = {n: None for n in DEC_PARAM_NAMES}
+        NS, HN, HD, TOKS = st['NS'], st['HN'], st['HD'], st['TOKS']
+        NSf = NS[1:].view(R, Ht)
+        NSUM = HN[1:].view(M, Hn)
+        emb3 = emb.view(16, R, E)
+        z1 = lambda n: _zeros(1, n, dev=dev)
+
+        ddur = (ddur.contiguous() if ddur is not None else _zeros(M, 5, 2, dev=dev)).view(M, 10)
+        dP = _empty(M, NP, dev=dev)
+        if dpitch is not None:
+            copy2d(dP, dpitch.contiguous().view(M, NP))
+        else:
+            dP.zero_()
+
+        # ---- duration GRU (5 steps) ----
+        w_out = P['dur_out_linear.weight']
+        w_hh_d = P['dec_dur_gru.weight_hh_l0']
+        dgi_d, dgh_d, dHD0 = gru_bwd(prec, HD, st['gates_d'], w_hh_d, lr=(ddur, 2, 10, 2, w_out))
+        g = _gbuf(w_out)
+        for d in range(5):
+            gemm(ddur[:, 2 * d:2 * d + 2], HD[d + 1], g, ta=True, tb=True, acc=True, prec=prec)
+        G['dur_out_linear.weight'] = g
+        G['dur_out_linear.bias'] = colsum(z1(2), ddur.view(M * 5, 2)).view(-1)
+        G['dec_dur_gru.weight_hh_l0'] = gemm(dgh_d.view(5 * M, 3 * Hd), HD[:5].view(5 * M, Hd), _gbuf(w_hh_d), ta=True,
+                                             tb=True, acc=True, prec=prec)
+        G['dec_dur_gru.bias_hh_l0'] = colsum(z1(3 * Hd), dgh_d.view(5 * M, 3 * Hd)).view(-1)
+        G['dec_dur_gru.bias_ih_l0'] = colsum(z1(3 * Hd), dgi_d.view(5 * M, 3 * Hd)).view(-1)
+        w_ih_d = P['dec_dur_gru.weight_ih_l0']
+        cs0 = colsum(z1(3 * Hd), dgi_d[0])                                       # step 0: dense <sos> token
+        g = gemm(cs0, P['dur_sos_token'].view(1, -1), _gbuf(w_ih_d), ta=True, tb=True, acc=True, prec=0, splitk=-1)
+        G['dur_sos_token'] = gemm(cs0, w_ih_d, tb=True, prec=0, splitk=-1).view(-1)
+        sel = _zeros(2, 3 * Hd, dev=dev)                                         # steps 1..4: one-hot tokens {0,1}
+        for d in range(1, 5):
+            colsum(sel, dgi_d[d], sel=st['idx'][d - 1], groups=2)
+        gemm(sel, _eye2(dev), g[:, 0:2], ta=True, acc=True, prec=0, splitk=-1)
+        G['dec_dur_gru.weight_ih_l0'] = g
+        del dgi_d, dgh_d
+
+        # ---- dur_hid_linear([note_summary | est_pitch]) and pitch_out_linear ----
+        w_dh = P['dur_hid_linear.weight']
+        dNSUM = gemm(dHD0, w_dh[:, :Hn], tb=True, prec=prec)                      # [M, Hn]
+        gemm(dHD0, w_dh[:, Hn:], dP, tb=True, acc=True, prec=prec)
+        g = _gbuf(w_dh)
+        gemm(dHD0, NSUM, g[:, :Hn], ta=True, tb=True, acc=True, prec=prec)
+        gemm(dHD0, st['pitch'], g[:, Hn:], ta=True, tb=True, acc=True, prec=prec)
+        G['dur_hid_linear.weight'] = g
+        G['dur_hid_linear.bias'] = colsum(z1(Hd), dHD0).view(-1)
+        w_p = P['pitch_out_linear.weight']
+        gemm(dP, w_p, dNSUM, tb=True, acc=True, prec=prec)
+        G['pitch_out_linear.weight'] = gemm(dP, NSUM, _gbuf(w_p), ta=True, tb=True, acc=True, prec=prec)
+        G['pitch_out_linear.bias'] = colsum(z1(NP), dP).view(-1)
+        del dP, dHD0
+
+        # ---- notes GRU (15 steps, batch 32*B) ----
+        w_hh_n, w_ih_n = P['dec_notes_gru.weight_hh_l0'], P['dec_notes_gru.weight_ih_l0']
+        dgi_n, dgh_n, dHN0 = gru_bwd(prec, HN, st['gates_n'], w_hh_n, dh_ext=dNSUM.view(15, R, Hn))
+        G['dec_notes_gru.weight_hh_l0'] = gemm(dgh_n.view(M, 3 * Hn), HN[:15].view(M, Hn), _gbuf(w_hh_n), ta=True, tb=True,
+                                               acc=True, prec=prec)
+        G['dec_notes_gru.bias_hh_l0'] = colsum(z1(3 * Hn), dgh_n.view(M, 3 * Hn)).view(-1)
+        del dgh_n, dNSUM
+        dGC = sum_steps(dgi_n)                                                    # [R, 3Hn]
+        G['dec_notes_gru.bias_ih_l0'] = colsum(z1(3 * Hn), dGC).view(-1)
+        g = _gbuf(w_ih_n)
+        gemm(dGC, NSf, g[:, :Ht], ta=True, tb=True, acc=True, prec=prec)
+        gemm(dgi_n.view(M, 3 * Hn), emb3[:15].view(M, E), g[:, Ht:], ta=True, tb=True, acc=True, prec=prec)
+        G['dec_notes_gru.weight_ih_l0'] = g
+        demb = _empty(16, R, E, dev=dev)
+        demb[15].zero_()
+        gemm(dgi_n.view(M, 3 * Hn), w_ih_n[:, Ht:], demb[:15].view(M, E), tb=True, prec=prec)
+        dNS = gemm(dGC, w_ih_n[:, :Ht], tb=True, prec=prec)                       # [R, Ht]
+        del dgi_n, dGC
+        w_tn = P['dec_time_to_notes_hid.weight']
+        gemm(dHN0, w_tn, dNS, tb=True, acc=True, prec=prec)
+        G['dec_time_to_notes_hid.weight'] = gemm(dHN0, NSf, _gbuf(w_tn), ta=True, tb=True, acc=True, prec=prec)
+        G['dec_time_to_notes_hid.bias'] = colsum(z1(Hn), dHN0).view(-1)
+
+        # ---- time GRU (32 steps, batch B) ----
+        w_hh_t, w_ih_t = P['dec_time_gru.weight_hh_l0'], P['dec_time_gru.weight_ih_l0']
+        dgi_t, dgh_t, dzhid = gru_bwd(prec, NS, st['gates_t'], w_hh_t, dh_ext=dNS.view(32, B, Ht))
+        G['dec_time_gru.weight_hh_l0'] = gemm(dgh_t.view(R, 3 * Ht), NS[:32].view(R, Ht), _gbuf(w_hh_t), ta=True, tb=True,
+                                              acc=True, prec=prec)
+        G['dec_time_gru.bias_hh_l0'] = colsum(z1(3 * Ht), dgh_t.view(R, 3 * Ht)).view(-1)
+        dZG = sum_steps(dgi_t)                                                    # [B, 3Ht]
+        G['dec_time_gru.bias_ih_l0'] = colsum(z1(3 * Ht), dZG).view(-1)
+        g = _gbuf(w_ih_t)
+        gemm(dZG, st['z_in'], g[:, 2 * He:], ta=True, tb=True, acc=True, prec=prec)
+        gemm(dgi_t.view(R, 3 * Ht), TOKS[:32].view(R, 2 * He), g[:, :2 * He], ta=True, tb=True, acc=True, prec=prec)
+        G['dec_time_gru.weight_ih_l0'] = g
+        dz_in = gemm(dZG, w_ih_t[:, 2 * He:], tb=True, prec=prec)                 # [B, Zi]
+        dTOKS = _empty(33, B, 2 * He, dev=dev)
+        dTOKS[32].zero_()
+        gemm(dgi_t.view(R, 3 * Ht), w_ih_t[:, :2 * He], dTOKS[:32].view(R, 2 * He), tb=True, prec=prec)
+        G['dec_init_input'] = colsum(z1(2 * He), dTOKS[0]).view(-1)
+        dxs = dTOKS[1:].view(R, 2 * He)
+        del dgi_t, dgh_t
+
+        # ---- ground-truth summaries: bi-GRU over embedded notes ----
+        w_emb_names = ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0', 'weight_ih_l0_reverse',
+                       'weight_hh_l0_reverse', 'bias_ih_l0_reverse', 'bias_hh_l0_reverse')
+        w_emb = [P['dec_notes_emb_gru.' + n] for n in w_emb_names]
+        ge, dx_emb = _bigru_backward(prec, emb3, w_emb, st['emb_saved'], dxs, True)
+        for n, gg in zip(w_emb_names, ge):
+            G['dec_notes_emb_gru.' + n] = gg
+        copy2d(demb.view(16 * R, E), dx_emb.view(16 * R, E), acc=True)
+
+        # ---- z linears ----
+        w_zh, w_zi = P['z2dec_hid_linear.weight'], P['z2dec_in_linear.weight']
+        dz = gemm(dzhid, w_zh, tb=True, prec=prec)
+        gemm(dz_in, w_zi, dz, tb=True, acc=True, prec=prec)
+        G['z2dec_hid_linear.weight'] = gemm(dzhid, z, _gbuf(w_zh), ta=True, tb=True, acc=True, prec=prec)
+        G['z2dec_hid_linear.bias'] = colsum(z1(Ht), dzhid).view(-1)
+        G['z2dec_in_linear.weight'] = gemm(dz_in, z, _gbuf(w_zi), ta=True, tb=True, acc=True, prec=prec)
+        G['z2dec_in_linear.bias'] = colsum(z1(w_zi.shape[0]), dz_in).view(-1)
+
+        return (dz, demb.view(16, 32, B, E), None, None, None) + tuple(G[n] for n in DEC_PARAM_NAMES)
+
+
+# =============================================================================================
+# RnnDecoder (chord decoder), teacher-forced (tfr3 = 1): ptvae.py:51-87
+# =============================================================================================
+CHD_PARAM_NAMES = ['init_input', 'z2dec_hid.weight', 'z2dec_hid.bias', 'z2dec_in.weight', 'z2dec_in.bias',
+                   'gru.weight_ih_l0', 'gru.weight_hh_l0', 'gru.bias_ih_l0', 'gru.bias_hh_l0',
+                   'root_out.weight', 'root_out.bias', 'chroma_out.weight', 'chroma_out.bias',
+                   'bass_out.weight', 'bass_out.bias']
+
+
+class ChordDecoderTFFn(torch.autograd.Function):
+    """(z_chd [B,Z], c_sm [8,B,36] step-major, *params) -> root [8,B,12], chroma [8,B,24], bass [8,B,12]"""
+
+    @staticmethod
+    def forward(ctx, z, c_sm, prec, *params):
+        P = dict(zip(CHD_PARAM_NAMES, params))
+        dev = z.device
+        z = z.contiguous()
+        B = z.shape[0]
+        T = c_sm.shape[0]
+        H = P['gru.weight_hh_l0'].shape[1]
+        I = c_sm.shape[2]
+        hall = _empty(T + 1, B, H, dev=dev)
+        gemm(z, P['z2dec_hid.weight'], hall[0], bias=P['z2dec_hid.bias'], prec=prec)
+        z_in = gemm(z, P['z2dec_in.weight'], bias=P['z2dec_in.bias'], prec=prec)
+        toks = _empty(T, B, I, dev=dev)
+        copy2d(toks[0], P['init_input'].view(1, -1), lds=0)
+        if T > 1:
+            copy2d(toks[1:].view((T - 1) * B, I), c_sm[:T - 1].reshape((T - 1) * B, I))
+        w_ih = P['gru.weight_ih_l0']
+        gi = gemm(toks.view(T * B, I), w_ih[:, :I], prec=prec)
+        zg = gemm(z_in, w_ih[:, I:], bias=P['gru.bias_ih_l0'], prec=prec)
+        gates = _empty(T, 4, B, H, dev=dev)
+        gru_fwd(prec, gi, B * 3 * H, 3 * H, P['gru.weight_hh_l0'], P['gru.bias_hh_l0'], hall, gates, gi2=zg, gi2_step=0,
+                gi2_ld=3 * H)
+        hs = hall[1:].view(T * B, H)
+        root = gemm(hs, P['root_out.weight'], bias=P['root_out.bias'], prec=prec)
+        chroma = gemm(hs, P['chroma_out.weight'], bias=P['chroma_out.bias'], prec=prec)
+        bass = gemm(hs, P['bass_out.weight'], bias=P['bass_out.bias'], prec=prec)
+        ctx.save_for_backward(z, *params)
+        ctx.st = dict(hall=hall, gates=gates, toks=toks, z_in=z_in, prec=prec, T=T, B=B, H=H, I=I)
+        return root.view(T, B, -1), chroma.view(T, B, -1), bass.view(T, B, -1)
+
+    @staticmethod
+    def backward(ctx, droot, dchroma, dbass):
+        z, *params = ctx.saved_tensors
+        P = dict(zip(CHD_PARAM_NAMES, params))
+        st = ctx.st
+        ctx.st = None
+        prec, T, B, H, I = st['prec'], st['T'], st['B'], st['H'], st['I']
+        dev = z.device
+        hall, toks = st['hall'], st['toks']
+        hs = hall[1:].view(T * B, H)
+        G = {}
+        dhs = None
+        for name, dlog in (('root_out', droot), ('chroma_out', dchroma), ('bass_out', dbass)):
+            w = P[name + '.weight']
+            if dlog is None:
+                G[name + '.weight'], G[name + '.bias'] = torch.zeros_like(w), torch.zeros_like(P[name + '.bias'])
+                continue
+            d2 = dlog.contiguous().view(T * B, -1)
+            if dhs is None:
+                dhs = gemm(d2, w, tb=True, prec=prec)
+            else:
+                gemm(d2, w, dhs, tb=True, acc=True, prec=prec)
+            G[name + '.weight'] = gemm(d2, hs, _gbuf(w), ta=True, tb=True, acc=True, prec=prec)
+            G[name + '.bias'] = colsum(_zeros(1, w.shape[0], dev=dev), d2).view(-1)
+        if dhs is None:
+            dhs = _zeros(T * B, H, dev=dev)
+        w_hh, w_ih = P['gru.weight_hh_l0'], P['gru.weight_ih_l0']
+        dgi, dgh, dh0 = gru_bwd(prec, hall, st['gates'], w_hh, dh_ext=dhs.view(T, B, H))
+        G['gru.weight_hh_l0'] = gemm(dgh.view(T * B, 3 * H), hall[:T].view(T * B, H), _gbuf(w_hh), ta=True, tb=True, acc=True,
+                                     prec=prec)
+        G['gru.bias_hh_l0'] = colsum(_zeros(1, 3 * H, dev=dev), dgh.view(T * B, 3 * H)).view(-1)
+        dzg = sum_steps(dgi)
+        G['gru.bias_ih_l0'] = colsum(_zeros(1, 3 * H, dev=dev), dzg).view(-1)
+        g = _gbuf(w_ih)
+        gemm(dzg, st['z_in'], g[:, I:], ta=True, tb=True, acc=True, prec=prec)
+        gemm(dgi.view(T * B, 3 * H), toks.view(T * B, I), g[:, :I], ta=True, tb=True, acc=True, prec=prec)
+        G['gru.weight_ih_l0'] = g
+        dz_in = gemm(dzg, w_ih[:, I:], tb=True, prec=prec)
+        dtok0 = gemm(dgi[0], w_ih[:, :I], tb=True, prec=prec)                     # only the learned start token
+        G['init_input'] = colsum(_zeros(1, I, dev=dev), dtok0).view(-1)
+        w_zh, w_zi = P['z2dec_hid.weight'], P['z2dec_in.weight']
+        dz = gemm(dh0, w_zh, tb=True, prec=prec)
+        gemm(dz_in, w_zi, dz, tb=True, acc=True, prec=prec)
+        G['z2dec_hid.weight'] = gemm(dh0, z, _gbuf(w_zh), ta=True, tb=True, acc=True, prec=prec)
+        G['z2dec_hid.bias'] = colsum(_zeros(1, H, dev=dev), dh0).view(-1)
+        G['z2dec_in.weight'] = gemm(dz_in, z, _gbuf(w_zi), ta=True, tb=True, acc=True, prec=prec)
+        G['z2dec_in.bias'] = colsum(_zeros(1, w_zi.shape[0], dev=dev), dz_in).view(-1)
+        return (dz, None, None) + tuple(G[n] for n in CHD_PARAM_NAMES)
+
+
+# =============================================================================================
+# loss_function  (model.py:57-90, ptvae.py:498-511)
+# =============================================================================================
+_PERM = {3: (1, 0, 2), 4: (2, 1, 0, 3), 5: (2, 1, 0, 3, 4)}     # API shape <-> step-major memory (self-inverse)
+
+
+def _chord_perm(t):
+    return (1, 0, 2) if t.dim() == 3 else (1, 0, 2, 3)
+
+
+def _mem_order(ts, perms):
+    """API-shaped tensors -> (tensors contiguous in memory order, step_major flag).  Step-major iff
+    EVERY tensor is a permuted view of a contiguous step-major buffer (what the decoders return);
+    otherwise all are made batch-major contiguous."""
+    tp = [t.permute(*p) for t, p in zip(ts, perms)]
+    if all(t.is_contiguous() for t in tp):
+        return tp, True
+    return [t.contiguous() for t in ts], False
+
+
+def _pianotree_ce_fwd(pitch, dur, x, sums, st):
+    (pitch_m, dur_m), sm = _mem_order([pitch, dur], [_PERM[4], _PERM[5]])
+    dev = pitch.device
+    B = x.shape[0]
+    rows = B * 480
+    NP = pitch.shape[-1]
+    pitch_t = torch.empty(rows, device=dev, dtype=torch.int32)
+    dur_t = torch.empty(rows * 5, device=dev, dtype=torch.int32)
+    counts = torch.zeros(2, device=dev, dtype=torch.int32)
+    call('ptv_pianotree_targets', ptr(x), B, int(sm), ptr(pitch_t), ptr(dur_t), ptr(counts), st)
+    call('ptv_ce_fwd', ptr(pitch_m), NP, ptr(pitch_t), rows, NP, 130, ptr(sums[0:]), st)
+    call('ptv_ce_fwd', ptr(dur_m), 2, ptr(dur_t), rows * 5, 2, 2, ptr(sums[1:]), st)
+    return pitch_m, dur_m, sm, pitch_t, dur_t, counts
+
+
+def _pianotree_ce_bwd(pitch_m, dur_m, sm, pitch_t, dur_t, gs, st):
+    NP = pitch_m.shape[-1]
+    rows = pitch_t.numel()
+    dpitch = torch.empty_like(pitch_m)
+    ddur = torch.empty_like(dur_m)
+    call('ptv_ce_bwd', ptr(pitch_m), NP, ptr(pitch_t), rows, NP, 130, ptr(gs[0:]), ptr(dpitch), NP, st)
+    call('ptv_ce_bwd', ptr(dur_m), 2, ptr(dur_t), rows * 5, 2, 2, ptr(gs[1:]), ptr(ddur), 2, st)
+    if sm:
+        dpitch, ddur = dpitch.permute(*_PERM[4]), ddur.permute(*_PERM[5])
+    return dpitch, ddur
+
+
+class VaeLossFn(torch.autograd.Function):
+    """(pitch [B,32,15,130], dur [B,32,15,5,2], mu_c, sd_c, mu_r, sd_r, root [B,8,12], chroma [B,8,12,2],
+    bass [B,8,12], x, c, beta, w0, w1) -> the 11 scalars of model.py:67-68 as one [11] tensor."""
+
+    @staticmethod
+    def forward(ctx, pitch, dur, mu_c, sd_c, mu_r, sd_r, root, chroma, bass, x, c, beta, w0, w1):
+        dev = pitch.device
+        B = x.shape[0]
+        st = stream_ptr()
+        x = x.contiguous()
+        c = c.contiguous()
+        mu_c, sd_c, mu_r, sd_r = (t.contiguous() for t in (mu_c, sd_c, mu_r, sd_r))
+        sums = _zeros(8, dev=dev)
+        pitch_m, dur_m, sm_p, pitch_t, dur_t, counts = _pianotree_ce_fwd(pitch, dur, x, sums, st)
+        (root_m, chroma_m, bass_m), sm_c = _mem_order([root, chroma, bass], [_chord_perm(root), _chord_perm(chroma),
+                                                                              _chord_perm(bass)])
+        root_t = torch.empty(B * 8, device=dev, dtype=torch.int32)
+        chroma_t = torch.empty(B * 96, device=dev, dtype=torch.int32)
+        bass_t = torch.empty(B * 8, device=dev, dtype=torch.int32)
+        call('ptv_chord_targets', ptr(c), B, int(sm_c), ptr(root_t), ptr(chroma_t), ptr(bass_t), st)
+        Z = mu_c.shape[1]
+        call('ptv_kl_fwd', ptr(mu_c), ptr(sd_c), mu_c.numel(), ptr(sums[2:]), st)
+        call('ptv_kl_fwd', ptr(mu_r), ptr(sd_r), mu_r.numel(), ptr(sums[3:]), st)
+        call('ptv_ce_fwd', ptr(root_m), 12, ptr(root_t), B * 8, 12, -1, ptr(sums[4:]), st)
+        call('ptv_ce_fwd', ptr(chroma_m), 2, ptr(chroma_t), B * 96, 2, -1, ptr(sums[5:]), st)
+        call('ptv_ce_fwd', ptr(bass_m), 12, ptr(bass_t), B * 8, 12, -1, ptr(sums[6:]), st)
+        out = _empty(11, dev=dev)
+        ctx.scal = (float(beta), float(w0), float(w1), float(B * Z), float(B * 8), float(B * 96))
+        call('ptv_loss_finalize', ptr(sums), ptr(counts), *ctx.scal, ptr(out), st)
+        ctx.save_for_backward(pitch_m, dur_m, mu_c, sd_c, mu_r, sd_r, root_m, chroma_m, bass_m, pitch_t, dur_t, counts,
+                              root_t, chroma_t, bass_t)
+        ctx.sm = (sm_p, sm_c)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (pitch_m, dur_m, mu_c, sd_c, mu_r, sd_r, root_m, chroma_m, bass_m, pitch_t, dur_t, counts, root_t, chroma_t,
+         bass_t) = ctx.saved_tensors
+        sm_p, sm_c = ctx.sm
+        dev = pitch_m.device
+        st = stream_ptr()
+        gs = _empty(8, dev=dev)
+        call('ptv_loss_bwd_scales', ptr(gout.contiguous()), ptr(counts), *ctx.scal, ptr(gs), st)
+        dpitch, ddur = _pianotree_ce_bwd(pitch_m, dur_m, sm_p, pitch_t, dur_t, gs, st)
+        dmu_c, dsd_c = torch.empty_like(mu_c), torch.empty_like(sd_c)
+        dmu_r, dsd_r = torch.empty_like(mu_r), torch.empty_like(sd_r)
+        call('ptv_kl_bwd', ptr(mu_c), ptr(sd_c), mu_c.numel(), ptr(gs[2:]), ptr(dmu_c), ptr(dsd_c), st)
+        call('ptv_kl_bwd', ptr(mu_r), ptr(sd_r), mu_r.numel(), ptr(gs[3:]), ptr(dmu_r), ptr(dsd_r), st)
+        droot, dchroma, dbass = torch.empty_like(root_m), torch.empty_like(chroma_m), torch.empty_like(bass_m)
+        call('ptv_ce_bwd', ptr(root_m), 12, ptr(root_t), root_t.numel(), 12, -1, ptr(gs[4:]), ptr(droot), 12, st)
+        call('ptv_ce_bwd', ptr(chroma_m), 2, ptr(chroma_t), chroma_t.numel(), 2, -1, ptr(gs[5:]), ptr(dchroma), 2, st)
+        call('ptv_ce_bwd', ptr(bass_m), 12, ptr(bass_t), bass_t.numel(), 12, -1, ptr(gs[6:]), ptr(dbass), 12, st)
+        if sm_c:
+            droot, dchroma, dbass = (t.permute(*_chord_perm(t)) for t in (droot, dchroma, dbass))
+        return (dpitch, ddur, dmu_c, dsd_c, dmu_r, dsd_r, droot, dchroma, dbass) + (None,) * 5
+
+
+class ReconLossFn(torch.autograd.Function):
+    """PtvaeDecoder.recon_loss (ptvae.py:498-511) -> [3] = (w0*pl + w1*dl, pl, dl)."""
+
+    @staticmethod
+    def forward(ctx, pitch, dur, x, w0, w1):
+        dev = pitch.device
+        st = stream_ptr()
+        x = x.contiguous()
+        sums = _zeros(8, dev=dev)
+        pitch_m, dur_m, sm, pitch_t, dur_t, counts = _pianotree_ce_fwd(pitch, dur, x, sums, st)
+        out = _empty(11, dev=dev)
+        ctx.scal = (0.0, float(w0), float(w1), 1.0, 1.0, 1.0)
+        call('ptv_loss_finalize', ptr(sums), ptr(counts), *ctx.scal, ptr(out), st)
+        ctx.save_for_backward(pitch_m, dur_m, pitch_t, dur_t, counts)
+        ctx.sm = sm
+        return out[1:4].clone()
+
+    @staticmethod
+    def backward(ctx, g3):
+        pitch_m, dur_m, pitch_t, dur_t, counts = ctx.saved_tensors
+        dev = pitch_m.device
+        st = stream_ptr()
+        g11 = _zeros(11, dev=dev)
+        copy2d(g11[1:4].view(1, 3), g3.contiguous().view(1, 3))
+        gs = _empty(8, dev=dev)
+        call('ptv_loss_bwd_scales', ptr(g11), ptr(counts), *ctx.scal, ptr(gs), st)
+        dpitch, ddur = _pianotree_ce_bwd(pitch_m, dur_m, ctx.sm, pitch_t, dur_t, gs, st)
+        return dpitch, ddur, None, None, None
+
+
+def recon_loss(x, pitch, dur, w0, w1):
+    return ReconLossFn.apply(pitch, dur, x, w0, w1)
+
+
+class KlFn(torch.autograd.Function):
+    """kl_with_normal (train_utils.py:45-49): mean over all elements of KL(N(mu,sd) || N(0,1))."""
+
+    @staticmethod
+    def forward(ctx, mu, sd):
+        mu, sd = mu.contiguous(), sd.contiguous()
+        s = _zeros(2, dev=mu.device)
+        call('ptv_kl_fwd', ptr(mu), ptr(sd), mu.numel(), ptr(s), stream_ptr())
+        copy2d(s[1:2].view(1, 1), s[0:1].view(1, 1), alpha=1.0 / mu.numel())
+        ctx.save_for_backward(mu, sd)
+        return s[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, sd = ctx.saved_tensors
+        gs = _empty(1, dev=mu.device)
+        copy2d(gs.view(1, 1), g.contiguous().view(1, 1), alpha=1.0 / mu.numel())
+        dmu, dsd = torch.empty_like(mu), torch.empty_like(sd)
+        call('ptv_kl_bwd', ptr(mu), ptr(sd), mu.numel(), ptr(gs), ptr(dmu), ptr(dsd), stream_ptr())
+        return dmu, dsd
+
+
+class ChordLossFn(torch.autograd.Function):
+    """DisentangleVAE.chord_loss (model.py:70-83) -> [4] = (chord, root, chroma, bass)."""
+
+    @staticmethod
+    def forward(ctx, root, chroma, bass, c):
+        dev = root.device
+        st = stream_ptr()
+        B = c.shape[0]
+        c = c.contiguous()
+        (root_m, chroma_m, bass_m), sm = _mem_order([root, chroma, bass], [_chord_perm(root), _chord_perm(chroma),
+                                                                            _chord_perm(bass)])
+        root_t = torch.empty(B * 8, device=dev, dtype=torch.int32)
+        chroma_t = torch.empty(B * 96, device=dev, dtype=torch.int32)
+        bass_t = torch.empty(B * 8, device=dev, dtype=torch.int32)
+        call('ptv_chord_targets', ptr(c), B, int(sm), ptr(root_t), ptr(chroma_t), ptr(bass_t), st)
+        sums = _zeros(8, dev=dev)
+        counts = torch.ones(2, device=dev, dtype=torch.int32)
+        call('ptv_ce_fwd', ptr(root_m), 12, ptr(root_t), B * 8, 12, -1, ptr(sums[4:]), st)
+        call('ptv_ce_fwd', ptr(chroma_m), 2, ptr(chroma_t), B * 96, 2, -1, ptr(sums[5:]), st)
+        call('ptv_ce_fwd', ptr(bass_m), 12, ptr(bass_t), B * 8, 12, -1, ptr(sums[6:]), st)
+        out = _empty(11, dev=dev)
+        ctx.scal = (0.0, 0.0, 0.0, 1.0, float(B * 8), float(B * 96))
+        call('ptv_loss_finalize', ptr(sums), ptr(counts), *ctx.scal, ptr(out), st)
+        ctx.save_for_backward(root_m, chroma_m, bass_m, root_t, chroma_t, bass_t, counts)
+        ctx.sm = sm
+        return out[7:11].clone()
+
+    @staticmethod
+    def backward(ctx, g4):
+        root_m, chroma_m, bass_m, root_t, chroma_t, bass_t, counts = ctx.saved_tensors
+        dev = root_m.device
+        st = stream_ptr()
+        g11 = _zeros(11, dev=dev)
+        copy2d(g11[7:11].view(1, 4), g4.contiguous().view(1, 4))
+        gs = _empty(8, dev=dev)
+        call('ptv_loss_bwd_scales', ptr(g11), ptr(counts), *ctx.scal, ptr(gs), st)
+        droot, dchroma, dbass = torch.empty_like(root_m), torch.empty_like(chroma_m), torch.empty_like(bass_m)
+        call('ptv_ce_bwd', ptr(root_m), 12, ptr(root_t), root_t.numel(), 12, -1, ptr(gs[4:]), ptr(droot), 12, st)
+        call('ptv_ce_bwd', ptr(chroma_m), 2, ptr(chroma_t), chroma_t.numel(), 2, -1, ptr(gs[5:]), ptr(dchroma), 2, st)
+        call('ptv_ce_bwd', ptr(bass_m), 12, ptr(bass_t), bass_t.numel(), 12, -1, ptr(gs[6:]), ptr(dbass), 12, st)
+        if ctx.sm:
+            droot, dchroma, dbass = (t.permute(*_chord_perm(t)) for t in (droot, dchroma, dbass))
+        return droot, dchroma, dbass, None

@@ -1,0 +1,106 @@
+"""DisentangleVAE (alias PolyphonicVAE): chord/texture disentanglement VAE, MI355X train-step path.
+
+Host-side mirror of the reference `model.py` (DisentangleVAE :11-96, inference family :117-184,
+init_model :244-265): same constructor, `forward(mode, ...)` dispatch, `run` / `loss` /
+`loss_function` / `kl_loss` / `chord_loss` signatures and return tuples, same `state_dict` keys.
+All arithmetic runs in libptvae_hip.so kernels.
+"""
+import torch
+
+from . import functional as F_
+from .amc_dl.torch_plus import PytorchModel
+from .ptvae import HipNormal, PtvaeDecoder, RnnDecoder, RnnEncoder, TextureEncoder
+
+LOSS_NAMES = ['loss', 'recon_loss', 'pl', 'dl', 'kl_loss', 'kl_chd', 'kl_rhy', 'chord_loss', 'root_loss',
+              'chroma_loss', 'bass_loss']                       # train.py:54-55
+
+
+class DisentangleVAE(PytorchModel):
+
+    def __init__(self, name, device, chd_encoder, rhy_encoder, decoder, chd_decoder):
+        super().__init__(name, device)
+        self.chd_encoder = chd_encoder
+        self.rhy_encoder = rhy_encoder
+        self.decoder = decoder
+        self.num_step = self.decoder.num_step
+        self.chd_decoder = chd_decoder
+        self.eps_source = None      # optional callable (name, shape, device) -> eps tensor (tests / DDP)
+
+    # ---- precision switch: 'fp32' (exact, parity) | 'bf16' (bf16 MFMA operands, fp32 accumulate)
+    def set_precision(self, precision):
+        assert precision in ('fp32', 'bf16')
+        for m in (self.chd_encoder, self.rhy_encoder, self.decoder, self.chd_decoder):
+            m.precision = precision
+        return self
+
+    def _rsample(self, name, dist):
+        eps = None
+        if self.eps_source is not None:
+            eps = self.eps_source(name, dist.mean.shape, dist.mean.device)
+        return dist.rsample(eps=eps)
+
+    # ---- model.py:42-55
+    def run(self, x, c, pr_mat, tfr1, tfr2, tfr3, confuse=True):
+        embedded_x, lengths = self.decoder.emb_x(x)
+        dist_chd = self.chd_encoder(c)
+        dist_rhy = self.rhy_encoder(pr_mat)
+        z_chd = self._rsample('chd', dist_chd)           # chd first, then rhy (train_utils.py:33-34)
+        z_rhy = self._rsample('rhy', dist_rhy)
+        dec_z = torch.cat([z_chd, z_rhy], dim=-1)
+        pitch_outs, dur_outs = self.decoder(dec_z, False, embedded_x, lengths, tfr1, tfr2)
+        recon_root, recon_chroma, recon_bass = self.chd_decoder(z_chd, False, tfr3, c)
+        return pitch_outs, dur_outs, dist_chd, dist_rhy, recon_root, recon_chroma, recon_bass
+
+    # ---- model.py:57-68: one fused loss node (CE with ignore_index x2, KL x2, chord CE x3)
+    def loss_function(self, x, c, recon_pitch, recon_dur, dist_chd, dist_rhy, recon_root, recon_chroma,
+                      recon_bass, beta, weights, weighted_dur=False):
+        if weighted_dur:
+            raise NotImplementedError('weighted_dur (ptvae.py:512-527) is unused by the train path')
+        out = F_.VaeLossFn.apply(recon_pitch, recon_dur, dist_chd.mean, dist_chd.scale, dist_rhy.mean,
+                                 dist_rhy.scale, recon_root, recon_chroma, recon_bass, x.long(), c.float(),
+                                 float(beta), float(weights[0]), float(weights[1]))
+        return tuple(out.unbind(0))
+
+    # ---- model.py:70-90 (stand-alone forms; loss_function computes them fused)
+    def chord_loss(self, c, recon_root, recon_chroma, recon_bass):
+        out = F_.ChordLossFn.apply(recon_root, recon_chroma, recon_bass, c.float())
+        return out[0], out[1], out[2], out[3]
+
+    def kl_loss(self, *dists):
+        kl_chd = F_.KlFn.apply(dists[0].mean, dists[0].scale)
+        kl_rhy = F_.KlFn.apply(dists[1].mean, dists[1].scale)
+        return kl_chd + kl_rhy, kl_chd, kl_rhy
+
+    # ---- model.py:92-96
+    def loss(self, x, c, pr_mat, tfr1=0., tfr2=0., tfr3=0., beta=0.1, weights=(1, 0.5), *_ignored_extra):
+        outputs = self.run(x, c, pr_mat, tfr1, tfr2, tfr3)
+        return self.loss_function(x, c, *outputs, beta, weights)
+
+    # ---- model.py:117-122
+    def inference_encode(self, pr_mat, c):
+        self.eval()
+        with torch.no_grad():
+            dist_chd = self.chd_encoder(c)
+            dist_rhy = self.rhy_encoder(pr_mat)
+        return dist_chd, dist_rhy
+
+    def inference_decode(self, z_chd, z_rhy):
+        raise NotImplementedError('free-running decode lands with the step-loop path')
+
+    def inference(self, pr_mat, c, sample):
+        raise NotImplementedError('free-running decode lands with the step-loop path')
+
+    # ---- model.py:244-265
+    @staticmethod
+    def init_model(device=None, chd_size=256, txt_size=256, num_channel=10):
+        name = 'disvae'
+        if device is None:
+            device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+        chd_encoder = RnnEncoder(36, 1024, chd_size)
+        rhy_encoder = TextureEncoder(256, 1024, txt_size, num_channel)
+        chd_decoder = RnnDecoder(z_dim=chd_size)
+        pt_decoder = PtvaeDecoder(note_embedding=None, dec_dur_hid_size=64, z_size=chd_size + txt_size)
+        return DisentangleVAE(name, device, chd_encoder, rhy_encoder, pt_decoder, chd_decoder)
+
+
+PolyphonicVAE = DisentangleVAE      # the name BASELINE.json's north_star uses

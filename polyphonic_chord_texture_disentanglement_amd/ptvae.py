@@ -1,0 +1,303 @@
+"""Network blocks of the polyphonic chord/texture VAE on MI355X HIP kernels.
+
+Host-side mirror of the reference `ptvae.py`: same class names, constructor signatures, method
+names, `state_dict` keys and default initialisation (same RNG draws, so `torch.manual_seed(s)`
+gives the reference's weights).  The modules hold parameters only; every forward/backward is a
+sequence of libptvae_hip.so kernels (see functional.py).  There is no CPU fallback: calling a
+module with CPU tensors raises.
+
+Reference: /root/reference/ptvae.py  (RnnEncoder :11-29, RnnDecoder :32-87, TextureEncoder :90-122,
+PtvaeEncoder :125-215, PtvaeDecoder :218-575).
+"""
+import math
+import random
+
+import torch
+from torch import nn
+
+from . import functional as F_
+from ._lib import prec_code
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter containers (same names / shapes / init order as torch.nn.{Linear,GRU,Conv2d})
+# ---------------------------------------------------------------------------------------------
+class Linear(nn.Module):
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(in_features) if in_features > 0 else 0
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x, prec=0):
+        shp = x.shape
+        y = F_.LinearFn.apply(x.reshape(-1, shp[-1]), self.weight, self.bias, prec)
+        return y.view(shp[:-1] + (self.out_features,))
+
+
+class GRU(nn.Module):
+    """Parameters of a single-layer (bi)GRU, keys weight_ih_l0 ... bias_hh_l0[_reverse]."""
+
+    def __init__(self, input_size, hidden_size, bidirectional=False):
+        super().__init__()
+        self.input_size, self.hidden_size, self.bidirectional = input_size, hidden_size, bidirectional
+        for sfx in ([''] + (['_reverse'] if bidirectional else [])):
+            setattr(self, 'weight_ih_l0' + sfx, nn.Parameter(torch.empty(3 * hidden_size, input_size)))
+            setattr(self, 'weight_hh_l0' + sfx, nn.Parameter(torch.empty(3 * hidden_size, hidden_size)))
+            setattr(self, 'bias_ih_l0' + sfx, nn.Parameter(torch.empty(3 * hidden_size)))
+            setattr(self, 'bias_hh_l0' + sfx, nn.Parameter(torch.empty(3 * hidden_size)))
+        stdv = 1.0 / math.sqrt(hidden_size) if hidden_size > 0 else 0
+        for w in self.parameters():
+            nn.init.uniform_(w, -stdv, stdv)
+
+    def weights(self):
+        names = ['weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0']
+        if self.bidirectional:
+            names += [n + '_reverse' for n in names]
+        return [getattr(self, n) for n in names]
+
+
+class Conv2dParams(nn.Module):
+    def __init__(self, in_ch, out_ch, kernel_size):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_ch, in_ch, *kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_ch))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        fan_in = in_ch * kernel_size[0] * kernel_size[1]
+        bound = 1 / math.sqrt(fan_in)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class HipNormal:
+    """Duck-typed torch.distributions.Normal (`.mean`, `.scale`, `.loc`, `.stddev`, `.rsample()`,
+    `.sample()`) whose rsample runs the reparameterisation kernel.  The model's run() returns
+    these where the reference returns Normal (model.py:45-48)."""
+
+    def __init__(self, loc, scale):
+        self.loc, self.scale = loc, scale
+
+    mean = property(lambda self: self.loc)
+    stddev = property(lambda self: self.scale)
+    variance = property(lambda self: self.scale * self.scale)
+
+    def rsample(self, sample_shape=torch.Size(), eps=None):
+        if eps is None:
+            eps = torch.randn(self.loc.shape, device=self.loc.device, dtype=self.loc.dtype)
+        return F_.ReparamFn.apply(self.loc, self.scale, eps.contiguous())
+
+    def sample(self, sample_shape=torch.Size()):
+        with torch.no_grad():
+            return self.rsample(sample_shape)
+
+
+def _require_cuda(t, who):
+    if not t.is_cuda:
+        raise RuntimeError('%s: input is on %s -- this build runs on MI355X HIP kernels only (no CPU '
+                           'fallback); move the model and inputs to a cuda device' % (who, t.device))
+
+
+class _PrecMixin:
+    """`precision` = 'fp32' (exact fp32 MFMA, parity path) or 'bf16' (bf16 MFMA operands)."""
+    precision = 'fp32'
+
+    @property
+    def _prec(self):
+        return prec_code(self.precision)
+
+
+# ---------------------------------------------------------------------------------------------
+class RnnEncoder(nn.Module, _PrecMixin):
+    """Chord encoder: bi-GRU over 8 chord steps -> Normal(mu, exp(linear_var)).  ptvae.py:11-29"""
+
+    def __init__(self, input_dim, hidden_dim, z_dim):
+        super().__init__()
+        self.gru = GRU(input_dim, hidden_dim, bidirectional=True)
+        self.linear_mu = Linear(hidden_dim * 2, z_dim)
+        self.linear_var = Linear(hidden_dim * 2, z_dim)
+        self.input_dim, self.hidden_dim, self.z_dim = input_dim, hidden_dim, z_dim
+
+    def forward(self, x):
+        _require_cuda(x, 'RnnEncoder')
+        x_sm = F_.Transpose01Fn.apply(x.float())                       # [T,B,I]
+        h = F_.BiGruFinalFn.apply(x_sm, None, self._prec, *self.gru.weights())
+        mu, sd = F_.EncoderHeadsFn.apply(h, self.linear_mu.weight, self.linear_mu.bias, self.linear_var.weight,
+                                         self.linear_var.bias, self._prec)
+        return HipNormal(mu, sd)
+
+
+class TextureEncoder(nn.Module, _PrecMixin):
+    """Piano-roll texture encoder (ptvae.py:90-122): conv(4x12,stride 4x1)+ReLU+maxpool(1x4) ->
+    raw view [B,8,C*29] -> fc1 -> fc2 -> bi-GRU(8 steps) -> Normal."""
+
+    def __init__(self, emb_size, hidden_dim, z_dim, num_channel=10):
+        super().__init__()
+        self.cnn = nn.Sequential(Conv2dParams(1, num_channel, (4, 12)))     # key 'cnn.0.*' as in the reference
+        self.fc1 = Linear(num_channel * 29, 1000)
+        self.fc2 = Linear(1000, emb_size)
+        self.gru = GRU(emb_size, hidden_dim, bidirectional=True)
+        self.linear_mu = Linear(hidden_dim * 2, z_dim)
+        self.linear_var = Linear(hidden_dim * 2, z_dim)
+        self.emb_size, self.hidden_dim, self.z_dim = emb_size, hidden_dim, z_dim
+
+    def forward(self, pr):
+        _require_cuda(pr, 'TextureEncoder')
+        bs = pr.size(0)
+        conv = self.cnn[0]
+        pooled = F_.TextureFrontFn.apply(pr.float(), conv.weight, conv.bias)            # [B,C,8,29]
+        feat = pooled.view(bs * 8, -1)                                 # the reference's raw .view(bs, 8, -1)
+        feat = F_.LinearFn.apply(feat, self.fc1.weight, self.fc1.bias, self._prec)
+        feat = F_.LinearFn.apply(feat, self.fc2.weight, self.fc2.bias, self._prec)
+        x_sm = F_.Transpose01Fn.apply(feat.view(bs, 8, -1))
+        h = F_.BiGruFinalFn.apply(x_sm, None, self._prec, *self.gru.weights())
+        mu, sd = F_.EncoderHeadsFn.apply(h, self.linear_mu.weight, self.linear_mu.bias, self.linear_var.weight,
+                                         self.linear_var.bias, self._prec)
+        return HipNormal(mu, sd)
+
+
+class RnnDecoder(nn.Module, _PrecMixin):
+    """Chord decoder (ptvae.py:32-87)."""
+
+    def __init__(self, input_dim=36, z_input_dim=256, hidden_dim=512, z_dim=256, num_step=32):
+        super().__init__()
+        self.z2dec_hid = Linear(z_dim, hidden_dim)
+        self.z2dec_in = Linear(z_dim, z_input_dim)
+        self.gru = GRU(input_dim + z_input_dim, hidden_dim)
+        self.init_input = nn.Parameter(torch.rand(36))
+        self.input_dim, self.hidden_dim, self.z_dim = input_dim, hidden_dim, z_dim
+        self.root_out = Linear(hidden_dim, 12)
+        self.chroma_out = Linear(hidden_dim, 24)
+        self.bass_out = Linear(hidden_dim, 12)
+        self.num_step = num_step
+
+    def _params(self):
+        sd = dict(self.named_parameters())
+        return [sd[n] for n in F_.CHD_PARAM_NAMES]
+
+    def forward(self, z_chd, inference, tfr, c=None):
+        _require_cuda(z_chd, 'RnnDecoder')
+        T = int(self.num_step / 4)
+        if inference:
+            tfr = 0.
+        # the reference draws one coin per step for the whole batch (ptvae.py:81); keep the stream aligned
+        coins = [random.random() < tfr for _ in range(T)]
+        if all(coins) and not inference:
+            c_sm = F_.Transpose01Fn.apply(c.float())
+            root, chroma, bass = F_.ChordDecoderTFFn.apply(z_chd, c_sm.detach(), self._prec, *self._params())
+        else:
+            raise NotImplementedError('free-running chord decoder lands with the step-loop path')
+        bs = z_chd.size(0)
+        # reference shapes [B,8,12] / [B,8,12,2] / [B,8,12] as views of the step-major buffers
+        return root.transpose(0, 1), chroma.view(T, bs, 12, 2).transpose(0, 1), bass.transpose(0, 1)
+
+
+class PtvaeDecoder(nn.Module, _PrecMixin):
+    """PianoTree decoder (ptvae.py:218-575): time GRU (32) -> notes GRU (15) -> pitch head +
+    5-step duration GRU."""
+
+    def __init__(self, device=None, note_embedding=None, max_simu_note=16, max_pitch=127, min_pitch=0,
+                 pitch_sos=128, pitch_eos=129, pitch_pad=130, dur_pad=2, dur_width=5, num_step=32,
+                 note_emb_size=128, z_size=512, dec_emb_hid_size=128, dec_time_hid_size=1024,
+                 dec_notes_hid_size=512, dec_z_in_size=256, dec_dur_hid_size=16):
+        super().__init__()
+        self.max_pitch, self.min_pitch = max_pitch, min_pitch
+        self.pitch_sos, self.pitch_eos, self.pitch_pad = pitch_sos, pitch_eos, pitch_pad
+        self.pitch_range = max_pitch - min_pitch + 3
+        self.dur_pad, self.dur_width = dur_pad, dur_width
+        self.note_size = self.pitch_range + dur_width
+        self.max_simu_note, self.num_step = max_simu_note, num_step
+        self.device = device if device is not None else ('cuda' if torch.cuda.is_available() else 'cpu')
+        if (max_simu_note, num_step, dur_width, self.pitch_range, pitch_pad, dur_pad) != (16, 32, 5, 130, 130, 2):
+            raise NotImplementedError('HIP kernels are specialised to the 32x16x(130+5) PianoTree grid')
+        self.note_emb_size, self.z_size = note_emb_size, z_size
+        self.dec_z_in_size, self.dec_emb_hid_size = dec_z_in_size, dec_emb_hid_size
+        self.dec_time_hid_size, self.dec_notes_hid_size = dec_time_hid_size, dec_notes_hid_size
+        self.dec_dur_hid_size = dec_dur_hid_size
+        self.dec_init_input = nn.Parameter(torch.rand(2 * dec_emb_hid_size))
+        self.dur_sos_token = nn.Parameter(torch.rand(dur_width))
+        self.note_embedding = Linear(self.note_size, note_emb_size) if note_embedding is None else note_embedding
+        self.z2dec_hid_linear = Linear(z_size, dec_time_hid_size)
+        self.z2dec_in_linear = Linear(z_size, dec_z_in_size)
+        self.dec_notes_emb_gru = GRU(note_emb_size, dec_emb_hid_size, bidirectional=True)
+        self.dec_time_gru = GRU(dec_z_in_size + 2 * dec_emb_hid_size, dec_time_hid_size)
+        self.dec_time_to_notes_hid = Linear(dec_time_hid_size, dec_notes_hid_size)
+        self.dec_notes_gru = GRU(dec_time_hid_size + note_emb_size, dec_notes_hid_size)
+        self.pitch_out_linear = Linear(dec_notes_hid_size, self.pitch_range)
+        self.dec_dur_gru = GRU(dur_width, dec_dur_hid_size)
+        self.dur_hid_linear = Linear(self.pitch_range + dec_notes_hid_size, dec_dur_hid_size)
+        self.dur_out_linear = Linear(dec_dur_hid_size, 2)
+        self.force_dur_idx = None          # [5, 480*B] int32: replay the oracle's duration argmaxes (tests)
+        self.last_dur_idx = None
+
+    def _params(self):
+        sd = dict(self.named_parameters())
+        return [sd[n] for n in F_.DEC_PARAM_NAMES]
+
+    # ---- ptvae.py:531-535 (+ :292-313)
+    def emb_x(self, x):
+        """-> (embedded [B,32,16,E], lengths [B,32]).  Shapes are the reference's; the memory behind
+        them is the decoder's step-major layout ([16,32,B,E] / [32,B]) exposed through permuted views,
+        so handing them back to `decoder()` costs no transpose (134 MB each way at B=512)."""
+        _require_cuda(x, 'PtvaeDecoder.emb_x')
+        emb, lengths = F_.EmbedFn.apply(x.long(), self.note_embedding.weight, self.note_embedding.bias)
+        return emb.permute(2, 1, 0, 3), lengths.view(32, x.size(0)).t()
+
+    def decoder(self, z, inference, x, lengths, teacher_forcing_ratio1, teacher_forcing_ratio2):
+        _require_cuda(z, 'PtvaeDecoder')
+        if inference:
+            assert x is None and lengths is None
+            assert teacher_forcing_ratio1 == 0 and teacher_forcing_ratio2 == 0
+            raise NotImplementedError('free-running decode lands with the step-loop path')
+        # the reference draws 14 coins (tfr2) per time step then one (tfr1) for t < 31  (ptvae.py:420,476)
+        all_tf = True
+        for t in range(self.num_step):
+            for _ in range(self.max_simu_note - 2):
+                all_tf &= random.random() < teacher_forcing_ratio2
+            if t < self.num_step - 1:
+                all_tf &= random.random() < teacher_forcing_ratio1
+        if not all_tf:
+            raise NotImplementedError('scheduled-sampling / free-running training lands with the step-loop path')
+        B = z.size(0)
+        emb = x.permute(2, 1, 0, 3)                                            # [16,32,B,E]
+        if not emb.is_contiguous():                                            # caller built a plain [B,32,16,E]
+            E = x.size(-1)
+            emb = F_.Transpose01Fn.apply(x.transpose(1, 2).reshape(B, 16 * 32, E)).view(16, 32, B, E)
+        len32 = lengths.t()
+        len32 = (len32 if (len32.is_contiguous() and len32.dtype == torch.int32) else len32.contiguous().int()).reshape(-1)
+        pitch, dur, idx = F_.DecoderTFFn.apply(z, emb, len32, self.force_dur_idx, self._prec, *self._params())
+        self.last_dur_idx = idx
+        # reference shapes [B,32,15,130] / [B,32,15,5,2] as permuted views of the step-major buffers
+        return pitch.permute(2, 1, 0, 3), dur.view(15, 32, B, 5, 2).permute(2, 1, 0, 3, 4)
+
+    def forward(self, z, inference, x, lengths, teacher_forcing_ratio1, teacher_forcing_ratio2):
+        return self.decoder(z, inference, x, lengths, teacher_forcing_ratio1, teacher_forcing_ratio2)
+
+    # ---- ptvae.py:498-529
+    def recon_loss(self, x, recon_pitch, recon_dur, weights=(1, 0.5), weighted_dur=False):
+        if weighted_dur:
+            raise NotImplementedError('weighted_dur variant (ptvae.py:512-527) is unused by the train path')
+        out = F_.recon_loss(x.long(), recon_pitch, recon_dur, float(weights[0]), float(weights[1]))
+        return out[0], out[1], out[2]
+
+
+class PtvaeEncoder(nn.Module):
+    """Present in the reference (ptvae.py:125-215) and constructed by its train.py:32, but unusable on
+    this path.  Kept importable with the reference signature; parameters only."""
+
+    def __init__(self, device, max_simu_note=16, max_pitch=127, min_pitch=0, pitch_sos=128, pitch_eos=129,
+                 pitch_pad=130, dur_pad=2, dur_width=5, num_step=32, note_emb_size=128, enc_notes_hid_size=256,
+                 enc_time_hid_size=512, z_size=512):
+        super().__init__()
+        self.pitch_range = max_pitch - min_pitch + 3
+        self.note_size = self.pitch_range + dur_width
+        self.device = device
+        self.note_embedding = Linear(self.note_size, note_emb_size)
+        self.enc_notes_gru = GRU(note_emb_size, enc_notes_hid_size, bidirectional=True)
+        self.enc_time_gru = GRU(2 * enc_notes_hid_size, enc_time_hid_size, bidirectional=True)
+        self.linear_mu = Linear(2 * enc_time_hid_size, z_size)
+        self.linear_std = Linear(2 * enc_time_hid_size, z_size)
+
+    def forward(self, x, return_iterators=False):
+        raise NotImplementedError('PtvaeEncoder is outside the train-step hot path (SURVEY.md §8f item 3)')

@@ -219,6 +219,12 @@ def main():
                      1., 1., 1., 0.1, (1, 0.5))
     print('anchor', [a.item() for a in anchor])
 
+    # default initialisation under torch.manual_seed(0): per-tensor checksums (init-order parity)
+    np.savez_compressed(os.path.join(HERE, 'full_init.npz'),
+                        names=np.array([k for k, _ in ma.state_dict().items()]),
+                        psum=np.array([v.double().sum().item() for v in ma.state_dict().values()]),
+                        pabs=np.array([v.double().abs().sum().item() for v in ma.state_dict().values()]))
+
     # ---- 3. schedules ----------------------------------------------------------
     import warnings
     warnings.simplefilter('ignore')

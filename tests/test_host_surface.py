@@ -1,0 +1,110 @@
+"""CPU: the host-side mirror keeps the reference's class surface, state_dict keys, default
+initialisation and schedules.  No kernels run here (the model refuses CPU tensors)."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import full_shapes, load_npz
+from polyphonic_chord_texture_disentanglement_amd import model as M
+from polyphonic_chord_texture_disentanglement_amd import ptvae as P
+from polyphonic_chord_texture_disentanglement_amd.amc_dl import torch_plus as tp
+from polyphonic_chord_texture_disentanglement_amd.amc_dl.torch_plus.train_utils import kl_anealing, scheduled_sampling
+
+
+def build_reduced(device='cpu'):
+    torch.manual_seed(0)
+    chd_enc = P.RnnEncoder(36, 32, 16)
+    rhy_enc = P.TextureEncoder(24, 32, 16, 3)
+    chd_dec = P.RnnDecoder(z_input_dim=16, hidden_dim=24, z_dim=16)
+    dec = P.PtvaeDecoder(device=device, note_emb_size=20, z_size=32, dec_emb_hid_size=12, dec_time_hid_size=40,
+                         dec_notes_hid_size=28, dec_z_in_size=16, dec_dur_hid_size=8)
+    return M.DisentangleVAE('disvae', device, chd_enc, rhy_enc, dec, chd_dec)
+
+
+def test_state_dict_keys_and_shapes_match_reference():
+    m = M.DisentangleVAE.init_model(torch.device('cpu'))
+    ref = full_shapes()
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert list(got.keys()) == list(ref.keys())
+    assert got == dict(ref)
+    assert sum(p.numel() for p in m.parameters()) == 27310079
+
+
+def test_default_init_reproduces_reference_rng_stream():
+    g = load_npz('full_init.npz')
+    torch.manual_seed(0)
+    m = M.DisentangleVAE.init_model(torch.device('cpu'))
+    sd = m.state_dict()
+    assert [str(n) for n in g['names']] == list(sd.keys())
+    psum = np.array([v.double().sum().item() for v in sd.values()])
+    pabs = np.array([v.double().abs().sum().item() for v in sd.values()])
+    np.testing.assert_allclose(psum, g['psum'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(pabs, g['pabs'], rtol=1e-12, atol=0)
+
+
+def test_reduced_config_init_is_bit_identical():
+    ref = load_npz('reduced_state.npz')
+    sd = build_reduced().state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k, v in sd.items():
+        assert np.array_equal(v.numpy(), ref[k]), k
+
+
+def test_mode_dispatch_and_aliases():
+    m = build_reduced()
+    assert M.PolyphonicVAE is M.DisentangleVAE
+    with pytest.raises(NotImplementedError):
+        m('bogus-mode')
+    x = torch.zeros(2, 32, 16, 6, dtype=torch.long)
+    with pytest.raises(RuntimeError, match='no CPU'):          # product path fails loudly off-GPU
+        m('train', x, torch.zeros(2, 8, 36), torch.zeros(2, 32, 128), tfr1=1., tfr2=1., tfr3=1.)
+
+
+def test_schedules_match_reference_tables():
+    g = load_npz('schedules.npz')
+    tf1 = tp.TeacherForcingScheduler(0.6, 0)
+    tf2 = tp.TeacherForcingScheduler(0.5, 0)
+    beta = tp.TeacherForcingScheduler(0.1, 0., f=kl_anealing)
+    ps = tp.ParameterScheduler(tfr1=tf1, tfr2=tf2, beta=beta, weights=tp.ConstantScheduler([1, 0.5]))
+    rows = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for _ in range(75):
+            d = ps.step()
+            rows.append([d['tfr1'], d['tfr2'], d['beta']])
+            assert d['weights'] == [1, 0.5]
+    np.testing.assert_allclose(np.array(rows)[g['steps']], g['table'], rtol=1e-12, atol=0)
+    ps.eval()                                                    # frozen in eval mode (scheduler.py:10-16)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        a, b = ps.step(), ps.step()
+    assert a == b
+    lin = torch.nn.Linear(2, 2)
+    opt = torch.optim.SGD(lin.parameters(), lr=1e-3)
+    sch = tp.MinExponentialLR(opt, gamma=0.9999, minimum=1e-5)
+    lrs = []
+    for _ in range(5):
+        opt.step()
+        sch.step()
+        lrs.append(opt.param_groups[0]['lr'])
+    np.testing.assert_allclose(lrs, g['lrs'], rtol=1e-12)
+    opt2 = torch.optim.SGD(lin.parameters(), lr=1e-3)
+    sch2 = tp.MinExponentialLR(opt2, gamma=0.5, minimum=1e-5)
+    for _ in range(20):
+        opt2.step()
+        sch2.step()
+    assert opt2.param_groups[0]['lr'] == 1e-5                    # floor
+
+
+def test_path_manager_and_writers(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    pm = tp.LogPathManager(None)
+    assert pm.epoch_model_path('disvae').endswith('models/disvae_epoch.pt')
+    assert pm.valid_model_path('disvae').endswith('disvae_valid.pt')
+    assert pm.final_model_path('disvae').endswith('disvae_final.pt')
+    names = ['loss', 'recon_loss']
+    sw = tp.SummaryWriters(names, {'loss': None}, pm.writer_path)
+    sw.write_task('train', {'loss': 1.0, 'recon_loss': 2.0}, 0)
+    assert sw.all_tags['train'] == {'train_loss': (0, 1)}
