@@ -1,0 +1,176 @@
+"""bench.py -- 2-bar piano-roll samples/sec of the full polyphonic-VAE train step on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W --batch 512 --precision bf16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A step = zero_grad -> model('train', x, c, pr_mat, tfr=1, beta, weights) -> backward -> RCCL
+all-reduce (N>1) -> fused global-norm clip + Adam -> MinExponentialLR.step, on synthetic batches
+resident in HBM (BASELINE.json configs[1]: batch 512 per GPU, bf16 MFMA GRU/Linear products,
+z_dim 256+256, teacher-forced decoder).  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# forward FLOP/sample with the loop-invariant notes-GRU input product hoisted (SURVEY.md §8d,
+# Appendix C); a train step is 3x forward.  Used for the whole-step TFLOP/s figure only.
+GFLOP_PER_SAMPLE_TRAIN = 6.15
+
+
+def cpu_baseline(batch=16):
+    """The CPU oracle (a restatement of the reference's as-written algorithm, validated against the
+    reference in tests/test_oracle_vs_golden.py) timed on this host: one full train step."""
+    import numpy as np
+    from oracle.ptvae_oracle import Oracle, clip_and_adam_step
+    from polyphonic_chord_texture_disentanglement_amd.model import DisentangleVAE
+    from polyphonic_chord_texture_disentanglement_amd.synthetic import synth_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    ref = DisentangleVAE.init_model(torch.device('cpu'))
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in ref.state_dict().items()}
+    plist = list(params.values())
+    m = [torch.zeros_like(p) for p in plist]
+    v = [torch.zeros_like(p) for p in plist]
+    x, c, pr = (torch.from_numpy(a) for a in synth_batch(batch, 1234))
+    gen = torch.Generator().manual_seed(7)
+    times = []
+    for step in range(2):                      # 1 warm-up + 1 timed
+        eps = [torch.randn(batch, 256, generator=gen) for _ in range(2)]
+        t0 = time.perf_counter()
+        for p in plist:
+            p.grad = None
+        losses = Oracle(params).loss(x, c, pr, 1., 1., 1., 0.1, [1, 0.5], eps[0], eps[1], lambda: 0.0)
+        losses[0].backward()
+        with torch.no_grad():
+            clip_and_adam_step(plist, [p.grad for p in plist], m, v, step + 1, 1e-3)
+        times.append(time.perf_counter() - t0)
+    return {'value': batch / times[-1], 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+            'sample': '1 warm-up + 1 timed train step (fwd+bwd+clip+Adam), batch %d, tfr=1, fp32, torch CPU '
+                      'oracle/ptvae_oracle.py, %.2f s/step' % (batch, times[-1])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=512, help='per-GPU batch (weak scaling)')
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    from polyphonic_chord_texture_disentanglement_amd import _lib
+    from polyphonic_chord_texture_disentanglement_amd.amc_dl.torch_plus import MinExponentialLR
+    from polyphonic_chord_texture_disentanglement_amd.dist import GradSync
+    from polyphonic_chord_texture_disentanglement_amd.model import DisentangleVAE
+    from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
+    from polyphonic_chord_texture_disentanglement_amd.synthetic import synth_batch
+    lib = _lib.lib()
+
+    torch.manual_seed(0)                                   # identical weights on every rank
+    model = DisentangleVAE.init_model(dev).to(dev).set_precision(args.precision)
+    opt = FusedClipAdam(model.parameters(), lr=1e-3)
+    sched = MinExponentialLR(opt, gamma=0.9999, minimum=1e-5)
+    sync = GradSync(model, opt) if world > 1 else None
+
+    B = args.batch
+    nb = 2
+    batches = []
+    for i in range(nb):                                    # disjoint data per rank (SURVEY §8d seeds)
+        x, c, pr = synth_batch(B, 1234 + rank * 10 ** 6 + i)
+        batches.append(tuple(torch.from_numpy(a).to(dev) for a in (x, c, pr)))
+    gen = torch.Generator(device=dev).manual_seed(7 + rank)
+    model.eps_source = lambda name, shape, device: torch.randn(shape, device=device, generator=gen)
+
+    def step(i):
+        x, c, pr = batches[i % nb]
+        opt.zero_grad()
+        out = model('train', x, c, pr, tfr1=1., tfr2=1., tfr3=1., beta=0.1, weights=[1, 0.5])
+        out[0].backward()
+        if sync is not None:
+            sync.all_reduce_grads()
+        opt.clip_and_step(1.0)
+        sched.step()
+        return out
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        out = step(i)
+    barrier()
+    lib.ptv_prof_reset()
+    lib.ptv_prof_config(32 * B, model.decoder.dec_notes_hid_size)
+    lib.ptv_prof_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    lib.ptv_prof_enable(0)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(out[0].item())
+
+    if rank == 0:
+        import ctypes
+        ms_per_step = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        # dominant kernel: the notes-GRU forward step (15 launches per train step, M = 32*B rows)
+        cnt = ctypes.c_long(0)
+        tot_ms = ctypes.c_double(0.0)
+        flop = ctypes.c_double(0.0)
+        lib.ptv_prof_read(ctypes.byref(cnt), ctypes.byref(tot_ms), ctypes.byref(flop))
+        peak = 2500.0 if args.precision == 'bf16' else 157.3
+        roof = None
+        if cnt.value > 0:
+            avg_ms = tot_ms.value / cnt.value
+            ach = flop.value / cnt.value / (avg_ms * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'kernel': 'gru_fwd_step_kernel (dec_notes_gru, M=%d H=512)' % (32 * B),
+                    'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                    'launches': cnt.value, 'avg_us': round(avg_ms * 1e3, 2), 'traffic': None}
+        res = {'metric': '2-bar piano-roll samples/sec (train step)', 'value': round(value, 1), 'unit': 'samples/s',
+               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
+               'config': {'workload': 'configs[1]: 1xMI355X batch=512/GPU, bf16 MFMA GRU/Linear, z_dim=256+256, '
+                                      'teacher-forced decoder (tfr=1), fwd+bwd+clip+Adam',
+                          'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world},
+               'step_tflops': round(value * GFLOP_PER_SAMPLE_TRAIN / 1e3, 2), 'final_loss': round(loss, 4),
+               'roofline': roof}
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -160,6 +160,17 @@ int ptv_grad_sumsq(const float* g, long n, float* sumsq, void* stream);
 int ptv_clip_adam_step(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float gscale, float clip,
                        float lr, float beta1, float beta2, float eps, int step, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Optional launch timing (bench.py roofline): HIP events recorded on the launch stream around every
+ * launch of one kernel family -- tag 1 = GRU forward step, 2 = GRU backward step -- restricted to
+ * launches with the given (M, H) (0 = any).  ptv_prof_read waits for the recorded events and returns
+ * the number of launches, their summed duration and their summed algorithmic FLOPs (2*M*3H*H each).
+ */
+int ptv_prof_enable(int tag);
+int ptv_prof_config(int M, int H);
+int ptv_prof_reset(void);
+int ptv_prof_read(long* count, double* total_ms, double* flops);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,8 @@ def _parse_header(path):
                 a = ' '.join(a.split())
                 if '*' in a:
                     argtypes.append(ctypes.c_void_p)
+                elif a.startswith('double '):
+                    argtypes.append(ctypes.c_double)
                 elif a.startswith('long '):
                     argtypes.append(ctypes.c_long)
                 elif a.startswith('int '):

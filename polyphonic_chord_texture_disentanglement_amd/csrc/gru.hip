@@ -161,6 +161,35 @@ __global__ __launch_bounds__(NTHREADS) void gru_bwd_step_kernel(GemmArgs g, EpiG
   gemm_body<CT, BM, BN, 2, 2, 1, false, true, EpiGruBwd>(g, ep);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// optional per-launch timing of one kernel family with HIP events on the launch stream
+// (bench.py's roofline: average duration of the dominant kernel over the timed region)
+// ---------------------------------------------------------------------------------------------
+namespace prof {
+constexpr int MAXEV = 8192;
+static int enabled = 0, filt_M = 0, filt_H = 0;
+static hipEvent_t ev0[MAXEV], ev1[MAXEV];
+static int created = 0, used = 0;
+static double flops = 0.0;
+static inline bool want(int tag, int M, int H) {
+  return enabled == tag && (filt_M == 0 || filt_M == M) && (filt_H == 0 || filt_H == H) && used < MAXEV;
+}
+static inline int begin(hipStream_t s) {
+  if (used >= created) {
+    if (hipEventCreate(&ev0[created]) != hipSuccess || hipEventCreate(&ev1[created]) != hipSuccess) return -1;
+    created++;
+  }
+  (void)hipEventRecord(ev0[used], s);
+  return used;
+}
+static inline void end(int i, hipStream_t s, double fl) {
+  (void)hipEventRecord(ev1[i], s);
+  used = i + 1;
+  flops += fl;
+}
+}  // namespace prof
+
 template <class CT>
 static void launch_fwd_step(const GemmArgs& g, const EpiGruFwd::Params& ep, hipStream_t s) {
   // units per block 64 (x3 gates) with 128 rows when that still fills the chip, else 32 x 64
@@ -204,7 +233,9 @@ extern "C" int ptv_gru_seq_fwd(int prec, int M, int H, int T,
                          b_hh, hall + (step + 1) * MH, H,
                          gates ? gates + (long)step * 4 * MH : nullptr, MH,
                          lengths, t, gi_idx, H};
+    const int pi = prof::want(1, M, H) ? prof::begin(s) : -1;
     if (prec == PTV_PREC_BF16) launch_fwd_step<BF16>(g, ep, s); else launch_fwd_step<F32>(g, ep, s);
+    if (pi >= 0) prof::end(pi, s, 2.0 * M * 3.0 * H * H);
   }
   PTV_CHECK_LAUNCH();
   return PTV_OK;
@@ -235,7 +266,9 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
                          hall + (long)step * MH, H,
                          dgi + (long)t * M3H, dgh + (long)step * M3H,
                          dhz + (step & 1) * MH, H};
+    const int pi = prof::want(2, M, H) ? prof::begin(s) : -1;
     if (prec == PTV_PREC_BF16) launch_bwd_step<BF16>(g, ep, s); else launch_bwd_step<F32>(g, ep, s);
+    if (pi >= 0) prof::end(pi, s, last ? 0.0 : 2.0 * M * 3.0 * H * H);
   }
   PTV_CHECK_LAUNCH();
   if (dh0) {
@@ -243,5 +276,22 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
     if (hipMemcpyAsync(dh0, dhz, MH * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return PTV_ERR_LAUNCH;
     PTV_TRY(ptv_gemm(prec, 0, 1, M, H, 3 * H, dgh, 3L * H, w_hh, H, dh0, H, nullptr, 1.0f, 1, 0, -1, stream));
   }
+  return PTV_OK;
+}
+
+extern "C" int ptv_prof_enable(int tag) { ptv::prof::enabled = tag; return PTV_OK; }
+extern "C" int ptv_prof_config(int M, int H) { ptv::prof::filt_M = M; ptv::prof::filt_H = H; return PTV_OK; }
+extern "C" int ptv_prof_reset(void) { ptv::prof::used = 0; ptv::prof::flops = 0.0; return PTV_OK; }
+extern "C" int ptv_prof_read(long* count, double* total_ms, double* flops) {
+  double tot = 0.0;
+  for (int i = 0; i < ptv::prof::used; i++) {
+    float ms = 0.f;
+    if (hipEventSynchronize(ptv::prof::ev1[i]) != hipSuccess) return PTV_ERR_LAUNCH;
+    if (hipEventElapsedTime(&ms, ptv::prof::ev0[i], ptv::prof::ev1[i]) != hipSuccess) return PTV_ERR_LAUNCH;
+    tot += ms;
+  }
+  if (count) *count = ptv::prof::used;
+  if (total_ms) *total_ms = tot;
+  if (flops) *flops = ptv::prof::flops;
   return PTV_OK;
 }

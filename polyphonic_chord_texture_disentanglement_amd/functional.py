@@ -100,8 +100,17 @@ def gru_bwd(prec, hall, gates, w_hh, *, dh_ext=None, dh_last=None, lr=None, reve
 
 
 def _gbuf(p):
-    """zero-initialised gradient buffer for parameter p (weight-gradient kernels accumulate)."""
-    return torch.zeros_like(p, memory_format=torch.contiguous_format)
+    """zero-initialised gradient buffer for parameter p (weight-gradient kernels accumulate into it):
+    a view of the optimiser's flat gradient bucket when one is registered (optim.GradArena)."""
+    from .optim import grad_buffer
+    return grad_buffer(p)
+
+
+def _bgrad(b, a):
+    """bias-style gradient: column sums of a [rows, N] into the gradient buffer of parameter b [N]"""
+    g = _gbuf(b)
+    colsum(g.view(1, -1), a)
+    return g
 
 
 def _as2d(t):
@@ -115,19 +124,18 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2, w, b, prec):
         y = gemm(x2, w, bias=b, prec=prec)
-        ctx.save_for_backward(x2, w)
+        ctx.save_for_backward(x2, w, b)
         ctx.prec = prec
-        ctx.has_bias = b is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w = ctx.saved_tensors
+        x2, w, b = ctx.saved_tensors
         prec = ctx.prec
         dy = dy.contiguous()
         dx = gemm(dy, w, tb=True, prec=prec) if ctx.needs_input_grad[0] else None
         dw = gemm(dy, x2, _gbuf(w), ta=True, tb=True, acc=True, prec=prec)
-        db = colsum(_zeros(1, w.shape[0], dev=w.device), dy).view(-1) if ctx.has_bias else None
+        db = _bgrad(b, dy) if b is not None else None
         return dx, dw, db, None
 
 
@@ -158,16 +166,16 @@ class EmbedFn(torch.autograd.Function):
         emb = _empty(16, 32, B, E, dev=w.device)
         lengths = torch.empty(32 * B, device=w.device, dtype=torch.int32)
         call('ptv_embed_fwd', ptr(x), ptr(w), ptr(b), ptr(emb), ptr(lengths), B, E, stream_ptr())
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, w, b)
         ctx.mark_non_differentiable(lengths)
         return emb, lengths
 
     @staticmethod
     def backward(ctx, demb, _dl):
-        x, w = ctx.saved_tensors
+        x, w, b = ctx.saved_tensors
         B, E = x.shape[0], w.shape[0]
         dw = _gbuf(w)
-        db = _zeros(E, dev=w.device)
+        db = _gbuf(b)
         call('ptv_embed_bwd', ptr(x), ptr(demb.contiguous()), ptr(dw), ptr(db), B, E, stream_ptr())
         return None, dw, db
 
@@ -210,8 +218,8 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
         dgi2, dgh2 = dgi.view(T * M, 3 * H), dgh.view(T * M, 3 * H)
         dw_ih = gemm(dgi2, xf, _gbuf(w_ih), ta=True, tb=True, acc=True, prec=prec)
         dw_hh = gemm(dgh2, hall[:T].view(T * M, H), _gbuf(w_hh), ta=True, tb=True, acc=True, prec=prec)
-        db_ih = colsum(_zeros(1, 3 * H, dev=xf.device), dgi2).view(-1)
-        db_hh = colsum(_zeros(1, 3 * H, dev=xf.device), dgh2).view(-1)
+        db_ih = _bgrad(b_ih, dgi2)
+        db_hh = _bgrad(b_hh, dgh2)
         grads += [dw_ih, dw_hh, db_ih, db_hh]
         if need_dx:
             if dx is None:
@@ -247,13 +255,13 @@ class EncoderHeadsFn(torch.autograd.Function):
     def forward(ctx, h, w_mu, b_mu, w_var, b_var, prec):
         mu = gemm(h, w_mu, bias=b_mu, prec=prec)
         sd = gemm(h, w_var, bias=b_var, act=1, prec=prec)
-        ctx.save_for_backward(h, w_mu, w_var, mu, sd)
+        ctx.save_for_backward(h, w_mu, w_var, mu, sd, b_mu, b_var)
         ctx.prec = prec
         return mu, sd
 
     @staticmethod
     def backward(ctx, dmu, dsd):
-        h, w_mu, w_var, mu, sd = ctx.saved_tensors
+        h, w_mu, w_var, mu, sd, b_mu, b_var = ctx.saved_tensors
         prec = ctx.prec
         B, Z = mu.shape
         dev = h.device
@@ -266,8 +274,8 @@ class EncoderHeadsFn(torch.autograd.Function):
         gemm(glv, w_var, dh, tb=True, acc=True, prec=prec)
         dw_mu = gemm(gmu, h, _gbuf(w_mu), ta=True, tb=True, acc=True, prec=prec)
         dw_var = gemm(glv, h, _gbuf(w_var), ta=True, tb=True, acc=True, prec=prec)
-        db_mu = colsum(_zeros(1, Z, dev=dev), gmu).view(-1)
-        db_var = colsum(_zeros(1, Z, dev=dev), glv).view(-1)
+        db_mu = _bgrad(b_mu, gmu)
+        db_var = _bgrad(b_var, glv)
         return dh, dw_mu, db_mu, dw_var, db_var, None
 
 
@@ -472,15 +480,16 @@ class DecoderTFFn(torch.autograd.Function):
         for d in range(5):
             gemm(ddur[:, 2 * d:2 * d + 2], HD[d + 1], g, ta=True, tb=True, acc=True, prec=prec)
         G['dur_out_linear.weight'] = g
-        G['dur_out_linear.bias'] = colsum(z1(2), ddur.view(M * 5, 2)).view(-1)
+        G['dur_out_linear.bias'] = _bgrad(P['dur_out_linear.bias'], ddur.view(M * 5, 2))
         G['dec_dur_gru.weight_hh_l0'] = gemm(dgh_d.view(5 * M, 3 * Hd), HD[:5].view(5 * M, Hd), _gbuf(w_hh_d), ta=True,
                                              tb=True, acc=True, prec=prec)
-        G['dec_dur_gru.bias_hh_l0'] = colsum(z1(3 * Hd), dgh_d.view(5 * M, 3 * Hd)).view(-1)
-        G['dec_dur_gru.bias_ih_l0'] = colsum(z1(3 * Hd), dgi_d.view(5 * M, 3 * Hd)).view(-1)
+        G['dec_dur_gru.bias_hh_l0'] = _bgrad(P['dec_dur_gru.bias_hh_l0'], dgh_d.view(5 * M, 3 * Hd))
+        G['dec_dur_gru.bias_ih_l0'] = _bgrad(P['dec_dur_gru.bias_ih_l0'], dgi_d.view(5 * M, 3 * Hd))
         w_ih_d = P['dec_dur_gru.weight_ih_l0']
         cs0 = colsum(z1(3 * Hd), dgi_d[0])                                       # step 0: dense <sos> token
         g = gemm(cs0, P['dur_sos_token'].view(1, -1), _gbuf(w_ih_d), ta=True, tb=True, acc=True, prec=0, splitk=-1)
-        G['dur_sos_token'] = gemm(cs0, w_ih_d, tb=True, prec=0, splitk=-1).view(-1)
+        G['dur_sos_token'] = _gbuf(P['dur_sos_token'])
+        gemm(cs0, w_ih_d, G['dur_sos_token'].view(1, -1), tb=True, prec=0, splitk=-1)
         sel = _zeros(2, 3 * Hd, dev=dev)                                         # steps 1..4: one-hot tokens {0,1}
         for d in range(1, 5):
             colsum(sel, dgi_d[d], sel=st['idx'][d - 1], groups=2)
@@ -496,11 +505,11 @@ class DecoderTFFn(torch.autograd.Function):
         gemm(dHD0, NSUM, g[:, :Hn], ta=True, tb=True, acc=True, prec=prec)
         gemm(dHD0, st['pitch'], g[:, Hn:], ta=True, tb=True, acc=True, prec=prec)
         G['dur_hid_linear.weight'] = g
-        G['dur_hid_linear.bias'] = colsum(z1(Hd), dHD0).view(-1)
+        G['dur_hid_linear.bias'] = _bgrad(P['dur_hid_linear.bias'], dHD0)
         w_p = P['pitch_out_linear.weight']
         gemm(dP, w_p, dNSUM, tb=True, acc=True, prec=prec)
         G['pitch_out_linear.weight'] = gemm(dP, NSUM, _gbuf(w_p), ta=True, tb=True, acc=True, prec=prec)
-        G['pitch_out_linear.bias'] = colsum(z1(NP), dP).view(-1)
+        G['pitch_out_linear.bias'] = _bgrad(P['pitch_out_linear.bias'], dP)
         del dP, dHD0
 
         # ---- notes GRU (15 steps, batch 32*B) ----
@@ -508,10 +517,10 @@ class DecoderTFFn(torch.autograd.Function):
         dgi_n, dgh_n, dHN0 = gru_bwd(prec, HN, st['gates_n'], w_hh_n, dh_ext=dNSUM.view(15, R, Hn))
         G['dec_notes_gru.weight_hh_l0'] = gemm(dgh_n.view(M, 3 * Hn), HN[:15].view(M, Hn), _gbuf(w_hh_n), ta=True, tb=True,
                                                acc=True, prec=prec)
-        G['dec_notes_gru.bias_hh_l0'] = colsum(z1(3 * Hn), dgh_n.view(M, 3 * Hn)).view(-1)
+        G['dec_notes_gru.bias_hh_l0'] = _bgrad(P['dec_notes_gru.bias_hh_l0'], dgh_n.view(M, 3 * Hn))
         del dgh_n, dNSUM
         dGC = sum_steps(dgi_n)                                                    # [R, 3Hn]
-        G['dec_notes_gru.bias_ih_l0'] = colsum(z1(3 * Hn), dGC).view(-1)
+        G['dec_notes_gru.bias_ih_l0'] = _bgrad(P['dec_notes_gru.bias_ih_l0'], dGC)
         g = _gbuf(w_ih_n)
         gemm(dGC, NSf, g[:, :Ht], ta=True, tb=True, acc=True, prec=prec)
         gemm(dgi_n.view(M, 3 * Hn), emb3[:15].view(M, E), g[:, Ht:], ta=True, tb=True, acc=True, prec=prec)
@@ -524,16 +533,16 @@ class DecoderTFFn(torch.autograd.Function):
         w_tn = P['dec_time_to_notes_hid.weight']
         gemm(dHN0, w_tn, dNS, tb=True, acc=True, prec=prec)
         G['dec_time_to_notes_hid.weight'] = gemm(dHN0, NSf, _gbuf(w_tn), ta=True, tb=True, acc=True, prec=prec)
-        G['dec_time_to_notes_hid.bias'] = colsum(z1(Hn), dHN0).view(-1)
+        G['dec_time_to_notes_hid.bias'] = _bgrad(P['dec_time_to_notes_hid.bias'], dHN0)
 
         # ---- time GRU (32 steps, batch B) ----
         w_hh_t, w_ih_t = P['dec_time_gru.weight_hh_l0'], P['dec_time_gru.weight_ih_l0']
         dgi_t, dgh_t, dzhid = gru_bwd(prec, NS, st['gates_t'], w_hh_t, dh_ext=dNS.view(32, B, Ht))
         G['dec_time_gru.weight_hh_l0'] = gemm(dgh_t.view(R, 3 * Ht), NS[:32].view(R, Ht), _gbuf(w_hh_t), ta=True, tb=True,
                                               acc=True, prec=prec)
-        G['dec_time_gru.bias_hh_l0'] = colsum(z1(3 * Ht), dgh_t.view(R, 3 * Ht)).view(-1)
+        G['dec_time_gru.bias_hh_l0'] = _bgrad(P['dec_time_gru.bias_hh_l0'], dgh_t.view(R, 3 * Ht))
         dZG = sum_steps(dgi_t)                                                    # [B, 3Ht]
-        G['dec_time_gru.bias_ih_l0'] = colsum(z1(3 * Ht), dZG).view(-1)
+        G['dec_time_gru.bias_ih_l0'] = _bgrad(P['dec_time_gru.bias_ih_l0'], dZG)
         g = _gbuf(w_ih_t)
         gemm(dZG, st['z_in'], g[:, 2 * He:], ta=True, tb=True, acc=True, prec=prec)
         gemm(dgi_t.view(R, 3 * Ht), TOKS[:32].view(R, 2 * He), g[:, :2 * He], ta=True, tb=True, acc=True, prec=prec)
@@ -542,7 +551,7 @@ class DecoderTFFn(torch.autograd.Function):
         dTOKS = _empty(33, B, 2 * He, dev=dev)
         dTOKS[32].zero_()
         gemm(dgi_t.view(R, 3 * Ht), w_ih_t[:, :2 * He], dTOKS[:32].view(R, 2 * He), tb=True, prec=prec)
-        G['dec_init_input'] = colsum(z1(2 * He), dTOKS[0]).view(-1)
+        G['dec_init_input'] = _bgrad(P['dec_init_input'], dTOKS[0])
         dxs = dTOKS[1:].view(R, 2 * He)
         del dgi_t, dgh_t
 
@@ -560,9 +569,9 @@ class DecoderTFFn(torch.autograd.Function):
         dz = gemm(dzhid, w_zh, tb=True, prec=prec)
         gemm(dz_in, w_zi, dz, tb=True, acc=True, prec=prec)
         G['z2dec_hid_linear.weight'] = gemm(dzhid, z, _gbuf(w_zh), ta=True, tb=True, acc=True, prec=prec)
-        G['z2dec_hid_linear.bias'] = colsum(z1(Ht), dzhid).view(-1)
+        G['z2dec_hid_linear.bias'] = _bgrad(P['z2dec_hid_linear.bias'], dzhid)
         G['z2dec_in_linear.weight'] = gemm(dz_in, z, _gbuf(w_zi), ta=True, tb=True, acc=True, prec=prec)
-        G['z2dec_in_linear.bias'] = colsum(z1(w_zi.shape[0]), dz_in).view(-1)
+        G['z2dec_in_linear.bias'] = _bgrad(P['z2dec_in_linear.bias'], dz_in)
 
         return (dz, demb.view(16, 32, B, E), None, None, None) + tuple(G[n] for n in DEC_PARAM_NAMES)
 
@@ -624,7 +633,7 @@ class ChordDecoderTFFn(torch.autograd.Function):
         for name, dlog in (('root_out', droot), ('chroma_out', dchroma), ('bass_out', dbass)):
             w = P[name + '.weight']
             if dlog is None:
-                G[name + '.weight'], G[name + '.bias'] = torch.zeros_like(w), torch.zeros_like(P[name + '.bias'])
+                G[name + '.weight'], G[name + '.bias'] = _gbuf(w), _gbuf(P[name + '.bias'])
                 continue
             d2 = dlog.contiguous().view(T * B, -1)
             if dhs is None:
@@ -632,30 +641,30 @@ class ChordDecoderTFFn(torch.autograd.Function):
             else:
                 gemm(d2, w, dhs, tb=True, acc=True, prec=prec)
             G[name + '.weight'] = gemm(d2, hs, _gbuf(w), ta=True, tb=True, acc=True, prec=prec)
-            G[name + '.bias'] = colsum(_zeros(1, w.shape[0], dev=dev), d2).view(-1)
+            G[name + '.bias'] = _bgrad(P[name + '.bias'], d2)
         if dhs is None:
             dhs = _zeros(T * B, H, dev=dev)
         w_hh, w_ih = P['gru.weight_hh_l0'], P['gru.weight_ih_l0']
         dgi, dgh, dh0 = gru_bwd(prec, hall, st['gates'], w_hh, dh_ext=dhs.view(T, B, H))
         G['gru.weight_hh_l0'] = gemm(dgh.view(T * B, 3 * H), hall[:T].view(T * B, H), _gbuf(w_hh), ta=True, tb=True, acc=True,
                                      prec=prec)
-        G['gru.bias_hh_l0'] = colsum(_zeros(1, 3 * H, dev=dev), dgh.view(T * B, 3 * H)).view(-1)
+        G['gru.bias_hh_l0'] = _bgrad(P['gru.bias_hh_l0'], dgh.view(T * B, 3 * H))
         dzg = sum_steps(dgi)
-        G['gru.bias_ih_l0'] = colsum(_zeros(1, 3 * H, dev=dev), dzg).view(-1)
+        G['gru.bias_ih_l0'] = _bgrad(P['gru.bias_ih_l0'], dzg)
         g = _gbuf(w_ih)
         gemm(dzg, st['z_in'], g[:, I:], ta=True, tb=True, acc=True, prec=prec)
         gemm(dgi.view(T * B, 3 * H), toks.view(T * B, I), g[:, :I], ta=True, tb=True, acc=True, prec=prec)
         G['gru.weight_ih_l0'] = g
         dz_in = gemm(dzg, w_ih[:, I:], tb=True, prec=prec)
         dtok0 = gemm(dgi[0], w_ih[:, :I], tb=True, prec=prec)                     # only the learned start token
-        G['init_input'] = colsum(_zeros(1, I, dev=dev), dtok0).view(-1)
+        G['init_input'] = _bgrad(P['init_input'], dtok0)
         w_zh, w_zi = P['z2dec_hid.weight'], P['z2dec_in.weight']
         dz = gemm(dh0, w_zh, tb=True, prec=prec)
         gemm(dz_in, w_zi, dz, tb=True, acc=True, prec=prec)
         G['z2dec_hid.weight'] = gemm(dh0, z, _gbuf(w_zh), ta=True, tb=True, acc=True, prec=prec)
-        G['z2dec_hid.bias'] = colsum(_zeros(1, H, dev=dev), dh0).view(-1)
+        G['z2dec_hid.bias'] = _bgrad(P['z2dec_hid.bias'], dh0)
         G['z2dec_in.weight'] = gemm(dz_in, z, _gbuf(w_zi), ta=True, tb=True, acc=True, prec=prec)
-        G['z2dec_in.bias'] = colsum(_zeros(1, w_zi.shape[0], dev=dev), dz_in).view(-1)
+        G['z2dec_in.bias'] = _bgrad(P['z2dec_in.bias'], dz_in)
         return (dz, None, None) + tuple(G[n] for n in CHD_PARAM_NAMES)
 
 

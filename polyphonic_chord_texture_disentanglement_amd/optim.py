@@ -1,0 +1,123 @@
+"""Flat-buffer optimiser for the train step: clip_grad_norm_ + Adam in two HIP launches.
+
+Replaces `torch.nn.utils.clip_grad_norm_(model.parameters(), clip)` + `torch.optim.Adam.step()`
+(reference amc_dl/torch_plus/module.py:142-144, train.py:50; Adam defaults beta (0.9, 0.999),
+eps 1e-8, no weight decay) with `ptv_grad_sumsq` + `ptv_clip_adam_step` over ONE flat fp32 buffer
+each for parameters, gradients and the two moments: 7 x 109 MB of HBM traffic per step, no host
+sync (the norm stays on the device).  The flat gradient buffer is also the RCCL all-reduce bucket.
+
+Parameters are re-pointed to views of the flat parameter buffer (state_dict keys/shapes are
+unchanged).  Gradients: `GradArena` hands the backward kernels zero-initialised views of the flat
+gradient buffer, so `.grad` of every parameter already lives in the bucket when backward ends.
+"""
+import torch
+
+from ._lib import call, ptr, stream_ptr
+
+_ARENA_OF = {}          # id(param) -> GradArena
+
+
+class GradArena:
+    def __init__(self, params):
+        self.params = list(params)
+        dev = self.params[0].device
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4            # keep every view 16-byte aligned
+        self.total = off
+        self.flat = torch.zeros(off, device=dev, dtype=torch.float32)
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._handed = set()
+        for p in self.params:
+            _ARENA_OF[id(p)] = self
+
+    def view(self, p):
+        i = self._index[id(p)]
+        o = self.offsets[i]
+        return self.flat[o:o + p.numel()].view(p.shape)      # fresh TensorImpl: autograd may adopt it as .grad
+
+    def take(self, p):
+        """zeroed gradient view for p, once per zero(); None if already handed out this step."""
+        if id(p) in self._handed:
+            return None
+        self._handed.add(id(p))
+        return self.view(p)
+
+    def zero(self):
+        self.flat.zero_()
+        self._handed.clear()
+
+    def holds_all_grads(self):
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * o:
+                return False
+        return True
+
+    def gather_grads(self):
+        """slow path (a gradient was produced outside the arena): copy .grad into the bucket"""
+        for p in self.params:
+            v = self.view(p)
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+            p.grad = v
+
+
+def grad_buffer(p):
+    """Used by functional.py: arena view when the parameter is registered, else a fresh zeros."""
+    a = _ARENA_OF.get(id(p))
+    if a is not None:
+        v = a.take(p)
+        if v is not None:
+            return v
+    return torch.zeros_like(p, memory_format=torch.contiguous_format)
+
+
+class FusedClipAdam(torch.optim.Optimizer):
+    """Adam with global-norm clipping fused in (`clip_and_step(clip)`); `step()` alone = no clipping."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        ps = [p for g in self.param_groups for p in g['params']]
+        assert len(self.param_groups) == 1 and all(p.is_cuda and p.dtype == torch.float32 for p in ps), \
+            'FusedClipAdam: one group of fp32 cuda parameters expected (move the model to the GPU first)'
+        self.arena = GradArena(ps)
+        self.flat_p = torch.empty(self.arena.total, device=ps[0].device, dtype=torch.float32).zero_()
+        for p, o in zip(ps, self.arena.offsets):
+            dst = self.flat_p[o:o + p.numel()].view(p.shape)
+            dst.copy_(p.data)
+            p.data = dst
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        self.sumsq = torch.zeros(1, device=ps[0].device, dtype=torch.float32)
+        self.step_count = 0
+        self.grad_scale = 1.0           # set to 1/world_size when the bucket holds a SUM over ranks
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.arena.params:
+            p.grad = None
+        self.arena.zero()
+
+    def grad_norm(self):
+        """pre-clip global L2 norm of the last step (device tensor; reading it syncs)"""
+        return self.sumsq.sqrt() * self.grad_scale
+
+    def clip_and_step(self, clip):
+        a = self.arena
+        if not a.holds_all_grads():
+            a.gather_grads()
+        g = self.param_groups[0]
+        self.step_count += 1
+        st = stream_ptr()
+        call('ptv_grad_sumsq', ptr(a.flat), a.total, ptr(self.sumsq), st)
+        call('ptv_clip_adam_step', ptr(self.flat_p), ptr(a.flat), ptr(self.exp_avg), ptr(self.exp_avg_sq), a.total,
+             ptr(self.sumsq), float(self.grad_scale), float(clip if clip is not None else 0.0), float(g['lr']),
+             float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), self.step_count, st)
+
+    def step(self, closure=None):
+        assert closure is None
+        self.clip_and_step(0.0)

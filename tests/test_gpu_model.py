@@ -111,3 +111,49 @@ def test_fresh_batch_vs_oracle_with_weighted_outputs():
     for k, p in m.named_parameters():
         ref = params[k].grad.numpy()
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=0, atol=2e-6 + 2e-4 * np.abs(ref).max(), err_msg=k)
+
+
+def test_three_step_training_trace_with_fused_clip_adam():
+    """zero_grad -> loss -> backward -> clip_grad_norm_(1) + Adam (fused HIP) -> MinExponentialLR, 3 steps,
+    against the trace recorded from the reference (torch.optim.Adam + clip_grad_norm_)."""
+    from polyphonic_chord_texture_disentanglement_amd.amc_dl.torch_plus import MinExponentialLR
+    from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
+    g = load_npz('reduced_train3.npz')
+    m = build_reduced(DEV).to(DEV)
+    opt = FusedClipAdam(m.parameters(), lr=1e-3)
+    sched = MinExponentialLR(opt, gamma=0.9999, minimum=1e-5)
+    for step in range(3):
+        x, c, pr = (torch.from_numpy(a).to(DEV) for a in synth_batch(3, 200 + step))
+        m.eps_source = lambda name, shape, device, s=step: torch.from_numpy(g['eps_%s.%d' % (name, s)]).to(device)
+        opt.zero_grad()
+        losses = m('train', x, c, pr, tfr1=1., tfr2=1., tfr3=1., beta=0.1, weights=[1, 0.5])
+        losses[0].backward()
+        assert opt.arena.holds_all_grads()                     # every gradient was produced in the flat bucket
+        opt.clip_and_step(1)
+        sched.step()
+        np.testing.assert_allclose(np.array([l.item() for l in losses]), g['losses.%d' % step], rtol=0, atol=1e-4)
+        assert abs(opt.grad_norm().item() - float(g['gnorm.%d' % step])) < 1e-3 * float(g['gnorm.%d' % step])
+        assert abs(opt.param_groups[0]['lr'] - float(g['lr.%d' % step])) < 1e-12
+        psum = np.array([p.detach().double().sum().item() for p in m.parameters()])
+        pabs = np.array([p.detach().double().abs().sum().item() for p in m.parameters()])
+        np.testing.assert_allclose(psum, g['psum.%d' % step], rtol=0, atol=5e-4)
+        np.testing.assert_allclose(pabs, g['pabs.%d' % step], rtol=1e-4, atol=1e-4)
+
+
+def test_fused_optimizer_matches_torch_adam_on_same_grads():
+    from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
+    torch.manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in ((37, 5), (130,), (8, 3, 4, 12), (1,))]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ref = torch.optim.Adam(qs, lr=1e-3)
+    opt = FusedClipAdam(ps, lr=1e-3)
+    for it in range(4):
+        grads = [torch.randn_like(p) * (3.0 if it % 2 == 0 else 0.01) for p in ps]
+        for p, q, gr in zip(ps, qs, grads):
+            p.grad = gr.clone()
+            q.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(qs, 1.0)
+        ref.step()
+        opt.clip_and_step(1.0)
+        for p, q in zip(ps, qs):
+            assert (p - q).abs().max() < 2e-6
