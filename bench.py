@@ -31,7 +31,11 @@ def cpu_baseline(batch=16):
     from oracle.ptvae_oracle import Oracle, clip_and_adam_step
     from polyphonic_chord_texture_disentanglement_amd.model import DisentangleVAE
     from polyphonic_chord_texture_disentanglement_amd.synthetic import synth_batch
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))          # the oracle's matmuls are small: more threads only add overhead
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     ref = DisentangleVAE.init_model(torch.device('cpu'))
@@ -121,6 +125,9 @@ def main():
 
     for i in range(args.warmup):
         out = step(i)
+        if rank == 0:
+            torch.cuda.synchronize()
+            print('[bench] warmup step %d done' % i, file=sys.stderr, flush=True)
     barrier()
     lib.ptv_prof_reset()
     lib.ptv_prof_config(32 * B, model.decoder.dec_notes_hid_size)
