@@ -43,29 +43,40 @@ __global__ void sum_steps_kernel(float* out, const float* in, long n, int T, lon
   }
 }
 
-// out[g*N + n] += sum_{rows r with (sel ? sel[r] : 0) == g} A[r*lda + n]       (block partial + atomics)
-// block = 256 threads = 64 columns x 4 row lanes
-__global__ void colsum_kernel(float* out, const float* A, long lda, long rows, int N, const int* sel, int G) {
-  __shared__ float red[4][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + cx;
+// out[g*N + n] += sum_{rows r with (sel ? sel[r] : 0) == g} A[r*lda + n]   (G <= 2; block partial + atomics)
+// block = 256 threads = 16 column quads (64 columns, 16-byte loads) x 16 row lanes
+template <bool VEC>
+__global__ void colsum_kernel(float* out, const float* __restrict__ A, long lda, long rows, int N, const int* __restrict__ sel, int G) {
+  __shared__ float red[2][16][64];
+  const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int n = blockIdx.x * 64 + cq * 4;
   const long rows_per_block = (rows + gridDim.y - 1) / gridDim.y;
   const long r0 = blockIdx.y * rows_per_block;
   const long r1 = min(rows, r0 + rows_per_block);
-  for (int g = 0; g < G; g++) {
-    float s = 0.f;
-    if (n < N) {
-      for (long r = r0 + ry; r < r1; r += 4) {
-        if (sel == nullptr || sel[r] == g) s += A[r * lda + n];
+  float s[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (n < N) {
+    for (long r = r0 + ry; r < r1; r += 16) {
+      const int g = sel ? sel[r] : 0;
+      float4 v;
+      if (VEC) v = *reinterpret_cast<const float4*>(A + r * lda + n);
+      else {
+        v.x = A[r * lda + n]; v.y = n + 1 < N ? A[r * lda + n + 1] : 0.f;
+        v.z = n + 2 < N ? A[r * lda + n + 2] : 0.f; v.w = n + 3 < N ? A[r * lda + n + 3] : 0.f;
       }
+      if (g == 0) { s[0][0] += v.x; s[0][1] += v.y; s[0][2] += v.z; s[0][3] += v.w; }
+      else if (g == 1) { s[1][0] += v.x; s[1][1] += v.y; s[1][2] += v.z; s[1][3] += v.w; }
     }
-    red[ry][cx] = s;
-    __syncthreads();
-    if (ry == 0 && n < N) {
-      float t = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
-      if (t != 0.f) atomicAdd(out + (long)g * N + n, t);
-    }
-    __syncthreads();
+  }
+  for (int g = 0; g < G; g++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) red[g][ry][cq * 4 + e] = s[g][e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < G * 64; i += blockDim.x) {
+    const int g = i / 64, c = i % 64;
+    float t = 0.f;
+#pragma unroll
+    for (int y = 0; y < 16; y++) t += red[g][y][c];
+    if (blockIdx.x * 64 + c < N && t != 0.f) atomicAdd(out + (long)g * N + blockIdx.x * 64 + c, t);
   }
 }
 
@@ -200,10 +211,14 @@ extern "C" int ptv_sum_steps(float* out, const float* in, long n, int T, long st
 }
 
 extern "C" int ptv_colsum(float* out, const float* A, long lda, long rows, int N, const int* sel, int G, void* stream) {
-  if (!out || !A || rows < 0 || N <= 0 || G <= 0) return PTV_ERR_ARG;
+  if (!out || !A || rows < 0 || N <= 0 || G <= 0 || G > 2) return PTV_ERR_ARG;
   if (rows == 0) return PTV_OK;
-  int gy = (int)((rows + 511) / 512); if (gy > 512) gy = 512; if (gy < 1) gy = 1;
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), gy), dim3(256), 0, (hipStream_t)stream, out, A, lda, rows, N, sel, G);
+  int gx = cdiv(N, 64);
+  long want = 2048 / gx; if (want < 1) want = 1;                 // ~2048 blocks in flight
+  long gy = (rows + 63) / 64; if (gy > want) gy = want; if (gy < 1) gy = 1;
+  const bool vec = ((lda & 3) == 0) && ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  if (vec) hipLaunchKernelGGL((colsum_kernel<true>), dim3(gx, (int)gy), dim3(256), 0, (hipStream_t)stream, out, A, lda, rows, N, sel, G);
+  else hipLaunchKernelGGL((colsum_kernel<false>), dim3(gx, (int)gy), dim3(256), 0, (hipStream_t)stream, out, A, lda, rows, N, sel, G);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

@@ -73,17 +73,22 @@ static void launch_plain(const GemmArgs& g, const EpiPlain::Params& ep, int spli
 
 template <class CT>
 static int gemm_dispatch(int transA, int transB, GemmArgs g, EpiPlain::Params ep, int splitk, hipStream_t s) {
-  // tile choice: 128x128 when it still yields >= ~1 block per CU, else 64x64
+  // tile choice: 128x128 when it still yields >= ~1 block per CU, else 64x64.  Weight-gradient
+  // products (transA: K = rows x steps is huge, M x N small) fill the chip with K splits; the
+  // thresholds / block targets below are the measured optima of scripts/bench_tn.py on MI355X.
   const long blocks_big = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
-  const bool big = blocks_big >= 192;
+  const bool deepk = transA && g.K >= 4096;
+  const bool big = blocks_big >= 192 || (deepk && g.M >= 256 && g.N >= 256);
   const int bm = big ? 128 : 64;
   long blocks = (long)cdiv(g.M, bm) * cdiv(g.N, bm);
   int splits = 1;
   if (splitk > 0) splits = splitk;
   else if (splitk == 0 && blocks < 256 && g.K >= 8 * CT::BK && ep.act == 0) {
-    splits = (int)((512 + blocks - 1) / blocks);
+    const long target = deepk ? (big ? 640 : 1536) : 512;
+    splits = (int)((target + blocks - 1) / blocks);
     int maxs = g.K / (4 * CT::BK);
     if (splits > maxs) splits = maxs;
+    if (splits > 192) splits = 192;
     if (splits < 1) splits = 1;
   }
   int kper = g.K;

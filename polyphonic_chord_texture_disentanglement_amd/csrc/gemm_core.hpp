@@ -29,13 +29,15 @@ constexpr int NTHREADS = 256;
 
 struct BF16 {
   using T = __bf16;
-  static constexpr int BK = 64;    // k per LDS tile
-  static constexpr int LDS_LD = 72;  // row stride in elements (64 + 16 B pad)
+  static constexpr int BK = 64;    // k per LDS tile (128 B per row)
+  static constexpr int LDS_LD = 64;  // unpadded; bank conflicts are removed by the XOR swizzle below
+  static constexpr int CH = 8;     // elements per 16-byte chunk
 };
 struct F32 {
   using T = float;
   static constexpr int BK = 32;
-  static constexpr int LDS_LD = 36;
+  static constexpr int LDS_LD = 32;
+  static constexpr int CH = 4;
 };
 
 struct GemmArgs {
@@ -45,6 +47,15 @@ struct GemmArgs {
   int k_per_split;            // K range handled by one blockIdx.z (multiple of BK); == K when no split
   long gate_stride;           // NG==3: B row of gate g, unit j is g*gate_stride + j   (N = #units)
 };
+
+// LDS image of a tile: [row][128 bytes], the eight 16-byte chunks of row r XOR-permuted by
+// ((r >> 2) ^ r) & 7.  With this permutation the transposing stores of the K-major loader
+// (ds_write_b64/b128 from 8 row-groups x k-quads), the row stores of the K-contiguous loader and
+// the ds_read_b128 fragment reads (16 rows x 4 chunks per wave) are all bank-conflict free under
+// the gfx950 lane-group rules (brute-forced in scripts/lds_swizzle_check.py).
+template <class CT> __device__ __forceinline__ int swz(int row, int k) {
+  return row * CT::LDS_LD + ((((k / CT::CH) ^ ((row >> 2) ^ row)) & 7) * CT::CH) + (k % CT::CH);
+}
 
 // ---------------------------------------------------------------------------------------------
 // tile staging
@@ -90,13 +101,27 @@ struct StageKC {
       v[i] = x;
     }
   }
+  // whole tile in range and 16-byte aligned: straight-line loads, no per-element predicates (a
+  // branchy loader makes hipcc wait for every load before the next branch -- nothing pipelines)
+  template <class RowMap>
+  __device__ __forceinline__ void load_fast(const float* __restrict__ p, long ld, int k0, RowMap rowmap) {
+    const int tid = threadIdx.x;
+    const int vr = tid % VPR, r0 = tid / VPR;
+    const float* base = p + k0 + vr * 4;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      int r = r0 + i * RPP;
+      if (ROWS % RPP != 0 && r >= ROWS) r = ROWS - 1;       // tail threads re-read the last row (never stored)
+      v[i] = *reinterpret_cast<const float4*>(base + rowmap(r) * ld);
+    }
+  }
   __device__ __forceinline__ void store(typename CT::T* s) const {
     const int tid = threadIdx.x;
     const int vr = tid % VPR, r0 = tid / VPR;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
       const int r = r0 + i * RPP;
-      if (ROWS % RPP == 0 || r < ROWS) lds_store4<CT>(s + r * CT::LDS_LD + vr * 4, v[i].x, v[i].y, v[i].z, v[i].w);
+      if (ROWS % RPP == 0 || r < ROWS) lds_store4<CT>(s + swz<CT>(r, vr * 4), v[i].x, v[i].y, v[i].z, v[i].w);
     }
   }
 };
@@ -109,12 +134,16 @@ struct StageKM {
   static constexpr int ITEMS = RG * KQ;
   static constexpr int NP = (ITEMS + NTHREADS - 1) / NTHREADS;
   float4 v[NP][4];
+  // work item -> (row group, k quad): 8 adjacent lanes cover 8 row groups (one 128-byte line per k
+  // row), the next lanes walk the k quads
+  static __device__ __forceinline__ int wi_rg(int w) { return (w & 7) + 8 * (w / (8 * KQ)); }
+  static __device__ __forceinline__ int wi_kq(int w) { return (w >> 3) % KQ; }
 
   __device__ __forceinline__ void load(const float* __restrict__ p, long ld, int k0, int kend, bool vec_ok, long row0, long nrows) {
 #pragma unroll
     for (int i = 0; i < NP; i++) {
       const int w = threadIdx.x + i * NTHREADS;
-      const int rg = w % RG, kq = w / RG;
+      const int rg = wi_rg(w), kq = wi_kq(w);
       const long r = row0 + rg * 4;
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
@@ -135,17 +164,26 @@ struct StageKM {
       }
     }
   }
+  __device__ __forceinline__ void load_fast(const float* __restrict__ p, long ld, int k0, long row0) {
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      int w = threadIdx.x + i * NTHREADS;
+      if (ITEMS % NTHREADS != 0 && w >= ITEMS) w = ITEMS - 1;
+      const float* q = p + (long)(k0 + wi_kq(w) * 4) * ld + row0 + wi_rg(w) * 4;
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) v[i][kk] = *reinterpret_cast<const float4*>(q + kk * ld);
+    }
+  }
   __device__ __forceinline__ void store(typename CT::T* s) const {
 #pragma unroll
     for (int i = 0; i < NP; i++) {
       const int w = threadIdx.x + i * NTHREADS;
       if (ITEMS % NTHREADS == 0 || w < ITEMS) {
-        const int rg = w % RG, kq = w / RG;
-        typename CT::T* d = s + (rg * 4) * CT::LDS_LD + kq * 4;
-        lds_store4<CT>(d + 0 * CT::LDS_LD, v[i][0].x, v[i][1].x, v[i][2].x, v[i][3].x);
-        lds_store4<CT>(d + 1 * CT::LDS_LD, v[i][0].y, v[i][1].y, v[i][2].y, v[i][3].y);
-        lds_store4<CT>(d + 2 * CT::LDS_LD, v[i][0].z, v[i][1].z, v[i][2].z, v[i][3].z);
-        lds_store4<CT>(d + 3 * CT::LDS_LD, v[i][0].w, v[i][1].w, v[i][2].w, v[i][3].w);
+        const int rg = wi_rg(w), kq = wi_kq(w);
+        lds_store4<CT>(s + swz<CT>(rg * 4 + 0, kq * 4), v[i][0].x, v[i][1].x, v[i][2].x, v[i][3].x);
+        lds_store4<CT>(s + swz<CT>(rg * 4 + 1, kq * 4), v[i][0].y, v[i][1].y, v[i][2].y, v[i][3].y);
+        lds_store4<CT>(s + swz<CT>(rg * 4 + 2, kq * 4), v[i][0].z, v[i][1].z, v[i][2].z, v[i][3].z);
+        lds_store4<CT>(s + swz<CT>(rg * 4 + 3, kq * 4), v[i][0].w, v[i][1].w, v[i][2].w, v[i][3].w);
       }
     }
   }
@@ -167,9 +205,9 @@ struct TileMma<BF16, FM, FNT> {
     for (int ks = 0; ks < BF16::BK; ks += 32) {
       bf16x8 a[FM], b[FNT];
 #pragma unroll
-      for (int i = 0; i < FM; i++) a[i] = *reinterpret_cast<const bf16x8*>(As + (a_row0 + i * 16 + r) * BF16::LDS_LD + ks + kq);
+      for (int i = 0; i < FM; i++) a[i] = *reinterpret_cast<const bf16x8*>(As + swz<BF16>(a_row0 + i * 16 + r, ks + kq));
 #pragma unroll
-      for (int j = 0; j < FNT; j++) b[j] = *reinterpret_cast<const bf16x8*>(Bs + (b_row(j) + r) * BF16::LDS_LD + ks + kq);
+      for (int j = 0; j < FNT; j++) b[j] = *reinterpret_cast<const bf16x8*>(Bs + swz<BF16>(b_row(j) + r, ks + kq));
 #pragma unroll
       for (int i = 0; i < FM; i++)
 #pragma unroll
@@ -188,9 +226,9 @@ struct TileMma<F32, FM, FNT> {
     for (int ks = 0; ks < F32::BK; ks += 16) {
       float4 a[FM], b[FNT];
 #pragma unroll
-      for (int i = 0; i < FM; i++) a[i] = *reinterpret_cast<const float4*>(As + (a_row0 + i * 16 + r) * F32::LDS_LD + ks + kq);
+      for (int i = 0; i < FM; i++) a[i] = *reinterpret_cast<const float4*>(As + swz<F32>(a_row0 + i * 16 + r, ks + kq));
 #pragma unroll
-      for (int j = 0; j < FNT; j++) b[j] = *reinterpret_cast<const float4*>(Bs + (b_row(j) + r) * F32::LDS_LD + ks + kq);
+      for (int j = 0; j < FNT; j++) b[j] = *reinterpret_cast<const float4*>(Bs + swz<F32>(b_row(j) + r, ks + kq));
       // lane group g=(lane>>4) feeds k = ks + 4g + e on MFMA e: a consistent k permutation of A and B
 #pragma unroll
       for (int i = 0; i < FM; i++)
@@ -246,11 +284,26 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
 #pragma unroll
     for (int j = 0; j < NG * FN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const bool fullA = vecA && (m_blk + BM <= g.M);          // block-uniform: rows of the tile all valid
+  const bool fullB = vecB && (n_blk + BN <= g.N);
+  auto rowfastA = [&](int r) -> long { return m_blk + r; };
+  auto rowfastB = [&](int r) -> long { return (long)(r / BN) * g.gate_stride + n_blk + (r % BN); };
   auto load_tiles = [&](int k0) {
-    if constexpr (KMAJOR_A) sa.load(g.A, g.lda, k0, kend, vecA, m_blk, g.M);
-    else sa.load(g.A, g.lda, k0, kend, vecA, rowmapA);
-    if constexpr (KMAJOR_B) sb.load(g.B, g.ldb, k0, kend, vecB, n_blk, g.N);
-    else sb.load(g.B, g.ldb, k0, kend, vecB, rowmapB);
+    const bool kfull = k0 + CT::BK <= kend;
+    if (fullA && kfull) {
+      if constexpr (KMAJOR_A) sa.load_fast(g.A, g.lda, k0, m_blk);
+      else sa.load_fast(g.A, g.lda, k0, rowfastA);
+    } else {
+      if constexpr (KMAJOR_A) sa.load(g.A, g.lda, k0, kend, vecA, m_blk, g.M);
+      else sa.load(g.A, g.lda, k0, kend, vecA, rowmapA);
+    }
+    if (fullB && kfull) {
+      if constexpr (KMAJOR_B) sb.load_fast(g.B, g.ldb, k0, n_blk);
+      else sb.load_fast(g.B, g.ldb, k0, rowfastB);
+    } else {
+      if constexpr (KMAJOR_B) sb.load(g.B, g.ldb, k0, kend, vecB, n_blk, g.N);
+      else sb.load(g.B, g.ldb, k0, kend, vecB, rowmapB);
+    }
   };
 
   if (kbeg < kend) load_tiles(kbeg);

@@ -203,10 +203,13 @@ static void launch_fwd_step(const GemmArgs& g, const EpiGruFwd::Params& ep, hipS
 template <class CT>
 static void launch_bwd_step(const GemmArgs& g, const EpiGruBwd::Params& ep, hipStream_t s) {
   const long blocks_big = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
+  const long blocks_mid = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
   if (blocks_big >= 192) {
     hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 128, 128>), dim3(cdiv(g.N, 128), cdiv(g.M, 128)), dim3(NTHREADS), 0, s, g, ep);
-  } else {
+  } else if (blocks_mid >= 192) {
     hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 64, 64>), dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
+  } else {
+    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 64, 32>), dim3(cdiv(g.N, 32), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
   }
 }
 
