@@ -60,100 +60,104 @@ template <class CT> __device__ __forceinline__ int swz(int row, int k) {
 // ---------------------------------------------------------------------------------------------
 // tile staging
 // ---------------------------------------------------------------------------------------------
-template <class CT> __device__ __forceinline__ void lds_store4(typename CT::T* dst, float a, float b, float c, float d);
-template <> __device__ __forceinline__ void lds_store4<BF16>(__bf16* dst, float a, float b, float c, float d) {
-  bf16x4 v; v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
-  *reinterpret_cast<bf16x4*>(dst) = v;
-}
-template <> __device__ __forceinline__ void lds_store4<F32>(float* dst, float a, float b, float c, float d) {
-  *reinterpret_cast<float4*>(dst) = make_float4(a, b, c, d);
-}
+// one 16-byte LDS chunk = CT::CH consecutive k of one row, converted from fp32
+template <class CT> struct Chunk;
+template <> struct Chunk<BF16> {
+  float4 lo, hi;                                   // k .. k+7
+  __device__ __forceinline__ void zero() { lo = hi = make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ __forceinline__ float& at(int e) { return e < 4 ? (&lo.x)[e] : (&hi.x)[e - 4]; }
+  __device__ __forceinline__ void load16(const float* q) { lo = *reinterpret_cast<const float4*>(q); hi = *reinterpret_cast<const float4*>(q + 4); }
+  __device__ __forceinline__ void store(__bf16* d) const {
+    bf16x8 v;
+    v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
+    v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
+    *reinterpret_cast<bf16x8*>(d) = v;
+  }
+};
+template <> struct Chunk<F32> {
+  float4 lo;
+  __device__ __forceinline__ void zero() { lo = make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ __forceinline__ float& at(int e) { return (&lo.x)[e]; }
+  __device__ __forceinline__ void load16(const float* q) { lo = *reinterpret_cast<const float4*>(q); }
+  __device__ __forceinline__ void store(float* d) const { *reinterpret_cast<float4*>(d) = lo; }
+};
 
-// K-contiguous source: tile ROWS x BK.  `rowbase(r)` gives the global row for tile row r or -1.
+// K-contiguous source: tile ROWS x BK, one 16-byte LDS chunk per thread per pass.
+//   8 threads cover a row (BK = 8 chunks), RPP = 32 rows per pass.
+// `ROWU(i)` = global row of tile row i*RPP (block-uniform); thread row offsets are added on top.
 template <class CT, int ROWS>
 struct StageKC {
-  static constexpr int VPR = CT::BK / 4;            // float4 per row
-  static constexpr int RPP = NTHREADS / VPR;        // rows per pass
-  static constexpr int NP = (ROWS + RPP - 1) / RPP;
-  float4 v[NP];
+  static constexpr int CPR = 8;                     // chunks per row
+  static constexpr int RPP = NTHREADS / CPR;        // 32 rows per pass
+  static constexpr int NP = ROWS / RPP;
+  static_assert(ROWS % RPP == 0, "tile rows must be a multiple of 32");
+  Chunk<CT> v[NP];
 
+  // general path: bounds-checked, any alignment
   template <class RowMap>
   __device__ __forceinline__ void load(const float* __restrict__ p, long ld, int k0, int kend, bool vec_ok, RowMap rowmap) {
     const int tid = threadIdx.x;
-    const int vr = tid % VPR, r0 = tid / VPR;
-    const int k = k0 + vr * 4;
+    const int c = tid % CPR, r0 = tid / CPR;
+    const int k = k0 + c * CT::CH;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-      const int r = r0 + i * RPP;
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      long g = (ROWS % RPP == 0 || r < ROWS) ? rowmap(r) : -1;
+      v[i].zero();
+      const long g = rowmap(r0 + i * RPP);
       if (g >= 0) {
         const float* q = p + g * ld + k;
-        if (vec_ok && k + 3 < kend) {
-          x = *reinterpret_cast<const float4*>(q);
-        } else {
-          if (k + 0 < kend) x.x = q[0];
-          if (k + 1 < kend) x.y = q[1];
-          if (k + 2 < kend) x.z = q[2];
-          if (k + 3 < kend) x.w = q[3];
+        if (vec_ok && k + CT::CH <= kend) v[i].load16(q);
+        else {
+#pragma unroll
+          for (int e = 0; e < CT::CH; e++) if (k + e < kend) v[i].at(e) = q[e];
         }
       }
-      v[i] = x;
     }
   }
-  // whole tile in range and 16-byte aligned: straight-line loads, no per-element predicates (a
-  // branchy loader makes hipcc wait for every load before the next branch -- nothing pipelines)
-  template <class RowMap>
-  __device__ __forceinline__ void load_fast(const float* __restrict__ p, long ld, int k0, RowMap rowmap) {
+  // fast path: whole tile in range and 16-byte aligned -> straight-line loads, block-uniform row bases
+  // (SGPR) + one 32-bit per-thread offset.  (A branchy loader makes hipcc wait for every load before
+  // the next branch: nothing pipelines.)
+  template <class RowU>
+  __device__ __forceinline__ void load_fast(const float* __restrict__ p, long ld, int k0, RowU rowu) {
     const int tid = threadIdx.x;
-    const int vr = tid % VPR, r0 = tid / VPR;
-    const float* base = p + k0 + vr * 4;
+    const unsigned toff = (unsigned)((tid / CPR) * ld + (tid % CPR) * CT::CH);
 #pragma unroll
-    for (int i = 0; i < NP; i++) {
-      int r = r0 + i * RPP;
-      if (ROWS % RPP != 0 && r >= ROWS) r = ROWS - 1;       // tail threads re-read the last row (never stored)
-      v[i] = *reinterpret_cast<const float4*>(base + rowmap(r) * ld);
-    }
+    for (int i = 0; i < NP; i++) v[i].load16(p + rowu(i * RPP) * ld + k0 + toff);
   }
   __device__ __forceinline__ void store(typename CT::T* s) const {
     const int tid = threadIdx.x;
-    const int vr = tid % VPR, r0 = tid / VPR;
+    const int c = tid % CPR, r0 = tid / CPR;
 #pragma unroll
-    for (int i = 0; i < NP; i++) {
-      const int r = r0 + i * RPP;
-      if (ROWS % RPP == 0 || r < ROWS) lds_store4<CT>(s + swz<CT>(r, vr * 4), v[i].x, v[i].y, v[i].z, v[i].w);
-    }
+    for (int i = 0; i < NP; i++) v[i].store(s + swz<CT>(r0 + i * RPP, c * CT::CH));
   }
 };
 
-// K-major source: element (r, k) at p[k*ld + r].  Work item = 4 k x 4 r register block.
+// K-major source: element (r, k) at p[k*ld + r].  Work item = CH k x 4 r register block -> four
+// 16-byte LDS chunks (rows r..r+3).  8 adjacent lanes cover 8 row groups (one 128-byte line per k row),
+// the next lanes walk the 8 k-chunks.
 template <class CT, int ROWS>
 struct StageKM {
   static constexpr int RG = ROWS / 4;                  // row groups
-  static constexpr int KQ = CT::BK / 4;                // k quads
-  static constexpr int ITEMS = RG * KQ;
+  static constexpr int ITEMS = RG * 8;                 // x 8 k-chunks
   static constexpr int NP = (ITEMS + NTHREADS - 1) / NTHREADS;
-  float4 v[NP][4];
-  // work item -> (row group, k quad): 8 adjacent lanes cover 8 row groups (one 128-byte line per k
-  // row), the next lanes walk the k quads
-  static __device__ __forceinline__ int wi_rg(int w) { return (w & 7) + 8 * (w / (8 * KQ)); }
-  static __device__ __forceinline__ int wi_kq(int w) { return (w >> 3) % KQ; }
+  static_assert(ITEMS % NTHREADS == 0 || NTHREADS % ITEMS == 0, "item count");
+  float4 v[NP][CT::CH];
+  // item w -> row group (w & 7) + 8 * (w / 64), k-chunk (w >> 3) & 7
+  static __device__ __forceinline__ int item() { return ITEMS < NTHREADS ? (int)(threadIdx.x % ITEMS) : (int)threadIdx.x; }
 
   __device__ __forceinline__ void load(const float* __restrict__ p, long ld, int k0, int kend, bool vec_ok, long row0, long nrows) {
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-      const int w = threadIdx.x + i * NTHREADS;
-      const int rg = wi_rg(w), kq = wi_kq(w);
+      const int w = item() + i * NTHREADS;
+      const int rg = (w & 7) + 8 * (w >> 6), kc = (w >> 3) & 7;
       const long r = row0 + rg * 4;
 #pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        const int k = k0 + kq * 4 + kk;
+      for (int kk = 0; kk < CT::CH; kk++) {
+        const int k = k0 + kc * CT::CH + kk;
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((ITEMS % NTHREADS == 0 || w < ITEMS) && k < kend) {
+        if (k < kend) {
           const float* q = p + (long)k * ld + r;
-          if (vec_ok && r + 3 < nrows) {
-            x = *reinterpret_cast<const float4*>(q);
-          } else {
+          if (vec_ok && r + 3 < nrows) x = *reinterpret_cast<const float4*>(q);
+          else {
             if (r + 0 < nrows) x.x = q[0];
             if (r + 1 < nrows) x.y = q[1];
             if (r + 2 < nrows) x.z = q[2];
@@ -165,25 +169,27 @@ struct StageKM {
     }
   }
   __device__ __forceinline__ void load_fast(const float* __restrict__ p, long ld, int k0, long row0) {
+    const int w0 = item();
+    const unsigned toff = (unsigned)((((w0 >> 3) & 7) * CT::CH) * ld + ((w0 & 7) + 8 * (w0 >> 6)) * 4);
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-      int w = threadIdx.x + i * NTHREADS;
-      if (ITEMS % NTHREADS != 0 && w >= ITEMS) w = ITEMS - 1;
-      const float* q = p + (long)(k0 + wi_kq(w) * 4) * ld + row0 + wi_rg(w) * 4;
+      const float* ub = p + (long)k0 * ld + row0 + i * (NTHREADS / 64) * 8 * 4;      // block-uniform
 #pragma unroll
-      for (int kk = 0; kk < 4; kk++) v[i][kk] = *reinterpret_cast<const float4*>(q + kk * ld);
+      for (int kk = 0; kk < CT::CH; kk++) v[i][kk] = *reinterpret_cast<const float4*>(ub + kk * ld + toff);
     }
   }
   __device__ __forceinline__ void store(typename CT::T* s) const {
+    if (ITEMS < NTHREADS && threadIdx.x >= ITEMS) return;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-      const int w = threadIdx.x + i * NTHREADS;
-      if (ITEMS % NTHREADS == 0 || w < ITEMS) {
-        const int rg = wi_rg(w), kq = wi_kq(w);
-        lds_store4<CT>(s + swz<CT>(rg * 4 + 0, kq * 4), v[i][0].x, v[i][1].x, v[i][2].x, v[i][3].x);
-        lds_store4<CT>(s + swz<CT>(rg * 4 + 1, kq * 4), v[i][0].y, v[i][1].y, v[i][2].y, v[i][3].y);
-        lds_store4<CT>(s + swz<CT>(rg * 4 + 2, kq * 4), v[i][0].z, v[i][1].z, v[i][2].z, v[i][3].z);
-        lds_store4<CT>(s + swz<CT>(rg * 4 + 3, kq * 4), v[i][0].w, v[i][1].w, v[i][2].w, v[i][3].w);
+      const int w = item() + i * NTHREADS;
+      const int rg = (w & 7) + 8 * (w >> 6), kc = (w >> 3) & 7;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        Chunk<CT> c;
+#pragma unroll
+        for (int kk = 0; kk < CT::CH; kk++) c.at(kk) = (&v[i][kk].x)[j];
+        c.store(s + swz<CT>(rg * 4 + j, kc * CT::CH));
       }
     }
   }
@@ -286,8 +292,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
 
   const bool fullA = vecA && (m_blk + BM <= g.M);          // block-uniform: rows of the tile all valid
   const bool fullB = vecB && (n_blk + BN <= g.N);
-  auto rowfastA = [&](int r) -> long { return m_blk + r; };
+  auto rowfastA = [&](int r) -> long { return m_blk + r; };                  // r = i*RPP: block-uniform
   auto rowfastB = [&](int r) -> long { return (long)(r / BN) * g.gate_stride + n_blk + (r % BN); };
+  static_assert(BN % 32 == 0 && BM % 32 == 0, "row passes must not straddle a gate block");
   auto load_tiles = [&](int k0) {
     const bool kfull = k0 + CT::BK <= kend;
     if (fullA && kfull) {

@@ -99,6 +99,45 @@ def gru_bwd(prec, hall, gates, w_hh, *, dh_ext=None, dh_last=None, lr=None, reve
     return dgi, dgh, dh0
 
 
+# ---------------------------------------------------------------------------------------------
+# HIP-stream fork/join: independent kernel chains (the two directions of a bi-GRU, the two encoders,
+# weight-gradient products vs. the BPTT chain) run on sibling streams so the small, latency-bound
+# step kernels overlap with the big GEMMs.  Streams are cached per (parent stream, slot).
+# ---------------------------------------------------------------------------------------------
+_CHILD_STREAMS = {}
+OVERLAP = True              # set False to serialise everything on the caller's stream (debugging)
+
+
+class Side:
+    """s = Side(slot); s(fn, *keep_alive) runs fn on the sibling stream after everything enqueued so far
+    on the parent; s.join() makes the parent wait for it.  `keep_alive` tensors stay referenced until
+    join so the caching allocator cannot hand their memory to later parent-stream work."""
+
+    def __init__(self, slot=0):
+        self.main = torch.cuda.current_stream()
+        key = (self.main.cuda_stream, self.main.device.index, slot)
+        if key not in _CHILD_STREAMS:
+            _CHILD_STREAMS[key] = torch.cuda.Stream(device=self.main.device)
+        self.s = _CHILD_STREAMS[key]
+        self.keep = []
+        self.used = False
+
+    def __call__(self, fn, *keep):
+        if not OVERLAP:
+            return fn()
+        self.s.wait_stream(self.main)
+        self.used = True
+        self.keep.extend(keep)
+        with torch.cuda.stream(self.s):
+            return fn()
+
+    def join(self):
+        if self.used:
+            self.main.wait_stream(self.s)
+        self.keep.clear()
+        self.used = False
+
+
 def _gbuf(p):
     """zero-initialised gradient buffer for parameter p (weight-gradient kernels accumulate into it):
     a view of the optimiser's flat gradient bucket when one is registered (optim.GradArena)."""
@@ -185,14 +224,15 @@ class EmbedFn(torch.autograd.Function):
 # =============================================================================================
 def _bigru_forward(prec, x3, lengths, w):
     """x3 [T,M,I] step-major.  w = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r).
-    Returns out [M,2H] and the saved state for backward."""
+    Returns out [M,2H] and the saved state for backward.  The two directions are independent
+    chains: the reverse one runs on a sibling stream."""
     T, M, I = x3.shape
     H = w[1].shape[1]
     dev = x3.device
     xf = x3.reshape(T * M, I)
-    saved = []
     out = _empty(M, 2 * H, dev=dev)
-    for d in range(2):
+
+    def direction(d):
         w_ih, w_hh, b_ih, b_hh = w[4 * d: 4 * d + 4]
         gi = gemm(xf, w_ih, bias=b_ih, prec=prec)                      # [T*M, 3H]
         hall = _empty(T + 1, M, H, dev=dev)
@@ -200,17 +240,21 @@ def _bigru_forward(prec, x3, lengths, w):
         gates = _empty(T, 4, M, H, dev=dev)
         gru_fwd(prec, gi, M * 3 * H, 3 * H, w_hh, b_hh, hall, gates, lengths=lengths, reverse=bool(d))
         copy2d(out[:, d * H:(d + 1) * H], hall[T])
-        saved.append((hall, gates))
-    return out, saved
+        return hall, gates, gi
+
+    side = Side(7)
+    rev = side(lambda: direction(1), xf, out)
+    fwd = direction(0)
+    side.join()
+    return out, [fwd[:2], rev[:2]]
 
 
 def _bigru_backward(prec, x3, w, saved, dout, need_dx):
     T, M, I = x3.shape
     H = w[1].shape[1]
     xf = x3.reshape(T * M, I)
-    grads = []
-    dx = None
-    for d in range(2):
+
+    def direction(d):
         w_ih, w_hh, b_ih, b_hh = w[4 * d: 4 * d + 4]
         hall, gates = saved[d]
         dgi, dgh, _ = gru_bwd(prec, hall, gates, w_hh, dh_last=dout[:, d * H:(d + 1) * H], reverse=bool(d),
@@ -220,13 +264,16 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
         dw_hh = gemm(dgh2, hall[:T].view(T * M, H), _gbuf(w_hh), ta=True, tb=True, acc=True, prec=prec)
         db_ih = _bgrad(b_ih, dgi2)
         db_hh = _bgrad(b_hh, dgh2)
-        grads += [dw_ih, dw_hh, db_ih, db_hh]
-        if need_dx:
-            if dx is None:
-                dx = gemm(dgi2, w_ih, tb=True, prec=prec)
-            else:
-                gemm(dgi2, w_ih, dx, tb=True, acc=True, prec=prec)
-    return grads, (dx.view(T, M, I) if dx is not None else None)
+        dx = gemm(dgi2, w_ih, tb=True, prec=prec) if need_dx else None
+        return [dw_ih, dw_hh, db_ih, db_hh], dx
+
+    side = Side(7)
+    g1, dx1 = side(lambda: direction(1), xf, dout)
+    g0, dx0 = direction(0)
+    side.join()
+    if need_dx:
+        copy2d(dx0, dx1, acc=True)
+    return g0 + g1, (dx0.view(T, M, I) if need_dx else None)
 
 
 class BiGruFinalFn(torch.autograd.Function):
@@ -451,6 +498,9 @@ class DecoderTFFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dpitch, ddur, _didx):
+        """BPTT chain (duration GRU -> heads -> notes GRU -> time GRU -> note-summary bi-GRU -> z) on the
+        caller's stream; every weight / bias gradient product is enqueued on a sibling stream as soon
+        as its operands exist, so the K-deep dW GEMMs overlap the latency-bound recurrent steps."""
         z, emb, *params = ctx.saved_tensors
         P = dict(zip(DEC_PARAM_NAMES, params))
         st = ctx.st
@@ -463,7 +513,17 @@ class DecoderTFFn(torch.autograd.Function):
         NSf = NS[1:].view(R, Ht)
         NSUM = HN[1:].view(M, Hn)
         emb3 = emb.view(16, R, E)
-        z1 = lambda n: _zeros(1, n, dev=dev)
+        side = Side(3)
+
+        def wgrad(name, dy, x, sub=None):
+            """G[name][:, sub] += dy^T . x"""
+            if G[name] is None:
+                G[name] = _gbuf(P[name])
+            out = G[name] if sub is None else G[name][:, sub]
+            gemm(dy, x, out, ta=True, tb=True, acc=True, prec=prec)
+
+        def bgrad(name, a):
+            G[name] = _bgrad(P[name], a)
 
         ddur = (ddur.contiguous() if ddur is not None else _zeros(M, 5, 2, dev=dev)).view(M, 10)
         dP = _empty(M, NP, dev=dev)
@@ -474,86 +534,88 @@ class DecoderTFFn(torch.autograd.Function):
 
         # ---- duration GRU (5 steps) ----
         w_out = P['dur_out_linear.weight']
-        w_hh_d = P['dec_dur_gru.weight_hh_l0']
+        w_hh_d, w_ih_d = P['dec_dur_gru.weight_hh_l0'], P['dec_dur_gru.weight_ih_l0']
         dgi_d, dgh_d, dHD0 = gru_bwd(prec, HD, st['gates_d'], w_hh_d, lr=(ddur, 2, 10, 2, w_out))
-        g = _gbuf(w_out)
-        for d in range(5):
-            gemm(ddur[:, 2 * d:2 * d + 2], HD[d + 1], g, ta=True, tb=True, acc=True, prec=prec)
-        G['dur_out_linear.weight'] = g
-        G['dur_out_linear.bias'] = _bgrad(P['dur_out_linear.bias'], ddur.view(M * 5, 2))
-        G['dec_dur_gru.weight_hh_l0'] = gemm(dgh_d.view(5 * M, 3 * Hd), HD[:5].view(5 * M, Hd), _gbuf(w_hh_d), ta=True,
-                                             tb=True, acc=True, prec=prec)
-        G['dec_dur_gru.bias_hh_l0'] = _bgrad(P['dec_dur_gru.bias_hh_l0'], dgh_d.view(5 * M, 3 * Hd))
-        G['dec_dur_gru.bias_ih_l0'] = _bgrad(P['dec_dur_gru.bias_ih_l0'], dgi_d.view(5 * M, 3 * Hd))
-        w_ih_d = P['dec_dur_gru.weight_ih_l0']
-        cs0 = colsum(z1(3 * Hd), dgi_d[0])                                       # step 0: dense <sos> token
-        g = gemm(cs0, P['dur_sos_token'].view(1, -1), _gbuf(w_ih_d), ta=True, tb=True, acc=True, prec=0, splitk=-1)
-        G['dur_sos_token'] = _gbuf(P['dur_sos_token'])
-        gemm(cs0, w_ih_d, G['dur_sos_token'].view(1, -1), tb=True, prec=0, splitk=-1)
-        sel = _zeros(2, 3 * Hd, dev=dev)                                         # steps 1..4: one-hot tokens {0,1}
-        for d in range(1, 5):
-            colsum(sel, dgi_d[d], sel=st['idx'][d - 1], groups=2)
-        gemm(sel, _eye2(dev), g[:, 0:2], ta=True, acc=True, prec=0, splitk=-1)
-        G['dec_dur_gru.weight_ih_l0'] = g
-        del dgi_d, dgh_d
+
+        def dur_wgrads():
+            for d in range(5):
+                wgrad('dur_out_linear.weight', ddur[:, 2 * d:2 * d + 2], HD[d + 1])
+            bgrad('dur_out_linear.bias', ddur.view(M * 5, 2))
+            wgrad('dec_dur_gru.weight_hh_l0', dgh_d.view(5 * M, 3 * Hd), HD[:5].view(5 * M, Hd))
+            bgrad('dec_dur_gru.bias_hh_l0', dgh_d.view(5 * M, 3 * Hd))
+            bgrad('dec_dur_gru.bias_ih_l0', dgi_d.view(5 * M, 3 * Hd))
+            cs0 = colsum(_zeros(1, 3 * Hd, dev=dev), dgi_d[0])                   # step 0: dense <sos> token
+            g = _gbuf(w_ih_d)
+            gemm(cs0, P['dur_sos_token'].view(1, -1), g, ta=True, tb=True, acc=True, prec=0, splitk=-1)
+            G['dur_sos_token'] = _gbuf(P['dur_sos_token'])
+            gemm(cs0, w_ih_d, G['dur_sos_token'].view(1, -1), tb=True, prec=0, splitk=-1)
+            sel = _zeros(2, 3 * Hd, dev=dev)                                     # steps 1..4: one-hot tokens {0,1}
+            for d in range(1, 5):
+                colsum(sel, dgi_d[d], sel=st['idx'][d - 1], groups=2)
+            gemm(sel, _eye2(dev), g[:, 0:2], ta=True, acc=True, prec=0, splitk=-1)
+            G['dec_dur_gru.weight_ih_l0'] = g
+        side(dur_wgrads, ddur, dgi_d, dgh_d)
 
         # ---- dur_hid_linear([note_summary | est_pitch]) and pitch_out_linear ----
-        w_dh = P['dur_hid_linear.weight']
+        w_dh, w_p = P['dur_hid_linear.weight'], P['pitch_out_linear.weight']
         dNSUM = gemm(dHD0, w_dh[:, :Hn], tb=True, prec=prec)                      # [M, Hn]
         gemm(dHD0, w_dh[:, Hn:], dP, tb=True, acc=True, prec=prec)
-        g = _gbuf(w_dh)
-        gemm(dHD0, NSUM, g[:, :Hn], ta=True, tb=True, acc=True, prec=prec)
-        gemm(dHD0, st['pitch'], g[:, Hn:], ta=True, tb=True, acc=True, prec=prec)
-        G['dur_hid_linear.weight'] = g
-        G['dur_hid_linear.bias'] = _bgrad(P['dur_hid_linear.bias'], dHD0)
-        w_p = P['pitch_out_linear.weight']
         gemm(dP, w_p, dNSUM, tb=True, acc=True, prec=prec)
-        G['pitch_out_linear.weight'] = gemm(dP, NSUM, _gbuf(w_p), ta=True, tb=True, acc=True, prec=prec)
-        G['pitch_out_linear.bias'] = _bgrad(P['pitch_out_linear.bias'], dP)
-        del dP, dHD0
+
+        def head_wgrads():
+            wgrad('dur_hid_linear.weight', dHD0, NSUM, slice(0, Hn))
+            wgrad('dur_hid_linear.weight', dHD0, st['pitch'], slice(Hn, None))
+            bgrad('dur_hid_linear.bias', dHD0)
+            wgrad('pitch_out_linear.weight', dP, NSUM)
+            bgrad('pitch_out_linear.bias', dP)
+        side(head_wgrads, dHD0, dP)
 
         # ---- notes GRU (15 steps, batch 32*B) ----
         w_hh_n, w_ih_n = P['dec_notes_gru.weight_hh_l0'], P['dec_notes_gru.weight_ih_l0']
         dgi_n, dgh_n, dHN0 = gru_bwd(prec, HN, st['gates_n'], w_hh_n, dh_ext=dNSUM.view(15, R, Hn))
-        G['dec_notes_gru.weight_hh_l0'] = gemm(dgh_n.view(M, 3 * Hn), HN[:15].view(M, Hn), _gbuf(w_hh_n), ta=True, tb=True,
-                                               acc=True, prec=prec)
-        G['dec_notes_gru.bias_hh_l0'] = _bgrad(P['dec_notes_gru.bias_hh_l0'], dgh_n.view(M, 3 * Hn))
-        del dgh_n, dNSUM
         dGC = sum_steps(dgi_n)                                                    # [R, 3Hn]
-        G['dec_notes_gru.bias_ih_l0'] = _bgrad(P['dec_notes_gru.bias_ih_l0'], dGC)
-        g = _gbuf(w_ih_n)
-        gemm(dGC, NSf, g[:, :Ht], ta=True, tb=True, acc=True, prec=prec)
-        gemm(dgi_n.view(M, 3 * Hn), emb3[:15].view(M, E), g[:, Ht:], ta=True, tb=True, acc=True, prec=prec)
-        G['dec_notes_gru.weight_ih_l0'] = g
         demb = _empty(16, R, E, dev=dev)
         demb[15].zero_()
         gemm(dgi_n.view(M, 3 * Hn), w_ih_n[:, Ht:], demb[:15].view(M, E), tb=True, prec=prec)
         dNS = gemm(dGC, w_ih_n[:, :Ht], tb=True, prec=prec)                       # [R, Ht]
-        del dgi_n, dGC
         w_tn = P['dec_time_to_notes_hid.weight']
         gemm(dHN0, w_tn, dNS, tb=True, acc=True, prec=prec)
-        G['dec_time_to_notes_hid.weight'] = gemm(dHN0, NSf, _gbuf(w_tn), ta=True, tb=True, acc=True, prec=prec)
-        G['dec_time_to_notes_hid.bias'] = _bgrad(P['dec_time_to_notes_hid.bias'], dHN0)
+
+        def notes_wgrads():
+            wgrad('dec_notes_gru.weight_hh_l0', dgh_n.view(M, 3 * Hn), HN[:15].view(M, Hn))
+            bgrad('dec_notes_gru.bias_hh_l0', dgh_n.view(M, 3 * Hn))
+            bgrad('dec_notes_gru.bias_ih_l0', dGC)
+            wgrad('dec_notes_gru.weight_ih_l0', dGC, NSf, slice(0, Ht))
+            wgrad('dec_notes_gru.weight_ih_l0', dgi_n.view(M, 3 * Hn), emb3[:15].view(M, E), slice(Ht, None))
+            wgrad('dec_time_to_notes_hid.weight', dHN0, NSf)
+            bgrad('dec_time_to_notes_hid.bias', dHN0)
+        side(notes_wgrads, dgi_n, dgh_n, dGC, dHN0, dNSUM)
 
         # ---- time GRU (32 steps, batch B) ----
         w_hh_t, w_ih_t = P['dec_time_gru.weight_hh_l0'], P['dec_time_gru.weight_ih_l0']
         dgi_t, dgh_t, dzhid = gru_bwd(prec, NS, st['gates_t'], w_hh_t, dh_ext=dNS.view(32, B, Ht))
-        G['dec_time_gru.weight_hh_l0'] = gemm(dgh_t.view(R, 3 * Ht), NS[:32].view(R, Ht), _gbuf(w_hh_t), ta=True, tb=True,
-                                              acc=True, prec=prec)
-        G['dec_time_gru.bias_hh_l0'] = _bgrad(P['dec_time_gru.bias_hh_l0'], dgh_t.view(R, 3 * Ht))
         dZG = sum_steps(dgi_t)                                                    # [B, 3Ht]
-        G['dec_time_gru.bias_ih_l0'] = _bgrad(P['dec_time_gru.bias_ih_l0'], dZG)
-        g = _gbuf(w_ih_t)
-        gemm(dZG, st['z_in'], g[:, 2 * He:], ta=True, tb=True, acc=True, prec=prec)
-        gemm(dgi_t.view(R, 3 * Ht), TOKS[:32].view(R, 2 * He), g[:, :2 * He], ta=True, tb=True, acc=True, prec=prec)
-        G['dec_time_gru.weight_ih_l0'] = g
         dz_in = gemm(dZG, w_ih_t[:, 2 * He:], tb=True, prec=prec)                 # [B, Zi]
         dTOKS = _empty(33, B, 2 * He, dev=dev)
         dTOKS[32].zero_()
         gemm(dgi_t.view(R, 3 * Ht), w_ih_t[:, :2 * He], dTOKS[:32].view(R, 2 * He), tb=True, prec=prec)
-        G['dec_init_input'] = _bgrad(P['dec_init_input'], dTOKS[0])
         dxs = dTOKS[1:].view(R, 2 * He)
-        del dgi_t, dgh_t
+        w_zh, w_zi = P['z2dec_hid_linear.weight'], P['z2dec_in_linear.weight']
+        dz = gemm(dzhid, w_zh, tb=True, prec=prec)
+        gemm(dz_in, w_zi, dz, tb=True, acc=True, prec=prec)
+
+        def time_wgrads():
+            wgrad('dec_time_gru.weight_hh_l0', dgh_t.view(R, 3 * Ht), NS[:32].view(R, Ht))
+            bgrad('dec_time_gru.bias_hh_l0', dgh_t.view(R, 3 * Ht))
+            bgrad('dec_time_gru.bias_ih_l0', dZG)
+            wgrad('dec_time_gru.weight_ih_l0', dZG, st['z_in'], slice(2 * He, None))
+            wgrad('dec_time_gru.weight_ih_l0', dgi_t.view(R, 3 * Ht), TOKS[:32].view(R, 2 * He), slice(0, 2 * He))
+            bgrad('dec_init_input', dTOKS[0])
+            wgrad('z2dec_hid_linear.weight', dzhid, z)
+            bgrad('z2dec_hid_linear.bias', dzhid)
+            wgrad('z2dec_in_linear.weight', dz_in, z)
+            bgrad('z2dec_in_linear.bias', dz_in)
+        side(time_wgrads, dgi_t, dgh_t, dZG, dTOKS, dzhid, dz_in, dNS)
 
         # ---- ground-truth summaries: bi-GRU over embedded notes ----
         w_emb_names = ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0', 'weight_ih_l0_reverse',
@@ -564,15 +626,7 @@ class DecoderTFFn(torch.autograd.Function):
             G['dec_notes_emb_gru.' + n] = gg
         copy2d(demb.view(16 * R, E), dx_emb.view(16 * R, E), acc=True)
 
-        # ---- z linears ----
-        w_zh, w_zi = P['z2dec_hid_linear.weight'], P['z2dec_in_linear.weight']
-        dz = gemm(dzhid, w_zh, tb=True, prec=prec)
-        gemm(dz_in, w_zi, dz, tb=True, acc=True, prec=prec)
-        G['z2dec_hid_linear.weight'] = gemm(dzhid, z, _gbuf(w_zh), ta=True, tb=True, acc=True, prec=prec)
-        G['z2dec_hid_linear.bias'] = _bgrad(P['z2dec_hid_linear.bias'], dzhid)
-        G['z2dec_in_linear.weight'] = gemm(dz_in, z, _gbuf(w_zi), ta=True, tb=True, acc=True, prec=prec)
-        G['z2dec_in_linear.bias'] = _bgrad(P['z2dec_in_linear.bias'], dz_in)
-
+        side.join()
         return (dz, demb.view(16, 32, B, E), None, None, None) + tuple(G[n] for n in DEC_PARAM_NAMES)
 
 

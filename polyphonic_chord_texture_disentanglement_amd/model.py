@@ -42,8 +42,13 @@ class DisentangleVAE(PytorchModel):
     # ---- model.py:42-55
     def run(self, x, c, pr_mat, tfr1, tfr2, tfr3, confuse=True):
         embedded_x, lengths = self.decoder.emb_x(x)
-        dist_chd = self.chd_encoder(c)
-        dist_rhy = self.rhy_encoder(pr_mat)
+        # the two encoders are independent of each other and of the embedding: sibling HIP streams
+        # (autograd replays each branch's backward on the stream its forward ran on)
+        s_chd, s_rhy = F_.Side(1), F_.Side(2)
+        dist_chd = s_chd(lambda: self.chd_encoder(c), c)
+        dist_rhy = s_rhy(lambda: self.rhy_encoder(pr_mat), pr_mat)
+        s_chd.join()
+        s_rhy.join()
         z_chd = self._rsample('chd', dist_chd)           # chd first, then rhy (train_utils.py:33-34)
         z_rhy = self._rsample('rhy', dist_rhy)
         dec_z = torch.cat([z_chd, z_rhy], dim=-1)
