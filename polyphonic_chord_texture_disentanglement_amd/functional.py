@@ -412,11 +412,12 @@ def _eye2(dev):
 
 
 class DecoderTFFn(torch.autograd.Function):
-    """(z [B,Zs], emb step-major [16,32,B,E], lengths int32 [32B], force_dur_idx or None, *params)
-    -> pitch logits step-major [15,32,B,130], dur logits [15*32*B, 5, 2]"""
+    """(z [B,Zs], emb step-major [16,32,B,E], xs [32B, 2He] ground-truth note summaries (BiGruFinalFn over
+    emb, ptvae.py:446-453), force_dur_idx or None, *params)
+    -> pitch logits step-major [15,32,B,130], dur logits [15*32*B, 5, 2], dur argmax indices"""
 
     @staticmethod
-    def forward(ctx, z, emb, lengths, force_dur, prec, *params):
+    def forward(ctx, z, emb, xs, force_dur, prec, *params):
         P = dict(zip(DEC_PARAM_NAMES, params))
         dev = z.device
         z = z.contiguous()
@@ -435,12 +436,8 @@ class DecoderTFFn(torch.autograd.Function):
         gemm(z, P['z2dec_hid_linear.weight'], NS[0], bias=P['z2dec_hid_linear.bias'], prec=prec)
         z_in = gemm(z, P['z2dec_in_linear.weight'], bias=P['z2dec_in_linear.bias'], prec=prec)
 
-        # --- ground-truth note summaries: packed bi-GRU final states (ptvae.py:446-453)
         emb3 = emb.view(16, R, E)
-        w_emb = [P['dec_notes_emb_gru.' + n] for n in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0',
-                                                        'weight_ih_l0_reverse', 'weight_hh_l0_reverse',
-                                                        'bias_ih_l0_reverse', 'bias_hh_l0_reverse')]
-        xs, emb_saved = _bigru_forward(prec, emb3, lengths, w_emb)             # [R, 2He], rows (t, b)
+        xs = xs.contiguous()
 
         # --- time GRU inputs: token_t = [init ; xs[t-1]], z_in broadcast over t  (ptvae.py:457-462,476-478)
         TOKS = _empty(33, B, 2 * He, dev=dev)
@@ -490,9 +487,8 @@ class DecoderTFFn(torch.autograd.Function):
                  stream_ptr())
 
         S.save_for_backward(z, emb, *params)
-        S.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in, emb_saved=emb_saved,
-                    TOKS=TOKS, gates_t=gates_t, HN=HN, gates_n=gates_n, pitch=pitch, HD=HD, gates_d=gates_d, idx=idx,
-                    lengths=lengths)
+        S.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in,
+                    TOKS=TOKS, gates_t=gates_t, HN=HN, gates_n=gates_n, pitch=pitch, HD=HD, gates_d=gates_d, idx=idx)
         S.mark_non_differentiable(idx)
         return pitch.view(15, 32, B, NP), dur, idx
 
@@ -617,17 +613,8 @@ class DecoderTFFn(torch.autograd.Function):
             bgrad('z2dec_in_linear.bias', dz_in)
         side(time_wgrads, dgi_t, dgh_t, dZG, dTOKS, dzhid, dz_in, dNS)
 
-        # ---- ground-truth summaries: bi-GRU over embedded notes ----
-        w_emb_names = ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0', 'weight_ih_l0_reverse',
-                       'weight_hh_l0_reverse', 'bias_ih_l0_reverse', 'bias_hh_l0_reverse')
-        w_emb = [P['dec_notes_emb_gru.' + n] for n in w_emb_names]
-        ge, dx_emb = _bigru_backward(prec, emb3, w_emb, st['emb_saved'], dxs, True)
-        for n, gg in zip(w_emb_names, ge):
-            G['dec_notes_emb_gru.' + n] = gg
-        copy2d(demb.view(16 * R, E), dx_emb.view(16 * R, E), acc=True)
-
         side.join()
-        return (dz, demb.view(16, 32, B, E), None, None, None) + tuple(G[n] for n in DEC_PARAM_NAMES)
+        return (dz, demb.view(16, 32, B, E), dxs, None, None) + tuple(G[n] for n in DEC_PARAM_NAMES)
 
 
 # =============================================================================================

@@ -52,8 +52,16 @@ class DisentangleVAE(PytorchModel):
         z_chd = self._rsample('chd', dist_chd)           # chd first, then rhy (train_utils.py:33-34)
         z_rhy = self._rsample('rhy', dist_rhy)
         dec_z = torch.cat([z_chd, z_rhy], dim=-1)
-        pitch_outs, dur_outs = self.decoder(dec_z, False, embedded_x, lengths, tfr1, tfr2)
-        recon_root, recon_chroma, recon_bass = self.chd_decoder(z_chd, False, tfr3, c)
+        # chord decoder (8 small steps) rides a sibling stream next to the PianoTree decoder.  Its coin
+        # flips come AFTER the decoder's in the reference's draw order: draw them first
+        # on the host in that order, then enqueue.
+        dec_coins = self.decoder.draw_coins(tfr1, tfr2)
+        chd_coins = self.chd_decoder.draw_coins(tfr3)
+        s_cd = F_.Side(4)
+        recon_root, recon_chroma, recon_bass = s_cd(
+            lambda: self.chd_decoder(z_chd, False, tfr3, c, coins=chd_coins), z_chd, c)
+        pitch_outs, dur_outs = self.decoder(dec_z, False, embedded_x, lengths, tfr1, tfr2, coins=dec_coins)
+        s_cd.join()
         return pitch_outs, dur_outs, dist_chd, dist_rhy, recon_root, recon_chroma, recon_bass
 
     # ---- model.py:57-68: one fused loss node (CE with ignore_index x2, KL x2, chord CE x3)

@@ -176,13 +176,18 @@ class RnnDecoder(nn.Module, _PrecMixin):
         sd = dict(self.named_parameters())
         return [sd[n] for n in F_.CHD_PARAM_NAMES]
 
-    def forward(self, z_chd, inference, tfr, c=None):
+    def draw_coins(self, tfr):
+        """one teacher-forcing coin per chord step for the whole batch (ptvae.py:81; the `break` at :79
+        never fires, so 8 draws)"""
+        return [random.random() < tfr for _ in range(int(self.num_step / 4))]
+
+    def forward(self, z_chd, inference, tfr, c=None, coins=None):
         _require_cuda(z_chd, 'RnnDecoder')
         T = int(self.num_step / 4)
         if inference:
             tfr = 0.
-        # the reference draws one coin per step for the whole batch (ptvae.py:81); keep the stream aligned
-        coins = [random.random() < tfr for _ in range(T)]
+        if coins is None:
+            coins = self.draw_coins(tfr)
         if all(coins) and not inference:
             c_sm = F_.Transpose01Fn.apply(c.float())
             root, chroma, bass = F_.ChordDecoderTFFn.apply(z_chd, c_sm.detach(), self._prec, *self._params())
@@ -229,6 +234,7 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
         self.dur_hid_linear = Linear(self.pitch_range + dec_notes_hid_size, dec_dur_hid_size)
         self.dur_out_linear = Linear(dec_dur_hid_size, 2)
         self.force_dur_idx = None          # [5, 480*B] int32: replay the oracle's duration argmaxes (tests)
+        self._summary = None
         self.last_dur_idx = None
 
     def _params(self):
@@ -242,21 +248,37 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
         so handing them back to `decoder()` costs no transpose (134 MB each way at B=512)."""
         _require_cuda(x, 'PtvaeDecoder.emb_x')
         emb, lengths = F_.EmbedFn.apply(x.long(), self.note_embedding.weight, self.note_embedding.bias)
+        # The ground-truth note summaries (packed bi-GRU over the embedded notes, ptvae.py:446-453) depend
+        # on the embedding only: start them now on a sibling stream so they overlap the encoders;
+        # decoder() picks the result up.
+        side = F_.Side(5)
+        xs = side(lambda: self._summarize(emb, lengths), emb, lengths)
+        self._summary = (emb, xs, side)
         return emb.permute(2, 1, 0, 3), lengths.view(32, x.size(0)).t()
 
-    def decoder(self, z, inference, x, lengths, teacher_forcing_ratio1, teacher_forcing_ratio2):
+    def _summarize(self, emb, len32):
+        n, t, b, e = emb.shape
+        return F_.BiGruFinalFn.apply(emb.view(n, t * b, e), len32, self._prec, *self.dec_notes_emb_gru.weights())
+
+    def draw_coins(self, tfr1, tfr2):
+        """Teacher-forcing decisions in the reference's draw order (ptvae.py:420,476): per time step 14
+        note-level coins (tfr2), then one time-level coin (tfr1) for t < 31 -> (notes [32][14], time [31])."""
+        notes, time = [], []
+        for t in range(self.num_step):
+            notes.append([random.random() < tfr2 for _ in range(self.max_simu_note - 2)])
+            if t < self.num_step - 1:
+                time.append(random.random() < tfr1)
+        return notes, time
+
+    def decoder(self, z, inference, x, lengths, teacher_forcing_ratio1, teacher_forcing_ratio2, coins=None):
         _require_cuda(z, 'PtvaeDecoder')
         if inference:
             assert x is None and lengths is None
             assert teacher_forcing_ratio1 == 0 and teacher_forcing_ratio2 == 0
             raise NotImplementedError('free-running decode lands with the step-loop path')
-        # the reference draws 14 coins (tfr2) per time step then one (tfr1) for t < 31  (ptvae.py:420,476)
-        all_tf = True
-        for t in range(self.num_step):
-            for _ in range(self.max_simu_note - 2):
-                all_tf &= random.random() < teacher_forcing_ratio2
-            if t < self.num_step - 1:
-                all_tf &= random.random() < teacher_forcing_ratio1
+        if coins is None:
+            coins = self.draw_coins(teacher_forcing_ratio1, teacher_forcing_ratio2)
+        all_tf = all(all(r) for r in coins[0]) and all(coins[1])
         if not all_tf:
             raise NotImplementedError('scheduled-sampling / free-running training lands with the step-loop path')
         B = z.size(0)
@@ -266,13 +288,20 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
             emb = F_.Transpose01Fn.apply(x.transpose(1, 2).reshape(B, 16 * 32, E)).view(16, 32, B, E)
         len32 = lengths.t()
         len32 = (len32 if (len32.is_contiguous() and len32.dtype == torch.int32) else len32.contiguous().int()).reshape(-1)
-        pitch, dur, idx = F_.DecoderTFFn.apply(z, emb, len32, self.force_dur_idx, self._prec, *self._params())
+        cached = getattr(self, '_summary', None)
+        self._summary = None
+        if cached is not None and cached[0].data_ptr() == emb.data_ptr() and cached[0].shape == emb.shape:
+            xs = cached[1]
+            cached[2].join()
+        else:
+            xs = self._summarize(emb, len32)
+        pitch, dur, idx = F_.DecoderTFFn.apply(z, emb, xs, self.force_dur_idx, self._prec, *self._params())
         self.last_dur_idx = idx
         # reference shapes [B,32,15,130] / [B,32,15,5,2] as permuted views of the step-major buffers
         return pitch.permute(2, 1, 0, 3), dur.view(15, 32, B, 5, 2).permute(2, 1, 0, 3, 4)
 
-    def forward(self, z, inference, x, lengths, teacher_forcing_ratio1, teacher_forcing_ratio2):
-        return self.decoder(z, inference, x, lengths, teacher_forcing_ratio1, teacher_forcing_ratio2)
+    def forward(self, z, inference, x, lengths, teacher_forcing_ratio1, teacher_forcing_ratio2, coins=None):
+        return self.decoder(z, inference, x, lengths, teacher_forcing_ratio1, teacher_forcing_ratio2, coins=coins)
 
     # ---- ptvae.py:498-529
     def recon_loss(self, x, recon_pitch, recon_dur, weights=(1, 0.5), weighted_dur=False):
