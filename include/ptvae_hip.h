@@ -98,10 +98,11 @@ int ptv_colsum(float* out, const float* A, long lda, long rows, int N, const int
  * Note embedding as a gather: PtvaeDecoder.emb_x (ptvae.py:531-535) = get_len_index_tensor
  * (ptvae.py:292-297) + index_tensor_to_multihot_tensor (ptvae.py:299-313) + note_embedding Linear.
  *   x [B,32,16,6] int64 -> emb STEP-MAJOR [16][32][B][E], lengths [32][B] int32 (lengths may be NULL)
- * bwd: dW[E,135] += demb^T . multihot, dbias[E] += colsum(demb)  (LDS-privatised, one atomic flush/block)
+ * bwd: ptv_multihot materialises the [16*32*B, 135] multi-hot matrix (same row order, row stride ld) so
+ *      that dW[E,135] = demb^T . multihot runs as a split-K ptv_gemm; dbias = ptv_colsum(demb).
  */
 int ptv_embed_fwd(const long* x, const float* W, const float* bias, float* emb, int* lengths, int B, int E, void* stream);
-int ptv_embed_bwd(const long* x, const float* demb, float* dW, float* dbias, int B, int E, void* stream);
+int ptv_multihot(const long* x, float* out, long ld, int B, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * TextureEncoder front end (ptvae.py:95-99,112-114): Conv2d(1,C,(4,12),stride(4,1)) + ReLU +

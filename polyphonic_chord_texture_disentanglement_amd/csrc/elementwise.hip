@@ -117,33 +117,18 @@ __global__ void lengths_kernel(const long* __restrict__ x, int* __restrict__ len
   lengths[i] = 16 - pad;
 }
 
-// dW[e, p] += sum_notes demb[note, e] * multihot[note, p];  dbias[e] += sum demb
-__global__ void embed_bwd_kernel(const long* __restrict__ x, const float* __restrict__ demb, float* __restrict__ dW,
-                                 float* __restrict__ dbias, int B, int E) {
-  extern __shared__ __attribute__((aligned(16))) float acc[];    // [136][E]: 135 columns + bias
-  for (int i = threadIdx.x; i < 136 * E; i += blockDim.x) acc[i] = 0.f;
-  __syncthreads();
+// multihot [16*32*B, 135] (row stride ld) in the embedding's step-major row order: the matrix the
+// reference multiplies by note_embedding.weight (ptvae.py:299-313).  Only the BACKWARD uses it here:
+// dW = demb^T . multihot is a K = 262144-deep product that belongs on the MFMA (split-K) path instead of
+// on atomics.
+__global__ void multihot_kernel(const long* __restrict__ x, float* __restrict__ out, long ld, int B) {
   const long notes = (long)B * 512;
-  const int per = blockDim.x / E > 0 ? blockDim.x / E : 1;
-  const int e = threadIdx.x % E, sub = threadIdx.x / E;
-  if (sub < per) {
-    for (long i = (long)blockIdx.x * per + sub; i < notes; i += (long)gridDim.x * per) {
-      const int b = (int)(i % B); const long q = i / B; const int t = (int)(q % 32), n = (int)(q / 32);
-      const long* xr = x + (((long)b * 32 + t) * 16 + n) * 6;
-      const float g = demb[i * E + e];
-      const int p = (int)xr[0];
-      if (p < 130) atomicAdd(&acc[p * E + e], g);
-#pragma unroll
-      for (int d = 0; d < 5; d++) { float dv = (float)xr[1 + d]; if (dv != 0.f) atomicAdd(&acc[(130 + d) * E + e], g * dv); }
-      atomicAdd(&acc[135 * E + e], g);
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 136 * E; i += blockDim.x) {
-    float v = acc[i];
-    if (v == 0.f) continue;
-    int ee = i % E, p = i / E;
-    if (p < 135) atomicAdd(dW + ee * 135 + p, v); else atomicAdd(dbias + ee, v);
+  for (long i = (long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); i < notes; i += (long)gridDim.x * (blockDim.x / 64)) {
+    const int b = (int)(i % B); const long q = i / B; const int t = (int)(q % 32), n = (int)(q / 32);
+    const long* xr = x + (((long)b * 32 + t) * 16 + n) * 6;
+    const int p = (int)xr[0];
+    float* o = out + i * ld;
+    for (int c = threadIdx.x & 63; c < 135; c += 64) o[c] = c < 130 ? (c == p ? 1.f : 0.f) : (float)xr[1 + c - 130];
   }
 }
 
@@ -232,9 +217,10 @@ extern "C" int ptv_embed_fwd(const long* x, const float* W, const float* bias, f
   return PTV_OK;
 }
 
-extern "C" int ptv_embed_bwd(const long* x, const float* demb, float* dW, float* dbias, int B, int E, void* stream) {
-  if (!x || !demb || !dW || !dbias || B <= 0 || E <= 0 || E > 256) return PTV_ERR_ARG;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((long)B * 512, 2 * 64, 512)), dim3(256), 136 * E * sizeof(float), (hipStream_t)stream, x, demb, dW, dbias, B, E);
+extern "C" int ptv_multihot(const long* x, float* out, long ld, int B, void* stream) {
+  if (!x || !out || B <= 0 || ld < 135) return PTV_ERR_ARG;
+  long nb = ((long)B * 512 + 3) / 4; if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(multihot_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, out, ld, B);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

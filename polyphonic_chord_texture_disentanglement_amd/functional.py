@@ -198,9 +198,10 @@ class EmbedFn(torch.autograd.Function):
     """x [B,32,16,6] int64 -> (emb step-major [16,32,B,E], lengths int32 [32*B])"""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, prec=0):
         B = x.shape[0]
         E = w.shape[0]
+        ctx.prec = prec
         x = x.contiguous()
         emb = _empty(16, 32, B, E, dev=w.device)
         lengths = torch.empty(32 * B, device=w.device, dtype=torch.int32)
@@ -213,10 +214,12 @@ class EmbedFn(torch.autograd.Function):
     def backward(ctx, demb, _dl):
         x, w, b = ctx.saved_tensors
         B, E = x.shape[0], w.shape[0]
-        dw = _gbuf(w)
-        db = _gbuf(b)
-        call('ptv_embed_bwd', ptr(x), ptr(demb.contiguous()), ptr(dw), ptr(db), B, E, stream_ptr())
-        return None, dw, db
+        demb2 = demb.contiguous().view(B * 512, E)
+        mh = _empty(B * 512, 136, dev=w.device)
+        call('ptv_multihot', ptr(x), ptr(mh), 136, B, stream_ptr())
+        dw = gemm(demb2, mh[:, :135], _gbuf(w), ta=True, tb=True, acc=True, prec=ctx.prec)
+        db = _bgrad(b, demb2)
+        return None, dw, db, None
 
 
 # =============================================================================================

@@ -247,7 +247,7 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
         them is the decoder's step-major layout ([16,32,B,E] / [32,B]) exposed through permuted views,
         so handing them back to `decoder()` costs no transpose (134 MB each way at B=512)."""
         _require_cuda(x, 'PtvaeDecoder.emb_x')
-        emb, lengths = F_.EmbedFn.apply(x.long(), self.note_embedding.weight, self.note_embedding.bias)
+        emb, lengths = F_.EmbedFn.apply(x.long(), self.note_embedding.weight, self.note_embedding.bias, self._prec)
         # The ground-truth note summaries (packed bi-GRU over the embedded notes, ptvae.py:446-453) depend
         # on the embedding only: start them now on a sibling stream so they overlap the encoders;
         # decoder() picks the result up.
