@@ -84,10 +84,27 @@ class DisentangleVAE(PytorchModel):
         kl_rhy = F_.KlFn.apply(dists[1].mean, dists[1].scale)
         return kl_chd + kl_rhy, kl_chd, kl_rhy
 
-    # ---- model.py:92-96
-    def loss(self, x, c, pr_mat, tfr1=0., tfr2=0., tfr3=0., beta=0.1, weights=(1, 0.5), *_ignored_extra):
-        outputs = self.run(x, c, pr_mat, tfr1, tfr2, tfr3)
-        return self.loss_function(x, c, *outputs, beta, weights)
+    # ---- model.py:92-96.  Same positional/keyword signature (x, c, pr_mat, tfr1=0., tfr2=0., tfr3=0.,
+    # beta=0.1, weights=(1, 0.5)); additionally a 4th positional TENSOR (the reference's unused `dt_x`,
+    # which makes its own trainer call fail -- SURVEY.md §0.2) is accepted and ignored.
+    def loss(self, x, c, pr_mat, *args, **kwargs):
+        args = list(args)
+        while args and torch.is_tensor(args[0]):
+            args.pop(0)
+        names = ('tfr1', 'tfr2', 'tfr3', 'beta', 'weights')
+        if len(args) > len(names):
+            raise TypeError('loss() takes at most %d scalar arguments after pr_mat' % len(names))
+        p = dict(tfr1=0., tfr2=0., tfr3=0., beta=0.1, weights=(1, 0.5))
+        for n, v in zip(names, args):
+            if n in kwargs:
+                raise TypeError("loss() got multiple values for argument '%s'" % n)
+            p[n] = v
+        for k, v in kwargs.items():
+            if k not in p:
+                raise TypeError("loss() got an unexpected keyword argument '%s'" % k)
+            p[k] = v
+        outputs = self.run(x, c, pr_mat, p['tfr1'], p['tfr2'], p['tfr3'])
+        return self.loss_function(x, c, *outputs, p['beta'], p['weights'])
 
     # ---- model.py:117-122
     def inference_encode(self, pr_mat, c):
