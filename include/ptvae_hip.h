@@ -63,6 +63,16 @@ int ptv_gru_seq_fwd(int prec, int M, int H, int T,
                     float* hall, float* gates,
                     const int* lengths, int reverse, const int* gi_idx, void* stream);
 
+/* One GRU cell step with explicit strides (same kernel as ptv_gru_seq_fwd, T = 1): the free-running
+ * decoder (ptvae.py:395-424,460-486) advances a [B]-row window of the step-major buffers per step. */
+int ptv_gru_step_fwd(int prec, int M, int H,
+                     const float* hprev, long ld_hprev,
+                     const float* gi, long gi_ld, const float* gi2, long gi2_ld,
+                     const float* w_hh, const float* b_hh,
+                     float* hout, long ld_hout,
+                     float* gates, long gates_plane,
+                     const int* lengths, int t, const int* gi_idx, void* stream);
+
 /* BPTT through ptv_gru_seq_fwd (replaces autograd through the same call sites).
  *   dh_ext [T] x [M,H]  gradient arriving at the state after processing step s (may be NULL)
  *   dh_last [M,H]       gradient arriving at the final state only (may be NULL)
@@ -152,6 +162,23 @@ int ptv_loss_bwd_scales(const float* gout11, const int* counts, float beta, floa
  */
 int ptv_dur_out_token(const float* h, int H, const float* w_out, const float* b_out, float* dur_out, long ld_out,
                       int* idx, const int* force_idx, long rows, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Free-running tokens.
+ * ptv_note_token (ptvae.py:408-416 + pitch_dur_ind_to_note_token :328-334): per row pitch argmax (first
+ *   maximal index), predicted token pred[r] = note_embedding(onehot(pitch) | 5 duration bits) with
+ *   dur_idx[d*dur_stride + r] the duration argmaxes, predicted grid row xhat[r] = (pitch, bits) int64,
+ *   running predicted length plen[r] (first <eos> step n; the last step fills 15).
+ * ptv_chord_token (ptvae.py:72-78): next chord-decoder token [B,36]; root/bass parts are the UNION over
+ *   the batch of the rows' argmax one-hots (the reference's index-broadcast quirk), chroma = per-row bits.
+ * ptv_route_slices: dst(mask[s]) (+)= src for nslices consecutive slices of slice_elems floats -- routes
+ *   token gradients to the ground-truth embedding (mask 1) or the predicted-token buffer (mask 0).
+ */
+int ptv_note_token(const float* pitch, long ld_pitch, const int* dur_idx, long dur_stride, const float* W, const float* bias, int E,
+                   float* pred, long ld_pred, long* xhat, long xhat_stride, int* plen, int n, int last,
+                   const int* force_pitch, int M, void* stream);
+int ptv_chord_token(const float* root, const float* chroma, const float* bass, unsigned* masks2, float* token, int B, void* stream);
+int ptv_route_slices(const float* src, float* dstA, float* dstB, const int* mask, long slice_elems, int nslices, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * clip_grad_norm_ (module.py:142-143) + torch.optim.Adam.step (train.py:50, scheduler.py:69-74) over

@@ -282,6 +282,25 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
   return PTV_OK;
 }
 
+// single GRU cell step with fully explicit strides (the free-running decoder walks row slices of the
+// step-major buffers: its per-time-step batch is a [B]-row window of the [32*B]-row matrices)
+extern "C" int ptv_gru_step_fwd(int prec, int M, int H,
+                                const float* hprev, long ld_hprev,
+                                const float* gi, long gi_ld, const float* gi2, long gi2_ld,
+                                const float* w_hh, const float* b_hh,
+                                float* hout, long ld_hout,
+                                float* gates, long gates_plane,
+                                const int* lengths, int t, const int* gi_idx, void* stream) {
+  if (M <= 0 || H <= 0 || (H & 3) || !hprev || !gi || !w_hh || !b_hh || !hout) return PTV_ERR_ARG;
+  if ((gi_ld & 3) || (ld_hprev & 3) || (ld_hout & 3) || (gi2 && (gi2_ld & 3)) || (gates && (gates_plane & 3))) return PTV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  GemmArgs g{hprev, ld_hprev, w_hh, H, M, H, H, H, (long)H};
+  EpiGruFwd::Params ep{hprev, ld_hprev, gi, gi_ld, gi2, gi2_ld, b_hh, hout, ld_hout, gates, gates_plane, lengths, t, gi_idx, H};
+  if (prec == PTV_PREC_BF16) launch_fwd_step<BF16>(g, ep, s); else launch_fwd_step<F32>(g, ep, s);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
 extern "C" int ptv_prof_enable(int tag) { ptv::prof::enabled = tag; return PTV_OK; }
 extern "C" int ptv_prof_config(int M, int H) { ptv::prof::filt_M = M; ptv::prof::filt_H = H; return PTV_OK; }
 extern "C" int ptv_prof_reset(void) { ptv::prof::used = 0; ptv::prof::flops = 0.0; return PTV_OK; }

@@ -59,6 +59,81 @@ __global__ void clip_adam_kernel(float* __restrict__ p, const float* __restrict_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// free-running decoder tokens (ptvae.py:408-416,328-334): per row, pitch argmax over the 130 logits,
+// predicted note token = note_embedding(onehot(pitch) | 5 duration argmax bits), predicted grid row
+// (pitch, bits) and the running predicted length (first <eos> position; 15 if none by the last step).
+// One wave per row.
+// ---------------------------------------------------------------------------------------------
+__global__ void note_token_kernel(const float* __restrict__ pitch, long ld_pitch, const int* __restrict__ dur_idx, long dur_stride,
+                                  const float* __restrict__ W, const float* __restrict__ bias, int E,
+                                  float* __restrict__ pred, long ld_pred, long* __restrict__ xhat, long xhat_stride,
+                                  int* __restrict__ plen, int n, int last, const int* __restrict__ force_pitch, int M) {
+  const int lane = threadIdx.x & 63;
+  for (int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < M; r += gridDim.x * (blockDim.x >> 6)) {
+    const float* lr = pitch + (long)r * ld_pitch;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int c = lane; c < 130; c += 64) { float v = lr[c]; if (v > best) { best = v; bi = c; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float ov = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }       // first maximal index (torch.max)
+    }
+    if (force_pitch) bi = force_pitch[r];
+    int bits[5];
+#pragma unroll
+    for (int d = 0; d < 5; d++) bits[d] = dur_idx[(long)d * dur_stride + r];
+    for (int e = lane; e < E; e += 64) {
+      float v = bias[e] + W[e * 135 + bi];
+#pragma unroll
+      for (int d = 0; d < 5; d++) v += W[e * 135 + 130 + d] * (float)bits[d];
+      pred[(long)r * ld_pred + e] = v;
+    }
+    if (lane == 0) {
+      long* xr = xhat + (long)r * xhat_stride;
+      xr[0] = bi;
+#pragma unroll
+      for (int d = 0; d < 5; d++) xr[1 + d] = bits[d];
+      int L = plen[r];
+      if (L == 0 && bi == 129) L = n;                 // lengths[eos & (lengths == 0)] = t      (ptvae.py:415-416)
+      if (last && L == 0) L = n;                      // lengths[lengths == 0] = t              (ptvae.py:425)
+      plen[r] = L;
+    }
+  }
+}
+
+// chord-decoder free-running token (ptvae.py:72-78).  QUIRK reproduced: the reference's index broadcast
+// makes the root / bass part of EVERY row the union over the batch of all rows' argmax one-hots.
+__global__ void chord_argmax_kernel(const float* __restrict__ root, const float* __restrict__ chroma, const float* __restrict__ bass,
+                                    unsigned* __restrict__ masks, float* __restrict__ token, int B) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int ar = 0, ab = 0;
+  for (int k = 1; k < 12; k++) { if (root[b * 12 + k] > root[b * 12 + ar]) ar = k; if (bass[b * 12 + k] > bass[b * 12 + ab]) ab = k; }
+  atomicOr(masks + 0, 1u << ar);
+  atomicOr(masks + 1, 1u << ab);
+  for (int k = 0; k < 12; k++) token[b * 36 + 12 + k] = chroma[b * 24 + 2 * k + 1] > chroma[b * 24 + 2 * k] ? 1.f : 0.f;
+}
+__global__ void chord_union_kernel(const unsigned* __restrict__ masks, float* __restrict__ token, int B) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * 12) return;
+  int b = i / 12, k = i % 12;
+  token[b * 36 + k] = (masks[0] >> k) & 1u ? 1.f : 0.f;
+  token[b * 36 + 24 + k] = (masks[1] >> k) & 1u ? 1.f : 0.f;
+}
+
+// dst_sel[s][row, :] (+)= src[s][row, :] where sel = mask[s] picks dstA (mask != 0) or dstB (may be null)
+__global__ void route_slices_kernel(const float* __restrict__ src, float* __restrict__ dstA, float* __restrict__ dstB,
+                                    const int* __restrict__ mask, long slice_elems, int nslices, int accumulate) {
+  const long total = slice_elems * nslices;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int s = (int)(i / slice_elems);
+    float* d = mask[s] ? dstA : dstB;
+    if (d) d[i] = accumulate ? d[i] + src[i] : src[i];
+  }
+}
+
 }  // namespace ptv
 
 using namespace ptv;
@@ -90,6 +165,35 @@ extern "C" int ptv_clip_adam_step(float* p, const float* g, float* m, float* v, 
   long nb = (n + 255) / 256; if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(clip_adam_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, gscale, clip, lr, beta1, beta2, eps,
                      (float)bc1, (float)sqrt(bc2));
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_note_token(const float* pitch, long ld_pitch, const int* dur_idx, long dur_stride, const float* W, const float* bias, int E,
+                              float* pred, long ld_pred, long* xhat, long xhat_stride, int* plen, int n, int last,
+                              const int* force_pitch, int M, void* stream) {
+  if (!pitch || !dur_idx || !W || !bias || !pred || !xhat || !plen || M <= 0 || E <= 0) return PTV_ERR_ARG;
+  int nb = (M + 3) / 4; if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(note_token_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, pitch, ld_pitch, dur_idx, dur_stride, W, bias, E,
+                     pred, ld_pred, xhat, xhat_stride, plen, n, last, force_pitch, M);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_chord_token(const float* root, const float* chroma, const float* bass, unsigned* masks2, float* token, int B, void* stream) {
+  if (!root || !chroma || !bass || !masks2 || !token || B <= 0) return PTV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(masks2, 0, 2 * sizeof(unsigned), s) != hipSuccess) return PTV_ERR_LAUNCH;
+  hipLaunchKernelGGL(chord_argmax_kernel, dim3(cdiv(B, 256)), dim3(256), 0, s, root, chroma, bass, masks2, token, B);
+  hipLaunchKernelGGL(chord_union_kernel, dim3(cdiv((long)B * 12, 256)), dim3(256), 0, s, masks2, token, B);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_route_slices(const float* src, float* dstA, float* dstB, const int* mask, long slice_elems, int nslices, int accumulate, void* stream) {
+  if (!src || !mask || slice_elems <= 0 || nslices <= 0) return PTV_ERR_ARG;
+  long nb = (slice_elems * nslices + 255) / 256; if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(route_slices_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, src, dstA, dstB, mask, slice_elems, nslices, accumulate);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

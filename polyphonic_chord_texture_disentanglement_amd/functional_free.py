@@ -1,0 +1,356 @@
+"""Scheduled-sampling / free-running PianoTree decoder and chord decoder (the step loop).
+
+Reference: `PtvaeDecoder.decoder/decode_notes/decode_note` (ptvae.py:336-496) with arbitrary
+teacher-forcing coins, `inference=True` (model.py:124-131), and `RnnDecoder.forward` (ptvae.py:51-87).
+
+Forward is inherently sequential -- every next token is an argmax of the previous step -- so it walks
+32 x 15 x (1 + 5) cell steps on [B]-row windows of the SAME step-major buffers the teacher-forced path
+uses.  Backward is not: argmax is not differentiable, so given the recorded tokens every recurrent chain is
+independent across time steps and the whole BPTT runs batched over all 32*B rows exactly like the
+teacher-forced path; token gradients are routed to the ground-truth embedding or to the predicted-token
+buffer (whose gradient reaches `note_embedding` and, through the re-summarising bi-GRU,
+`dec_notes_emb_gru`) -- never into the logits that produced the argmax.
+"""
+import torch
+
+from . import functional as F_
+from ._lib import call, ptr, stream_ptr
+from .functional import (DEC_PARAM_NAMES, Side, _bgrad, _bigru_backward, _empty, _eye2, _gbuf, _onehot2x5, _zeros,
+                         colsum, copy2d, gemm, gru_bwd, sum_steps)
+
+FREE_PARAM_NAMES = DEC_PARAM_NAMES + ['note_embedding.weight', 'note_embedding.bias']
+EMB_GRU = ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0', 'weight_ih_l0_reverse', 'weight_hh_l0_reverse',
+           'bias_ih_l0_reverse', 'bias_hh_l0_reverse')
+
+
+def gru_step(prec, hprev, gi, gi_ld, w_hh, b_hh, hout, *, gi2=None, gates=None, plane=0, lengths=None, t=0, gi_idx=None):
+    M, H = hout.shape
+    call('ptv_gru_step_fwd', prec, M, H, ptr(hprev), hprev.stride(0), ptr(gi), gi_ld, ptr(gi2),
+         gi2.stride(0) if gi2 is not None else 0, ptr(w_hh), ptr(b_hh), ptr(hout), hout.stride(0), ptr(gates), plane,
+         ptr(lengths), t, ptr(gi_idx), stream_ptr())
+
+
+class DecoderStepFn(torch.autograd.Function):
+    """(z, emb [16,32,B,E] or None, xs [32B,2He] or None, coins, inference, force, prec, *params)
+    -> pitch [15,32,B,130], dur [15*32*B,5,2], xhat int64 [B,32,16,6] (predicted grid), dur idx"""
+
+    @staticmethod
+    def forward(ctx, z, emb, xs, coins, inference, force, prec, *params):
+        P = dict(zip(FREE_PARAM_NAMES, params))
+        dev = z.device
+        z = z.contiguous()
+        B = z.shape[0]
+        R = 32 * B
+        E = P['note_embedding.weight'].shape[0]
+        He = P['dec_notes_emb_gru.weight_hh_l0'].shape[1]
+        Ht = P['dec_time_gru.weight_hh_l0'].shape[1]
+        Hn = P['dec_notes_gru.weight_hh_l0'].shape[1]
+        Hd = P['dec_dur_gru.weight_hh_l0'].shape[1]
+        NP = P['pitch_out_linear.weight'].shape[0]
+        M = 15 * R
+        train = (not inference) and any(ctx.needs_input_grad)
+        coin_notes, coin_time = coins
+        w_emb, b_emb = P['note_embedding.weight'], P['note_embedding.bias']
+        st = stream_ptr()
+
+        NS = _empty(33, B, Ht, dev=dev)
+        gemm(z, P['z2dec_hid_linear.weight'], NS[0], bias=P['z2dec_hid_linear.bias'], prec=prec)
+        z_in = gemm(z, P['z2dec_in_linear.weight'], bias=P['z2dec_in_linear.bias'], prec=prec)
+        w_ih_t = P['dec_time_gru.weight_ih_l0']
+        zg = gemm(z_in, w_ih_t[:, 2 * He:], bias=P['dec_time_gru.bias_ih_l0'], prec=prec)
+        TOKS = _empty(33, B, 2 * He, dev=dev)
+        copy2d(TOKS[0], P['dec_init_input'].view(1, -1), lds=0)
+        gates_t = _empty(32, 4, B, Ht, dev=dev) if train else None
+
+        HN = _empty(16, R, Hn, dev=dev)
+        gates_n = _empty(15, 4, R, Hn, dev=dev) if train else None
+        TOK = _empty(15, R, E, dev=dev)
+        PRED = _zeros(16, R, E, dev=dev)
+        xhat = torch.full((B, 32, 16, 6), 2, device=dev, dtype=torch.long)
+        xhat[:, :, :, 0] = 130
+        xhat[:, :, 0, 0] = 128
+        plen = torch.zeros(R, device=dev, dtype=torch.int32)
+        pitch = _empty(M, NP, dev=dev)
+        HD = _empty(6, M, Hd, dev=dev)
+        gates_d = _empty(5, 4, M, Hd, dev=dev) if train else None
+        idx = torch.empty(5, M, device=dev, dtype=torch.int32)
+        dur = _empty(M, 5, 2, dev=dev)
+        dur2 = dur.view(M, 10)
+        need_resum = inference or not all(coin_time)
+        XH = [_zeros(17, R, He, dev=dev) for _ in range(2)] if need_resum else None
+        XG = ([_zeros(16, 4, R, He, dev=dev) for _ in range(2)] if train else [None, None]) if need_resum else None
+
+        if inference:
+            sos = torch.tensor([[128, 2, 2, 2, 2, 2]], device=dev, dtype=torch.long).view(1, 1, 1, 6).expand(1, 32, 16, 6).contiguous()
+            sos_emb = _empty(16, 32, 1, E, dev=dev)
+            call('ptv_embed_fwd', ptr(sos), ptr(w_emb), ptr(b_emb), ptr(sos_emb), None, 1, E, st)
+            sos_row = sos_emb.view(-1, E)[0:1]
+        w_ih_n, w_hh_n, b_hh_n = P['dec_notes_gru.weight_ih_l0'], P['dec_notes_gru.weight_hh_l0'], P['dec_notes_gru.bias_hh_l0']
+        w_dh = P['dur_hid_linear.weight']
+        w_ih_d, b_ih_d = P['dec_dur_gru.weight_ih_l0'], P['dec_dur_gru.bias_ih_l0']
+        w_hh_d, b_hh_d = P['dec_dur_gru.weight_hh_l0'], P['dec_dur_gru.bias_hh_l0']
+        tab0 = gemm(P['dur_sos_token'].view(1, -1), w_ih_d, bias=b_ih_d, prec=0)
+        tab = gemm(_onehot2x5(dev), w_ih_d, bias=b_ih_d, prec=0)
+        emb3 = emb.view(16, R, E) if emb is not None else None
+        wE = [P['dec_notes_emb_gru.' + n] for n in EMB_GRU]
+        force_pitch = force.get('pitch') if force else None          # [15, R] int32
+        force_dur = force.get('dur') if force else None              # [5, 15R] int32
+
+        for t in range(32):
+            rows = slice(t * B, (t + 1) * B)
+            gi = gemm(TOKS[t], w_ih_t[:, :2 * He], prec=prec)
+            gru_step(prec, NS[t], gi, 3 * Ht, P['dec_time_gru.weight_hh_l0'], P['dec_time_gru.bias_hh_l0'], NS[t + 1], gi2=zg,
+                     gates=gates_t[t] if train else None, plane=B * Ht)
+            ns = NS[t + 1]
+            gemm(ns, P['dec_time_to_notes_hid.weight'], HN[0][rows], bias=P['dec_time_to_notes_hid.bias'], prec=prec)
+            GCt = gemm(ns, w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec)
+            if inference:
+                copy2d(TOK[0][rows], sos_row, lds=0)
+            else:
+                copy2d(TOK[0][rows], emb3[0][rows])
+            copy2d(PRED[0][rows], TOK[0][rows])
+            for n in range(15):
+                gi_tok = gemm(TOK[n][rows], w_ih_n[:, Ht:], prec=prec)
+                gru_step(prec, HN[n][rows], gi_tok, 3 * Hn, w_hh_n, b_hh_n, HN[n + 1][rows], gi2=GCt,
+                         gates=gates_n[n][:, rows] if train else None, plane=R * Hn)
+                h = HN[n + 1][rows]
+                pr = slice(n * R + t * B, n * R + (t + 1) * B)
+                gemm(h, P['pitch_out_linear.weight'], pitch[pr], bias=P['pitch_out_linear.bias'], prec=prec)
+                gemm(h, w_dh[:, :Hn], HD[0][pr], bias=P['dur_hid_linear.bias'], prec=prec)
+                gemm(pitch[pr], w_dh[:, Hn:], HD[0][pr], acc=True, prec=prec)
+                for d in range(5):
+                    g_, g_ld, g_idx = (tab0, 0, None) if d == 0 else (tab, 3 * Hd, idx[d - 1][pr])
+                    gru_step(prec, HD[d][pr], g_, g_ld, w_hh_d, b_hh_d, HD[d + 1][pr],
+                             gates=gates_d[d][:, pr] if train else None, plane=M * Hd, gi_idx=g_idx)
+                    call('ptv_dur_out_token', ptr(HD[d + 1][pr]), Hd, ptr(P['dur_out_linear.weight']),
+                         ptr(P['dur_out_linear.bias']), ptr(dur2[pr][:, 2 * d:]), 10, ptr(idx[d][pr]),
+                         ptr(force_dur[d][pr]) if force_dur is not None else None, B, st)
+                call('ptv_note_token', ptr(pitch[pr]), NP, ptr(idx[0][pr]), M, ptr(w_emb), ptr(b_emb), E,
+                     ptr(PRED[n + 1][rows]), E, ptr(xhat[0, t, n + 1]), 32 * 16 * 6, ptr(plen[rows]), n + 1, int(n == 14),
+                     ptr(force_pitch[n][rows]) if force_pitch is not None else None, B, st)
+                if n < 14:
+                    use_gt = (not inference) and coin_notes[t][n]
+                    copy2d(TOK[n + 1][rows], emb3[n + 1][rows] if use_gt else PRED[n + 1][rows])
+            if t == 31:
+                break
+            if (not inference) and coin_time[t]:
+                copy2d(TOKS[t + 1], xs[rows])
+            else:
+                # token = final states of dec_notes_emb_gru over the predicted notes (ptvae.py:480-486)
+                PT = _empty(16, B * E, dev=dev)
+                copy2d(PT, PRED.view(16, R * E)[:, t * B * E:(t + 1) * B * E])
+                for d in range(2):
+                    gi_e = gemm(PT.view(16 * B, E), wE[4 * d], bias=wE[4 * d + 2], prec=prec).view(16, B, 3 * He)
+                    for s_ in range(16):
+                        tt = 15 - s_ if d else s_
+                        gru_step(prec, XH[d][s_][rows], gi_e[tt], 3 * He, wE[4 * d + 1], wE[4 * d + 3], XH[d][s_ + 1][rows],
+                                 gates=XG[d][s_][:, rows] if train else None, plane=R * He, lengths=plen[rows], t=tt)
+                    copy2d(TOKS[t + 1][:, d * He:(d + 1) * He], XH[d][16][rows])
+
+        if train:
+            ctx.save_for_backward(z, emb, *params)
+            ctx.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in, TOKS=TOKS,
+                          gates_t=gates_t, HN=HN, gates_n=gates_n, pitch=pitch, HD=HD, gates_d=gates_d, idx=idx, TOK=TOK,
+                          PRED=PRED, xhat=xhat, XH=XH, XG=XG, coins=coins, has_xs=xs is not None)
+        ctx.mark_non_differentiable(xhat, idx)
+        return pitch.view(15, 32, B, NP), dur, xhat, idx
+
+    @staticmethod
+    def backward(ctx, dpitch, ddur, _dx, _di):
+        z, emb, *params = ctx.saved_tensors
+        P = dict(zip(FREE_PARAM_NAMES, params))
+        st = ctx.st
+        ctx.st = None
+        B, R, E, He, Ht, Hn, Hd, NP, prec = (st[k] for k in ('B', 'R', 'E', 'He', 'Ht', 'Hn', 'Hd', 'NP', 'prec'))
+        dev = z.device
+        M = 15 * R
+        G = {n: None for n in FREE_PARAM_NAMES}
+        NS, HN, HD, TOKS, TOK, PRED = st['NS'], st['HN'], st['HD'], st['TOKS'], st['TOK'], st['PRED']
+        NSf = NS[1:].view(R, Ht)
+        NSUM = HN[1:].view(M, Hn)
+        coin_notes, coin_time = st['coins']
+        side = Side(3)
+        sp = stream_ptr()
+
+        def wgrad(name, dy, x, sub=None):
+            if G[name] is None:
+                G[name] = _gbuf(P[name])
+            out = G[name] if sub is None else G[name][:, sub]
+            gemm(dy, x, out, ta=True, tb=True, acc=True, prec=prec)
+
+        def bgrad(name, a):
+            if G[name] is None:
+                G[name] = _bgrad(P[name], a)
+            else:
+                colsum(G[name].view(1, -1), a)
+
+        ddur = (ddur.contiguous() if ddur is not None else _zeros(M, 5, 2, dev=dev)).view(M, 10)
+        dP = _empty(M, NP, dev=dev)
+        if dpitch is not None:
+            copy2d(dP, dpitch.contiguous().view(M, NP))
+        else:
+            dP.zero_()
+
+        # ---- duration GRU, heads, notes GRU: identical to the teacher-forced path (batched over all rows)
+        w_out = P['dur_out_linear.weight']
+        w_hh_d, w_ih_d = P['dec_dur_gru.weight_hh_l0'], P['dec_dur_gru.weight_ih_l0']
+        dgi_d, dgh_d, dHD0 = gru_bwd(prec, HD, st['gates_d'], w_hh_d, lr=(ddur, 2, 10, 2, w_out))
+
+        def dur_wgrads():
+            for d in range(5):
+                wgrad('dur_out_linear.weight', ddur[:, 2 * d:2 * d + 2], HD[d + 1])
+            bgrad('dur_out_linear.bias', ddur.view(M * 5, 2))
+            wgrad('dec_dur_gru.weight_hh_l0', dgh_d.view(5 * M, 3 * Hd), HD[:5].view(5 * M, Hd))
+            bgrad('dec_dur_gru.bias_hh_l0', dgh_d.view(5 * M, 3 * Hd))
+            bgrad('dec_dur_gru.bias_ih_l0', dgi_d.view(5 * M, 3 * Hd))
+            cs0 = colsum(_zeros(1, 3 * Hd, dev=dev), dgi_d[0])
+            g = _gbuf(w_ih_d)
+            gemm(cs0, P['dur_sos_token'].view(1, -1), g, ta=True, tb=True, acc=True, prec=0, splitk=-1)
+            G['dur_sos_token'] = _gbuf(P['dur_sos_token'])
+            gemm(cs0, w_ih_d, G['dur_sos_token'].view(1, -1), tb=True, prec=0, splitk=-1)
+            sel = _zeros(2, 3 * Hd, dev=dev)
+            for d in range(1, 5):
+                colsum(sel, dgi_d[d], sel=st['idx'][d - 1], groups=2)
+            gemm(sel, _eye2(dev), g[:, 0:2], ta=True, acc=True, prec=0, splitk=-1)
+            G['dec_dur_gru.weight_ih_l0'] = g
+        side(dur_wgrads, ddur, dgi_d, dgh_d)
+
+        w_dh, w_p = P['dur_hid_linear.weight'], P['pitch_out_linear.weight']
+        dNSUM = gemm(dHD0, w_dh[:, :Hn], tb=True, prec=prec)
+        gemm(dHD0, w_dh[:, Hn:], dP, tb=True, acc=True, prec=prec)
+        gemm(dP, w_p, dNSUM, tb=True, acc=True, prec=prec)
+
+        def head_wgrads():
+            wgrad('dur_hid_linear.weight', dHD0, NSUM, slice(0, Hn))
+            wgrad('dur_hid_linear.weight', dHD0, st['pitch'], slice(Hn, None))
+            bgrad('dur_hid_linear.bias', dHD0)
+            wgrad('pitch_out_linear.weight', dP, NSUM)
+            bgrad('pitch_out_linear.bias', dP)
+        side(head_wgrads, dHD0, dP)
+
+        w_hh_n, w_ih_n = P['dec_notes_gru.weight_hh_l0'], P['dec_notes_gru.weight_ih_l0']
+        dgi_n, dgh_n, dHN0 = gru_bwd(prec, HN, st['gates_n'], w_hh_n, dh_ext=dNSUM.view(15, R, Hn))
+        dGC = sum_steps(dgi_n)
+        dTOK = gemm(dgi_n.view(M, 3 * Hn), w_ih_n[:, Ht:], tb=True, prec=prec).view(15, R, E)
+        dNS = gemm(dGC, w_ih_n[:, :Ht], tb=True, prec=prec)
+        w_tn = P['dec_time_to_notes_hid.weight']
+        gemm(dHN0, w_tn, dNS, tb=True, acc=True, prec=prec)
+
+        def notes_wgrads():
+            wgrad('dec_notes_gru.weight_hh_l0', dgh_n.view(M, 3 * Hn), HN[:15].view(M, Hn))
+            bgrad('dec_notes_gru.bias_hh_l0', dgh_n.view(M, 3 * Hn))
+            bgrad('dec_notes_gru.bias_ih_l0', dGC)
+            wgrad('dec_notes_gru.weight_ih_l0', dGC, NSf, slice(0, Ht))
+            wgrad('dec_notes_gru.weight_ih_l0', dgi_n.view(M, 3 * Hn), TOK.view(M, E), slice(Ht, None))
+            wgrad('dec_time_to_notes_hid.weight', dHN0, NSf)
+            bgrad('dec_time_to_notes_hid.bias', dHN0)
+        side(notes_wgrads, dgi_n, dgh_n, dGC, dHN0, dNSUM)
+
+        # ---- route token gradients: ground-truth embedding (coin true / slot 0) vs predicted tokens
+        demb = _zeros(16, R, E, dev=dev)
+        dPRED = _zeros(16, R, E, dev=dev)
+        mask_tok = torch.ones(15, 32, dtype=torch.int32)
+        for t in range(32):
+            for n in range(14):
+                mask_tok[n + 1, t] = 1 if coin_notes[t][n] else 0
+        mask_tok = mask_tok.to(dev)
+        call('ptv_route_slices', ptr(dTOK), ptr(demb), ptr(dPRED), ptr(mask_tok), B * E, 15 * 32, 0, sp)
+
+        # ---- time GRU
+        w_hh_t, w_ih_t = P['dec_time_gru.weight_hh_l0'], P['dec_time_gru.weight_ih_l0']
+        dgi_t, dgh_t, dzhid = gru_bwd(prec, NS, st['gates_t'], w_hh_t, dh_ext=dNS.view(32, B, Ht))
+        dZG = sum_steps(dgi_t)
+        dz_in = gemm(dZG, w_ih_t[:, 2 * He:], tb=True, prec=prec)
+        dTOKS = _empty(33, B, 2 * He, dev=dev)
+        dTOKS[32].zero_()
+        gemm(dgi_t.view(R, 3 * Ht), w_ih_t[:, :2 * He], dTOKS[:32].view(R, 2 * He), tb=True, prec=prec)
+        w_zh, w_zi = P['z2dec_hid_linear.weight'], P['z2dec_in_linear.weight']
+        dz = gemm(dzhid, w_zh, tb=True, prec=prec)
+        gemm(dz_in, w_zi, dz, tb=True, acc=True, prec=prec)
+
+        def time_wgrads():
+            wgrad('dec_time_gru.weight_hh_l0', dgh_t.view(R, 3 * Ht), NS[:32].view(R, Ht))
+            bgrad('dec_time_gru.bias_hh_l0', dgh_t.view(R, 3 * Ht))
+            bgrad('dec_time_gru.bias_ih_l0', dZG)
+            wgrad('dec_time_gru.weight_ih_l0', dZG, st['z_in'], slice(2 * He, None))
+            wgrad('dec_time_gru.weight_ih_l0', dgi_t.view(R, 3 * Ht), TOKS[:32].view(R, 2 * He), slice(0, 2 * He))
+            bgrad('dec_init_input', dTOKS[0])
+            wgrad('z2dec_hid_linear.weight', dzhid, z)
+            bgrad('z2dec_hid_linear.bias', dzhid)
+            wgrad('z2dec_in_linear.weight', dz_in, z)
+            bgrad('z2dec_in_linear.bias', dz_in)
+        side(time_wgrads, dgi_t, dgh_t, dZG, dTOKS, dzhid, dz_in, dNS)
+
+        # ---- time tokens: ground-truth summaries (coin true) vs re-summarised predictions
+        dxs = _zeros(32, B, 2 * He, dev=dev)
+        dxsp = _zeros(32, B, 2 * He, dev=dev)
+        mask_time = torch.tensor([1 if c else 0 for c in coin_time] + [1], dtype=torch.int32).to(dev)
+        call('ptv_route_slices', ptr(dTOKS[1:]), ptr(dxs), ptr(dxsp), ptr(mask_time), B * 2 * He, 32, 0, sp)
+        if st['XH'] is not None:
+            wE = [P['dec_notes_emb_gru.' + n] for n in EMB_GRU]
+            saved = [(st['XH'][0], st['XG'][0]), (st['XH'][1], st['XG'][1])]
+            ge, dx_pred = _bigru_backward(prec, PRED, wE, saved, dxsp.view(R, 2 * He), True)
+            for n, gg in zip(EMB_GRU, ge):
+                G['dec_notes_emb_gru.' + n] = gg
+            copy2d(dPRED.view(16 * R, E), dx_pred.view(16 * R, E), acc=True)
+
+        # ---- predicted tokens -> note_embedding (slot 0 is the ground-truth <sos> embedding)
+        copy2d(demb[0], dPRED[0], acc=True)
+        dPRED[0].zero_()
+        mh = _empty(B * 512, 136, dev=dev)
+        call('ptv_multihot', ptr(st['xhat']), ptr(mh), 136, B, sp)
+        wgrad('note_embedding.weight', dPRED.view(16 * R, E), mh[:, :135])
+        bgrad('note_embedding.bias', dPRED.view(16 * R, E))
+
+        side.join()
+        grads = tuple(G[n] for n in FREE_PARAM_NAMES)
+        return (dz, demb.view(16, 32, B, E), dxs.view(R, 2 * He) if st['has_xs'] else None, None, None, None, None) + grads
+
+
+# =============================================================================================
+# RnnDecoder (chord decoder) with arbitrary coins: ptvae.py:51-87
+# =============================================================================================
+class ChordDecoderStepFn(torch.autograd.Function):
+    """(z_chd, c_sm [8,B,36] or None, coins [8] bools, prec, *params) -> root [8,B,12], chroma [8,B,24], bass [8,B,12]"""
+
+    @staticmethod
+    def forward(ctx, z, c_sm, coins, prec, *params):
+        P = dict(zip(F_.CHD_PARAM_NAMES, params))
+        dev = z.device
+        z = z.contiguous()
+        B = z.shape[0]
+        T = len(coins)
+        H = P['gru.weight_hh_l0'].shape[1]
+        I = P['init_input'].shape[0]
+        hall = _empty(T + 1, B, H, dev=dev)
+        gemm(z, P['z2dec_hid.weight'], hall[0], bias=P['z2dec_hid.bias'], prec=prec)
+        z_in = gemm(z, P['z2dec_in.weight'], bias=P['z2dec_in.bias'], prec=prec)
+        w_ih = P['gru.weight_ih_l0']
+        zg = gemm(z_in, w_ih[:, I:], bias=P['gru.bias_ih_l0'], prec=prec)
+        toks = _empty(T, B, I, dev=dev)
+        copy2d(toks[0], P['init_input'].view(1, -1), lds=0)
+        gates = _empty(T, 4, B, H, dev=dev)
+        root, chroma, bass = _empty(T, B, 12, dev=dev), _empty(T, B, 24, dev=dev), _empty(T, B, 12, dev=dev)
+        masks = torch.zeros(2, device=dev, dtype=torch.int32)
+        for t in range(T):
+            gi = gemm(toks[t], w_ih[:, :I], prec=prec)
+            gru_step(prec, hall[t], gi, 3 * H, P['gru.weight_hh_l0'], P['gru.bias_hh_l0'], hall[t + 1], gi2=zg, gates=gates[t],
+                     plane=B * H)
+            gemm(hall[t + 1], P['root_out.weight'], root[t], bias=P['root_out.bias'], prec=prec)
+            gemm(hall[t + 1], P['chroma_out.weight'], chroma[t], bias=P['chroma_out.bias'], prec=prec)
+            gemm(hall[t + 1], P['bass_out.weight'], bass[t], bias=P['bass_out.bias'], prec=prec)
+            if t + 1 < T:
+                if coins[t] and c_sm is not None:
+                    copy2d(toks[t + 1], c_sm[t])
+                else:
+                    call('ptv_chord_token', ptr(root[t]), ptr(chroma[t]), ptr(bass[t]), ptr(masks), ptr(toks[t + 1]), B,
+                         stream_ptr())
+        ctx.save_for_backward(z, *params)
+        ctx.st = dict(hall=hall, gates=gates, toks=toks, z_in=z_in, prec=prec, T=T, B=B, H=H, I=I)
+        return root, chroma, bass
+
+    @staticmethod
+    def backward(ctx, droot, dchroma, dbass):
+        # tokens are constants (ground truth or argmax one-hots): same BPTT as the teacher-forced path
+        g = F_.ChordDecoderTFFn.backward(ctx, droot, dchroma, dbass)
+        return (g[0], None, None, None) + tuple(g[3:])

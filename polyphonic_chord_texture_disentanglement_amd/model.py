@@ -114,11 +114,57 @@ class DisentangleVAE(PytorchModel):
             dist_rhy = self.rhy_encoder(pr_mat)
         return dist_chd, dist_rhy
 
+    # ---- model.py:124-131: free-running decode; est_x = the argmax grid the step loop produced on device
+    # (identical to output_to_numpy's argmax of the returned logits, ptvae.py:537-544)
     def inference_decode(self, z_chd, z_rhy):
-        raise NotImplementedError('free-running decode lands with the step-loop path')
+        self.eval()
+        with torch.no_grad():
+            dec_z = torch.cat([z_chd, z_rhy], dim=-1)
+            self.decoder(dec_z, True, None, None, 0., 0.)
+            est_x = self.decoder.last_xhat[:, :, 1:, :].cpu().numpy()
+        return est_x
 
+    # ---- model.py:133-142
     def inference(self, pr_mat, c, sample):
-        raise NotImplementedError('free-running decode lands with the step-loop path')
+        self.eval()
+        with torch.no_grad():
+            dist_chd = self.chd_encoder(c)
+            dist_rhy = self.rhy_encoder(pr_mat)
+            z_chd = self._rsample('chd', dist_chd) if sample else dist_chd.mean
+            z_rhy = self._rsample('rhy', dist_rhy) if sample else dist_rhy.mean
+        return self.inference_decode(z_chd, z_rhy)
+
+    # ---- model.py:144-148
+    def swap(self, pr_mat1, pr_mat2, c1, c2, fix_rhy, fix_chd):
+        pr_mat = pr_mat1 if fix_rhy else pr_mat2
+        c = c1 if fix_chd else c2
+        return self.inference(pr_mat, c, sample=False)
+
+    # ---- model.py:150-172
+    def posterior_sample(self, pr_mat, c, scale=None, sample_chd=True, sample_txt=True):
+        if scale is None and sample_chd and sample_txt:
+            return self.inference(pr_mat, c, sample=True)
+        dist_chd, dist_rhy = self.inference_encode(pr_mat, c)
+        if scale is not None:
+            dist_chd = HipNormal(dist_chd.mean, dist_chd.scale * scale)
+            dist_rhy = HipNormal(dist_rhy.mean, dist_rhy.scale * scale)
+        with torch.no_grad():
+            z_chd = self._rsample('chd', dist_chd) if sample_chd else dist_chd.mean
+            z_rhy = self._rsample('rhy', dist_rhy) if sample_txt else dist_rhy.mean
+        return self.inference_decode(z_chd, z_rhy)
+
+    # ---- model.py:174-184
+    def prior_sample(self, x, c, sample_chd=False, sample_rhy=False, scale=1.):
+        dist_chd, dist_rhy = self.inference_encode(x, c)
+        mean = torch.zeros_like(dist_rhy.mean)
+        loc = torch.ones_like(dist_rhy.mean) * scale
+        if sample_chd:
+            dist_chd = HipNormal(mean, loc)
+        if sample_rhy:
+            dist_rhy = HipNormal(mean, loc)
+        with torch.no_grad():
+            z_chd, z_rhy = self._rsample('chd', dist_chd), self._rsample('rhy', dist_rhy)
+        return self.inference_decode(z_chd, z_rhy)
 
     # ---- model.py:244-265
     @staticmethod

@@ -16,6 +16,7 @@ import torch
 from torch import nn
 
 from . import functional as F_
+from . import functional_free as FF_
 from ._lib import prec_code
 
 
@@ -188,11 +189,11 @@ class RnnDecoder(nn.Module, _PrecMixin):
             tfr = 0.
         if coins is None:
             coins = self.draw_coins(tfr)
+        c_sm = F_.Transpose01Fn.apply(c.float()).detach() if (c is not None and not inference) else None
         if all(coins) and not inference:
-            c_sm = F_.Transpose01Fn.apply(c.float())
-            root, chroma, bass = F_.ChordDecoderTFFn.apply(z_chd, c_sm.detach(), self._prec, *self._params())
+            root, chroma, bass = F_.ChordDecoderTFFn.apply(z_chd, c_sm, self._prec, *self._params())
         else:
-            raise NotImplementedError('free-running chord decoder lands with the step-loop path')
+            root, chroma, bass = FF_.ChordDecoderStepFn.apply(z_chd, c_sm, list(coins), self._prec, *self._params())
         bs = z_chd.size(0)
         # reference shapes [B,8,12] / [B,8,12,2] / [B,8,12] as views of the step-major buffers
         return root.transpose(0, 1), chroma.view(T, bs, 12, 2).transpose(0, 1), bass.transpose(0, 1)
@@ -234,12 +235,18 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
         self.dur_hid_linear = Linear(self.pitch_range + dec_notes_hid_size, dec_dur_hid_size)
         self.dur_out_linear = Linear(dec_dur_hid_size, 2)
         self.force_dur_idx = None          # [5, 480*B] int32: replay the oracle's duration argmaxes (tests)
+        self.force_trace = None            # {'pitch': [15, 32B] int32, 'dur': [5, 480B] int32}: replay mode (tests)
+        self.last_xhat = None              # predicted grid [B,32,16,6] int64 of the last step-loop decode
         self._summary = None
         self.last_dur_idx = None
 
     def _params(self):
         sd = dict(self.named_parameters())
         return [sd[n] for n in F_.DEC_PARAM_NAMES]
+
+    def _params_free(self):
+        sd = dict(self.named_parameters())
+        return [sd[n] for n in FF_.FREE_PARAM_NAMES]
 
     # ---- ptvae.py:531-535 (+ :292-313)
     def emb_x(self, x):
@@ -272,16 +279,18 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
 
     def decoder(self, z, inference, x, lengths, teacher_forcing_ratio1, teacher_forcing_ratio2, coins=None):
         _require_cuda(z, 'PtvaeDecoder')
+        B = z.size(0)
         if inference:
             assert x is None and lengths is None
             assert teacher_forcing_ratio1 == 0 and teacher_forcing_ratio2 == 0
-            raise NotImplementedError('free-running decode lands with the step-loop path')
+            coins = ([[False] * (self.max_simu_note - 2)] * self.num_step, [False] * (self.num_step - 1))
+            pitch, dur, xhat, idx = FF_.DecoderStepFn.apply(z, None, None, coins, True, self.force_trace, self._prec,
+                                                            *self._params_free())
+            self.last_dur_idx, self.last_xhat = idx, xhat
+            return pitch.permute(2, 1, 0, 3), dur.view(15, 32, B, 5, 2).permute(2, 1, 0, 3, 4)
         if coins is None:
             coins = self.draw_coins(teacher_forcing_ratio1, teacher_forcing_ratio2)
         all_tf = all(all(r) for r in coins[0]) and all(coins[1])
-        if not all_tf:
-            raise NotImplementedError('scheduled-sampling / free-running training lands with the step-loop path')
-        B = z.size(0)
         emb = x.permute(2, 1, 0, 3)                                            # [16,32,B,E]
         if not emb.is_contiguous():                                            # caller built a plain [B,32,16,E]
             E = x.size(-1)
@@ -295,6 +304,11 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
             cached[2].join()
         else:
             xs = self._summarize(emb, len32)
+        if not all_tf:
+            pitch, dur, xhat, idx = FF_.DecoderStepFn.apply(z, emb, xs, coins, False, self.force_trace, self._prec,
+                                                            *self._params_free())
+            self.last_dur_idx, self.last_xhat = idx, xhat
+            return pitch.permute(2, 1, 0, 3), dur.view(15, 32, B, 5, 2).permute(2, 1, 0, 3, 4)
         pitch, dur, idx = F_.DecoderTFFn.apply(z, emb, xs, self.force_dur_idx, self._prec, *self._params())
         self.last_dur_idx = idx
         # reference shapes [B,32,15,130] / [B,32,15,5,2] as permuted views of the step-major buffers
@@ -302,6 +316,13 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
 
     def forward(self, z, inference, x, lengths, teacher_forcing_ratio1, teacher_forcing_ratio2, coins=None):
         return self.decoder(z, inference, x, lengths, teacher_forcing_ratio1, teacher_forcing_ratio2, coins=coins)
+
+    # ---- ptvae.py:537-544
+    def output_to_numpy(self, recon_pitch, recon_dur):
+        est_pitch = recon_pitch.max(-1)[1].unsqueeze(-1)
+        est_dur = recon_dur.max(-1)[1]
+        est_x = torch.cat([est_pitch, est_dur], dim=-1).cpu().numpy()
+        return est_x, recon_pitch.detach().cpu().numpy(), recon_dur.detach().cpu().numpy()
 
     # ---- ptvae.py:498-529
     def recon_loss(self, x, recon_pitch, recon_dur, weights=(1, 0.5), weighted_dur=False):
