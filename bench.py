@@ -69,6 +69,10 @@ def main():
     ap.add_argument('--batch', type=int, default=512, help='per-GPU batch (weak scaling)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='decode mode: replay the step loop from a captured hipGraph')
+    ap.add_argument('--tfr', type=float, default=1.0, help='teacher-forcing ratio (1 = configs[1]; 0 = free-running training)')
+    ap.add_argument('--mode', default='train', choices=['train', 'decode'],
+                    help="'decode' = configs[3]: free-running inference_decode samples/s")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -94,6 +98,7 @@ def main():
     torch.manual_seed(0)                                   # identical weights on every rank
     model = DisentangleVAE.init_model(dev).to(dev).set_precision(args.precision)
     opt = FusedClipAdam(model.parameters(), lr=1e-3)
+    model.decoder.use_graph = args.graph
     sched = MinExponentialLR(opt, gamma=0.9999, minimum=1e-5)
     sync = GradSync(model, opt) if world > 1 else None
 
@@ -109,7 +114,13 @@ def main():
     def step(i):
         x, c, pr = batches[i % nb]
         opt.zero_grad()
-        out = model('train', x, c, pr, tfr1=1., tfr2=1., tfr3=1., beta=0.1, weights=[1, 0.5])
+        if args.mode == 'decode':
+            zc = torch.randn(B, 256, device=dev, generator=gen)
+            zr = torch.randn(B, 256, device=dev, generator=gen)
+            with torch.no_grad():
+                model.decoder(torch.cat([zc, zr], -1), True, None, None, 0., 0.)
+            return (model.decoder.last_xhat.sum().float(),)
+        out = model('train', x, c, pr, tfr1=args.tfr, tfr2=args.tfr, tfr3=args.tfr, beta=0.1, weights=[1, 0.5])
         out[0].backward()
         if sync is not None:
             sync.all_reduce_grads()
@@ -162,12 +173,18 @@ def main():
             roof = {'bound': 'mfma', 'kernel': 'gru_fwd_step_kernel (dec_notes_gru, M=%d H=512)' % (32 * B),
                     'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                     'launches': cnt.value, 'avg_us': round(avg_ms * 1e3, 2), 'traffic': None}
-        res = {'metric': '2-bar piano-roll samples/sec (train step)', 'value': round(value, 1), 'unit': 'samples/s',
+        if args.mode == 'decode':
+            workload = 'configs[3]: free-running PtvaeDecoder sampling (inference_decode), batch=%d, 32x15x(1+5) step loop' % B
+        elif args.tfr >= 1.0:
+            workload = ('configs[1]: 1xMI355X batch=512/GPU, bf16 MFMA GRU/Linear, z_dim=256+256, teacher-forced decoder '
+                        '(tfr=1), fwd+bwd+clip+Adam')
+        else:
+            workload = 'train step with teacher-forcing ratio %.2f (step-loop decoder), batch=%d/GPU, fwd+bwd+clip+Adam' % (args.tfr, B)
+        res = {'metric': '2-bar piano-roll samples/sec (train step)' if args.mode == 'train' else '2-bar piano-roll samples/sec (free-running decode)', 'value': round(value, 1), 'unit': 'samples/s',
                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
-               'config': {'workload': 'configs[1]: 1xMI355X batch=512/GPU, bf16 MFMA GRU/Linear, z_dim=256+256, '
-                                      'teacher-forced decoder (tfr=1), fwd+bwd+clip+Adam',
+               'config': {'workload': workload,
                           'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world},
                'step_tflops': round(value * GFLOP_PER_SAMPLE_TRAIN / 1e3, 2), 'final_loss': round(loss, 4),
                'roofline': roof}

@@ -23,6 +23,17 @@ EMB_GRU = ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0', 'weight_i
            'bias_ih_l0_reverse', 'bias_hh_l0_reverse')
 
 
+_SOS = {}
+
+
+def _sos_grid(dev):
+    """a [1,32,16,6] grid whose every row is <sos> (ptvae.py:315-320); cached so graph capture sees no H2D copy"""
+    k = str(dev)
+    if k not in _SOS:
+        _SOS[k] = torch.tensor([128, 2, 2, 2, 2, 2], dtype=torch.long).view(1, 1, 1, 6).expand(1, 32, 16, 6).contiguous().to(dev)
+    return _SOS[k]
+
+
 def gru_step(prec, hprev, gi, gi_ld, w_hh, b_hh, hout, *, gi2=None, gates=None, plane=0, lengths=None, t=0, gi_idx=None):
     M, H = hout.shape
     call('ptv_gru_step_fwd', prec, M, H, ptr(hprev), hprev.stride(0), ptr(gi), gi_ld, ptr(gi2),
@@ -81,7 +92,7 @@ class DecoderStepFn(torch.autograd.Function):
         XG = ([_zeros(16, 4, R, He, dev=dev) for _ in range(2)] if train else [None, None]) if need_resum else None
 
         if inference:
-            sos = torch.tensor([[128, 2, 2, 2, 2, 2]], device=dev, dtype=torch.long).view(1, 1, 1, 6).expand(1, 32, 16, 6).contiguous()
+            sos = _sos_grid(dev)
             sos_emb = _empty(16, 32, 1, E, dev=dev)
             call('ptv_embed_fwd', ptr(sos), ptr(w_emb), ptr(b_emb), ptr(sos_emb), None, 1, E, st)
             sos_row = sos_emb.view(-1, E)[0:1]

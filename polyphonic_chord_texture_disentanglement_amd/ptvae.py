@@ -237,12 +237,39 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
         self.force_dur_idx = None          # [5, 480*B] int32: replay the oracle's duration argmaxes (tests)
         self.force_trace = None            # {'pitch': [15, 32B] int32, 'dur': [5, 480B] int32}: replay mode (tests)
         self.last_xhat = None              # predicted grid [B,32,16,6] int64 of the last step-loop decode
+        self.use_graph = False             # replay inference decodes from a captured hipGraph
+        self._graphs = {}
         self._summary = None
         self.last_dur_idx = None
 
     def _params(self):
         sd = dict(self.named_parameters())
         return [sd[n] for n in F_.DEC_PARAM_NAMES]
+
+    def _graph_decode(self, z, coins):
+        """Free-running decode replayed from a captured hipGraph: the step loop is ~9,000 tiny launches whose
+        order and arguments depend only on (B, precision) -- capture once, then one graph launch per call.
+        The graph holds raw parameter pointers, so it is re-captured if the parameter storage moves."""
+        ps = self._params_free()
+        key = (z.shape[0], self._prec, z.device.index, tuple(p.data_ptr() for p in ps))
+        ent = self._graphs.get(key)
+        if ent is None:
+            static_z = z.detach().clone()
+            cur = torch.cuda.current_stream()
+            s = torch.cuda.Stream(device=z.device)
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):                         # warm-up outside capture (lazy inits, allocator)
+                FF_.DecoderStepFn.apply(static_z, None, None, coins, True, None, self._prec, *ps)
+            cur.wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs = FF_.DecoderStepFn.apply(static_z, None, None, coins, True, None, self._prec, *ps)
+            self._graphs.clear()
+            ent = self._graphs[key] = (g, static_z, outs)
+        g, static_z, outs = ent
+        static_z.copy_(z)
+        g.replay()
+        return outs
 
     def _params_free(self):
         sd = dict(self.named_parameters())
@@ -284,8 +311,11 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
             assert x is None and lengths is None
             assert teacher_forcing_ratio1 == 0 and teacher_forcing_ratio2 == 0
             coins = ([[False] * (self.max_simu_note - 2)] * self.num_step, [False] * (self.num_step - 1))
-            pitch, dur, xhat, idx = FF_.DecoderStepFn.apply(z, None, None, coins, True, self.force_trace, self._prec,
-                                                            *self._params_free())
+            if self.use_graph and not torch.is_grad_enabled() and self.force_trace is None:
+                pitch, dur, xhat, idx = self._graph_decode(z, coins)
+            else:
+                pitch, dur, xhat, idx = FF_.DecoderStepFn.apply(z, None, None, coins, True, self.force_trace, self._prec,
+                                                                *self._params_free())
             self.last_dur_idx, self.last_xhat = idx, xhat
             return pitch.permute(2, 1, 0, 3), dur.view(15, 32, B, 5, 2).permute(2, 1, 0, 3, 4)
         if coins is None:

@@ -261,3 +261,15 @@ def test_full_free_running_vs_reference_golden(monkeypatch):
     tot = sum(float(p.grad.double().pow(2).sum()) for p in m.parameters()) ** 0.5
     ref = sum(float(g['gnorm.' + k]) ** 2 for k, _ in m.named_parameters()) ** 0.5
     assert abs(tot - ref) < 0.02 * ref
+
+
+def test_graph_replayed_decode_equals_eager():
+    g = load_npz('reduced_infer.npz')
+    m = build_reduced(DEV).to(DEV)
+    zc, zr = torch.from_numpy(g['z_chd']).to(DEV), torch.from_numpy(g['z_rhy']).to(DEV)
+    eager = m.inference_decode(zc, zr)
+    m.decoder.use_graph = True
+    first = m.inference_decode(zc, zr)                 # captures
+    again = m.inference_decode(zc.flip(0), zr.flip(0))  # replays with new latent codes
+    assert np.array_equal(eager, first)
+    assert np.array_equal(eager[::-1], again)
