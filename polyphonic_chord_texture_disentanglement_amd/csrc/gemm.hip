@@ -18,10 +18,10 @@ struct EpiPlain {
     int atomic;       // split-K partial sums: atomicAdd into C (C pre-initialised)
   };
   template <int FM, int FN, int NG>
-  static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], int m0, int n0, int M, int N) {
+  static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], int m0, int n0, int M, int N, int split) {
     const int lane = threadIdx.x & 63;
     const bool vec = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
-    const bool use_bias = p.bias != nullptr && blockIdx.z == 0;
+    const bool use_bias = p.bias != nullptr && split == 0;
 #pragma unroll
     for (int i = 0; i < FM; i++) {
       const int m = m0 + i * 16 + (lane & 15);
@@ -93,8 +93,14 @@ static int gemm_dispatch(int transA, int transB, GemmArgs g, EpiPlain::Params ep
   }
   int kper = g.K;
   if (splits > 1) {
+    if (splits >= 8) splits = (splits + 7) / 8 * 8;            // whole splits per XCD (gemm_body's block map)
     kper = cdiv(cdiv(g.K, splits), CT::BK) * CT::BK;
-    splits = cdiv(g.K, kper);
+    const int s2 = cdiv(g.K, kper);
+    if (s2 != splits && (s2 & 7) != 0 && s2 >= 8) {            // keep a multiple of 8 after rounding kper up
+      splits = s2 / 8 * 8;
+      kper = cdiv(cdiv(g.K, splits), CT::BK) * CT::BK;
+      splits = cdiv(g.K, kper);
+    } else splits = s2;
   }
   g.k_per_split = kper;
   if (splits > 1) {

@@ -265,8 +265,37 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
   __shared__ __attribute__((aligned(16))) T As[BM * CT::LDS_LD];
   __shared__ __attribute__((aligned(16))) T Bs[BROWS * CT::LDS_LD];
 
-  const int m_blk = blockIdx.y * BM, n_blk = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * g.k_per_split;
+  // Block -> (m tile, n tile, K split), XCD-aware.  Blocks are dispatched round-robin over the 8 XCDs
+  // (block id % 8; speed only, never correctness -- MI355X_MICROARCH.md), each with a private 4 MB L2:
+  //  * no K split: XCD x owns the m tiles = x (mod 8) and walks them n-fastest, so the n tiles that
+  //    re-read one A row panel run back-to-back on ONE XCD (the big activation operand crosses the
+  //    fabric once and is still in that L2 when its next n tile starts)
+  //  * K splits (weight gradients): a whole split -- every tile that re-reads the same K slab of both
+  //    operands -- is pinned to one XCD
+  const int ntn = gridDim.x, ntm = gridDim.y, nsp = gridDim.z;
+  const int bid = blockIdx.x + ntn * (blockIdx.y + ntm * blockIdx.z);
+  const int per = ntm * ntn;
+  int mt, nt, split;
+  if (nsp > 1 && (nsp & 7) == 0) {
+    const int slot = bid >> 3;
+    split = (bid & 7) + 8 * (slot / per);
+    const int tile = slot % per;
+    mt = tile / ntn; nt = tile % ntn;
+  } else if (nsp == 1 && g.M >= g.N && (ntm & 7) == 0) {       // A is the big operand: pin its row panels
+    const int slot = bid >> 3;
+    split = 0;
+    mt = (slot / ntn) * 8 + (bid & 7); nt = slot % ntn;
+  } else if (nsp == 1 && g.M < g.N && (ntn & 7) == 0) {        // B (weights) is the big operand: pin its panels
+    const int slot = bid >> 3;
+    split = 0;
+    nt = (slot / ntm) * 8 + (bid & 7); mt = slot % ntm;
+  } else {
+    split = bid / per;
+    const int tile = bid % per;
+    mt = tile / ntn; nt = tile % ntn;
+  }
+  const int m_blk = mt * BM, n_blk = nt * BN;
+  const int kbeg = split * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
   const int wave = threadIdx.x >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
@@ -323,7 +352,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
     TileMma<CT, FM, NG * FN>::run(As, wm * WTM, Bs,
                                   [&](int j) { return (j / FN) * BN + wn * WTN + (j % FN) * 16; }, acc);
   }
-  Epi::template apply<FM, FN, NG>(ep, acc, m_blk + wm * WTM, n_blk + wn * WTN, g.M, g.N);
+  Epi::template apply<FM, FN, NG>(ep, acc, m_blk + wm * WTM, n_blk + wn * WTN, g.M, g.N, split);
 }
 
 }  // namespace ptv

@@ -28,7 +28,7 @@ struct EpiGruFwd {
     int H;
   };
   template <int FM, int FN, int NG>
-  static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], int m0, int j0, int M, int H) {
+  static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], int m0, int j0, int M, int H, int split) {
     static_assert(NG == 3, "GRU epilogue needs the three gates");
     const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -99,7 +99,7 @@ struct EpiGruBwd {
     int H;
   };
   template <int FM, int FN, int NG>
-  static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], int m0, int j0, int M, int H) {
+  static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], int m0, int j0, int M, int H, int split) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int i = 0; i < FM; i++) {
