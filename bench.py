@@ -81,8 +81,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        ndev = torch.cuda.device_count()
+        backend = os.environ.get('PTV_DIST_BACKEND', 'nccl')     # 'gloo' lets a 1-GPU box exercise the N>1 flow
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
+        local_rank = local_rank % max(ndev, 1)
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
