@@ -25,6 +25,17 @@ extern "C" {
 #define PTV_PREC_F32 0
 #define PTV_PREC_BF16 1
 
+/* dtype bits of ptv_gemm: operands / result held as bf16 in HBM (bf16 precision only).  In bf16 mode
+ * tensors that only ever feed MFMA operands are kept as bf16: half the traffic, no conversion. */
+#define PTV_A_BF16 1
+#define PTV_B_BF16 2
+#define PTV_C_BF16 4
+/* dtype bits of the GRU entry points */
+#define PTV_GRU_GATES_BF16 1   /* saved gate planes */
+#define PTV_GRU_GI_BF16 2      /* gi */
+#define PTV_GRU_GI2_BF16 4     /* gi2 */
+#define PTV_GRU_DG_BF16 8      /* dgi / dgh (backward) */
+
 /* Library / build identification ("gfx950"). */
 const char* ptv_arch(void);
 int ptv_abi_version(void);
@@ -39,9 +50,9 @@ int ptv_abi_version(void);
  *   splitk: 0 auto, >0 forced number of K splits, <0 never split
  */
 int ptv_gemm(int prec, int transA, int transB, int M, int N, int K,
-             const float* A, long lda, const float* B, long ldb,
-             float* C, long ldc, const float* bias, float alpha,
-             int accumulate, int act, int splitk, void* stream);
+             const void* A, long lda, const void* B, long ldb,
+             void* C, long ldc, const float* bias, float alpha,
+             int accumulate, int act, int splitk, int dtypes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GRU recurrence over T steps for M independent rows (torch.nn.GRU cell semantics; replaces the
@@ -57,21 +68,21 @@ int ptv_gemm(int prec, int transA, int transB, int M, int N, int K,
  *                 one-hot token, so W_i x + b_i is a 2-row table indexed by the previous argmax)
  */
 int ptv_gru_seq_fwd(int prec, int M, int H, int T,
-                    const float* gi, long gi_step_stride, long gi_ld,
-                    const float* gi2, long gi2_step_stride, long gi2_ld,
+                    const void* gi, long gi_step_stride, long gi_ld,
+                    const void* gi2, long gi2_step_stride, long gi2_ld,
                     const float* w_hh, const float* b_hh,
-                    float* hall, float* gates,
-                    const int* lengths, int reverse, const int* gi_idx, void* stream);
+                    float* hall, void* gates,
+                    const int* lengths, int reverse, const int* gi_idx, int flags, void* stream);
 
 /* One GRU cell step with explicit strides (same kernel as ptv_gru_seq_fwd, T = 1): the free-running
  * decoder (ptvae.py:395-424,460-486) advances a [B]-row window of the step-major buffers per step. */
 int ptv_gru_step_fwd(int prec, int M, int H,
                      const float* hprev, long ld_hprev,
-                     const float* gi, long gi_ld, const float* gi2, long gi2_ld,
+                     const void* gi, long gi_ld, const void* gi2, long gi2_ld,
                      const float* w_hh, const float* b_hh,
                      float* hout, long ld_hout,
-                     float* gates, long gates_plane,
-                     const int* lengths, int t, const int* gi_idx, void* stream);
+                     void* gates, long gates_plane,
+                     const int* lengths, int t, const int* gi_idx, int flags, void* stream);
 
 /* BPTT through ptv_gru_seq_fwd (replaces autograd through the same call sites).
  *   dh_ext [T] x [M,H]  gradient arriving at the state after processing step s (may be NULL)
@@ -83,12 +94,12 @@ int ptv_gru_step_fwd(int prec, int M, int H,
  * Weight gradients follow with ptv_gemm(transA=1,transB=1): dW_hh += dgh^T.hall[0:T], dW_ih += dgi^T.x
  */
 int ptv_gru_seq_bwd(int prec, int M, int H, int T,
-                    const float* hall, const float* gates, const float* w_hh,
+                    const float* hall, const void* gates, const float* w_hh,
                     const float* dh_ext, long ext_step_stride, long ext_ld,
                     const float* dh_last, long last_ld,
                     const float* lr_a, long lr_step_stride, long lr_lda, int lr_k, const float* lr_b,
-                    float* dgi, float* dgh, float* dhz, float* dh0,
-                    int reverse, void* stream);
+                    void* dgi, void* dgh, float* dhz, float* dh0,
+                    int reverse, int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Streaming helpers (layout shuffles and reductions that torch would do with cat/transpose/sum).
@@ -99,10 +110,10 @@ int ptv_copy2d(float* dst, long ldd, const float* src, long lds, long rows, int 
 /* [D0,D1,W] -> [D1,D0,W]  (batch-major API tensors <-> step-major internal layout) */
 int ptv_transpose01(float* dst, const float* src, int D0, int D1, int W, void* stream);
 /* out[i] = (accumulate ? out[i] : 0) + sum_t in[t*stride + i] */
-int ptv_sum_steps(float* out, const float* in, long n, int T, long stride, int accumulate, void* stream);
+int ptv_sum_steps(float* out, const void* in, long n, int T, long stride, int accumulate, int in_bf16, void* stream);
 /* out[g*N + n] += sum over rows r with (sel ? sel[r] : 0) == g of A[r*lda + n]   (bias gradients;
  * with sel: the duration GRU's W_ih gradient, whose inputs are one-hot tokens) */
-int ptv_colsum(float* out, const float* A, long lda, long rows, int N, const int* sel, int G, void* stream);
+int ptv_colsum(float* out, const void* A, long lda, long rows, int N, const int* sel, int G, int a_bf16, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Note embedding as a gather: PtvaeDecoder.emb_x (ptvae.py:531-535) = get_len_index_tensor

@@ -80,7 +80,7 @@ def prec_code(p):
 def ptr(t):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.int64, torch.uint8), \
+    assert t.is_cuda and t.dtype in (torch.float32, torch.bfloat16, torch.int32, torch.int64, torch.uint8), \
         'device fp32/int tensor expected, got %s %s' % (t.device, t.dtype)
     return ctypes.c_void_p(t.data_ptr())
 

@@ -3,6 +3,7 @@
 // All are simple streaming kernels: coalesced 4-byte/16-byte accesses, grid-stride loops,
 // wave-shuffle + LDS reductions, one atomic per block where a cross-block sum is needed.
 #include "common.hpp"
+#include "gemm_core.hpp"
 #include "../../include/ptvae_hip.h"
 
 namespace ptv {
@@ -35,10 +36,10 @@ __global__ void transpose01_kernel(float* dst, const float* src, int D0, int D1,
 }
 
 // out[i] = (accumulate? out[i] : 0) + sum_t in[t*stride + i]
-__global__ void sum_steps_kernel(float* out, const float* in, long n, int T, long stride, int accumulate) {
+__global__ void sum_steps_kernel(float* out, const void* in, long n, int T, long stride, int accumulate, int in_bf16) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float s = accumulate ? out[i] : 0.f;
-    for (int t = 0; t < T; t++) s += in[t * stride + i];
+    for (int t = 0; t < T; t++) s += ld1f(in, t * stride + i, in_bf16);
     out[i] = s;
   }
 }
@@ -46,7 +47,7 @@ __global__ void sum_steps_kernel(float* out, const float* in, long n, int T, lon
 // out[g*N + n] += sum_{rows r with (sel ? sel[r] : 0) == g} A[r*lda + n]   (G <= 2; block partial + atomics)
 // block = 256 threads = 16 column quads (64 columns, 16-byte loads) x 16 row lanes
 template <bool VEC>
-__global__ void colsum_kernel(float* out, const float* __restrict__ A, long lda, long rows, int N, const int* __restrict__ sel, int G) {
+__global__ void colsum_kernel(float* out, const void* __restrict__ A, long lda, long rows, int N, const int* __restrict__ sel, int G, int bf) {
   __shared__ float red[2][16][64];
   const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
   const int n = blockIdx.x * 64 + cq * 4;
@@ -58,10 +59,10 @@ __global__ void colsum_kernel(float* out, const float* __restrict__ A, long lda,
     for (long r = r0 + ry; r < r1; r += 16) {
       const int g = sel ? sel[r] : 0;
       float4 v;
-      if (VEC) v = *reinterpret_cast<const float4*>(A + r * lda + n);
+      if (VEC) v = ld4f(A, r * lda + n, bf);
       else {
-        v.x = A[r * lda + n]; v.y = n + 1 < N ? A[r * lda + n + 1] : 0.f;
-        v.z = n + 2 < N ? A[r * lda + n + 2] : 0.f; v.w = n + 3 < N ? A[r * lda + n + 3] : 0.f;
+        v.x = ld1f(A, r * lda + n, bf); v.y = n + 1 < N ? ld1f(A, r * lda + n + 1, bf) : 0.f;
+        v.z = n + 2 < N ? ld1f(A, r * lda + n + 2, bf) : 0.f; v.w = n + 3 < N ? ld1f(A, r * lda + n + 3, bf) : 0.f;
       }
       if (g == 0) { s[0][0] += v.x; s[0][1] += v.y; s[0][2] += v.z; s[0][3] += v.w; }
       else if (g == 1) { s[1][0] += v.x; s[1][1] += v.y; s[1][2] += v.z; s[1][3] += v.w; }
@@ -188,22 +189,22 @@ extern "C" int ptv_transpose01(float* dst, const float* src, int D0, int D1, int
   return PTV_OK;
 }
 
-extern "C" int ptv_sum_steps(float* out, const float* in, long n, int T, long stride, int accumulate, void* stream) {
+extern "C" int ptv_sum_steps(float* out, const void* in, long n, int T, long stride, int accumulate, int in_bf16, void* stream) {
   if (!out || !in || n <= 0 || T <= 0) return PTV_ERR_ARG;
-  hipLaunchKernelGGL(sum_steps_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, in, n, T, stride, accumulate);
+  hipLaunchKernelGGL(sum_steps_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, in, n, T, stride, accumulate, in_bf16);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
 
-extern "C" int ptv_colsum(float* out, const float* A, long lda, long rows, int N, const int* sel, int G, void* stream) {
+extern "C" int ptv_colsum(float* out, const void* A, long lda, long rows, int N, const int* sel, int G, int a_bf16, void* stream) {
   if (!out || !A || rows < 0 || N <= 0 || G <= 0 || G > 2) return PTV_ERR_ARG;
   if (rows == 0) return PTV_OK;
   int gx = cdiv(N, 64);
   long want = 2048 / gx; if (want < 1) want = 1;                 // ~2048 blocks in flight
   long gy = (rows + 63) / 64; if (gy > want) gy = want; if (gy < 1) gy = 1;
-  const bool vec = ((lda & 3) == 0) && ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-  if (vec) hipLaunchKernelGGL((colsum_kernel<true>), dim3(gx, (int)gy), dim3(256), 0, (hipStream_t)stream, out, A, lda, rows, N, sel, G);
-  else hipLaunchKernelGGL((colsum_kernel<false>), dim3(gx, (int)gy), dim3(256), 0, (hipStream_t)stream, out, A, lda, rows, N, sel, G);
+  const bool vec = ((lda & 3) == 0) && ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & (a_bf16 ? 7 : 15)) == 0);
+  if (vec) hipLaunchKernelGGL((colsum_kernel<true>), dim3(gx, (int)gy), dim3(256), 0, (hipStream_t)stream, out, A, lda, rows, N, sel, G, a_bf16);
+  else hipLaunchKernelGGL((colsum_kernel<false>), dim3(gx, (int)gy), dim3(256), 0, (hipStream_t)stream, out, A, lda, rows, N, sel, G, a_bf16);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

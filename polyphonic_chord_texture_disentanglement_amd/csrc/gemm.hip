@@ -10,17 +10,19 @@ namespace ptv {
 // C[m,n] = act(alpha*acc + bias[n]) (+ C[m,n] when accumulate); atomic adds when split-K
 struct EpiPlain {
   struct Params {
-    float* C; long ldc;
+    void* C; long ldc;
     const float* bias;
     float alpha;
     int accumulate;   // C += ...
     int act;          // 0 none, 1 exp
-    int atomic;       // split-K partial sums: atomicAdd into C (C pre-initialised)
+    int atomic;       // split-K partial sums: atomicAdd into C (C pre-initialised, fp32 only)
+    int c_bf16;       // C holds bf16
   };
   template <int FM, int FN, int NG>
   static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], int m0, int n0, int M, int N, int split) {
     const int lane = threadIdx.x & 63;
-    const bool vec = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
+    const bool bf = p.c_bf16 != 0;
+    const bool vec = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & (bf ? 7 : 15)) == 0);
     const bool use_bias = p.bias != nullptr && split == 0;
 #pragma unroll
     for (int i = 0; i < FM; i++) {
@@ -37,26 +39,26 @@ struct EpiPlain {
           if (use_bias && n + e < N) v[e] += p.bias[n + e];
           if (p.act == 1) v[e] = expf(v[e]);
         }
-        float* c = p.C + (long)m * p.ldc + n;
+        const long off = (long)m * p.ldc + n;
         if (p.atomic) {
+          float* c = reinterpret_cast<float*>(p.C) + off;
 #pragma unroll
           for (int e = 0; e < 4; e++) if (n + e < N) atomicAdd(c + e, v[e]);
         } else if (vec && n + 3 < N) {
-          float4 o = make_float4(v[0], v[1], v[2], v[3]);
-          if (p.accumulate) { float4 q = *reinterpret_cast<float4*>(c); o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
-          *reinterpret_cast<float4*>(c) = o;
+          if (p.accumulate) { const float4 q = ld4f(p.C, off, bf); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
+          st4f(p.C, off, bf, v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; e++) if (n + e < N) c[e] = p.accumulate ? c[e] + v[e] : v[e];
+          for (int e = 0; e < 4; e++) if (n + e < N) st1f(p.C, off + e, bf, p.accumulate ? ld1f(p.C, off + e, bf) + v[e] : v[e]);
         }
       }
     }
   }
 };
 
-template <class CT, int BM, int BN, int WGM, int WGN, bool KA, bool KB>
+template <class CT, int BM, int BN, int WGM, int WGN, bool KA, bool KB, bool SA, bool SB>
 __global__ __launch_bounds__(NTHREADS) void gemm_plain_kernel(GemmArgs g, EpiPlain::Params ep) {
-  gemm_body<CT, BM, BN, WGM, WGN, 1, KA, KB, EpiPlain>(g, ep);
+  gemm_body<CT, BM, BN, WGM, WGN, 1, KA, KB, EpiPlain, SA, SB>(g, ep);
 }
 
 __global__ void fill_rows_kernel(float* C, long ldc, int M, int N, float v) {
@@ -65,13 +67,13 @@ __global__ void fill_rows_kernel(float* C, long ldc, int M, int N, float v) {
   for (; i < total; i += (long)gridDim.x * blockDim.x) C[(i / N) * ldc + (i % N)] = v;
 }
 
-template <class CT, int BM, int BN, bool KA, bool KB>
+template <class CT, int BM, int BN, bool KA, bool KB, bool SA, bool SB>
 static void launch_plain(const GemmArgs& g, const EpiPlain::Params& ep, int splits, hipStream_t s) {
   dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), splits);
-  hipLaunchKernelGGL((gemm_plain_kernel<CT, BM, BN, 2, 2, KA, KB>), grid, dim3(NTHREADS), 0, s, g, ep);
+  hipLaunchKernelGGL((gemm_plain_kernel<CT, BM, BN, 2, 2, KA, KB, SA, SB>), grid, dim3(NTHREADS), 0, s, g, ep);
 }
 
-template <class CT>
+template <class CT, bool SA, bool SB>
 static int gemm_dispatch(int transA, int transB, GemmArgs g, EpiPlain::Params ep, int splitk, hipStream_t s) {
   // tile choice: 128x128 when it still yields >= ~1 block per CU, else 64x64.  Weight-gradient
   // products (transA: K = rows x steps is huge, M x N small) fill the chip with K splits; the
@@ -83,7 +85,7 @@ static int gemm_dispatch(int transA, int transB, GemmArgs g, EpiPlain::Params ep
   long blocks = (long)cdiv(g.M, bm) * cdiv(g.N, bm);
   int splits = 1;
   if (splitk > 0) splits = splitk;
-  else if (splitk == 0 && blocks < 256 && g.K >= 8 * CT::BK && ep.act == 0) {
+  else if (splitk == 0 && blocks < 256 && g.K >= 8 * CT::BK && ep.act == 0 && !ep.c_bf16) {
     const long target = deepk ? (big ? 640 : 1536) : 512;
     splits = (int)((target + blocks - 1) / blocks);
     int maxs = g.K / (4 * CT::BK);
@@ -108,13 +110,13 @@ static int gemm_dispatch(int transA, int transB, GemmArgs g, EpiPlain::Params ep
     if (!ep.accumulate) {
       long total = (long)g.M * g.N;
       int nb = (int)((total + 255) / 256); if (nb > 2048) nb = 2048;
-      hipLaunchKernelGGL(fill_rows_kernel, dim3(nb), dim3(256), 0, s, ep.C, ep.ldc, g.M, g.N, 0.f);
+      hipLaunchKernelGGL(fill_rows_kernel, dim3(nb), dim3(256), 0, s, reinterpret_cast<float*>(ep.C), ep.ldc, g.M, g.N, 0.f);
     }
   }
 #define PTV_LAUNCH(KA, KB)                                              \
   do {                                                                  \
-    if (big) launch_plain<CT, 128, 128, KA, KB>(g, ep, splits, s);      \
-    else launch_plain<CT, 64, 64, KA, KB>(g, ep, splits, s);            \
+    if (big) launch_plain<CT, 128, 128, KA, KB, SA, SB>(g, ep, splits, s);      \
+    else launch_plain<CT, 64, 64, KA, KB, SA, SB>(g, ep, splits, s);            \
   } while (0)
   if (!transA && !transB) PTV_LAUNCH(false, false);
   else if (!transA && transB) PTV_LAUNCH(false, true);
@@ -127,16 +129,23 @@ static int gemm_dispatch(int transA, int transB, GemmArgs g, EpiPlain::Params ep
 }  // namespace ptv
 
 extern "C" int ptv_gemm(int prec, int transA, int transB, int M, int N, int K,
-                        const float* A, long lda, const float* B, long ldb,
-                        float* C, long ldc, const float* bias, float alpha,
-                        int accumulate, int act, int splitk, void* stream) {
+                        const void* A, long lda, const void* B, long ldb,
+                        void* C, long ldc, const float* bias, float alpha,
+                        int accumulate, int act, int splitk, int dtypes, void* stream) {
   if (M < 0 || N < 0 || K < 0 || !A || !B || !C) return PTV_ERR_ARG;
   if (M == 0 || N == 0) return PTV_OK;
+  const bool sa = dtypes & 1, sb = dtypes & 2, sc = dtypes & 4;
+  if ((sa || sb) && prec != PTV_PREC_BF16) return PTV_ERR_ARG;       // bf16 operands feed the bf16 MFMA path only
+  if (sc && splitk > 1) return PTV_ERR_ARG;                          // split-K accumulates with fp32 atomics
   ptv::GemmArgs g{A, lda, B, ldb, M, N, K, K, 0};
-  ptv::EpiPlain::Params ep{C, ldc, bias, alpha, accumulate, act, 0};
+  ptv::EpiPlain::Params ep{C, ldc, bias, alpha, accumulate, act, 0, sc ? 1 : 0};
   hipStream_t s = (hipStream_t)stream;
-  int rc = (prec == PTV_PREC_BF16) ? ptv::gemm_dispatch<ptv::BF16>(transA, transB, g, ep, splitk, s)
-                                   : ptv::gemm_dispatch<ptv::F32>(transA, transB, g, ep, splitk, s);
+  int rc;
+  if (prec != PTV_PREC_BF16) rc = ptv::gemm_dispatch<ptv::F32, false, false>(transA, transB, g, ep, splitk, s);
+  else if (sa && sb) rc = ptv::gemm_dispatch<ptv::BF16, true, true>(transA, transB, g, ep, splitk, s);
+  else if (sa) rc = ptv::gemm_dispatch<ptv::BF16, true, false>(transA, transB, g, ep, splitk, s);
+  else if (sb) rc = ptv::gemm_dispatch<ptv::BF16, false, true>(transA, transB, g, ep, splitk, s);
+  else rc = ptv::gemm_dispatch<ptv::BF16, false, false>(transA, transB, g, ep, splitk, s);
   if (rc != PTV_OK) return rc;
   PTV_CHECK_LAUNCH();
   return PTV_OK;

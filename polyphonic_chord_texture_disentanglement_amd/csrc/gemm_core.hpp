@@ -18,6 +18,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace ptv {
 
@@ -26,6 +27,29 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int NTHREADS = 256;
+
+// 4 consecutive elements of an fp32 or bf16 array (runtime dtype flag; epilogue traffic in bf16 mode)
+__device__ __forceinline__ float4 ld4f(const void* p, long i, bool bf) {
+  if (bf) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p) + i);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  }
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i);
+}
+__device__ __forceinline__ void st4f(void* p, long i, bool bf, float a, float b, float c, float d) {
+  if (bf) {
+    bf16x4 v; v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p) + i) = v;
+  } else {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + i) = make_float4(a, b, c, d);
+  }
+}
+__device__ __forceinline__ float ld1f(const void* p, long i, bool bf) {
+  return bf ? (float)reinterpret_cast<const __bf16*>(p)[i] : reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void st1f(void* p, long i, bool bf, float v) {
+  if (bf) reinterpret_cast<__bf16*>(p)[i] = (__bf16)v; else reinterpret_cast<float*>(p)[i] = v;
+}
 
 struct BF16 {
   using T = __bf16;
@@ -41,8 +65,8 @@ struct F32 {
 };
 
 struct GemmArgs {
-  const float* A; long lda;   // KMAJOR_A ? A[k*lda + m] : A[m*lda + k]
-  const float* B; long ldb;   // KMAJOR_B ? B[k*ldb + n] : B[n*ldb + k]
+  const void* A; long lda;    // KMAJOR_A ? A[k*lda + m] : A[m*lda + k]   (fp32, or bf16 when the kernel's SA is set)
+  const void* B; long ldb;    // KMAJOR_B ? B[k*ldb + n] : B[n*ldb + k]
   int M, N, K;
   int k_per_split;            // K range handled by one blockIdx.z (multiple of BK); == K when no split
   long gate_stride;           // NG==3: B row of gate g, unit j is g*gate_stride + j   (N = #units)
@@ -60,12 +84,17 @@ template <class CT> __device__ __forceinline__ int swz(int row, int k) {
 // ---------------------------------------------------------------------------------------------
 // tile staging
 // ---------------------------------------------------------------------------------------------
-// one 16-byte LDS chunk = CT::CH consecutive k of one row, converted from fp32
-template <class CT> struct Chunk;
-template <> struct Chunk<BF16> {
+// one 16-byte LDS chunk = CT::CH consecutive k of one row.  SB = the HBM source already holds bf16
+// (activations / gradients that only ever feed MFMA operands are kept as bf16 copies in bf16 mode:
+// half the operand traffic, no conversion while staging); otherwise fp32 converted on the way.
+template <bool SB> struct SrcT { using T = float; };
+template <> struct SrcT<true> { using T = __bf16; };
+
+template <class CT, bool SB> struct Chunk;
+template <> struct Chunk<BF16, false> {
   float4 lo, hi;                                   // k .. k+7
   __device__ __forceinline__ void zero() { lo = hi = make_float4(0.f, 0.f, 0.f, 0.f); }
-  __device__ __forceinline__ float& at(int e) { return e < 4 ? (&lo.x)[e] : (&hi.x)[e - 4]; }
+  __device__ __forceinline__ void set(int e, float x) { if (e < 4) (&lo.x)[e] = x; else (&hi.x)[e - 4] = x; }
   __device__ __forceinline__ void load16(const float* q) { lo = *reinterpret_cast<const float4*>(q); hi = *reinterpret_cast<const float4*>(q + 4); }
   __device__ __forceinline__ void store(__bf16* d) const {
     bf16x8 v;
@@ -74,28 +103,35 @@ template <> struct Chunk<BF16> {
     *reinterpret_cast<bf16x8*>(d) = v;
   }
 };
-template <> struct Chunk<F32> {
+template <> struct Chunk<BF16, true> {
+  bf16x8 v;
+  __device__ __forceinline__ void zero() { for (int e = 0; e < 8; e++) v[e] = (__bf16)0.f; }
+  __device__ __forceinline__ void set(int e, __bf16 x) { v[e] = x; }
+  __device__ __forceinline__ void load16(const __bf16* q) { v = *reinterpret_cast<const bf16x8*>(q); }
+  __device__ __forceinline__ void store(__bf16* d) const { *reinterpret_cast<bf16x8*>(d) = v; }
+};
+template <> struct Chunk<F32, false> {
   float4 lo;
   __device__ __forceinline__ void zero() { lo = make_float4(0.f, 0.f, 0.f, 0.f); }
-  __device__ __forceinline__ float& at(int e) { return (&lo.x)[e]; }
+  __device__ __forceinline__ void set(int e, float x) { (&lo.x)[e] = x; }
   __device__ __forceinline__ void load16(const float* q) { lo = *reinterpret_cast<const float4*>(q); }
   __device__ __forceinline__ void store(float* d) const { *reinterpret_cast<float4*>(d) = lo; }
 };
 
 // K-contiguous source: tile ROWS x BK, one 16-byte LDS chunk per thread per pass.
 //   8 threads cover a row (BK = 8 chunks), RPP = 32 rows per pass.
-// `ROWU(i)` = global row of tile row i*RPP (block-uniform); thread row offsets are added on top.
-template <class CT, int ROWS>
+template <class CT, int ROWS, bool SB>
 struct StageKC {
+  using S = typename SrcT<SB>::T;
   static constexpr int CPR = 8;                     // chunks per row
   static constexpr int RPP = NTHREADS / CPR;        // 32 rows per pass
   static constexpr int NP = ROWS / RPP;
   static_assert(ROWS % RPP == 0, "tile rows must be a multiple of 32");
-  Chunk<CT> v[NP];
+  Chunk<CT, SB> v[NP];
 
   // general path: bounds-checked, any alignment
   template <class RowMap>
-  __device__ __forceinline__ void load(const float* __restrict__ p, long ld, int k0, int kend, bool vec_ok, RowMap rowmap) {
+  __device__ __forceinline__ void load(const S* __restrict__ p, long ld, int k0, int kend, bool vec_ok, RowMap rowmap) {
     const int tid = threadIdx.x;
     const int c = tid % CPR, r0 = tid / CPR;
     const int k = k0 + c * CT::CH;
@@ -104,11 +140,11 @@ struct StageKC {
       v[i].zero();
       const long g = rowmap(r0 + i * RPP);
       if (g >= 0) {
-        const float* q = p + g * ld + k;
+        const S* q = p + g * ld + k;
         if (vec_ok && k + CT::CH <= kend) v[i].load16(q);
         else {
 #pragma unroll
-          for (int e = 0; e < CT::CH; e++) if (k + e < kend) v[i].at(e) = q[e];
+          for (int e = 0; e < CT::CH; e++) if (k + e < kend) v[i].set(e, q[e]);
         }
       }
     }
@@ -117,7 +153,7 @@ struct StageKC {
   // (SGPR) + one 32-bit per-thread offset.  (A branchy loader makes hipcc wait for every load before
   // the next branch: nothing pipelines.)
   template <class RowU>
-  __device__ __forceinline__ void load_fast(const float* __restrict__ p, long ld, int k0, RowU rowu) {
+  __device__ __forceinline__ void load_fast(const S* __restrict__ p, long ld, int k0, RowU rowu) {
     const int tid = threadIdx.x;
     const unsigned toff = (unsigned)((tid / CPR) * ld + (tid % CPR) * CT::CH);
 #pragma unroll
@@ -131,10 +167,10 @@ struct StageKC {
   }
 };
 
-// K-major source: element (r, k) at p[k*ld + r].  Work item = CH k x 4 r register block -> four
+// K-major fp32 source: element (r, k) at p[k*ld + r].  Work item = CH k x 4 r register block -> four
 // 16-byte LDS chunks (rows r..r+3).  8 adjacent lanes cover 8 row groups (one 128-byte line per k row),
 // the next lanes walk the 8 k-chunks.
-template <class CT, int ROWS>
+template <class CT, int ROWS, bool SB>
 struct StageKM {
   static constexpr int RG = ROWS / 4;                  // row groups
   static constexpr int ITEMS = RG * 8;                 // x 8 k-chunks
@@ -186,11 +222,65 @@ struct StageKM {
       const int rg = (w & 7) + 8 * (w >> 6), kc = (w >> 3) & 7;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        Chunk<CT> c;
+        Chunk<CT, false> c;
 #pragma unroll
-        for (int kk = 0; kk < CT::CH; kk++) c.at(kk) = (&v[i][kk].x)[j];
+        for (int kk = 0; kk < CT::CH; kk++) c.set(kk, (&v[i][kk].x)[j]);
         c.store(s + swz<CT>(rg * 4 + j, kc * CT::CH));
       }
+    }
+  }
+};
+
+// K-major bf16 source: work item = 8 k x 8 r block of bf16 (eight 16-byte loads, one per k row) ->
+// eight LDS chunks (rows r..r+7).  LW adjacent lanes cover LW row groups (up to a 128-byte line per k row).
+template <int ROWS>
+struct StageKM<BF16, ROWS, true> {
+  static constexpr int RG = ROWS / 8;
+  static constexpr int LW = RG < 8 ? RG : 8;
+  static constexpr int ITEMS = RG * 8;                 // x 8 k-chunks (= ROWS)
+  static_assert(ITEMS <= NTHREADS, "one item per thread");
+  bf16x8 v[8];
+  static __device__ __forceinline__ int item() { return (int)(threadIdx.x % ITEMS); }
+  static __device__ __forceinline__ int wi_rg(int w) { return (w % LW) + LW * (w / (LW * 8)); }
+  static __device__ __forceinline__ int wi_kc(int w) { return (w / LW) % 8; }
+
+  __device__ __forceinline__ void load(const __bf16* __restrict__ p, long ld, int k0, int kend, bool vec_ok, long row0, long nrows) {
+    const int w = item();
+    const long r = row0 + wi_rg(w) * 8;
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) {
+      const int k = k0 + wi_kc(w) * 8 + kk;
+      bf16x8 x;
+#pragma unroll
+      for (int e = 0; e < 8; e++) x[e] = (__bf16)0.f;
+      if (k < kend) {
+        const __bf16* q = p + (long)k * ld + r;
+        if (vec_ok && r + 7 < nrows) x = *reinterpret_cast<const bf16x8*>(q);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; e++) if (r + e < nrows) x[e] = q[e];
+        }
+      }
+      v[kk] = x;
+    }
+  }
+  __device__ __forceinline__ void load_fast(const __bf16* __restrict__ p, long ld, int k0, long row0) {
+    const int w = item();
+    const unsigned toff = (unsigned)((wi_kc(w) * 8) * ld + wi_rg(w) * 8);
+    const __bf16* ub = p + (long)k0 * ld + row0;
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) v[kk] = *reinterpret_cast<const bf16x8*>(ub + kk * ld + toff);
+  }
+  __device__ __forceinline__ void store(__bf16* s) const {
+    if (ITEMS < NTHREADS && threadIdx.x >= ITEMS) return;
+    const int w = item();
+    const int rg = wi_rg(w), kc = wi_kc(w);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      bf16x8 c;
+#pragma unroll
+      for (int kk = 0; kk < 8; kk++) c[kk] = v[kk][j];
+      *reinterpret_cast<bf16x8*>(s + swz<BF16>(rg * 8 + j, kc * 8)) = c;
     }
   }
 };
@@ -254,7 +344,7 @@ struct TileMma<F32, FM, FNT> {
 //   m0 = first m of the wave's tile, j0 = first unit (n) of the wave's tile;
 //   acc[fm][g*FN + fn] is gate g, fragment (fm, fn).
 // ---------------------------------------------------------------------------------------------
-template <class CT, int BM, int BN, int WGM, int WGN, int NG, bool KMAJOR_A, bool KMAJOR_B, class Epi>
+template <class CT, int BM, int BN, int WGM, int WGN, int NG, bool KMAJOR_A, bool KMAJOR_B, class Epi, bool SA = false, bool SB = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi::Params& ep) {
   static_assert(WGM * WGN == 4, "4 waves");
   static_assert(!(NG == 3 && KMAJOR_B), "gate gather needs K-contiguous weights");
@@ -300,8 +390,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
   const int wave = threadIdx.x >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
 
-  const bool vecA = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
-  const bool vecB = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+  static_assert(!(SA || SB) || std::is_same<CT, BF16>::value, "bf16 sources feed the bf16 MFMA path only");
+  using TA = typename SrcT<SA>::T;
+  using TB = typename SrcT<SB>::T;
+  const TA* Ap = reinterpret_cast<const TA*>(g.A);
+  const TB* Bp = reinterpret_cast<const TB*>(g.B);
+  const bool vecA = ((g.lda & (SA ? 7 : 3)) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+  const bool vecB = ((g.ldb & (SB ? 7 : 3)) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
 
   auto rowmapA = [&](int r) -> long { long m = m_blk + r; return m < g.M ? m : -1; };
   auto rowmapB = [&](int r) -> long {
@@ -310,8 +405,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
     return n < g.N ? (long)gate * g.gate_stride + n : -1;
   };
 
-  typename std::conditional<KMAJOR_A, StageKM<CT, BM>, StageKC<CT, BM>>::type sa;
-  typename std::conditional<KMAJOR_B, StageKM<CT, BROWS>, StageKC<CT, BROWS>>::type sb;
+  typename std::conditional<KMAJOR_A, StageKM<CT, BM, SA>, StageKC<CT, BM, SA>>::type sa;
+  typename std::conditional<KMAJOR_B, StageKM<CT, BROWS, SB>, StageKC<CT, BROWS, SB>>::type sb;
 
   f32x4 acc[FM][NG * FN];
 #pragma unroll
@@ -327,18 +422,18 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
   auto load_tiles = [&](int k0) {
     const bool kfull = k0 + CT::BK <= kend;
     if (fullA && kfull) {
-      if constexpr (KMAJOR_A) sa.load_fast(g.A, g.lda, k0, m_blk);
-      else sa.load_fast(g.A, g.lda, k0, rowfastA);
+      if constexpr (KMAJOR_A) sa.load_fast(Ap, g.lda, k0, m_blk);
+      else sa.load_fast(Ap, g.lda, k0, rowfastA);
     } else {
-      if constexpr (KMAJOR_A) sa.load(g.A, g.lda, k0, kend, vecA, m_blk, g.M);
-      else sa.load(g.A, g.lda, k0, kend, vecA, rowmapA);
+      if constexpr (KMAJOR_A) sa.load(Ap, g.lda, k0, kend, vecA, m_blk, g.M);
+      else sa.load(Ap, g.lda, k0, kend, vecA, rowmapA);
     }
     if (fullB && kfull) {
-      if constexpr (KMAJOR_B) sb.load_fast(g.B, g.ldb, k0, n_blk);
-      else sb.load_fast(g.B, g.ldb, k0, rowfastB);
+      if constexpr (KMAJOR_B) sb.load_fast(Bp, g.ldb, k0, n_blk);
+      else sb.load_fast(Bp, g.ldb, k0, rowfastB);
     } else {
-      if constexpr (KMAJOR_B) sb.load(g.B, g.ldb, k0, kend, vecB, n_blk, g.N);
-      else sb.load(g.B, g.ldb, k0, kend, vecB, rowmapB);
+      if constexpr (KMAJOR_B) sb.load(Bp, g.ldb, k0, kend, vecB, n_blk, g.N);
+      else sb.load(Bp, g.ldb, k0, kend, vecB, rowmapB);
     }
   };
 

@@ -18,19 +18,21 @@ namespace ptv {
 struct EpiGruFwd {
   struct Params {
     const float* hprev; long ld_hprev;
-    const float* gi; long ld_gi;        // [M, 3H] input-side pre-activations (b_ih included)
-    const float* gi2; long ld_gi2;      // optional second addend (e.g. per-step token part), may be null
+    const void* gi; long ld_gi;         // [M, 3H] input-side pre-activations (b_ih included); fp32 or bf16
+    const void* gi2; long ld_gi2;       // optional second addend (e.g. per-step token part), may be null
     const float* bhh;                   // [3H]
     float* hout; long ld_hout;
-    float* gates; long plane;           // saved (r, z, n, hn) as 4 planes [M,H]; null = do not save
+    void* gates; long plane;            // saved (r, z, n, hn) as 4 planes [M,H]; null = do not save; fp32 or bf16
     const int* lengths; int t;          // packed-sequence mask: row m is updated iff t < lengths[m]
     const int* gi_idx;                  // optional: row m reads gi row gi_idx[m] (token-indexed gate table)
     int H;
+    int flags;                          // PTV_GRU_*_BF16
   };
   template <int FM, int FN, int NG>
   static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], int m0, int j0, int M, int H, int split) {
     static_assert(NG == 3, "GRU epilogue needs the three gates");
     const int lane = threadIdx.x & 63;
+    const bool gbf = p.flags & PTV_GRU_GATES_BF16, ibf = p.flags & PTV_GRU_GI_BF16, i2bf = p.flags & PTV_GRU_GI2_BF16;
 #pragma unroll
     for (int i = 0; i < FM; i++) {
       const int m = m0 + i * 16 + (lane & 15);
@@ -40,16 +42,16 @@ struct EpiGruFwd {
       for (int f = 0; f < FN; f++) {
         const int j = j0 + f * 16 + (lane >> 4) * 4;
         if (j >= H) continue;
-        // H is a multiple of 4 for every GRU on the path (host checks) -> 16-byte accesses
+        // H is a multiple of 4 for every GRU on the path (host checks) -> vector accesses
         const long gm = p.gi_idx ? p.gi_idx[m] : m;
-        const float4 gr = *reinterpret_cast<const float4*>(p.gi + gm * p.ld_gi + j);
-        const float4 gz = *reinterpret_cast<const float4*>(p.gi + gm * p.ld_gi + H + j);
-        const float4 gn = *reinterpret_cast<const float4*>(p.gi + gm * p.ld_gi + 2 * H + j);
+        const float4 gr = ld4f(p.gi, gm * p.ld_gi + j, ibf);
+        const float4 gz = ld4f(p.gi, gm * p.ld_gi + H + j, ibf);
+        const float4 gn = ld4f(p.gi, gm * p.ld_gi + 2 * H + j, ibf);
         float4 hr = make_float4(0, 0, 0, 0), hz = hr, hn2 = hr;
         if (p.gi2) {
-          hr = *reinterpret_cast<const float4*>(p.gi2 + (long)m * p.ld_gi2 + j);
-          hz = *reinterpret_cast<const float4*>(p.gi2 + (long)m * p.ld_gi2 + H + j);
-          hn2 = *reinterpret_cast<const float4*>(p.gi2 + (long)m * p.ld_gi2 + 2 * H + j);
+          hr = ld4f(p.gi2, (long)m * p.ld_gi2 + j, i2bf);
+          hz = ld4f(p.gi2, (long)m * p.ld_gi2 + H + j, i2bf);
+          hn2 = ld4f(p.gi2, (long)m * p.ld_gi2 + 2 * H + j, i2bf);
         }
         const float4 br = *reinterpret_cast<const float4*>(p.bhh + j);
         const float4 bz = *reinterpret_cast<const float4*>(p.bhh + H + j);
@@ -72,11 +74,11 @@ struct EpiGruFwd {
         }
         *reinterpret_cast<float4*>(p.hout + (long)m * p.ld_hout + j) = make_float4(h[0], h[1], h[2], h[3]);
         if (p.gates) {
-          float* gs = p.gates + (long)m * H + j;
-          *reinterpret_cast<float4*>(gs + 0 * p.plane) = make_float4(r[0], r[1], r[2], r[3]);
-          *reinterpret_cast<float4*>(gs + 1 * p.plane) = make_float4(z[0], z[1], z[2], z[3]);
-          *reinterpret_cast<float4*>(gs + 2 * p.plane) = make_float4(n[0], n[1], n[2], n[3]);
-          *reinterpret_cast<float4*>(gs + 3 * p.plane) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+          const long gs = (long)m * H + j;
+          st4f(p.gates, gs + 0 * p.plane, gbf, r[0], r[1], r[2], r[3]);
+          st4f(p.gates, gs + 1 * p.plane, gbf, z[0], z[1], z[2], z[3]);
+          st4f(p.gates, gs + 2 * p.plane, gbf, n[0], n[1], n[2], n[3]);
+          st4f(p.gates, gs + 3 * p.plane, gbf, hn[0], hn[1], hn[2], hn[3]);
         }
       }
     }
@@ -92,15 +94,17 @@ struct EpiGruBwd {
     const float* dh_ext; long ld_ext;   // [M,H] gradient arriving at this step's output from outside, may be null
     const float* dh_ext2; long ld_ext2; // second external addend (e.g. final-state grad), may be null
     const float* lr_a; long lr_lda; int lr_k; const float* lr_b;   // optional low-rank addend: dh += lr_a[m, 0:k] . lr_b[k, H]
-    const float* gates; long plane;     // saved r,z,n,hn of this step
+    const void* gates; long plane;      // saved r,z,n,hn of this step (fp32 or bf16)
     const float* hprev; long ld_hprev;
-    float* dgi; float* dgh;             // [M,3H] each
+    void* dgi; void* dgh;               // [M,3H] each (fp32 or bf16)
     float* dhz;                         // [M,H] out: dh (x) z
     int H;
+    int flags;
   };
   template <int FM, int FN, int NG>
   static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], int m0, int j0, int M, int H, int split) {
     const int lane = threadIdx.x & 63;
+    const bool gbf = p.flags & PTV_GRU_GATES_BF16, dbf = p.flags & PTV_GRU_DG_BF16;
 #pragma unroll
     for (int i = 0; i < FM; i++) {
       const int m = m0 + i * 16 + (lane & 15);
@@ -120,11 +124,11 @@ struct EpiGruBwd {
             dh[0] += a * q.x; dh[1] += a * q.y; dh[2] += a * q.z; dh[3] += a * q.w;
           }
         }
-        const float* gs = p.gates + (long)m * H + j;
-        const float4 r4 = *reinterpret_cast<const float4*>(gs + 0 * p.plane);
-        const float4 z4 = *reinterpret_cast<const float4*>(gs + 1 * p.plane);
-        const float4 n4 = *reinterpret_cast<const float4*>(gs + 2 * p.plane);
-        const float4 q4 = *reinterpret_cast<const float4*>(gs + 3 * p.plane);
+        const long gs = (long)m * H + j;
+        const float4 r4 = ld4f(p.gates, gs + 0 * p.plane, gbf);
+        const float4 z4 = ld4f(p.gates, gs + 1 * p.plane, gbf);
+        const float4 n4 = ld4f(p.gates, gs + 2 * p.plane, gbf);
+        const float4 q4 = ld4f(p.gates, gs + 3 * p.plane, gbf);
         const float4 hp4 = *reinterpret_cast<const float4*>(p.hprev + (long)m * p.ld_hprev + j);
         const float r[4] = {r4.x, r4.y, r4.z, r4.w}, z[4] = {z4.x, z4.y, z4.z, z4.w}, n[4] = {n4.x, n4.y, n4.z, n4.w};
         const float hn[4] = {q4.x, q4.y, q4.z, q4.w}, hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
@@ -137,15 +141,13 @@ struct EpiGruBwd {
           dnr[e] = dn[e] * r[e];
           dhz[e] = dh[e] * z[e];
         }
-        float* gi = p.dgi + (long)m * 3 * H + j;
-        float* gh = p.dgh + (long)m * 3 * H + j;
-        const float4 vr = make_float4(dr[0], dr[1], dr[2], dr[3]), vz = make_float4(dz[0], dz[1], dz[2], dz[3]);
-        *reinterpret_cast<float4*>(gi) = vr;
-        *reinterpret_cast<float4*>(gi + H) = vz;
-        *reinterpret_cast<float4*>(gi + 2 * H) = make_float4(dn[0], dn[1], dn[2], dn[3]);
-        *reinterpret_cast<float4*>(gh) = vr;
-        *reinterpret_cast<float4*>(gh + H) = vz;
-        *reinterpret_cast<float4*>(gh + 2 * H) = make_float4(dnr[0], dnr[1], dnr[2], dnr[3]);
+        const long go = (long)m * 3 * H + j;
+        st4f(p.dgi, go, dbf, dr[0], dr[1], dr[2], dr[3]);
+        st4f(p.dgi, go + H, dbf, dz[0], dz[1], dz[2], dz[3]);
+        st4f(p.dgi, go + 2 * H, dbf, dn[0], dn[1], dn[2], dn[3]);
+        st4f(p.dgh, go, dbf, dr[0], dr[1], dr[2], dr[3]);
+        st4f(p.dgh, go + H, dbf, dz[0], dz[1], dz[2], dz[3]);
+        st4f(p.dgh, go + 2 * H, dbf, dnr[0], dnr[1], dnr[2], dnr[3]);
         *reinterpret_cast<float4*>(p.dhz + (long)m * H + j) = make_float4(dhz[0], dhz[1], dhz[2], dhz[3]);
       }
     }
@@ -156,9 +158,9 @@ template <class CT, int BM, int BJ>
 __global__ __launch_bounds__(NTHREADS) void gru_fwd_step_kernel(GemmArgs g, EpiGruFwd::Params ep) {
   gemm_body<CT, BM, BJ, 2, 2, 3, false, false, EpiGruFwd>(g, ep);
 }
-template <class CT, int BM, int BN>
+template <class CT, int BM, int BN, bool SA>
 __global__ __launch_bounds__(NTHREADS) void gru_bwd_step_kernel(GemmArgs g, EpiGruBwd::Params ep) {
-  gemm_body<CT, BM, BN, 2, 2, 1, false, true, EpiGruBwd>(g, ep);
+  gemm_body<CT, BM, BN, 2, 2, 1, false, true, EpiGruBwd, SA, false>(g, ep);
 }
 
 
@@ -200,16 +202,16 @@ static void launch_fwd_step(const GemmArgs& g, const EpiGruFwd::Params& ep, hipS
     hipLaunchKernelGGL((gru_fwd_step_kernel<CT, 64, 32>), dim3(cdiv(g.N, 32), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
   }
 }
-template <class CT>
+template <class CT, bool SA>
 static void launch_bwd_step(const GemmArgs& g, const EpiGruBwd::Params& ep, hipStream_t s) {
   const long blocks_big = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
   const long blocks_mid = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
   if (blocks_big >= 192) {
-    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 128, 128>), dim3(cdiv(g.N, 128), cdiv(g.M, 128)), dim3(NTHREADS), 0, s, g, ep);
+    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 128, 128, SA>), dim3(cdiv(g.N, 128), cdiv(g.M, 128)), dim3(NTHREADS), 0, s, g, ep);
   } else if (blocks_mid >= 192) {
-    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 64, 64>), dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
+    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 64, 64, SA>), dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
   } else {
-    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 64, 32>), dim3(cdiv(g.N, 32), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
+    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 64, 32, SA>), dim3(cdiv(g.N, 32), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
   }
 }
 
@@ -218,11 +220,11 @@ static void launch_bwd_step(const GemmArgs& g, const EpiGruBwd::Params& ep, hipS
 using namespace ptv;
 
 extern "C" int ptv_gru_seq_fwd(int prec, int M, int H, int T,
-                               const float* gi, long gi_step_stride, long gi_ld,
-                               const float* gi2, long gi2_step_stride, long gi2_ld,
+                               const void* gi, long gi_step_stride, long gi_ld,
+                               const void* gi2, long gi2_step_stride, long gi2_ld,
                                const float* w_hh, const float* b_hh,
-                               float* hall, float* gates,
-                               const int* lengths, int reverse, const int* gi_idx, void* stream) {
+                               float* hall, void* gates,
+                               const int* lengths, int reverse, const int* gi_idx, int flags, void* stream) {
   if (M <= 0 || H <= 0 || T <= 0 || (H & 3) || !gi || !w_hh || !b_hh || !hall) return PTV_ERR_ARG;
   if ((gi_ld & 3) || (gi_step_stride & 3) || (gi2 && ((gi2_ld & 3) || (gi2_step_stride & 3)))) return PTV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -230,12 +232,14 @@ extern "C" int ptv_gru_seq_fwd(int prec, int M, int H, int T,
   for (int step = 0; step < T; step++) {
     const int t = reverse ? T - 1 - step : step;
     GemmArgs g{hall + step * MH, H, w_hh, H, M, H, H, H, (long)H};
+    const long esz_gi = (flags & PTV_GRU_GI_BF16) ? 2 : 4, esz_gi2 = (flags & PTV_GRU_GI2_BF16) ? 2 : 4;
+    const long esz_g = (flags & PTV_GRU_GATES_BF16) ? 2 : 4;
     EpiGruFwd::Params ep{hall + step * MH, H,
-                         gi + t * gi_step_stride, gi_ld,
-                         gi2 ? gi2 + t * gi2_step_stride : nullptr, gi2_ld,
+                         (const char*)gi + t * gi_step_stride * esz_gi, gi_ld,
+                         gi2 ? (const char*)gi2 + t * gi2_step_stride * esz_gi2 : nullptr, gi2_ld,
                          b_hh, hall + (step + 1) * MH, H,
-                         gates ? gates + (long)step * 4 * MH : nullptr, MH,
-                         lengths, t, gi_idx, H};
+                         gates ? (char*)gates + (long)step * 4 * MH * esz_g : nullptr, MH,
+                         lengths, t, gi_idx, H, flags};
     const int pi = prof::want(1, M, H) ? prof::begin(s) : -1;
     if (prec == PTV_PREC_BF16) launch_fwd_step<BF16>(g, ep, s); else launch_fwd_step<F32>(g, ep, s);
     if (pi >= 0) prof::end(pi, s, 2.0 * M * 3.0 * H * H);
@@ -245,13 +249,14 @@ extern "C" int ptv_gru_seq_fwd(int prec, int M, int H, int T,
 }
 
 extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
-                               const float* hall, const float* gates, const float* w_hh,
+                               const float* hall, const void* gates, const float* w_hh,
                                const float* dh_ext, long ext_step_stride, long ext_ld,
                                const float* dh_last, long last_ld,
                                const float* lr_a, long lr_step_stride, long lr_lda, int lr_k, const float* lr_b,
-                               float* dgi, float* dgh, float* dhz, float* dh0,
-                               int reverse, void* stream) {
+                               void* dgi, void* dgh, float* dhz, float* dh0,
+                               int reverse, int flags, void* stream) {
   if (M <= 0 || H <= 0 || T <= 0 || (H & 3) || !hall || !gates || !w_hh || !dgi || !dgh || !dhz) return PTV_ERR_ARG;
+  if ((flags & PTV_GRU_DG_BF16) && (prec != PTV_PREC_BF16 || (H & 7))) return PTV_ERR_ARG;
   if (dh_ext && ((ext_ld & 3) || (ext_step_stride & 3))) return PTV_ERR_ARG;
   if (dh_last && (last_ld & 3)) return PTV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -260,24 +265,27 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
     const int t = reverse ? T - 1 - step : step;
     const bool last = step == T - 1;
     // dh_{step+1} = dgh_{step+1} . W_hh (K = 3H; K = 0 at the last step) + dhz_{step+1} + external grads
-    GemmArgs g{last ? dgh : dgh + (long)(step + 1) * M3H, 3L * H, w_hh, H, M, H, last ? 0 : 3 * H, last ? 0 : 3 * H, 0};
+    const bool dbf = flags & PTV_GRU_DG_BF16;
+    const long esz_d = dbf ? 2 : 4, esz_g = (flags & PTV_GRU_GATES_BF16) ? 2 : 4;
+    GemmArgs g{last ? dgh : (const char*)dgh + (long)(step + 1) * M3H * esz_d, 3L * H, w_hh, H, M, H, last ? 0 : 3 * H, last ? 0 : 3 * H, 0};
     EpiGruBwd::Params ep{last ? nullptr : dhz + ((step + 1) & 1) * MH,
                          dh_ext ? dh_ext + (long)step * ext_step_stride : nullptr, ext_ld,
                          last ? dh_last : nullptr, last_ld,
                          lr_a ? lr_a + (long)step * lr_step_stride : nullptr, lr_lda, lr_k, lr_b,
-                         gates + (long)step * 4 * MH, MH,
+                         (const char*)gates + (long)step * 4 * MH * esz_g, MH,
                          hall + (long)step * MH, H,
-                         dgi + (long)t * M3H, dgh + (long)step * M3H,
-                         dhz + (step & 1) * MH, H};
+                         (char*)dgi + (long)t * M3H * esz_d, (char*)dgh + (long)step * M3H * esz_d,
+                         dhz + (step & 1) * MH, H, flags};
     const int pi = prof::want(2, M, H) ? prof::begin(s) : -1;
-    if (prec == PTV_PREC_BF16) launch_bwd_step<BF16>(g, ep, s); else launch_bwd_step<F32>(g, ep, s);
+    if (prec == PTV_PREC_BF16) { if (dbf) launch_bwd_step<BF16, true>(g, ep, s); else launch_bwd_step<BF16, false>(g, ep, s); }
+    else launch_bwd_step<F32, false>(g, ep, s);
     if (pi >= 0) prof::end(pi, s, last ? 0.0 : 2.0 * M * 3.0 * H * H);
   }
   PTV_CHECK_LAUNCH();
   if (dh0) {
     // dh0 = dhz_0 + dgh_0 . W_hh
     if (hipMemcpyAsync(dh0, dhz, MH * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return PTV_ERR_LAUNCH;
-    PTV_TRY(ptv_gemm(prec, 0, 1, M, H, 3 * H, dgh, 3L * H, w_hh, H, dh0, H, nullptr, 1.0f, 1, 0, -1, stream));
+    PTV_TRY(ptv_gemm(prec, 0, 1, M, H, 3 * H, dgh, 3L * H, w_hh, H, dh0, H, nullptr, 1.0f, 1, 0, -1, (flags & PTV_GRU_DG_BF16) ? 1 : 0, stream));
   }
   return PTV_OK;
 }
@@ -286,16 +294,16 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
 // step-major buffers: its per-time-step batch is a [B]-row window of the [32*B]-row matrices)
 extern "C" int ptv_gru_step_fwd(int prec, int M, int H,
                                 const float* hprev, long ld_hprev,
-                                const float* gi, long gi_ld, const float* gi2, long gi2_ld,
+                                const void* gi, long gi_ld, const void* gi2, long gi2_ld,
                                 const float* w_hh, const float* b_hh,
                                 float* hout, long ld_hout,
-                                float* gates, long gates_plane,
-                                const int* lengths, int t, const int* gi_idx, void* stream) {
+                                void* gates, long gates_plane,
+                                const int* lengths, int t, const int* gi_idx, int flags, void* stream) {
   if (M <= 0 || H <= 0 || (H & 3) || !hprev || !gi || !w_hh || !b_hh || !hout) return PTV_ERR_ARG;
   if ((gi_ld & 3) || (ld_hprev & 3) || (ld_hout & 3) || (gi2 && (gi2_ld & 3)) || (gates && (gates_plane & 3))) return PTV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   GemmArgs g{hprev, ld_hprev, w_hh, H, M, H, H, H, (long)H};
-  EpiGruFwd::Params ep{hprev, ld_hprev, gi, gi_ld, gi2, gi2_ld, b_hh, hout, ld_hout, gates, gates_plane, lengths, t, gi_idx, H};
+  EpiGruFwd::Params ep{hprev, ld_hprev, gi, gi_ld, gi2, gi2_ld, b_hh, hout, ld_hout, gates, gates_plane, lengths, t, gi_idx, H, flags};
   if (prec == PTV_PREC_BF16) launch_fwd_step<BF16>(g, ep, s); else launch_fwd_step<F32>(g, ep, s);
   PTV_CHECK_LAUNCH();
   return PTV_OK;

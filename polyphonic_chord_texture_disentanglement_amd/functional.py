@@ -12,10 +12,21 @@ import torch
 from ._lib import call, prec_code, ptr, stream_ptr
 
 F32 = torch.float32
+BF16 = torch.bfloat16
+BF16_STORAGE = True         # bf16 precision: tensors that only feed MFMA operands / epilogues live as bf16 in HBM
 
 
-def _empty(*shape, dev):
-    return torch.empty(*shape, device=dev, dtype=F32)
+def _empty(*shape, dev, dtype=F32):
+    return torch.empty(*shape, device=dev, dtype=dtype)
+
+
+def _act_dtype(prec, H=8):
+    """storage dtype of saved gates / gate gradients / input-side pre-activations"""
+    return BF16 if (prec == 1 and BF16_STORAGE and H % 8 == 0) else F32
+
+
+def _bf(t):
+    return 1 if (t is not None and t.dtype == BF16) else 0
 
 
 def _zeros(*shape, dev):
@@ -27,17 +38,19 @@ def _ld(t):
     return t.stride(0)
 
 
-def gemm(a, b, out=None, *, ta=False, tb=False, bias=None, alpha=1.0, acc=False, act=0, prec=0, splitk=0):
-    """out[M,N] = act(alpha * op(a) . op(b)^T + bias) (+ out);  see ptv_gemm in include/ptvae_hip.h."""
+def gemm(a, b, out=None, *, ta=False, tb=False, bias=None, alpha=1.0, acc=False, act=0, prec=0, splitk=0, out_dtype=F32):
+    """out[M,N] = act(alpha * op(a) . op(b)^T + bias) (+ out);  see ptv_gemm in include/ptvae_hip.h.
+    a / b / out may be bf16 tensors (bf16 precision only)."""
     M, K = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
     N, Kb = (b.shape[1], b.shape[0]) if tb else (b.shape[0], b.shape[1])
     assert K == Kb, (a.shape, b.shape, ta, tb)
     if out is None:
         assert not acc
-        out = _empty(M, N, dev=a.device)
+        out = _empty(M, N, dev=a.device, dtype=out_dtype)
     assert tuple(out.shape) == (M, N), (out.shape, M, N)
+    dt = _bf(a) | (_bf(b) << 1) | (_bf(out) << 2)
     call('ptv_gemm', prec, int(ta), int(tb), M, N, K, ptr(a), _ld(a), ptr(b), _ld(b), ptr(out), _ld(out),
-         ptr(bias), float(alpha), int(acc), int(act), int(splitk), stream_ptr())
+         ptr(bias), float(alpha), int(acc), int(act), int(-1 if _bf(out) else splitk), dt, stream_ptr())
     return out
 
 
@@ -51,7 +64,7 @@ def copy2d(dst, src, *, alpha=1.0, acc=False, rows=None, cols=None, lds=None):
 
 def colsum(out, a, sel=None, groups=1):
     """out[g, n] += sum_{rows with sel==g} a[row, n]"""
-    call('ptv_colsum', ptr(out), ptr(a), _ld(a), a.shape[0], a.shape[1], ptr(sel), groups, stream_ptr())
+    call('ptv_colsum', ptr(out), ptr(a), _ld(a), a.shape[0], a.shape[1], ptr(sel), groups, _bf(a), stream_ptr())
     return out
 
 
@@ -61,7 +74,7 @@ def sum_steps(x3, out=None, acc=False):
     assert x3.is_contiguous()
     if out is None:
         out = _empty(*x3.shape[1:], dev=x3.device)
-    call('ptv_sum_steps', ptr(out), ptr(x3), n, T, n, int(acc), stream_ptr())
+    call('ptv_sum_steps', ptr(out), ptr(x3), n, T, n, int(acc), _bf(x3), stream_ptr())
     return out
 
 
@@ -74,12 +87,17 @@ def transpose01(x):
     return out
 
 
+def _gru_flags(gates=None, gi=None, gi2=None, dg=None):
+    return _bf(gates) | (_bf(gi) << 1) | (_bf(gi2) << 2) | (_bf(dg) << 3)
+
+
 def gru_fwd(prec, gi, gi_step, gi_ld, w_hh, b_hh, hall, gates, *, gi2=None, gi2_step=0, gi2_ld=0, lengths=None,
             reverse=False, gi_idx=None, T=None):
     T1, M, H = hall.shape
     T = T1 - 1 if T is None else T
     call('ptv_gru_seq_fwd', prec, M, H, T, ptr(gi), gi_step, gi_ld, ptr(gi2), gi2_step, gi2_ld, ptr(w_hh),
-         ptr(b_hh), ptr(hall), ptr(gates), ptr(lengths), int(reverse), ptr(gi_idx), stream_ptr())
+         ptr(b_hh), ptr(hall), ptr(gates), ptr(lengths), int(reverse), ptr(gi_idx), _gru_flags(gates, gi, gi2),
+         stream_ptr())
 
 
 def gru_bwd(prec, hall, gates, w_hh, *, dh_ext=None, dh_last=None, lr=None, reverse=False, need_dh0=True):
@@ -87,15 +105,16 @@ def gru_bwd(prec, hall, gates, w_hh, *, dh_ext=None, dh_last=None, lr=None, reve
     T1, M, H = hall.shape
     T = T1 - 1
     dev = hall.device
-    dgi = _empty(T, M, 3 * H, dev=dev)
-    dgh = _empty(T, M, 3 * H, dev=dev)
+    dt = _act_dtype(prec, H)
+    dgi = _empty(T, M, 3 * H, dev=dev, dtype=dt)
+    dgh = _empty(T, M, 3 * H, dev=dev, dtype=dt)
     dhz = _empty(2, M, H, dev=dev)
     dh0 = _empty(M, H, dev=dev) if need_dh0 else None
     ext = (ptr(dh_ext), dh_ext.stride(0), dh_ext.stride(1)) if dh_ext is not None else (None, 0, 0)
     last = (ptr(dh_last), dh_last.stride(0)) if dh_last is not None else (None, 0)
     lra = (ptr(lr[0]), lr[1], lr[2], lr[3], ptr(lr[4])) if lr is not None else (None, 0, 0, 0, None)
     call('ptv_gru_seq_bwd', prec, M, H, T, ptr(hall), ptr(gates), ptr(w_hh), *ext, *last, *lra, ptr(dgi),
-         ptr(dgh), ptr(dhz), ptr(dh0), int(reverse), stream_ptr())
+         ptr(dgh), ptr(dhz), ptr(dh0), int(reverse), _gru_flags(gates, dg=dgi), stream_ptr())
     return dgi, dgh, dh0
 
 
@@ -237,10 +256,10 @@ def _bigru_forward(prec, x3, lengths, w):
 
     def direction(d):
         w_ih, w_hh, b_ih, b_hh = w[4 * d: 4 * d + 4]
-        gi = gemm(xf, w_ih, bias=b_ih, prec=prec)                      # [T*M, 3H]
+        gi = gemm(xf, w_ih, bias=b_ih, prec=prec, out_dtype=_act_dtype(prec, H))          # [T*M, 3H]
         hall = _empty(T + 1, M, H, dev=dev)
         hall[0].zero_()
-        gates = _empty(T, 4, M, H, dev=dev)
+        gates = _empty(T, 4, M, H, dev=dev, dtype=_act_dtype(prec, H))
         gru_fwd(prec, gi, M * 3 * H, 3 * H, w_hh, b_hh, hall, gates, lengths=lengths, reverse=bool(d))
         copy2d(out[:, d * H:(d + 1) * H], hall[T])
         return hall, gates, gi
@@ -449,7 +468,7 @@ class DecoderTFFn(torch.autograd.Function):
         w_ih_t = P['dec_time_gru.weight_ih_l0']
         gi_t = gemm(TOKS[:32].view(R, 2 * He), w_ih_t[:, :2 * He], prec=prec)  # [32*B, 3Ht]
         zg = gemm(z_in, w_ih_t[:, 2 * He:], bias=P['dec_time_gru.bias_ih_l0'], prec=prec)
-        gates_t = _empty(32, 4, B, Ht, dev=dev)
+        gates_t = _empty(32, 4, B, Ht, dev=dev, dtype=_act_dtype(prec, Ht))
         gru_fwd(prec, gi_t, B * 3 * Ht, 3 * Ht, P['dec_time_gru.weight_hh_l0'], P['dec_time_gru.bias_hh_l0'], NS,
                 gates_t, gi2=zg, gi2_step=0, gi2_ld=3 * Ht)
         NSf = NS[1:].view(R, Ht)                                               # notes_summary rows (t, b)
@@ -458,9 +477,10 @@ class DecoderTFFn(torch.autograd.Function):
         HN = _empty(16, R, Hn, dev=dev)
         gemm(NSf, P['dec_time_to_notes_hid.weight'], HN[0], bias=P['dec_time_to_notes_hid.bias'], prec=prec)
         w_ih_n = P['dec_notes_gru.weight_ih_l0']
-        GC = gemm(NSf, w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec)          # [R, 3Hn]
-        GT = gemm(emb3[:15].view(15 * R, E), w_ih_n[:, Ht:], prec=prec)                        # [15R, 3Hn]
-        gates_n = _empty(15, 4, R, Hn, dev=dev)
+        adt = _act_dtype(prec, Hn)
+        GC = gemm(NSf, w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec, out_dtype=adt)      # [R, 3Hn]
+        GT = gemm(emb3[:15].view(15 * R, E), w_ih_n[:, Ht:], prec=prec, out_dtype=adt)                    # [15R, 3Hn]
+        gates_n = _empty(15, 4, R, Hn, dev=dev, dtype=adt)
         gru_fwd(prec, GT, R * 3 * Hn, 3 * Hn, P['dec_notes_gru.weight_hh_l0'], P['dec_notes_gru.bias_hh_l0'], HN,
                 gates_n, gi2=GC, gi2_step=0, gi2_ld=3 * Hn)
         NSUM = HN[1:].view(15 * R, Hn)
@@ -477,7 +497,7 @@ class DecoderTFFn(torch.autograd.Function):
         w_ih_d, b_ih_d = P['dec_dur_gru.weight_ih_l0'], P['dec_dur_gru.bias_ih_l0']
         tab0 = gemm(P['dur_sos_token'].view(1, -1), w_ih_d, bias=b_ih_d, prec=0)       # [1, 3Hd]  (tiny: exact)
         tab = gemm(_onehot2x5(dev), w_ih_d, bias=b_ih_d, prec=0)                       # [2, 3Hd]
-        gates_d = _empty(5, 4, M, Hd, dev=dev)
+        gates_d = _empty(5, 4, M, Hd, dev=dev, dtype=_act_dtype(prec, Hd))
         dur = _empty(M, 5, 2, dev=dev)
         idx = torch.empty(5, M, device=dev, dtype=torch.int32)
         dur2 = dur.view(M, 10)
@@ -651,7 +671,7 @@ class ChordDecoderTFFn(torch.autograd.Function):
         w_ih = P['gru.weight_ih_l0']
         gi = gemm(toks.view(T * B, I), w_ih[:, :I], prec=prec)
         zg = gemm(z_in, w_ih[:, I:], bias=P['gru.bias_ih_l0'], prec=prec)
-        gates = _empty(T, 4, B, H, dev=dev)
+        gates = _empty(T, 4, B, H, dev=dev, dtype=_act_dtype(prec, H))
         gru_fwd(prec, gi, B * 3 * H, 3 * H, P['gru.weight_hh_l0'], P['gru.bias_hh_l0'], hall, gates, gi2=zg, gi2_step=0,
                 gi2_ld=3 * H)
         hs = hall[1:].view(T * B, H)

@@ -38,7 +38,7 @@ def gru_step(prec, hprev, gi, gi_ld, w_hh, b_hh, hout, *, gi2=None, gates=None, 
     M, H = hout.shape
     call('ptv_gru_step_fwd', prec, M, H, ptr(hprev), hprev.stride(0), ptr(gi), gi_ld, ptr(gi2),
          gi2.stride(0) if gi2 is not None else 0, ptr(w_hh), ptr(b_hh), ptr(hout), hout.stride(0), ptr(gates), plane,
-         ptr(lengths), t, ptr(gi_idx), stream_ptr())
+         ptr(lengths), t, ptr(gi_idx), F_._gru_flags(gates, gi, gi2), stream_ptr())
 
 
 class DecoderStepFn(torch.autograd.Function):
@@ -71,10 +71,10 @@ class DecoderStepFn(torch.autograd.Function):
         zg = gemm(z_in, w_ih_t[:, 2 * He:], bias=P['dec_time_gru.bias_ih_l0'], prec=prec)
         TOKS = _empty(33, B, 2 * He, dev=dev)
         copy2d(TOKS[0], P['dec_init_input'].view(1, -1), lds=0)
-        gates_t = _empty(32, 4, B, Ht, dev=dev) if train else None
+        gates_t = _empty(32, 4, B, Ht, dev=dev, dtype=F_._act_dtype(prec, Ht)) if train else None
 
         HN = _empty(16, R, Hn, dev=dev)
-        gates_n = _empty(15, 4, R, Hn, dev=dev) if train else None
+        gates_n = _empty(15, 4, R, Hn, dev=dev, dtype=F_._act_dtype(prec, Hn)) if train else None
         TOK = _empty(15, R, E, dev=dev)
         PRED = _zeros(16, R, E, dev=dev)
         xhat = torch.full((B, 32, 16, 6), 2, device=dev, dtype=torch.long)
@@ -83,13 +83,13 @@ class DecoderStepFn(torch.autograd.Function):
         plen = torch.zeros(R, device=dev, dtype=torch.int32)
         pitch = _empty(M, NP, dev=dev)
         HD = _empty(6, M, Hd, dev=dev)
-        gates_d = _empty(5, 4, M, Hd, dev=dev) if train else None
+        gates_d = _empty(5, 4, M, Hd, dev=dev, dtype=F_._act_dtype(prec, Hd)) if train else None
         idx = torch.empty(5, M, device=dev, dtype=torch.int32)
         dur = _empty(M, 5, 2, dev=dev)
         dur2 = dur.view(M, 10)
         need_resum = inference or not all(coin_time)
         XH = [_zeros(17, R, He, dev=dev) for _ in range(2)] if need_resum else None
-        XG = ([_zeros(16, 4, R, He, dev=dev) for _ in range(2)] if train else [None, None]) if need_resum else None
+        XG = ([torch.zeros(16, 4, R, He, device=dev, dtype=F_._act_dtype(prec, He)) for _ in range(2)] if train else [None, None]) if need_resum else None
 
         if inference:
             sos = _sos_grid(dev)
@@ -340,7 +340,7 @@ class ChordDecoderStepFn(torch.autograd.Function):
         zg = gemm(z_in, w_ih[:, I:], bias=P['gru.bias_ih_l0'], prec=prec)
         toks = _empty(T, B, I, dev=dev)
         copy2d(toks[0], P['init_input'].view(1, -1), lds=0)
-        gates = _empty(T, 4, B, H, dev=dev)
+        gates = _empty(T, 4, B, H, dev=dev, dtype=F_._act_dtype(prec, H))
         root, chroma, bass = _empty(T, B, 12, dev=dev), _empty(T, B, 24, dev=dev), _empty(T, B, 12, dev=dev)
         masks = torch.zeros(2, device=dev, dtype=torch.int32)
         for t in range(T):

@@ -115,5 +115,5 @@ def test_gru_seq_fwd_bwd(prec, M, H, I, T, masked, reverse):
     assert (dwhh.cpu() - w_hh.grad).abs().max() < gtol * max(1.0, w_hh.grad.abs().max().item())
     dwih = ops.gemm(dgi.view(T * M, 3 * H), d(x).view(T * M, I), trans_a=True, trans_b=True, prec=prec)
     assert (dwih.cpu() - w_ih.grad).abs().max() < gtol * max(1.0, w_ih.grad.abs().max().item())
-    assert (dgi.sum((0, 1)).cpu() - b_ih.grad).abs().max() < gtol * max(1.0, b_ih.grad.abs().max().item())
-    assert (dgh.sum((0, 1)).cpu() - b_hh.grad).abs().max() < gtol * max(1.0, b_hh.grad.abs().max().item())
+    assert (dgi.float().sum((0, 1)).cpu() - b_ih.grad).abs().max() < gtol * max(1.0, b_ih.grad.abs().max().item())
+    assert (dgh.float().sum((0, 1)).cpu() - b_hh.grad).abs().max() < gtol * max(1.0, b_hh.grad.abs().max().item())
