@@ -166,24 +166,36 @@ def main():
         import ctypes
         ms_per_step = dt / args.steps * 1e3
         value = world * B * args.steps / dt
-        # dominant kernel: the notes-GRU forward step (15 launches per train step, M = 32*B rows)
+        # dominant kernel: the notes-GRU forward step (15 launches per train step, M = 32*B rows).  Its
+        # arithmetic intensity (25.8 GFLOP over ~238 MB at B=512) is below the MI355X balance point
+        # (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B), so the HBM roofline bounds it.
         cnt = ctypes.c_long(0)
         tot_ms = ctypes.c_double(0.0)
         flop = ctypes.c_double(0.0)
         lib.ptv_prof_read(ctypes.byref(cnt), ctypes.byref(tot_ms), ctypes.byref(flop))
-        peak = 2500.0 if args.precision == 'bf16' else 157.3
         roof = None
         if cnt.value > 0:
-            avg_ms = tot_ms.value / cnt.value
-            ach = flop.value / cnt.value / (avg_ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'kernel': 'gru_fwd_step_kernel (dec_notes_gru, M=%d H=512)' % (32 * B),
-                    'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                    'launches': cnt.value, 'avg_us': round(avg_ms * 1e3, 2), 'traffic': None}
+            M_, H_ = 32 * B, model.decoder.dec_notes_hid_size
+            asz = 2 if (args.precision == 'bf16' and H_ % 8 == 0) else 4        # gi / gi2 / saved gates storage
+            # algorithmic bytes per launch: h_prev (A operand + blend, once) + gi + gi2 + W_hh + b_hh read;
+            # h and the 4 saved gate planes written
+            alg_bytes = M_ * H_ * 4 + 2 * M_ * 3 * H_ * asz + 3 * H_ * H_ * 4 + 3 * H_ * 4 + M_ * H_ * 4 + 4 * M_ * H_ * asz
+            avg_s = tot_ms.value / cnt.value * 1e-3
+            traffic = None
+            pmc = os.path.join(ROOT, 'profiles', 'r01_notes_gru_fwd_pmc.json')
+            if B == 512 and args.precision == 'bf16' and os.path.exists(pmc):
+                traffic = json.load(open(pmc))['hbm_bytes_per_launch']            # rocprofv3 PMC, see that file
+            roof = {'bound': 'hbm', 'kernel': 'gru_fwd_step_kernel (dec_notes_gru step, M=%d H=%d)' % (M_, H_),
+                    'achieved': round(alg_bytes / avg_s / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                    'frac': round(alg_bytes / avg_s / 1e9 / 8000.0, 4), 'traffic': traffic,
+                    'algorithmic_bytes': alg_bytes, 'launches': cnt.value, 'avg_us': round(avg_s * 1e6, 2),
+                    'mfma_tflops': round(flop.value / cnt.value / avg_s / 1e12, 1)}
         if args.mode == 'decode':
             workload = 'configs[3]: free-running PtvaeDecoder sampling (inference_decode), batch=%d, 32x15x(1+5) step loop' % B
         elif args.tfr >= 1.0:
-            workload = ('configs[1]: 1xMI355X batch=512/GPU, bf16 MFMA GRU/Linear, z_dim=256+256, teacher-forced decoder '
-                        '(tfr=1), fwd+bwd+clip+Adam')
+            workload = ('configs[%d]: %dxMI355X batch=%d/GPU%s, %s MFMA GRU/Linear, z_dim=256+256, teacher-forced decoder '
+                        '(tfr=1), fwd+bwd+clip+Adam' % (1 if world == 1 else 2, world, B,
+                                                        '' if world == 1 else ' (DDP, RCCL grad all-reduce)', args.precision))
         else:
             workload = 'train step with teacher-forcing ratio %.2f (step-loop decoder), batch=%d/GPU, fwd+bwd+clip+Adam' % (args.tfr, B)
         res = {'metric': '2-bar piano-roll samples/sec (train step)' if args.mode == 'train' else '2-bar piano-roll samples/sec (free-running decode)', 'value': round(value, 1), 'unit': 'samples/s',
