@@ -344,7 +344,7 @@ struct TileMma<F32, FM, FNT> {
 //   m0 = first m of the wave's tile, j0 = first unit (n) of the wave's tile;
 //   acc[fm][g*FN + fn] is gate g, fragment (fm, fn).
 // ---------------------------------------------------------------------------------------------
-template <class CT, int BM, int BN, int WGM, int WGN, int NG, bool KMAJOR_A, bool KMAJOR_B, class Epi, bool SA = false, bool SB = false>
+template <class CT, int BM, int BN, int WGM, int WGN, int NG, bool KMAJOR_A, bool KMAJOR_B, class Epi, bool SA = false, bool SB = false, int PF = 1>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi::Params& ep) {
   static_assert(WGM * WGN == 4, "4 waves");
   static_assert(!(NG == 3 && KMAJOR_B), "gate gather needs K-contiguous weights");
@@ -405,8 +405,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
     return n < g.N ? (long)gate * g.gate_stride + n : -1;
   };
 
-  typename std::conditional<KMAJOR_A, StageKM<CT, BM, SA>, StageKC<CT, BM, SA>>::type sa;
-  typename std::conditional<KMAJOR_B, StageKM<CT, BROWS, SB>, StageKC<CT, BROWS, SB>>::type sb;
+  // PF register stages: global loads for PF tiles are in flight ahead of the MFMAs (the small-M
+  // recurrent steps run one block per CU, so load latency is only hidden by depth, not by occupancy)
+  typename std::conditional<KMAJOR_A, StageKM<CT, BM, SA>, StageKC<CT, BM, SA>>::type sa[PF];
+  typename std::conditional<KMAJOR_B, StageKM<CT, BROWS, SB>, StageKC<CT, BROWS, SB>>::type sb[PF];
 
   f32x4 acc[FM][NG * FN];
 #pragma unroll
@@ -419,33 +421,68 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
   auto rowfastA = [&](int r) -> long { return m_blk + r; };                  // r = i*RPP: block-uniform
   auto rowfastB = [&](int r) -> long { return (long)(r / BN) * g.gate_stride + n_blk + (r % BN); };
   static_assert(BN % 32 == 0 && BM % 32 == 0, "row passes must not straddle a gate block");
-  auto load_tiles = [&](int k0) {
+  auto load_tiles = [&](auto& sa_, auto& sb_, int k0) {
     const bool kfull = k0 + CT::BK <= kend;
     if (fullA && kfull) {
-      if constexpr (KMAJOR_A) sa.load_fast(Ap, g.lda, k0, m_blk);
-      else sa.load_fast(Ap, g.lda, k0, rowfastA);
+      if constexpr (KMAJOR_A) sa_.load_fast(Ap, g.lda, k0, m_blk);
+      else sa_.load_fast(Ap, g.lda, k0, rowfastA);
     } else {
-      if constexpr (KMAJOR_A) sa.load(Ap, g.lda, k0, kend, vecA, m_blk, g.M);
-      else sa.load(Ap, g.lda, k0, kend, vecA, rowmapA);
+      if constexpr (KMAJOR_A) sa_.load(Ap, g.lda, k0, kend, vecA, m_blk, g.M);
+      else sa_.load(Ap, g.lda, k0, kend, vecA, rowmapA);
     }
     if (fullB && kfull) {
-      if constexpr (KMAJOR_B) sb.load_fast(Bp, g.ldb, k0, n_blk);
-      else sb.load_fast(Bp, g.ldb, k0, rowfastB);
+      if constexpr (KMAJOR_B) sb_.load_fast(Bp, g.ldb, k0, n_blk);
+      else sb_.load_fast(Bp, g.ldb, k0, rowfastB);
     } else {
-      if constexpr (KMAJOR_B) sb.load(Bp, g.ldb, k0, kend, vecB, n_blk, g.N);
-      else sb.load(Bp, g.ldb, k0, kend, vecB, rowmapB);
+      if constexpr (KMAJOR_B) sb_.load(Bp, g.ldb, k0, kend, vecB, n_blk, g.N);
+      else sb_.load(Bp, g.ldb, k0, kend, vecB, rowmapB);
     }
   };
-
-  if (kbeg < kend) load_tiles(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += CT::BK) {
+  auto fast_tiles = [&](auto& sa_, auto& sb_, int k0) {          // no predicates at all (steady state)
+    if constexpr (KMAJOR_A) sa_.load_fast(Ap, g.lda, k0, m_blk);
+    else sa_.load_fast(Ap, g.lda, k0, rowfastA);
+    if constexpr (KMAJOR_B) sb_.load_fast(Bp, g.ldb, k0, n_blk);
+    else sb_.load_fast(Bp, g.ldb, k0, rowfastB);
+  };
+  auto consume = [&](auto& sa_, auto& sb_) {
     __syncthreads();              // previous tile fully consumed
-    sa.store(As);
-    sb.store(Bs);
+    sa_.store(As);
+    sb_.store(Bs);
     __syncthreads();
-    if (k0 + CT::BK < kend) load_tiles(k0 + CT::BK);     // prefetch next tile under the MFMAs
+  };
+  auto mma = [&]() {
     TileMma<CT, FM, NG * FN>::run(As, wm * WTM, Bs,
                                   [&](int j) { return (j / FN) * BN + wn * WTN + (j % FN) * 16; }, acc);
+  };
+
+  int k0 = kbeg;
+  if constexpr (PF > 1) {
+    // deep pipeline, branch-free steady state: every stage's loads are PF tiles old when consumed, and the
+    // straight-line body lets hipcc wait with a counted vmcnt instead of draining the queue
+    if (fullA && fullB && kbeg + 2 * PF * CT::BK <= kend) {
+#pragma unroll
+      for (int p = 0; p < PF; p++) fast_tiles(sa[p], sb[p], k0 + p * CT::BK);
+      for (; k0 + 2 * PF * CT::BK <= kend; k0 += PF * CT::BK) {
+#pragma unroll
+        for (int p = 0; p < PF; p++) {
+          consume(sa[p], sb[p]);
+          fast_tiles(sa[p], sb[p], k0 + (PF + p) * CT::BK);
+          mma();
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < PF; p++) {                       // drain the PF tiles still in registers
+        consume(sa[p], sb[p]);
+        mma();
+      }
+      k0 += PF * CT::BK;
+    }
+  }
+  if (k0 < kend) load_tiles(sa[0], sb[0], k0);
+  for (; k0 < kend; k0 += CT::BK) {
+    consume(sa[0], sb[0]);
+    if (k0 + CT::BK < kend) load_tiles(sa[0], sb[0], k0 + CT::BK);     // prefetch next tile under the MFMAs
+    mma();
   }
   Epi::template apply<FM, FN, NG>(ep, acc, m_blk + wm * WTM, n_blk + wn * WTN, g.M, g.N, split);
 }

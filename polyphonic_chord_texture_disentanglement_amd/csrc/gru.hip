@@ -156,11 +156,11 @@ struct EpiGruBwd {
 
 template <class CT, int BM, int BJ>
 __global__ __launch_bounds__(NTHREADS) void gru_fwd_step_kernel(GemmArgs g, EpiGruFwd::Params ep) {
-  gemm_body<CT, BM, BJ, 2, 2, 3, false, false, EpiGruFwd>(g, ep);
+  gemm_body<CT, BM, BJ, 2, 2, 3, false, false, EpiGruFwd, false, false, (BM * BJ <= 64 * 32 ? 3 : 1)>(g, ep);
 }
 template <class CT, int BM, int BN, bool SA>
 __global__ __launch_bounds__(NTHREADS) void gru_bwd_step_kernel(GemmArgs g, EpiGruBwd::Params ep) {
-  gemm_body<CT, BM, BN, 2, 2, 1, false, true, EpiGruBwd, SA, false>(g, ep);
+  gemm_body<CT, BM, BN, 2, 2, 1, false, true, EpiGruBwd, SA, false, (BM * BN <= 64 * 32 ? 4 : (BM * BN <= 64 * 64 ? 2 : 1))>(g, ep);
 }
 
 
