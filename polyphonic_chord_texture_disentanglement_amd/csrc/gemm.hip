@@ -58,7 +58,7 @@ struct EpiPlain {
 
 template <class CT, int BM, int BN, int WGM, int WGN, bool KA, bool KB, bool SA, bool SB>
 __global__ __launch_bounds__(NTHREADS) void gemm_plain_kernel(GemmArgs g, EpiPlain::Params ep) {
-  gemm_body<CT, BM, BN, WGM, WGN, 1, KA, KB, EpiPlain, SA, SB>(g, ep);
+  gemm_body<CT, BM, BN, WGM, WGN, 1, KA, KB, EpiPlain, SA, SB, (BM * BN <= 64 * 64 ? 2 : 1)>(g, ep);
 }
 
 __global__ void fill_rows_kernel(float* C, long ldc, int M, int N, float v) {

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(NTHREADS) void gru_fwd_step_kernel(GemmArgs g, EpiG
 }
 template <class CT, int BM, int BN, bool SA>
 __global__ __launch_bounds__(NTHREADS) void gru_bwd_step_kernel(GemmArgs g, EpiGruBwd::Params ep) {
-  gemm_body<CT, BM, BN, 2, 2, 1, false, true, EpiGruBwd, SA, false, (BM * BN <= 64 * 32 ? 4 : (BM * BN <= 64 * 64 ? 2 : 1))>(g, ep);
+  gemm_body<CT, BM, BN, 2, 2, 1, false, true, EpiGruBwd, SA, false, (BM * BN <= 64 * 32 ? 4 : (BM * BN <= 64 * 64 ? 3 : 2))>(g, ep);
 }
 
 
