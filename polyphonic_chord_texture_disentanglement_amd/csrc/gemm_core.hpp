@@ -456,8 +456,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
   };
 
   int k0 = kbeg;
-  if constexpr (PF > 1) {
-    // deep pipeline, branch-free steady state: every stage's loads are PF tiles old when consumed, and the
+  {
+    // pipeline with a branch-free steady state: every stage's loads are PF tiles old when consumed, and the
     // straight-line body lets hipcc wait with a counted vmcnt instead of draining the queue
     if (fullA && fullB && kbeg + 2 * PF * CT::BK <= kend) {
 #pragma unroll
