@@ -35,6 +35,7 @@ extern "C" {
 #define PTV_GRU_GI_BF16 2      /* gi */
 #define PTV_GRU_GI2_BF16 4     /* gi2 */
 #define PTV_GRU_DG_BF16 8      /* dgi / dgh (backward) */
+#define PTV_GRU_SKIP_CAST0 32  /* hall16 slot 0 is already valid (chained single-step calls) */
 
 /* Library / build identification ("gfx950"). */
 const char* ptv_arch(void);
@@ -60,6 +61,8 @@ int ptv_gemm(int prec, int transA, int transB, int M, int N, int K,
  *   gi  [T] x [M,3H]   input-side pre-activations W_i x + b_i (gate order r,z,n), produced by ptv_gemm
  *   gi2 optional second addend with its own strides (may be NULL)
  *   hall [T+1][M][H]   slot 0 = initial state (written by the caller), slot s+1 = state after step s
+ *   hall16 [T+1][M][H] optional bf16 copy of hall (bf16 precision): read as the MFMA operand of each step,
+ *                 written next to hall, and reused by the caller as a bf16 operand of later products
  *   gates [T][4][M][H] saved r,z,n,(W_hn h + b_hn) for the backward pass, or NULL (inference)
  *   lengths[M] or NULL: packed-sequence masking (row m updated at time t iff t < lengths[m]),
  *                 the pack_padded_sequence semantics of ptvae.py:446-453,480-486
@@ -71,13 +74,13 @@ int ptv_gru_seq_fwd(int prec, int M, int H, int T,
                     const void* gi, long gi_step_stride, long gi_ld,
                     const void* gi2, long gi2_step_stride, long gi2_ld,
                     const float* w_hh, const float* b_hh,
-                    float* hall, void* gates,
+                    float* hall, void* hall16, void* gates,
                     const int* lengths, int reverse, const int* gi_idx, int flags, void* stream);
 
 /* One GRU cell step with explicit strides (same kernel as ptv_gru_seq_fwd, T = 1): the free-running
  * decoder (ptvae.py:395-424,460-486) advances a [B]-row window of the step-major buffers per step. */
 int ptv_gru_step_fwd(int prec, int M, int H,
-                     const float* hprev, long ld_hprev,
+                     const float* hprev, long ld_hprev, const void* hprev16, void* hout16,
                      const void* gi, long gi_ld, const void* gi2, long gi2_ld,
                      const float* w_hh, const float* b_hh,
                      float* hout, long ld_hout,

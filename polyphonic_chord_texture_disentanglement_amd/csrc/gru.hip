@@ -22,6 +22,7 @@ struct EpiGruFwd {
     const void* gi2; long ld_gi2;       // optional second addend (e.g. per-step token part), may be null
     const float* bhh;                   // [3H]
     float* hout; long ld_hout;
+    __bf16* hout16;                     // optional bf16 copy of the new state [M,H] dense (MFMA operand for later products)
     void* gates; long plane;            // saved (r, z, n, hn) as 4 planes [M,H]; null = do not save; fp32 or bf16
     const int* lengths; int t;          // packed-sequence mask: row m is updated iff t < lengths[m]
     const int* gi_idx;                  // optional: row m reads gi row gi_idx[m] (token-indexed gate table)
@@ -73,6 +74,7 @@ struct EpiGruFwd {
           h[e] = (1.0f - z[e]) * n[e] + z[e] * hP[e];
         }
         *reinterpret_cast<float4*>(p.hout + (long)m * p.ld_hout + j) = make_float4(h[0], h[1], h[2], h[3]);
+        if (p.hout16) st4f(p.hout16, (long)m * H + j, true, h[0], h[1], h[2], h[3]);
         if (p.gates) {
           const long gs = (long)m * H + j;
           st4f(p.gates, gs + 0 * p.plane, gbf, r[0], r[1], r[2], r[3]);
@@ -154,9 +156,15 @@ struct EpiGruBwd {
   }
 };
 
-template <class CT, int BM, int BJ>
+template <class CT, int BM, int BJ, bool SA>
 __global__ __launch_bounds__(NTHREADS) void gru_fwd_step_kernel(GemmArgs g, EpiGruFwd::Params ep) {
-  gemm_body<CT, BM, BJ, 2, 2, 3, false, false, EpiGruFwd, false, false, (BM * BJ <= 64 * 32 ? 3 : 1)>(g, ep);
+  gemm_body<CT, BM, BJ, 2, 2, 3, false, false, EpiGruFwd, SA, false, (BM * BJ <= 64 * 32 ? 3 : 1)>(g, ep);
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ src, long lds, __bf16* __restrict__ dst, long rows, int cols) {
+  const long total = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    dst[i] = (__bf16)src[(i / cols) * lds + (i % cols)];
 }
 template <class CT, int BM, int BN, bool SA>
 __global__ __launch_bounds__(NTHREADS) void gru_bwd_step_kernel(GemmArgs g, EpiGruBwd::Params ep) {
@@ -192,16 +200,25 @@ static inline void end(int i, hipStream_t s, double fl) {
 }
 }  // namespace prof
 
-template <class CT>
+template <class CT, bool SA>
 static void launch_fwd_step(const GemmArgs& g, const EpiGruFwd::Params& ep, hipStream_t s) {
   // units per block 64 (x3 gates) with 128 rows when that still fills the chip, else 32 x 64
   const long blocks_big = (long)cdiv(g.M, 128) * cdiv(g.N, 64);
   if (blocks_big >= 192) {
-    hipLaunchKernelGGL((gru_fwd_step_kernel<CT, 128, 64>), dim3(cdiv(g.N, 64), cdiv(g.M, 128)), dim3(NTHREADS), 0, s, g, ep);
+    hipLaunchKernelGGL((gru_fwd_step_kernel<CT, 128, 64, SA>), dim3(cdiv(g.N, 64), cdiv(g.M, 128)), dim3(NTHREADS), 0, s, g, ep);
   } else {
-    hipLaunchKernelGGL((gru_fwd_step_kernel<CT, 64, 32>), dim3(cdiv(g.N, 32), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
+    hipLaunchKernelGGL((gru_fwd_step_kernel<CT, 64, 32, SA>), dim3(cdiv(g.N, 32), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
   }
 }
+static void launch_fwd_any(int prec, bool a16, const GemmArgs& g, const EpiGruFwd::Params& ep, hipStream_t s) {
+  if (prec == PTV_PREC_BF16) { if (a16) launch_fwd_step<BF16, true>(g, ep, s); else launch_fwd_step<BF16, false>(g, ep, s); }
+  else launch_fwd_step<F32, false>(g, ep, s);
+}
+static void cast_rows_bf16(const float* src, long lds, void* dst, long rows, int cols, hipStream_t s) {
+  long nb = (rows * cols + 255) / 256; if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((int)nb), dim3(256), 0, s, src, lds, (__bf16*)dst, rows, cols);
+}
+
 template <class CT, bool SA>
 static void launch_bwd_step(const GemmArgs& g, const EpiGruBwd::Params& ep, hipStream_t s) {
   const long blocks_big = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
@@ -223,25 +240,28 @@ extern "C" int ptv_gru_seq_fwd(int prec, int M, int H, int T,
                                const void* gi, long gi_step_stride, long gi_ld,
                                const void* gi2, long gi2_step_stride, long gi2_ld,
                                const float* w_hh, const float* b_hh,
-                               float* hall, void* gates,
+                               float* hall, void* hall16, void* gates,
                                const int* lengths, int reverse, const int* gi_idx, int flags, void* stream) {
   if (M <= 0 || H <= 0 || T <= 0 || (H & 3) || !gi || !w_hh || !b_hh || !hall) return PTV_ERR_ARG;
   if ((gi_ld & 3) || (gi_step_stride & 3) || (gi2 && ((gi2_ld & 3) || (gi2_step_stride & 3)))) return PTV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const long MH = (long)M * H;
+  const bool a16 = hall16 != nullptr;
+  if (a16 && (prec != PTV_PREC_BF16 || (H & 7))) return PTV_ERR_ARG;
+  if (a16 && !(flags & PTV_GRU_SKIP_CAST0)) cast_rows_bf16(hall, H, hall16, M, H, s);   // slot 0 (the caller wrote it in fp32)
   for (int step = 0; step < T; step++) {
     const int t = reverse ? T - 1 - step : step;
-    GemmArgs g{hall + step * MH, H, w_hh, H, M, H, H, H, (long)H};
+    GemmArgs g{a16 ? (const void*)((const __bf16*)hall16 + step * MH) : (const void*)(hall + step * MH), H, w_hh, H, M, H, H, H, (long)H};
     const long esz_gi = (flags & PTV_GRU_GI_BF16) ? 2 : 4, esz_gi2 = (flags & PTV_GRU_GI2_BF16) ? 2 : 4;
     const long esz_g = (flags & PTV_GRU_GATES_BF16) ? 2 : 4;
     EpiGruFwd::Params ep{hall + step * MH, H,
                          (const char*)gi + t * gi_step_stride * esz_gi, gi_ld,
                          gi2 ? (const char*)gi2 + t * gi2_step_stride * esz_gi2 : nullptr, gi2_ld,
-                         b_hh, hall + (step + 1) * MH, H,
+                         b_hh, hall + (step + 1) * MH, H, a16 ? (__bf16*)hall16 + (step + 1) * MH : nullptr,
                          gates ? (char*)gates + (long)step * 4 * MH * esz_g : nullptr, MH,
                          lengths, t, gi_idx, H, flags};
     const int pi = prof::want(1, M, H) ? prof::begin(s) : -1;
-    if (prec == PTV_PREC_BF16) launch_fwd_step<BF16>(g, ep, s); else launch_fwd_step<F32>(g, ep, s);
+    launch_fwd_any(prec, a16, g, ep, s);
     if (pi >= 0) prof::end(pi, s, 2.0 * M * 3.0 * H * H);
   }
   PTV_CHECK_LAUNCH();
@@ -293,7 +313,7 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
 // single GRU cell step with fully explicit strides (the free-running decoder walks row slices of the
 // step-major buffers: its per-time-step batch is a [B]-row window of the [32*B]-row matrices)
 extern "C" int ptv_gru_step_fwd(int prec, int M, int H,
-                                const float* hprev, long ld_hprev,
+                                const float* hprev, long ld_hprev, const void* hprev16, void* hout16,
                                 const void* gi, long gi_ld, const void* gi2, long gi2_ld,
                                 const float* w_hh, const float* b_hh,
                                 float* hout, long ld_hout,
@@ -302,9 +322,11 @@ extern "C" int ptv_gru_step_fwd(int prec, int M, int H,
   if (M <= 0 || H <= 0 || (H & 3) || !hprev || !gi || !w_hh || !b_hh || !hout) return PTV_ERR_ARG;
   if ((gi_ld & 3) || (ld_hprev & 3) || (ld_hout & 3) || (gi2 && (gi2_ld & 3)) || (gates && (gates_plane & 3))) return PTV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  GemmArgs g{hprev, ld_hprev, w_hh, H, M, H, H, H, (long)H};
-  EpiGruFwd::Params ep{hprev, ld_hprev, gi, gi_ld, gi2, gi2_ld, b_hh, hout, ld_hout, gates, gates_plane, lengths, t, gi_idx, H, flags};
-  if (prec == PTV_PREC_BF16) launch_fwd_step<BF16>(g, ep, s); else launch_fwd_step<F32>(g, ep, s);
+  const bool a16 = hprev16 != nullptr;
+  if ((a16 || hout16) && (prec != PTV_PREC_BF16 || (H & 7))) return PTV_ERR_ARG;
+  GemmArgs g{a16 ? hprev16 : (const void*)hprev, a16 ? (long)H : ld_hprev, w_hh, H, M, H, H, H, (long)H};
+  EpiGruFwd::Params ep{hprev, ld_hprev, gi, gi_ld, gi2, gi2_ld, b_hh, hout, ld_hout, (__bf16*)hout16, gates, gates_plane, lengths, t, gi_idx, H, flags};
+  launch_fwd_any(prec, a16, g, ep, s);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

@@ -92,12 +92,17 @@ def _gru_flags(gates=None, gi=None, gi2=None, dg=None):
 
 
 def gru_fwd(prec, gi, gi_step, gi_ld, w_hh, b_hh, hall, gates, *, gi2=None, gi2_step=0, gi2_ld=0, lengths=None,
-            reverse=False, gi_idx=None, T=None):
+            reverse=False, gi_idx=None, T=None, hall16=None, skip_cast0=False):
     T1, M, H = hall.shape
     T = T1 - 1 if T is None else T
     call('ptv_gru_seq_fwd', prec, M, H, T, ptr(gi), gi_step, gi_ld, ptr(gi2), gi2_step, gi2_ld, ptr(w_hh),
-         ptr(b_hh), ptr(hall), ptr(gates), ptr(lengths), int(reverse), ptr(gi_idx), _gru_flags(gates, gi, gi2),
-         stream_ptr())
+         ptr(b_hh), ptr(hall), ptr(hall16), ptr(gates), ptr(lengths), int(reverse), ptr(gi_idx),
+         _gru_flags(gates, gi, gi2) | (32 if skip_cast0 else 0), stream_ptr())
+
+
+def _hall16(prec, T1, M, H, dev):
+    """bf16 shadow of a GRU state buffer (bf16 precision): MFMA operand of every later product on it"""
+    return _empty(T1, M, H, dev=dev, dtype=BF16) if _act_dtype(prec, H) == BF16 else None
 
 
 def gru_bwd(prec, hall, gates, w_hh, *, dh_ext=None, dh_last=None, lr=None, reverse=False, need_dh0=True):
@@ -259,16 +264,17 @@ def _bigru_forward(prec, x3, lengths, w):
         gi = gemm(xf, w_ih, bias=b_ih, prec=prec, out_dtype=_act_dtype(prec, H))          # [T*M, 3H]
         hall = _empty(T + 1, M, H, dev=dev)
         hall[0].zero_()
+        h16 = _hall16(prec, T + 1, M, H, dev)
         gates = _empty(T, 4, M, H, dev=dev, dtype=_act_dtype(prec, H))
-        gru_fwd(prec, gi, M * 3 * H, 3 * H, w_hh, b_hh, hall, gates, lengths=lengths, reverse=bool(d))
+        gru_fwd(prec, gi, M * 3 * H, 3 * H, w_hh, b_hh, hall, gates, lengths=lengths, reverse=bool(d), hall16=h16)
         copy2d(out[:, d * H:(d + 1) * H], hall[T])
-        return hall, gates, gi
+        return hall, gates, h16
 
     side = Side(7)
     rev = side(lambda: direction(1), xf, out)
     fwd = direction(0)
     side.join()
-    return out, [fwd[:2], rev[:2]]
+    return out, [fwd, rev]
 
 
 def _bigru_backward(prec, x3, w, saved, dout, need_dx):
@@ -278,12 +284,13 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
 
     def direction(d):
         w_ih, w_hh, b_ih, b_hh = w[4 * d: 4 * d + 4]
-        hall, gates = saved[d]
+        hall, gates, h16 = saved[d]
         dgi, dgh, _ = gru_bwd(prec, hall, gates, w_hh, dh_last=dout[:, d * H:(d + 1) * H], reverse=bool(d),
                               need_dh0=False)
         dgi2, dgh2 = dgi.view(T * M, 3 * H), dgh.view(T * M, 3 * H)
         dw_ih = gemm(dgi2, xf, _gbuf(w_ih), ta=True, tb=True, acc=True, prec=prec)
-        dw_hh = gemm(dgh2, hall[:T].view(T * M, H), _gbuf(w_hh), ta=True, tb=True, acc=True, prec=prec)
+        dw_hh = gemm(dgh2, (h16 if h16 is not None else hall)[:T].view(T * M, H), _gbuf(w_hh), ta=True, tb=True, acc=True,
+                     prec=prec)
         db_ih = _bgrad(b_ih, dgi2)
         db_hh = _bgrad(b_hh, dgh2)
         dx = gemm(dgi2, w_ih, tb=True, prec=prec) if need_dx else None
@@ -469,28 +476,33 @@ class DecoderTFFn(torch.autograd.Function):
         gi_t = gemm(TOKS[:32].view(R, 2 * He), w_ih_t[:, :2 * He], prec=prec)  # [32*B, 3Ht]
         zg = gemm(z_in, w_ih_t[:, 2 * He:], bias=P['dec_time_gru.bias_ih_l0'], prec=prec)
         gates_t = _empty(32, 4, B, Ht, dev=dev, dtype=_act_dtype(prec, Ht))
+        NS16 = _hall16(prec, 33, B, Ht, dev)
         gru_fwd(prec, gi_t, B * 3 * Ht, 3 * Ht, P['dec_time_gru.weight_hh_l0'], P['dec_time_gru.bias_hh_l0'], NS,
-                gates_t, gi2=zg, gi2_step=0, gi2_ld=3 * Ht)
+                gates_t, gi2=zg, gi2_step=0, gi2_ld=3 * Ht, hall16=NS16)
         NSf = NS[1:].view(R, Ht)                                               # notes_summary rows (t, b)
+        NSf_op = NS16[1:].view(R, Ht) if NS16 is not None else NSf              # same values as an MFMA operand
 
         # --- notes GRU: h0 = dec_time_to_notes_hid(ns); input [ns | token], ns part hoisted (ptvae.py:374-398)
         HN = _empty(16, R, Hn, dev=dev)
-        gemm(NSf, P['dec_time_to_notes_hid.weight'], HN[0], bias=P['dec_time_to_notes_hid.bias'], prec=prec)
+        gemm(NSf_op, P['dec_time_to_notes_hid.weight'], HN[0], bias=P['dec_time_to_notes_hid.bias'], prec=prec)
         w_ih_n = P['dec_notes_gru.weight_ih_l0']
         adt = _act_dtype(prec, Hn)
-        GC = gemm(NSf, w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec, out_dtype=adt)      # [R, 3Hn]
+        GC = gemm(NSf_op, w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec, out_dtype=adt)      # [R, 3Hn]
         GT = gemm(emb3[:15].view(15 * R, E), w_ih_n[:, Ht:], prec=prec, out_dtype=adt)                    # [15R, 3Hn]
         gates_n = _empty(15, 4, R, Hn, dev=dev, dtype=adt)
+        HN16 = _hall16(prec, 16, R, Hn, dev)
         gru_fwd(prec, GT, R * 3 * Hn, 3 * Hn, P['dec_notes_gru.weight_hh_l0'], P['dec_notes_gru.bias_hh_l0'], HN,
-                gates_n, gi2=GC, gi2_step=0, gi2_ld=3 * Hn)
+                gates_n, gi2=GC, gi2_step=0, gi2_ld=3 * Hn, hall16=HN16)
         NSUM = HN[1:].view(15 * R, Hn)
+        NSUM_op = HN16[1:].view(15 * R, Hn) if HN16 is not None else NSUM
 
         # --- pitch head + duration GRU initial state (ptvae.py:343-352)
         M = 15 * R
-        pitch = gemm(NSUM, P['pitch_out_linear.weight'], bias=P['pitch_out_linear.bias'], prec=prec)   # [M,130]
+        pitch = gemm(NSUM_op, P['pitch_out_linear.weight'], bias=P['pitch_out_linear.bias'], prec=prec)   # [M,130]
         w_dh = P['dur_hid_linear.weight']
         HD = _empty(6, M, Hd, dev=dev)
-        gemm(NSUM, w_dh[:, :Hn], HD[0], bias=P['dur_hid_linear.bias'], prec=prec)
+        HD16 = _hall16(prec, 6, M, Hd, dev)
+        gemm(NSUM_op, w_dh[:, :Hn], HD[0], bias=P['dur_hid_linear.bias'], prec=prec)
         gemm(pitch, w_dh[:, Hn:], HD[0], acc=True, prec=prec)
 
         # --- 5-step duration GRU with argmax feedback (ptvae.py:353-367)
@@ -504,13 +516,14 @@ class DecoderTFFn(torch.autograd.Function):
         for d in range(5):
             gi, gi_ld, gi_idx = (tab0, 0, None) if d == 0 else (tab, 3 * Hd, idx[d - 1])
             gru_fwd(prec, gi, 0, gi_ld, P['dec_dur_gru.weight_hh_l0'], P['dec_dur_gru.bias_hh_l0'], HD[d:d + 2],
-                    gates_d[d], gi_idx=gi_idx, T=1)
+                    gates_d[d], gi_idx=gi_idx, T=1, hall16=HD16[d:d + 2] if HD16 is not None else None, skip_cast0=d > 0)
             call('ptv_dur_out_token', ptr(HD[d + 1]), Hd, ptr(P['dur_out_linear.weight']), ptr(P['dur_out_linear.bias']),
                  ptr(dur2[:, 2 * d:]), 10, ptr(idx[d]), ptr(force_dur[d]) if force_dur is not None else None, M,
                  stream_ptr())
 
         S.save_for_backward(z, emb, *params)
-        S.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in,
+        S.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in, NS16=NS16, HN16=HN16,
+                    HD16=HD16,
                     TOKS=TOKS, gates_t=gates_t, HN=HN, gates_n=gates_n, pitch=pitch, HD=HD, gates_d=gates_d, idx=idx)
         S.mark_non_differentiable(idx)
         return pitch.view(15, 32, B, NP), dur, idx
@@ -531,6 +544,11 @@ class DecoderTFFn(torch.autograd.Function):
         NS, HN, HD, TOKS = st['NS'], st['HN'], st['HD'], st['TOKS']
         NSf = NS[1:].view(R, Ht)
         NSUM = HN[1:].view(M, Hn)
+        # bf16 shadows of the state buffers (bf16 precision) as the activation operands of the dW products
+        NSo = st['NS16'] if st.get('NS16') is not None else NS
+        HNo = st['HN16'] if st.get('HN16') is not None else HN
+        HDo = st['HD16'] if st.get('HD16') is not None else HD
+        NSf_op, NSUM_op = NSo[1:].view(R, Ht), HNo[1:].view(M, Hn)
         emb3 = emb.view(16, R, E)
         side = Side(3)
 
@@ -558,9 +576,9 @@ class DecoderTFFn(torch.autograd.Function):
 
         def dur_wgrads():
             for d in range(5):
-                wgrad('dur_out_linear.weight', ddur[:, 2 * d:2 * d + 2], HD[d + 1])
+                wgrad('dur_out_linear.weight', ddur[:, 2 * d:2 * d + 2], HDo[d + 1])
             bgrad('dur_out_linear.bias', ddur.view(M * 5, 2))
-            wgrad('dec_dur_gru.weight_hh_l0', dgh_d.view(5 * M, 3 * Hd), HD[:5].view(5 * M, Hd))
+            wgrad('dec_dur_gru.weight_hh_l0', dgh_d.view(5 * M, 3 * Hd), HDo[:5].view(5 * M, Hd))
             bgrad('dec_dur_gru.bias_hh_l0', dgh_d.view(5 * M, 3 * Hd))
             bgrad('dec_dur_gru.bias_ih_l0', dgi_d.view(5 * M, 3 * Hd))
             cs0 = colsum(_zeros(1, 3 * Hd, dev=dev), dgi_d[0])                   # step 0: dense <sos> token
@@ -582,10 +600,10 @@ class DecoderTFFn(torch.autograd.Function):
         gemm(dP, w_p, dNSUM, tb=True, acc=True, prec=prec)
 
         def head_wgrads():
-            wgrad('dur_hid_linear.weight', dHD0, NSUM, slice(0, Hn))
+            wgrad('dur_hid_linear.weight', dHD0, NSUM_op, slice(0, Hn))
             wgrad('dur_hid_linear.weight', dHD0, st['pitch'], slice(Hn, None))
             bgrad('dur_hid_linear.bias', dHD0)
-            wgrad('pitch_out_linear.weight', dP, NSUM)
+            wgrad('pitch_out_linear.weight', dP, NSUM_op)
             bgrad('pitch_out_linear.bias', dP)
         side(head_wgrads, dHD0, dP)
 
@@ -601,12 +619,12 @@ class DecoderTFFn(torch.autograd.Function):
         gemm(dHN0, w_tn, dNS, tb=True, acc=True, prec=prec)
 
         def notes_wgrads():
-            wgrad('dec_notes_gru.weight_hh_l0', dgh_n.view(M, 3 * Hn), HN[:15].view(M, Hn))
+            wgrad('dec_notes_gru.weight_hh_l0', dgh_n.view(M, 3 * Hn), HNo[:15].view(M, Hn))
             bgrad('dec_notes_gru.bias_hh_l0', dgh_n.view(M, 3 * Hn))
             bgrad('dec_notes_gru.bias_ih_l0', dGC)
-            wgrad('dec_notes_gru.weight_ih_l0', dGC, NSf, slice(0, Ht))
+            wgrad('dec_notes_gru.weight_ih_l0', dGC, NSf_op, slice(0, Ht))
             wgrad('dec_notes_gru.weight_ih_l0', dgi_n.view(M, 3 * Hn), emb3[:15].view(M, E), slice(Ht, None))
-            wgrad('dec_time_to_notes_hid.weight', dHN0, NSf)
+            wgrad('dec_time_to_notes_hid.weight', dHN0, NSf_op)
             bgrad('dec_time_to_notes_hid.bias', dHN0)
         side(notes_wgrads, dgi_n, dgh_n, dGC, dHN0, dNSUM)
 
@@ -624,7 +642,7 @@ class DecoderTFFn(torch.autograd.Function):
         gemm(dz_in, w_zi, dz, tb=True, acc=True, prec=prec)
 
         def time_wgrads():
-            wgrad('dec_time_gru.weight_hh_l0', dgh_t.view(R, 3 * Ht), NS[:32].view(R, Ht))
+            wgrad('dec_time_gru.weight_hh_l0', dgh_t.view(R, 3 * Ht), NSo[:32].view(R, Ht))
             bgrad('dec_time_gru.bias_hh_l0', dgh_t.view(R, 3 * Ht))
             bgrad('dec_time_gru.bias_ih_l0', dZG)
             wgrad('dec_time_gru.weight_ih_l0', dZG, st['z_in'], slice(2 * He, None))

@@ -36,7 +36,7 @@ def _sos_grid(dev):
 
 def gru_step(prec, hprev, gi, gi_ld, w_hh, b_hh, hout, *, gi2=None, gates=None, plane=0, lengths=None, t=0, gi_idx=None):
     M, H = hout.shape
-    call('ptv_gru_step_fwd', prec, M, H, ptr(hprev), hprev.stride(0), ptr(gi), gi_ld, ptr(gi2),
+    call('ptv_gru_step_fwd', prec, M, H, ptr(hprev), hprev.stride(0), None, None, ptr(gi), gi_ld, ptr(gi2),
          gi2.stride(0) if gi2 is not None else 0, ptr(w_hh), ptr(b_hh), ptr(hout), hout.stride(0), ptr(gates), plane,
          ptr(lengths), t, ptr(gi_idx), F_._gru_flags(gates, gi, gi2), stream_ptr())
 
@@ -299,7 +299,7 @@ class DecoderStepFn(torch.autograd.Function):
         call('ptv_route_slices', ptr(dTOKS[1:]), ptr(dxs), ptr(dxsp), ptr(mask_time), B * 2 * He, 32, 0, sp)
         if st['XH'] is not None:
             wE = [P['dec_notes_emb_gru.' + n] for n in EMB_GRU]
-            saved = [(st['XH'][0], st['XG'][0]), (st['XH'][1], st['XG'][1])]
+            saved = [(st['XH'][0], st['XG'][0], None), (st['XH'][1], st['XG'][1], None)]
             ge, dx_pred = _bigru_backward(prec, PRED, wE, saved, dxsp.view(R, 2 * He), True)
             for n, gg in zip(EMB_GRU, ge):
                 G['dec_notes_emb_gru.' + n] = gg
