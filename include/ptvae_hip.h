@@ -35,6 +35,7 @@ extern "C" {
 #define PTV_GRU_GI_BF16 2      /* gi */
 #define PTV_GRU_GI2_BF16 4     /* gi2 */
 #define PTV_GRU_DG_BF16 8      /* dgi / dgh (backward) */
+#define PTV_GRU_W_BF16 16       /* w_hh points at a bf16 copy of the weight (needs hall16 / DG_BF16) */
 #define PTV_GRU_SKIP_CAST0 32  /* hall16 slot 0 is already valid (chained single-step calls) */
 
 /* Library / build identification ("gfx950"). */
@@ -73,7 +74,7 @@ int ptv_gemm(int prec, int transA, int transB, int M, int N, int K,
 int ptv_gru_seq_fwd(int prec, int M, int H, int T,
                     const void* gi, long gi_step_stride, long gi_ld,
                     const void* gi2, long gi2_step_stride, long gi2_ld,
-                    const float* w_hh, const float* b_hh,
+                    const void* w_hh, const float* b_hh,
                     float* hall, void* hall16, void* gates,
                     const int* lengths, int reverse, const int* gi_idx, int flags, void* stream);
 
@@ -82,7 +83,7 @@ int ptv_gru_seq_fwd(int prec, int M, int H, int T,
 int ptv_gru_step_fwd(int prec, int M, int H,
                      const float* hprev, long ld_hprev, const void* hprev16, void* hout16,
                      const void* gi, long gi_ld, const void* gi2, long gi2_ld,
-                     const float* w_hh, const float* b_hh,
+                     const void* w_hh, const float* b_hh,
                      float* hout, long ld_hout,
                      void* gates, long gates_plane,
                      const int* lengths, int t, const int* gi_idx, int flags, void* stream);
@@ -97,7 +98,7 @@ int ptv_gru_step_fwd(int prec, int M, int H,
  * Weight gradients follow with ptv_gemm(transA=1,transB=1): dW_hh += dgh^T.hall[0:T], dW_ih += dgi^T.x
  */
 int ptv_gru_seq_bwd(int prec, int M, int H, int T,
-                    const float* hall, const void* gates, const float* w_hh,
+                    const float* hall, const void* gates, const void* w_hh,
                     const float* dh_ext, long ext_step_stride, long ext_ld,
                     const float* dh_last, long last_ld,
                     const float* lr_a, long lr_step_stride, long lr_lda, int lr_k, const float* lr_b,
@@ -198,6 +199,8 @@ int ptv_route_slices(const float* src, float* dstA, float* dstB, const int* mask
  * clip_grad_norm_ (module.py:142-143) + torch.optim.Adam.step (train.py:50, scheduler.py:69-74) over
  * flat fp32 buffers: sumsq = |g|^2 (device scalar), then p,m,v updated with g*gscale clipped to `clip`.
  */
+/* dst[i] = bf16(src[i]): refreshes the bf16 shadow of the flat parameter buffer once per step */
+int ptv_cast_bf16(const float* src, void* dst, long n, void* stream);
 int ptv_grad_sumsq(const float* g, long n, float* sumsq, void* stream);
 int ptv_clip_adam_step(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float gscale, float clip,
                        float lr, float beta1, float beta2, float eps, int step, void* stream);

@@ -156,9 +156,9 @@ struct EpiGruBwd {
   }
 };
 
-template <class CT, int BM, int BJ, bool SA>
+template <class CT, int BM, int BJ, bool SA, bool SB>
 __global__ __launch_bounds__(NTHREADS) void gru_fwd_step_kernel(GemmArgs g, EpiGruFwd::Params ep) {
-  gemm_body<CT, BM, BJ, 2, 2, 3, false, false, EpiGruFwd, SA, false, (BM * BJ <= 64 * 32 ? 3 : 1)>(g, ep);
+  gemm_body<CT, BM, BJ, 2, 2, 3, false, false, EpiGruFwd, SA, SB, (BM * BJ <= 64 * 32 ? 3 : 1)>(g, ep);
 }
 
 __global__ void cast_bf16_kernel(const float* __restrict__ src, long lds, __bf16* __restrict__ dst, long rows, int cols) {
@@ -166,9 +166,9 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, long lds, __bf16
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
     dst[i] = (__bf16)src[(i / cols) * lds + (i % cols)];
 }
-template <class CT, int BM, int BN, bool SA>
+template <class CT, int BM, int BN, bool SA, bool SB>
 __global__ __launch_bounds__(NTHREADS) void gru_bwd_step_kernel(GemmArgs g, EpiGruBwd::Params ep) {
-  gemm_body<CT, BM, BN, 2, 2, 1, false, true, EpiGruBwd, SA, false, (BM * BN <= 64 * 32 ? 4 : (BM * BN <= 64 * 64 ? 3 : 2))>(g, ep);
+  gemm_body<CT, BM, BN, 2, 2, 1, false, true, EpiGruBwd, SA, SB, (BM * BN <= 64 * 32 ? 4 : (BM * BN <= 64 * 64 ? 3 : 2))>(g, ep);
 }
 
 
@@ -200,35 +200,38 @@ static inline void end(int i, hipStream_t s, double fl) {
 }
 }  // namespace prof
 
-template <class CT, bool SA>
+template <class CT, bool SA, bool SB>
 static void launch_fwd_step(const GemmArgs& g, const EpiGruFwd::Params& ep, hipStream_t s) {
   // units per block 64 (x3 gates) with 128 rows when that still fills the chip, else 32 x 64
   const long blocks_big = (long)cdiv(g.M, 128) * cdiv(g.N, 64);
   if (blocks_big >= 192) {
-    hipLaunchKernelGGL((gru_fwd_step_kernel<CT, 128, 64, SA>), dim3(cdiv(g.N, 64), cdiv(g.M, 128)), dim3(NTHREADS), 0, s, g, ep);
+    hipLaunchKernelGGL((gru_fwd_step_kernel<CT, 128, 64, SA, SB>), dim3(cdiv(g.N, 64), cdiv(g.M, 128)), dim3(NTHREADS), 0, s, g, ep);
   } else {
-    hipLaunchKernelGGL((gru_fwd_step_kernel<CT, 64, 32, SA>), dim3(cdiv(g.N, 32), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
+    hipLaunchKernelGGL((gru_fwd_step_kernel<CT, 64, 32, SA, SB>), dim3(cdiv(g.N, 32), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
   }
 }
-static void launch_fwd_any(int prec, bool a16, const GemmArgs& g, const EpiGruFwd::Params& ep, hipStream_t s) {
-  if (prec == PTV_PREC_BF16) { if (a16) launch_fwd_step<BF16, true>(g, ep, s); else launch_fwd_step<BF16, false>(g, ep, s); }
-  else launch_fwd_step<F32, false>(g, ep, s);
+static void launch_fwd_any(int prec, bool a16, bool w16, const GemmArgs& g, const EpiGruFwd::Params& ep, hipStream_t s) {
+  if (prec == PTV_PREC_BF16) {
+    if (a16 && w16) launch_fwd_step<BF16, true, true>(g, ep, s);
+    else if (a16) launch_fwd_step<BF16, true, false>(g, ep, s);
+    else launch_fwd_step<BF16, false, false>(g, ep, s);
+  } else launch_fwd_step<F32, false, false>(g, ep, s);
 }
 static void cast_rows_bf16(const float* src, long lds, void* dst, long rows, int cols, hipStream_t s) {
   long nb = (rows * cols + 255) / 256; if (nb > 2048) nb = 2048;
   hipLaunchKernelGGL(cast_bf16_kernel, dim3((int)nb), dim3(256), 0, s, src, lds, (__bf16*)dst, rows, cols);
 }
 
-template <class CT, bool SA>
+template <class CT, bool SA, bool SB>
 static void launch_bwd_step(const GemmArgs& g, const EpiGruBwd::Params& ep, hipStream_t s) {
   const long blocks_big = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
   const long blocks_mid = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
   if (blocks_big >= 192) {
-    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 128, 128, SA>), dim3(cdiv(g.N, 128), cdiv(g.M, 128)), dim3(NTHREADS), 0, s, g, ep);
+    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 128, 128, SA, SB>), dim3(cdiv(g.N, 128), cdiv(g.M, 128)), dim3(NTHREADS), 0, s, g, ep);
   } else if (blocks_mid >= 192) {
-    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 64, 64, SA>), dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
+    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 64, 64, SA, SB>), dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
   } else {
-    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 64, 32, SA>), dim3(cdiv(g.N, 32), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
+    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 64, 32, SA, SB>), dim3(cdiv(g.N, 32), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
   }
 }
 
@@ -239,7 +242,7 @@ using namespace ptv;
 extern "C" int ptv_gru_seq_fwd(int prec, int M, int H, int T,
                                const void* gi, long gi_step_stride, long gi_ld,
                                const void* gi2, long gi2_step_stride, long gi2_ld,
-                               const float* w_hh, const float* b_hh,
+                               const void* w_hh, const float* b_hh,
                                float* hall, void* hall16, void* gates,
                                const int* lengths, int reverse, const int* gi_idx, int flags, void* stream) {
   if (M <= 0 || H <= 0 || T <= 0 || (H & 3) || !gi || !w_hh || !b_hh || !hall) return PTV_ERR_ARG;
@@ -247,7 +250,9 @@ extern "C" int ptv_gru_seq_fwd(int prec, int M, int H, int T,
   hipStream_t s = (hipStream_t)stream;
   const long MH = (long)M * H;
   const bool a16 = hall16 != nullptr;
-  if (a16 && (prec != PTV_PREC_BF16 || (H & 7))) return PTV_ERR_ARG;
+  const bool w16 = flags & PTV_GRU_W_BF16;
+  if ((a16 || w16) && (prec != PTV_PREC_BF16 || (H & 7))) return PTV_ERR_ARG;
+  if (w16 && !a16) return PTV_ERR_ARG;                           // bf16 weights ride with the bf16 state shadow
   if (a16 && !(flags & PTV_GRU_SKIP_CAST0)) cast_rows_bf16(hall, H, hall16, M, H, s);   // slot 0 (the caller wrote it in fp32)
   for (int step = 0; step < T; step++) {
     const int t = reverse ? T - 1 - step : step;
@@ -261,7 +266,7 @@ extern "C" int ptv_gru_seq_fwd(int prec, int M, int H, int T,
                          gates ? (char*)gates + (long)step * 4 * MH * esz_g : nullptr, MH,
                          lengths, t, gi_idx, H, flags};
     const int pi = prof::want(1, M, H) ? prof::begin(s) : -1;
-    launch_fwd_any(prec, a16, g, ep, s);
+    launch_fwd_any(prec, a16, w16, g, ep, s);
     if (pi >= 0) prof::end(pi, s, 2.0 * M * 3.0 * H * H);
   }
   PTV_CHECK_LAUNCH();
@@ -269,7 +274,7 @@ extern "C" int ptv_gru_seq_fwd(int prec, int M, int H, int T,
 }
 
 extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
-                               const float* hall, const void* gates, const float* w_hh,
+                               const float* hall, const void* gates, const void* w_hh,
                                const float* dh_ext, long ext_step_stride, long ext_ld,
                                const float* dh_last, long last_ld,
                                const float* lr_a, long lr_step_stride, long lr_lda, int lr_k, const float* lr_b,
@@ -277,6 +282,8 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
                                int reverse, int flags, void* stream) {
   if (M <= 0 || H <= 0 || T <= 0 || (H & 3) || !hall || !gates || !w_hh || !dgi || !dgh || !dhz) return PTV_ERR_ARG;
   if ((flags & PTV_GRU_DG_BF16) && (prec != PTV_PREC_BF16 || (H & 7))) return PTV_ERR_ARG;
+  const bool w16 = flags & PTV_GRU_W_BF16;
+  if (w16 && !(flags & PTV_GRU_DG_BF16)) return PTV_ERR_ARG;
   if (dh_ext && ((ext_ld & 3) || (ext_step_stride & 3))) return PTV_ERR_ARG;
   if (dh_last && (last_ld & 3)) return PTV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -297,15 +304,18 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
                          (char*)dgi + (long)t * M3H * esz_d, (char*)dgh + (long)step * M3H * esz_d,
                          dhz + (step & 1) * MH, H, flags};
     const int pi = prof::want(2, M, H) ? prof::begin(s) : -1;
-    if (prec == PTV_PREC_BF16) { if (dbf) launch_bwd_step<BF16, true>(g, ep, s); else launch_bwd_step<BF16, false>(g, ep, s); }
-    else launch_bwd_step<F32, false>(g, ep, s);
+    if (prec == PTV_PREC_BF16) {
+      if (dbf && w16) launch_bwd_step<BF16, true, true>(g, ep, s);
+      else if (dbf) launch_bwd_step<BF16, true, false>(g, ep, s);
+      else launch_bwd_step<BF16, false, false>(g, ep, s);
+    } else launch_bwd_step<F32, false, false>(g, ep, s);
     if (pi >= 0) prof::end(pi, s, last ? 0.0 : 2.0 * M * 3.0 * H * H);
   }
   PTV_CHECK_LAUNCH();
   if (dh0) {
     // dh0 = dhz_0 + dgh_0 . W_hh
     if (hipMemcpyAsync(dh0, dhz, MH * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return PTV_ERR_LAUNCH;
-    PTV_TRY(ptv_gemm(prec, 0, 1, M, H, 3 * H, dgh, 3L * H, w_hh, H, dh0, H, nullptr, 1.0f, 1, 0, -1, (flags & PTV_GRU_DG_BF16) ? 1 : 0, stream));
+    PTV_TRY(ptv_gemm(prec, 0, 1, M, H, 3 * H, dgh, 3L * H, w_hh, H, dh0, H, nullptr, 1.0f, 1, 0, -1, ((flags & PTV_GRU_DG_BF16) ? 1 : 0) | (w16 ? 2 : 0), stream));
   }
   return PTV_OK;
 }
@@ -315,7 +325,7 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
 extern "C" int ptv_gru_step_fwd(int prec, int M, int H,
                                 const float* hprev, long ld_hprev, const void* hprev16, void* hout16,
                                 const void* gi, long gi_ld, const void* gi2, long gi2_ld,
-                                const float* w_hh, const float* b_hh,
+                                const void* w_hh, const float* b_hh,
                                 float* hout, long ld_hout,
                                 void* gates, long gates_plane,
                                 const int* lengths, int t, const int* gi_idx, int flags, void* stream) {
@@ -323,10 +333,12 @@ extern "C" int ptv_gru_step_fwd(int prec, int M, int H,
   if ((gi_ld & 3) || (ld_hprev & 3) || (ld_hout & 3) || (gi2 && (gi2_ld & 3)) || (gates && (gates_plane & 3))) return PTV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const bool a16 = hprev16 != nullptr;
-  if ((a16 || hout16) && (prec != PTV_PREC_BF16 || (H & 7))) return PTV_ERR_ARG;
+  const bool w16 = flags & PTV_GRU_W_BF16;
+  if ((a16 || hout16 || w16) && (prec != PTV_PREC_BF16 || (H & 7))) return PTV_ERR_ARG;
+  if (w16 && !a16) return PTV_ERR_ARG;
   GemmArgs g{a16 ? hprev16 : (const void*)hprev, a16 ? (long)H : ld_hprev, w_hh, H, M, H, H, H, (long)H};
   EpiGruFwd::Params ep{hprev, ld_hprev, gi, gi_ld, gi2, gi2_ld, b_hh, hout, ld_hout, (__bf16*)hout16, gates, gates_plane, lengths, t, gi_idx, H, flags};
-  launch_fwd_any(prec, a16, g, ep, s);
+  launch_fwd_any(prec, a16, w16, g, ep, s);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

@@ -1,5 +1,6 @@
 // misc.hip -- duration-head token kernel, chord-decoder token kernel, fused clip + Adam.
 #include "common.hpp"
+#include "gemm_core.hpp"
 #include "../../include/ptvae_hip.h"
 
 namespace ptv {
@@ -27,6 +28,13 @@ __global__ void dur_out_token_kernel(const float* __restrict__ h, int H, const f
 // gradient global norm + clip_grad_norm_(.,clip) + Adam (module.py:142-144, train.py:50) over the
 // flat parameter / gradient buffers.  Two launches, no host sync: the norm stays on the device.
 // ---------------------------------------------------------------------------------------------
+__global__ void cast_flat_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    st4f(dst, i * 4, true, v.x, v.y, v.z, v.w);
+  }
+}
+
 __global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
   __shared__ float red[4];
   float s = 0.f;
@@ -194,6 +202,14 @@ extern "C" int ptv_route_slices(const float* src, float* dstA, float* dstB, cons
   if (!src || !mask || slice_elems <= 0 || nslices <= 0) return PTV_ERR_ARG;
   long nb = (slice_elems * nslices + 255) / 256; if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(route_slices_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, src, dstA, dstB, mask, slice_elems, nslices, accumulate);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_cast_bf16(const float* src, void* dst, long n, void* stream) {
+  if (!src || !dst || n <= 0 || (n & 3)) return PTV_ERR_ARG;
+  long nb = (n / 4 + 255) / 256; if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(cast_flat_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, n / 4);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

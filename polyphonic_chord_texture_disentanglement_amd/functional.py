@@ -29,6 +29,16 @@ def _bf(t):
     return 1 if (t is not None and t.dtype == BF16) else 0
 
 
+def _W(p, prec):
+    """weight as an MFMA operand: its bf16 shadow in bf16 precision when the optimiser keeps one"""
+    if prec == 1 and BF16_STORAGE and p.dim() >= 2 and p.shape[-1] % 8 == 0:
+        from .optim import weight_shadow
+        w = weight_shadow(p)
+        if w is not None:
+            return w
+    return p
+
+
 def _zeros(*shape, dev):
     return torch.zeros(*shape, device=dev, dtype=F32)
 
@@ -87,17 +97,19 @@ def transpose01(x):
     return out
 
 
-def _gru_flags(gates=None, gi=None, gi2=None, dg=None):
-    return _bf(gates) | (_bf(gi) << 1) | (_bf(gi2) << 2) | (_bf(dg) << 3)
+def _gru_flags(gates=None, gi=None, gi2=None, dg=None, w=None):
+    return _bf(gates) | (_bf(gi) << 1) | (_bf(gi2) << 2) | (_bf(dg) << 3) | (_bf(w) << 4)
 
 
 def gru_fwd(prec, gi, gi_step, gi_ld, w_hh, b_hh, hall, gates, *, gi2=None, gi2_step=0, gi2_ld=0, lengths=None,
             reverse=False, gi_idx=None, T=None, hall16=None, skip_cast0=False):
     T1, M, H = hall.shape
     T = T1 - 1 if T is None else T
+    if hall16 is not None:
+        w_hh = _W(w_hh, prec)
     call('ptv_gru_seq_fwd', prec, M, H, T, ptr(gi), gi_step, gi_ld, ptr(gi2), gi2_step, gi2_ld, ptr(w_hh),
          ptr(b_hh), ptr(hall), ptr(hall16), ptr(gates), ptr(lengths), int(reverse), ptr(gi_idx),
-         _gru_flags(gates, gi, gi2) | (32 if skip_cast0 else 0), stream_ptr())
+         _gru_flags(gates, gi, gi2, w=w_hh) | (32 if skip_cast0 else 0), stream_ptr())
 
 
 def _hall16(prec, T1, M, H, dev):
@@ -119,7 +131,7 @@ def gru_bwd(prec, hall, gates, w_hh, *, dh_ext=None, dh_last=None, lr=None, reve
     last = (ptr(dh_last), dh_last.stride(0)) if dh_last is not None else (None, 0)
     lra = (ptr(lr[0]), lr[1], lr[2], lr[3], ptr(lr[4])) if lr is not None else (None, 0, 0, 0, None)
     call('ptv_gru_seq_bwd', prec, M, H, T, ptr(hall), ptr(gates), ptr(w_hh), *ext, *last, *lra, ptr(dgi),
-         ptr(dgh), ptr(dhz), ptr(dh0), int(reverse), _gru_flags(gates, dg=dgi), stream_ptr())
+         ptr(dgh), ptr(dhz), ptr(dh0), int(reverse), _gru_flags(gates, dg=dgi, w=w_hh), stream_ptr())
     return dgi, dgh, dh0
 
 
@@ -186,7 +198,7 @@ def _as2d(t):
 class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2, w, b, prec):
-        y = gemm(x2, w, bias=b, prec=prec)
+        y = gemm(x2, _W(w, prec), bias=b, prec=prec)
         ctx.save_for_backward(x2, w, b)
         ctx.prec = prec
         return y
@@ -261,7 +273,7 @@ def _bigru_forward(prec, x3, lengths, w):
 
     def direction(d):
         w_ih, w_hh, b_ih, b_hh = w[4 * d: 4 * d + 4]
-        gi = gemm(xf, w_ih, bias=b_ih, prec=prec, out_dtype=_act_dtype(prec, H))          # [T*M, 3H]
+        gi = gemm(xf, _W(w_ih, prec), bias=b_ih, prec=prec, out_dtype=_act_dtype(prec, H))          # [T*M, 3H]
         hall = _empty(T + 1, M, H, dev=dev)
         hall[0].zero_()
         h16 = _hall16(prec, T + 1, M, H, dev)
@@ -329,8 +341,8 @@ class BiGruFinalFn(torch.autograd.Function):
 class EncoderHeadsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, w_mu, b_mu, w_var, b_var, prec):
-        mu = gemm(h, w_mu, bias=b_mu, prec=prec)
-        sd = gemm(h, w_var, bias=b_var, act=1, prec=prec)
+        mu = gemm(h, _W(w_mu, prec), bias=b_mu, prec=prec)
+        sd = gemm(h, _W(w_var, prec), bias=b_var, act=1, prec=prec)
         ctx.save_for_backward(h, w_mu, w_var, mu, sd, b_mu, b_var)
         ctx.prec = prec
         return mu, sd
@@ -448,22 +460,23 @@ class DecoderTFFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, emb, xs, force_dur, prec, *params):
         P = dict(zip(DEC_PARAM_NAMES, params))
+        W = {n: _W(p, prec) for n, p in P.items()}            # bf16 shadows of the weights as MFMA operands
         dev = z.device
         z = z.contiguous()
         B = z.shape[0]
         R = 32 * B
         E = emb.shape[-1]
-        He = P['dec_notes_emb_gru.weight_hh_l0'].shape[1]
-        Ht = P['dec_time_gru.weight_hh_l0'].shape[1]
-        Hn = P['dec_notes_gru.weight_hh_l0'].shape[1]
-        Hd = P['dec_dur_gru.weight_hh_l0'].shape[1]
-        NP = P['pitch_out_linear.weight'].shape[0]              # 130
+        He = W['dec_notes_emb_gru.weight_hh_l0'].shape[1]
+        Ht = W['dec_time_gru.weight_hh_l0'].shape[1]
+        Hn = W['dec_notes_gru.weight_hh_l0'].shape[1]
+        Hd = W['dec_dur_gru.weight_hh_l0'].shape[1]
+        NP = W['pitch_out_linear.weight'].shape[0]              # 130
         S = ctx                                                  # stash everything on ctx
 
         # --- z -> initial time state, z_in  (ptvae.py:435-437)
         NS = _empty(33, B, Ht, dev=dev)
-        gemm(z, P['z2dec_hid_linear.weight'], NS[0], bias=P['z2dec_hid_linear.bias'], prec=prec)
-        z_in = gemm(z, P['z2dec_in_linear.weight'], bias=P['z2dec_in_linear.bias'], prec=prec)
+        gemm(z, W['z2dec_hid_linear.weight'], NS[0], bias=P['z2dec_hid_linear.bias'], prec=prec)
+        z_in = gemm(z, W['z2dec_in_linear.weight'], bias=P['z2dec_in_linear.bias'], prec=prec)
 
         emb3 = emb.view(16, R, E)
         xs = xs.contiguous()
@@ -472,41 +485,41 @@ class DecoderTFFn(torch.autograd.Function):
         TOKS = _empty(33, B, 2 * He, dev=dev)
         copy2d(TOKS[0], P['dec_init_input'].view(1, -1), lds=0)
         copy2d(TOKS[1:].view(R, 2 * He), xs)
-        w_ih_t = P['dec_time_gru.weight_ih_l0']
+        w_ih_t = W['dec_time_gru.weight_ih_l0']
         gi_t = gemm(TOKS[:32].view(R, 2 * He), w_ih_t[:, :2 * He], prec=prec)  # [32*B, 3Ht]
         zg = gemm(z_in, w_ih_t[:, 2 * He:], bias=P['dec_time_gru.bias_ih_l0'], prec=prec)
         gates_t = _empty(32, 4, B, Ht, dev=dev, dtype=_act_dtype(prec, Ht))
         NS16 = _hall16(prec, 33, B, Ht, dev)
-        gru_fwd(prec, gi_t, B * 3 * Ht, 3 * Ht, P['dec_time_gru.weight_hh_l0'], P['dec_time_gru.bias_hh_l0'], NS,
+        gru_fwd(prec, gi_t, B * 3 * Ht, 3 * Ht, W['dec_time_gru.weight_hh_l0'], P['dec_time_gru.bias_hh_l0'], NS,
                 gates_t, gi2=zg, gi2_step=0, gi2_ld=3 * Ht, hall16=NS16)
         NSf = NS[1:].view(R, Ht)                                               # notes_summary rows (t, b)
         NSf_op = NS16[1:].view(R, Ht) if NS16 is not None else NSf              # same values as an MFMA operand
 
         # --- notes GRU: h0 = dec_time_to_notes_hid(ns); input [ns | token], ns part hoisted (ptvae.py:374-398)
         HN = _empty(16, R, Hn, dev=dev)
-        gemm(NSf_op, P['dec_time_to_notes_hid.weight'], HN[0], bias=P['dec_time_to_notes_hid.bias'], prec=prec)
-        w_ih_n = P['dec_notes_gru.weight_ih_l0']
+        gemm(NSf_op, W['dec_time_to_notes_hid.weight'], HN[0], bias=P['dec_time_to_notes_hid.bias'], prec=prec)
+        w_ih_n = W['dec_notes_gru.weight_ih_l0']
         adt = _act_dtype(prec, Hn)
         GC = gemm(NSf_op, w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec, out_dtype=adt)      # [R, 3Hn]
         GT = gemm(emb3[:15].view(15 * R, E), w_ih_n[:, Ht:], prec=prec, out_dtype=adt)                    # [15R, 3Hn]
         gates_n = _empty(15, 4, R, Hn, dev=dev, dtype=adt)
         HN16 = _hall16(prec, 16, R, Hn, dev)
-        gru_fwd(prec, GT, R * 3 * Hn, 3 * Hn, P['dec_notes_gru.weight_hh_l0'], P['dec_notes_gru.bias_hh_l0'], HN,
+        gru_fwd(prec, GT, R * 3 * Hn, 3 * Hn, W['dec_notes_gru.weight_hh_l0'], P['dec_notes_gru.bias_hh_l0'], HN,
                 gates_n, gi2=GC, gi2_step=0, gi2_ld=3 * Hn, hall16=HN16)
         NSUM = HN[1:].view(15 * R, Hn)
         NSUM_op = HN16[1:].view(15 * R, Hn) if HN16 is not None else NSUM
 
         # --- pitch head + duration GRU initial state (ptvae.py:343-352)
         M = 15 * R
-        pitch = gemm(NSUM_op, P['pitch_out_linear.weight'], bias=P['pitch_out_linear.bias'], prec=prec)   # [M,130]
-        w_dh = P['dur_hid_linear.weight']
+        pitch = gemm(NSUM_op, W['pitch_out_linear.weight'], bias=P['pitch_out_linear.bias'], prec=prec)   # [M,130]
+        w_dh = W['dur_hid_linear.weight']
         HD = _empty(6, M, Hd, dev=dev)
         HD16 = _hall16(prec, 6, M, Hd, dev)
         gemm(NSUM_op, w_dh[:, :Hn], HD[0], bias=P['dur_hid_linear.bias'], prec=prec)
         gemm(pitch, w_dh[:, Hn:], HD[0], acc=True, prec=prec)
 
         # --- 5-step duration GRU with argmax feedback (ptvae.py:353-367)
-        w_ih_d, b_ih_d = P['dec_dur_gru.weight_ih_l0'], P['dec_dur_gru.bias_ih_l0']
+        w_ih_d, b_ih_d = W['dec_dur_gru.weight_ih_l0'], P['dec_dur_gru.bias_ih_l0']
         tab0 = gemm(P['dur_sos_token'].view(1, -1), w_ih_d, bias=b_ih_d, prec=0)       # [1, 3Hd]  (tiny: exact)
         tab = gemm(_onehot2x5(dev), w_ih_d, bias=b_ih_d, prec=0)                       # [2, 3Hd]
         gates_d = _empty(5, 4, M, Hd, dev=dev, dtype=_act_dtype(prec, Hd))
@@ -515,7 +528,7 @@ class DecoderTFFn(torch.autograd.Function):
         dur2 = dur.view(M, 10)
         for d in range(5):
             gi, gi_ld, gi_idx = (tab0, 0, None) if d == 0 else (tab, 3 * Hd, idx[d - 1])
-            gru_fwd(prec, gi, 0, gi_ld, P['dec_dur_gru.weight_hh_l0'], P['dec_dur_gru.bias_hh_l0'], HD[d:d + 2],
+            gru_fwd(prec, gi, 0, gi_ld, W['dec_dur_gru.weight_hh_l0'], P['dec_dur_gru.bias_hh_l0'], HD[d:d + 2],
                     gates_d[d], gi_idx=gi_idx, T=1, hall16=HD16[d:d + 2] if HD16 is not None else None, skip_cast0=d > 0)
             call('ptv_dur_out_token', ptr(HD[d + 1]), Hd, ptr(P['dur_out_linear.weight']), ptr(P['dur_out_linear.bias']),
                  ptr(dur2[:, 2 * d:]), 10, ptr(idx[d]), ptr(force_dur[d]) if force_dur is not None else None, M,
@@ -538,6 +551,7 @@ class DecoderTFFn(torch.autograd.Function):
         st = ctx.st
         ctx.st = None
         B, R, E, He, Ht, Hn, Hd, NP, prec = (st[k] for k in ('B', 'R', 'E', 'He', 'Ht', 'Hn', 'Hd', 'NP', 'prec'))
+        W = P                                             # K-major (dX) products read the fp32 weights
         dev = z.device
         M = 15 * R
         G = {n: None for n in DEC_PARAM_NAMES}
@@ -571,7 +585,7 @@ class DecoderTFFn(torch.autograd.Function):
 
         # ---- duration GRU (5 steps) ----
         w_out = P['dur_out_linear.weight']
-        w_hh_d, w_ih_d = P['dec_dur_gru.weight_hh_l0'], P['dec_dur_gru.weight_ih_l0']
+        w_hh_d, w_ih_d = W['dec_dur_gru.weight_hh_l0'], W['dec_dur_gru.weight_ih_l0']
         dgi_d, dgh_d, dHD0 = gru_bwd(prec, HD, st['gates_d'], w_hh_d, lr=(ddur, 2, 10, 2, w_out))
 
         def dur_wgrads():
@@ -582,7 +596,7 @@ class DecoderTFFn(torch.autograd.Function):
             bgrad('dec_dur_gru.bias_hh_l0', dgh_d.view(5 * M, 3 * Hd))
             bgrad('dec_dur_gru.bias_ih_l0', dgi_d.view(5 * M, 3 * Hd))
             cs0 = colsum(_zeros(1, 3 * Hd, dev=dev), dgi_d[0])                   # step 0: dense <sos> token
-            g = _gbuf(w_ih_d)
+            g = _gbuf(P['dec_dur_gru.weight_ih_l0'])
             gemm(cs0, P['dur_sos_token'].view(1, -1), g, ta=True, tb=True, acc=True, prec=0, splitk=-1)
             G['dur_sos_token'] = _gbuf(P['dur_sos_token'])
             gemm(cs0, w_ih_d, G['dur_sos_token'].view(1, -1), tb=True, prec=0, splitk=-1)
@@ -594,7 +608,7 @@ class DecoderTFFn(torch.autograd.Function):
         side(dur_wgrads, ddur, dgi_d, dgh_d)
 
         # ---- dur_hid_linear([note_summary | est_pitch]) and pitch_out_linear ----
-        w_dh, w_p = P['dur_hid_linear.weight'], P['pitch_out_linear.weight']
+        w_dh, w_p = W['dur_hid_linear.weight'], W['pitch_out_linear.weight']
         dNSUM = gemm(dHD0, w_dh[:, :Hn], tb=True, prec=prec)                      # [M, Hn]
         gemm(dHD0, w_dh[:, Hn:], dP, tb=True, acc=True, prec=prec)
         gemm(dP, w_p, dNSUM, tb=True, acc=True, prec=prec)
@@ -608,14 +622,14 @@ class DecoderTFFn(torch.autograd.Function):
         side(head_wgrads, dHD0, dP)
 
         # ---- notes GRU (15 steps, batch 32*B) ----
-        w_hh_n, w_ih_n = P['dec_notes_gru.weight_hh_l0'], P['dec_notes_gru.weight_ih_l0']
+        w_hh_n, w_ih_n = W['dec_notes_gru.weight_hh_l0'], W['dec_notes_gru.weight_ih_l0']
         dgi_n, dgh_n, dHN0 = gru_bwd(prec, HN, st['gates_n'], w_hh_n, dh_ext=dNSUM.view(15, R, Hn))
         dGC = sum_steps(dgi_n)                                                    # [R, 3Hn]
         demb = _empty(16, R, E, dev=dev)
         demb[15].zero_()
         gemm(dgi_n.view(M, 3 * Hn), w_ih_n[:, Ht:], demb[:15].view(M, E), tb=True, prec=prec)
         dNS = gemm(dGC, w_ih_n[:, :Ht], tb=True, prec=prec)                       # [R, Ht]
-        w_tn = P['dec_time_to_notes_hid.weight']
+        w_tn = W['dec_time_to_notes_hid.weight']
         gemm(dHN0, w_tn, dNS, tb=True, acc=True, prec=prec)
 
         def notes_wgrads():
@@ -629,7 +643,7 @@ class DecoderTFFn(torch.autograd.Function):
         side(notes_wgrads, dgi_n, dgh_n, dGC, dHN0, dNSUM)
 
         # ---- time GRU (32 steps, batch B) ----
-        w_hh_t, w_ih_t = P['dec_time_gru.weight_hh_l0'], P['dec_time_gru.weight_ih_l0']
+        w_hh_t, w_ih_t = W['dec_time_gru.weight_hh_l0'], W['dec_time_gru.weight_ih_l0']
         dgi_t, dgh_t, dzhid = gru_bwd(prec, NS, st['gates_t'], w_hh_t, dh_ext=dNS.view(32, B, Ht))
         dZG = sum_steps(dgi_t)                                                    # [B, 3Ht]
         dz_in = gemm(dZG, w_ih_t[:, 2 * He:], tb=True, prec=prec)                 # [B, Zi]
@@ -637,7 +651,7 @@ class DecoderTFFn(torch.autograd.Function):
         dTOKS[32].zero_()
         gemm(dgi_t.view(R, 3 * Ht), w_ih_t[:, :2 * He], dTOKS[:32].view(R, 2 * He), tb=True, prec=prec)
         dxs = dTOKS[1:].view(R, 2 * He)
-        w_zh, w_zi = P['z2dec_hid_linear.weight'], P['z2dec_in_linear.weight']
+        w_zh, w_zi = W['z2dec_hid_linear.weight'], W['z2dec_in_linear.weight']
         dz = gemm(dzhid, w_zh, tb=True, prec=prec)
         gemm(dz_in, w_zi, dz, tb=True, acc=True, prec=prec)
 

@@ -9,6 +9,7 @@ import torch
 
 from . import functional as F_
 from .amc_dl.torch_plus import PytorchModel
+from .optim import refresh_weight_shadows
 from .ptvae import HipNormal, PtvaeDecoder, RnnDecoder, RnnEncoder, TextureEncoder
 
 LOSS_NAMES = ['loss', 'recon_loss', 'pl', 'dl', 'kl_loss', 'kl_chd', 'kl_rhy', 'chord_loss', 'root_loss',
@@ -41,6 +42,7 @@ class DisentangleVAE(PytorchModel):
 
     # ---- model.py:42-55
     def run(self, x, c, pr_mat, tfr1, tfr2, tfr3, confuse=True):
+        refresh_weight_shadows()                         # bf16 operand copies of the flat parameter buffer (if any)
         embedded_x, lengths = self.decoder.emb_x(x)
         # the two encoders are independent of each other and of the embedding: sibling HIP streams
         # (autograd replays each branch's backward on the stream its forward ran on)

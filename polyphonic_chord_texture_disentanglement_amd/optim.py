@@ -15,6 +15,7 @@ import torch
 from ._lib import call, ptr, stream_ptr
 
 _ARENA_OF = {}          # id(param) -> GradArena
+_SHADOW_OF = {}         # id(param) -> (FusedClipAdam, offset): bf16 copy of the flat parameter buffer
 
 
 class GradArena:
@@ -25,7 +26,7 @@ class GradArena:
         off = 0
         for p in self.params:
             self.offsets.append(off)
-            off += (p.numel() + 3) // 4 * 4            # keep every view 16-byte aligned
+            off += (p.numel() + 7) // 8 * 8            # every view 16-byte aligned in the fp32 AND the bf16 copy
         self.total = off
         self.flat = torch.zeros(off, device=dev, dtype=torch.float32)
         self._index = {id(p): i for i, p in enumerate(self.params)}
@@ -66,6 +67,25 @@ class GradArena:
             p.grad = v
 
 
+def weight_shadow(p):
+    """bf16 copy of parameter p (a view of the optimiser's bf16 shadow of the flat parameter buffer), or None.
+    In bf16 precision every weight is an MFMA operand only: converting the 27M parameters once per step
+    replaces a conversion in every tile load of every product."""
+    ent = _SHADOW_OF.get(id(p))
+    if ent is None:
+        return None
+    opt, off = ent
+    if p.data_ptr() != opt.flat_p.data_ptr() + 4 * off:          # parameter storage moved: shadow is not of p any more
+        return None
+    return opt.flat_p16[off:off + p.numel()].view(p.shape)
+
+
+def refresh_weight_shadows():
+    """re-cast every registered flat parameter buffer (called at the start of each forward)"""
+    for opt in {id(e[0]): e[0] for e in _SHADOW_OF.values()}.values():
+        opt.refresh_shadow()
+
+
 def grad_buffer(p):
     """Used by functional.py: arena view when the parameter is registered, else a fresh zeros."""
     a = _ARENA_OF.get(id(p))
@@ -91,11 +111,18 @@ class FusedClipAdam(torch.optim.Optimizer):
             dst = self.flat_p[o:o + p.numel()].view(p.shape)
             dst.copy_(p.data)
             p.data = dst
+        self.flat_p16 = torch.empty(self.arena.total, device=ps[0].device, dtype=torch.bfloat16)
+        for p, o in zip(ps, self.arena.offsets):
+            _SHADOW_OF[id(p)] = (self, o)
+        self.refresh_shadow()
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.sumsq = torch.zeros(1, device=ps[0].device, dtype=torch.float32)
         self.step_count = 0
         self.grad_scale = 1.0           # set to 1/world_size when the bucket holds a SUM over ranks
+
+    def refresh_shadow(self):
+        call('ptv_cast_bf16', ptr(self.flat_p), ptr(self.flat_p16), self.arena.total, stream_ptr())
 
     def zero_grad(self, set_to_none=True):
         for p in self.arena.params:
