@@ -35,7 +35,8 @@ extern "C" {
 #define PTV_GRU_GI_BF16 2      /* gi */
 #define PTV_GRU_GI2_BF16 4     /* gi2 */
 #define PTV_GRU_DG_BF16 8      /* dgi / dgh (backward) */
-#define PTV_GRU_W_BF16 16       /* w_hh points at a bf16 copy of the weight (needs hall16 / DG_BF16) */
+#define PTV_GRU_W_BF16 16       /* w_hh points at a bf16 copy of the weight (needs hall16 / DG_BF16);
+                                   forward: W_hh [3H,H]; backward: the TRANSPOSED copy W_hh^T [H,3H] */
 #define PTV_GRU_SKIP_CAST0 32  /* hall16 slot 0 is already valid (chained single-step calls) */
 
 /* Library / build identification ("gfx950"). */
@@ -201,6 +202,8 @@ int ptv_route_slices(const float* src, float* dstA, float* dstB, const int* mask
  */
 /* dst[i] = bf16(src[i]): refreshes the bf16 shadow of the flat parameter buffer once per step */
 int ptv_cast_bf16(const float* src, void* dst, long n, void* stream);
+/* dst[c*rows + r] = bf16(src[r*cols + c]): transposed bf16 copy of a weight matrix (operand of the dX products) */
+int ptv_transpose_cast_bf16(const float* src, void* dst, int rows, int cols, void* stream);
 int ptv_grad_sumsq(const float* g, long n, float* sumsq, void* stream);
 int ptv_clip_adam_step(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float gscale, float clip,
                        float lr, float beta1, float beta2, float eps, int step, void* stream);

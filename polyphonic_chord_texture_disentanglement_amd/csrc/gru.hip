@@ -166,9 +166,11 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, long lds, __bf16
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
     dst[i] = (__bf16)src[(i / cols) * lds + (i % cols)];
 }
+// SB: the weight operand is the bf16 TRANSPOSED shadow W_hh^T [H, 3H] (K-contiguous rows: the fast loader);
+// otherwise the fp32 parameter W_hh [3H, H] read K-major
 template <class CT, int BM, int BN, bool SA, bool SB>
 __global__ __launch_bounds__(NTHREADS) void gru_bwd_step_kernel(GemmArgs g, EpiGruBwd::Params ep) {
-  gemm_body<CT, BM, BN, 2, 2, 1, false, true, EpiGruBwd, SA, SB, (BM * BN <= 64 * 32 ? 4 : (BM * BN <= 64 * 64 ? 3 : 2))>(g, ep);
+  gemm_body<CT, BM, BN, 2, 2, 1, false, !SB, EpiGruBwd, SA, SB, (BM * BN <= 64 * 32 ? 4 : (BM * BN <= 64 * 64 ? 3 : 2))>(g, ep);
 }
 
 
@@ -294,7 +296,7 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
     // dh_{step+1} = dgh_{step+1} . W_hh (K = 3H; K = 0 at the last step) + dhz_{step+1} + external grads
     const bool dbf = flags & PTV_GRU_DG_BF16;
     const long esz_d = dbf ? 2 : 4, esz_g = (flags & PTV_GRU_GATES_BF16) ? 2 : 4;
-    GemmArgs g{last ? dgh : (const char*)dgh + (long)(step + 1) * M3H * esz_d, 3L * H, w_hh, H, M, H, last ? 0 : 3 * H, last ? 0 : 3 * H, 0};
+    GemmArgs g{last ? dgh : (const char*)dgh + (long)(step + 1) * M3H * esz_d, 3L * H, w_hh, w16 ? 3L * H : (long)H, M, H, last ? 0 : 3 * H, last ? 0 : 3 * H, 0};
     EpiGruBwd::Params ep{last ? nullptr : dhz + ((step + 1) & 1) * MH,
                          dh_ext ? dh_ext + (long)step * ext_step_stride : nullptr, ext_ld,
                          last ? dh_last : nullptr, last_ld,
@@ -315,7 +317,8 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
   if (dh0) {
     // dh0 = dhz_0 + dgh_0 . W_hh
     if (hipMemcpyAsync(dh0, dhz, MH * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return PTV_ERR_LAUNCH;
-    PTV_TRY(ptv_gemm(prec, 0, 1, M, H, 3 * H, dgh, 3L * H, w_hh, H, dh0, H, nullptr, 1.0f, 1, 0, -1, ((flags & PTV_GRU_DG_BF16) ? 1 : 0) | (w16 ? 2 : 0), stream));
+    PTV_TRY(ptv_gemm(prec, 0, w16 ? 0 : 1, M, H, 3 * H, dgh, 3L * H, w_hh, w16 ? 3L * H : (long)H, dh0, H, nullptr, 1.0f, 1, 0, -1,
+                     ((flags & PTV_GRU_DG_BF16) ? 1 : 0) | (w16 ? 2 : 0), stream));
   }
   return PTV_OK;
 }

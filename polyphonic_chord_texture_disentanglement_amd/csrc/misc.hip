@@ -35,6 +35,22 @@ __global__ void cast_flat_bf16_kernel(const float* __restrict__ src, __bf16* __r
   }
 }
 
+// 32x32 LDS-tiled transpose + cast (coalesced both ways)
+__global__ void transpose_cast_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? src[(long)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) dst[(long)c * rows + r] = (__bf16)tile[tx][i];
+  }
+}
+
 __global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
   __shared__ float red[4];
   float s = 0.f;
@@ -210,6 +226,13 @@ extern "C" int ptv_cast_bf16(const float* src, void* dst, long n, void* stream) 
   if (!src || !dst || n <= 0 || (n & 3)) return PTV_ERR_ARG;
   long nb = (n / 4 + 255) / 256; if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(cast_flat_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, n / 4);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_transpose_cast_bf16(const float* src, void* dst, int rows, int cols, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0) return PTV_ERR_ARG;
+  hipLaunchKernelGGL(transpose_cast_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, rows, cols);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

@@ -97,6 +97,23 @@ def transpose01(x):
     return out
 
 
+def _WT(p, prec):
+    """transposed bf16 shadow [K_in, N_out] of a weight [N_out, K_in] (bf16 precision, if the optimiser keeps one)"""
+    if prec == 1 and BF16_STORAGE and p.dim() == 2:
+        from .optim import weight_shadow_t
+        return weight_shadow_t(p)
+    return None
+
+
+def gemm_dx(dy, w, cols=None, out=None, *, acc=False, prec=0):
+    """input gradient of a Linear: dy . w[:, cols].  With a transposed bf16 shadow of w this is a K-contiguous
+    (NT) product on bf16 weight tiles; otherwise the fp32 weight is read K-major."""
+    wt = _WT(w, prec)
+    if wt is not None:
+        return gemm(dy, wt if cols is None else wt[cols, :], out, acc=acc, prec=prec)
+    return gemm(dy, w if cols is None else w[:, cols], out, tb=True, acc=acc, prec=prec)
+
+
 def _gru_flags(gates=None, gi=None, gi2=None, dg=None, w=None):
     return _bf(gates) | (_bf(gi) << 1) | (_bf(gi2) << 2) | (_bf(dg) << 3) | (_bf(w) << 4)
 
@@ -130,6 +147,9 @@ def gru_bwd(prec, hall, gates, w_hh, *, dh_ext=None, dh_last=None, lr=None, reve
     ext = (ptr(dh_ext), dh_ext.stride(0), dh_ext.stride(1)) if dh_ext is not None else (None, 0, 0)
     last = (ptr(dh_last), dh_last.stride(0)) if dh_last is not None else (None, 0)
     lra = (ptr(lr[0]), lr[1], lr[2], lr[3], ptr(lr[4])) if lr is not None else (None, 0, 0, 0, None)
+    if dt == BF16:
+        wt = _WT(w_hh, prec)                  # W_hh^T [H,3H] bf16: K-contiguous weight tiles for the BPTT products
+        w_hh = wt if wt is not None else w_hh
     call('ptv_gru_seq_bwd', prec, M, H, T, ptr(hall), ptr(gates), ptr(w_hh), *ext, *last, *lra, ptr(dgi),
          ptr(dgh), ptr(dhz), ptr(dh0), int(reverse), _gru_flags(gates, dg=dgi, w=w_hh), stream_ptr())
     return dgi, dgh, dh0
@@ -208,7 +228,7 @@ class LinearFn(torch.autograd.Function):
         x2, w, b = ctx.saved_tensors
         prec = ctx.prec
         dy = dy.contiguous()
-        dx = gemm(dy, w, tb=True, prec=prec) if ctx.needs_input_grad[0] else None
+        dx = gemm_dx(dy, w, prec=prec) if ctx.needs_input_grad[0] else None
         dw = gemm(dy, x2, _gbuf(w), ta=True, tb=True, acc=True, prec=prec)
         db = _bgrad(b, dy) if b is not None else None
         return dx, dw, db, None
@@ -305,7 +325,7 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
                      prec=prec)
         db_ih = _bgrad(b_ih, dgi2)
         db_hh = _bgrad(b_hh, dgh2)
-        dx = gemm(dgi2, w_ih, tb=True, prec=prec) if need_dx else None
+        dx = gemm_dx(dgi2, w_ih, prec=prec) if need_dx else None
         return [dw_ih, dw_hh, db_ih, db_hh], dx
 
     side = Side(7)
@@ -358,8 +378,8 @@ class EncoderHeadsFn(torch.autograd.Function):
         gmu, glv = _empty(B, Z, dev=dev), _empty(B, Z, dev=dev)
         call('ptv_reparam_kl_bwd', ptr(mu), ptr(sd), None, None, 0, ptr(dmu), ptr(dsd), 0.0, 1, ptr(gmu), ptr(glv),
              B, Z, stream_ptr())
-        dh = gemm(gmu, w_mu, tb=True, prec=prec)
-        gemm(glv, w_var, dh, tb=True, acc=True, prec=prec)
+        dh = gemm_dx(gmu, w_mu, prec=prec)
+        gemm_dx(glv, w_var, out=dh, acc=True, prec=prec)
         dw_mu = gemm(gmu, h, _gbuf(w_mu), ta=True, tb=True, acc=True, prec=prec)
         dw_var = gemm(glv, h, _gbuf(w_var), ta=True, tb=True, acc=True, prec=prec)
         db_mu = _bgrad(b_mu, gmu)
@@ -609,9 +629,9 @@ class DecoderTFFn(torch.autograd.Function):
 
         # ---- dur_hid_linear([note_summary | est_pitch]) and pitch_out_linear ----
         w_dh, w_p = W['dur_hid_linear.weight'], W['pitch_out_linear.weight']
-        dNSUM = gemm(dHD0, w_dh[:, :Hn], tb=True, prec=prec)                      # [M, Hn]
-        gemm(dHD0, w_dh[:, Hn:], dP, tb=True, acc=True, prec=prec)
-        gemm(dP, w_p, dNSUM, tb=True, acc=True, prec=prec)
+        dNSUM = gemm_dx(dHD0, w_dh, slice(0, Hn), prec=prec)                      # [M, Hn]
+        gemm_dx(dHD0, w_dh, slice(Hn, None), out=dP, acc=True, prec=prec)
+        gemm_dx(dP, w_p, out=dNSUM, acc=True, prec=prec)
 
         def head_wgrads():
             wgrad('dur_hid_linear.weight', dHD0, NSUM_op, slice(0, Hn))
@@ -627,10 +647,10 @@ class DecoderTFFn(torch.autograd.Function):
         dGC = sum_steps(dgi_n)                                                    # [R, 3Hn]
         demb = _empty(16, R, E, dev=dev)
         demb[15].zero_()
-        gemm(dgi_n.view(M, 3 * Hn), w_ih_n[:, Ht:], demb[:15].view(M, E), tb=True, prec=prec)
-        dNS = gemm(dGC, w_ih_n[:, :Ht], tb=True, prec=prec)                       # [R, Ht]
+        gemm_dx(dgi_n.view(M, 3 * Hn), w_ih_n, slice(Ht, None), out=demb[:15].view(M, E), prec=prec)
+        dNS = gemm_dx(dGC, w_ih_n, slice(0, Ht), prec=prec)                       # [R, Ht]
         w_tn = W['dec_time_to_notes_hid.weight']
-        gemm(dHN0, w_tn, dNS, tb=True, acc=True, prec=prec)
+        gemm_dx(dHN0, w_tn, out=dNS, acc=True, prec=prec)
 
         def notes_wgrads():
             wgrad('dec_notes_gru.weight_hh_l0', dgh_n.view(M, 3 * Hn), HNo[:15].view(M, Hn))
@@ -646,14 +666,14 @@ class DecoderTFFn(torch.autograd.Function):
         w_hh_t, w_ih_t = W['dec_time_gru.weight_hh_l0'], W['dec_time_gru.weight_ih_l0']
         dgi_t, dgh_t, dzhid = gru_bwd(prec, NS, st['gates_t'], w_hh_t, dh_ext=dNS.view(32, B, Ht))
         dZG = sum_steps(dgi_t)                                                    # [B, 3Ht]
-        dz_in = gemm(dZG, w_ih_t[:, 2 * He:], tb=True, prec=prec)                 # [B, Zi]
+        dz_in = gemm_dx(dZG, w_ih_t, slice(2 * He, None), prec=prec)              # [B, Zi]
         dTOKS = _empty(33, B, 2 * He, dev=dev)
         dTOKS[32].zero_()
-        gemm(dgi_t.view(R, 3 * Ht), w_ih_t[:, :2 * He], dTOKS[:32].view(R, 2 * He), tb=True, prec=prec)
+        gemm_dx(dgi_t.view(R, 3 * Ht), w_ih_t, slice(0, 2 * He), out=dTOKS[:32].view(R, 2 * He), prec=prec)
         dxs = dTOKS[1:].view(R, 2 * He)
         w_zh, w_zi = W['z2dec_hid_linear.weight'], W['z2dec_in_linear.weight']
-        dz = gemm(dzhid, w_zh, tb=True, prec=prec)
-        gemm(dz_in, w_zi, dz, tb=True, acc=True, prec=prec)
+        dz = gemm_dx(dzhid, w_zh, prec=prec)
+        gemm_dx(dz_in, w_zi, out=dz, acc=True, prec=prec)
 
         def time_wgrads():
             wgrad('dec_time_gru.weight_hh_l0', dgh_t.view(R, 3 * Ht), NSo[:32].view(R, Ht))

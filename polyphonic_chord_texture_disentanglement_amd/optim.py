@@ -10,12 +10,14 @@ Parameters are re-pointed to views of the flat parameter buffer (state_dict keys
 unchanged).  Gradients: `GradArena` hands the backward kernels zero-initialised views of the flat
 gradient buffer, so `.grad` of every parameter already lives in the bucket when backward ends.
 """
+import weakref
+
 import torch
 
 from ._lib import call, ptr, stream_ptr
 
 _ARENA_OF = {}          # id(param) -> GradArena
-_SHADOW_OF = {}         # id(param) -> (FusedClipAdam, offset): bf16 copy of the flat parameter buffer
+_SHADOW_OF = {}         # param data_ptr -> (FusedClipAdam, offset, numel): bf16 copies of the flat parameter buffer
 
 
 class GradArena:
@@ -71,18 +73,37 @@ def weight_shadow(p):
     """bf16 copy of parameter p (a view of the optimiser's bf16 shadow of the flat parameter buffer), or None.
     In bf16 precision every weight is an MFMA operand only: converting the 27M parameters once per step
     replaces a conversion in every tile load of every product."""
-    ent = _SHADOW_OF.get(id(p))
-    if ent is None:
+    ent = _SHADOW_OF.get(p.data_ptr())
+    opt = ent[0]() if ent is not None else None
+    if opt is None or ent[2] != p.numel() or not p.is_contiguous():
         return None
-    opt, off = ent
-    if p.data_ptr() != opt.flat_p.data_ptr() + 4 * off:          # parameter storage moved: shadow is not of p any more
-        return None
+    off = ent[1]
     return opt.flat_p16[off:off + p.numel()].view(p.shape)
+
+
+def weight_shadow_t(p):
+    """bf16 TRANSPOSED copy of a 2-D parameter p [N,K] -> [K,N] (K-contiguous operand of the dX products
+    dY . W and of the BPTT step), or None"""
+    ent = _SHADOW_OF.get(p.data_ptr())
+    opt = ent[0]() if ent is not None else None
+    if opt is None or p.dim() != 2 or ent[2] != p.numel() or not p.is_contiguous():
+        return None
+    off = ent[1]
+    if off not in opt._mat_offsets:
+        return None
+    return opt.flat_pT16[off:off + p.numel()].view(p.shape[1], p.shape[0])
 
 
 def refresh_weight_shadows():
     """re-cast every registered flat parameter buffer (called at the start of each forward)"""
-    for opt in {id(e[0]): e[0] for e in _SHADOW_OF.values()}.values():
+    live = {}
+    for key, e in list(_SHADOW_OF.items()):
+        opt = e[0]()
+        if opt is None:
+            del _SHADOW_OF[key]                      # its optimiser (and flat buffers) are gone
+        else:
+            live[id(opt)] = opt
+    for opt in live.values():
         opt.refresh_shadow()
 
 
@@ -112,8 +133,11 @@ class FusedClipAdam(torch.optim.Optimizer):
             dst.copy_(p.data)
             p.data = dst
         self.flat_p16 = torch.empty(self.arena.total, device=ps[0].device, dtype=torch.bfloat16)
+        self.flat_pT16 = torch.empty(self.arena.total, device=ps[0].device, dtype=torch.bfloat16)
+        self._mats = [(p, o) for p, o in zip(ps, self.arena.offsets) if p.dim() == 2 and p.shape[0] % 8 == 0 and p.shape[1] >= 8]
+        self._mat_offsets = {o for _, o in self._mats}
         for p, o in zip(ps, self.arena.offsets):
-            _SHADOW_OF[id(p)] = (self, o)
+            _SHADOW_OF[p.data_ptr()] = (weakref.ref(self), o, p.numel())
         self.refresh_shadow()
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
@@ -122,7 +146,10 @@ class FusedClipAdam(torch.optim.Optimizer):
         self.grad_scale = 1.0           # set to 1/world_size when the bucket holds a SUM over ranks
 
     def refresh_shadow(self):
-        call('ptv_cast_bf16', ptr(self.flat_p), ptr(self.flat_p16), self.arena.total, stream_ptr())
+        st = stream_ptr()
+        call('ptv_cast_bf16', ptr(self.flat_p), ptr(self.flat_p16), self.arena.total, st)
+        for p, o in self._mats:                                  # transposed copies of the matrices
+            call('ptv_transpose_cast_bf16', ptr(p), ptr(self.flat_pT16[o:]), p.shape[0], p.shape[1], st)
 
     def zero_grad(self, set_to_none=True):
         for p in self.arena.params:

@@ -191,7 +191,7 @@ def test_trainer_surface_runs_one_epoch_and_saves_checkpoints(tmp_path, monkeypa
     m2.eps_source = m.eps_source = lambda name, shape, device: torch.zeros(shape, device=device)
     l2 = m2('train', x, c, pr, torch.zeros(2, 1, device=DEV), tfr1=1., tfr2=1., tfr3=1., beta=0.1, weights=[1, 0.5])
     l3 = m('train', x, c, pr, tfr1=1., tfr2=1., tfr3=1., beta=0.1, weights=[1, 0.5])
-    assert len(l1) == 11 and abs(l2[0].item() - l3[0].item()) < 1e-6
+    assert len(l1) == 11 and abs(l2[0].item() - l3[0].item()) < 1e-5      # same weights; block-sum order differs
 
 
 def _coin_hook(monkeypatch, coins):
