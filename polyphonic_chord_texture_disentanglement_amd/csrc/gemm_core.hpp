@@ -231,25 +231,26 @@ struct StageKM {
   }
 };
 
-// K-major bf16 source: work item = 8 k x 8 r block of bf16 (eight 16-byte loads, one per k row) ->
-// eight LDS chunks (rows r..r+7).  LW adjacent lanes cover LW row groups (up to a 128-byte line per k row).
+// K-major bf16 source: work item = 4 k x 8 r block of bf16 (four 16-byte loads, one per k row) -> eight
+// 8-byte LDS half-chunks (rows r..r+7, 4 consecutive k).  LW adjacent lanes cover LW row groups (up to one
+// 128-byte line per k row), the next lanes walk the 16 k-quads; ROWS = 128 keeps all 256 threads loading.
 template <int ROWS>
 struct StageKM<BF16, ROWS, true> {
   static constexpr int RG = ROWS / 8;
   static constexpr int LW = RG < 8 ? RG : 8;
-  static constexpr int ITEMS = RG * 8;                 // x 8 k-chunks (= ROWS)
+  static constexpr int ITEMS = RG * 16;                // x 16 k-quads
   static_assert(ITEMS <= NTHREADS, "one item per thread");
-  bf16x8 v[8];
+  bf16x8 v[4];
   static __device__ __forceinline__ int item() { return (int)(threadIdx.x % ITEMS); }
-  static __device__ __forceinline__ int wi_rg(int w) { return (w % LW) + LW * (w / (LW * 8)); }
-  static __device__ __forceinline__ int wi_kc(int w) { return (w / LW) % 8; }
+  static __device__ __forceinline__ int wi_rg(int w) { return (w % LW) + LW * (w / (LW * 16)); }
+  static __device__ __forceinline__ int wi_kq(int w) { return (w / LW) % 16; }
 
   __device__ __forceinline__ void load(const __bf16* __restrict__ p, long ld, int k0, int kend, bool vec_ok, long row0, long nrows) {
     const int w = item();
     const long r = row0 + wi_rg(w) * 8;
 #pragma unroll
-    for (int kk = 0; kk < 8; kk++) {
-      const int k = k0 + wi_kc(w) * 8 + kk;
+    for (int kk = 0; kk < 4; kk++) {
+      const int k = k0 + wi_kq(w) * 4 + kk;
       bf16x8 x;
 #pragma unroll
       for (int e = 0; e < 8; e++) x[e] = (__bf16)0.f;
@@ -266,21 +267,21 @@ struct StageKM<BF16, ROWS, true> {
   }
   __device__ __forceinline__ void load_fast(const __bf16* __restrict__ p, long ld, int k0, long row0) {
     const int w = item();
-    const unsigned toff = (unsigned)((wi_kc(w) * 8) * ld + wi_rg(w) * 8);
+    const unsigned toff = (unsigned)((wi_kq(w) * 4) * ld + wi_rg(w) * 8);
     const __bf16* ub = p + (long)k0 * ld + row0;
 #pragma unroll
-    for (int kk = 0; kk < 8; kk++) v[kk] = *reinterpret_cast<const bf16x8*>(ub + kk * ld + toff);
+    for (int kk = 0; kk < 4; kk++) v[kk] = *reinterpret_cast<const bf16x8*>(ub + kk * ld + toff);
   }
   __device__ __forceinline__ void store(__bf16* s) const {
     if (ITEMS < NTHREADS && threadIdx.x >= ITEMS) return;
     const int w = item();
-    const int rg = wi_rg(w), kc = wi_kc(w);
+    const int rg = wi_rg(w), kq = wi_kq(w);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      bf16x8 c;
+      bf16x4 c;
 #pragma unroll
-      for (int kk = 0; kk < 8; kk++) c[kk] = v[kk][j];
-      *reinterpret_cast<bf16x8*>(s + swz<BF16>(rg * 8 + j, kc * 8)) = c;
+      for (int kk = 0; kk < 4; kk++) c[kk] = v[kk][j];
+      *reinterpret_cast<bf16x4*>(s + swz<BF16>(rg * 8 + j, kq * 4)) = c;
     }
   }
 };
