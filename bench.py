@@ -176,10 +176,12 @@ def main():
         roof = None
         if cnt.value > 0:
             M_, H_ = 32 * B, model.decoder.dec_notes_hid_size
-            asz = 2 if (args.precision == 'bf16' and H_ % 8 == 0) else 4        # gi / gi2 / saved gates storage
-            # algorithmic bytes per launch: h_prev (A operand + blend, once) + gi + gi2 + W_hh + b_hh read;
-            # h and the 4 saved gate planes written
-            alg_bytes = M_ * H_ * 4 + 2 * M_ * 3 * H_ * asz + 3 * H_ * H_ * 4 + 3 * H_ * 4 + M_ * H_ * 4 + 4 * M_ * H_ * asz
+            b16 = args.precision == 'bf16' and H_ % 8 == 0                        # bf16 storage of MFMA-only tensors
+            asz = 2 if b16 else 4                                                 # gi / gi2 / saved gates
+            # algorithmic bytes per launch.  read: h_prev fp32 (blend) [+ its bf16 shadow as the MFMA operand],
+            # gi, gi2, W_hh, b_hh;  written: h fp32 [+ bf16 shadow] and the 4 saved gate planes
+            alg_bytes = (M_ * H_ * 4 + (M_ * H_ * 2 if b16 else 0) + 2 * M_ * 3 * H_ * asz + 3 * H_ * H_ * asz + 3 * H_ * 4
+                         + M_ * H_ * 4 + (M_ * H_ * 2 if b16 else 0) + 4 * M_ * H_ * asz)
             avg_s = tot_ms.value / cnt.value * 1e-3
             traffic = None
             pmc = os.path.join(ROOT, 'profiles', 'r01_notes_gru_fwd_pmc.json')

@@ -15,7 +15,7 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     rows = list(csv.DictReader(open(f)))
     if c == 'FETCH_SIZE':
         print(list(rows[0].keys()))
-    ker = [r for r in rows if 'gru_fwd_step_kernel<ptv::BF16, 128, 64>' in r['Kernel_Name'] and r['Counter_Name'] == c]
+    ker = [r for r in rows if 'gru_fwd_step_kernel<ptv::BF16, 128, 64' in r['Kernel_Name'] and r['Counter_Name'] == c]
     # notes GRU: grid 8 x 128 workgroups of 256 threads
     sel = [r for r in ker if int(r.get('Grid_Size', r.get('Grid_Size_X', 0))) in (8 * 128 * 256, 8 * 256)]
     per = {}
