@@ -1,9 +1,15 @@
-"""PytorchModel base class and the TrainingInterface step loop (reference
-amc_dl/torch_plus/module.py).  Same public surface; differences are confined to what one process
-per GPU needs: `parallel=True` means torch.distributed data parallelism with an RCCL gradient
-all-reduce (instead of nn.DataParallel, module.py:67-68), the 11 logged scalars leave the device
-in ONE transfer per step (instead of 22 .item() syncs, module.py:113-124), and the fused
-clip+Adam kernel is used when the optimizer provides it."""
+"""Model base class and training loop of the trainer surface (API of the reference's
+amc_dl/torch_plus/module.py), built for one process per MI355X:
+
+* `PytorchModel.forward(mode, ...)` dispatches 'run'/0, 'loss'/'train'/1, 'inference'/'eval'/'val'/2
+  exactly like module.py:36-44.
+* `TrainingInterface` keeps the constructor, properties, `train/eval/run/save_model/epoch_report` and the
+  per-batch order of module.py:129-150 (zero_grad -> parameter schedule -> model('train', ...) -> backward
+  -> clip -> optimizer + LR step -> log).  `parallel=True` means torch.distributed data parallelism with
+  ONE RCCL all-reduce of the flat gradient bucket (not nn.DataParallel, module.py:67-68); the 11 logged
+  scalars leave the device in one transfer per batch (the reference does 22 `.item()` syncs,
+  module.py:113-124); a `FusedClipAdam` optimizer clips and steps in two kernel launches.
+"""
 import time
 
 import torch
@@ -11,17 +17,17 @@ from torch import nn
 
 from .train_utils import epoch_time
 
+_RUN, _LOSS, _INFER = ('run', 0), ('loss', 'train', 1), ('inference', 'eval', 'val', 2)
+
 
 class PytorchModel(nn.Module):
-    """module.py:8-57"""
 
     def __init__(self, name, device):
         self.name = name
-        super().__init__()
-        if device is None:
-            device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
-        self.device = device
+        nn.Module.__init__(self)
+        self.device = device if device is not None else torch.device('cuda' if torch.cuda.is_available() else 'cpu')
 
+    # subclasses provide these four
     def run(self, *input):
         raise NotImplementedError
 
@@ -35,17 +41,15 @@ class PytorchModel(nn.Module):
         raise NotImplementedError
 
     def forward(self, mode, *input, **kwargs):
-        if mode in ('run', 0):
-            return self.run(*input, **kwargs)
-        if mode in ('loss', 'train', 1):
-            return self.loss(*input, **kwargs)
-        if mode in ('inference', 'eval', 'val', 2):
-            return self.inference(*input, **kwargs)
+        for keys, fn in ((_RUN, self.run), (_LOSS, self.loss), (_INFER, self.inference)):
+            if mode in keys:
+                return fn(*input, **kwargs)
         raise NotImplementedError
 
     def load_model(self, model_path, map_location=None):
-        dic = torch.load(model_path, map_location=self.device if map_location is None else map_location)
-        self.load_state_dict({k.replace('module.', ''): v for k, v in dic.items()})
+        """state_dict file -> parameters; 'module.' prefixes of DataParallel checkpoints are dropped."""
+        state = torch.load(model_path, map_location=map_location if map_location is not None else self.device)
+        self.load_state_dict({key.replace('module.', ''): val for key, val in state.items()})
         self.to(self.device)
 
     @staticmethod
@@ -54,73 +58,70 @@ class PytorchModel(nn.Module):
 
 
 class TrainingInterface:
-    """module.py:60-213"""
 
     def __init__(self, device, model, parallel, log_path_mng, data_loaders, summary_writers, opt_scheduler,
                  param_scheduler, n_epoch, **kwargs):
-        self.model = model
-        self.model.device = device
-        self.model.to(device)
-        self.parallel = bool(parallel)
-        self.path_mng = log_path_mng
-        self.summary_writers = summary_writers
-        self.data_loaders = data_loaders
-        self.opt_scheduler = opt_scheduler
-        self.param_scheduler = param_scheduler
-        self.device = device
-        self.n_epoch = n_epoch
+        model.device = device
+        self.model = model.to(device)
+        self.device, self.parallel, self.n_epoch = device, bool(parallel), n_epoch
+        self.path_mng, self.summary_writers, self.data_loaders = log_path_mng, summary_writers, data_loaders
+        self.opt_scheduler, self.param_scheduler = opt_scheduler, param_scheduler
         self.epoch = self.train_step = self.val_step = 0
-        self.grad_sync = None           # set to a dist.GradSync for multi-GPU data parallel
-        for k, v in kwargs.items():
-            setattr(self, k, v)
+        self.grad_sync = None                          # dist.GradSync when data parallel
+        self.__dict__.update(kwargs)
         if self.parallel and self.grad_sync is None:
             from ...dist import GradSync
-            self.grad_sync = GradSync(self.model)
+            self.grad_sync = GradSync(self.model, getattr(opt_scheduler, 'optimizer', None))
 
+    # ---- read-only views the reference exposes as properties
     name = property(lambda self: self.model.name)
     log_path = property(lambda self: self.path_mng.log_path)
     model_path = property(lambda self: self.path_mng.model_path)
     writer_path = property(lambda self: self.path_mng.writer_path)
     writer_names = property(lambda self: self.summary_writers.writer_names)
 
-    def _init_loss_dic(self):
-        return {k: 0. for k in self.writer_names}
-
+    # ---- loss bookkeeping
     @staticmethod
     def _host_values(loss_items):
-        """all scalars -> python floats with one device->host copy"""
-        return torch.stack([l.detach().reshape(()) for l in loss_items]).tolist()
+        """scalar tensors -> python floats with ONE device-to-host copy"""
+        if loss_items and isinstance(loss_items[0], float):
+            return list(loss_items)
+        return torch.stack([item.detach().reshape(()) for item in loss_items]).tolist()
 
-    def _accumulate_loss_dic(self, loss_dic, loss_items):
-        assert len(self.writer_names) == len(loss_items)
-        vals = loss_items if isinstance(loss_items[0], float) else self._host_values(loss_items)
-        for k, v in zip(self.writer_names, vals):
-            loss_dic[k] += v
-        return loss_dic
+    def _init_loss_dic(self):
+        return dict.fromkeys(self.writer_names, 0.)
 
     def _write_loss_to_dic(self, loss_items):
-        assert len(self.writer_names) == len(loss_items)
-        vals = loss_items if isinstance(loss_items[0], float) else self._host_values(loss_items)
-        return dict(zip(self.writer_names, vals))
+        assert len(loss_items) == len(self.writer_names)
+        return dict(zip(self.writer_names, self._host_values(loss_items)))
+
+    def _accumulate_loss_dic(self, loss_dic, loss_items):
+        for key, val in self._write_loss_to_dic(loss_items).items():
+            loss_dic[key] += val
+        return loss_dic
+
+    def _sum_parallel_loss(self, loss):
+        """data-parallel reporting = mean of the replicas' scalars (module.py:152-159)"""
+        return self.grad_sync.mean_scalars(loss) if (self.parallel and self.grad_sync is not None) else loss
 
     def _batch_to_inputs(self, batch):
         raise NotImplementedError
 
-    def _sum_parallel_loss(self, loss):
-        """module.py:152-159: data-parallel loss = mean of the replicas' scalars."""
-        if self.parallel and self.grad_sync is not None:
-            return self.grad_sync.mean_scalars(loss)
-        return loss
-
+    # ---- one optimisation step
     def _clip_and_step(self):
-        opt = self.opt_scheduler.optimizer
-        if hasattr(opt, 'clip_and_step'):                      # fused HIP clip + Adam (one pass)
-            opt.clip_and_step(self.opt_scheduler.clip)
-            self.opt_scheduler.scheduler.step()
-            self.opt_scheduler._update_step()
-        else:                                                  # the reference's two calls (module.py:142-144)
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.opt_scheduler.clip)
-            self.opt_scheduler.step()
+        sched, opt = self.opt_scheduler, self.opt_scheduler.optimizer
+        if hasattr(opt, 'clip_and_step'):
+            opt.clip_and_step(sched.clip)              # fused HIP global-norm clip + Adam
+            sched.scheduler.step()
+            sched._update_step()
+        else:                                          # torch optimizer: the reference's two calls
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), sched.clip)
+            sched.step()
+
+    def _log(self, task, outputs, loss_dic, step):
+        vals = self._host_values(self._sum_parallel_loss(outputs))
+        self._accumulate_loss_dic(loss_dic, vals)
+        self.summary_writers.write_task(task, self._write_loss_to_dic(vals), step)
 
     def train(self, **kwargs):
         self.model.train()
@@ -129,30 +130,26 @@ class TrainingInterface:
         for batch in self.data_loaders.train_loader:
             inputs = self._batch_to_inputs(batch)
             self.opt_scheduler.optimizer_zero_grad()
-            input_params = self.param_scheduler.step()
-            outputs = self.model('train', *inputs, **input_params)
+            outputs = self.model('train', *inputs, **self.param_scheduler.step())
             outputs[0].backward()
             if self.grad_sync is not None:
                 self.grad_sync.all_reduce_grads()
             self._clip_and_step()
-            vals = self._host_values(self._sum_parallel_loss(outputs))
-            self._accumulate_loss_dic(epoch_loss_dic, vals)
-            self.summary_writers.write_task('train', self._write_loss_to_dic(vals), self.train_step)
+            self._log('train', outputs, epoch_loss_dic, self.train_step)
             self.train_step += 1
         return epoch_loss_dic
 
     def eval(self):
+        """validation pass: same call as training (mode 'train', module.py:170) without gradients; the
+        parameter schedulers are frozen in 'val' mode"""
         self.model.eval()
         self.param_scheduler.eval()
         epoch_loss_dic = self._init_loss_dic()
         for batch in self.data_loaders.val_loader:
             inputs = self._batch_to_inputs(batch)
-            input_params = self.param_scheduler.step()
             with torch.no_grad():
-                outputs = self._sum_parallel_loss(self.model('train', *inputs, **input_params))
-            vals = self._host_values(outputs)
-            self._accumulate_loss_dic(epoch_loss_dic, vals)
-            self.summary_writers.write_task('val', self._write_loss_to_dic(vals), self.val_step)
+                outputs = self.model('train', *inputs, **self.param_scheduler.step())
+            self._log('val', outputs, epoch_loss_dic, self.val_step)
             self.val_step += 1
         return epoch_loss_dic
 
@@ -161,23 +158,24 @@ class TrainingInterface:
 
     def epoch_report(self, start_time, end_time, train_loss, valid_loss):
         mins, secs = epoch_time(start_time, end_time)
-        print(f'Epoch: {self.epoch + 1:02} | Time: {mins}m {secs}s', flush=True)
-        print(f'\tTrain Loss: {train_loss:.3f}', flush=True)
-        print(f'\t Valid. Loss: {valid_loss:.3f}', flush=True)
+        for line in (f'Epoch: {self.epoch + 1:02} | Time: {mins}m {secs}s', f'\tTrain Loss: {train_loss:.3f}',
+                     f'\t Valid. Loss: {valid_loss:.3f}'):
+            print(line, flush=True)
 
     def run(self, start_epoch=0, start_train_step=0, start_val_step=0):
+        """n_epoch x (train, eval); checkpoints '<name>_epoch.pt' every epoch, '<name>_valid.pt' on a new
+        best validation loss, '<name>_final.pt' at the end (module.py:195-213)."""
         self.epoch, self.train_step, self.val_step = start_epoch, start_train_step, start_val_step
-        best_valid_loss = float('inf')
+        best = float('inf')
         for _ in range(self.n_epoch):
-            t0 = time.time()
-            train_loss = self.train()['loss']
-            val_loss = self.eval()['loss']
-            t1 = time.time()
+            tic = time.time()
+            train_loss, val_loss = self.train()['loss'], self.eval()['loss']
+            toc = time.time()
             self.save_model(self.path_mng.epoch_model_path(self.name))
-            if val_loss < best_valid_loss:
-                best_valid_loss = val_loss
+            if val_loss < best:
+                best = val_loss
                 self.save_model(self.path_mng.valid_model_path(self.name))
-            self.epoch_report(t0, t1, train_loss, val_loss)
+            self.epoch_report(tic, toc, train_loss, val_loss)
             self.epoch += 1
         self.save_model(self.path_mng.final_model_path(self.name))
         print('Model saved.')

@@ -1,23 +1,19 @@
-"""Per-batch schedulers (reference amc_dl/torch_plus/scheduler.py): a step counter that only
-advances in 'train' mode, teacher-forcing / KL schedules driven by it, the optimiser + LR pair,
-and the dict-of-schedulers the trainer queries once per batch."""
+"""Per-batch schedulers of the trainer (API of the reference's amc_dl/torch_plus/scheduler.py).
+
+All of them share one piece of state: a batch counter that advances only while the scheduler is in
+'train' mode (`scheduler.py:10-16`), so validation passes see frozen values.  The teacher-forcing and
+KL-weight schedules are functions of that integer counter (`scheduler.py:48-54`), which is why the
+published settings saturate after two batches."""
 from .train_utils import scheduled_sampling
+
+_MODES = ('train', 'val')
 
 
 class _Scheduler:
+    """Counter + mode.  Subclasses implement `step()` and call `_update_step()` once per batch."""
 
     def __init__(self, step=0, mode='train'):
-        self._step = step
-        self._mode = mode
-
-    def _update_step(self):
-        if self._mode == 'train':
-            self._step += 1
-        elif self._mode != 'val':
-            raise NotImplementedError
-
-    def step(self):
-        raise NotImplementedError
+        self._step, self._mode = step, mode
 
     def train(self):
         self._mode = 'train'
@@ -25,12 +21,20 @@ class _Scheduler:
     def eval(self):
         self._mode = 'val'
 
+    def _update_step(self):
+        if self._mode not in _MODES:
+            raise NotImplementedError(self._mode)
+        self._step += int(self._mode == 'train')
+
+    def step(self):
+        raise NotImplementedError
+
 
 class ConstantScheduler(_Scheduler):
-    """scheduler.py:28-36"""
+    """Always the same value (`weights=[1, 0.5]` in train.py:62)."""
 
     def __init__(self, param, step=0.):
-        super().__init__(step)
+        _Scheduler.__init__(self, step)
         self.param = param
 
     def step(self):
@@ -39,27 +43,28 @@ class ConstantScheduler(_Scheduler):
 
 
 class TeacherForcingScheduler(_Scheduler):
-    """scheduler.py:39-54: value = f(step counter, high, low), read BEFORE the counter advances."""
+    """value_k = f(k, high, low) with k the number of TRAINING batches seen so far; the value is read
+    before the counter moves (scheduler.py:48-54)."""
 
     def __init__(self, high, low, f=scheduled_sampling, step=0):
-        super().__init__(step)
-        self.high, self.low = high, low
-        self.schedule_f = f
+        _Scheduler.__init__(self, step)
+        self.high, self.low, self.schedule_f = high, low, f
 
     def get_tfr(self):
         return self.schedule_f(self._step, self.high, self.low)
 
     def step(self):
-        value = self.get_tfr()
+        current = self.get_tfr()
         self._update_step()
-        return value
+        return current
 
 
 class OptimizerScheduler(_Scheduler):
-    """scheduler.py:57-74: optimizer.step() then LR scheduler.step(), once per BATCH."""
+    """Bundles optimizer, LR scheduler and the gradient-clipping threshold; `step()` = optimizer.step()
+    followed by one LR-scheduler step (per batch, scheduler.py:69-74)."""
 
     def __init__(self, optimizer, scheduler, clip, step=0):
-        super().__init__(step)
+        _Scheduler.__init__(self, step)
         self.optimizer, self.scheduler, self.clip = optimizer, scheduler, clip
 
     def optimizer_zero_grad(self):
@@ -74,22 +79,22 @@ class OptimizerScheduler(_Scheduler):
 
 
 class ParameterScheduler(_Scheduler):
-    """scheduler.py:77-99: {name: scheduler} -> {name: value} per batch."""
+    """Named schedulers -> the keyword arguments of `model('train', ...)` for this batch."""
 
     def __init__(self, step=0, mode='train', **schedulers):
-        super().__init__(step)
-        self.schedulers = schedulers
+        _Scheduler.__init__(self, step)
+        self.schedulers, self.mode = schedulers, mode
+
+    def _set_mode(self, mode):
         self.mode = mode
+        for sch in self.schedulers.values():
+            (sch.train if mode == 'train' else sch.eval)()
 
     def train(self):
-        self.mode = 'train'
-        for s in self.schedulers.values():
-            s.train()
+        self._set_mode('train')
 
     def eval(self):
-        self.mode = 'val'
-        for s in self.schedulers.values():
-            s.eval()
+        self._set_mode('val')
 
     def step(self, require_zero_grad=False):
-        return {k: s.step() for k, s in self.schedulers.items()}
+        return {name: sch.step() for name, sch in self.schedulers.items()}
