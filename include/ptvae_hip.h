@@ -180,6 +180,21 @@ int ptv_dur_out_token(const float* h, int H, const float* w_out, const float* b_
                       int* idx, const int* force_idx, long rows, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The whole 5-step duration GRU of decode_note (ptvae.py:353-367) in ONE kernel (bf16 precision, H = 64):
+ * W_hh and the 3-row gate table stay in LDS, the state in registers, each wave owns 16 rows for all 5
+ * steps; est_dur and the argmax feedback are computed in the same kernel.  Returns PTV_ERR_ARG for other
+ * H (callers then use ptv_gru_step_fwd + ptv_dur_out_token per step).
+ *   hall / hall16: state after step d at base + d*plane_h + row*64 (either may be NULL)
+ *   gates: plane p of step d at base + d*step_g + p*plane_g + row*64 (NULL = inference)
+ *   dur_out[row*ld_out + 2d..2d+1], idx[d*idx_stride + row]; force (replay) may be NULL
+ */
+int ptv_dur_gru_fwd(int H, long M, const float* h0, long ld_h0, const float* w_hh, const float* b_hh,
+                    const float* tab0, const float* tab, const float* w_out, const float* b_out,
+                    float* hall, long plane_h, void* hall16, void* gates, long plane_g, long step_g, int gates_bf16,
+                    float* dur_out, long ld_out, int* idx, long idx_stride, const int* force, long force_stride,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Free-running tokens.
  * ptv_note_token (ptvae.py:408-416 + pitch_dur_ind_to_note_token :328-334): per row pitch argmax (first
  *   maximal index), predicted token pred[r] = note_embedding(onehot(pitch) | 5 duration bits) with

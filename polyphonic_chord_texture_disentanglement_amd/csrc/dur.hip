@@ -1,0 +1,154 @@
+// dur.hip -- the 5-step duration GRU of PtvaeDecoder.decode_note (ptvae.py:353-367) as ONE kernel.
+//
+//   token_0 = dur_sos_token;  for d in 0..4:  h = GRU(token_d, h);  est_dur_d = dur_out_linear(h);
+//                                             token_{d+1} = onehot5[argmax est_dur_d]
+//
+// The input token is one of three vectors, so W_i token + b_i is a 3-row table; the recurrence is
+// 64-wide.  Per step the generic path launches a GRU-step kernel and a token kernel and round-trips the
+// state through HBM; here a wave owns 16 rows for all 5 steps:
+//   * W_hh (bf16, 192 x 64) and the gate tables live in LDS for the whole kernel
+//   * the hidden state stays in registers (fp32, MFMA C-layout: lane = row, 16 units) and is mirrored as
+//     bf16 into a per-wave LDS tile that feeds the next step's MFMA A operand
+//   * h . W_hh^T is 24 v_mfma_f32_16x16x32_bf16 per step per wave; the 2-wide output layer and the argmax
+//     are a 4-lane shuffle reduction
+//   * what the backward needs (states, gate planes) is streamed out once; nothing is read back.
+// bf16 precision, H = 64 only (the init_model() configuration); other shapes use the per-step kernels.
+#include "common.hpp"
+#include "gemm_core.hpp"
+#include "../../include/ptvae_hip.h"
+
+namespace ptv {
+
+constexpr int DH = 64;                 // hidden size
+constexpr int DLD = DH + 8;            // LDS row stride (bf16 elements): 144 B, conflict-free b128 reads
+
+struct DurArgs {
+  const float* h0; long ld_h0;         // [M, 64] initial state (dur_hid_linear output)
+  const float* w_hh; const float* b_hh;   // [192, 64], [192]
+  const float* tab0; const float* tab;    // [192] = W_i sos + b_i ; [2][192] = W_i onehot(0/1) + b_i
+  const float* w_out; const float* b_out; // [2, 64], [2]
+  float* hall; long plane_h;           // state after step d at hall + d*plane_h (+ row*64); may be null
+  __bf16* hall16;                      // bf16 copy, same indexing; may be null
+  void* gates; long plane_g; long step_g; int gates_bf16;   // gate plane p of step d at gates + d*step_g + p*plane_g
+  float* dur_out; long ld_out;         // est_dur_d at dur_out[row*ld_out + 2d .. 2d+1]
+  int* idx; long idx_stride;           // idx[d*idx_stride + row]
+  const int* force; long force_stride; // replay mode (tests), may be null
+  long M;
+};
+
+__global__ __launch_bounds__(256) void dur_gru_fwd_kernel(DurArgs a) {
+  __shared__ __attribute__((aligned(16))) __bf16 Ws[3 * DH * DLD];       // W_hh as bf16
+  __shared__ __attribute__((aligned(16))) __bf16 Hs[4][16 * DLD];        // per-wave state tile
+  __shared__ float tabs[3][3 * DH];                                     // gate tables: sos, idx0, idx1
+  __shared__ float bh[3 * DH];
+  __shared__ float wo[2 * DH + 2];
+  for (int i = threadIdx.x; i < 3 * DH * DH; i += 256) Ws[(i / DH) * DLD + (i % DH)] = (__bf16)a.w_hh[i];
+  for (int i = threadIdx.x; i < 3 * DH; i += 256) {
+    tabs[0][i] = a.tab0[i]; tabs[1][i] = a.tab[i]; tabs[2][i] = a.tab[3 * DH + i];
+    bh[i] = a.b_hh[i];
+  }
+  for (int i = threadIdx.x; i < 2 * DH; i += 256) wo[i] = a.w_out[i];
+  if (threadIdx.x < 2) wo[2 * DH + threadIdx.x] = a.b_out[threadIdx.x];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rl = lane & 15, ug = (lane >> 4) * 4;                        // row in tile, first unit of each fragment
+  __bf16* hs = Hs[wave];
+  const long tiles = (a.M + 15) / 16;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < tiles; tile += (long)gridDim.x * 4) {
+    const long row = tile * 16 + rl;
+    const bool ok = row < a.M;
+    float h[4][4];                                                      // h[f][e]: unit f*16 + ug + e
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) v = *reinterpret_cast<const float4*>(a.h0 + row * a.ld_h0 + f * 16 + ug);
+      h[f][0] = v.x; h[f][1] = v.y; h[f][2] = v.z; h[f][3] = v.w;
+    }
+    int tok = 0;                                                        // table row: 0 = sos, 1 + idx afterwards
+#pragma unroll 1
+    for (int d = 0; d < 5; d++) {
+      // state -> LDS (bf16) as the MFMA operand
+#pragma unroll
+      for (int f = 0; f < 4; f++) {
+        bf16x4 p; p[0] = (__bf16)h[f][0]; p[1] = (__bf16)h[f][1]; p[2] = (__bf16)h[f][2]; p[3] = (__bf16)h[f][3];
+        *reinterpret_cast<bf16x4*>(hs + rl * DLD + f * 16 + ug) = p;
+      }
+      __builtin_amdgcn_wave_barrier();
+      f32x4 acc[12];
+#pragma unroll
+      for (int n = 0; n < 12; n++) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < DH; ks += 32) {
+        const bf16x8 hb = *reinterpret_cast<const bf16x8*>(hs + rl * DLD + ks + (lane >> 4) * 8);
+#pragma unroll
+        for (int n = 0; n < 12; n++) {
+          const bf16x8 wb = *reinterpret_cast<const bf16x8*>(Ws + (n * 16 + rl) * DLD + ks + (lane >> 4) * 8);
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, hb, acc[n], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const float* gi = tabs[tok];
+      float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+      for (int f = 0; f < 4; f++) {
+        float r[4], z[4], n[4], hn[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int j = f * 16 + ug + e;
+          r[e] = sigmoidf_(gi[j] + acc[f][e] + bh[j]);
+          z[e] = sigmoidf_(gi[DH + j] + acc[4 + f][e] + bh[DH + j]);
+          hn[e] = acc[8 + f][e] + bh[2 * DH + j];
+          n[e] = tanhf_(gi[2 * DH + j] + r[e] * hn[e]);
+          h[f][e] = (1.0f - z[e]) * n[e] + z[e] * h[f][e];
+          o0 += wo[j] * h[f][e];
+          o1 += wo[DH + j] * h[f][e];
+        }
+        if (ok) {
+          const long off = row * DH + f * 16 + ug;
+          if (a.hall) *reinterpret_cast<float4*>(a.hall + d * a.plane_h + off) = make_float4(h[f][0], h[f][1], h[f][2], h[f][3]);
+          if (a.hall16) st4f(a.hall16, d * a.plane_h + off, true, h[f][0], h[f][1], h[f][2], h[f][3]);
+          if (a.gates) {
+            const long g0 = d * a.step_g + off;
+            st4f(a.gates, g0 + 0 * a.plane_g, a.gates_bf16, r[0], r[1], r[2], r[3]);
+            st4f(a.gates, g0 + 1 * a.plane_g, a.gates_bf16, z[0], z[1], z[2], z[3]);
+            st4f(a.gates, g0 + 2 * a.plane_g, a.gates_bf16, n[0], n[1], n[2], n[3]);
+            st4f(a.gates, g0 + 3 * a.plane_g, a.gates_bf16, hn[0], hn[1], hn[2], hn[3]);
+          }
+        }
+      }
+      // est_dur = dur_out_linear(h): reduce the 4 lanes that share this row (lanes rl, rl+16, rl+32, rl+48)
+      o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64);
+      o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64);
+      o0 += wo[2 * DH]; o1 += wo[2 * DH + 1];
+      int id = o1 > o0 ? 1 : 0;                                           // first max wins ties (torch.max)
+      if (a.force && ok) id = a.force[d * a.force_stride + row];
+      if (ok && lane < 16) {
+        a.dur_out[row * a.ld_out + 2 * d] = o0;
+        a.dur_out[row * a.ld_out + 2 * d + 1] = o1;
+        a.idx[d * a.idx_stride + row] = id;
+      }
+      tok = 1 + id;
+    }
+  }
+}
+
+}  // namespace ptv
+
+using namespace ptv;
+
+extern "C" int ptv_dur_gru_fwd(int H, long M, const float* h0, long ld_h0, const float* w_hh, const float* b_hh,
+                               const float* tab0, const float* tab, const float* w_out, const float* b_out,
+                               float* hall, long plane_h, void* hall16, void* gates, long plane_g, long step_g, int gates_bf16,
+                               float* dur_out, long ld_out, int* idx, long idx_stride, const int* force, long force_stride,
+                               void* stream) {
+  if (H != DH) return PTV_ERR_ARG;                 // callers fall back to the per-step kernels for other sizes
+  if (M <= 0 || !h0 || !w_hh || !b_hh || !tab0 || !tab || !w_out || !b_out || !dur_out || !idx) return PTV_ERR_ARG;
+  if ((ld_h0 & 3) || (plane_h & 3) || (plane_g & 3) || (step_g & 3)) return PTV_ERR_ARG;
+  DurArgs a{h0, ld_h0, w_hh, b_hh, tab0, tab, w_out, b_out, hall, plane_h, (__bf16*)hall16, gates, plane_g, step_g, gates_bf16,
+            dur_out, ld_out, idx, idx_stride, force, force_stride, M};
+  long nb = ((M + 15) / 16 + 3) / 4; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(dur_gru_fwd_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, a);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}

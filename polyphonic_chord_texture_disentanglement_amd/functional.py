@@ -13,6 +13,7 @@ from ._lib import call, prec_code, ptr, stream_ptr
 
 F32 = torch.float32
 BF16 = torch.bfloat16
+FUSED_DUR = True            # bf16 precision, H = 64: the 5-step duration GRU runs as one kernel (csrc/dur.hip)
 BF16_STORAGE = True         # bf16 precision: tensors that only feed MFMA operands / epilogues live as bf16 in HBM
 
 
@@ -546,13 +547,22 @@ class DecoderTFFn(torch.autograd.Function):
         dur = _empty(M, 5, 2, dev=dev)
         idx = torch.empty(5, M, device=dev, dtype=torch.int32)
         dur2 = dur.view(M, 10)
-        for d in range(5):
-            gi, gi_ld, gi_idx = (tab0, 0, None) if d == 0 else (tab, 3 * Hd, idx[d - 1])
-            gru_fwd(prec, gi, 0, gi_ld, W['dec_dur_gru.weight_hh_l0'], P['dec_dur_gru.bias_hh_l0'], HD[d:d + 2],
-                    gates_d[d], gi_idx=gi_idx, T=1, hall16=HD16[d:d + 2] if HD16 is not None else None, skip_cast0=d > 0)
-            call('ptv_dur_out_token', ptr(HD[d + 1]), Hd, ptr(P['dur_out_linear.weight']), ptr(P['dur_out_linear.bias']),
-                 ptr(dur2[:, 2 * d:]), 10, ptr(idx[d]), ptr(force_dur[d]) if force_dur is not None else None, M,
-                 stream_ptr())
+        if prec == 1 and Hd == 64 and FUSED_DUR:
+            # one kernel for the 5 steps + output layer + argmax feedback (dur.hip)
+            call('ptv_dur_gru_fwd', Hd, M, ptr(HD[0]), Hd, ptr(P['dec_dur_gru.weight_hh_l0']), ptr(P['dec_dur_gru.bias_hh_l0']),
+                 ptr(tab0), ptr(tab), ptr(P['dur_out_linear.weight']), ptr(P['dur_out_linear.bias']),
+                 ptr(HD[1]), M * Hd, ptr(HD16[1]) if HD16 is not None else None, ptr(gates_d), M * Hd, 4 * M * Hd, _bf(gates_d),
+                 ptr(dur2), 10, ptr(idx), M, ptr(force_dur) if force_dur is not None else None, M, stream_ptr())
+            if HD16 is not None:
+                call('ptv_cast_bf16', ptr(HD[0]), ptr(HD16[0]), M * Hd, stream_ptr())       # slot 0 of the shadow
+        else:
+            for d in range(5):
+                gi, gi_ld, gi_idx = (tab0, 0, None) if d == 0 else (tab, 3 * Hd, idx[d - 1])
+                gru_fwd(prec, gi, 0, gi_ld, P['dec_dur_gru.weight_hh_l0'], P['dec_dur_gru.bias_hh_l0'], HD[d:d + 2],
+                        gates_d[d], gi_idx=gi_idx, T=1, hall16=HD16[d:d + 2] if HD16 is not None else None, skip_cast0=d > 0)
+                call('ptv_dur_out_token', ptr(HD[d + 1]), Hd, ptr(P['dur_out_linear.weight']), ptr(P['dur_out_linear.bias']),
+                     ptr(dur2[:, 2 * d:]), 10, ptr(idx[d]), ptr(force_dur[d]) if force_dur is not None else None, M,
+                     stream_ptr())
 
         S.save_for_backward(z, emb, *params)
         S.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in, NS16=NS16, HN16=HN16,

@@ -273,3 +273,29 @@ def test_graph_replayed_decode_equals_eager():
     again = m.inference_decode(zc.flip(0), zr.flip(0))  # replays with new latent codes
     assert np.array_equal(eager, first)
     assert np.array_equal(eager[::-1], again)
+
+
+def test_fused_duration_gru_kernel_equals_per_step_kernels():
+    """csrc/dur.hip (one kernel for the 5 duration steps) vs the per-step kernels, bf16 precision, full config."""
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    g = load_npz('full_tf1_b4.npz')
+    x, c, pr = synth_batch(int(g['B']), int(g['data_seed']))
+    m = M.DisentangleVAE.init_model(torch.device(DEV))
+    m.load_state_dict(full_params())
+    m.to(DEV).set_precision('bf16')
+    res = {}
+    for fused in (True, False):
+        F_.FUSED_DUR = fused
+        try:
+            outs, losses = _run(m, g, x, c, pr)
+            losses[0].backward()
+            res[fused] = (outs[1].detach().clone(), m.decoder.last_dur_idx.clone(), np.array([l.item() for l in losses]),
+                          m.decoder.dec_dur_gru.weight_hh_l0.grad.clone())
+        finally:
+            F_.FUSED_DUR = True
+    d_f, i_f, l_f, g_f = res[True]
+    d_s, i_s, l_s, g_s = res[False]
+    assert (i_f == i_s).float().mean() > 0.999                       # same argmax feedback decisions
+    assert (d_f - d_s).abs().max() < 2e-2                            # bf16 operand rounding only
+    np.testing.assert_allclose(l_f, l_s, rtol=0, atol=2e-3)
+    assert (g_f - g_s).abs().max() < 0.05 * g_s.abs().max()
