@@ -129,13 +129,19 @@ class DecoderStepFn(torch.autograd.Function):
                 gemm(h, P['pitch_out_linear.weight'], pitch[pr], bias=P['pitch_out_linear.bias'], prec=prec)
                 gemm(h, w_dh[:, :Hn], HD[0][pr], bias=P['dur_hid_linear.bias'], prec=prec)
                 gemm(pitch[pr], w_dh[:, Hn:], HD[0][pr], acc=True, prec=prec)
-                for d in range(5):
-                    g_, g_ld, g_idx = (tab0, 0, None) if d == 0 else (tab, 3 * Hd, idx[d - 1][pr])
-                    gru_step(prec, HD[d][pr], g_, g_ld, w_hh_d, b_hh_d, HD[d + 1][pr],
-                             gates=gates_d[d][:, pr] if train else None, plane=M * Hd, gi_idx=g_idx)
-                    call('ptv_dur_out_token', ptr(HD[d + 1][pr]), Hd, ptr(P['dur_out_linear.weight']),
-                         ptr(P['dur_out_linear.bias']), ptr(dur2[pr][:, 2 * d:]), 10, ptr(idx[d][pr]),
-                         ptr(force_dur[d][pr]) if force_dur is not None else None, B, st)
+                if prec == 1 and Hd == 64 and F_.FUSED_DUR:
+                    call('ptv_dur_gru_fwd', Hd, B, ptr(HD[0][pr]), Hd, ptr(w_hh_d), ptr(b_hh_d), ptr(tab0), ptr(tab),
+                         ptr(P['dur_out_linear.weight']), ptr(P['dur_out_linear.bias']), ptr(HD[1][pr]), M * Hd, None,
+                         ptr(gates_d[0][0][pr]) if train else None, M * Hd, 4 * M * Hd, F_._bf(gates_d), ptr(dur2[pr]), 10,
+                         ptr(idx[0][pr]), M, ptr(force_dur[0][pr]) if force_dur is not None else None, M, st)
+                else:
+                    for d in range(5):
+                        g_, g_ld, g_idx = (tab0, 0, None) if d == 0 else (tab, 3 * Hd, idx[d - 1][pr])
+                        gru_step(prec, HD[d][pr], g_, g_ld, w_hh_d, b_hh_d, HD[d + 1][pr],
+                                 gates=gates_d[d][:, pr] if train else None, plane=M * Hd, gi_idx=g_idx)
+                        call('ptv_dur_out_token', ptr(HD[d + 1][pr]), Hd, ptr(P['dur_out_linear.weight']),
+                             ptr(P['dur_out_linear.bias']), ptr(dur2[pr][:, 2 * d:]), 10, ptr(idx[d][pr]),
+                             ptr(force_dur[d][pr]) if force_dur is not None else None, B, st)
                 call('ptv_note_token', ptr(pitch[pr]), NP, ptr(idx[0][pr]), M, ptr(w_emb), ptr(b_emb), E,
                      ptr(PRED[n + 1][rows]), E, ptr(xhat[0, t, n + 1]), 32 * 16 * 6, ptr(plen[rows]), n + 1, int(n == 14),
                      ptr(force_pitch[n][rows]) if force_pitch is not None else None, B, st)
