@@ -18,40 +18,62 @@ struct EpiPlain {
     int atomic;       // split-K partial sums: atomicAdd into C (C pre-initialised, fp32 only)
     int c_bf16;       // C holds bf16
   };
+  template <int FM, int FN, int NG> struct Pre {};
   template <int FM, int FN, int NG>
-  static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], int m0, int n0, int M, int N, int split) {
-    const int lane = threadIdx.x & 63;
+  static __device__ __forceinline__ void prefetch(const Params&, Pre<FM, FN, NG>&, int, int, int, int) {}
+  // wave tiles 32 / 64 columns wide: accumulators go through RowStage so C is written in whole row runs
+  template <int FN> static constexpr bool staged() { return FN == 2 || FN == 4; }
+  template <int FM, int FN, int NG> static constexpr int lds_bytes() { return staged<FN>() ? 4 * RowStage<1, (staged<FN>() ? FN * 16 : 64)>::WAVE_BYTES : 0; }
+  template <int FM, int FN, int NG>
+  static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], const Pre<FM, FN, NG>&,
+                                               int m0, int n0, int M, int N, int split, char* lds) {
     const bool bf = p.c_bf16 != 0;
     const bool vec = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & (bf ? 7 : 15)) == 0);
     const bool use_bias = p.bias != nullptr && split == 0;
+    if constexpr (staged<FN>()) {
+      using RS = RowStage<1, FN * 16>;
+      float* st = RS::base(lds);
+      const int u = RS::unit();
 #pragma unroll
-    for (int i = 0; i < FM; i++) {
-      const int m = m0 + i * 16 + (lane & 15);
-      if (m >= M) continue;
+      for (int i = 0; i < FM; i++) {
+        RS::put(st, acc[i]);
 #pragma unroll
-      for (int j = 0; j < FN; j++) {
-        const int n = n0 + j * 16 + (lane >> 4) * 4;
-        if (n >= N) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          v[e] = p.alpha * acc[i][j][e];
-          if (use_bias && n + e < N) v[e] += p.bias[n + e];
-          if (p.act == 1) v[e] = expf(v[e]);
+        for (int c = 0; c < RS::PASSES; c++) {
+          const int row = RS::row(c), m = m0 + i * 16 + row, n = n0 + u;
+          if (m < M && n < N) cell(p, m, n, N, RS::get(st, row, u), bf, vec, use_bias);
         }
-        const long off = (long)m * p.ldc + n;
-        if (p.atomic) {
-          float* c = reinterpret_cast<float*>(p.C) + off;
-#pragma unroll
-          for (int e = 0; e < 4; e++) if (n + e < N) atomicAdd(c + e, v[e]);
-        } else if (vec && n + 3 < N) {
-          if (p.accumulate) { const float4 q = ld4f(p.C, off, bf); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
-          st4f(p.C, off, bf, v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; e++) if (n + e < N) st1f(p.C, off + e, bf, p.accumulate ? ld1f(p.C, off + e, bf) + v[e] : v[e]);
-        }
+        __builtin_amdgcn_wave_barrier();
       }
+    } else {
+      const int lane = threadIdx.x & 63;
+#pragma unroll
+      for (int i = 0; i < FM; i++)
+#pragma unroll
+        for (int j = 0; j < FN; j++) {
+          const int m = m0 + i * 16 + (lane & 15), n = n0 + j * 16 + (lane >> 4) * 4;
+          if (m < M && n < N) cell(p, m, n, N, acc[i][j], bf, vec, use_bias);
+        }
+    }
+  }
+  static __device__ __forceinline__ void cell(const Params& p, int m, int n, int N, const f32x4& a, bool bf, bool vec, bool use_bias) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      v[e] = p.alpha * a[e];
+      if (use_bias && n + e < N) v[e] += p.bias[n + e];
+      if (p.act == 1) v[e] = expf(v[e]);
+    }
+    const long off = (long)m * p.ldc + n;
+    if (p.atomic) {
+      float* c = reinterpret_cast<float*>(p.C) + off;
+#pragma unroll
+      for (int e = 0; e < 4; e++) if (n + e < N) atomicAdd(c + e, v[e]);
+    } else if (vec && n + 3 < N) {
+      if (p.accumulate) { const float4 q = ld4f(p.C, off, bf); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
+      st4f(p.C, off, bf, v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; e++) if (n + e < N) st1f(p.C, off + e, bf, p.accumulate ? ld1f(p.C, off + e, bf) + v[e] : v[e]);
     }
   }
 };

@@ -341,6 +341,51 @@ struct TileMma<F32, FM, FNT> {
 };
 
 // ---------------------------------------------------------------------------------------------
+// RowStage: accumulator fragments -> wave-private LDS -> row-contiguous lanes.
+// In the MFMA C layout a lane owns 4 units of ONE row and the 16 lanes of a column group sit on 16
+// different rows, so every global access of an epilogue touches 16 rows x 32-64 bytes; measured on the
+// GRU cell's operand mix that pattern streams at 3.3 TB/s where row-contiguous lanes reach 4.2 (8 lanes
+// per row) to 4.8 TB/s (16 lanes per row) -- scripts/micro/epi_pattern.hip.  Epilogues therefore pass each
+// 16-row fragment row through LDS: afterwards W/4 consecutive lanes cover one row's W units (W = units of
+// the wave tile, 32 or 64) and a wave instruction touches 8 or 4 rows in whole 64-256 byte runs.
+//   * C-layout ds_write_b128 (8 contiguous lanes = 8 rows): row stride S = NG*W + 4 floats, S/4 odd -> the
+//     8 rows land on 8 disjoint 4-bank groups: conflict-free.
+//   * read-back ds_read_b128: each hardware lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32 --
+//     MI355X_MICROARCH.md LDS table) is mapped onto one whole row (W = 64), or onto two rows 8 apart
+//     (W = 32: 8*S = 32 mod 64 banks, the halves tile the 64 banks): conflict-free.
+// ---------------------------------------------------------------------------------------------
+template <int NG, int W>
+struct RowStage {
+  static_assert(W == 32 || W == 64, "wave tiles of 32 or 64 units");
+  static constexpr int NF = NG * W / 16;                  // fragments per staged row
+  static constexpr int S = NG * W + 4;                    // floats per staged row
+  static constexpr int WAVE_BYTES = 16 * S * 4;
+  static constexpr int PASSES = W == 64 ? 4 : 2;          // wave instructions per 16-row fragment row
+  static __device__ __forceinline__ float* base(char* lds) { return reinterpret_cast<float*>(lds) + (threadIdx.x >> 6) * (16 * S); }
+  // acc row i of the wave (fragments g*FN + f) -> LDS; st[row][g*W + unit]
+  static __device__ __forceinline__ void put(float* st, const f32x4 (&a)[NF]) {
+    const int lane = threadIdx.x & 63;
+    float* w = st + (lane & 15) * S + (lane >> 4) * 4;
+#pragma unroll
+    for (int f = 0; f < NF; f++) *reinterpret_cast<f32x4*>(w + f * 16) = a[f];
+    __builtin_amdgcn_wave_barrier();
+  }
+  // lane -> row (0..15) of pass ps and first unit (0..W-4) of its 4-unit chunk
+  static __device__ __forceinline__ int row(int ps) {
+    const int lane = threadIdx.x & 63, q = (lane >> 2) & 7;
+    const int grp = (lane >> 5) * 2 + ((0x96 >> q) & 1);          // hardware b128 lane group 0..3
+    return W == 64 ? ps * 4 + grp : ps * 4 + grp + 8 * (q >> 2);
+  }
+  static __device__ __forceinline__ int unit() {
+    const int lane = threadIdx.x & 63, q = (lane >> 2) & 7;
+    return W == 64 ? ((q >> 1) * 4 + (lane & 3)) * 4 : (((q >> 1) & 1) * 4 + (lane & 3)) * 4;
+  }
+  static __device__ __forceinline__ f32x4 get(const float* st, int r, int col) {
+    return *reinterpret_cast<const f32x4*>(st + r * S + col);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
 // the kernel body.  Epi::apply(ep, acc, m0, j0, M, N) is called once per wave with
 //   m0 = first m of the wave's tile, j0 = first unit (n) of the wave's tile;
 //   acc[fm][g*FN + fn] is gate g, fragment (fm, fn).
@@ -353,8 +398,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int FM = WTM / 16, FN = WTN / 16;
   constexpr int BROWS = NG * BN;
-  __shared__ __attribute__((aligned(16))) T As[BM * CT::LDS_LD];
-  __shared__ __attribute__((aligned(16))) T Bs[BROWS * CT::LDS_LD];
+  // one LDS arena: the operand tiles of the main loop, reused by epilogues that stage accumulators (RowStage)
+  constexpr int MAIN_BYTES = (BM + BROWS) * CT::LDS_LD * (int)sizeof(T);
+  constexpr int EPI_BYTES = Epi::template lds_bytes<FM, FN, NG>();
+  __shared__ __attribute__((aligned(16))) char smem[MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES];
+  T* As = reinterpret_cast<T*>(smem);
+  T* Bs = As + BM * CT::LDS_LD;
 
   // Block -> (m tile, n tile, K split), XCD-aware.  Blocks are dispatched round-robin over the 8 XCDs
   // (block id % 8; speed only, never correctness -- MI355X_MICROARCH.md), each with a private 4 MB L2:
@@ -410,6 +459,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
   // recurrent steps run one block per CU, so load latency is only hidden by depth, not by occupancy)
   typename std::conditional<KMAJOR_A, StageKM<CT, BM, SA>, StageKC<CT, BM, SA>>::type sa[PF];
   typename std::conditional<KMAJOR_B, StageKM<CT, BROWS, SB>, StageKC<CT, BROWS, SB>>::type sb[PF];
+
+  // epilogue operands an Epi wants in flight under the main loop (empty for most)
+  typename Epi::template Pre<FM, FN, NG> pre;
+  Epi::template prefetch<FM, FN, NG>(ep, pre, m_blk + wm * WTM, n_blk + wn * WTN, g.M, g.N);
 
   f32x4 acc[FM][NG * FN];
 #pragma unroll
@@ -485,7 +538,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
     if (k0 + CT::BK < kend) load_tiles(sa[0], sb[0], k0 + CT::BK);     // prefetch next tile under the MFMAs
     mma();
   }
-  Epi::template apply<FM, FN, NG>(ep, acc, m_blk + wm * WTM, n_blk + wn * WTN, g.M, g.N, split);
+  if constexpr (EPI_BYTES > 0) __syncthreads();            // every wave is done with the operand tiles
+  Epi::template apply<FM, FN, NG>(ep, acc, pre, m_blk + wm * WTM, n_blk + wn * WTN, g.M, g.N, split, smem);
 }
 
 }  // namespace ptv

@@ -15,77 +15,150 @@ namespace ptv {
 // ---------------------------------------------------------------------------------------------
 // forward step epilogue: acc[.][g*FN+fn] = (h_prev . W_h{g}^T) for unit j of gate g
 // ---------------------------------------------------------------------------------------------
-struct EpiGruFwd {
-  struct Params {
-    const float* hprev; long ld_hprev;
-    const void* gi; long ld_gi;         // [M, 3H] input-side pre-activations (b_ih included); fp32 or bf16
-    const void* gi2; long ld_gi2;       // optional second addend (e.g. per-step token part), may be null
-    const float* bhh;                   // [3H]
-    float* hout; long ld_hout;
-    __bf16* hout16;                     // optional bf16 copy of the new state [M,H] dense (MFMA operand for later products)
-    void* gates; long plane;            // saved (r, z, n, hn) as 4 planes [M,H]; null = do not save; fp32 or bf16
-    const int* lengths; int t;          // packed-sequence mask: row m is updated iff t < lengths[m]
-    const int* gi_idx;                  // optional: row m reads gi row gi_idx[m] (token-indexed gate table)
-    int H;
-    int flags;                          // PTV_GRU_*_BF16
+struct GruFwdParams {
+  const float* hprev; long ld_hprev;
+  const void* gi; long ld_gi;         // [M, 3H] input-side pre-activations (b_ih included); fp32 or bf16
+  const void* gi2; long ld_gi2;       // optional second addend (e.g. per-step token part), may be null
+  const float* bhh;                   // [3H]
+  float* hout; long ld_hout;
+  __bf16* hout16;                     // optional bf16 copy of the new state [M,H] dense (MFMA operand for later products)
+  void* gates; long plane;            // saved (r, z, n, hn) as 4 planes [M,H]; null = do not save; fp32 or bf16
+  const int* lengths; int t;          // packed-sequence mask: row m is updated iff t < lengths[m]
+  const int* gi_idx;                  // optional: row m reads gi row gi_idx[m] (token-indexed gate table)
+  int H;
+  int flags;                          // PTV_GRU_*_BF16
+};
+
+// FAST: the teacher-forced bf16-storage case (gi and gates bf16, no gi2 / gi_idx), dtype branches resolved at
+// compile time and the per-element operands (gi, h_prev) PREFETCHED into registers before the main loop:
+// the cell is a streaming kernel with a short K loop, and its HBM rate is set by how many bytes each CU
+// keeps in flight -- operands requested at kernel start arrive under the MFMAs instead of being waited for
+// one cell at a time in the epilogue.
+template <bool FAST>
+struct EpiGruFwdT {
+  using Params = GruFwdParams;
+  // wave tiles 32 or 64 units wide go through RowStage (row-contiguous lanes); narrower ones stay in the C layout.
+  // A lane then owns NC cells (row, 4 units) per 16-row fragment row i.
+  template <int FN> static constexpr bool staged() { return FN == 2 || FN == 4; }
+  template <int FN> static constexpr int ncell() { return staged<FN>() ? RowStage<3, (staged<FN>() ? FN * 16 : 64)>::PASSES : FN; }
+  template <int FM, int FN, int NG> static constexpr int lds_bytes() { return staged<FN>() ? 4 * RowStage<3, (staged<FN>() ? FN * 16 : 64)>::WAVE_BYTES : 0; }
+  template <int FN> static __device__ __forceinline__ void coord(int i, int c, int& row, int& u) {
+    if constexpr (staged<FN>()) {
+      using RS = RowStage<3, FN * 16>;
+      row = i * 16 + RS::row(c); u = RS::unit();
+    } else {
+      const int lane = threadIdx.x & 63;
+      row = i * 16 + (lane & 15); u = c * 16 + (lane >> 4) * 4;
+    }
+  }
+  template <int FM, int FN, int NG> struct Pre {
+    bf16x4 g[FAST ? FM : 1][FAST ? ncell<FN>() : 1][3];
+    float4 hp[FAST ? FM : 1][FAST ? ncell<FN>() : 1];
   };
   template <int FM, int FN, int NG>
-  static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], int m0, int j0, int M, int H, int split) {
-    static_assert(NG == 3, "GRU epilogue needs the three gates");
-    const int lane = threadIdx.x & 63;
-    const bool gbf = p.flags & PTV_GRU_GATES_BF16, ibf = p.flags & PTV_GRU_GI_BF16, i2bf = p.flags & PTV_GRU_GI2_BF16;
+  static __device__ __forceinline__ void prefetch(const Params& p, Pre<FM, FN, NG>& pre, int m0, int j0, int M, int H) {
+    if constexpr (FAST) {
+      const __bf16* gi = reinterpret_cast<const __bf16*>(p.gi);
 #pragma unroll
-    for (int i = 0; i < FM; i++) {
-      const int m = m0 + i * 16 + (lane & 15);
-      if (m >= M) continue;
-      const bool live = p.lengths == nullptr || p.t < p.lengths[m];
+      for (int i = 0; i < FM; i++)
 #pragma unroll
-      for (int f = 0; f < FN; f++) {
-        const int j = j0 + f * 16 + (lane >> 4) * 4;
-        if (j >= H) continue;
-        // H is a multiple of 4 for every GRU on the path (host checks) -> vector accesses
-        const long gm = p.gi_idx ? p.gi_idx[m] : m;
-        const float4 gr = ld4f(p.gi, gm * p.ld_gi + j, ibf);
-        const float4 gz = ld4f(p.gi, gm * p.ld_gi + H + j, ibf);
-        const float4 gn = ld4f(p.gi, gm * p.ld_gi + 2 * H + j, ibf);
-        float4 hr = make_float4(0, 0, 0, 0), hz = hr, hn2 = hr;
-        if (p.gi2) {
-          hr = ld4f(p.gi2, (long)m * p.ld_gi2 + j, i2bf);
-          hz = ld4f(p.gi2, (long)m * p.ld_gi2 + H + j, i2bf);
-          hn2 = ld4f(p.gi2, (long)m * p.ld_gi2 + 2 * H + j, i2bf);
-        }
-        const float4 br = *reinterpret_cast<const float4*>(p.bhh + j);
-        const float4 bz = *reinterpret_cast<const float4*>(p.bhh + H + j);
-        const float4 bn = *reinterpret_cast<const float4*>(p.bhh + 2 * H + j);
-        const float4 hp = *reinterpret_cast<const float4*>(p.hprev + (long)m * p.ld_hprev + j);
-        const float gir[4] = {gr.x + hr.x, gr.y + hr.y, gr.z + hr.z, gr.w + hr.w};
-        const float giz[4] = {gz.x + hz.x, gz.y + hz.y, gz.z + hz.z, gz.w + hz.w};
-        const float gin[4] = {gn.x + hn2.x, gn.y + hn2.y, gn.z + hn2.z, gn.w + hn2.w};
-        const float bR[4] = {br.x, br.y, br.z, br.w}, bZ[4] = {bz.x, bz.y, bz.z, bz.w}, bN[4] = {bn.x, bn.y, bn.z, bn.w};
-        const float hP[4] = {hp.x, hp.y, hp.z, hp.w};
-        float r[4], z[4], n[4], hn[4], h[4];
+        for (int c = 0; c < ncell<FN>(); c++) {
+          int row, u; coord<FN>(i, c, row, u);
+          const long m = min(m0 + row, M - 1);        // clamped: always a valid address, no branch
+          const int j = min(j0 + u, H - 4);
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          r[e] = sigmoidf_(gir[e] + acc[i][0 * FN + f][e] + bR[e]);
-          z[e] = sigmoidf_(giz[e] + acc[i][1 * FN + f][e] + bZ[e]);
-          hn[e] = acc[i][2 * FN + f][e] + bN[e];
-          n[e] = tanhf_(gin[e] + r[e] * hn[e]);
-          if (!live) { r[e] = 0.f; z[e] = 1.f; n[e] = 0.f; }     // masked row: h' = h, zero gate grads
-          h[e] = (1.0f - z[e]) * n[e] + z[e] * hP[e];
+          for (int gt = 0; gt < 3; gt++) pre.g[i][c][gt] = *reinterpret_cast<const bf16x4*>(gi + m * p.ld_gi + gt * H + j);
+          pre.hp[i][c] = *reinterpret_cast<const float4*>(p.hprev + m * p.ld_hprev + j);
         }
-        *reinterpret_cast<float4*>(p.hout + (long)m * p.ld_hout + j) = make_float4(h[0], h[1], h[2], h[3]);
-        if (p.hout16) st4f(p.hout16, (long)m * H + j, true, h[0], h[1], h[2], h[3]);
-        if (p.gates) {
-          const long gs = (long)m * H + j;
-          st4f(p.gates, gs + 0 * p.plane, gbf, r[0], r[1], r[2], r[3]);
-          st4f(p.gates, gs + 1 * p.plane, gbf, z[0], z[1], z[2], z[3]);
-          st4f(p.gates, gs + 2 * p.plane, gbf, n[0], n[1], n[2], n[3]);
-          st4f(p.gates, gs + 3 * p.plane, gbf, hn[0], hn[1], hn[2], hn[3]);
-        }
+    }
+  }
+  // one cell: row m, units j..j+3; a_r/a_z/a_n = h_prev . W_h{r,z,n}^T
+  static __device__ __forceinline__ void cell(const Params& p, int m, int j, int H, const f32x4& a_r, const f32x4& a_z, const f32x4& a_n,
+                                              const bf16x4* pg, const float4* php) {
+    const bool gbf = FAST || (p.flags & PTV_GRU_GATES_BF16), ibf = p.flags & PTV_GRU_GI_BF16, i2bf = p.flags & PTV_GRU_GI2_BF16;
+    const bool live = p.lengths == nullptr || p.t < p.lengths[m];
+    // H is a multiple of 4 for every GRU on the path (host checks) -> vector accesses
+    float gir[4], giz[4], gin[4], hP[4];
+    if constexpr (FAST) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) { gir[e] = (float)pg[0][e]; giz[e] = (float)pg[1][e]; gin[e] = (float)pg[2][e]; }
+      hP[0] = php->x; hP[1] = php->y; hP[2] = php->z; hP[3] = php->w;
+    } else {
+      const long gm = p.gi_idx ? p.gi_idx[m] : m;
+      const float4 gr = ld4f(p.gi, gm * p.ld_gi + j, ibf);
+      const float4 gz = ld4f(p.gi, gm * p.ld_gi + H + j, ibf);
+      const float4 gn = ld4f(p.gi, gm * p.ld_gi + 2 * H + j, ibf);
+      float4 hr = make_float4(0, 0, 0, 0), hz = hr, hn2 = hr;
+      if (p.gi2) {
+        hr = ld4f(p.gi2, (long)m * p.ld_gi2 + j, i2bf);
+        hz = ld4f(p.gi2, (long)m * p.ld_gi2 + H + j, i2bf);
+        hn2 = ld4f(p.gi2, (long)m * p.ld_gi2 + 2 * H + j, i2bf);
       }
+      const float4 hp = *reinterpret_cast<const float4*>(p.hprev + (long)m * p.ld_hprev + j);
+      gir[0] = gr.x + hr.x; gir[1] = gr.y + hr.y; gir[2] = gr.z + hr.z; gir[3] = gr.w + hr.w;
+      giz[0] = gz.x + hz.x; giz[1] = gz.y + hz.y; giz[2] = gz.z + hz.z; giz[3] = gz.w + hz.w;
+      gin[0] = gn.x + hn2.x; gin[1] = gn.y + hn2.y; gin[2] = gn.z + hn2.z; gin[3] = gn.w + hn2.w;
+      hP[0] = hp.x; hP[1] = hp.y; hP[2] = hp.z; hP[3] = hp.w;
+    }
+    const float4 br = *reinterpret_cast<const float4*>(p.bhh + j);
+    const float4 bz = *reinterpret_cast<const float4*>(p.bhh + H + j);
+    const float4 bn = *reinterpret_cast<const float4*>(p.bhh + 2 * H + j);
+    const float bR[4] = {br.x, br.y, br.z, br.w}, bZ[4] = {bz.x, bz.y, bz.z, bz.w}, bN[4] = {bn.x, bn.y, bn.z, bn.w};
+    float r[4], z[4], n[4], hn[4], h[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      r[e] = sigmoidf_(gir[e] + a_r[e] + bR[e]);
+      z[e] = sigmoidf_(giz[e] + a_z[e] + bZ[e]);
+      hn[e] = a_n[e] + bN[e];
+      n[e] = tanhf_(gin[e] + r[e] * hn[e]);
+      if (!live) { r[e] = 0.f; z[e] = 1.f; n[e] = 0.f; }     // masked row: h' = h, zero gate grads
+      h[e] = (1.0f - z[e]) * n[e] + z[e] * hP[e];
+    }
+    *reinterpret_cast<float4*>(p.hout + (long)m * p.ld_hout + j) = make_float4(h[0], h[1], h[2], h[3]);
+    if (FAST || p.hout16) st4f(p.hout16, (long)m * H + j, true, h[0], h[1], h[2], h[3]);
+    if (p.gates) {
+      const long gs = (long)m * H + j;
+      st4f(p.gates, gs + 0 * p.plane, gbf, r[0], r[1], r[2], r[3]);
+      st4f(p.gates, gs + 1 * p.plane, gbf, z[0], z[1], z[2], z[3]);
+      st4f(p.gates, gs + 2 * p.plane, gbf, n[0], n[1], n[2], n[3]);
+      st4f(p.gates, gs + 3 * p.plane, gbf, hn[0], hn[1], hn[2], hn[3]);
+    }
+  }
+  template <int FM, int FN, int NG>
+  static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], const Pre<FM, FN, NG>& pre,
+                                               int m0, int j0, int M, int H, int split, char* lds) {
+    static_assert(NG == 3, "GRU epilogue needs the three gates");
+    constexpr int PI = FAST ? 1 : 0;                       // Pre is [1][1] when unused
+    if constexpr (staged<FN>()) {
+      constexpr int W = FN * 16;
+      using RS = RowStage<3, W>;
+      float* st = RS::base(lds);
+#pragma unroll
+      for (int i = 0; i < FM; i++) {
+        RS::put(st, acc[i]);
+#pragma unroll
+        for (int c = 0; c < RS::PASSES; c++) {
+          int row, u; coord<FN>(i, c, row, u);
+          const int m = m0 + row, j = j0 + u, rl = row - i * 16;
+          if (m < M && j < H)
+            cell(p, m, j, H, RS::get(st, rl, u), RS::get(st, rl, W + u), RS::get(st, rl, 2 * W + u), pre.g[i * PI][c * PI], &pre.hp[i * PI][c * PI]);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < FM; i++)
+#pragma unroll
+        for (int f = 0; f < FN; f++) {
+          int row, u; coord<FN>(i, f, row, u);
+          const int m = m0 + row, j = j0 + u;
+          if (m < M && j < H)
+            cell(p, m, j, H, acc[i][0 * FN + f], acc[i][1 * FN + f], acc[i][2 * FN + f], pre.g[i * PI][f * PI], &pre.hp[i * PI][f * PI]);
+        }
     }
   }
 };
+using EpiGruFwd = EpiGruFwdT<false>;
 
 // ---------------------------------------------------------------------------------------------
 // BPTT step epilogue: acc = dgh_{s+1} . W_hh  (grad reaching h_{s+1}... see gru_seq_bwd)
@@ -103,19 +176,45 @@ struct EpiGruBwd {
     int H;
     int flags;
   };
+  template <int FM, int FN, int NG> struct Pre {};
   template <int FM, int FN, int NG>
-  static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], int m0, int j0, int M, int H, int split) {
-    const int lane = threadIdx.x & 63;
+  static __device__ __forceinline__ void prefetch(const Params&, Pre<FM, FN, NG>&, int, int, int, int) {}
+  template <int FN> static constexpr bool staged() { return FN == 2 || FN == 4; }
+  template <int FM, int FN, int NG> static constexpr int lds_bytes() { return staged<FN>() ? 4 * RowStage<1, (staged<FN>() ? FN * 16 : 64)>::WAVE_BYTES : 0; }
+  template <int FM, int FN, int NG>
+  static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], const Pre<FM, FN, NG>&,
+                                               int m0, int j0, int M, int H, int split, char* lds) {
+    if constexpr (staged<FN>()) {
+      using RS = RowStage<1, FN * 16>;
+      float* st = RS::base(lds);
+      const int u = RS::unit();
+#pragma unroll
+      for (int i = 0; i < FM; i++) {
+        RS::put(st, acc[i]);
+#pragma unroll
+        for (int c = 0; c < RS::PASSES; c++) {
+          const int row = RS::row(c), m = m0 + i * 16 + row, j = j0 + u;
+          if (m < M && j < H) cell(p, m, j, H, RS::get(st, row, u));
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else {
+      const int lane = threadIdx.x & 63;
+#pragma unroll
+      for (int i = 0; i < FM; i++)
+#pragma unroll
+        for (int f = 0; f < FN; f++) {
+          const int m = m0 + i * 16 + (lane & 15), j = j0 + f * 16 + (lane >> 4) * 4;
+          if (m < M && j < H) cell(p, m, j, H, acc[i][f]);
+        }
+    }
+  }
+  // one cell: row m, units j..j+3; a = dgh_{s+1} . W_hh
+  static __device__ __forceinline__ void cell(const Params& p, int m, int j, int H, const f32x4& av) {
     const bool gbf = p.flags & PTV_GRU_GATES_BF16, dbf = p.flags & PTV_GRU_DG_BF16;
-#pragma unroll
-    for (int i = 0; i < FM; i++) {
-      const int m = m0 + i * 16 + (lane & 15);
-      if (m >= M) continue;
-#pragma unroll
-      for (int f = 0; f < FN; f++) {
-        const int j = j0 + f * 16 + (lane >> 4) * 4;
-        if (j >= H) continue;
-        float dh[4] = {acc[i][f][0], acc[i][f][1], acc[i][f][2], acc[i][f][3]};
+    {
+      {
+        float dh[4] = {av[0], av[1], av[2], av[3]};
         if (p.dhz_next) { const float4 q = *reinterpret_cast<const float4*>(p.dhz_next + (long)m * H + j); dh[0] += q.x; dh[1] += q.y; dh[2] += q.z; dh[3] += q.w; }
         if (p.dh_ext) { const float4 q = *reinterpret_cast<const float4*>(p.dh_ext + (long)m * p.ld_ext + j); dh[0] += q.x; dh[1] += q.y; dh[2] += q.z; dh[3] += q.w; }
         if (p.dh_ext2) { const float4 q = *reinterpret_cast<const float4*>(p.dh_ext2 + (long)m * p.ld_ext2 + j); dh[0] += q.x; dh[1] += q.y; dh[2] += q.z; dh[3] += q.w; }
@@ -156,9 +255,9 @@ struct EpiGruBwd {
   }
 };
 
-template <class CT, int BM, int BJ, bool SA, bool SB>
-__global__ __launch_bounds__(NTHREADS) void gru_fwd_step_kernel(GemmArgs g, EpiGruFwd::Params ep) {
-  gemm_body<CT, BM, BJ, 2, 2, 3, false, false, EpiGruFwd, SA, SB, (BM * BJ <= 64 * 32 ? 3 : 1)>(g, ep);
+template <class CT, int BM, int BJ, bool SA, bool SB, bool FAST>
+__global__ __launch_bounds__(NTHREADS) void gru_fwd_step_kernel(GemmArgs g, GruFwdParams ep) {
+  gemm_body<CT, BM, BJ, 2, 2, 3, false, false, EpiGruFwdT<FAST>, SA, SB, (BM * BJ <= 64 * 32 ? 3 : 1)>(g, ep);
 }
 
 __global__ void cast_bf16_kernel(const float* __restrict__ src, long lds, __bf16* __restrict__ dst, long rows, int cols) {
@@ -202,22 +301,26 @@ static inline void end(int i, hipStream_t s, double fl) {
 }
 }  // namespace prof
 
-template <class CT, bool SA, bool SB>
-static void launch_fwd_step(const GemmArgs& g, const EpiGruFwd::Params& ep, hipStream_t s) {
-  // units per block 64 (x3 gates) with 128 rows when that still fills the chip, else 32 x 64
-  const long blocks_big = (long)cdiv(g.M, 128) * cdiv(g.N, 64);
-  if (blocks_big >= 192) {
-    hipLaunchKernelGGL((gru_fwd_step_kernel<CT, 128, 64, SA, SB>), dim3(cdiv(g.N, 64), cdiv(g.M, 128)), dim3(NTHREADS), 0, s, g, ep);
+template <class CT, bool SA, bool SB, bool FAST>
+static void launch_fwd_step(const GemmArgs& g, const GruFwdParams& ep, hipStream_t s) {
+  // 64 rows x 64 units (x3 gates) per block when that fills the chip, else 64 x 32 (the small-M recurrent steps)
+  const long blocks_big = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
+  if (blocks_big >= 384) {
+    hipLaunchKernelGGL((gru_fwd_step_kernel<CT, 64, 64, SA, SB, FAST>), dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
   } else {
-    hipLaunchKernelGGL((gru_fwd_step_kernel<CT, 64, 32, SA, SB>), dim3(cdiv(g.N, 32), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
+    hipLaunchKernelGGL((gru_fwd_step_kernel<CT, 64, 32, SA, SB, FAST>), dim3(cdiv(g.N, 32), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
   }
 }
-static void launch_fwd_any(int prec, bool a16, bool w16, const GemmArgs& g, const EpiGruFwd::Params& ep, hipStream_t s) {
+static void launch_fwd_any(int prec, bool a16, bool w16, const GemmArgs& g, const GruFwdParams& ep, hipStream_t s) {
+  // FAST epilogue: all-bf16 storage, plain row indexing (the teacher-forced path)
+  const bool fast = a16 && w16 && ep.hout16 && (ep.flags & PTV_GRU_GI_BF16) && (!ep.gates || (ep.flags & PTV_GRU_GATES_BF16)) &&
+                    !ep.gi2 && !ep.gi_idx && g.M >= 1 && ep.H >= 4;
   if (prec == PTV_PREC_BF16) {
-    if (a16 && w16) launch_fwd_step<BF16, true, true>(g, ep, s);
-    else if (a16) launch_fwd_step<BF16, true, false>(g, ep, s);
-    else launch_fwd_step<BF16, false, false>(g, ep, s);
-  } else launch_fwd_step<F32, false, false>(g, ep, s);
+    if (fast) launch_fwd_step<BF16, true, true, true>(g, ep, s);
+    else if (a16 && w16) launch_fwd_step<BF16, true, true, false>(g, ep, s);
+    else if (a16) launch_fwd_step<BF16, true, false, false>(g, ep, s);
+    else launch_fwd_step<BF16, false, false, false>(g, ep, s);
+  } else launch_fwd_step<F32, false, false, false>(g, ep, s);
 }
 static void cast_rows_bf16(const float* src, long lds, void* dst, long rows, int cols, hipStream_t s) {
   long nb = (rows * cols + 255) / 256; if (nb > 2048) nb = 2048;
