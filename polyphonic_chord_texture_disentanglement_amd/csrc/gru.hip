@@ -34,9 +34,10 @@ struct GruFwdParams {
 // the cell is a streaming kernel with a short K loop, and its HBM rate is set by how many bytes each CU
 // keeps in flight -- operands requested at kernel start arrive under the MFMAs instead of being waited for
 // one cell at a time in the epilogue.
-template <bool FAST>
+template <int MODE>   // 0 generic, 1 FAST, 2 FAST with a bf16 gi2 addend
 struct EpiGruFwdT {
   using Params = GruFwdParams;
+  static constexpr bool FAST = MODE > 0, G2 = MODE == 2;
   // wave tiles 32 or 64 units wide go through RowStage (row-contiguous lanes); narrower ones stay in the C layout.
   // A lane then owns NC cells (row, 4 units) per 16-row fragment row i.
   template <int FN> static constexpr bool staged() { return FN == 2 || FN == 4; }
@@ -53,6 +54,7 @@ struct EpiGruFwdT {
   }
   template <int FM, int FN, int NG> struct Pre {
     bf16x4 g[FAST ? FM : 1][FAST ? ncell<FN>() : 1][3];
+    bf16x4 g2[G2 ? FM : 1][G2 ? ncell<FN>() : 1][3];
     float4 hp[FAST ? FM : 1][FAST ? ncell<FN>() : 1];
   };
   template <int FM, int FN, int NG>
@@ -68,13 +70,18 @@ struct EpiGruFwdT {
           const int j = min(j0 + u, H - 4);
 #pragma unroll
           for (int gt = 0; gt < 3; gt++) pre.g[i][c][gt] = *reinterpret_cast<const bf16x4*>(gi + m * p.ld_gi + gt * H + j);
+          if constexpr (G2) {
+            const __bf16* gi2 = reinterpret_cast<const __bf16*>(p.gi2);
+#pragma unroll
+            for (int gt = 0; gt < 3; gt++) pre.g2[i][c][gt] = *reinterpret_cast<const bf16x4*>(gi2 + m * p.ld_gi2 + gt * H + j);
+          }
           pre.hp[i][c] = *reinterpret_cast<const float4*>(p.hprev + m * p.ld_hprev + j);
         }
     }
   }
   // one cell: row m, units j..j+3; a_r/a_z/a_n = h_prev . W_h{r,z,n}^T
   static __device__ __forceinline__ void cell(const Params& p, int m, int j, int H, const f32x4& a_r, const f32x4& a_z, const f32x4& a_n,
-                                              const bf16x4* pg, const float4* php) {
+                                              const bf16x4* pg, const bf16x4* pg2, const float4* php) {
     const bool gbf = FAST || (p.flags & PTV_GRU_GATES_BF16), ibf = p.flags & PTV_GRU_GI_BF16, i2bf = p.flags & PTV_GRU_GI2_BF16;
     const bool live = p.lengths == nullptr || p.t < p.lengths[m];
     // H is a multiple of 4 for every GRU on the path (host checks) -> vector accesses
@@ -82,6 +89,10 @@ struct EpiGruFwdT {
     if constexpr (FAST) {
 #pragma unroll
       for (int e = 0; e < 4; e++) { gir[e] = (float)pg[0][e]; giz[e] = (float)pg[1][e]; gin[e] = (float)pg[2][e]; }
+      if constexpr (G2) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) { gir[e] += (float)pg2[0][e]; giz[e] += (float)pg2[1][e]; gin[e] += (float)pg2[2][e]; }
+      }
       hP[0] = php->x; hP[1] = php->y; hP[2] = php->z; hP[3] = php->w;
     } else {
       const long gm = p.gi_idx ? p.gi_idx[m] : m;
@@ -128,7 +139,7 @@ struct EpiGruFwdT {
   static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], const Pre<FM, FN, NG>& pre,
                                                int m0, int j0, int M, int H, int split, char* lds) {
     static_assert(NG == 3, "GRU epilogue needs the three gates");
-    constexpr int PI = FAST ? 1 : 0;                       // Pre is [1][1] when unused
+    constexpr int PI = FAST ? 1 : 0, P2 = G2 ? 1 : 0;      // Pre arrays are [1][1] when unused
     if constexpr (staged<FN>()) {
       constexpr int W = FN * 16;
       using RS = RowStage<3, W>;
@@ -141,7 +152,7 @@ struct EpiGruFwdT {
           int row, u; coord<FN>(i, c, row, u);
           const int m = m0 + row, j = j0 + u, rl = row - i * 16;
           if (m < M && j < H)
-            cell(p, m, j, H, RS::get(st, rl, u), RS::get(st, rl, W + u), RS::get(st, rl, 2 * W + u), pre.g[i * PI][c * PI], &pre.hp[i * PI][c * PI]);
+            cell(p, m, j, H, RS::get(st, rl, u), RS::get(st, rl, W + u), RS::get(st, rl, 2 * W + u), pre.g[i * PI][c * PI], pre.g2[i * P2][c * P2], &pre.hp[i * PI][c * PI]);
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -153,12 +164,12 @@ struct EpiGruFwdT {
           int row, u; coord<FN>(i, f, row, u);
           const int m = m0 + row, j = j0 + u;
           if (m < M && j < H)
-            cell(p, m, j, H, acc[i][0 * FN + f], acc[i][1 * FN + f], acc[i][2 * FN + f], pre.g[i * PI][f * PI], &pre.hp[i * PI][f * PI]);
+            cell(p, m, j, H, acc[i][0 * FN + f], acc[i][1 * FN + f], acc[i][2 * FN + f], pre.g[i * PI][f * PI], pre.g2[i * P2][f * P2], &pre.hp[i * PI][f * PI]);
         }
     }
   }
 };
-using EpiGruFwd = EpiGruFwdT<false>;
+using EpiGruFwd = EpiGruFwdT<0>;
 
 // ---------------------------------------------------------------------------------------------
 // BPTT step epilogue: acc = dgh_{s+1} . W_hh  (grad reaching h_{s+1}... see gru_seq_bwd)
@@ -255,9 +266,9 @@ struct EpiGruBwd {
   }
 };
 
-template <class CT, int BM, int BJ, bool SA, bool SB, bool FAST>
-__global__ __launch_bounds__(NTHREADS) void gru_fwd_step_kernel(GemmArgs g, GruFwdParams ep) {
-  gemm_body<CT, BM, BJ, 2, 2, 3, false, false, EpiGruFwdT<FAST>, SA, SB, (BM * BJ <= 64 * 32 ? 3 : 1)>(g, ep);
+template <class CT, int BM, int BJ, bool SA, bool SB, int MODE>
+__global__ __launch_bounds__(NTHREADS, 2) void gru_fwd_step_kernel(GemmArgs g, GruFwdParams ep) {
+  gemm_body<CT, BM, BJ, 2, 2, 3, false, false, EpiGruFwdT<MODE>, SA, SB, (BM * BJ <= 64 * 32 ? 3 : 1)>(g, ep);
 }
 
 __global__ void cast_bf16_kernel(const float* __restrict__ src, long lds, __bf16* __restrict__ dst, long rows, int cols) {
@@ -301,7 +312,7 @@ static inline void end(int i, hipStream_t s, double fl) {
 }
 }  // namespace prof
 
-template <class CT, bool SA, bool SB, bool FAST>
+template <class CT, bool SA, bool SB, int FAST>
 static void launch_fwd_step(const GemmArgs& g, const GruFwdParams& ep, hipStream_t s) {
   // 64 rows x 64 units (x3 gates) per block when that fills the chip, else 64 x 32 (the small-M recurrent steps)
   const long blocks_big = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
@@ -314,13 +325,14 @@ static void launch_fwd_step(const GemmArgs& g, const GruFwdParams& ep, hipStream
 static void launch_fwd_any(int prec, bool a16, bool w16, const GemmArgs& g, const GruFwdParams& ep, hipStream_t s) {
   // FAST epilogue: all-bf16 storage, plain row indexing (the teacher-forced path)
   const bool fast = a16 && w16 && ep.hout16 && (ep.flags & PTV_GRU_GI_BF16) && (!ep.gates || (ep.flags & PTV_GRU_GATES_BF16)) &&
-                    !ep.gi2 && !ep.gi_idx && g.M >= 1 && ep.H >= 4;
+                    (!ep.gi2 || (ep.flags & PTV_GRU_GI2_BF16)) && !ep.gi_idx && g.M >= 1 && ep.H >= 4;
   if (prec == PTV_PREC_BF16) {
-    if (fast) launch_fwd_step<BF16, true, true, true>(g, ep, s);
-    else if (a16 && w16) launch_fwd_step<BF16, true, true, false>(g, ep, s);
-    else if (a16) launch_fwd_step<BF16, true, false, false>(g, ep, s);
-    else launch_fwd_step<BF16, false, false, false>(g, ep, s);
-  } else launch_fwd_step<F32, false, false, false>(g, ep, s);
+    if (fast && ep.gi2) launch_fwd_step<BF16, true, true, 2>(g, ep, s);
+    else if (fast) launch_fwd_step<BF16, true, true, 1>(g, ep, s);
+    else if (a16 && w16) launch_fwd_step<BF16, true, true, 0>(g, ep, s);
+    else if (a16) launch_fwd_step<BF16, true, false, 0>(g, ep, s);
+    else launch_fwd_step<BF16, false, false, 0>(g, ep, s);
+  } else launch_fwd_step<F32, false, false, 0>(g, ep, s);
 }
 static void cast_rows_bf16(const float* src, long lds, void* dst, long rows, int cols, hipStream_t s) {
   long nb = (rows * cols + 255) / 256; if (nb > 2048) nb = 2048;

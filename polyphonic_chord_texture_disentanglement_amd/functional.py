@@ -507,8 +507,9 @@ class DecoderTFFn(torch.autograd.Function):
         copy2d(TOKS[0], P['dec_init_input'].view(1, -1), lds=0)
         copy2d(TOKS[1:].view(R, 2 * He), xs)
         w_ih_t = W['dec_time_gru.weight_ih_l0']
-        gi_t = gemm(TOKS[:32].view(R, 2 * He), w_ih_t[:, :2 * He], prec=prec)  # [32*B, 3Ht]
-        zg = gemm(z_in, w_ih_t[:, 2 * He:], bias=P['dec_time_gru.bias_ih_l0'], prec=prec)
+        adt_t = _act_dtype(prec, Ht)
+        gi_t = gemm(TOKS[:32].view(R, 2 * He), w_ih_t[:, :2 * He], prec=prec, out_dtype=adt_t)  # [32*B, 3Ht]
+        zg = gemm(z_in, w_ih_t[:, 2 * He:], bias=P['dec_time_gru.bias_ih_l0'], prec=prec, out_dtype=adt_t)
         gates_t = _empty(32, 4, B, Ht, dev=dev, dtype=_act_dtype(prec, Ht))
         NS16 = _hall16(prec, 33, B, Ht, dev)
         gru_fwd(prec, gi_t, B * 3 * Ht, 3 * Ht, W['dec_time_gru.weight_hh_l0'], P['dec_time_gru.bias_hh_l0'], NS,

@@ -12,7 +12,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int PAT, int CELLS>
 __global__ __launch_bounds__(256) void k(const __bf16* __restrict__ gi, const float* __restrict__ hp, float* __restrict__ h,
-                                         __bf16* __restrict__ h16, __bf16* __restrict__ gates, int M, int H) {
+                                         __bf16* __restrict__ h16, __bf16* __restrict__ gates, int M, int H, const __bf16* __restrict__ gi2) {
   // block tile: 64 rows x 64 units
   const int ntn = H / 64;
   const int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn;
@@ -61,6 +61,28 @@ __global__ __launch_bounds__(256) void k(const __bf16* __restrict__ gi, const fl
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) v[e] = (float)g[ps][0][e] + (float)g[ps][1][e] * (float)g[ps][2][e] + ((const float*)&p[ps])[e];
+      *(float4*)(h + m * H + j) = make_float4(v[0], v[1], v[2], v[3]);
+      bf16x4 o; for (int e = 0; e < 4; e++) o[e] = (__bf16)v[e];
+      *(bf16x4*)(h16 + m * H + j) = o;
+#pragma unroll
+      for (int q = 0; q < 4; q++) *(bf16x4*)(gates + q * plane + m * H + j) = o;
+    }
+  } else if constexpr (PAT == 4) {
+    bf16x4 g[4][3], g2[4][3]; float4 p[4];
+    const int j = nt * 64 + (wave & 1) * 32 + (lane & 7) * 4;
+#pragma unroll
+    for (int ps = 0; ps < 4; ps++) {
+      const long m = mt * 64 + (wave >> 1) * 32 + ps * 8 + (lane >> 3);
+#pragma unroll
+      for (int q = 0; q < 3; q++) { g[ps][q] = *(const bf16x4*)(gi + m * 3 * H + q * H + j); g2[ps][q] = *(const bf16x4*)(gi2 + m * 3 * H + q * H + j); }
+      p[ps] = *(const float4*)(hp + m * H + j);
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ps++) {
+      const long m = mt * 64 + (wave >> 1) * 32 + ps * 8 + (lane >> 3);
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[e] = (float)g[ps][0][e] + (float)g2[ps][0][e] + ((float)g[ps][1][e] + (float)g2[ps][1][e]) * ((float)g[ps][2][e] + (float)g2[ps][2][e]) + ((const float*)&p[ps])[e];
       *(float4*)(h + m * H + j) = make_float4(v[0], v[1], v[2], v[3]);
       bf16x4 o; for (int e = 0; e < 4; e++) o[e] = (__bf16)v[e];
       *(bf16x4*)(h16 + m * H + j) = o;
@@ -119,29 +141,32 @@ __global__ __launch_bounds__(256) void k(const __bf16* __restrict__ gi, const fl
 
 int main(int argc, char** argv) {
   const int M = 16384, H = 512, T = 8;
-  __bf16 *gi, *h16, *gates; float *hp, *h;
+  __bf16 *gi, *h16, *gates, *gi2; float *hp, *h;
+  hipMalloc(&gi2, (size_t)M * 3 * H * 2); hipMemset(gi2, 0, (size_t)M * 3 * H * 2);
   hipMalloc(&gi, (size_t)T * M * 3 * H * 2); hipMalloc(&hp, (size_t)T * M * H * 4); hipMalloc(&h, (size_t)T * M * H * 4);
   hipMalloc(&h16, (size_t)T * M * H * 2); hipMalloc(&gates, (size_t)T * 4 * M * H * 2);
   hipMemset(gi, 0, (size_t)T * M * 3 * H * 2); hipMemset(hp, 0, (size_t)T * M * H * 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const double bytes = (double)M * H * (6 + 4 + 4 + 2 + 8);
-  for (int pat = 0; pat < 4; pat++) {
+  for (int pat = 0; pat < 5; pat++) {
     float best = 1e9;
     for (int rep = 0; rep < 4; rep++) {
       hipEventRecord(e0);
       for (int t = 0; t < T; t++) {
         const dim3 grid(M / 64 * H / 64);
         const long o = (long)t * M * H;
-        if (pat == 0) hipLaunchKernelGGL((k<0, 4>), grid, dim3(256), 0, 0, gi + 3 * o, hp + o, h + o, h16 + o, gates + 4 * o, M, H);
-        if (pat == 1) hipLaunchKernelGGL((k<1, 4>), grid, dim3(256), 0, 0, gi + 3 * o, hp + o, h + o, h16 + o, gates + 4 * o, M, H);
-        if (pat == 3) hipLaunchKernelGGL((k<3, 4>), grid, dim3(256), 0, 0, gi + 3 * o, hp + o, h + o, h16 + o, gates + 4 * o, M, H);
-        if (pat == 2) hipLaunchKernelGGL((k<2, 4>), grid, dim3(256), 0, 0, gi + 3 * o, hp + o, h + o, h16 + o, gates + 4 * o, M, H);
+        if (pat == 0) hipLaunchKernelGGL((k<0, 4>), grid, dim3(256), 0, 0, gi + 3 * o, hp + o, h + o, h16 + o, gates + 4 * o, M, H, gi2);
+        if (pat == 1) hipLaunchKernelGGL((k<1, 4>), grid, dim3(256), 0, 0, gi + 3 * o, hp + o, h + o, h16 + o, gates + 4 * o, M, H, gi2);
+        if (pat == 3) hipLaunchKernelGGL((k<3, 4>), grid, dim3(256), 0, 0, gi + 3 * o, hp + o, h + o, h16 + o, gates + 4 * o, M, H, gi2);
+        if (pat == 4) hipLaunchKernelGGL((k<4, 4>), grid, dim3(256), 0, 0, gi + 3 * o, hp + o, h + o, h16 + o, gates + 4 * o, M, H, gi2);
+        if (pat == 2) hipLaunchKernelGGL((k<2, 4>), grid, dim3(256), 0, 0, gi + 3 * o, hp + o, h + o, h16 + o, gates + 4 * o, M, H, gi2);
       }
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       if (ms < best) best = ms;
     }
-    printf("pattern %d: %.1f us/launch  %.2f TB/s\n", pat, best * 1e3 / T, bytes / (best * 1e-3 / T) / 1e12);
+    const double by = bytes + (pat == 4 ? (double)M * H * 6 : 0);
+    printf("pattern %d: %.1f us/launch  %.2f TB/s\n", pat, best * 1e3 / T, by / (best * 1e-3 / T) / 1e12);
   }
   return 0;
 }
