@@ -6,6 +6,7 @@
 //   r = s(gi_r + W_hr h + b_hr)  z = s(gi_z + W_hz h + b_hz)  n = tanh(gi_n + r*(W_hn h + b_hn))
 //   h' = (1-z)*n + z*h            (gi = W_i x + b_i is produced by a batched input-side GEMM)
 #include <type_traits>
+#include <cstdlib>
 #include "common.hpp"
 #include "gemm_core.hpp"
 #include "../../include/ptvae_hip.h"
@@ -174,19 +175,71 @@ using EpiGruFwd = EpiGruFwdT<0>;
 // ---------------------------------------------------------------------------------------------
 // BPTT step epilogue: acc = dgh_{s+1} . W_hh  (grad reaching h_{s+1}... see gru_seq_bwd)
 // ---------------------------------------------------------------------------------------------
-struct EpiGruBwd {
-  struct Params {
-    const float* dhz_next;              // [M,H] dh (x) z carried from the later step, null at the last step
-    const float* dh_ext; long ld_ext;   // [M,H] gradient arriving at this step's output from outside, may be null
-    const float* dh_ext2; long ld_ext2; // second external addend (e.g. final-state grad), may be null
-    const float* lr_a; long lr_lda; int lr_k; const float* lr_b;   // optional low-rank addend: dh += lr_a[m, 0:k] . lr_b[k, H]
-    const void* gates; long plane;      // saved r,z,n,hn of this step (fp32 or bf16)
-    const float* hprev; long ld_hprev;
-    void* dgi; void* dgh;               // [M,3H] each (fp32 or bf16)
-    float* dhz;                         // [M,H] out: dh (x) z
-    int H;
-    int flags;
-  };
+struct GruBwdParams {
+  const float* dhz_next;              // [M,H] dh (x) z carried from the later step, null at the last step
+  const float* dh_ext; long ld_ext;   // [M,H] gradient arriving at this step's output from outside, may be null
+  const float* dh_ext2; long ld_ext2; // second external addend (e.g. final-state grad), may be null
+  const float* lr_a; long lr_lda; int lr_k; const float* lr_b;   // optional low-rank addend: dh += lr_a[m, 0:k] . lr_b[k, H]
+  const void* gates; long plane;      // saved r,z,n,hn of this step (fp32 or bf16)
+  const float* hprev; long ld_hprev;
+  void* dgi; void* dgh;               // [M,3H] each (fp32 or bf16)
+  float* dhz;                         // [M,H] out: dh (x) z
+  int H;
+  int flags;
+};
+
+// FAST: bf16 gates and gate gradients, no low-rank addend (the teacher-forced bf16 path): dtype branches
+// resolved at compile time, and the operands of cell c+1 are requested before cell c is computed, so a
+// lane always has one cell's loads in flight behind the arithmetic and stores of the previous one.
+template <bool FAST>
+struct EpiGruBwdT {
+  using Params = GruBwdParams;
+  struct Ops { bf16x4 g[4]; float4 hp, dz, e1, e2; };
+  static __device__ __forceinline__ Ops load_ops(const Params& p, int m_, int j_, int M, int H) {
+    Ops o;
+    const long m = min(m_, M - 1); const int j = min(j_, H - 4);            // clamped: valid address, no branch
+    const __bf16* gt = reinterpret_cast<const __bf16*>(p.gates) + m * H + j;
+#pragma unroll
+    for (int q = 0; q < 4; q++) o.g[q] = *reinterpret_cast<const bf16x4*>(gt + q * p.plane);
+    o.hp = *reinterpret_cast<const float4*>(p.hprev + m * p.ld_hprev + j);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    o.dz = p.dhz_next ? *reinterpret_cast<const float4*>(p.dhz_next + m * H + j) : zero;
+    o.e1 = p.dh_ext ? *reinterpret_cast<const float4*>(p.dh_ext + m * p.ld_ext + j) : zero;
+    o.e2 = p.dh_ext2 ? *reinterpret_cast<const float4*>(p.dh_ext2 + m * p.ld_ext2 + j) : zero;
+    return o;
+  }
+  static __device__ __forceinline__ void cell_fast(const Params& p, int m, int j, int H, const f32x4& av, const Ops& o) {
+    const float dzn[4] = {o.dz.x, o.dz.y, o.dz.z, o.dz.w}, e1[4] = {o.e1.x, o.e1.y, o.e1.z, o.e1.w}, e2[4] = {o.e2.x, o.e2.y, o.e2.z, o.e2.w};
+    const float hp[4] = {o.hp.x, o.hp.y, o.hp.z, o.hp.w};
+    float dr[4], dz[4], dn[4], dnr[4], dhz[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float dh = av[e] + dzn[e] + e1[e] + e2[e];
+      const float r = (float)o.g[0][e], z = (float)o.g[1][e], n = (float)o.g[2][e], hn = (float)o.g[3][e];
+      dn[e] = dh * (1.0f - z) * (1.0f - n * n);
+      dz[e] = dh * (hp[e] - n) * z * (1.0f - z);
+      dr[e] = dn[e] * hn * r * (1.0f - r);
+      dnr[e] = dn[e] * r;
+      dhz[e] = dh * z;
+    }
+    const long go = (long)m * 3 * H + j;
+    st4f(p.dgi, go, true, dr[0], dr[1], dr[2], dr[3]);
+    st4f(p.dgi, go + H, true, dz[0], dz[1], dz[2], dz[3]);
+    st4f(p.dgi, go + 2 * H, true, dn[0], dn[1], dn[2], dn[3]);
+    st4f(p.dgh, go, true, dr[0], dr[1], dr[2], dr[3]);
+    st4f(p.dgh, go + H, true, dz[0], dz[1], dz[2], dz[3]);
+    st4f(p.dgh, go + 2 * H, true, dnr[0], dnr[1], dnr[2], dnr[3]);
+    *reinterpret_cast<float4*>(p.dhz + (long)m * H + j) = make_float4(dhz[0], dhz[1], dhz[2], dhz[3]);
+  }
+  template <int FN> static __device__ __forceinline__ void coord(int c, int& row, int& u) {   // cell c of a 16-row fragment row
+    if constexpr (staged<FN>()) {
+      using RS = RowStage<1, FN * 16>;
+      row = RS::row(c); u = RS::unit();
+    } else {
+      const int lane = threadIdx.x & 63;
+      row = lane & 15; u = c * 16 + (lane >> 4) * 4;
+    }
+  }
   template <int FM, int FN, int NG> struct Pre {};
   template <int FM, int FN, int NG>
   static __device__ __forceinline__ void prefetch(const Params&, Pre<FM, FN, NG>&, int, int, int, int) {}
@@ -195,6 +248,33 @@ struct EpiGruBwd {
   template <int FM, int FN, int NG>
   static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], const Pre<FM, FN, NG>&,
                                                int m0, int j0, int M, int H, int split, char* lds) {
+    if constexpr (FAST) {
+      constexpr int NC = staged<FN>() ? RowStage<1, (staged<FN>() ? FN * 16 : 64)>::PASSES : FN;
+      Ops o[2];
+      { int row, u; coord<FN>(0, row, u); o[0] = load_ops(p, m0 + row, j0 + u, M, H); }
+      [[maybe_unused]] float* st = nullptr;
+      if constexpr (staged<FN>()) st = RowStage<1, (staged<FN>() ? FN * 16 : 64)>::base(lds);
+#pragma unroll
+      for (int i = 0; i < FM; i++) {
+        if constexpr (staged<FN>()) RowStage<1, (staged<FN>() ? FN * 16 : 64)>::put(st, acc[i]);
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+          constexpr int dummy = 0; (void)dummy;
+          const int idx = i * NC + c;
+          if (idx + 1 < FM * NC) {
+            int row, u; coord<FN>((idx + 1) % NC, row, u);
+            o[(idx + 1) & 1] = load_ops(p, m0 + ((idx + 1) / NC) * 16 + row, j0 + u, M, H);
+          }
+          int row, u; coord<FN>(c, row, u);
+          const int m = m0 + i * 16 + row, j = j0 + u;
+          f32x4 av;
+          if constexpr (staged<FN>()) av = RowStage<1, (staged<FN>() ? FN * 16 : 64)>::get(st, row, u); else av = acc[i][c];
+          if (m < M && j < H) cell_fast(p, m, j, H, av, o[idx & 1]);
+        }
+        if constexpr (staged<FN>()) __builtin_amdgcn_wave_barrier();
+      }
+      return;
+    }
     if constexpr (staged<FN>()) {
       using RS = RowStage<1, FN * 16>;
       float* st = RS::base(lds);
@@ -278,9 +358,9 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, long lds, __bf16
 }
 // SB: the weight operand is the bf16 TRANSPOSED shadow W_hh^T [H, 3H] (K-contiguous rows: the fast loader);
 // otherwise the fp32 parameter W_hh [3H, H] read K-major
-template <class CT, int BM, int BN, bool SA, bool SB>
-__global__ __launch_bounds__(NTHREADS) void gru_bwd_step_kernel(GemmArgs g, EpiGruBwd::Params ep) {
-  gemm_body<CT, BM, BN, 2, 2, 1, false, !SB, EpiGruBwd, SA, SB, (BM * BN <= 64 * 32 ? 4 : (BM * BN <= 64 * 64 ? 3 : 2))>(g, ep);
+template <class CT, int BM, int BN, bool SA, bool SB, bool FAST>
+__global__ __launch_bounds__(NTHREADS) void gru_bwd_step_kernel(GemmArgs g, GruBwdParams ep) {
+  gemm_body<CT, BM, BN, 2, 2, 1, false, !SB, EpiGruBwdT<FAST>, SA, SB, (BM * BN <= 64 * 32 ? 4 : (BM * BN <= 64 * 64 ? 3 : 2))>(g, ep);
 }
 
 
@@ -339,16 +419,18 @@ static void cast_rows_bf16(const float* src, long lds, void* dst, long rows, int
   hipLaunchKernelGGL(cast_bf16_kernel, dim3((int)nb), dim3(256), 0, s, src, lds, (__bf16*)dst, rows, cols);
 }
 
-template <class CT, bool SA, bool SB>
-static void launch_bwd_step(const GemmArgs& g, const EpiGruBwd::Params& ep, hipStream_t s) {
+template <class CT, bool SA, bool SB, bool FAST>
+static void launch_bwd_step(const GemmArgs& g, const GruBwdParams& ep, hipStream_t s) {
+  static int tile = getenv("PTV_BWD_TILE") ? atoi(getenv("PTV_BWD_TILE")) : 0;   // DBGTMP
+  if (tile == 64) { hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 64, 64, SA, SB, FAST>), dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep); return; }
   const long blocks_big = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
   const long blocks_mid = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
   if (blocks_big >= 192) {
-    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 128, 128, SA, SB>), dim3(cdiv(g.N, 128), cdiv(g.M, 128)), dim3(NTHREADS), 0, s, g, ep);
+    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 128, 128, SA, SB, FAST>), dim3(cdiv(g.N, 128), cdiv(g.M, 128)), dim3(NTHREADS), 0, s, g, ep);
   } else if (blocks_mid >= 192) {
-    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 64, 64, SA, SB>), dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
+    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 64, 64, SA, SB, FAST>), dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
   } else {
-    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 64, 32, SA, SB>), dim3(cdiv(g.N, 32), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
+    hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 64, 32, SA, SB, FAST>), dim3(cdiv(g.N, 32), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
   }
 }
 
@@ -412,7 +494,7 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
     const bool dbf = flags & PTV_GRU_DG_BF16;
     const long esz_d = dbf ? 2 : 4, esz_g = (flags & PTV_GRU_GATES_BF16) ? 2 : 4;
     GemmArgs g{last ? dgh : (const char*)dgh + (long)(step + 1) * M3H * esz_d, 3L * H, w_hh, w16 ? 3L * H : (long)H, M, H, last ? 0 : 3 * H, last ? 0 : 3 * H, 0};
-    EpiGruBwd::Params ep{last ? nullptr : dhz + ((step + 1) & 1) * MH,
+    GruBwdParams ep{last ? nullptr : dhz + ((step + 1) & 1) * MH,
                          dh_ext ? dh_ext + (long)step * ext_step_stride : nullptr, ext_ld,
                          last ? dh_last : nullptr, last_ld,
                          lr_a ? lr_a + (long)step * lr_step_stride : nullptr, lr_lda, lr_k, lr_b,
@@ -421,11 +503,14 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
                          (char*)dgi + (long)t * M3H * esz_d, (char*)dgh + (long)step * M3H * esz_d,
                          dhz + (step & 1) * MH, H, flags};
     const int pi = prof::want(2, M, H) ? prof::begin(s) : -1;
+    static int nofast = getenv("PTV_NOFAST") ? 1 : 0;   // DBGTMP
+    const bool fast = !nofast && dbf && w16 && (flags & PTV_GRU_GATES_BF16) && !lr_a;      // all-bf16 storage, no low-rank addend
     if (prec == PTV_PREC_BF16) {
-      if (dbf && w16) launch_bwd_step<BF16, true, true>(g, ep, s);
-      else if (dbf) launch_bwd_step<BF16, true, false>(g, ep, s);
-      else launch_bwd_step<BF16, false, false>(g, ep, s);
-    } else launch_bwd_step<F32, false, false>(g, ep, s);
+      if (fast) launch_bwd_step<BF16, true, true, true>(g, ep, s);
+      else if (dbf && w16) launch_bwd_step<BF16, true, true, false>(g, ep, s);
+      else if (dbf) launch_bwd_step<BF16, true, false, false>(g, ep, s);
+      else launch_bwd_step<BF16, false, false, false>(g, ep, s);
+    } else launch_bwd_step<F32, false, false, false>(g, ep, s);
     if (pi >= 0) prof::end(pi, s, last ? 0.0 : 2.0 * M * 3.0 * H * H);
   }
   PTV_CHECK_LAUNCH();
