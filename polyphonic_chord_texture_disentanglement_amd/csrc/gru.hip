@@ -188,13 +188,13 @@ struct GruBwdParams {
   int flags;
 };
 
-// FAST: bf16 gates and gate gradients, no low-rank addend (the teacher-forced bf16 path): dtype branches
+// FAST: bf16 gates and gate gradients, low-rank addend of rank <= 2 (the teacher-forced bf16 path): dtype branches
 // resolved at compile time, and the operands of cell c+1 are requested before cell c is computed, so a
 // lane always has one cell's loads in flight behind the arithmetic and stores of the previous one.
 template <bool FAST>
 struct EpiGruBwdT {
   using Params = GruBwdParams;
-  struct Ops { bf16x4 g[4]; float4 hp, dz, e1, e2; };
+  struct Ops { bf16x4 g[4]; float4 hp, dz, e1, e2; float la[2]; };   // la: low-rank coefficients of the row (lr_k <= 2)
   static __device__ __forceinline__ Ops load_ops(const Params& p, int m_, int j_, int M, int H) {
     Ops o;
     const long m = min(m_, M - 1); const int j = min(j_, H - 4);            // clamped: valid address, no branch
@@ -206,15 +206,26 @@ struct EpiGruBwdT {
     o.dz = p.dhz_next ? *reinterpret_cast<const float4*>(p.dhz_next + m * H + j) : zero;
     o.e1 = p.dh_ext ? *reinterpret_cast<const float4*>(p.dh_ext + m * p.ld_ext + j) : zero;
     o.e2 = p.dh_ext2 ? *reinterpret_cast<const float4*>(p.dh_ext2 + m * p.ld_ext2 + j) : zero;
+    o.la[0] = p.lr_a ? p.lr_a[m * p.lr_lda] : 0.f;
+    o.la[1] = (p.lr_a && p.lr_k > 1) ? p.lr_a[m * p.lr_lda + 1] : 0.f;
     return o;
   }
   static __device__ __forceinline__ void cell_fast(const Params& p, int m, int j, int H, const f32x4& av, const Ops& o) {
     const float dzn[4] = {o.dz.x, o.dz.y, o.dz.z, o.dz.w}, e1[4] = {o.e1.x, o.e1.y, o.e1.z, o.e1.w}, e2[4] = {o.e2.x, o.e2.y, o.e2.z, o.e2.w};
     const float hp[4] = {o.hp.x, o.hp.y, o.hp.z, o.hp.w};
+    float lr[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.lr_a) {                                                           // dh += lr_a[m, 0:k] . lr_b[k, H], k <= 2
+      const float4 b0 = *reinterpret_cast<const float4*>(p.lr_b + j);
+      lr[0] = o.la[0] * b0.x; lr[1] = o.la[0] * b0.y; lr[2] = o.la[0] * b0.z; lr[3] = o.la[0] * b0.w;
+      if (p.lr_k > 1) {
+        const float4 b1 = *reinterpret_cast<const float4*>(p.lr_b + H + j);
+        lr[0] += o.la[1] * b1.x; lr[1] += o.la[1] * b1.y; lr[2] += o.la[1] * b1.z; lr[3] += o.la[1] * b1.w;
+      }
+    }
     float dr[4], dz[4], dn[4], dnr[4], dhz[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      const float dh = av[e] + dzn[e] + e1[e] + e2[e];
+      const float dh = av[e] + dzn[e] + e1[e] + e2[e] + lr[e];
       const float r = (float)o.g[0][e], z = (float)o.g[1][e], n = (float)o.g[2][e], hn = (float)o.g[3][e];
       dn[e] = dh * (1.0f - z) * (1.0f - n * n);
       dz[e] = dh * (hp[e] - n) * z * (1.0f - z);
@@ -425,7 +436,7 @@ static void launch_bwd_step(const GemmArgs& g, const GruBwdParams& ep, hipStream
   if (tile == 64) { hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 64, 64, SA, SB, FAST>), dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep); return; }
   const long blocks_big = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
   const long blocks_mid = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
-  if (blocks_big >= 192) {
+  if (blocks_big >= 192 && g.N > 64) {
     hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 128, 128, SA, SB, FAST>), dim3(cdiv(g.N, 128), cdiv(g.M, 128)), dim3(NTHREADS), 0, s, g, ep);
   } else if (blocks_mid >= 192) {
     hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 64, 64, SA, SB, FAST>), dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep);
@@ -504,7 +515,7 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
                          dhz + (step & 1) * MH, H, flags};
     const int pi = prof::want(2, M, H) ? prof::begin(s) : -1;
     static int nofast = getenv("PTV_NOFAST") ? 1 : 0;   // DBGTMP
-    const bool fast = !nofast && dbf && w16 && (flags & PTV_GRU_GATES_BF16) && !lr_a;      // all-bf16 storage, no low-rank addend
+    const bool fast = !nofast && dbf && w16 && (flags & PTV_GRU_GATES_BF16) && (!lr_a || lr_k <= 2);   // all-bf16 storage
     if (prec == PTV_PREC_BF16) {
       if (fast) launch_bwd_step<BF16, true, true, true>(g, ep, s);
       else if (dbf && w16) launch_bwd_step<BF16, true, true, false>(g, ep, s);
