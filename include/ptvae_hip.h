@@ -195,6 +195,24 @@ int ptv_dur_gru_fwd(int H, long M, const float* h0, long ld_h0, const float* w_h
                     void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Backward of the 5-step duration GRU (autograd of ptvae.py:353-367) in ONE kernel (bf16 gates, H = 64): dh
+ * stays in registers over the 5 steps, dgh_d . W_hh runs against W_hh^T resident in LDS, and the parameter
+ * gradients are accumulated in-kernel from LDS-transposed row tiles.  Writes dh0 [M,64] (gradient reaching
+ * dur_hid_linear's output) and one [256 x 80] fp32 partial per block into part[nblocks][ptv_dur_gru_bwd_part_size()]:
+ *   rows 0..191 = (dr, dz, dn*r) gate units, rows 192..255 = dn;  columns 0..63 = . h_d (dW_hh),
+ *   columns 64..66 = sums over the rows whose step input was <sos> / one-hot token 0 / token 1.
+ * ptv_dur_bwd_finalize folds the column-summed partial S [256 x 80] into the gradients of weight_hh, bias_hh,
+ * bias_ih, weight_ih [192, I] and the <sos> token [I] (all +=).
+ *   gates/hall as written by ptv_dur_gru_fwd; ddur [M, 10] = d loss / d est_dur; idx[d*idx_stride + row].
+ */
+int ptv_dur_gru_bwd_part_size(void);
+int ptv_dur_gru_bwd(int H, long M, const void* gates, long plane_g, long step_g, const float* hall, long plane_h,
+                    const float* ddur, long ld_dd, const float* w_hh, const float* w_out,
+                    const int* idx, long idx_stride, float* dh0, float* part, int nblocks, void* stream);
+int ptv_dur_bwd_finalize(const float* S, float* g_whh, float* g_bhh, float* g_bih, float* g_wih, float* g_sos,
+                         const float* w_ih, const float* sos, int I, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Free-running tokens.
  * ptv_note_token (ptvae.py:408-416 + pitch_dur_ind_to_note_token :328-334): per row pitch argmax (first
  *   maximal index), predicted token pred[r] = note_embedding(onehot(pitch) | 5 duration bits) with

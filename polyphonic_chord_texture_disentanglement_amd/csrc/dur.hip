@@ -20,7 +20,7 @@
 namespace ptv {
 
 constexpr int DH = 64;                 // hidden size
-constexpr int DLD = DH + 8;            // LDS row stride (bf16 elements): 144 B, conflict-free b128 reads
+constexpr int DLD = DH + 16;           // LDS row stride (bf16 elements): 160 B = 32 mod 64, conflict-free b128 fragment reads
 
 struct DurArgs {
   const float* h0; long ld_h0;         // [M, 64] initial state (dur_hid_linear output)

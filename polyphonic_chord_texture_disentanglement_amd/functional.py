@@ -9,7 +9,7 @@ Reference call sites are cited per function (paths are into /root/reference).
 """
 import torch
 
-from ._lib import call, prec_code, ptr, stream_ptr
+from ._lib import call, lib, prec_code, ptr, stream_ptr
 
 F32 = torch.float32
 BF16 = torch.bfloat16
@@ -617,26 +617,50 @@ class DecoderTFFn(torch.autograd.Function):
         # ---- duration GRU (5 steps) ----
         w_out = P['dur_out_linear.weight']
         w_hh_d, w_ih_d = W['dec_dur_gru.weight_hh_l0'], W['dec_dur_gru.weight_ih_l0']
-        dgi_d, dgh_d, dHD0 = gru_bwd(prec, HD, st['gates_d'], w_hh_d, lr=(ddur, 2, 10, 2, w_out))
+        fused = prec == 1 and Hd == 64 and FUSED_DUR and st['gates_d'].dtype == BF16
+        if fused:
+            # one kernel for the 5 BPTT steps; parameter gradients come back as per-block partials (csrc/dur_bwd.hip)
+            nblk = min(256, (M + 63) // 64)
+            psz = lib().ptv_dur_gru_bwd_part_size()
+            part = _empty(nblk, psz, dev=dev)
+            dHD0 = _empty(M, Hd, dev=dev)
+            gd = st['gates_d']
+            call('ptv_dur_gru_bwd', Hd, M, ptr(gd), M * Hd, 4 * M * Hd, ptr(HD), M * Hd, ptr(ddur), 10,
+                 ptr(P['dec_dur_gru.weight_hh_l0']), ptr(w_out), ptr(st['idx']), M, ptr(dHD0), ptr(part), nblk, stream_ptr())
 
-        def dur_wgrads():
-            for d in range(5):
-                wgrad('dur_out_linear.weight', ddur[:, 2 * d:2 * d + 2], HDo[d + 1])
-            bgrad('dur_out_linear.bias', ddur.view(M * 5, 2))
-            wgrad('dec_dur_gru.weight_hh_l0', dgh_d.view(5 * M, 3 * Hd), HDo[:5].view(5 * M, Hd))
-            bgrad('dec_dur_gru.bias_hh_l0', dgh_d.view(5 * M, 3 * Hd))
-            bgrad('dec_dur_gru.bias_ih_l0', dgi_d.view(5 * M, 3 * Hd))
-            cs0 = colsum(_zeros(1, 3 * Hd, dev=dev), dgi_d[0])                   # step 0: dense <sos> token
-            g = _gbuf(P['dec_dur_gru.weight_ih_l0'])
-            gemm(cs0, P['dur_sos_token'].view(1, -1), g, ta=True, tb=True, acc=True, prec=0, splitk=-1)
-            G['dur_sos_token'] = _gbuf(P['dur_sos_token'])
-            gemm(cs0, w_ih_d, G['dur_sos_token'].view(1, -1), tb=True, prec=0, splitk=-1)
-            sel = _zeros(2, 3 * Hd, dev=dev)                                     # steps 1..4: one-hot tokens {0,1}
-            for d in range(1, 5):
-                colsum(sel, dgi_d[d], sel=st['idx'][d - 1], groups=2)
-            gemm(sel, _eye2(dev), g[:, 0:2], ta=True, acc=True, prec=0, splitk=-1)
-            G['dec_dur_gru.weight_ih_l0'] = g
-        side(dur_wgrads, ddur, dgi_d, dgh_d)
+            def dur_wgrads():
+                for d in range(5):
+                    wgrad('dur_out_linear.weight', ddur[:, 2 * d:2 * d + 2], HDo[d + 1])
+                bgrad('dur_out_linear.bias', ddur.view(M * 5, 2))
+                S = colsum(_zeros(1, psz, dev=dev), part)
+                for name in ('dec_dur_gru.weight_hh_l0', 'dec_dur_gru.bias_hh_l0', 'dec_dur_gru.bias_ih_l0',
+                             'dec_dur_gru.weight_ih_l0', 'dur_sos_token'):
+                    G[name] = _gbuf(P[name])
+                call('ptv_dur_bwd_finalize', ptr(S), ptr(G['dec_dur_gru.weight_hh_l0']), ptr(G['dec_dur_gru.bias_hh_l0']),
+                     ptr(G['dec_dur_gru.bias_ih_l0']), ptr(G['dec_dur_gru.weight_ih_l0']), ptr(G['dur_sos_token']),
+                     ptr(P['dec_dur_gru.weight_ih_l0']), ptr(P['dur_sos_token']), P['dur_sos_token'].numel(), stream_ptr())
+            side(dur_wgrads, ddur, part)
+        else:
+            dgi_d, dgh_d, dHD0 = gru_bwd(prec, HD, st['gates_d'], w_hh_d, lr=(ddur, 2, 10, 2, w_out))
+
+            def dur_wgrads():
+                for d in range(5):
+                    wgrad('dur_out_linear.weight', ddur[:, 2 * d:2 * d + 2], HDo[d + 1])
+                bgrad('dur_out_linear.bias', ddur.view(M * 5, 2))
+                wgrad('dec_dur_gru.weight_hh_l0', dgh_d.view(5 * M, 3 * Hd), HDo[:5].view(5 * M, Hd))
+                bgrad('dec_dur_gru.bias_hh_l0', dgh_d.view(5 * M, 3 * Hd))
+                bgrad('dec_dur_gru.bias_ih_l0', dgi_d.view(5 * M, 3 * Hd))
+                cs0 = colsum(_zeros(1, 3 * Hd, dev=dev), dgi_d[0])                   # step 0: dense <sos> token
+                g = _gbuf(P['dec_dur_gru.weight_ih_l0'])
+                gemm(cs0, P['dur_sos_token'].view(1, -1), g, ta=True, tb=True, acc=True, prec=0, splitk=-1)
+                G['dur_sos_token'] = _gbuf(P['dur_sos_token'])
+                gemm(cs0, w_ih_d, G['dur_sos_token'].view(1, -1), tb=True, prec=0, splitk=-1)
+                sel = _zeros(2, 3 * Hd, dev=dev)                                     # steps 1..4: one-hot tokens {0,1}
+                for d in range(1, 5):
+                    colsum(sel, dgi_d[d], sel=st['idx'][d - 1], groups=2)
+                gemm(sel, _eye2(dev), g[:, 0:2], ta=True, acc=True, prec=0, splitk=-1)
+                G['dec_dur_gru.weight_ih_l0'] = g
+            side(dur_wgrads, ddur, dgi_d, dgh_d)
 
         # ---- dur_hid_linear([note_summary | est_pitch]) and pitch_out_linear ----
         w_dh, w_p = W['dur_hid_linear.weight'], W['pitch_out_linear.weight']

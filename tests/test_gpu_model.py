@@ -275,11 +275,15 @@ def test_graph_replayed_decode_equals_eager():
     assert np.array_equal(eager[::-1], again)
 
 
-def test_fused_duration_gru_kernel_equals_per_step_kernels():
-    """csrc/dur.hip (one kernel for the 5 duration steps) vs the per-step kernels, bf16 precision, full config."""
+@pytest.mark.parametrize('B', [4, 3])          # 480*B rows: whole 64-row tiles / a ragged last tile
+def test_fused_duration_gru_kernel_equals_per_step_kernels(B):
+    """csrc/dur.hip + dur_bwd.hip (one kernel each for the 5 duration steps, forward and backward) vs the per-step
+    kernels, bf16 precision, full config."""
     from polyphonic_chord_texture_disentanglement_amd import functional as F_
-    g = load_npz('full_tf1_b4.npz')
-    x, c, pr = synth_batch(int(g['B']), int(g['data_seed']))
+    g = dict(load_npz('full_tf1_b4.npz'))
+    x, c, pr = synth_batch(B, int(g['data_seed']))
+    for k in [k for k in g if k.startswith('eps_')]:
+        g[k] = g[k][:B]
     m = M.DisentangleVAE.init_model(torch.device(DEV))
     m.load_state_dict(full_params())
     m.to(DEV).set_precision('bf16')
@@ -289,8 +293,11 @@ def test_fused_duration_gru_kernel_equals_per_step_kernels():
         try:
             outs, losses = _run(m, g, x, c, pr)
             losses[0].backward()
-            res[fused] = (outs[1].detach().clone(), m.decoder.last_dur_idx.clone(), np.array([l.item() for l in losses]),
-                          m.decoder.dec_dur_gru.weight_hh_l0.grad.clone())
+            dec = m.decoder
+            grads = {n: p.grad.clone() for n, p in dec.named_parameters()
+                     if n.startswith(('dec_dur_gru.', 'dur_sos_token', 'dur_out_linear.', 'dur_hid_linear.', 'pitch_out_linear.'))}
+            res[fused] = (outs[1].detach().clone(), dec.last_dur_idx.clone(), np.array([l.item() for l in losses]), grads)
+            m.zero_grad()
         finally:
             F_.FUSED_DUR = True
     d_f, i_f, l_f, g_f = res[True]
@@ -298,7 +305,11 @@ def test_fused_duration_gru_kernel_equals_per_step_kernels():
     assert (i_f == i_s).float().mean() > 0.999                       # same argmax feedback decisions
     assert (d_f - d_s).abs().max() < 2e-2                            # bf16 operand rounding only
     np.testing.assert_allclose(l_f, l_s, rtol=0, atol=2e-3)
-    assert (g_f - g_s).abs().max() < 0.05 * g_s.abs().max()
+    # the fused backward (csrc/dur_bwd.hip: in-kernel parameter-gradient accumulation) against the per-step BPTT
+    # kernels + split-K products: every duration-GRU parameter and what sits upstream of dh0
+    assert len(g_f) >= 10
+    for n in g_s:
+        assert (g_f[n] - g_s[n]).abs().max() < 0.05 * g_s[n].abs().max() + 1e-6, n
 
 
 def test_fused_duration_gru_in_the_step_loop(monkeypatch):
