@@ -209,6 +209,39 @@ def _bgrad(b, a):
     return g
 
 
+def dur_bwd_fusable(prec, Hd, gates_d):
+    return prec == 1 and Hd == 64 and FUSED_DUR and gates_d.dtype == BF16
+
+
+def dur_bwd_fused(P, G, gates_d, idx, HD, HDo, ddur, wgrad, bgrad, side):
+    """backward of the 5-step duration GRU as one kernel (csrc/dur_bwd.hip) -> dHD0 [M, Hd]; the parameter gradients
+    come back as per-block partials that a column sum + ptv_dur_bwd_finalize fold into G on a side stream"""
+    _, M, Hd = HD.shape
+    dev = HD.device
+    nblk = min(256, (M + 63) // 64)
+    psz = lib().ptv_dur_gru_bwd_part_size()
+    part = _empty(nblk, psz, dev=dev)
+    dHD0 = _empty(M, Hd, dev=dev)
+    call('ptv_dur_gru_bwd', Hd, M, ptr(gates_d), M * Hd, 4 * M * Hd, ptr(HD), M * Hd, ptr(ddur), 10,
+         ptr(P['dec_dur_gru.weight_hh_l0']), ptr(P['dur_out_linear.weight']), ptr(idx), M, ptr(dHD0), ptr(part), nblk,
+         stream_ptr())
+
+    def dur_wgrads():
+        for d in range(5):
+            wgrad('dur_out_linear.weight', ddur[:, 2 * d:2 * d + 2], HDo[d + 1])
+        bgrad('dur_out_linear.bias', ddur.view(M * 5, 2))
+        S = colsum(_zeros(1, psz, dev=dev), part)
+        names = ('dec_dur_gru.weight_hh_l0', 'dec_dur_gru.bias_hh_l0', 'dec_dur_gru.bias_ih_l0', 'dec_dur_gru.weight_ih_l0',
+                 'dur_sos_token')
+        for name in names:
+            G[name] = _gbuf(P[name])
+        call('ptv_dur_bwd_finalize', ptr(S), *[ptr(G[n]) for n in names], ptr(P['dec_dur_gru.weight_ih_l0']),
+             ptr(P['dur_sos_token']), P['dur_sos_token'].numel(), stream_ptr())
+    side(dur_wgrads, ddur, part)
+    return dHD0
+
+
+
 def _as2d(t):
     return t.view(1, -1) if t.dim() == 1 else t
 
@@ -617,29 +650,8 @@ class DecoderTFFn(torch.autograd.Function):
         # ---- duration GRU (5 steps) ----
         w_out = P['dur_out_linear.weight']
         w_hh_d, w_ih_d = W['dec_dur_gru.weight_hh_l0'], W['dec_dur_gru.weight_ih_l0']
-        fused = prec == 1 and Hd == 64 and FUSED_DUR and st['gates_d'].dtype == BF16
-        if fused:
-            # one kernel for the 5 BPTT steps; parameter gradients come back as per-block partials (csrc/dur_bwd.hip)
-            nblk = min(256, (M + 63) // 64)
-            psz = lib().ptv_dur_gru_bwd_part_size()
-            part = _empty(nblk, psz, dev=dev)
-            dHD0 = _empty(M, Hd, dev=dev)
-            gd = st['gates_d']
-            call('ptv_dur_gru_bwd', Hd, M, ptr(gd), M * Hd, 4 * M * Hd, ptr(HD), M * Hd, ptr(ddur), 10,
-                 ptr(P['dec_dur_gru.weight_hh_l0']), ptr(w_out), ptr(st['idx']), M, ptr(dHD0), ptr(part), nblk, stream_ptr())
-
-            def dur_wgrads():
-                for d in range(5):
-                    wgrad('dur_out_linear.weight', ddur[:, 2 * d:2 * d + 2], HDo[d + 1])
-                bgrad('dur_out_linear.bias', ddur.view(M * 5, 2))
-                S = colsum(_zeros(1, psz, dev=dev), part)
-                for name in ('dec_dur_gru.weight_hh_l0', 'dec_dur_gru.bias_hh_l0', 'dec_dur_gru.bias_ih_l0',
-                             'dec_dur_gru.weight_ih_l0', 'dur_sos_token'):
-                    G[name] = _gbuf(P[name])
-                call('ptv_dur_bwd_finalize', ptr(S), ptr(G['dec_dur_gru.weight_hh_l0']), ptr(G['dec_dur_gru.bias_hh_l0']),
-                     ptr(G['dec_dur_gru.bias_ih_l0']), ptr(G['dec_dur_gru.weight_ih_l0']), ptr(G['dur_sos_token']),
-                     ptr(P['dec_dur_gru.weight_ih_l0']), ptr(P['dur_sos_token']), P['dur_sos_token'].numel(), stream_ptr())
-            side(dur_wgrads, ddur, part)
+        if dur_bwd_fusable(prec, Hd, st['gates_d']):
+            dHD0 = dur_bwd_fused(P, G, st['gates_d'], st['idx'], HD, HDo, ddur, wgrad, bgrad, side)
         else:
             dgi_d, dgh_d, dHD0 = gru_bwd(prec, HD, st['gates_d'], w_hh_d, lr=(ddur, 2, 10, 2, w_out))
 

@@ -211,7 +211,9 @@ class DecoderStepFn(torch.autograd.Function):
         # ---- duration GRU, heads, notes GRU: identical to the teacher-forced path (batched over all rows)
         w_out = P['dur_out_linear.weight']
         w_hh_d, w_ih_d = P['dec_dur_gru.weight_hh_l0'], P['dec_dur_gru.weight_ih_l0']
-        dgi_d, dgh_d, dHD0 = gru_bwd(prec, HD, st['gates_d'], w_hh_d, lr=(ddur, 2, 10, 2, w_out))
+        fused_dur = F_.dur_bwd_fusable(prec, Hd, st['gates_d'])
+        if not fused_dur:
+            dgi_d, dgh_d, dHD0 = gru_bwd(prec, HD, st['gates_d'], w_hh_d, lr=(ddur, 2, 10, 2, w_out))
 
         def dur_wgrads():
             for d in range(5):
@@ -230,7 +232,10 @@ class DecoderStepFn(torch.autograd.Function):
                 colsum(sel, dgi_d[d], sel=st['idx'][d - 1], groups=2)
             gemm(sel, _eye2(dev), g[:, 0:2], ta=True, acc=True, prec=0, splitk=-1)
             G['dec_dur_gru.weight_ih_l0'] = g
-        side(dur_wgrads, ddur, dgi_d, dgh_d)
+        if fused_dur:
+            dHD0 = F_.dur_bwd_fused(P, G, st['gates_d'], st['idx'], HD, HD, ddur, wgrad, bgrad, side)
+        else:
+            side(dur_wgrads, ddur, dgi_d, dgh_d)
 
         w_dh, w_p = P['dur_hid_linear.weight'], P['pitch_out_linear.weight']
         dNSUM = gemm(dHD0, w_dh[:, :Hn], tb=True, prec=prec)
