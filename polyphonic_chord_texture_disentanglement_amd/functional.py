@@ -44,6 +44,24 @@ def _zeros(*shape, dev):
     return torch.zeros(*shape, device=dev, dtype=F32)
 
 
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def _row_dense(t):
+    """t [..., C] is a [rows, C] matrix with one constant row stride >= C (contiguous, or rows padded)"""
+    if t.dim() < 2 or t.stride(-1) != 1 or t.stride(-2) < t.shape[-1]:
+        return False
+    return all(t.stride(i) == t.stride(i + 1) * t.shape[i + 1] for i in range(t.dim() - 2))
+
+
+def _rows2d(t):
+    """[..., C] -> [rows, C] view when row-dense (keeps a padded row stride), else a contiguous copy"""
+    if _row_dense(t):
+        return t.as_strided((t.numel() // t.shape[-1], t.shape[-1]), (t.stride(-2), 1), t.storage_offset())
+    return t.contiguous().view(-1, t.shape[-1])
+
+
 def _ld(t):
     assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
     return t.stride(0)
@@ -566,7 +584,10 @@ class DecoderTFFn(torch.autograd.Function):
 
         # --- pitch head + duration GRU initial state (ptvae.py:343-352)
         M = 15 * R
-        pitch = gemm(NSUM_op, W['pitch_out_linear.weight'], bias=P['pitch_out_linear.bias'], prec=prec)   # [M,130]
+        # logits rows padded to a multiple of 8 floats: 130-wide rows would put every row of this tensor (an operand of
+        # four more products) off the 16-byte grid and force element-wise loads / stores
+        pitch = _empty(M, _pad8(NP), dev=dev)[:, :NP]
+        gemm(NSUM_op, W['pitch_out_linear.weight'], pitch, bias=P['pitch_out_linear.bias'], prec=prec)          # [M,130]
         w_dh = W['dur_hid_linear.weight']
         HD = _empty(6, M, Hd, dev=dev)
         HD16 = _hall16(prec, 6, M, Hd, dev)
@@ -641,11 +662,11 @@ class DecoderTFFn(torch.autograd.Function):
             G[name] = _bgrad(P[name], a)
 
         ddur = (ddur.contiguous() if ddur is not None else _zeros(M, 5, 2, dev=dev)).view(M, 10)
-        dP = _empty(M, NP, dev=dev)
+        dP = _empty(M, _pad8(NP), dev=dev)[:, :NP]               # row-padded like the logits
         if dpitch is not None:
-            copy2d(dP, dpitch.contiguous().view(M, NP))
+            copy2d(dP, _rows2d(dpitch))
         else:
-            dP.zero_()
+            copy2d(dP, _zeros(1, NP, dev=dev), lds=0)
 
         # ---- duration GRU (5 steps) ----
         w_out = P['dur_out_linear.weight']
@@ -846,7 +867,7 @@ def _mem_order(ts, perms):
     EVERY tensor is a permuted view of a contiguous step-major buffer (what the decoders return);
     otherwise all are made batch-major contiguous."""
     tp = [t.permute(*p) for t, p in zip(ts, perms)]
-    if all(t.is_contiguous() for t in tp):
+    if all(t.is_contiguous() or _row_dense(t) for t in tp):
         return tp, True
     return [t.contiguous() for t in ts], False
 
@@ -861,7 +882,7 @@ def _pianotree_ce_fwd(pitch, dur, x, sums, st):
     dur_t = torch.empty(rows * 5, device=dev, dtype=torch.int32)
     counts = torch.zeros(2, device=dev, dtype=torch.int32)
     call('ptv_pianotree_targets', ptr(x), B, int(sm), ptr(pitch_t), ptr(dur_t), ptr(counts), st)
-    call('ptv_ce_fwd', ptr(pitch_m), NP, ptr(pitch_t), rows, NP, 130, ptr(sums[0:]), st)
+    call('ptv_ce_fwd', ptr(pitch_m), pitch_m.stride(-2), ptr(pitch_t), rows, NP, 130, ptr(sums[0:]), st)
     call('ptv_ce_fwd', ptr(dur_m), 2, ptr(dur_t), rows * 5, 2, 2, ptr(sums[1:]), st)
     return pitch_m, dur_m, sm, pitch_t, dur_t, counts
 
@@ -869,9 +890,10 @@ def _pianotree_ce_fwd(pitch, dur, x, sums, st):
 def _pianotree_ce_bwd(pitch_m, dur_m, sm, pitch_t, dur_t, gs, st):
     NP = pitch_m.shape[-1]
     rows = pitch_t.numel()
-    dpitch = torch.empty_like(pitch_m)
+    ld = pitch_m.stride(-2)                                  # gradient in the logits' (possibly row-padded) layout
+    dpitch = torch.empty(rows, ld, device=pitch_m.device)[:, :NP].as_strided(pitch_m.shape, pitch_m.stride())
     ddur = torch.empty_like(dur_m)
-    call('ptv_ce_bwd', ptr(pitch_m), NP, ptr(pitch_t), rows, NP, 130, ptr(gs[0:]), ptr(dpitch), NP, st)
+    call('ptv_ce_bwd', ptr(pitch_m), ld, ptr(pitch_t), rows, NP, 130, ptr(gs[0:]), ptr(dpitch), ld, st)
     call('ptv_ce_bwd', ptr(dur_m), 2, ptr(dur_t), rows * 5, 2, 2, ptr(gs[1:]), ptr(ddur), 2, st)
     if sm:
         dpitch, ddur = dpitch.permute(*_PERM[4]), ddur.permute(*_PERM[5])

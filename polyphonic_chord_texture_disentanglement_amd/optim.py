@@ -78,6 +78,8 @@ def weight_shadow(p):
     if opt is None or ent[2] != p.numel() or not p.is_contiguous():
         return None
     off = ent[1]
+    if off in opt._row_padded:                       # rows not a multiple of 8 elements: separate row-padded copy
+        return opt._row_padded[off][1][:, :p.shape[1]]
     return opt.flat_p16[off:off + p.numel()].view(p.shape)
 
 
@@ -136,6 +138,10 @@ class FusedClipAdam(torch.optim.Optimizer):
         self.flat_pT16 = torch.empty(self.arena.total, device=ps[0].device, dtype=torch.bfloat16)
         self._mats = [(p, o) for p, o in zip(ps, self.arena.offsets) if p.dim() == 2 and p.shape[0] % 8 == 0 and p.shape[1] >= 8]
         self._mat_offsets = {o for _, o in self._mats}
+        # matrices whose rows are not a multiple of 8 elements (dur_hid_linear [64, 642]): a bf16 view of the flat
+        # buffer would start every row off the 16-byte grid, so they get their own copy with rows padded to 8
+        self._row_padded = {o: (p, torch.zeros(p.shape[0], (p.shape[1] + 7) // 8 * 8, device=p.device, dtype=torch.bfloat16))
+                            for p, o in zip(ps, self.arena.offsets) if p.dim() == 2 and p.shape[1] % 8 != 0 and p.shape[1] >= 64}
         for p, o in zip(ps, self.arena.offsets):
             _SHADOW_OF[p.data_ptr()] = (weakref.ref(self), o, p.numel())
         self.refresh_shadow()
@@ -150,6 +156,8 @@ class FusedClipAdam(torch.optim.Optimizer):
         call('ptv_cast_bf16', ptr(self.flat_p), ptr(self.flat_p16), self.arena.total, st)
         for p, o in self._mats:                                  # transposed copies of the matrices
             call('ptv_transpose_cast_bf16', ptr(p), ptr(self.flat_pT16[o:]), p.shape[0], p.shape[1], st)
+        for p, buf in self._row_padded.values():
+            buf[:, :p.shape[1]].copy_(p.data)
 
     def zero_grad(self, set_to_none=True):
         for p in self.arena.params:
