@@ -1,6 +1,7 @@
 // gemm.hip -- plain dense products on the MFMA core: Linear forward (NT), dX (NN), dW (TN, split-K).
 // C-ABI entry: ptv_gemm (include/ptvae_hip.h).
 #include <type_traits>
+#include <cstdlib>
 #include "common.hpp"
 #include "gemm_core.hpp"
 #include "../../include/ptvae_hip.h"
@@ -34,6 +35,20 @@ struct EpiPlain {
       using RS = RowStage<1, FN * 16>;
       float* st = RS::base(lds);
       const int u = RS::unit();
+      // interior wave tiles with aligned C: one of four straight-line epilogues (the generic cell below carries
+      // every runtime option and costs ~100 instructions per cell -- for short-K products that, not memory,
+      // set the block lifetime)
+      const bool bias_ok = !use_bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
+      if (vec && bias_ok && p.act == 0 && m0 + 16 * FM <= M && n0 + 16 * FN <= N && !(bf && (p.accumulate || p.atomic))) {
+        const int mode = p.atomic ? 3 : (p.accumulate ? 2 : (bf ? 1 : 0));
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (use_bias) b4 = *reinterpret_cast<const float4*>(p.bias + n0 + u);
+        if (mode == 0) fast_rows<FM, FN, 0>(p, acc, st, m0, n0 + u, b4);
+        else if (mode == 1) fast_rows<FM, FN, 1>(p, acc, st, m0, n0 + u, b4);
+        else if (mode == 2) fast_rows<FM, FN, 2>(p, acc, st, m0, n0 + u, b4);
+        else fast_rows<FM, FN, 3>(p, acc, st, m0, n0 + u, b4);
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < FM; i++) {
         RS::put(st, acc[i]);
@@ -53,6 +68,35 @@ struct EpiPlain {
           const int m = m0 + i * 16 + (lane & 15), n = n0 + j * 16 + (lane >> 4) * 4;
           if (m < M && n < N) cell(p, m, n, N, acc[i][j], bf, vec, use_bias);
         }
+    }
+  }
+  // MODE 0: store fp32, 1: store bf16, 2: C += (fp32), 3: atomicAdd (fp32 split-K partials)
+  template <int FM, int FN, int MODE>
+  static __device__ __forceinline__ void fast_rows(const Params& p, f32x4 (&acc)[FM][FN], float* st, int m0, int n, const float4& b4) {
+    using RS = RowStage<1, FN * 16>;
+    const int u = RS::unit();
+#pragma unroll
+    for (int i = 0; i < FM; i++) {
+      RS::put(st, acc[i]);
+#pragma unroll
+      for (int c = 0; c < RS::PASSES; c++) {
+        const int row = RS::row(c);
+        const f32x4 a = RS::get(st, row, u);
+        const long off = (long)(m0 + i * 16 + row) * p.ldc + n;
+        float v0 = p.alpha * a[0] + b4.x, v1 = p.alpha * a[1] + b4.y, v2 = p.alpha * a[2] + b4.z, v3 = p.alpha * a[3] + b4.w;
+        if constexpr (MODE == 1) {
+          bf16x4 o; o[0] = (__bf16)v0; o[1] = (__bf16)v1; o[2] = (__bf16)v2; o[3] = (__bf16)v3;
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.C) + off) = o;
+        } else if constexpr (MODE == 3) {
+          float* cp = reinterpret_cast<float*>(p.C) + off;
+          atomicAdd(cp, v0); atomicAdd(cp + 1, v1); atomicAdd(cp + 2, v2); atomicAdd(cp + 3, v3);
+        } else {
+          float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + off);
+          if constexpr (MODE == 2) { const float4 q = *cp; v0 += q.x; v1 += q.y; v2 += q.z; v3 += q.w; }
+          *cp = make_float4(v0, v1, v2, v3);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
   static __device__ __forceinline__ void cell(const Params& p, int m, int n, int N, const f32x4& a, bool bf, bool vec, bool use_bias) {
@@ -102,7 +146,8 @@ static int gemm_dispatch(int transA, int transB, GemmArgs g, EpiPlain::Params ep
   // thresholds / block targets below are the measured optima of scripts/bench_tn.py on MI355X.
   const long blocks_big = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
   const bool deepk = transA && g.K >= 4096;
-  const bool big = blocks_big >= 192 || (deepk && g.M >= 256 && g.N >= 256);
+  static int force = getenv("PTV_GEMM_TILE") ? atoi(getenv("PTV_GEMM_TILE")) : 0;   // DBGTMP
+  const bool big = force ? force == 128 : (blocks_big >= 192 || (deepk && g.M >= 256 && g.N >= 256));
   const int bm = big ? 128 : 64;
   long blocks = (long)cdiv(g.M, bm) * cdiv(g.N, bm);
   int splits = 1;
