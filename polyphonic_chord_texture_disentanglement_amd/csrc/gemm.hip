@@ -122,9 +122,18 @@ struct EpiPlain {
   }
 };
 
+#ifndef PTV_PF_TN
+#define PTV_PF_TN 3
+#endif
+#ifndef PTV_PF_NT
+#define PTV_PF_NT 2
+#endif
+// register prefetch depth of the 128x128 tile: bf16 sources stage 16 B per thread per k row, cheap enough to go deeper
+#define PLAIN_PF_BIG(KA, KB, SA, SB) ((SA) && (SB) ? ((KA) ? PTV_PF_TN : PTV_PF_NT) : 1)
+
 template <class CT, int BM, int BN, int WGM, int WGN, bool KA, bool KB, bool SA, bool SB>
 __global__ __launch_bounds__(NTHREADS) void gemm_plain_kernel(GemmArgs g, EpiPlain::Params ep) {
-  gemm_body<CT, BM, BN, WGM, WGN, 1, KA, KB, EpiPlain, SA, SB, (BM * BN <= 64 * 64 ? 2 : 1)>(g, ep);
+  gemm_body<CT, BM, BN, WGM, WGN, 1, KA, KB, EpiPlain, SA, SB, (BM * BN <= 64 * 64 ? 2 : PLAIN_PF_BIG(KA, KB, SA, SB))>(g, ep);
 }
 
 __global__ void fill_rows_kernel(float* C, long ldc, int M, int N, float v) {
