@@ -203,10 +203,10 @@ int ptv_dur_gru_fwd(int H, long M, const float* h0, long ld_h0, const float* w_h
  *   columns 64..66 = sums over the rows whose step input was <sos> / one-hot token 0 / token 1.
  * ptv_dur_bwd_finalize folds the column-summed partial S [256 x 80] into the gradients of weight_hh, bias_hh,
  * bias_ih, weight_ih [192, I] and the <sos> token [I] (all +=).
- *   gates/hall as written by ptv_dur_gru_fwd; ddur [M, 10] = d loss / d est_dur; idx[d*idx_stride + row].
+ *   gates/hall as written by ptv_dur_gru_fwd (hall: the fp32 states or, h_bf16 = 1, their bf16 copies hall16); ddur [M, 10] = d loss / d est_dur; idx[d*idx_stride + row].
  */
 int ptv_dur_gru_bwd_part_size(void);
-int ptv_dur_gru_bwd(int H, long M, const void* gates, long plane_g, long step_g, const float* hall, long plane_h,
+int ptv_dur_gru_bwd(int H, long M, const void* gates, long plane_g, long step_g, const void* hall, long plane_h, int h_bf16,
                     const float* ddur, long ld_dd, const float* w_hh, const float* w_out,
                     const int* idx, long idx_stride, float* dh0, float* part, int nblocks, void* stream);
 int ptv_dur_bwd_finalize(const float* S, float* g_whh, float* g_bhh, float* g_bih, float* g_wih, float* g_sos,

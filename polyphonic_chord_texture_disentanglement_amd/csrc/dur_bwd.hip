@@ -30,7 +30,7 @@ constexpr int PART = 256 * PART_COLS;   // floats per block partial
 
 struct DurBwdArgs {
   const __bf16* gates; long plane_g, step_g;     // gate plane p of step d at gates + d*step_g + p*plane_g (+ row*64 + unit)
-  const float* hall; long plane_h;               // h_d at hall + d*plane_h (+ row*64 + unit), d = 0..5
+  const void* hall; long plane_h; int h_bf16;    // h_d at hall + d*plane_h (+ row*64 + unit), d = 0..4; fp32 or bf16
   const float* ddur; long ld_dd;                 // [M, 10]: d loss / d est_dur
   const float* w_hh; const float* w_out;         // [192, 64], [2, 64]
   const int* idx; long idx_stride;               // idx[d*idx_stride + row]: token fed to step d+1
@@ -41,17 +41,28 @@ struct DurBwdArgs {
 
 struct DurOps { bf16x4 g[4][4]; float4 hp[4]; };   // [plane][fragment]
 
+template <bool HB>
 __device__ __forceinline__ void dur_load(const DurBwdArgs& a, int d, long row, int ug, DurOps& o) {
   const __bf16* gp = a.gates + d * a.step_g + row * BH + ug;
 #pragma unroll
   for (int p = 0; p < 4; p++)
 #pragma unroll
     for (int f = 0; f < 4; f++) o.g[p][f] = *reinterpret_cast<const bf16x4*>(gp + p * a.plane_g + f * 16);
-  const float* hp = a.hall + d * a.plane_h + row * BH + ug;
+  if constexpr (HB) {
+    const __bf16* hp = reinterpret_cast<const __bf16*>(a.hall) + d * a.plane_h + row * BH + ug;
 #pragma unroll
-  for (int f = 0; f < 4; f++) o.hp[f] = *reinterpret_cast<const float4*>(hp + f * 16);
+    for (int f = 0; f < 4; f++) {
+      const bf16x4 v = *reinterpret_cast<const bf16x4*>(hp + f * 16);
+      o.hp[f] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    }
+  } else {
+    const float* hp = reinterpret_cast<const float*>(a.hall) + d * a.plane_h + row * BH + ug;
+#pragma unroll
+    for (int f = 0; f < 4; f++) o.hp[f] = *reinterpret_cast<const float4*>(hp + f * 16);
+  }
 }
 
+template <bool HB>
 __global__ __launch_bounds__(256, 1) void dur_gru_bwd_kernel(DurBwdArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 WT[BH * WLD];          // W_hh^T: WT[unit][gate-unit]
   __shared__ __attribute__((aligned(16))) __bf16 DG[4][16 * WLD];       // per-wave dgh rows [16][192]
@@ -94,11 +105,11 @@ __global__ __launch_bounds__(256, 1) void dur_gru_bwd_kernel(DurBwdArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; e++) carry[f][e] = 0.f;
     DurOps ops[2];
-    dur_load(a, 4, rowc, ug, ops[0]);
+    dur_load<HB>(a, 4, rowc, ug, ops[0]);
 #pragma unroll
     for (int d = 4; d >= 0; d--) {
       const DurOps& o = ops[(4 - d) & 1];
-      if (d > 0) dur_load(a, d - 1, rowc, ug, ops[(5 - d) & 1]);       // next step's operands in flight under this one
+      if (d > 0) dur_load<HB>(a, d - 1, rowc, ug, ops[(5 - d) & 1]);       // next step's operands in flight under this one
       float dhz[4][4];
 #pragma unroll
       for (int f = 0; f < 4; f++) {
@@ -206,14 +217,15 @@ using namespace ptv;
 
 extern "C" int ptv_dur_gru_bwd_part_size(void) { return PART; }
 
-extern "C" int ptv_dur_gru_bwd(int H, long M, const void* gates, long plane_g, long step_g, const float* hall, long plane_h,
+extern "C" int ptv_dur_gru_bwd(int H, long M, const void* gates, long plane_g, long step_g, const void* hall, long plane_h, int h_bf16,
                                const float* ddur, long ld_dd, const float* w_hh, const float* w_out,
                                const int* idx, long idx_stride, float* dh0, float* part, int nblocks, void* stream) {
   if (H != BH) return PTV_ERR_ARG;
   if (M <= 0 || !gates || !hall || !ddur || !w_hh || !w_out || !idx || !dh0 || !part || nblocks <= 0) return PTV_ERR_ARG;
   if ((plane_g & 3) || (step_g & 3) || (plane_h & 3) || (ld_dd & 1)) return PTV_ERR_ARG;
-  DurBwdArgs a{(const __bf16*)gates, plane_g, step_g, hall, plane_h, ddur, ld_dd, w_hh, w_out, idx, idx_stride, dh0, part, M};
-  hipLaunchKernelGGL(dur_gru_bwd_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, a);
+  DurBwdArgs a{(const __bf16*)gates, plane_g, step_g, hall, plane_h, h_bf16, ddur, ld_dd, w_hh, w_out, idx, idx_stride, dh0, part, M};
+  if (h_bf16) hipLaunchKernelGGL(dur_gru_bwd_kernel<true>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(dur_gru_bwd_kernel<false>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, a);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

@@ -1,7 +1,6 @@
 // gemm.hip -- plain dense products on the MFMA core: Linear forward (NT), dX (NN), dW (TN, split-K).
 // C-ABI entry: ptv_gemm (include/ptvae_hip.h).
 #include <type_traits>
-#include <cstdlib>
 #include "common.hpp"
 #include "gemm_core.hpp"
 #include "../../include/ptvae_hip.h"
@@ -155,8 +154,7 @@ static int gemm_dispatch(int transA, int transB, GemmArgs g, EpiPlain::Params ep
   // thresholds / block targets below are the measured optima of scripts/bench_tn.py on MI355X.
   const long blocks_big = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
   const bool deepk = transA && g.K >= 4096;
-  static int force = getenv("PTV_GEMM_TILE") ? atoi(getenv("PTV_GEMM_TILE")) : 0;   // DBGTMP
-  const bool big = force ? force == 128 : (blocks_big >= 192 || (deepk && g.M >= 256 && g.N >= 256));
+  const bool big = blocks_big >= 192 || (deepk && g.M >= 256 && g.N >= 256);
   const int bm = big ? 128 : 64;
   long blocks = (long)cdiv(g.M, bm) * cdiv(g.N, bm);
   int splits = 1;

@@ -6,7 +6,6 @@
 //   r = s(gi_r + W_hr h + b_hr)  z = s(gi_z + W_hz h + b_hz)  n = tanh(gi_n + r*(W_hn h + b_hn))
 //   h' = (1-z)*n + z*h            (gi = W_i x + b_i is produced by a batched input-side GEMM)
 #include <type_traits>
-#include <cstdlib>
 #include "common.hpp"
 #include "gemm_core.hpp"
 #include "../../include/ptvae_hip.h"
@@ -432,8 +431,6 @@ static void cast_rows_bf16(const float* src, long lds, void* dst, long rows, int
 
 template <class CT, bool SA, bool SB, bool FAST>
 static void launch_bwd_step(const GemmArgs& g, const GruBwdParams& ep, hipStream_t s) {
-  static int tile = getenv("PTV_BWD_TILE") ? atoi(getenv("PTV_BWD_TILE")) : 0;   // DBGTMP
-  if (tile == 64) { hipLaunchKernelGGL((gru_bwd_step_kernel<CT, 64, 64, SA, SB, FAST>), dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(NTHREADS), 0, s, g, ep); return; }
   const long blocks_big = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
   const long blocks_mid = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
   if (blocks_big >= 192 && g.N > 64) {
@@ -514,8 +511,7 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
                          (char*)dgi + (long)t * M3H * esz_d, (char*)dgh + (long)step * M3H * esz_d,
                          dhz + (step & 1) * MH, H, flags};
     const int pi = prof::want(2, M, H) ? prof::begin(s) : -1;
-    static int nofast = getenv("PTV_NOFAST") ? 1 : 0;   // DBGTMP
-    const bool fast = !nofast && dbf && w16 && (flags & PTV_GRU_GATES_BF16) && (!lr_a || lr_k <= 2);   // all-bf16 storage
+    const bool fast = dbf && w16 && (flags & PTV_GRU_GATES_BF16) && (!lr_a || lr_k <= 2);   // all-bf16 storage
     if (prec == PTV_PREC_BF16) {
       if (fast) launch_bwd_step<BF16, true, true, true>(g, ep, s);
       else if (dbf && w16) launch_bwd_step<BF16, true, true, false>(g, ep, s);

@@ -240,7 +240,8 @@ def dur_bwd_fused(P, G, gates_d, idx, HD, HDo, ddur, wgrad, bgrad, side):
     psz = lib().ptv_dur_gru_bwd_part_size()
     part = _empty(nblk, psz, dev=dev)
     dHD0 = _empty(M, Hd, dev=dev)
-    call('ptv_dur_gru_bwd', Hd, M, ptr(gates_d), M * Hd, 4 * M * Hd, ptr(HD), M * Hd, ptr(ddur), 10,
+    hsrc = HDo if HDo.dtype == BF16 else HD                 # bf16 state copies when the forward kept them (half the reads)
+    call('ptv_dur_gru_bwd', Hd, M, ptr(gates_d), M * Hd, 4 * M * Hd, ptr(hsrc), M * Hd, int(hsrc.dtype == BF16), ptr(ddur), 10,
          ptr(P['dec_dur_gru.weight_hh_l0']), ptr(P['dur_out_linear.weight']), ptr(idx), M, ptr(dHD0), ptr(part), nblk,
          stream_ptr())
 
@@ -606,7 +607,8 @@ class DecoderTFFn(torch.autograd.Function):
             # one kernel for the 5 steps + output layer + argmax feedback (dur.hip)
             call('ptv_dur_gru_fwd', Hd, M, ptr(HD[0]), Hd, ptr(P['dec_dur_gru.weight_hh_l0']), ptr(P['dec_dur_gru.bias_hh_l0']),
                  ptr(tab0), ptr(tab), ptr(P['dur_out_linear.weight']), ptr(P['dur_out_linear.bias']),
-                 ptr(HD[1]), M * Hd, ptr(HD16[1]) if HD16 is not None else None, ptr(gates_d), M * Hd, 4 * M * Hd, _bf(gates_d),
+                 None if HD16 is not None else ptr(HD[1]), M * Hd,          # fp32 states stay in registers when the bf16
+                 ptr(HD16[1]) if HD16 is not None else None, ptr(gates_d), M * Hd, 4 * M * Hd, _bf(gates_d),   # copies exist
                  ptr(dur2), 10, ptr(idx), M, ptr(force_dur) if force_dur is not None else None, M, stream_ptr())
             if HD16 is not None:
                 call('ptv_cast_bf16', ptr(HD[0]), ptr(HD16[0]), M * Hd, stream_ptr())       # slot 0 of the shadow
@@ -622,7 +624,8 @@ class DecoderTFFn(torch.autograd.Function):
         S.save_for_backward(z, emb, *params)
         S.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in, NS16=NS16, HN16=HN16,
                     HD16=HD16,
-                    TOKS=TOKS, gates_t=gates_t, HN=HN, gates_n=gates_n, pitch=pitch, HD=HD, gates_d=gates_d, idx=idx)
+                    TOKS=TOKS, gates_t=gates_t, HN=HN, gates_n=gates_n, pitch=pitch, HD=HD, gates_d=gates_d, idx=idx,
+                    dur16_only=bool(prec == 1 and Hd == 64 and FUSED_DUR and HD16 is not None))   # HD[1:] never written
         S.mark_non_differentiable(idx)
         return pitch.view(15, 32, B, NP), dur, idx
 
@@ -671,7 +674,7 @@ class DecoderTFFn(torch.autograd.Function):
         # ---- duration GRU (5 steps) ----
         w_out = P['dur_out_linear.weight']
         w_hh_d, w_ih_d = W['dec_dur_gru.weight_hh_l0'], W['dec_dur_gru.weight_ih_l0']
-        if dur_bwd_fusable(prec, Hd, st['gates_d']):
+        if dur_bwd_fusable(prec, Hd, st['gates_d']) or st['dur16_only']:
             dHD0 = dur_bwd_fused(P, G, st['gates_d'], st['idx'], HD, HDo, ddur, wgrad, bgrad, side)
         else:
             dgi_d, dgh_d, dHD0 = gru_bwd(prec, HD, st['gates_d'], w_hh_d, lr=(ddur, 2, 10, 2, w_out))
