@@ -152,6 +152,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i)
+    t_host = time.perf_counter() - t0                      # all K steps enqueued (host side of the pipeline)
     barrier()
     dt = time.perf_counter() - t0
     lib.ptv_prof_enable(0)
@@ -207,7 +208,7 @@ def main():
                'config': {'workload': workload,
                           'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world},
                'step_tflops': round(value * GFLOP_PER_SAMPLE_TRAIN / 1e3, 2), 'final_loss': round(loss, 4),
-               'roofline': roof}
+               'host_enqueue_ms_per_step': round(t_host / args.steps * 1e3, 3), 'roofline': roof}
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res), flush=True)

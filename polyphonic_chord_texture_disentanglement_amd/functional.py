@@ -212,6 +212,32 @@ class Side:
         self.keep.clear()
         self.used = False
 
+    def defer(self):
+        """join at the END of the running backward pass instead of now: for side work that only produces parameter
+        gradients (nothing later in the backward reads them), so it can overlap with whatever the autograd engine
+        runs next -- the decoder's weight-gradient products then run under the encoders' latency-bound BPTT chains.
+        Outside a backward pass this is join()."""
+        if not self.used:
+            return self.join()
+        try:
+            if not _DEFERRED:
+                torch.autograd.Variable._execution_engine.queue_callback(_join_deferred)
+        except RuntimeError:                      # not inside the autograd engine
+            return self.join()
+        _DEFERRED.append((self.s, list(self.keep)))
+        self.keep.clear()
+        self.used = False
+
+
+_DEFERRED = []
+
+
+def _join_deferred():
+    cur = torch.cuda.current_stream()
+    for s, _keep in _DEFERRED:
+        cur.wait_stream(s)
+    _DEFERRED.clear()
+
 
 def _gbuf(p):
     """zero-initialised gradient buffer for parameter p (weight-gradient kernels accumulate into it):
@@ -759,7 +785,7 @@ class DecoderTFFn(torch.autograd.Function):
             bgrad('z2dec_in_linear.bias', dz_in)
         side(time_wgrads, dgi_t, dgh_t, dZG, dTOKS, dzhid, dz_in, dNS)
 
-        side.join()
+        side.defer()                             # parameter gradients only: joined when the backward pass ends
         return (dz, demb.view(16, 32, B, E), dxs, None, None) + tuple(G[n] for n in DEC_PARAM_NAMES)
 
 
