@@ -358,6 +358,9 @@ struct EpiGruBwdT {
 
 template <class CT, int BM, int BJ, bool SA, bool SB, int MODE>
 __global__ __launch_bounds__(NTHREADS, 2) void gru_fwd_step_kernel(GemmArgs g, GruFwdParams ep) {
+  // the recurrent steps are the serial chain of the step: their waves outrank the weight-gradient products that
+  // share the CUs from sibling streams (wave priority only orders instruction issue inside a CU)
+  __builtin_amdgcn_s_setprio(3);
   gemm_body<CT, BM, BJ, 2, 2, 3, false, false, EpiGruFwdT<MODE>, SA, SB, (BM * BJ <= 64 * 32 ? 3 : 1)>(g, ep);
 }
 
@@ -370,6 +373,7 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, long lds, __bf16
 // otherwise the fp32 parameter W_hh [3H, H] read K-major
 template <class CT, int BM, int BN, bool SA, bool SB, bool FAST>
 __global__ __launch_bounds__(NTHREADS) void gru_bwd_step_kernel(GemmArgs g, GruBwdParams ep) {
+  __builtin_amdgcn_s_setprio(3);
   gemm_body<CT, BM, BN, 2, 2, 1, false, !SB, EpiGruBwdT<FAST>, SA, SB, (BM * BN <= 64 * 32 ? 4 : (BM * BN <= 64 * 64 ? 3 : 2))>(g, ep);
 }
 
