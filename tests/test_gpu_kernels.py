@@ -117,3 +117,53 @@ def test_gru_seq_fwd_bwd(prec, M, H, I, T, masked, reverse):
     assert (dwih.cpu() - w_ih.grad).abs().max() < gtol * max(1.0, w_ih.grad.abs().max().item())
     assert (dgi.float().sum((0, 1)).cpu() - b_ih.grad).abs().max() < gtol * max(1.0, b_ih.grad.abs().max().item())
     assert (dgh.float().sum((0, 1)).cpu() - b_hh.grad).abs().max() < gtol * max(1.0, b_hh.grad.abs().max().item())
+
+
+@pytest.mark.parametrize('M,H,T,use_gi2', [(1000, 128, 4, True), (4096, 512, 2, True), (4100, 512, 2, False), (512, 1024, 3, True)])
+def test_gru_seq_bf16_storage_fast_path(M, H, T, use_gi2):
+    """the bf16-storage fast path of the step kernels (bf16 gi / gi2 / gates / state and weight shadows: prefetching
+    row-staged epilogues, 64x64 and 64x32 tiles, ragged M) against the fp32 oracle cell, forward and BPTT"""
+    from polyphonic_chord_texture_disentanglement_amd._lib import call, ptr, stream_ptr
+    dev = _dev()
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(M + H + T)
+    k = 1.0 / np.sqrt(H)
+    w_hh = ((torch.rand(3 * H, H, generator=g) * 2 - 1) * k).to(bf).float().requires_grad_()      # bf16-representable weights
+    b_hh = ((torch.rand(3 * H, generator=g) * 2 - 1) * k).requires_grad_()
+    gi = (torch.randn(T, M, 3 * H, generator=g) * 0.5).to(bf).float().requires_grad_()
+    gi2 = (torch.randn(M, 3 * H, generator=g) * 0.5).to(bf).float() if use_gi2 else None
+    h0 = (torch.randn(M, H, generator=g) * 0.5).requires_grad_()
+    dh_ext = torch.randn(T, M, H, generator=g) * 0.1
+    # oracle: GRU cell with precomputed input-side pre-activations (b_ih folded into gi)
+    h, hs = h0, []
+    for t in range(T):
+        x = gi[t] + (gi2 if use_gi2 else 0)
+        gh = orc.linear(h, w_hh, b_hh)
+        r = torch.sigmoid(x[:, :H] + gh[:, :H]); z = torch.sigmoid(x[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(x[:, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1 - z) * n + z * h
+        hs.append(h)
+    hs = torch.stack(hs)
+    (hs * dh_ext).sum().backward()
+
+    d = lambda t: t.detach().to(dev)
+    gi_d = d(gi).to(bf); gi2_d = d(gi2).to(bf) if use_gi2 else None
+    w16, wt16 = d(w_hh).to(bf).contiguous(), d(w_hh).t().contiguous().to(bf)
+    hall = torch.zeros(T + 1, M, H, device=dev); hall[0] = d(h0)
+    hall16 = torch.zeros(T + 1, M, H, device=dev, dtype=bf)
+    gates = torch.empty(T, 4, M, H, device=dev, dtype=bf)
+    FL = 1 | 2 | 8 | 16 | (4 if use_gi2 else 0)
+    call('ptv_gru_seq_fwd', 1, M, H, T, ptr(gi_d), M * 3 * H, 3 * H, ptr(gi2_d), 0, 3 * H if use_gi2 else 0, ptr(w16), ptr(d(b_hh)),
+         ptr(hall), ptr(hall16), ptr(gates), None, 0, None, FL, stream_ptr())
+    assert (hall[1:].cpu() - hs.detach()).abs().max() < 3e-2
+    assert (hall16[1:].float() - hall[1:]).abs().max() < 1e-2                      # the shadow is the rounded state
+    dgi = torch.empty(T, M, 3 * H, device=dev, dtype=bf); dgh = torch.empty_like(dgi)
+    dhz = torch.empty(2, M, H, device=dev); dh0 = torch.empty(M, H, device=dev)
+    de = dh_ext.to(dev)
+    call('ptv_gru_seq_bwd', 1, M, H, T, ptr(hall), ptr(gates), ptr(wt16), ptr(de), de.stride(0), de.stride(1),
+         None, 0, None, 0, 0, 0, None, ptr(dgi), ptr(dgh), ptr(dhz), ptr(dh0), 0, FL, stream_ptr())
+    tol = 0.05
+    assert (dh0.cpu() - h0.grad).abs().max() < tol * max(1.0, h0.grad.abs().max().item())
+    assert (dgi.float().cpu() - gi.grad).abs().max() < tol * max(1.0, gi.grad.abs().max().item())
+    db = dgh.float().sum((0, 1)).cpu()
+    assert (db - b_hh.grad).abs().max() < tol * max(1.0, b_hh.grad.abs().max().item())
