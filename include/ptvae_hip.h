@@ -237,6 +237,9 @@ int ptv_route_slices(const float* src, float* dstA, float* dstB, const int* mask
 int ptv_cast_bf16(const float* src, void* dst, long n, void* stream);
 /* dst[c*rows + r] = bf16(src[r*cols + c]): transposed bf16 copy of a weight matrix (operand of the dX products) */
 int ptv_transpose_cast_bf16(const float* src, void* dst, int rows, int cols, void* stream);
+/* the same for every matrix of the flat parameter buffer in one launch: desc[i] = {offset, rows, cols, first 32x32 tile}
+ * (device array of nmat x 4 longs, tiles numbered consecutively; ntiles = their total); flat_t[offset + c*rows + r] */
+int ptv_transpose_cast_bf16_batched(const float* flat, void* flat_t, const long* desc, int nmat, long ntiles, void* stream);
 int ptv_grad_sumsq(const float* g, long n, float* sumsq, void* stream);
 int ptv_clip_adam_step(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float gscale, float clip,
                        float lr, float beta1, float beta2, float eps, int step, void* stream);

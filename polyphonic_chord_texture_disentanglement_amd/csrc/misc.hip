@@ -51,6 +51,33 @@ __global__ void transpose_cast_kernel(const float* __restrict__ src, __bf16* __r
   }
 }
 
+// every weight matrix of the flat buffer in ONE launch: desc[i] = (offset, rows, cols, first tile); a block finds its
+// matrix by a short scan of the tile prefix (the ~40 per-matrix launches of the per-step shadow refresh were a
+// 0.3 ms serial prologue of 5-microsecond kernels)
+__global__ void transpose_cast_batched_kernel(const float* __restrict__ flat, __bf16* __restrict__ flat_t,
+                                              const long* __restrict__ desc, int nmat) {
+  __shared__ float tile[32][33];
+  int mi = 0;
+  while (mi + 1 < nmat && desc[4 * (mi + 1) + 3] <= (long)blockIdx.x) mi++;
+  const long off = desc[4 * mi];
+  const int rows = (int)desc[4 * mi + 1], cols = (int)desc[4 * mi + 2];
+  const int t = (int)(blockIdx.x - desc[4 * mi + 3]);
+  const int tc = (cols + 31) / 32;
+  const int c0 = (t % tc) * 32, r0 = (t / tc) * 32;
+  const float* src = flat + off;
+  __bf16* dst = flat_t + off;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? src[(long)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) dst[(long)c * rows + r] = (__bf16)tile[tx][i];
+  }
+}
+
 __global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
   __shared__ float red[4];
   float s = 0.f;
@@ -226,6 +253,13 @@ extern "C" int ptv_cast_bf16(const float* src, void* dst, long n, void* stream) 
   if (!src || !dst || n <= 0 || (n & 3)) return PTV_ERR_ARG;
   long nb = (n / 4 + 255) / 256; if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(cast_flat_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, n / 4);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_transpose_cast_bf16_batched(const float* flat, void* flat_t, const long* desc, int nmat, long ntiles, void* stream) {
+  if (!flat || !flat_t || !desc || nmat <= 0 || ntiles <= 0) return PTV_ERR_ARG;
+  hipLaunchKernelGGL(transpose_cast_batched_kernel, dim3((unsigned)ntiles), dim3(256), 0, (hipStream_t)stream, flat, (__bf16*)flat_t, desc, nmat);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

@@ -138,6 +138,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         self.flat_pT16 = torch.empty(self.arena.total, device=ps[0].device, dtype=torch.bfloat16)
         self._mats = [(p, o) for p, o in zip(ps, self.arena.offsets) if p.dim() == 2 and p.shape[0] % 8 == 0 and p.shape[1] >= 8]
         self._mat_offsets = {o for _, o in self._mats}
+        self._tdesc = None
         # matrices whose rows are not a multiple of 8 elements (dur_hid_linear [64, 642]): a bf16 view of the flat
         # buffer would start every row off the 16-byte grid, so they get their own copy with rows padded to 8
         self._row_padded = {o: (p, torch.zeros(p.shape[0], (p.shape[1] + 7) // 8 * 8, device=p.device, dtype=torch.bfloat16))
@@ -154,8 +155,15 @@ class FusedClipAdam(torch.optim.Optimizer):
     def refresh_shadow(self):
         st = stream_ptr()
         call('ptv_cast_bf16', ptr(self.flat_p), ptr(self.flat_p16), self.arena.total, st)
-        for p, o in self._mats:                                  # transposed copies of the matrices
-            call('ptv_transpose_cast_bf16', ptr(p), ptr(self.flat_pT16[o:]), p.shape[0], p.shape[1], st)
+        if self._mats:                                           # transposed copies of the matrices: one launch
+            if self._tdesc is None:
+                d, t = [], 0
+                for p, o in self._mats:
+                    d += [o, p.shape[0], p.shape[1], t]
+                    t += ((p.shape[0] + 31) // 32) * ((p.shape[1] + 31) // 32)
+                self._tdesc = (torch.tensor(d, dtype=torch.int64, device=self.flat_p.device), t)
+            call('ptv_transpose_cast_bf16_batched', ptr(self.flat_p), ptr(self.flat_pT16), ptr(self._tdesc[0]), len(self._mats),
+                 self._tdesc[1], st)
         for p, buf in self._row_padded.values():
             buf[:, :p.shape[1]].copy_(p.data)
 
