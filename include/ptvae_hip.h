@@ -37,6 +37,7 @@ extern "C" {
 #define PTV_GRU_DG_BF16 8      /* dgi / dgh (backward) */
 #define PTV_GRU_W_BF16 16       /* w_hh points at a bf16 copy of the weight (needs hall16 / DG_BF16);
                                    forward: W_hh [3H,H]; backward: the TRANSPOSED copy W_hh^T [H,3H] */
+#define PTV_GRU_EXT_BF16 64     /* dh_ext (backward) holds bf16 */
 #define PTV_GRU_SKIP_CAST0 32  /* hall16 slot 0 is already valid (chained single-step calls) */
 
 /* Library / build identification ("gfx950"). */
@@ -100,7 +101,7 @@ int ptv_gru_step_fwd(int prec, int M, int H,
  */
 int ptv_gru_seq_bwd(int prec, int M, int H, int T,
                     const float* hall, const void* gates, const void* w_hh,
-                    const float* dh_ext, long ext_step_stride, long ext_ld,
+                    const void* dh_ext, long ext_step_stride, long ext_ld,
                     const float* dh_last, long last_ld,
                     const float* lr_a, long lr_step_stride, long lr_lda, int lr_k, const float* lr_b,
                     void* dgi, void* dgh, float* dhz, float* dh0,

@@ -38,13 +38,14 @@ struct EpiPlain {
       // every runtime option and costs ~100 instructions per cell -- for short-K products that, not memory,
       // set the block lifetime)
       const bool bias_ok = !use_bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
-      if (vec && bias_ok && p.act == 0 && m0 + 16 * FM <= M && n0 + 16 * FN <= N && !(bf && (p.accumulate || p.atomic))) {
-        const int mode = p.atomic ? 3 : (p.accumulate ? 2 : (bf ? 1 : 0));
+      if (vec && bias_ok && p.act == 0 && m0 + 16 * FM <= M && n0 + 16 * FN <= N && !(bf && p.atomic)) {
+        const int mode = p.atomic ? 3 : (p.accumulate ? (bf ? 4 : 2) : (bf ? 1 : 0));
         float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (use_bias) b4 = *reinterpret_cast<const float4*>(p.bias + n0 + u);
         if (mode == 0) fast_rows<FM, FN, 0>(p, acc, st, m0, n0 + u, b4);
         else if (mode == 1) fast_rows<FM, FN, 1>(p, acc, st, m0, n0 + u, b4);
         else if (mode == 2) fast_rows<FM, FN, 2>(p, acc, st, m0, n0 + u, b4);
+        else if (mode == 4) fast_rows<FM, FN, 4>(p, acc, st, m0, n0 + u, b4);
         else fast_rows<FM, FN, 3>(p, acc, st, m0, n0 + u, b4);
         return;
       }
@@ -69,7 +70,7 @@ struct EpiPlain {
         }
     }
   }
-  // MODE 0: store fp32, 1: store bf16, 2: C += (fp32), 3: atomicAdd (fp32 split-K partials)
+  // MODE 0: store fp32, 1: store bf16, 2: C += (fp32), 3: atomicAdd (fp32 split-K partials), 4: C += (bf16)
   template <int FM, int FN, int MODE>
   static __device__ __forceinline__ void fast_rows(const Params& p, f32x4 (&acc)[FM][FN], float* st, int m0, int n, const float4& b4) {
     using RS = RowStage<1, FN * 16>;
@@ -83,7 +84,11 @@ struct EpiPlain {
         const f32x4 a = RS::get(st, row, u);
         const long off = (long)(m0 + i * 16 + row) * p.ldc + n;
         float v0 = p.alpha * a[0] + b4.x, v1 = p.alpha * a[1] + b4.y, v2 = p.alpha * a[2] + b4.z, v3 = p.alpha * a[3] + b4.w;
-        if constexpr (MODE == 1) {
+        if constexpr (MODE == 1 || MODE == 4) {
+          if constexpr (MODE == 4) {
+            const bf16x4 q = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.C) + off);
+            v0 += (float)q[0]; v1 += (float)q[1]; v2 += (float)q[2]; v3 += (float)q[3];
+          }
           bf16x4 o; o[0] = (__bf16)v0; o[1] = (__bf16)v1; o[2] = (__bf16)v2; o[3] = (__bf16)v3;
           *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.C) + off) = o;
         } else if constexpr (MODE == 3) {

@@ -176,7 +176,7 @@ using EpiGruFwd = EpiGruFwdT<0>;
 // ---------------------------------------------------------------------------------------------
 struct GruBwdParams {
   const float* dhz_next;              // [M,H] dh (x) z carried from the later step, null at the last step
-  const float* dh_ext; long ld_ext;   // [M,H] gradient arriving at this step's output from outside, may be null
+  const void* dh_ext; long ld_ext;    // [M,H] gradient arriving at this step's output from outside (fp32, or bf16 with PTV_GRU_EXT_BF16), may be null
   const float* dh_ext2; long ld_ext2; // second external addend (e.g. final-state grad), may be null
   const float* lr_a; long lr_lda; int lr_k; const float* lr_b;   // optional low-rank addend: dh += lr_a[m, 0:k] . lr_b[k, H]
   const void* gates; long plane;      // saved r,z,n,hn of this step (fp32 or bf16)
@@ -203,7 +203,7 @@ struct EpiGruBwdT {
     o.hp = *reinterpret_cast<const float4*>(p.hprev + m * p.ld_hprev + j);
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     o.dz = p.dhz_next ? *reinterpret_cast<const float4*>(p.dhz_next + m * H + j) : zero;
-    o.e1 = p.dh_ext ? *reinterpret_cast<const float4*>(p.dh_ext + m * p.ld_ext + j) : zero;
+    o.e1 = p.dh_ext ? ld4f(p.dh_ext, m * p.ld_ext + j, p.flags & PTV_GRU_EXT_BF16) : zero;
     o.e2 = p.dh_ext2 ? *reinterpret_cast<const float4*>(p.dh_ext2 + m * p.ld_ext2 + j) : zero;
     o.la[0] = p.lr_a ? p.lr_a[m * p.lr_lda] : 0.f;
     o.la[1] = (p.lr_a && p.lr_k > 1) ? p.lr_a[m * p.lr_lda + 1] : 0.f;
@@ -317,7 +317,7 @@ struct EpiGruBwdT {
       {
         float dh[4] = {av[0], av[1], av[2], av[3]};
         if (p.dhz_next) { const float4 q = *reinterpret_cast<const float4*>(p.dhz_next + (long)m * H + j); dh[0] += q.x; dh[1] += q.y; dh[2] += q.z; dh[3] += q.w; }
-        if (p.dh_ext) { const float4 q = *reinterpret_cast<const float4*>(p.dh_ext + (long)m * p.ld_ext + j); dh[0] += q.x; dh[1] += q.y; dh[2] += q.z; dh[3] += q.w; }
+        if (p.dh_ext) { const float4 q = ld4f(p.dh_ext, (long)m * p.ld_ext + j, p.flags & PTV_GRU_EXT_BF16); dh[0] += q.x; dh[1] += q.y; dh[2] += q.z; dh[3] += q.w; }
         if (p.dh_ext2) { const float4 q = *reinterpret_cast<const float4*>(p.dh_ext2 + (long)m * p.ld_ext2 + j); dh[0] += q.x; dh[1] += q.y; dh[2] += q.z; dh[3] += q.w; }
         if (p.lr_a) {
           for (int k = 0; k < p.lr_k; k++) {
@@ -486,7 +486,7 @@ extern "C" int ptv_gru_seq_fwd(int prec, int M, int H, int T,
 
 extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
                                const float* hall, const void* gates, const void* w_hh,
-                               const float* dh_ext, long ext_step_stride, long ext_ld,
+                               const void* dh_ext, long ext_step_stride, long ext_ld,
                                const float* dh_last, long last_ld,
                                const float* lr_a, long lr_step_stride, long lr_lda, int lr_k, const float* lr_b,
                                void* dgi, void* dgh, float* dhz, float* dh0,
@@ -496,6 +496,7 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
   const bool w16 = flags & PTV_GRU_W_BF16;
   if (w16 && !(flags & PTV_GRU_DG_BF16)) return PTV_ERR_ARG;
   if (dh_ext && ((ext_ld & 3) || (ext_step_stride & 3))) return PTV_ERR_ARG;
+  if ((flags & PTV_GRU_EXT_BF16) && prec != PTV_PREC_BF16) return PTV_ERR_ARG;
   if (dh_last && (last_ld & 3)) return PTV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const long MH = (long)M * H, M3H = 3 * MH;
@@ -507,7 +508,7 @@ extern "C" int ptv_gru_seq_bwd(int prec, int M, int H, int T,
     const long esz_d = dbf ? 2 : 4, esz_g = (flags & PTV_GRU_GATES_BF16) ? 2 : 4;
     GemmArgs g{last ? dgh : (const char*)dgh + (long)(step + 1) * M3H * esz_d, 3L * H, w_hh, w16 ? 3L * H : (long)H, M, H, last ? 0 : 3 * H, last ? 0 : 3 * H, 0};
     GruBwdParams ep{last ? nullptr : dhz + ((step + 1) & 1) * MH,
-                         dh_ext ? dh_ext + (long)step * ext_step_stride : nullptr, ext_ld,
+                         dh_ext ? (const char*)dh_ext + (long)step * ext_step_stride * ((flags & PTV_GRU_EXT_BF16) ? 2 : 4) : nullptr, ext_ld,
                          last ? dh_last : nullptr, last_ld,
                          lr_a ? lr_a + (long)step * lr_step_stride : nullptr, lr_lda, lr_k, lr_b,
                          (const char*)gates + (long)step * 4 * MH * esz_g, MH,

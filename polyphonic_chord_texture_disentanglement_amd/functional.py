@@ -133,8 +133,8 @@ def gemm_dx(dy, w, cols=None, out=None, *, acc=False, prec=0):
     return gemm(dy, w if cols is None else w[:, cols], out, tb=True, acc=acc, prec=prec)
 
 
-def _gru_flags(gates=None, gi=None, gi2=None, dg=None, w=None):
-    return _bf(gates) | (_bf(gi) << 1) | (_bf(gi2) << 2) | (_bf(dg) << 3) | (_bf(w) << 4)
+def _gru_flags(gates=None, gi=None, gi2=None, dg=None, w=None, ext=None):
+    return _bf(gates) | (_bf(gi) << 1) | (_bf(gi2) << 2) | (_bf(dg) << 3) | (_bf(w) << 4) | (_bf(ext) << 6)
 
 
 def gru_fwd(prec, gi, gi_step, gi_ld, w_hh, b_hh, hall, gates, *, gi2=None, gi2_step=0, gi2_ld=0, lengths=None,
@@ -170,7 +170,7 @@ def gru_bwd(prec, hall, gates, w_hh, *, dh_ext=None, dh_last=None, lr=None, reve
         wt = _WT(w_hh, prec)                  # W_hh^T [H,3H] bf16: K-contiguous weight tiles for the BPTT products
         w_hh = wt if wt is not None else w_hh
     call('ptv_gru_seq_bwd', prec, M, H, T, ptr(hall), ptr(gates), ptr(w_hh), *ext, *last, *lra, ptr(dgi),
-         ptr(dgh), ptr(dhz), ptr(dh0), int(reverse), _gru_flags(gates, dg=dgi, w=w_hh), stream_ptr())
+         ptr(dgh), ptr(dhz), ptr(dh0), int(reverse), _gru_flags(gates, dg=dgi, w=w_hh, ext=dh_ext), stream_ptr())
     return dgi, dgh, dh0
 
 
@@ -726,7 +726,9 @@ class DecoderTFFn(torch.autograd.Function):
 
         # ---- dur_hid_linear([note_summary | est_pitch]) and pitch_out_linear ----
         w_dh, w_p = W['dur_hid_linear.weight'], W['pitch_out_linear.weight']
-        dNSUM = gemm_dx(dHD0, w_dh, slice(0, Hn), prec=prec)                      # [M, Hn]
+        # gradient reaching the notes-GRU states: only ever an addend of the BPTT epilogue -> activation dtype
+        dNSUM = _empty(M, Hn, dev=dev, dtype=_act_dtype(prec, Hn))
+        gemm_dx(dHD0, w_dh, slice(0, Hn), out=dNSUM, prec=prec)                   # [M, Hn]
         gemm_dx(dHD0, w_dh, slice(Hn, None), out=dP, acc=True, prec=prec)
         gemm_dx(dP, w_p, out=dNSUM, acc=True, prec=prec)
 
