@@ -136,7 +136,7 @@ struct EpiPlain {
 #define PLAIN_PF_BIG(KA, KB, SA, SB) ((SA) && (SB) ? ((KA) ? PTV_PF_TN : PTV_PF_NT) : 1)
 
 template <class CT, int BM, int BN, int WGM, int WGN, bool KA, bool KB, bool SA, bool SB>
-__global__ __launch_bounds__(NTHREADS) void gemm_plain_kernel(GemmArgs g, EpiPlain::Params ep) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_plain_kernel(GemmArgs g, EpiPlain::Params ep) {
   gemm_body<CT, BM, BN, WGM, WGN, 1, KA, KB, EpiPlain, SA, SB, (BM * BN <= 64 * 64 ? 2 : PLAIN_PF_BIG(KA, KB, SA, SB))>(g, ep);
 }
 
