@@ -179,6 +179,9 @@ int ptv_loss_bwd_scales(const float* gout11, const int* counts, float beta, floa
  */
 int ptv_dur_out_token(const float* h, int H, const float* w_out, const float* b_out, float* dur_out, long ld_out,
                       int* idx, const int* force_idx, long rows, void* stream);
+/* weight gradient of dur_out_linear (autograd of ptvae.py:361-362 over the 5 duration steps) in one pass over the bf16 state
+ * planes: gw[c*64 + u] += sum_d sum_m ddur[m*ld_dd + 2d + c] * hall16[(d+1)*plane_h + m*64 + u]   (H = 64) */
+int ptv_dur_out_wgrad(const float* ddur, long ld_dd, const void* hall16, long plane_h, float* gw, long rows, int H, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * The whole 5-step duration GRU of decode_note (ptvae.py:353-367) in ONE kernel (bf16 precision, H = 64):

@@ -198,6 +198,44 @@ extern "C" int ptv_dur_out_token(const float* h, int H, const float* w_out, cons
   return PTV_OK;
 }
 
+// weight gradient of dur_out_linear over all 5 duration steps in one pass:  gW[c][u] += sum_d sum_m ddur[m][2d+c] * h_{d+1}[m][u]
+// (5 separate [2 x 64] split-K products each re-launch and re-read; this reads the 5 bf16 state planes once).
+// block: 256 threads = 8 unit-octets (16-byte loads of 8 bf16) x 32 row lanes; LDS tree over the row lanes, atomics per block.
+__global__ void dur_out_wgrad_kernel(const float* __restrict__ ddur, long ld_dd, const __bf16* __restrict__ hall16, long plane_h,
+                                     float* __restrict__ gw, long rows, int H) {
+  __shared__ float red[32][2][64];
+  const int uo = threadIdx.x & 7, rlane = threadIdx.x >> 3;
+  float a0[8], a1[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) a0[e] = a1[e] = 0.f;
+  for (long r = (long)blockIdx.x * 32 + rlane; r < rows; r += (long)gridDim.x * 32) {
+#pragma unroll
+    for (int d = 0; d < 5; d++) {
+      const float2 g = *reinterpret_cast<const float2*>(ddur + r * ld_dd + 2 * d);
+      const bf16x8 h = *reinterpret_cast<const bf16x8*>(hall16 + (d + 1) * plane_h + r * H + uo * 8);
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const float hv = (float)h[e]; a0[e] += g.x * hv; a1[e] += g.y * hv; }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e++) { red[rlane][0][uo * 8 + e] = a0[e]; red[rlane][1][uo * 8 + e] = a1[e]; }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int c = threadIdx.x >> 6, u = threadIdx.x & 63;
+    float s = 0.f;
+    for (int q = 0; q < 32; q++) s += red[q][c][u];
+    atomicAdd(gw + c * H + u, s);
+  }
+}
+
+extern "C" int ptv_dur_out_wgrad(const float* ddur, long ld_dd, const void* hall16, long plane_h, float* gw, long rows, int H, void* stream) {
+  if (!ddur || !hall16 || !gw || rows <= 0 || H != 64 || (ld_dd & 1) || (plane_h & 7)) return PTV_ERR_ARG;
+  long nb = (rows + 31) / 32; if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(dur_out_wgrad_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, ddur, ld_dd, (const __bf16*)hall16, plane_h, gw, rows, H);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
 extern "C" int ptv_grad_sumsq(const float* g, long n, float* sumsq, void* stream) {
   if (!g || !sumsq || n <= 0) return PTV_ERR_ARG;
   if (reinterpret_cast<uintptr_t>(g) & 15) return PTV_ERR_ARG;

@@ -253,6 +253,16 @@ def _bgrad(b, a):
     return g
 
 
+def _bgrad_hh(b_hh, dgh2, gb_ih):
+    """bias_hh gradient of a GRU from dgh [rows, 3H] given the finished bias_ih gradient: dgi and dgh share their r and z
+    thirds (only the n third differs: dn vs dn*r), so those column sums are copied and only the last third is summed"""
+    g = _gbuf(b_hh)
+    H = b_hh.numel() // 3
+    copy2d(g.view(1, -1)[:, :2 * H], gb_ih.view(1, -1)[:, :2 * H], acc=True)
+    colsum(g.view(1, -1)[:, 2 * H:], dgh2[:, 2 * H:])
+    return g
+
+
 def dur_bwd_fusable(prec, Hd, gates_d):
     return prec == 1 and Hd == 64 and FUSED_DUR and gates_d.dtype == BF16
 
@@ -272,8 +282,12 @@ def dur_bwd_fused(P, G, gates_d, idx, HD, HDo, ddur, wgrad, bgrad, side):
          stream_ptr())
 
     def dur_wgrads():
-        for d in range(5):
-            wgrad('dur_out_linear.weight', ddur[:, 2 * d:2 * d + 2], HDo[d + 1])
+        if HDo.dtype == BF16:                     # one pass over the 5 bf16 state planes instead of 5 split-K products
+            G['dur_out_linear.weight'] = _gbuf(P['dur_out_linear.weight'])
+            call('ptv_dur_out_wgrad', ptr(ddur), 10, ptr(HDo), M * Hd, ptr(G['dur_out_linear.weight']), M, Hd, stream_ptr())
+        else:
+            for d in range(5):
+                wgrad('dur_out_linear.weight', ddur[:, 2 * d:2 * d + 2], HDo[d + 1])
         bgrad('dur_out_linear.bias', ddur.view(M * 5, 2))
         S = colsum(_zeros(1, psz, dev=dev), part)
         names = ('dec_dur_gru.weight_hh_l0', 'dec_dur_gru.bias_hh_l0', 'dec_dur_gru.bias_ih_l0', 'dec_dur_gru.weight_ih_l0',
@@ -403,7 +417,7 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
         dw_hh = gemm(dgh2, (h16 if h16 is not None else hall)[:T].view(T * M, H), _gbuf(w_hh), ta=True, tb=True, acc=True,
                      prec=prec)
         db_ih = _bgrad(b_ih, dgi2)
-        db_hh = _bgrad(b_hh, dgh2)
+        db_hh = _bgrad_hh(b_hh, dgh2, db_ih)
         dx = gemm_dx(dgi2, w_ih, prec=prec) if need_dx else None
         return [dw_ih, dw_hh, db_ih, db_hh], dx
 
@@ -753,8 +767,8 @@ class DecoderTFFn(torch.autograd.Function):
 
         def notes_wgrads():
             wgrad('dec_notes_gru.weight_hh_l0', dgh_n.view(M, 3 * Hn), HNo[:15].view(M, Hn))
-            bgrad('dec_notes_gru.bias_hh_l0', dgh_n.view(M, 3 * Hn))
             bgrad('dec_notes_gru.bias_ih_l0', dGC)
+            G['dec_notes_gru.bias_hh_l0'] = _bgrad_hh(P['dec_notes_gru.bias_hh_l0'], dgh_n.view(M, 3 * Hn), G['dec_notes_gru.bias_ih_l0'])
             wgrad('dec_notes_gru.weight_ih_l0', dGC, NSf_op, slice(0, Ht))
             wgrad('dec_notes_gru.weight_ih_l0', dgi_n.view(M, 3 * Hn), emb3[:15].view(M, E), slice(Ht, None))
             wgrad('dec_time_to_notes_hid.weight', dHN0, NSf_op)
@@ -776,8 +790,8 @@ class DecoderTFFn(torch.autograd.Function):
 
         def time_wgrads():
             wgrad('dec_time_gru.weight_hh_l0', dgh_t.view(R, 3 * Ht), NSo[:32].view(R, Ht))
-            bgrad('dec_time_gru.bias_hh_l0', dgh_t.view(R, 3 * Ht))
             bgrad('dec_time_gru.bias_ih_l0', dZG)
+            G['dec_time_gru.bias_hh_l0'] = _bgrad_hh(P['dec_time_gru.bias_hh_l0'], dgh_t.view(R, 3 * Ht), G['dec_time_gru.bias_ih_l0'])
             wgrad('dec_time_gru.weight_ih_l0', dZG, st['z_in'], slice(2 * He, None))
             wgrad('dec_time_gru.weight_ih_l0', dgi_t.view(R, 3 * Ht), TOKS[:32].view(R, 2 * He), slice(0, 2 * He))
             bgrad('dec_init_input', dTOKS[0])
