@@ -90,6 +90,77 @@ __global__ void ce_wave_kernel(const float* __restrict__ logits, long ld, const 
   }
 }
 
+// rows padded to a multiple of 4 floats (the 130-wide pitch logits live in 136-float rows): half a wave per row, 16-byte
+// loads / stores, two rows per wave instruction stream.  C <= 256.  (The scalar kernel above moved 4 bytes per lane.)
+template <bool BWD>
+__global__ void ce_vec_kernel(const float* __restrict__ logits, long ld, const int* __restrict__ tgt, long rows, int C, int ignore,
+                              float* __restrict__ nll_sum, const float* __restrict__ gscale, float* __restrict__ dlogits, long ldd) {
+  __shared__ float red[8];
+  const int lane = threadIdx.x & 63, sub = lane & 31, hw = threadIdx.x >> 5;       // 8 half-waves per block
+  float local = 0.f;
+  const float gs = BWD ? gscale[0] : 0.f;
+  const int nch = (C + 3) >> 2;
+  for (long r0 = (long)blockIdx.x * 8; r0 < rows; r0 += (long)gridDim.x * 8) {
+    const long r = r0 + hw;
+    const bool live = r < rows;
+    const long rc = live ? r : rows - 1;
+    const float* lr = logits + rc * ld;
+    const int t = tgt[rc];
+    float4 v[2]; float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int j = sub + 32 * k;
+      v[k] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      if (j < nch) {
+        v[k] = *reinterpret_cast<const float4*>(lr + 4 * j);
+        if (4 * j + 1 >= C) v[k].y = -INFINITY;
+        if (4 * j + 2 >= C) v[k].z = -INFINITY;
+        if (4 * j + 3 >= C) v[k].w = -INFINITY;
+      }
+      m = fmaxf(m, fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(v[k].z, v[k].w)));
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float4 e[2]; float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      e[k] = make_float4(expf(v[k].x - m), expf(v[k].y - m), expf(v[k].z - m), expf(v[k].w - m));    // exp(-inf) = 0 on masked slots
+      s += e[k].x + e[k].y + e[k].z + e[k].w;
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const bool valid = t != ignore;
+    if (!BWD) {
+      if (live && valid && sub == 0) local += -(lr[t] - m - logf(s));
+    } else if (live) {
+      float* dr = dlogits + r * ldd;
+      const float inv = gs / s;
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int j = sub + 32 * k;
+        if (j < nch) {
+          float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (valid) {
+            d = make_float4(e[k].x * inv, e[k].y * inv, e[k].z * inv, e[k].w * inv);
+            const int q = t - 4 * j;
+            if (q == 0) d.x -= gs; else if (q == 1) d.y -= gs; else if (q == 2) d.z -= gs; else if (q == 3) d.w -= gs;
+          }
+          *reinterpret_cast<float4*>(dr + 4 * j) = d;            // slots >= C fall into the row padding
+        }
+      }
+    }
+  }
+  if (!BWD) {
+    if (sub == 0) red[hw] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) { float t = 0.f; for (int i = 0; i < 8; i++) t += red[i]; if (t != 0.f) atomicAdd(nll_sum, t); }
+  }
+}
+
+static inline bool ce_vec_ok(const float* p, long ld, int C) {
+  return C > 16 && (ld & 3) == 0 && ld >= ((C + 3) & ~3) && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+}
+
 // one thread per row, C <= 16 (duration bits C=2, chord heads C=12 / 2)
 template <bool BWD>
 __global__ void ce_small_kernel(const float* __restrict__ logits, long ld, const int* __restrict__ tgt, long rows, int C, int ignore,
@@ -209,6 +280,7 @@ extern "C" int ptv_ce_fwd(const float* logits, long ld, const int* targets, long
   if (!logits || !targets || !nll_sum || rows <= 0 || C <= 0 || C > 256) return PTV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (C <= 16) hipLaunchKernelGGL((ce_small_kernel<false>), dim3(grid_rows(rows, 256, 2048)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nll_sum, nullptr, nullptr, 0L);
+  else if (ce_vec_ok(logits, ld, C)) hipLaunchKernelGGL((ce_vec_kernel<false>), dim3(grid_rows(rows, 8, 16384)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nll_sum, nullptr, nullptr, 0L);
   else hipLaunchKernelGGL((ce_wave_kernel<false>), dim3(grid_rows(rows, 4, 16384)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nll_sum, nullptr, nullptr, 0L);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
@@ -218,6 +290,7 @@ extern "C" int ptv_ce_bwd(const float* logits, long ld, const int* targets, long
   if (!logits || !targets || !gscale || !dlogits || rows <= 0 || C <= 0 || C > 256) return PTV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (C <= 16) hipLaunchKernelGGL((ce_small_kernel<true>), dim3(grid_rows(rows, 256, 2048)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nullptr, gscale, dlogits, ldd);
+  else if (ce_vec_ok(logits, ld, C) && ce_vec_ok(dlogits, ldd, C)) hipLaunchKernelGGL((ce_vec_kernel<true>), dim3(grid_rows(rows, 8, 16384)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nullptr, gscale, dlogits, ldd);
   else hipLaunchKernelGGL((ce_wave_kernel<true>), dim3(grid_rows(rows, 4, 16384)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nullptr, gscale, dlogits, ldd);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
