@@ -128,6 +128,28 @@ __global__ void embed_fwd_kernel(const long* __restrict__ x, const float* __rest
   for (int i = threadIdx.x; i < 135 * E; i += blockDim.x) { int e = i % E, p = i / E; wt[i] = W[e * 135 + p]; }
   __syncthreads();
   const long notes = (long)B * 512;
+  if ((E & 3) == 0 && blockDim.x >= E / 4) {
+    // 4 features per thread: 16-byte LDS reads and stores, blockDim / (E/4) notes in flight per block
+    const int tpn = E / 4, per = blockDim.x / tpn;
+    const int e = (threadIdx.x % tpn) * 4, sub = threadIdx.x / tpn;
+    if (sub >= per) return;
+    const float4 bv = *reinterpret_cast<const float4*>(bias + e);
+    for (long i = (long)blockIdx.x * per + sub; i < notes; i += (long)gridDim.x * per) {
+      const int b = (int)(i % B); const long q = i / B; const int t = (int)(q % 32), n = (int)(q / 32);
+      const long* xr = x + (((long)b * 32 + t) * 16 + n) * 6;
+      const int p = (int)xr[0];
+      float4 v = bv;
+      if (p < 130) { const float4 w = *reinterpret_cast<const float4*>(wt + p * E + e); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+#pragma unroll
+      for (int d = 0; d < 5; d++) {
+        const float f = (float)xr[1 + d];
+        const float4 w = *reinterpret_cast<const float4*>(wt + (130 + d) * E + e);
+        v.x += w.x * f; v.y += w.y * f; v.z += w.z * f; v.w += w.w * f;
+      }
+      *reinterpret_cast<float4*>(emb + i * E + e) = v;
+    }
+    return;
+  }
   const int per = blockDim.x / E > 0 ? blockDim.x / E : 1;       // notes in flight per block
   const int e = threadIdx.x % E, sub = threadIdx.x / E;
   if (sub >= per) return;
@@ -252,7 +274,7 @@ extern "C" int ptv_colsum(float* out, const void* A, long lda, long rows, int N,
 extern "C" int ptv_embed_fwd(const long* x, const float* W, const float* bias, float* emb, int* lengths, int B, int E, void* stream) {
   if (!x || !W || !bias || !emb || B <= 0 || E <= 0 || E > 256) return PTV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for((long)B * 512, 2, 1024)), dim3(256), 135 * E * sizeof(float), s, x, W, bias, emb, B, E);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for((long)B * 512, 8, 1024)), dim3(256), 135 * E * sizeof(float), s, x, W, bias, emb, B, E);
   if (lengths) hipLaunchKernelGGL(lengths_kernel, dim3(cdiv((long)B * 32, 256)), dim3(256), 0, s, x, lengths, B);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
