@@ -177,7 +177,8 @@ class DecoderStepFn(torch.autograd.Function):
         z, emb, *params = ctx.saved_tensors
         P = dict(zip(FREE_PARAM_NAMES, params))
         st = ctx.st
-        ctx.st = None
+        if not getattr(ctx, 'keep_state', False):        # a captured forward (GraphedDecoderStepFn) reuses its buffers
+            ctx.st = None
         B, R, E, He, Ht, Hn, Hd, NP, prec = (st[k] for k in ('B', 'R', 'E', 'He', 'Ht', 'Hn', 'Hd', 'NP', 'prec'))
         dev = z.device
         M = 15 * R
@@ -332,6 +333,66 @@ class DecoderStepFn(torch.autograd.Function):
 # =============================================================================================
 # RnnDecoder (chord decoder) with arbitrary coins: ptvae.py:51-87
 # =============================================================================================
+class _CapturedCtx:
+    """stands in for the autograd ctx of DecoderStepFn while its forward is captured into a hipGraph"""
+
+    def __init__(self, n_inputs):
+        self.needs_input_grad = (True,) * n_inputs
+        self.saved_tensors = ()
+        self.st = None
+        self.keep_state = True
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *a):
+        pass
+
+
+class GraphedDecoderStepFn(torch.autograd.Function):
+    """Free-running TRAINING forward (every teacher-forcing coin false: what the reference's schedules reach after two
+    steps) replayed from a captured hipGraph.  The step loop is ~9,000 small launches whose order and arguments depend
+    only on (B, precision, parameter storage): capture DecoderStepFn.forward once -- outputs and every buffer the backward
+    needs are the graph's static tensors -- then one graph launch per step; the backward is DecoderStepFn.backward on
+    those buffers.  `cache` is a dict owned by the decoder module."""
+
+    @staticmethod
+    def forward(ctx, cache, z, emb, xs, prec, *params):
+        B = z.shape[0]
+        key = (B, prec, z.device.index, tuple(p.data_ptr() for p in params), emb.shape, xs is not None)
+        ent = cache.get(key)
+        coins = ([[False] * 14] * 32, [False] * 31)
+        if ent is None:
+            sz, se = z.detach().clone().contiguous(), emb.detach().clone()
+            sx = xs.detach().clone() if xs is not None else None
+            cur = torch.cuda.current_stream()
+            s = torch.cuda.Stream(device=z.device)
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):                       # warm-up outside capture (lazy inits, allocator)
+                DecoderStepFn.forward(_CapturedCtx(7 + len(params)), sz, se, sx, coins, False, None, prec, *params)
+            cur.wait_stream(s)
+            cap = _CapturedCtx(7 + len(params))
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs = DecoderStepFn.forward(cap, sz, se, sx, coins, False, None, prec, *params)
+            cache.clear()
+            ent = cache[key] = (g, sz, se, cap, outs)
+        g, sz, se, cap, outs = ent
+        sz.copy_(z)
+        se[0].copy_(emb[0])                                   # only the <sos> slot of the ground truth is read when no coin is true
+        g.replay()
+        ctx.cap = cap
+        outs = tuple(o.detach() for o in outs)               # fresh tensor objects over the graph's static storage
+        ctx.mark_non_differentiable(outs[2], outs[3])
+        return outs
+
+    @staticmethod
+    def backward(ctx, dpitch, ddur, _dx, _di):
+        r = DecoderStepFn.backward(ctx.cap, dpitch, ddur, None, None)
+        # DecoderStepFn inputs: (z, emb, xs, coins, inference, force, prec, *params) -> ours: (cache, z, emb, xs, prec, *params)
+        return (None, r[0], r[1], r[2], None) + tuple(r[7:])
+
+
 class ChordDecoderStepFn(torch.autograd.Function):
     """(z_chd, c_sm [8,B,36] or None, coins [8] bools, prec, *params) -> root [8,B,12], chroma [8,B,24], bass [8,B,12]"""
 

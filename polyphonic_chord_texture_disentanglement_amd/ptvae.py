@@ -239,6 +239,7 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
         self.last_xhat = None              # predicted grid [B,32,16,6] int64 of the last step-loop decode
         self.use_graph = False             # replay inference decodes from a captured hipGraph
         self._graphs = {}
+        self._train_graphs = {}
         self._summary = None
         self.last_dur_idx = None
 
@@ -335,8 +336,14 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
         else:
             xs = self._summarize(emb, len32)
         if not all_tf:
-            pitch, dur, xhat, idx = FF_.DecoderStepFn.apply(z, emb, xs, coins, False, self.force_trace, self._prec,
-                                                            *self._params_free())
+            none_tf = not any(any(r) for r in coins[0]) and not any(coins[1])
+            if self.use_graph and none_tf and self.force_trace is None and torch.is_grad_enabled():
+                # free-running training step: forward replayed from a captured hipGraph
+                pitch, dur, xhat, idx = FF_.GraphedDecoderStepFn.apply(self._train_graphs, z, emb, xs, self._prec,
+                                                                       *self._params_free())
+            else:
+                pitch, dur, xhat, idx = FF_.DecoderStepFn.apply(z, emb, xs, coins, False, self.force_trace, self._prec,
+                                                                *self._params_free())
             self.last_dur_idx, self.last_xhat = idx, xhat
             return pitch.permute(2, 1, 0, 3), dur.view(15, 32, B, 5, 2).permute(2, 1, 0, 3, 4)
         pitch, dur, idx = F_.DecoderTFFn.apply(z, emb, xs, self.force_dur_idx, self._prec, *self._params())

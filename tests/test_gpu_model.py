@@ -337,3 +337,35 @@ def test_fused_duration_gru_in_the_step_loop(monkeypatch):
     assert (res[True][0] == res[False][0]).float().mean() > 0.995          # same predicted grid
     np.testing.assert_allclose(res[True][1], res[False][1], rtol=0, atol=5e-3)
     assert (res[True][2] - res[False][2]).abs().max() < 0.1 * res[False][2].abs().max()
+
+
+def test_graph_captured_free_running_training_step_equals_eager():
+    """tfr = 0 training step with the decoder forward replayed from a captured hipGraph (use_graph) vs the eager step loop:
+    same losses and gradients, on the capture call and on a replay with different data"""
+    m = M.DisentangleVAE.init_model(torch.device(DEV))
+    m.load_state_dict(full_params())
+    m.to(DEV).set_precision('bf16')
+    g = load_npz('full_tf0_b4.npz')
+    res = {}
+    for graph in (False, True):
+        m.decoder.use_graph = graph
+        out = []
+        for seed in (int(g['data_seed']), int(g['data_seed']) + 1, int(g['data_seed'])):
+            x, c, pr = synth_batch(int(g['B']), seed)
+            xt, ct, prt = (torch.from_numpy(a).to(DEV) for a in (x, c, pr))
+            m.eps_source = _eps_source(g)
+            m.zero_grad()
+            outs = m.run(xt, ct, prt, 0., 0., 0.)
+            losses = m.loss_function(xt, ct, *outs, 0.1, [1, 0.5])
+            losses[0].backward()
+            torch.cuda.synchronize()
+            out.append((np.array([l.item() for l in losses]), m.decoder.last_xhat.clone(),
+                        {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+        res[graph] = out
+    m.decoder.use_graph = False
+    assert len(m.decoder._train_graphs) == 1
+    for (l0, x0, g0), (l1, x1, g1) in zip(res[False], res[True]):
+        np.testing.assert_allclose(l1, l0, rtol=0, atol=5e-3)
+        assert (x0 == x1).float().mean() > 0.995
+        for n in g0:
+            assert (g1[n] - g0[n]).abs().max() <= 0.05 * g0[n].abs().max() + 1e-6, n
