@@ -10,7 +10,8 @@
  *   - every pointer is a DEVICE pointer owned by the caller (torch tensors on the Python side);
  *     all matrices are fp32 row-major with explicit leading dimensions (in elements)
  *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it, nothing synchronises
- *   - return value: 0 = ok, <0 = error (PTV_ERR_*); no exceptions cross the ABI
+ *   - return value: 0 = ok, <0 = error (-1 bad argument, -2 launch failure, -3 unsupported shape for a
+ *     specialised kernel: use the generic entry point); no exceptions cross the ABI
  *   - `prec`: PTV_PREC_F32 (0) = v_mfma_f32_16x16x4_f32, exact fp32 (parity path);
  *             PTV_PREC_BF16 (1) = v_mfma_f32_16x16x32_bf16, bf16 operands / fp32 accumulate
  *     (state, activations, gradients and weights stay fp32 in HBM in both modes)
@@ -106,6 +107,40 @@ int ptv_gru_seq_bwd(int prec, int M, int H, int T,
                     const float* lr_a, long lr_step_stride, long lr_lda, int lr_k, const float* lr_b,
                     void* dgi, void* dgh, float* dhz, float* dh0,
                     int reverse, int flags, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Persistent, weight-stationary form of ptv_gru_seq_fwd / ptv_gru_seq_bwd for the small-M chains (the 32-step
+ * dec_time_gru ptvae.py:461-462, the encoder bi-GRUs ptvae.py:23,116, the chord decoder ptvae.py:64-65):
+ * ONE launch walks all T steps of up to 4 independent chains (e.g. both directions of a bi-GRU).  A workgroup
+ * keeps its W_hh slice in LDS and the state of its own cells in registers for the whole sequence; per step only
+ * the bf16 MFMA operand (h_s, or dgh_s in the BPTT) is exchanged between the workgroups of one row group
+ * (write-through stores + arrival counter + L1-bypassing loads).  bf16 precision / bf16 storage only:
+ *   gi, gi2, gates, dgi, dgh are bf16; w_hh16 = bf16 W_hh [3H,H]; w_t16 = bf16 W_hh^T [H,3H]; hall fp32 + hall16.
+ * Same tensor layouts and semantics as ptv_gru_seq_fwd / ptv_gru_seq_bwd (dgi by time, dgh by processing step).
+ * All array arguments are HOST arrays of NC entries (device pointers / strides per chain).
+ * `xch`: per chain a bf16 scratch tensor for the exchanged operand, (T+1)*M*H elements (forward) / T*M*3H (backward),
+ *   held K-blocked [step][k/8][row][8] so that the consumers' MFMA-fragment loads are contiguous across lanes.
+ * `sync`: 16 * (1 + 32) device words ZEROED by the caller on `stream` before the call: word 0 = error flag (non-zero
+ *   after the launch = a bounded spin gave up, results invalid), word 16*(1+g) = arrival counter of row group g.
+ * Returns PTV_ERR_UNSUPPORTED (-3) when the shape does not fit one workgroup per CU (H % 256, H <= 1024,
+ * rows per workgroup <= 256): the caller then uses the per-step entry points.  At most ONE persistent launch may
+ * be in flight on the device at a time (chain them with events across streams).
+ */
+int ptv_gru_persist_supported(int NC, int M, int H);
+/* how consumers read the exchanged operand: 0 = sc1 loads, 1 = nt loads, 2 = plain loads behind one agent acquire per step */
+int ptv_gru_persist_load_policy(int lp);
+int ptv_gru_persist_fwd(int NC, int M, int H, int T,
+                        const void* const* gi, const long* gi_step, const long* gi_ld,
+                        const void* const* gi2, const long* gi2_step, const long* gi2_ld,
+                        const void* const* w_hh16, const float* const* b_hh,
+                        float* const* hall, void* const* hall16, void* const* gates,
+                        const int* const* lengths, const int* reverse, void* const* xch, unsigned* sync, void* stream);
+int ptv_gru_persist_bwd(int NC, int M, int H, int T,
+                        const float* const* hall, const void* const* gates, const void* const* w_t16,
+                        const void* const* dh_ext, const long* ext_step, const long* ext_ld, const int* ext_bf16,
+                        const float* const* dh_last, const long* last_ld,
+                        void* const* dgi, void* const* dgh, float* const* dh0,
+                        const int* reverse, void* const* xch, unsigned* sync, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Streaming helpers (layout shuffles and reductions that torch would do with cat/transpose/sum).

@@ -7,6 +7,7 @@
 #define PTV_OK 0
 #define PTV_ERR_ARG (-1)
 #define PTV_ERR_LAUNCH (-2)
+#define PTV_ERR_UNSUPPORTED (-3)   // shape / device outside what a specialised kernel handles: caller uses the generic path
 
 #define PTV_PREC_F32 0
 #define PTV_PREC_BF16 1

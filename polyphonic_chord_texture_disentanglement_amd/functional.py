@@ -7,14 +7,23 @@ sees one contiguous matrix; API tensors are converted at the boundary (Transpose
 
 Reference call sites are cited per function (paths are into /root/reference).
 """
+import ctypes
+import os
+
 import torch
 
-from ._lib import call, lib, prec_code, ptr, stream_ptr
+from ._lib import call, check, lib, prec_code, ptr, stream_ptr
 
 F32 = torch.float32
 BF16 = torch.bfloat16
 FUSED_DUR = True            # bf16 precision, H = 64: the 5-step duration GRU runs as one kernel (csrc/dur.hip)
 BF16_STORAGE = True         # bf16 precision: tensors that only feed MFMA operands / epilogues live as bf16 in HBM
+# bf16 precision: small-M recurrences as ONE persistent launch per sequence (csrc/gru_persist.hip).  'auto': where the
+# recurrence is the critical path -- rows <= PERSIST_MAX_ROWS, or no backward pass to overlap with (inference).  At
+# B = 512 the train step is throughput-bound: the per-step kernels leave the CUs to the weight-gradient products that
+# run beside them on sibling streams, a persistent grid does not (measured: DESIGN.md section 4).
+PERSIST = os.environ.get('PTV_PERSIST', 'auto')            # 'auto' | '1' | '0'
+PERSIST_MAX_ROWS = 256
 
 
 def _empty(*shape, dev, dtype=F32):
@@ -137,12 +146,128 @@ def _gru_flags(gates=None, gi=None, gi2=None, dg=None, w=None, ext=None):
     return _bf(gates) | (_bf(gi) << 1) | (_bf(gi2) << 2) | (_bf(dg) << 3) | (_bf(w) << 4) | (_bf(ext) << 6)
 
 
+# ---------------------------------------------------------------------------------------------
+# persistent weight-stationary recurrences (csrc/gru_persist.hip): one launch per sequence (or per pair of
+# bi-GRU directions).  A persistent grid spins on arrival counters, so two of them must never be half-resident at
+# the same time: every launch waits for the event of the previous one, whatever stream that ran on.
+# ---------------------------------------------------------------------------------------------
+_PERSIST_LAST = {}          # device index -> event recorded after the last persistent launch
+_PERSIST_SYNC = []          # (sync words, error index) of recent launches, for persist_check()
+_PERSIST_OK = {}
+
+
+def _parr(ts):
+    return (ctypes.c_void_p * len(ts))(*[(t.data_ptr() if t is not None else None) for t in ts])
+
+
+def _larr(vs):
+    return (ctypes.c_long * len(vs))(*[int(v) for v in vs])
+
+
+def _iarr(vs):
+    return (ctypes.c_int * len(vs))(*[int(v) for v in vs])
+
+
+def persist_supported(NC, M, H):
+    mode = str(PERSIST).lower()
+    if mode in ('0', 'false', 'off') or torch.cuda.is_current_stream_capturing():
+        return False
+    if mode == 'auto' and M > PERSIST_MAX_ROWS and torch.is_grad_enabled():
+        return False
+    key = (NC, M, H, torch.cuda.current_device())
+    if key not in _PERSIST_OK:
+        _PERSIST_OK[key] = bool(lib().ptv_gru_persist_supported(NC, M, H))
+    return _PERSIST_OK[key]
+
+
+class _PersistTurn:
+    """with _PersistTurn(): <one persistent launch on the current stream>"""
+
+    def __enter__(self):
+        self.cur = torch.cuda.current_stream()
+        ev = _PERSIST_LAST.get(self.cur.device.index)
+        if ev is not None:
+            self.cur.wait_event(ev)
+        return self
+
+    def __exit__(self, *exc):
+        ev = torch.cuda.Event()
+        ev.record(self.cur)
+        _PERSIST_LAST[self.cur.device.index] = ev
+        return False
+
+
+def _persist_sync(NC, dev):
+    """zeroed sync words of one launch: word 0 = error flag, word 16*(1+g) = arrival counter of row group g"""
+    sync = torch.zeros(16 * 33, device=dev, dtype=torch.int32)
+    _PERSIST_SYNC.append(sync)
+    if len(_PERSIST_SYNC) > 64:
+        del _PERSIST_SYNC[:32]
+    return sync
+
+
+def persist_check():
+    """raises if a bounded spin of a recent persistent launch gave up (synchronises: tests / the end of a bench)"""
+    bad = [i for i, sw in enumerate(_PERSIST_SYNC) if int(sw[0].item()) != 0]
+    del _PERSIST_SYNC[:]
+    if bad:
+        raise RuntimeError('persistent GRU launch gave up waiting for its row group (recent launches %s)' % bad)
+
+
+def gru_persist_fwd(M, H, T, chains):
+    """chains: dicts with gi (bf16 [T,M,3H] view), gi_step, gi_ld, gi2, gi2_step, gi2_ld, w16 (bf16 [3H,H]), b_hh, hall, hall16,
+    gates (bf16 or None), lengths, reverse.  One launch for all of them."""
+    NC = len(chains)
+    g = lambda k: [c.get(k) for c in chains]
+    dev = chains[0]['hall'].device
+    sync = _persist_sync(NC, dev)
+    xch = [torch.empty((T + 1) * M * H, device=dev, dtype=BF16) for _ in chains]     # exchanged operand, K-blocked
+    with _PersistTurn():
+        rc = lib().ptv_gru_persist_fwd(NC, M, H, T, _parr(g('gi')), _larr(g('gi_step')), _larr(g('gi_ld')),
+                                       _parr(g('gi2')), _larr([c.get('gi2_step', 0) for c in chains]),
+                                       _larr([c.get('gi2_ld', 0) for c in chains]), _parr(g('w16')), _parr(g('b_hh')),
+                                       _parr(g('hall')), _parr(g('hall16')), _parr(g('gates')), _parr(g('lengths')),
+                                       _iarr([int(bool(c.get('reverse'))) for c in chains]), _parr(xch), ptr(sync), stream_ptr())
+    check(rc, 'ptv_gru_persist_fwd')
+
+
+def gru_persist_bwd(M, H, T, chains):
+    """chains: dicts with hall, gates, wt16 (bf16 W_hh^T [H,3H]), dh_ext ([T,M,H] fp32/bf16 view or None), dh_last, dgi, dgh,
+    dh0 (or None), reverse"""
+    NC = len(chains)
+    g = lambda k: [c.get(k) for c in chains]
+    ext = g('dh_ext')
+    last = g('dh_last')
+    dev = chains[0]['hall'].device
+    sync = _persist_sync(NC, dev)
+    xch = [torch.empty(T * M * 3 * H, device=dev, dtype=BF16) for _ in chains]
+    with _PersistTurn():
+        rc = lib().ptv_gru_persist_bwd(NC, M, H, T, _parr(g('hall')), _parr(g('gates')), _parr(g('wt16')),
+                                       _parr(ext), _larr([e.stride(0) if e is not None else 0 for e in ext]),
+                                       _larr([e.stride(1) if e is not None else 0 for e in ext]),
+                                       _iarr([_bf(e) for e in ext]),
+                                       _parr(last), _larr([l.stride(0) if l is not None else 0 for l in last]),
+                                       _parr(g('dgi')), _parr(g('dgh')), _parr(g('dh0')),
+                                       _iarr([int(bool(c.get('reverse'))) for c in chains]), _parr(xch), ptr(sync), stream_ptr())
+    check(rc, 'ptv_gru_persist_bwd')
+
+
+def _persist_fwd_ok(prec, M, H, T, gi, gi2, gates, gi_idx, hall16, w16, NC=1):
+    return (prec == 1 and T >= 2 and hall16 is not None and gi.dtype == BF16 and (gi2 is None or gi2.dtype == BF16)
+            and (gates is None or gates.dtype == BF16) and gi_idx is None and w16 is not None and w16.dtype == BF16
+            and persist_supported(NC, M, H))
+
+
 def gru_fwd(prec, gi, gi_step, gi_ld, w_hh, b_hh, hall, gates, *, gi2=None, gi2_step=0, gi2_ld=0, lengths=None,
             reverse=False, gi_idx=None, T=None, hall16=None, skip_cast0=False):
     T1, M, H = hall.shape
     T = T1 - 1 if T is None else T
     if hall16 is not None:
         w_hh = _W(w_hh, prec)
+    if not skip_cast0 and _persist_fwd_ok(prec, M, H, T, gi, gi2, gates, gi_idx, hall16, w_hh):
+        return gru_persist_fwd(M, H, T, [dict(gi=gi, gi_step=gi_step, gi_ld=gi_ld, gi2=gi2, gi2_step=gi2_step, gi2_ld=gi2_ld,
+                                              w16=w_hh, b_hh=b_hh, hall=hall, hall16=hall16, gates=gates, lengths=lengths,
+                                              reverse=reverse)])
     call('ptv_gru_seq_fwd', prec, M, H, T, ptr(gi), gi_step, gi_ld, ptr(gi2), gi2_step, gi2_ld, ptr(w_hh),
          ptr(b_hh), ptr(hall), ptr(hall16), ptr(gates), ptr(lengths), int(reverse), ptr(gi_idx),
          _gru_flags(gates, gi, gi2, w=w_hh) | (32 if skip_cast0 else 0), stream_ptr())
@@ -168,6 +293,11 @@ def gru_bwd(prec, hall, gates, w_hh, *, dh_ext=None, dh_last=None, lr=None, reve
     lra = (ptr(lr[0]), lr[1], lr[2], lr[3], ptr(lr[4])) if lr is not None else (None, 0, 0, 0, None)
     if dt == BF16:
         wt = _WT(w_hh, prec)                  # W_hh^T [H,3H] bf16: K-contiguous weight tiles for the BPTT products
+        if (wt is not None and lr is None and T >= 2 and gates.dtype == BF16 and persist_supported(1, M, H)
+                and (dh_ext is None or dh_ext.stride(2) == 1)):
+            gru_persist_bwd(M, H, T, [dict(hall=hall, gates=gates, wt16=wt, dh_ext=dh_ext, dh_last=dh_last, dgi=dgi, dgh=dgh,
+                                           dh0=dh0, reverse=reverse)])
+            return dgi, dgh, dh0
         w_hh = wt if wt is not None else w_hh
     call('ptv_gru_seq_bwd', prec, M, H, T, ptr(hall), ptr(gates), ptr(w_hh), *ext, *last, *lra, ptr(dgi),
          ptr(dgh), ptr(dhz), ptr(dh0), int(reverse), _gru_flags(gates, dg=dgi, w=w_hh, ext=dh_ext), stream_ptr())
@@ -237,6 +367,13 @@ def _join_deferred():
     for s, _keep in _DEFERRED:
         cur.wait_stream(s)
     _DEFERRED.clear()
+
+
+def reset_deferred():
+    """join whatever deferred side-stream work is still registered (a backward pass that raised never ran its end-of-pass
+    callback): called by FusedClipAdam.zero_grad() and by the first node of every backward pass (VaeLossFn)"""
+    if _DEFERRED:
+        _join_deferred()
 
 
 def _gbuf(p):
@@ -395,6 +532,26 @@ def _bigru_forward(prec, x3, lengths, w):
         copy2d(out[:, d * H:(d + 1) * H], hall[T])
         return hall, gates, h16
 
+    adt = _act_dtype(prec, H)
+    w16 = [_W(w[1], prec), _W(w[5], prec)]
+    if prec == 1 and T >= 2 and adt == BF16 and w16[0].dtype == BF16 and w16[1].dtype == BF16 and persist_supported(2, M, H):
+        # both directions in ONE persistent launch (csrc/gru_persist.hip): per step the two chains share the exchange latency
+        chains, saved = [], []
+        for d in range(2):
+            w_ih, w_hh, b_ih, b_hh = w[4 * d: 4 * d + 4]
+            gi = gemm(xf, _W(w_ih, prec), bias=b_ih, prec=prec, out_dtype=adt)
+            hall = _empty(T + 1, M, H, dev=dev)
+            hall[0].zero_()
+            h16 = _hall16(prec, T + 1, M, H, dev)
+            gates = _empty(T, 4, M, H, dev=dev, dtype=adt)
+            chains.append(dict(gi=gi, gi_step=M * 3 * H, gi_ld=3 * H, w16=w16[d], b_hh=b_hh, hall=hall, hall16=h16, gates=gates,
+                               lengths=lengths, reverse=bool(d)))
+            saved.append((hall, gates, h16))
+        gru_persist_fwd(M, H, T, chains)
+        for d in range(2):
+            copy2d(out[:, d * H:(d + 1) * H], saved[d][0][T])
+        return out, saved
+
     side = Side(7)
     rev = side(lambda: direction(1), xf, out)
     fwd = direction(0)
@@ -421,9 +578,36 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
         dx = gemm_dx(dgi2, w_ih, prec=prec) if need_dx else None
         return [dw_ih, dw_hh, db_ih, db_hh], dx
 
+    def products(d, dgi, dgh):
+        w_ih, w_hh, b_ih, b_hh = w[4 * d: 4 * d + 4]
+        hall, gates, h16 = saved[d]
+        dgi2, dgh2 = dgi.view(T * M, 3 * H), dgh.view(T * M, 3 * H)
+        dw_ih = gemm(dgi2, xf, _gbuf(w_ih), ta=True, tb=True, acc=True, prec=prec)
+        dw_hh = gemm(dgh2, (h16 if h16 is not None else hall)[:T].view(T * M, H), _gbuf(w_hh), ta=True, tb=True, acc=True,
+                     prec=prec)
+        db_ih = _bgrad(b_ih, dgi2)
+        db_hh = _bgrad_hh(b_hh, dgh2, db_ih)
+        dx = gemm_dx(dgi2, w_ih, prec=prec) if need_dx else None
+        return [dw_ih, dw_hh, db_ih, db_hh], dx
+
     side = Side(7)
-    g1, dx1 = side(lambda: direction(1), xf, dout)
-    g0, dx0 = direction(0)
+    wts = [_WT(w[1], prec), _WT(w[5], prec)]
+    adt = _act_dtype(prec, H)
+    if (T >= 2 and adt == BF16 and wts[0] is not None and wts[1] is not None and saved[0][1].dtype == BF16
+            and saved[0][2] is not None and persist_supported(2, M, H)):
+        # BPTT of both directions in ONE persistent launch, then the weight-gradient products of the two on sibling streams
+        chains = []
+        for d in range(2):
+            hall, gates, h16 = saved[d]
+            chains.append(dict(hall=hall, gates=gates, wt16=wts[d], dh_ext=None, dh_last=dout[:, d * H:(d + 1) * H],
+                               dgi=_empty(T, M, 3 * H, dev=x3.device, dtype=adt), dgh=_empty(T, M, 3 * H, dev=x3.device, dtype=adt),
+                               dh0=None, reverse=bool(d)))
+        gru_persist_bwd(M, H, T, chains)
+        g1, dx1 = side(lambda: products(1, chains[1]['dgi'], chains[1]['dgh']), xf, dout, chains[1]['dgi'], chains[1]['dgh'])
+        g0, dx0 = products(0, chains[0]['dgi'], chains[0]['dgh'])
+    else:
+        g1, dx1 = side(lambda: direction(1), xf, dout)
+        g0, dx0 = direction(0)
     side.join()
     if need_dx:
         copy2d(dx0, dx1, acc=True)
@@ -801,7 +985,14 @@ class DecoderTFFn(torch.autograd.Function):
             bgrad('z2dec_in_linear.bias', dz_in)
         side(time_wgrads, dgi_t, dgh_t, dZG, dTOKS, dzhid, dz_in, dNS)
 
-        side.defer()                             # parameter gradients only: joined when the backward pass ends
+        # parameter gradients only: joined when the backward pass ends -- but only if autograd ADOPTS the tensors
+        # (p.grad is None and the buffer is this step's arena view); an accumulation `p.grad += g` would run on this
+        # node's stream without a dependency on the side stream
+        from .optim import is_arena_view
+        if all(P[n].grad is None and is_arena_view(P[n], G[n]) for n in DEC_PARAM_NAMES):
+            side.defer()
+        else:
+            side.join()
         return (dz, demb.view(16, 32, B, E), dxs, None, None) + tuple(G[n] for n in DEC_PARAM_NAMES)
 
 
@@ -986,6 +1177,7 @@ class VaeLossFn(torch.autograd.Function):
         sm_p, sm_c = ctx.sm
         dev = pitch_m.device
         st = stream_ptr()
+        reset_deferred()                        # first node of the backward pass: nothing may be left from an aborted one
         gs = _empty(8, dev=dev)
         call('ptv_loss_bwd_scales', ptr(gout.contiguous()), ptr(counts), *ctx.scal, ptr(gs), st)
         dpitch, ddur = _pianotree_ce_bwd(pitch_m, dur_m, sm_p, pitch_t, dur_t, gs, st)

@@ -78,6 +78,7 @@ def weight_shadow(p):
     if opt is None or ent[2] != p.numel() or not p.is_contiguous():
         return None
     off = ent[1]
+    opt.refresh_shadow_if_stale()
     if off in opt._row_padded:                       # rows not a multiple of 8 elements: separate row-padded copy
         return opt._row_padded[off][1][:, :p.shape[1]]
     return opt.flat_p16[off:off + p.numel()].view(p.shape)
@@ -93,11 +94,15 @@ def weight_shadow_t(p):
     off = ent[1]
     if off not in opt._mat_offsets:
         return None
+    opt.refresh_shadow_if_stale()
     return opt.flat_pT16[off:off + p.numel()].view(p.shape[1], p.shape[0])
 
 
 def refresh_weight_shadows():
-    """re-cast every registered flat parameter buffer (called at the start of each forward)"""
+    """bring the bf16 operand copies of every registered flat parameter buffer up to date (called at the start of each
+    forward / inference entry point, on the caller's stream, before work forks to sibling streams).  A no-op when the
+    parameters have not changed since the last cast: the copies carry a stamp (optimiser step count + the parameters'
+    in-place version counters, which `load_state_dict` / `copy_` / `uniform_` bump)."""
     live = {}
     for key, e in list(_SHADOW_OF.items()):
         opt = e[0]()
@@ -106,7 +111,15 @@ def refresh_weight_shadows():
         else:
             live[id(opt)] = opt
     for opt in live.values():
-        opt.refresh_shadow()
+        opt.refresh_shadow_if_stale()
+
+
+def is_arena_view(p, g):
+    """g is the gradient view the arena handed out for parameter p in this step"""
+    a = _ARENA_OF.get(id(p))
+    if a is None or g is None:
+        return False
+    return g.data_ptr() == a.flat.data_ptr() + 4 * a.offsets[a._index[id(p)]]
 
 
 def grad_buffer(p):
@@ -145,14 +158,28 @@ class FusedClipAdam(torch.optim.Optimizer):
                             for p, o in zip(ps, self.arena.offsets) if p.dim() == 2 and p.shape[1] % 8 != 0 and p.shape[1] >= 64}
         for p, o in zip(ps, self.arena.offsets):
             _SHADOW_OF[p.data_ptr()] = (weakref.ref(self), o, p.numel())
-        self.refresh_shadow()
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.sumsq = torch.zeros(1, device=ps[0].device, dtype=torch.float32)
         self.step_count = 0
+        self._dirty = 0
+        self._shadow_stamp = None
         self.grad_scale = 1.0           # set to 1/world_size when the bucket holds a SUM over ranks
+        self.refresh_shadow()
+
+    def _stamp(self):
+        return (self.step_count, self._dirty, sum(p._version for p in self.arena.params))
+
+    def mark_dirty(self):
+        """call after writing parameters through a path torch cannot see (raw pointers, `.data` tricks)"""
+        self._dirty += 1
+
+    def refresh_shadow_if_stale(self):
+        if self._shadow_stamp != self._stamp():
+            self.refresh_shadow()
 
     def refresh_shadow(self):
+        self._shadow_stamp = self._stamp()
         st = stream_ptr()
         call('ptv_cast_bf16', ptr(self.flat_p), ptr(self.flat_p16), self.arena.total, st)
         if self._mats:                                           # transposed copies of the matrices: one launch
@@ -168,9 +195,36 @@ class FusedClipAdam(torch.optim.Optimizer):
             buf[:, :p.shape[1]].copy_(p.data)
 
     def zero_grad(self, set_to_none=True):
+        from .functional import reset_deferred
+        reset_deferred()                   # side-stream gradient work of an earlier (possibly aborted) backward
         for p in self.arena.params:
             p.grad = None
         self.arena.zero()
+
+    # ---- checkpointing: Adam moments and the step count live outside torch's per-parameter `state`, so the generic
+    # Optimizer.state_dict() would lose them (the reference saves weights only, module.py:179-183)
+    def state_dict(self):
+        n = [p.numel() for p in self.arena.params]
+        unpad = lambda flat: torch.cat([flat[o:o + k] for o, k in zip(self.arena.offsets, n)]).cpu()
+        g = self.param_groups[0]
+        return {'format': 'FusedClipAdam/1', 'step_count': self.step_count, 'lr': g['lr'], 'betas': tuple(g['betas']),
+                'eps': g['eps'], 'initial_lr': g.get('initial_lr'), 'numel': n,
+                'exp_avg': unpad(self.exp_avg), 'exp_avg_sq': unpad(self.exp_avg_sq)}
+
+    def load_state_dict(self, state):
+        assert state.get('format') == 'FusedClipAdam/1', 'not a FusedClipAdam state'
+        n = [p.numel() for p in self.arena.params]
+        assert list(state['numel']) == n, 'optimizer state belongs to a different parameter list'
+        off = 0
+        for o, k in zip(self.arena.offsets, n):
+            self.exp_avg[o:o + k].copy_(state['exp_avg'][off:off + k])
+            self.exp_avg_sq[o:o + k].copy_(state['exp_avg_sq'][off:off + k])
+            off += k
+        self.step_count = int(state['step_count'])
+        g = self.param_groups[0]
+        g['lr'], g['betas'], g['eps'] = float(state['lr']), tuple(state['betas']), float(state['eps'])
+        if state.get('initial_lr') is not None:
+            g['initial_lr'] = float(state['initial_lr'])
 
     def grad_norm(self):
         """pre-clip global L2 norm of the last step (device tensor; reading it syncs)"""

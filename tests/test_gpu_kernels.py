@@ -167,3 +167,90 @@ def test_gru_seq_bf16_storage_fast_path(M, H, T, use_gi2):
     assert (dgi.float().cpu() - gi.grad).abs().max() < tol * max(1.0, gi.grad.abs().max().item())
     db = dgh.float().sum((0, 1)).cpu()
     assert (db - b_hh.grad).abs().max() < tol * max(1.0, b_hh.grad.abs().max().item())
+
+
+@pytest.mark.parametrize('NC,M,H,T,masked,use_gi2', [(1, 512, 1024, 6, False, True), (2, 512, 1024, 4, True, False),
+                                                     (1, 512, 512, 8, False, True), (1, 1024, 1024, 3, False, False),
+                                                     (1, 300, 512, 5, True, False), (2, 100, 1024, 3, False, True),
+                                                     (4, 512, 1024, 3, False, False)])
+def test_gru_persistent_kernels_vs_oracle_and_step_kernels(NC, M, H, T, masked, use_gi2):
+    """csrc/gru_persist.hip (one weight-stationary launch per sequence, state exchanged between workgroups per step)
+    against the fp32 oracle cell and against the per-step kernels of csrc/gru.hip on the same bf16 operands: forward
+    states + saved gates, BPTT dgi / dgh / dh0; NC chains per launch, reversed chains, masked rows, ragged M."""
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    from polyphonic_chord_texture_disentanglement_amd._lib import call, lib, ptr, stream_ptr
+    dev = _dev()
+    bf = torch.bfloat16
+    if not lib().ptv_gru_persist_supported(NC, M, H):
+        pytest.skip('shape does not fit one workgroup per CU on this device')
+    import os
+    if 'PTV_LP' in os.environ:                       # experiment switch: how consumers read the exchanged operand
+        lib().ptv_gru_persist_load_policy(int(os.environ['PTV_LP']))
+    g = torch.Generator().manual_seed(NC * 1000 + M + H + T)
+    k = 1.0 / np.sqrt(H)
+    d = lambda t: t.detach().to(dev)
+    fw, bw, ref = [], [], []
+    for ci in range(NC):
+        reverse = bool(ci & 1)
+        w_hh = ((torch.rand(3 * H, H, generator=g) * 2 - 1) * k).to(bf).float().requires_grad_()
+        b_hh = ((torch.rand(3 * H, generator=g) * 2 - 1) * k).requires_grad_()
+        gi = (torch.randn(T, M, 3 * H, generator=g) * 0.5).to(bf).float().requires_grad_()
+        gi2 = (torch.randn(M, 3 * H, generator=g) * 0.5).to(bf).float() if use_gi2 else None
+        h0 = (torch.randn(M, H, generator=g) * 0.5).requires_grad_()
+        lengths = torch.randint(1, T + 1, (M,), generator=g) if masked else None
+        dh_ext = torch.randn(T, M, H, generator=g) * 0.1
+        dh_last = torch.randn(M, H + 8, generator=g)[:, :H] * 0.1              # strided rows
+        h, hs = h0, []
+        for s_ in range(T):
+            t = T - 1 - s_ if reverse else s_
+            x = gi[t] + (gi2 if use_gi2 else 0)
+            gh = orc.linear(h, w_hh, b_hh)
+            r = torch.sigmoid(x[:, :H] + gh[:, :H]); z = torch.sigmoid(x[:, H:2 * H] + gh[:, H:2 * H])
+            n = torch.tanh(x[:, 2 * H:] + r * gh[:, 2 * H:])
+            nh = (1 - z) * n + z * h
+            h = nh if lengths is None else torch.where((t < lengths).unsqueeze(1), nh, h)
+            hs.append(h)
+        hs = torch.stack(hs)
+        ((hs * dh_ext).sum() + (hs[-1] * dh_last).sum()).backward()
+        ref.append((hs.detach(), h0.grad, gi.grad, b_hh.grad))
+        hall = torch.zeros(T + 1, M, H, device=dev); hall[0] = d(h0)
+        c = dict(gi=d(gi).to(bf), gi_step=M * 3 * H, gi_ld=3 * H, gi2=d(gi2).to(bf) if use_gi2 else None, gi2_step=0,
+                 gi2_ld=3 * H if use_gi2 else 0, w16=d(w_hh).to(bf).contiguous(), b_hh=d(b_hh), hall=hall,
+                 hall16=torch.zeros(T + 1, M, H, device=dev, dtype=bf), gates=torch.zeros(T, 4, M, H, device=dev, dtype=bf),
+                 lengths=lengths.int().to(dev) if masked else None, reverse=reverse)
+        fw.append(c)
+        de = dh_ext.to(dev)
+        dl = torch.zeros(M, H + 8, device=dev); dl[:, :H] = dh_last.to(dev)
+        bw.append(dict(hall=hall, gates=c['gates'], wt16=d(w_hh).t().contiguous().to(bf), dh_ext=de, dh_last=dl[:, :H],
+                       dgi=torch.zeros(T, M, 3 * H, device=dev, dtype=bf), dgh=torch.zeros(T, M, 3 * H, device=dev, dtype=bf),
+                       dh0=torch.zeros(M, H, device=dev), reverse=reverse))
+    F_.gru_persist_fwd(M, H, T, fw)
+    F_.gru_persist_bwd(M, H, T, bw)
+    F_.persist_check()
+    for ci in range(NC):
+        c, b = fw[ci], bw[ci]
+        hs, dh0_ref, dgi_ref, dbhh_ref = ref[ci]
+        assert (c['hall'][1:].cpu() - hs).abs().max() < 3e-2
+        assert (c['hall16'][1:].float() - c['hall'][1:]).abs().max() < 1e-2
+        tol = 0.05
+        assert (b['dh0'].cpu() - dh0_ref).abs().max() < tol * max(1.0, dh0_ref.abs().max().item())
+        assert (b['dgi'].float().cpu() - dgi_ref).abs().max() < tol * max(1.0, dgi_ref.abs().max().item())
+        db = b['dgh'].float().sum((0, 1)).cpu()
+        assert (db - dbhh_ref).abs().max() < tol * max(1.0, dbhh_ref.abs().max().item())
+        # the per-step kernels on the same operands: same arithmetic up to summation order / bf16 rounding of the state
+        hall2 = torch.zeros_like(c['hall']); hall2[0] = c['hall'][0]
+        h16_2 = torch.zeros_like(c['hall16']); gates2 = torch.zeros_like(c['gates'])
+        FL = 1 | 2 | 8 | 16 | (4 if use_gi2 else 0)
+        call('ptv_gru_seq_fwd', 1, M, H, T, ptr(c['gi']), M * 3 * H, 3 * H, ptr(c['gi2']), 0, c['gi2_ld'], ptr(c['w16']), ptr(c['b_hh']),
+             ptr(hall2), ptr(h16_2), ptr(gates2), ptr(c['lengths']), int(c['reverse']), None, FL, stream_ptr())
+        assert (hall2 - c['hall']).abs().max() < 2e-2
+        assert (gates2.float() - c['gates'].float()).abs().max() < 3e-2
+        dgi2 = torch.zeros_like(b['dgi']); dgh2 = torch.zeros_like(b['dgh'])
+        dhz = torch.empty(2, M, H, device=dev); dh02 = torch.empty(M, H, device=dev)
+        de, dl = b['dh_ext'], b['dh_last']
+        call('ptv_gru_seq_bwd', 1, M, H, T, ptr(c['hall']), ptr(c['gates']), ptr(b['wt16']), ptr(de), de.stride(0), de.stride(1),
+             ptr(dl), dl.stride(0), None, 0, 0, 0, None, ptr(dgi2), ptr(dgh2), ptr(dhz), ptr(dh02), int(c['reverse']), FL, stream_ptr())
+        sc = max(1.0, dgi_ref.abs().max().item())
+        assert (dgi2.float() - b['dgi'].float()).abs().max() < 0.03 * sc
+        assert (dgh2.float() - b['dgh'].float()).abs().max() < 0.03 * sc
+        assert (dh02 - b['dh0']).abs().max() < 0.03 * max(1.0, dh0_ref.abs().max().item())
