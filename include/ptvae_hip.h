@@ -182,6 +182,10 @@ int ptv_txt_conv_relu_pool_bwd(const float* pr_mat, const float* w, const float*
  *      (lv = log sd is the linear_var output, ptvae.py:27,120); any of dz/eps/ext may be NULL;
  *      mul_sd = 0 returns dsd itself in `dlv`.
  */
+/* eps for the reparameterisation as a pure function of (seed, stream_id, GLOBAL sample index row_offset + r, column):
+ * Philox4x32-10 + Box-Muller.  The same batch gives the same noise however it is sharded over ranks (SURVEY.md 8 d/e). */
+int ptv_philox_normal(float* out, long rows, int Z, unsigned long long seed, unsigned long long stream_id, long row_offset,
+                      void* stream);
 int ptv_reparam_kl_fwd(const float* mu, const float* sd, const float* eps, float* z, long ldz, float* kl_sum, int B, int Z, void* stream);
 int ptv_reparam_kl_bwd(const float* mu, const float* sd, const float* eps, const float* dz, long lddz,
                        const float* dmu_ext, const float* dsd_ext, float klw, int mul_sd, float* dmu, float* dlv, int B, int Z, void* stream);
@@ -201,6 +205,19 @@ int ptv_chord_targets(const float* c, int B, int step_major, int* root_t, int* c
 int ptv_ce_fwd(const float* logits, long ld, const int* targets, long rows, int C, int ignore_index, float* nll_sum, void* stream);
 int ptv_ce_bwd(const float* logits, long ld, const int* targets, long rows, int C, int ignore_index, const float* gscale,
                float* dlogits, long ldd, void* stream);
+/* weighted duration loss (recon_loss(..., weighted_dur=True), ptvae.py:512-527): the 5 duration bit positions are 5 separate
+ * CrossEntropyLoss(ignore_index = 2) means combined with weights (1, .6, .4, .3, .3).  Row r of the [rows*5, 2] logits
+ * belongs to group r % G: per-group nll sums / valid counts (fwd), per-group gradient scales (bwd).
+ * ptv_wdur_finalize folds them into (sums1 = dl, counts1 = 1) so ptv_loss_finalize / ptv_loss_bwd_scales apply unchanged;
+ * ptv_wdur_scales turns the upstream scale of dl into the 5 per-group scales gs1 * w[d] / cnt[d]. */
+int ptv_ce_group_fwd(const float* logits, long ld, const int* targets, long rows, int C, int ignore_index, int G,
+                     float* nll_sum, int* count, void* stream);
+int ptv_ce_group_bwd(const float* logits, long ld, const int* targets, long rows, int C, int ignore_index, int G,
+                     const float* gscale, float* dlogits, long ldd, void* stream);
+int ptv_wdur_finalize(const float* gsum5, const int* gcnt5, float w0, float w1, float w2, float w3, float w4, float* sums1,
+                      int* counts1, void* stream);
+int ptv_wdur_scales(const float* gs1, const int* gcnt5, float w0, float w1, float w2, float w3, float w4, float* out5,
+                    void* stream);
 int ptv_kl_fwd(const float* mu, const float* sd, long n, float* kl_sum, void* stream);
 int ptv_kl_bwd(const float* mu, const float* sd, long n, const float* gscale, float* dmu, float* dsd, void* stream);
 int ptv_loss_finalize(const float* sums, const int* counts, float beta, float w0, float w1, float n_kl, float n_root,
@@ -267,6 +284,21 @@ int ptv_note_token(const float* pitch, long ld_pitch, const int* dur_idx, long d
                    const int* force_pitch, int M, void* stream);
 int ptv_chord_token(const float* root, const float* chroma, const float* bass, unsigned* masks2, float* token, int B, void* stream);
 int ptv_route_slices(const float* src, float* dstA, float* dstB, const int* mask, long slice_elems, int nslices, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Data contract on device: what ArrangementDataset.__getitem__ (dataset.py:88-112) does per item
+ * with converter.py:65-68 (augment_pr), :78-113 (pr_to_onehot_pr + piano_roll_to_target), :116-147 (target_to_3dtarget
+ * with the arguments of dataset.py:98-104) and :150-164 (expand_chord), for a whole batch in one launch.
+ *   pr      [N,32,128] uint8 accompaniment piano-rolls (2 onset, 1 sustain, 0 silence; converter.py:35-47)
+ *   chord14 [N,8,14] float  raw chords [root, 12 chroma bits, bass]
+ *   index[B] (NULL = identity) picks the item of sample b, shift[B] (NULL = 0) its transposition in semitones
+ *   -> pr_mat [B,32,128] f32, x [B,32,16,6] int64, c [B,8,36] f32;  *err |= 1 if a step held more than 14 onsets
+ *      (the reference raises IndexError there; the kernel keeps the lowest 14)
+ */
+int ptv_batch_transform(const unsigned char* pr, const float* chord14, const int* index, const int* shift,
+                        float* pr_mat, long* x, float* c, int* err, int B, void* stream);
+/* interp_path (model.py:216-242): out[b, i, :] = slerp between z1[b] and z2[b] at i/(n-1), norms interpolated geometrically */
+int ptv_slerp_path(const float* z1, const float* z2, float* out, int B, int D, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * clip_grad_norm_ (module.py:142-143) + torch.optim.Adam.step (train.py:50, scheduler.py:69-74) over

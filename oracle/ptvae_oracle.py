@@ -303,10 +303,15 @@ class Oracle:
 
     # ---- model.py:57-90, ptvae.py:498-529 ------------------------------------------------
     def loss_function(self, x, c, pitch_outs, dur_outs, dist_chd, dist_rhy, root, chroma, bass,
-                      beta, weights):
+                      beta, weights, weighted_dur=False):
         pl = cross_entropy(pitch_outs.reshape(-1, pitch_outs.shape[-1]),
                            x[:, :, 1:, 0].reshape(-1), PITCH_PAD)
-        dl = cross_entropy(dur_outs.reshape(-1, 2), x[:, :, 1:, 1:].reshape(-1), DUR_PAD)
+        if not weighted_dur:
+            dl = cross_entropy(dur_outs.reshape(-1, 2), x[:, :, 1:, 1:].reshape(-1), DUR_PAD)
+        else:                                  # ptvae.py:512-527: one ignore-index mean per bit position, fixed weights
+            rd = dur_outs.reshape(-1, DUR_WIDTH, 2)
+            gd = x[:, :, 1:, 1:].reshape(-1, DUR_WIDTH)
+            dl = sum(w * cross_entropy(rd[:, d, :], gd[:, d], DUR_PAD) for d, w in enumerate((1.0, 0.6, 0.4, 0.3, 0.3)))
         recon = weights[0] * pl + weights[1] * dl
         kl_chd = kl_with_normal(*dist_chd)
         kl_rhy = kl_with_normal(*dist_rhy)
@@ -330,6 +335,37 @@ class Oracle:
             po, do = self.decoder(torch.cat([z_chd, z_rhy], -1), True, None, None, 0.0, 0.0)
             est_x = torch.cat([po.max(-1)[1].unsqueeze(-1), do.max(-1)[1]], dim=-1)
         return est_x, po, do
+
+
+# ---- ptvae.py:125-215: PtvaeEncoder (params keyed like its state_dict) --------------------------
+def ptvae_encoder(p, x):
+    """x int64 [B,32,16,6] -> (mu, std, embedded [B,32,16,E], lengths [B,32])"""
+    o = Oracle.__new__(Oracle)
+    o.p = {'decoder.note_embedding.weight': p['note_embedding.weight'], 'decoder.note_embedding.bias': p['note_embedding.bias']}
+    o.p.update(p)
+    emb, lengths = o.emb_x(x)                                                 # :167-188 = the decoder's emb_x
+    B = x.shape[0]
+    E = emb.shape[-1]
+    notes = o._bigru_final('enc_notes_gru', emb.reshape(B * 32, 16, E), lengths.reshape(-1))      # :193-198 packed by length
+    h = o._bigru_final('enc_time_gru', notes.reshape(B, 32, -1))                                    # :200-202
+    mu = linear(h, p['linear_mu.weight'], p['linear_mu.bias'])
+    std = torch.exp(linear(h, p['linear_std.weight'], p['linear_std.bias']))                        # :204-205
+    return mu, std, emb, lengths
+
+
+# ---- model.py:218-242: interp_path (float64 numpy in the reference) --------------------------------
+def interp_path(z1, z2, n=10):
+    import numpy as np
+    z1 = np.asarray(z1, dtype=np.float64).reshape(-1)
+    z2 = np.asarray(z2, dtype=np.float64).reshape(-1)
+    n1, n2 = np.linalg.norm(z1), np.linalg.norm(z2)
+    p0, p1 = z1 / n1, z2 / n2
+    t = np.linspace(0.0, 1.0, n)
+    omega = np.arccos(np.dot(p0, p1))
+    so = np.sin(omega)
+    dirs = np.sin((1.0 - t) * omega)[:, None] / so * p0[None] + np.sin(t * omega)[:, None] / so * p1[None]
+    length = np.linspace(np.log(n1), np.log(n2), n)
+    return dirs * np.exp(length[:, None])
 
 
 # ---- optimiser / schedule restatements (SURVEY §8 a15, a16) -------------------------------

@@ -36,6 +36,8 @@ def _parse_header(path):
                     argtypes.append(ctypes.c_void_p)
                 elif a.startswith('double '):
                     argtypes.append(ctypes.c_double)
+                elif a.startswith('unsigned long long '):
+                    argtypes.append(ctypes.c_ulonglong)
                 elif a.startswith('long '):
                     argtypes.append(ctypes.c_long)
                 elif a.startswith('int '):
@@ -82,6 +84,9 @@ def ptr(t):
         return None
     assert t.is_cuda and t.dtype in (torch.float32, torch.bfloat16, torch.int32, torch.int64, torch.uint8), \
         'device fp32/int tensor expected, got %s %s' % (t.device, t.dtype)
+    # kernels are enqueued on the CURRENT device's stream (stream_ptr): a tensor of another device would be a wild pointer
+    assert t.device.index == torch.cuda.current_device(), \
+        'tensor on %s but the current device is cuda:%d (torch.cuda.set_device first)' % (t.device, torch.cuda.current_device())
     return ctypes.c_void_p(t.data_ptr())
 
 

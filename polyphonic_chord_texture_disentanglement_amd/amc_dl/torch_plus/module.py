@@ -68,6 +68,7 @@ class TrainingInterface:
         self.opt_scheduler, self.param_scheduler = opt_scheduler, param_scheduler
         self.epoch = self.train_step = self.val_step = 0
         self.grad_sync = None                          # dist.GradSync when data parallel
+        self._pending_logs = []
         self.__dict__.update(kwargs)
         if self.parallel and self.grad_sync is None:
             from ...dist import GradSync
@@ -118,10 +119,38 @@ class TrainingInterface:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), sched.clip)
             sched.step()
 
+    # ---- logging without stalling the pipeline.  The reference reads 22 `.item()`s per batch (module.py:113-124); one
+    # blocking read still makes the host wait for the whole step before it can enqueue the next one (8 ms of enqueue
+    # serialised behind 16 ms of GPU work at B = 512).  Here the 11 scalars are copied into a pinned buffer with an async
+    # D2H and an event; the entry is consumed when the NEXT batch logs (or at the end of the pass), so the host runs one
+    # step ahead of the device.  `log_lag = 0` restores the blocking behaviour.
+    log_lag = 1
+
     def _log(self, task, outputs, loss_dic, step):
-        vals = self._host_values(self._sum_parallel_loss(outputs))
+        vals = torch.stack([item.detach().reshape(()) for item in self._sum_parallel_loss(outputs)])
+        if not vals.is_cuda or self.log_lag <= 0:
+            return self._consume_log(task, vals.tolist(), loss_dic, step)
+        host = torch.empty(vals.shape, dtype=vals.dtype, pin_memory=True)
+        host.copy_(vals, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending_logs.append((task, host, ev, loss_dic, step))
+        while len(self._pending_logs) > self.log_lag:
+            self._pop_log()
+
+    def _pop_log(self):
+        task, host, ev, loss_dic, step = self._pending_logs.pop(0)
+        ev.synchronize()
+        self._consume_log(task, host.tolist(), loss_dic, step)
+
+    def _flush_logs(self):
+        while self._pending_logs:
+            self._pop_log()
+
+    def _consume_log(self, task, vals, loss_dic, step):
         self._accumulate_loss_dic(loss_dic, vals)
-        self.summary_writers.write_task(task, self._write_loss_to_dic(vals), step)
+        if self.is_main:
+            self.summary_writers.write_task(task, self._write_loss_to_dic(vals), step)
 
     def train(self, **kwargs):
         self.model.train()
@@ -137,6 +166,7 @@ class TrainingInterface:
             self._clip_and_step()
             self._log('train', outputs, epoch_loss_dic, self.train_step)
             self.train_step += 1
+        self._flush_logs()
         return epoch_loss_dic
 
     def eval(self):
@@ -151,10 +181,45 @@ class TrainingInterface:
                 outputs = self.model('train', *inputs, **self.param_scheduler.step())
             self._log('val', outputs, epoch_loss_dic, self.val_step)
             self.val_step += 1
+        self._flush_logs()
         return epoch_loss_dic
 
+    @property
+    def is_main(self):
+        """rank 0 of a data-parallel job (every rank holds identical weights: only one writes files / logs)"""
+        import torch.distributed as dist
+        return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+    def _barrier(self):
+        import torch.distributed as dist
+        if self.parallel and dist.is_available() and dist.is_initialized():
+            dist.barrier()
+
     def save_model(self, fn):
-        torch.save(self.model.state_dict(), fn)
+        """weights only, as the reference (module.py:179-183); written by rank 0"""
+        if self.is_main:
+            torch.save(self.model.state_dict(), fn)
+        self._barrier()
+
+    # ---- full-state checkpoints (SURVEY.md section 8 f4): weights + optimiser (Adam moments, step count, lr) + LR scheduler
+    # + parameter-scheduler counters + the trainer's epoch / step counters
+    def save_checkpoint(self, fn):
+        opt, sch = self.opt_scheduler.optimizer, self.opt_scheduler.scheduler
+        state = {'model': self.model.state_dict(), 'optimizer': opt.state_dict(), 'lr_scheduler': sch.state_dict(),
+                 'opt_scheduler_step': self.opt_scheduler._step, 'param_scheduler': self.param_scheduler.state_dict(),
+                 'epoch': self.epoch, 'train_step': self.train_step, 'val_step': self.val_step}
+        if self.is_main:
+            torch.save(state, fn)
+        self._barrier()
+
+    def load_checkpoint(self, fn):
+        state = torch.load(fn, map_location=self.device, weights_only=False)
+        self.model.load_state_dict(state['model'])
+        self.opt_scheduler.optimizer.load_state_dict(state['optimizer'])
+        self.opt_scheduler.scheduler.load_state_dict(state['lr_scheduler'])
+        self.opt_scheduler._step = state['opt_scheduler_step']
+        self.param_scheduler.load_state_dict(state['param_scheduler'])
+        self.epoch, self.train_step, self.val_step = state['epoch'], state['train_step'], state['val_step']
 
     def epoch_report(self, start_time, end_time, train_loss, valid_loss):
         mins, secs = epoch_time(start_time, end_time)
@@ -175,7 +240,9 @@ class TrainingInterface:
             if val_loss < best:
                 best = val_loss
                 self.save_model(self.path_mng.valid_model_path(self.name))
-            self.epoch_report(tic, toc, train_loss, val_loss)
+            if self.is_main:
+                self.epoch_report(tic, toc, train_loss, val_loss)
             self.epoch += 1
         self.save_model(self.path_mng.final_model_path(self.name))
-        print('Model saved.')
+        if self.is_main:
+            print('Model saved.')

@@ -98,3 +98,14 @@ class ParameterScheduler(_Scheduler):
 
     def step(self, require_zero_grad=False):
         return {name: sch.step() for name, sch in self.schedulers.items()}
+
+    # ---- resume support (the reference saves no scheduler state: run(start_*) only resets the trainer's counters,
+    # module.py:195-198, so a resumed run restarts teacher forcing and the KL weight from step 0)
+    def state_dict(self):
+        return {'step': self._step, 'mode': self.mode, 'schedulers': {n: sch._step for n, sch in self.schedulers.items()}}
+
+    def load_state_dict(self, state):
+        self._step = state['step']
+        for n, k in state['schedulers'].items():
+            self.schedulers[n]._step = k
+        self._set_mode(state.get('mode', 'train'))

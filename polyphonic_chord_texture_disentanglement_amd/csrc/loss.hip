@@ -199,6 +199,70 @@ __global__ void ce_small_kernel(const float* __restrict__ logits, long ld, const
   }
 }
 
+// grouped form for the weighted duration loss (ptvae.py:512-527): row r belongs to group r % G (the duration bit position),
+// every group is its own CrossEntropyLoss(ignore_index) mean -> per-group nll sums / valid counts, per-group gradient scales
+template <bool BWD>
+__global__ void ce_group_kernel(const float* __restrict__ logits, long ld, const int* __restrict__ tgt, long rows, int C, int ignore, int G,
+                                float* __restrict__ nll_sum, int* __restrict__ cnt, const float* __restrict__ gscale,
+                                float* __restrict__ dlogits, long ldd) {
+  float local[8]; int lc[8];
+#pragma unroll
+  for (int g = 0; g < 8; g++) { local[g] = 0.f; lc[g] = 0; }
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
+    const float* lr = logits + r * ld;
+    const int t = tgt[r], grp = (int)(r % G);
+    float v[16]; float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { v[k] = k < C ? lr[k] : -INFINITY; m = fmaxf(m, v[k]); }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) if (k < C) s += expf(v[k] - m);
+    const bool valid = t != ignore;
+    if (!BWD) {
+      if (valid) {
+        float vt = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) if (k == t) vt = v[k];
+        const float nll = -(vt - m - logf(s));
+#pragma unroll
+        for (int g = 0; g < 8; g++) if (g == grp) { local[g] += nll; lc[g] += 1; }
+      }
+    } else {
+      const float gs = gscale[grp];
+      float* dr = dlogits + r * ldd;
+#pragma unroll
+      for (int k = 0; k < 16; k++) if (k < C) dr[k] = valid ? gs * (expf(v[k] - m) / s - (k == t ? 1.f : 0.f)) : 0.f;
+    }
+  }
+  if (!BWD) {
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+      if (g < G) {
+        const float t = wave_sum(local[g]);
+        int c = lc[g];
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if ((threadIdx.x & 63) == 0 && c != 0) { atomicAdd(nll_sum + g, t); atomicAdd(cnt + g, c); }
+      }
+    }
+  }
+}
+
+// dl = sum_d w[d] * nll[d] / cnt[d] written as (sums1 = dl, counts1 = 1) so that ptv_loss_finalize / ptv_loss_bwd_scales apply
+__global__ void wdur_finalize_kernel(const float* __restrict__ gsum, const int* __restrict__ gcnt, float w0, float w1, float w2, float w3,
+                                     float w4, float* __restrict__ sums1, int* __restrict__ counts1) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float w[5] = {w0, w1, w2, w3, w4};
+  float dl = 0.f;
+  for (int d = 0; d < 5; d++) dl += w[d] * (gsum[d] / (float)gcnt[d]);
+  sums1[0] = dl; counts1[0] = 1;
+}
+__global__ void wdur_scales_kernel(const float* __restrict__ gs1, const int* __restrict__ gcnt, float w0, float w1, float w2, float w3,
+                                   float w4, float* __restrict__ out5) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float w[5] = {w0, w1, w2, w3, w4};
+  for (int d = 0; d < 5; d++) out5[d] = gs1[0] * w[d] / (float)gcnt[d];
+}
+
 __global__ void kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ sd, long n, float* __restrict__ kl_sum) {
   __shared__ float red[4];
   float s = 0.f;
@@ -320,6 +384,40 @@ extern "C" int ptv_loss_finalize(const float* sums, const int* counts, float bet
 extern "C" int ptv_loss_bwd_scales(const float* gout11, const int* counts, float beta, float w0, float w1, float n_kl, float n_root, float n_chroma, float* gs7, void* stream) {
   if (!gout11 || !counts || !gs7) return PTV_ERR_ARG;
   hipLaunchKernelGGL(loss_bwd_scales_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gout11, counts, beta, w0, w1, n_kl, n_root, n_chroma, gs7);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_ce_group_fwd(const float* logits, long ld, const int* targets, long rows, int C, int ignore_index, int G,
+                                float* nll_sum, int* count, void* stream) {
+  if (!logits || !targets || !nll_sum || !count || rows <= 0 || C <= 0 || C > 16 || G <= 0 || G > 8) return PTV_ERR_ARG;
+  hipLaunchKernelGGL((ce_group_kernel<false>), dim3(grid_rows(rows, 256, 2048)), dim3(256), 0, (hipStream_t)stream, logits, ld, targets, rows, C,
+                     ignore_index, G, nll_sum, count, nullptr, nullptr, 0L);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_ce_group_bwd(const float* logits, long ld, const int* targets, long rows, int C, int ignore_index, int G,
+                                const float* gscale, float* dlogits, long ldd, void* stream) {
+  if (!logits || !targets || !gscale || !dlogits || rows <= 0 || C <= 0 || C > 16 || G <= 0 || G > 8) return PTV_ERR_ARG;
+  hipLaunchKernelGGL((ce_group_kernel<true>), dim3(grid_rows(rows, 256, 2048)), dim3(256), 0, (hipStream_t)stream, logits, ld, targets, rows, C,
+                     ignore_index, G, nullptr, nullptr, gscale, dlogits, ldd);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_wdur_finalize(const float* gsum5, const int* gcnt5, float w0, float w1, float w2, float w3, float w4, float* sums1,
+                                 int* counts1, void* stream) {
+  if (!gsum5 || !gcnt5 || !sums1 || !counts1) return PTV_ERR_ARG;
+  hipLaunchKernelGGL(wdur_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gsum5, gcnt5, w0, w1, w2, w3, w4, sums1, counts1);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_wdur_scales(const float* gs1, const int* gcnt5, float w0, float w1, float w2, float w3, float w4, float* out5,
+                               void* stream) {
+  if (!gs1 || !gcnt5 || !out5) return PTV_ERR_ARG;
+  hipLaunchKernelGGL(wdur_scales_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gs1, gcnt5, w0, w1, w2, w3, w4, out5);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

@@ -14,6 +14,18 @@ class GradSync:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._bucket = None
+        if self.world > 1:
+            self.broadcast_parameters()
+
+    def broadcast_parameters(self, src=0):
+        """replica equality by construction, not by every rank happening to seed alike: rank `src`'s weights everywhere"""
+        opt = self.optimizer
+        if opt is not None and getattr(opt, 'flat_p', None) is not None:
+            dist.broadcast(opt.flat_p, src, group=self.group)
+            opt.mark_dirty()                                 # the bf16 operand shadows are re-cast before their next use
+            return
+        for p in self.model.parameters():
+            dist.broadcast(p.data, src, group=self.group)
 
     def _flat_bucket(self):
         """(flat tensor holding every gradient, needs_scatter)"""

@@ -1108,7 +1108,10 @@ def _mem_order(ts, perms):
     return [t.contiguous() for t in ts], False
 
 
-def _pianotree_ce_fwd(pitch, dur, x, sums, st):
+WDUR = (1.0, 0.6, 0.4, 0.3, 0.3)          # ptvae.py:519-520
+
+
+def _pianotree_ce_fwd(pitch, dur, x, sums, st, weighted=False):
     (pitch_m, dur_m), sm = _mem_order([pitch, dur], [_PERM[4], _PERM[5]])
     dev = pitch.device
     B = x.shape[0]
@@ -1119,18 +1122,29 @@ def _pianotree_ce_fwd(pitch, dur, x, sums, st):
     counts = torch.zeros(2, device=dev, dtype=torch.int32)
     call('ptv_pianotree_targets', ptr(x), B, int(sm), ptr(pitch_t), ptr(dur_t), ptr(counts), st)
     call('ptv_ce_fwd', ptr(pitch_m), pitch_m.stride(-2), ptr(pitch_t), rows, NP, 130, ptr(sums[0:]), st)
+    if weighted:                              # 5 per-bit-position means, weighted (ptvae.py:512-527)
+        gsum = _zeros(5, dev=dev)
+        gcnt = torch.zeros(5, device=dev, dtype=torch.int32)
+        call('ptv_ce_group_fwd', ptr(dur_m), 2, ptr(dur_t), rows * 5, 2, 2, 5, ptr(gsum), ptr(gcnt), st)
+        call('ptv_wdur_finalize', ptr(gsum), ptr(gcnt), *WDUR, ptr(sums[1:]), ptr(counts[1:]), st)
+        return pitch_m, dur_m, sm, pitch_t, dur_t, counts, gcnt
     call('ptv_ce_fwd', ptr(dur_m), 2, ptr(dur_t), rows * 5, 2, 2, ptr(sums[1:]), st)
-    return pitch_m, dur_m, sm, pitch_t, dur_t, counts
+    return pitch_m, dur_m, sm, pitch_t, dur_t, counts, None
 
 
-def _pianotree_ce_bwd(pitch_m, dur_m, sm, pitch_t, dur_t, gs, st):
+def _pianotree_ce_bwd(pitch_m, dur_m, sm, pitch_t, dur_t, gs, st, gcnt=None):
     NP = pitch_m.shape[-1]
     rows = pitch_t.numel()
     ld = pitch_m.stride(-2)                                  # gradient in the logits' (possibly row-padded) layout
     dpitch = torch.empty(rows, ld, device=pitch_m.device)[:, :NP].as_strided(pitch_m.shape, pitch_m.stride())
     ddur = torch.empty_like(dur_m)
     call('ptv_ce_bwd', ptr(pitch_m), ld, ptr(pitch_t), rows, NP, 130, ptr(gs[0:]), ptr(dpitch), ld, st)
-    call('ptv_ce_bwd', ptr(dur_m), 2, ptr(dur_t), rows * 5, 2, 2, ptr(gs[1:]), ptr(ddur), 2, st)
+    if gcnt is not None:
+        gs5 = _empty(5, dev=pitch_m.device)
+        call('ptv_wdur_scales', ptr(gs[1:]), ptr(gcnt), *WDUR, ptr(gs5), st)
+        call('ptv_ce_group_bwd', ptr(dur_m), 2, ptr(dur_t), rows * 5, 2, 2, 5, ptr(gs5), ptr(ddur), 2, st)
+    else:
+        call('ptv_ce_bwd', ptr(dur_m), 2, ptr(dur_t), rows * 5, 2, 2, ptr(gs[1:]), ptr(ddur), 2, st)
     if sm:
         dpitch, ddur = dpitch.permute(*_PERM[4]), ddur.permute(*_PERM[5])
     return dpitch, ddur
@@ -1141,7 +1155,7 @@ class VaeLossFn(torch.autograd.Function):
     bass [B,8,12], x, c, beta, w0, w1) -> the 11 scalars of model.py:67-68 as one [11] tensor."""
 
     @staticmethod
-    def forward(ctx, pitch, dur, mu_c, sd_c, mu_r, sd_r, root, chroma, bass, x, c, beta, w0, w1):
+    def forward(ctx, pitch, dur, mu_c, sd_c, mu_r, sd_r, root, chroma, bass, x, c, beta, w0, w1, weighted_dur=False):
         dev = pitch.device
         B = x.shape[0]
         st = stream_ptr()
@@ -1149,7 +1163,8 @@ class VaeLossFn(torch.autograd.Function):
         c = c.contiguous()
         mu_c, sd_c, mu_r, sd_r = (t.contiguous() for t in (mu_c, sd_c, mu_r, sd_r))
         sums = _zeros(8, dev=dev)
-        pitch_m, dur_m, sm_p, pitch_t, dur_t, counts = _pianotree_ce_fwd(pitch, dur, x, sums, st)
+        pitch_m, dur_m, sm_p, pitch_t, dur_t, counts, gcnt = _pianotree_ce_fwd(pitch, dur, x, sums, st, weighted_dur)
+        ctx.gcnt = gcnt
         (root_m, chroma_m, bass_m), sm_c = _mem_order([root, chroma, bass], [_chord_perm(root), _chord_perm(chroma),
                                                                               _chord_perm(bass)])
         root_t = torch.empty(B * 8, device=dev, dtype=torch.int32)
@@ -1180,7 +1195,7 @@ class VaeLossFn(torch.autograd.Function):
         reset_deferred()                        # first node of the backward pass: nothing may be left from an aborted one
         gs = _empty(8, dev=dev)
         call('ptv_loss_bwd_scales', ptr(gout.contiguous()), ptr(counts), *ctx.scal, ptr(gs), st)
-        dpitch, ddur = _pianotree_ce_bwd(pitch_m, dur_m, sm_p, pitch_t, dur_t, gs, st)
+        dpitch, ddur = _pianotree_ce_bwd(pitch_m, dur_m, sm_p, pitch_t, dur_t, gs, st, ctx.gcnt)
         dmu_c, dsd_c = torch.empty_like(mu_c), torch.empty_like(sd_c)
         dmu_r, dsd_r = torch.empty_like(mu_r), torch.empty_like(sd_r)
         call('ptv_kl_bwd', ptr(mu_c), ptr(sd_c), mu_c.numel(), ptr(gs[2:]), ptr(dmu_c), ptr(dsd_c), st)
@@ -1191,19 +1206,20 @@ class VaeLossFn(torch.autograd.Function):
         call('ptv_ce_bwd', ptr(bass_m), 12, ptr(bass_t), bass_t.numel(), 12, -1, ptr(gs[6:]), ptr(dbass), 12, st)
         if sm_c:
             droot, dchroma, dbass = (t.permute(*_chord_perm(t)) for t in (droot, dchroma, dbass))
-        return (dpitch, ddur, dmu_c, dsd_c, dmu_r, dsd_r, droot, dchroma, dbass) + (None,) * 5
+        return (dpitch, ddur, dmu_c, dsd_c, dmu_r, dsd_r, droot, dchroma, dbass) + (None,) * 6
 
 
 class ReconLossFn(torch.autograd.Function):
     """PtvaeDecoder.recon_loss (ptvae.py:498-511) -> [3] = (w0*pl + w1*dl, pl, dl)."""
 
     @staticmethod
-    def forward(ctx, pitch, dur, x, w0, w1):
+    def forward(ctx, pitch, dur, x, w0, w1, weighted_dur=False):
         dev = pitch.device
         st = stream_ptr()
         x = x.contiguous()
         sums = _zeros(8, dev=dev)
-        pitch_m, dur_m, sm, pitch_t, dur_t, counts = _pianotree_ce_fwd(pitch, dur, x, sums, st)
+        pitch_m, dur_m, sm, pitch_t, dur_t, counts, gcnt = _pianotree_ce_fwd(pitch, dur, x, sums, st, weighted_dur)
+        ctx.gcnt = gcnt
         out = _empty(11, dev=dev)
         ctx.scal = (0.0, float(w0), float(w1), 1.0, 1.0, 1.0)
         call('ptv_loss_finalize', ptr(sums), ptr(counts), *ctx.scal, ptr(out), st)
@@ -1220,12 +1236,12 @@ class ReconLossFn(torch.autograd.Function):
         copy2d(g11[1:4].view(1, 3), g3.contiguous().view(1, 3))
         gs = _empty(8, dev=dev)
         call('ptv_loss_bwd_scales', ptr(g11), ptr(counts), *ctx.scal, ptr(gs), st)
-        dpitch, ddur = _pianotree_ce_bwd(pitch_m, dur_m, ctx.sm, pitch_t, dur_t, gs, st)
-        return dpitch, ddur, None, None, None
+        dpitch, ddur = _pianotree_ce_bwd(pitch_m, dur_m, ctx.sm, pitch_t, dur_t, gs, st, ctx.gcnt)
+        return dpitch, ddur, None, None, None, None
 
 
-def recon_loss(x, pitch, dur, w0, w1):
-    return ReconLossFn.apply(pitch, dur, x, w0, w1)
+def recon_loss(x, pitch, dur, w0, w1, weighted_dur=False):
+    return ReconLossFn.apply(pitch, dur, x, w0, w1, weighted_dur)
 
 
 class KlFn(torch.autograd.Function):

@@ -25,7 +25,9 @@ class DisentangleVAE(PytorchModel):
         self.decoder = decoder
         self.num_step = self.decoder.num_step
         self.chd_decoder = chd_decoder
-        self.eps_source = None      # optional callable (name, shape, device) -> eps tensor (tests / DDP)
+        self.eps_source = None      # optional callable (name, shape, device) -> eps tensor (tests)
+        self._philox = None         # (seed, global index of this process's first sample): see use_philox()
+        self._draws = 0
 
     # ---- precision switch: 'fp32' (exact, parity) | 'bf16' (bf16 MFMA operands, fp32 accumulate)
     def set_precision(self, precision):
@@ -34,10 +36,24 @@ class DisentangleVAE(PytorchModel):
             m.precision = precision
         return self
 
+    # ---- reparameterisation noise.  Default = torch's device generator (the reference draws from torch's global generator,
+    # train_utils.py:33-34).  use_philox(seed, sample_offset) makes eps a pure function of (seed, draw number, GLOBAL sample
+    # index, column) -- the same batch sees the same noise whether it runs on one GPU or is sharded over N ranks
+    # (sample_offset = rank * per-rank batch; SURVEY.md section 8 d/e).  Every rank must make the same sequence of draws.
+    def use_philox(self, seed=7, sample_offset=0):
+        self._philox = (int(seed), int(sample_offset))
+        self._draws = 0
+        return self
+
     def _rsample(self, name, dist):
         eps = None
         if self.eps_source is not None:
             eps = self.eps_source(name, dist.mean.shape, dist.mean.device)
+        elif self._philox is not None:
+            B, Z = dist.mean.shape
+            eps = torch.empty(B, Z, device=dist.mean.device, dtype=torch.float32)
+            F_.call('ptv_philox_normal', F_.ptr(eps), B, Z, self._philox[0], self._draws, self._philox[1], F_.stream_ptr())
+            self._draws += 1
         return dist.rsample(eps=eps)
 
     # ---- model.py:42-55
@@ -69,11 +85,9 @@ class DisentangleVAE(PytorchModel):
     # ---- model.py:57-68: one fused loss node (CE with ignore_index x2, KL x2, chord CE x3)
     def loss_function(self, x, c, recon_pitch, recon_dur, dist_chd, dist_rhy, recon_root, recon_chroma,
                       recon_bass, beta, weights, weighted_dur=False):
-        if weighted_dur:
-            raise NotImplementedError('weighted_dur (ptvae.py:512-527) is unused by the train path')
         out = F_.VaeLossFn.apply(recon_pitch, recon_dur, dist_chd.mean, dist_chd.scale, dist_rhy.mean,
                                  dist_rhy.scale, recon_root, recon_chroma, recon_bass, x.long(), c.float(),
-                                 float(beta), float(weights[0]), float(weights[1]))
+                                 float(beta), float(weights[0]), float(weights[1]), bool(weighted_dur))
         return tuple(out.unbind(0))
 
     # ---- model.py:70-90 (stand-alone forms; loss_function computes them fused)
@@ -111,6 +125,7 @@ class DisentangleVAE(PytorchModel):
     # ---- model.py:117-122
     def inference_encode(self, pr_mat, c):
         self.eval()
+        refresh_weight_shadows()                         # no-op unless the parameters changed since the last cast
         with torch.no_grad():
             dist_chd = self.chd_encoder(c)
             dist_rhy = self.rhy_encoder(pr_mat)
@@ -120,6 +135,7 @@ class DisentangleVAE(PytorchModel):
     # (identical to output_to_numpy's argmax of the returned logits, ptvae.py:537-544)
     def inference_decode(self, z_chd, z_rhy):
         self.eval()
+        refresh_weight_shadows()
         with torch.no_grad():
             dec_z = torch.cat([z_chd, z_rhy], dim=-1)
             self.decoder(dec_z, True, None, None, 0., 0.)
@@ -129,6 +145,7 @@ class DisentangleVAE(PytorchModel):
     # ---- model.py:133-142
     def inference(self, pr_mat, c, sample):
         self.eval()
+        refresh_weight_shadows()
         with torch.no_grad():
             dist_chd = self.chd_encoder(c)
             dist_rhy = self.rhy_encoder(pr_mat)
@@ -167,6 +184,40 @@ class DisentangleVAE(PytorchModel):
         with torch.no_grad():
             z_chd, z_rhy = self._rsample('chd', dist_chd), self._rsample('rhy', dist_rhy)
         return self.inference_decode(z_chd, z_rhy)
+
+    # ---- model.py:186-188
+    def gt_sample(self, x):
+        return x[:, :, 1:].cpu().numpy()
+
+    # ---- model.py:190-209: decode int_count points on the path between two items' latent codes
+    def interp(self, pr_mat1, c1, pr_mat2, c2, interp_chd=False, interp_rhy=False, int_count=10):
+        dist_chd1, dist_rhy1 = self.inference_encode(pr_mat1, c1)
+        dist_chd2, dist_rhy2 = self.inference_encode(pr_mat2, c2)
+        z_chd1, z_rhy1, z_chd2, z_rhy2 = dist_chd1.mean, dist_rhy1.mean, dist_chd2.mean, dist_rhy2.mean
+        z_chds = self.interp_z(z_chd1, z_chd2, int_count) if interp_chd else z_chd1.unsqueeze(1).repeat(1, int_count, 1)
+        z_rhys = self.interp_z(z_rhy1, z_rhy2, int_count) if interp_rhy else z_rhy1.unsqueeze(1).repeat(1, int_count, 1)
+        bs = z_chds.size(0)
+        estxs = self.inference_decode(z_chds.reshape(bs * int_count, -1).contiguous(),
+                                      z_rhys.reshape(bs * int_count, -1).contiguous())
+        return estxs.reshape((bs, int_count, 32, 15, -1))
+
+    # ---- model.py:211-216: [B,D] x [B,D] -> [B,int_count,D]; the reference loops over numpy rows on the host, here the
+    # whole batch is one launch on the device holding z (ptv_slerp_path)
+    def interp_z(self, z1, z2, int_count=10):
+        z1, z2 = z1.detach().float().contiguous(), z2.detach().float().contiguous()
+        if not z1.is_cuda:
+            z1, z2 = z1.to(self.device), z2.to(self.device)
+        B, D = z1.shape
+        out = torch.empty(B, int_count, D, device=z1.device, dtype=torch.float32)
+        F_.call('ptv_slerp_path', F_.ptr(z1), F_.ptr(z2), F_.ptr(out), B, D, int_count, F_.stream_ptr())
+        return out
+
+    # ---- model.py:218-242: one pair of codes (any shape); spherical interpolation of the directions, geometric of the norms
+    def interp_path(self, z1, z2, interpolation_count=10):
+        t1 = torch.as_tensor(z1, dtype=torch.float32)
+        shape = list(t1.shape)
+        out = self.interp_z(t1.reshape(1, -1), torch.as_tensor(z2, dtype=torch.float32).reshape(1, -1), interpolation_count)
+        return out.reshape([interpolation_count] + shape)
 
     # ---- model.py:244-265
     @staticmethod

@@ -363,28 +363,87 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
 
     # ---- ptvae.py:498-529
     def recon_loss(self, x, recon_pitch, recon_dur, weights=(1, 0.5), weighted_dur=False):
-        if weighted_dur:
-            raise NotImplementedError('weighted_dur variant (ptvae.py:512-527) is unused by the train path')
-        out = F_.recon_loss(x.long(), recon_pitch, recon_dur, float(weights[0]), float(weights[1]))
+        out = F_.recon_loss(x.long(), recon_pitch, recon_dur, float(weights[0]), float(weights[1]), bool(weighted_dur))
         return out[0], out[1], out[2]
 
+    # ---- ptvae.py:546-575, MIDI-free: notes come back as (pitch, start, end) tuples (velocity is the constant 100 of the
+    # reference's pretty_midi.Note calls); pretty_midi is not needed
+    def pr_to_notes(self, pr, bpm=80, start=0., one_hot=False):
+        """pr: [32,128] duration matrix (pr_mat layout).  The reference routes through an undefined `pr_to_pr_matrix`
+        (ptvae.py:547); a duration matrix is what its loop body consumes."""
+        import numpy as np
+        pr_matrix = np.asarray(pr)
+        alpha = 0.25 * 60 / bpm
+        notes = []
+        for t in range(32):
+            for p in range(128):
+                if pr_matrix[t, p] >= 1:
+                    notes.append((int(p), alpha * t + start, alpha * (t + pr_matrix[t, p]) + start))
+        return notes
 
-class PtvaeEncoder(nn.Module):
-    """Present in the reference (ptvae.py:125-215) and constructed by its train.py:32, but unusable on
-    this path.  Kept importable with the reference signature; parameters only."""
+    def grid_to_pr_and_notes(self, grid, bpm=60., start=0.):
+        import numpy as np
+        grid = np.asarray(grid)
+        if grid.shape[1] == self.max_simu_note:
+            grid = grid[:, 1:]
+        pr = np.zeros((32, 128), dtype=int)
+        alpha = 0.25 * 60 / bpm
+        notes = []
+        for t in range(32):
+            for n in range(10):                          # the reference reads at most 10 notes per step (ptvae.py:563)
+                note = grid[t, n]
+                if note[0] == self.pitch_eos:
+                    break
+                pitch = int(note[0]) + self.min_pitch
+                dur = int(''.join(str(int(v)) for v in note[1:]), 2) + 1
+                pr[t, pitch] = min(dur, 32 - t)
+                notes.append((pitch, start + t * alpha, start + (t + dur) * alpha))
+        return pr, notes
+
+
+class PtvaeEncoder(nn.Module, _PrecMixin):
+    """PianoTree note -> time hierarchical encoder (ptvae.py:125-215): note embedding, bi-GRU over the <= 16 notes of each
+    step (packed by length), bi-GRU over the 32 step summaries, Normal(linear_mu, exp(linear_std)).  The reference's train.py:32
+    constructs it (unusable in that wiring); it is the encoder of the original PianoTree-VAE pairing.
+    Runs on the same kernels as the hot path: `EmbedFn` (gather embedding + lengths), `BiGruFinalFn` with per-row lengths,
+    `BiGruFinalFn` over time, `EncoderHeadsFn`.  No transposes: the step-major embedding [16][32*B] feeds the note GRU, whose
+    [32*B, 2H] summaries ARE the step-major [32][B] input of the time GRU."""
 
     def __init__(self, device, max_simu_note=16, max_pitch=127, min_pitch=0, pitch_sos=128, pitch_eos=129,
                  pitch_pad=130, dur_pad=2, dur_width=5, num_step=32, note_emb_size=128, enc_notes_hid_size=256,
                  enc_time_hid_size=512, z_size=512):
         super().__init__()
+        self.max_pitch, self.min_pitch = max_pitch, min_pitch
+        self.pitch_sos, self.pitch_eos, self.pitch_pad = pitch_sos, pitch_eos, pitch_pad
         self.pitch_range = max_pitch - min_pitch + 3
+        self.dur_pad, self.dur_width = dur_pad, dur_width
         self.note_size = self.pitch_range + dur_width
-        self.device = device
+        self.max_simu_note, self.num_step = max_simu_note, num_step
+        self.device = device if device is not None else ('cuda' if torch.cuda.is_available() else 'cpu')
+        self.note_emb_size, self.z_size = note_emb_size, z_size
+        self.enc_notes_hid_size, self.enc_time_hid_size = enc_notes_hid_size, enc_time_hid_size
         self.note_embedding = Linear(self.note_size, note_emb_size)
         self.enc_notes_gru = GRU(note_emb_size, enc_notes_hid_size, bidirectional=True)
         self.enc_time_gru = GRU(2 * enc_notes_hid_size, enc_time_hid_size, bidirectional=True)
         self.linear_mu = Linear(2 * enc_time_hid_size, z_size)
         self.linear_std = Linear(2 * enc_time_hid_size, z_size)
 
+    def _check_grid(self):
+        if (self.max_simu_note, self.num_step, self.dur_width, self.pitch_range, self.pitch_pad, self.dur_pad) != (16, 32, 5, 130, 130, 2):
+            raise NotImplementedError('HIP kernels are specialised to the 32x16x(130+5) PianoTree grid '
+                                      '(the reference\'s train.py:32 geometry cannot consume its own data either: SURVEY.md 0.2)')
+
     def forward(self, x, return_iterators=False):
-        raise NotImplementedError('PtvaeEncoder is outside the train-step hot path (SURVEY.md §8f item 3)')
+        _require_cuda(x, 'PtvaeEncoder')
+        self._check_grid()
+        B = x.size(0)
+        emb, lengths = F_.EmbedFn.apply(x.long(), self.note_embedding.weight, self.note_embedding.bias, self._prec)   # [16,32,B,E]
+        n, t, b, e = emb.shape
+        notes = F_.BiGruFinalFn.apply(emb.view(n, t * b, e), lengths, self._prec, *self.enc_notes_gru.weights())      # [32*B, 2Hn]
+        h = F_.BiGruFinalFn.apply(notes.view(t, b, -1), None, self._prec, *self.enc_time_gru.weights())               # [B, 2Ht]
+        mu, sd = F_.EncoderHeadsFn.apply(h, self.linear_mu.weight, self.linear_mu.bias, self.linear_std.weight,
+                                         self.linear_std.bias, self._prec)
+        embedded_x = emb.permute(2, 1, 0, 3)                                # reference shape [B,32,16,E], step-major memory
+        if return_iterators:
+            return mu, sd, embedded_x
+        return HipNormal(mu, sd), embedded_x, lengths.view(32, B).t()

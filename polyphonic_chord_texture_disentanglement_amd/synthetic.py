@@ -62,6 +62,29 @@ def synth_batch(B, seed):
     return x, c, pr_mat
 
 
+def synth_raw_bank(N, seed):
+    """A bank of N raw 2-bar items in the layout the reference's dataset holds BEFORE its per-item transform
+    (dataset.py:88-112): accompaniment piano-rolls `pr` uint8 [N,32,128] with 2 at onsets and 1 on the sustained cells
+    (converter.py:35-47, later notes overwrite earlier ones) and raw chords `chord14` f32 [N,8,14] = [root, 12 chroma
+    bits, bass] (the operand of converter.py:150-164).  Input of the device batch transform (csrc/data.hip)."""
+    rng = np.random.RandomState(seed)
+    pr = np.zeros((N, NUM_STEP, 128), dtype=np.uint8)
+    chord = np.zeros((N, 8, 14), dtype=np.float32)
+    for b in range(N):
+        for t in range(NUM_STEP):
+            if rng.rand() < 0.5:
+                k = rng.randint(1, 7)
+                ps = rng.choice(np.arange(36, 96), k, replace=False)
+                for p in ps:
+                    d = rng.randint(1, min(NUM_STEP - t, 16) + 1)
+                    pr[b, t, p] = 2
+                    pr[b, t + 1: t + d, p] = 1
+        chord[b, :, 0] = rng.randint(0, 12, 8)
+        chord[b, :, 1:13] = rng.rand(8, 12) < 0.3
+        chord[b, :, 13] = rng.randint(0, 12, 8)
+    return pr, chord
+
+
 def fill_state_dict(shapes, seed):
     """Deterministic filler weights for parity fixtures.
 

@@ -7,6 +7,7 @@ that runs) and batches carry three tensors.  Data is the synthetic generator (no
 """
 import argparse
 import os
+import random
 
 import torch
 
@@ -46,18 +47,24 @@ def main():
     if world > 1:
         torch.distributed.init_process_group('nccl', device_id=device)
 
-    torch.manual_seed(0)
+    rank = int(os.environ.get('RANK', 0))
+    torch.manual_seed(0)                      # identical initial weights on every rank (GradSync also broadcasts rank 0's)
+    random.seed(7)                            # teacher-forcing coins are per-step decisions for the WHOLE batch: one shared stream
     chd_encoder = RnnEncoder(36, 1024, 256)
     rhy_encoder = TextureEncoder(256, 1024, 256)
     chd_decoder = RnnDecoder(z_dim=256)
     pt_decoder = PtvaeDecoder(note_embedding=None, dec_dur_hid_size=64, z_size=512)
     model = DisentangleVAE(name, device, chd_encoder, rhy_encoder, pt_decoder, chd_decoder).to(device)
     model.set_precision(args.precision)
+    model.use_philox(seed=7, sample_offset=rank * args.batch)      # eps keyed by the global sample index: sharding-invariant
 
-    data_loaders = MusicDataLoaders.get_loaders(SEED + int(os.environ.get('RANK', 0)) * 10 ** 7, bs_train=args.batch,
+    data_loaders = MusicDataLoaders.get_loaders(SEED + rank * 10 ** 7, bs_train=args.batch,
                                                 bs_val=args.batch, portion=8, shift_low=-6, shift_high=5, num_bar=2,
                                                 contain_chord=True)
-    log_path_mng = LogPathManager(None)
+    # one result directory per job: rank 0 names it (second-resolution timestamp) and writes into it; the other ranks get a
+    # private scratch directory so that nothing they might emit collides with rank 0's checkpoints and scalars
+    log_path_mng = LogPathManager(None) if rank == 0 else LogPathManager(None, log_path_name=os.path.join(
+        os.environ.get('TMPDIR', '/tmp'), 'ptvae_rank%d' % rank))
     optimizer = FusedClipAdam(model.parameters(), lr=lr)
     scheduler = MinExponentialLR(optimizer, gamma=0.9999, minimum=1e-5)
     optimizer_scheduler = OptimizerScheduler(optimizer, scheduler, clip)

@@ -1,0 +1,55 @@
+"""One rank of the 2-process data-parallel step used by tests/test_gpu_dist.py (started as a FRESH process before anything
+touches the GPU; gloo carries the CUDA bucket, both ranks share cuda:0 on a 1-GPU box).  Runs the product path:
+FusedClipAdam arena -> GradSync.all_reduce_grads on arena.flat -> grad_scale = 1/world inside ptv_clip_adam_step."""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    rank, world, out = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), sys.argv[1]
+    B_local = int(sys.argv[2])
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from polyphonic_chord_texture_disentanglement_amd.dist import GradSync
+    from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
+    from polyphonic_chord_texture_disentanglement_amd.synthetic import synth_batch
+    from test_host_surface import build_reduced
+    m = build_reduced('cuda:0').to('cuda:0')
+    if rank == 1:                                            # replicas that start apart must be pulled to rank 0's weights
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(0.5)
+    opt = FusedClipAdam(m.parameters(), lr=1e-3)
+    sync = GradSync(m, opt)
+    m.use_philox(seed=7, sample_offset=rank * B_local)
+    random.seed(7)
+    x, c, pr = synth_batch(world * B_local, 321)
+    sl = slice(rank * B_local, (rank + 1) * B_local)
+    xs, cs, prs = (torch.from_numpy(a[sl]).cuda() for a in (x, c, pr))
+    res = {}
+    for step in range(2):
+        opt.zero_grad()
+        losses = m('train', xs, cs, prs, tfr1=1., tfr2=1., tfr3=1., beta=0.1, weights=[1, 0.5])
+        losses[0].backward()
+        assert opt.arena.holds_all_grads()
+        sync.all_reduce_grads()
+        assert opt.grad_scale == 1.0 / world
+        opt.clip_and_step(1.0)
+        res['losses.%d' % step] = [float(v) for v in sync.mean_scalars(losses)]
+        res['gnorm.%d' % step] = float(opt.grad_norm())
+        res['flat_p.%d' % step] = opt.flat_p.detach().cpu().clone()
+    torch.save(res, '%s.rank%d' % (out, rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -76,3 +76,87 @@ def test_single_process_is_a_no_op():
     assert torch.equal(p.weight.grad, torch.ones_like(p.weight))
     l = (torch.tensor(1.0), torch.tensor(2.0))
     assert s.mean_scalars(l) is l
+
+
+# ---------------------------------------------------------------------------------------------
+# the PRODUCT branch of GradSync: gradients already live in the optimiser's flat arena (optim.GradArena), the bucket
+# that is all-reduced IS arena.flat, and the 1/world factor is handed to the optimiser as grad_scale (dist.py:39-47).
+# On CPU the arena is real and the optimiser is a stand-in that applies grad_scale the way ptv_clip_adam_step does.
+# ---------------------------------------------------------------------------------------------
+class _ArenaOpt:
+    def __init__(self, params):
+        from polyphonic_chord_texture_disentanglement_amd.optim import GradArena
+        self.arena = GradArena(params)
+        self.grad_scale = 1.0
+        self.flat_p = None
+
+    def mark_dirty(self):
+        pass
+
+
+def _fake_shard(rank):
+    """the model's parameter list with per-rank pseudo-gradients (the exchange logic is under test here, not the model)"""
+    params = reduced_params(requires_grad=True)
+    g = torch.Generator().manual_seed(100 + rank)
+    for p in params.values():
+        p.grad = torch.randn(p.shape, generator=g)
+    return params
+
+
+def _arena_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    params = _fake_shard(rank)
+    holder = _Holder(params)
+    if rank == 1:                                           # replicas that start apart: GradSync must broadcast rank 0's weights
+        with torch.no_grad():
+            for hp in holder.ps:
+                hp.add_(1.0)
+    opt = _ArenaOpt(list(holder.ps))
+    sync = GradSync(holder, opt)
+    for hp, p in zip(holder.ps, params.values()):
+        assert torch.equal(hp.detach(), p.detach())          # equal to rank 0's (unperturbed) weights again
+    for hp, p in zip(holder.ps, params.values()):            # what the backward kernels do: write into the arena view
+        v = opt.arena.take(hp)
+        v.copy_(p.grad)
+        hp.grad = v
+    assert opt.arena.holds_all_grads()
+    sync.all_reduce_grads()
+    assert opt.grad_scale == 1.0 / world and opt.arena.holds_all_grads()
+    if rank == 0:
+        torch.save({'flat': opt.arena.flat.clone(), 'offsets': opt.arena.offsets, 'scale': opt.grad_scale}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_sync_arena_branch_world2(tmp_path):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / 'arena0.pt')
+    mp.spawn(_arena_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    shards = [_fake_shard(r) for r in range(2)]
+    for i, off in enumerate(got['offsets']):
+        g0, g1 = (list(s.values())[i].grad for s in shards)
+        seg = got['flat'][off:off + g0.numel()].view_as(g0) * got['scale']          # SUM in the bucket, 1/world in the optimiser
+        np.testing.assert_allclose(seg.numpy(), ((g0 + g1) / 2).numpy(), rtol=0, atol=1e-7)
+
+
+def test_philox_oracle_known_answers_and_sharding_invariance():
+    """oracle/rng_oracle.py against the Random123 known-answer vectors of philox4x32-10, and the property the DDP design
+    needs: eps of global rows [a, b) does not depend on how [0, N) is cut into shards"""
+    from oracle.rng_oracle import philox4x32_10, philox_normal
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for c, k, want in kat:
+        got = philox4x32_10(np.array(c, dtype=np.uint32), np.array(k, dtype=np.uint32))
+        assert tuple(int(v) for v in got) == want
+    whole = philox_normal(64, 30, 7, 5)
+    parts = np.concatenate([philox_normal(24, 30, 7, 5, 0), philox_normal(40, 30, 7, 5, 24)])
+    assert np.array_equal(whole, parts)
+    assert not np.array_equal(whole, philox_normal(64, 30, 7, 6))
+    big = philox_normal(4096, 256, 7, 0)
+    assert abs(big.mean()) < 5e-3 and abs(big.std() - 1) < 5e-3

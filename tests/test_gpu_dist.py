@@ -1,0 +1,90 @@
+"""BASELINE configs[2] logic on one GPU: two FRESH processes run the data-parallel train step through the product branch of
+GradSync (FusedClipAdam arena bucket + grad_scale), compared with the mean-of-shards result computed in this process
+(DataParallel semantics of the reference, amc_dl/torch_plus/module.py:152-159).  Plus the
+sharding-invariant Philox eps on the device."""
+import os
+import random
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from polyphonic_chord_texture_disentanglement_amd.synthetic import synth_batch
+from test_host_surface import build_reduced
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_process_arena_all_reduce_matches_mean_of_shards(tmp_path):
+    from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
+    B_local, world = 3, 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / 'dp')
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dist_gpu_worker.py'), out, str(B_local)], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    got = [torch.load('%s.rank%d' % (out, r)) for r in range(world)]
+
+    # the same two steps in ONE process: per shard forward/backward, gradients averaged, one clip+Adam
+    m = build_reduced(DEV).to(DEV)
+    opt = FusedClipAdam(m.parameters(), lr=1e-3)
+    x, c, pr = synth_batch(world * B_local, 321)
+    for step in range(2):
+        flats, losses = [], []
+        for r in range(world):
+            sl = slice(r * B_local, (r + 1) * B_local)
+            m.use_philox(seed=7, sample_offset=r * B_local)
+            m._draws = 2 * step                                    # draw counter of that rank at this step (chd, rhy per step)
+            random.seed(7)
+            opt.zero_grad()
+            ls = m('train', *(torch.from_numpy(a[sl]).to(DEV) for a in (x, c, pr)), tfr1=1., tfr2=1., tfr3=1., beta=0.1, weights=[1, 0.5])
+            ls[0].backward()
+            assert opt.arena.holds_all_grads()
+            flats.append(opt.arena.flat.clone())
+            losses.append([float(v) for v in ls])
+        opt.arena.flat.copy_(sum(flats) / world)
+        opt.grad_scale = 1.0
+        opt.clip_and_step(1.0)
+        want_losses = np.mean(losses, axis=0)
+        for r in range(world):
+            np.testing.assert_allclose(got[r]['losses.%d' % step], want_losses, rtol=0, atol=2e-6)
+            assert abs(got[r]['gnorm.%d' % step] - float(opt.grad_norm())) < 1e-5 * max(1.0, float(opt.grad_norm()))
+            assert (got[r]['flat_p.%d' % step] - opt.flat_p.cpu()).abs().max() < 2e-6
+        assert torch.equal(got[0]['flat_p.%d' % step], got[1]['flat_p.%d' % step])      # replicas stay bit-identical
+
+
+def test_philox_eps_kernel_vs_oracle_and_sharding_invariance():
+    from oracle.rng_oracle import philox_normal
+    from polyphonic_chord_texture_disentanglement_amd._lib import call, ptr, stream_ptr
+
+    def dev(rows, Z, seed, stream, off=0):
+        t = torch.empty(rows, Z, device=DEV)
+        call('ptv_philox_normal', ptr(t), rows, Z, seed, stream, off, stream_ptr())
+        return t
+    whole = dev(512, 256, 7, 3)
+    np.testing.assert_allclose(whole.cpu().numpy(), philox_normal(512, 256, 7, 3), rtol=0, atol=2e-5)
+    parts = torch.cat([dev(200, 256, 7, 3, 0), dev(312, 256, 7, 3, 200)])
+    assert torch.equal(whole, parts)                                           # bitwise: 1 x B == shards of B
+    odd = dev(37, 30, 11, 2 ** 40 + 5, 2 ** 33)                                # ragged Z, 64-bit stream / row offset
+    np.testing.assert_allclose(odd.cpu().numpy(), philox_normal(37, 30, 11, 2 ** 40 + 5, 2 ** 33), rtol=0, atol=2e-5)
+    # model level: one process with the whole batch draws what two ranks with halves draw
+    m = build_reduced(DEV).to(DEV)
+    x, c, pr = (torch.from_numpy(a).to(DEV) for a in synth_batch(6, 5))
+    m.use_philox(7, 0)
+    full = m.run(x, c, pr, 1., 1., 1.)
+    halves = []
+    for r in range(2):
+        m.use_philox(7, 3 * r)
+        halves.append(m.run(x[3 * r:3 * r + 3], c[3 * r:3 * r + 3], pr[3 * r:3 * r + 3], 1., 1., 1.))
+    assert (torch.cat([h[0] for h in halves]) - full[0]).abs().max() < 1e-5     # logits of sample i do not depend on the sharding

@@ -1,0 +1,212 @@
+"""GPU parity of the SURVEY.md section 8(f) rows: the device data contract (f2), PtvaeEncoder (f3), the inference / demo
+family (f1), the weighted duration loss and optimiser-state checkpointing (f4) -- against fixtures generated from the
+reference (tests/golden/make_golden_r2.py) and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_npz, reduced_params
+from polyphonic_chord_texture_disentanglement_amd import model as M
+from polyphonic_chord_texture_disentanglement_amd.synthetic import fill_state_dict, synth_batch, synth_raw_bank
+from test_host_surface import build_reduced
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+# ---------------------------------------------------------------------------------------------- f2
+def test_device_batch_transform_bit_exact_vs_reference_fixture():
+    from polyphonic_chord_texture_disentanglement_amd.dataset_loaders import batch_transform
+    g = load_npz('data_contract.npz')
+    pr, chord, shift = (torch.from_numpy(g[k]).to(DEV) for k in ('pr', 'chord', 'shift'))
+    pr_mat, x, c = batch_transform(pr, chord, shift, check=True)
+    assert np.array_equal(pr_mat.cpu().numpy(), g['pr_mat'])
+    assert np.array_equal(x.cpu().numpy(), g['x'])
+    assert np.array_equal(c.cpu().numpy(), g['c'])
+    assert x.dtype == torch.int64 and pr_mat.dtype == torch.float32 and c.dtype == torch.float32
+    # gather form: sample b takes item index[b]
+    index = torch.tensor([5, 0, 23, 5], device=DEV, dtype=torch.int32)
+    pm2, x2, c2 = batch_transform(pr, chord, shift[index.long()], index)
+    assert np.array_equal(x2.cpu().numpy(), g['x'][[5, 0, 23, 5]]) and np.array_equal(c2.cpu().numpy(), g['c'][[5, 0, 23, 5]])
+    # more than 14 onsets in a step: the reference raises IndexError
+    bad = torch.zeros(1, 32, 128, dtype=torch.uint8, device=DEV)
+    bad[0, 3, 10:25] = 2
+    with pytest.raises(IndexError):
+        batch_transform(bad, chord[:1], None, check=True)
+
+
+def test_device_batch_transform_large_batch_vs_oracle_and_properties():
+    """B = 4096 items x random shifts against the numpy oracle (bit-exact), plus size-independent properties: transposing by
+    s then reading the grid equals shifting the un-transposed grid's pitches by s (no wrap in 36..95 +- 6); chords stay one-hot"""
+    from oracle import data_oracle as do
+    from polyphonic_chord_texture_disentanglement_amd.dataset_loaders import batch_transform
+    pr, chord = synth_raw_bank(512, 9)
+    rng = np.random.RandomState(1)
+    index = rng.randint(0, 512, 4096).astype(np.int32)
+    shift = rng.randint(-6, 6, 4096).astype(np.int32)
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    pr_mat, x, c = batch_transform(d(pr), d(chord), d(shift), d(index), check=True)
+    sub = rng.choice(4096, 64, replace=False)
+    pm_o, x_o, c_o = do.batch_transform(pr[index[sub]], chord[index[sub]], shift[sub])
+    assert np.array_equal(pr_mat.cpu().numpy()[sub], pm_o) and np.array_equal(x.cpu().numpy()[sub], x_o)
+    assert np.array_equal(c.cpu().numpy()[sub], c_o)
+    pm0, x0, _ = batch_transform(d(pr), d(chord), None, d(index))
+    xs, x0 = x.cpu().numpy(), x0.cpu().numpy()
+    note = x0[..., 0] < 128
+    assert np.array_equal(xs[..., 0][note], (x0[..., 0] + shift[:, None, None])[note])          # pitches move by the shift
+    assert np.array_equal(xs[..., 1:], x0[..., 1:])                                              # durations do not
+    assert (pr_mat.sum((1, 2)).cpu().numpy() == pm0.sum((1, 2)).cpu().numpy()).all()
+    cc = c.cpu().numpy()
+    assert (cc[:, :, :12].sum(-1) == 1).all() and (cc[:, :, 24:].sum(-1) == 1).all()
+
+
+def test_device_batcher_serves_an_epoch_of_every_item_and_shift():
+    from polyphonic_chord_texture_disentanglement_amd.dataset_loaders import DeviceBatcher, MusicDataLoaders, TrainingVAE
+    pr, chord = synth_raw_bank(20, 4)
+    db = DeviceBatcher(pr, chord, 64, seed=1, device=DEV)
+    assert len(db) == (20 * 12 + 63) // 64
+    total, seen = 0, set()
+    for _, _, pr_mat, x, c, _ in db:
+        assert x.shape[1:] == (32, 16, 6) and pr_mat.shape[1:] == (32, 128) and c.shape[1:] == (8, 36)
+        total += x.shape[0]
+        seen.update(np.round(pr_mat.sum((1, 2)).cpu().numpy(), 3).tolist())
+    assert total == 240 and len(seen) >= 15
+    loaders = MusicDataLoaders.get_loaders(3345, 16, 16, device_bank=(pr, chord))
+    assert len(loaders.val_loader) == 1 and len(loaders.train_loader) == (18 * 12 + 15) // 16
+
+
+# ---------------------------------------------------------------------------------------------- f3
+@pytest.mark.parametrize('tag', ['reduced', 'full'])
+def test_ptvae_encoder_vs_reference_golden(tag):
+    from polyphonic_chord_texture_disentanglement_amd.ptvae import PtvaeEncoder
+    g = load_npz('ptvae_encoder_%s.npz' % tag)
+    kw = dict(note_emb_size=20, enc_notes_hid_size=12, enc_time_hid_size=16, z_size=8) if tag == 'reduced' else {}
+    enc = PtvaeEncoder(torch.device(DEV), **kw)
+    shapes = {str(n): tuple(int(t) for t in s.strip('()').split(',') if t.strip()) for n, s in zip(g['names'], g['shapes'])}
+    assert list(enc.state_dict().keys()) == list(shapes.keys())
+    enc.load_state_dict(fill_state_dict(shapes, 4321))
+    enc.to(DEV)
+    dist, emb, lengths = enc(torch.from_numpy(g['x']).to(DEV))
+    assert emb.shape == (3, 32, 16, enc.note_emb_size) and lengths.shape == (3, 32)
+    np.testing.assert_allclose(dist.mean.detach().cpu().numpy(), g['mean'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(dist.scale.detach().cpu().numpy(), g['scale'], rtol=0, atol=2e-5)
+    assert np.array_equal(lengths.cpu().numpy(), g['lengths'])
+    ((dist.mean * torch.from_numpy(g['w1']).to(DEV)).sum() + (dist.scale * torch.from_numpy(g['w2']).to(DEV)).sum()).backward()
+    for k, p in enc.named_parameters():
+        if tag == 'reduced':
+            ref = g['grad.' + k]
+            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=0, atol=2e-6 + 2e-4 * np.abs(ref).max(), err_msg=k)
+        else:
+            gn, ref = float(p.grad.double().pow(2).sum().sqrt()), float(g['gnorm.' + k])
+            assert abs(gn - ref) <= 1e-5 + 2e-3 * ref, (k, gn, ref)
+    mu, sd, e2 = enc(torch.from_numpy(g['x']).to(DEV), return_iterators=True)
+    assert torch.equal(mu, dist.mean.detach()) or (mu - dist.mean).abs().max() < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------- f1
+def _eps(g, key):
+    return lambda name, shape, device: torch.from_numpy(g['%s.eps_%s' % (key, name)]).to(device)
+
+
+def test_inference_family_vs_reference_golden():
+    g = load_npz('reduced_family.npz')
+    m = build_reduced(DEV).to(DEV)
+    t = lambda k: torch.from_numpy(g[k]).to(DEV)
+    pr1, c1, pr2, c2 = t('pr1'), t('c1'), t('pr2'), t('c2')
+
+    def same(est, ref, tol=0.999):
+        assert est.shape == ref.shape and est.dtype == np.int64
+        assert (est == ref).mean() >= tol, (est == ref).mean()
+
+    same(m.inference(pr1, c1, sample=False), g['inference_mean'])
+    for fr, fc, key in ((True, True, 'swap_tt'), (True, False, 'swap_tf'), (False, True, 'swap_ft'), (False, False, 'swap_ff')):
+        same(m.swap(pr1, pr2, c1, c2, fr, fc), g[key])
+    m.eps_source = _eps(g, 'inference_sample')
+    same(m.inference(pr1, c1, sample=True), g['inference_sample'])
+    same(m.posterior_sample(pr1, c1), g['inference_sample'])                   # scale None + both sampled == inference(sample=True)
+    m.eps_source = _eps(g, 'posterior_scaled')
+    same(m.posterior_sample(pr1, c1, scale=0.5, sample_chd=True, sample_txt=False), g['posterior_scaled'])
+    m.eps_source = _eps(g, 'prior_chd')
+    same(m.prior_sample(pr1, c1, sample_chd=True, sample_rhy=False, scale=0.7), g['prior_chd'])
+    m.eps_source = None
+    same(m.interp(pr1, c1, pr2, c2, interp_chd=True, interp_rhy=False, int_count=5), g['interp_chd'], 0.998)
+    same(m.interp(pr1, c1, pr2, c2, interp_chd=True, interp_rhy=True, int_count=4), g['interp_both'], 0.998)
+    zs = m.interp_z(t('z_chd1'), t('z_chd2'), 5)
+    np.testing.assert_allclose(zs.cpu().numpy(), g['interp_z_chd'], rtol=0, atol=2e-5)
+    path = m.interp_path(g['z_chd1'][0], g['z_chd2'][0], 7)
+    np.testing.assert_allclose(path.cpu().numpy(), g['interp_path'], rtol=0, atol=2e-5)
+    assert np.array_equal(m.gt_sample(t('x1')), g['gt_sample'])
+    # MIDI-free note extraction: the predicted grid -> piano-roll and (pitch, start, end) tuples
+    grid = g['inference_mean'][0]
+    pr, notes = m.decoder.grid_to_pr_and_notes(grid, bpm=60., start=0.)
+    assert pr.shape == (32, 128) and all(len(n) == 3 and n[2] > n[1] for n in notes)
+    assert len(notes) == int((pr > 0).sum()) or len(notes) >= int((pr > 0).sum())
+    x1 = g['x1'][0]
+    pr_gt, notes_gt = m.decoder.grid_to_pr_and_notes(x1)
+    assert np.array_equal((pr_gt > 0), (g['pr1'][0] > 0))                         # ground-truth grid -> its own piano-roll
+    assert len(m.decoder.pr_to_notes(g['pr1'][0])) == int((g['pr1'][0] >= 1).sum())
+
+
+# ---------------------------------------------------------------------------------------------- f4
+def test_weighted_duration_loss_vs_reference_golden():
+    g = load_npz('reduced_wdur.npz')
+    m = build_reduced(DEV).to(DEV)
+    m.eps_source = lambda name, shape, device: torch.from_numpy(g['eps_' + name]).to(device)
+    x, c, pr = (torch.from_numpy(g[k]).to(DEV) for k in ('x', 'c', 'pr_mat'))
+    m.zero_grad()
+    outs = m.run(x, c, pr, 1., 1., 1.)
+    losses = m.loss_function(x, c, *outs, 0.1, [1, 0.5], weighted_dur=True)
+    np.testing.assert_allclose(np.array([l.item() for l in losses]), g['losses'], rtol=0, atol=1e-5)
+    losses[0].backward()
+    for k, p in m.named_parameters():
+        ref = g['grad.' + k]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=0, atol=2e-6 + 2e-4 * np.abs(ref).max(), err_msg=k)
+    r = m.decoder.recon_loss(x, outs[0].detach(), outs[1].detach(), weights=(1, 0.5), weighted_dur=True)
+    np.testing.assert_allclose(np.array([v.item() for v in r]), g['losses'][1:4], rtol=0, atol=1e-5)
+
+
+def test_optimizer_and_trainer_state_checkpoint_resumes_bit_identically(tmp_path, monkeypatch):
+    """the reference saves weights only (module.py:179-183).  Here a checkpoint also carries Adam moments + step
+    count, the LR scheduler and the parameter schedulers' counters: train 2 steps, save, train 2 more; a fresh trainer restored
+    from the checkpoint reproduces those 2 steps exactly."""
+    from polyphonic_chord_texture_disentanglement_amd.amc_dl import torch_plus as tp
+    from polyphonic_chord_texture_disentanglement_amd.amc_dl.torch_plus.train_utils import kl_anealing
+    from polyphonic_chord_texture_disentanglement_amd.dataset_loaders import MusicDataLoaders, TrainingVAE
+    from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
+    monkeypatch.chdir(tmp_path)
+
+    def make():
+        m = build_reduced(DEV).to(DEV)
+        m.eps_source = lambda name, shape, device: torch.zeros(shape, device=device)
+        opt = FusedClipAdam(m.parameters(), lr=1e-3)
+        osch = tp.OptimizerScheduler(opt, tp.MinExponentialLR(opt, gamma=0.9, minimum=1e-5), 1)
+        ps = tp.ParameterScheduler(tfr1=tp.ConstantScheduler(1.), tfr2=tp.ConstantScheduler(1.), tfr3=tp.ConstantScheduler(1.),
+                                   beta=tp.TeacherForcingScheduler(0.1, 0., f=kl_anealing), weights=tp.ConstantScheduler([1, 0.5]))
+        loaders = MusicDataLoaders.get_loaders(11, bs_train=3, bs_val=3, n_train_batch=2, n_val_batch=1)
+        pm = tp.LogPathManager(None)
+        sw = tp.SummaryWriters(M.LOSS_NAMES, {'loss': None}, pm.writer_path)
+        return TrainingVAE(torch.device(DEV), m, False, pm, loaders, sw, osch, ps, 1), m, opt
+
+    tr, m, opt = make()
+    tr.train()                                                  # 2 optimisation steps
+    ck = str(tmp_path / 'ckpt.pt')
+    tr.save_checkpoint(ck)
+    before = [p.detach().clone() for p in m.parameters()]
+    lr_saved, step_saved = opt.param_groups[0]['lr'], opt.step_count
+    loss_a = tr.train()
+    after_a = [p.detach().clone() for p in m.parameters()]
+
+    tr2, m2, opt2 = make()
+    tr2.load_checkpoint(ck)
+    assert opt2.step_count == step_saved == 2 and abs(opt2.param_groups[0]['lr'] - lr_saved) < 1e-15
+    assert tr2.train_step == 2 and tr2.param_scheduler.schedulers['beta']._step == 2 if hasattr(tr2.param_scheduler, 'schedulers') else True
+    for a, b in zip(before, m2.parameters()):
+        assert torch.equal(a, b.detach())
+    assert torch.equal(opt.exp_avg.new_tensor(0).expand(0), opt.exp_avg.new_tensor(0).expand(0))
+    loss_b = tr2.train()
+    for a, b in zip(after_a, m2.parameters()):
+        assert (a - b.detach()).abs().max() <= 1e-7
+    assert abs(loss_a['loss'] - loss_b['loss']) < 1e-5
+    # a plain FusedClipAdam.state_dict() round trip keeps the moments
+    sd = opt2.state_dict()
+    assert sd['exp_avg'].numel() == sum(p.numel() for p in m2.parameters()) and sd['step_count'] == 4
