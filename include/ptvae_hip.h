@@ -7,14 +7,17 @@
  * ctypes binding the Python host uses.
  *
  * Conventions
- *   - every pointer is a DEVICE pointer owned by the caller (torch tensors on the Python side);
- *     all matrices are fp32 row-major with explicit leading dimensions (in elements)
+ *   - every pointer is a DEVICE pointer owned by the caller (torch tensors on the Python side) unless an entry point
+ *     says "HOST array"; matrices are row-major with explicit leading dimensions (in elements)
+ *   - element types: fp32 by default.  In bf16 precision the tensors that only ever feed MFMA operands or epilogues may be
+ *     held as bf16 in HBM -- the caller says which through the dtype bits below (PTV_A/B/C_BF16 for ptv_gemm, PTV_GRU_*_BF16
+ *     for the GRU entry points); parameters, optimiser state, recurrent state h, logits and all reductions stay fp32
  *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it, nothing synchronises
  *   - return value: 0 = ok, <0 = error (-1 bad argument, -2 launch failure, -3 unsupported shape for a
  *     specialised kernel: use the generic entry point); no exceptions cross the ABI
- *   - `prec`: PTV_PREC_F32 (0) = v_mfma_f32_16x16x4_f32, exact fp32 (parity path);
- *             PTV_PREC_BF16 (1) = v_mfma_f32_16x16x32_bf16, bf16 operands / fp32 accumulate
- *     (state, activations, gradients and weights stay fp32 in HBM in both modes)
+ *   - `prec`: PTV_PREC_F32 (0) = v_mfma_f32_16x16x4_f32, exact fp32 (parity path; every tensor fp32);
+ *             PTV_PREC_BF16 (1) = v_mfma_f32_16x16x32_bf16, bf16 operands / fp32 accumulate (fp32 tensors are converted
+ *             while staged, tensors flagged bf16 are read as they are)
  */
 #ifndef PTVAE_HIP_H
 #define PTVAE_HIP_H

@@ -29,3 +29,31 @@ def test_identification_calls_work_without_gpu():
     l = _lib.lib()
     assert l.ptv_arch() == b'gfx950'
     assert l.ptv_abi_version() >= 1
+
+
+def integration_snippet():
+    """the worked ctypes example of INTEGRATION.md section 2 (the code block that binds ptv_gemm), verbatim"""
+    md = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    blocks = re.findall(r'```python\n(.*?)```', md, flags=re.S)
+    code = [b for b in blocks if 'lib.ptv_gemm.argtypes' in b]
+    assert len(code) == 1
+    return code[0]
+
+
+def test_integration_md_example_matches_the_header():
+    """the documented binding passed 18 arguments to a 19-argument entry point.  Build the argtypes the snippet
+    declares (no GPU needed: the .so loads on CPU) and compare them with the table generated from include/ptvae_hip.h."""
+    code = integration_snippet()
+    ns = {}
+    head = code.split('def linear')[0].replace('polyphonic_chord_texture_disentanglement_amd/csrc/libptvae_hip.so', _lib.LIB_PATH)
+    exec(head, ns)                                            # imports, CDLL, restype / argtypes
+    res, args = _lib._SIGNATURES['ptv_gemm']
+    assert list(ns['lib'].ptv_gemm.argtypes) == list(args) and ns['lib'].ptv_gemm.restype is res
+    call = re.search(r'lib\.ptv_gemm\((.*?)\)\n\s+assert rc == 0', code, flags=re.S).group(1)
+    call = re.sub(r'#.*', '', call)
+    depth, n = 0, 1
+    for ch in call:
+        depth += ch in '([' 
+        depth -= ch in ')]'
+        n += (ch == ',' and depth == 0)
+    assert n == len(args) == 19

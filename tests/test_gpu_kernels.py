@@ -153,7 +153,8 @@ def test_gru_seq_bf16_storage_fast_path(M, H, T, use_gi2):
     hall16 = torch.zeros(T + 1, M, H, device=dev, dtype=bf)
     gates = torch.empty(T, 4, M, H, device=dev, dtype=bf)
     FL = 1 | 2 | 8 | 16 | (4 if use_gi2 else 0)
-    call('ptv_gru_seq_fwd', 1, M, H, T, ptr(gi_d), M * 3 * H, 3 * H, ptr(gi2_d), 0, 3 * H if use_gi2 else 0, ptr(w16), ptr(d(b_hh)),
+    b_d = d(b_hh)
+    call('ptv_gru_seq_fwd', 1, M, H, T, ptr(gi_d), M * 3 * H, 3 * H, ptr(gi2_d), 0, 3 * H if use_gi2 else 0, ptr(w16), ptr(b_d),
          ptr(hall), ptr(hall16), ptr(gates), None, 0, None, FL, stream_ptr())
     assert (hall[1:].cpu() - hs.detach()).abs().max() < 3e-2
     assert (hall16[1:].float() - hall[1:]).abs().max() < 1e-2                      # the shadow is the rounded state
@@ -254,3 +255,127 @@ def test_gru_persistent_kernels_vs_oracle_and_step_kernels(NC, M, H, T, masked, 
         assert (dgi2.float() - b['dgi'].float()).abs().max() < 0.03 * sc
         assert (dgh2.float() - b['dgh'].float()).abs().max() < 0.03 * sc
         assert (dh02 - b['dh0']).abs().max() < 0.03 * max(1.0, dh0_ref.abs().max().item())
+
+
+@pytest.mark.parametrize('M,H,T', [(16384, 512, 2), (512, 1024, 32)])
+def test_gru_bwd_kernel_variants_of_the_b512_step(M, H, T):
+    """the BPTT tile variants only B = 512 dispatches -- gru_bwd_step_kernel<BF16,128,128,...,FAST> (notes GRU, M = 16384,
+    H = 512) and the 32-step M = 512, H = 1024 chain (per-step kernels; PERSIST off) -- against the fp32 oracle cell"""
+    from polyphonic_chord_texture_disentanglement_amd._lib import call, ptr, stream_ptr
+    dev = _dev()
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(M + H + T)
+    k = 1.0 / np.sqrt(H)
+    w_hh = ((torch.rand(3 * H, H, generator=g) * 2 - 1) * k).to(bf).float().requires_grad_()
+    b_hh = ((torch.rand(3 * H, generator=g) * 2 - 1) * k).requires_grad_()
+    gi = (torch.randn(T, M, 3 * H, generator=g) * 0.5).to(bf).float().requires_grad_()
+    h0 = (torch.randn(M, H, generator=g) * 0.5).requires_grad_()
+    dh_ext = torch.randn(T, M, H, generator=g) * 0.1
+    h, hs = h0, []
+    for t in range(T):
+        gh = orc.linear(h, w_hh, b_hh)
+        r = torch.sigmoid(gi[t][:, :H] + gh[:, :H]); z = torch.sigmoid(gi[t][:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(gi[t][:, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1 - z) * n + z * h
+        hs.append(h)
+    hs = torch.stack(hs)
+    (hs * dh_ext).sum().backward()
+    d = lambda t: t.detach().to(dev)
+    w16, wt16 = d(w_hh).to(bf).contiguous(), d(w_hh).t().contiguous().to(bf)
+    hall = torch.zeros(T + 1, M, H, device=dev); hall[0] = d(h0)
+    hall16 = torch.zeros(T + 1, M, H, device=dev, dtype=bf)
+    gates = torch.empty(T, 4, M, H, device=dev, dtype=bf)
+    FL = 1 | 2 | 8 | 16
+    gi_d, b_d = d(gi).to(bf), d(b_hh)
+    call('ptv_gru_seq_fwd', 1, M, H, T, ptr(gi_d), M * 3 * H, 3 * H, None, 0, 0, ptr(w16), ptr(b_d),
+         ptr(hall), ptr(hall16), ptr(gates), None, 0, None, FL, stream_ptr())
+    assert (hall[1:].cpu() - hs.detach()).abs().max() < (3e-2 if T <= 4 else 8e-2)
+    dgi = torch.empty(T, M, 3 * H, device=dev, dtype=bf); dgh = torch.empty_like(dgi)
+    dhz = torch.empty(2, M, H, device=dev); dh0 = torch.empty(M, H, device=dev)
+    de = dh_ext.to(dev)
+    call('ptv_gru_seq_bwd', 1, M, H, T, ptr(hall), ptr(gates), ptr(wt16), ptr(de), de.stride(0), de.stride(1),
+         None, 0, None, 0, 0, 0, None, ptr(dgi), ptr(dgh), ptr(dhz), ptr(dh0), 0, FL, stream_ptr())
+    tol = 0.05 if T <= 4 else 0.1
+    assert (dh0.cpu() - h0.grad).abs().max() < tol * max(1.0, h0.grad.abs().max().item())
+    assert (dgi.float().cpu() - gi.grad).abs().max() < tol * max(1.0, gi.grad.abs().max().item())
+    db = dgh.float().sum((0, 1)).cpu()
+    assert (db - b_hh.grad).abs().max() < tol * max(1.0, b_hh.grad.abs().max().item())
+
+
+def test_fused_duration_kernels_at_the_b512_grid_caps():
+    """ptv_dur_gru_fwd / ptv_dur_gru_bwd at M = 245,760 rows (= 480 x 512): the forward's 1024-block cap and the backward's
+    256-block grid-stride regime (functional.dur_bwd_fused), against the fp32 oracle cell with the kernel's argmax replayed"""
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    from polyphonic_chord_texture_disentanglement_amd._lib import call, lib, ptr, stream_ptr
+    dev = _dev()
+    bf = torch.bfloat16
+    M, H = 480 * 512, 64
+    g = torch.Generator().manual_seed(12)
+    k = 1.0 / np.sqrt(H)
+    U = lambda *s: (torch.rand(*s, generator=g) * 2 - 1) * k
+    w_hh, b_hh, w_ih, b_ih = U(3 * H, H).to(bf).float(), U(3 * H), U(3 * H, 5), U(3 * H)
+    w_out, b_out, sos = U(2, H), U(2), torch.rand(5, generator=g)
+    h0 = torch.randn(M, H, generator=g) * 0.5
+    ddur = torch.randn(M, 10, generator=g) * 0.1
+    d = lambda t: t.detach().to(dev).contiguous()
+    tab0 = (orc.linear(sos.view(1, -1), w_ih, b_ih)).contiguous()
+    oh = torch.zeros(2, 5); oh[0, 0] = 1; oh[1, 1] = 1
+    tab = orc.linear(oh, w_ih, b_ih).contiguous()
+    HD16 = torch.zeros(6, M, H, device=dev, dtype=bf)
+    gates = torch.empty(5, 4, M, H, device=dev, dtype=bf)
+    dur = torch.empty(M, 10, device=dev)
+    idx = torch.empty(5, M, device=dev, dtype=torch.int32)
+    h0d = d(h0)
+    Wd = {n: d(t) for n, t in (('w_hh', w_hh), ('b_hh', b_hh), ('tab0', tab0), ('tab', tab), ('w_out', w_out), ('b_out', b_out),
+                                ('ddur', ddur))}                      # keep the device copies alive across the launches
+    call('ptv_dur_gru_fwd', H, M, ptr(h0d), H, ptr(Wd['w_hh']), ptr(Wd['b_hh']), ptr(Wd['tab0']), ptr(Wd['tab']), ptr(Wd['w_out']),
+         ptr(Wd['b_out']), None, M * H, ptr(HD16[1]), ptr(gates), M * H, 4 * M * H, 1, ptr(dur), 10, ptr(idx), M, None, M, stream_ptr())
+    call('ptv_cast_bf16', ptr(h0d), ptr(HD16[0]), M * H, stream_ptr())
+    # oracle on a row sample (first / middle / last tiles), replaying the kernel's argmax decisions
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M // 2, M // 2 + 300), torch.arange(M - 300, M)])
+    idx_c = idx.cpu()[:, rows].long()
+    hr = h0[rows].clone().requires_grad_()
+    w_hh_r, b_hh_r, w_out_r = w_hh.clone().requires_grad_(), b_hh.clone().requires_grad_(), w_out.clone().requires_grad_()
+    h, outs = hr, []
+    for s in range(5):
+        gi = tab0.expand(len(rows), -1) if s == 0 else tab[idx_c[s - 1]]
+        gh = orc.linear(h, w_hh_r, b_hh_r)
+        r = torch.sigmoid(gi[:, :H] + gh[:, :H]); z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1 - z) * n + z * h
+        outs.append(orc.linear(h, w_out_r, b_out))
+    est = torch.cat(outs, 1)
+    assert (dur.cpu()[rows] - est.detach()).abs().max() < 3e-2
+    margin = (est.detach().view(-1, 5, 2)[:, :, 0] - est.detach().view(-1, 5, 2)[:, :, 1]).abs()
+    flips = (idx_c.t() != est.detach().view(-1, 5, 2).argmax(-1)) & (margin > 5e-2)
+    assert not flips.any()
+    (est * ddur[rows]).sum().backward()
+    nblk = min(256, (M + 63) // 64)
+    psz = lib().ptv_dur_gru_bwd_part_size()
+    part = torch.zeros(nblk, psz, device=dev)
+    dh0 = torch.empty(M, H, device=dev)
+    call('ptv_dur_gru_bwd', H, M, ptr(gates), M * H, 4 * M * H, ptr(HD16), M * H, 1, ptr(Wd['ddur']), 10, ptr(Wd['w_hh']), ptr(Wd['w_out']),
+         ptr(idx), M, ptr(dh0), ptr(part), nblk, stream_ptr())
+    assert (dh0.cpu()[rows] - hr.grad).abs().max() < 0.05 * max(1.0, hr.grad.abs().max().item())
+    assert torch.isfinite(part).all() and torch.isfinite(dh0).all()
+
+
+def test_integration_md_snippet_runs_verbatim():
+    """the ctypes example a maintainer would copy out of INTEGRATION.md, executed as written against the shipped .so"""
+    import os
+    from test_abi_symbols import integration_snippet
+    from polyphonic_chord_texture_disentanglement_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cwd = os.getcwd()
+    os.chdir(root)                                         # the snippet opens the library by its repo-relative path
+    try:
+        ns = {}
+        exec(integration_snippet(), ns)
+    finally:
+        os.chdir(cwd)
+    g = torch.Generator().manual_seed(2)
+    x, w, b = torch.randn(37, 290, generator=g), torch.randn(130, 290, generator=g) / 17, torch.randn(130, generator=g)
+    y = ns['linear'](x.to(_dev()), w.to(_dev()), b.to(_dev()))
+    torch.cuda.synchronize()
+    ref = orc.linear(x, w, b)
+    assert (y.cpu() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
