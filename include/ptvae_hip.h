@@ -304,6 +304,37 @@ int ptv_batch_transform(const unsigned char* pr, const float* chord14, const int
 int ptv_slerp_path(const float* z1, const float* z2, float* out, int B, int D, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Free-running / scheduled-sampling decoder as row-partitioned persistent kernels (csrc/freerun.hip): PtvaeDecoder.decode_notes
+ * + decode_note (ptvae.py:336-428) for ONE time step t and ALL 15 note steps in one launch, a workgroup per panel of 16 samples
+ * (state in LDS / registers, weights streamed from L2 in MFMA-fragment-major packing), and the re-summarisation of the
+ * predicted notes (bi-GRU with packed-sequence masking, ptvae.py:476-486) that yields the next time-step token.
+ * bf16 MFMA operands, fp32 state / logits; init_model() geometry only (E = He = 128, Hn = 512, Hd = 64, 130 pitches).
+ *   ptv_pack_mfma_b: W fp32 [N][ld] (K columns from the given base) -> bf16 [ceil(N/16)][ceil(K/32)][64 lanes][8]: the B fragment
+ *     of 16 rows x 32 k as one contiguous 1-KB wave load (zero padded); ptv_pack_mfma_b_size = elements of `out`.
+ *   ptv_free_note_loop: w / io are HOST arrays of 16 / 17 device pointers:
+ *     w  = { pack(dec_notes_gru.weight_hh), pack(dec_notes_gru.weight_ih[:, Ht:]), pack(pitch_out_linear.weight),
+ *            pack(dur_hid_linear.weight[:, :512]), pack(dur_hid_linear.weight[:, 512:]), pack(dec_dur_gru.weight_hh),
+ *            dec_notes_gru.bias_hh, pitch_out_linear.bias, dur_hid_linear.bias, dec_dur_gru.bias_hh, tab0 [192] = W_ih_d sos + b,
+ *            tab [2][192] = W_ih_d onehot(0/1) + b, dur_out_linear.weight, .bias, note_embedding.weight^T [135][128], .bias }
+ *     io = { gc [B][1536] (W_ih_n[:, :Ht] ns + b_ih for this t), emb [16][R][128] ground-truth embedding or NULL,
+ *            HN [16][R][512] (slot 0 rows of t = initial state, written by the caller), gates_n [15][4][R][512] bf16,
+ *            pitch [M][ld_pitch], HD [6][M][64], gates_d [5][4][M][64] bf16, dur [M][10], idx [5][M] int32,
+ *            TOK [15][R][128] (slot 0 rows of t = first token, written by the caller), PRED [16][R][128],
+ *            xhat [B][32][16][6] int64, plen [R] int32 (zeroed), force_pitch [15][R] or NULL, force_dur [5][M] or NULL,
+ *            HN16 [16][R][512] bf16 or NULL, HD16 [6][M][64] bf16 or NULL (bf16 state copies for the backward; HD16 replaces HD[1..5]) }
+ *     with R = 32*B, M = 15*R; the rows of time step t are [t*B, (t+1)*B).  coin_mask bit n = feed the ground-truth note n+1
+ *     (teacher-forcing coin, ptvae.py:420).  train = 0 skips what only the backward reads (HN, gates, HD, TOK).
+ *   ptv_free_resummarize: w = { pack(W_ih), pack(W_hh), pack(W_ih_reverse), pack(W_hh_reverse), b_ih, b_hh, b_ih_r, b_hh_r } of
+ *     dec_notes_emb_gru; io = { PRED, plen, XH fwd [17][R][128] (slot 0 zero), XH bwd, XG fwd [16][4][R][128] bf16, XG bwd,
+ *     tok_next = TOKS[t+1] [B][256] }.
+ */
+long ptv_pack_mfma_b_size(int N, int K);
+int ptv_pack_mfma_b(const float* W, long ld, int N, int K, void* out, void* stream);
+int ptv_free_note_loop(const void* const* w, const void* const* io, long ld_pitch, int B, int t, unsigned coin_mask, int train,
+                       void* stream);
+int ptv_free_resummarize(const void* const* w, const void* const* io, int B, int t, int train, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * clip_grad_norm_ (module.py:142-143) + torch.optim.Adam.step (train.py:50, scheduler.py:69-74) over
  * flat fp32 buffers: sumsq = |g|^2 (device scalar), then p,m,v updated with g*gscale clipped to `clip`.
  */

@@ -26,7 +26,7 @@ def _parse_header(path):
     src = open(path).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     sigs = {}
-    for m in re.finditer(r'(const char\*|int)\s+(ptv_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;', src, flags=re.S):
+    for m in re.finditer(r'(const char\*|int|long)\s+(ptv_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;', src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         argtypes = []
         if args and args != 'void':
@@ -40,13 +40,15 @@ def _parse_header(path):
                     argtypes.append(ctypes.c_ulonglong)
                 elif a.startswith('long '):
                     argtypes.append(ctypes.c_long)
+                elif a.startswith('unsigned '):
+                    argtypes.append(ctypes.c_uint)
                 elif a.startswith('int '):
                     argtypes.append(ctypes.c_int)
                 elif a.startswith('float '):
                     argtypes.append(ctypes.c_float)
                 else:
                     raise RuntimeError('unparsed argument %r of %s' % (a, name))
-        sigs[name] = (ctypes.c_char_p if ret.startswith('const char') else ctypes.c_int, argtypes)
+        sigs[name] = (ctypes.c_char_p if ret.startswith('const char') else (ctypes.c_long if ret == 'long' else ctypes.c_int), argtypes)
     return sigs
 
 

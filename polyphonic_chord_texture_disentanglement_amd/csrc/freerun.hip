@@ -1,0 +1,589 @@
+// freerun.hip -- the free-running / scheduled-sampling PianoTree decoder as row-partitioned persistent kernels.
+//
+// Reference: PtvaeDecoder.decode_notes / decode_note (ptvae.py:336-428) and the re-summarisation of the predicted notes
+// (ptvae.py:476-486) -- what the reference's train.py schedule runs from its third batch on and what
+// inference_decode runs always (model.py:124-131).  Every next token is an argmax of the previous step, so the forward is a
+// 32 x 15 x (1 + 5) deep dependency chain; as per-step launches on [B]-row windows it was ~9,000 launches per forward, each
+// using a sliver of the chip (6.1k samples/s at B = 512 against 30k teacher-forced).
+//
+// Samples are independent, so the chain is partitioned by ROWS: a workgroup owns a panel of 16 samples (one MFMA M tile)
+// and walks, for one time step t, ALL 15 note steps by itself:
+//     notes-GRU cell  ->  pitch head  ->  argmax  ->  dur_hid  ->  5-step duration GRU + argmax feedback  ->  token embed
+// with the panel's state in LDS / registers (h fp32 + bf16, logits, duration state) and the weights streamed from L2 in an
+// MFMA-fragment-major packing (ptv_pack_mfma_b: a B fragment of 16 units x 32 k is ONE contiguous 1-KB wave load; reading
+// fragments out of the row-major weight costs 64 cache-line lookups per load and binds on the address path).  Nothing is
+// exchanged between workgroups: no flags, no residency requirement.  What the batched backward needs (states, gates,
+// logits, tokens) is streamed out in the step-major layouts of functional_free.DecoderStepFn, which is unchanged.
+// A second kernel runs the bi-GRU over a panel's 16 predicted notes (packed-sequence masking by the predicted length) that
+// produces the next time-step token.  The time GRU step itself (M = B rows, H = 1024: 7.8 MB of weights per step) stays on
+// the chip-wide step kernels of gru.hip.
+// Specialised to the init_model() geometry (E = 128, Hn = 512, Hd = 64, He = 128, 130 pitches), bf16 MFMA operands, fp32
+// state / logits -- the bf16 precision policy of the teacher-forced path.  Other configurations use the step loop.
+#include "common.hpp"
+#include "gemm_core.hpp"
+#include "../../include/ptvae_hip.h"
+
+namespace ptv {
+
+constexpr int FE = 128, FHN = 512, FHD = 64, FNP = 130, FHE = 128;
+constexpr int FP = 16;                       // rows per panel
+constexpr int H16LD = FHN + 16;              // bf16 row strides: stride/2 words = 8 (mod 64) -> conflict-free b128 fragment reads
+constexpr int T16LD = FE + 16;
+constexpr int P16LD = 160 + 16;              // pitch logits as an MFMA operand, K padded 130 -> 160
+constexpr int D16LD = FHD + 16;
+constexpr int PITLD = 144;                   // fp32 logits row (9 tiles)
+
+__device__ __forceinline__ float fsig(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
+// accumulator fragment (C layout: lane = row + 16*quad) -> epilogue layout (lane = 4*row + quad): afterwards 4 ADJACENT lanes
+// hold the 16 units of one row, so global traffic of the epilogue goes out in 32-64 byte runs instead of 64 scattered pieces
+__device__ __forceinline__ f32x4 to_rowmajor_lanes(const f32x4& v) {
+  const int lane = threadIdx.x & 63, src = (lane >> 2) + 16 * (lane & 3);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; e++) o[e] = __shfl(v[e], src, 64);
+  return o;
+}
+
+// acc[j] += A(LDS bf16 [16][lda], K = KB*32) . Wp(tile j)^T ; packed tiles: frag (tile, kb) at wp[(tile*KB + kb)*64 + lane].
+// The k loop is unrolled by UN only: UN*NT fragment loads (16 B per lane each) are in flight per iteration -- a full unroll
+// lets the compiler hoist every load of the product and spill.
+template <int NT, int KB, int UN>
+__device__ __forceinline__ void panel_mma(const bf16x8* __restrict__ wp, const int (&tile)[NT], const __bf16* A, int lda, f32x4 (&acc)[NT]) {
+  const int lane = threadIdx.x & 63, rl = lane & 15, kq = (lane >> 4) * 8;
+  static_assert(KB % UN == 0 || KB < UN, "unroll factor");
+#pragma unroll 1
+  for (int k0 = 0; k0 < KB; k0 += UN) {
+    bf16x8 b[UN][NT];
+#pragma unroll
+    for (int q = 0; q < UN; q++)
+#pragma unroll
+      for (int j = 0; j < NT; j++)
+        if (k0 + q < KB) b[q][j] = wp[((long)tile[j] * KB + k0 + q) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < UN; q++) {
+      if (k0 + q < KB) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + rl * lda + (k0 + q) * 32 + kq);
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[q][j], a, acc[j], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// the gate products of one pass (6 tiles: r0 r1 z0 z1 n0 n1): accH += h . W_hh^T (K = 512), accT += token . W_ih[:, Ht:]^T
+// (K = 128) as ONE explicitly software-pipelined stream of 5 groups of 4 k-blocks (24 fragment loads = 24 KB per wave each):
+// the loads of group g+1 are issued before the MFMAs of group g, with static register double buffers.  Left to the compiler the
+// same loop came out either pipelined (14 us per note step) or with every group's latency exposed (36 us) from build to build.
+template <int KBH, int KBT>
+__device__ __forceinline__ void gate_products(const bf16x8* __restrict__ wh, const bf16x8* __restrict__ wt, const int (&tile)[6],
+                                              const __bf16* Ah, int ldh, const __bf16* At, int ldt, f32x4 (&accH)[6], f32x4 (&accT)[6]) {
+  static_assert(KBH % 4 == 0 && KBT == 4, "groups of 4 k-blocks");
+  const int lane = threadIdx.x & 63, rl = lane & 15, kq = (lane >> 4) * 8;
+  constexpr int NG = KBH / 4;
+  bf16x8 b[2][4][6];
+  auto ld = [&](bf16x8 (&d)[4][6], const bf16x8* w, int KB, int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int j = 0; j < 6; j++) d[q][j] = w[((long)tile[j] * KB + k0 + q) * 64 + lane];
+  };
+  auto mm = [&](const bf16x8 (&d)[4][6], const __bf16* A, int lda, int k0, f32x4 (&acc)[6]) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + rl * lda + (k0 + q) * 32 + kq);
+#pragma unroll
+      for (int j = 0; j < 6; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d[q][j], a, acc[j], 0, 0, 0);
+    }
+  };
+  ld(b[0], wh, KBH, 0);
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    if (g + 1 < NG) ld(b[(g + 1) & 1], wh, KBH, (g + 1) * 4);
+    else ld(b[(g + 1) & 1], wt, KBT, 0);
+    mm(b[g & 1], Ah, ldh, g * 4, accH);
+  }
+  mm(b[NG & 1], At, ldt, 0, accT);
+}
+
+__device__ __forceinline__ void st_bf16x4_lds(__bf16* p, float a, float b, float c, float d) {
+  bf16x4 v; v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
+  *reinterpret_cast<bf16x4*>(p) = v;
+}
+
+// =============================================================================================
+// weight packing: W fp32 [N][ld] (columns 0..K-1 of the given base) -> MFMA B-fragment-major bf16
+//   out[((nt*KB + kb)*64 + lane)*8 + e] = W[nt*16 + (lane & 15)][kb*32 + (lane >> 4)*8 + e]   (0 beyond N / K)
+// =============================================================================================
+__global__ void pack_b_kernel(const float* __restrict__ W, long ld, int N, int K, __bf16* __restrict__ out, int NT, int KB) {
+  const long total = (long)NT * KB * 64;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const long f = i >> 6;
+    const int kb = (int)(f % KB), nt = (int)(f / KB);
+    const int n = nt * 16 + (lane & 15), k0 = kb * 32 + (lane >> 4) * 8;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = (__bf16)((n < N && k0 + e < K) ? W[(long)n * ld + k0 + e] : 0.f);
+    *reinterpret_cast<bf16x8*>(out + i * 8) = v;
+  }
+}
+
+// =============================================================================================
+// note loop of one time step for one 16-row panel
+// =============================================================================================
+struct NoteLoopArgs {
+  const bf16x8 *wg_h, *wg_t, *wp, *wd_h, *wd_p, *wdur;
+  const float *b_hh_n, *b_p, *b_dh, *b_hh_d, *tab0, *tab, *w_out, *b_out, *w_embT, *b_emb;
+  const float* gc;                 // [B][1536] hoisted input part of the notes GRU for this t (b_ih included)
+  const float* emb;                // ground-truth embedding, step-major [16][R][128]; null in inference
+  float* HN; __bf16* gates_n; float* pitch; long ld_pitch; float* HD; __bf16* gates_d; float* dur; int* idx;
+  float* TOK; float* PRED; long* xhat; int* plen;
+  const int* force_pitch; const int* force_dur;
+  long* dbg_out;                  // timing experiments: per workgroup {XCC id, CU/SE id word, cycles}
+  __bf16* HN16; __bf16* HD16;     // optional bf16 copies of the states (operands of the backward's products); HD16 replaces HD[1..5]
+  int B, t, R, M;
+  unsigned coin_mask;              // bit n: the token fed to note step n+1 is the ground truth (teacher forcing coin, ptvae.py:420)
+  int train;                       // save what the backward needs (states, gates, fed tokens)
+  int dbg;                         // timing experiments: skip phases (results invalid)
+};
+
+__global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
+  __shared__ __attribute__((aligned(16))) float hf[FP][FHN];                   // notes-GRU state, fp32
+  __shared__ __attribute__((aligned(16))) __bf16 h16[2][FP][H16LD];            // its bf16 MFMA-operand copy (double buffered)
+  __shared__ __attribute__((aligned(16))) __bf16 tok16[FP][T16LD];             // current input token
+  __shared__ __attribute__((aligned(16))) float pit[FP][PITLD];                // pitch logits
+  __shared__ __attribute__((aligned(16))) __bf16 pit16[FP][P16LD];
+  __shared__ __attribute__((aligned(16))) float hdf[FP][FHD];                  // duration-GRU state
+  __shared__ __attribute__((aligned(16))) __bf16 hd16[2][FP][D16LD];
+  __shared__ __attribute__((aligned(16))) bf16x8 wdl[12 * 2 * 64];             // duration W_hh, fragment-major (24 KB)
+  __shared__ float tabs[3][3 * FHD];
+  __shared__ float bhd[3 * FHD];
+  __shared__ float wo[2 * FHD + 2];
+  __shared__ float part[4][FP][2];
+  __shared__ int pidx[FP];
+  __shared__ int dtok[FP];
+  __shared__ int bits[FP][5];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long t_begin = a.dbg_out ? (long)__builtin_amdgcn_s_memtime() : 0;
+  const int crow = lane & 15, ckq = lane >> 4;                // accumulator (C) layout
+  const int erow = lane >> 2, eq = lane & 3;                  // epilogue layout
+  const int B = a.B, R = a.R, t = a.t;
+  const long M = a.M;
+  const int r0 = blockIdx.x * FP;                             // first sample of the panel
+  const int rE = min(r0 + erow, B - 1), rC = min(r0 + crow, B - 1);
+  const bool okE = r0 + erow < B, okC = r0 + crow < B;
+  const long wrowE = (long)t * B + rE, wrowC = (long)t * B + rC;   // row in the [R]-row step-major matrices
+
+  // ---- one-time loads: duration GRU weights / tables -> LDS, initial state and first token -> LDS
+  for (int i = tid; i < 12 * 2 * 64; i += 256) wdl[i] = a.wdur[i];
+  for (int i = tid; i < 3 * FHD; i += 256) { tabs[0][i] = a.tab0[i]; tabs[1][i] = a.tab[i]; tabs[2][i] = a.tab[3 * FHD + i]; bhd[i] = a.b_hh_d[i]; }
+  for (int i = tid; i < 2 * FHD; i += 256) wo[i] = a.w_out[i];
+  if (tid < 2) wo[2 * FHD + tid] = a.b_out[tid];
+  for (int i = tid; i < FP * (FHN / 4); i += 256) {
+    const int row = i / (FHN / 4), c4 = (i % (FHN / 4)) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(a.HN + ((long)t * B + min(r0 + row, B - 1)) * FHN + c4);
+    *reinterpret_cast<float4*>(&hf[row][c4]) = v;
+    st_bf16x4_lds(&h16[0][row][c4], v.x, v.y, v.z, v.w);
+    if (a.train && a.HN16 && r0 + row < B) st_bf16x4_lds(a.HN16 + ((long)t * B + r0 + row) * FHN + c4, v.x, v.y, v.z, v.w);
+  }
+  for (int i = tid; i < FP * (FE / 4); i += 256) {
+    const int row = i / (FE / 4), c4 = (i % (FE / 4)) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(a.TOK + ((long)t * B + min(r0 + row, B - 1)) * FE + c4);
+    st_bf16x4_lds(&tok16[row][c4], v.x, v.y, v.z, v.w);
+  }
+  for (int i = tid; i < FP * (P16LD - FNP); i += 256) pit16[i / (P16LD - FNP)][FNP + i % (P16LD - FNP)] = (__bf16)0.f;   // K padding of the logits operand
+  if (tid < FP) pidx[tid] = 0;
+
+  __syncthreads();
+
+  for (int n = 0; n < 15; n++) {
+    const int cur = n & 1, nxt = cur ^ 1;
+    // ================= P1: notes-GRU cell.  wave w owns units [w*128, w*128+128) = 8 tiles of 16, two per pass =================
+#pragma unroll 1
+    for (int p = 0; p < ((a.dbg & 2) ? 0 : 4); p++) {
+      const int ut0 = wave * 8 + p * 2;
+      // per-lane constants in the epilogue layout (4 adjacent lanes = 16 units of one row): the hoisted input part GC (b_ih
+      // included) and b_hh, requested before the products
+      float4 gR[2], gZ[2], gN[2], bR[2], bZ[2], bN[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int u = (ut0 + j) * 16 + eq * 4;
+        const float* g = a.gc + (long)rE * (3 * FHN);
+        gR[j] = *reinterpret_cast<const float4*>(g + u); gZ[j] = *reinterpret_cast<const float4*>(g + FHN + u); gN[j] = *reinterpret_cast<const float4*>(g + 2 * FHN + u);
+        bR[j] = *reinterpret_cast<const float4*>(a.b_hh_n + u); bZ[j] = *reinterpret_cast<const float4*>(a.b_hh_n + FHN + u);
+        bN[j] = *reinterpret_cast<const float4*>(a.b_hh_n + 2 * FHN + u);
+      }
+      f32x4 accH[6], accT[6];                                   // (r0, r1, z0, z1, n0, n1): h . W_hh^T and token . W_ih[:, Ht:]^T
+#pragma unroll
+      for (int j = 0; j < 6; j++) accH[j] = accT[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int tl[6] = {ut0, ut0 + 1, 32 + ut0, 33 + ut0, 64 + ut0, 65 + ut0};
+      if (!(a.dbg & 1)) gate_products<16, 4>(a.wg_h, a.wg_t, tl, &h16[cur][0][0], H16LD, &tok16[0][0], T16LD, accH, accT);
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int u = (ut0 + j) * 16 + eq * 4;
+        f32x4 sR, sZ;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { sR[e] = accH[j][e] + accT[j][e]; sZ[e] = accH[2 + j][e] + accT[2 + j][e]; }
+        const f32x4 aR = to_rowmajor_lanes(sR), aZ = to_rowmajor_lanes(sZ), aI = to_rowmajor_lanes(accT[4 + j]), aH = to_rowmajor_lanes(accH[4 + j]);
+        const float4 hp4 = *reinterpret_cast<const float4*>(&hf[erow][u]);
+        const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+        const float kR[4] = {gR[j].x + bR[j].x, gR[j].y + bR[j].y, gR[j].z + bR[j].z, gR[j].w + bR[j].w};
+        const float kZ[4] = {gZ[j].x + bZ[j].x, gZ[j].y + bZ[j].y, gZ[j].z + bZ[j].z, gZ[j].w + bZ[j].w};
+        const float kN[4] = {gN[j].x, gN[j].y, gN[j].z, gN[j].w}, kB[4] = {bN[j].x, bN[j].y, bN[j].z, bN[j].w};
+        float r[4], z[4], nn[4], hn[4], h[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          r[e] = fsig(aR[e] + kR[e]);
+          z[e] = fsig(aZ[e] + kZ[e]);
+          hn[e] = aH[e] + kB[e];
+          nn[e] = ftanh(aI[e] + kN[e] + r[e] * hn[e]);
+          h[e] = (1.0f - z[e]) * nn[e] + z[e] * hp[e];
+        }
+        *reinterpret_cast<float4*>(&hf[erow][u]) = make_float4(h[0], h[1], h[2], h[3]);
+        st_bf16x4_lds(&h16[nxt][erow][u], h[0], h[1], h[2], h[3]);
+        if (a.train && okE) {
+          *reinterpret_cast<float4*>(a.HN + ((long)(n + 1) * R + wrowE) * FHN + u) = make_float4(h[0], h[1], h[2], h[3]);
+          if (a.HN16) st_bf16x4_lds(a.HN16 + ((long)(n + 1) * R + wrowE) * FHN + u, h[0], h[1], h[2], h[3]);
+          __bf16* gp = a.gates_n + (((long)n * 4) * R + wrowE) * FHN + u;
+          const long pl = (long)R * FHN;
+          st_bf16x4_lds(gp, r[0], r[1], r[2], r[3]);
+          st_bf16x4_lds(gp + pl, z[0], z[1], z[2], z[3]);
+          st_bf16x4_lds(gp + 2 * pl, nn[0], nn[1], nn[2], nn[3]);
+          st_bf16x4_lds(gp + 3 * pl, hn[0], hn[1], hn[2], hn[3]);
+        }
+      }
+    }
+    __syncthreads();
+    // ================= P2: pitch head (9 tiles over 4 waves) + dur_hid part 1 =================
+    for (int nt = wave; nt < ((a.dbg & 4) ? 0 : 9); nt += 4) {
+      f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+      const int tl[1] = {nt};
+      panel_mma<1, 16, 8>(a.wp, tl, &h16[nxt][0][0], H16LD, acc);
+      const int c0 = nt * 16 + ckq * 4;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int c = c0 + e;
+        const float v = c < FNP ? acc[0][e] + a.b_p[c] : 0.f;
+        pit[crow][c] = v;
+        pit16[crow][c] = (__bf16)v;
+      }
+    }
+    __syncthreads();
+    // ================= P3: argmax over the 130 logits (16 lanes per row, first maximal index) + logits out =================
+    {
+      const int row = tid >> 4, j = tid & 15;
+      float best = -INFINITY; int bi = 0x7fffffff;
+      const long pr = (long)n * R + (long)t * B + min(r0 + row, B - 1);
+      const bool ok = r0 + row < B;
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        const int c = j + 16 * k;
+        if (c < FNP) {
+          const float v = pit[row][c];
+          if (ok) a.pitch[pr * a.ld_pitch + c] = v;
+          if (v > best) { best = v; bi = c; }
+        }
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      if (a.force_pitch) bi = a.force_pitch[(long)n * R + (long)t * B + min(r0 + row, B - 1)];
+      if (j == 0) pidx[row] = bi;
+    }
+    // ================= P4: dur_hid_linear([h | logits]) -> initial duration state (wave w = units w*16..) =================
+    {
+      f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+      const int tl[1] = {wave};
+      panel_mma<1, 16, 8>(a.wd_h, tl, &h16[nxt][0][0], H16LD, acc);
+      panel_mma<1, 5, 8>(a.wd_p, tl, &pit16[0][0], P16LD, acc);
+      const int u = wave * 16 + ckq * 4;
+      const float4 b4 = *reinterpret_cast<const float4*>(a.b_dh + u);
+      const float h[4] = {acc[0][0] + b4.x, acc[0][1] + b4.y, acc[0][2] + b4.z, acc[0][3] + b4.w};
+      *reinterpret_cast<float4*>(&hdf[crow][u]) = make_float4(h[0], h[1], h[2], h[3]);
+      st_bf16x4_lds(&hd16[0][crow][u], h[0], h[1], h[2], h[3]);
+      if (a.train && okC) {
+        *reinterpret_cast<float4*>(a.HD + ((long)n * R + wrowC) * FHD + u) = make_float4(h[0], h[1], h[2], h[3]);
+        if (a.HD16) st_bf16x4_lds(a.HD16 + ((long)n * R + wrowC) * FHD + u, h[0], h[1], h[2], h[3]);
+      }
+    }
+    if (tid < FP) dtok[tid] = 0;
+    __syncthreads();
+    // ================= P5: 5-step duration GRU, argmax feedback (wave w = units w*16..w*16+15) =================
+    {
+      const long prC = (long)n * R + wrowC;
+      const int u = wave * 16 + ckq * 4;
+#pragma unroll 1
+      for (int d = 0; d < ((a.dbg & 8) ? 0 : 5); d++) {
+        const int dc = d & 1, dn = dc ^ 1;
+        f32x4 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; g++) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+          const bf16x8 av = *reinterpret_cast<const bf16x8*>(&hd16[dc][crow][kb * 32 + ckq * 8]);
+#pragma unroll
+          for (int g = 0; g < 3; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdl[((g * 4 + wave) * 2 + kb) * 64 + lane], av, acc[g], 0, 0, 0);
+        }
+        const float* gi = tabs[dtok[crow]];
+        const float4 hp4 = *reinterpret_cast<const float4*>(&hdf[crow][u]);
+        const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+        float r[4], z[4], nn[4], hn[4], h[4], o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int jj = u + e;
+          r[e] = fsig(gi[jj] + acc[0][e] + bhd[jj]);
+          z[e] = fsig(gi[FHD + jj] + acc[1][e] + bhd[FHD + jj]);
+          hn[e] = acc[2][e] + bhd[2 * FHD + jj];
+          nn[e] = ftanh(gi[2 * FHD + jj] + r[e] * hn[e]);
+          h[e] = (1.0f - z[e]) * nn[e] + z[e] * hp[e];
+          o0 += wo[jj] * h[e]; o1 += wo[FHD + jj] * h[e];
+        }
+        *reinterpret_cast<float4*>(&hdf[crow][u]) = make_float4(h[0], h[1], h[2], h[3]);
+        st_bf16x4_lds(&hd16[dn][crow][u], h[0], h[1], h[2], h[3]);
+        if (a.train && okC) {
+          if (a.HD16) st_bf16x4_lds(a.HD16 + ((long)(d + 1) * M + prC) * FHD + u, h[0], h[1], h[2], h[3]);
+          else *reinterpret_cast<float4*>(a.HD + ((long)(d + 1) * M + prC) * FHD + u) = make_float4(h[0], h[1], h[2], h[3]);
+          __bf16* gp = a.gates_d + (((long)d * 4) * M + prC) * FHD + u;
+          const long pl = M * FHD;
+          st_bf16x4_lds(gp, r[0], r[1], r[2], r[3]);
+          st_bf16x4_lds(gp + pl, z[0], z[1], z[2], z[3]);
+          st_bf16x4_lds(gp + 2 * pl, nn[0], nn[1], nn[2], nn[3]);
+          st_bf16x4_lds(gp + 3 * pl, hn[0], hn[1], hn[2], hn[3]);
+        }
+        o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64);
+        o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64);
+        if (lane < 16) { part[wave][lane][0] = o0; part[wave][lane][1] = o1; }
+        __syncthreads();
+        if (tid < FP) {
+          const float e0 = part[0][tid][0] + part[1][tid][0] + part[2][tid][0] + part[3][tid][0] + wo[2 * FHD];
+          const float e1 = part[0][tid][1] + part[1][tid][1] + part[2][tid][1] + part[3][tid][1] + wo[2 * FHD + 1];
+          int id = e1 > e0 ? 1 : 0;                                             // first max wins ties (torch.max)
+          const bool ok = r0 + tid < B;
+          const long pr = (long)n * R + (long)t * B + min(r0 + tid, B - 1);
+          if (a.force_dur) id = a.force_dur[(long)d * M + pr];
+          if (ok) {
+            a.dur[pr * 10 + 2 * d] = e0; a.dur[pr * 10 + 2 * d + 1] = e1;
+            a.idx[(long)d * M + pr] = id;
+          }
+          bits[tid][d] = id;
+          dtok[tid] = 1 + id;
+        }
+        __syncthreads();
+      }
+    }
+    // ================= P6: predicted token = note_embedding(onehot(pitch) | 5 duration bits); next input token =================
+    {
+      const int row = tid >> 4, e0 = (tid & 15) * 8;
+      const bool ok = r0 + row < B;
+      const long wr = (long)t * B + min(r0 + row, B - 1);
+      const int pch = pidx[row];
+      float v[8];
+      const float4 b0 = *reinterpret_cast<const float4*>(a.b_emb + e0), b1 = *reinterpret_cast<const float4*>(a.b_emb + e0 + 4);
+      const float4 w0 = *reinterpret_cast<const float4*>(a.w_embT + (long)pch * FE + e0), w1 = *reinterpret_cast<const float4*>(a.w_embT + (long)pch * FE + e0 + 4);
+      v[0] = b0.x + w0.x; v[1] = b0.y + w0.y; v[2] = b0.z + w0.z; v[3] = b0.w + w0.w;
+      v[4] = b1.x + w1.x; v[5] = b1.y + w1.y; v[6] = b1.z + w1.z; v[7] = b1.w + w1.w;
+#pragma unroll
+      for (int d = 0; d < 5; d++) {
+        const float4 q0 = *reinterpret_cast<const float4*>(a.w_embT + (long)(FNP + d) * FE + e0), q1 = *reinterpret_cast<const float4*>(a.w_embT + (long)(FNP + d) * FE + e0 + 4);
+        const float f = (float)bits[row][d];
+        v[0] += f * q0.x; v[1] += f * q0.y; v[2] += f * q0.z; v[3] += f * q0.w;
+        v[4] += f * q1.x; v[5] += f * q1.y; v[6] += f * q1.z; v[7] += f * q1.w;
+      }
+      if (ok) {
+        float* pp = a.PRED + ((long)(n + 1) * R + wr) * FE + e0;
+        *reinterpret_cast<float4*>(pp) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(pp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+      if (n < 14) {
+        if ((a.coin_mask >> n) & 1u) {                                          // teacher forcing: the ground-truth note n+1
+          const float* gp = a.emb + ((long)(n + 1) * R + wr) * FE + e0;
+          const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
+          v[0] = g0.x; v[1] = g0.y; v[2] = g0.z; v[3] = g0.w; v[4] = g1.x; v[5] = g1.y; v[6] = g1.z; v[7] = g1.w;
+        }
+        if (a.train && ok) {
+          float* tp = a.TOK + ((long)(n + 1) * R + wr) * FE + e0;
+          *reinterpret_cast<float4*>(tp) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(tp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        st_bf16x4_lds(&tok16[row][e0], v[0], v[1], v[2], v[3]);
+        st_bf16x4_lds(&tok16[row][e0 + 4], v[4], v[5], v[6], v[7]);
+      }
+      if (tid < FP && r0 + tid < B) {
+        const int rw = r0 + tid;
+        long* xr = a.xhat + (((long)rw * 32 + t) * 16 + n + 1) * 6;
+        const int pb = pidx[tid];
+        xr[0] = pb;
+#pragma unroll
+        for (int d = 0; d < 5; d++) xr[1 + d] = bits[tid][d];
+        int L = a.plen[(long)t * B + rw];
+        if (L == 0 && pb == 129) L = n + 1;                                     // first <eos>            (ptvae.py:415-416)
+        if (n == 14 && L == 0) L = n + 1;                                       // no <eos> by the end     (ptvae.py:425)
+        a.plen[(long)t * B + rw] = L;
+      }
+    }
+    __syncthreads();
+  }
+  if (a.dbg_out && tid == 0) {
+    unsigned xcc, hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    a.dbg_out[blockIdx.x * 3 + 0] = xcc; a.dbg_out[blockIdx.x * 3 + 1] = hwid;
+    a.dbg_out[blockIdx.x * 3 + 2] = (long)__builtin_amdgcn_s_memtime() - t_begin;
+  }
+}
+
+// =============================================================================================
+// re-summarisation of a panel's predicted notes: bi-GRU(128 -> 128) over PRED[0..15], packed by the predicted length
+// (ptvae.py:480-486) -> the next time-step token TOKS[t+1] = [fwd final | bwd final].  grid = (panels, 2 directions)
+// =============================================================================================
+struct ResumArgs {
+  const bf16x8* w_ih[2]; const bf16x8* w_hh[2];        // packed [24][4][64] each
+  const float* b_ih[2]; const float* b_hh[2];           // [384]
+  const float* PRED;                                    // [16][R][128]
+  const int* plen;                                      // [R]
+  float* XH[2]; __bf16* XG[2];                          // states [17][R][128] (slot 0 = 0), gates [16][4][R][128] (train)
+  float* tok_next;                                      // TOKS[t+1]: [B][256]
+  int B, t, R, train;
+};
+
+__global__ __launch_bounds__(256, 1) void resum_kernel(ResumArgs a) {
+  __shared__ __attribute__((aligned(16))) __bf16 x16[16][FP][T16LD];        // the 16 predicted note tokens of the panel
+  __shared__ __attribute__((aligned(16))) __bf16 h16[2][FP][T16LD];
+  __shared__ __attribute__((aligned(16))) float hf[FP][FHE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int erow = lane >> 2, eq = lane & 3;
+  const int B = a.B, R = a.R, t = a.t, dir = blockIdx.y;
+  const int r0 = blockIdx.x * FP;
+  const int rE = min(r0 + erow, B - 1);
+  const bool okE = r0 + erow < B;
+  const long wrowE = (long)t * B + rE;
+  for (int i = tid; i < 16 * FP * (FE / 4); i += 256) {
+    const int c4 = (i % (FE / 4)) * 4, row = (i / (FE / 4)) % FP, s = i / (FP * (FE / 4));
+    const float4 v = *reinterpret_cast<const float4*>(a.PRED + ((long)s * R + (long)t * B + min(r0 + row, B - 1)) * FE + c4);
+    st_bf16x4_lds(&x16[s][row][c4], v.x, v.y, v.z, v.w);
+  }
+  for (int i = tid; i < FP * FHE; i += 256) { hf[i / FHE][i % FHE] = 0.f; h16[0][i / FHE][i % FHE] = (__bf16)0.f; }
+  const int len = a.plen[wrowE];
+  float4 bR[2], bZ[2], bI[2], bH[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int u = (wave * 2 + j) * 16 + eq * 4;
+    const float4 ir = *reinterpret_cast<const float4*>(a.b_ih[dir] + u), hr = *reinterpret_cast<const float4*>(a.b_hh[dir] + u);
+    const float4 iz = *reinterpret_cast<const float4*>(a.b_ih[dir] + FHE + u), hz = *reinterpret_cast<const float4*>(a.b_hh[dir] + FHE + u);
+    bR[j] = make_float4(ir.x + hr.x, ir.y + hr.y, ir.z + hr.z, ir.w + hr.w);
+    bZ[j] = make_float4(iz.x + hz.x, iz.y + hz.y, iz.z + hz.z, iz.w + hz.w);
+    bI[j] = *reinterpret_cast<const float4*>(a.b_ih[dir] + 2 * FHE + u);
+    bH[j] = *reinterpret_cast<const float4*>(a.b_hh[dir] + 2 * FHE + u);
+  }
+  __syncthreads();
+  for (int s = 0; s < 16; s++) {
+    const int tt = dir ? 15 - s : s, cur = s & 1, nxt = cur ^ 1;
+    f32x4 accX[6], accH[6];                                     // (r0, r1, z0, z1, n0, n1): x . W_ih^T and h . W_hh^T
+#pragma unroll
+    for (int j = 0; j < 6; j++) accX[j] = accH[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ut0 = wave * 2;
+    const int tl[6] = {ut0, ut0 + 1, 8 + ut0, 9 + ut0, 16 + ut0, 17 + ut0};
+    gate_products<4, 4>(a.w_ih[dir], a.w_hh[dir], tl, &x16[tt][0][0], T16LD, &h16[cur][0][0], T16LD, accX, accH);
+    const bool live = tt < len;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int u = (wave * 2 + j) * 16 + eq * 4;
+      f32x4 sR, sZ;
+#pragma unroll
+      for (int e = 0; e < 4; e++) { sR[e] = accX[j][e] + accH[j][e]; sZ[e] = accX[2 + j][e] + accH[2 + j][e]; }
+      const f32x4 aR = to_rowmajor_lanes(sR), aZ = to_rowmajor_lanes(sZ), aI = to_rowmajor_lanes(accX[4 + j]), aH = to_rowmajor_lanes(accH[4 + j]);
+      const float4 hp4 = *reinterpret_cast<const float4*>(&hf[erow][u]);
+      const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+      const float kR[4] = {bR[j].x, bR[j].y, bR[j].z, bR[j].w}, kZ[4] = {bZ[j].x, bZ[j].y, bZ[j].z, bZ[j].w};
+      const float kI[4] = {bI[j].x, bI[j].y, bI[j].z, bI[j].w}, kH[4] = {bH[j].x, bH[j].y, bH[j].z, bH[j].w};
+      float r[4], z[4], nn[4], hn[4], h[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        r[e] = fsig(aR[e] + kR[e]);
+        z[e] = fsig(aZ[e] + kZ[e]);
+        hn[e] = aH[e] + kH[e];
+        nn[e] = ftanh(aI[e] + kI[e] + r[e] * hn[e]);
+        if (!live) { r[e] = 0.f; z[e] = 1.f; nn[e] = 0.f; }                    // masked row: h' = h, zero gate grads
+        h[e] = (1.0f - z[e]) * nn[e] + z[e] * hp[e];
+      }
+      *reinterpret_cast<float4*>(&hf[erow][u]) = make_float4(h[0], h[1], h[2], h[3]);
+      st_bf16x4_lds(&h16[nxt][erow][u], h[0], h[1], h[2], h[3]);
+      if (okE) {
+        if (a.train) {
+          *reinterpret_cast<float4*>(a.XH[dir] + ((long)(s + 1) * R + wrowE) * FHE + u) = make_float4(h[0], h[1], h[2], h[3]);
+          __bf16* gp = a.XG[dir] + (((long)s * 4) * R + wrowE) * FHE + u;
+          const long pl = (long)R * FHE;
+          st_bf16x4_lds(gp, r[0], r[1], r[2], r[3]);
+          st_bf16x4_lds(gp + pl, z[0], z[1], z[2], z[3]);
+          st_bf16x4_lds(gp + 2 * pl, nn[0], nn[1], nn[2], nn[3]);
+          st_bf16x4_lds(gp + 3 * pl, hn[0], hn[1], hn[2], hn[3]);
+        }
+        if (s == 15) *reinterpret_cast<float4*>(a.tok_next + (long)rE * (2 * FHE) + dir * FHE + u) = make_float4(h[0], h[1], h[2], h[3]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace ptv
+
+using namespace ptv;
+
+extern "C" long ptv_pack_mfma_b_size(int N, int K) { return (long)((N + 15) / 16) * ((K + 31) / 32) * 512; }
+
+extern "C" int ptv_pack_mfma_b(const float* W, long ld, int N, int K, void* out, void* stream) {
+  if (!W || !out || N <= 0 || K <= 0 || ld < K) return PTV_ERR_ARG;
+  const int NT = (N + 15) / 16, KB = (K + 31) / 32;
+  long nb = ((long)NT * KB * 64 + 255) / 256; if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(pack_b_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, W, ld, N, K, (__bf16*)out, NT, KB);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+// w[16]: wg_h, wg_t, wp, wd_h, wd_p, wdur (packed bf16), b_hh_n, b_p, b_dh, b_hh_d, tab0, tab, w_out, b_out, w_embT, b_emb
+// io[17]: gc, emb, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, force_pitch, force_dur, HN16, HD16
+extern "C" int ptv_free_note_loop(const void* const* w, const void* const* io, long ld_pitch, int B, int t, unsigned coin_mask, int train,
+                                  void* stream) {
+  if (!w || !io || B <= 0 || t < 0 || t >= 32) return PTV_ERR_ARG;
+  for (int i = 0; i < 16; i++) if (!w[i]) return PTV_ERR_ARG;
+  if (!io[0] || !io[2] || !io[4] || !io[7] || !io[8] || !io[9] || !io[10] || !io[11] || !io[12]) return PTV_ERR_ARG;
+  if (train && (!io[3] || !io[5] || !io[6])) return PTV_ERR_ARG;
+  if (coin_mask && !io[1]) return PTV_ERR_ARG;
+  NoteLoopArgs a{};
+  a.wg_h = (const bf16x8*)w[0]; a.wg_t = (const bf16x8*)w[1]; a.wp = (const bf16x8*)w[2]; a.wd_h = (const bf16x8*)w[3];
+  a.wd_p = (const bf16x8*)w[4]; a.wdur = (const bf16x8*)w[5];
+  a.b_hh_n = (const float*)w[6]; a.b_p = (const float*)w[7]; a.b_dh = (const float*)w[8]; a.b_hh_d = (const float*)w[9];
+  a.tab0 = (const float*)w[10]; a.tab = (const float*)w[11]; a.w_out = (const float*)w[12]; a.b_out = (const float*)w[13];
+  a.w_embT = (const float*)w[14]; a.b_emb = (const float*)w[15];
+  a.gc = (const float*)io[0]; a.emb = (const float*)io[1]; a.HN = (float*)io[2]; a.gates_n = (__bf16*)io[3];
+  a.pitch = (float*)io[4]; a.ld_pitch = ld_pitch; a.HD = (float*)io[5]; a.gates_d = (__bf16*)io[6]; a.dur = (float*)io[7];
+  a.idx = (int*)io[8]; a.TOK = (float*)io[9]; a.PRED = (float*)io[10]; a.xhat = (long*)io[11]; a.plen = (int*)io[12];
+  a.force_pitch = (const int*)io[13]; a.force_dur = (const int*)io[14]; a.HN16 = (__bf16*)io[15]; a.HD16 = (__bf16*)io[16];
+  a.dbg_out = (train >> 8) & 64 ? (long*)io[17] : nullptr;
+  a.B = B; a.t = t; a.R = 32 * B; a.M = 15 * 32 * B; a.coin_mask = coin_mask; a.train = train & 1; a.dbg = train >> 8;
+  hipLaunchKernelGGL(note_loop_kernel, dim3((B + FP - 1) / FP), dim3(256), 0, (hipStream_t)stream, a);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+// w[8]: w_ih, w_hh, w_ih_r, w_hh_r (packed bf16), b_ih, b_hh, b_ih_r, b_hh_r;  io[7]: PRED, plen, XH0, XH1, XG0, XG1, tok_next
+extern "C" int ptv_free_resummarize(const void* const* w, const void* const* io, int B, int t, int train, void* stream) {
+  if (!w || !io || B <= 0 || t < 0 || t >= 32) return PTV_ERR_ARG;
+  for (int i = 0; i < 8; i++) if (!w[i]) return PTV_ERR_ARG;
+  if (!io[0] || !io[1] || !io[6]) return PTV_ERR_ARG;
+  if (train && (!io[2] || !io[3] || !io[4] || !io[5])) return PTV_ERR_ARG;
+  ResumArgs a{};
+  a.w_ih[0] = (const bf16x8*)w[0]; a.w_hh[0] = (const bf16x8*)w[1]; a.w_ih[1] = (const bf16x8*)w[2]; a.w_hh[1] = (const bf16x8*)w[3];
+  a.b_ih[0] = (const float*)w[4]; a.b_hh[0] = (const float*)w[5]; a.b_ih[1] = (const float*)w[6]; a.b_hh[1] = (const float*)w[7];
+  a.PRED = (const float*)io[0]; a.plen = (const int*)io[1]; a.XH[0] = (float*)io[2]; a.XH[1] = (float*)io[3];
+  a.XG[0] = (__bf16*)io[4]; a.XG[1] = (__bf16*)io[5]; a.tok_next = (float*)io[6];
+  a.B = B; a.t = t; a.R = 32 * B; a.train = train;
+  hipLaunchKernelGGL(resum_kernel, dim3((B + FP - 1) / FP, 2), dim3(256), 0, (hipStream_t)stream, a);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}

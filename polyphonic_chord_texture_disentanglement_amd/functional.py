@@ -18,12 +18,10 @@ F32 = torch.float32
 BF16 = torch.bfloat16
 FUSED_DUR = True            # bf16 precision, H = 64: the 5-step duration GRU runs as one kernel (csrc/dur.hip)
 BF16_STORAGE = True         # bf16 precision: tensors that only feed MFMA operands / epilogues live as bf16 in HBM
-# bf16 precision: small-M recurrences as ONE persistent launch per sequence (csrc/gru_persist.hip).  'auto': where the
-# recurrence is the critical path -- rows <= PERSIST_MAX_ROWS, or no backward pass to overlap with (inference).  At
-# B = 512 the train step is throughput-bound: the per-step kernels leave the CUs to the weight-gradient products that
-# run beside them on sibling streams, a persistent grid does not (measured: DESIGN.md section 4).
-PERSIST = os.environ.get('PTV_PERSIST', 'auto')            # 'auto' | '1' | '0'
-PERSIST_MAX_ROWS = 256
+# bf16 precision: small-M recurrences (time GRU, encoder bi-GRUs; forward and BPTT) as ONE persistent launch per sequence
+# (csrc/gru_persist.hip) wherever the shape fits one workgroup per CU.  Measured on one box, teacher-forced train step:
+# B = 512: 28.7-30.1k samples/s with the per-step kernels, 31.7-32.9k persistent; B = 128: 14.5k -> 17.2k; B = 256: 23.1k -> 26.1k.
+PERSIST = os.environ.get('PTV_PERSIST', '1')            # '1' | '0'
 
 
 def _empty(*shape, dev, dtype=F32):
@@ -169,10 +167,7 @@ def _iarr(vs):
 
 
 def persist_supported(NC, M, H):
-    mode = str(PERSIST).lower()
-    if mode in ('0', 'false', 'off') or torch.cuda.is_current_stream_capturing():
-        return False
-    if mode == 'auto' and M > PERSIST_MAX_ROWS and torch.is_grad_enabled():
+    if str(PERSIST).lower() in ('0', 'false', 'off') or torch.cuda.is_current_stream_capturing():
         return False
     key = (NC, M, H, torch.cuda.current_device())
     if key not in _PERSIST_OK:
@@ -855,145 +850,152 @@ class DecoderTFFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dpitch, ddur, _didx):
-        """BPTT chain (duration GRU -> heads -> notes GRU -> time GRU -> note-summary bi-GRU -> z) on the
-        caller's stream; every weight / bias gradient product is enqueued on a sibling stream as soon
-        as its operands exist, so the K-deep dW GEMMs overlap the latency-bound recurrent steps."""
         z, emb, *params = ctx.saved_tensors
         P = dict(zip(DEC_PARAM_NAMES, params))
         st = ctx.st
         ctx.st = None
-        B, R, E, He, Ht, Hn, Hd, NP, prec = (st[k] for k in ('B', 'R', 'E', 'He', 'Ht', 'Hn', 'Hd', 'NP', 'prec'))
-        W = P                                             # K-major (dX) products read the fp32 weights
-        dev = z.device
-        M = 15 * R
-        G = {n: None for n in DEC_PARAM_NAMES}
-        NS, HN, HD, TOKS = st['NS'], st['HN'], st['HD'], st['TOKS']
-        NSf = NS[1:].view(R, Ht)
-        NSUM = HN[1:].view(M, Hn)
-        # bf16 shadows of the state buffers (bf16 precision) as the activation operands of the dW products
-        NSo = st['NS16'] if st.get('NS16') is not None else NS
-        HNo = st['HN16'] if st.get('HN16') is not None else HN
-        HDo = st['HD16'] if st.get('HD16') is not None else HD
-        NSf_op, NSUM_op = NSo[1:].view(R, Ht), HNo[1:].view(M, Hn)
-        emb3 = emb.view(16, R, E)
-        side = Side(3)
-
-        def wgrad(name, dy, x, sub=None):
-            """G[name][:, sub] += dy^T . x"""
-            if G[name] is None:
-                G[name] = _gbuf(P[name])
-            out = G[name] if sub is None else G[name][:, sub]
-            gemm(dy, x, out, ta=True, tb=True, acc=True, prec=prec)
-
-        def bgrad(name, a):
-            G[name] = _bgrad(P[name], a)
-
-        ddur = (ddur.contiguous() if ddur is not None else _zeros(M, 5, 2, dev=dev)).view(M, 10)
-        dP = _empty(M, _pad8(NP), dev=dev)[:, :NP]               # row-padded like the logits
-        if dpitch is not None:
-            copy2d(dP, _rows2d(dpitch))
-        else:
-            copy2d(dP, _zeros(1, NP, dev=dev), lds=0)
-
-        # ---- duration GRU (5 steps) ----
-        w_out = P['dur_out_linear.weight']
-        w_hh_d, w_ih_d = W['dec_dur_gru.weight_hh_l0'], W['dec_dur_gru.weight_ih_l0']
-        if dur_bwd_fusable(prec, Hd, st['gates_d']) or st['dur16_only']:
-            dHD0 = dur_bwd_fused(P, G, st['gates_d'], st['idx'], HD, HDo, ddur, wgrad, bgrad, side)
-        else:
-            dgi_d, dgh_d, dHD0 = gru_bwd(prec, HD, st['gates_d'], w_hh_d, lr=(ddur, 2, 10, 2, w_out))
-
-            def dur_wgrads():
-                for d in range(5):
-                    wgrad('dur_out_linear.weight', ddur[:, 2 * d:2 * d + 2], HDo[d + 1])
-                bgrad('dur_out_linear.bias', ddur.view(M * 5, 2))
-                wgrad('dec_dur_gru.weight_hh_l0', dgh_d.view(5 * M, 3 * Hd), HDo[:5].view(5 * M, Hd))
-                bgrad('dec_dur_gru.bias_hh_l0', dgh_d.view(5 * M, 3 * Hd))
-                bgrad('dec_dur_gru.bias_ih_l0', dgi_d.view(5 * M, 3 * Hd))
-                cs0 = colsum(_zeros(1, 3 * Hd, dev=dev), dgi_d[0])                   # step 0: dense <sos> token
-                g = _gbuf(P['dec_dur_gru.weight_ih_l0'])
-                gemm(cs0, P['dur_sos_token'].view(1, -1), g, ta=True, tb=True, acc=True, prec=0, splitk=-1)
-                G['dur_sos_token'] = _gbuf(P['dur_sos_token'])
-                gemm(cs0, w_ih_d, G['dur_sos_token'].view(1, -1), tb=True, prec=0, splitk=-1)
-                sel = _zeros(2, 3 * Hd, dev=dev)                                     # steps 1..4: one-hot tokens {0,1}
-                for d in range(1, 5):
-                    colsum(sel, dgi_d[d], sel=st['idx'][d - 1], groups=2)
-                gemm(sel, _eye2(dev), g[:, 0:2], ta=True, acc=True, prec=0, splitk=-1)
-                G['dec_dur_gru.weight_ih_l0'] = g
-            side(dur_wgrads, ddur, dgi_d, dgh_d)
-
-        # ---- dur_hid_linear([note_summary | est_pitch]) and pitch_out_linear ----
-        w_dh, w_p = W['dur_hid_linear.weight'], W['pitch_out_linear.weight']
-        # gradient reaching the notes-GRU states: only ever an addend of the BPTT epilogue -> activation dtype
-        dNSUM = _empty(M, Hn, dev=dev, dtype=_act_dtype(prec, Hn))
-        gemm_dx(dHD0, w_dh, slice(0, Hn), out=dNSUM, prec=prec)                   # [M, Hn]
-        gemm_dx(dHD0, w_dh, slice(Hn, None), out=dP, acc=True, prec=prec)
-        gemm_dx(dP, w_p, out=dNSUM, acc=True, prec=prec)
-
-        def head_wgrads():
-            wgrad('dur_hid_linear.weight', dHD0, NSUM_op, slice(0, Hn))
-            wgrad('dur_hid_linear.weight', dHD0, st['pitch'], slice(Hn, None))
-            bgrad('dur_hid_linear.bias', dHD0)
-            wgrad('pitch_out_linear.weight', dP, NSUM_op)
-            bgrad('pitch_out_linear.bias', dP)
-        side(head_wgrads, dHD0, dP)
-
-        # ---- notes GRU (15 steps, batch 32*B) ----
-        w_hh_n, w_ih_n = W['dec_notes_gru.weight_hh_l0'], W['dec_notes_gru.weight_ih_l0']
-        dgi_n, dgh_n, dHN0 = gru_bwd(prec, HN, st['gates_n'], w_hh_n, dh_ext=dNSUM.view(15, R, Hn))
-        dGC = sum_steps(dgi_n)                                                    # [R, 3Hn]
-        demb = _empty(16, R, E, dev=dev)
-        demb[15].zero_()
-        gemm_dx(dgi_n.view(M, 3 * Hn), w_ih_n, slice(Ht, None), out=demb[:15].view(M, E), prec=prec)
-        dNS = gemm_dx(dGC, w_ih_n, slice(0, Ht), prec=prec)                       # [R, Ht]
-        w_tn = W['dec_time_to_notes_hid.weight']
-        gemm_dx(dHN0, w_tn, out=dNS, acc=True, prec=prec)
-
-        def notes_wgrads():
-            wgrad('dec_notes_gru.weight_hh_l0', dgh_n.view(M, 3 * Hn), HNo[:15].view(M, Hn))
-            bgrad('dec_notes_gru.bias_ih_l0', dGC)
-            G['dec_notes_gru.bias_hh_l0'] = _bgrad_hh(P['dec_notes_gru.bias_hh_l0'], dgh_n.view(M, 3 * Hn), G['dec_notes_gru.bias_ih_l0'])
-            wgrad('dec_notes_gru.weight_ih_l0', dGC, NSf_op, slice(0, Ht))
-            wgrad('dec_notes_gru.weight_ih_l0', dgi_n.view(M, 3 * Hn), emb3[:15].view(M, E), slice(Ht, None))
-            wgrad('dec_time_to_notes_hid.weight', dHN0, NSf_op)
-            bgrad('dec_time_to_notes_hid.bias', dHN0)
-        side(notes_wgrads, dgi_n, dgh_n, dGC, dHN0, dNSUM)
-
-        # ---- time GRU (32 steps, batch B) ----
-        w_hh_t, w_ih_t = W['dec_time_gru.weight_hh_l0'], W['dec_time_gru.weight_ih_l0']
-        dgi_t, dgh_t, dzhid = gru_bwd(prec, NS, st['gates_t'], w_hh_t, dh_ext=dNS.view(32, B, Ht))
-        dZG = sum_steps(dgi_t)                                                    # [B, 3Ht]
-        dz_in = gemm_dx(dZG, w_ih_t, slice(2 * He, None), prec=prec)              # [B, Zi]
-        dTOKS = _empty(33, B, 2 * He, dev=dev)
-        dTOKS[32].zero_()
-        gemm_dx(dgi_t.view(R, 3 * Ht), w_ih_t, slice(0, 2 * He), out=dTOKS[:32].view(R, 2 * He), prec=prec)
-        dxs = dTOKS[1:].view(R, 2 * He)
-        w_zh, w_zi = W['z2dec_hid_linear.weight'], W['z2dec_in_linear.weight']
-        dz = gemm_dx(dzhid, w_zh, prec=prec)
-        gemm_dx(dz_in, w_zi, out=dz, acc=True, prec=prec)
-
-        def time_wgrads():
-            wgrad('dec_time_gru.weight_hh_l0', dgh_t.view(R, 3 * Ht), NSo[:32].view(R, Ht))
-            bgrad('dec_time_gru.bias_ih_l0', dZG)
-            G['dec_time_gru.bias_hh_l0'] = _bgrad_hh(P['dec_time_gru.bias_hh_l0'], dgh_t.view(R, 3 * Ht), G['dec_time_gru.bias_ih_l0'])
-            wgrad('dec_time_gru.weight_ih_l0', dZG, st['z_in'], slice(2 * He, None))
-            wgrad('dec_time_gru.weight_ih_l0', dgi_t.view(R, 3 * Ht), TOKS[:32].view(R, 2 * He), slice(0, 2 * He))
-            bgrad('dec_init_input', dTOKS[0])
-            wgrad('z2dec_hid_linear.weight', dzhid, z)
-            bgrad('z2dec_hid_linear.bias', dzhid)
-            wgrad('z2dec_in_linear.weight', dz_in, z)
-            bgrad('z2dec_in_linear.bias', dz_in)
-        side(time_wgrads, dgi_t, dgh_t, dZG, dTOKS, dzhid, dz_in, dNS)
-
+        R, E = st['R'], st['E']
+        dz, demb, dTOKS, G, side = decoder_bwd_core(P, st, z, emb.view(16, R, E)[:15].view(15 * R, E), dpitch, ddur)
         # parameter gradients only: joined when the backward pass ends -- but only if autograd ADOPTS the tensors
         # (p.grad is None and the buffer is this step's arena view); an accumulation `p.grad += g` would run on this
         # node's stream without a dependency on the side stream
         from .optim import is_arena_view
-        if all(P[n].grad is None and is_arena_view(P[n], G[n]) for n in DEC_PARAM_NAMES):
+        if all(G[n] is None or (P[n].grad is None and is_arena_view(P[n], G[n])) for n in DEC_PARAM_NAMES):
             side.defer()
         else:
             side.join()
-        return (dz, demb.view(16, 32, B, E), dxs, None, None) + tuple(G[n] for n in DEC_PARAM_NAMES)
+        B, He = st['B'], st['He']
+        return (dz, demb.view(16, 32, B, E), dTOKS[1:].view(R, 2 * He), None, None) + tuple(G[n] for n in DEC_PARAM_NAMES)
+
+
+def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
+    """BPTT of the PianoTree decoder given the saved forward state `st` -- shared by the teacher-forced node (DecoderTFFn) and
+    the step-loop node (functional_free.DecoderStepFn: argmax is not differentiable, so with the fed tokens recorded every
+    chain is the same batched BPTT).  Chain (duration GRU -> heads -> notes GRU -> time GRU -> z) on the caller's stream; every
+    weight / bias gradient product is enqueued on a sibling stream as soon as its operands exist, so the K-deep dW GEMMs
+    overlap the latency-bound recurrent steps.
+      tok_op [15*R, E]: the note tokens that were FED to the notes GRU (ground-truth embedding rows, or the recorded mix)
+    -> (dz, dtok [16,R,E] gradient w.r.t. the fed note tokens (slot 15 zero), dTOKS [33,B,2He] gradient w.r.t. the time-step
+        tokens, G parameter gradients by name, side stream handle -- the caller joins or defers it)"""
+    B, R, E, He, Ht, Hn, Hd, NP, prec = (st[k] for k in ('B', 'R', 'E', 'He', 'Ht', 'Hn', 'Hd', 'NP', 'prec'))
+    W = P                                             # K-major (dX) products read the fp32 weights
+    dev = z.device
+    M = 15 * R
+    G = {n: None for n in DEC_PARAM_NAMES}
+    NS, HN, HD, TOKS = st['NS'], st['HN'], st['HD'], st['TOKS']
+    # bf16 shadows of the state buffers (bf16 precision) as the activation operands of the dW products
+    NSo = st['NS16'] if st.get('NS16') is not None else NS
+    HNo = st['HN16'] if st.get('HN16') is not None else HN
+    HDo = st['HD16'] if st.get('HD16') is not None else HD
+    NSf_op, NSUM_op = NSo[1:].view(R, Ht), HNo[1:].view(M, Hn)
+    side = Side(3)
+
+    def wgrad(name, dy, x, sub=None):
+        """G[name][:, sub] += dy^T . x"""
+        if G[name] is None:
+            G[name] = _gbuf(P[name])
+        out = G[name] if sub is None else G[name][:, sub]
+        gemm(dy, x, out, ta=True, tb=True, acc=True, prec=prec)
+
+    def bgrad(name, a):
+        G[name] = _bgrad(P[name], a)
+
+    ddur = (ddur.contiguous() if ddur is not None else _zeros(M, 5, 2, dev=dev)).view(M, 10)
+    dP = _empty(M, _pad8(NP), dev=dev)[:, :NP]               # row-padded like the logits
+    if dpitch is not None:
+        copy2d(dP, _rows2d(dpitch))
+    else:
+        copy2d(dP, _zeros(1, NP, dev=dev), lds=0)
+
+    # ---- duration GRU (5 steps) ----
+    w_out = P['dur_out_linear.weight']
+    w_hh_d, w_ih_d = W['dec_dur_gru.weight_hh_l0'], W['dec_dur_gru.weight_ih_l0']
+    if dur_bwd_fusable(prec, Hd, st['gates_d']) or st.get('dur16_only'):
+        dHD0 = dur_bwd_fused(P, G, st['gates_d'], st['idx'], HD, HDo, ddur, wgrad, bgrad, side)
+    else:
+        dgi_d, dgh_d, dHD0 = gru_bwd(prec, HD, st['gates_d'], w_hh_d, lr=(ddur, 2, 10, 2, w_out))
+
+        def dur_wgrads():
+            for d in range(5):
+                wgrad('dur_out_linear.weight', ddur[:, 2 * d:2 * d + 2], HDo[d + 1])
+            bgrad('dur_out_linear.bias', ddur.view(M * 5, 2))
+            wgrad('dec_dur_gru.weight_hh_l0', dgh_d.view(5 * M, 3 * Hd), HDo[:5].view(5 * M, Hd))
+            bgrad('dec_dur_gru.bias_hh_l0', dgh_d.view(5 * M, 3 * Hd))
+            bgrad('dec_dur_gru.bias_ih_l0', dgi_d.view(5 * M, 3 * Hd))
+            cs0 = colsum(_zeros(1, 3 * Hd, dev=dev), dgi_d[0])                   # step 0: dense <sos> token
+            g = _gbuf(P['dec_dur_gru.weight_ih_l0'])
+            gemm(cs0, P['dur_sos_token'].view(1, -1), g, ta=True, tb=True, acc=True, prec=0, splitk=-1)
+            G['dur_sos_token'] = _gbuf(P['dur_sos_token'])
+            gemm(cs0, w_ih_d, G['dur_sos_token'].view(1, -1), tb=True, prec=0, splitk=-1)
+            sel = _zeros(2, 3 * Hd, dev=dev)                                     # steps 1..4: one-hot tokens {0,1}
+            for d in range(1, 5):
+                colsum(sel, dgi_d[d], sel=st['idx'][d - 1], groups=2)
+            gemm(sel, _eye2(dev), g[:, 0:2], ta=True, acc=True, prec=0, splitk=-1)
+            G['dec_dur_gru.weight_ih_l0'] = g
+        side(dur_wgrads, ddur, dgi_d, dgh_d)
+
+    # ---- dur_hid_linear([note_summary | est_pitch]) and pitch_out_linear ----
+    w_dh, w_p = W['dur_hid_linear.weight'], W['pitch_out_linear.weight']
+    # gradient reaching the notes-GRU states: only ever an addend of the BPTT epilogue -> activation dtype
+    dNSUM = _empty(M, Hn, dev=dev, dtype=_act_dtype(prec, Hn))
+    gemm_dx(dHD0, w_dh, slice(0, Hn), out=dNSUM, prec=prec)                   # [M, Hn]
+    gemm_dx(dHD0, w_dh, slice(Hn, None), out=dP, acc=True, prec=prec)
+    gemm_dx(dP, w_p, out=dNSUM, acc=True, prec=prec)
+
+    def head_wgrads():
+        wgrad('dur_hid_linear.weight', dHD0, NSUM_op, slice(0, Hn))
+        wgrad('dur_hid_linear.weight', dHD0, st['pitch'], slice(Hn, None))
+        bgrad('dur_hid_linear.bias', dHD0)
+        wgrad('pitch_out_linear.weight', dP, NSUM_op)
+        bgrad('pitch_out_linear.bias', dP)
+    side(head_wgrads, dHD0, dP)
+
+    # ---- notes GRU (15 steps, batch 32*B) ----
+    w_hh_n, w_ih_n = W['dec_notes_gru.weight_hh_l0'], W['dec_notes_gru.weight_ih_l0']
+    dgi_n, dgh_n, dHN0 = gru_bwd(prec, HN, st['gates_n'], w_hh_n, dh_ext=dNSUM.view(15, R, Hn))
+    dGC = sum_steps(dgi_n)                                                    # [R, 3Hn]
+    dtok = _empty(16, R, E, dev=dev)
+    dtok[15].zero_()
+    gemm_dx(dgi_n.view(M, 3 * Hn), w_ih_n, slice(Ht, None), out=dtok[:15].view(M, E), prec=prec)
+    dNS = gemm_dx(dGC, w_ih_n, slice(0, Ht), prec=prec)                       # [R, Ht]
+    w_tn = W['dec_time_to_notes_hid.weight']
+    gemm_dx(dHN0, w_tn, out=dNS, acc=True, prec=prec)
+
+    def notes_wgrads():
+        wgrad('dec_notes_gru.weight_hh_l0', dgh_n.view(M, 3 * Hn), HNo[:15].view(M, Hn))
+        bgrad('dec_notes_gru.bias_ih_l0', dGC)
+        G['dec_notes_gru.bias_hh_l0'] = _bgrad_hh(P['dec_notes_gru.bias_hh_l0'], dgh_n.view(M, 3 * Hn), G['dec_notes_gru.bias_ih_l0'])
+        wgrad('dec_notes_gru.weight_ih_l0', dGC, NSf_op, slice(0, Ht))
+        wgrad('dec_notes_gru.weight_ih_l0', dgi_n.view(M, 3 * Hn), tok_op, slice(Ht, None))
+        wgrad('dec_time_to_notes_hid.weight', dHN0, NSf_op)
+        bgrad('dec_time_to_notes_hid.bias', dHN0)
+    side(notes_wgrads, dgi_n, dgh_n, dGC, dHN0, dNSUM)
+
+    # ---- time GRU (32 steps, batch B) ----
+    w_hh_t, w_ih_t = W['dec_time_gru.weight_hh_l0'], W['dec_time_gru.weight_ih_l0']
+    dgi_t, dgh_t, dzhid = gru_bwd(prec, NS, st['gates_t'], w_hh_t, dh_ext=dNS.view(32, B, Ht))
+    dZG = sum_steps(dgi_t)                                                    # [B, 3Ht]
+    dz_in = gemm_dx(dZG, w_ih_t, slice(2 * He, None), prec=prec)              # [B, Zi]
+    dTOKS = _empty(33, B, 2 * He, dev=dev)
+    dTOKS[32].zero_()
+    gemm_dx(dgi_t.view(R, 3 * Ht), w_ih_t, slice(0, 2 * He), out=dTOKS[:32].view(R, 2 * He), prec=prec)
+    w_zh, w_zi = W['z2dec_hid_linear.weight'], W['z2dec_in_linear.weight']
+    dz = gemm_dx(dzhid, w_zh, prec=prec)
+    gemm_dx(dz_in, w_zi, out=dz, acc=True, prec=prec)
+
+    def time_wgrads():
+        wgrad('dec_time_gru.weight_hh_l0', dgh_t.view(R, 3 * Ht), NSo[:32].view(R, Ht))
+        bgrad('dec_time_gru.bias_ih_l0', dZG)
+        G['dec_time_gru.bias_hh_l0'] = _bgrad_hh(P['dec_time_gru.bias_hh_l0'], dgh_t.view(R, 3 * Ht), G['dec_time_gru.bias_ih_l0'])
+        wgrad('dec_time_gru.weight_ih_l0', dZG, st['z_in'], slice(2 * He, None))
+        wgrad('dec_time_gru.weight_ih_l0', dgi_t.view(R, 3 * Ht), TOKS[:32].view(R, 2 * He), slice(0, 2 * He))
+        bgrad('dec_init_input', dTOKS[0])
+        wgrad('z2dec_hid_linear.weight', dzhid, z)
+        bgrad('z2dec_hid_linear.bias', dzhid)
+        wgrad('z2dec_in_linear.weight', dz_in, z)
+        bgrad('z2dec_in_linear.bias', dz_in)
+    side(time_wgrads, dgi_t, dgh_t, dZG, dTOKS, dzhid, dz_in, dNS)
+    return dz, dtok, dTOKS, G, side
 
 
 # =============================================================================================

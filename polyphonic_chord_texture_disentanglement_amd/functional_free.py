@@ -11,10 +11,12 @@ teacher-forced path; token gradients are routed to the ground-truth embedding or
 buffer (whose gradient reaches `note_embedding` and, through the re-summarising bi-GRU,
 `dec_notes_emb_gru`) -- never into the logits that produced the argmax.
 """
+import os
+
 import torch
 
 from . import functional as F_
-from ._lib import call, ptr, stream_ptr
+from ._lib import call, lib, ptr, stream_ptr
 from .functional import (DEC_PARAM_NAMES, Side, _bgrad, _bigru_backward, _empty, _eye2, _gbuf, _onehot2x5, _zeros,
                          colsum, copy2d, gemm, gru_bwd, sum_steps)
 
@@ -34,9 +36,58 @@ def _sos_grid(dev):
     return _SOS[k]
 
 
-def gru_step(prec, hprev, gi, gi_ld, w_hh, b_hh, hout, *, gi2=None, gates=None, plane=0, lengths=None, t=0, gi_idx=None):
+# ---------------------------------------------------------------------------------------------
+# row-partitioned persistent kernels for the step loop (csrc/freerun.hip): one launch per time step walks all 15 note steps of
+# a 16-sample panel, one more re-summarises the predicted notes.  bf16 precision, init_model() geometry.
+# ---------------------------------------------------------------------------------------------
+FREE_PERSIST = os.environ.get('PTV_FREE_PERSIST', '1') not in ('0', 'false', 'off')
+_PACKS = {}
+_PACK_SRC = ('dec_notes_gru.weight_hh_l0', 'dec_notes_gru.weight_ih_l0', 'pitch_out_linear.weight', 'dur_hid_linear.weight',
+             'dec_dur_gru.weight_hh_l0', 'note_embedding.weight', 'dec_notes_emb_gru.weight_ih_l0', 'dec_notes_emb_gru.weight_hh_l0',
+             'dec_notes_emb_gru.weight_ih_l0_reverse', 'dec_notes_emb_gru.weight_hh_l0_reverse')
+
+
+def free_persist_ok(prec, E, He, Hn, Hd, NP):
+    return FREE_PERSIST and prec == 1 and F_.BF16_STORAGE and (E, He, Hn, Hd, NP) == (128, 128, 512, 64, 130)
+
+
+def _pack(w2d, K=None):
+    """fp32 [N, >=K] (any row stride) -> MFMA B-fragment-major bf16 (ptv_pack_mfma_b)"""
+    N = w2d.shape[0]
+    K = w2d.shape[1] if K is None else K
+    out = torch.empty(lib().ptv_pack_mfma_b_size(N, K), device=w2d.device, dtype=torch.bfloat16)
+    call('ptv_pack_mfma_b', ptr(w2d), w2d.stride(0), N, K, ptr(out), stream_ptr())
+    return out
+
+
+def _free_packs(P, Ht):
+    """fragment-major bf16 copies of the weights the persistent step-loop kernels stream, re-packed when a parameter changed
+    (in-place version counters + the fused optimiser's step count, like the bf16 weight shadows of optim.py)"""
+    from .optim import _SHADOW_OF
+    src = [P[n] for n in _PACK_SRC]
+    ent = _SHADOW_OF.get(src[0].data_ptr())
+    opt = ent[0]() if ent is not None else None
+    stamp = (sum(p._version for p in src), opt.step_count if opt is not None else -1, opt._dirty if opt is not None else -1)
+    key = tuple(p.data_ptr() for p in src)
+    hit = _PACKS.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    w_ih_n, w_dh, w_emb = P['dec_notes_gru.weight_ih_l0'], P['dur_hid_linear.weight'], P['note_embedding.weight']
+    w_embT = torch.empty(w_emb.shape[1], w_emb.shape[0], device=w_emb.device, dtype=torch.float32)
+    call('ptv_transpose01', ptr(w_embT), ptr(w_emb), w_emb.shape[0], w_emb.shape[1], 1, stream_ptr())
+    pk = dict(wg_h=_pack(P['dec_notes_gru.weight_hh_l0']), wg_t=_pack(w_ih_n[:, Ht:]), wp=_pack(P['pitch_out_linear.weight']),
+              wd_h=_pack(w_dh[:, :512]), wd_p=_pack(w_dh[:, 512:]), wdur=_pack(P['dec_dur_gru.weight_hh_l0']), w_embT=w_embT,
+              e_ih=_pack(P['dec_notes_emb_gru.weight_ih_l0']), e_hh=_pack(P['dec_notes_emb_gru.weight_hh_l0']),
+              e_ih_r=_pack(P['dec_notes_emb_gru.weight_ih_l0_reverse']), e_hh_r=_pack(P['dec_notes_emb_gru.weight_hh_l0_reverse']))
+    if len(_PACKS) > 4:
+        _PACKS.clear()
+    _PACKS[key] = (stamp, pk)
+    return pk
+
+
+def gru_step(prec, hprev, gi, gi_ld, w_hh, b_hh, hout, *, gi2=None, gates=None, plane=0, lengths=None, t=0, gi_idx=None, hout16=None):
     M, H = hout.shape
-    call('ptv_gru_step_fwd', prec, M, H, ptr(hprev), hprev.stride(0), None, None, ptr(gi), gi_ld, ptr(gi2),
+    call('ptv_gru_step_fwd', prec, M, H, ptr(hprev), hprev.stride(0), None, ptr(hout16), ptr(gi), gi_ld, ptr(gi2),
          gi2.stride(0) if gi2 is not None else 0, ptr(w_hh), ptr(b_hh), ptr(hout), hout.stride(0), ptr(gates), plane,
          ptr(lengths), t, ptr(gi_idx), F_._gru_flags(gates, gi, gi2), stream_ptr())
 
@@ -81,7 +132,8 @@ class DecoderStepFn(torch.autograd.Function):
         xhat[:, :, :, 0] = 130
         xhat[:, :, 0, 0] = 128
         plen = torch.zeros(R, device=dev, dtype=torch.int32)
-        pitch = _empty(M, NP, dev=dev)
+        fast = free_persist_ok(prec, E, He, Hn, Hd, NP) and (not train or F_._act_dtype(prec, Hn) == torch.bfloat16)
+        pitch = _empty(M, F_._pad8(NP), dev=dev)[:, :NP] if fast else _empty(M, NP, dev=dev)
         HD = _empty(6, M, Hd, dev=dev)
         gates_d = _empty(5, 4, M, Hd, dev=dev, dtype=F_._act_dtype(prec, Hd)) if train else None
         idx = torch.empty(5, M, device=dev, dtype=torch.int32)
@@ -107,11 +159,24 @@ class DecoderStepFn(torch.autograd.Function):
         force_pitch = force.get('pitch') if force else None          # [15, R] int32
         force_dur = force.get('dur') if force else None              # [5, 15R] int32
 
+        HN16 = HD16 = NS16 = None
+        if fast and train:                                       # bf16 state copies: MFMA operands of the batched backward
+            HN16 = _empty(16, R, Hn, dev=dev, dtype=torch.bfloat16)
+            HD16 = _empty(6, M, Hd, dev=dev, dtype=torch.bfloat16)
+            if Ht % 8 == 0:
+                NS16 = _empty(33, B, Ht, dev=dev, dtype=torch.bfloat16)
+                call('ptv_cast_bf16', ptr(NS[0]), ptr(NS16[0]), B * Ht, st)
+        if fast:
+            pk = _free_packs(P, Ht)
+            wl = F_._parr([pk['wg_h'], pk['wg_t'], pk['wp'], pk['wd_h'], pk['wd_p'], pk['wdur'], b_hh_n, P['pitch_out_linear.bias'],
+                           P['dur_hid_linear.bias'], b_hh_d, tab0, tab, P['dur_out_linear.weight'], P['dur_out_linear.bias'],
+                           pk['w_embT'], b_emb])
+            wr = F_._parr([pk['e_ih'], pk['e_hh'], pk['e_ih_r'], pk['e_hh_r'], wE[2], wE[3], wE[6], wE[7]])
         for t in range(32):
             rows = slice(t * B, (t + 1) * B)
             gi = gemm(TOKS[t], w_ih_t[:, :2 * He], prec=prec)
             gru_step(prec, NS[t], gi, 3 * Ht, P['dec_time_gru.weight_hh_l0'], P['dec_time_gru.bias_hh_l0'], NS[t + 1], gi2=zg,
-                     gates=gates_t[t] if train else None, plane=B * Ht)
+                     gates=gates_t[t] if train else None, plane=B * Ht, hout16=NS16[t + 1] if NS16 is not None else None)
             ns = NS[t + 1]
             gemm(ns, P['dec_time_to_notes_hid.weight'], HN[0][rows], bias=P['dec_time_to_notes_hid.bias'], prec=prec)
             GCt = gemm(ns, w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec)
@@ -120,6 +185,22 @@ class DecoderStepFn(torch.autograd.Function):
             else:
                 copy2d(TOK[0][rows], emb3[0][rows])
             copy2d(PRED[0][rows], TOK[0][rows])
+            if fast:
+                # all 15 note steps of this time step in ONE launch (csrc/freerun.hip); then the next time-step token
+                mask = 0
+                if not inference:
+                    for n in range(14):
+                        mask |= int(bool(coin_notes[t][n])) << n
+                io = F_._parr([GCt, emb3, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, force_pitch, force_dur, HN16, HD16])
+                call('ptv_free_note_loop', wl, io, pitch.stride(0), B, t, mask, int(train), st)
+                if t == 31:
+                    break
+                if (not inference) and coin_time[t]:
+                    copy2d(TOKS[t + 1], xs[rows])
+                else:
+                    io = F_._parr([PRED, plen, XH[0], XH[1], XG[0], XG[1], TOKS[t + 1]])
+                    call('ptv_free_resummarize', wr, io, B, t, int(train), st)
+                continue
             for n in range(15):
                 gi_tok = gemm(TOK[n][rows], w_ih_n[:, Ht:], prec=prec)
                 gru_step(prec, HN[n][rows], gi_tok, 3 * Hn, w_hh_n, b_hh_n, HN[n + 1][rows], gi2=GCt,
@@ -168,7 +249,8 @@ class DecoderStepFn(torch.autograd.Function):
             ctx.save_for_backward(z, emb, *params)
             ctx.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in, TOKS=TOKS,
                           gates_t=gates_t, HN=HN, gates_n=gates_n, pitch=pitch, HD=HD, gates_d=gates_d, idx=idx, TOK=TOK,
-                          PRED=PRED, xhat=xhat, XH=XH, XG=XG, coins=coins, has_xs=xs is not None)
+                          PRED=PRED, xhat=xhat, XH=XH, XG=XG, coins=coins, has_xs=xs is not None,
+                          NS16=NS16, HN16=HN16, HD16=HD16, dur16_only=HD16 is not None)
         ctx.mark_non_differentiable(xhat, idx)
         return pitch.view(15, 32, B, NP), dur, xhat, idx
 
@@ -182,13 +264,13 @@ class DecoderStepFn(torch.autograd.Function):
         B, R, E, He, Ht, Hn, Hd, NP, prec = (st[k] for k in ('B', 'R', 'E', 'He', 'Ht', 'Hn', 'Hd', 'NP', 'prec'))
         dev = z.device
         M = 15 * R
-        G = {n: None for n in FREE_PARAM_NAMES}
-        NS, HN, HD, TOKS, TOK, PRED = st['NS'], st['HN'], st['HD'], st['TOKS'], st['TOK'], st['PRED']
-        NSf = NS[1:].view(R, Ht)
-        NSUM = HN[1:].view(M, Hn)
+        PRED = st['PRED']
         coin_notes, coin_time = st['coins']
-        side = Side(3)
         sp = stream_ptr()
+        # ---- duration GRU, heads, notes GRU, time GRU: the batched BPTT of the teacher-forced path on the recorded fed tokens
+        dz, dTOK, dTOKS, G0, side = F_.decoder_bwd_core(P, st, z, st['TOK'].view(M, E), dpitch, ddur)
+        G = {n: None for n in FREE_PARAM_NAMES}
+        G.update(G0)
 
         def wgrad(name, dy, x, sub=None):
             if G[name] is None:
@@ -202,73 +284,6 @@ class DecoderStepFn(torch.autograd.Function):
             else:
                 colsum(G[name].view(1, -1), a)
 
-        ddur = (ddur.contiguous() if ddur is not None else _zeros(M, 5, 2, dev=dev)).view(M, 10)
-        dP = _empty(M, NP, dev=dev)
-        if dpitch is not None:
-            copy2d(dP, dpitch.contiguous().view(M, NP))
-        else:
-            dP.zero_()
-
-        # ---- duration GRU, heads, notes GRU: identical to the teacher-forced path (batched over all rows)
-        w_out = P['dur_out_linear.weight']
-        w_hh_d, w_ih_d = P['dec_dur_gru.weight_hh_l0'], P['dec_dur_gru.weight_ih_l0']
-        fused_dur = F_.dur_bwd_fusable(prec, Hd, st['gates_d'])
-        if not fused_dur:
-            dgi_d, dgh_d, dHD0 = gru_bwd(prec, HD, st['gates_d'], w_hh_d, lr=(ddur, 2, 10, 2, w_out))
-
-        def dur_wgrads():
-            for d in range(5):
-                wgrad('dur_out_linear.weight', ddur[:, 2 * d:2 * d + 2], HD[d + 1])
-            bgrad('dur_out_linear.bias', ddur.view(M * 5, 2))
-            wgrad('dec_dur_gru.weight_hh_l0', dgh_d.view(5 * M, 3 * Hd), HD[:5].view(5 * M, Hd))
-            bgrad('dec_dur_gru.bias_hh_l0', dgh_d.view(5 * M, 3 * Hd))
-            bgrad('dec_dur_gru.bias_ih_l0', dgi_d.view(5 * M, 3 * Hd))
-            cs0 = colsum(_zeros(1, 3 * Hd, dev=dev), dgi_d[0])
-            g = _gbuf(w_ih_d)
-            gemm(cs0, P['dur_sos_token'].view(1, -1), g, ta=True, tb=True, acc=True, prec=0, splitk=-1)
-            G['dur_sos_token'] = _gbuf(P['dur_sos_token'])
-            gemm(cs0, w_ih_d, G['dur_sos_token'].view(1, -1), tb=True, prec=0, splitk=-1)
-            sel = _zeros(2, 3 * Hd, dev=dev)
-            for d in range(1, 5):
-                colsum(sel, dgi_d[d], sel=st['idx'][d - 1], groups=2)
-            gemm(sel, _eye2(dev), g[:, 0:2], ta=True, acc=True, prec=0, splitk=-1)
-            G['dec_dur_gru.weight_ih_l0'] = g
-        if fused_dur:
-            dHD0 = F_.dur_bwd_fused(P, G, st['gates_d'], st['idx'], HD, HD, ddur, wgrad, bgrad, side)
-        else:
-            side(dur_wgrads, ddur, dgi_d, dgh_d)
-
-        w_dh, w_p = P['dur_hid_linear.weight'], P['pitch_out_linear.weight']
-        dNSUM = gemm(dHD0, w_dh[:, :Hn], tb=True, prec=prec)
-        gemm(dHD0, w_dh[:, Hn:], dP, tb=True, acc=True, prec=prec)
-        gemm(dP, w_p, dNSUM, tb=True, acc=True, prec=prec)
-
-        def head_wgrads():
-            wgrad('dur_hid_linear.weight', dHD0, NSUM, slice(0, Hn))
-            wgrad('dur_hid_linear.weight', dHD0, st['pitch'], slice(Hn, None))
-            bgrad('dur_hid_linear.bias', dHD0)
-            wgrad('pitch_out_linear.weight', dP, NSUM)
-            bgrad('pitch_out_linear.bias', dP)
-        side(head_wgrads, dHD0, dP)
-
-        w_hh_n, w_ih_n = P['dec_notes_gru.weight_hh_l0'], P['dec_notes_gru.weight_ih_l0']
-        dgi_n, dgh_n, dHN0 = gru_bwd(prec, HN, st['gates_n'], w_hh_n, dh_ext=dNSUM.view(15, R, Hn))
-        dGC = sum_steps(dgi_n)
-        dTOK = gemm(dgi_n.view(M, 3 * Hn), w_ih_n[:, Ht:], tb=True, prec=prec).view(15, R, E)
-        dNS = gemm(dGC, w_ih_n[:, :Ht], tb=True, prec=prec)
-        w_tn = P['dec_time_to_notes_hid.weight']
-        gemm(dHN0, w_tn, dNS, tb=True, acc=True, prec=prec)
-
-        def notes_wgrads():
-            wgrad('dec_notes_gru.weight_hh_l0', dgh_n.view(M, 3 * Hn), HN[:15].view(M, Hn))
-            bgrad('dec_notes_gru.bias_hh_l0', dgh_n.view(M, 3 * Hn))
-            bgrad('dec_notes_gru.bias_ih_l0', dGC)
-            wgrad('dec_notes_gru.weight_ih_l0', dGC, NSf, slice(0, Ht))
-            wgrad('dec_notes_gru.weight_ih_l0', dgi_n.view(M, 3 * Hn), TOK.view(M, E), slice(Ht, None))
-            wgrad('dec_time_to_notes_hid.weight', dHN0, NSf)
-            bgrad('dec_time_to_notes_hid.bias', dHN0)
-        side(notes_wgrads, dgi_n, dgh_n, dGC, dHN0, dNSUM)
-
         # ---- route token gradients: ground-truth embedding (coin true / slot 0) vs predicted tokens
         demb = _zeros(16, R, E, dev=dev)
         dPRED = _zeros(16, R, E, dev=dev)
@@ -278,31 +293,6 @@ class DecoderStepFn(torch.autograd.Function):
                 mask_tok[n + 1, t] = 1 if coin_notes[t][n] else 0
         mask_tok = mask_tok.to(dev)
         call('ptv_route_slices', ptr(dTOK), ptr(demb), ptr(dPRED), ptr(mask_tok), B * E, 15 * 32, 0, sp)
-
-        # ---- time GRU
-        w_hh_t, w_ih_t = P['dec_time_gru.weight_hh_l0'], P['dec_time_gru.weight_ih_l0']
-        dgi_t, dgh_t, dzhid = gru_bwd(prec, NS, st['gates_t'], w_hh_t, dh_ext=dNS.view(32, B, Ht))
-        dZG = sum_steps(dgi_t)
-        dz_in = gemm(dZG, w_ih_t[:, 2 * He:], tb=True, prec=prec)
-        dTOKS = _empty(33, B, 2 * He, dev=dev)
-        dTOKS[32].zero_()
-        gemm(dgi_t.view(R, 3 * Ht), w_ih_t[:, :2 * He], dTOKS[:32].view(R, 2 * He), tb=True, prec=prec)
-        w_zh, w_zi = P['z2dec_hid_linear.weight'], P['z2dec_in_linear.weight']
-        dz = gemm(dzhid, w_zh, tb=True, prec=prec)
-        gemm(dz_in, w_zi, dz, tb=True, acc=True, prec=prec)
-
-        def time_wgrads():
-            wgrad('dec_time_gru.weight_hh_l0', dgh_t.view(R, 3 * Ht), NS[:32].view(R, Ht))
-            bgrad('dec_time_gru.bias_hh_l0', dgh_t.view(R, 3 * Ht))
-            bgrad('dec_time_gru.bias_ih_l0', dZG)
-            wgrad('dec_time_gru.weight_ih_l0', dZG, st['z_in'], slice(2 * He, None))
-            wgrad('dec_time_gru.weight_ih_l0', dgi_t.view(R, 3 * Ht), TOKS[:32].view(R, 2 * He), slice(0, 2 * He))
-            bgrad('dec_init_input', dTOKS[0])
-            wgrad('z2dec_hid_linear.weight', dzhid, z)
-            bgrad('z2dec_hid_linear.bias', dzhid)
-            wgrad('z2dec_in_linear.weight', dz_in, z)
-            bgrad('z2dec_in_linear.bias', dz_in)
-        side(time_wgrads, dgi_t, dgh_t, dZG, dTOKS, dzhid, dz_in, dNS)
 
         # ---- time tokens: ground-truth summaries (coin true) vs re-summarised predictions
         dxs = _zeros(32, B, 2 * He, dev=dev)

@@ -546,3 +546,83 @@ def test_full_batch_512_bf16_step_on_the_benched_code_paths():
         torch.cuda.empty_cache()
     np.testing.assert_allclose(res['bf16'][0], res['fp32'][0], rtol=0, atol=2e-2)
     assert abs(res['bf16'][1] - res['fp32'][1]) < 0.03 * res['fp32'][1]
+
+
+# ---------------------------------------------------------------------------------------------
+# csrc/freerun.hip: the step loop as row-partitioned persistent kernels (one launch per time step for all 15 note steps of a
+# 16-sample panel + one for the re-summarisation) against the per-step kernels it replaces, bf16 precision, full config
+# ---------------------------------------------------------------------------------------------
+def _free_run(m, g, B, seed, persist, tfr, force=None, coins=None, monkeypatch=None):
+    from polyphonic_chord_texture_disentanglement_amd import functional_free as FF_
+    x, c, pr = synth_batch(B, seed)
+    xt, ct, prt = (torch.from_numpy(a).to(DEV) for a in (x, c, pr))
+    gen = torch.Generator().manual_seed(5)
+    eps = {'chd': torch.randn(B, 256, generator=gen), 'rhy': torch.randn(B, 256, generator=gen)}
+    m.eps_source = lambda name, shape, device: eps[name].to(device)
+    old = FF_.FREE_PERSIST
+    FF_.FREE_PERSIST = persist
+    try:
+        import random
+        random.seed(3)
+        m.decoder.force_trace = force
+        m.zero_grad()
+        outs = m.run(xt, ct, prt, *tfr)
+        losses = m.loss_function(xt, ct, *outs, 0.1, [1, 0.5])
+        losses[0].backward()
+        torch.cuda.synchronize()
+    finally:
+        FF_.FREE_PERSIST = old
+        m.decoder.force_trace = None
+    return (outs[0].detach().clone(), outs[1].detach().clone(), m.decoder.last_xhat.clone(), m.decoder.last_dur_idx.clone(),
+            np.array([l.item() for l in losses]), {n: p.grad.clone() for n, p in m.named_parameters()})
+
+
+@pytest.mark.parametrize('B,tfr', [(4, (0., 0., 0.)), (19, (0., 0., 0.)), (8, (0.5, 0.5, 0.5))])
+def test_persistent_step_loop_kernels_equal_the_per_step_kernels(B, tfr):
+    m = M.DisentangleVAE.init_model(torch.device(DEV))
+    m.load_state_dict(full_params())
+    m.to(DEV).set_precision('bf16')
+    ref = _free_run(m, None, B, 77, False, tfr)
+    # replay the per-step path's decisions: every tensor must agree to bf16 rounding of the operands
+    R = 32 * B
+    xh = ref[2]                                                  # [B,32,16,6]
+    force = {'pitch': xh[:, :, 1:, 0].permute(2, 1, 0).reshape(15, R).int().contiguous(),
+             'dur': ref[3].clone()}
+    a = _free_run(m, None, B, 77, True, tfr, force=force)
+    b = _free_run(m, None, B, 77, False, tfr, force=force)
+    assert (a[0] - b[0]).abs().max() < 3e-2 and (a[1] - b[1]).abs().max() < 3e-2          # logits
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])                             # forced decisions, grid, lengths
+    np.testing.assert_allclose(a[4], b[4], rtol=0, atol=5e-3)
+    for n in b[5]:
+        assert (a[5][n] - b[5][n]).abs().max() <= 0.05 * b[5][n].abs().max() + 1e-6, n
+    # un-forced: same trajectory except at near-ties
+    u = _free_run(m, None, B, 77, True, tfr)
+    assert (u[2] == ref[2]).float().mean() > 0.99
+    np.testing.assert_allclose(u[4], ref[4], rtol=0, atol=2e-2)
+
+
+def test_persistent_step_loop_inference_decode_and_graph():
+    from polyphonic_chord_texture_disentanglement_amd import functional_free as FF_
+    g = load_npz('full_infer_b4.npz')
+    m = M.DisentangleVAE.init_model(torch.device(DEV))
+    m.load_state_dict(full_params())
+    m.to(DEV).set_precision('bf16')
+    zc, zr = torch.from_numpy(g['z_chd']).to(DEV), torch.from_numpy(g['z_rhy']).to(DEV)
+    est = {}
+    for persist in (True, False):
+        FF_.FREE_PERSIST = persist
+        try:
+            est[persist] = m.inference_decode(zc, zr)
+        finally:
+            FF_.FREE_PERSIST = True
+    # un-forced bf16 trajectories of an UNTRAINED model: this fixture has pitch margins down to 1e-7, and one flipped near-tie
+    # changes the rest of that time step -- both bf16 paths agree with each other and with the fp32 reference to a few percent
+    # of the cells (the forced comparison of the test above is the exact one)
+    assert (est[True] == est[False]).mean() > 0.97
+    assert (est[True] == g['est_x']).mean() > 0.96 and (est[False] == g['est_x']).mean() > 0.96
+    m.decoder.use_graph = True
+    first = m.inference_decode(zc, zr)
+    again = m.inference_decode(zc.flip(0), zr.flip(0))
+    m.decoder.use_graph = False
+    # (split-K products accumulate with atomics: run-to-run rounding differs in the last bit, which near-ties amplify)
+    assert (first == est[True]).mean() > 0.97 and (again == est[True][::-1]).mean() > 0.97
