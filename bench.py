@@ -24,10 +24,12 @@ import torch  # noqa: E402
 GFLOP_PER_SAMPLE_TRAIN = 6.15
 
 
-def cpu_baseline(batch=16):
-    """The CPU oracle (a restatement of the reference's as-written algorithm, validated against the
-    reference in tests/test_oracle_vs_golden.py) timed on this host: one full train step."""
-    import numpy as np
+def cpu_baseline(batch=16, timed=3):
+    """The CPU oracle (a restatement of the reference's as-written algorithm, validated against the reference in
+    tests/test_oracle_vs_golden.py) timed on this host's cores: full train steps (fwd + bwd + clip + Adam) at BASELINE
+    configs[0] (B = 16), teacher-forced and free-running, 1 warm-up + `timed` steps each, min and median.
+    The reference itself, timed in the build container on 8 vCPU: profiles/r02_reference_cpu_timing.json."""
+    import statistics
     from oracle.ptvae_oracle import Oracle, clip_and_adam_step
     from polyphonic_chord_texture_disentanglement_amd.model import DisentangleVAE
     from polyphonic_chord_texture_disentanglement_amd.synthetic import synth_batch
@@ -39,26 +41,121 @@ def cpu_baseline(batch=16):
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     ref = DisentangleVAE.init_model(torch.device('cpu'))
-    params = {k: v.detach().clone().requires_grad_(True) for k, v in ref.state_dict().items()}
-    plist = list(params.values())
-    m = [torch.zeros_like(p) for p in plist]
-    v = [torch.zeros_like(p) for p in plist]
     x, c, pr = (torch.from_numpy(a) for a in synth_batch(batch, 1234))
-    gen = torch.Generator().manual_seed(7)
-    times = []
-    for step in range(2):                      # 1 warm-up + 1 timed
-        eps = [torch.randn(batch, 256, generator=gen) for _ in range(2)]
-        t0 = time.perf_counter()
-        for p in plist:
-            p.grad = None
-        losses = Oracle(params).loss(x, c, pr, 1., 1., 1., 0.1, [1, 0.5], eps[0], eps[1], lambda: 0.0)
-        losses[0].backward()
+    out = {}
+    for tfr in (1.0, 0.0):
+        params = {k: v.detach().clone().requires_grad_(True) for k, v in ref.state_dict().items()}
+        plist = list(params.values())
+        m = [torch.zeros_like(p) for p in plist]
+        v = [torch.zeros_like(p) for p in plist]
+        gen = torch.Generator().manual_seed(7)
+        times = []
+        for step in range(1 + timed):
+            eps = [torch.randn(batch, 256, generator=gen) for _ in range(2)]
+            t0 = time.perf_counter()
+            for p in plist:
+                p.grad = None
+            losses = Oracle(params).loss(x, c, pr, tfr, tfr, tfr, 0.1, [1, 0.5], eps[0], eps[1], lambda: 0.5)
+            losses[0].backward()
+            with torch.no_grad():
+                clip_and_adam_step(plist, [p.grad for p in plist], m, v, step + 1, 1e-3)
+            times.append(time.perf_counter() - t0)
+        times = times[1:]
+        out['tfr=%g' % tfr] = {'s_per_step_min': round(min(times), 3), 's_per_step_median': round(statistics.median(times), 3),
+                               'samples_per_s_best': round(batch / min(times), 2)}
+    best = out['tfr=1']
+    return {'value': best['samples_per_s_best'], 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+            'sample': '1 warm-up + %d timed train steps (fwd+bwd+clip+Adam) each at tfr=1 and tfr=0, batch %d, fp32, torch CPU '
+                      'oracle/ptvae_oracle.py; value = best teacher-forced step' % (timed, batch), 'cases': out}
+
+
+def _measure(step_fn, steps, warmup):
+    for i in range(warmup):
+        step_fn(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step_fn(warmup + i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def extras(dev, B, rank):
+    """driver-visible side figures (never `value`): the other BASELINE configs and the trainer surface, a few steps each"""
+    import random
+    from polyphonic_chord_texture_disentanglement_amd.amc_dl import torch_plus as tp
+    from polyphonic_chord_texture_disentanglement_amd.amc_dl.torch_plus.train_utils import kl_anealing
+    from polyphonic_chord_texture_disentanglement_amd.dataset_loaders import DeviceBatcher, TrainingVAE
+    from polyphonic_chord_texture_disentanglement_amd.model import DisentangleVAE, LOSS_NAMES
+    from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
+    from polyphonic_chord_texture_disentanglement_amd.synthetic import synth_batch, synth_raw_bank
+    out = {}
+
+    def train_setup(prec):
+        torch.manual_seed(0)
+        m = DisentangleVAE.init_model(dev).to(dev).set_precision(prec)
+        m.use_philox(7, 0)
+        opt = FusedClipAdam(m.parameters(), lr=1e-3)
+        data = [tuple(torch.from_numpy(a).to(dev) for a in synth_batch(B, 99 + i)) for i in range(2)]
+        return m, opt, data
+
+    def train_fn(m, opt, data, tfr):
+        def fn(i):
+            x, c, pr = data[i % 2]
+            opt.zero_grad()
+            o = m('train', x, c, pr, tfr1=tfr, tfr2=tfr, tfr3=tfr, beta=0.1, weights=[1, 0.5])
+            o[0].backward()
+            opt.clip_and_step(1.0)
+        return fn
+
+    random.seed(7)
+    m, opt, data = train_setup('bf16')
+    t = _measure(train_fn(m, opt, data, 0.0), 4, 2)
+    out['train_free_running_tfr0'] = {'samples_per_s': round(B / t, 1), 'ms_per_step': round(t * 1e3, 2), 'batch': B, 'dtype': 'bf16',
+                                      'note': "the reference's train.py schedule from its third batch on (SURVEY 0.4)"}
+    # the trainer surface: TrainingVAE.train() with the device-resident data path (raw piano-roll bank -> ptv_batch_transform),
+    # train.py's schedulers, fused clip+Adam, one non-blocking 11-scalar log per batch
+    pr_bank, ch_bank = synth_raw_bank(256, 5)
+    loader = DeviceBatcher(pr_bank, ch_bank, B, seed=1, device=dev, drop_last=True)
+    nb = len(loader)
+
+    class _L:
+        train_loader, val_loader = loader, []
+    pm = tp.LogPathManager(None, log_path_name=os.path.join(os.environ.get('TMPDIR', '/tmp'), 'ptvae_bench'))
+    osch = tp.OptimizerScheduler(opt, tp.MinExponentialLR(opt, gamma=0.9999, minimum=1e-5), 1)
+    ps = tp.ParameterScheduler(tfr1=tp.ConstantScheduler(1.), tfr2=tp.ConstantScheduler(1.), tfr3=tp.ConstantScheduler(1.),
+                               beta=tp.TeacherForcingScheduler(0.1, 0., f=kl_anealing), weights=tp.ConstantScheduler([1, 0.5]))
+    sw = tp.SummaryWriters(LOSS_NAMES, {'loss': None}, pm.writer_path)
+    tr = TrainingVAE(dev, m, False, pm, _L, sw, osch, ps, 1)
+    tr.train()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr.train()
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / nb
+    out['trainer_surface_teacher_forced'] = {'samples_per_s': round(B / t, 1), 'ms_per_step': round(t * 1e3, 2), 'batch': B,
+                                             'note': 'TrainingVAE.train(): device batch transform + step + async logging, %d batches' % nb}
+    del m, opt, tr
+    torch.cuda.empty_cache()
+    m, opt, data = train_setup('fp32')
+    t = _measure(train_fn(m, opt, data, 1.0), 3, 1)
+    out['train_teacher_forced_fp32'] = {'samples_per_s': round(B / t, 1), 'ms_per_step': round(t * 1e3, 2), 'batch': B, 'dtype': 'f32',
+                                        'note': 'the <=1e-4 parity path (exact fp32 MFMA)'}
+    del m, opt
+    torch.cuda.empty_cache()
+    torch.manual_seed(0)
+    m = DisentangleVAE.init_model(dev).to(dev).set_precision('bf16')
+    m.decoder.use_graph = True
+    Bd = 2048
+    z = torch.randn(Bd, 512, device=dev)
+
+    def dec(i):
         with torch.no_grad():
-            clip_and_adam_step(plist, [p.grad for p in plist], m, v, step + 1, 1e-3)
-        times.append(time.perf_counter() - t0)
-    return {'value': batch / times[-1], 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
-            'sample': '1 warm-up + 1 timed train step (fwd+bwd+clip+Adam), batch %d, tfr=1, fp32, torch CPU '
-                      'oracle/ptvae_oracle.py, %.2f s/step' % (batch, times[-1])}
+            m.decoder(z, True, None, None, 0., 0.)
+    t = _measure(dec, 3, 2)
+    out['decode_free_running_b2048_graph'] = {'samples_per_s': round(Bd / t, 1), 'ms_per_decode': round(t * 1e3, 2), 'batch': Bd,
+                                              'note': 'configs[3]: inference_decode step loop replayed from a hipGraph'}
+    return out
 
 
 def main():
@@ -69,6 +166,7 @@ def main():
     ap.add_argument('--batch', type=int, default=512, help='per-GPU batch (weak scaling)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the side figures (tfr=0 train, trainer surface, fp32, decode)')
     ap.add_argument('--graph', action='store_true', help='decode mode: replay the step loop from a captured hipGraph')
     ap.add_argument('--tfr', type=float, default=1.0, help='teacher-forcing ratio (1 = configs[1]; 0 = free-running training)')
     ap.add_argument('--mode', default='train', choices=['train', 'decode'],
@@ -114,8 +212,10 @@ def main():
     for i in range(nb):                                    # disjoint data per rank (SURVEY §8d seeds)
         x, c, pr = synth_batch(B, 1234 + rank * 10 ** 6 + i)
         batches.append(tuple(torch.from_numpy(a).to(dev) for a in (x, c, pr)))
-    gen = torch.Generator(device=dev).manual_seed(7 + rank)
-    model.eps_source = lambda name, shape, device: torch.randn(shape, device=device, generator=gen)
+    import random
+    gen = torch.Generator(device=dev).manual_seed(7 + rank)     # decode mode only
+    model.use_philox(seed=7, sample_offset=rank * B)           # eps keyed by the GLOBAL sample index: sharding-invariant
+    random.seed(7)                                             # teacher-forcing coins: one stream shared by all ranks
 
     def step(i):
         x, c, pr = batches[i % nb]
@@ -209,6 +309,15 @@ def main():
                           'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world},
                'step_tflops': round(value * GFLOP_PER_SAMPLE_TRAIN / 1e3, 2), 'final_loss': round(loss, 4),
                'host_enqueue_ms_per_step': round(t_host / args.steps * 1e3, 3), 'roofline': roof}
+        from polyphonic_chord_texture_disentanglement_amd.functional import persist_check
+        persist_check()                                        # a persistent launch that gave up would have invalidated the run
+        if world == 1 and args.mode == 'train' and not args.no_extras:
+            del model, opt
+            torch.cuda.empty_cache()
+            try:
+                res['extra'] = extras(dev, B, rank)
+            except Exception as e:                             # side figures must never cost the headline line
+                res['extra'] = {'error': repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res), flush=True)

@@ -335,6 +335,23 @@ int ptv_free_note_loop(const void* const* w, const void* const* io, long ld_pitc
 int ptv_free_resummarize(const void* const* w, const void* const* io, int B, int t, int train, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The teacher-forced notes GRU (dec_notes_gru over 15 note steps x 32*B rows, ptvae.py:395-398 restructured per SURVEY.md 7.1)
+ * as row-partitioned persistent kernels (csrc/notes_persist.hip): ONE launch for the whole sequence, a workgroup owns 64 rows,
+ * the state stays on the CU, W_hh streams from L2 in ptv_pack_mfma_b packing, the token product is fused.  bf16 precision,
+ * Hn = 512, E = 128.
+ *   fwd: wg_h = pack(W_hh [1536,512]), wg_t = pack(W_ih[:, Ht:] [1536,128]); gc bf16 [R][1536] = W_ih[:, :Ht] ns + b_ih;
+ *        emb fp32 [T][R][128] fed tokens; HN fp32 [T+1][R][512] (slot 0 written by the caller), HN16 bf16 same shape (all slots
+ *        written here), gates bf16 [T][4][R][512] (r, z, n, W_hn h + b_hn) or NULL.
+ *   bwd: wt = pack(W_hh^T [512,1536]); ext bf16 [T][R][512] = gradient arriving at the state after step s;
+ *        dgi / dgh bf16 [T][R][1536]; dh0 fp32 [R][512] or NULL; scratch: ptv_notes_gru_persist_scratch_elems(R) bf16 elements.
+ */
+int ptv_notes_gru_persist_fwd(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
+                              float* HN, void* HN16, void* gates, long R, int T, void* stream);
+long ptv_notes_gru_persist_scratch_elems(long R);
+int ptv_notes_gru_persist_bwd(const void* wt, const float* HN, const void* gates, const void* ext, void* dgi, void* dgh,
+                              float* dh0, void* scratch, long R, int T, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * clip_grad_norm_ (module.py:142-143) + torch.optim.Adam.step (train.py:50, scheduler.py:69-74) over
  * flat fp32 buffers: sumsq = |g|^2 (device scalar), then p,m,v updated with g*gscale clipped to `clip`.
  */

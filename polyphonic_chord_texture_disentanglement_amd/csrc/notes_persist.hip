@@ -1,0 +1,401 @@
+// notes_persist.hip -- the teacher-forced notes GRU (dec_notes_gru, ptvae.py:395-398 restructured to ONE 15-step sequence over
+// 32*B rows) as row-partitioned persistent kernels: forward and BPTT, one launch each.
+//
+// 71 % of the forward FLOPs of the model live in this recurrence.  As one launch per step it was the largest exclusive item
+// of the train step (15 x 97 us forward at 0.34 of the HBM roofline, 15 x 129 us backward): every step re-read the state from
+// HBM (fp32 + bf16), the input-side pre-activations of a separately launched product (0.75 GB written and read back), and
+// started cold.  Rows are independent, so a workgroup can own 64 rows (four MFMA M tiles) for ALL 15 steps:
+//   * the MFMA operand copy of the state (bf16) never leaves the CU (LDS, double buffered); the fp32 state is written once
+//     per step (the backward needs it anyway) and read back by the lane that wrote it; BPTT: dh (x) z in LDS (fp32, 128 KB), dgh -- the next step's A operand, 64 x 1536, too large for
+//     LDS -- in a private, L2-resident scratch tile held K-blocked so fragment loads are contiguous
+//   * W_hh is streamed from L2 in MFMA-fragment-major packing (ptv_pack_mfma_b), one fragment load serving four M tiles:
+//     the same 1.5 MB per CU per step the per-step kernels pulled through L2, now the ONLY large read besides GC
+//   * the token product (emb . W_ih[:, Ht:]^T) is fused: K = 128 more per step instead of a [15*R, 1536] tensor
+//   * epilogues run in a "wide row" lane layout (4 adjacent lanes = 32 contiguous units of one row, 8 per lane): every global
+//     access is a 16- or 32-byte piece of a 64-128-byte run
+// No workgroup waits for another: no flags, no residency requirement, any grid size.
+// bf16 MFMA operands, fp32 state and accumulation (the bf16 precision policy); Hn = 512, E = 128 (init_model() geometry).
+#include "common.hpp"
+#include "gemm_core.hpp"
+#include "../../include/ptvae_hip.h"
+
+namespace ptv {
+
+constexpr int NH = 512, NE = 128, NRP = 64;          // hidden units, token width, rows per workgroup
+constexpr int NH16LD = NH + 16, NT16LD = NE + 16;    // bf16 LDS row strides: conflict-free b128 fragment reads
+
+__device__ __forceinline__ float nsig(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ntanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
+// two accumulator fragments of ADJACENT unit tiles (C layout: lane = row + 16*quad, 4 units per lane per tile) -> wide-row
+// layout: lane = 4*row + q holds units q*8 .. q*8+7 of the 32 units of the pair
+__device__ __forceinline__ void pair_to_rows(const f32x4& f0, const f32x4& f1, float (&o)[8]) {
+  const int lane = threadIdx.x & 63, row = lane >> 2, q = lane & 3;
+  const int s0 = row + 16 * ((q & 1) * 2), s1 = s0 + 16;
+  const bool hi = q >> 1;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const float a0 = __shfl(f0[e], s0, 64), a1 = __shfl(f1[e], s0, 64);
+    const float b0 = __shfl(f0[e], s1, 64), b1 = __shfl(f1[e], s1, 64);
+    o[e] = hi ? a1 : a0;
+    o[4 + e] = hi ? b1 : b0;
+  }
+}
+
+// streaming traffic (read once / written once per launch) carries the non-temporal hint: with the default policy the ~26 MB per
+// XCD per step of activations evicted the W_hh fragments every workgroup re-reads each step (L2 hit rate 60 %)
+typedef __attribute__((ext_vector_type(4))) float f4v;
+__device__ __forceinline__ bf16x8 ldnt_bf16x8(const __bf16* p) { return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p)); }
+__device__ __forceinline__ float4 ldnt_f4(const float* p) {
+  const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void stnt_bf16x8(__bf16* p, const float (&v)[8]) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; e++) o[e] = (__bf16)v[e];
+  __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p));
+}
+__device__ __forceinline__ void stnt_f32x8(float* p, const float (&v)[8]) {
+  __builtin_nontemporal_store(f4v{v[0], v[1], v[2], v[3]}, reinterpret_cast<f4v*>(p));
+  __builtin_nontemporal_store(f4v{v[4], v[5], v[6], v[7]}, reinterpret_cast<f4v*>(p + 4));
+}
+
+__device__ __forceinline__ void ld_bf16x8(const __bf16* p, float (&o)[8]) {
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int e = 0; e < 8; e++) o[e] = (float)v[e];
+}
+__device__ __forceinline__ void st_bf16x8(__bf16* p, const float (&v)[8]) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; e++) o[e] = (__bf16)v[e];
+  *reinterpret_cast<bf16x8*>(p) = o;
+}
+__device__ __forceinline__ void ld_f32x8(const float* p, float (&o)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void st_f32x8(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// =============================================================================================
+// forward
+// =============================================================================================
+struct NotesFwdArgs {
+  const bf16x8 *wg_h, *wg_t;       // packed W_hh [96 tiles][16 kb][64], W_ih[:, Ht:] [96][4][64]
+  const float* b_hh;               // [1536]
+  const __bf16* gc;                // [R][1536] hoisted input part W_ih[:, :Ht] ns + b_ih
+  const float* emb;                // fed tokens, step-major [T][R][128] fp32
+  float* HN; __bf16* HN16;         // [T+1][R][512]; slot 0 of HN written by the caller
+  __bf16* gates;                   // [T][4][R][512] or null
+  int R, T, dbg;
+};
+
+template <int NW, bool PREF>
+__global__ __launch_bounds__(NW * 64, 1) void notes_fwd_kernel(NotesFwdArgs a) {
+  constexpr int NTH = NW * 64, NPASS = 16 / NW, UTW = 32 / NW;           // threads, passes per step, unit tiles per wave
+  extern __shared__ __attribute__((aligned(16))) char nsm[];
+  __bf16* h16 = reinterpret_cast<__bf16*>(nsm);                          // [2][64][NH16LD]
+  __bf16* tok16 = h16 + 2 * NRP * NH16LD;                                // [64][NT16LD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rl = lane & 15, kq = (lane >> 4) * 8;                        // fragment coordinates
+  const int erow = lane >> 2, eq = lane & 3;                             // wide-row epilogue coordinates
+  const long R = a.R;
+  const long r0 = (long)blockIdx.x * NRP;
+  const long RH = R * NH;
+
+  // ---- initial state: bf16 operand copy -> LDS and HN16 slot 0
+  for (int i = tid; i < NRP * (NH / 8); i += NTH) {
+    const int row = i / (NH / 8), c8 = (i % (NH / 8)) * 8;
+    const long gr = min(r0 + row, R - 1);
+    float v[8];
+    ld_f32x8(a.HN + gr * NH + c8, v);
+    st_bf16x8(h16 + row * NH16LD + c8, v);
+    if (r0 + row < R) st_bf16x8(a.HN16 + gr * NH + c8, v);
+  }
+  long grow[4]; bool ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { ok[i] = r0 + i * 16 + erow < R; grow[i] = min(r0 + i * 16 + erow, R - 1); }
+  const int prot = (a.dbg & 8) ? 0 : (blockIdx.x >> 3) & (NPASS - 1), krot = (a.dbg & 8) ? 0 : ((blockIdx.x >> 5) & 7) * 2;
+
+  for (int n = 0; n < a.T; n++) {
+    const int cur = n & 1, nxt = cur ^ 1;
+    const __bf16* hc = h16 + cur * NRP * NH16LD;
+    __bf16* hn_ = h16 + nxt * NRP * NH16LD;
+    // ---- this step's fed tokens -> LDS (bf16 MFMA operand)
+    for (int i = tid; i < NRP * (NE / 8); i += NTH) {
+      const int row = i / (NE / 8), c8 = (i % (NE / 8)) * 8;
+      float v[8];
+      ld_f32x8(a.emb + ((long)n * R + min(r0 + row, R - 1)) * NE + c8, v);
+      st_bf16x8(tok16 + row * NT16LD + c8, v);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int p0 = 0; p0 < NPASS; p0++) {
+      // workgroups of one XCD run in near lockstep and would all ask the L2 for the same few fragment lines at the same moment
+      // (a handful of its 16 channels busy, the rest idle): each walks the passes and the k-blocks from its own starting point
+      const int p = (p0 + prot) & (NPASS - 1);
+      const int ut0 = wave * UTW + p * 2;
+      const int u = ut0 * 16 + eq * 8;                                   // this lane's first unit of the pass
+      // acc[i][0..3] = r0 r1 z0 z1 (h and token parts summed), [4,5] = W_hn h, [6,7] = W_in token
+      f32x4 acc[4][8];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int tl[6] = {ut0, ut0 + 1, 32 + ut0, 33 + ut0, 64 + ut0, 65 + ut0};
+      // epilogue operands of the pass (GC and the fp32 state of this lane's cells) are requested BEFORE the products: they come
+      // from HBM, and waiting for them per M tile in the epilogue exposed that latency 16 times per step
+      bf16x8 gq[4][3]; float4 hq[4][2];
+#pragma unroll
+      for (int i = 0; i < (PREF ? 4 : 0); i++) {
+        const __bf16* g = a.gc + grow[i] * (3 * NH) + u;
+#pragma unroll
+        for (int gt = 0; gt < 3; gt++) gq[i][gt] = ldnt_bf16x8(g + gt * NH);
+        const float* hp = a.HN + (long)n * RH + grow[i] * NH + u;
+        hq[i][0] = ldnt_f4(hp); hq[i][1] = ldnt_f4(hp + 4);
+      }
+      // software-pipelined stream of 16 + 4 k-blocks through a ring of 4 fragment buffers: the loads of k-block k+3 are issued
+      // before the MFMAs of k-block k (24 MFMAs = ~400 cycles per k-block against ~900 cycles of L2 latency)
+      constexpr int RD = PREF ? 4 : 3;                                   // ring depth (prefetch distance RD - 1)
+      bf16x8 b[RD][6];
+      auto ldw = [&](bf16x8 (&d)[6], int k) {                            // k < 16: W_hh block (k + krot) % 16; else W_ih[:, Ht:] block k - 16
+#pragma unroll
+        for (int j = 0; j < 6; j++) d[j] = k < 16 ? a.wg_h[((long)tl[j] * 16 + ((k + krot) & 15)) * 64 + lane] : a.wg_t[((long)tl[j] * 4 + (k - 16)) * 64 + lane];
+      };
+#pragma unroll
+      for (int k = 0; k < RD - 1; k++) ldw(b[k], k);
+#pragma unroll
+      for (int k = 0; k < 20; k++) {
+        if (k + RD - 1 < 20) ldw(b[(k + RD - 1) % RD], k + RD - 1);
+        const bool tokpart = k >= 16;
+        const __bf16* A = tokpart ? tok16 : hc;
+        const int lda = tokpart ? NT16LD : NH16LD, kb = tokpart ? k - 16 : ((k + krot) & 15);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const bf16x8 av = *reinterpret_cast<const bf16x8*>(A + (i * 16 + rl) * lda + kb * 32 + kq);
+#pragma unroll
+          for (int j = 0; j < 6; j++) {
+            const int slot = j < 4 ? j : (tokpart ? j + 2 : j);
+            acc[i][slot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[k % RD][j], av, acc[i][slot], 0, 0, 0);
+          }
+        }
+      }
+      if (a.dbg & 2) continue;
+      // ---- epilogue: GRU cell on this lane's cells of the pass
+      float bR[8], bZ[8], bN[8];
+      ld_f32x8(a.b_hh + u, bR); ld_f32x8(a.b_hh + NH + u, bZ); ld_f32x8(a.b_hh + 2 * NH + u, bN);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        float gR[8], gZ[8], gN[8], aR[8], aZ[8], aH[8], aI[8], hp[8];
+        if constexpr (!PREF) {                                           // two waves per SIMD: the partner covers the latency
+          const __bf16* g = a.gc + grow[i] * (3 * NH) + u;
+#pragma unroll
+          for (int gt = 0; gt < 3; gt++) gq[i][gt] = ldnt_bf16x8(g + gt * NH);
+          const float* hpp = a.HN + (long)n * RH + grow[i] * NH + u;
+          hq[i][0] = ldnt_f4(hpp); hq[i][1] = ldnt_f4(hpp + 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) { gR[e] = (float)gq[i][0][e]; gZ[e] = (float)gq[i][1][e]; gN[e] = (float)gq[i][2][e]; }
+        // fp32 state of these cells: written by this very lane one step ago (the whole fp32 state, 128 KB per workgroup, fits
+        // neither LDS next to the bf16 operand copies nor the register file next to the accumulators)
+        hp[0] = hq[i][0].x; hp[1] = hq[i][0].y; hp[2] = hq[i][0].z; hp[3] = hq[i][0].w;
+        hp[4] = hq[i][1].x; hp[5] = hq[i][1].y; hp[6] = hq[i][1].z; hp[7] = hq[i][1].w;
+        pair_to_rows(acc[i][0], acc[i][1], aR); pair_to_rows(acc[i][2], acc[i][3], aZ);
+        pair_to_rows(acc[i][4], acc[i][5], aH); pair_to_rows(acc[i][6], acc[i][7], aI);
+        float r[8], z[8], nn[8], hn[8], h[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          r[e] = nsig(aR[e] + gR[e] + bR[e]);
+          z[e] = nsig(aZ[e] + gZ[e] + bZ[e]);
+          hn[e] = aH[e] + bN[e];
+          nn[e] = ntanh(aI[e] + gN[e] + r[e] * hn[e]);
+          h[e] = (1.0f - z[e]) * nn[e] + z[e] * hp[e];
+        }
+        st_bf16x8(hn_ + (i * 16 + erow) * NH16LD + u, h);
+        if (ok[i] && !(a.dbg & 4)) {
+          const long o = (long)(n + 1) * RH + grow[i] * NH + u;
+          st_f32x8(a.HN + o, h);                                       // read back next step: default policy
+          stnt_bf16x8(a.HN16 + o, h);
+          if (a.gates) {
+            __bf16* gp = a.gates + (long)n * 4 * RH + grow[i] * NH + u;
+            stnt_bf16x8(gp, r); stnt_bf16x8(gp + RH, z); stnt_bf16x8(gp + 2 * RH, nn); stnt_bf16x8(gp + 3 * RH, hn);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);                               // keep the M tiles' epilogues (and the passes) apart: register pressure
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// =============================================================================================
+// BPTT
+// =============================================================================================
+struct NotesBwdArgs {
+  const bf16x8* wt;                // packed W_hh^T [32 tiles of output units][48 kb][64]
+  const float* HN; const __bf16* gates;
+  const __bf16* ext;               // [T][R][512] bf16 gradient arriving at the state after step s (dNSUM)
+  __bf16* dgi; __bf16* dgh;        // [T][R][1536]
+  float* dh0;                      // [R][512]
+  __bf16* scratch;                 // [grid][2][192 chunks][64 rows][8]: dgh of the workgroup's rows, K-blocked (A operand of the next step)
+  int R, T;
+};
+
+__global__ __launch_bounds__(256, 1) void notes_bwd_kernel(NotesBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char nsm[];
+  float* dhz = reinterpret_cast<float*>(nsm);                            // [64][512] fp32: dh (x) z carried to the earlier step
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rl = lane & 15, kqi = lane >> 4;
+  const int erow = lane >> 2, eq = lane & 3;
+  const long R = a.R;
+  const long r0 = (long)blockIdx.x * NRP;
+  const long RH = R * NH, R3H = 3 * RH;
+  __bf16* sc = a.scratch + (long)blockIdx.x * 2 * (192 * NRP * 8);
+  for (int i = tid; i < NRP * NH; i += 256) dhz[i] = 0.f;
+  long grow[4]; bool ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { ok[i] = r0 + i * 16 + erow < R; grow[i] = min(r0 + i * 16 + erow, R - 1); }
+  __syncthreads();
+
+  for (int s = a.T - 1; s >= -1; s--) {
+    const bool last = s == a.T - 1;
+    const __bf16* scr = sc + ((s + 1) & 1) * (192 * NRP * 8);             // dgh_{s+1}, written by the previous iteration
+    __bf16* scw = sc + (s & 1) * (192 * NRP * 8);
+    // HBM operands of the epilogue items (4 tile pairs x 4 M tiles; saved gates, previous state, external gradient) run 2 items
+    // ahead of the arithmetic through a ring of 3 register sets; the first two are requested before the products
+    struct Ops { bf16x8 g[4]; bf16x8 ex; float4 hp[2]; };
+    Ops ops[3];
+    auto ldops = [&](Ops& o, int it) {
+      const int pr = it >> 2, i = it & 3;
+      const int u = (wave * 8 + pr * 2) * 16 + eq * 8;
+      const long base = (long)s * RH + grow[i] * NH + u;
+      const __bf16* gp = a.gates + (long)s * 4 * RH + grow[i] * NH + u;
+#pragma unroll
+      for (int q = 0; q < 4; q++) o.g[q] = ldnt_bf16x8(gp + q * RH);
+      o.ex = ldnt_bf16x8(a.ext + base);
+      o.hp[0] = ldnt_f4(a.HN + base); o.hp[1] = ldnt_f4(a.HN + base + 4);
+    };
+    if (s >= 0) { ldops(ops[0], 0); ldops(ops[1], 1); }
+    // acc[i][j]: M tile i, unit tile wave*8 + j
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!last) {
+      // dh = dgh_{s+1} . W_hh: K = 1536 in 48 k-blocks; A fragments from the K-blocked scratch (chunk = 8 k of 64 rows: the 16
+      // lanes of a quad read 256 contiguous bytes), B fragments of W_hh^T from L2; groups of 2 k-blocks, software pipelined
+      bf16x8 bw[3][8], aw[3][4];
+      auto ldg = [&](int buf, int k) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) bw[buf][j] = a.wt[((long)(wave * 8 + j) * 48 + k) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; i++) aw[buf][i] = *reinterpret_cast<const bf16x8*>(scr + (((long)(k * 4 + kqi)) * NRP + i * 16 + rl) * 8);
+      };
+      auto mm = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 8; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[buf][j], aw[buf][i], acc[i][j], 0, 0, 0);
+      };
+      // ring of 3: the loads of k-block k+2 are issued before the MFMAs of k-block k (32 MFMAs = ~500 cycles per k-block)
+      ldg(0, 0); ldg(1, 1);
+#pragma unroll 1
+      for (int k = 0; k < 48; k += 3) {
+        ldg(2, k + 2);
+        mm(0);
+        if (k + 3 < 48) ldg(0, k + 3);
+        mm(1);
+        if (k + 4 < 48) ldg(1, k + 4);
+        mm(2);
+      }
+    }
+    // ---- epilogue: 16 items (4 tile pairs x 4 M tiles) in the wide-row layout
+    {
+#pragma unroll
+      for (int it = 0; it < 16; it++) {
+        const int pr = it >> 2, i = it & 3;
+        const int u = (wave * 8 + pr * 2) * 16 + eq * 8;
+        if (s >= 0 && it + 2 < 16) ldops(ops[(it + 2) % 3], it + 2);
+        float dh[8];
+        pair_to_rows(acc[i][2 * pr], acc[i][2 * pr + 1], dh);
+        float* dzp = dhz + (i * 16 + erow) * NH + u;
+        float cz[8];
+        ld_f32x8(dzp, cz);
+        if (s < 0) {                                                     // dh0 = dhz_0 + dgh_0 . W_hh
+#pragma unroll
+          for (int e = 0; e < 8; e++) dh[e] += cz[e];
+          if (ok[i] && a.dh0) st_f32x8(a.dh0 + grow[i] * NH + u, dh);
+          continue;
+        }
+        const Ops& o = ops[it % 3];
+        const float hp[8] = {o.hp[0].x, o.hp[0].y, o.hp[0].z, o.hp[0].w, o.hp[1].x, o.hp[1].y, o.hp[1].z, o.hp[1].w};
+        float dr[8], dz[8], dn[8], dnr[8], dq[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const float gr = (float)o.g[0][e], gz = (float)o.g[1][e], gn = (float)o.g[2][e], gh = (float)o.g[3][e];
+          const float d = dh[e] + cz[e] + (float)o.ex[e];
+          dn[e] = d * (1.0f - gz) * (1.0f - gn * gn);
+          dz[e] = d * (hp[e] - gn) * gz * (1.0f - gz);
+          dr[e] = dn[e] * gh * gr * (1.0f - gr);
+          dnr[e] = dn[e] * gr;
+          dq[e] = d * gz;
+        }
+        st_f32x8(dzp, dq);
+        // the next step's A operand: chunk (gate*512 + u)/8 of the K-blocked scratch, this row
+        __bf16* sp = scw + ((long)(u >> 3) * NRP + i * 16 + erow) * 8;
+        st_bf16x8(sp, dr); st_bf16x8(sp + (long)(NH / 8) * NRP * 8, dz); st_bf16x8(sp + (long)(2 * NH / 8) * NRP * 8, dnr);
+        if (ok[i]) {
+          __bf16* ph = a.dgh + (long)s * R3H + grow[i] * (3 * NH) + u;
+          stnt_bf16x8(ph, dr); stnt_bf16x8(ph + NH, dz); stnt_bf16x8(ph + 2 * NH, dnr);
+          __bf16* pi = a.dgi + (long)s * R3H + grow[i] * (3 * NH) + u;
+          stnt_bf16x8(pi, dr); stnt_bf16x8(pi + NH, dz); stnt_bf16x8(pi + 2 * NH, dn);
+        }
+      }
+    }
+    __syncthreads();                                                     // scratch + dhz of this step complete before the next products
+  }
+}
+
+}  // namespace ptv
+
+using namespace ptv;
+
+extern "C" int ptv_notes_gru_persist_fwd(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
+                                         float* HN, void* HN16, void* gates, long R, int T, void* stream) {
+  if (!wg_h || !wg_t || !b_hh || !gc || !emb || !HN || !HN16 || R <= 0 || T <= 0) return PTV_ERR_ARG;
+  NotesFwdArgs a{(const bf16x8*)wg_h, (const bf16x8*)wg_t, b_hh, (const __bf16*)gc, emb, HN, (__bf16*)HN16, (__bf16*)gates, (int)R, T & 0xff, T >> 8};
+  const size_t lds = (size_t)(2 * NRP * NH16LD + NRP * NT16LD) * sizeof(__bf16);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(notes_fwd_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PTV_ERR_LAUNCH;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(notes_fwd_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PTV_ERR_LAUNCH;
+    attr = true;
+  }
+  const dim3 grid((unsigned)((R + NRP - 1) / NRP));
+  if (a.dbg & 16) hipLaunchKernelGGL((notes_fwd_kernel<4, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((notes_fwd_kernel<8, false>), grid, dim3(512), lds, (hipStream_t)stream, a);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" long ptv_notes_gru_persist_scratch_elems(long R) { return ((R + NRP - 1) / NRP) * 2 * (192L * NRP * 8); }
+
+extern "C" int ptv_notes_gru_persist_bwd(const void* wt, const float* HN, const void* gates, const void* ext, void* dgi, void* dgh,
+                                         float* dh0, void* scratch, long R, int T, void* stream) {
+  if (!wt || !HN || !gates || !ext || !dgi || !dgh || !scratch || R <= 0 || T <= 0) return PTV_ERR_ARG;
+  NotesBwdArgs a{(const bf16x8*)wt, HN, (const __bf16*)gates, (const __bf16*)ext, (__bf16*)dgi, (__bf16*)dgh, dh0, (__bf16*)scratch, (int)R, T};
+  const size_t lds = (size_t)NRP * NH * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(notes_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PTV_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(notes_bwd_kernel, dim3((unsigned)((R + NRP - 1) / NRP)), dim3(256), lds, (hipStream_t)stream, a);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}

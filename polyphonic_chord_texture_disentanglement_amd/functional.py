@@ -710,6 +710,50 @@ class TextureFrontFn(torch.autograd.Function):
 # PtvaeDecoder, teacher-forced (tfr1 = tfr2 = 1): restructured from 2912 dependent cells to
 # 32 + 15 + 5 sequential steps.  ptvae.py:336-496.
 # =============================================================================================
+# ---------------------------------------------------------------------------------------------
+# row-partitioned persistent notes GRU (csrc/notes_persist.hip)
+# ---------------------------------------------------------------------------------------------
+NOTES_PERSIST = os.environ.get('PTV_NOTES_PERSIST', '1') not in ('0', 'false', 'off')
+_NOTES_PACKS = {}
+
+
+def pack_mfma_b(w2d, K=None):
+    """fp32 [N, >=K] (any row stride) -> MFMA B-fragment-major bf16 (ptv_pack_mfma_b): one contiguous 1-KB load per fragment"""
+    N = w2d.shape[0]
+    K = w2d.shape[1] if K is None else K
+    out = torch.empty(lib().ptv_pack_mfma_b_size(N, K), device=w2d.device, dtype=BF16)
+    call('ptv_pack_mfma_b', ptr(w2d), w2d.stride(0), N, K, ptr(out), stream_ptr())
+    return out
+
+
+def param_stamp(params):
+    """changes whenever one of `params` may have changed: in-place version counters + the fused optimiser's step count"""
+    from .optim import _SHADOW_OF
+    ent = _SHADOW_OF.get(params[0].data_ptr())
+    opt = ent[0]() if ent is not None else None
+    return (sum(p._version for p in params), opt.step_count if opt is not None else -1, opt._dirty if opt is not None else -1)
+
+
+def notes_packs(w_ih, w_hh, Ht):
+    """fragment-major copies of the notes-GRU weights: W_hh, W_ih[:, Ht:] (forward) and W_hh^T (BPTT); cached per parameter version"""
+    key = (w_ih.data_ptr(), w_hh.data_ptr())
+    stamp = param_stamp([w_ih, w_hh])
+    hit = _NOTES_PACKS.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    wT = torch.empty(w_hh.shape[1], w_hh.shape[0], device=w_hh.device, dtype=F32)
+    call('ptv_transpose01', ptr(wT), ptr(w_hh), w_hh.shape[0], w_hh.shape[1], 1, stream_ptr())
+    pk = dict(wg_h=pack_mfma_b(w_hh), wg_t=pack_mfma_b(w_ih[:, Ht:]), wt=pack_mfma_b(wT))
+    if len(_NOTES_PACKS) > 4:
+        _NOTES_PACKS.clear()
+    _NOTES_PACKS[key] = (stamp, pk)
+    return pk
+
+
+def notes_persist_ok(prec, Hn, E, gates_dtype=BF16):
+    return NOTES_PERSIST and prec == 1 and BF16_STORAGE and Hn == 512 and E == 128 and gates_dtype == BF16
+
+
 DEC_PARAM_NAMES = [
     'dec_init_input', 'dur_sos_token',
     'z2dec_hid_linear.weight', 'z2dec_hid_linear.bias', 'z2dec_in_linear.weight', 'z2dec_in_linear.bias',
@@ -794,11 +838,17 @@ class DecoderTFFn(torch.autograd.Function):
         w_ih_n = W['dec_notes_gru.weight_ih_l0']
         adt = _act_dtype(prec, Hn)
         GC = gemm(NSf_op, w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec, out_dtype=adt)      # [R, 3Hn]
-        GT = gemm(emb3[:15].view(15 * R, E), w_ih_n[:, Ht:], prec=prec, out_dtype=adt)                    # [15R, 3Hn]
         gates_n = _empty(15, 4, R, Hn, dev=dev, dtype=adt)
         HN16 = _hall16(prec, 16, R, Hn, dev)
-        gru_fwd(prec, GT, R * 3 * Hn, 3 * Hn, W['dec_notes_gru.weight_hh_l0'], P['dec_notes_gru.bias_hh_l0'], HN,
-                gates_n, gi2=GC, gi2_step=0, gi2_ld=3 * Hn, hall16=HN16)
+        if notes_persist_ok(prec, Hn, E, adt) and emb3.dtype == F32 and emb3.is_contiguous():
+            # ONE launch for the 15 note steps, 64 rows per workgroup, token product fused (csrc/notes_persist.hip)
+            pk = notes_packs(P['dec_notes_gru.weight_ih_l0'], P['dec_notes_gru.weight_hh_l0'], Ht)
+            call('ptv_notes_gru_persist_fwd', ptr(pk['wg_h']), ptr(pk['wg_t']), ptr(P['dec_notes_gru.bias_hh_l0']), ptr(GC), ptr(emb3),
+                 ptr(HN), ptr(HN16), ptr(gates_n), R, 15, stream_ptr())
+        else:
+            GT = gemm(emb3[:15].view(15 * R, E), w_ih_n[:, Ht:], prec=prec, out_dtype=adt)                    # [15R, 3Hn]
+            gru_fwd(prec, GT, R * 3 * Hn, 3 * Hn, W['dec_notes_gru.weight_hh_l0'], P['dec_notes_gru.bias_hh_l0'], HN,
+                    gates_n, gi2=GC, gi2_step=0, gi2_ld=3 * Hn, hall16=HN16)
         NSUM = HN[1:].view(15 * R, Hn)
         NSUM_op = HN16[1:].view(15 * R, Hn) if HN16 is not None else NSUM
 
@@ -952,7 +1002,16 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
 
     # ---- notes GRU (15 steps, batch 32*B) ----
     w_hh_n, w_ih_n = W['dec_notes_gru.weight_hh_l0'], W['dec_notes_gru.weight_ih_l0']
-    dgi_n, dgh_n, dHN0 = gru_bwd(prec, HN, st['gates_n'], w_hh_n, dh_ext=dNSUM.view(15, R, Hn))
+    if (notes_persist_ok(prec, Hn, E, st['gates_n'].dtype) and dNSUM.dtype == BF16 and HN.dtype == F32):
+        pk = notes_packs(w_ih_n, w_hh_n, Ht)
+        dgi_n = _empty(15, R, 3 * Hn, dev=dev, dtype=BF16)
+        dgh_n = _empty(15, R, 3 * Hn, dev=dev, dtype=BF16)
+        dHN0 = _empty(R, Hn, dev=dev)
+        scratch = _empty(lib().ptv_notes_gru_persist_scratch_elems(R), dev=dev, dtype=BF16)
+        call('ptv_notes_gru_persist_bwd', ptr(pk['wt']), ptr(HN), ptr(st['gates_n']), ptr(dNSUM), ptr(dgi_n), ptr(dgh_n), ptr(dHN0),
+             ptr(scratch), R, 15, stream_ptr())
+    else:
+        dgi_n, dgh_n, dHN0 = gru_bwd(prec, HN, st['gates_n'], w_hh_n, dh_ext=dNSUM.view(15, R, Hn))
     dGC = sum_steps(dgi_n)                                                    # [R, 3Hn]
     dtok = _empty(16, R, E, dev=dev)
     dtok[15].zero_()

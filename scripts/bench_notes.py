@@ -1,0 +1,74 @@
+"""notes GRU at the B = 512 train-step shape (R = 16384 rows, 15 steps): persistent kernels (csrc/notes_persist.hip) next to the
+per-step kernels + token product they replace.  python scripts/bench_notes.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from polyphonic_chord_texture_disentanglement_amd import functional as F_  # noqa: E402
+from polyphonic_chord_texture_disentanglement_amd._lib import call, lib, ptr, stream_ptr  # noqa: E402
+
+dev = torch.device('cuda:0')
+bf = torch.bfloat16
+R, T, H, E = int(sys.argv[1]) if len(sys.argv) > 1 else 16384, 15, 512, 128
+g = torch.Generator(device=dev).manual_seed(1)
+rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+w_hh, w_tok, b_hh = rn(3 * H, H) / H ** 0.5, rn(3 * H, E) / H ** 0.5, rn(3 * H) * 0.1
+gc, emb = (rn(R, 3 * H) * 0.5).to(bf), rn(T, R, E) * 0.5
+ext = (rn(T, R, H) * 0.1).to(bf)
+wg_h, wg_t, wt = F_.pack_mfma_b(w_hh), F_.pack_mfma_b(w_tok), F_.pack_mfma_b(w_hh.t().contiguous())
+HN = torch.zeros(T + 1, R, H, device=dev); HN[0] = rn(R, H) * 0.5
+HN16 = torch.zeros(T + 1, R, H, device=dev, dtype=bf)
+gates = torch.zeros(T, 4, R, H, device=dev, dtype=bf)
+dgi = torch.zeros(T, R, 3 * H, device=dev, dtype=bf); dgh = torch.zeros_like(dgi)
+dh0 = torch.zeros(R, H, device=dev)
+scratch = torch.empty(lib().ptv_notes_gru_persist_scratch_elems(R), device=dev, dtype=bf)
+w16, wt16, wtok16 = w_hh.to(bf).contiguous(), w_hh.t().contiguous().to(bf), w_tok.to(bf)
+dhz = torch.empty(2, R, H, device=dev)
+FL = 1 | 2 | 4 | 8 | 16
+
+
+def timeit(fn, n=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+def p_fwd():
+    call('ptv_notes_gru_persist_fwd', ptr(wg_h), ptr(wg_t), ptr(b_hh), ptr(gc), ptr(emb), ptr(HN), ptr(HN16), ptr(gates), R, T, stream_ptr())
+
+
+def p_bwd():
+    call('ptv_notes_gru_persist_bwd', ptr(wt), ptr(HN), ptr(gates), ptr(ext), ptr(dgi), ptr(dgh), ptr(dh0), ptr(scratch), R, T, stream_ptr())
+
+
+def s_fwd():
+    GT = F_.gemm(emb.view(T * R, E), wtok16, prec=1, out_dtype=bf)
+    call('ptv_gru_seq_fwd', 1, R, H, T, ptr(GT), R * 3 * H, 3 * H, ptr(gc), 0, 3 * H, ptr(w16), ptr(b_hh), ptr(HN), ptr(HN16), ptr(gates),
+         None, 0, None, FL, stream_ptr())
+
+
+def s_bwd():
+    call('ptv_gru_seq_bwd', 1, R, H, T, ptr(HN), ptr(gates), ptr(wt16), ptr(ext), ext.stride(0), ext.stride(1), None, 0, None, 0, 0, 0, None,
+         ptr(dgi), ptr(dgh), ptr(dhz), ptr(dh0), 0, FL | 64, stream_ptr())
+
+
+for name, fn in (('forward  per-step kernels + token product', s_fwd), ('forward  persistent', p_fwd),
+                 ('backward per-step kernels', s_bwd), ('backward persistent', p_bwd)):
+    t = timeit(fn)
+    print('R=%d T=%d  %-42s %8.1f us  (%.1f us per step)' % (R, T, name, t, t / T), flush=True)
+
+for name, dbg in (('fwd persistent: 4 waves + operand prefetch', 16), ('fwd persistent: no stagger', 8), ('fwd persistent: no epilogue', 2), ('fwd persistent: no global stores', 4),
+                  ('fwd persistent: no products, no stores', 5), ('fwd persistent: nothing but prefetch + token staging', 3)):
+    def f(dbg=dbg):
+        call('ptv_notes_gru_persist_fwd', ptr(wg_h), ptr(wg_t), ptr(b_hh), ptr(gc), ptr(emb), ptr(HN), ptr(HN16), ptr(gates), R, T | (dbg << 8), stream_ptr())
+    t = timeit(f)
+    print('R=%d T=%d  %-52s %8.1f us  (%.1f us per step)' % (R, T, name, t, t / T), flush=True)

@@ -379,3 +379,71 @@ def test_integration_md_snippet_runs_verbatim():
     torch.cuda.synchronize()
     ref = orc.linear(x, w, b)
     assert (y.cpu() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('R,T', [(512, 15), (200, 4), (16384, 2)])
+def test_notes_gru_persistent_kernels_vs_step_kernels_and_oracle(R, T):
+    """csrc/notes_persist.hip (row-partitioned: a workgroup owns 64 rows for the whole sequence, token product fused, dgh through a
+    K-blocked scratch tile) against the per-step kernels + separate token product on the same bf16 operands, and against the
+    fp32 oracle cell; whole / ragged last panel / the B = 512 row count"""
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    from polyphonic_chord_texture_disentanglement_amd._lib import call, lib, ptr, stream_ptr
+    dev = _dev()
+    bf = torch.bfloat16
+    H, E = 512, 128
+    g = torch.Generator().manual_seed(R + T)
+    k = 1.0 / np.sqrt(H)
+    U = lambda *s: (torch.rand(*s, generator=g) * 2 - 1) * k
+    w_hh, w_tok, b_hh = U(3 * H, H).to(bf).float(), U(3 * H, E).to(bf).float(), U(3 * H)
+    gc = (torch.randn(R, 3 * H, generator=g) * 0.5).to(bf)
+    emb = (torch.randn(T, R, E, generator=g) * 0.5).to(bf).float()
+    h0 = torch.randn(R, H, generator=g) * 0.5
+    ext = (torch.randn(T, R, H, generator=g) * 0.1).to(bf)
+    d = lambda t: t.to(dev).contiguous()
+    Wd = dict(w_hh=d(w_hh), w_tok=d(w_tok), b_hh=d(b_hh), gc=d(gc), emb=d(emb), ext=d(ext))
+    wg_h, wg_t = F_.pack_mfma_b(Wd['w_hh']), F_.pack_mfma_b(Wd['w_tok'])
+    wt = F_.pack_mfma_b(Wd['w_hh'].t().contiguous())
+    HN = torch.zeros(T + 1, R, H, device=dev); HN[0] = d(h0)
+    HN16 = torch.zeros(T + 1, R, H, device=dev, dtype=bf)
+    gates = torch.zeros(T, 4, R, H, device=dev, dtype=bf)
+    call('ptv_notes_gru_persist_fwd', ptr(wg_h), ptr(wg_t), ptr(Wd['b_hh']), ptr(Wd['gc']), ptr(Wd['emb']), ptr(HN), ptr(HN16), ptr(gates),
+         R, T, stream_ptr())
+    dgi = torch.zeros(T, R, 3 * H, device=dev, dtype=bf); dgh = torch.zeros_like(dgi)
+    dh0 = torch.zeros(R, H, device=dev)
+    scratch = torch.empty(lib().ptv_notes_gru_persist_scratch_elems(R), device=dev, dtype=bf)
+    call('ptv_notes_gru_persist_bwd', ptr(wt), ptr(HN), ptr(gates), ptr(Wd['ext']), ptr(dgi), ptr(dgh), ptr(dh0), ptr(scratch), R, T, stream_ptr())
+    # ---- the per-step kernels on the same operands
+    GT = F_.gemm(Wd['emb'].view(T * R, E), Wd['w_tok'].to(bf), prec=1, out_dtype=bf)
+    HN2 = torch.zeros_like(HN); HN2[0] = HN[0]
+    HN16_2 = torch.zeros_like(HN16); gates2 = torch.zeros_like(gates)
+    FL = 1 | 2 | 4 | 8 | 16
+    w16, wt16 = Wd['w_hh'].to(bf).contiguous(), Wd['w_hh'].t().contiguous().to(bf)
+    call('ptv_gru_seq_fwd', 1, R, H, T, ptr(GT), R * 3 * H, 3 * H, ptr(Wd['gc']), 0, 3 * H, ptr(w16), ptr(Wd['b_hh']),
+         ptr(HN2), ptr(HN16_2), ptr(gates2), None, 0, None, FL, stream_ptr())
+    assert (HN - HN2).abs().max() < 3e-2
+    assert (HN16.float() - HN).abs().max() < 1e-2
+    assert (gates.float() - gates2.float()).abs().max() < 4e-2
+    dgi2 = torch.zeros_like(dgi); dgh2 = torch.zeros_like(dgh)
+    dhz = torch.empty(2, R, H, device=dev); dh02 = torch.empty(R, H, device=dev)
+    e = Wd['ext']
+    call('ptv_gru_seq_bwd', 1, R, H, T, ptr(HN), ptr(gates), ptr(wt16), ptr(e), e.stride(0), e.stride(1), None, 0, None, 0, 0, 0, None,
+         ptr(dgi2), ptr(dgh2), ptr(dhz), ptr(dh02), 0, FL | 64, stream_ptr())
+    sc = max(1.0, dgi2.float().abs().max().item())
+    assert (dgi.float() - dgi2.float()).abs().max() < 0.03 * sc
+    assert (dgh.float() - dgh2.float()).abs().max() < 0.03 * sc
+    assert (dh0 - dh02).abs().max() < 0.03 * max(1.0, dh02.abs().max().item())
+    # ---- fp32 oracle cell on a row sample
+    rows = torch.cat([torch.arange(0, min(R, 40)), torch.arange(R - min(R, 40), R)])
+    hr = h0[rows].clone().requires_grad_()
+    h, hs = hr, []
+    for t in range(T):
+        x = gc[rows].float() + orc.linear(emb[t][rows], w_tok)
+        gh = orc.linear(h, w_hh, b_hh)
+        r = torch.sigmoid(x[:, :H] + gh[:, :H]); z = torch.sigmoid(x[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(x[:, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1 - z) * n + z * h
+        hs.append(h)
+    hs = torch.stack(hs)
+    (hs * ext[:, rows].float()).sum().backward()
+    assert (HN[1:, rows.to(dev)].cpu() - hs.detach()).abs().max() < 4e-2
+    assert (dh0[rows.to(dev)].cpu() - hr.grad).abs().max() < 0.05 * max(1.0, hr.grad.abs().max().item())
