@@ -311,6 +311,8 @@ int ptv_slerp_path(const float* z1, const float* z2, float* out, int B, int D, i
  * bf16 MFMA operands, fp32 state / logits; init_model() geometry only (E = He = 128, Hn = 512, Hd = 64, 130 pitches).
  *   ptv_pack_mfma_b: W fp32 [N][ld] (K columns from the given base) -> bf16 [ceil(N/16)][ceil(K/32)][64 lanes][8]: the B fragment
  *     of 16 rows x 32 k as one contiguous 1-KB wave load (zero padded); ptv_pack_mfma_b_size = elements of `out`.
+ *     pairs = 1 (N % 32 == 0) interleaves the rows of every pair of tiles so that lane (row, quad) of the MFMA C layout owns the 8
+ *     consecutive output columns 32t + 8*quad .. +7 across the pair's two accumulators (no cross-lane movement in the epilogue).
  *   ptv_free_note_loop: w / io are HOST arrays of 16 / 17 device pointers:
  *     w  = { pack(dec_notes_gru.weight_hh), pack(dec_notes_gru.weight_ih[:, Ht:]), pack(pitch_out_linear.weight),
  *            pack(dur_hid_linear.weight[:, :512]), pack(dur_hid_linear.weight[:, 512:]), pack(dec_dur_gru.weight_hh),
@@ -329,7 +331,7 @@ int ptv_slerp_path(const float* z1, const float* z2, float* out, int B, int D, i
  *     tok_next = TOKS[t+1] [B][256] }.
  */
 long ptv_pack_mfma_b_size(int N, int K);
-int ptv_pack_mfma_b(const float* W, long ld, int N, int K, void* out, void* stream);
+int ptv_pack_mfma_b(const float* W, long ld, int N, int K, void* out, int pairs, void* stream);
 int ptv_free_note_loop(const void* const* w, const void* const* io, long ld_pitch, int B, int t, unsigned coin_mask, int train,
                        void* stream);
 int ptv_free_resummarize(const void* const* w, const void* const* io, int B, int t, int train, void* stream);

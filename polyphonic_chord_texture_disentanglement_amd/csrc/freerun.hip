@@ -116,13 +116,20 @@ __device__ __forceinline__ void st_bf16x4_lds(__bf16* p, float a, float b, float
 // weight packing: W fp32 [N][ld] (columns 0..K-1 of the given base) -> MFMA B-fragment-major bf16
 //   out[((nt*KB + kb)*64 + lane)*8 + e] = W[nt*16 + (lane & 15)][kb*32 + (lane >> 4)*8 + e]   (0 beyond N / K)
 // =============================================================================================
-__global__ void pack_b_kernel(const float* __restrict__ W, long ld, int N, int K, __bf16* __restrict__ out, int NT, int KB) {
+// pairs = 1: rows are interleaved inside every PAIR of tiles so that a lane's accumulator registers of the two tiles are 8
+// CONSECUTIVE output columns: fragment row c of tile 2t   <- source row 32t + (c / 4) * 8 + c % 4,
+//                                              tile 2t+1 <- source row 32t + (c / 4) * 8 + 4 + c % 4
+// (MFMA C layout: lane = row + 16 * quad holds columns 4 * quad .. 4 * quad + 3 of a tile) -> lane (row, quad) owns columns
+// 32t + 8 * quad .. + 7 with no cross-lane movement: 16- / 32-byte epilogue accesses straight from the accumulators.
+__global__ void pack_b_kernel(const float* __restrict__ W, long ld, int N, int K, __bf16* __restrict__ out, int NT, int KB, int pairs) {
   const long total = (long)NT * KB * 64;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int lane = (int)(i & 63);
     const long f = i >> 6;
     const int kb = (int)(f % KB), nt = (int)(f / KB);
-    const int n = nt * 16 + (lane & 15), k0 = kb * 32 + (lane >> 4) * 8;
+    const int c = lane & 15;
+    const int n = pairs ? (nt >> 1) * 32 + (c >> 2) * 8 + (nt & 1) * 4 + (c & 3) : nt * 16 + c;
+    const int k0 = kb * 32 + (lane >> 4) * 8;
     bf16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; e++) v[e] = (__bf16)((n < N && k0 + e < K) ? W[(long)n * ld + k0 + e] : 0.f);
@@ -536,11 +543,11 @@ using namespace ptv;
 
 extern "C" long ptv_pack_mfma_b_size(int N, int K) { return (long)((N + 15) / 16) * ((K + 31) / 32) * 512; }
 
-extern "C" int ptv_pack_mfma_b(const float* W, long ld, int N, int K, void* out, void* stream) {
-  if (!W || !out || N <= 0 || K <= 0 || ld < K) return PTV_ERR_ARG;
+extern "C" int ptv_pack_mfma_b(const float* W, long ld, int N, int K, void* out, int pairs, void* stream) {
+  if (!W || !out || N <= 0 || K <= 0 || ld < K || (pairs && (N & 31))) return PTV_ERR_ARG;
   const int NT = (N + 15) / 16, KB = (K + 31) / 32;
   long nb = ((long)NT * KB * 64 + 255) / 256; if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(pack_b_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, W, ld, N, K, (__bf16*)out, NT, KB);
+  hipLaunchKernelGGL(pack_b_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, W, ld, N, K, (__bf16*)out, NT, KB, pairs);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

@@ -11,8 +11,9 @@
 //   * W_hh is streamed from L2 in MFMA-fragment-major packing (ptv_pack_mfma_b), one fragment load serving four M tiles:
 //     the same 1.5 MB per CU per step the per-step kernels pulled through L2, now the ONLY large read besides GC
 //   * the token product (emb . W_ih[:, Ht:]^T) is fused: K = 128 more per step instead of a [15*R, 1536] tensor
-//   * epilogues run in a "wide row" lane layout (4 adjacent lanes = 32 contiguous units of one row, 8 per lane): every global
-//     access is a 16- or 32-byte piece of a 64-128-byte run
+//   * the weight tiles are packed pair-interleaved (ptv_pack_mfma_b, pairs = 1): a lane's accumulators of two adjacent tiles are 8
+//     consecutive units of one row, so the epilogue runs in the MFMA's own lane layout with 16- / 32-byte accesses and no cross-lane
+//     movement (a first version transposed lanes with 64 ds_bpermute per tile pair: the LDS crossbar became the bottleneck)
 // No workgroup waits for another: no flags, no residency requirement, any grid size.
 // bf16 MFMA operands, fp32 state and accumulation (the bf16 precision policy); Hn = 512, E = 128 (init_model() geometry).
 #include "common.hpp"
@@ -27,19 +28,11 @@ constexpr int NH16LD = NH + 16, NT16LD = NE + 16;    // bf16 LDS row strides: co
 __device__ __forceinline__ float nsig(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float ntanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
-// two accumulator fragments of ADJACENT unit tiles (C layout: lane = row + 16*quad, 4 units per lane per tile) -> wide-row
-// layout: lane = 4*row + q holds units q*8 .. q*8+7 of the 32 units of the pair
+// the two accumulator fragments of a PAIR of unit tiles packed with ptv_pack_mfma_b(pairs = 1): lane (row = lane % 16,
+// quad = lane / 16) already holds the 8 consecutive units 8*quad .. 8*quad+7 of the pair's 32 -- no cross-lane movement
 __device__ __forceinline__ void pair_to_rows(const f32x4& f0, const f32x4& f1, float (&o)[8]) {
-  const int lane = threadIdx.x & 63, row = lane >> 2, q = lane & 3;
-  const int s0 = row + 16 * ((q & 1) * 2), s1 = s0 + 16;
-  const bool hi = q >> 1;
 #pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const float a0 = __shfl(f0[e], s0, 64), a1 = __shfl(f1[e], s0, 64);
-    const float b0 = __shfl(f0[e], s1, 64), b1 = __shfl(f1[e], s1, 64);
-    o[e] = hi ? a1 : a0;
-    o[4 + e] = hi ? b1 : b0;
-  }
+  for (int e = 0; e < 4; e++) { o[e] = f0[e]; o[4 + e] = f1[e]; }
 }
 
 // streaming traffic (read once / written once per launch) carries the non-temporal hint: with the default policy the ~26 MB per
@@ -102,7 +95,7 @@ __global__ __launch_bounds__(NW * 64, 1) void notes_fwd_kernel(NotesFwdArgs a) {
   __bf16* tok16 = h16 + 2 * NRP * NH16LD;                                // [64][NT16LD]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rl = lane & 15, kq = (lane >> 4) * 8;                        // fragment coordinates
-  const int erow = lane >> 2, eq = lane & 3;                             // wide-row epilogue coordinates
+  const int erow = lane & 15, eq = lane >> 4;                            // epilogue coordinates = the MFMA C layout (pair-interleaved tiles)
   const long R = a.R;
   const long r0 = (long)blockIdx.x * NRP;
   const long RH = R * NH;
@@ -250,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void notes_bwd_kernel(NotesBwdArgs a) {
   float* dhz = reinterpret_cast<float*>(nsm);                            // [64][512] fp32: dh (x) z carried to the earlier step
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rl = lane & 15, kqi = lane >> 4;
-  const int erow = lane >> 2, eq = lane & 3;
+  const int erow = lane & 15, eq = lane >> 4;
   const long R = a.R;
   const long r0 = (long)blockIdx.x * NRP;
   const long RH = R * NH, R3H = 3 * RH;
@@ -377,8 +370,11 @@ extern "C" int ptv_notes_gru_persist_fwd(const void* wg_h, const void* wg_t, con
     attr = true;
   }
   const dim3 grid((unsigned)((R + NRP - 1) / NRP));
-  if (a.dbg & 16) hipLaunchKernelGGL((notes_fwd_kernel<4, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((notes_fwd_kernel<8, false>), grid, dim3(512), lds, (hipStream_t)stream, a);
+  // 4 waves with the epilogue operands prefetched under the products: 65 us per step at R = 16384; 8 waves (two per SIMD, no
+  // prefetch: dbg bit 16) measured 73 -- the waves of a workgroup move through the phases together, so a second wave per SIMD
+  // does not fill the first one's gaps
+  if (a.dbg & 16) hipLaunchKernelGGL((notes_fwd_kernel<8, false>), grid, dim3(512), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((notes_fwd_kernel<4, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

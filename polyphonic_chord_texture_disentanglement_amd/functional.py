@@ -717,12 +717,12 @@ NOTES_PERSIST = os.environ.get('PTV_NOTES_PERSIST', '1') not in ('0', 'false', '
 _NOTES_PACKS = {}
 
 
-def pack_mfma_b(w2d, K=None):
+def pack_mfma_b(w2d, K=None, pairs=False):
     """fp32 [N, >=K] (any row stride) -> MFMA B-fragment-major bf16 (ptv_pack_mfma_b): one contiguous 1-KB load per fragment"""
     N = w2d.shape[0]
     K = w2d.shape[1] if K is None else K
     out = torch.empty(lib().ptv_pack_mfma_b_size(N, K), device=w2d.device, dtype=BF16)
-    call('ptv_pack_mfma_b', ptr(w2d), w2d.stride(0), N, K, ptr(out), stream_ptr())
+    call('ptv_pack_mfma_b', ptr(w2d), w2d.stride(0), N, K, ptr(out), int(pairs), stream_ptr())
     return out
 
 
@@ -743,7 +743,7 @@ def notes_packs(w_ih, w_hh, Ht):
         return hit[1]
     wT = torch.empty(w_hh.shape[1], w_hh.shape[0], device=w_hh.device, dtype=F32)
     call('ptv_transpose01', ptr(wT), ptr(w_hh), w_hh.shape[0], w_hh.shape[1], 1, stream_ptr())
-    pk = dict(wg_h=pack_mfma_b(w_hh), wg_t=pack_mfma_b(w_ih[:, Ht:]), wt=pack_mfma_b(wT))
+    pk = dict(wg_h=pack_mfma_b(w_hh, pairs=True), wg_t=pack_mfma_b(w_ih[:, Ht:], pairs=True), wt=pack_mfma_b(wT, pairs=True))
     if len(_NOTES_PACKS) > 4:
         _NOTES_PACKS.clear()
     _NOTES_PACKS[key] = (stamp, pk)

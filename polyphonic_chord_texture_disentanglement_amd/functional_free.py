@@ -51,12 +51,12 @@ def free_persist_ok(prec, E, He, Hn, Hd, NP):
     return FREE_PERSIST and prec == 1 and F_.BF16_STORAGE and (E, He, Hn, Hd, NP) == (128, 128, 512, 64, 130)
 
 
-def _pack(w2d, K=None):
+def _pack(w2d, K=None, pairs=False):
     """fp32 [N, >=K] (any row stride) -> MFMA B-fragment-major bf16 (ptv_pack_mfma_b)"""
     N = w2d.shape[0]
     K = w2d.shape[1] if K is None else K
     out = torch.empty(lib().ptv_pack_mfma_b_size(N, K), device=w2d.device, dtype=torch.bfloat16)
-    call('ptv_pack_mfma_b', ptr(w2d), w2d.stride(0), N, K, ptr(out), stream_ptr())
+    call('ptv_pack_mfma_b', ptr(w2d), w2d.stride(0), N, K, ptr(out), int(pairs), stream_ptr())
     return out
 
 

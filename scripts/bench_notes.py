@@ -17,7 +17,7 @@ rn = lambda *s: torch.randn(*s, device=dev, generator=g)
 w_hh, w_tok, b_hh = rn(3 * H, H) / H ** 0.5, rn(3 * H, E) / H ** 0.5, rn(3 * H) * 0.1
 gc, emb = (rn(R, 3 * H) * 0.5).to(bf), rn(T, R, E) * 0.5
 ext = (rn(T, R, H) * 0.1).to(bf)
-wg_h, wg_t, wt = F_.pack_mfma_b(w_hh), F_.pack_mfma_b(w_tok), F_.pack_mfma_b(w_hh.t().contiguous())
+wg_h, wg_t, wt = F_.pack_mfma_b(w_hh, pairs=True), F_.pack_mfma_b(w_tok, pairs=True), F_.pack_mfma_b(w_hh.t().contiguous(), pairs=True)
 HN = torch.zeros(T + 1, R, H, device=dev); HN[0] = rn(R, H) * 0.5
 HN16 = torch.zeros(T + 1, R, H, device=dev, dtype=bf)
 gates = torch.zeros(T, 4, R, H, device=dev, dtype=bf)
@@ -66,7 +66,7 @@ for name, fn in (('forward  per-step kernels + token product', s_fwd), ('forward
     t = timeit(fn)
     print('R=%d T=%d  %-42s %8.1f us  (%.1f us per step)' % (R, T, name, t, t / T), flush=True)
 
-for name, dbg in (('fwd persistent: 4 waves + operand prefetch', 16), ('fwd persistent: no stagger', 8), ('fwd persistent: no epilogue', 2), ('fwd persistent: no global stores', 4),
+for name, dbg in (('fwd persistent: 8 waves, no operand prefetch', 16), ('fwd persistent: no stagger', 8), ('fwd persistent: no epilogue', 2), ('fwd persistent: no global stores', 4),
                   ('fwd persistent: no products, no stores', 5), ('fwd persistent: nothing but prefetch + token staging', 3)):
     def f(dbg=dbg):
         call('ptv_notes_gru_persist_fwd', ptr(wg_h), ptr(wg_t), ptr(b_hh), ptr(gc), ptr(emb), ptr(HN), ptr(HN16), ptr(gates), R, T | (dbg << 8), stream_ptr())

@@ -401,8 +401,8 @@ def test_notes_gru_persistent_kernels_vs_step_kernels_and_oracle(R, T):
     ext = (torch.randn(T, R, H, generator=g) * 0.1).to(bf)
     d = lambda t: t.to(dev).contiguous()
     Wd = dict(w_hh=d(w_hh), w_tok=d(w_tok), b_hh=d(b_hh), gc=d(gc), emb=d(emb), ext=d(ext))
-    wg_h, wg_t = F_.pack_mfma_b(Wd['w_hh']), F_.pack_mfma_b(Wd['w_tok'])
-    wt = F_.pack_mfma_b(Wd['w_hh'].t().contiguous())
+    wg_h, wg_t = F_.pack_mfma_b(Wd['w_hh'], pairs=True), F_.pack_mfma_b(Wd['w_tok'], pairs=True)
+    wt = F_.pack_mfma_b(Wd['w_hh'].t().contiguous(), pairs=True)
     HN = torch.zeros(T + 1, R, H, device=dev); HN[0] = d(h0)
     HN16 = torch.zeros(T + 1, R, H, device=dev, dtype=bf)
     gates = torch.zeros(T, 4, R, H, device=dev, dtype=bf)
