@@ -353,6 +353,23 @@ long ptv_notes_gru_persist_scratch_elems(long R);
 int ptv_notes_gru_persist_bwd(const void* wt, const float* HN, const void* gates, const void* ext, void* dgi, void* dgh,
                               float* dh0, void* scratch, long R, int T, void* stream);
 
+/* The same kernels for any GRU whose rows are many and independent; H = 512 (above) or H = 128 with 128 inputs, which is one
+ * direction of dec_notes_emb_gru, the note-summary bi-GRU over the 16 notes of each of the 32*B steps (ptvae.py:446-453,480-486).
+ *   fwd: w_hh = pack(W_hh [3H,H]), w_x = pack(W_ih [3H,128]) (pairs = 1); b_ih NULL when folded into gc; gc bf16 [R][3H] or NULL;
+ *        x fp32, row m of step t at x + t*x_step + m*128; lengths int32 [R] or NULL (row m is updated at time t iff t < lengths[m],
+ *        as nn.utils.rnn.pack_padded_sequence does); reverse = 1 walks time T-1..0; out (or NULL) receives the final state,
+ *        row m at out + m*out_ld (out_ld % 4 == 0).
+ *   bwd: ext bf16 [T][R][H] or NULL; dh_last fp32 (row stride last_ld) = gradient of the final state, or NULL; dgi is indexed by
+ *        TIME, dgh by processing step (so dgh pairs with HN16[:T] and dgi with x in the weight-gradient products).
+ */
+int ptv_row_gru_persist_fwd(int H, const void* w_hh, const void* w_x, const float* b_hh, const float* b_ih, const void* gc,
+                            const float* x, long x_step, const int* lengths, float* HN, void* HN16, void* gates,
+                            float* out, long out_ld, long R, int T, int reverse, void* stream);
+long ptv_row_gru_persist_scratch_elems(int H, long R);
+int ptv_row_gru_persist_bwd(int H, const void* wt, const float* HN, const void* gates, const void* ext,
+                            const float* dh_last, long last_ld, void* dgi, void* dgh, float* dh0, void* scratch,
+                            long R, int T, int reverse, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * clip_grad_norm_ (module.py:142-143) + torch.optim.Adam.step (train.py:50, scheduler.py:69-74) over
  * flat fp32 buffers: sumsq = |g|^2 (device scalar), then p,m,v updated with g*gscale clipped to `clip`.

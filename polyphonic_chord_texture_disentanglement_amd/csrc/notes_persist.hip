@@ -22,8 +22,8 @@
 
 namespace ptv {
 
-constexpr int NH = 512, NE = 128, NRP = 64;          // hidden units, token width, rows per workgroup
-constexpr int NH16LD = NH + 16, NT16LD = NE + 16;    // bf16 LDS row strides: conflict-free b128 fragment reads
+constexpr int NE = 128, NRP = 64;                    // input (token) width, rows per workgroup
+constexpr int NT16LD = NE + 16;                      // bf16 LDS row strides (+16): conflict-free b128 fragment reads
 
 __device__ __forceinline__ float nsig(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float ntanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
@@ -75,61 +75,69 @@ __device__ __forceinline__ void st_f32x8(float* p, const float (&v)[8]) {
 }
 
 // =============================================================================================
-// forward
+// forward.  H = 512: the notes GRU (hoisted input part GC, no mask).  H = 128: one direction of dec_notes_emb_gru, the note
+// summary bi-GRU over the 16 notes of each of the 32*B steps (ptvae.py:446-453,480-486): b_ih, packed-sequence mask by length,
+// reversed time order for the *_reverse direction, final state written to its half of the summary.
 // =============================================================================================
-struct NotesFwdArgs {
-  const bf16x8 *wg_h, *wg_t;       // packed W_hh [96 tiles][16 kb][64], W_ih[:, Ht:] [96][4][64]
-  const float* b_hh;               // [1536]
-  const __bf16* gc;                // [R][1536] hoisted input part W_ih[:, :Ht] ns + b_ih
-  const float* emb;                // fed tokens, step-major [T][R][128] fp32
-  float* HN; __bf16* HN16;         // [T+1][R][512]; slot 0 of HN written by the caller
-  __bf16* gates;                   // [T][4][R][512] or null
-  int R, T, dbg;
+struct RowGruFwdArgs {
+  const bf16x8 *w_hh, *w_x;        // pair-interleaved packing: W_hh [3H/16 tiles][H/32 kb][64], W_x [3H/16][4][64]
+  const float* b_hh; const float* b_ih;   // [3H]; b_ih may be null (folded into gc)
+  const __bf16* gc;                // [R][3H] hoisted input part (b_ih included) or null
+  const float* x; long x_step;     // fed tokens fp32: x + t*x_step + row*128
+  const int* lengths;              // [R] or null: row m is updated at time t iff t < lengths[m]
+  float* HN; __bf16* HN16;         // [T+1][R][H]; slot 0 of HN written by the caller
+  __bf16* gates;                   // [T][4][R][H] or null
+  float* out; long out_ld;         // final state -> out[row*out_ld + unit], or null
+  int R, T, reverse, dbg;
 };
 
-template <int NW, bool PREF>
-__global__ __launch_bounds__(NW * 64, 1) void notes_fwd_kernel(NotesFwdArgs a) {
-  constexpr int NTH = NW * 64, NPASS = 16 / NW, UTW = 32 / NW;           // threads, passes per step, unit tiles per wave
+template <int H>
+__global__ __launch_bounds__(256, 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
+  constexpr int KBH = H / 32, NUT = H / 16, NPASS = H / 128, UTW = NUT / 4, HLD = H + 16, KT = KBH + 4;
   extern __shared__ __attribute__((aligned(16))) char nsm[];
-  __bf16* h16 = reinterpret_cast<__bf16*>(nsm);                          // [2][64][NH16LD]
-  __bf16* tok16 = h16 + 2 * NRP * NH16LD;                                // [64][NT16LD]
+  __bf16* h16 = reinterpret_cast<__bf16*>(nsm);                          // [2][64][HLD]
+  __bf16* tok16 = h16 + 2 * NRP * HLD;                                   // [64][NT16LD]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rl = lane & 15, kq = (lane >> 4) * 8;                        // fragment coordinates
   const int erow = lane & 15, eq = lane >> 4;                            // epilogue coordinates = the MFMA C layout (pair-interleaved tiles)
   const long R = a.R;
   const long r0 = (long)blockIdx.x * NRP;
-  const long RH = R * NH;
+  const long RH = R * H;
 
   // ---- initial state: bf16 operand copy -> LDS and HN16 slot 0
-  for (int i = tid; i < NRP * (NH / 8); i += NTH) {
-    const int row = i / (NH / 8), c8 = (i % (NH / 8)) * 8;
+  for (int i = tid; i < NRP * (H / 8); i += 256) {
+    const int row = i / (H / 8), c8 = (i % (H / 8)) * 8;
     const long gr = min(r0 + row, R - 1);
     float v[8];
-    ld_f32x8(a.HN + gr * NH + c8, v);
-    st_bf16x8(h16 + row * NH16LD + c8, v);
-    if (r0 + row < R) st_bf16x8(a.HN16 + gr * NH + c8, v);
+    ld_f32x8(a.HN + gr * H + c8, v);
+    st_bf16x8(h16 + row * HLD + c8, v);
+    if (r0 + row < R) st_bf16x8(a.HN16 + gr * H + c8, v);
   }
-  long grow[4]; bool ok[4];
+  long grow[4]; bool ok[4]; int len[4];
 #pragma unroll
-  for (int i = 0; i < 4; i++) { ok[i] = r0 + i * 16 + erow < R; grow[i] = min(r0 + i * 16 + erow, R - 1); }
-  const int prot = (a.dbg & 8) ? 0 : (blockIdx.x >> 3) & (NPASS - 1), krot = (a.dbg & 8) ? 0 : ((blockIdx.x >> 5) & 7) * 2;
+  for (int i = 0; i < 4; i++) {
+    ok[i] = r0 + i * 16 + erow < R; grow[i] = min(r0 + i * 16 + erow, R - 1);
+    len[i] = a.lengths ? a.lengths[grow[i]] : 0x7fffffff;
+  }
+  // workgroups of one XCD run in near lockstep and would all ask the L2 for the same few fragment lines at the same moment (a
+  // handful of its 16 channels busy, the rest idle): each walks the passes and the k-blocks from its own starting point
+  const int prot = (a.dbg & 8) ? 0 : (blockIdx.x >> 3) & (NPASS - 1), krot = (a.dbg & 8) ? 0 : (((blockIdx.x >> 5) & 7) * 2) & (KBH - 1);
 
   for (int n = 0; n < a.T; n++) {
     const int cur = n & 1, nxt = cur ^ 1;
-    const __bf16* hc = h16 + cur * NRP * NH16LD;
-    __bf16* hn_ = h16 + nxt * NRP * NH16LD;
+    const int tt = a.reverse ? a.T - 1 - n : n;
+    const __bf16* hc = h16 + cur * NRP * HLD;
+    __bf16* hn_ = h16 + nxt * NRP * HLD;
     // ---- this step's fed tokens -> LDS (bf16 MFMA operand)
-    for (int i = tid; i < NRP * (NE / 8); i += NTH) {
+    for (int i = tid; i < NRP * (NE / 8); i += 256) {
       const int row = i / (NE / 8), c8 = (i % (NE / 8)) * 8;
       float v[8];
-      ld_f32x8(a.emb + ((long)n * R + min(r0 + row, R - 1)) * NE + c8, v);
+      ld_f32x8(a.x + (long)tt * a.x_step + min(r0 + row, R - 1) * NE + c8, v);
       st_bf16x8(tok16 + row * NT16LD + c8, v);
     }
     __syncthreads();
 #pragma unroll 1
     for (int p0 = 0; p0 < NPASS; p0++) {
-      // workgroups of one XCD run in near lockstep and would all ask the L2 for the same few fragment lines at the same moment
-      // (a handful of its 16 channels busy, the rest idle): each walks the passes and the k-blocks from its own starting point
       const int p = (p0 + prot) & (NPASS - 1);
       const int ut0 = wave * UTW + p * 2;
       const int u = ut0 * 16 + eq * 8;                                   // this lane's first unit of the pass
@@ -139,84 +147,94 @@ __global__ __launch_bounds__(NW * 64, 1) void notes_fwd_kernel(NotesFwdArgs a) {
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int tl[6] = {ut0, ut0 + 1, 32 + ut0, 33 + ut0, 64 + ut0, 65 + ut0};
+      const int tl[6] = {ut0, ut0 + 1, NUT + ut0, NUT + 1 + ut0, 2 * NUT + ut0, 2 * NUT + 1 + ut0};
       // epilogue operands of the pass (GC and the fp32 state of this lane's cells) are requested BEFORE the products: they come
       // from HBM, and waiting for them per M tile in the epilogue exposed that latency 16 times per step
       bf16x8 gq[4][3]; float4 hq[4][2];
 #pragma unroll
-      for (int i = 0; i < (PREF ? 4 : 0); i++) {
-        const __bf16* g = a.gc + grow[i] * (3 * NH) + u;
+      for (int i = 0; i < 4; i++) {
+        if (a.gc) {
+          const __bf16* g = a.gc + grow[i] * (3 * H) + u;
 #pragma unroll
-        for (int gt = 0; gt < 3; gt++) gq[i][gt] = ldnt_bf16x8(g + gt * NH);
-        const float* hp = a.HN + (long)n * RH + grow[i] * NH + u;
+          for (int gt = 0; gt < 3; gt++) gq[i][gt] = ldnt_bf16x8(g + gt * H);
+        }
+        const float* hp = a.HN + (long)n * RH + grow[i] * H + u;
         hq[i][0] = ldnt_f4(hp); hq[i][1] = ldnt_f4(hp + 4);
       }
-      // software-pipelined stream of 16 + 4 k-blocks through a ring of 4 fragment buffers: the loads of k-block k+3 are issued
+      // software-pipelined stream of KBH + 4 k-blocks through a ring of 4 fragment buffers: the loads of k-block k+3 are issued
       // before the MFMAs of k-block k (24 MFMAs = ~400 cycles per k-block against ~900 cycles of L2 latency)
-      constexpr int RD = PREF ? 4 : 3;                                   // ring depth (prefetch distance RD - 1)
-      bf16x8 b[RD][6];
-      auto ldw = [&](bf16x8 (&d)[6], int k) {                            // k < 16: W_hh block (k + krot) % 16; else W_ih[:, Ht:] block k - 16
+      bf16x8 b[4][6];
+      auto ldw = [&](bf16x8 (&d)[6], int k) {                            // k < KBH: W_hh block (k + krot) % KBH; else W_x block k - KBH
 #pragma unroll
-        for (int j = 0; j < 6; j++) d[j] = k < 16 ? a.wg_h[((long)tl[j] * 16 + ((k + krot) & 15)) * 64 + lane] : a.wg_t[((long)tl[j] * 4 + (k - 16)) * 64 + lane];
+        for (int j = 0; j < 6; j++)
+          d[j] = k < KBH ? a.w_hh[((long)tl[j] * KBH + ((k + krot) & (KBH - 1))) * 64 + lane] : a.w_x[((long)tl[j] * 4 + (k - KBH)) * 64 + lane];
       };
+      ldw(b[0], 0); ldw(b[1], 1); ldw(b[2], 2);
 #pragma unroll
-      for (int k = 0; k < RD - 1; k++) ldw(b[k], k);
-#pragma unroll
-      for (int k = 0; k < 20; k++) {
-        if (k + RD - 1 < 20) ldw(b[(k + RD - 1) % RD], k + RD - 1);
-        const bool tokpart = k >= 16;
+      for (int k = 0; k < KT; k++) {
+        if (k + 3 < KT) ldw(b[(k + 3) & 3], k + 3);
+        const bool tokpart = k >= KBH;
         const __bf16* A = tokpart ? tok16 : hc;
-        const int lda = tokpart ? NT16LD : NH16LD, kb = tokpart ? k - 16 : ((k + krot) & 15);
+        const int lda = tokpart ? NT16LD : HLD, kb = tokpart ? k - KBH : ((k + krot) & (KBH - 1));
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const bf16x8 av = *reinterpret_cast<const bf16x8*>(A + (i * 16 + rl) * lda + kb * 32 + kq);
 #pragma unroll
           for (int j = 0; j < 6; j++) {
             const int slot = j < 4 ? j : (tokpart ? j + 2 : j);
-            acc[i][slot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[k % RD][j], av, acc[i][slot], 0, 0, 0);
+            acc[i][slot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[k & 3][j], av, acc[i][slot], 0, 0, 0);
           }
         }
       }
-      if (a.dbg & 2) continue;
       // ---- epilogue: GRU cell on this lane's cells of the pass
-      float bR[8], bZ[8], bN[8];
-      ld_f32x8(a.b_hh + u, bR); ld_f32x8(a.b_hh + NH + u, bZ); ld_f32x8(a.b_hh + 2 * NH + u, bN);
+      float bR[8], bZ[8], bN[8], bI[8];
+      ld_f32x8(a.b_hh + u, bR); ld_f32x8(a.b_hh + H + u, bZ); ld_f32x8(a.b_hh + 2 * H + u, bN);
+#pragma unroll
+      for (int e = 0; e < 8; e++) bI[e] = 0.f;
+      if (a.b_ih) {
+        float t8[8];
+        ld_f32x8(a.b_ih + u, t8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) bR[e] += t8[e];
+        ld_f32x8(a.b_ih + H + u, t8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) bZ[e] += t8[e];
+        ld_f32x8(a.b_ih + 2 * H + u, bI);
+      }
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         float gR[8], gZ[8], gN[8], aR[8], aZ[8], aH[8], aI[8], hp[8];
-        if constexpr (!PREF) {                                           // two waves per SIMD: the partner covers the latency
-          const __bf16* g = a.gc + grow[i] * (3 * NH) + u;
 #pragma unroll
-          for (int gt = 0; gt < 3; gt++) gq[i][gt] = ldnt_bf16x8(g + gt * NH);
-          const float* hpp = a.HN + (long)n * RH + grow[i] * NH + u;
-          hq[i][0] = ldnt_f4(hpp); hq[i][1] = ldnt_f4(hpp + 4);
+        for (int e = 0; e < 8; e++) {
+          gR[e] = a.gc ? (float)gq[i][0][e] : 0.f; gZ[e] = a.gc ? (float)gq[i][1][e] : 0.f; gN[e] = a.gc ? (float)gq[i][2][e] : 0.f;
         }
-#pragma unroll
-        for (int e = 0; e < 8; e++) { gR[e] = (float)gq[i][0][e]; gZ[e] = (float)gq[i][1][e]; gN[e] = (float)gq[i][2][e]; }
-        // fp32 state of these cells: written by this very lane one step ago (the whole fp32 state, 128 KB per workgroup, fits
-        // neither LDS next to the bf16 operand copies nor the register file next to the accumulators)
+        // fp32 state of these cells: written by this very lane one step ago (the whole fp32 state, 128 KB per workgroup at H = 512,
+        // fits neither LDS next to the bf16 operand copies nor the register file next to the accumulators)
         hp[0] = hq[i][0].x; hp[1] = hq[i][0].y; hp[2] = hq[i][0].z; hp[3] = hq[i][0].w;
         hp[4] = hq[i][1].x; hp[5] = hq[i][1].y; hp[6] = hq[i][1].z; hp[7] = hq[i][1].w;
         pair_to_rows(acc[i][0], acc[i][1], aR); pair_to_rows(acc[i][2], acc[i][3], aZ);
         pair_to_rows(acc[i][4], acc[i][5], aH); pair_to_rows(acc[i][6], acc[i][7], aI);
+        const bool live = tt < len[i];
         float r[8], z[8], nn[8], hn[8], h[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) {
           r[e] = nsig(aR[e] + gR[e] + bR[e]);
           z[e] = nsig(aZ[e] + gZ[e] + bZ[e]);
           hn[e] = aH[e] + bN[e];
-          nn[e] = ntanh(aI[e] + gN[e] + r[e] * hn[e]);
+          nn[e] = ntanh(aI[e] + gN[e] + bI[e] + r[e] * hn[e]);
+          if (!live) { r[e] = 0.f; z[e] = 1.f; nn[e] = 0.f; }             // masked row: h' = h, zero gate gradients
           h[e] = (1.0f - z[e]) * nn[e] + z[e] * hp[e];
         }
-        st_bf16x8(hn_ + (i * 16 + erow) * NH16LD + u, h);
-        if (ok[i] && !(a.dbg & 4)) {
-          const long o = (long)(n + 1) * RH + grow[i] * NH + u;
+        st_bf16x8(hn_ + (i * 16 + erow) * HLD + u, h);
+        if (ok[i]) {
+          const long o = (long)(n + 1) * RH + grow[i] * H + u;
           st_f32x8(a.HN + o, h);                                       // read back next step: default policy
           stnt_bf16x8(a.HN16 + o, h);
           if (a.gates) {
-            __bf16* gp = a.gates + (long)n * 4 * RH + grow[i] * NH + u;
+            __bf16* gp = a.gates + (long)n * 4 * RH + grow[i] * H + u;
             stnt_bf16x8(gp, r); stnt_bf16x8(gp + RH, z); stnt_bf16x8(gp + 2 * RH, nn); stnt_bf16x8(gp + 3 * RH, hn);
           }
+          if (a.out && n == a.T - 1) st_f32x8(a.out + grow[i] * a.out_ld + u, h);
         }
         __builtin_amdgcn_sched_barrier(0);                               // keep the M tiles' epilogues (and the passes) apart: register pressure
       }
@@ -228,64 +246,69 @@ __global__ __launch_bounds__(NW * 64, 1) void notes_fwd_kernel(NotesFwdArgs a) {
 // =============================================================================================
 // BPTT
 // =============================================================================================
-struct NotesBwdArgs {
-  const bf16x8* wt;                // packed W_hh^T [32 tiles of output units][48 kb][64]
+struct RowGruBwdArgs {
+  const bf16x8* wt;                // pair-interleaved packing of W_hh^T: [H/16 tiles of output units][3H/32 kb][64]
   const float* HN; const __bf16* gates;
-  const __bf16* ext;               // [T][R][512] bf16 gradient arriving at the state after step s (dNSUM)
-  __bf16* dgi; __bf16* dgh;        // [T][R][1536]
-  float* dh0;                      // [R][512]
-  __bf16* scratch;                 // [grid][2][192 chunks][64 rows][8]: dgh of the workgroup's rows, K-blocked (A operand of the next step)
-  int R, T;
+  const __bf16* ext;               // [T][R][H] bf16 gradient arriving at the state after step s, or null
+  const float* dh_last; long last_ld;   // gradient arriving at the final state only (rows of stride last_ld), or null
+  __bf16* dgi; __bf16* dgh;        // [T][R][3H]: dgi by TIME index, dgh by processing step
+  float* dh0;                      // [R][H] or null
+  __bf16* scratch;                 // [grid][2][3H/8 chunks][64 rows][8]: dgh of the workgroup's rows, K-blocked (A operand of the next step)
+  int R, T, reverse;
 };
 
-__global__ __launch_bounds__(256, 1) void notes_bwd_kernel(NotesBwdArgs a) {
+template <int H>
+__global__ __launch_bounds__(256, 1) void row_gru_bwd_kernel(RowGruBwdArgs a) {
+  constexpr int KT = 3 * H / 32, NTW = H / 64, NCH = 3 * H / 8;           // k-blocks, output tiles per wave, scratch chunks
   extern __shared__ __attribute__((aligned(16))) char nsm[];
-  float* dhz = reinterpret_cast<float*>(nsm);                            // [64][512] fp32: dh (x) z carried to the earlier step
+  float* dhz = reinterpret_cast<float*>(nsm);                            // [64][H] fp32: dh (x) z carried to the earlier step
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rl = lane & 15, kqi = lane >> 4;
   const int erow = lane & 15, eq = lane >> 4;
   const long R = a.R;
   const long r0 = (long)blockIdx.x * NRP;
-  const long RH = R * NH, R3H = 3 * RH;
-  __bf16* sc = a.scratch + (long)blockIdx.x * 2 * (192 * NRP * 8);
-  for (int i = tid; i < NRP * NH; i += 256) dhz[i] = 0.f;
+  const long RH = R * H, R3H = 3 * RH;
+  __bf16* sc = a.scratch + (long)blockIdx.x * 2 * (NCH * NRP * 8);
+  for (int i = tid; i < NRP * H; i += 256) dhz[i] = 0.f;
   long grow[4]; bool ok[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) { ok[i] = r0 + i * 16 + erow < R; grow[i] = min(r0 + i * 16 + erow, R - 1); }
   __syncthreads();
 
-  for (int s = a.T - 1; s >= -1; s--) {
+  for (int s = a.T - 1; s >= (a.dh0 ? -1 : 0); s--) {
     const bool last = s == a.T - 1;
-    const __bf16* scr = sc + ((s + 1) & 1) * (192 * NRP * 8);             // dgh_{s+1}, written by the previous iteration
-    __bf16* scw = sc + (s & 1) * (192 * NRP * 8);
-    // HBM operands of the epilogue items (4 tile pairs x 4 M tiles; saved gates, previous state, external gradient) run 2 items
+    const int tt = s < 0 ? 0 : (a.reverse ? a.T - 1 - s : s);
+    const __bf16* scr = sc + ((s + 1) & 1) * (NCH * NRP * 8);             // dgh_{s+1}, written by the previous iteration
+    __bf16* scw = sc + (s & 1) * (NCH * NRP * 8);
+    // HBM operands of the epilogue items (tile pairs x 4 M tiles; saved gates, previous state, external gradient) run 2 items
     // ahead of the arithmetic through a ring of 3 register sets; the first two are requested before the products
     struct Ops { bf16x8 g[4]; bf16x8 ex; float4 hp[2]; };
     Ops ops[3];
+    constexpr int NIT = (NTW / 2) * 4;
     auto ldops = [&](Ops& o, int it) {
       const int pr = it >> 2, i = it & 3;
-      const int u = (wave * 8 + pr * 2) * 16 + eq * 8;
-      const long base = (long)s * RH + grow[i] * NH + u;
-      const __bf16* gp = a.gates + (long)s * 4 * RH + grow[i] * NH + u;
+      const int u = (wave * NTW + pr * 2) * 16 + eq * 8;
+      const long base = (long)s * RH + grow[i] * H + u;
+      const __bf16* gp = a.gates + (long)s * 4 * RH + grow[i] * H + u;
 #pragma unroll
       for (int q = 0; q < 4; q++) o.g[q] = ldnt_bf16x8(gp + q * RH);
-      o.ex = ldnt_bf16x8(a.ext + base);
+      if (a.ext) o.ex = ldnt_bf16x8(a.ext + base);
       o.hp[0] = ldnt_f4(a.HN + base); o.hp[1] = ldnt_f4(a.HN + base + 4);
     };
     if (s >= 0) { ldops(ops[0], 0); ldops(ops[1], 1); }
-    // acc[i][j]: M tile i, unit tile wave*8 + j
-    f32x4 acc[4][8];
+    // acc[i][j]: M tile i, unit tile wave*NTW + j
+    f32x4 acc[4][NTW];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-      for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NTW; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!last) {
-      // dh = dgh_{s+1} . W_hh: K = 1536 in 48 k-blocks; A fragments from the K-blocked scratch (chunk = 8 k of 64 rows: the 16
-      // lanes of a quad read 256 contiguous bytes), B fragments of W_hh^T from L2; groups of 2 k-blocks, software pipelined
-      bf16x8 bw[3][8], aw[3][4];
+      // dh = dgh_{s+1} . W_hh: K = 3H; A fragments from the K-blocked scratch (chunk = 8 k of 64 rows: the 16 lanes of a quad read
+      // 256 contiguous bytes), B fragments of W_hh^T from L2; ring of 3: the loads of k-block k+2 precede the MFMAs of k-block k
+      bf16x8 bw[3][NTW], aw[3][4];
       auto ldg = [&](int buf, int k) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) bw[buf][j] = a.wt[((long)(wave * 8 + j) * 48 + k) * 64 + lane];
+        for (int j = 0; j < NTW; j++) bw[buf][j] = a.wt[((long)(wave * NTW + j) * KT + k) * 64 + lane];
 #pragma unroll
         for (int i = 0; i < 4; i++) aw[buf][i] = *reinterpret_cast<const bf16x8*>(scr + (((long)(k * 4 + kqi)) * NRP + i * 16 + rl) * 8);
       };
@@ -293,105 +316,133 @@ __global__ __launch_bounds__(256, 1) void notes_bwd_kernel(NotesBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
-          for (int j = 0; j < 8; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[buf][j], aw[buf][i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NTW; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[buf][j], aw[buf][i], acc[i][j], 0, 0, 0);
       };
-      // ring of 3: the loads of k-block k+2 are issued before the MFMAs of k-block k (32 MFMAs = ~500 cycles per k-block)
+      static_assert(KT % 3 == 0, "ring of 3");
       ldg(0, 0); ldg(1, 1);
 #pragma unroll 1
-      for (int k = 0; k < 48; k += 3) {
+      for (int k = 0; k < KT; k += 3) {
         ldg(2, k + 2);
         mm(0);
-        if (k + 3 < 48) ldg(0, k + 3);
+        if (k + 3 < KT) ldg(0, k + 3);
         mm(1);
-        if (k + 4 < 48) ldg(1, k + 4);
+        if (k + 4 < KT) ldg(1, k + 4);
         mm(2);
       }
     }
-    // ---- epilogue: 16 items (4 tile pairs x 4 M tiles) in the wide-row layout
-    {
+    // ---- epilogue items in the MFMA lane layout (pair-interleaved tiles: 8 consecutive units per lane)
 #pragma unroll
-      for (int it = 0; it < 16; it++) {
-        const int pr = it >> 2, i = it & 3;
-        const int u = (wave * 8 + pr * 2) * 16 + eq * 8;
-        if (s >= 0 && it + 2 < 16) ldops(ops[(it + 2) % 3], it + 2);
-        float dh[8];
-        pair_to_rows(acc[i][2 * pr], acc[i][2 * pr + 1], dh);
-        float* dzp = dhz + (i * 16 + erow) * NH + u;
-        float cz[8];
-        ld_f32x8(dzp, cz);
-        if (s < 0) {                                                     // dh0 = dhz_0 + dgh_0 . W_hh
+    for (int it = 0; it < NIT; it++) {
+      const int pr = it >> 2, i = it & 3;
+      const int u = (wave * NTW + pr * 2) * 16 + eq * 8;
+      if (s >= 0 && it + 2 < NIT) ldops(ops[(it + 2) % 3], it + 2);
+      float dh[8];
+      pair_to_rows(acc[i][2 * pr], acc[i][2 * pr + 1], dh);
+      float* dzp = dhz + (i * 16 + erow) * H + u;
+      float cz[8];
+      ld_f32x8(dzp, cz);
+      if (s < 0) {                                                       // dh0 = dhz_0 + dgh_0 . W_hh
 #pragma unroll
-          for (int e = 0; e < 8; e++) dh[e] += cz[e];
-          if (ok[i] && a.dh0) st_f32x8(a.dh0 + grow[i] * NH + u, dh);
-          continue;
-        }
-        const Ops& o = ops[it % 3];
-        const float hp[8] = {o.hp[0].x, o.hp[0].y, o.hp[0].z, o.hp[0].w, o.hp[1].x, o.hp[1].y, o.hp[1].z, o.hp[1].w};
-        float dr[8], dz[8], dn[8], dnr[8], dq[8];
+        for (int e = 0; e < 8; e++) dh[e] += cz[e];
+        if (ok[i]) st_f32x8(a.dh0 + grow[i] * H + u, dh);
+        continue;
+      }
+      const Ops& o = ops[it % 3];
+      const float hp[8] = {o.hp[0].x, o.hp[0].y, o.hp[0].z, o.hp[0].w, o.hp[1].x, o.hp[1].y, o.hp[1].z, o.hp[1].w};
+      float lastg[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-          const float gr = (float)o.g[0][e], gz = (float)o.g[1][e], gn = (float)o.g[2][e], gh = (float)o.g[3][e];
-          const float d = dh[e] + cz[e] + (float)o.ex[e];
-          dn[e] = d * (1.0f - gz) * (1.0f - gn * gn);
-          dz[e] = d * (hp[e] - gn) * gz * (1.0f - gz);
-          dr[e] = dn[e] * gh * gr * (1.0f - gr);
-          dnr[e] = dn[e] * gr;
-          dq[e] = d * gz;
-        }
-        st_f32x8(dzp, dq);
-        // the next step's A operand: chunk (gate*512 + u)/8 of the K-blocked scratch, this row
-        __bf16* sp = scw + ((long)(u >> 3) * NRP + i * 16 + erow) * 8;
-        st_bf16x8(sp, dr); st_bf16x8(sp + (long)(NH / 8) * NRP * 8, dz); st_bf16x8(sp + (long)(2 * NH / 8) * NRP * 8, dnr);
-        if (ok[i]) {
-          __bf16* ph = a.dgh + (long)s * R3H + grow[i] * (3 * NH) + u;
-          stnt_bf16x8(ph, dr); stnt_bf16x8(ph + NH, dz); stnt_bf16x8(ph + 2 * NH, dnr);
-          __bf16* pi = a.dgi + (long)s * R3H + grow[i] * (3 * NH) + u;
-          stnt_bf16x8(pi, dr); stnt_bf16x8(pi + NH, dz); stnt_bf16x8(pi + 2 * NH, dn);
-        }
+      for (int e = 0; e < 8; e++) lastg[e] = 0.f;
+      if (last && a.dh_last) ld_f32x8(a.dh_last + grow[i] * a.last_ld + u, lastg);
+      float dr[8], dz[8], dn[8], dnr[8], dq[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float gr = (float)o.g[0][e], gz = (float)o.g[1][e], gn = (float)o.g[2][e], gh = (float)o.g[3][e];
+        const float d = dh[e] + cz[e] + (a.ext ? (float)o.ex[e] : 0.f) + lastg[e];
+        dn[e] = d * (1.0f - gz) * (1.0f - gn * gn);
+        dz[e] = d * (hp[e] - gn) * gz * (1.0f - gz);
+        dr[e] = dn[e] * gh * gr * (1.0f - gr);
+        dnr[e] = dn[e] * gr;
+        dq[e] = d * gz;
+      }
+      st_f32x8(dzp, dq);
+      // the next step's A operand: chunk (gate*H + u)/8 of the K-blocked scratch, this row
+      __bf16* sp = scw + ((long)(u >> 3) * NRP + i * 16 + erow) * 8;
+      st_bf16x8(sp, dr); st_bf16x8(sp + (long)(H / 8) * NRP * 8, dz); st_bf16x8(sp + (long)(2 * H / 8) * NRP * 8, dnr);
+      if (ok[i]) {
+        __bf16* ph = a.dgh + (long)s * R3H + grow[i] * (3 * H) + u;
+        stnt_bf16x8(ph, dr); stnt_bf16x8(ph + H, dz); stnt_bf16x8(ph + 2 * H, dnr);
+        __bf16* pi = a.dgi + (long)tt * R3H + grow[i] * (3 * H) + u;
+        stnt_bf16x8(pi, dr); stnt_bf16x8(pi + H, dz); stnt_bf16x8(pi + 2 * H, dn);
       }
     }
     __syncthreads();                                                     // scratch + dhz of this step complete before the next products
   }
 }
 
+template <int H>
+static int launch_fwd(const RowGruFwdArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)(2 * NRP * (H + 16) + NRP * NT16LD) * sizeof(__bf16);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(row_gru_fwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PTV_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL((row_gru_fwd_kernel<H>), dim3((unsigned)((a.R + NRP - 1) / NRP)), dim3(256), lds, s, a);
+  return PTV_OK;
+}
+template <int H>
+static int launch_bwd(const RowGruBwdArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)NRP * H * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(row_gru_bwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PTV_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL((row_gru_bwd_kernel<H>), dim3((unsigned)((a.R + NRP - 1) / NRP)), dim3(256), lds, s, a);
+  return PTV_OK;
+}
+
 }  // namespace ptv
 
 using namespace ptv;
 
-extern "C" int ptv_notes_gru_persist_fwd(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
-                                         float* HN, void* HN16, void* gates, long R, int T, void* stream) {
-  if (!wg_h || !wg_t || !b_hh || !gc || !emb || !HN || !HN16 || R <= 0 || T <= 0) return PTV_ERR_ARG;
-  NotesFwdArgs a{(const bf16x8*)wg_h, (const bf16x8*)wg_t, b_hh, (const __bf16*)gc, emb, HN, (__bf16*)HN16, (__bf16*)gates, (int)R, T & 0xff, T >> 8};
-  const size_t lds = (size_t)(2 * NRP * NH16LD + NRP * NT16LD) * sizeof(__bf16);
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(notes_fwd_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PTV_ERR_LAUNCH;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(notes_fwd_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PTV_ERR_LAUNCH;
-    attr = true;
-  }
-  const dim3 grid((unsigned)((R + NRP - 1) / NRP));
-  // 4 waves with the epilogue operands prefetched under the products: 65 us per step at R = 16384; 8 waves (two per SIMD, no
-  // prefetch: dbg bit 16) measured 73 -- the waves of a workgroup move through the phases together, so a second wave per SIMD
-  // does not fill the first one's gaps
-  if (a.dbg & 16) hipLaunchKernelGGL((notes_fwd_kernel<8, false>), grid, dim3(512), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((notes_fwd_kernel<4, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
+extern "C" int ptv_row_gru_persist_fwd(int H, const void* w_hh, const void* w_x, const float* b_hh, const float* b_ih, const void* gc,
+                                       const float* x, long x_step, const int* lengths, float* HN, void* HN16, void* gates,
+                                       float* out, long out_ld, long R, int T, int reverse, void* stream) {
+  if (!w_hh || !w_x || !b_hh || !x || !HN || !HN16 || R <= 0 || T <= 0 || (H != 512 && H != 128)) return PTV_ERR_ARG;
+  if (out && (out_ld & 3)) return PTV_ERR_ARG;
+  RowGruFwdArgs a{(const bf16x8*)w_hh, (const bf16x8*)w_x, b_hh, b_ih, (const __bf16*)gc, x, x_step, lengths, HN, (__bf16*)HN16,
+                  (__bf16*)gates, out, out_ld, (int)R, T & 0xff, reverse, T >> 8};
+  PTV_TRY(H == 512 ? launch_fwd<512>(a, (hipStream_t)stream) : launch_fwd<128>(a, (hipStream_t)stream));
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
 
-extern "C" long ptv_notes_gru_persist_scratch_elems(long R) { return ((R + NRP - 1) / NRP) * 2 * (192L * NRP * 8); }
+extern "C" long ptv_row_gru_persist_scratch_elems(int H, long R) { return ((R + NRP - 1) / NRP) * 2 * ((3L * H / 8) * NRP * 8); }
+
+extern "C" int ptv_row_gru_persist_bwd(int H, const void* wt, const float* HN, const void* gates, const void* ext,
+                                       const float* dh_last, long last_ld, void* dgi, void* dgh, float* dh0, void* scratch,
+                                       long R, int T, int reverse, void* stream) {
+  if (!wt || !HN || !gates || !dgi || !dgh || !scratch || R <= 0 || T <= 0 || (H != 512 && H != 128)) return PTV_ERR_ARG;
+  if (dh_last && (last_ld & 3)) return PTV_ERR_ARG;
+  RowGruBwdArgs a{(const bf16x8*)wt, HN, (const __bf16*)gates, (const __bf16*)ext, dh_last, last_ld, (__bf16*)dgi, (__bf16*)dgh, dh0,
+                  (__bf16*)scratch, (int)R, T, reverse};
+  PTV_TRY(H == 512 ? launch_bwd<512>(a, (hipStream_t)stream) : launch_bwd<128>(a, (hipStream_t)stream));
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+// the notes GRU through the generic entry points (kept as named entry points of the train step's dominant recurrence)
+extern "C" int ptv_notes_gru_persist_fwd(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
+                                         float* HN, void* HN16, void* gates, long R, int T, void* stream) {
+  if (!gc) return PTV_ERR_ARG;
+  return ptv_row_gru_persist_fwd(512, wg_h, wg_t, b_hh, nullptr, gc, emb, R * NE, nullptr, HN, HN16, gates, nullptr, 0, R, T, 0, stream);
+}
+
+extern "C" long ptv_notes_gru_persist_scratch_elems(long R) { return ptv_row_gru_persist_scratch_elems(512, R); }
 
 extern "C" int ptv_notes_gru_persist_bwd(const void* wt, const float* HN, const void* gates, const void* ext, void* dgi, void* dgh,
                                          float* dh0, void* scratch, long R, int T, void* stream) {
-  if (!wt || !HN || !gates || !ext || !dgi || !dgh || !scratch || R <= 0 || T <= 0) return PTV_ERR_ARG;
-  NotesBwdArgs a{(const bf16x8*)wt, HN, (const __bf16*)gates, (const __bf16*)ext, (__bf16*)dgi, (__bf16*)dgh, dh0, (__bf16*)scratch, (int)R, T};
-  const size_t lds = (size_t)NRP * NH * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(notes_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PTV_ERR_LAUNCH;
-    attr = true;
-  }
-  hipLaunchKernelGGL(notes_bwd_kernel, dim3((unsigned)((R + NRP - 1) / NRP)), dim3(256), lds, (hipStream_t)stream, a);
-  PTV_CHECK_LAUNCH();
-  return PTV_OK;
+  if (!ext) return PTV_ERR_ARG;
+  return ptv_row_gru_persist_bwd(512, wt, HN, gates, ext, nullptr, 0, dgi, dgh, dh0, scratch, R, T, 0, stream);
 }

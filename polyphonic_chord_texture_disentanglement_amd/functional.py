@@ -547,6 +547,26 @@ def _bigru_forward(prec, x3, lengths, w):
             copy2d(out[:, d * H:(d + 1) * H], saved[d][0][T])
         return out, saved
 
+    if row_gru_ok(prec, H, I, M, adt) and x3.dtype == F32:
+        # many short independent rows (dec_notes_emb_gru: 32*B rows x 16 notes): row-partitioned persistent kernels, one launch per
+        # direction for the whole sequence (csrc/notes_persist.hip), input product fused; the directions overlap on sibling streams
+        def rows(d):
+            w_ih, w_hh, b_ih, b_hh = w[4 * d: 4 * d + 4]
+            pk = notes_packs(w_ih, w_hh, 0)
+            hall = _empty(T + 1, M, H, dev=dev)
+            hall[0].zero_()
+            h16 = _empty(T + 1, M, H, dev=dev, dtype=BF16)
+            gates = _empty(T, 4, M, H, dev=dev, dtype=BF16)
+            call('ptv_row_gru_persist_fwd', H, ptr(pk['wg_h']), ptr(pk['wg_t']), ptr(b_hh), ptr(b_ih), None, ptr(x3), M * I,
+                 ptr(lengths) if lengths is not None else None, ptr(hall), ptr(h16), ptr(gates), out.data_ptr() + 4 * d * H, 2 * H,
+                 M, T, d, stream_ptr())
+            return hall, gates, h16
+        side = Side(7)
+        rev = side(lambda: rows(1), x3, out)
+        fwd = rows(0)
+        side.join()
+        return out, [fwd, rev]
+
     side = Side(7)
     rev = side(lambda: direction(1), xf, out)
     fwd = direction(0)
@@ -600,6 +620,19 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
         gru_persist_bwd(M, H, T, chains)
         g1, dx1 = side(lambda: products(1, chains[1]['dgi'], chains[1]['dgh']), xf, dout, chains[1]['dgi'], chains[1]['dgh'])
         g0, dx0 = products(0, chains[0]['dgi'], chains[0]['dgh'])
+    elif row_gru_ok(prec, H, I, M, adt) and saved[0][1].dtype == BF16 and saved[0][2] is not None:
+        def rows(d):
+            w_ih, w_hh = w[4 * d], w[4 * d + 1]
+            hall, gates, h16 = saved[d]
+            pk = notes_packs(w_ih, w_hh, 0)
+            dgi = _empty(T, M, 3 * H, dev=x3.device, dtype=BF16)
+            dgh = _empty(T, M, 3 * H, dev=x3.device, dtype=BF16)
+            scratch = _empty(lib().ptv_row_gru_persist_scratch_elems(H, M), dev=x3.device, dtype=BF16)
+            call('ptv_row_gru_persist_bwd', H, ptr(pk['wt']), ptr(hall), ptr(gates), None, dout.data_ptr() + 4 * d * H, dout.stride(0),
+                 ptr(dgi), ptr(dgh), None, ptr(scratch), M, T, d, stream_ptr())
+            return products(d, dgi, dgh)
+        g1, dx1 = side(lambda: rows(1), xf, dout)
+        g0, dx0 = rows(0)
     else:
         g1, dx1 = side(lambda: direction(1), xf, dout)
         g0, dx0 = direction(0)
@@ -748,6 +781,12 @@ def notes_packs(w_ih, w_hh, Ht):
         _NOTES_PACKS.clear()
     _NOTES_PACKS[key] = (stamp, pk)
     return pk
+
+
+def row_gru_ok(prec, H, I, M, adt):
+    """the H = 128 instance of the row-partitioned persistent GRU (dec_notes_emb_gru): worth it when the rows fill the chip"""
+    return (NOTES_PERSIST and os.environ.get('PTV_ROW_GRU128', '1') != '0' and prec == 1 and BF16_STORAGE and H == 128 and I == 128
+            and adt == BF16 and M >= 4096)
 
 
 def notes_persist_ok(prec, Hn, E, gates_dtype=BF16):

@@ -447,3 +447,52 @@ def test_notes_gru_persistent_kernels_vs_step_kernels_and_oracle(R, T):
     (hs * ext[:, rows].float()).sum().backward()
     assert (HN[1:, rows.to(dev)].cpu() - hs.detach()).abs().max() < 4e-2
     assert (dh0[rows.to(dev)].cpu() - hr.grad).abs().max() < 0.05 * max(1.0, hr.grad.abs().max().item())
+
+
+@pytest.mark.parametrize('M,T', [(4096, 16), (4100, 5)])
+def test_row_gru_h128_bidirectional_with_lengths_vs_step_kernels_and_oracle(M, T, monkeypatch):
+    """dec_notes_emb_gru through the H = 128 instance of csrc/notes_persist.hip (lengths mask, reversed direction, final state into
+    its half of the summary, gradient arriving at the final state only) against the per-step path on the same operands and the
+    fp32 oracle's packed-sequence bi-GRU (oracle _bigru_final, ptvae.py:446-453)"""
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    from oracle.ptvae_oracle import Oracle
+    dev = _dev()
+    H = I = 128
+    g = torch.Generator().manual_seed(M + T)
+    k = 1.0 / np.sqrt(H)
+    U = lambda *s: ((torch.rand(*s, generator=g) * 2 - 1) * k)
+    names = ['weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0']
+    shapes = [(3 * H, I), (3 * H, H), (3 * H,), (3 * H,)]
+    cpu_w = {('g.' + n + s): U(*sh) for s in ('', '_reverse') for n, sh in zip(names, shapes)}
+    order = ['g.' + n + s for s in ('', '_reverse') for n in names]
+    x = torch.randn(T, M, I, generator=g) * 0.7
+    lengths = torch.randint(0, T + 1, (M,), generator=g, dtype=torch.int32)
+    lengths[:3] = torch.tensor([0, T, 1], dtype=torch.int32)
+    dout = torch.randn(M, 2 * H, generator=g) * 0.3
+
+    def run(persist):
+        monkeypatch.setattr(F_, 'NOTES_PERSIST', persist)
+        w = [cpu_w[n].to(dev).requires_grad_() for n in order]
+        xd = x.to(dev).requires_grad_()
+        assert F_.row_gru_ok(1, H, I, M, torch.bfloat16) == persist
+        out = F_.BiGruFinalFn.apply(xd, lengths.to(dev), 1, *w)
+        out.backward(dout.to(dev))
+        torch.cuda.synchronize()
+        return out.detach().cpu(), xd.grad.cpu(), [p.grad.cpu() for p in w]
+
+    o1, dx1, g1 = run(True)
+    o0, dx0, g0 = run(False)
+    assert (o1 - o0).abs().max() < 2e-2
+    assert (dx1 - dx0).abs().max() < 0.03 * max(1.0, dx0.abs().max().item())
+    for a, b in zip(g1, g0):
+        assert (a - b).abs().max() < 0.03 * max(1.0, b.abs().max().item())
+    # ---- fp32 oracle on a row sample (weight gradients need all rows: compare out and dx there)
+    rows = torch.cat([torch.arange(0, 48), torch.arange(M - 48, M)])
+    orc_ = Oracle.__new__(Oracle)                               # only the bi-GRU helper is used: no full parameter set needed
+    orc_.p = cpu_w
+    xr = x[:, rows].transpose(0, 1).contiguous().requires_grad_()
+    ref = orc_._bigru_final('g', xr, lengths[rows])
+    ref.backward(dout[rows])
+    assert (o1[rows] - ref.detach()).abs().max() < 3e-2
+    assert (dx1[:, rows] - xr.grad.transpose(0, 1)).abs().max() < 0.05 * max(1.0, xr.grad.abs().max().item())
+    assert (o1[0] == 0).all()                                   # a row of length 0 never leaves the zero state
