@@ -158,6 +158,49 @@ def extras(dev, B, rank):
     return out
 
 
+def _roofline(lib, B, model, args):
+    """roofline of the dominant kernels, measured live (HIP events on the launch stream, ptv_prof_*): the notes GRU of the
+    teacher-forced decoder as ONE row-partitioned persistent launch per direction of time (csrc/notes_persist.hip), forward
+    (tag 3) and BPTT (tag 4).  Algorithmic bytes per launch (DESIGN.md section 6, R = 32*B rows, H = 512, E = 128, T = 15 steps):
+      fwd  per step: GC bf16 R*3H*2 (hoisted input part) + fed token fp32 R*E*4 read; state fp32 R*H*4 + bf16 R*H*2 and the four
+           saved gate planes bf16 4*R*H*2 written; once: W_hh and W_ih[:, Ht:] bf16, b_hh, the initial state.
+      bwd  per step: gates 4*R*H*2 + gradient arriving at the state R*H*2 + previous state fp32 R*H*4 read; dgi and dgh bf16
+           2*R*3H*2 written; once: W_hh^T bf16, dh0 fp32.
+    Intensity is ~180 FLOP/B, below the MI355X balance point (2.5 PFLOP/s / 8 TB/s = 312): HBM bounds both; the MFMA fraction is
+    reported beside it."""
+    import ctypes
+    R, H, E, T = 32 * B, model.decoder.dec_notes_hid_size, 128, 15
+    fwd_bytes = T * (R * 3 * H * 2 + R * E * 4 + R * H * 4 + R * H * 2 + 4 * R * H * 2) + 3 * H * (H + E) * 2 + 3 * H * 4 + R * H * 4
+    bwd_bytes = T * (4 * R * H * 2 + R * H * 2 + R * H * 4 + 2 * R * 3 * H * 2) + 3 * H * H * 2 + R * H * 4
+    pmc = {}
+    pmc_path = os.path.join(ROOT, 'profiles', 'r02_row_gru_pmc.json')
+    if B == 512 and args.precision == 'bf16' and os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))
+    out = []
+    for tag, name, nbytes in ((4, 'row_gru_bwd_kernel<512>', bwd_bytes), (3, 'row_gru_fwd_kernel<512>', fwd_bytes)):
+        cnt, ms, fl = ctypes.c_long(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        lib.ptv_prof_read_tag(tag, ctypes.byref(cnt), ctypes.byref(ms), ctypes.byref(fl))
+        if cnt.value == 0:
+            continue
+        avg_s = ms.value / cnt.value * 1e-3
+        gbs, tfs = nbytes / avg_s / 1e9, fl.value / cnt.value / avg_s / 1e12
+        k = pmc.get(name, {})
+        out.append({'bound': 'hbm', 'kernel': '%s (dec_notes_gru, R=%d rows x T=%d steps in one launch)' % (name, R, T),
+                    'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
+                    'traffic': k.get('hbm_bytes_per_launch'), 'algorithmic_bytes': nbytes, 'launches': cnt.value,
+                    'avg_us': round(avg_s * 1e6, 1), 'total_ms': round(ms.value, 2),
+                    'mfma': {'achieved': round(tfs, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(tfs / 2500.0, 4),
+                             'busy_frac_pmc': k.get('mfma_busy_frac')},
+                    'flop_per_byte': round(fl.value / cnt.value / nbytes, 1), 'balance_flop_per_byte': 312.5,
+                    'note': 'in situ: the launch shares the GPU with the weight-gradient products on sibling streams'})
+    if not out:
+        return None
+    out.sort(key=lambda r: -r['total_ms'])
+    roof = out[0]
+    roof['also'] = out[1:]
+    return roof
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -248,7 +291,7 @@ def main():
     barrier()
     lib.ptv_prof_reset()
     lib.ptv_prof_config(32 * B, model.decoder.dec_notes_hid_size)
-    lib.ptv_prof_enable(1)
+    lib.ptv_prof_enable(4 | 8)                             # tags 3, 4: the row-partitioned notes GRU, forward and BPTT
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i)
@@ -267,32 +310,7 @@ def main():
         import ctypes
         ms_per_step = dt / args.steps * 1e3
         value = world * B * args.steps / dt
-        # dominant kernel: the notes-GRU forward step (15 launches per train step, M = 32*B rows).  Its
-        # arithmetic intensity (25.8 GFLOP over ~238 MB at B=512) is below the MI355X balance point
-        # (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B), so the HBM roofline bounds it.
-        cnt = ctypes.c_long(0)
-        tot_ms = ctypes.c_double(0.0)
-        flop = ctypes.c_double(0.0)
-        lib.ptv_prof_read(ctypes.byref(cnt), ctypes.byref(tot_ms), ctypes.byref(flop))
-        roof = None
-        if cnt.value > 0:
-            M_, H_ = 32 * B, model.decoder.dec_notes_hid_size
-            b16 = args.precision == 'bf16' and H_ % 8 == 0                        # bf16 storage of MFMA-only tensors
-            asz = 2 if b16 else 4                                                 # gi / gi2 / saved gates
-            # algorithmic bytes per launch.  read: h_prev fp32 (blend) [+ its bf16 shadow as the MFMA operand],
-            # gi, gi2, W_hh, b_hh;  written: h fp32 [+ bf16 shadow] and the 4 saved gate planes
-            alg_bytes = (M_ * H_ * 4 + (M_ * H_ * 2 if b16 else 0) + 2 * M_ * 3 * H_ * asz + 3 * H_ * H_ * asz + 3 * H_ * 4
-                         + M_ * H_ * 4 + (M_ * H_ * 2 if b16 else 0) + 4 * M_ * H_ * asz)
-            avg_s = tot_ms.value / cnt.value * 1e-3
-            traffic = None
-            pmc = os.path.join(ROOT, 'profiles', 'r01_notes_gru_fwd_pmc.json')
-            if B == 512 and args.precision == 'bf16' and os.path.exists(pmc):
-                traffic = json.load(open(pmc))['hbm_bytes_per_launch']            # rocprofv3 PMC, see that file
-            roof = {'bound': 'hbm', 'kernel': 'gru_fwd_step_kernel (dec_notes_gru step, M=%d H=%d)' % (M_, H_),
-                    'achieved': round(alg_bytes / avg_s / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
-                    'frac': round(alg_bytes / avg_s / 1e9 / 8000.0, 4), 'traffic': traffic,
-                    'algorithmic_bytes': alg_bytes, 'launches': cnt.value, 'avg_us': round(avg_s * 1e6, 2),
-                    'mfma_tflops': round(flop.value / cnt.value / avg_s / 1e12, 1)}
+        roof = _roofline(lib, B, model, args) if args.mode == 'train' and args.tfr >= 1.0 else None
         if args.mode == 'decode':
             workload = 'configs[3]: free-running PtvaeDecoder sampling (inference_decode), batch=%d, 32x15x(1+5) step loop' % B
         elif args.tfr >= 1.0:

@@ -386,14 +386,16 @@ int ptv_clip_adam_step(float* p, const float* g, float* m, float* v, long n, con
                        float lr, float beta1, float beta2, float eps, int step, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Optional launch timing (bench.py roofline): HIP events recorded on the launch stream around every
- * launch of one kernel family -- tag 1 = GRU forward step, 2 = GRU backward step -- restricted to
- * launches with the given (M, H) (0 = any).  ptv_prof_read waits for the recorded events and returns
- * the number of launches, their summed duration and their summed algorithmic FLOPs (2*M*3H*H each).
+ * Optional launch timing (bench.py roofline): HIP events recorded on the launch stream around every launch of the enabled
+ * kernel families.  Tags: 1 = GRU forward step, 2 = GRU backward step (csrc/gru.hip), 3 = row-partitioned persistent GRU forward,
+ * 4 = its BPTT (csrc/notes_persist.hip; M = rows R).  ptv_prof_enable takes a bit mask (bit tag-1), ptv_prof_config restricts to
+ * launches with the given (M, H) (0 = any).  ptv_prof_read_tag waits for the recorded events and returns the number of launches of
+ * one tag (0 = all), their summed duration and their summed algorithmic MFMA FLOPs.
  */
-int ptv_prof_enable(int tag);
+int ptv_prof_enable(int mask);
 int ptv_prof_config(int M, int H);
 int ptv_prof_reset(void);
+int ptv_prof_read_tag(int tag, long* count, double* total_ms, double* flops);
 int ptv_prof_read(long* count, double* total_ms, double* flops);
 
 #ifdef __cplusplus

@@ -8,6 +8,7 @@
 #include <type_traits>
 #include "common.hpp"
 #include "gemm_core.hpp"
+#include "prof.hpp"
 #include "../../include/ptvae_hip.h"
 
 namespace ptv {
@@ -383,26 +384,31 @@ __global__ __launch_bounds__(NTHREADS) void gru_bwd_step_kernel(GemmArgs g, GruB
 // (bench.py's roofline: average duration of the dominant kernel over the timed region)
 // ---------------------------------------------------------------------------------------------
 namespace prof {
+// launch timing for bench.py's roofline block (declared in prof.hpp; csrc/notes_persist.hip records through the same table)
 constexpr int MAXEV = 8192;
-static int enabled = 0, filt_M = 0, filt_H = 0;
+static int enabled = 0, filt_M = 0, filt_H = 0;          // enabled: bit (tag-1) set = record launches of that family
 static hipEvent_t ev0[MAXEV], ev1[MAXEV];
-static int created = 0, used = 0;
-static double flops = 0.0;
-static inline bool want(int tag, int M, int H) {
-  return enabled == tag && (filt_M == 0 || filt_M == M) && (filt_H == 0 || filt_H == H) && used < MAXEV;
+static int slot_tag[MAXEV];
+static double slot_flops[MAXEV];
+static int created = 0, used = 0, cur_tag = 0;
+bool want(int tag, int M, int H) {
+  const bool ok = (enabled & (1 << (tag - 1))) && (filt_M == 0 || filt_M == M) && (filt_H == 0 || filt_H == H) && used < MAXEV;
+  if (ok) cur_tag = tag;
+  return ok;
 }
-static inline int begin(hipStream_t s) {
+int begin(hipStream_t s) {
   if (used >= created) {
     if (hipEventCreate(&ev0[created]) != hipSuccess || hipEventCreate(&ev1[created]) != hipSuccess) return -1;
     created++;
   }
   (void)hipEventRecord(ev0[used], s);
+  slot_tag[used] = cur_tag;
   return used;
 }
-static inline void end(int i, hipStream_t s, double fl) {
+void end(int i, hipStream_t s, double fl) {
   (void)hipEventRecord(ev1[i], s);
+  slot_flops[i] = fl;
   used = i + 1;
-  flops += fl;
 }
 }  // namespace prof
 
@@ -558,19 +564,22 @@ extern "C" int ptv_gru_step_fwd(int prec, int M, int H,
   return PTV_OK;
 }
 
-extern "C" int ptv_prof_enable(int tag) { ptv::prof::enabled = tag; return PTV_OK; }
+extern "C" int ptv_prof_enable(int mask) { ptv::prof::enabled = mask; return PTV_OK; }
 extern "C" int ptv_prof_config(int M, int H) { ptv::prof::filt_M = M; ptv::prof::filt_H = H; return PTV_OK; }
-extern "C" int ptv_prof_reset(void) { ptv::prof::used = 0; ptv::prof::flops = 0.0; return PTV_OK; }
-extern "C" int ptv_prof_read(long* count, double* total_ms, double* flops) {
-  double tot = 0.0;
+extern "C" int ptv_prof_reset(void) { ptv::prof::used = 0; return PTV_OK; }
+extern "C" int ptv_prof_read_tag(int tag, long* count, double* total_ms, double* flops) {
+  double tot = 0.0, fl = 0.0;
+  long n = 0;
   for (int i = 0; i < ptv::prof::used; i++) {
+    if (tag != 0 && ptv::prof::slot_tag[i] != tag) continue;
     float ms = 0.f;
     if (hipEventSynchronize(ptv::prof::ev1[i]) != hipSuccess) return PTV_ERR_LAUNCH;
     if (hipEventElapsedTime(&ms, ptv::prof::ev0[i], ptv::prof::ev1[i]) != hipSuccess) return PTV_ERR_LAUNCH;
-    tot += ms;
+    tot += ms; fl += ptv::prof::slot_flops[i]; n++;
   }
-  if (count) *count = ptv::prof::used;
+  if (count) *count = n;
   if (total_ms) *total_ms = tot;
-  if (flops) *flops = ptv::prof::flops;
+  if (flops) *flops = fl;
   return PTV_OK;
 }
+extern "C" int ptv_prof_read(long* count, double* total_ms, double* flops) { return ptv_prof_read_tag(0, count, total_ms, flops); }

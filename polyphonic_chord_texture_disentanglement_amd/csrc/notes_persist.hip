@@ -18,6 +18,7 @@
 // bf16 MFMA operands, fp32 state and accumulation (the bf16 precision policy); Hn = 512, E = 128 (init_model() geometry).
 #include "common.hpp"
 #include "gemm_core.hpp"
+#include "prof.hpp"
 #include "../../include/ptvae_hip.h"
 
 namespace ptv {
@@ -413,7 +414,9 @@ extern "C" int ptv_row_gru_persist_fwd(int H, const void* w_hh, const void* w_x,
   if (out && (out_ld & 3)) return PTV_ERR_ARG;
   RowGruFwdArgs a{(const bf16x8*)w_hh, (const bf16x8*)w_x, b_hh, b_ih, (const __bf16*)gc, x, x_step, lengths, HN, (__bf16*)HN16,
                   (__bf16*)gates, out, out_ld, (int)R, T & 0xff, reverse, T >> 8};
+  const int pi = prof::want(3, (int)R, H) ? prof::begin((hipStream_t)stream) : -1;
   PTV_TRY(H == 512 ? launch_fwd<512>(a, (hipStream_t)stream) : launch_fwd<128>(a, (hipStream_t)stream));
+  if (pi >= 0) prof::end(pi, (hipStream_t)stream, 2.0 * R * 3.0 * H * (H + NE) * (T & 0xff));
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
@@ -427,7 +430,9 @@ extern "C" int ptv_row_gru_persist_bwd(int H, const void* wt, const float* HN, c
   if (dh_last && (last_ld & 3)) return PTV_ERR_ARG;
   RowGruBwdArgs a{(const bf16x8*)wt, HN, (const __bf16*)gates, (const __bf16*)ext, dh_last, last_ld, (__bf16*)dgi, (__bf16*)dgh, dh0,
                   (__bf16*)scratch, (int)R, T, reverse};
+  const int pi = prof::want(4, (int)R, H) ? prof::begin((hipStream_t)stream) : -1;
   PTV_TRY(H == 512 ? launch_bwd<512>(a, (hipStream_t)stream) : launch_bwd<128>(a, (hipStream_t)stream));
+  if (pi >= 0) prof::end(pi, (hipStream_t)stream, 2.0 * R * 3.0 * H * H * (T - 1 + (dh0 ? 1 : 0)));
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

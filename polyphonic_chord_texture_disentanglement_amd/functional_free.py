@@ -13,6 +13,8 @@ buffer (whose gradient reaches `note_embedding` and, through the re-summarising 
 """
 import os
 
+import weakref
+
 import torch
 
 from . import functional as F_
@@ -339,19 +341,55 @@ class _CapturedCtx:
         pass
 
 
+class _GraphEntry:
+    """one captured free-running training forward + the buffers its backward reads.  `pending` is a weak reference to the
+    autograd ctx of the replay whose backward has not run yet: a second replay before that would overwrite NS / HN / gates /
+    PRED under it (two loss() calls and one backward, gradient accumulation over micro-batches, ...)"""
+
+    def __init__(self, g, sz, se, cap, outs):
+        self.g, self.sz, self.se, self.cap, self.outs = g, sz, se, cap, outs
+        self.pending = None
+
+    def busy(self):
+        c = self.pending() if self.pending is not None else None
+        return c is not None and not getattr(c, 'done', True)
+
+
+GRAPH_CACHE_SLOTS = 3          # e.g. train and validation batch sizes alternating: no re-capture (~9,000 launches + warm-up) per switch
+
+
+def _graph_key(z, emb, xs, prec, params):
+    return (z.shape[0], prec, z.device.index, tuple(p.data_ptr() for p in params), tuple(emb.shape), xs is not None,
+            F_.FUSED_DUR, F_.BF16_STORAGE, F_.NOTES_PERSIST, F_.PERSIST, FREE_PERSIST)
+
+
+def graphed_decoder_step(cache, z, emb, xs, prec, *params):
+    """GraphedDecoderStepFn when its captured buffers are free, the eager DecoderStepFn (same kernels, own buffers) while an
+    earlier replay of the same graph still waits for its backward"""
+    ent = cache.get(_graph_key(z, emb, xs, prec, params))
+    if ent is not None and ent.busy():
+        coins = ([[False] * 14] * 32, [False] * 31)
+        return DecoderStepFn.apply(z, emb, xs, coins, False, None, prec, *params)
+    return GraphedDecoderStepFn.apply(cache, z, emb, xs, prec, *params)
+
+
 class GraphedDecoderStepFn(torch.autograd.Function):
     """Free-running TRAINING forward (every teacher-forcing coin false: what the reference's schedules reach after two
-    steps) replayed from a captured hipGraph.  The step loop is ~9,000 small launches whose order and arguments depend
-    only on (B, precision, parameter storage): capture DecoderStepFn.forward once -- outputs and every buffer the backward
-    needs are the graph's static tensors -- then one graph launch per step; the backward is DecoderStepFn.backward on
-    those buffers.  `cache` is a dict owned by the decoder module."""
+    steps) replayed from a captured hipGraph.  The launch order and arguments of the step loop depend only on (B, precision,
+    parameter storage, the module-level kernel toggles): capture DecoderStepFn.forward once -- every buffer the backward needs
+    is the graph's static storage -- then one graph launch per step; the backward is DecoderStepFn.backward on those buffers.
+    The returned tensors are copies (they do not change under the caller at the next replay).  `cache` is a dict owned by the
+    decoder module, a small LRU.  Call through graphed_decoder_step(), which falls back to the eager path while a replay's
+    backward is pending."""
 
     @staticmethod
     def forward(ctx, cache, z, emb, xs, prec, *params):
-        B = z.shape[0]
-        key = (B, prec, z.device.index, tuple(p.data_ptr() for p in params), emb.shape, xs is not None)
+        key = _graph_key(z, emb, xs, prec, params)
         ent = cache.get(key)
         coins = ([[False] * 14] * 32, [False] * 31)
+        if ent is not None and ent.busy():
+            raise RuntimeError('GraphedDecoderStepFn: the previous replay of this graph has not been back-propagated yet; '
+                               'call graphed_decoder_step(), which runs such forwards eagerly')
         if ent is None:
             sz, se = z.detach().clone().contiguous(), emb.detach().clone()
             sx = xs.detach().clone() if xs is not None else None
@@ -365,20 +403,28 @@ class GraphedDecoderStepFn(torch.autograd.Function):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 outs = DecoderStepFn.forward(cap, sz, se, sx, coins, False, None, prec, *params)
-            cache.clear()
-            ent = cache[key] = (g, sz, se, cap, outs)
-        g, sz, se, cap, outs = ent
-        sz.copy_(z)
-        se[0].copy_(emb[0])                                   # only the <sos> slot of the ground truth is read when no coin is true
-        g.replay()
-        ctx.cap = cap
-        outs = tuple(o.detach() for o in outs)               # fresh tensor objects over the graph's static storage
+            while len(cache) >= GRAPH_CACHE_SLOTS:           # least recently used first (dicts keep insertion order)
+                victim = next((k for k, e in cache.items() if not e.busy()), None)
+                if victim is None:
+                    break
+                del cache[victim]
+            ent = cache[key] = _GraphEntry(g, sz, se, cap, outs)
+        else:
+            cache[key] = cache.pop(key)                      # most recently used last
+        ent.sz.copy_(z)
+        ent.se[0].copy_(emb[0])                               # only the <sos> slot of the ground truth is read when no coin is true
+        ent.g.replay()
+        ctx.cap = ent.cap
+        ctx.done = not any(ctx.needs_input_grad)
+        ent.pending = weakref.ref(ctx)
+        outs = tuple(o.clone() for o in ent.outs)
         ctx.mark_non_differentiable(outs[2], outs[3])
         return outs
 
     @staticmethod
     def backward(ctx, dpitch, ddur, _dx, _di):
         r = DecoderStepFn.backward(ctx.cap, dpitch, ddur, None, None)
+        ctx.done = True
         # DecoderStepFn inputs: (z, emb, xs, coins, inference, force, prec, *params) -> ours: (cache, z, emb, xs, prec, *params)
         return (None, r[0], r[1], r[2], None) + tuple(r[7:])
 

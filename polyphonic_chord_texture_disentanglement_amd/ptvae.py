@@ -339,8 +339,7 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
             none_tf = not any(any(r) for r in coins[0]) and not any(coins[1])
             if self.use_graph and none_tf and self.force_trace is None and torch.is_grad_enabled():
                 # free-running training step: forward replayed from a captured hipGraph
-                pitch, dur, xhat, idx = FF_.GraphedDecoderStepFn.apply(self._train_graphs, z, emb, xs, self._prec,
-                                                                       *self._params_free())
+                pitch, dur, xhat, idx = FF_.graphed_decoder_step(self._train_graphs, z, emb, xs, self._prec, *self._params_free())
             else:
                 pitch, dur, xhat, idx = FF_.DecoderStepFn.apply(z, emb, xs, coins, False, self.force_trace, self._prec,
                                                                 *self._params_free())

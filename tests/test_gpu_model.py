@@ -339,6 +339,44 @@ def test_fused_duration_gru_in_the_step_loop(monkeypatch):
     assert (res[True][2] - res[False][2]).abs().max() < 0.1 * res[False][2].abs().max()
 
 
+def test_graphed_training_forward_twice_before_backward_keeps_the_first_graph_intact():
+    """a second forward while the first replay's backward is still pending must not overwrite the captured buffers: it runs
+    eagerly (graphed_decoder_step), and the first backward gives the gradients of the first batch; returned outputs are copies"""
+    m = M.DisentangleVAE.init_model(torch.device(DEV))
+    m.load_state_dict(full_params())
+    m.to(DEV).set_precision('bf16')
+    g = load_npz('full_tf0_b4.npz')
+    batches = [tuple(torch.from_numpy(a).to(DEV) for a in synth_batch(int(g['B']), int(g['data_seed']) + i)) for i in range(2)]
+
+    def fwd(b):
+        m.eps_source = _eps_source(g)
+        outs = m.run(*b, 0., 0., 0.)
+        return outs, m.loss_function(b[0], b[1], *outs, 0.1, [1, 0.5])[0]
+
+    m.decoder.use_graph = False
+    m.zero_grad()
+    fwd(batches[0])[1].backward()
+    want = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    m.decoder.use_graph = True
+    m.zero_grad()
+    fwd(batches[0])[1].backward()                               # capture + first replay, backward done
+    m.zero_grad()
+    outs_a, loss_a = fwd(batches[0])                            # replay, backward pending
+    pitch_a = outs_a[0].clone()
+    ent = next(iter(m.decoder._train_graphs.values()))
+    assert ent.busy()
+    outs_b, loss_b = fwd(batches[1])                            # must not touch the captured buffers
+    assert torch.equal(outs_a[0], pitch_a)
+    loss_a.backward()
+    assert not ent.busy()
+    torch.cuda.synchronize()
+    m.decoder.use_graph = False
+    for n, w in want.items():
+        got = dict(m.named_parameters())[n].grad
+        assert (got - w).abs().max() <= 0.05 * w.abs().max() + 1e-6, n
+    del outs_b, loss_b
+
+
 def test_graph_captured_free_running_training_step_equals_eager():
     """tfr = 0 training step with the decoder forward replayed from a captured hipGraph (use_graph) vs the eager step loop:
     same losses and gradients, on the capture call and on a replay with different data"""
