@@ -386,6 +386,16 @@ int ptv_clip_adam_step(float* p, const float* g, float* m, float* v, long n, con
                        float lr, float beta1, float beta2, float eps, int step, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Weight-gradient product (csrc/wgrad.hip): C[M,N] (fp32, row stride ldc) (+)= alpha * sum_k A[k*lda + m] * B[k*ldb + n], i.e.
+ * grad_W = grad_out^T . input as autograd forms it for every nn.Linear / nn.GRU weight (ptvae.py:16-17,23,64,116,360,396,450,461),
+ * with both operands stored row-per-sample.  bf16 MFMA, fp32 accumulate; dtypes bit 0 / 1 = A / B already bf16 in HBM (fp32
+ * otherwise, rounded to bf16 on the way in).  K is cut into slabs that reduce into C with fp32 atomics; slabs = 0 picks the count.
+ * ptv_gemm(prec = bf16, transA = transB = 1) routes here.
+ */
+int ptv_wgrad(int M, int N, int K, const void* A, long lda, const void* B, long ldb, float* C, long ldc, float alpha,
+              int accumulate, int dtypes, int slabs, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optional launch timing (bench.py roofline): HIP events recorded on the launch stream around every launch of the enabled
  * kernel families.  Tags: 1 = GRU forward step, 2 = GRU backward step (csrc/gru.hip), 3 = row-partitioned persistent GRU forward,
  * 4 = its BPTT (csrc/notes_persist.hip; M = rows R).  ptv_prof_enable takes a bit mask (bit tag-1), ptv_prof_config restricts to

@@ -1,5 +1,6 @@
 // gemm.hip -- plain dense products on the MFMA core: Linear forward (NT), dX (NN), dW (TN, split-K).
 // C-ABI entry: ptv_gemm (include/ptvae_hip.h).
+#include <stdlib.h>
 #include <type_traits>
 #include "common.hpp"
 #include "gemm_core.hpp"
@@ -216,6 +217,10 @@ extern "C" int ptv_gemm(int prec, int transA, int transB, int M, int N, int K,
   const bool sa = dtypes & 1, sb = dtypes & 2, sc = dtypes & 4;
   if ((sa || sb) && prec != PTV_PREC_BF16) return PTV_ERR_ARG;       // bf16 operands feed the bf16 MFMA path only
   if (sc && splitk > 1) return PTV_ERR_ARG;                          // split-K accumulates with fp32 atomics
+  // weight gradients (both operands row-per-sample): the transposing-LDS-read kernel of wgrad.hip
+  static const bool use_wgrad = [] { const char* e = getenv("PTV_WGRAD"); return !(e && e[0] == '0'); }();
+  if (use_wgrad && prec == PTV_PREC_BF16 && transA && transB && !sc && !bias && act == 0 && K >= 512 && splitk <= 0)
+    return ptv_wgrad(M, N, K, A, lda, B, ldb, reinterpret_cast<float*>(C), ldc, alpha, accumulate, dtypes & 3, 0, stream);
   ptv::GemmArgs g{A, lda, B, ldb, M, N, K, K, 0};
   ptv::EpiPlain::Params ep{C, ldc, bias, alpha, accumulate, act, 0, sc ? 1 : 0};
   hipStream_t s = (hipStream_t)stream;

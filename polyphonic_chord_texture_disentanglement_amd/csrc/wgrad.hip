@@ -1,0 +1,308 @@
+// wgrad.hip -- weight-gradient products dW[M,N] += alpha * A^T B on the MFMA core, A [K,M] and B [K,N] both K-major (rows = the
+// 32*B*T samples of the batch, thousands to hundreds of thousands of them; M, N = a layer's output / input widths).
+//
+// These are what autograd computes for every nn.Linear / nn.GRU weight of the reference (ptvae.py:16-17,23,64,116,360,396,450,
+// 461): grad_W = grad_out^T . input.  Both operands arrive row-per-sample, i.e. k-strided for an MFMA fragment.  The generic
+// GEMM (gemm_core.hpp) transposes them in registers on the way into LDS (eight 8-byte LDS stores per thread per tile); here the
+// tile goes into LDS exactly as it lies in HBM ([k][columns], 16-byte copies) and the fragments come out through gfx950's
+// transposing LDS read (ds_read_b64_tr_b16: a 16-lane group reads a [4 k][16 columns] block, lane i receives column i).
+//
+//   block  = 128 x 128 outputs, 4 waves as 2 x 2 (64 x 64 each: 4 x 4 accumulator fragments), one slab of K
+//   stage  = 32 rows of A and of B (2 x 9 KB with the row padding); two LDS buffers, two register sets of prefetch
+//   k order inside a 32-row stage: lane group g takes rows 4g..4g+3 and 16+4g..16+4g+3 (the same permutation for both operands,
+//           so the product is unchanged) -- the four groups of a wave then read 16 consecutive rows: conflict-free at the
+//           288-byte row stride
+//   slabs  reduce into C with fp32 atomics (every caller accumulates into a gradient buffer), blocks of one XCD share panels
+//           through that XCD's L2 (tile ranges or whole slabs per XCD)
+//
+// fp32 sources are rounded to bf16 on the way into LDS (the bf16 precision mode's MFMA operands, as in gemm_core.hpp).
+// Entry: ptv_wgrad (include/ptvae_hip.h); ptv_gemm routes its bf16 transA && transB calls here.
+#include <stdlib.h>
+#include "common.hpp"
+#include "../../include/ptvae_hip.h"
+
+namespace ptv {
+
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef short ws16x4 __attribute__((ext_vector_type(4)));
+typedef short ws16x8 __attribute__((ext_vector_type(8)));
+typedef float wf32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) ws16x4 lds_s16x4;
+
+constexpr int WBM = 128, WBN = 128, WBK = 32, WLD = 144;       // tile, stage depth, LDS row stride in bf16 (288 B)
+constexpr int WSTAGE = WBK * WLD;                              // elements of one operand's stage
+
+struct WgArgs {
+  const void* A; long lda;
+  const void* B; long ldb;
+  float* C; long ldc;
+  int M, N, K, kper;             // kper: rows of K per slab (multiple of 32)
+  int tiles_m, tiles_n, nslab;
+  int map;                       // 0: slab = b / tiles; 1: whole slabs per XCD; 2: tile ranges per XCD
+  float alpha;
+};
+
+// one thread's share of a stage of one operand: 2 chunks of 8 columns (chunk c: row c / 16, columns (c % 16) * 8).
+// Columns at or beyond ncols only ever meet outputs that are not stored, so a chunk that straddles ncols may be read whole as long as
+// the bytes exist (every row but the matrix's last: the overread lands in the next row); the element-wise path serves that last
+// row and operands whose rows are not 16-byte aligned.
+template <bool F32SRC> struct WSrc { using T = __bf16; };
+template <> struct WSrc<true> { using T = float; };
+
+template <bool F32SRC>
+__device__ __attribute__((noinline)) wbf16x8 wload_slow(const void* p, long off, int nvalid) {
+  const typename WSrc<F32SRC>::T* q = reinterpret_cast<const typename WSrc<F32SRC>::T*>(p) + off;
+  wbf16x8 x;
+#pragma unroll
+  for (int e = 0; e < 8; e++) x[e] = e < nvalid ? (__bf16)q[e] : (__bf16)0.f;
+  return x;
+}
+
+template <bool F32SRC> struct WStage;
+template <> struct WStage<false> {
+  wbf16x8 v[2];
+  // no guards and no select on the loaded data (which would pin the wait for it right behind the load): 16-byte aligned rows,
+  // every row of the stage in range; a chunk at or beyond ncols reads column 0's bytes instead -- whatever it holds only meets
+  // outputs that are never stored
+  __device__ __forceinline__ void load_fast(const __bf16* p, long ld) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      v[i] = *reinterpret_cast<const wbf16x8*>(p + (long)(i * 16) * ld);
+    }
+  }
+  __device__ __forceinline__ void load(const void* p, long ld, int k0, int kend, int klast, int col, int ncols, bool vec) {
+    const __bf16* s = reinterpret_cast<const __bf16*>(p);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int k = k0 + (threadIdx.x >> 4) + i * 16;
+      wbf16x8 x;
+#pragma unroll
+      for (int e = 0; e < 8; e++) x[e] = (__bf16)0.f;
+      if (k < kend && col < ncols) {
+        if (vec && (col + 8 <= ncols || k < klast)) x = *reinterpret_cast<const wbf16x8*>(s + (long)k * ld + col);
+        else x = wload_slow<false>(p, (long)k * ld + col, ncols - col);
+      }
+      v[i] = x;
+    }
+  }
+  __device__ __forceinline__ void store(__bf16* st) const {
+#pragma unroll
+    for (int i = 0; i < 2; i++) *reinterpret_cast<wbf16x8*>(st + ((threadIdx.x >> 4) + i * 16) * WLD + (threadIdx.x & 15) * 8) = v[i];
+  }
+};
+template <> struct WStage<true> {
+  wf32x4 v[2][2];
+  __device__ __forceinline__ void load_fast(const float* p, long ld) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const float* q = p + (long)(i * 16) * ld;
+      v[i][0] = *reinterpret_cast<const wf32x4*>(q); v[i][1] = *reinterpret_cast<const wf32x4*>(q + 4);
+    }
+  }
+  __device__ __forceinline__ void load(const void* p, long ld, int k0, int kend, int klast, int col, int ncols, bool vec) {
+    const float* s = reinterpret_cast<const float*>(p);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int k = k0 + (threadIdx.x >> 4) + i * 16;
+      wf32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+      if (k < kend && col < ncols) {
+        if (vec && (col + 8 <= ncols || k < klast)) {
+          const float* q = s + (long)k * ld + col;
+          lo = *reinterpret_cast<const wf32x4*>(q);
+          hi = *reinterpret_cast<const wf32x4*>(q + 4);
+        } else {
+          const wbf16x8 x = wload_slow<true>(p, (long)k * ld + col, ncols - col);
+#pragma unroll
+          for (int e = 0; e < 4; e++) { lo[e] = (float)x[e]; hi[e] = (float)x[4 + e]; }
+        }
+      }
+      v[i][0] = lo; v[i][1] = hi;
+    }
+  }
+  __device__ __forceinline__ void store(__bf16* st) const {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      wbf16x8 x;
+#pragma unroll
+      for (int e = 0; e < 4; e++) { x[e] = (__bf16)v[i][0][e]; x[4 + e] = (__bf16)v[i][1][e]; }
+      *reinterpret_cast<wbf16x8*>(st + ((threadIdx.x >> 4) + i * 16) * WLD + (threadIdx.x & 15) * 8) = x;
+    }
+  }
+};
+
+// MFMA operand of 16 columns starting at `col`: lane (i = lane & 15, g = lane >> 4) receives rows 4g..4g+3 and 16+4g..16+4g+3 of
+// column col + i.  Supplier lane s of a 16-lane group hands in the address of row s >> 2, columns 4 (s & 3) .. +3 of the block.
+__device__ __forceinline__ wbf16x8 tr_frag(const __bf16* st, int col) {
+  const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
+  const __bf16* p = st + (g * 4 + (s >> 2)) * WLD + col + (s & 3) * 4;
+  const ws16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const ws16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * WLD));
+  const ws16x8 w = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(wbf16x8, w);
+}
+
+// GUARD = false: rows 16-byte aligned, K a multiple of 32 and not reaching the operands' last row (see ptv_wgrad)
+template <bool AF32, bool BF32, bool GUARD, int NSET>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
+  __shared__ __attribute__((aligned(16))) __bf16 As[2 * WSTAGE];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2 * WSTAGE];
+  const int tiles = g.tiles_m * g.tiles_n;
+  int b = blockIdx.x, slab, tile;
+  if (g.map == 1) { const int q = b >> 3; slab = (q / tiles) * 8 + (b & 7); tile = q % tiles; }
+  else if (g.map == 2) { const int tx = tiles >> 3, q = b >> 3; tile = (b & 7) * tx + q % tx; slab = q / tx; }
+  else { slab = b / tiles; tile = b % tiles; }
+  const int k_begin = slab * g.kper;
+  if (k_begin >= g.K) return;
+  const int k_end = min(g.K, k_begin + g.kper);
+  const int m_blk = (tile / g.tiles_n) * WBM, n_blk = (tile % g.tiles_n) * WBN;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const bool veca = (g.lda % (AF32 ? 4 : 8) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+  const bool vecb = (g.ldb % (BF32 ? 4 : 8) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+
+  wf32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = wf32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nst = (k_end - k_begin + WBK - 1) / WBK;
+  // NSET register sets of prefetch: stage t lives in set t % NSET until iteration t-1 moves it into LDS buffer t & 1; its loads
+  // were issued NSET iterations before that.  bf16 sources cost 4 VGPRs per chunk, fp32 sources 8.
+  WStage<AF32> ra[NSET];
+  WStage<BF32> rb[NSET];
+  const int cola = m_blk + (threadIdx.x & 15) * 8, colb = n_blk + (threadIdx.x & 15) * 8;
+  const bool coka = cola < g.M, cokb = colb < g.N;
+  const typename WSrc<AF32>::T* pa = reinterpret_cast<const typename WSrc<AF32>::T*>(g.A) + (long)(k_begin + (threadIdx.x >> 4)) * g.lda + (coka ? cola : 0);
+  const typename WSrc<BF32>::T* pb = reinterpret_cast<const typename WSrc<BF32>::T*>(g.B) + (long)(k_begin + (threadIdx.x >> 4)) * g.ldb + (cokb ? colb : 0);
+#define WG_FETCH(set, t)                                                                            \
+  do {                                                                                              \
+    if constexpr (GUARD) {                                                                          \
+      ra[set].load(g.A, g.lda, k_begin + (t) * WBK, k_end, g.K - 1, cola, g.M, veca);               \
+      rb[set].load(g.B, g.ldb, k_begin + (t) * WBK, k_end, g.K - 1, colb, g.N, vecb);               \
+    } else {                                                                                        \
+      ra[set].load_fast(pa + (long)(t) * WBK * g.lda, g.lda);                                       \
+      rb[set].load_fast(pb + (long)(t) * WBK * g.ldb, g.ldb);                                       \
+    }                                                                                               \
+  } while (0)
+  // every fetch is unconditional (the stage index is clamped to the slab's last stage; a redundant stage is never consumed): no
+  // control flow between a load and the LDS store that consumes it, so the compiler's s_waitcnt vmcnt() are exact counts instead of
+  // the vmcnt(0) it falls back to across branches -- which would serialise the whole prefetch
+  const int last = nst - 1;
+#pragma unroll
+  for (int u = 0; u < NSET; u++) WG_FETCH(u, min(u, last));
+  ra[0].store(As); rb[0].store(Bs);
+  WG_FETCH(0, min(NSET, last));
+  __syncthreads();
+#define WG_BODY(u, t)                                                                                   \
+  do {                                                                                                  \
+    const __bf16* as = As + ((u) & 1) * WSTAGE;                                                         \
+    const __bf16* bs = Bs + ((u) & 1) * WSTAGE;                                                         \
+    wbf16x8 fa[4], fb[4];                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 4; i++) fa[i] = tr_frag(as, wm + i * 16);                     \
+    _Pragma("unroll") for (int j = 0; j < 4; j++) fb[j] = tr_frag(bs, wn + j * 16);                     \
+    /* the other buffer was last read before the barrier that ended the previous stage */              \
+    constexpr int nu = ((u) + 1) % NSET;                                                                \
+    ra[nu].store(As + (((u) + 1) & 1) * WSTAGE); rb[nu].store(Bs + (((u) + 1) & 1) * WSTAGE);           \
+    WG_FETCH(nu, min((t) + 1 + NSET, last));                                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; i++)                                                       \
+      _Pragma("unroll") for (int j = 0; j < 4; j++)                                                     \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);          \
+    __syncthreads();                                                                                    \
+  } while (0)
+  int t0 = 0;
+  for (; t0 + NSET <= nst; t0 += NSET) {
+    WG_BODY(0, t0);
+    WG_BODY(1, t0 + 1);
+    if constexpr (NSET == 4) { WG_BODY(2, t0 + 2); WG_BODY(3, t0 + 3); }
+  }
+  if (t0 < nst) {
+    WG_BODY(0, t0);
+    if constexpr (NSET == 4) {
+      if (t0 + 1 < nst) { WG_BODY(1, t0 + 1); if (t0 + 2 < nst) WG_BODY(2, t0 + 2); }
+    }
+  }
+#undef WG_BODY
+#undef WG_FETCH
+  // acc[i][j]: lane holds C[m = wm + 16 i + 4 (lane >> 4) + r][n = wn + 16 j + (lane & 15)], r = 0..3: one atomic instruction of the
+  // wave covers 4 rows x 16 consecutive columns (4 cache lines; the other operand order would touch 16)
+  const bool single = g.nslab == 1;
+  const bool inner = m_blk + WBM <= g.M && n_blk + WBN <= g.N;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int n = n_blk + wn + j * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int m = m_blk + wm + i * 16 + (lane >> 4) * 4 + r;
+        if (!inner && (m >= g.M || n >= g.N)) continue;
+        float* cp = g.C + (long)m * g.ldc + n;
+        if (single) *cp += g.alpha * acc[i][j][r];              // the only writer of this element: plain read-modify-write
+        else atomicAdd(cp, g.alpha * acc[i][j][r]);
+      }
+    }
+  }
+}
+
+__global__ void wgrad_zero_kernel(float* C, long ldc, int M, int N) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)M * N;
+  for (; i < total; i += (long)gridDim.x * blockDim.x) C[(i / N) * ldc + (i % N)] = 0.f;
+}
+
+}  // namespace ptv
+
+using namespace ptv;
+
+extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const void* B, long ldb, float* C, long ldc, float alpha,
+                         int accumulate, int dtypes, int slabs, void* stream) {
+  if (M < 0 || N < 0 || K < 0 || !A || !B || !C) return PTV_ERR_ARG;
+  if (M == 0 || N == 0) return PTV_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) {
+    const long total = (long)M * N;
+    int nb = (int)((total + 255) / 256); if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(wgrad_zero_kernel, dim3(nb), dim3(256), 0, s, C, ldc, M, N);
+  }
+  if (K == 0) { PTV_CHECK_LAUNCH(); return PTV_OK; }
+  const bool af = !(dtypes & 1), bf = !(dtypes & 2);
+  const bool vec = (lda % (af ? 4 : 8) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                   (ldb % (bf ? 4 : 8) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  // the unguarded kernel reads whole 8-column chunks: where a chunk straddles M or N it spills into the next row, so it stops
+  // short of the operands' last row; the guarded kernel takes the remaining <= 32 rows (and everything when rows are unaligned)
+  const bool odd = (M % 8) || (N % 8);
+  const int kfast = !vec ? 0 : (odd ? ((K - 1) / WBK) * WBK : (K / WBK) * WBK);
+  static const int nset_env = [] { const char* e = getenv("PTV_WGRAD_NSET"); return e ? atoi(e) : 0; }();
+  const int nset = (af || bf) ? 2 : (nset_env == 4 ? 4 : 2);       // 4 register sets only fit with bf16 sources
+  auto launch = [&](bool guard, int k0, int kn, int want_slabs) {
+    WgArgs g{static_cast<const char*>(A) + (long)k0 * lda * (af ? 4 : 2), lda, static_cast<const char*>(B) + (long)k0 * ldb * (bf ? 4 : 2), ldb,
+             C, ldc, M, N, kn, 0, cdiv(M, WBM), cdiv(N, WBN), 1, 0, alpha};
+    const int tiles = g.tiles_m * g.tiles_n;
+    // enough blocks for two per CU; a slab is at least 4 stages deep
+    int ns = want_slabs > 0 ? want_slabs : (640 + tiles - 1) / tiles;
+    const int maxs = kn / (4 * WBK) > 0 ? kn / (4 * WBK) : 1;
+    if (ns > maxs) ns = maxs;
+    if (tiles % 8 == 0) g.map = 2;
+    else if (ns >= 8) { ns = (ns + 7) / 8 * 8; g.map = 1; }
+    g.kper = cdiv(cdiv(kn, ns), WBK) * WBK;
+    if (g.map != 1) ns = cdiv(kn, g.kper);
+    g.nslab = ns;
+    const dim3 grid((unsigned)(tiles * ns));
+#define WG_LAUNCH(AF, BF)                                                                                      \
+    do {                                                                                                       \
+      if (guard) hipLaunchKernelGGL((wgrad_kernel<AF, BF, true, 2>), grid, dim3(256), 0, s, g);                \
+      else if (nset == 2) hipLaunchKernelGGL((wgrad_kernel<AF, BF, false, 2>), grid, dim3(256), 0, s, g);      \
+      else if constexpr (!(AF) && !(BF)) hipLaunchKernelGGL((wgrad_kernel<false, false, false, 4>), grid, dim3(256), 0, s, g); \
+    } while (0)
+    if (af && bf) WG_LAUNCH(true, true);
+    else if (af) WG_LAUNCH(true, false);
+    else if (bf) WG_LAUNCH(false, true);
+    else WG_LAUNCH(false, false);
+#undef WG_LAUNCH
+  };
+  if (kfast > 0) launch(false, 0, kfast, slabs);
+  if (kfast < K) launch(true, kfast, K - kfast, kfast > 0 ? 1 : slabs);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
