@@ -279,12 +279,23 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
     WgArgs g{static_cast<const char*>(A) + (long)k0 * lda * (af ? 4 : 2), lda, static_cast<const char*>(B) + (long)k0 * ldb * (bf ? 4 : 2), ldb,
              C, ldc, M, N, kn, 0, cdiv(M, WBM), cdiv(N, WBN), 1, 0, alpha};
     const int tiles = g.tiles_m * g.tiles_n;
-    // enough blocks for two per CU; a slab is at least 4 stages deep
-    int ns = want_slabs > 0 ? want_slabs : (640 + tiles - 1) / tiles;
+    // slab count (measured optima of scripts/bench_wgrad.py sweep on MI355X).  Every slab pays M*N atomics, and a grid that is
+    // just over one block per CU leaves a tail, so: about one block per CU (never more) for the skinny, HBM-bound products;
+    // about three per CU for the MFMA-heavy ones (many tiles), where co-resident blocks hide each other's stalls; a slab is at least
+    // 32 (short K) or 64 stages deep
+    int ns = want_slabs;
+    if (ns <= 0) {
+      const bool shortk = kn <= 8192;
+      ns = shortk ? (256 + tiles - 1) / tiles : (tiles >= 32 ? 768 : 256) / tiles;
+      const int deep = shortk ? (kn >= 2048 ? kn / 1024 : kn / 256) : kn / 2048;
+      if (ns > deep) ns = deep;
+      if (ns >= 8) ns = ns / 8 * 8;
+      if (ns < 1) ns = 1;
+    }
     const int maxs = kn / (4 * WBK) > 0 ? kn / (4 * WBK) : 1;
     if (ns > maxs) ns = maxs;
     if (tiles % 8 == 0) g.map = 2;
-    else if (ns >= 8) { ns = (ns + 7) / 8 * 8; g.map = 1; }
+    else if (ns >= 8 && ns % 8 == 0) g.map = 1;
     g.kper = cdiv(cdiv(kn, ns), WBK) * WBK;
     if (g.map != 1) ns = cdiv(kn, g.kper);
     g.nslab = ns;
