@@ -390,10 +390,12 @@ int ptv_clip_adam_step(float* p, const float* g, float* m, float* v, long n, con
  * grad_W = grad_out^T . input as autograd forms it for every nn.Linear / nn.GRU weight (ptvae.py:16-17,23,64,116,360,396,450,461),
  * with both operands stored row-per-sample.  bf16 MFMA, fp32 accumulate; dtypes bit 0 / 1 = A / B already bf16 in HBM (fp32
  * otherwise, rounded to bf16 on the way in).  K is cut into slabs that reduce into C with fp32 atomics; slabs = 0 picks the count.
+ * colsum_a (or NULL): fp32 [M] += sum_k A[k*lda + m], the bias gradient that belongs to the same layer (grad_b = column sums of
+ * grad_out), taken from the A tiles while they are in LDS instead of a second pass over A (always accumulates).
  * ptv_gemm(prec = bf16, transA = transB = 1) routes here.
  */
 int ptv_wgrad(int M, int N, int K, const void* A, long lda, const void* B, long ldb, float* C, long ldc, float alpha,
-              int accumulate, int dtypes, int slabs, void* stream);
+              int accumulate, int dtypes, int slabs, float* colsum_a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optional launch timing (bench.py roofline): HIP events recorded on the launch stream around every launch of the enabled

@@ -40,6 +40,7 @@ struct WgArgs {
   int tiles_m, tiles_n, nslab;
   int map;                       // 0: slab = b / tiles; 1: whole slabs per XCD; 2: tile ranges per XCD
   float alpha;
+  float* csum;                   // [M] += column sums of A (the bias gradient that goes with this weight gradient), or null
 };
 
 // one thread's share of a stage of one operand: 2 chunks of 8 columns (chunk c: row c / 16, columns (c % 16) * 8).
@@ -166,6 +167,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = wf32x4{0.f, 0.f, 0.f, 0.f};
 
+  // bias gradient: sum_k A[k][m] = A^T . 1 -- four more MFMAs per stage against a fragment of ones, in the waves that own the first
+  // 64 columns of the first column tile; the A tile is already in LDS, a separate column-sum kernel would read A from HBM again
+  const bool do_sum = g.csum != nullptr && n_blk == 0 && wn == 0;
+  wf32x4 accs[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) accs[i] = wf32x4{0.f, 0.f, 0.f, 0.f};
+  wbf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; e++) ones[e] = (__bf16)1.0f;
   const int nst = (k_end - k_begin + WBK - 1) / WBK;
   // NSET register sets of prefetch: stage t lives in set t % NSET until iteration t-1 moves it into LDS buffer t & 1; its loads
   // were issued NSET iterations before that.  bf16 sources cost 4 VGPRs per chunk, fp32 sources 8.
@@ -208,6 +218,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
     _Pragma("unroll") for (int i = 0; i < 4; i++)                                                       \
       _Pragma("unroll") for (int j = 0; j < 4; j++)                                                     \
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);          \
+    if (do_sum) {                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < 4; i++)                                                     \
+        accs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accs[i], 0, 0, 0);               \
+    }                                                                                                   \
     __syncthreads();                                                                                    \
   } while (0)
   int t0 = 0;
@@ -226,6 +240,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
 #undef WG_FETCH
   // acc[i][j]: lane holds C[m = wm + 16 i + 4 (lane >> 4) + r][n = wn + 16 j + (lane & 15)], r = 0..3: one atomic instruction of the
   // wave covers 4 rows x 16 consecutive columns (4 cache lines; the other operand order would touch 16)
+  if (do_sum && (lane & 15) == 0) {                              // every column of accs holds the same sums
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int m = m_blk + wm + i * 16 + (lane >> 4) * 4 + r;
+        if (m < g.M) atomicAdd(g.csum + m, accs[i][r]);
+      }
+  }
   const bool single = g.nslab == 1;
   const bool inner = m_blk + WBM <= g.M && n_blk + WBN <= g.N;
 #pragma unroll
@@ -256,7 +279,7 @@ __global__ void wgrad_zero_kernel(float* C, long ldc, int M, int N) {
 using namespace ptv;
 
 extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const void* B, long ldb, float* C, long ldc, float alpha,
-                         int accumulate, int dtypes, int slabs, void* stream) {
+                         int accumulate, int dtypes, int slabs, float* colsum_a, void* stream) {
   if (M < 0 || N < 0 || K < 0 || !A || !B || !C) return PTV_ERR_ARG;
   if (M == 0 || N == 0) return PTV_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -277,7 +300,7 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
   const int nset = (af || bf) ? 2 : (nset_env == 4 ? 4 : 2);       // 4 register sets only fit with bf16 sources
   auto launch = [&](bool guard, int k0, int kn, int want_slabs) {
     WgArgs g{static_cast<const char*>(A) + (long)k0 * lda * (af ? 4 : 2), lda, static_cast<const char*>(B) + (long)k0 * ldb * (bf ? 4 : 2), ldb,
-             C, ldc, M, N, kn, 0, cdiv(M, WBM), cdiv(N, WBN), 1, 0, alpha};
+             C, ldc, M, N, kn, 0, cdiv(M, WBM), cdiv(N, WBN), 1, 0, alpha, colsum_a};
     const int tiles = g.tiles_m * g.tiles_n;
     // slab count (measured optima of scripts/bench_wgrad.py sweep on MI355X).  Every slab pays M*N atomics, and a grid that is
     // just over one block per CU leaves a tail, so: about one block per CU (never more) for the skinny, HBM-bound products;

@@ -9,6 +9,7 @@ Reference call sites are cited per function (paths are into /root/reference).
 """
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -395,6 +396,23 @@ def _bgrad_hh(b_hh, dgh2, gb_ih):
     return g
 
 
+WGRAD_FUSE_BIAS = os.environ.get('PTV_WGRAD_BIAS', '1') != '0'
+
+
+def wgrad_bias(dy, x, gw, gb, prec):
+    """gw [N_out, N_in] += dy^T . x and gb [N_out] += column sums of dy: a layer's weight and bias gradient in one pass over
+    dy (ptv_wgrad's colsum_a) where the weight-gradient kernel applies; otherwise the product and a column-sum kernel"""
+    K = dy.shape[0]
+    if (WGRAD_FUSE_BIAS and prec == 1 and K >= 512 and gw.dtype == F32 and dy.stride(1) == 1 and x.stride(1) == 1
+            and os.environ.get('PTV_WGRAD', '1') != '0'):
+        call('ptv_wgrad', dy.shape[1], x.shape[1], K, ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(gw), _ld(gw), 1.0, 1,
+             _bf(dy) | (_bf(x) << 1), 0, ptr(gb), stream_ptr())
+    else:
+        gemm(dy, x, gw, ta=True, tb=True, acc=True, prec=prec)
+        colsum(gb.view(1, -1), dy)
+    return gw, gb
+
+
 def dur_bwd_fusable(prec, Hd, gates_d):
     return prec == 1 and Hd == 64 and FUSED_DUR and gates_d.dtype == BF16
 
@@ -454,8 +472,10 @@ class LinearFn(torch.autograd.Function):
         prec = ctx.prec
         dy = dy.contiguous()
         dx = gemm_dx(dy, w, prec=prec) if ctx.needs_input_grad[0] else None
-        dw = gemm(dy, x2, _gbuf(w), ta=True, tb=True, acc=True, prec=prec)
-        db = _bgrad(b, dy) if b is not None else None
+        if b is not None:
+            dw, db = wgrad_bias(dy, x2, _gbuf(w), _gbuf(b), prec)
+        else:
+            dw, db = gemm(dy, x2, _gbuf(w), ta=True, tb=True, acc=True, prec=prec), None
         return dx, dw, db, None
 
 
@@ -585,11 +605,8 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
         dgi, dgh, _ = gru_bwd(prec, hall, gates, w_hh, dh_last=dout[:, d * H:(d + 1) * H], reverse=bool(d),
                               need_dh0=False)
         dgi2, dgh2 = dgi.view(T * M, 3 * H), dgh.view(T * M, 3 * H)
-        dw_ih = gemm(dgi2, xf, _gbuf(w_ih), ta=True, tb=True, acc=True, prec=prec)
-        dw_hh = gemm(dgh2, (h16 if h16 is not None else hall)[:T].view(T * M, H), _gbuf(w_hh), ta=True, tb=True, acc=True,
-                     prec=prec)
-        db_ih = _bgrad(b_ih, dgi2)
-        db_hh = _bgrad_hh(b_hh, dgh2, db_ih)
+        dw_ih, db_ih = wgrad_bias(dgi2, xf, _gbuf(w_ih), _gbuf(b_ih), prec)
+        dw_hh, db_hh = wgrad_bias(dgh2, (h16 if h16 is not None else hall)[:T].view(T * M, H), _gbuf(w_hh), _gbuf(b_hh), prec)
         dx = gemm_dx(dgi2, w_ih, prec=prec) if need_dx else None
         return [dw_ih, dw_hh, db_ih, db_hh], dx
 
@@ -597,11 +614,8 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
         w_ih, w_hh, b_ih, b_hh = w[4 * d: 4 * d + 4]
         hall, gates, h16 = saved[d]
         dgi2, dgh2 = dgi.view(T * M, 3 * H), dgh.view(T * M, 3 * H)
-        dw_ih = gemm(dgi2, xf, _gbuf(w_ih), ta=True, tb=True, acc=True, prec=prec)
-        dw_hh = gemm(dgh2, (h16 if h16 is not None else hall)[:T].view(T * M, H), _gbuf(w_hh), ta=True, tb=True, acc=True,
-                     prec=prec)
-        db_ih = _bgrad(b_ih, dgi2)
-        db_hh = _bgrad_hh(b_hh, dgh2, db_ih)
+        dw_ih, db_ih = wgrad_bias(dgi2, xf, _gbuf(w_ih), _gbuf(b_ih), prec)
+        dw_hh, db_hh = wgrad_bias(dgh2, (h16 if h16 is not None else hall)[:T].view(T * M, H), _gbuf(w_hh), _gbuf(b_hh), prec)
         dx = gemm_dx(dgi2, w_ih, prec=prec) if need_dx else None
         return [dw_ih, dw_hh, db_ih, db_hh], dx
 
@@ -747,7 +761,29 @@ class TextureFrontFn(torch.autograd.Function):
 # row-partitioned persistent notes GRU (csrc/notes_persist.hip)
 # ---------------------------------------------------------------------------------------------
 NOTES_PERSIST = os.environ.get('PTV_NOTES_PERSIST', '1') not in ('0', 'false', 'off')
-_NOTES_PACKS = {}
+class PackCache:
+    """packed weight copies keyed by the source parameters' addresses, valid while (a) the stamp -- in-place version counters, the
+    fused optimiser's step count -- is unchanged and (b) the tensors that were packed are still alive: an address alone can come
+    back for a different tensor once the first one is freed (weak references to the tensor objects seen at insertion; the forward
+    pass inserts with the module's Parameter objects, the backward's saved-tensor aliases then hit the same entry)"""
+
+    def __init__(self, slots=6):
+        self.d, self.slots = {}, slots
+
+    def get(self, srcs, stamp):
+        hit = self.d.get(tuple(p.data_ptr() for p in srcs))
+        if hit is not None and hit[0] == stamp and all(r() is not None for r in hit[2]):
+            return hit[1]
+        return None
+
+    def put(self, srcs, stamp, packs):
+        if len(self.d) >= self.slots:
+            self.d.clear()
+        self.d[tuple(p.data_ptr() for p in srcs)] = (stamp, packs, [weakref.ref(p) for p in srcs])
+        return packs
+
+
+_NOTES_PACKS = PackCache()
 
 
 def pack_mfma_b(w2d, K=None, pairs=False):
@@ -769,18 +805,14 @@ def param_stamp(params):
 
 def notes_packs(w_ih, w_hh, Ht):
     """fragment-major copies of the notes-GRU weights: W_hh, W_ih[:, Ht:] (forward) and W_hh^T (BPTT); cached per parameter version"""
-    key = (w_ih.data_ptr(), w_hh.data_ptr())
     stamp = param_stamp([w_ih, w_hh])
-    hit = _NOTES_PACKS.get(key)
-    if hit is not None and hit[0] == stamp:
-        return hit[1]
+    hit = _NOTES_PACKS.get([w_ih, w_hh], stamp)
+    if hit is not None:
+        return hit
     wT = torch.empty(w_hh.shape[1], w_hh.shape[0], device=w_hh.device, dtype=F32)
     call('ptv_transpose01', ptr(wT), ptr(w_hh), w_hh.shape[0], w_hh.shape[1], 1, stream_ptr())
     pk = dict(wg_h=pack_mfma_b(w_hh, pairs=True), wg_t=pack_mfma_b(w_ih[:, Ht:], pairs=True), wt=pack_mfma_b(wT, pairs=True))
-    if len(_NOTES_PACKS) > 4:
-        _NOTES_PACKS.clear()
-    _NOTES_PACKS[key] = (stamp, pk)
-    return pk
+    return _NOTES_PACKS.put([w_ih, w_hh], stamp, pk)
 
 
 def row_gru_ok(prec, H, I, M, adt):
@@ -989,6 +1021,14 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     def bgrad(name, a):
         G[name] = _bgrad(P[name], a)
 
+    def wgrad_b(name, bname, dy, x, sub=None):
+        """G[name][:, sub] += dy^T . x and G[bname] += column sums of dy, one pass over dy"""
+        if G[name] is None:
+            G[name] = _gbuf(P[name])
+        if G[bname] is None:
+            G[bname] = _gbuf(P[bname])
+        wgrad_bias(dy, x, G[name] if sub is None else G[name][:, sub], G[bname], prec)
+
     ddur = (ddur.contiguous() if ddur is not None else _zeros(M, 5, 2, dev=dev)).view(M, 10)
     dP = _empty(M, _pad8(NP), dev=dev)[:, :NP]               # row-padded like the logits
     if dpitch is not None:
@@ -1032,11 +1072,9 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     gemm_dx(dP, w_p, out=dNSUM, acc=True, prec=prec)
 
     def head_wgrads():
-        wgrad('dur_hid_linear.weight', dHD0, NSUM_op, slice(0, Hn))
+        wgrad_b('dur_hid_linear.weight', 'dur_hid_linear.bias', dHD0, NSUM_op, slice(0, Hn))
         wgrad('dur_hid_linear.weight', dHD0, st['pitch'], slice(Hn, None))
-        bgrad('dur_hid_linear.bias', dHD0)
-        wgrad('pitch_out_linear.weight', dP, NSUM_op)
-        bgrad('pitch_out_linear.bias', dP)
+        wgrad_b('pitch_out_linear.weight', 'pitch_out_linear.bias', dP, NSUM_op)
     side(head_wgrads, dHD0, dP)
 
     # ---- notes GRU (15 steps, batch 32*B) ----
@@ -1060,9 +1098,9 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     gemm_dx(dHN0, w_tn, out=dNS, acc=True, prec=prec)
 
     def notes_wgrads():
-        wgrad('dec_notes_gru.weight_hh_l0', dgh_n.view(M, 3 * Hn), HNo[:15].view(M, Hn))
+        # bias_hh gradient = column sums of dgh (its r and z thirds equal dgi's), taken inside the W_hh product
+        wgrad_b('dec_notes_gru.weight_hh_l0', 'dec_notes_gru.bias_hh_l0', dgh_n.view(M, 3 * Hn), HNo[:15].view(M, Hn))
         bgrad('dec_notes_gru.bias_ih_l0', dGC)
-        G['dec_notes_gru.bias_hh_l0'] = _bgrad_hh(P['dec_notes_gru.bias_hh_l0'], dgh_n.view(M, 3 * Hn), G['dec_notes_gru.bias_ih_l0'])
         wgrad('dec_notes_gru.weight_ih_l0', dGC, NSf_op, slice(0, Ht))
         wgrad('dec_notes_gru.weight_ih_l0', dgi_n.view(M, 3 * Hn), tok_op, slice(Ht, None))
         wgrad('dec_time_to_notes_hid.weight', dHN0, NSf_op)

@@ -43,7 +43,7 @@ def _sos_grid(dev):
 # a 16-sample panel, one more re-summarises the predicted notes.  bf16 precision, init_model() geometry.
 # ---------------------------------------------------------------------------------------------
 FREE_PERSIST = os.environ.get('PTV_FREE_PERSIST', '1') not in ('0', 'false', 'off')
-_PACKS = {}
+_PACKS = F_.PackCache()
 _PACK_SRC = ('dec_notes_gru.weight_hh_l0', 'dec_notes_gru.weight_ih_l0', 'pitch_out_linear.weight', 'dur_hid_linear.weight',
              'dec_dur_gru.weight_hh_l0', 'note_embedding.weight', 'dec_notes_emb_gru.weight_ih_l0', 'dec_notes_emb_gru.weight_hh_l0',
              'dec_notes_emb_gru.weight_ih_l0_reverse', 'dec_notes_emb_gru.weight_hh_l0_reverse')
@@ -70,10 +70,9 @@ def _free_packs(P, Ht):
     ent = _SHADOW_OF.get(src[0].data_ptr())
     opt = ent[0]() if ent is not None else None
     stamp = (sum(p._version for p in src), opt.step_count if opt is not None else -1, opt._dirty if opt is not None else -1)
-    key = tuple(p.data_ptr() for p in src)
-    hit = _PACKS.get(key)
-    if hit is not None and hit[0] == stamp:
-        return hit[1]
+    hit = _PACKS.get(src, stamp)
+    if hit is not None:
+        return hit
     w_ih_n, w_dh, w_emb = P['dec_notes_gru.weight_ih_l0'], P['dur_hid_linear.weight'], P['note_embedding.weight']
     w_embT = torch.empty(w_emb.shape[1], w_emb.shape[0], device=w_emb.device, dtype=torch.float32)
     call('ptv_transpose01', ptr(w_embT), ptr(w_emb), w_emb.shape[0], w_emb.shape[1], 1, stream_ptr())
@@ -81,10 +80,7 @@ def _free_packs(P, Ht):
               wd_h=_pack(w_dh[:, :512]), wd_p=_pack(w_dh[:, 512:]), wdur=_pack(P['dec_dur_gru.weight_hh_l0']), w_embT=w_embT,
               e_ih=_pack(P['dec_notes_emb_gru.weight_ih_l0']), e_hh=_pack(P['dec_notes_emb_gru.weight_hh_l0']),
               e_ih_r=_pack(P['dec_notes_emb_gru.weight_ih_l0_reverse']), e_hh_r=_pack(P['dec_notes_emb_gru.weight_hh_l0_reverse']))
-    if len(_PACKS) > 4:
-        _PACKS.clear()
-    _PACKS[key] = (stamp, pk)
-    return pk
+    return _PACKS.put(src, stamp, pk)
 
 
 def gru_step(prec, hprev, gi, gi_ld, w_hh, b_hh, hout, *, gi2=None, gates=None, plane=0, lengths=None, t=0, gi_idx=None, hout16=None):

@@ -496,3 +496,41 @@ def test_row_gru_h128_bidirectional_with_lengths_vs_step_kernels_and_oracle(M, T
     assert (o1[rows] - ref.detach()).abs().max() < 3e-2
     assert (dx1[:, rows] - xr.grad.transpose(0, 1)).abs().max() < 0.05 * max(1.0, xr.grad.abs().max().item())
     assert (o1[0] == 0).all()                                   # a row of length 0 never leaves the zero state
+
+
+@pytest.mark.parametrize('M,N,K,dt,pad', [(384, 128, 4096, 3, 0), (130, 512, 2000, 2, 6), (1536, 128, 1056, 1, 0), (64, 130, 999, 0, 6),
+                                          (128, 135, 640, 0, 1), (3072, 36, 512, 1, 4), (12, 512, 4100, 0, 0), (256, 1000, 8192, 3, 0)])
+def test_wgrad_kernel_vs_fp64_product_and_column_sums(M, N, K, dt, pad):
+    """csrc/wgrad.hip (transposing-LDS-read weight-gradient kernel): C += A^T B and the fused bias gradient sum_k A[k, :] against
+    a float64 product of the bf16-rounded operands -- fp32 / bf16 sources, widths that are not multiples of 8 or 128 (130, 135, 36,
+    12), K that is not a multiple of the 32-row stage, row strides that are / are not 16-byte aligned (`pad`), every slab count"""
+    from polyphonic_chord_texture_disentanglement_amd._lib import call, ptr, stream_ptr
+    dev = _dev()
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(K, M + pad, generator=g)
+    B = torch.randn(K, N + pad, generator=g)
+    Ad = (A.to(bf) if dt & 1 else A).to(dev)[:, :M]
+    Bd = (B.to(bf) if dt & 2 else B).to(dev)[:, :N]
+    A64, B64 = A[:, :M].to(bf).double(), B[:, :N].to(bf).double()
+    C0 = torch.randn(M, N, generator=g)
+    b0 = torch.randn(M, generator=g)
+    want = C0.double() + 0.5 * (A64.t() @ B64)
+    want_b = b0.double() + A64.sum(0)
+    for slabs in (0, 1, 3, 8):
+        C = C0.to(dev).clone()
+        bias = b0.to(dev).clone()
+        call('ptv_wgrad', M, N, K, ptr(Ad), Ad.stride(0), ptr(Bd), Bd.stride(0), ptr(C), C.stride(0), 0.5, 1, dt, slabs, ptr(bias), stream_ptr())
+        torch.cuda.synchronize()
+        sc = max(1.0, want.abs().max().item())
+        assert (C.cpu().double() - want).abs().max() < 2e-5 * sc, slabs
+        assert (bias.cpu().double() - want_b).abs().max() < 2e-5 * max(1.0, want_b.abs().max().item()), slabs
+    # accumulate = 0 overwrites C; through ptv_gemm (the route the autograd functions take)
+    C = torch.full((M, N), 7.0, device=dev)
+    call('ptv_wgrad', M, N, K, ptr(Ad), Ad.stride(0), ptr(Bd), Bd.stride(0), ptr(C), C.stride(0), 1.0, 0, dt, 0, None, stream_ptr())
+    C2 = C0.to(dev).clone()
+    call('ptv_gemm', 1, 1, 1, M, N, K, ptr(Ad), Ad.stride(0), ptr(Bd), Bd.stride(0), ptr(C2), C2.stride(0), None, 0.5, 1, 0, 0, dt, stream_ptr())
+    torch.cuda.synchronize()
+    full = A64.t() @ B64
+    assert (C.cpu().double() - full).abs().max() < 2e-5 * max(1.0, full.abs().max().item())
+    assert (C2.cpu().double() - want).abs().max() < 2e-5 * max(1.0, want.abs().max().item())
