@@ -1,6 +1,8 @@
-timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "wgrad" 2>&1 | tail -5
-for i in 1 2; do
-PTV_WGRAD_BIAS=0 timeout 300 python bench.py --no-extras --no-cpu-baseline --steps 30 --warmup 8 2>&1 | tail -1 | cut -c1-200
-PTV_WGRAD_BIAS=1 timeout 300 python bench.py --no-extras --no-cpu-baseline --steps 30 --warmup 8 2>&1 | tail -1 | cut -c1-200
-done
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r02c
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/r02c -o bench -- python bench.py --no-extras --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/r02c/bench.log 2>&1
+grep '"metric"' gpurun_out/r02c/bench.log | cut -c1-1500
+rm -f $(find gpurun_out/r02c -name "*kernel_trace.csv")
+timeout 900 python bench.py > gpurun_out/r02c/bench_full.log 2>&1
+tail -1 gpurun_out/r02c/bench_full.log
