@@ -325,7 +325,9 @@ int ptv_slerp_path(const float* z1, const float* z2, float* out, int B, int D, i
  *            xhat [B][32][16][6] int64, plen [R] int32 (zeroed), force_pitch [15][R] or NULL, force_dur [5][M] or NULL,
  *            HN16 [16][R][512] bf16 or NULL, HD16 [6][M][64] bf16 or NULL (bf16 state copies for the backward; HD16 replaces HD[1..5]) }
  *     with R = 32*B, M = 15*R; the rows of time step t are [t*B, (t+1)*B).  coin_mask bit n = feed the ground-truth note n+1
- *     (teacher-forcing coin, ptvae.py:420).  train = 0 skips what only the backward reads (HN, gates, HD, TOK).
+ *     (teacher-forcing coin, ptvae.py:420).  train = 0 skips what only the backward reads (HN, gates, HD, TOK); train = 2 stores only
+ *     the fed tokens TOK: the caller then recomputes states and gates for ALL rows with the batched kernels (ptv_notes_gru_persist_fwd,
+ *     ptv_dur_gru_fwd with the stored decisions forced), cheaper than 16-row panels streaming them out note step by note step.
  *   ptv_free_resummarize: w = { pack(W_ih), pack(W_hh), pack(W_ih_reverse), pack(W_hh_reverse), b_ih, b_hh, b_ih_r, b_hh_r } of
  *     dec_notes_emb_gru; io = { PRED, plen, XH fwd [17][R][128] (slot 0 zero), XH bwd, XG fwd [16][4][R][128] bf16, XG bwd,
  *     tok_next = TOKS[t+1] [B][256] }.

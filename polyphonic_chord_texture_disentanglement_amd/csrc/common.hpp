@@ -47,6 +47,12 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Barrier for exchanges that go through LDS only.  __syncthreads() carries a workgroup-scope fence, for which hipcc also drains the
+// wave's outstanding GLOBAL stores (s_waitcnt vmcnt(0)): about a microsecond of write-acknowledge latency at every barrier of a
+// kernel that streams results to HBM while it iterates.  Use only where no other wave of the workgroup reads what this wave wrote
+// to global memory.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace ptv

@@ -152,7 +152,8 @@ struct NoteLoopArgs {
   __bf16* HN16; __bf16* HD16;     // optional bf16 copies of the states (operands of the backward's products); HD16 replaces HD[1..5]
   int B, t, R, M;
   unsigned coin_mask;              // bit n: the token fed to note step n+1 is the ground truth (teacher forcing coin, ptvae.py:420)
-  int train;                       // save what the backward needs (states, gates, fed tokens)
+  int train;                       // save what the backward needs (states, gates)
+  int tok_store;                   // save the fed tokens (train, or the light mode whose caller recomputes states and gates batched)
   int dbg;                         // timing experiments: skip phases (results invalid)
 };
 
@@ -206,6 +207,8 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
 
   __syncthreads();
 
+  // waves exchange through LDS only inside the loop (every global store is an output nobody here reads back from another
+  // wave): lds_barrier() keeps the training-mode stores of states and gates in flight across the 14 barriers of a note step
   for (int n = 0; n < 15; n++) {
     const int cur = n & 1, nxt = cur ^ 1;
     // ================= P1: notes-GRU cell.  wave w owns units [w*128, w*128+128) = 8 tiles of 16, two per pass =================
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     // ================= P2: pitch head (9 tiles over 4 waves) + dur_hid part 1 =================
     for (int nt = wave; nt < ((a.dbg & 4) ? 0 : 9); nt += 4) {
       f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
         pit16[crow][c] = (__bf16)v;
       }
     }
-    __syncthreads();
+    lds_barrier();
     // ================= P3: argmax over the 130 logits (16 lanes per row, first maximal index) + logits out =================
     {
       const int row = tid >> 4, j = tid & 15;
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
       }
     }
     if (tid < FP) dtok[tid] = 0;
-    __syncthreads();
+    lds_barrier();
     // ================= P5: 5-step duration GRU, argmax feedback (wave w = units w*16..w*16+15) =================
     {
       const long prC = (long)n * R + wrowC;
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
         o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64);
         o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64);
         if (lane < 16) { part[wave][lane][0] = o0; part[wave][lane][1] = o1; }
-        __syncthreads();
+        lds_barrier();
         if (tid < FP) {
           const float e0 = part[0][tid][0] + part[1][tid][0] + part[2][tid][0] + part[3][tid][0] + wo[2 * FHD];
           const float e1 = part[0][tid][1] + part[1][tid][1] + part[2][tid][1] + part[3][tid][1] + wo[2 * FHD + 1];
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
           bits[tid][d] = id;
           dtok[tid] = 1 + id;
         }
-        __syncthreads();
+        lds_barrier();
       }
     }
     // ================= P6: predicted token = note_embedding(onehot(pitch) | 5 duration bits); next input token =================
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
           const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
           v[0] = g0.x; v[1] = g0.y; v[2] = g0.z; v[3] = g0.w; v[4] = g1.x; v[5] = g1.y; v[6] = g1.z; v[7] = g1.w;
         }
-        if (a.train && ok) {
+        if (a.tok_store && ok) {
           float* tp = a.TOK + ((long)(n + 1) * R + wr) * FE + e0;
           *reinterpret_cast<float4*>(tp) = make_float4(v[0], v[1], v[2], v[3]);
           *reinterpret_cast<float4*>(tp + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
         a.plen[(long)t * B + rw] = L;
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
   if (a.dbg_out && tid == 0) {
     unsigned xcc, hwid;
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(256, 1) void resum_kernel(ResumArgs a) {
         if (s == 15) *reinterpret_cast<float4*>(a.tok_next + (long)rE * (2 * FHE) + dir * FHE + u) = make_float4(h[0], h[1], h[2], h[3]);
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -559,7 +562,7 @@ extern "C" int ptv_free_note_loop(const void* const* w, const void* const* io, l
   if (!w || !io || B <= 0 || t < 0 || t >= 32) return PTV_ERR_ARG;
   for (int i = 0; i < 16; i++) if (!w[i]) return PTV_ERR_ARG;
   if (!io[0] || !io[2] || !io[4] || !io[7] || !io[8] || !io[9] || !io[10] || !io[11] || !io[12]) return PTV_ERR_ARG;
-  if (train && (!io[3] || !io[5] || !io[6])) return PTV_ERR_ARG;
+  if ((train & 3) == 1 && (!io[3] || !io[5] || !io[6])) return PTV_ERR_ARG;
   if (coin_mask && !io[1]) return PTV_ERR_ARG;
   NoteLoopArgs a{};
   a.wg_h = (const bf16x8*)w[0]; a.wg_t = (const bf16x8*)w[1]; a.wp = (const bf16x8*)w[2]; a.wd_h = (const bf16x8*)w[3];
@@ -572,7 +575,7 @@ extern "C" int ptv_free_note_loop(const void* const* w, const void* const* io, l
   a.idx = (int*)io[8]; a.TOK = (float*)io[9]; a.PRED = (float*)io[10]; a.xhat = (long*)io[11]; a.plen = (int*)io[12];
   a.force_pitch = (const int*)io[13]; a.force_dur = (const int*)io[14]; a.HN16 = (__bf16*)io[15]; a.HD16 = (__bf16*)io[16];
   a.dbg_out = (train >> 8) & 64 ? (long*)io[17] : nullptr;
-  a.B = B; a.t = t; a.R = 32 * B; a.M = 15 * 32 * B; a.coin_mask = coin_mask; a.train = train & 1; a.dbg = train >> 8;
+  a.B = B; a.t = t; a.R = 32 * B; a.M = 15 * 32 * B; a.coin_mask = coin_mask; a.train = (train & 3) == 1; a.tok_store = (train & 3) != 0; a.dbg = train >> 8;
   hipLaunchKernelGGL(note_loop_kernel, dim3((B + FP - 1) / FP), dim3(256), 0, (hipStream_t)stream, a);
   PTV_CHECK_LAUNCH();
   return PTV_OK;

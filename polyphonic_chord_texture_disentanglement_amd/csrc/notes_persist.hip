@@ -124,6 +124,8 @@ __global__ __launch_bounds__(256, 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
   // handful of its 16 channels busy, the rest idle): each walks the passes and the k-blocks from its own starting point
   const int prot = (a.dbg & 8) ? 0 : (blockIdx.x >> 3) & (NPASS - 1), krot = (a.dbg & 8) ? 0 : (((blockIdx.x >> 5) & 7) * 2) & (KBH - 1);
 
+  // inside the step loop the waves exchange through LDS only (the fp32 state a lane re-reads from HN is its own store): lds_barrier()
+  // lets a step's 117 MB of state / gate stores drain under the next step's products instead of at the step boundary
   for (int n = 0; n < a.T; n++) {
     const int cur = n & 1, nxt = cur ^ 1;
     const int tt = a.reverse ? a.T - 1 - n : n;
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
       ld_f32x8(a.x + (long)tt * a.x_step + min(r0 + row, R - 1) * NE + c8, v);
       st_bf16x8(tok16 + row * NT16LD + c8, v);
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll 1
     for (int p0 = 0; p0 < NPASS; p0++) {
       const int p = (p0 + prot) & (NPASS - 1);
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256, 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
         __builtin_amdgcn_sched_barrier(0);                               // keep the M tiles' epilogues (and the passes) apart: register pressure
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 

@@ -43,6 +43,9 @@ def _sos_grid(dev):
 # a 16-sample panel, one more re-summarises the predicted notes.  bf16 precision, init_model() geometry.
 # ---------------------------------------------------------------------------------------------
 FREE_PERSIST = os.environ.get('PTV_FREE_PERSIST', '1') not in ('0', 'false', 'off')
+# training forward of the step loop: the panels store only decisions, logits and fed tokens; states and gates the backward needs are
+# recomputed afterwards for all 480*B rows at once by the teacher-forced kernels (same tokens, same decisions forced)
+FREE_REPLAY = os.environ.get('PTV_FREE_REPLAY', '1') not in ('0', 'false', 'off')
 _PACKS = F_.PackCache()
 _PACK_SRC = ('dec_notes_gru.weight_hh_l0', 'dec_notes_gru.weight_ih_l0', 'pitch_out_linear.weight', 'dur_hid_linear.weight',
              'dec_dur_gru.weight_hh_l0', 'note_embedding.weight', 'dec_notes_emb_gru.weight_ih_l0', 'dec_notes_emb_gru.weight_hh_l0',
@@ -164,6 +167,8 @@ class DecoderStepFn(torch.autograd.Function):
             if Ht % 8 == 0:
                 NS16 = _empty(33, B, Ht, dev=dev, dtype=torch.bfloat16)
                 call('ptv_cast_bf16', ptr(NS[0]), ptr(NS16[0]), B * Ht, st)
+        replay = (fast and train and FREE_REPLAY and F_.notes_persist_ok(prec, Hn, E) and Hd == 64 and F_.FUSED_DUR and NS16 is not None
+                  and force_dur is None and force_pitch is None)
         if fast:
             pk = _free_packs(P, Ht)
             wl = F_._parr([pk['wg_h'], pk['wg_t'], pk['wp'], pk['wd_h'], pk['wd_p'], pk['wdur'], b_hh_n, P['pitch_out_linear.bias'],
@@ -190,14 +195,14 @@ class DecoderStepFn(torch.autograd.Function):
                     for n in range(14):
                         mask |= int(bool(coin_notes[t][n])) << n
                 io = F_._parr([GCt, emb3, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, force_pitch, force_dur, HN16, HD16])
-                call('ptv_free_note_loop', wl, io, pitch.stride(0), B, t, mask, int(train), st)
+                call('ptv_free_note_loop', wl, io, pitch.stride(0), B, t, mask, 2 if replay else int(train), st)
                 if t == 31:
                     break
                 if (not inference) and coin_time[t]:
                     copy2d(TOKS[t + 1], xs[rows])
                 else:
                     io = F_._parr([PRED, plen, XH[0], XH[1], XG[0], XG[1], TOKS[t + 1]])
-                    call('ptv_free_resummarize', wr, io, B, t, int(train), st)
+                    call('ptv_free_resummarize', wr, io, B, t, int(train and not replay), st)
                 continue
             for n in range(15):
                 gi_tok = gemm(TOK[n][rows], w_ih_n[:, Ht:], prec=prec)
@@ -243,11 +248,33 @@ class DecoderStepFn(torch.autograd.Function):
                                  gates=XG[d][s_][:, rows] if train else None, plane=R * He, lengths=plen[rows], t=tt)
                     copy2d(TOKS[t + 1][:, d * He:(d + 1) * He], XH[d][16][rows])
 
+        XH16 = [None, None]
+        if replay:
+            # ---- recompute what the backward reads, batched over all rows (the step loop above stored decisions and tokens only)
+            GC16 = gemm(NS16[1:].view(R, Ht), w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec, out_dtype=torch.bfloat16)
+            pkn = F_.notes_packs(w_ih_n, w_hh_n, Ht)
+            call('ptv_notes_gru_persist_fwd', ptr(pkn['wg_h']), ptr(pkn['wg_t']), ptr(b_hh_n), ptr(GC16), ptr(TOK), ptr(HN), ptr(HN16),
+                 ptr(gates_n), R, 15, st)
+            NSUM_op = HN16[1:].view(M, Hn)
+            gemm(NSUM_op, w_dh[:, :Hn], HD[0], bias=P['dur_hid_linear.bias'], prec=prec)
+            gemm(pitch, w_dh[:, Hn:], HD[0], acc=True, prec=prec)
+            dur_scr, idx_scr = _empty(M, 10, dev=dev), torch.empty(5, M, device=dev, dtype=torch.int32)
+            call('ptv_dur_gru_fwd', Hd, M, ptr(HD[0]), Hd, ptr(w_hh_d), ptr(b_hh_d), ptr(tab0), ptr(tab), ptr(P['dur_out_linear.weight']),
+                 ptr(P['dur_out_linear.bias']), None, M * Hd, ptr(HD16[1]), ptr(gates_d), M * Hd, 4 * M * Hd, 1, ptr(dur_scr), 10,
+                 ptr(idx_scr), M, ptr(idx), M, st)
+            call('ptv_cast_bf16', ptr(HD[0]), ptr(HD16[0]), M * Hd, st)
+            if need_resum:
+                for d in range(2):
+                    w_ih_e, w_hh_e, b_ih_e, b_hh_e = wE[4 * d: 4 * d + 4]
+                    pke = F_.notes_packs(w_ih_e, w_hh_e, 0)
+                    XH16[d] = _empty(17, R, He, dev=dev, dtype=torch.bfloat16)
+                    call('ptv_row_gru_persist_fwd', He, ptr(pke['wg_h']), ptr(pke['wg_t']), ptr(b_hh_e), ptr(b_ih_e), None, ptr(PRED), R * E,
+                         ptr(plen), ptr(XH[d]), ptr(XH16[d]), ptr(XG[d]), None, 0, R, 16, d, st)
         if train:
             ctx.save_for_backward(z, emb, *params)
             ctx.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in, TOKS=TOKS,
                           gates_t=gates_t, HN=HN, gates_n=gates_n, pitch=pitch, HD=HD, gates_d=gates_d, idx=idx, TOK=TOK,
-                          PRED=PRED, xhat=xhat, XH=XH, XG=XG, coins=coins, has_xs=xs is not None,
+                          PRED=PRED, xhat=xhat, XH=XH, XG=XG, XH16=XH16, coins=coins, has_xs=xs is not None,
                           NS16=NS16, HN16=HN16, HD16=HD16, dur16_only=HD16 is not None)
         ctx.mark_non_differentiable(xhat, idx)
         return pitch.view(15, 32, B, NP), dur, xhat, idx
@@ -299,7 +326,7 @@ class DecoderStepFn(torch.autograd.Function):
         call('ptv_route_slices', ptr(dTOKS[1:]), ptr(dxs), ptr(dxsp), ptr(mask_time), B * 2 * He, 32, 0, sp)
         if st['XH'] is not None:
             wE = [P['dec_notes_emb_gru.' + n] for n in EMB_GRU]
-            saved = [(st['XH'][0], st['XG'][0], None), (st['XH'][1], st['XG'][1], None)]
+            saved = [(st['XH'][0], st['XG'][0], st['XH16'][0]), (st['XH'][1], st['XG'][1], st['XH16'][1])]
             ge, dx_pred = _bigru_backward(prec, PRED, wE, saved, dxsp.view(R, 2 * He), True)
             for n, gg in zip(EMB_GRU, ge):
                 G['dec_notes_emb_gru.' + n] = gg

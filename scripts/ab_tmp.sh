@@ -1,8 +1,3 @@
-cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r02c
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/r02c -o bench -- python bench.py --no-extras --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/r02c/bench.log 2>&1
-grep '"metric"' gpurun_out/r02c/bench.log | cut -c1-1500
-rm -f $(find gpurun_out/r02c -name "*kernel_trace.csv")
-timeout 900 python bench.py > gpurun_out/r02c/bench_full.log 2>&1
-tail -1 gpurun_out/r02c/bench_full.log
+timeout 900 python -m pytest tests/test_gpu_model.py -x -q 2>&1 | tail -5
+PTV_FREE_REPLAY=0 timeout 300 python bench.py --no-extras --no-cpu-baseline --tfr 0 --steps 6 --warmup 3 2>&1 | tail -1 | cut -c1-200
+PTV_FREE_REPLAY=1 timeout 300 python bench.py --no-extras --no-cpu-baseline --tfr 0 --steps 6 --warmup 3 2>&1 | tail -1 | cut -c1-200

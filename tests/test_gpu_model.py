@@ -664,3 +664,36 @@ def test_persistent_step_loop_inference_decode_and_graph():
     m.decoder.use_graph = False
     # (split-K products accumulate with atomics: run-to-run rounding differs in the last bit, which near-ties amplify)
     assert (first == est[True]).mean() > 0.97 and (again == est[True][::-1]).mean() > 0.97
+
+
+def test_free_running_training_batched_recompute_equals_streamed_states(monkeypatch):
+    """tfr = 0 training step, full geometry: the default forward stores only decisions / logits / fed tokens in the step loop and
+    recomputes states and gates for the backward with the batched kernels (functional_free.FREE_REPLAY); against the variant whose
+    16-row panels stream states and gates out note step by note step: identical losses and decisions (same forward), gradients
+    equal to bf16 rounding of the recomputed activations"""
+    from polyphonic_chord_texture_disentanglement_amd import functional_free as FF_
+    m = M.DisentangleVAE.init_model(torch.device(DEV))
+    m.load_state_dict(full_params())
+    m.to(DEV).set_precision('bf16')
+    g = load_npz('full_tf0_b4.npz')
+    B = 32
+    x, c, pr = synth_batch(B, int(g['data_seed']) + 5)
+    xt, ct, prt = (torch.from_numpy(a).to(DEV) for a in (x, c, pr))
+    eps = {n: torch.randn(B, 256, generator=torch.Generator().manual_seed(i)).to(DEV) for i, n in enumerate(('chd', 'rhy'))}
+    res = {}
+    for replay in (False, True):
+        monkeypatch.setattr(FF_, 'FREE_REPLAY', replay)
+        m.eps_source = lambda name, shape, device: eps[name]
+        m.zero_grad()
+        outs = m.run(xt, ct, prt, 0., 0., 0.)
+        losses = m.loss_function(xt, ct, *outs, 0.1, [1, 0.5])
+        losses[0].backward()
+        torch.cuda.synchronize()
+        res[replay] = (np.array([l.item() for l in losses]), m.decoder.last_xhat.clone(),
+                       {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    (l0, x0, g0), (l1, x1, g1) = res[False], res[True]
+    np.testing.assert_allclose(l1, l0, rtol=0, atol=5e-3)
+    assert (x0 == x1).float().mean() > 0.995
+    assert set(g0) == set(g1)
+    for n in g0:
+        assert (g1[n] - g0[n]).abs().max() <= 0.04 * g0[n].abs().max() + 1e-6, n
