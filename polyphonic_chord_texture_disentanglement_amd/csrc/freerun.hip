@@ -169,9 +169,8 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
   __shared__ float tabs[3][3 * FHD];
   __shared__ float bhd[3 * FHD];
   __shared__ float wo[2 * FHD + 2];
-  __shared__ float part[4][FP][2];
+  __shared__ float part[2][4][FP][2];                                          // double buffered: one barrier per duration step
   __shared__ int pidx[FP];
-  __shared__ int dtok[FP];
   __shared__ int bits[FP][5];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -321,12 +320,12 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
         if (a.HD16) st_bf16x4_lds(a.HD16 + ((long)n * R + wrowC) * FHD + u, h[0], h[1], h[2], h[3]);
       }
     }
-    if (tid < FP) dtok[tid] = 0;
     lds_barrier();
     // ================= P5: 5-step duration GRU, argmax feedback (wave w = units w*16..w*16+15) =================
     {
       const long prC = (long)n * R + wrowC;
       const int u = wave * 16 + ckq * 4;
+      int dtk = 0;                                                             // this lane's row: 0 = <sos>, 1 + previous decision
 #pragma unroll 1
       for (int d = 0; d < ((a.dbg & 8) ? 0 : 5); d++) {
         const int dc = d & 1, dn = dc ^ 1;
@@ -339,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
 #pragma unroll
           for (int g = 0; g < 3; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdl[((g * 4 + wave) * 2 + kb) * 64 + lane], av, acc[g], 0, 0, 0);
         }
-        const float* gi = tabs[dtok[crow]];
+        const float* gi = tabs[dtk];
         const float4 hp4 = *reinterpret_cast<const float4*>(&hdf[crow][u]);
         const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
         float r[4], z[4], nn[4], hn[4], h[4], o0 = 0.f, o1 = 0.f;
@@ -367,25 +366,27 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
         }
         o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64);
         o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64);
-        if (lane < 16) { part[wave][lane][0] = o0; part[wave][lane][1] = o1; }
+        if (lane < 16) { part[dc][wave][lane][0] = o0; part[dc][wave][lane][1] = o1; }
         lds_barrier();
-        if (tid < FP) {
-          const float e0 = part[0][tid][0] + part[1][tid][0] + part[2][tid][0] + part[3][tid][0] + wo[2 * FHD];
-          const float e1 = part[0][tid][1] + part[1][tid][1] + part[2][tid][1] + part[3][tid][1] + wo[2 * FHD + 1];
+        // every lane forms the two logits of ITS row from the four waves' partial sums and takes the decision itself (no second
+        // barrier to pass the token around); the panel's first 16 threads also publish them
+        {
+          const float e0 = part[dc][0][crow][0] + part[dc][1][crow][0] + part[dc][2][crow][0] + part[dc][3][crow][0] + wo[2 * FHD];
+          const float e1 = part[dc][0][crow][1] + part[dc][1][crow][1] + part[dc][2][crow][1] + part[dc][3][crow][1] + wo[2 * FHD + 1];
           int id = e1 > e0 ? 1 : 0;                                             // first max wins ties (torch.max)
-          const bool ok = r0 + tid < B;
-          const long pr = (long)n * R + (long)t * B + min(r0 + tid, B - 1);
-          if (a.force_dur) id = a.force_dur[(long)d * M + pr];
-          if (ok) {
-            a.dur[pr * 10 + 2 * d] = e0; a.dur[pr * 10 + 2 * d + 1] = e1;
-            a.idx[(long)d * M + pr] = id;
+          if (a.force_dur) id = a.force_dur[(long)d * M + prC];
+          dtk = 1 + id;
+          if (tid < FP) {                                                      // wave 0, lanes 0..15: crow == tid
+            if (okC) {
+              a.dur[prC * 10 + 2 * d] = e0; a.dur[prC * 10 + 2 * d + 1] = e1;
+              a.idx[(long)d * M + prC] = id;
+            }
+            bits[tid][d] = id;
           }
-          bits[tid][d] = id;
-          dtok[tid] = 1 + id;
         }
-        lds_barrier();
       }
     }
+    lds_barrier();                                                             // bits[] of the last duration step
     // ================= P6: predicted token = note_embedding(onehot(pitch) | 5 duration bits); next input token =================
     {
       const int row = tid >> 4, e0 = (tid & 15) * 8;

@@ -175,6 +175,12 @@ class DecoderStepFn(torch.autograd.Function):
                            P['dur_hid_linear.bias'], b_hh_d, tab0, tab, P['dur_out_linear.weight'], P['dur_out_linear.bias'],
                            pk['w_embT'], b_emb])
             wr = F_._parr([pk['e_ih'], pk['e_hh'], pk['e_ih_r'], pk['e_hh_r'], wE[2], wE[3], wE[6], wE[7]])
+        # the first note token of every time step is the <sos> embedding (ptvae.py:388-392): one copy for all 32 steps
+        if inference:
+            copy2d(TOK[0], sos_row, lds=0)
+        else:
+            copy2d(TOK[0], emb3[0])
+        copy2d(PRED[0], TOK[0])
         for t in range(32):
             rows = slice(t * B, (t + 1) * B)
             gi = gemm(TOKS[t], w_ih_t[:, :2 * He], prec=prec)
@@ -183,11 +189,6 @@ class DecoderStepFn(torch.autograd.Function):
             ns = NS[t + 1]
             gemm(ns, P['dec_time_to_notes_hid.weight'], HN[0][rows], bias=P['dec_time_to_notes_hid.bias'], prec=prec)
             GCt = gemm(ns, w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec)
-            if inference:
-                copy2d(TOK[0][rows], sos_row, lds=0)
-            else:
-                copy2d(TOK[0][rows], emb3[0][rows])
-            copy2d(PRED[0][rows], TOK[0][rows])
             if fast:
                 # all 15 note steps of this time step in ONE launch (csrc/freerun.hip); then the next time-step token
                 mask = 0
