@@ -164,14 +164,14 @@ def _roofline(lib, B, model, args):
     (tag 3) and BPTT (tag 4).  Algorithmic bytes per launch (DESIGN.md section 6, R = 32*B rows, H = 512, E = 128, T = 15 steps):
       fwd  per step: GC bf16 R*3H*2 (hoisted input part) + fed token fp32 R*E*4 read; state fp32 R*H*4 + bf16 R*H*2 and the four
            saved gate planes bf16 4*R*H*2 written; once: W_hh and W_ih[:, Ht:] bf16, b_hh, the initial state.
-      bwd  per step: gates 4*R*H*2 + gradient arriving at the state R*H*2 + previous state fp32 R*H*4 read; dgi and dgh bf16
-           2*R*3H*2 written; once: W_hh^T bf16, dh0 fp32.
+      bwd  per step: gates 4*R*H*2 + gradient arriving at the state R*H*2 + previous state fp32 R*H*4 read; dgi bf16 R*3H*2 and
+           the n third of dgh R*H*2 written (its r / z thirds are dgi's); once: W_hh^T bf16, dh0 fp32.
     Intensity is ~180 FLOP/B, below the MI355X balance point (2.5 PFLOP/s / 8 TB/s = 312): HBM bounds both; the MFMA fraction is
     reported beside it."""
     import ctypes
     R, H, E, T = 32 * B, model.decoder.dec_notes_hid_size, 128, 15
     fwd_bytes = T * (R * 3 * H * 2 + R * E * 4 + R * H * 4 + R * H * 2 + 4 * R * H * 2) + 3 * H * (H + E) * 2 + 3 * H * 4 + R * H * 4
-    bwd_bytes = T * (4 * R * H * 2 + R * H * 2 + R * H * 4 + 2 * R * 3 * H * 2) + 3 * H * H * 2 + R * H * 4
+    bwd_bytes = T * (4 * R * H * 2 + R * H * 2 + R * H * 4 + R * 3 * H * 2 + R * H * 2) + 3 * H * H * 2 + R * H * 4
     pmc = {}
     pmc_path = os.path.join(ROOT, 'profiles', 'r02_row_gru_pmc.json')
     if B == 512 and args.precision == 'bf16' and os.path.exists(pmc_path):

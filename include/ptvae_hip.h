@@ -347,7 +347,9 @@ int ptv_free_resummarize(const void* const* w, const void* const* io, int B, int
  *        emb fp32 [T][R][128] fed tokens; HN fp32 [T+1][R][512] (slot 0 written by the caller), HN16 bf16 same shape (all slots
  *        written here), gates bf16 [T][4][R][512] (r, z, n, W_hn h + b_hn) or NULL.
  *   bwd: wt = pack(W_hh^T [512,1536]); ext bf16 [T][R][512] = gradient arriving at the state after step s;
- *        dgi / dgh bf16 [T][R][1536]; dh0 fp32 [R][512] or NULL; scratch: ptv_notes_gru_persist_scratch_elems(R) bf16 elements.
+ *        dgi bf16 [T][R][1536]; dgh bf16 [T][R][512] = the n third (dn * r) only -- the r and z thirds of dgh are dgi's, so
+ *        grad W_hh[0:1024] = dgi[:, 0:1024]^T . h and grad W_hh[1024:] = dgh^T . h; dh0 fp32 [R][512] or NULL; scratch:
+ *        ptv_notes_gru_persist_scratch_elems(R) bf16 elements.
  */
 int ptv_notes_gru_persist_fwd(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
                               float* HN, void* HN16, void* gates, long R, int T, void* stream);
@@ -361,7 +363,10 @@ int ptv_notes_gru_persist_bwd(const void* wt, const float* HN, const void* gates
  *        x fp32, row m of step t at x + t*x_step + m*128; lengths int32 [R] or NULL (row m is updated at time t iff t < lengths[m],
  *        as nn.utils.rnn.pack_padded_sequence does); reverse = 1 walks time T-1..0; out (or NULL) receives the final state,
  *        row m at out + m*out_ld (out_ld % 4 == 0).
- *   bwd: ext bf16 [T][R][H] or NULL; dh_last fp32 (row stride last_ld) = gradient of the final state, or NULL; dgi is indexed by
+ *        The two instances are specialised: H = 512 needs gc and takes no b_ih / lengths / reverse / out; H = 128 needs b_ih and no
+ *        gc (PTV_ERR_UNSUPPORTED otherwise).
+ *   bwd: ext bf16 [T][R][H] (H = 512 only, required there); dh_last fp32 (row stride last_ld) = gradient of the final state (H = 128
+ *        only), or NULL; H = 512 writes only the n third of dgh ([T][R][512], see above); dgi is indexed by
  *        TIME, dgh by processing step (so dgh pairs with HN16[:T] and dgi with x in the weight-gradient products).
  */
 int ptv_row_gru_persist_fwd(int H, const void* w_hh, const void* w_x, const float* b_hh, const float* b_ih, const void* gc,

@@ -92,7 +92,9 @@ struct RowGruFwdArgs {
   int R, T, reverse, dbg;
 };
 
-template <int H>
+// EMB = false: the notes GRU (hoisted input part gc, b_ih folded in, no mask, no final-state output); EMB = true: a direction of
+// dec_notes_emb_gru (b_ih, optional length mask, optional reversed time, final state)
+template <int H, bool EMB>
 __global__ __launch_bounds__(256, 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
   constexpr int KBH = H / 32, NUT = H / 16, NPASS = H / 128, UTW = NUT / 4, HLD = H + 16, KT = KBH + 4;
   extern __shared__ __attribute__((aligned(16))) char nsm[];
@@ -118,7 +120,8 @@ __global__ __launch_bounds__(256, 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     ok[i] = r0 + i * 16 + erow < R; grow[i] = min(r0 + i * 16 + erow, R - 1);
-    len[i] = a.lengths ? a.lengths[grow[i]] : 0x7fffffff;
+    len[i] = 0x7fffffff;
+    if constexpr (EMB) { if (a.lengths) len[i] = a.lengths[grow[i]]; }
   }
   // workgroups of one XCD run in near lockstep and would all ask the L2 for the same few fragment lines at the same moment (a
   // handful of its 16 channels busy, the rest idle): each walks the passes and the k-blocks from its own starting point
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
   // lets a step's 117 MB of state / gate stores drain under the next step's products instead of at the step boundary
   for (int n = 0; n < a.T; n++) {
     const int cur = n & 1, nxt = cur ^ 1;
-    const int tt = a.reverse ? a.T - 1 - n : n;
+    const int tt = (EMB && a.reverse) ? a.T - 1 - n : n;
     const __bf16* hc = h16 + cur * NRP * HLD;
     __bf16* hn_ = h16 + nxt * NRP * HLD;
     // ---- this step's fed tokens -> LDS (bf16 MFMA operand)
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256, 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
       bf16x8 gq[4][3]; float4 hq[4][2];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        if (a.gc) {
+        if constexpr (!EMB) {
           const __bf16* g = a.gc + grow[i] * (3 * H) + u;
 #pragma unroll
           for (int gt = 0; gt < 3; gt++) gq[i][gt] = ldnt_bf16x8(g + gt * H);
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
       ld_f32x8(a.b_hh + u, bR); ld_f32x8(a.b_hh + H + u, bZ); ld_f32x8(a.b_hh + 2 * H + u, bN);
 #pragma unroll
       for (int e = 0; e < 8; e++) bI[e] = 0.f;
-      if (a.b_ih) {
+      if constexpr (EMB) {
         float t8[8];
         ld_f32x8(a.b_ih + u, t8);
 #pragma unroll
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256, 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
         float gR[8], gZ[8], gN[8], aR[8], aZ[8], aH[8], aI[8], hp[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-          gR[e] = a.gc ? (float)gq[i][0][e] : 0.f; gZ[e] = a.gc ? (float)gq[i][1][e] : 0.f; gN[e] = a.gc ? (float)gq[i][2][e] : 0.f;
+          gR[e] = EMB ? 0.f : (float)gq[i][0][e]; gZ[e] = EMB ? 0.f : (float)gq[i][1][e]; gN[e] = EMB ? 0.f : (float)gq[i][2][e];
         }
         // fp32 state of these cells: written by this very lane one step ago (the whole fp32 state, 128 KB per workgroup at H = 512,
         // fits neither LDS next to the bf16 operand copies nor the register file next to the accumulators)
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
         hp[4] = hq[i][1].x; hp[5] = hq[i][1].y; hp[6] = hq[i][1].z; hp[7] = hq[i][1].w;
         pair_to_rows(acc[i][0], acc[i][1], aR); pair_to_rows(acc[i][2], acc[i][3], aZ);
         pair_to_rows(acc[i][4], acc[i][5], aH); pair_to_rows(acc[i][6], acc[i][7], aI);
-        const bool live = tt < len[i];
+        const bool live = !EMB || tt < len[i];
         float r[8], z[8], nn[8], hn[8], h[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) {
@@ -233,11 +236,14 @@ __global__ __launch_bounds__(256, 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
           const long o = (long)(n + 1) * RH + grow[i] * H + u;
           st_f32x8(a.HN + o, h);                                       // read back next step: default policy
           stnt_bf16x8(a.HN16 + o, h);
-          if (a.gates) {
+          if (a.gates && (a.dbg & 32)) {                                 // experiment: the same bytes as 1-KB-contiguous wave stores
+            __bf16* gp = a.gates + (long)n * 4 * RH + (((((long)blockIdx.x * NPASS + p0) * 4 + i) * 4 + wave) * 4) * 512 + lane * 8;
+            stnt_bf16x8(gp, r); stnt_bf16x8(gp + 512, z); stnt_bf16x8(gp + 1024, nn); stnt_bf16x8(gp + 1536, hn);
+          } else if (a.gates && !(a.dbg & 4)) {
             __bf16* gp = a.gates + (long)n * 4 * RH + grow[i] * H + u;
             stnt_bf16x8(gp, r); stnt_bf16x8(gp + RH, z); stnt_bf16x8(gp + 2 * RH, nn); stnt_bf16x8(gp + 3 * RH, hn);
           }
-          if (a.out && n == a.T - 1) st_f32x8(a.out + grow[i] * a.out_ld + u, h);
+          if constexpr (EMB) { if (a.out && n == a.T - 1) st_f32x8(a.out + grow[i] * a.out_ld + u, h); }
         }
         __builtin_amdgcn_sched_barrier(0);                               // keep the M tiles' epilogues (and the passes) apart: register pressure
       }
@@ -254,13 +260,15 @@ struct RowGruBwdArgs {
   const float* HN; const __bf16* gates;
   const __bf16* ext;               // [T][R][H] bf16 gradient arriving at the state after step s, or null
   const float* dh_last; long last_ld;   // gradient arriving at the final state only (rows of stride last_ld), or null
-  __bf16* dgi; __bf16* dgh;        // [T][R][3H]: dgi by TIME index, dgh by processing step
+  __bf16* dgi; __bf16* dgh;        // dgi [T][R][3H] by TIME index; dgh by processing step: [T][R][3H] (EMB) or its n third only [T][R][H]
   float* dh0;                      // [R][H] or null
   __bf16* scratch;                 // [grid][2][3H/8 chunks][64 rows][8]: dgh of the workgroup's rows, K-blocked (A operand of the next step)
   int R, T, reverse;
 };
 
-template <int H>
+// EMB = false: the notes GRU (gradient arrives at every state: ext; forward time order; dh0 wanted); EMB = true: a direction of
+// dec_notes_emb_gru (gradient arrives at the final state only: dh_last; optional reversed time)
+template <int H, bool EMB>
 __global__ __launch_bounds__(256, 1) void row_gru_bwd_kernel(RowGruBwdArgs a) {
   constexpr int KT = 3 * H / 32, NTW = H / 64, NCH = 3 * H / 8;           // k-blocks, output tiles per wave, scratch chunks
   extern __shared__ __attribute__((aligned(16))) char nsm[];
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(256, 1) void row_gru_bwd_kernel(RowGruBwdArgs a) {
 
   for (int s = a.T - 1; s >= (a.dh0 ? -1 : 0); s--) {
     const bool last = s == a.T - 1;
-    const int tt = s < 0 ? 0 : (a.reverse ? a.T - 1 - s : s);
+    const int tt = s < 0 ? 0 : ((EMB && a.reverse) ? a.T - 1 - s : s);
     const __bf16* scr = sc + ((s + 1) & 1) * (NCH * NRP * 8);             // dgh_{s+1}, written by the previous iteration
     __bf16* scw = sc + (s & 1) * (NCH * NRP * 8);
     // HBM operands of the epilogue items (tile pairs x 4 M tiles; saved gates, previous state, external gradient) run 2 items
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void row_gru_bwd_kernel(RowGruBwdArgs a) {
       const __bf16* gp = a.gates + (long)s * 4 * RH + grow[i] * H + u;
 #pragma unroll
       for (int q = 0; q < 4; q++) o.g[q] = ldnt_bf16x8(gp + q * RH);
-      if (a.ext) o.ex = ldnt_bf16x8(a.ext + base);
+      if constexpr (!EMB) o.ex = ldnt_bf16x8(a.ext + base);
       o.hp[0] = ldnt_f4(a.HN + base); o.hp[1] = ldnt_f4(a.HN + base + 4);
     };
     if (s >= 0) { ldops(ops[0], 0); ldops(ops[1], 1); }
@@ -355,12 +363,12 @@ __global__ __launch_bounds__(256, 1) void row_gru_bwd_kernel(RowGruBwdArgs a) {
       float lastg[8];
 #pragma unroll
       for (int e = 0; e < 8; e++) lastg[e] = 0.f;
-      if (last && a.dh_last) ld_f32x8(a.dh_last + grow[i] * a.last_ld + u, lastg);
+      if constexpr (EMB) { if (last && a.dh_last) ld_f32x8(a.dh_last + grow[i] * a.last_ld + u, lastg); }
       float dr[8], dz[8], dn[8], dnr[8], dq[8];
 #pragma unroll
       for (int e = 0; e < 8; e++) {
         const float gr = (float)o.g[0][e], gz = (float)o.g[1][e], gn = (float)o.g[2][e], gh = (float)o.g[3][e];
-        const float d = dh[e] + cz[e] + (a.ext ? (float)o.ex[e] : 0.f) + lastg[e];
+        const float d = dh[e] + cz[e] + (EMB ? lastg[e] : (float)o.ex[e]);
         dn[e] = d * (1.0f - gz) * (1.0f - gn * gn);
         dz[e] = d * (hp[e] - gn) * gz * (1.0f - gz);
         dr[e] = dn[e] * gh * gr * (1.0f - gr);
@@ -372,8 +380,13 @@ __global__ __launch_bounds__(256, 1) void row_gru_bwd_kernel(RowGruBwdArgs a) {
       __bf16* sp = scw + ((long)(u >> 3) * NRP + i * 16 + erow) * 8;
       st_bf16x8(sp, dr); st_bf16x8(sp + (long)(H / 8) * NRP * 8, dz); st_bf16x8(sp + (long)(2 * H / 8) * NRP * 8, dnr);
       if (ok[i]) {
-        __bf16* ph = a.dgh + (long)s * R3H + grow[i] * (3 * H) + u;
-        stnt_bf16x8(ph, dr); stnt_bf16x8(ph + H, dz); stnt_bf16x8(ph + 2 * H, dnr);
+        if constexpr (EMB) {
+          __bf16* ph = a.dgh + (long)s * R3H + grow[i] * (3 * H) + u;
+          stnt_bf16x8(ph, dr); stnt_bf16x8(ph + H, dz); stnt_bf16x8(ph + 2 * H, dnr);
+        } else {
+          // forward time order: the r and z thirds of dgh ARE dgi's (same rows, same step) -- only the n third (dn * r) goes out
+          stnt_bf16x8(a.dgh + (long)s * RH + grow[i] * H + u, dnr);
+        }
         __bf16* pi = a.dgi + (long)tt * R3H + grow[i] * (3 * H) + u;
         stnt_bf16x8(pi, dr); stnt_bf16x8(pi + H, dz); stnt_bf16x8(pi + 2 * H, dn);
       }
@@ -382,26 +395,26 @@ __global__ __launch_bounds__(256, 1) void row_gru_bwd_kernel(RowGruBwdArgs a) {
   }
 }
 
-template <int H>
+template <int H, bool EMB>
 static int launch_fwd(const RowGruFwdArgs& a, hipStream_t s) {
   const size_t lds = (size_t)(2 * NRP * (H + 16) + NRP * NT16LD) * sizeof(__bf16);
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(row_gru_fwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PTV_ERR_LAUNCH;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(row_gru_fwd_kernel<H, EMB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PTV_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL((row_gru_fwd_kernel<H>), dim3((unsigned)((a.R + NRP - 1) / NRP)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((row_gru_fwd_kernel<H, EMB>), dim3((unsigned)((a.R + NRP - 1) / NRP)), dim3(256), lds, s, a);
   return PTV_OK;
 }
-template <int H>
+template <int H, bool EMB>
 static int launch_bwd(const RowGruBwdArgs& a, hipStream_t s) {
   const size_t lds = (size_t)NRP * H * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(row_gru_bwd_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PTV_ERR_LAUNCH;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(row_gru_bwd_kernel<H, EMB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PTV_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL((row_gru_bwd_kernel<H>), dim3((unsigned)((a.R + NRP - 1) / NRP)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((row_gru_bwd_kernel<H, EMB>), dim3((unsigned)((a.R + NRP - 1) / NRP)), dim3(256), lds, s, a);
   return PTV_OK;
 }
 
@@ -417,7 +430,10 @@ extern "C" int ptv_row_gru_persist_fwd(int H, const void* w_hh, const void* w_x,
   RowGruFwdArgs a{(const bf16x8*)w_hh, (const bf16x8*)w_x, b_hh, b_ih, (const __bf16*)gc, x, x_step, lengths, HN, (__bf16*)HN16,
                   (__bf16*)gates, out, out_ld, (int)R, T & 0xff, reverse, T >> 8};
   const int pi = prof::want(3, (int)R, H) ? prof::begin((hipStream_t)stream) : -1;
-  PTV_TRY(H == 512 ? launch_fwd<512>(a, (hipStream_t)stream) : launch_fwd<128>(a, (hipStream_t)stream));
+  // H = 512 is the notes GRU (gc given, bias folded, dense); H = 128 the note-summary GRU (b_ih given, mask / reverse / final state)
+  if (H == 512 && (!gc || b_ih || lengths || reverse || out)) return PTV_ERR_UNSUPPORTED;
+  if (H == 128 && (gc || !b_ih)) return PTV_ERR_UNSUPPORTED;
+  PTV_TRY(H == 512 ? (launch_fwd<512, false>(a, (hipStream_t)stream)) : (launch_fwd<128, true>(a, (hipStream_t)stream)));
   if (pi >= 0) prof::end(pi, (hipStream_t)stream, 2.0 * R * 3.0 * H * (H + NE) * (T & 0xff));
   PTV_CHECK_LAUNCH();
   return PTV_OK;
@@ -433,7 +449,9 @@ extern "C" int ptv_row_gru_persist_bwd(int H, const void* wt, const float* HN, c
   RowGruBwdArgs a{(const bf16x8*)wt, HN, (const __bf16*)gates, (const __bf16*)ext, dh_last, last_ld, (__bf16*)dgi, (__bf16*)dgh, dh0,
                   (__bf16*)scratch, (int)R, T, reverse};
   const int pi = prof::want(4, (int)R, H) ? prof::begin((hipStream_t)stream) : -1;
-  PTV_TRY(H == 512 ? launch_bwd<512>(a, (hipStream_t)stream) : launch_bwd<128>(a, (hipStream_t)stream));
+  if (H == 512 && (!ext || dh_last || reverse)) return PTV_ERR_UNSUPPORTED;
+  if (H == 128 && ext) return PTV_ERR_UNSUPPORTED;
+  PTV_TRY(H == 512 ? (launch_bwd<512, false>(a, (hipStream_t)stream)) : (launch_bwd<128, true>(a, (hipStream_t)stream)));
   if (pi >= 0) prof::end(pi, (hipStream_t)stream, 2.0 * R * 3.0 * H * H * (T - 1 + (dh0 ? 1 : 0)));
   PTV_CHECK_LAUNCH();
   return PTV_OK;

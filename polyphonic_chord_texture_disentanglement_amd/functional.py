@@ -1082,7 +1082,7 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     if (notes_persist_ok(prec, Hn, E, st['gates_n'].dtype) and dNSUM.dtype == BF16 and HN.dtype == F32):
         pk = notes_packs(w_ih_n, w_hh_n, Ht)
         dgi_n = _empty(15, R, 3 * Hn, dev=dev, dtype=BF16)
-        dgh_n = _empty(15, R, 3 * Hn, dev=dev, dtype=BF16)
+        dgh_n = _empty(15, R, Hn, dev=dev, dtype=BF16)          # n third only: the r / z thirds of dgh are dgi's
         dHN0 = _empty(R, Hn, dev=dev)
         scratch = _empty(lib().ptv_notes_gru_persist_scratch_elems(R), dev=dev, dtype=BF16)
         call('ptv_notes_gru_persist_bwd', ptr(pk['wt']), ptr(HN), ptr(st['gates_n']), ptr(dNSUM), ptr(dgi_n), ptr(dgh_n), ptr(dHN0),
@@ -1098,8 +1098,16 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     gemm_dx(dHN0, w_tn, out=dNS, acc=True, prec=prec)
 
     def notes_wgrads():
-        # bias_hh gradient = column sums of dgh (its r and z thirds equal dgi's), taken inside the W_hh product
-        wgrad_b('dec_notes_gru.weight_hh_l0', 'dec_notes_gru.bias_hh_l0', dgh_n.view(M, 3 * Hn), HNo[:15].view(M, Hn))
+        # bias_hh gradient = column sums of dgh (its r and z thirds equal dgi's), taken inside the W_hh products
+        if dgh_n.shape[-1] == Hn:                                # persistent BPTT: dgh holds its n third only
+            for name in ('dec_notes_gru.weight_hh_l0', 'dec_notes_gru.bias_hh_l0'):
+                if G[name] is None:
+                    G[name] = _gbuf(P[name])
+            gw, gb, h_op = G['dec_notes_gru.weight_hh_l0'], G['dec_notes_gru.bias_hh_l0'], HNo[:15].view(M, Hn)
+            wgrad_bias(dgi_n.view(M, 3 * Hn)[:, :2 * Hn], h_op, gw[:2 * Hn], gb[:2 * Hn], prec)
+            wgrad_bias(dgh_n.view(M, Hn), h_op, gw[2 * Hn:], gb[2 * Hn:], prec)
+        else:
+            wgrad_b('dec_notes_gru.weight_hh_l0', 'dec_notes_gru.bias_hh_l0', dgh_n.view(M, 3 * Hn), HNo[:15].view(M, Hn))
         bgrad('dec_notes_gru.bias_ih_l0', dGC)
         wgrad('dec_notes_gru.weight_ih_l0', dGC, NSf_op, slice(0, Ht))
         wgrad('dec_notes_gru.weight_ih_l0', dgi_n.view(M, 3 * Hn), tok_op, slice(Ht, None))

@@ -86,11 +86,15 @@ def _free_packs(P, Ht):
     return _PACKS.put(src, stamp, pk)
 
 
-def gru_step(prec, hprev, gi, gi_ld, w_hh, b_hh, hout, *, gi2=None, gates=None, plane=0, lengths=None, t=0, gi_idx=None, hout16=None):
+def gru_step(prec, hprev, gi, gi_ld, w_hh, b_hh, hout, *, gi2=None, gates=None, plane=0, lengths=None, t=0, gi_idx=None, hout16=None,
+             hprev16=None):
+    """one GRU cell on a window of rows; with a bf16 copy of the previous state (hprev16) the weight may be its bf16 shadow"""
     M, H = hout.shape
-    call('ptv_gru_step_fwd', prec, M, H, ptr(hprev), hprev.stride(0), None, ptr(hout16), ptr(gi), gi_ld, ptr(gi2),
+    if hprev16 is None and w_hh.dtype == torch.bfloat16:
+        raise ValueError('a bf16 weight shadow needs the bf16 copy of the previous state')
+    call('ptv_gru_step_fwd', prec, M, H, ptr(hprev), hprev.stride(0), ptr(hprev16), ptr(hout16), ptr(gi), gi_ld, ptr(gi2),
          gi2.stride(0) if gi2 is not None else 0, ptr(w_hh), ptr(b_hh), ptr(hout), hout.stride(0), ptr(gates), plane,
-         ptr(lengths), t, ptr(gi_idx), F_._gru_flags(gates, gi, gi2), stream_ptr())
+         ptr(lengths), t, ptr(gi_idx), F_._gru_flags(gates, gi, gi2, w=w_hh), stream_ptr())
 
 
 class DecoderStepFn(torch.autograd.Function):
@@ -164,9 +168,13 @@ class DecoderStepFn(torch.autograd.Function):
         if fast and train:                                       # bf16 state copies: MFMA operands of the batched backward
             HN16 = _empty(16, R, Hn, dev=dev, dtype=torch.bfloat16)
             HD16 = _empty(6, M, Hd, dev=dev, dtype=torch.bfloat16)
-            if Ht % 8 == 0:
-                NS16 = _empty(33, B, Ht, dev=dev, dtype=torch.bfloat16)
-                call('ptv_cast_bf16', ptr(NS[0]), ptr(NS16[0]), B * Ht, st)
+        if fast and Ht % 8 == 0:                                 # ... and of the time GRU / the per-step products in the loop
+            NS16 = _empty(33, B, Ht, dev=dev, dtype=torch.bfloat16)
+            call('ptv_cast_bf16', ptr(NS[0]), ptr(NS16[0]), B * Ht, st)
+        # per time step the loop runs four M = B products whose cost is reading the weights: their bf16 shadows halve it
+        w_hh_t = F_._W(P['dec_time_gru.weight_hh_l0'], prec) if NS16 is not None else P['dec_time_gru.weight_hh_l0']
+        w_ih_t16, w_tn16, w_ih_n16 = (F_._W(w_ih_t, prec), F_._W(P['dec_time_to_notes_hid.weight'], prec), F_._W(w_ih_n, prec)) if fast \
+            else (w_ih_t, P['dec_time_to_notes_hid.weight'], w_ih_n)
         replay = (fast and train and FREE_REPLAY and F_.notes_persist_ok(prec, Hn, E) and Hd == 64 and F_.FUSED_DUR and NS16 is not None
                   and force_dur is None and force_pitch is None)
         if fast:
@@ -183,12 +191,13 @@ class DecoderStepFn(torch.autograd.Function):
         copy2d(PRED[0], TOK[0])
         for t in range(32):
             rows = slice(t * B, (t + 1) * B)
-            gi = gemm(TOKS[t], w_ih_t[:, :2 * He], prec=prec)
-            gru_step(prec, NS[t], gi, 3 * Ht, P['dec_time_gru.weight_hh_l0'], P['dec_time_gru.bias_hh_l0'], NS[t + 1], gi2=zg,
-                     gates=gates_t[t] if train else None, plane=B * Ht, hout16=NS16[t + 1] if NS16 is not None else None)
-            ns = NS[t + 1]
-            gemm(ns, P['dec_time_to_notes_hid.weight'], HN[0][rows], bias=P['dec_time_to_notes_hid.bias'], prec=prec)
-            GCt = gemm(ns, w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec)
+            gi = gemm(TOKS[t], w_ih_t16[:, :2 * He], prec=prec)
+            gru_step(prec, NS[t], gi, 3 * Ht, w_hh_t, P['dec_time_gru.bias_hh_l0'], NS[t + 1], gi2=zg,
+                     gates=gates_t[t] if train else None, plane=B * Ht, hout16=NS16[t + 1] if NS16 is not None else None,
+                     hprev16=NS16[t] if NS16 is not None else None)
+            ns = NS16[t + 1] if NS16 is not None else NS[t + 1]
+            gemm(ns, w_tn16, HN[0][rows], bias=P['dec_time_to_notes_hid.bias'], prec=prec)
+            GCt = gemm(ns, w_ih_n16[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec)
             if fast:
                 # all 15 note steps of this time step in ONE launch (csrc/freerun.hip); then the next time-step token
                 mask = 0

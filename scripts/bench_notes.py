@@ -21,7 +21,8 @@ wg_h, wg_t, wt = F_.pack_mfma_b(w_hh, pairs=True), F_.pack_mfma_b(w_tok, pairs=T
 HN = torch.zeros(T + 1, R, H, device=dev); HN[0] = rn(R, H) * 0.5
 HN16 = torch.zeros(T + 1, R, H, device=dev, dtype=bf)
 gates = torch.zeros(T, 4, R, H, device=dev, dtype=bf)
-dgi = torch.zeros(T, R, 3 * H, device=dev, dtype=bf); dgh = torch.zeros_like(dgi)
+dgi = torch.zeros(T, R, 3 * H, device=dev, dtype=bf); dgh = torch.zeros(T, R, H, device=dev, dtype=bf)
+dgh_steps = torch.zeros_like(dgi)
 dh0 = torch.zeros(R, H, device=dev)
 scratch = torch.empty(lib().ptv_notes_gru_persist_scratch_elems(R), device=dev, dtype=bf)
 w16, wt16, wtok16 = w_hh.to(bf).contiguous(), w_hh.t().contiguous().to(bf), w_tok.to(bf)
@@ -58,7 +59,7 @@ def s_fwd():
 
 def s_bwd():
     call('ptv_gru_seq_bwd', 1, R, H, T, ptr(HN), ptr(gates), ptr(wt16), ptr(ext), ext.stride(0), ext.stride(1), None, 0, None, 0, 0, 0, None,
-         ptr(dgi), ptr(dgh), ptr(dhz), ptr(dh0), 0, FL | 64, stream_ptr())
+         ptr(dgi), ptr(dgh_steps), ptr(dhz), ptr(dh0), 0, FL | 64, stream_ptr())
 
 
 for name, fn in (('forward  per-step kernels + token product', s_fwd), ('forward  persistent', p_fwd),
@@ -66,9 +67,10 @@ for name, fn in (('forward  per-step kernels + token product', s_fwd), ('forward
     t = timeit(fn)
     print('R=%d T=%d  %-42s %8.1f us  (%.1f us per step)' % (R, T, name, t, t / T), flush=True)
 
-for name, dbg in (('fwd persistent: 8 waves, no operand prefetch', 16), ('fwd persistent: no stagger', 8), ('fwd persistent: no epilogue', 2), ('fwd persistent: no global stores', 4),
-                  ('fwd persistent: no products, no stores', 5), ('fwd persistent: nothing but prefetch + token staging', 3)):
+for name, dbg in (('fwd persistent: default', 0), ('fwd persistent: no stagger', 8), ('fwd persistent: no gate stores', 4),
+                  ('fwd persistent: gate stores as 1-KB-contiguous wave stores (wrong layout, timing only)', 32), ('fwd persistent: default', 0)):
     def f(dbg=dbg):
-        call('ptv_notes_gru_persist_fwd', ptr(wg_h), ptr(wg_t), ptr(b_hh), ptr(gc), ptr(emb), ptr(HN), ptr(HN16), ptr(gates), R, T | (dbg << 8), stream_ptr())
+        call('ptv_row_gru_persist_fwd', 512, ptr(wg_h), ptr(wg_t), ptr(b_hh), None, ptr(gc), ptr(emb), R * 128, None, ptr(HN), ptr(HN16), ptr(gates),
+             None, 0, R, T | (dbg << 8), 0, stream_ptr())
     t = timeit(f)
-    print('R=%d T=%d  %-52s %8.1f us  (%.1f us per step)' % (R, T, name, t, t / T), flush=True)
+    print('R=%d T=%d  %-90s %8.1f us  (%.1f us per step)' % (R, T, name, t, t / T), flush=True)
