@@ -324,6 +324,8 @@ int ptv_slerp_path(const float* z1, const float* z2, float* out, int B, int D, i
  *            TOK [15][R][128] (slot 0 rows of t = first token, written by the caller), PRED [16][R][128],
  *            xhat [B][32][16][6] int64, plen [R] int32 (zeroed), force_pitch [15][R] or NULL, force_dur [5][M] or NULL,
  *            HN16 [16][R][512] bf16 or NULL, HD16 [6][M][64] bf16 or NULL (bf16 state copies for the backward; HD16 replaces HD[1..5]) }
+ *     io[17] = NULL (timing experiments), io[18] = NULL or fp32 [B][2048] = [initial state | gc] of this time step (then io[0] is
+ *     ignored and slot 0 of HN is written by the kernel): io has 19 entries;
  *     with R = 32*B, M = 15*R; the rows of time step t are [t*B, (t+1)*B).  coin_mask bit n = feed the ground-truth note n+1
  *     (teacher-forcing coin, ptvae.py:420).  train = 0 skips what only the backward reads (HN, gates, HD, TOK); train = 2 stores only
  *     the fed tokens TOK: the caller then recomputes states and gates for ALL rows with the batched kernels (ptv_notes_gru_persist_fwd,

@@ -143,7 +143,8 @@ __global__ void pack_b_kernel(const float* __restrict__ W, long ld, int N, int K
 struct NoteLoopArgs {
   const bf16x8 *wg_h, *wg_t, *wp, *wd_h, *wd_p, *wdur;
   const float *b_hh_n, *b_p, *b_dh, *b_hh_d, *tab0, *tab, *w_out, *b_out, *w_embT, *b_emb;
-  const float* gc;                 // [B][1536] hoisted input part of the notes GRU for this t (b_ih included)
+  const float* gc; long ld_gc;     // hoisted input part of the notes GRU for this t (b_ih included): row b at gc + b*ld_gc, 1536 wide
+  const float* h0; long ld_h0;     // initial notes-GRU state of this t: row b at h0 + b*ld_h0 (null: slot 0 of HN holds it already)
   const float* emb;                // ground-truth embedding, step-major [16][R][128]; null in inference
   float* HN; __bf16* gates_n; float* pitch; long ld_pitch; float* HD; __bf16* gates_d; float* dur; int* idx;
   float* TOK; float* PRED; long* xhat; int* plen;
@@ -191,7 +192,10 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
   if (tid < 2) wo[2 * FHD + tid] = a.b_out[tid];
   for (int i = tid; i < FP * (FHN / 4); i += 256) {
     const int row = i / (FHN / 4), c4 = (i % (FHN / 4)) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(a.HN + ((long)t * B + min(r0 + row, B - 1)) * FHN + c4);
+    const int rb = min(r0 + row, B - 1);
+    const float4 v = a.h0 ? *reinterpret_cast<const float4*>(a.h0 + (long)rb * a.ld_h0 + c4)
+                          : *reinterpret_cast<const float4*>(a.HN + ((long)t * B + rb) * FHN + c4);
+    if (a.h0 && r0 + row < B) *reinterpret_cast<float4*>(a.HN + ((long)t * B + rb) * FHN + c4) = v;   // slot 0 of HN for the backward
     *reinterpret_cast<float4*>(&hf[row][c4]) = v;
     st_bf16x4_lds(&h16[0][row][c4], v.x, v.y, v.z, v.w);
     if (a.train && a.HN16 && r0 + row < B) st_bf16x4_lds(a.HN16 + ((long)t * B + r0 + row) * FHN + c4, v.x, v.y, v.z, v.w);
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         const int u = (ut0 + j) * 16 + eq * 4;
-        const float* g = a.gc + (long)rE * (3 * FHN);
+        const float* g = a.gc + (long)rE * a.ld_gc;
         gR[j] = *reinterpret_cast<const float4*>(g + u); gZ[j] = *reinterpret_cast<const float4*>(g + FHN + u); gN[j] = *reinterpret_cast<const float4*>(g + 2 * FHN + u);
         bR[j] = *reinterpret_cast<const float4*>(a.b_hh_n + u); bZ[j] = *reinterpret_cast<const float4*>(a.b_hh_n + FHN + u);
         bN[j] = *reinterpret_cast<const float4*>(a.b_hh_n + 2 * FHN + u);
@@ -266,7 +270,12 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
       }
     }
     lds_barrier();
-    // ================= P2: pitch head (9 tiles over 4 waves) + dur_hid part 1 =================
+    // ================= P2: pitch head (9 tiles over 4 waves) + the state part of dur_hid_linear (one tile per wave) =================
+    f32x4 accD[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    {
+      const int tl[1] = {wave};
+      panel_mma<1, 16, 8>(a.wd_h, tl, &h16[nxt][0][0], H16LD, accD);
+    }
     for (int nt = wave; nt < ((a.dbg & 4) ? 0 : 9); nt += 4) {
       f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
       const int tl[1] = {nt};
@@ -306,13 +315,11 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
     }
     // ================= P4: dur_hid_linear([h | logits]) -> initial duration state (wave w = units w*16..) =================
     {
-      f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
       const int tl[1] = {wave};
-      panel_mma<1, 16, 8>(a.wd_h, tl, &h16[nxt][0][0], H16LD, acc);
-      panel_mma<1, 5, 8>(a.wd_p, tl, &pit16[0][0], P16LD, acc);
+      panel_mma<1, 5, 8>(a.wd_p, tl, &pit16[0][0], P16LD, accD);               // + the logits part (K = 130 padded to 160)
       const int u = wave * 16 + ckq * 4;
       const float4 b4 = *reinterpret_cast<const float4*>(a.b_dh + u);
-      const float h[4] = {acc[0][0] + b4.x, acc[0][1] + b4.y, acc[0][2] + b4.z, acc[0][3] + b4.w};
+      const float h[4] = {accD[0][0] + b4.x, accD[0][1] + b4.y, accD[0][2] + b4.z, accD[0][3] + b4.w};
       *reinterpret_cast<float4*>(&hdf[crow][u]) = make_float4(h[0], h[1], h[2], h[3]);
       st_bf16x4_lds(&hd16[0][crow][u], h[0], h[1], h[2], h[3]);
       if (a.train && okC) {
@@ -557,12 +564,12 @@ extern "C" int ptv_pack_mfma_b(const float* W, long ld, int N, int K, void* out,
 }
 
 // w[16]: wg_h, wg_t, wp, wd_h, wd_p, wdur (packed bf16), b_hh_n, b_p, b_dh, b_hh_d, tab0, tab, w_out, b_out, w_embT, b_emb
-// io[17]: gc, emb, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, force_pitch, force_dur, HN16, HD16
+// io[19]: gc, emb, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, force_pitch, force_dur, HN16, HD16, dbg words, h0gc
 extern "C" int ptv_free_note_loop(const void* const* w, const void* const* io, long ld_pitch, int B, int t, unsigned coin_mask, int train,
                                   void* stream) {
   if (!w || !io || B <= 0 || t < 0 || t >= 32) return PTV_ERR_ARG;
   for (int i = 0; i < 16; i++) if (!w[i]) return PTV_ERR_ARG;
-  if (!io[0] || !io[2] || !io[4] || !io[7] || !io[8] || !io[9] || !io[10] || !io[11] || !io[12]) return PTV_ERR_ARG;
+  if ((!io[0] && !io[18]) || !io[2] || !io[4] || !io[7] || !io[8] || !io[9] || !io[10] || !io[11] || !io[12]) return PTV_ERR_ARG;
   if ((train & 3) == 1 && (!io[3] || !io[5] || !io[6])) return PTV_ERR_ARG;
   if (coin_mask && !io[1]) return PTV_ERR_ARG;
   NoteLoopArgs a{};
@@ -571,7 +578,11 @@ extern "C" int ptv_free_note_loop(const void* const* w, const void* const* io, l
   a.b_hh_n = (const float*)w[6]; a.b_p = (const float*)w[7]; a.b_dh = (const float*)w[8]; a.b_hh_d = (const float*)w[9];
   a.tab0 = (const float*)w[10]; a.tab = (const float*)w[11]; a.w_out = (const float*)w[12]; a.b_out = (const float*)w[13];
   a.w_embT = (const float*)w[14]; a.b_emb = (const float*)w[15];
-  a.gc = (const float*)io[0]; a.emb = (const float*)io[1]; a.HN = (float*)io[2]; a.gates_n = (__bf16*)io[3];
+  // io[18] (or NULL): [h0 | gc] of this time step as one fp32 [B][2048] matrix (one product for both, dec_time_to_notes_hid and the
+  // hoisted part of W_ih stacked); then io[0] is ignored and slot 0 of HN is written here
+  a.h0 = (const float*)io[18]; a.ld_h0 = 4 * FHN;
+  a.gc = a.h0 ? a.h0 + FHN : (const float*)io[0]; a.ld_gc = a.h0 ? 4 * FHN : 3 * FHN;
+  a.emb = (const float*)io[1]; a.HN = (float*)io[2]; a.gates_n = (__bf16*)io[3];
   a.pitch = (float*)io[4]; a.ld_pitch = ld_pitch; a.HD = (float*)io[5]; a.gates_d = (__bf16*)io[6]; a.dur = (float*)io[7];
   a.idx = (int*)io[8]; a.TOK = (float*)io[9]; a.PRED = (float*)io[10]; a.xhat = (long*)io[11]; a.plen = (int*)io[12];
   a.force_pitch = (const int*)io[13]; a.force_dur = (const int*)io[14]; a.HN16 = (__bf16*)io[15]; a.HD16 = (__bf16*)io[16];

@@ -49,7 +49,8 @@ FREE_REPLAY = os.environ.get('PTV_FREE_REPLAY', '1') not in ('0', 'false', 'off'
 _PACKS = F_.PackCache()
 _PACK_SRC = ('dec_notes_gru.weight_hh_l0', 'dec_notes_gru.weight_ih_l0', 'pitch_out_linear.weight', 'dur_hid_linear.weight',
              'dec_dur_gru.weight_hh_l0', 'note_embedding.weight', 'dec_notes_emb_gru.weight_ih_l0', 'dec_notes_emb_gru.weight_hh_l0',
-             'dec_notes_emb_gru.weight_ih_l0_reverse', 'dec_notes_emb_gru.weight_hh_l0_reverse')
+             'dec_notes_emb_gru.weight_ih_l0_reverse', 'dec_notes_emb_gru.weight_hh_l0_reverse', 'dec_time_to_notes_hid.weight',
+             'dec_time_to_notes_hid.bias', 'dec_notes_gru.bias_ih_l0')
 
 
 def free_persist_ok(prec, E, He, Hn, Hd, NP):
@@ -82,7 +83,9 @@ def _free_packs(P, Ht):
     pk = dict(wg_h=_pack(P['dec_notes_gru.weight_hh_l0']), wg_t=_pack(w_ih_n[:, Ht:]), wp=_pack(P['pitch_out_linear.weight']),
               wd_h=_pack(w_dh[:, :512]), wd_p=_pack(w_dh[:, 512:]), wdur=_pack(P['dec_dur_gru.weight_hh_l0']), w_embT=w_embT,
               e_ih=_pack(P['dec_notes_emb_gru.weight_ih_l0']), e_hh=_pack(P['dec_notes_emb_gru.weight_hh_l0']),
-              e_ih_r=_pack(P['dec_notes_emb_gru.weight_ih_l0_reverse']), e_hh_r=_pack(P['dec_notes_emb_gru.weight_hh_l0_reverse']))
+              e_ih_r=_pack(P['dec_notes_emb_gru.weight_ih_l0_reverse']), e_hh_r=_pack(P['dec_notes_emb_gru.weight_hh_l0_reverse']),
+              w_cat=torch.cat([P['dec_time_to_notes_hid.weight'], w_ih_n[:, :Ht]], 0).to(torch.bfloat16).contiguous(),
+              b_cat=torch.cat([P['dec_time_to_notes_hid.bias'], P['dec_notes_gru.bias_ih_l0']], 0).contiguous())
     return _PACKS.put(src, stamp, pk)
 
 
@@ -132,12 +135,13 @@ class DecoderStepFn(torch.autograd.Function):
         HN = _empty(16, R, Hn, dev=dev)
         gates_n = _empty(15, 4, R, Hn, dev=dev, dtype=F_._act_dtype(prec, Hn)) if train else None
         TOK = _empty(15, R, E, dev=dev)
-        PRED = _zeros(16, R, E, dev=dev)
+        PRED = None                                                # allocated below (zero-filled only where something may stay unwritten)
         xhat = torch.full((B, 32, 16, 6), 2, device=dev, dtype=torch.long)
         xhat[:, :, :, 0] = 130
         xhat[:, :, 0, 0] = 128
         plen = torch.zeros(R, device=dev, dtype=torch.int32)
         fast = free_persist_ok(prec, E, He, Hn, Hd, NP) and (not train or F_._act_dtype(prec, Hn) == torch.bfloat16)
+        PRED = _empty(16, R, E, dev=dev) if fast else _zeros(16, R, E, dev=dev)      # the persistent note loop writes every slot
         pitch = _empty(M, F_._pad8(NP), dev=dev)[:, :NP] if fast else _empty(M, NP, dev=dev)
         HD = _empty(6, M, Hd, dev=dev)
         gates_d = _empty(5, 4, M, Hd, dev=dev, dtype=F_._act_dtype(prec, Hd)) if train else None
@@ -145,8 +149,6 @@ class DecoderStepFn(torch.autograd.Function):
         dur = _empty(M, 5, 2, dev=dev)
         dur2 = dur.view(M, 10)
         need_resum = inference or not all(coin_time)
-        XH = [_zeros(17, R, He, dev=dev) for _ in range(2)] if need_resum else None
-        XG = ([torch.zeros(16, 4, R, He, device=dev, dtype=F_._act_dtype(prec, He)) for _ in range(2)] if train else [None, None]) if need_resum else None
 
         if inference:
             sos = _sos_grid(dev)
@@ -177,6 +179,15 @@ class DecoderStepFn(torch.autograd.Function):
             else (w_ih_t, P['dec_time_to_notes_hid.weight'], w_ih_n)
         replay = (fast and train and FREE_REPLAY and F_.notes_persist_ok(prec, Hn, E) and Hd == 64 and F_.FUSED_DUR and NS16 is not None
                   and force_dur is None and force_pitch is None)
+        XH = XG = None
+        if need_resum and replay:                                # the batched recompute writes every row of every slot but slot 0
+            XH = [_empty(17, R, He, dev=dev) for _ in range(2)]
+            for d in range(2):
+                XH[d][0].zero_()
+            XG = [_empty(16, 4, R, He, dev=dev, dtype=torch.bfloat16) for _ in range(2)]
+        elif need_resum:
+            XH = [_zeros(17, R, He, dev=dev) for _ in range(2)]
+            XG = [torch.zeros(16, 4, R, He, device=dev, dtype=F_._act_dtype(prec, He)) for _ in range(2)] if train else [None, None]
         if fast:
             pk = _free_packs(P, Ht)
             wl = F_._parr([pk['wg_h'], pk['wg_t'], pk['wp'], pk['wd_h'], pk['wd_p'], pk['wdur'], b_hh_n, P['pitch_out_linear.bias'],
@@ -196,15 +207,22 @@ class DecoderStepFn(torch.autograd.Function):
                      gates=gates_t[t] if train else None, plane=B * Ht, hout16=NS16[t + 1] if NS16 is not None else None,
                      hprev16=NS16[t] if NS16 is not None else None)
             ns = NS16[t + 1] if NS16 is not None else NS[t + 1]
-            gemm(ns, w_tn16, HN[0][rows], bias=P['dec_time_to_notes_hid.bias'], prec=prec)
-            GCt = gemm(ns, w_ih_n16[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec)
+            if fast:
+                # initial notes-GRU state and the hoisted input part in ONE product against the stacked weights ([512 | 1536] rows):
+                # 256 blocks, no split-K, no zero fill
+                H0GC = gemm(ns, pk['w_cat'], bias=pk['b_cat'], prec=prec)
+                GCt = None
+            else:
+                gemm(ns, w_tn16, HN[0][rows], bias=P['dec_time_to_notes_hid.bias'], prec=prec)
+                GCt = gemm(ns, w_ih_n16[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec)
             if fast:
                 # all 15 note steps of this time step in ONE launch (csrc/freerun.hip); then the next time-step token
                 mask = 0
                 if not inference:
                     for n in range(14):
                         mask |= int(bool(coin_notes[t][n])) << n
-                io = F_._parr([GCt, emb3, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, force_pitch, force_dur, HN16, HD16])
+                io = F_._parr([GCt, emb3, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, force_pitch, force_dur, HN16, HD16,
+                               None, H0GC])
                 call('ptv_free_note_loop', wl, io, pitch.stride(0), B, t, mask, 2 if replay else int(train), st)
                 if t == 31:
                     break

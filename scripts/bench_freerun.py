@@ -38,7 +38,7 @@ PRED = torch.zeros(16, R, 128, device=dev)
 xhat = torch.zeros(B, 32, 16, 6, device=dev, dtype=torch.long)
 plen = torch.zeros(R, device=dev, dtype=torch.int32)
 dbg_out = torch.zeros(3 * ((B + 15) // 16), device=dev, dtype=torch.long)
-io = F_._parr([GC, None, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, None, None, None, None, dbg_out])
+io = F_._parr([GC, None, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, None, None, None, None, dbg_out, None])
 
 
 def run(flags):
