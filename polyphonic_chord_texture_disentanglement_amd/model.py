@@ -59,7 +59,11 @@ class DisentangleVAE(PytorchModel):
     # ---- model.py:42-55
     def run(self, x, c, pr_mat, tfr1, tfr2, tfr3, confuse=True):
         refresh_weight_shadows()                         # bf16 operand copies of the flat parameter buffer (if any)
-        embedded_x, lengths = self.decoder.emb_x(x)
+        self.decoder.summaries_needed = tfr1 > 0             # with tfr1 = 0 no time step is fed a ground-truth note summary
+        try:
+            embedded_x, lengths = self.decoder.emb_x(x)
+        finally:
+            self.decoder.summaries_needed = True
         # the two encoders are independent of each other and of the embedding: sibling HIP streams
         # (autograd replays each branch's backward on the stream its forward ran on)
         s_chd, s_rhy = F_.Side(1), F_.Side(2)

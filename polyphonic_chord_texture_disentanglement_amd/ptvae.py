@@ -241,6 +241,7 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
         self._graphs = {}
         self._train_graphs = {}
         self._summary = None
+        self.summaries_needed = True       # emb_x() starts the ground-truth note summaries early unless told they are dead values
         self.last_dur_idx = None
 
     def _params(self):
@@ -286,9 +287,13 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
         # The ground-truth note summaries (packed bi-GRU over the embedded notes, ptvae.py:446-453) depend
         # on the embedding only: start them now on a sibling stream so they overlap the encoders;
         # decoder() picks the result up.
-        side = F_.Side(5)
-        xs = side(lambda: self._summarize(emb, lengths), emb, lengths)
-        self._summary = (emb, xs, side)
+        # (not when the caller knows that no time step will be teacher-forced -- DisentangleVAE.run with tfr1 = 0, the reference's
+        # schedule from its third batch on: the summaries are then dead values with zero gradient, ptvae.py:476-478)
+        self._summary = None
+        if self.summaries_needed:
+            side = F_.Side(5)
+            xs = side(lambda: self._summarize(emb, lengths), emb, lengths)
+            self._summary = (emb, xs, side)
         return emb.permute(2, 1, 0, 3), lengths.view(32, x.size(0)).t()
 
     def _summarize(self, emb, len32):
@@ -333,8 +338,10 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
         if cached is not None and cached[0].data_ptr() == emb.data_ptr() and cached[0].shape == emb.shape:
             xs = cached[1]
             cached[2].join()
-        else:
+        elif any(coins[1]):
             xs = self._summarize(emb, len32)
+        else:
+            xs = None                                                          # no time step reads a ground-truth summary
         if not all_tf:
             none_tf = not any(any(r) for r in coins[0]) and not any(coins[1])
             if self.use_graph and none_tf and self.force_trace is None and torch.is_grad_enabled():
