@@ -236,10 +236,7 @@ __global__ __launch_bounds__(256, 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
           const long o = (long)(n + 1) * RH + grow[i] * H + u;
           st_f32x8(a.HN + o, h);                                       // read back next step: default policy
           stnt_bf16x8(a.HN16 + o, h);
-          if (a.gates && (a.dbg & 32)) {                                 // experiment: the same bytes as 1-KB-contiguous wave stores
-            __bf16* gp = a.gates + (long)n * 4 * RH + (((((long)blockIdx.x * NPASS + p0) * 4 + i) * 4 + wave) * 4) * 512 + lane * 8;
-            stnt_bf16x8(gp, r); stnt_bf16x8(gp + 512, z); stnt_bf16x8(gp + 1024, nn); stnt_bf16x8(gp + 1536, hn);
-          } else if (a.gates && !(a.dbg & 4)) {
+          if (a.gates) {
             __bf16* gp = a.gates + (long)n * 4 * RH + grow[i] * H + u;
             stnt_bf16x8(gp, r); stnt_bf16x8(gp + RH, z); stnt_bf16x8(gp + 2 * RH, nn); stnt_bf16x8(gp + 3 * RH, hn);
           }

@@ -67,10 +67,9 @@ for name, fn in (('forward  per-step kernels + token product', s_fwd), ('forward
     t = timeit(fn)
     print('R=%d T=%d  %-42s %8.1f us  (%.1f us per step)' % (R, T, name, t, t / T), flush=True)
 
-for name, dbg in (('fwd persistent: default', 0), ('fwd persistent: no stagger', 8), ('fwd persistent: no gate stores', 4),
-                  ('fwd persistent: gate stores as 1-KB-contiguous wave stores (wrong layout, timing only)', 32), ('fwd persistent: default', 0)):
+for name, dbg in (('fwd persistent: default', 0), ('fwd persistent: no stagger of pass / k order', 8)):
     def f(dbg=dbg):
         call('ptv_row_gru_persist_fwd', 512, ptr(wg_h), ptr(wg_t), ptr(b_hh), None, ptr(gc), ptr(emb), R * 128, None, ptr(HN), ptr(HN16), ptr(gates),
              None, 0, R, T | (dbg << 8), 0, stream_ptr())
     t = timeit(f)
-    print('R=%d T=%d  %-90s %8.1f us  (%.1f us per step)' % (R, T, name, t, t / T), flush=True)
+    print('R=%d T=%d  %-60s %8.1f us  (%.1f us per step)' % (R, T, name, t, t / T), flush=True)
