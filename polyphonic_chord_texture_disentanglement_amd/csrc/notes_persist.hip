@@ -95,7 +95,7 @@ struct RowGruFwdArgs {
 // EMB = false: the notes GRU (hoisted input part gc, b_ih folded in, no mask, no final-state output); EMB = true: a direction of
 // dec_notes_emb_gru (b_ih, optional length mask, optional reversed time, final state)
 template <int H, bool EMB>
-__global__ __launch_bounds__(256, 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
+__global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
   constexpr int KBH = H / 32, NUT = H / 16, NPASS = H / 128, UTW = NUT / 4, HLD = H + 16, KT = KBH + 4;
   extern __shared__ __attribute__((aligned(16))) char nsm[];
   __bf16* h16 = reinterpret_cast<__bf16*>(nsm);                          // [2][64][HLD]
@@ -148,101 +148,124 @@ __global__ __launch_bounds__(256, 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
       const int ut0 = wave * UTW + p * 2;
       const int u = ut0 * 16 + eq * 8;                                   // this lane's first unit of the pass
       // acc[i][0..3] = r0 r1 z0 z1 (h and token parts summed), [4,5] = W_hn h, [6,7] = W_in token
-      f32x4 acc[4][8];
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int tl[6] = {ut0, ut0 + 1, NUT + ut0, NUT + 1 + ut0, 2 * NUT + ut0, 2 * NUT + 1 + ut0};
-      // epilogue operands of the pass (GC and the fp32 state of this lane's cells) are requested BEFORE the products: they come
-      // from HBM, and waiting for them per M tile in the epilogue exposed that latency 16 times per step
-      bf16x8 gq[4][3]; float4 hq[4][2];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        if constexpr (!EMB) {
-          const __bf16* g = a.gc + grow[i] * (3 * H) + u;
-#pragma unroll
-          for (int gt = 0; gt < 3; gt++) gq[i][gt] = ldnt_bf16x8(g + gt * H);
-        }
-        const float* hp = a.HN + (long)n * RH + grow[i] * H + u;
-        hq[i][0] = ldnt_f4(hp); hq[i][1] = ldnt_f4(hp + 4);
-      }
-      // software-pipelined stream of KBH + 4 k-blocks through a ring of 4 fragment buffers: the loads of k-block k+3 are issued
-      // before the MFMAs of k-block k (24 MFMAs = ~400 cycles per k-block against ~900 cycles of L2 latency)
-      bf16x8 b[4][6];
-      auto ldw = [&](bf16x8 (&d)[6], int k) {                            // k < KBH: W_hh block (k + krot) % KBH; else W_x block k - KBH
-#pragma unroll
-        for (int j = 0; j < 6; j++)
-          d[j] = k < KBH ? a.w_hh[((long)tl[j] * KBH + ((k + krot) & (KBH - 1))) * 64 + lane] : a.w_x[((long)tl[j] * 4 + (k - KBH)) * 64 + lane];
-      };
-      ldw(b[0], 0); ldw(b[1], 1); ldw(b[2], 2);
-#pragma unroll
-      for (int k = 0; k < KT; k++) {
-        if (k + 3 < KT) ldw(b[(k + 3) & 3], k + 3);
-        const bool tokpart = k >= KBH;
-        const __bf16* A = tokpart ? tok16 : hc;
-        const int lda = tokpart ? NT16LD : HLD, kb = tokpart ? k - KBH : ((k + krot) & (KBH - 1));
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const bf16x8 av = *reinterpret_cast<const bf16x8*>(A + (i * 16 + rl) * lda + kb * 32 + kq);
-#pragma unroll
-          for (int j = 0; j < 6; j++) {
-            const int slot = j < 4 ? j : (tokpart ? j + 2 : j);
-            acc[i][slot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[k & 3][j], av, acc[i][slot], 0, 0, 0);
+      // H = 128: the 4 M tiles of the panel in two halves (the fragments stream twice: 48 KB per wave and half) so that two
+      // workgroups fit the register file of a CU
+      constexpr int MH = H == 128 ? 2 : 4;
+#pragma unroll 1
+      for (int mh = 0; mh < 4; mh += MH) {
+      // the accumulators START at the biases (a lane's registers of a tile pair are 8 consecutive units of one row: the bias depends
+        // on the unit only), so the epilogue carries no bias registers
+        f32x4 acc[MH][8];
+        {
+          float bR[8], bZ[8], bN[8], bI[8];
+          ld_f32x8(a.b_hh + u, bR); ld_f32x8(a.b_hh + H + u, bZ); ld_f32x8(a.b_hh + 2 * H + u, bN);
+  #pragma unroll
+          for (int e = 0; e < 8; e++) bI[e] = 0.f;
+          if constexpr (EMB) {
+            float t8[8];
+            ld_f32x8(a.b_ih + u, t8);
+  #pragma unroll
+            for (int e = 0; e < 8; e++) bR[e] += t8[e];
+            ld_f32x8(a.b_ih + H + u, t8);
+  #pragma unroll
+            for (int e = 0; e < 8; e++) bZ[e] += t8[e];
+            ld_f32x8(a.b_ih + 2 * H + u, bI);
+          }
+  #pragma unroll
+          for (int i = 0; i < MH; i++) {
+            acc[i][0] = f32x4{bR[0], bR[1], bR[2], bR[3]}; acc[i][1] = f32x4{bR[4], bR[5], bR[6], bR[7]};
+            acc[i][2] = f32x4{bZ[0], bZ[1], bZ[2], bZ[3]}; acc[i][3] = f32x4{bZ[4], bZ[5], bZ[6], bZ[7]};
+            acc[i][4] = f32x4{bN[0], bN[1], bN[2], bN[3]}; acc[i][5] = f32x4{bN[4], bN[5], bN[6], bN[7]};
+            acc[i][6] = f32x4{bI[0], bI[1], bI[2], bI[3]}; acc[i][7] = f32x4{bI[4], bI[5], bI[6], bI[7]};
           }
         }
-      }
-      // ---- epilogue: GRU cell on this lane's cells of the pass
-      float bR[8], bZ[8], bN[8], bI[8];
-      ld_f32x8(a.b_hh + u, bR); ld_f32x8(a.b_hh + H + u, bZ); ld_f32x8(a.b_hh + 2 * H + u, bN);
-#pragma unroll
-      for (int e = 0; e < 8; e++) bI[e] = 0.f;
-      if constexpr (EMB) {
-        float t8[8];
-        ld_f32x8(a.b_ih + u, t8);
-#pragma unroll
-        for (int e = 0; e < 8; e++) bR[e] += t8[e];
-        ld_f32x8(a.b_ih + H + u, t8);
-#pragma unroll
-        for (int e = 0; e < 8; e++) bZ[e] += t8[e];
-        ld_f32x8(a.b_ih + 2 * H + u, bI);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        float gR[8], gZ[8], gN[8], aR[8], aZ[8], aH[8], aI[8], hp[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-          gR[e] = EMB ? 0.f : (float)gq[i][0][e]; gZ[e] = EMB ? 0.f : (float)gq[i][1][e]; gN[e] = EMB ? 0.f : (float)gq[i][2][e];
-        }
-        // fp32 state of these cells: written by this very lane one step ago (the whole fp32 state, 128 KB per workgroup at H = 512,
-        // fits neither LDS next to the bf16 operand copies nor the register file next to the accumulators)
-        hp[0] = hq[i][0].x; hp[1] = hq[i][0].y; hp[2] = hq[i][0].z; hp[3] = hq[i][0].w;
-        hp[4] = hq[i][1].x; hp[5] = hq[i][1].y; hp[6] = hq[i][1].z; hp[7] = hq[i][1].w;
-        pair_to_rows(acc[i][0], acc[i][1], aR); pair_to_rows(acc[i][2], acc[i][3], aZ);
-        pair_to_rows(acc[i][4], acc[i][5], aH); pair_to_rows(acc[i][6], acc[i][7], aI);
-        const bool live = !EMB || tt < len[i];
-        float r[8], z[8], nn[8], hn[8], h[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-          r[e] = nsig(aR[e] + gR[e] + bR[e]);
-          z[e] = nsig(aZ[e] + gZ[e] + bZ[e]);
-          hn[e] = aH[e] + bN[e];
-          nn[e] = ntanh(aI[e] + gN[e] + bI[e] + r[e] * hn[e]);
-          if (!live) { r[e] = 0.f; z[e] = 1.f; nn[e] = 0.f; }             // masked row: h' = h, zero gate gradients
-          h[e] = (1.0f - z[e]) * nn[e] + z[e] * hp[e];
-        }
-        st_bf16x8(hn_ + (i * 16 + erow) * HLD + u, h);
-        if (ok[i]) {
-          const long o = (long)(n + 1) * RH + grow[i] * H + u;
-          st_f32x8(a.HN + o, h);                                       // read back next step: default policy
-          stnt_bf16x8(a.HN16 + o, h);
-          if (a.gates) {
-            __bf16* gp = a.gates + (long)n * 4 * RH + grow[i] * H + u;
-            stnt_bf16x8(gp, r); stnt_bf16x8(gp + RH, z); stnt_bf16x8(gp + 2 * RH, nn); stnt_bf16x8(gp + 3 * RH, hn);
+        const int tl[6] = {ut0, ut0 + 1, NUT + ut0, NUT + 1 + ut0, 2 * NUT + ut0, 2 * NUT + 1 + ut0};
+        // epilogue operands of the pass (GC and the fp32 state of this lane's cells) are requested BEFORE the products: they come
+        // from HBM, and waiting for them per M tile in the epilogue exposed that latency 16 times per step
+        bf16x8 gq[MH][3]; float4 hq[MH][2];
+  #pragma unroll
+        for (int i = 0; i < MH; i++) {
+          if constexpr (!EMB) {
+            const __bf16* g = a.gc + grow[mh + i] * (3 * H) + u;
+  #pragma unroll
+            for (int gt = 0; gt < 3; gt++) gq[i][gt] = ldnt_bf16x8(g + gt * H);
           }
-          if constexpr (EMB) { if (a.out && n == a.T - 1) st_f32x8(a.out + grow[i] * a.out_ld + u, h); }
+          if constexpr (H != 128) {                                        // (H = 128: loaded per tile in the epilogue -- registers)
+            const float* hp = a.HN + (long)n * RH + grow[mh + i] * H + u;
+            hq[i][0] = ldnt_f4(hp); hq[i][1] = ldnt_f4(hp + 4);
+          }
         }
-        __builtin_amdgcn_sched_barrier(0);                               // keep the M tiles' epilogues (and the passes) apart: register pressure
+        // software-pipelined stream of KBH + 4 k-blocks through a ring of 4 fragment buffers: the loads of k-block k+3 are issued
+        // before the MFMAs of k-block k (24 MFMAs = ~400 cycles per k-block against ~900 cycles of L2 latency)
+        // (H = 128: two workgroups share a CU -- both directions of the note-summary GRU run side by side -- so half the registers:
+        // a ring of 2)
+        constexpr int RD = H == 128 ? 2 : 4;
+        bf16x8 b[RD][6];
+        auto ldw = [&](bf16x8 (&d)[6], int k) {                            // k < KBH: W_hh block (k + krot) % KBH; else W_x block k - KBH
+  #pragma unroll
+          for (int j = 0; j < 6; j++)
+            d[j] = k < KBH ? a.w_hh[((long)tl[j] * KBH + ((k + krot) & (KBH - 1))) * 64 + lane] : a.w_x[((long)tl[j] * 4 + (k - KBH)) * 64 + lane];
+        };
+  #pragma unroll
+        for (int k = 0; k < RD - 1; k++) ldw(b[k], k);
+  #pragma unroll
+        for (int k = 0; k < KT; k++) {
+          if (k + RD - 1 < KT) ldw(b[(k + RD - 1) % RD], k + RD - 1);
+          const bool tokpart = k >= KBH;
+          const __bf16* A = tokpart ? tok16 : hc;
+          const int lda = tokpart ? NT16LD : HLD, kb = tokpart ? k - KBH : ((k + krot) & (KBH - 1));
+  #pragma unroll
+          for (int i = 0; i < MH; i++) {
+            const bf16x8 av = *reinterpret_cast<const bf16x8*>(A + ((mh + i) * 16 + rl) * lda + kb * 32 + kq);
+  #pragma unroll
+            for (int j = 0; j < 6; j++) {
+              const int slot = j < 4 ? j : (tokpart ? j + 2 : j);
+              acc[i][slot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[k % RD][j], av, acc[i][slot], 0, 0, 0);
+            }
+          }
+        }
+        // ---- epilogue: GRU cell on this lane's cells of the pass
+  #pragma unroll
+        for (int i = 0; i < MH; i++) {
+          float gR[8], gZ[8], gN[8], aR[8], aZ[8], aH[8], aI[8], hp[8];
+  #pragma unroll
+          for (int e = 0; e < 8; e++) {
+            gR[e] = EMB ? 0.f : (float)gq[i][0][e]; gZ[e] = EMB ? 0.f : (float)gq[i][1][e]; gN[e] = EMB ? 0.f : (float)gq[i][2][e];
+          }
+          // fp32 state of these cells: written by this very lane one step ago (the whole fp32 state, 128 KB per workgroup at H = 512,
+          // fits neither LDS next to the bf16 operand copies nor the register file next to the accumulators)
+          if constexpr (H == 128) {
+            const float* hpp = a.HN + (long)n * RH + grow[mh + i] * H + u;
+            hq[i][0] = ldnt_f4(hpp); hq[i][1] = ldnt_f4(hpp + 4);
+          }
+          hp[0] = hq[i][0].x; hp[1] = hq[i][0].y; hp[2] = hq[i][0].z; hp[3] = hq[i][0].w;
+          hp[4] = hq[i][1].x; hp[5] = hq[i][1].y; hp[6] = hq[i][1].z; hp[7] = hq[i][1].w;
+          pair_to_rows(acc[i][0], acc[i][1], aR); pair_to_rows(acc[i][2], acc[i][3], aZ);
+          pair_to_rows(acc[i][4], acc[i][5], aH); pair_to_rows(acc[i][6], acc[i][7], aI);
+          const bool live = !EMB || tt < len[mh + i];
+          float r[8], z[8], nn[8], hn[8], h[8];
+  #pragma unroll
+          for (int e = 0; e < 8; e++) {
+            r[e] = nsig(aR[e] + gR[e]);
+            z[e] = nsig(aZ[e] + gZ[e]);
+            hn[e] = aH[e];
+            nn[e] = ntanh(aI[e] + gN[e] + r[e] * hn[e]);
+            if (!live) { r[e] = 0.f; z[e] = 1.f; nn[e] = 0.f; }             // masked row: h' = h, zero gate gradients
+            h[e] = (1.0f - z[e]) * nn[e] + z[e] * hp[e];
+          }
+          st_bf16x8(hn_ + ((mh + i) * 16 + erow) * HLD + u, h);
+          if (ok[mh + i]) {
+            const long o = (long)(n + 1) * RH + grow[mh + i] * H + u;
+            st_f32x8(a.HN + o, h);                                       // read back next step: default policy
+            stnt_bf16x8(a.HN16 + o, h);
+            if (a.gates) {
+              __bf16* gp = a.gates + (long)n * 4 * RH + grow[mh + i] * H + u;
+              stnt_bf16x8(gp, r); stnt_bf16x8(gp + RH, z); stnt_bf16x8(gp + 2 * RH, nn); stnt_bf16x8(gp + 3 * RH, hn);
+            }
+            if constexpr (EMB) { if (a.out && n == a.T - 1) st_f32x8(a.out + grow[mh + i] * a.out_ld + u, h); }
+          }
+          __builtin_amdgcn_sched_barrier(0);                               // keep the M tiles' epilogues (and the passes) apart: register pressure
+        }
       }
     }
     lds_barrier();
@@ -266,7 +289,7 @@ struct RowGruBwdArgs {
 // EMB = false: the notes GRU (gradient arrives at every state: ext; forward time order; dh0 wanted); EMB = true: a direction of
 // dec_notes_emb_gru (gradient arrives at the final state only: dh_last; optional reversed time)
 template <int H, bool EMB>
-__global__ __launch_bounds__(256, 1) void row_gru_bwd_kernel(RowGruBwdArgs a) {
+__global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowGruBwdArgs a) {
   constexpr int KT = 3 * H / 32, NTW = H / 64, NCH = 3 * H / 8;           // k-blocks, output tiles per wave, scratch chunks
   extern __shared__ __attribute__((aligned(16))) char nsm[];
   float* dhz = reinterpret_cast<float*>(nsm);                            // [64][H] fp32: dh (x) z carried to the earlier step
