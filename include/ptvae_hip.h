@@ -330,6 +330,8 @@ int ptv_slerp_path(const float* z1, const float* z2, float* out, int B, int D, i
  *     (teacher-forcing coin, ptvae.py:420).  train = 0 skips what only the backward reads (HN, gates, HD, TOK); train = 2 stores only
  *     the fed tokens TOK: the caller then recomputes states and gates for ALL rows with the batched kernels (ptv_notes_gru_persist_fwd,
  *     ptv_dur_gru_fwd with the stored decisions forced), cheaper than 16-row panels streaming them out note step by note step.
+ *     Bits 16 / 17 of train force the 4-wave kernel / the 8-wave kernel whose producer waves stream the next note step's state
+ *     products under the head phases of the current one (default: by panel count).
  *   ptv_free_resummarize: w = { pack(W_ih), pack(W_hh), pack(W_ih_reverse), pack(W_hh_reverse), b_ih, b_hh, b_ih_r, b_hh_r } of
  *     dec_notes_emb_gru; io = { PRED, plen, XH fwd [17][R][128] (slot 0 zero), XH bwd, XG fwd [16][4][R][128] bf16, XG bwd,
  *     tok_next = TOKS[t+1] [B][256] }.

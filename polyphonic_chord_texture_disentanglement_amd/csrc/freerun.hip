@@ -456,6 +456,379 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
 }
 
 // =============================================================================================
+// The same note loop with the state products taken off the critical path: 8 waves.  The notes-GRU products W_hh . h are bound by
+// the CU's L2 port (1.6 MB of fragments per note step) and need only the state, not the next token -- so waves 0-3 ("producers")
+// stream them for step n+1 WHILE waves 4-7 ("heads") run pitch head, argmax, dur_hid, the duration GRU and the token embedding of
+// step n.  When the token arrives, the producers add the short token part (K = 128), run the cell epilogue and hand the new state
+// over.  Both groups execute the same nine workgroup barriers per note step (gfx950 has no named barriers), so each of the eight
+// product segments is paired with one head phase:
+//   producers: token part + epilogue | B0 | segment 1 | B1 | ... | segment 8 | B8
+//   heads:                      wait | B0 | pitch head | B1 | argmax, dur_hid | B2 | dur step 0..4 | B3..B7 | embedding | B8
+// =============================================================================================
+__global__ __launch_bounds__(512, 1) void note_loop2_kernel(NoteLoopArgs a) {
+  __shared__ __attribute__((aligned(16))) float hf[FP][FHN];                   // notes-GRU state, fp32
+  __shared__ __attribute__((aligned(16))) __bf16 h16[2][FP][H16LD];            // its bf16 MFMA-operand copy (double buffered)
+  __shared__ __attribute__((aligned(16))) __bf16 tok16[FP][T16LD];             // current input token
+  __shared__ __attribute__((aligned(16))) float pit[FP][PITLD];                // pitch logits
+  __shared__ __attribute__((aligned(16))) __bf16 pit16[FP][P16LD];
+  __shared__ __attribute__((aligned(16))) float hdf[FP][FHD];                  // duration-GRU state
+  __shared__ __attribute__((aligned(16))) __bf16 hd16[2][FP][D16LD];
+  __shared__ __attribute__((aligned(16))) bf16x8 wdl[12 * 2 * 64];             // duration W_hh, fragment-major (24 KB)
+  __shared__ float tabs[3][3 * FHD];
+  __shared__ float bhd[3 * FHD];
+  __shared__ float wo[2 * FHD + 2];
+  __shared__ float part[2][4][FP][2];                                          // double buffered: one barrier per duration step
+  __shared__ int pidx[FP];
+  __shared__ int bits[FP][5];
+
+
+  const int tid0 = threadIdx.x, lane = tid0 & 63;
+  const bool producer = tid0 < 256;
+  const int tid = tid0 & 255, wave = __builtin_amdgcn_readfirstlane((tid0 >> 6) & 3);   // thread / wave index inside the group (wave: SGPR)
+  const int crow = lane & 15, ckq = lane >> 4;                // accumulator (C) layout
+  const int erow = lane >> 2, eq = lane & 3;                  // epilogue layout
+  const int B = a.B, R = a.R, t = a.t;
+  const long M = a.M;
+  const int r0 = blockIdx.x * FP;                             // first sample of the panel
+  const int rE = min(r0 + erow, B - 1), rC = min(r0 + crow, B - 1);
+  const bool okE = r0 + erow < B, okC = r0 + crow < B;
+  const long wrowE = (long)t * B + rE, wrowC = (long)t * B + rC;   // row in the [R]-row step-major matrices
+
+  // ---- one-time loads: duration GRU weights / tables -> LDS, initial state and first token -> LDS
+  for (int i = tid0; i < 12 * 2 * 64; i += 512) wdl[i] = a.wdur[i];
+  for (int i = tid0; i < 3 * FHD; i += 512) { tabs[0][i] = a.tab0[i]; tabs[1][i] = a.tab[i]; tabs[2][i] = a.tab[3 * FHD + i]; bhd[i] = a.b_hh_d[i]; }
+  for (int i = tid0; i < 2 * FHD; i += 512) wo[i] = a.w_out[i];
+  if (tid0 < 2) wo[2 * FHD + tid0] = a.b_out[tid0];
+  for (int i = tid0; i < FP * (FHN / 4); i += 512) {
+    const int row = i / (FHN / 4), c4 = (i % (FHN / 4)) * 4;
+    const int rb = min(r0 + row, B - 1);
+    const float4 v = a.h0 ? *reinterpret_cast<const float4*>(a.h0 + (long)rb * a.ld_h0 + c4)
+                          : *reinterpret_cast<const float4*>(a.HN + ((long)t * B + rb) * FHN + c4);
+    if (a.h0 && r0 + row < B) *reinterpret_cast<float4*>(a.HN + ((long)t * B + rb) * FHN + c4) = v;   // slot 0 of HN for the backward
+    *reinterpret_cast<float4*>(&hf[row][c4]) = v;
+    st_bf16x4_lds(&h16[0][row][c4], v.x, v.y, v.z, v.w);
+    if (a.train && a.HN16 && r0 + row < B) st_bf16x4_lds(a.HN16 + ((long)t * B + r0 + row) * FHN + c4, v.x, v.y, v.z, v.w);
+  }
+  for (int i = tid0; i < FP * (FE / 4); i += 512) {
+    const int row = i / (FE / 4), c4 = (i % (FE / 4)) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(a.TOK + ((long)t * B + min(r0 + row, B - 1)) * FE + c4);
+    st_bf16x4_lds(&tok16[row][c4], v.x, v.y, v.z, v.w);
+  }
+  for (int i = tid0; i < FP * (P16LD - FNP); i += 512) pit16[i / (P16LD - FNP)][FNP + i % (P16LD - FNP)] = (__bf16)0.f;   // K padding of the logits operand
+  if (tid0 < FP) pidx[tid0] = 0;
+
+  __syncthreads();
+
+  if (producer) {
+    const int rl = lane & 15, kq = (lane >> 4) * 8;             // fragment coordinates
+    f32x4 accH[4][6];                                           // W_hh . h of the step being prepared, all four passes
+    bf16x8 tf[4][6];                                            // token-part fragments of the pass about to run
+    auto tiles = [&](int p, int (&tl)[6]) {
+      const int ut0 = wave * 8 + p * 2;
+      tl[0] = ut0; tl[1] = ut0 + 1; tl[2] = 32 + ut0; tl[3] = 33 + ut0; tl[4] = 64 + ut0; tl[5] = 65 + ut0;
+    };
+    auto load_tok_frags = [&](const bf16x8* wt, int p) {
+      int tl[6]; tiles(p, tl);
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) tf[q][j] = (wt + (tl[j] * 4 + q) * 64)[lane];          // uniform base (SGPR) + lane offset: no 64-bit VGPR address per load
+    };
+    // the state products as ONE software pipeline over 64 units (pass, k-block) with a ring of 5 fragment sets; `sync` puts a
+    // workgroup barrier after every 8th unit (the pairing with the head phases), loads keep flying across it
+    auto h_products = [&](const bf16x8* wh, const __bf16* hsrc, bool sync) {
+      bf16x8 b[5][6];
+      auto ldu = [&](bf16x8 (&d)[6], int un) {
+        int tl[6]; tiles(un >> 4, tl);
+#pragma unroll
+        for (int j = 0; j < 6; j++) d[j] = (wh + (tl[j] * 16 + (un & 15)) * 64)[lane];
+      };
+#pragma unroll
+      for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) accH[p][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      ldu(b[0], 0); ldu(b[1], 1); ldu(b[2], 2); ldu(b[3], 3);
+#pragma unroll
+      for (int un = 0; un < 64; un++) {
+        if (un + 4 < 64) ldu(b[(un + 4) % 5], un + 4);
+        const bf16x8 av = *reinterpret_cast<const bf16x8*>(hsrc + rl * H16LD + (un & 15) * 32 + kq);
+#pragma unroll
+        for (int j = 0; j < 6; j++) accH[un >> 4][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[un % 5][j], av, accH[un >> 4][j], 0, 0, 0);
+        if (sync && (un & 7) == 7) lds_barrier();
+        __builtin_amdgcn_sched_barrier(0);                        // or the scheduler hoists all 384 fragment loads and spills
+      }
+    };
+    h_products(a.wg_h, &h16[0][0][0], false);                    // step 0: the heads wait at B0 meanwhile
+    load_tok_frags(a.wg_t, 0);
+    for (int n = 0; n < 15; n++) {
+      const int cur = n & 1, nxt = cur ^ 1;
+      (void)cur;
+      // the weight pointers pass through an opaque register copy per note step: otherwise the compiler hoists the address arithmetic
+      // of all 480 fragment loads out of this loop and spills it
+      const bf16x8 *wh = a.wg_h, *wt = a.wg_t;
+      asm volatile("" : "+s"(wh), "+s"(wt));
+      // ---- token part + cell epilogue, pass by pass
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        const int ut0 = wave * 8 + p * 2;
+        float4 gR[2], gZ[2], gN[2], bR[2], bZ[2], bN[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int u = (ut0 + j) * 16 + eq * 4;
+          const float* g = a.gc + (long)rE * a.ld_gc;
+          gR[j] = *reinterpret_cast<const float4*>(g + u); gZ[j] = *reinterpret_cast<const float4*>(g + FHN + u); gN[j] = *reinterpret_cast<const float4*>(g + 2 * FHN + u);
+          bR[j] = *reinterpret_cast<const float4*>(a.b_hh_n + u); bZ[j] = *reinterpret_cast<const float4*>(a.b_hh_n + FHN + u);
+          bN[j] = *reinterpret_cast<const float4*>(a.b_hh_n + 2 * FHN + u);
+        }
+        f32x4 accT[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) accT[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const bf16x8 av = *reinterpret_cast<const bf16x8*>(&tok16[0][0] + rl * T16LD + q * 32 + kq);
+#pragma unroll
+          for (int j = 0; j < 6; j++) accT[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf[q][j], av, accT[j], 0, 0, 0);
+        }
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int u = (ut0 + j) * 16 + eq * 4;
+        f32x4 sR, sZ;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { sR[e] = accH[p][j][e] + accT[j][e]; sZ[e] = accH[p][2 + j][e] + accT[2 + j][e]; }
+        const f32x4 aR = to_rowmajor_lanes(sR), aZ = to_rowmajor_lanes(sZ), aI = to_rowmajor_lanes(accT[4 + j]), aH = to_rowmajor_lanes(accH[p][4 + j]);
+        const float4 hp4 = *reinterpret_cast<const float4*>(&hf[erow][u]);
+        const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+        const float kR[4] = {gR[j].x + bR[j].x, gR[j].y + bR[j].y, gR[j].z + bR[j].z, gR[j].w + bR[j].w};
+        const float kZ[4] = {gZ[j].x + bZ[j].x, gZ[j].y + bZ[j].y, gZ[j].z + bZ[j].z, gZ[j].w + bZ[j].w};
+        const float kN[4] = {gN[j].x, gN[j].y, gN[j].z, gN[j].w}, kB[4] = {bN[j].x, bN[j].y, bN[j].z, bN[j].w};
+        float r[4], z[4], nn[4], hn[4], h[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          r[e] = fsig(aR[e] + kR[e]);
+          z[e] = fsig(aZ[e] + kZ[e]);
+          hn[e] = aH[e] + kB[e];
+          nn[e] = ftanh(aI[e] + kN[e] + r[e] * hn[e]);
+          h[e] = (1.0f - z[e]) * nn[e] + z[e] * hp[e];
+        }
+        *reinterpret_cast<float4*>(&hf[erow][u]) = make_float4(h[0], h[1], h[2], h[3]);
+        st_bf16x4_lds(&h16[nxt][erow][u], h[0], h[1], h[2], h[3]);
+        if (a.train && okE) {
+          *reinterpret_cast<float4*>(a.HN + ((long)(n + 1) * R + wrowE) * FHN + u) = make_float4(h[0], h[1], h[2], h[3]);
+          if (a.HN16) st_bf16x4_lds(a.HN16 + ((long)(n + 1) * R + wrowE) * FHN + u, h[0], h[1], h[2], h[3]);
+          __bf16* gp = a.gates_n + (((long)n * 4) * R + wrowE) * FHN + u;
+          const long pl = (long)R * FHN;
+          st_bf16x4_lds(gp, r[0], r[1], r[2], r[3]);
+          st_bf16x4_lds(gp + pl, z[0], z[1], z[2], z[3]);
+          st_bf16x4_lds(gp + 2 * pl, nn[0], nn[1], nn[2], nn[3]);
+          st_bf16x4_lds(gp + 3 * pl, hn[0], hn[1], hn[2], hn[3]);
+        }
+      }
+        if (p < 3) load_tok_frags(wt, p + 1);
+      }
+      lds_barrier();                                             // B0: the new state is in LDS
+      if (n < 14) {
+        h_products(wh, &h16[nxt][0][0], true);                   // B1..B8 inside
+        load_tok_frags(wt, 0);
+      } else {
+#pragma unroll 1
+        for (int s = 0; s < 8; s++) lds_barrier();
+      }
+    }
+  } else {
+    // the decision of duration step d for `row` from the four waves' partial sums (complete after that step's barrier)
+    auto dur_decision = [&](int d, int row, long pr) {
+      const int dc = d & 1;
+      const float e0 = part[dc][0][row][0] + part[dc][1][row][0] + part[dc][2][row][0] + part[dc][3][row][0] + wo[2 * FHD];
+      const float e1 = part[dc][0][row][1] + part[dc][1][row][1] + part[dc][2][row][1] + part[dc][3][row][1] + wo[2 * FHD + 1];
+      int id = e1 > e0 ? 1 : 0;
+      if (a.force_dur) id = a.force_dur[(long)d * M + pr];
+      return id;
+    };
+    for (int n = 0; n < 15; n++) {
+      const int cur = n & 1, nxt = cur ^ 1;
+      (void)cur;
+      lds_barrier();                                             // B0
+    // ================= P2: pitch head (9 tiles over 4 waves) + the state part of dur_hid_linear (one tile per wave) =================
+    f32x4 accD[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    {
+      const int tl[1] = {wave};
+      panel_mma<1, 16, 8>(a.wd_h, tl, &h16[nxt][0][0], H16LD, accD);
+    }
+    for (int nt = wave; nt < 9; nt += 4) {
+      f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+      const int tl[1] = {nt};
+      panel_mma<1, 16, 8>(a.wp, tl, &h16[nxt][0][0], H16LD, acc);
+      const int c0 = nt * 16 + ckq * 4;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int c = c0 + e;
+        const float v = c < FNP ? acc[0][e] + a.b_p[c] : 0.f;
+        pit[crow][c] = v;
+        pit16[crow][c] = (__bf16)v;
+      }
+    }
+    lds_barrier();                                               // B1
+    // ================= P3: argmax over the 130 logits (16 lanes per row, first maximal index) + logits out =================
+    {
+      const int row = tid >> 4, j = tid & 15;
+      float best = -INFINITY; int bi = 0x7fffffff;
+      const long pr = (long)n * R + (long)t * B + min(r0 + row, B - 1);
+      const bool ok = r0 + row < B;
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        const int c = j + 16 * k;
+        if (c < FNP) {
+          const float v = pit[row][c];
+          if (ok) a.pitch[pr * a.ld_pitch + c] = v;
+          if (v > best) { best = v; bi = c; }
+        }
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      if (a.force_pitch) bi = a.force_pitch[(long)n * R + (long)t * B + min(r0 + row, B - 1)];
+      if (j == 0) pidx[row] = bi;
+    }
+    // ================= P4: dur_hid_linear([h | logits]) -> initial duration state (wave w = units w*16..) =================
+    {
+      const int tl[1] = {wave};
+      panel_mma<1, 5, 8>(a.wd_p, tl, &pit16[0][0], P16LD, accD);               // + the logits part (K = 130 padded to 160)
+      const int u = wave * 16 + ckq * 4;
+      const float4 b4 = *reinterpret_cast<const float4*>(a.b_dh + u);
+      const float h[4] = {accD[0][0] + b4.x, accD[0][1] + b4.y, accD[0][2] + b4.z, accD[0][3] + b4.w};
+      *reinterpret_cast<float4*>(&hdf[crow][u]) = make_float4(h[0], h[1], h[2], h[3]);
+      st_bf16x4_lds(&hd16[0][crow][u], h[0], h[1], h[2], h[3]);
+      if (a.train && okC) {
+        *reinterpret_cast<float4*>(a.HD + ((long)n * R + wrowC) * FHD + u) = make_float4(h[0], h[1], h[2], h[3]);
+        if (a.HD16) st_bf16x4_lds(a.HD16 + ((long)n * R + wrowC) * FHD + u, h[0], h[1], h[2], h[3]);
+      }
+    }
+    lds_barrier();                                               // B2
+    // ================= P5: 5-step duration GRU, argmax feedback (wave w = units w*16..w*16+15) =================
+    {
+      const long prC = (long)n * R + wrowC;
+      const int u = wave * 16 + ckq * 4;
+      int dtk = 0;                                                             // this lane's row: 0 = <sos>, 1 + previous decision
+#pragma unroll 1
+      for (int d = 0; d < 5; d++) {
+        const int dc = d & 1, dn = dc ^ 1;
+        f32x4 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; g++) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+          const bf16x8 av = *reinterpret_cast<const bf16x8*>(&hd16[dc][crow][kb * 32 + ckq * 8]);
+#pragma unroll
+          for (int g = 0; g < 3; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdl[((g * 4 + wave) * 2 + kb) * 64 + lane], av, acc[g], 0, 0, 0);
+        }
+        const float* gi = tabs[dtk];
+        const float4 hp4 = *reinterpret_cast<const float4*>(&hdf[crow][u]);
+        const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+        float r[4], z[4], nn[4], hn[4], h[4], o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int jj = u + e;
+          r[e] = fsig(gi[jj] + acc[0][e] + bhd[jj]);
+          z[e] = fsig(gi[FHD + jj] + acc[1][e] + bhd[FHD + jj]);
+          hn[e] = acc[2][e] + bhd[2 * FHD + jj];
+          nn[e] = ftanh(gi[2 * FHD + jj] + r[e] * hn[e]);
+          h[e] = (1.0f - z[e]) * nn[e] + z[e] * hp[e];
+          o0 += wo[jj] * h[e]; o1 += wo[FHD + jj] * h[e];
+        }
+        *reinterpret_cast<float4*>(&hdf[crow][u]) = make_float4(h[0], h[1], h[2], h[3]);
+        st_bf16x4_lds(&hd16[dn][crow][u], h[0], h[1], h[2], h[3]);
+        if (a.train && okC) {
+          if (a.HD16) st_bf16x4_lds(a.HD16 + ((long)(d + 1) * M + prC) * FHD + u, h[0], h[1], h[2], h[3]);
+          else *reinterpret_cast<float4*>(a.HD + ((long)(d + 1) * M + prC) * FHD + u) = make_float4(h[0], h[1], h[2], h[3]);
+          __bf16* gp = a.gates_d + (((long)d * 4) * M + prC) * FHD + u;
+          const long pl = M * FHD;
+          st_bf16x4_lds(gp, r[0], r[1], r[2], r[3]);
+          st_bf16x4_lds(gp + pl, z[0], z[1], z[2], z[3]);
+          st_bf16x4_lds(gp + 2 * pl, nn[0], nn[1], nn[2], nn[3]);
+          st_bf16x4_lds(gp + 3 * pl, hn[0], hn[1], hn[2], hn[3]);
+        }
+        o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64);
+        o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64);
+        if (lane < 16) { part[dc][wave][lane][0] = o0; part[dc][wave][lane][1] = o1; }
+        lds_barrier();
+        // every lane forms the two logits of ITS row from the four waves' partial sums and takes the decision itself (no second
+        // barrier to pass the token around); the panel's first 16 threads also publish them
+        {
+          const float e0 = part[dc][0][crow][0] + part[dc][1][crow][0] + part[dc][2][crow][0] + part[dc][3][crow][0] + wo[2 * FHD];
+          const float e1 = part[dc][0][crow][1] + part[dc][1][crow][1] + part[dc][2][crow][1] + part[dc][3][crow][1] + wo[2 * FHD + 1];
+          int id = e1 > e0 ? 1 : 0;                                             // first max wins ties (torch.max)
+          if (a.force_dur) id = a.force_dur[(long)d * M + prC];
+          dtk = 1 + id;
+          if (tid < FP) {                                                      // wave 0, lanes 0..15: crow == tid
+            if (okC) {
+              a.dur[prC * 10 + 2 * d] = e0; a.dur[prC * 10 + 2 * d + 1] = e1;
+              a.idx[(long)d * M + prC] = id;
+            }
+            bits[tid][d] = id;
+          }
+        }
+      }
+    }
+    // ================= P6: predicted token = note_embedding(onehot(pitch) | 5 duration bits); next input token =================
+    {
+      const int row = tid >> 4, e0 = (tid & 15) * 8;
+      const bool ok = r0 + row < B;
+      const long wr = (long)t * B + min(r0 + row, B - 1);
+      const int pch = pidx[row];
+      const int last_bit = dur_decision(4, row, (long)n * R + wr);
+      float v[8];
+      const float4 b0 = *reinterpret_cast<const float4*>(a.b_emb + e0), b1 = *reinterpret_cast<const float4*>(a.b_emb + e0 + 4);
+      const float4 w0 = *reinterpret_cast<const float4*>(a.w_embT + (long)pch * FE + e0), w1 = *reinterpret_cast<const float4*>(a.w_embT + (long)pch * FE + e0 + 4);
+      v[0] = b0.x + w0.x; v[1] = b0.y + w0.y; v[2] = b0.z + w0.z; v[3] = b0.w + w0.w;
+      v[4] = b1.x + w1.x; v[5] = b1.y + w1.y; v[6] = b1.z + w1.z; v[7] = b1.w + w1.w;
+#pragma unroll
+      for (int d = 0; d < 5; d++) {
+        const float4 q0 = *reinterpret_cast<const float4*>(a.w_embT + (long)(FNP + d) * FE + e0), q1 = *reinterpret_cast<const float4*>(a.w_embT + (long)(FNP + d) * FE + e0 + 4);
+        const float f = (float)(d < 4 ? bits[row][d] : last_bit);
+        v[0] += f * q0.x; v[1] += f * q0.y; v[2] += f * q0.z; v[3] += f * q0.w;
+        v[4] += f * q1.x; v[5] += f * q1.y; v[6] += f * q1.z; v[7] += f * q1.w;
+      }
+      if (ok) {
+        float* pp = a.PRED + ((long)(n + 1) * R + wr) * FE + e0;
+        *reinterpret_cast<float4*>(pp) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(pp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+      if (n < 14) {
+        if ((a.coin_mask >> n) & 1u) {                                          // teacher forcing: the ground-truth note n+1
+          const float* gp = a.emb + ((long)(n + 1) * R + wr) * FE + e0;
+          const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
+          v[0] = g0.x; v[1] = g0.y; v[2] = g0.z; v[3] = g0.w; v[4] = g1.x; v[5] = g1.y; v[6] = g1.z; v[7] = g1.w;
+        }
+        if (a.tok_store && ok) {
+          float* tp = a.TOK + ((long)(n + 1) * R + wr) * FE + e0;
+          *reinterpret_cast<float4*>(tp) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(tp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        st_bf16x4_lds(&tok16[row][e0], v[0], v[1], v[2], v[3]);
+        st_bf16x4_lds(&tok16[row][e0 + 4], v[4], v[5], v[6], v[7]);
+      }
+      if (tid < FP && r0 + tid < B) {
+        const int rw = r0 + tid;
+        long* xr = a.xhat + (((long)rw * 32 + t) * 16 + n + 1) * 6;
+        const int pb = pidx[tid];
+        xr[0] = pb;
+#pragma unroll
+        for (int d = 0; d < 4; d++) xr[1 + d] = bits[tid][d];
+        xr[5] = dur_decision(4, tid, (long)n * R + (long)t * B + rw);
+        int L = a.plen[(long)t * B + rw];
+        if (L == 0 && pb == 129) L = n + 1;                                     // first <eos>            (ptvae.py:415-416)
+        if (n == 14 && L == 0) L = n + 1;                                       // no <eos> by the end     (ptvae.py:425)
+        a.plen[(long)t * B + rw] = L;
+      }
+    }
+    lds_barrier();                                               // B8: the next token is in LDS
+    }
+  }
+}
+
+// =============================================================================================
 // re-summarisation of a panel's predicted notes: bi-GRU(128 -> 128) over PRED[0..15], packed by the predicted length
 // (ptvae.py:480-486) -> the next time-step token TOKS[t+1] = [fwd final | bwd final].  grid = (panels, 2 directions)
 // =============================================================================================
@@ -587,8 +960,16 @@ extern "C" int ptv_free_note_loop(const void* const* w, const void* const* io, l
   a.idx = (int*)io[8]; a.TOK = (float*)io[9]; a.PRED = (float*)io[10]; a.xhat = (long*)io[11]; a.plen = (int*)io[12];
   a.force_pitch = (const int*)io[13]; a.force_dur = (const int*)io[14]; a.HN16 = (__bf16*)io[15]; a.HD16 = (__bf16*)io[16];
   a.dbg_out = (train >> 8) & 64 ? (long*)io[17] : nullptr;
-  a.B = B; a.t = t; a.R = 32 * B; a.M = 15 * 32 * B; a.coin_mask = coin_mask; a.train = (train & 3) == 1; a.tok_store = (train & 3) != 0; a.dbg = train >> 8;
-  hipLaunchKernelGGL(note_loop_kernel, dim3((B + FP - 1) / FP), dim3(256), 0, (hipStream_t)stream, a);
+  a.B = B; a.t = t; a.R = 32 * B; a.M = 15 * 32 * B; a.coin_mask = coin_mask; a.train = (train & 3) == 1; a.tok_store = (train & 3) != 0; a.dbg = (train >> 8) & 0xff;
+  // two kernels: 4 waves walking the phases one after the other, or producers / heads split over 8 waves (the state products of
+  // the next note step under the heads of the current one).  Measured (scripts/bench_freerun3.py): with few panels (B = 512: 32
+  // workgroups) a note step is bound by ONE CU's L2 port either way and the heads' small dependent loads queue behind the producers'
+  // deep prefetch (30.4 vs 32.0 us per note step); with many panels (B = 2048) the chip's L2 is the limit and the overlap wins
+  // (47.0 -> 40.8 us).  train bit 16 / 17 force the 4-wave / 8-wave kernel.
+  const int panels = (B + FP - 1) / FP;
+  const bool split = (train & 0x20000) || (!(train & 0x10000) && panels >= 96);
+  if (!split) hipLaunchKernelGGL(note_loop_kernel, dim3(panels), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(note_loop2_kernel, dim3(panels), dim3(512), 0, (hipStream_t)stream, a);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

@@ -46,6 +46,8 @@ FREE_PERSIST = os.environ.get('PTV_FREE_PERSIST', '1') not in ('0', 'false', 'of
 # training forward of the step loop: the panels store only decisions, logits and fed tokens; states and gates the backward needs are
 # recomputed afterwards for all 480*B rows at once by the teacher-forced kernels (same tokens, same decisions forced)
 FREE_REPLAY = os.environ.get('PTV_FREE_REPLAY', '1') not in ('0', 'false', 'off')
+# note-loop kernel: None = by panel count (csrc/freerun.hip), True / False = force the producers-heads split / the 4-wave kernel
+NOTE_LOOP_SPLIT = None
 _PACKS = F_.PackCache()
 _PACK_SRC = ('dec_notes_gru.weight_hh_l0', 'dec_notes_gru.weight_ih_l0', 'pitch_out_linear.weight', 'dur_hid_linear.weight',
              'dec_dur_gru.weight_hh_l0', 'note_embedding.weight', 'dec_notes_emb_gru.weight_ih_l0', 'dec_notes_emb_gru.weight_hh_l0',
@@ -223,7 +225,8 @@ class DecoderStepFn(torch.autograd.Function):
                         mask |= int(bool(coin_notes[t][n])) << n
                 io = F_._parr([GCt, emb3, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, force_pitch, force_dur, HN16, HD16,
                                None, H0GC])
-                call('ptv_free_note_loop', wl, io, pitch.stride(0), B, t, mask, 2 if replay else int(train), st)
+                call('ptv_free_note_loop', wl, io, pitch.stride(0), B, t, mask,
+                     (2 if replay else int(train)) | (0 if NOTE_LOOP_SPLIT is None else (0x20000 if NOTE_LOOP_SPLIT else 0x10000)), st)
                 if t == 31:
                     break
                 if (not inference) and coin_time[t]:

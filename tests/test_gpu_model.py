@@ -697,3 +697,39 @@ def test_free_running_training_batched_recompute_equals_streamed_states(monkeypa
     assert set(g0) == set(g1)
     for n in g0:
         assert (g1[n] - g0[n]).abs().max() <= 0.04 * g0[n].abs().max() + 1e-6, n
+
+
+def test_note_loop_producer_head_split_kernel_equals_four_wave_kernel(monkeypatch):
+    """csrc/freerun.hip has two note-loop kernels (4 waves phase by phase / producers + heads over 8 waves, chosen by panel count):
+    same decisions and logits from both, in inference and in a free-running training step (full geometry)"""
+    from polyphonic_chord_texture_disentanglement_amd import functional_free as FF_
+    m = M.DisentangleVAE.init_model(torch.device(DEV))
+    m.load_state_dict(full_params())
+    m.to(DEV).set_precision('bf16')
+    B = 40                                                       # 3 panels, the last one ragged
+    g = torch.Generator().manual_seed(11)
+    z = (torch.randn(B, 512, generator=g) * 0.8).to(DEV)
+    x, c, pr = synth_batch(B, 321)
+    xt, ct, prt = (torch.from_numpy(a).to(DEV) for a in (x, c, pr))
+    eps = {n: torch.randn(B, 256, generator=torch.Generator().manual_seed(i)).to(DEV) for i, n in enumerate(('chd', 'rhy'))}
+    res = {}
+    for split in (False, True):
+        monkeypatch.setattr(FF_, 'NOTE_LOOP_SPLIT', split)
+        with torch.no_grad():
+            pitch, dur = m.decoder(z, True, None, None, 0., 0.)
+        xh = m.decoder.last_xhat.clone()
+        m.eps_source = lambda name, shape, device: eps[name]
+        m.zero_grad()
+        outs = m.run(xt, ct, prt, 0., 0., 0.)
+        losses = m.loss_function(xt, ct, *outs, 0.1, [1, 0.5])
+        losses[0].backward()
+        torch.cuda.synchronize()
+        res[split] = (pitch.clone(), dur.clone(), xh, np.array([l.item() for l in losses]), m.decoder.last_xhat.clone(),
+                      {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    a, b = res[False], res[True]
+    assert (a[2] == b[2]).float().mean() > 0.999 and (a[4] == b[4]).float().mean() > 0.995
+    same = (a[2] == b[2]).all(-1)[:, :, 1:].permute(2, 1, 0)     # [15,32,B]: compare logits where the fed history agrees
+    assert same.float().mean() > 0.99
+    np.testing.assert_allclose(b[3], a[3], rtol=0, atol=5e-3)
+    for n in a[5]:
+        assert (b[5][n] - a[5][n]).abs().max() <= 0.05 * a[5][n].abs().max() + 1e-6, n
