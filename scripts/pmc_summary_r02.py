@@ -33,7 +33,7 @@ json.dump(res, open('%s/pmc_by_kernel.json' % d, 'w'), indent=1)
 pick = {}
 for r in res:
     for name in ('row_gru_bwd_kernel<512>', 'row_gru_fwd_kernel<512>', 'row_gru_bwd_kernel<128>', 'row_gru_fwd_kernel<128>'):
-        if r['kernel'].startswith(name):
+        if r['kernel'].startswith(name[:-1]):          # 'row_gru_bwd_kernel<512' matches the <512, false> instantiation
             pick[name] = {k: r[k] for k in ('launches', 'read_bytes_per_launch', 'write_bytes_per_launch', 'hbm_bytes_per_launch', 'mfma_busy_frac')}
 pick['_how'] = ('rocprofv3 --pmc (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_MFMA, three passes) '
                 '-- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras; scripts/gpu_pmc_r02.sh; corrections in '
