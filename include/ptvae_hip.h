@@ -370,7 +370,9 @@ int ptv_notes_gru_persist_bwd(const void* wt, const float* HN, const void* gates
  *        The two instances are specialised: H = 512 needs gc and takes no b_ih / lengths / reverse / out; H = 128 needs b_ih and no
  *        gc (PTV_ERR_UNSUPPORTED otherwise).
  *   bwd: ext bf16 [T][R][H] (H = 512 only, required there); dh_last fp32 (row stride last_ld) = gradient of the final state (H = 128
- *        only), or NULL; H = 512 writes only the n third of dgh ([T][R][512], see above); dgi is indexed by
+ *        only), or NULL; lengths: the lengths the forward ran with, or NULL -- with lengths both kernels pass over the steps that lie
+ *        beyond the longest row of a 64-row panel (identity for the whole panel, as pack_padded_sequence leaves them out;
+ *        the forward then leaves that step's gates unwritten, so the backward MUST be given the same lengths); H = 512 writes only the n third of dgh ([T][R][512], see above); dgi is indexed by
  *        TIME, dgh by processing step (so dgh pairs with HN16[:T] and dgi with x in the weight-gradient products).
  */
 int ptv_row_gru_persist_fwd(int H, const void* w_hh, const void* w_x, const float* b_hh, const float* b_ih, const void* gc,
@@ -378,8 +380,8 @@ int ptv_row_gru_persist_fwd(int H, const void* w_hh, const void* w_x, const floa
                             float* out, long out_ld, long R, int T, int reverse, void* stream);
 long ptv_row_gru_persist_scratch_elems(int H, long R);
 int ptv_row_gru_persist_bwd(int H, const void* wt, const float* HN, const void* gates, const void* ext,
-                            const float* dh_last, long last_ld, void* dgi, void* dgh, float* dh0, void* scratch,
-                            long R, int T, int reverse, void* stream);
+                            const float* dh_last, long last_ld, const int* lengths, void* dgi, void* dgh, float* dh0,
+                            void* scratch, long R, int T, int reverse, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * clip_grad_norm_ (module.py:142-143) + torch.optim.Adam.step (train.py:50, scheduler.py:69-74) over

@@ -123,6 +123,20 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
     len[i] = 0x7fffffff;
     if constexpr (EMB) { if (a.lengths) len[i] = a.lengths[grow[i]]; }
   }
+  // EMB with lengths: a (panel, time) pair beyond the longest row of the panel is the identity for all 64 rows (the reference packs
+  // the sequences, ptvae.py:446-453: on this data the mean length is 3.7 of 16 notes) -- such steps only pass the state on
+  int pmax = a.T;
+  if constexpr (EMB) {
+    if (a.lengths) {
+      int* misc = reinterpret_cast<int*>(tok16 + NRP * NT16LD);
+      if (tid == 0) misc[0] = 0;
+      __syncthreads();
+      if (tid < NRP && r0 + tid < R) atomicMax(misc, a.lengths[r0 + tid]);
+      __syncthreads();
+      pmax = min(misc[0], a.T);
+    }
+  }
+  int slot = 0, cur = 0;                                                   // HN slot holding the current fp32 state; current bf16 LDS buffer
   // workgroups of one XCD run in near lockstep and would all ask the L2 for the same few fragment lines at the same moment (a
   // handful of its 16 channels busy, the rest idle): each walks the passes and the k-blocks from its own starting point
   const int prot = (a.dbg & 8) ? 0 : (blockIdx.x >> 3) & (NPASS - 1), krot = (a.dbg & 8) ? 0 : (((blockIdx.x >> 5) & 7) * 2) & (KBH - 1);
@@ -130,8 +144,26 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
   // inside the step loop the waves exchange through LDS only (the fp32 state a lane re-reads from HN is its own store): lds_barrier()
   // lets a step's 117 MB of state / gate stores drain under the next step's products instead of at the step boundary
   for (int n = 0; n < a.T; n++) {
-    const int cur = n & 1, nxt = cur ^ 1;
     const int tt = (EMB && a.reverse) ? a.T - 1 - n : n;
+    if constexpr (EMB) {
+      if (tt >= pmax) {                                                    // whole panel masked: h' = h
+        __syncthreads();                                                   // the previous step's state stores (other lanes' mapping) are complete
+        for (int i = tid; i < NRP * (H / 8); i += 256) {
+          const int row = i / (H / 8), c8 = (i % (H / 8)) * 8;
+          if (r0 + row < R) {
+            const long gr = r0 + row;
+            *reinterpret_cast<bf16x8*>(a.HN16 + (long)(n + 1) * RH + gr * H + c8) = *reinterpret_cast<const bf16x8*>(h16 + cur * NRP * HLD + row * HLD + c8);
+            float v[8];
+            ld_f32x8(a.HN + (long)slot * RH + gr * H + c8, v);
+            st_f32x8(a.HN + (long)(n + 1) * RH + gr * H + c8, v);
+          }
+        }
+        __syncthreads();                                                   // the copy is read back through other lanes' mapping: global fence
+        slot = n + 1;
+        continue;
+      }
+    }
+    const int nxt = cur ^ 1;
     const __bf16* hc = h16 + cur * NRP * HLD;
     __bf16* hn_ = h16 + nxt * NRP * HLD;
     // ---- this step's fed tokens -> LDS (bf16 MFMA operand)
@@ -235,7 +267,7 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
           // fp32 state of these cells: written by this very lane one step ago (the whole fp32 state, 128 KB per workgroup at H = 512,
           // fits neither LDS next to the bf16 operand copies nor the register file next to the accumulators)
           if constexpr (H == 128) {
-            const float* hpp = a.HN + (long)n * RH + grow[mh + i] * H + u;
+            const float* hpp = a.HN + (long)slot * RH + grow[mh + i] * H + u;
             hq[i][0] = ldnt_f4(hpp); hq[i][1] = ldnt_f4(hpp + 4);
           }
           hp[0] = hq[i][0].x; hp[1] = hq[i][0].y; hp[2] = hq[i][0].z; hp[3] = hq[i][0].w;
@@ -262,13 +294,26 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
               __bf16* gp = a.gates + (long)n * 4 * RH + grow[mh + i] * H + u;
               stnt_bf16x8(gp, r); stnt_bf16x8(gp + RH, z); stnt_bf16x8(gp + 2 * RH, nn); stnt_bf16x8(gp + 3 * RH, hn);
             }
-            if constexpr (EMB) { if (a.out && n == a.T - 1) st_f32x8(a.out + grow[mh + i] * a.out_ld + u, h); }
-          }
+            }
           __builtin_amdgcn_sched_barrier(0);                               // keep the M tiles' epilogues (and the passes) apart: register pressure
         }
       }
     }
     lds_barrier();
+    slot = n + 1; cur = nxt;
+  }
+  if constexpr (EMB) {
+    if (a.out) {                                                           // final state = the last written slot
+      __syncthreads();
+      for (int i = tid; i < NRP * (H / 8); i += 256) {
+        const int row = i / (H / 8), c8 = (i % (H / 8)) * 8;
+        if (r0 + row < R) {
+          float v[8];
+          ld_f32x8(a.HN + (long)slot * RH + (r0 + row) * H + c8, v);
+          st_f32x8(a.out + (r0 + row) * a.out_ld + c8, v);
+        }
+      }
+    }
   }
 }
 
@@ -280,6 +325,7 @@ struct RowGruBwdArgs {
   const float* HN; const __bf16* gates;
   const __bf16* ext;               // [T][R][H] bf16 gradient arriving at the state after step s, or null
   const float* dh_last; long last_ld;   // gradient arriving at the final state only (rows of stride last_ld), or null
+  const int* lengths;              // EMB: the lengths the forward ran with (it skipped the panel's fully masked steps), or null
   __bf16* dgi; __bf16* dgh;        // dgi [T][R][3H] by TIME index; dgh by processing step: [T][R][3H] (EMB) or its n third only [T][R][H]
   float* dh0;                      // [R][H] or null
   __bf16* scratch;                 // [grid][2][3H/8 chunks][64 rows][8]: dgh of the workgroup's rows, K-blocked (A operand of the next step)
@@ -304,11 +350,37 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowG
   long grow[4]; bool ok[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) { ok[i] = r0 + i * 16 + erow < R; grow[i] = min(r0 + i * 16 + erow, R - 1); }
+  int pmax = a.T;
+  if constexpr (EMB) {
+    if (a.lengths) {
+      int* misc = reinterpret_cast<int*>(dhz + NRP * H);
+      if (tid == 0) misc[0] = 0;
+      __syncthreads();
+      if (tid < NRP && r0 + tid < R) atomicMax(misc, a.lengths[r0 + tid]);
+      __syncthreads();
+      pmax = min(misc[0], a.T);
+    }
+  }
   __syncthreads();
+  bool first_active = true;                                               // no later step has handed a dgh over yet
 
   for (int s = a.T - 1; s >= (a.dh0 ? -1 : 0); s--) {
-    const bool last = s == a.T - 1;
     const int tt = s < 0 ? 0 : ((EMB && a.reverse) ? a.T - 1 - s : s);
+    if constexpr (EMB) {
+      if (s >= 0 && tt >= pmax) {                                          // the forward passed the state through: zero gate gradients
+        for (int i = tid; i < NRP * (3 * H / 8); i += 256) {
+          const int row = i / (3 * H / 8), c8 = (i % (3 * H / 8)) * 8;
+          if (r0 + row < R) {
+            const bf16x8 zz = {};
+            *reinterpret_cast<bf16x8*>(a.dgh + (long)s * R3H + (r0 + row) * (3 * H) + c8) = zz;
+            *reinterpret_cast<bf16x8*>(a.dgi + (long)tt * R3H + (r0 + row) * (3 * H) + c8) = zz;
+          }
+        }
+        continue;
+      }
+    }
+    const bool last = first_active;
+    first_active = false;
     const __bf16* scr = sc + ((s + 1) & 1) * (NCH * NRP * 8);             // dgh_{s+1}, written by the previous iteration
     __bf16* scw = sc + (s & 1) * (NCH * NRP * 8);
     // HBM operands of the epilogue items (tile pairs x 4 M tiles; saved gates, previous state, external gradient) run 2 items
@@ -417,7 +489,7 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowG
 
 template <int H, bool EMB>
 static int launch_fwd(const RowGruFwdArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)(2 * NRP * (H + 16) + NRP * NT16LD) * sizeof(__bf16);
+  const size_t lds = (size_t)(2 * NRP * (H + 16) + NRP * NT16LD) * sizeof(__bf16) + 16;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(row_gru_fwd_kernel<H, EMB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PTV_ERR_LAUNCH;
@@ -428,7 +500,7 @@ static int launch_fwd(const RowGruFwdArgs& a, hipStream_t s) {
 }
 template <int H, bool EMB>
 static int launch_bwd(const RowGruBwdArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)NRP * H * sizeof(float);
+  const size_t lds = (size_t)NRP * H * sizeof(float) + 16;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(row_gru_bwd_kernel<H, EMB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PTV_ERR_LAUNCH;
@@ -462,11 +534,12 @@ extern "C" int ptv_row_gru_persist_fwd(int H, const void* w_hh, const void* w_x,
 extern "C" long ptv_row_gru_persist_scratch_elems(int H, long R) { return ((R + NRP - 1) / NRP) * 2 * ((3L * H / 8) * NRP * 8); }
 
 extern "C" int ptv_row_gru_persist_bwd(int H, const void* wt, const float* HN, const void* gates, const void* ext,
-                                       const float* dh_last, long last_ld, void* dgi, void* dgh, float* dh0, void* scratch,
-                                       long R, int T, int reverse, void* stream) {
+                                       const float* dh_last, long last_ld, const int* lengths, void* dgi, void* dgh, float* dh0,
+                                       void* scratch, long R, int T, int reverse, void* stream) {
   if (!wt || !HN || !gates || !dgi || !dgh || !scratch || R <= 0 || T <= 0 || (H != 512 && H != 128)) return PTV_ERR_ARG;
   if (dh_last && (last_ld & 3)) return PTV_ERR_ARG;
-  RowGruBwdArgs a{(const bf16x8*)wt, HN, (const __bf16*)gates, (const __bf16*)ext, dh_last, last_ld, (__bf16*)dgi, (__bf16*)dgh, dh0,
+  if (H == 512 && lengths) return PTV_ERR_UNSUPPORTED;
+  RowGruBwdArgs a{(const bf16x8*)wt, HN, (const __bf16*)gates, (const __bf16*)ext, dh_last, last_ld, lengths, (__bf16*)dgi, (__bf16*)dgh, dh0,
                   (__bf16*)scratch, (int)R, T, reverse};
   const int pi = prof::want(4, (int)R, H) ? prof::begin((hipStream_t)stream) : -1;
   if (H == 512 && (!ext || dh_last || reverse)) return PTV_ERR_UNSUPPORTED;
@@ -489,5 +562,5 @@ extern "C" long ptv_notes_gru_persist_scratch_elems(long R) { return ptv_row_gru
 extern "C" int ptv_notes_gru_persist_bwd(const void* wt, const float* HN, const void* gates, const void* ext, void* dgi, void* dgh,
                                          float* dh0, void* scratch, long R, int T, void* stream) {
   if (!ext) return PTV_ERR_ARG;
-  return ptv_row_gru_persist_bwd(512, wt, HN, gates, ext, nullptr, 0, dgi, dgh, dh0, scratch, R, T, 0, stream);
+  return ptv_row_gru_persist_bwd(512, wt, HN, gates, ext, nullptr, 0, nullptr, dgi, dgh, dh0, scratch, R, T, 0, stream);
 }

@@ -580,7 +580,7 @@ def _bigru_forward(prec, x3, lengths, w):
             call('ptv_row_gru_persist_fwd', H, ptr(pk['wg_h']), ptr(pk['wg_t']), ptr(b_hh), ptr(b_ih), None, ptr(x3), M * I,
                  ptr(lengths) if lengths is not None else None, ptr(hall), ptr(h16), ptr(gates), out.data_ptr() + 4 * d * H, 2 * H,
                  M, T, d, stream_ptr())
-            return hall, gates, h16
+            return hall, gates, h16, lengths                      # the backward must skip the same fully masked panel steps
         side = Side(7)
         rev = side(lambda: rows(1), x3, out)
         fwd = rows(0)
@@ -601,7 +601,7 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
 
     def direction(d):
         w_ih, w_hh, b_ih, b_hh = w[4 * d: 4 * d + 4]
-        hall, gates, h16 = saved[d]
+        hall, gates, h16 = saved[d][:3]
         dgi, dgh, _ = gru_bwd(prec, hall, gates, w_hh, dh_last=dout[:, d * H:(d + 1) * H], reverse=bool(d),
                               need_dh0=False)
         dgi2, dgh2 = dgi.view(T * M, 3 * H), dgh.view(T * M, 3 * H)
@@ -612,7 +612,7 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
 
     def products(d, dgi, dgh):
         w_ih, w_hh, b_ih, b_hh = w[4 * d: 4 * d + 4]
-        hall, gates, h16 = saved[d]
+        hall, gates, h16 = saved[d][:3]
         dgi2, dgh2 = dgi.view(T * M, 3 * H), dgh.view(T * M, 3 * H)
         dw_ih, db_ih = wgrad_bias(dgi2, xf, _gbuf(w_ih), _gbuf(b_ih), prec)
         dw_hh, db_hh = wgrad_bias(dgh2, (h16 if h16 is not None else hall)[:T].view(T * M, H), _gbuf(w_hh), _gbuf(b_hh), prec)
@@ -627,23 +627,25 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
         # BPTT of both directions in ONE persistent launch, then the weight-gradient products of the two on sibling streams
         chains = []
         for d in range(2):
-            hall, gates, h16 = saved[d]
+            hall, gates, h16 = saved[d][:3]
             chains.append(dict(hall=hall, gates=gates, wt16=wts[d], dh_ext=None, dh_last=dout[:, d * H:(d + 1) * H],
                                dgi=_empty(T, M, 3 * H, dev=x3.device, dtype=adt), dgh=_empty(T, M, 3 * H, dev=x3.device, dtype=adt),
                                dh0=None, reverse=bool(d)))
         gru_persist_bwd(M, H, T, chains)
         g1, dx1 = side(lambda: products(1, chains[1]['dgi'], chains[1]['dgh']), xf, dout, chains[1]['dgi'], chains[1]['dgh'])
         g0, dx0 = products(0, chains[0]['dgi'], chains[0]['dgh'])
-    elif row_gru_ok(prec, H, I, M, adt) and saved[0][1].dtype == BF16 and saved[0][2] is not None:
+    elif ((row_gru_ok(prec, H, I, M, adt) or len(saved[0]) > 3) and saved[0][1].dtype == BF16 and saved[0][2] is not None):
+        # (a forward that ran on the row kernels with lengths left the gates of skipped panel steps unwritten: same kernels back)
         def rows(d):
             w_ih, w_hh = w[4 * d], w[4 * d + 1]
-            hall, gates, h16 = saved[d]
+            hall, gates, h16 = saved[d][:3]
+            lengths = saved[d][3] if len(saved[d]) > 3 else None
             pk = notes_packs(w_ih, w_hh, 0)
             dgi = _empty(T, M, 3 * H, dev=x3.device, dtype=BF16)
             dgh = _empty(T, M, 3 * H, dev=x3.device, dtype=BF16)
             scratch = _empty(lib().ptv_row_gru_persist_scratch_elems(H, M), dev=x3.device, dtype=BF16)
             call('ptv_row_gru_persist_bwd', H, ptr(pk['wt']), ptr(hall), ptr(gates), None, dout.data_ptr() + 4 * d * H, dout.stride(0),
-                 ptr(dgi), ptr(dgh), None, ptr(scratch), M, T, d, stream_ptr())
+                 ptr(lengths) if lengths is not None else None, ptr(dgi), ptr(dgh), None, ptr(scratch), M, T, d, stream_ptr())
             return products(d, dgi, dgh)
         g1, dx1 = side(lambda: rows(1), xf, dout)
         g0, dx0 = rows(0)

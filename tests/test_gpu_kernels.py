@@ -450,11 +450,12 @@ def test_notes_gru_persistent_kernels_vs_step_kernels_and_oracle(R, T):
     assert (dh0[rows.to(dev)].cpu() - hr.grad).abs().max() < 0.05 * max(1.0, hr.grad.abs().max().item())
 
 
-@pytest.mark.parametrize('M,T', [(4096, 16), (4100, 5)])
-def test_row_gru_h128_bidirectional_with_lengths_vs_step_kernels_and_oracle(M, T, monkeypatch):
+@pytest.mark.parametrize('M,T,maxlen', [(4096, 16, 16), (4100, 5, 5), (4200, 16, 6), (4096, 16, 0)])
+def test_row_gru_h128_bidirectional_with_lengths_vs_step_kernels_and_oracle(M, T, maxlen, monkeypatch):
     """dec_notes_emb_gru through the H = 128 instance of csrc/notes_persist.hip (lengths mask, reversed direction, final state into
     its half of the summary, gradient arriving at the final state only) against the per-step path on the same operands and the
-    fp32 oracle's packed-sequence bi-GRU (oracle _bigru_final, ptvae.py:446-453)"""
+    fp32 oracle's packed-sequence bi-GRU (oracle _bigru_final, ptvae.py:446-453); short sequences (panels whose late steps are skipped
+    altogether) and the all-empty batch included"""
     from polyphonic_chord_texture_disentanglement_amd import functional as F_
     from oracle.ptvae_oracle import Oracle
     dev = _dev()
@@ -467,8 +468,11 @@ def test_row_gru_h128_bidirectional_with_lengths_vs_step_kernels_and_oracle(M, T
     cpu_w = {('g.' + n + s): U(*sh) for s in ('', '_reverse') for n, sh in zip(names, shapes)}
     order = ['g.' + n + s for s in ('', '_reverse') for n in names]
     x = torch.randn(T, M, I, generator=g) * 0.7
-    lengths = torch.randint(0, T + 1, (M,), generator=g, dtype=torch.int32)
-    lengths[:3] = torch.tensor([0, T, 1], dtype=torch.int32)
+    # maxlen < T: whole 64-row panels have nothing to do at the late note positions (the kernels pass over those steps); one panel
+    # keeps a full-length row, one row is empty
+    lengths = torch.randint(0, maxlen + 1, (M,), generator=g, dtype=torch.int32)
+    if maxlen > 0:
+        lengths[:3] = torch.tensor([0, T, 1], dtype=torch.int32)
     dout = torch.randn(M, 2 * H, generator=g) * 0.3
 
     def run(persist):
