@@ -363,8 +363,36 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowG
   }
   __syncthreads();
   bool first_active = true;                                               // no later step has handed a dgh over yet
+  int s_top = a.T - 1;
+  if constexpr (!EMB) {
+    // A step whose arriving gradient is zero for all 64 rows, with nothing arriving from later steps either, produces exactly zero
+    // gate gradients: the loss ignores the padded note slots (CrossEntropyLoss(ignore_index), ptvae.py:498-511), which are the LATE
+    // steps of every row -- on this data 8 of the 15.  Tested on the arriving gradient itself (one 64-KB read per step), so it holds
+    // for whatever loss produced it.  The BPTT proper starts at the last step that has something.
+    for (; s_top >= 0; s_top--) {
+      unsigned nz = 0;
+      for (int i = tid; i < NRP * (H / 8); i += 256) {
+        const int row = i / (H / 8), c8 = (i % (H / 8)) * 8;
+        if (r0 + row < R) {
+          typedef __attribute__((ext_vector_type(4))) unsigned u4v;
+          const u4v w = *reinterpret_cast<const u4v*>(a.ext + (long)s_top * RH + (r0 + row) * H + c8);
+          nz |= (w[0] | w[1] | w[2] | w[3]) & 0x7fff7fffu;                // -0.0 is zero too
+        }
+      }
+      if (__syncthreads_or(nz != 0)) break;
+      for (int i = tid; i < NRP * (H / 8); i += 256) {
+        const int row = i / (H / 8), c8 = (i % (H / 8)) * 8;
+        if (r0 + row < R) {
+          const bf16x8 zz = {};
+          __bf16* pi = a.dgi + (long)s_top * R3H + (r0 + row) * (3 * H) + c8;
+          *reinterpret_cast<bf16x8*>(pi) = zz; *reinterpret_cast<bf16x8*>(pi + H) = zz; *reinterpret_cast<bf16x8*>(pi + 2 * H) = zz;
+          *reinterpret_cast<bf16x8*>(a.dgh + (long)s_top * RH + (r0 + row) * H + c8) = zz;
+        }
+      }
+    }
+  }
 
-  for (int s = a.T - 1; s >= (a.dh0 ? -1 : 0); s--) {
+  for (int s = s_top; s >= (a.dh0 ? -1 : 0); s--) {
     const int tt = s < 0 ? 0 : ((EMB && a.reverse) ? a.T - 1 - s : s);
     if constexpr (EMB) {
       if (s >= 0 && tt >= pmax) {                                          // the forward passed the state through: zero gate gradients

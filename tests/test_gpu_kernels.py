@@ -381,11 +381,12 @@ def test_integration_md_snippet_runs_verbatim():
     assert (y.cpu() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize('R,T', [(512, 15), (200, 4), (16384, 2)])
-def test_notes_gru_persistent_kernels_vs_step_kernels_and_oracle(R, T):
+@pytest.mark.parametrize('R,T,zero_from', [(512, 15, None), (200, 4, None), (16384, 2, None), (512, 15, 7), (300, 6, 0)])
+def test_notes_gru_persistent_kernels_vs_step_kernels_and_oracle(R, T, zero_from):
     """csrc/notes_persist.hip (row-partitioned: a workgroup owns 64 rows for the whole sequence, token product fused, dgh through a
     K-blocked scratch tile) against the per-step kernels + separate token product on the same bf16 operands, and against the
-    fp32 oracle cell; whole / ragged last panel / the B = 512 row count"""
+    fp32 oracle cell; whole / ragged last panel / the B = 512 row count / no gradient arriving at the late steps (skipped by the
+    BPTT kernel, panel by panel)"""
     from polyphonic_chord_texture_disentanglement_amd import functional as F_
     from polyphonic_chord_texture_disentanglement_amd._lib import call, lib, ptr, stream_ptr
     dev = _dev()
@@ -399,6 +400,10 @@ def test_notes_gru_persistent_kernels_vs_step_kernels_and_oracle(R, T):
     emb = (torch.randn(T, R, E, generator=g) * 0.5).to(bf).float()
     h0 = torch.randn(R, H, generator=g) * 0.5
     ext = (torch.randn(T, R, H, generator=g) * 0.1).to(bf)
+    if zero_from is not None:                                   # no gradient arrives at the late steps (padded note slots the loss ignores):
+        ext[zero_from:] = 0                                     # the BPTT kernel passes over them; rows 64.. of step zero_from-1 too
+        if zero_from > 0:
+            ext[zero_from - 1, 64:] = 0
     d = lambda t: t.to(dev).contiguous()
     Wd = dict(w_hh=d(w_hh), w_tok=d(w_tok), b_hh=d(b_hh), gc=d(gc), emb=d(emb), ext=d(ext))
     wg_h, wg_t = F_.pack_mfma_b(Wd['w_hh'], pairs=True), F_.pack_mfma_b(Wd['w_tok'], pairs=True)
