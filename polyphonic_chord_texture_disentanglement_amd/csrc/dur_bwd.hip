@@ -95,6 +95,20 @@ __global__ __launch_bounds__(256, 1) void dur_gru_bwd_kernel(DurBwdArgs a) {
       const float2 v = *reinterpret_cast<const float2*>(a.ddur + rowc * a.ld_dd + 2 * i);
       dd[2 * i] = ok ? v.x : 0.f; dd[2 * i + 1] = ok ? v.y : 0.f;
     }
+    // a tile whose 64 rows receive no gradient (padded note slots: CrossEntropyLoss(ignore_index=2), ptvae.py:505-510 -- the late
+    // note steps of every row, about half of all tiles on this data) has exactly zero state and parameter gradients
+    {
+      bool nzr = false;
+#pragma unroll
+      for (int i = 0; i < 10; i++) nzr |= dd[i] != 0.f;
+      if (!__syncthreads_or(nzr)) {
+        if (ok) {
+#pragma unroll
+          for (int f = 0; f < 4; f++) *reinterpret_cast<float4*>(a.dh0 + row * BH + f * 16 + ug) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        continue;
+      }
+    }
     int cls[5];
     cls[0] = 0;
 #pragma unroll

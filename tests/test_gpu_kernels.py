@@ -317,6 +317,8 @@ def test_fused_duration_kernels_at_the_b512_grid_caps():
     w_out, b_out, sos = U(2, H), U(2), torch.rand(5, generator=g)
     h0 = torch.randn(M, H, generator=g) * 0.5
     ddur = torch.randn(M, 10, generator=g) * 0.1
+    ddur[M // 2 + 100: M // 2 + 64 * 50] = 0                 # whole 64-row tiles without gradient (padded note slots): the backward skips them
+    ddur[M - 64 * 3:] = 0
     d = lambda t: t.detach().to(dev).contiguous()
     tab0 = (orc.linear(sos.view(1, -1), w_ih, b_ih)).contiguous()
     oh = torch.zeros(2, 5); oh[0, 0] = 1; oh[1, 1] = 1
@@ -358,6 +360,7 @@ def test_fused_duration_kernels_at_the_b512_grid_caps():
          ptr(idx), M, ptr(dh0), ptr(part), nblk, stream_ptr())
     assert (dh0.cpu()[rows] - hr.grad).abs().max() < 0.05 * max(1.0, hr.grad.abs().max().item())
     assert torch.isfinite(part).all() and torch.isfinite(dh0).all()
+    assert (dh0[M - 64 * 3:] == 0).all() and (dh0[M // 2 + 128: M // 2 + 64 * 49] == 0).all()
 
 
 def test_integration_md_snippet_runs_verbatim():
