@@ -353,13 +353,16 @@ int ptv_free_resummarize(const void* const* w, const void* const* io, int B, int
  *   bwd: wt = pack(W_hh^T [512,1536]); ext bf16 [T][R][512] = gradient arriving at the state after step s;
  *        dgi bf16 [T][R][1536]; dgh bf16 [T][R][512] = the n third (dn * r) only -- the r and z thirds of dgh are dgi's, so
  *        grad W_hh[0:1024] = dgi[:, 0:1024]^T . h and grad W_hh[1024:] = dgh^T . h; dh0 fp32 [R][512] or NULL; scratch:
- *        ptv_notes_gru_persist_scratch_elems(R) bf16 elements.
+ *        ptv_notes_gru_persist_scratch_elems(R) bf16 elements.  The BPTT passes over the late steps of a 64-row panel at which no gradient
+ *        arrives (zero rows of ext: the padded note slots the loss ignores) and writes zero rows for them; top_step (or NULL; device int,
+ *        initialised to -1 by the caller) receives the last step at which anything arrived for any panel, so that the products over dgi /
+ *        dgh can stop after that step's rows (ptv_wgrad k_top).
  */
 int ptv_notes_gru_persist_fwd(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
                               float* HN, void* HN16, void* gates, long R, int T, void* stream);
 long ptv_notes_gru_persist_scratch_elems(long R);
 int ptv_notes_gru_persist_bwd(const void* wt, const float* HN, const void* gates, const void* ext, void* dgi, void* dgh,
-                              float* dh0, void* scratch, long R, int T, void* stream);
+                              float* dh0, void* scratch, long R, int T, int* top_step, void* stream);
 
 /* The same kernels for any GRU whose rows are many and independent; H = 512 (above) or H = 128 with 128 inputs, which is one
  * direction of dec_notes_emb_gru, the note-summary bi-GRU over the 16 notes of each of the 32*B steps (ptvae.py:446-453,480-486).
@@ -381,7 +384,7 @@ int ptv_row_gru_persist_fwd(int H, const void* w_hh, const void* w_x, const floa
 long ptv_row_gru_persist_scratch_elems(int H, long R);
 int ptv_row_gru_persist_bwd(int H, const void* wt, const float* HN, const void* gates, const void* ext,
                             const float* dh_last, long last_ld, const int* lengths, void* dgi, void* dgh, float* dh0,
-                            void* scratch, long R, int T, int reverse, void* stream);
+                            void* scratch, long R, int T, int reverse, int* top_step, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * clip_grad_norm_ (module.py:142-143) + torch.optim.Adam.step (train.py:50, scheduler.py:69-74) over
@@ -405,10 +408,12 @@ int ptv_clip_adam_step(float* p, const float* g, float* m, float* v, long n, con
  * otherwise, rounded to bf16 on the way in).  K is cut into slabs that reduce into C with fp32 atomics; slabs = 0 picks the count.
  * colsum_a (or NULL): fp32 [M] += sum_k A[k*lda + m], the bias gradient that belongs to the same layer (grad_b = column sums of
  * grad_out), taken from the A tiles while they are in LDS instead of a second pass over A (always accumulates).
+ * k_top (or NULL): device int; the rows of A from (*k_top + 1) * k_unit on are zero (the kernel that wrote A says so: the notes BPTT
+ * reports the last note step at which any gradient arrived) -- the product stops there.  k_unit must be a multiple of 32.
  * ptv_gemm(prec = bf16, transA = transB = 1) routes here.
  */
 int ptv_wgrad(int M, int N, int K, const void* A, long lda, const void* B, long ldb, float* C, long ldc, float alpha,
-              int accumulate, int dtypes, int slabs, float* colsum_a, void* stream);
+              int accumulate, int dtypes, int slabs, float* colsum_a, const int* k_top, long k_unit, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optional launch timing (bench.py roofline): HIP events recorded on the launch stream around every launch of the enabled

@@ -326,6 +326,7 @@ struct RowGruBwdArgs {
   const __bf16* ext;               // [T][R][H] bf16 gradient arriving at the state after step s, or null
   const float* dh_last; long last_ld;   // gradient arriving at the final state only (rows of stride last_ld), or null
   const int* lengths;              // EMB: the lengths the forward ran with (it skipped the panel's fully masked steps), or null
+  int* top_step;                   // !EMB: atomicMax'ed with the last step at which a gradient arrived for any panel (or null)
   __bf16* dgi; __bf16* dgh;        // dgi [T][R][3H] by TIME index; dgh by processing step: [T][R][3H] (EMB) or its n third only [T][R][H]
   float* dh0;                      // [R][H] or null
   __bf16* scratch;                 // [grid][2][3H/8 chunks][64 rows][8]: dgh of the workgroup's rows, K-blocked (A operand of the next step)
@@ -390,6 +391,7 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowG
         }
       }
     }
+    if (a.top_step && tid == 0 && s_top >= 0) atomicMax(a.top_step, s_top);   // consumers of dgi / dgh may stop after this step's rows
   }
 
   for (int s = s_top; s >= (a.dh0 ? -1 : 0); s--) {
@@ -563,11 +565,11 @@ extern "C" long ptv_row_gru_persist_scratch_elems(int H, long R) { return ((R + 
 
 extern "C" int ptv_row_gru_persist_bwd(int H, const void* wt, const float* HN, const void* gates, const void* ext,
                                        const float* dh_last, long last_ld, const int* lengths, void* dgi, void* dgh, float* dh0,
-                                       void* scratch, long R, int T, int reverse, void* stream) {
+                                       void* scratch, long R, int T, int reverse, int* top_step, void* stream) {
   if (!wt || !HN || !gates || !dgi || !dgh || !scratch || R <= 0 || T <= 0 || (H != 512 && H != 128)) return PTV_ERR_ARG;
   if (dh_last && (last_ld & 3)) return PTV_ERR_ARG;
   if (H == 512 && lengths) return PTV_ERR_UNSUPPORTED;
-  RowGruBwdArgs a{(const bf16x8*)wt, HN, (const __bf16*)gates, (const __bf16*)ext, dh_last, last_ld, lengths, (__bf16*)dgi, (__bf16*)dgh, dh0,
+  RowGruBwdArgs a{(const bf16x8*)wt, HN, (const __bf16*)gates, (const __bf16*)ext, dh_last, last_ld, lengths, top_step, (__bf16*)dgi, (__bf16*)dgh, dh0,
                   (__bf16*)scratch, (int)R, T, reverse};
   const int pi = prof::want(4, (int)R, H) ? prof::begin((hipStream_t)stream) : -1;
   if (H == 512 && (!ext || dh_last || reverse)) return PTV_ERR_UNSUPPORTED;
@@ -588,7 +590,7 @@ extern "C" int ptv_notes_gru_persist_fwd(const void* wg_h, const void* wg_t, con
 extern "C" long ptv_notes_gru_persist_scratch_elems(long R) { return ptv_row_gru_persist_scratch_elems(512, R); }
 
 extern "C" int ptv_notes_gru_persist_bwd(const void* wt, const float* HN, const void* gates, const void* ext, void* dgi, void* dgh,
-                                         float* dh0, void* scratch, long R, int T, void* stream) {
+                                         float* dh0, void* scratch, long R, int T, int* top_step, void* stream) {
   if (!ext) return PTV_ERR_ARG;
-  return ptv_row_gru_persist_bwd(512, wt, HN, gates, ext, nullptr, 0, nullptr, dgi, dgh, dh0, scratch, R, T, 0, stream);
+  return ptv_row_gru_persist_bwd(512, wt, HN, gates, ext, nullptr, 0, nullptr, dgi, dgh, dh0, scratch, R, T, 0, top_step, stream);
 }

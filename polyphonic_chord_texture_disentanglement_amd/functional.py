@@ -399,17 +399,19 @@ def _bgrad_hh(b_hh, dgh2, gb_ih):
 WGRAD_FUSE_BIAS = os.environ.get('PTV_WGRAD_BIAS', '1') != '0'
 
 
-def wgrad_bias(dy, x, gw, gb, prec):
-    """gw [N_out, N_in] += dy^T . x and gb [N_out] += column sums of dy: a layer's weight and bias gradient in one pass over
-    dy (ptv_wgrad's colsum_a) where the weight-gradient kernel applies; otherwise the product and a column-sum kernel"""
+def wgrad_bias(dy, x, gw, gb, prec, k_top=None, k_unit=0):
+    """gw [N_out, N_in] += dy^T . x and gb [N_out] (or None) += column sums of dy: a layer's weight and bias gradient in one pass
+    over dy (ptv_wgrad's colsum_a) where the weight-gradient kernel applies; otherwise the product and a column-sum kernel.
+    k_top (device int) / k_unit: the rows of dy from (k_top + 1) * k_unit on are zero (ptv_wgrad)"""
     K = dy.shape[0]
     if (WGRAD_FUSE_BIAS and prec == 1 and K >= 512 and gw.dtype == F32 and dy.stride(1) == 1 and x.stride(1) == 1
             and os.environ.get('PTV_WGRAD', '1') != '0'):
         call('ptv_wgrad', dy.shape[1], x.shape[1], K, ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(gw), _ld(gw), 1.0, 1,
-             _bf(dy) | (_bf(x) << 1), 0, ptr(gb), stream_ptr())
+             _bf(dy) | (_bf(x) << 1), 0, ptr(gb), ptr(k_top), int(k_unit), stream_ptr())
     else:
         gemm(dy, x, gw, ta=True, tb=True, acc=True, prec=prec)
-        colsum(gb.view(1, -1), dy)
+        if gb is not None:
+            colsum(gb.view(1, -1), dy)
     return gw, gb
 
 
@@ -645,7 +647,7 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
             dgh = _empty(T, M, 3 * H, dev=x3.device, dtype=BF16)
             scratch = _empty(lib().ptv_row_gru_persist_scratch_elems(H, M), dev=x3.device, dtype=BF16)
             call('ptv_row_gru_persist_bwd', H, ptr(pk['wt']), ptr(hall), ptr(gates), None, dout.data_ptr() + 4 * d * H, dout.stride(0),
-                 ptr(lengths) if lengths is not None else None, ptr(dgi), ptr(dgh), None, ptr(scratch), M, T, d, stream_ptr())
+                 ptr(lengths) if lengths is not None else None, ptr(dgi), ptr(dgh), None, ptr(scratch), M, T, d, None, stream_ptr())
             return products(d, dgi, dgh)
         g1, dx1 = side(lambda: rows(1), xf, dout)
         g0, dx0 = rows(0)
@@ -1087,9 +1089,11 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
         dgh_n = _empty(15, R, Hn, dev=dev, dtype=BF16)          # n third only: the r / z thirds of dgh are dgi's
         dHN0 = _empty(R, Hn, dev=dev)
         scratch = _empty(lib().ptv_notes_gru_persist_scratch_elems(R), dev=dev, dtype=BF16)
+        top_step = torch.full((1,), -1, device=dev, dtype=torch.int32)     # <- last note step at which any gradient arrived
         call('ptv_notes_gru_persist_bwd', ptr(pk['wt']), ptr(HN), ptr(st['gates_n']), ptr(dNSUM), ptr(dgi_n), ptr(dgh_n), ptr(dHN0),
-             ptr(scratch), R, 15, stream_ptr())
+             ptr(scratch), R, 15, ptr(top_step), stream_ptr())
     else:
+        top_step = None
         dgi_n, dgh_n, dHN0 = gru_bwd(prec, HN, st['gates_n'], w_hh_n, dh_ext=dNSUM.view(15, R, Hn))
     dGC = sum_steps(dgi_n)                                                    # [R, 3Hn]
     dtok = _empty(16, R, E, dev=dev)
@@ -1106,13 +1110,19 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
                 if G[name] is None:
                     G[name] = _gbuf(P[name])
             gw, gb, h_op = G['dec_notes_gru.weight_hh_l0'], G['dec_notes_gru.bias_hh_l0'], HNo[:15].view(M, Hn)
-            wgrad_bias(dgi_n.view(M, 3 * Hn)[:, :2 * Hn], h_op, gw[:2 * Hn], gb[:2 * Hn], prec)
-            wgrad_bias(dgh_n.view(M, Hn), h_op, gw[2 * Hn:], gb[2 * Hn:], prec)
+            # (the rows of dgi / dgh after the last step that received a gradient are zero: the products stop there)
+            wgrad_bias(dgi_n.view(M, 3 * Hn)[:, :2 * Hn], h_op, gw[:2 * Hn], gb[:2 * Hn], prec, top_step, R)
+            wgrad_bias(dgh_n.view(M, Hn), h_op, gw[2 * Hn:], gb[2 * Hn:], prec, top_step, R)
         else:
             wgrad_b('dec_notes_gru.weight_hh_l0', 'dec_notes_gru.bias_hh_l0', dgh_n.view(M, 3 * Hn), HNo[:15].view(M, Hn))
         bgrad('dec_notes_gru.bias_ih_l0', dGC)
         wgrad('dec_notes_gru.weight_ih_l0', dGC, NSf_op, slice(0, Ht))
-        wgrad('dec_notes_gru.weight_ih_l0', dgi_n.view(M, 3 * Hn), tok_op, slice(Ht, None))
+        if top_step is not None:
+            if G['dec_notes_gru.weight_ih_l0'] is None:
+                G['dec_notes_gru.weight_ih_l0'] = _gbuf(P['dec_notes_gru.weight_ih_l0'])
+            wgrad_bias(dgi_n.view(M, 3 * Hn), tok_op, G['dec_notes_gru.weight_ih_l0'][:, Ht:], None, prec, top_step, R)
+        else:
+            wgrad('dec_notes_gru.weight_ih_l0', dgi_n.view(M, 3 * Hn), tok_op, slice(Ht, None))
         wgrad('dec_time_to_notes_hid.weight', dHN0, NSf_op)
         bgrad('dec_time_to_notes_hid.bias', dHN0)
     side(notes_wgrads, dgi_n, dgh_n, dGC, dHN0, dNSUM)

@@ -48,7 +48,7 @@ def p_fwd():
 
 
 def p_bwd():
-    call('ptv_notes_gru_persist_bwd', ptr(wt), ptr(HN), ptr(gates), ptr(ext), ptr(dgi), ptr(dgh), ptr(dh0), ptr(scratch), R, T, stream_ptr())
+    call('ptv_notes_gru_persist_bwd', ptr(wt), ptr(HN), ptr(gates), ptr(ext), ptr(dgi), ptr(dgh), ptr(dh0), ptr(scratch), R, T, None, stream_ptr())
 
 
 def s_fwd():

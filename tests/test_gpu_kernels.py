@@ -419,7 +419,7 @@ def test_notes_gru_persistent_kernels_vs_step_kernels_and_oracle(R, T, zero_from
     dgi = torch.zeros(T, R, 3 * H, device=dev, dtype=bf); dgh = torch.zeros(T, R, H, device=dev, dtype=bf)     # dgh: n third only
     dh0 = torch.zeros(R, H, device=dev)
     scratch = torch.empty(lib().ptv_notes_gru_persist_scratch_elems(R), device=dev, dtype=bf)
-    call('ptv_notes_gru_persist_bwd', ptr(wt), ptr(HN), ptr(gates), ptr(Wd['ext']), ptr(dgi), ptr(dgh), ptr(dh0), ptr(scratch), R, T, stream_ptr())
+    call('ptv_notes_gru_persist_bwd', ptr(wt), ptr(HN), ptr(gates), ptr(Wd['ext']), ptr(dgi), ptr(dgh), ptr(dh0), ptr(scratch), R, T, None, stream_ptr())
     # ---- the per-step kernels on the same operands
     GT = F_.gemm(Wd['emb'].view(T * R, E), Wd['w_tok'].to(bf), prec=1, out_dtype=bf)
     HN2 = torch.zeros_like(HN); HN2[0] = HN[0]
@@ -533,14 +533,26 @@ def test_wgrad_kernel_vs_fp64_product_and_column_sums(M, N, K, dt, pad):
     for slabs in (0, 1, 3, 8):
         C = C0.to(dev).clone()
         bias = b0.to(dev).clone()
-        call('ptv_wgrad', M, N, K, ptr(Ad), Ad.stride(0), ptr(Bd), Bd.stride(0), ptr(C), C.stride(0), 0.5, 1, dt, slabs, ptr(bias), stream_ptr())
+        call('ptv_wgrad', M, N, K, ptr(Ad), Ad.stride(0), ptr(Bd), Bd.stride(0), ptr(C), C.stride(0), 0.5, 1, dt, slabs, ptr(bias), None, 0, stream_ptr())
         torch.cuda.synchronize()
         sc = max(1.0, want.abs().max().item())
         assert (C.cpu().double() - want).abs().max() < 2e-5 * sc, slabs
         assert (bias.cpu().double() - want_b).abs().max() < 2e-5 * max(1.0, want_b.abs().max().item()), slabs
+    # k_top: the caller knows the rows from (k_top + 1) * k_unit on are zero -- same result on an operand where they are
+    if K >= 128:
+        unit, top = 32, (K // 32) // 2 - 1
+        Az = Ad.clone(); Az[(top + 1) * unit:] = 0
+        ktop = torch.tensor([top], device=dev, dtype=torch.int32)
+        Ca, Cb = C0.to(dev).clone(), C0.to(dev).clone()
+        ba, bb = b0.to(dev).clone(), b0.to(dev).clone()
+        call('ptv_wgrad', M, N, K, ptr(Az), Az.stride(0), ptr(Bd), Bd.stride(0), ptr(Ca), Ca.stride(0), 0.5, 1, dt, 0, ptr(ba), None, 0, stream_ptr())
+        call('ptv_wgrad', M, N, K, ptr(Az), Az.stride(0), ptr(Bd), Bd.stride(0), ptr(Cb), Cb.stride(0), 0.5, 1, dt, 0, ptr(bb), ptr(ktop), unit,
+             stream_ptr())
+        torch.cuda.synchronize()
+        assert (Ca - Cb).abs().max() < 2e-5 * max(1.0, Ca.abs().max().item()) and (ba - bb).abs().max() < 2e-5 * max(1.0, ba.abs().max().item())
     # accumulate = 0 overwrites C; through ptv_gemm (the route the autograd functions take)
     C = torch.full((M, N), 7.0, device=dev)
-    call('ptv_wgrad', M, N, K, ptr(Ad), Ad.stride(0), ptr(Bd), Bd.stride(0), ptr(C), C.stride(0), 1.0, 0, dt, 0, None, stream_ptr())
+    call('ptv_wgrad', M, N, K, ptr(Ad), Ad.stride(0), ptr(Bd), Bd.stride(0), ptr(C), C.stride(0), 1.0, 0, dt, 0, None, None, 0, stream_ptr())
     C2 = C0.to(dev).clone()
     call('ptv_gemm', 1, 1, 1, M, N, K, ptr(Ad), Ad.stride(0), ptr(Bd), Bd.stride(0), ptr(C2), C2.stride(0), None, 0.5, 1, 0, 0, dt, stream_ptr())
     torch.cuda.synchronize()
