@@ -61,6 +61,11 @@ int ptv_gemm(int prec, int transA, int transB, int M, int N, int K,
              const void* A, long lda, const void* B, long ldb,
              void* C, long ldc, const float* bias, float alpha,
              int accumulate, int act, int splitk, int dtypes, void* stream);
+/* the same with a row limit on A (transA = 0): the rows of A from (*m_top + 1) * m_unit on are known to be zero (device int written
+ * by the kernel that produced A, see ptv_notes_gru_persist_bwd): those row tiles skip the product, C gets bias / stays as it is */
+int ptv_gemm_mtop(int prec, int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
+                  void* C, long ldc, const float* bias, float alpha, int accumulate, int act, int splitk, int dtypes,
+                  const int* m_top, long m_unit, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GRU recurrence over T steps for M independent rows (torch.nn.GRU cell semantics; replaces the
@@ -155,6 +160,9 @@ int ptv_copy2d(float* dst, long ldd, const float* src, long lds, long rows, int 
 int ptv_transpose01(float* dst, const float* src, int D0, int D1, int W, void* stream);
 /* out[i] = (accumulate ? out[i] : 0) + sum_t in[t*stride + i] */
 int ptv_sum_steps(float* out, const void* in, long n, int T, long stride, int accumulate, int in_bf16, void* stream);
+/* the same over the planes 0 .. *t_top only (device int; the later planes are known to be zero, see ptv_notes_gru_persist_bwd) */
+int ptv_sum_steps_top(float* out, const void* in, long n, int T, long stride, int accumulate, int in_bf16, const int* t_top,
+                      void* stream);
 /* out[g*N + n] += sum over rows r with (sel ? sel[r] : 0) == g of A[r*lda + n]   (bias gradients;
  * with sel: the duration GRU's W_ih gradient, whose inputs are one-hot tokens) */
 int ptv_colsum(float* out, const void* A, long lda, long rows, int N, const int* sel, int G, int a_bf16, void* stream);

@@ -36,7 +36,8 @@ __global__ void transpose01_kernel(float* dst, const float* src, int D0, int D1,
 }
 
 // out[i] = (accumulate? out[i] : 0) + sum_t in[t*stride + i]
-__global__ void sum_steps_kernel(float* out, const void* in, long n, int T, long stride, int accumulate, int in_bf16) {
+__global__ void sum_steps_kernel(float* out, const void* in, long n, int T, long stride, int accumulate, int in_bf16, const int* t_top) {
+  if (t_top) T = min(T, *t_top + 1);                              // the planes after *t_top are known to be zero
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float s = accumulate ? out[i] : 0.f;
     for (int t = 0; t < T; t++) s += ld1f(in, t * stride + i, in_bf16);
@@ -46,8 +47,10 @@ __global__ void sum_steps_kernel(float* out, const void* in, long n, int T, long
 
 // vector form: 16-byte loads (8 bf16 / 4 fp32 per thread), the T planes of one element group requested together
 template <bool BF>
-__global__ void sum_steps_vec_kernel(float* __restrict__ out, const void* __restrict__ in, long nvec, int T, long stride, int accumulate) {
+__global__ void sum_steps_vec_kernel(float* __restrict__ out, const void* __restrict__ in, long nvec, int T, long stride, int accumulate,
+                                     const int* __restrict__ t_top) {
   constexpr int E = BF ? 8 : 4;
+  if (t_top) T = min(T, *t_top + 1);
   for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
     const long i = v * E;
     float s[E];
@@ -247,15 +250,20 @@ extern "C" int ptv_transpose01(float* dst, const float* src, int D0, int D1, int
   return PTV_OK;
 }
 
-extern "C" int ptv_sum_steps(float* out, const void* in, long n, int T, long stride, int accumulate, int in_bf16, void* stream) {
+extern "C" int ptv_sum_steps_top(float* out, const void* in, long n, int T, long stride, int accumulate, int in_bf16, const int* t_top,
+                                 void* stream) {
   if (!out || !in || n <= 0 || T <= 0) return PTV_ERR_ARG;
   const int E = in_bf16 ? 8 : 4;
   const bool vec = (n % E) == 0 && (stride % E) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-  if (vec && in_bf16) hipLaunchKernelGGL(sum_steps_vec_kernel<true>, dim3(grid_for(n / E)), dim3(256), 0, (hipStream_t)stream, out, in, n / E, T, stride, accumulate);
-  else if (vec) hipLaunchKernelGGL(sum_steps_vec_kernel<false>, dim3(grid_for(n / E)), dim3(256), 0, (hipStream_t)stream, out, in, n / E, T, stride, accumulate);
-  else hipLaunchKernelGGL(sum_steps_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, in, n, T, stride, accumulate, in_bf16);
+  if (vec && in_bf16) hipLaunchKernelGGL(sum_steps_vec_kernel<true>, dim3(grid_for(n / E)), dim3(256), 0, (hipStream_t)stream, out, in, n / E, T, stride, accumulate, t_top);
+  else if (vec) hipLaunchKernelGGL(sum_steps_vec_kernel<false>, dim3(grid_for(n / E)), dim3(256), 0, (hipStream_t)stream, out, in, n / E, T, stride, accumulate, t_top);
+  else hipLaunchKernelGGL(sum_steps_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, in, n, T, stride, accumulate, in_bf16, t_top);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
+}
+
+extern "C" int ptv_sum_steps(float* out, const void* in, long n, int T, long stride, int accumulate, int in_bf16, void* stream) {
+  return ptv_sum_steps_top(out, in, n, T, stride, accumulate, in_bf16, nullptr, stream);
 }
 
 extern "C" int ptv_colsum(float* out, const void* A, long lda, long rows, int N, const int* sel, int G, int a_bf16, void* stream) {

@@ -208,10 +208,10 @@ static int gemm_dispatch(int transA, int transB, GemmArgs g, EpiPlain::Params ep
 
 }  // namespace ptv
 
-extern "C" int ptv_gemm(int prec, int transA, int transB, int M, int N, int K,
-                        const void* A, long lda, const void* B, long ldb,
-                        void* C, long ldc, const float* bias, float alpha,
-                        int accumulate, int act, int splitk, int dtypes, void* stream) {
+extern "C" int ptv_gemm_mtop(int prec, int transA, int transB, int M, int N, int K,
+                             const void* A, long lda, const void* B, long ldb,
+                             void* C, long ldc, const float* bias, float alpha,
+                             int accumulate, int act, int splitk, int dtypes, const int* m_top, long m_unit, void* stream) {
   if (M < 0 || N < 0 || K < 0 || !A || !B || !C) return PTV_ERR_ARG;
   if (M == 0 || N == 0) return PTV_OK;
   const bool sa = dtypes & 1, sb = dtypes & 2, sc = dtypes & 4;
@@ -221,7 +221,8 @@ extern "C" int ptv_gemm(int prec, int transA, int transB, int M, int N, int K,
   static const bool use_wgrad = [] { const char* e = getenv("PTV_WGRAD"); return !(e && e[0] == '0'); }();
   if (use_wgrad && prec == PTV_PREC_BF16 && transA && transB && !sc && !bias && act == 0 && K >= 512 && splitk <= 0)
     return ptv_wgrad(M, N, K, A, lda, B, ldb, reinterpret_cast<float*>(C), ldc, alpha, accumulate, dtypes & 3, 0, nullptr, nullptr, 0, stream);
-  ptv::GemmArgs g{A, lda, B, ldb, M, N, K, K, 0};
+  if (m_top && (transA || m_unit <= 0)) return PTV_ERR_ARG;            // a row limit on A: A must be row-per-sample
+  ptv::GemmArgs g{A, lda, B, ldb, M, N, K, K, 0, m_top, m_unit};
   ptv::EpiPlain::Params ep{C, ldc, bias, alpha, accumulate, act, 0, sc ? 1 : 0};
   hipStream_t s = (hipStream_t)stream;
   int rc;
@@ -233,4 +234,11 @@ extern "C" int ptv_gemm(int prec, int transA, int transB, int M, int N, int K,
   if (rc != PTV_OK) return rc;
   PTV_CHECK_LAUNCH();
   return PTV_OK;
+}
+
+extern "C" int ptv_gemm(int prec, int transA, int transB, int M, int N, int K,
+                        const void* A, long lda, const void* B, long ldb,
+                        void* C, long ldc, const float* bias, float alpha,
+                        int accumulate, int act, int splitk, int dtypes, void* stream) {
+  return ptv_gemm_mtop(prec, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, accumulate, act, splitk, dtypes, nullptr, 0, stream);
 }

@@ -70,6 +70,7 @@ struct GemmArgs {
   int M, N, K;
   int k_per_split;            // K range handled by one blockIdx.z (multiple of BK); == K when no split
   long gate_stride;           // NG==3: B row of gate g, unit j is g*gate_stride + j   (N = #units)
+  const int* m_top; long m_unit;   // rows of A from (*m_top + 1) * m_unit on are known to be zero (or null): those tiles skip the K loop
 };
 
 // LDS image of a tile: [row][128 bytes], the eight 16-byte chunks of row r XOR-permuted by
@@ -436,7 +437,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
   }
   const int m_blk = mt * BM, n_blk = nt * BN;
   const int kbeg = split * g.k_per_split;
-  const int kend = min(g.K, kbeg + g.k_per_split);
+  // a row tile that lies in the part of A its producer declared zero contributes nothing: empty K range, the epilogue still runs
+  // (C = bias / unchanged)
+  const bool dead = g.m_top != nullptr && m_blk >= ((long)*g.m_top + 1) * g.m_unit;
+  const int kend = dead ? kbeg : min(g.K, kbeg + g.k_per_split);
   const int wave = threadIdx.x >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
 

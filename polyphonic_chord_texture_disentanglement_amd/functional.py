@@ -75,7 +75,8 @@ def _ld(t):
     return t.stride(0)
 
 
-def gemm(a, b, out=None, *, ta=False, tb=False, bias=None, alpha=1.0, acc=False, act=0, prec=0, splitk=0, out_dtype=F32):
+def gemm(a, b, out=None, *, ta=False, tb=False, bias=None, alpha=1.0, acc=False, act=0, prec=0, splitk=0, out_dtype=F32, m_top=None,
+         m_unit=0):
     """out[M,N] = act(alpha * op(a) . op(b)^T + bias) (+ out);  see ptv_gemm in include/ptvae_hip.h.
     a / b / out may be bf16 tensors (bf16 precision only)."""
     M, K = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
@@ -86,6 +87,10 @@ def gemm(a, b, out=None, *, ta=False, tb=False, bias=None, alpha=1.0, acc=False,
         out = _empty(M, N, dev=a.device, dtype=out_dtype)
     assert tuple(out.shape) == (M, N), (out.shape, M, N)
     dt = _bf(a) | (_bf(b) << 1) | (_bf(out) << 2)
+    if m_top is not None:                                   # rows of a from (m_top + 1) * m_unit on are zero (device int)
+        call('ptv_gemm_mtop', prec, int(ta), int(tb), M, N, K, ptr(a), _ld(a), ptr(b), _ld(b), ptr(out), _ld(out),
+             ptr(bias), float(alpha), int(acc), int(act), int(-1 if _bf(out) else splitk), dt, ptr(m_top), int(m_unit), stream_ptr())
+        return out
     call('ptv_gemm', prec, int(ta), int(tb), M, N, K, ptr(a), _ld(a), ptr(b), _ld(b), ptr(out), _ld(out),
          ptr(bias), float(alpha), int(acc), int(act), int(-1 if _bf(out) else splitk), dt, stream_ptr())
     return out
@@ -105,13 +110,14 @@ def colsum(out, a, sel=None, groups=1):
     return out
 
 
-def sum_steps(x3, out=None, acc=False):
+def sum_steps(x3, out=None, acc=False, t_top=None):
+    """out = sum over the leading axis; t_top (device int): the planes after it are known to be zero"""
     T = x3.shape[0]
     n = x3[0].numel()
     assert x3.is_contiguous()
     if out is None:
         out = _empty(*x3.shape[1:], dev=x3.device)
-    call('ptv_sum_steps', ptr(out), ptr(x3), n, T, n, int(acc), _bf(x3), stream_ptr())
+    call('ptv_sum_steps_top', ptr(out), ptr(x3), n, T, n, int(acc), _bf(x3), ptr(t_top), stream_ptr())
     return out
 
 
@@ -132,13 +138,13 @@ def _WT(p, prec):
     return None
 
 
-def gemm_dx(dy, w, cols=None, out=None, *, acc=False, prec=0):
+def gemm_dx(dy, w, cols=None, out=None, *, acc=False, prec=0, m_top=None, m_unit=0):
     """input gradient of a Linear: dy . w[:, cols].  With a transposed bf16 shadow of w this is a K-contiguous
     (NT) product on bf16 weight tiles; otherwise the fp32 weight is read K-major."""
     wt = _WT(w, prec)
     if wt is not None:
-        return gemm(dy, wt if cols is None else wt[cols, :], out, acc=acc, prec=prec)
-    return gemm(dy, w if cols is None else w[:, cols], out, tb=True, acc=acc, prec=prec)
+        return gemm(dy, wt if cols is None else wt[cols, :], out, acc=acc, prec=prec, m_top=m_top, m_unit=m_unit)
+    return gemm(dy, w if cols is None else w[:, cols], out, tb=True, acc=acc, prec=prec, m_top=m_top, m_unit=m_unit)
 
 
 def _gru_flags(gates=None, gi=None, gi2=None, dg=None, w=None, ext=None):
@@ -1095,10 +1101,10 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     else:
         top_step = None
         dgi_n, dgh_n, dHN0 = gru_bwd(prec, HN, st['gates_n'], w_hh_n, dh_ext=dNSUM.view(15, R, Hn))
-    dGC = sum_steps(dgi_n)                                                    # [R, 3Hn]
+    dGC = sum_steps(dgi_n, t_top=top_step)                                    # [R, 3Hn]
     dtok = _empty(16, R, E, dev=dev)
     dtok[15].zero_()
-    gemm_dx(dgi_n.view(M, 3 * Hn), w_ih_n, slice(Ht, None), out=dtok[:15].view(M, E), prec=prec)
+    gemm_dx(dgi_n.view(M, 3 * Hn), w_ih_n, slice(Ht, None), out=dtok[:15].view(M, E), prec=prec, m_top=top_step, m_unit=R)
     dNS = gemm_dx(dGC, w_ih_n, slice(0, Ht), prec=prec)                       # [R, Ht]
     w_tn = W['dec_time_to_notes_hid.weight']
     gemm_dx(dHN0, w_tn, out=dNS, acc=True, prec=prec)

@@ -593,3 +593,26 @@ def test_embed_fwd_and_multihot_kernels_vs_oracle_emb_x(B):
     want = torch.cat([onehot[..., :130], xt[..., 1:].float()], -1).permute(2, 1, 0, 3).reshape(16 * 32 * B, 135)
     assert torch.equal(mh[:, :135].cpu(), want)
     assert (mh[:, 135] == -1.0).all()                                          # the padding column is the caller's
+
+
+@pytest.mark.parametrize('acc', [False, True])
+def test_gemm_row_limit_and_sum_steps_plane_limit_equal_the_dense_kernels(acc):
+    """ptv_gemm_mtop / ptv_sum_steps_top: a producer declares the tail of an operand zero through a device int (the notes BPTT's
+    top_step); the limited kernels give what the dense ones give on an operand whose tail IS zero -- bias rows included"""
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    T, R, K, N = 7, 192, 96, 40
+    top = torch.tensor([3], device=dev, dtype=torch.int32)
+    A = torch.randn(T, R, K, generator=g).to(dev)
+    A[4:] = 0
+    W = torch.randn(N, K, generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    for prec, a_ in ((0, A), (1, A.to(torch.bfloat16))):
+        c0 = torch.randn(T * R, N, generator=g).to(dev)
+        dense = F_.gemm(a_.view(T * R, K), W, c0.clone() if acc else None, bias=None if acc else bias, acc=acc, prec=prec)
+        lim = F_.gemm(a_.view(T * R, K), W, c0.clone() if acc else None, bias=None if acc else bias, acc=acc, prec=prec, m_top=top, m_unit=R)
+        assert torch.equal(dense, lim)
+        s0 = F_.sum_steps(a_)
+        s1 = F_.sum_steps(a_, t_top=top)
+        assert torch.equal(s0, s1)
