@@ -161,6 +161,9 @@ int ptv_transpose01(float* dst, const float* src, int D0, int D1, int W, void* s
 /* out[i] = (accumulate ? out[i] : 0) + sum_t in[t*stride + i] */
 int ptv_sum_steps(float* out, const void* in, long n, int T, long stride, int accumulate, int in_bf16, void* stream);
 /* the same over the planes 0 .. *t_top only (device int; the later planes are known to be zero, see ptv_notes_gru_persist_bwd) */
+/* *top = max(*top, index of the last `unit`-row block of x [rows, cols] (fp32, row stride ld) that holds a non-zero): which trailing
+ * note steps of a gradient received nothing (the loss ignores padded slots) -- the limit handed to ptv_gemm_mtop / ptv_wgrad */
+int ptv_last_nonzero_unit(const float* x, long rows, int cols, long ld, long unit, int* top, void* stream);
 int ptv_sum_steps_top(float* out, const void* in, long n, int T, long stride, int accumulate, int in_bf16, const int* t_top,
                       void* stream);
 /* out[g*N + n] += sum over rows r with (sel ? sel[r] : 0) == g of A[r*lda + n]   (bias gradients;

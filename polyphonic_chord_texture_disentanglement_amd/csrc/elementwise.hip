@@ -250,6 +250,24 @@ extern "C" int ptv_transpose01(float* dst, const float* src, int D0, int D1, int
   return PTV_OK;
 }
 
+// top = max(top, (last row block that holds a non-zero) / unit): which trailing part of a gradient matrix is all zero
+__global__ void last_nonzero_kernel(const float* __restrict__ x, long rows, int cols, long ld, long unit, int* __restrict__ top) {
+  const long chunks = (rows + 63) / 64;
+  for (long c = chunks - 1 - blockIdx.x; c >= 0; c -= gridDim.x) {
+    if ((c * 64) / unit <= *reinterpret_cast<volatile int*>(top)) break;            // already covered by a later block's report
+    bool nz = false;
+    const long r1 = min(rows, (c + 1) * 64);
+    for (long i = c * 64 * (long)cols + threadIdx.x; i < r1 * cols; i += blockDim.x) {
+      const long r = i / cols; const int q = (int)(i % cols);
+      nz |= x[r * ld + q] != 0.f;
+    }
+    if (__syncthreads_or(nz)) {
+      if (threadIdx.x == 0) atomicMax(top, (int)((r1 - 1) / unit));
+      break;                                                                       // every earlier chunk of this block is below it
+    }
+  }
+}
+
 extern "C" int ptv_sum_steps_top(float* out, const void* in, long n, int T, long stride, int accumulate, int in_bf16, const int* t_top,
                                  void* stream) {
   if (!out || !in || n <= 0 || T <= 0) return PTV_ERR_ARG;
@@ -307,6 +325,14 @@ extern "C" int ptv_reparam_kl_bwd(const float* mu, const float* sd, const float*
                                   const float* dmu_ext, const float* dsd_ext, float klw, int mul_sd, float* dmu, float* dlv, int B, int Z, void* stream) {
   if (!mu || !sd || !dmu || !dlv || B <= 0 || Z <= 0) return PTV_ERR_ARG;
   hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3(grid_for((long)B * Z)), dim3(256), 0, (hipStream_t)stream, mu, sd, eps, dz, lddz, dmu_ext, dsd_ext, klw, mul_sd, dmu, dlv, B, Z);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_last_nonzero_unit(const float* x, long rows, int cols, long ld, long unit, int* top, void* stream) {
+  if (!x || !top || rows <= 0 || cols <= 0 || ld < cols || unit <= 0) return PTV_ERR_ARG;
+  long nb = (rows + 63) / 64; if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(last_nonzero_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, unit, top);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

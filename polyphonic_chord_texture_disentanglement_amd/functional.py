@@ -1031,13 +1031,14 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     def bgrad(name, a):
         G[name] = _bgrad(P[name], a)
 
-    def wgrad_b(name, bname, dy, x, sub=None):
-        """G[name][:, sub] += dy^T . x and G[bname] += column sums of dy, one pass over dy"""
+    def wgrad_b(name, bname, dy, x, sub=None, k_top=None):
+        """G[name][:, sub] += dy^T . x and (bname) G[bname] += column sums of dy, one pass over dy; k_top: the rows of dy after note
+        step k_top (device int) are zero"""
         if G[name] is None:
             G[name] = _gbuf(P[name])
-        if G[bname] is None:
+        if bname is not None and G[bname] is None:
             G[bname] = _gbuf(P[bname])
-        wgrad_bias(dy, x, G[name] if sub is None else G[name][:, sub], G[bname], prec)
+        wgrad_bias(dy, x, G[name] if sub is None else G[name][:, sub], G[bname] if bname is not None else None, prec, k_top, R)
 
     ddur = (ddur.contiguous() if ddur is not None else _zeros(M, 5, 2, dev=dev)).view(M, 10)
     dP = _empty(M, _pad8(NP), dev=dev)[:, :NP]               # row-padded like the logits
@@ -1045,6 +1046,12 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
         copy2d(dP, _rows2d(dpitch))
     else:
         copy2d(dP, _zeros(1, NP, dev=dev), lds=0)
+
+    # the loss ignores the padded note slots (the late note steps of every row): find the last note step that received any gradient
+    # (on the gradients themselves) -- the head products below stop there, as the BPTT does on its own
+    top_h = torch.full((1,), -1, device=dev, dtype=torch.int32)
+    call('ptv_last_nonzero_unit', ptr(dP), M, NP, dP.stride(0), R, ptr(top_h), stream_ptr())
+    call('ptv_last_nonzero_unit', ptr(ddur), M, 10, 10, R, ptr(top_h), stream_ptr())
 
     # ---- duration GRU (5 steps) ----
     w_out = P['dur_out_linear.weight']
@@ -1077,14 +1084,14 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     w_dh, w_p = W['dur_hid_linear.weight'], W['pitch_out_linear.weight']
     # gradient reaching the notes-GRU states: only ever an addend of the BPTT epilogue -> activation dtype
     dNSUM = _empty(M, Hn, dev=dev, dtype=_act_dtype(prec, Hn))
-    gemm_dx(dHD0, w_dh, slice(0, Hn), out=dNSUM, prec=prec)                   # [M, Hn]
-    gemm_dx(dHD0, w_dh, slice(Hn, None), out=dP, acc=True, prec=prec)
-    gemm_dx(dP, w_p, out=dNSUM, acc=True, prec=prec)
+    gemm_dx(dHD0, w_dh, slice(0, Hn), out=dNSUM, prec=prec, m_top=top_h, m_unit=R)                   # [M, Hn]
+    gemm_dx(dHD0, w_dh, slice(Hn, None), out=dP, acc=True, prec=prec, m_top=top_h, m_unit=R)
+    gemm_dx(dP, w_p, out=dNSUM, acc=True, prec=prec, m_top=top_h, m_unit=R)
 
     def head_wgrads():
-        wgrad_b('dur_hid_linear.weight', 'dur_hid_linear.bias', dHD0, NSUM_op, slice(0, Hn))
-        wgrad('dur_hid_linear.weight', dHD0, st['pitch'], slice(Hn, None))
-        wgrad_b('pitch_out_linear.weight', 'pitch_out_linear.bias', dP, NSUM_op)
+        wgrad_b('dur_hid_linear.weight', 'dur_hid_linear.bias', dHD0, NSUM_op, slice(0, Hn), top_h)
+        wgrad_b('dur_hid_linear.weight', None, dHD0, st['pitch'], slice(Hn, None), top_h)
+        wgrad_b('pitch_out_linear.weight', 'pitch_out_linear.bias', dP, NSUM_op, None, top_h)
     side(head_wgrads, dHD0, dP)
 
     # ---- notes GRU (15 steps, batch 32*B) ----
