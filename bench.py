@@ -143,6 +143,22 @@ def extras(dev, B, rank):
                                         'note': 'the <=1e-4 parity path (exact fp32 MFMA)'}
     del m, opt
     torch.cuda.empty_cache()
+    # the headline with every zero-skip switched off: the backward computes the (exactly zero) gradients of the padded note slots and
+    # the note-summary GRU runs all 16 note positions of every row, as dense autograd would
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    F_.ZERO_SKIP = False
+    try:
+        m, opt, data = train_setup('bf16')
+        t = _measure(train_fn(m, opt, data, 1.0), 6, 3)
+        out['train_teacher_forced_dense_backward'] = {
+            'samples_per_s': round(B / t, 1), 'ms_per_step': round(t * 1e3, 2), 'batch': B, 'dtype': 'bf16',
+            'note': 'PTV_ZERO_SKIP=0: same results; the headline passes over note steps / tiles whose gradient is exactly zero (decided on '
+                    'the gradients themselves) and over packed-sequence padding'}
+        del m, opt
+    finally:
+        F_.ZERO_SKIP = True
+        F_.zero_skip_sync()
+    torch.cuda.empty_cache()
     torch.manual_seed(0)
     m = DisentangleVAE.init_model(dev).to(dev).set_precision('bf16')
     m.decoder.use_graph = True

@@ -163,6 +163,9 @@ int ptv_sum_steps(float* out, const void* in, long n, int T, long stride, int ac
 /* the same over the planes 0 .. *t_top only (device int; the later planes are known to be zero, see ptv_notes_gru_persist_bwd) */
 /* *top = max(*top, index of the last `unit`-row block of x [rows, cols] (fp32, row stride ld) that holds a non-zero): which trailing
  * note steps of a gradient received nothing (the loss ignores padded slots) -- the limit handed to ptv_gemm_mtop / ptv_wgrad */
+/* process-wide switch (default 1): the backward kernels pass over work whose result is exactly zero -- note steps / tiles at which no
+ * gradient arrives (tested on the arriving gradient), panel steps beyond the longest packed sequence.  0 = run everything dense. */
+int ptv_zero_skip(int enable);
 int ptv_last_nonzero_unit(const float* x, long rows, int cols, long ld, long unit, int* top, void* stream);
 int ptv_sum_steps_top(float* out, const void* in, long n, int T, long stride, int accumulate, int in_bf16, const int* t_top,
                       void* stream);

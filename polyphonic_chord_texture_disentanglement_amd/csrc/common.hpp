@@ -53,6 +53,10 @@ __device__ __forceinline__ float wave_max(float v) {
 // to global memory.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ptv_zero_skip (misc.hip): the backward kernels pass over work whose result is exactly zero (note steps / tiles at which no gradient
+// arrives, panel steps beyond the longest sequence); 0 makes them run dense (timing comparisons)
+extern int g_zero_skip;
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace ptv

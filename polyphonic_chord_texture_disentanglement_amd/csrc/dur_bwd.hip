@@ -37,6 +37,7 @@ struct DurBwdArgs {
   float* dh0;                                    // [M, 64]
   float* part;                                   // [gridDim.x][PART]
   long M;
+  int skip;                                      // pass over tiles that receive no gradient
 };
 
 struct DurOps { bf16x4 g[4][4]; float4 hp[4]; };   // [plane][fragment]
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256, 1) void dur_gru_bwd_kernel(DurBwdArgs a) {
       bool nzr = false;
 #pragma unroll
       for (int i = 0; i < 10; i++) nzr |= dd[i] != 0.f;
-      if (!__syncthreads_or(nzr)) {
+      if (a.skip && !__syncthreads_or(nzr)) {
         if (ok) {
 #pragma unroll
           for (int f = 0; f < 4; f++) *reinterpret_cast<float4*>(a.dh0 + row * BH + f * 16 + ug) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -237,7 +238,7 @@ extern "C" int ptv_dur_gru_bwd(int H, long M, const void* gates, long plane_g, l
   if (H != BH) return PTV_ERR_ARG;
   if (M <= 0 || !gates || !hall || !ddur || !w_hh || !w_out || !idx || !dh0 || !part || nblocks <= 0) return PTV_ERR_ARG;
   if ((plane_g & 3) || (step_g & 3) || (plane_h & 3) || (ld_dd & 1)) return PTV_ERR_ARG;
-  DurBwdArgs a{(const __bf16*)gates, plane_g, step_g, hall, plane_h, h_bf16, ddur, ld_dd, w_hh, w_out, idx, idx_stride, dh0, part, M};
+  DurBwdArgs a{(const __bf16*)gates, plane_g, step_g, hall, plane_h, h_bf16, ddur, ld_dd, w_hh, w_out, idx, idx_stride, dh0, part, M, g_zero_skip};
   if (h_bf16) hipLaunchKernelGGL(dur_gru_bwd_kernel<true>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(dur_gru_bwd_kernel<false>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, a);
   PTV_CHECK_LAUNCH();

@@ -4,6 +4,7 @@
 #include "../../include/ptvae_hip.h"
 
 namespace ptv {
+int g_zero_skip = 1;
 
 // est_dur = dur_out_linear(h) (ptvae.py:361-362), next token index = argmax (ptvae.py:365-367).
 // 16 lanes per row (float4 each covers H <= 64 ... loops for larger H), 4 rows per wave.
@@ -308,3 +309,5 @@ extern "C" int ptv_transpose_cast_bf16(const float* src, void* dst, int rows, in
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
+
+extern "C" int ptv_zero_skip(int enable) { ptv::g_zero_skip = enable ? 1 : 0; return PTV_OK; }

@@ -90,6 +90,7 @@ struct RowGruFwdArgs {
   __bf16* gates;                   // [T][4][R][H] or null
   float* out; long out_ld;         // final state -> out[row*out_ld + unit], or null
   int R, T, reverse, dbg;
+  int skip;                        // pass over the steps beyond the longest row of the panel (EMB with lengths)
 };
 
 // EMB = false: the notes GRU (hoisted input part gc, b_ih folded in, no mask, no final-state output); EMB = true: a direction of
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
   // the sequences, ptvae.py:446-453: on this data the mean length is 3.7 of 16 notes) -- such steps only pass the state on
   int pmax = a.T;
   if constexpr (EMB) {
-    if (a.lengths) {
+    if (a.lengths && a.skip) {
       int* misc = reinterpret_cast<int*>(tok16 + NRP * NT16LD);
       if (tid == 0) misc[0] = 0;
       __syncthreads();
@@ -331,6 +332,7 @@ struct RowGruBwdArgs {
   float* dh0;                      // [R][H] or null
   __bf16* scratch;                 // [grid][2][3H/8 chunks][64 rows][8]: dgh of the workgroup's rows, K-blocked (A operand of the next step)
   int R, T, reverse;
+  int skip;                        // pass over steps whose result is exactly zero
 };
 
 // EMB = false: the notes GRU (gradient arrives at every state: ext; forward time order; dh0 wanted); EMB = true: a direction of
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowG
   for (int i = 0; i < 4; i++) { ok[i] = r0 + i * 16 + erow < R; grow[i] = min(r0 + i * 16 + erow, R - 1); }
   int pmax = a.T;
   if constexpr (EMB) {
-    if (a.lengths) {
+    if (a.lengths) {                                                     // given iff the forward skipped: must match it
       int* misc = reinterpret_cast<int*>(dhz + NRP * H);
       if (tid == 0) misc[0] = 0;
       __syncthreads();
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowG
     // gate gradients: the loss ignores the padded note slots (CrossEntropyLoss(ignore_index), ptvae.py:498-511), which are the LATE
     // steps of every row -- on this data 8 of the 15.  Tested on the arriving gradient itself (one 64-KB read per step), so it holds
     // for whatever loss produced it.  The BPTT proper starts at the last step that has something.
-    for (; s_top >= 0; s_top--) {
+    for (; a.skip && s_top >= 0; s_top--) {
       unsigned nz = 0;
       for (int i = tid; i < NRP * (H / 8); i += 256) {
         const int row = i / (H / 8), c8 = (i % (H / 8)) * 8;
@@ -550,7 +552,7 @@ extern "C" int ptv_row_gru_persist_fwd(int H, const void* w_hh, const void* w_x,
   if (!w_hh || !w_x || !b_hh || !x || !HN || !HN16 || R <= 0 || T <= 0 || (H != 512 && H != 128)) return PTV_ERR_ARG;
   if (out && (out_ld & 3)) return PTV_ERR_ARG;
   RowGruFwdArgs a{(const bf16x8*)w_hh, (const bf16x8*)w_x, b_hh, b_ih, (const __bf16*)gc, x, x_step, lengths, HN, (__bf16*)HN16,
-                  (__bf16*)gates, out, out_ld, (int)R, T & 0xff, reverse, T >> 8};
+                  (__bf16*)gates, out, out_ld, (int)R, T & 0xff, reverse, T >> 8, g_zero_skip};
   const int pi = prof::want(3, (int)R, H) ? prof::begin((hipStream_t)stream) : -1;
   // H = 512 is the notes GRU (gc given, bias folded, dense); H = 128 the note-summary GRU (b_ih given, mask / reverse / final state)
   if (H == 512 && (!gc || b_ih || lengths || reverse || out)) return PTV_ERR_UNSUPPORTED;
@@ -570,7 +572,7 @@ extern "C" int ptv_row_gru_persist_bwd(int H, const void* wt, const float* HN, c
   if (dh_last && (last_ld & 3)) return PTV_ERR_ARG;
   if (H == 512 && lengths) return PTV_ERR_UNSUPPORTED;
   RowGruBwdArgs a{(const bf16x8*)wt, HN, (const __bf16*)gates, (const __bf16*)ext, dh_last, last_ld, lengths, top_step, (__bf16*)dgi, (__bf16*)dgh, dh0,
-                  (__bf16*)scratch, (int)R, T, reverse};
+                  (__bf16*)scratch, (int)R, T, reverse, g_zero_skip};
   const int pi = prof::want(4, (int)R, H) ? prof::begin((hipStream_t)stream) : -1;
   if (H == 512 && (!ext || dh_last || reverse)) return PTV_ERR_UNSUPPORTED;
   if (H == 128 && ext) return PTV_ERR_UNSUPPORTED;

@@ -403,6 +403,18 @@ def _bgrad_hh(b_hh, dgh2, gb_ih):
 
 
 WGRAD_FUSE_BIAS = os.environ.get('PTV_WGRAD_BIAS', '1') != '0'
+# the backward passes over work whose result is exactly zero: note steps / tiles at which no gradient arrives (the loss ignores the
+# padded note slots), panel steps beyond the longest packed note sequence.  Decided on the gradients / lengths themselves, so the
+# results do not change; PTV_ZERO_SKIP=0 runs everything dense (bench.py reports that figure next to the headline)
+ZERO_SKIP = os.environ.get('PTV_ZERO_SKIP', '1') != '0'
+_ZERO_SKIP_SET = []
+
+
+def zero_skip_sync():
+    """hand the current ZERO_SKIP to the library (cheap; called by the decoder backward and the bi-GRU forward)"""
+    if not _ZERO_SKIP_SET or _ZERO_SKIP_SET[0] != ZERO_SKIP:
+        lib().ptv_zero_skip(int(ZERO_SKIP))
+        _ZERO_SKIP_SET[:] = [ZERO_SKIP]
 
 
 def wgrad_bias(dy, x, gw, gb, prec, k_top=None, k_unit=0):
@@ -575,6 +587,7 @@ def _bigru_forward(prec, x3, lengths, w):
             copy2d(out[:, d * H:(d + 1) * H], saved[d][0][T])
         return out, saved
 
+    zero_skip_sync()
     if row_gru_ok(prec, H, I, M, adt) and x3.dtype == F32:
         # many short independent rows (dec_notes_emb_gru: 32*B rows x 16 notes): row-partitioned persistent kernels, one launch per
         # direction for the whole sequence (csrc/notes_persist.hip), input product fused; the directions overlap on sibling streams
@@ -588,7 +601,7 @@ def _bigru_forward(prec, x3, lengths, w):
             call('ptv_row_gru_persist_fwd', H, ptr(pk['wg_h']), ptr(pk['wg_t']), ptr(b_hh), ptr(b_ih), None, ptr(x3), M * I,
                  ptr(lengths) if lengths is not None else None, ptr(hall), ptr(h16), ptr(gates), out.data_ptr() + 4 * d * H, 2 * H,
                  M, T, d, stream_ptr())
-            return hall, gates, h16, lengths                      # the backward must skip the same fully masked panel steps
+            return hall, gates, h16, (lengths if ZERO_SKIP else None)      # the backward must skip the same fully masked panel steps
         side = Side(7)
         rev = side(lambda: rows(1), x3, out)
         fwd = rows(0)
@@ -1049,9 +1062,12 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
 
     # the loss ignores the padded note slots (the late note steps of every row): find the last note step that received any gradient
     # (on the gradients themselves) -- the head products below stop there, as the BPTT does on its own
-    top_h = torch.full((1,), -1, device=dev, dtype=torch.int32)
-    call('ptv_last_nonzero_unit', ptr(dP), M, NP, dP.stride(0), R, ptr(top_h), stream_ptr())
-    call('ptv_last_nonzero_unit', ptr(ddur), M, 10, 10, R, ptr(top_h), stream_ptr())
+    zero_skip_sync()
+    top_h = None
+    if ZERO_SKIP:
+        top_h = torch.full((1,), -1, device=dev, dtype=torch.int32)
+        call('ptv_last_nonzero_unit', ptr(dP), M, NP, dP.stride(0), R, ptr(top_h), stream_ptr())
+        call('ptv_last_nonzero_unit', ptr(ddur), M, 10, 10, R, ptr(top_h), stream_ptr())
 
     # ---- duration GRU (5 steps) ----
     w_out = P['dur_out_linear.weight']
@@ -1102,7 +1118,7 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
         dgh_n = _empty(15, R, Hn, dev=dev, dtype=BF16)          # n third only: the r / z thirds of dgh are dgi's
         dHN0 = _empty(R, Hn, dev=dev)
         scratch = _empty(lib().ptv_notes_gru_persist_scratch_elems(R), dev=dev, dtype=BF16)
-        top_step = torch.full((1,), -1, device=dev, dtype=torch.int32)     # <- last note step at which any gradient arrived
+        top_step = torch.full((1,), -1, device=dev, dtype=torch.int32) if ZERO_SKIP else None   # <- last note step with a gradient
         call('ptv_notes_gru_persist_bwd', ptr(pk['wt']), ptr(HN), ptr(st['gates_n']), ptr(dNSUM), ptr(dgi_n), ptr(dgh_n), ptr(dHN0),
              ptr(scratch), R, 15, ptr(top_step), stream_ptr())
     else:

@@ -281,6 +281,7 @@ class DecoderStepFn(torch.autograd.Function):
 
         XH16 = [None, None]
         if replay:
+            F_.zero_skip_sync()
             # ---- recompute what the backward reads, batched over all rows (the step loop above stored decisions and tokens only)
             GC16 = gemm(NS16[1:].view(R, Ht), w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec, out_dtype=torch.bfloat16)
             pkn = F_.notes_packs(w_ih_n, w_hh_n, Ht)
@@ -305,7 +306,7 @@ class DecoderStepFn(torch.autograd.Function):
             ctx.save_for_backward(z, emb, *params)
             ctx.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in, TOKS=TOKS,
                           gates_t=gates_t, HN=HN, gates_n=gates_n, pitch=pitch, HD=HD, gates_d=gates_d, idx=idx, TOK=TOK,
-                          PRED=PRED, xhat=xhat, XH=XH, XG=XG, XH16=XH16, plen=plen, coins=coins, has_xs=xs is not None,
+                          PRED=PRED, xhat=xhat, XH=XH, XG=XG, XH16=XH16, plen=plen, skipped=F_.ZERO_SKIP, coins=coins, has_xs=xs is not None,
                           NS16=NS16, HN16=HN16, HD16=HD16, dur16_only=HD16 is not None)
         ctx.mark_non_differentiable(xhat, idx)
         return pitch.view(15, 32, B, NP), dur, xhat, idx
@@ -357,7 +358,7 @@ class DecoderStepFn(torch.autograd.Function):
         call('ptv_route_slices', ptr(dTOKS[1:]), ptr(dxs), ptr(dxsp), ptr(mask_time), B * 2 * He, 32, 0, sp)
         if st['XH'] is not None:
             wE = [P['dec_notes_emb_gru.' + n] for n in EMB_GRU]
-            saved = [(st['XH'][d_], st['XG'][d_], st['XH16'][d_]) + ((st['plen'],) if st['XH16'][d_] is not None else ()) for d_ in range(2)]
+            saved = [(st['XH'][d_], st['XG'][d_], st['XH16'][d_]) + ((st['plen'] if st['skipped'] else None,) if st['XH16'][d_] is not None else ()) for d_ in range(2)]
             ge, dx_pred = _bigru_backward(prec, PRED, wE, saved, dxsp.view(R, 2 * He), True)
             for n, gg in zip(EMB_GRU, ge):
                 G['dec_notes_emb_gru.' + n] = gg
