@@ -193,7 +193,11 @@ def _roofline(lib, B, model, args):
     if B == 512 and args.precision == 'bf16' and os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
     out = []
-    for tag, name, nbytes in ((4, 'row_gru_bwd_kernel<512>', bwd_bytes), (3, 'row_gru_fwd_kernel<512>', fwd_bytes)):
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    kernels = [(3, 'row_gru_fwd_kernel<512>', fwd_bytes)]
+    if not F_.ZERO_SKIP:                                    # with the zero-skip on, the BPTT launch moves a data-dependent share of
+        kernels.insert(0, (4, 'row_gru_bwd_kernel<512>', bwd_bytes))   # these bytes (late note steps without gradient are passed over)
+    for tag, name, nbytes in kernels:
         cnt, ms, fl = ctypes.c_long(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
         lib.ptv_prof_read_tag(tag, ctypes.byref(cnt), ctypes.byref(ms), ctypes.byref(fl))
         if cnt.value == 0:
