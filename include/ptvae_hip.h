@@ -424,10 +424,12 @@ int ptv_clip_adam_step(float* p, const float* g, float* m, float* v, long n, con
  * grad_out), taken from the A tiles while they are in LDS instead of a second pass over A (always accumulates).
  * k_top (or NULL): device int; the rows of A from (*k_top + 1) * k_unit on are zero (the kernel that wrote A says so: the notes BPTT
  * reports the last note step at which any gradient arrived) -- the product stops there.  k_unit must be a multiple of 32.
+ * k_rev > 0: A holds its k_rev units in reversed order (the *_reverse direction of a GRU, gradients indexed by processing step):
+ * the zero part is then the rows BEFORE (k_rev - *k_top - 1) * k_unit and the product starts there.
  * ptv_gemm(prec = bf16, transA = transB = 1) routes here.
  */
 int ptv_wgrad(int M, int N, int K, const void* A, long lda, const void* B, long ldb, float* C, long ldc, float alpha,
-              int accumulate, int dtypes, int slabs, float* colsum_a, const int* k_top, long k_unit, void* stream);
+              int accumulate, int dtypes, int slabs, float* colsum_a, const int* k_top, long k_unit, int k_rev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optional launch timing (bench.py roofline): HIP events recorded on the launch stream around every launch of the enabled

@@ -327,7 +327,8 @@ struct RowGruBwdArgs {
   const __bf16* ext;               // [T][R][H] bf16 gradient arriving at the state after step s, or null
   const float* dh_last; long last_ld;   // gradient arriving at the final state only (rows of stride last_ld), or null
   const int* lengths;              // EMB: the lengths the forward ran with (it skipped the panel's fully masked steps), or null
-  int* top_step;                   // !EMB: atomicMax'ed with the last step at which a gradient arrived for any panel (or null)
+  int* top_step;                   // atomicMax'ed with the last step at which a gradient arrived for any panel (!EMB) / the last time
+                                   // index any row reaches (EMB with lengths), or null
   __bf16* dgi; __bf16* dgh;        // dgi [T][R][3H] by TIME index; dgh by processing step: [T][R][3H] (EMB) or its n third only [T][R][H]
   float* dh0;                      // [R][H] or null
   __bf16* scratch;                 // [grid][2][3H/8 chunks][64 rows][8]: dgh of the workgroup's rows, K-blocked (A operand of the next step)
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowG
       if (tid < NRP && r0 + tid < R) atomicMax(misc, a.lengths[r0 + tid]);
       __syncthreads();
       pmax = min(misc[0], a.T);
+      if (a.top_step && tid == 0 && pmax > 0) atomicMax(a.top_step, pmax - 1);   // last TIME index with a live row in any panel
     }
   }
   __syncthreads();

@@ -42,6 +42,7 @@ struct WgArgs {
   float alpha;
   float* csum;                   // [M] += column sums of A (the bias gradient that goes with this weight gradient), or null
   const int* k_top; long k_unit;  // rows from (*k_top + 1) * k_unit on are known to be zero in A (written by the kernel that produced A), or null
+  int k_rev;                     // > 0: A is stored in REVERSED unit order (k_rev units): the zero part is the rows BEFORE (k_rev - *k_top - 1) * k_unit
 };
 
 // one thread's share of a stage of one operand: 2 chunks of 8 columns (chunk c: row c / 16, columns (c % 16) * 8).
@@ -153,14 +154,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
   if (g.map == 1) { const int q = b >> 3; slab = (q / tiles) * 8 + (b & 7); tile = q % tiles; }
   else if (g.map == 2) { const int tx = tiles >> 3, q = b >> 3; tile = (b & 7) * tx + q % tx; slab = q / tx; }
   else { slab = b / tiles; tile = b % tiles; }
-  const int k_begin = slab * g.kper;
+  int k_begin = slab * g.kper;
   int k_lim = g.K;
-  if (g.k_top) {                                                  // (a multiple of the 32-row stage whenever k_unit is)
-    const long lim = ((long)*g.k_top + 1) * g.k_unit;
-    if (lim < k_lim) k_lim = (int)lim;
+  int k_from = 0;
+  if (g.k_top) {                                                  // (multiples of the 32-row stage whenever k_unit is)
+    if (g.k_rev > 0) {
+      const long lo = ((long)g.k_rev - *g.k_top - 1) * g.k_unit;
+      if (lo > 0) k_from = (int)min((long)g.K, lo);
+    } else {
+      const long lim = ((long)*g.k_top + 1) * g.k_unit;
+      if (lim < k_lim) k_lim = (int)lim;
+    }
   }
-  if (k_begin >= k_lim) return;
+  if (k_begin >= k_lim || k_begin + g.kper <= k_from) return;
   const int k_end = min(k_lim, k_begin + g.kper);
+  if (k_from > k_begin) k_begin = k_from;                         // (k_from is a multiple of 32 like every slab start)
   const int m_blk = (tile / g.tiles_n) * WBM, n_blk = (tile % g.tiles_n) * WBN;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -285,7 +293,7 @@ __global__ void wgrad_zero_kernel(float* C, long ldc, int M, int N) {
 using namespace ptv;
 
 extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const void* B, long ldb, float* C, long ldc, float alpha,
-                         int accumulate, int dtypes, int slabs, float* colsum_a, const int* k_top, long k_unit, void* stream) {
+                         int accumulate, int dtypes, int slabs, float* colsum_a, const int* k_top, long k_unit, int k_rev, void* stream) {
   if (M < 0 || N < 0 || K < 0 || !A || !B || !C) return PTV_ERR_ARG;
   if (k_top && (k_unit <= 0 || k_unit % WBK)) return PTV_ERR_ARG;
   if (M == 0 || N == 0) return PTV_OK;
@@ -307,7 +315,7 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
   const int nset = (af || bf) ? 2 : (nset_env == 4 ? 4 : 2);       // 4 register sets only fit with bf16 sources
   auto launch = [&](bool guard, int k0, int kn, int want_slabs) {
     WgArgs g{static_cast<const char*>(A) + (long)k0 * lda * (af ? 4 : 2), lda, static_cast<const char*>(B) + (long)k0 * ldb * (bf ? 4 : 2), ldb,
-             C, ldc, M, N, kn, 0, cdiv(M, WBM), cdiv(N, WBN), 1, 0, alpha, colsum_a, k0 == 0 ? k_top : nullptr, k_unit};
+             C, ldc, M, N, kn, 0, cdiv(M, WBM), cdiv(N, WBN), 1, 0, alpha, colsum_a, k0 == 0 ? k_top : nullptr, k_unit, k_rev};
     const int tiles = g.tiles_m * g.tiles_n;
     // slab count (measured optima of scripts/bench_wgrad.py sweep on MI355X).  Every slab pays M*N atomics, and a grid that is
     // just over one block per CU leaves a tail, so: about one block per CU (never more) for the skinny, HBM-bound products;

@@ -364,6 +364,16 @@ class Side:
 _DEFERRED = []
 
 
+TRACE = None          # set to a list by scripts/trace_marks.py: (name, event on the current stream) markers of the backward chain
+
+
+def mark(name):
+    if TRACE is not None:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        TRACE.append((name, e))
+
+
 def _join_deferred():
     cur = torch.cuda.current_stream()
     for s, _keep in _DEFERRED:
@@ -417,7 +427,7 @@ def zero_skip_sync():
         _ZERO_SKIP_SET[:] = [ZERO_SKIP]
 
 
-def wgrad_bias(dy, x, gw, gb, prec, k_top=None, k_unit=0):
+def wgrad_bias(dy, x, gw, gb, prec, k_top=None, k_unit=0, k_rev=0):
     """gw [N_out, N_in] += dy^T . x and gb [N_out] (or None) += column sums of dy: a layer's weight and bias gradient in one pass
     over dy (ptv_wgrad's colsum_a) where the weight-gradient kernel applies; otherwise the product and a column-sum kernel.
     k_top (device int) / k_unit: the rows of dy from (k_top + 1) * k_unit on are zero (ptv_wgrad)"""
@@ -425,7 +435,7 @@ def wgrad_bias(dy, x, gw, gb, prec, k_top=None, k_unit=0):
     if (WGRAD_FUSE_BIAS and prec == 1 and K >= 512 and gw.dtype == F32 and dy.stride(1) == 1 and x.stride(1) == 1
             and os.environ.get('PTV_WGRAD', '1') != '0'):
         call('ptv_wgrad', dy.shape[1], x.shape[1], K, ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(gw), _ld(gw), 1.0, 1,
-             _bf(dy) | (_bf(x) << 1), 0, ptr(gb), ptr(k_top), int(k_unit), stream_ptr())
+             _bf(dy) | (_bf(x) << 1), 0, ptr(gb), ptr(k_top), int(k_unit) if k_top is not None else 0, int(k_rev), stream_ptr())
     else:
         gemm(dy, x, gw, ta=True, tb=True, acc=True, prec=prec)
         if gb is not None:
@@ -631,13 +641,16 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
         dx = gemm_dx(dgi2, w_ih, prec=prec) if need_dx else None
         return [dw_ih, dw_hh, db_ih, db_hh], dx
 
-    def products(d, dgi, dgh):
+    def products(d, dgi, dgh, top=None):
+        """top (device int, from the BPTT kernel): no row is longer than top + 1, so dgi (indexed by time) is zero after that time
+        and dgh (indexed by processing step) after that step -- or, in the reversed direction, BEFORE step T - top - 1"""
         w_ih, w_hh, b_ih, b_hh = w[4 * d: 4 * d + 4]
         hall, gates, h16 = saved[d][:3]
         dgi2, dgh2 = dgi.view(T * M, 3 * H), dgh.view(T * M, 3 * H)
-        dw_ih, db_ih = wgrad_bias(dgi2, xf, _gbuf(w_ih), _gbuf(b_ih), prec)
-        dw_hh, db_hh = wgrad_bias(dgh2, (h16 if h16 is not None else hall)[:T].view(T * M, H), _gbuf(w_hh), _gbuf(b_hh), prec)
-        dx = gemm_dx(dgi2, w_ih, prec=prec) if need_dx else None
+        dw_ih, db_ih = wgrad_bias(dgi2, xf, _gbuf(w_ih), _gbuf(b_ih), prec, top, M)
+        dw_hh, db_hh = wgrad_bias(dgh2, (h16 if h16 is not None else hall)[:T].view(T * M, H), _gbuf(w_hh), _gbuf(b_hh), prec, top, M,
+                                  k_rev=T if d else 0)
+        dx = gemm_dx(dgi2, w_ih, prec=prec, m_top=top, m_unit=M) if need_dx else None
         return [dw_ih, dw_hh, db_ih, db_hh], dx
 
     side = Side(7)
@@ -665,9 +678,10 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
             dgi = _empty(T, M, 3 * H, dev=x3.device, dtype=BF16)
             dgh = _empty(T, M, 3 * H, dev=x3.device, dtype=BF16)
             scratch = _empty(lib().ptv_row_gru_persist_scratch_elems(H, M), dev=x3.device, dtype=BF16)
+            top = torch.full((1,), -1, device=x3.device, dtype=torch.int32) if (lengths is not None and M % 32 == 0) else None
             call('ptv_row_gru_persist_bwd', H, ptr(pk['wt']), ptr(hall), ptr(gates), None, dout.data_ptr() + 4 * d * H, dout.stride(0),
-                 ptr(lengths) if lengths is not None else None, ptr(dgi), ptr(dgh), None, ptr(scratch), M, T, d, None, stream_ptr())
-            return products(d, dgi, dgh)
+                 ptr(lengths) if lengths is not None else None, ptr(dgi), ptr(dgh), None, ptr(scratch), M, T, d, ptr(top), stream_ptr())
+            return products(d, dgi, dgh, top)
         g1, dx1 = side(lambda: rows(1), xf, dout)
         g0, dx0 = rows(0)
     else:
@@ -908,6 +922,7 @@ class DecoderTFFn(torch.autograd.Function):
         gemm(z, W['z2dec_hid_linear.weight'], NS[0], bias=P['z2dec_hid_linear.bias'], prec=prec)
         z_in = gemm(z, W['z2dec_in_linear.weight'], bias=P['z2dec_in_linear.bias'], prec=prec)
 
+        mark('dec_fwd:start')
         emb3 = emb.view(16, R, E)
         xs = xs.contiguous()
 
@@ -923,6 +938,7 @@ class DecoderTFFn(torch.autograd.Function):
         NS16 = _hall16(prec, 33, B, Ht, dev)
         gru_fwd(prec, gi_t, B * 3 * Ht, 3 * Ht, W['dec_time_gru.weight_hh_l0'], P['dec_time_gru.bias_hh_l0'], NS,
                 gates_t, gi2=zg, gi2_step=0, gi2_ld=3 * Ht, hall16=NS16)
+        mark('dec_fwd:time_gru')
         NSf = NS[1:].view(R, Ht)                                               # notes_summary rows (t, b)
         NSf_op = NS16[1:].view(R, Ht) if NS16 is not None else NSf              # same values as an MFMA operand
 
@@ -943,6 +959,7 @@ class DecoderTFFn(torch.autograd.Function):
             GT = gemm(emb3[:15].view(15 * R, E), w_ih_n[:, Ht:], prec=prec, out_dtype=adt)                    # [15R, 3Hn]
             gru_fwd(prec, GT, R * 3 * Hn, 3 * Hn, W['dec_notes_gru.weight_hh_l0'], P['dec_notes_gru.bias_hh_l0'], HN,
                     gates_n, gi2=GC, gi2_step=0, gi2_ld=3 * Hn, hall16=HN16)
+        mark('dec_fwd:notes_gru')
         NSUM = HN[1:].view(15 * R, Hn)
         NSUM_op = HN16[1:].view(15 * R, Hn) if HN16 is not None else NSUM
 
@@ -958,6 +975,7 @@ class DecoderTFFn(torch.autograd.Function):
         gemm(NSUM_op, w_dh[:, :Hn], HD[0], bias=P['dur_hid_linear.bias'], prec=prec)
         gemm(pitch, w_dh[:, Hn:], HD[0], acc=True, prec=prec)
 
+        mark('dec_fwd:heads')
         # --- 5-step duration GRU with argmax feedback (ptvae.py:353-367)
         w_ih_d, b_ih_d = W['dec_dur_gru.weight_ih_l0'], P['dec_dur_gru.bias_ih_l0']
         tab0 = gemm(P['dur_sos_token'].view(1, -1), w_ih_d, bias=b_ih_d, prec=0)       # [1, 3Hd]  (tiny: exact)
@@ -1062,6 +1080,7 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
 
     # the loss ignores the padded note slots (the late note steps of every row): find the last note step that received any gradient
     # (on the gradients themselves) -- the head products below stop there, as the BPTT does on its own
+    mark('dec_bwd:start')
     zero_skip_sync()
     top_h = None
     if ZERO_SKIP:
@@ -1096,6 +1115,7 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
             G['dec_dur_gru.weight_ih_l0'] = g
         side(dur_wgrads, ddur, dgi_d, dgh_d)
 
+    mark('dec_bwd:dur_bptt')
     # ---- dur_hid_linear([note_summary | est_pitch]) and pitch_out_linear ----
     w_dh, w_p = W['dur_hid_linear.weight'], W['pitch_out_linear.weight']
     # gradient reaching the notes-GRU states: only ever an addend of the BPTT epilogue -> activation dtype
@@ -1110,6 +1130,7 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
         wgrad_b('pitch_out_linear.weight', 'pitch_out_linear.bias', dP, NSUM_op, None, top_h)
     side(head_wgrads, dHD0, dP)
 
+    mark('dec_bwd:head_dx')
     # ---- notes GRU (15 steps, batch 32*B) ----
     w_hh_n, w_ih_n = W['dec_notes_gru.weight_hh_l0'], W['dec_notes_gru.weight_ih_l0']
     if (notes_persist_ok(prec, Hn, E, st['gates_n'].dtype) and dNSUM.dtype == BF16 and HN.dtype == F32):
@@ -1124,6 +1145,7 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     else:
         top_step = None
         dgi_n, dgh_n, dHN0 = gru_bwd(prec, HN, st['gates_n'], w_hh_n, dh_ext=dNSUM.view(15, R, Hn))
+    mark('dec_bwd:notes_bptt')
     dGC = sum_steps(dgi_n, t_top=top_step)                                    # [R, 3Hn]
     dtok = _empty(16, R, E, dev=dev)
     dtok[15].zero_()
@@ -1156,9 +1178,11 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
         bgrad('dec_time_to_notes_hid.bias', dHN0)
     side(notes_wgrads, dgi_n, dgh_n, dGC, dHN0, dNSUM)
 
+    mark('dec_bwd:notes_dx')
     # ---- time GRU (32 steps, batch B) ----
     w_hh_t, w_ih_t = W['dec_time_gru.weight_hh_l0'], W['dec_time_gru.weight_ih_l0']
     dgi_t, dgh_t, dzhid = gru_bwd(prec, NS, st['gates_t'], w_hh_t, dh_ext=dNS.view(32, B, Ht))
+    mark('dec_bwd:time_bptt')
     dZG = sum_steps(dgi_t)                                                    # [B, 3Ht]
     dz_in = gemm_dx(dZG, w_ih_t, slice(2 * He, None), prec=prec)              # [B, Zi]
     dTOKS = _empty(33, B, 2 * He, dev=dev)

@@ -58,7 +58,9 @@ class DisentangleVAE(PytorchModel):
 
     # ---- model.py:42-55
     def run(self, x, c, pr_mat, tfr1, tfr2, tfr3, confuse=True):
+        F_.mark('run:start')
         refresh_weight_shadows()                         # bf16 operand copies of the flat parameter buffer (if any)
+        F_.mark('run:shadows')
         self.decoder.summaries_needed = tfr1 > 0             # with tfr1 = 0 no time step is fed a ground-truth note summary
         try:
             embedded_x, lengths = self.decoder.emb_x(x)
@@ -66,11 +68,13 @@ class DisentangleVAE(PytorchModel):
             self.decoder.summaries_needed = True
         # the two encoders are independent of each other and of the embedding: sibling HIP streams
         # (autograd replays each branch's backward on the stream its forward ran on)
+        F_.mark('run:emb_x')
         s_chd, s_rhy = F_.Side(1), F_.Side(2)
         dist_chd = s_chd(lambda: self.chd_encoder(c), c)
         dist_rhy = s_rhy(lambda: self.rhy_encoder(pr_mat), pr_mat)
         s_chd.join()
         s_rhy.join()
+        F_.mark('run:encoders')
         z_chd = self._rsample('chd', dist_chd)           # chd first, then rhy (train_utils.py:33-34)
         z_rhy = self._rsample('rhy', dist_rhy)
         dec_z = torch.cat([z_chd, z_rhy], dim=-1)

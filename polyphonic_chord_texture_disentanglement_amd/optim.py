@@ -237,6 +237,8 @@ class FusedClipAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         self.step_count += 1
         self._opt_called = True            # what torch's LRScheduler checks to order step() calls
+        from . import functional as F_
+        F_.mark('opt:start')
         st = stream_ptr()
         call('ptv_grad_sumsq', ptr(a.flat), a.total, ptr(self.sumsq), st)
         call('ptv_clip_adam_step', ptr(self.flat_p), ptr(a.flat), ptr(self.exp_avg), ptr(self.exp_avg_sq), a.total,

@@ -66,7 +66,7 @@ for M, N, K, dt in SHAPES:
             if sl * 128 > K:
                 break
             res.append((sl, timeit(lambda: call('ptv_wgrad', M, N, K, ptr(Ad), Ad.stride(0), ptr(Bd), Bd.stride(0), ptr(C), C.stride(0), 1.0, 1,
-                                                  dt, sl, None, None, 0, stream_ptr()), 5)))
+                                                  dt, sl, None, None, 0, 0, stream_ptr()), 5)))
         print('   slabs: ' + ' '.join('%d:%.0f' % r for r in res))
     byt = K * (M * (2 if dt & 1 else 4) + N * (2 if dt & 2 else 4))
     print('TN M=%5d N=%5d K=%7d dt=%d  %8.1f us %7.1f TF/s %6.2f TB/s  rel err %.2e' % (M, N, K, dt, us, 2.0 * M * N * K / us / 1e6, byt / us / 1e6, err),

@@ -1,0 +1,54 @@
+"""Where the backward of the teacher-forced B=512 step spends its time on the MAIN stream, unprofiled: functional.mark() events.
+python scripts/trace_marks.py"""
+import os
+import random
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from polyphonic_chord_texture_disentanglement_amd import functional as F_  # noqa: E402
+from polyphonic_chord_texture_disentanglement_amd.model import DisentangleVAE  # noqa: E402
+from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam  # noqa: E402
+from polyphonic_chord_texture_disentanglement_amd.synthetic import synth_batch  # noqa: E402
+
+B = 512
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+random.seed(7)
+m = DisentangleVAE.init_model(dev).to(dev).set_precision('bf16')
+m.use_philox(7, 0)
+opt = FusedClipAdam(m.parameters(), lr=1e-3)
+data = tuple(torch.from_numpy(a).to(dev) for a in synth_batch(B, 99))
+
+
+def step():
+    opt.zero_grad()
+    F_.mark('step:start')
+    o = m('train', *data, tfr1=1.0, tfr2=1.0, tfr3=1.0, beta=0.1, weights=[1, 0.5])
+    F_.mark('fwd:end')
+    o[0].backward()
+    F_.mark('bwd:end')
+    opt.clip_and_step(1.0)
+    F_.mark('opt:end')
+
+
+for _ in range(5):
+    step()
+torch.cuda.synchronize()
+acc = {}
+N = 10
+for _ in range(N):
+    F_.TRACE = []
+    step()
+    torch.cuda.synchronize()
+    tr = F_.TRACE
+    F_.TRACE = None
+    t0 = tr[0][1]
+    for name, e in tr:
+        acc.setdefault(name, []).append(t0.elapsed_time(e))
+prev = 0.0
+for name, v in acc.items():
+    t = sum(v) / len(v)
+    print('%-22s at %7.3f ms   (+%.3f)' % (name, t, t - prev))
+    prev = t

@@ -533,7 +533,7 @@ def test_wgrad_kernel_vs_fp64_product_and_column_sums(M, N, K, dt, pad):
     for slabs in (0, 1, 3, 8):
         C = C0.to(dev).clone()
         bias = b0.to(dev).clone()
-        call('ptv_wgrad', M, N, K, ptr(Ad), Ad.stride(0), ptr(Bd), Bd.stride(0), ptr(C), C.stride(0), 0.5, 1, dt, slabs, ptr(bias), None, 0, stream_ptr())
+        call('ptv_wgrad', M, N, K, ptr(Ad), Ad.stride(0), ptr(Bd), Bd.stride(0), ptr(C), C.stride(0), 0.5, 1, dt, slabs, ptr(bias), None, 0, 0, stream_ptr())
         torch.cuda.synchronize()
         sc = max(1.0, want.abs().max().item())
         assert (C.cpu().double() - want).abs().max() < 2e-5 * sc, slabs
@@ -545,14 +545,23 @@ def test_wgrad_kernel_vs_fp64_product_and_column_sums(M, N, K, dt, pad):
         ktop = torch.tensor([top], device=dev, dtype=torch.int32)
         Ca, Cb = C0.to(dev).clone(), C0.to(dev).clone()
         ba, bb = b0.to(dev).clone(), b0.to(dev).clone()
-        call('ptv_wgrad', M, N, K, ptr(Az), Az.stride(0), ptr(Bd), Bd.stride(0), ptr(Ca), Ca.stride(0), 0.5, 1, dt, 0, ptr(ba), None, 0, stream_ptr())
-        call('ptv_wgrad', M, N, K, ptr(Az), Az.stride(0), ptr(Bd), Bd.stride(0), ptr(Cb), Cb.stride(0), 0.5, 1, dt, 0, ptr(bb), ptr(ktop), unit,
+        call('ptv_wgrad', M, N, K, ptr(Az), Az.stride(0), ptr(Bd), Bd.stride(0), ptr(Ca), Ca.stride(0), 0.5, 1, dt, 0, ptr(ba), None, 0, 0, stream_ptr())
+        call('ptv_wgrad', M, N, K, ptr(Az), Az.stride(0), ptr(Bd), Bd.stride(0), ptr(Cb), Cb.stride(0), 0.5, 1, dt, 0, ptr(bb), ptr(ktop), unit, 0,
              stream_ptr())
         torch.cuda.synchronize()
         assert (Ca - Cb).abs().max() < 2e-5 * max(1.0, Ca.abs().max().item()) and (ba - bb).abs().max() < 2e-5 * max(1.0, ba.abs().max().item())
+        # the reversed order (gradients of a *_reverse GRU direction, indexed by processing step): a zero PREFIX
+        U = K // unit
+        Ar = Ad.clone(); Ar[:(U - top - 1) * unit] = 0
+        Ca, Cb = C0.to(dev).clone(), C0.to(dev).clone()
+        call('ptv_wgrad', M, N, K, ptr(Ar), Ar.stride(0), ptr(Bd), Bd.stride(0), ptr(Ca), Ca.stride(0), 0.5, 1, dt, 0, None, None, 0, 0, stream_ptr())
+        call('ptv_wgrad', M, N, K, ptr(Ar), Ar.stride(0), ptr(Bd), Bd.stride(0), ptr(Cb), Cb.stride(0), 0.5, 1, dt, 0, None, ptr(ktop), unit, U,
+             stream_ptr())
+        torch.cuda.synchronize()
+        assert (Ca - Cb).abs().max() < 2e-5 * max(1.0, Ca.abs().max().item())
     # accumulate = 0 overwrites C; through ptv_gemm (the route the autograd functions take)
     C = torch.full((M, N), 7.0, device=dev)
-    call('ptv_wgrad', M, N, K, ptr(Ad), Ad.stride(0), ptr(Bd), Bd.stride(0), ptr(C), C.stride(0), 1.0, 0, dt, 0, None, None, 0, stream_ptr())
+    call('ptv_wgrad', M, N, K, ptr(Ad), Ad.stride(0), ptr(Bd), Bd.stride(0), ptr(C), C.stride(0), 1.0, 0, dt, 0, None, None, 0, 0, stream_ptr())
     C2 = C0.to(dev).clone()
     call('ptv_gemm', 1, 1, 1, M, N, K, ptr(Ad), Ad.stride(0), ptr(Bd), Bd.stride(0), ptr(C2), C2.stride(0), None, 0.5, 1, 0, 0, dt, stream_ptr())
     torch.cuda.synchronize()
