@@ -19,6 +19,8 @@ struct EpiPlain {
     int atomic;       // split-K partial sums: atomicAdd into C (C pre-initialised, fp32 only)
     int c_bf16;       // C holds bf16
   };
+  // a row tile that lies in the declared-zero part of A (GemmArgs::m_top): accumulating or atomically adding zero changes nothing
+  static __device__ __forceinline__ bool dead_is_noop(const Params& p) { return (p.accumulate || p.atomic) && p.act == 0 && p.bias == nullptr; }
   template <int FM, int FN, int NG> struct Pre {};
   template <int FM, int FN, int NG>
   static __device__ __forceinline__ void prefetch(const Params&, Pre<FM, FN, NG>&, int, int, int, int) {}

@@ -440,6 +440,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
   // a row tile that lies in the part of A its producer declared zero contributes nothing: empty K range, the epilogue still runs
   // (C = bias / unchanged)
   const bool dead = g.m_top != nullptr && m_blk >= ((long)*g.m_top + 1) * g.m_unit;
+  if (dead && Epi::dead_is_noop(ep)) return;                    // C += 0: nothing to read or write (block-uniform, before any barrier)
   const int kend = dead ? kbeg : min(g.K, kbeg + g.k_per_split);
   const int wave = threadIdx.x >> 6;
   const int wm = wave / WGN, wn = wave % WGN;

@@ -37,6 +37,7 @@ struct GruFwdParams {
 // one cell at a time in the epilogue.
 template <int MODE>   // 0 generic, 1 FAST, 2 FAST with a bf16 gi2 addend
 struct EpiGruFwdT {
+  template <class P> static __device__ __forceinline__ bool dead_is_noop(const P&) { return false; }   // (GemmArgs::m_top is never set here)
   using Params = GruFwdParams;
   static constexpr bool FAST = MODE > 0, G2 = MODE == 2;
   // wave tiles 32 or 64 units wide go through RowStage (row-contiguous lanes); narrower ones stay in the C layout.
@@ -193,6 +194,7 @@ struct GruBwdParams {
 // lane always has one cell's loads in flight behind the arithmetic and stores of the previous one.
 template <bool FAST>
 struct EpiGruBwdT {
+  template <class P> static __device__ __forceinline__ bool dead_is_noop(const P&) { return false; }   // (GemmArgs::m_top is never set here)
   using Params = GruBwdParams;
   struct Ops { bf16x4 g[4]; float4 hp, dz, e1, e2; float la[2]; };   // la: low-rank coefficients of the row (lr_k <= 2)
   static __device__ __forceinline__ Ops load_ops(const Params& p, int m_, int j_, int M, int H) {

@@ -763,7 +763,7 @@ def test_zero_skip_backward_equals_dense_backward(monkeypatch):
     F_.zero_skip_sync()
     for tfr in (1.0, 0.0):
         (l0, g0), (l1, g1) = res[False, tfr], res[True, tfr]
-        np.testing.assert_allclose(l1, l0, rtol=0, atol=(1e-6 if tfr == 1.0 else 5e-3))
+        np.testing.assert_allclose(l1, l0, rtol=0, atol=(3e-5 if tfr == 1.0 else 5e-3))     # split-K atomics: ~1e-6 relative run to run
         for n in g0:
             tol = 2e-3 if tfr == 1.0 else 0.05                  # tfr = 0: near-tie argmaxes may flip between two runs
             assert (g1[n] - g0[n]).abs().max() <= tol * g0[n].abs().max() + 1e-7, (tfr, n)
