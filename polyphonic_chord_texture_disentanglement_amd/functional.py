@@ -9,6 +9,7 @@ Reference call sites are cited per function (paths are into /root/reference).
 """
 import ctypes
 import os
+import time
 import weakref
 
 import torch
@@ -371,14 +372,16 @@ def mark(name):
     if TRACE is not None:
         e = torch.cuda.Event(enable_timing=True)
         e.record(torch.cuda.current_stream())
-        TRACE.append((name, e))
+        TRACE.append((name, e, time.perf_counter()))
 
 
 def _join_deferred():
+    mark('deferred:join_start')
     cur = torch.cuda.current_stream()
     for s, _keep in _DEFERRED:
         cur.wait_stream(s)
     _DEFERRED.clear()
+    mark('deferred:joined')
 
 
 def reset_deferred():
@@ -706,7 +709,9 @@ class BiGruFinalFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x3, *w = ctx.saved_tensors
+        mark('bigru_bwd:start M=%d' % x3.shape[1])
         grads, dx = _bigru_backward(ctx.prec, x3, w, ctx.saved_state, dout.contiguous(), ctx.needs_input_grad[0])
+        mark('bigru_bwd:end M=%d' % x3.shape[1])
         ctx.saved_state = None
         return (dx, None, None) + tuple(grads)
 
@@ -1018,6 +1023,7 @@ class DecoderTFFn(torch.autograd.Function):
         ctx.st = None
         R, E = st['R'], st['E']
         dz, demb, dTOKS, G, side = decoder_bwd_core(P, st, z, emb.view(16, R, E)[:15].view(15 * R, E), dpitch, ddur)
+        mark('dec_bwd:end')
         # parameter gradients only: joined when the backward pass ends -- but only if autograd ADOPTS the tensors
         # (p.grad is None and the buffer is this step's arena view); an accumulation `p.grad += g` would run on this
         # node's stream without a dependency on the side stream

@@ -39,16 +39,15 @@ torch.cuda.synchronize()
 acc = {}
 N = 10
 for _ in range(N):
+    step()                                   # an untraced step in flight: the traced one is enqueued while the GPU is busy, as in steady state
     F_.TRACE = []
     step()
     torch.cuda.synchronize()
     tr = F_.TRACE
     F_.TRACE = None
-    t0 = tr[0][1]
-    for name, e in tr:
-        acc.setdefault(name, []).append(t0.elapsed_time(e))
-prev = 0.0
-for name, v in acc.items():
-    t = sum(v) / len(v)
-    print('%-22s at %7.3f ms   (+%.3f)' % (name, t, t - prev))
-    prev = t
+    t0, h0 = tr[0][1], tr[0][2]
+    for name, e, h in tr:
+        acc.setdefault(name, []).append((t0.elapsed_time(e), (h - h0) * 1e3))
+print('%-28s %10s %10s   (the host enqueues a step while the GPU still runs the previous one: only differences matter)' % ('mark', 'GPU ms', 'host ms'))
+for name, t, h in sorted(((n, sum(x[0] for x in v) / len(v), sum(x[1] for x in v) / len(v)) for n, v in acc.items()), key=lambda x: x[1]):
+    print('%-28s %10.3f %10.3f' % (name, t, h))
