@@ -254,9 +254,9 @@ extern "C" int ptv_transpose01(float* dst, const float* src, int D0, int D1, int
 __global__ void last_nonzero_kernel(const float* __restrict__ x, long rows, int cols, long ld, long unit, int* __restrict__ top) {
   const long chunks = (rows + 63) / 64;
   for (long c = chunks - 1 - blockIdx.x; c >= 0; c -= gridDim.x) {
-    if ((c * 64) / unit <= *reinterpret_cast<volatile int*>(top)) break;            // already covered by a later block's report
-    bool nz = false;
     const long r1 = min(rows, (c + 1) * 64);
+    if ((r1 - 1) / unit <= *reinterpret_cast<volatile int*>(top)) break;           // the chunk's LAST row is already covered by a report
+    bool nz = false;
     for (long i = c * 64 * (long)cols + threadIdx.x; i < r1 * cols; i += blockDim.x) {
       const long r = i / cols; const int q = (int)(i % cols);
       nz |= x[r * ld + q] != 0.f;

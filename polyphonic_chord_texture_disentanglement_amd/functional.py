@@ -316,14 +316,42 @@ _CHILD_STREAMS = {}
 OVERLAP = True              # set False to serialise everything on the caller's stream (debugging)
 
 
+def _record_stream(obj, stream):
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            _record_stream(o, stream)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            _record_stream(o, stream)
+    elif hasattr(obj, '__dict__') and not callable(obj):          # small result holders (e.g. HipNormal)
+        for o in vars(obj).values():
+            if isinstance(o, (torch.Tensor, list, tuple, dict)):
+                _record_stream(o, stream)
+
+
 class Side:
     """s = Side(slot); s(fn, *keep_alive) runs fn on the sibling stream after everything enqueued so far
-    on the parent; s.join() makes the parent wait for it.  `keep_alive` tensors stay referenced until
-    join so the caching allocator cannot hand their memory to later parent-stream work."""
+    on the parent; s.join() makes the parent wait for it.  `keep_alive` tensors (or containers of tensors) stay referenced
+    until join so the caching allocator cannot hand their memory to later parent-stream work while the sibling's kernels
+    are still queued: EVERYTHING fn reads that might be released before the join belongs there -- with defer() that includes
+    the node's saved forward state, which the autograd engine drops the moment the node returns.  (Never the gradient buffers
+    fn writes: a second reference makes AccumulateGrad clone them -- on its own stream, before the sibling has run --
+    instead of adopting them.)"""
 
     def __init__(self, slot=0):
         self.main = torch.cuda.current_stream()
-        key = (self.main.cuda_stream, self.main.device.index, slot)
+        # The sibling streams are folded onto a pool of 4 (slot mod 4): the HIP runtime multiplexes all streams of a process onto 4
+        # hardware queues anyway (GPU_MAX_HW_QUEUES; with 5 or more the step gets 40 % SLOWER), and which of ~10 private streams
+        # end up sharing a queue -- i.e. silently serialise -- is then decided by creation order.  With the pool the sharing is
+        # explicit; measured 9.67 vs 9.94 ms per step (pool sizes 2 / 3 / 5 / 7: 10.0 / 9.8 / 10.3 / 10.3).  0 = private streams.
+        pool = int(os.environ.get('PTV_SIDE_POOL', '4'))
+        if pool > 0:
+            key = ('pool', self.main.device.index, slot % pool)
+        else:
+            key = (self.main.cuda_stream, self.main.device.index, slot)
         if key not in _CHILD_STREAMS:
             _CHILD_STREAMS[key] = torch.cuda.Stream(device=self.main.device)
         self.s = _CHILD_STREAMS[key]
@@ -337,7 +365,13 @@ class Side:
         self.used = True
         self.keep.extend(keep)
         with torch.cuda.stream(self.s):
-            return fn()
+            r = fn()
+        # What fn returns was allocated under the sibling stream and will be read on the parent after join(): tell the caching
+        # allocator, or the block goes back to the SIBLING's pool the moment Python drops the tensor and the next allocation there
+        # may overwrite it while the parent's reader is still queued (seen as partly wrong dx / gradients once in ~10 runs).
+        if self.s != self.main:
+            _record_stream(r, self.main)
+        return r
 
     def join(self):
         if self.used:
@@ -1210,6 +1244,9 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
         wgrad('z2dec_in_linear.weight', dz_in, z)
         bgrad('z2dec_in_linear.bias', dz_in)
     side(time_wgrads, dgi_t, dgh_t, dZG, dTOKS, dzhid, dz_in, dNS)
+    # the caller defers the join to the end of the backward pass; the node's saved forward state (released when the node returns)
+    # is still being read by the products queued above
+    side.keep.extend((st, z, tok_op))
     return dz, dtok, dTOKS, G, side
 
 

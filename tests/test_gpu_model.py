@@ -767,3 +767,43 @@ def test_zero_skip_backward_equals_dense_backward(monkeypatch):
         for n in g0:
             tol = 2e-3 if tfr == 1.0 else 0.05                  # tfr = 0: near-tie argmaxes may flip between two runs
             assert (g1[n] - g0[n]).abs().max() <= tol * g0[n].abs().max() + 1e-7, (tfr, n)
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_sibling_streams_do_not_change_a_steady_state_training_run(prec, monkeypatch):
+    """functional.Side: the weight-gradient products run on sibling HIP streams, the decoder's joined only when the backward pass
+    ends.  Against the same run with everything on one stream (functional.OVERLAP = False), in STEADY STATE -- models built one after
+    the other in one process and several optimiser steps each, so every block comes from the caching allocator's warm pool (no
+    hipMalloc, which would serialise and hide a missing dependency or a buffer released under a queued reader): same losses, same
+    gradients at every step"""
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
+    B, steps = 16, 4
+    runs = {}
+    for tag, overlap in (('warmup', True), ('serial', False), ('overlap', True), ('overlap2', True)):
+        monkeypatch.setattr(F_, 'OVERLAP', overlap)
+        m = M.DisentangleVAE.init_model(torch.device(DEV))
+        m.load_state_dict(full_params())
+        m.to(DEV).set_precision(prec)
+        opt = FusedClipAdam(m.parameters(), lr=1e-3)
+        m.use_philox(7, 0)
+        out = []
+        for step in range(steps):
+            x, c, pr = (torch.from_numpy(a).to(DEV) for a in synth_batch(B, 50 + step))
+            opt.zero_grad()
+            losses = m('train', x, c, pr, tfr1=1., tfr2=1., tfr3=1., beta=0.1, weights=[1, 0.5])
+            losses[0].backward()
+            assert opt.arena.holds_all_grads()                     # every gradient adopted in place (no early clone)
+            out.append((np.array([l.item() for l in losses]), opt.arena.flat.clone()))
+            opt.clip_and_step(1.0)
+        runs[tag] = (out, [(n, o, p.numel()) for (n, p), o in zip(m.named_parameters(), opt.arena.offsets)])
+        del m, opt
+    ref, index = runs['serial']
+    for tag in ('overlap', 'overlap2'):
+        for step in range(steps):
+            (l0, g0), (l1, g1) = ref[step], runs[tag][0][step]
+            np.testing.assert_allclose(l1, l0, rtol=0, atol=2e-4 * (step + 1), err_msg='%s step %d' % (tag, step))
+            for n, o, k in index:
+                a, b = g0[o:o + k], g1[o:o + k]
+                tol = (1e-2 if prec == 'bf16' else 5e-4) * (step + 1)   # order of the fp32 atomics (+ bf16 roundings they flip); grows per step
+                assert (a - b).abs().max() <= tol * a.abs().max() + 1e-7, (tag, step, n, float((a - b).abs().max()), float(a.abs().max()))
