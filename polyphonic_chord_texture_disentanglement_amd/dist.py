@@ -1,10 +1,44 @@
-"""Data-parallel gradient exchange: one process per GPU, one RCCL all-reduce of the flat gradient
-bucket per step (27.3M fp32 = 109 MB over xGMI).  Replaces the reference's nn.DataParallel
+"""Data-parallel gradient exchange: one process per GPU, RCCL all-reduce of the flat gradient bucket
+(27.3M fp32 = 109 MB over xGMI) in two parts per step.  Replaces the reference's nn.DataParallel
 (amc_dl/torch_plus/module.py:67-68,152-159): samples are independent through forward/backward, so
 the only exchange is the gradient SUM; the 1/world factor is folded into the clip+Adam kernel.
-`backend='nccl'` is RCCL on ROCm; the CPU tests use gloo."""
+
+Gradients become final in a known order during the backward pass: the PianoTree decoder's node finishes first (32 % of the
+27.3M parameters, at 7.4 of the 9.8 ms step), then the two encoders' bi-GRUs (53 %, at 8.6 ms), then the note-summary
+GRU; what follows each of them is latency-bound BPTT that leaves the xGMI links idle.  So each of these slices of the bucket
+starts its all-reduce the moment its last weight-gradient product is enqueued (functional.GRAD_READY_HOOK, on a communication
+stream that waits for the producing streams), under the rest of the backward pass; `all_reduce_grads()` then reduces what is
+left (heads, CNN, embedding, chord decoder: a few per cent) and waits for the early parts.
+xGMI is point-to-point: a ring all-reduce is bound per link, so one large early message beats many small buckets here.
+`backend='nccl'` is RCCL on ROCm; the CPU tests use gloo.  PTV_EARLY_ALLREDUCE=0: one all-reduce after the backward pass."""
+import os
+import weakref
+
 import torch
 import torch.distributed as dist
+
+
+def merge_ranges(ranges):
+    """sorted, disjoint union of half-open (start, end) ranges; touching ranges fuse"""
+    out = []
+    for a, b in sorted(r for r in ranges if r[1] > r[0]):
+        if out and a <= out[-1][1]:
+            out[-1][1] = max(out[-1][1], b)
+        else:
+            out.append([a, b])
+    return [tuple(r) for r in out]
+
+
+def complement_ranges(ranges, total):
+    """what merge_ranges(ranges) leaves of [0, total)"""
+    out, pos = [], 0
+    for a, b in merge_ranges(ranges):
+        if a > pos:
+            out.append((pos, a))
+        pos = max(pos, b)
+    if pos < total:
+        out.append((pos, total))
+    return out
 
 
 class GradSync:
@@ -14,8 +48,15 @@ class GradSync:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._bucket = None
+        self._early = []                                     # [((start, end), work)] all-reduces started during the backward pass
+        self._comm = None
+        self.early = os.environ.get('PTV_EARLY_ALLREDUCE', '1') != '0'
         if self.world > 1:
             self.broadcast_parameters()
+            if self.early and optimizer is not None and hasattr(optimizer, 'arena'):
+                from . import functional as F_
+                me = weakref.ref(self)
+                F_.GRAD_READY_HOOK = lambda params, streams: (me() is not None) and me().grads_ready(params, streams)
 
     def broadcast_parameters(self, src=0):
         """replica equality by construction, not by every rank happening to seed alike: rank `src`'s weights everywhere"""
@@ -48,11 +89,55 @@ class GradSync:
             off += k
         return self._bucket, True
 
+    def grads_ready(self, params, streams=()):
+        """the gradients of `params` (registered with the optimiser's arena, adopted in place) are final once the work enqueued so
+        far on the current stream and on `streams` has run: start their all-reduce now, on the communication stream"""
+        opt = self.optimizer
+        if self.world == 1 or not self.early or opt is None or not hasattr(opt, 'arena'):
+            return False
+        a = opt.arena
+        ranges = []
+        for p in params:
+            i = a._index.get(id(p))
+            if i is None:
+                continue
+            ranges.append((a.offsets[i], a.offsets[i] + (p.numel() + 7) // 8 * 8))
+        ranges = [r for r in merge_ranges(ranges) if not any(r[0] < e[0][1] and e[0][0] < r[1] for e in self._early)]
+        if not ranges:
+            return False
+        if a.flat.is_cuda:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=a.flat.device)
+            self._comm.wait_stream(torch.cuda.current_stream())
+            for s in streams:
+                self._comm.wait_stream(s)
+            with torch.cuda.stream(self._comm):
+                for r in ranges:
+                    self._early.append((r, dist.all_reduce(a.flat[r[0]:min(r[1], a.total)], op=dist.ReduceOp.SUM, group=self.group,
+                                                           async_op=True)))
+        else:
+            for r in ranges:
+                self._early.append((r, dist.all_reduce(a.flat[r[0]:min(r[1], a.total)], op=dist.ReduceOp.SUM, group=self.group,
+                                                       async_op=True)))
+        return True
+
     def all_reduce_grads(self):
         if self.world == 1:
             return
+        early, self._early = self._early, []
         flat, scatter = self._flat_bucket()
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        if early and not scatter:
+            # (every rank started the same early ranges in the same order: the hook fires from the same autograd node everywhere)
+            for r in complement_ranges([e[0] for e in early], flat.numel()):
+                dist.all_reduce(flat[r[0]:r[1]], op=dist.ReduceOp.SUM, group=self.group)
+            for _, w in early:
+                w.wait()                                 # RCCL: the current stream waits; gloo: the host does
+            if flat.is_cuda and self._comm is not None:
+                torch.cuda.current_stream().wait_stream(self._comm)
+        else:
+            for _, w in early:
+                w.wait()
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         opt = self.optimizer
         if not scatter:
             opt.grad_scale = 1.0 / self.world            # folded into ptv_clip_adam_step

@@ -397,6 +397,7 @@ class Side:
 
 
 _DEFERRED = []
+GRAD_READY_HOOK = None      # callable(params, streams) set by dist.GradSync: the gradients of `params` are complete once `streams` drain
 
 
 TRACE = None          # set to a list by scripts/trace_marks.py: (name, event on the current stream) markers of the backward chain
@@ -747,6 +748,12 @@ class BiGruFinalFn(torch.autograd.Function):
         grads, dx = _bigru_backward(ctx.prec, x3, w, ctx.saved_state, dout.contiguous(), ctx.needs_input_grad[0])
         mark('bigru_bwd:end M=%d' % x3.shape[1])
         ctx.saved_state = None
+        if GRAD_READY_HOOK is not None:                   # data parallel: a bi-GRU's 8 gradients are final here (its side stream is joined)
+            from .optim import is_arena_view
+            # (w is ordered by direction, the products return [ih, hh, b_ih, b_hh] per direction)
+            pairs = list(zip(w[0:4], grads[0:4])) + list(zip(w[4:8], grads[4:8]))
+            if all(p_.grad is None and is_arena_view(p_, g_) for p_, g_ in pairs):
+                GRAD_READY_HOOK([p_ for p_, _ in pairs], ())
         return (dx, None, None) + tuple(grads)
 
 
@@ -1063,7 +1070,10 @@ class DecoderTFFn(torch.autograd.Function):
         # node's stream without a dependency on the side stream
         from .optim import is_arena_view
         if all(G[n] is None or (P[n].grad is None and is_arena_view(P[n], G[n])) for n in DEC_PARAM_NAMES):
+            side_stream = side.s
             side.defer()
+            if GRAD_READY_HOOK is not None:               # data parallel: this slice of the gradient bucket can leave now (dist.GradSync)
+                GRAD_READY_HOOK([P[n] for n in DEC_PARAM_NAMES if G[n] is not None], (side_stream,))
         else:
             side.join()
         B, He = st['B'], st['He']

@@ -40,6 +40,10 @@ def main():
         losses = m('train', xs, cs, prs, tfr1=1., tfr2=1., tfr3=1., beta=0.1, weights=[1, 0.5])
         losses[0].backward()
         assert opt.arena.holds_all_grads()
+        # the decoder's slice of the bucket left during the backward pass (functional.GRAD_READY_HOOK -> GradSync.grads_ready)
+        early = sum(b - a for (a, b), _ in sync._early)
+        assert (early > 0) == (os.environ.get('PTV_EARLY_ALLREDUCE', '1') != '0'), (early, opt.arena.total)
+        res['early.%d' % step] = early
         sync.all_reduce_grads()
         assert opt.grad_scale == 1.0 / world
         opt.clip_and_step(1.0)

@@ -20,7 +20,10 @@ DEV = 'cuda:0'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_process_arena_all_reduce_matches_mean_of_shards(tmp_path):
+@pytest.mark.parametrize('early', ['1', '0'])
+def test_two_process_arena_all_reduce_matches_mean_of_shards(tmp_path, early):
+    """early = 1 (default): the decoder's slice of the bucket starts its all-reduce from inside the backward pass, on a
+    communication stream, while the encoders' chains still run (dist.GradSync.grads_ready); 0: one all-reduce afterwards"""
     from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
     B_local, world = 3, 2
     with socket.socket() as s:
@@ -30,7 +33,7 @@ def test_two_process_arena_all_reduce_matches_mean_of_shards(tmp_path):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+                   HSA_ENABLE_IPC_MODE_LEGACY='0', PTV_EARLY_ALLREDUCE=early)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dist_gpu_worker.py'), out, str(B_local)], env=env))
     for p in procs:
         assert p.wait(timeout=600) == 0
