@@ -51,7 +51,9 @@ class GradSync:
         self._early = []                                     # [((start, end), work)] all-reduces started during the backward pass
         self._comm = None
         self.early = os.environ.get('PTV_EARLY_ALLREDUCE', '1') != '0'
-        if self.world > 1:
+        # PTV_DP_FORCE=1: run the exchange on a group of ONE rank too (tests: the RCCL / stream mechanics on a 1-GPU box)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get('PTV_DP_FORCE') == '1')
+        if self.active:
             self.broadcast_parameters()
             if self.early and optimizer is not None and hasattr(optimizer, 'arena'):
                 from . import functional as F_
@@ -93,7 +95,7 @@ class GradSync:
         """the gradients of `params` (registered with the optimiser's arena, adopted in place) are final once the work enqueued so
         far on the current stream and on `streams` has run: start their all-reduce now, on the communication stream"""
         opt = self.optimizer
-        if self.world == 1 or not self.early or opt is None or not hasattr(opt, 'arena'):
+        if not self.active or not self.early or opt is None or not hasattr(opt, 'arena'):
             return False
         a = opt.arena
         ranges = []
@@ -122,7 +124,7 @@ class GradSync:
         return True
 
     def all_reduce_grads(self):
-        if self.world == 1:
+        if not self.active:
             return
         early, self._early = self._early, []
         flat, scatter = self._flat_bucket()
@@ -154,7 +156,7 @@ class GradSync:
 
     def mean_scalars(self, losses):
         """module.py:152-159 semantics: the reported loss is the mean of the replicas' scalars."""
-        if self.world == 1:
+        if not self.active:
             return losses
         t = torch.stack([l.detach().reshape(()) for l in losses])
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)

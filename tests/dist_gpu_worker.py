@@ -16,8 +16,8 @@ import torch.distributed as dist  # noqa: E402
 def main():
     rank, world, out = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), sys.argv[1]
     B_local = int(sys.argv[2])
-    dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.cuda.set_device(0)
+    dist.init_process_group(os.environ.get('PTV_TEST_BACKEND', 'gloo'), rank=rank, world_size=world)
     from polyphonic_chord_texture_disentanglement_amd.dist import GradSync
     from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
     from polyphonic_chord_texture_disentanglement_amd.synthetic import synth_batch

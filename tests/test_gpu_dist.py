@@ -20,6 +20,36 @@ DEV = 'cuda:0'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def test_rccl_group_of_one_runs_the_overlapped_exchange(tmp_path):
+    """the same worker over RCCL (backend nccl) with a group of ONE rank and PTV_DP_FORCE=1: the early all-reduces on the
+    communication stream, their waits and the remainder run through RCCL on the device (two ranks cannot share a GPU under
+    RCCL); a sum over one rank changes nothing, so the two steps must equal a plain single-process run"""
+    from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / 'dp1')
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0',
+               PTV_TEST_BACKEND='nccl', PTV_DP_FORCE='1', PTV_EARLY_ALLREDUCE='1')
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dist_gpu_worker.py'), out, '4'], env=env)
+    assert p.wait(timeout=600) == 0
+    got = torch.load(out + '.rank0')
+    assert got['early.0'] > 0
+    m = build_reduced(DEV).to(DEV)
+    opt = FusedClipAdam(m.parameters(), lr=1e-3)
+    m.use_philox(seed=7, sample_offset=0)
+    random.seed(7)
+    x, c, pr = (torch.from_numpy(a).to(DEV) for a in synth_batch(4, 321))
+    for step in range(2):
+        opt.zero_grad()
+        ls = m('train', x, c, pr, tfr1=1., tfr2=1., tfr3=1., beta=0.1, weights=[1, 0.5])
+        ls[0].backward()
+        opt.clip_and_step(1.0)
+        np.testing.assert_allclose(got['losses.%d' % step], [float(v.detach()) for v in ls], rtol=0, atol=2e-5)
+        assert abs(got['gnorm.%d' % step] - float(opt.grad_norm())) <= 2e-5 * float(opt.grad_norm())
+        assert (got['flat_p.%d' % step] - opt.flat_p.cpu()).abs().max() < 2e-5
+
+
 @pytest.mark.parametrize('early', ['1', '0'])
 def test_two_process_arena_all_reduce_matches_mean_of_shards(tmp_path, early):
     """early = 1 (default): the decoder's slice of the bucket starts its all-reduce from inside the backward pass, on a
