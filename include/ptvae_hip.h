@@ -339,13 +339,19 @@ int ptv_slerp_path(const float* z1, const float* z2, float* out, int B, int D, i
  *            xhat [B][32][16][6] int64, plen [R] int32 (zeroed), force_pitch [15][R] or NULL, force_dur [5][M] or NULL,
  *            HN16 [16][R][512] bf16 or NULL, HD16 [6][M][64] bf16 or NULL (bf16 state copies for the backward; HD16 replaces HD[1..5]) }
  *     io[17] = NULL (timing experiments), io[18] = NULL or fp32 [B][2048] = [initial state | gc] of this time step (then io[0] is
- *     ignored and slot 0 of HN is written by the kernel): io has 19 entries;
+ *     ignored and slot 0 of HN is written by the kernel); io[19] = xch, bf16 [ceil(B/16)][2][16][512], io[20] = cnt, uint32
+ *     [ceil(B/16) + 1] ZEROED by the caller before the launch of t = 0 (cluster mode below; else NULL): io has 21 entries;
  *     with R = 32*B, M = 15*R; the rows of time step t are [t*B, (t+1)*B).  coin_mask bit n = feed the ground-truth note n+1
  *     (teacher-forcing coin, ptvae.py:420).  train = 0 skips what only the backward reads (HN, gates, HD, TOK); train = 2 stores only
  *     the fed tokens TOK: the caller then recomputes states and gates for ALL rows with the batched kernels (ptv_notes_gru_persist_fwd,
  *     ptv_dur_gru_fwd with the stored decisions forced), cheaper than 16-row panels streaming them out note step by note step.
  *     Bits 16 / 17 of train force the 4-wave kernel / the 8-wave kernel whose producer waves stream the next note step's state
  *     products under the head phases of the current one (default: by panel count).
+ *     Bits 18-20 of train = S in {2, 4}: cluster mode of the 4-wave kernel -- S workgroups (co-resident: ceil(B/16) * S <= 128, else
+ *     PTV_ERR_UNSUPPORTED) share a panel: each streams 1/S of the notes-GRU gate weights (the product bound by one CU's L2 port), the
+ *     new bf16 state is all-gathered through xch once per note step (8-byte agent-scope stores / loads, one arrival counter per
+ *     panel; the launches of t = 0..31 must follow each other in order on one stream), heads / duration GRU / embedding are computed
+ *     redundantly by all members and written by member 0.  cnt[ceil(B/16)] != 0 afterwards: a member gave up waiting (results void).
  *   ptv_free_resummarize: w = { pack(W_ih), pack(W_hh), pack(W_ih_reverse), pack(W_hh_reverse), b_ih, b_hh, b_ih_r, b_hh_r } of
  *     dec_notes_emb_gru; io = { PRED, plen, XH fwd [17][R][128] (slot 0 zero), XH bwd, XG fwd [16][4][R][128] bf16, XG bwd,
  *     tok_next = TOKS[t+1] [B][256] }.

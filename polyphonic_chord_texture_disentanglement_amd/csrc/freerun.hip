@@ -140,6 +140,9 @@ __global__ void pack_b_kernel(const float* __restrict__ W, long ld, int N, int K
 // =============================================================================================
 // note loop of one time step for one 16-row panel
 // =============================================================================================
+typedef __attribute__((address_space(1))) unsigned gu32;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
 struct NoteLoopArgs {
   const bf16x8 *wg_h, *wg_t, *wp, *wd_h, *wd_p, *wdur;
   const float *b_hh_n, *b_p, *b_dh, *b_hh_d, *tab0, *tab, *w_out, *b_out, *w_embT, *b_emb;
@@ -156,6 +159,11 @@ struct NoteLoopArgs {
   int train;                       // save what the backward needs (states, gates)
   int tok_store;                   // save the fed tokens (train, or the light mode whose caller recomputes states and gates batched)
   int dbg;                         // timing experiments: skip phases (results invalid)
+  // cluster mode (note_loop_kernel only): S workgroups share a panel -- each streams 1/S of the gate weights, the new bf16 state is
+  // all-gathered through `xch` once per note step, everything after the cell is computed by all S redundantly
+  int S;
+  __bf16* xch;                     // [panels][2][16][512] bf16 exchange buffer
+  unsigned* cnt;                   // [panels] arrival counters (zeroed by the caller before t = 0) + [1] error word
 };
 
 __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
@@ -180,9 +188,23 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
   const int erow = lane >> 2, eq = lane & 3;                  // epilogue layout
   const int B = a.B, R = a.R, t = a.t;
   const long M = a.M;
-  const int r0 = blockIdx.x * FP;                             // first sample of the panel
+  // cluster mode: the S members of a panel are S consecutive workgroups OF ONE XCD (workgroups go round-robin over the 8 XCDs:
+  // speed only -- the exchange is agent-scope either way), member 0 is the one that writes the panel's outputs
+  const int S = a.S;
+  int panel = blockIdx.x, mem = 0;
+  if (S > 1) {
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    panel = (q / S) * 8 + x; mem = q % S;
+    if (panel * FP >= B) return;                              // (whole panels only: nobody waits for these)
+  }
+  const bool lead = mem == 0;
+  const int p_lo = mem * (4 / S), p_hi = p_lo + 4 / S;        // the P1 passes (32 units per wave each) this member computes
+  gu32* const xcnt = S > 1 ? (gu32*)(a.cnt + panel) : nullptr;
+  gu32* const xerr = S > 1 ? (gu32*)(a.cnt + (B + FP - 1) / FP) : nullptr;
+  bool dead = false;
+  const int r0 = panel * FP;                                  // first sample of the panel
   const int rE = min(r0 + erow, B - 1), rC = min(r0 + crow, B - 1);
-  const bool okE = r0 + erow < B, okC = r0 + crow < B;
+  const bool okE = r0 + erow < B, okC = r0 + crow < B && lead;   // (okC guards output stores only)
   const long wrowE = (long)t * B + rE, wrowC = (long)t * B + rC;   // row in the [R]-row step-major matrices
 
   // ---- one-time loads: duration GRU weights / tables -> LDS, initial state and first token -> LDS
@@ -195,10 +217,10 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
     const int rb = min(r0 + row, B - 1);
     const float4 v = a.h0 ? *reinterpret_cast<const float4*>(a.h0 + (long)rb * a.ld_h0 + c4)
                           : *reinterpret_cast<const float4*>(a.HN + ((long)t * B + rb) * FHN + c4);
-    if (a.h0 && r0 + row < B) *reinterpret_cast<float4*>(a.HN + ((long)t * B + rb) * FHN + c4) = v;   // slot 0 of HN for the backward
+    if (a.h0 && r0 + row < B && lead) *reinterpret_cast<float4*>(a.HN + ((long)t * B + rb) * FHN + c4) = v;   // slot 0 of HN for the backward
     *reinterpret_cast<float4*>(&hf[row][c4]) = v;
     st_bf16x4_lds(&h16[0][row][c4], v.x, v.y, v.z, v.w);
-    if (a.train && a.HN16 && r0 + row < B) st_bf16x4_lds(a.HN16 + ((long)t * B + r0 + row) * FHN + c4, v.x, v.y, v.z, v.w);
+    if (a.train && a.HN16 && r0 + row < B && lead) st_bf16x4_lds(a.HN16 + ((long)t * B + r0 + row) * FHN + c4, v.x, v.y, v.z, v.w);
   }
   for (int i = tid; i < FP * (FE / 4); i += 256) {
     const int row = i / (FE / 4), c4 = (i % (FE / 4)) * 4;
@@ -216,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
     const int cur = n & 1, nxt = cur ^ 1;
     // ================= P1: notes-GRU cell.  wave w owns units [w*128, w*128+128) = 8 tiles of 16, two per pass =================
 #pragma unroll 1
-    for (int p = 0; p < ((a.dbg & 2) ? 0 : 4); p++) {
+    for (int p = p_lo; p < ((a.dbg & 2) ? 0 : p_hi); p++) {
       const int ut0 = wave * 8 + p * 2;
       // per-lane constants in the epilogue layout (4 adjacent lanes = 16 units of one row): the hoisted input part GC (b_ih
       // included) and b_hh, requested before the products
@@ -270,6 +292,38 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
       }
     }
     lds_barrier();
+    if (S > 1) {
+      // ---- all-gather of the new bf16 state: own slices (4/S passes x 4 waves x 32 units x 16 rows) out with write-through
+      // stores, one arrival per member, the other members' slices in with L1-bypassing loads (8-byte pieces: 4 units of a row)
+      __bf16* xb = a.xch + ((long)panel * 2 + (n & 1)) * (FP * FHN);
+      const int npo = 4 / S;
+      for (int i = tid; i < 512 * npo; i += 256) {
+        const int piece = i & 7, row = (i >> 3) & 15, wp = i >> 7;               // wp: (wave, owned pass)
+        const int u = (wp / npo) * 128 + (p_lo + wp % npo) * 32 + piece * 4;
+        __hip_atomic_store((gu64*)(xb + row * FHN + u), *reinterpret_cast<const unsigned long long*>(&h16[nxt][row][u]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_fetch_add(xcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (unsigned)(t * 15 + n + 1) * S;
+        unsigned spins = 0;
+        while (!dead && __hip_atomic_load(xcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1u << 24)) { __hip_atomic_store(xerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; }
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < 512 * (4 - npo); i += 256) {
+        const int piece = i & 7, row = (i >> 3) & 15, wp = i >> 7;               // wp: (wave, foreign pass)
+        const int fp = wp % (4 - npo), pass = fp < p_lo ? fp : fp + npo;
+        const int u = (wp / (4 - npo)) * 128 + pass * 32 + piece * 4;
+        *reinterpret_cast<unsigned long long*>(&h16[nxt][row][u]) =
+            __hip_atomic_load((gu64*)(xb + row * FHN + u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      lds_barrier();
+    }
     // ================= P2: pitch head (9 tiles over 4 waves) + the state part of dur_hid_linear (one tile per wave) =================
     f32x4 accD[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
     {
@@ -295,7 +349,7 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
       const int row = tid >> 4, j = tid & 15;
       float best = -INFINITY; int bi = 0x7fffffff;
       const long pr = (long)n * R + (long)t * B + min(r0 + row, B - 1);
-      const bool ok = r0 + row < B;
+      const bool ok = r0 + row < B && lead;
 #pragma unroll
       for (int k = 0; k < 9; k++) {
         const int c = j + 16 * k;
@@ -397,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
     // ================= P6: predicted token = note_embedding(onehot(pitch) | 5 duration bits); next input token =================
     {
       const int row = tid >> 4, e0 = (tid & 15) * 8;
-      const bool ok = r0 + row < B;
+      const bool ok = r0 + row < B && lead;
       const long wr = (long)t * B + min(r0 + row, B - 1);
       const int pch = pidx[row];
       float v[8];
@@ -431,7 +485,7 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
         st_bf16x4_lds(&tok16[row][e0], v[0], v[1], v[2], v[3]);
         st_bf16x4_lds(&tok16[row][e0 + 4], v[4], v[5], v[6], v[7]);
       }
-      if (tid < FP && r0 + tid < B) {
+      if (tid < FP && r0 + tid < B && lead) {
         const int rw = r0 + tid;
         long* xr = a.xhat + (((long)rw * 32 + t) * 16 + n + 1) * 6;
         const int pb = pidx[tid];
@@ -937,7 +991,8 @@ extern "C" int ptv_pack_mfma_b(const float* W, long ld, int N, int K, void* out,
 }
 
 // w[16]: wg_h, wg_t, wp, wd_h, wd_p, wdur (packed bf16), b_hh_n, b_p, b_dh, b_hh_d, tab0, tab, w_out, b_out, w_embT, b_emb
-// io[19]: gc, emb, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, force_pitch, force_dur, HN16, HD16, dbg words, h0gc
+// io[21]: gc, emb, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, force_pitch, force_dur, HN16, HD16, dbg words, h0gc,
+//         xch, cnt (cluster mode, train bits 18-20 = S in {2, 4}: S workgroups per 16-sample panel, ptvae_hip.h)
 extern "C" int ptv_free_note_loop(const void* const* w, const void* const* io, long ld_pitch, int B, int t, unsigned coin_mask, int train,
                                   void* stream) {
   if (!w || !io || B <= 0 || t < 0 || t >= 32) return PTV_ERR_ARG;
@@ -968,7 +1023,14 @@ extern "C" int ptv_free_note_loop(const void* const* w, const void* const* io, l
   // (47.0 -> 40.8 us).  train bit 16 / 17 force the 4-wave / 8-wave kernel.
   const int panels = (B + FP - 1) / FP;
   const bool split = (train & 0x20000) || (!(train & 0x10000) && panels >= 96);
-  if (!split) hipLaunchKernelGGL(note_loop_kernel, dim3(panels), dim3(256), 0, (hipStream_t)stream, a);
+  // cluster mode: S members per panel, all co-resident (they wait for each other once per note step): at most half the chip
+  const int S = (train >> 18) & 7;
+  a.S = 1;
+  if (S > 1) {
+    if ((S != 2 && S != 4) || split || !io[19] || !io[20] || panels * S > 128) return PTV_ERR_UNSUPPORTED;
+    a.S = S; a.xch = (__bf16*)io[19]; a.cnt = (unsigned*)io[20];
+  }
+  if (!split) hipLaunchKernelGGL(note_loop_kernel, dim3(a.S > 1 ? (panels + 7) / 8 * 8 * a.S : panels), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(note_loop2_kernel, dim3(panels), dim3(512), 0, (hipStream_t)stream, a);
   PTV_CHECK_LAUNCH();
   return PTV_OK;

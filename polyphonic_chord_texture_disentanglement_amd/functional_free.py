@@ -48,6 +48,19 @@ FREE_PERSIST = os.environ.get('PTV_FREE_PERSIST', '1') not in ('0', 'false', 'of
 FREE_REPLAY = os.environ.get('PTV_FREE_REPLAY', '1') not in ('0', 'false', 'off')
 # note-loop kernel: None = by panel count (csrc/freerun.hip), True / False = force the producers-heads split / the 4-wave kernel
 NOTE_LOOP_SPLIT = None
+# cluster mode of the 4-wave kernel: S workgroups per 16-sample panel, each streaming 1/S of the notes-GRU gate weights (bound by ONE
+# CU's L2 port), the new state all-gathered once per note step.  None = by panel count (4 up to 32 panels, 2 up to 64), 0 = off
+LAST_CLUSTER_COUNTERS = None
+NOTE_LOOP_CLUSTER = None if os.environ.get('PTV_NOTE_CLUSTER') is None else int(os.environ['PTV_NOTE_CLUSTER'])
+
+
+def note_loop_cluster(B):
+    panels = (B + 15) // 16
+    if NOTE_LOOP_SPLIT or (NOTE_LOOP_SPLIT is None and panels >= 96):
+        return 0
+    if NOTE_LOOP_CLUSTER is not None:
+        return NOTE_LOOP_CLUSTER if NOTE_LOOP_CLUSTER in (2, 4) and panels * NOTE_LOOP_CLUSTER <= 128 else 0
+    return 4 if panels <= 32 else (2 if panels <= 64 else 0)
 _PACKS = F_.PackCache()
 _PACK_SRC = ('dec_notes_gru.weight_hh_l0', 'dec_notes_gru.weight_ih_l0', 'pitch_out_linear.weight', 'dur_hid_linear.weight',
              'dec_dur_gru.weight_hh_l0', 'note_embedding.weight', 'dec_notes_emb_gru.weight_ih_l0', 'dec_notes_emb_gru.weight_hh_l0',
@@ -190,7 +203,14 @@ class DecoderStepFn(torch.autograd.Function):
         elif need_resum:
             XH = [_zeros(17, R, He, dev=dev) for _ in range(2)]
             XG = [torch.zeros(16, 4, R, He, device=dev, dtype=F_._act_dtype(prec, He)) for _ in range(2)] if train else [None, None]
+        cluster, xch, xcnt = 0, None, None
         if fast:
+            cluster = note_loop_cluster(B)
+            if cluster:
+                global LAST_CLUSTER_COUNTERS
+                xch = _empty((B + 15) // 16 * 2 * 16 * Hn, dev=dev, dtype=torch.bfloat16)
+                xcnt = torch.zeros((B + 15) // 16 + 1, device=dev, dtype=torch.int32)    # arrival counters of t = 0..31 + error word
+                LAST_CLUSTER_COUNTERS = xcnt             # (tests: every panel counts 32 * 15 * S arrivals, the error word stays 0)
             pk = _free_packs(P, Ht)
             wl = F_._parr([pk['wg_h'], pk['wg_t'], pk['wp'], pk['wd_h'], pk['wd_p'], pk['wdur'], b_hh_n, P['pitch_out_linear.bias'],
                            P['dur_hid_linear.bias'], b_hh_d, tab0, tab, P['dur_out_linear.weight'], P['dur_out_linear.bias'],
@@ -224,9 +244,10 @@ class DecoderStepFn(torch.autograd.Function):
                     for n in range(14):
                         mask |= int(bool(coin_notes[t][n])) << n
                 io = F_._parr([GCt, emb3, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, force_pitch, force_dur, HN16, HD16,
-                               None, H0GC])
+                               None, H0GC, xch, xcnt])
                 call('ptv_free_note_loop', wl, io, pitch.stride(0), B, t, mask,
-                     (2 if replay else int(train)) | (0 if NOTE_LOOP_SPLIT is None else (0x20000 if NOTE_LOOP_SPLIT else 0x10000)), st)
+                     (2 if replay else int(train)) | (0 if NOTE_LOOP_SPLIT is None else (0x20000 if NOTE_LOOP_SPLIT else 0x10000))
+                     | (cluster << 18), st)
                 if t == 31:
                     break
                 if (not inference) and coin_time[t]:

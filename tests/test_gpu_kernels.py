@@ -625,3 +625,70 @@ def test_gemm_row_limit_and_sum_steps_plane_limit_equal_the_dense_kernels(acc):
         s0 = F_.sum_steps(a_)
         s1 = F_.sum_steps(a_, t_top=top)
         assert torch.equal(s0, s1)
+
+
+@pytest.mark.parametrize('B', [40, 16, 250])
+def test_note_loop_cluster_mode_is_bit_identical_to_one_workgroup_per_panel(B):
+    """ptv_free_note_loop with S = 2 / 4 workgroups per 16-sample panel (each streams 1/S of the notes-GRU gate weights, the new
+    bf16 state is all-gathered once per note step through agent-scope 8-byte stores / loads, the heads are computed redundantly):
+    the arithmetic per unit is the same, so logits, decisions, tokens and states must equal the S = 1 launch BIT FOR BIT -- over
+    two consecutive time steps (the arrival counters run on), inference and training mode; every panel counts 15 * S arrivals per
+    launch and no member gave up waiting"""
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    from polyphonic_chord_texture_disentanglement_amd import functional_free as FF_
+    from polyphonic_chord_texture_disentanglement_amd._lib import call, stream_ptr
+    from polyphonic_chord_texture_disentanglement_amd.model import DisentangleVAE
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    m = DisentangleVAE.init_model(dev).to(dev)
+    P = dict(m.decoder.named_parameters())
+    R, M = 32 * B, 15 * 32 * B
+    panels = (B + 15) // 16
+    pk = FF_._free_packs(P, 1024)
+    w_ih_d, b_ih_d = P['dec_dur_gru.weight_ih_l0'], P['dec_dur_gru.bias_ih_l0']
+    tab0 = F_.gemm(P['dur_sos_token'].view(1, -1), w_ih_d, bias=b_ih_d, prec=0)
+    tab = F_.gemm(F_._onehot2x5(dev), w_ih_d, bias=b_ih_d, prec=0)
+    wl = F_._parr([pk['wg_h'], pk['wg_t'], pk['wp'], pk['wd_h'], pk['wd_p'], pk['wdur'], P['dec_notes_gru.bias_hh_l0'],
+                   P['pitch_out_linear.bias'], P['dur_hid_linear.bias'], P['dec_dur_gru.bias_hh_l0'], tab0, tab,
+                   P['dur_out_linear.weight'], P['dur_out_linear.bias'], pk['w_embT'], P['note_embedding.bias']])
+    bf = torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(5)
+    GC = torch.randn(2, B, 1536, device=dev, generator=g) * 0.6
+    HN0 = torch.randn(R, 512, device=dev, generator=g) * 0.5
+    TOK0 = torch.randn(R, 128, device=dev, generator=g) * 0.5
+    emb = torch.randn(16, R, 128, device=dev, generator=g) * 0.5
+    res = {}
+    for S in (1, 2, 4):
+        if panels * S > 128:
+            continue
+        for train in (0, 1):
+            HN = torch.zeros(16, R, 512, device=dev); HN[0] = HN0
+            gates_n = torch.zeros(15, 4, R, 512, device=dev, dtype=bf)
+            pitch = torch.zeros(M, 136, device=dev)
+            HD = torch.zeros(6, M, 64, device=dev)
+            gates_d = torch.zeros(5, 4, M, 64, device=dev, dtype=bf)
+            dur = torch.zeros(M, 10, device=dev)
+            idx = torch.zeros(5, M, device=dev, dtype=torch.int32)
+            TOK = torch.zeros(15, R, 128, device=dev); TOK[0] = TOK0
+            PRED = torch.zeros(16, R, 128, device=dev)
+            xhat = torch.zeros(B, 32, 16, 6, device=dev, dtype=torch.long)
+            plen = torch.zeros(R, device=dev, dtype=torch.int32)
+            xch = torch.empty(panels * 2 * 16 * 512, device=dev, dtype=bf)
+            cnt = torch.zeros(panels + 1, device=dev, dtype=torch.int32)
+            for t in (0, 1):
+                io = F_._parr([GC[t], emb, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, None, None, None, None, None, None,
+                               xch if S > 1 else None, cnt if S > 1 else None])
+                call('ptv_free_note_loop', wl, io, 136, B, t, 0x15a5 if train else 0, train | 0x10000 | ((S if S > 1 else 0) << 18), stream_ptr())
+            torch.cuda.synchronize()
+            if S > 1:
+                c = cnt.cpu()
+                assert int(c[-1]) == 0 and (c[:-1] == 2 * 15 * S).all(), c
+            res[S, train] = [v.clone() for v in (pitch, dur, idx, xhat, plen, PRED, TOK, HN, gates_n, HD, gates_d)]
+    names = ('pitch', 'dur', 'idx', 'xhat', 'plen', 'PRED', 'TOK', 'HN', 'gates_n', 'HD', 'gates_d')
+    for (S, train), got in res.items():
+        if S == 1:
+            continue
+        ref = res[1, train]
+        for n, a_, b_ in zip(names, ref, got):
+            assert torch.equal(a_, b_), (S, train, n, float((a_.float() - b_.float()).abs().max()))
+    assert (res[1, 1][3][:, :2, 1:, 0] != 0).any()             # the decisions are not trivially constant
