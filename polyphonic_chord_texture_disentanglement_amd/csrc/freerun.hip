@@ -141,7 +141,7 @@ __global__ void pack_b_kernel(const float* __restrict__ W, long ld, int N, int K
 // note loop of one time step for one 16-row panel
 // =============================================================================================
 typedef __attribute__((address_space(1))) unsigned gu32;
-typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 struct NoteLoopArgs {
   const bf16x8 *wg_h, *wg_t, *wp, *wd_h, *wd_p, *wdur;
@@ -293,15 +293,15 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
     }
     lds_barrier();
     if (S > 1) {
-      // ---- all-gather of the new bf16 state: own slices (4/S passes x 4 waves x 32 units x 16 rows) out with write-through
-      // stores, one arrival per member, the other members' slices in with L1-bypassing loads (8-byte pieces: 4 units of a row)
+      // ---- all-gather of the new bf16 state: own slices (4/S passes x 4 waves x 32 units x 16 rows) out with write-through (sc1)
+      // stores, one arrival per member, the other members' slices in with sc1 loads (16-byte pieces: 8 units of a row)
       __bf16* xb = a.xch + ((long)panel * 2 + (n & 1)) * (FP * FHN);
+      const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xb, 0, FP * FHN * 2, 0x00020000);
       const int npo = 4 / S;
-      for (int i = tid; i < 512 * npo; i += 256) {
-        const int piece = i & 7, row = (i >> 3) & 15, wp = i >> 7;               // wp: (wave, owned pass)
-        const int u = (wp / npo) * 128 + (p_lo + wp % npo) * 32 + piece * 4;
-        __hip_atomic_store((gu64*)(xb + row * FHN + u), *reinterpret_cast<const unsigned long long*>(&h16[nxt][row][u]), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = tid; i < 256 * npo; i += 256) {
+        const int piece = i & 3, row = (i >> 2) & 15, wp = i >> 6;               // wp: (wave, owned pass)
+        const int u = (wp / npo) * 128 + (p_lo + wp % npo) * 32 + piece * 8;
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&h16[nxt][row][u]), xr, (row * FHN + u) * 2, 0, 16);   // sc1
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -315,12 +315,11 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
         }
       }
       __syncthreads();
-      for (int i = tid; i < 512 * (4 - npo); i += 256) {
-        const int piece = i & 7, row = (i >> 3) & 15, wp = i >> 7;               // wp: (wave, foreign pass)
+      for (int i = tid; i < 256 * (4 - npo); i += 256) {
+        const int piece = i & 3, row = (i >> 2) & 15, wp = i >> 6;               // wp: (wave, foreign pass)
         const int fp = wp % (4 - npo), pass = fp < p_lo ? fp : fp + npo;
-        const int u = (wp / (4 - npo)) * 128 + pass * 32 + piece * 4;
-        *reinterpret_cast<unsigned long long*>(&h16[nxt][row][u]) =
-            __hip_atomic_load((gu64*)(xb + row * FHN + u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int u = (wp / (4 - npo)) * 128 + pass * 32 + piece * 8;
+        *reinterpret_cast<u32x4*>(&h16[nxt][row][u]) = __builtin_amdgcn_raw_buffer_load_b128(xr, (row * FHN + u) * 2, 0, 16);            // sc1
       }
       lds_barrier();
     }

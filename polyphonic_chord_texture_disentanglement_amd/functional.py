@@ -159,6 +159,7 @@ def _gru_flags(gates=None, gi=None, gi2=None, dg=None, w=None, ext=None):
 # ---------------------------------------------------------------------------------------------
 _PERSIST_LAST = {}          # device index -> event recorded after the last persistent launch
 _PERSIST_SYNC = []          # (sync words, error index) of recent launches, for persist_check()
+_CLUSTER_SYNC = []          # arrival counters + error word (last) of recent cluster-mode step loops (functional_free), for persist_check()
 _PERSIST_OK = {}
 
 
@@ -213,8 +214,12 @@ def persist_check():
     """raises if a bounded spin of a recent persistent launch gave up (synchronises: tests / the end of a bench)"""
     bad = [i for i, sw in enumerate(_PERSIST_SYNC) if int(sw[0].item()) != 0]
     del _PERSIST_SYNC[:]
+    badc = [i for i, sw in enumerate(_CLUSTER_SYNC) if int(sw[-1].item()) != 0]
+    del _CLUSTER_SYNC[:]
     if bad:
         raise RuntimeError('persistent GRU launch gave up waiting for its row group (recent launches %s)' % bad)
+    if badc:
+        raise RuntimeError('cluster-mode note loop: a member gave up waiting for its panel (recent forward passes %s)' % badc)
 
 
 def gru_persist_fwd(M, H, T, chains):

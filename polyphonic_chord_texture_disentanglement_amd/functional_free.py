@@ -11,6 +11,7 @@ teacher-forced path; token gradients are routed to the ground-truth embedding or
 buffer (whose gradient reaches `note_embedding` and, through the re-summarising bi-GRU,
 `dec_notes_emb_gru`) -- never into the logits that produced the argmax.
 """
+import contextlib
 import os
 
 import weakref
@@ -206,11 +207,17 @@ class DecoderStepFn(torch.autograd.Function):
         cluster, xch, xcnt = 0, None, None
         if fast:
             cluster = note_loop_cluster(B)
+            capturing = torch.cuda.is_current_stream_capturing()
+            if capturing and torch.is_grad_enabled():
+                cluster = 0          # a captured training forward replays next to other streams' persistent launches, unordered with them
             if cluster:
                 global LAST_CLUSTER_COUNTERS
                 xch = _empty((B + 15) // 16 * 2 * 16 * Hn, dev=dev, dtype=torch.bfloat16)
                 xcnt = torch.zeros((B + 15) // 16 + 1, device=dev, dtype=torch.int32)    # arrival counters of t = 0..31 + error word
                 LAST_CLUSTER_COUNTERS = xcnt             # (tests: every panel counts 32 * 15 * S arrivals, the error word stays 0)
+                F_._CLUSTER_SYNC.append(xcnt)
+                if len(F_._CLUSTER_SYNC) > 64:
+                    del F_._CLUSTER_SYNC[:32]
             pk = _free_packs(P, Ht)
             wl = F_._parr([pk['wg_h'], pk['wg_t'], pk['wp'], pk['wd_h'], pk['wd_p'], pk['wdur'], b_hh_n, P['pitch_out_linear.bias'],
                            P['dur_hid_linear.bias'], b_hh_d, tab0, tab, P['dur_out_linear.weight'], P['dur_out_linear.bias'],
@@ -245,9 +252,12 @@ class DecoderStepFn(torch.autograd.Function):
                         mask |= int(bool(coin_notes[t][n])) << n
                 io = F_._parr([GCt, emb3, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, force_pitch, force_dur, HN16, HD16,
                                None, H0GC, xch, xcnt])
-                call('ptv_free_note_loop', wl, io, pitch.stride(0), B, t, mask,
-                     (2 if replay else int(train)) | (0 if NOTE_LOOP_SPLIT is None else (0x20000 if NOTE_LOOP_SPLIT else 0x10000))
-                     | (cluster << 18), st)
+                # (cluster mode: the members of a panel spin on each other -- like every persistent launch it takes its turn, so that
+                # it is never half-resident next to another spinning grid, e.g. the chord decoder's on its sibling stream)
+                with (F_._PersistTurn() if cluster and not capturing else contextlib.nullcontext()):
+                    call('ptv_free_note_loop', wl, io, pitch.stride(0), B, t, mask,
+                         (2 if replay else int(train)) | (0 if NOTE_LOOP_SPLIT is None else (0x20000 if NOTE_LOOP_SPLIT else 0x10000))
+                         | (cluster << 18), st)
                 if t == 31:
                     break
                 if (not inference) and coin_time[t]:

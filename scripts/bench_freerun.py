@@ -38,11 +38,18 @@ PRED = torch.zeros(16, R, 128, device=dev)
 xhat = torch.zeros(B, 32, 16, 6, device=dev, dtype=torch.long)
 plen = torch.zeros(R, device=dev, dtype=torch.int32)
 dbg_out = torch.zeros(3 * ((B + 15) // 16), device=dev, dtype=torch.long)
-io = F_._parr([GC, None, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, None, None, None, None, dbg_out, None])
+S = int(os.environ.get('S', '0'))                  # cluster mode: S workgroups per panel (0 = off)
+xch = torch.empty(((B + 15) // 16) * 2 * 16 * 512, device=dev, dtype=bf)
+cnt = torch.zeros((B + 15) // 16 + 1, device=dev, dtype=torch.int32)
+io = F_._parr([GC, None, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, None, None, None, None, dbg_out, None, xch, cnt])
 
 
 def run(flags):
-    call('ptv_free_note_loop', wl, io, 136, B, 3, 0, flags, stream_ptr())
+    if S:
+        cnt.zero_()                                # (the arrival counters run on from launch to launch of one forward pass: t = 0 here)
+        call('ptv_free_note_loop', wl, io, 136, B, 0, 0, flags | (S << 18), stream_ptr())
+    else:
+        call('ptv_free_note_loop', wl, io, 136, B, 3, 0, flags, stream_ptr())
 
 
 def timeit(flags, n=10):
@@ -64,6 +71,8 @@ for name, dbg in (('all phases', 0), ('no gate products', 1), ('no GRU cell (P1)
         t = timeit(train | (dbg << 8))
         print('B=%d %-28s train=%d  %8.1f us per launch  %6.1f us per note step' % (B, name, train, t, t / 15), flush=True)
 
+if S:
+    sys.exit(0)
 # the same launch with the caches disturbed in between (what the real step loop does: the time-GRU step and its products stream
 # ~20 MB of other weights between two note-loop launches) and walking t
 big = torch.empty(64 << 20, device=dev, dtype=torch.uint8)

@@ -802,7 +802,9 @@ def test_sibling_streams_do_not_change_a_steady_state_training_run(prec, monkeyp
     for tag in ('overlap', 'overlap2'):
         for step in range(steps):
             (l0, g0), (l1, g1) = ref[step], runs[tag][0][step]
-            np.testing.assert_allclose(l1, l0, rtol=0, atol=2e-4 * (step + 1), err_msg='%s step %d' % (tag, step))
+            # (bf16: the order of the fp32 atomics flips roundings of the bf16 operands; after an Adam step that is ~1e-3 on a loss --
+            # measured up to 8e-4 at step 3; a missing dependency shows as >= 2e-2)
+            np.testing.assert_allclose(l1, l0, rtol=0, atol=(2e-3 if prec == 'bf16' else 2e-4) * (step + 1), err_msg='%s step %d' % (tag, step))
             for n, o, k in index:
                 a, b = g0[o:o + k], g1[o:o + k]
                 tol = (1e-2 if prec == 'bf16' else 5e-4) * (step + 1)   # order of the fp32 atomics (+ bf16 roundings they flip); grows per step
