@@ -106,6 +106,19 @@ __global__ void ce_vec_kernel(const float* __restrict__ logits, long ld, const i
     const long rc = live ? r : rows - 1;
     const float* lr = logits + rc * ld;
     const int t = tgt[rc];
+    // rows whose target is ignore_index (the padded note slots: more than half of the pitch rows) contribute nothing forward and a zero
+    // row backward: their logits are never read.  (t is uniform over the half-wave that owns the row; the shuffles stay inside it.)
+    if (!live || t == ignore) {
+      if (BWD && live) {
+        float* dr = dlogits + r * ldd;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const int j = sub + 32 * k;
+          if (j < nch) *reinterpret_cast<float4*>(dr + 4 * j) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      continue;
+    }
     float4 v[2]; float m = -INFINITY;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
@@ -344,8 +357,8 @@ extern "C" int ptv_ce_fwd(const float* logits, long ld, const int* targets, long
   if (!logits || !targets || !nll_sum || rows <= 0 || C <= 0 || C > 256) return PTV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (C <= 16) hipLaunchKernelGGL((ce_small_kernel<false>), dim3(grid_rows(rows, 256, 2048)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nll_sum, nullptr, nullptr, 0L);
-  else if (ce_vec_ok(logits, ld, C)) hipLaunchKernelGGL((ce_vec_kernel<false>), dim3(grid_rows(rows, 8, 16384)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nll_sum, nullptr, nullptr, 0L);
-  else hipLaunchKernelGGL((ce_wave_kernel<false>), dim3(grid_rows(rows, 4, 16384)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nll_sum, nullptr, nullptr, 0L);
+  else if (ce_vec_ok(logits, ld, C)) hipLaunchKernelGGL((ce_vec_kernel<false>), dim3(grid_rows(rows, 8, 2048)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nll_sum, nullptr, nullptr, 0L);   // (one atomicAdd on nll_sum per block: 16384 blocks spent 210 us queueing on that one address, 2048: 51 us)
+  else hipLaunchKernelGGL((ce_wave_kernel<false>), dim3(grid_rows(rows, 4, 2048)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nll_sum, nullptr, nullptr, 0L);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
