@@ -128,7 +128,7 @@ __global__ void colsum_kernel(float* out, const void* __restrict__ A, long lda, 
 __global__ void embed_fwd_kernel(const long* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
                                  float* __restrict__ emb, int B, int E) {
   extern __shared__ __attribute__((aligned(16))) float wt[];     // [135][E] transposed weight
-  for (int i = threadIdx.x; i < 135 * E; i += blockDim.x) { int e = i % E, p = i / E; wt[i] = W[e * 135 + p]; }
+  for (int i = threadIdx.x; i < 135 * E; i += blockDim.x) { int e = i / 135, p = i % 135; wt[p * E + e] = W[i]; }     // (coalesced reads; the transposing side is the LDS)
   __syncthreads();
   const long notes = (long)B * 512;
   if ((E & 3) == 0 && blockDim.x >= E / 4) {
@@ -137,19 +137,34 @@ __global__ void embed_fwd_kernel(const long* __restrict__ x, const float* __rest
     const int e = (threadIdx.x % tpn) * 4, sub = threadIdx.x / tpn;
     if (sub >= per) return;
     const float4 bv = *reinterpret_cast<const float4*>(bias + e);
-    for (long i = (long)blockIdx.x * per + sub; i < notes; i += (long)gridDim.x * per) {
-      const int b = (int)(i % B); const long q = i / B; const int t = (int)(q % 32), n = (int)(q / 32);
-      const long* xr = x + (((long)b * 32 + t) * 16 + n) * 6;
-      const int p = (int)xr[0];
-      float4 v = bv;
-      if (p < 130) { const float4 w = *reinterpret_cast<const float4*>(wt + p * E + e); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+    // four notes per thread and trip: their index rows (6 x int64 each, one cache line apart from every neighbour) are requested
+    // together -- with one note per trip the loop was a chain of exposed load latencies (8 notes in flight per block)
+    const long stride = (long)gridDim.x * per;
+    for (long i0 = (long)blockIdx.x * per + sub; i0 < notes; i0 += 4 * stride) {
+      long xi[4][6];
 #pragma unroll
-      for (int d = 0; d < 5; d++) {
-        const float f = (float)xr[1 + d];
-        const float4 w = *reinterpret_cast<const float4*>(wt + (130 + d) * E + e);
-        v.x += w.x * f; v.y += w.y * f; v.z += w.z * f; v.w += w.w * f;
+      for (int u = 0; u < 4; u++) {
+        const long i = min(i0 + u * stride, notes - 1);
+        const int b = (int)(i % B); const long q = i / B; const int t = (int)(q % 32), n = (int)(q / 32);
+        const long* xr = x + (((long)b * 32 + t) * 16 + n) * 6;
+#pragma unroll
+        for (int d = 0; d < 6; d++) xi[u][d] = xr[d];
       }
-      *reinterpret_cast<float4*>(emb + i * E + e) = v;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const long i = i0 + u * stride;
+        if (i >= notes) break;
+        const int p = (int)xi[u][0];
+        float4 v = bv;
+        if (p < 130) { const float4 w = *reinterpret_cast<const float4*>(wt + p * E + e); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+#pragma unroll
+        for (int d = 0; d < 5; d++) {
+          const float f = (float)xi[u][1 + d];
+          const float4 w = *reinterpret_cast<const float4*>(wt + (130 + d) * E + e);
+          v.x += w.x * f; v.y += w.y * f; v.z += w.z * f; v.w += w.w * f;
+        }
+        *reinterpret_cast<float4*>(emb + i * E + e) = v;
+      }
     }
     return;
   }
@@ -300,7 +315,7 @@ extern "C" int ptv_colsum(float* out, const void* A, long lda, long rows, int N,
 extern "C" int ptv_embed_fwd(const long* x, const float* W, const float* bias, float* emb, int* lengths, int B, int E, void* stream) {
   if (!x || !W || !bias || !emb || B <= 0 || E <= 0 || E > 256) return PTV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for((long)B * 512, 8, 1024)), dim3(256), 135 * E * sizeof(float), s, x, W, bias, emb, B, E);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for((long)B * 512, 8, 512)), dim3(256), 135 * E * sizeof(float), s, x, W, bias, emb, B, E);   // (two 69-KB blocks per CU: one round)
   if (lengths) hipLaunchKernelGGL(lengths_kernel, dim3(cdiv((long)B * 32, 256)), dim3(256), 0, s, x, lengths, B);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
