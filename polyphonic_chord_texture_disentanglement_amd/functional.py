@@ -456,6 +456,7 @@ def _bgrad_hh(b_hh, dgh2, gb_ih):
 
 
 WGRAD_FUSE_BIAS = os.environ.get('PTV_WGRAD_BIAS', '1') != '0'
+DP_INPLACE = os.environ.get('PTV_DP_INPLACE', '1') != '0'        # decoder backward accumulates into the loss node's dpitch buffer (no 134-MB copy)
 # the backward passes over work whose result is exactly zero: note steps / tiles at which no gradient arrives (the loss ignores the
 # padded note slots), panel steps beyond the longest packed note sequence.  Decided on the gradients / lengths themselves, so the
 # results do not change; PTV_ZERO_SKIP=0 runs everything dense (bench.py reports that figure next to the headline)
@@ -1127,11 +1128,17 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
         wgrad_bias(dy, x, G[name] if sub is None else G[name][:, sub], G[bname] if bname is not None else None, prec, k_top, R)
 
     ddur = (ddur.contiguous() if ddur is not None else _zeros(M, 5, 2, dev=dev)).view(M, 10)
-    dP = _empty(M, _pad8(NP), dev=dev)[:, :NP]               # row-padded like the logits
-    if dpitch is not None:
-        copy2d(dP, _rows2d(dpitch))
+    if (DP_INPLACE and dpitch is not None and dpitch.dtype == F32 and _row_dense(dpitch) and dpitch.stride(-2) == _pad8(NP)
+            and dpitch.numel() == M * NP and not dpitch.requires_grad):
+        # the loss node hands the logits' gradient over in the logits' own row-padded layout: it becomes the accumulator of the head
+        # chain as it is (it has no other consumer; a `retain_grad()` on the logits would see the accumulated values -- PTV_DP_INPLACE=0)
+        dP = _rows2d(dpitch)
     else:
-        copy2d(dP, _zeros(1, NP, dev=dev), lds=0)
+        dP = _empty(M, _pad8(NP), dev=dev)[:, :NP]           # row-padded like the logits
+        if dpitch is not None:
+            copy2d(dP, _rows2d(dpitch))
+        else:
+            copy2d(dP, _zeros(1, NP, dev=dev), lds=0)
 
     # the loss ignores the padded note slots (the late note steps of every row): find the last note step that received any gradient
     # (on the gradients themselves) -- the head products below stop there, as the BPTT does on its own
