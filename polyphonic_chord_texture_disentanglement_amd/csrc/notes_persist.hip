@@ -350,22 +350,26 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowG
   const long r0 = (long)blockIdx.x * NRP;
   const long RH = R * H, R3H = 3 * RH;
   __bf16* sc = a.scratch + (long)blockIdx.x * 2 * (NCH * NRP * 8);
-  for (int i = tid; i < NRP * H; i += 256) dhz[i] = 0.f;
   long grow[4]; bool ok[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) { ok[i] = r0 + i * 16 + erow < R; grow[i] = min(r0 + i * 16 + erow, R - 1); }
   int pmax = a.T;
   if constexpr (EMB) {
     if (a.lengths) {                                                     // given iff the forward skipped: must match it
-      int* misc = reinterpret_cast<int*>(dhz + NRP * H);
+      // (the scratch word is the first word of dhz, zeroed afterwards: the kernel's LDS is exactly 64*H*4 bytes -- at H = 128 two of
+      // these workgroups plus one 96-KB persistent-GRU workgroup fill the CU's 160 KB to the byte, 16 bytes more and they exclude
+      // each other: the note-summary BPTT could not run under the encoders' BPTT chains)
+      int* misc = reinterpret_cast<int*>(dhz);
       if (tid == 0) misc[0] = 0;
       __syncthreads();
       if (tid < NRP && r0 + tid < R) atomicMax(misc, a.lengths[r0 + tid]);
       __syncthreads();
       pmax = min(misc[0], a.T);
       if (a.top_step && tid == 0 && pmax > 0) atomicMax(a.top_step, pmax - 1);   // last TIME index with a live row in any panel
+      __syncthreads();
     }
   }
+  for (int i = tid; i < NRP * H; i += 256) dhz[i] = 0.f;
   __syncthreads();
   bool first_active = true;                                               // no later step has handed a dgh over yet
   int s_top = a.T - 1;
@@ -534,7 +538,7 @@ static int launch_fwd(const RowGruFwdArgs& a, hipStream_t s) {
 }
 template <int H, bool EMB>
 static int launch_bwd(const RowGruBwdArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)NRP * H * sizeof(float) + 16;
+  const size_t lds = (size_t)NRP * H * sizeof(float);
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(row_gru_bwd_kernel<H, EMB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PTV_ERR_LAUNCH;

@@ -10,6 +10,7 @@ Reference: /root/reference/ptvae.py  (RnnEncoder :11-29, RnnDecoder :32-87, Text
 PtvaeEncoder :125-215, PtvaeDecoder :218-575).
 """
 import math
+import os
 import random
 
 import torch
@@ -18,6 +19,9 @@ from torch import nn
 from . import functional as F_
 from . import functional_free as FF_
 from ._lib import prec_code
+
+# stream slot of the ground-truth note summaries (functional.Side; autograd replays their BPTT on the same stream): -1 = the caller's
+SUMMARY_SLOT = int(os.environ.get('PTV_SUMMARY_SLOT', '5'))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -291,9 +295,12 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
         # schedule from its third batch on: the summaries are then dead values with zero gradient, ptvae.py:476-478)
         self._summary = None
         if self.summaries_needed:
-            side = F_.Side(5)
-            xs = side(lambda: self._summarize(emb, lengths), emb, lengths)
-            self._summary = (emb, xs, side)
+            if SUMMARY_SLOT < 0:                             # on the caller's stream (idle while the encoders run)
+                self._summary = (emb, self._summarize(emb, lengths), None)
+            else:
+                side = F_.Side(SUMMARY_SLOT)
+                xs = side(lambda: self._summarize(emb, lengths), emb, lengths)
+                self._summary = (emb, xs, side)
         return emb.permute(2, 1, 0, 3), lengths.view(32, x.size(0)).t()
 
     def _summarize(self, emb, len32):
@@ -337,7 +344,8 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
         self._summary = None
         if cached is not None and cached[0].data_ptr() == emb.data_ptr() and cached[0].shape == emb.shape:
             xs = cached[1]
-            cached[2].join()
+            if cached[2] is not None:
+                cached[2].join()
         elif any(coins[1]):
             xs = self._summarize(emb, len32)
         else:
