@@ -209,6 +209,18 @@ __global__ void multihot_kernel(const long* __restrict__ x, float* __restrict__ 
   }
 }
 
+// the same rows as bf16 (0, 1 and 2 are exact): half the bytes for the bf16-precision weight-gradient product
+__global__ void multihot_bf16_kernel(const long* __restrict__ x, __bf16* __restrict__ out, long ld, int B) {
+  const long notes = (long)B * 512;
+  for (long i = (long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); i < notes; i += (long)gridDim.x * (blockDim.x / 64)) {
+    const int b = (int)(i % B); const long q = i / B; const int t = (int)(q % 32), n = (int)(q / 32);
+    const long* xr = x + (((long)b * 32 + t) * 16 + n) * 6;
+    const int p = (int)xr[0];
+    __bf16* o = out + i * ld;
+    for (int c = threadIdx.x & 63; c < 136; c += 64) o[c] = (__bf16)(c < 130 ? (c == p ? 1.f : 0.f) : (c < 135 ? (float)xr[1 + c - 130] : 0.f));
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // reparameterisation + KL (train_utils.py:33-34,45-49):  z = mu + std*eps ; kl = mean(-log std + (std^2+mu^2)/2 - 1/2)
 // ---------------------------------------------------------------------------------------------
@@ -325,6 +337,14 @@ extern "C" int ptv_multihot(const long* x, float* out, long ld, int B, void* str
   if (!x || !out || B <= 0 || ld < 135) return PTV_ERR_ARG;
   long nb = ((long)B * 512 + 3) / 4; if (nb > 8192) nb = 8192;
   hipLaunchKernelGGL(multihot_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, out, ld, B);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_multihot_bf16(const long* x, void* out, long ld, int B, void* stream) {
+  if (!x || !out || B <= 0 || ld < 136) return PTV_ERR_ARG;
+  long nb = ((long)B * 512 + 3) / 4; if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(multihot_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)out, ld, B);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

@@ -358,7 +358,14 @@ class Side:
         else:
             key = (self.main.cuda_stream, self.main.device.index, slot)
         if key not in _CHILD_STREAMS:
-            _CHILD_STREAMS[key] = torch.cuda.Stream(device=self.main.device)
+            if pool > 0:
+                # all pool streams at once, in a FIXED order: which hardware queue a stream lands on follows creation order, and
+                # creating them lazily in first-use order made the step time depend on which slot happened to be used first (0.4 ms)
+                order = [1, 2, 0, 3] if pool == 4 else list(range(pool))
+                for k in order:
+                    _CHILD_STREAMS.setdefault(('pool', self.main.device.index, k), torch.cuda.Stream(device=self.main.device))
+            else:
+                _CHILD_STREAMS[key] = torch.cuda.Stream(device=self.main.device)
         self.s = _CHILD_STREAMS[key]
         self.keep = []
         self.used = False
@@ -456,6 +463,7 @@ def _bgrad_hh(b_hh, dgh2, gb_ih):
 
 
 WGRAD_FUSE_BIAS = os.environ.get('PTV_WGRAD_BIAS', '1') != '0'
+EMBED_MH_FWD = os.environ.get('PTV_EMBED_MH_FWD', '1') != '0'    # multi-hot operand of the note_embedding gradient built during the forward
 DP_INPLACE = os.environ.get('PTV_DP_INPLACE', '1') != '0'        # decoder backward accumulates into the loss node's dpitch buffer (no 134-MB copy)
 # the backward passes over work whose result is exactly zero: note steps / tiles at which no gradient arrives (the loss ignores the
 # padded note slots), panel steps beyond the longest packed note sequence.  Decided on the gradients / lengths themselves, so the
@@ -583,6 +591,19 @@ class EmbedFn(torch.autograd.Function):
         call('ptv_embed_fwd', ptr(x), ptr(w), ptr(b), ptr(emb), ptr(lengths), B, E, stream_ptr())
         ctx.save_for_backward(x, w, b)
         ctx.mark_non_differentiable(lengths)
+        # The weight gradient is dy^T . multihot(x), and multihot(x) depends on the input only: in bf16 precision it is built NOW, on a
+        # sibling stream under the encoders (bf16: 0 / 1 / 2 are exact), instead of at the very end of the backward pass, where nothing
+        # is left to hide it behind
+        ctx.mh = ctx.mh_side = None
+        if (EMBED_MH_FWD and prec == 1 and E % 8 == 0 and OVERLAP and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+                and not torch.cuda.is_current_stream_capturing()):
+            def build():
+                mh = _empty(B * 512, 136, dev=w.device, dtype=BF16)
+                call('ptv_multihot_bf16', ptr(x), ptr(mh), 136, B, stream_ptr())
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                return mh, ev
+            ctx.mh, ctx.mh_side = Side(7)(build, x)           # (pool stream 3: idle in the forward; streams 0 / 2 delayed the encoders)            # (mh_side: the event the backward waits for -- not the whole stream)
         return emb, lengths
 
     @staticmethod
@@ -590,6 +611,11 @@ class EmbedFn(torch.autograd.Function):
         x, w, b = ctx.saved_tensors
         B, E = x.shape[0], w.shape[0]
         demb2 = demb.contiguous().view(B * 512, E)
+        if ctx.mh is not None:
+            torch.cuda.current_stream().wait_event(ctx.mh_side)
+            mh, ctx.mh, ctx.mh_side = ctx.mh, None, None
+            dw, db = wgrad_bias(demb2, mh[:, :135], _gbuf(w), _gbuf(b), ctx.prec)      # bias gradient inside the same pass over dy
+            return None, dw, db, None
         mh = _empty(B * 512, 136, dev=w.device)
         call('ptv_multihot', ptr(x), ptr(mh), 136, B, stream_ptr())
         dw = gemm(demb2, mh[:, :135], _gbuf(w), ta=True, tb=True, acc=True, prec=ctx.prec)
