@@ -422,6 +422,9 @@ int ptv_transpose_cast_bf16_batched(const float* flat, void* flat_t, const long*
 int ptv_grad_sumsq(const float* g, long n, float* sumsq, void* stream);
 int ptv_clip_adam_step(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float gscale, float clip,
                        float lr, float beta1, float beta2, float eps, int step, void* stream);
+/* the same step that also writes the bf16 operand copy p16[i] = bf16(p[i]) of the updated parameters (p16 may be NULL) */
+int ptv_clip_adam_step_shadow(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float gscale, float clip,
+                              float lr, float beta1, float beta2, float eps, int step, void* p16, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Weight-gradient product (csrc/wgrad.hip): C[M,N] (fp32, row stride ldc) (+)= alpha * sum_k A[k*lda + m] * B[k*ldb + n], i.e.

@@ -96,7 +96,7 @@ __global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restr
 
 __global__ void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
                                  const float* __restrict__ sumsq, float gscale, float clip, float lr, float b1, float b2, float eps,
-                                 float bc1, float bc2_sqrt) {
+                                 float bc1, float bc2_sqrt, __bf16* __restrict__ p16) {
   // grads are first scaled by gscale (1/world_size after a sum all-reduce); sumsq is of the UNSCALED buffer
   const float norm = sqrtf(sumsq[0]) * gscale;
   float coef = clip > 0.f ? clip / (norm + 1e-6f) : 1.f;
@@ -107,7 +107,9 @@ __global__ void clip_adam_kernel(float* __restrict__ p, const float* __restrict_
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi; v[i] = vi;
-    p[i] -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    const float pn = p[i] - step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    p[i] = pn;
+    if (p16) p16[i] = (__bf16)pn;               // the bf16 operand copy of the parameters, refreshed in the same pass (else: a 109-MB cast next step)
   }
 }
 
@@ -248,15 +250,20 @@ extern "C" int ptv_grad_sumsq(const float* g, long n, float* sumsq, void* stream
   return PTV_OK;
 }
 
-extern "C" int ptv_clip_adam_step(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float gscale, float clip,
-                                  float lr, float beta1, float beta2, float eps, int step, void* stream) {
+extern "C" int ptv_clip_adam_step_shadow(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float gscale, float clip,
+                                         float lr, float beta1, float beta2, float eps, int step, void* p16, void* stream) {
   if (!p || !g || !m || !v || !sumsq || n <= 0 || step < 1) return PTV_ERR_ARG;
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   long nb = (n + 255) / 256; if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(clip_adam_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, gscale, clip, lr, beta1, beta2, eps,
-                     (float)bc1, (float)sqrt(bc2));
+                     (float)bc1, (float)sqrt(bc2), (__bf16*)p16);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
+}
+
+extern "C" int ptv_clip_adam_step(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float gscale, float clip,
+                                  float lr, float beta1, float beta2, float eps, int step, void* stream) {
+  return ptv_clip_adam_step_shadow(p, g, m, v, n, sumsq, gscale, clip, lr, beta1, beta2, eps, step, nullptr, stream);
 }
 
 extern "C" int ptv_note_token(const float* pitch, long ld_pitch, const int* dur_idx, long dur_stride, const float* W, const float* bias, int E,

@@ -10,6 +10,7 @@ Parameters are re-pointed to views of the flat parameter buffer (state_dict keys
 unchanged).  Gradients: `GradArena` hands the backward kernels zero-initialised views of the flat
 gradient buffer, so `.grad` of every parameter already lives in the bucket when backward ends.
 """
+import os
 import weakref
 
 import torch
@@ -17,6 +18,7 @@ import torch
 from ._lib import call, ptr, stream_ptr
 
 _ARENA_OF = {}          # id(param) -> GradArena
+ADAM_SHADOW = os.environ.get('PTV_ADAM_SHADOW', '1') != '0'      # the Adam kernel also writes the bf16 operand copy of the parameters
 _SHADOW_OF = {}         # param data_ptr -> (FusedClipAdam, offset, numel): bf16 copies of the flat parameter buffer
 
 
@@ -164,6 +166,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         self.step_count = 0
         self._dirty = 0
         self._shadow_stamp = None
+        self._plain_stamp = None        # stamp at which flat_p16 (the untransposed bf16 copy) was last written
         self.grad_scale = 1.0           # set to 1/world_size when the bucket holds a SUM over ranks
         self.refresh_shadow()
 
@@ -181,7 +184,9 @@ class FusedClipAdam(torch.optim.Optimizer):
     def refresh_shadow(self):
         self._shadow_stamp = self._stamp()
         st = stream_ptr()
-        call('ptv_cast_bf16', ptr(self.flat_p), ptr(self.flat_p16), self.arena.total, st)
+        if self._plain_stamp != self._shadow_stamp:          # (after an optimiser step the Adam kernel has written flat_p16 already)
+            call('ptv_cast_bf16', ptr(self.flat_p), ptr(self.flat_p16), self.arena.total, st)
+            self._plain_stamp = self._shadow_stamp
         if self._mats:                                           # transposed copies of the matrices: one launch
             if self._tdesc is None:
                 d, t = [], 0
@@ -241,9 +246,13 @@ class FusedClipAdam(torch.optim.Optimizer):
         F_.mark('opt:start')
         st = stream_ptr()
         call('ptv_grad_sumsq', ptr(a.flat), a.total, ptr(self.sumsq), st)
-        call('ptv_clip_adam_step', ptr(self.flat_p), ptr(a.flat), ptr(self.exp_avg), ptr(self.exp_avg_sq), a.total,
+        # the kernel also writes the bf16 operand copy of the updated parameters (one more 55-MB stream in a 760-MB pass) -- the next
+        # forward then only re-transposes the matrices instead of re-reading all 109 MB first
+        call('ptv_clip_adam_step_shadow', ptr(self.flat_p), ptr(a.flat), ptr(self.exp_avg), ptr(self.exp_avg_sq), a.total,
              ptr(self.sumsq), float(self.grad_scale), float(clip if clip is not None else 0.0), float(g['lr']),
-             float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), self.step_count, st)
+             float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), self.step_count, ptr(self.flat_p16) if ADAM_SHADOW else None, st)
+        if ADAM_SHADOW:
+            self._plain_stamp = self._stamp()
 
     def step(self, closure=None):
         assert closure is None
