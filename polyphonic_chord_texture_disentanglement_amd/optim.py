@@ -18,6 +18,7 @@ import torch
 from ._lib import call, ptr, stream_ptr
 
 _ARENA_OF = {}          # id(param) -> GradArena
+SHADOW_T_ASYNC = os.environ.get('PTV_SHADOW_T_ASYNC', '1') != '0'  # transposed bf16 shadows refreshed on a sibling stream (read by the backward only)
 ADAM_SHADOW = os.environ.get('PTV_ADAM_SHADOW', '1') != '0'      # the Adam kernel also writes the bf16 operand copy of the parameters
 _SHADOW_OF = {}         # param data_ptr -> (FusedClipAdam, offset, numel): bf16 copies of the flat parameter buffer
 
@@ -97,6 +98,8 @@ def weight_shadow_t(p):
     if off not in opt._mat_offsets:
         return None
     opt.refresh_shadow_if_stale()
+    if opt._t_event is not None:
+        torch.cuda.current_stream().wait_event(opt._t_event)
     return opt.flat_pT16[off:off + p.numel()].view(p.shape[1], p.shape[0])
 
 
@@ -166,6 +169,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         self.step_count = 0
         self._dirty = 0
         self._shadow_stamp = None
+        self._t_event = None            # recorded after the last transposed-shadow refresh when that ran on a sibling stream
         self._plain_stamp = None        # stamp at which flat_p16 (the untransposed bf16 copy) was last written
         self.grad_scale = 1.0           # set to 1/world_size when the bucket holds a SUM over ranks
         self.refresh_shadow()
@@ -194,8 +198,20 @@ class FusedClipAdam(torch.optim.Optimizer):
                     d += [o, p.shape[0], p.shape[1], t]
                     t += ((p.shape[0] + 31) // 32) * ((p.shape[1] + 31) // 32)
                 self._tdesc = (torch.tensor(d, dtype=torch.int64, device=self.flat_p.device), t)
-            call('ptv_transpose_cast_bf16_batched', ptr(self.flat_p), ptr(self.flat_pT16), ptr(self._tdesc[0]), len(self._mats),
-                 self._tdesc[1], st)
+            def transposes():
+                call('ptv_transpose_cast_bf16_batched', ptr(self.flat_p), ptr(self.flat_pT16), ptr(self._tdesc[0]), len(self._mats),
+                     self._tdesc[1], stream_ptr())
+            from . import functional as F_
+            self._t_event = None
+            if SHADOW_T_ASYNC and F_.OVERLAP and not torch.cuda.is_current_stream_capturing():
+                # only the backward pass reads the transposed copies (dX products, BPTT): refresh them on a sibling stream, off the
+                # head of the step; weight_shadow_t() makes its caller's stream wait for the event
+                side = F_.Side(7)
+                side(transposes)
+                self._t_event = torch.cuda.Event()
+                self._t_event.record(side.s)
+            else:
+                transposes()
         for p, buf in self._row_padded.values():
             buf[:, :p.shape[1]].copy_(p.data)
 
