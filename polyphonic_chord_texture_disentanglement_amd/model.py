@@ -61,17 +61,18 @@ class DisentangleVAE(PytorchModel):
         F_.mark('run:start')
         refresh_weight_shadows()                         # bf16 operand copies of the flat parameter buffer (if any)
         F_.mark('run:shadows')
+        # the two encoders are independent of each other and of the embedding: sibling HIP streams
+        # (autograd replays each branch's backward on the stream its forward ran on).  They fork FIRST: a sibling stream waits for
+        # what its parent has queued so far, and the embedding (queued on the parent next) is not their input
+        s_chd, s_rhy = F_.Side(1), F_.Side(2)
+        dist_chd = s_chd(lambda: self.chd_encoder(c), c)
+        dist_rhy = s_rhy(lambda: self.rhy_encoder(pr_mat), pr_mat)
         self.decoder.summaries_needed = tfr1 > 0             # with tfr1 = 0 no time step is fed a ground-truth note summary
         try:
             embedded_x, lengths = self.decoder.emb_x(x)
         finally:
             self.decoder.summaries_needed = True
-        # the two encoders are independent of each other and of the embedding: sibling HIP streams
-        # (autograd replays each branch's backward on the stream its forward ran on)
         F_.mark('run:emb_x')
-        s_chd, s_rhy = F_.Side(1), F_.Side(2)
-        dist_chd = s_chd(lambda: self.chd_encoder(c), c)
-        dist_rhy = s_rhy(lambda: self.rhy_encoder(pr_mat), pr_mat)
         s_chd.join()
         s_rhy.join()
         F_.mark('run:encoders')
