@@ -1208,15 +1208,17 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     w_dh, w_p = W['dur_hid_linear.weight'], W['pitch_out_linear.weight']
     # gradient reaching the notes-GRU states: only ever an addend of the BPTT epilogue -> activation dtype
     dNSUM = _empty(M, Hn, dev=dev, dtype=_act_dtype(prec, Hn))
-    gemm_dx(dHD0, w_dh, slice(0, Hn), out=dNSUM, prec=prec, m_top=top_h, m_unit=R)                   # [M, Hn]
-    gemm_dx(dHD0, w_dh, slice(Hn, None), out=dP, acc=True, prec=prec, m_top=top_h, m_unit=R)
-    gemm_dx(dP, w_p, out=dNSUM, acc=True, prec=prec, m_top=top_h, m_unit=R)
+    gemm_dx(dHD0, w_dh, slice(Hn, None), out=dP, acc=True, prec=prec, m_top=top_h, m_unit=R)         # dP complete
 
     def head_wgrads():
         wgrad_b('dur_hid_linear.weight', 'dur_hid_linear.bias', dHD0, NSUM_op, slice(0, Hn), top_h)
         wgrad_b('dur_hid_linear.weight', None, dHD0, st['pitch'], slice(Hn, None), top_h)
         wgrad_b('pitch_out_linear.weight', 'pitch_out_linear.bias', dP, NSUM_op, None, top_h)
+    # (forked as soon as its operands exist: a sibling stream waits for everything its parent has QUEUED, so the products the chain
+    # queues next would be a false dependency)
     side(head_wgrads, dHD0, dP)
+    gemm_dx(dHD0, w_dh, slice(0, Hn), out=dNSUM, prec=prec, m_top=top_h, m_unit=R)                   # [M, Hn]
+    gemm_dx(dP, w_p, out=dNSUM, acc=True, prec=prec, m_top=top_h, m_unit=R)
 
     mark('dec_bwd:head_dx')
     # ---- notes GRU (15 steps, batch 32*B) ----
@@ -1235,12 +1237,15 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
         dgi_n, dgh_n, dHN0 = gru_bwd(prec, HN, st['gates_n'], w_hh_n, dh_ext=dNSUM.view(15, R, Hn))
     mark('dec_bwd:notes_bptt')
     dGC = sum_steps(dgi_n, t_top=top_step)                                    # [R, 3Hn]
-    dtok = _empty(16, R, E, dev=dev)
-    dtok[15].zero_()
-    gemm_dx(dgi_n.view(M, 3 * Hn), w_ih_n, slice(Ht, None), out=dtok[:15].view(M, E), prec=prec, m_top=top_step, m_unit=R)
-    dNS = gemm_dx(dGC, w_ih_n, slice(0, Ht), prec=prec)                       # [R, Ht]
-    w_tn = W['dec_time_to_notes_hid.weight']
-    gemm_dx(dHN0, w_tn, out=dNS, acc=True, prec=prec)
+
+    def notes_dx():
+        dtok = _empty(16, R, E, dev=dev)
+        dtok[15].zero_()
+        gemm_dx(dgi_n.view(M, 3 * Hn), w_ih_n, slice(Ht, None), out=dtok[:15].view(M, E), prec=prec, m_top=top_step, m_unit=R)
+        dNS = gemm_dx(dGC, w_ih_n, slice(0, Ht), prec=prec)                   # [R, Ht]
+        w_tn = W['dec_time_to_notes_hid.weight']
+        gemm_dx(dHN0, w_tn, out=dNS, acc=True, prec=prec)
+        return dtok, dNS
 
     def notes_wgrads():
         # bias_hh gradient = column sums of dgh (its r and z thirds equal dgi's), taken inside the W_hh products
@@ -1264,7 +1269,8 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
             wgrad('dec_notes_gru.weight_ih_l0', dgi_n.view(M, 3 * Hn), tok_op, slice(Ht, None))
         wgrad('dec_time_to_notes_hid.weight', dHN0, NSf_op)
         bgrad('dec_time_to_notes_hid.bias', dHN0)
-    side(notes_wgrads, dgi_n, dgh_n, dGC, dHN0, dNSUM)
+    side(notes_wgrads, dgi_n, dgh_n, dGC, dHN0, dNSUM)                       # forked before the chain's dX products are queued
+    dtok, dNS = notes_dx()
 
     mark('dec_bwd:notes_dx')
     # ---- time GRU (32 steps, batch B) ----
