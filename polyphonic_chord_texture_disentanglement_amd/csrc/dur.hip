@@ -22,6 +22,18 @@ namespace ptv {
 constexpr int DH = 64;                 // hidden size
 constexpr int DLD = DH + 16;           // LDS row stride (bf16 elements): 160 B = 32 mod 64, conflict-free b128 fragment reads
 
+__device__ __forceinline__ void st8f(void* p, long i, bool bf, const float (&v)[8]) {
+  if (bf) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = (__bf16)v[e];
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p) + i) = o;
+  } else {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + i) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
 struct DurArgs {
   const float* h0; long ld_h0;         // [M, 64] initial state (dur_hid_linear output)
   const float* w_hh; const float* b_hh;   // [192, 64], [192]
@@ -36,13 +48,19 @@ struct DurArgs {
   long M;
 };
 
-__global__ __launch_bounds__(256) void dur_gru_fwd_kernel(DurArgs a) {
+__global__ __launch_bounds__(256, 2) void dur_gru_fwd_kernel(DurArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 Ws[3 * DH * DLD];       // W_hh as bf16
   __shared__ __attribute__((aligned(16))) __bf16 Hs[4][16 * DLD];        // per-wave state tile
   __shared__ float tabs[3][3 * DH];                                     // gate tables: sos, idx0, idx1
   __shared__ float bh[3 * DH];
   __shared__ float wo[2 * DH + 2];
-  for (int i = threadIdx.x; i < 3 * DH * DH; i += 256) Ws[(i / DH) * DLD + (i % DH)] = (__bf16)a.w_hh[i];
+  // W_hh rows are STORED in the order the MFMA tiles consume them (pair-interleaved units, below): the fragment reads stay on 16
+  // consecutive LDS rows (conflict-free); unit u of gate g -> tile f = 2*(u/32) + (u%8)/4, operand row 4*((u%32)/8) + u%4
+  for (int i = threadIdx.x; i < 3 * DH * DH; i += 256) {
+    const int r = i / DH, g = r / DH, u = r % DH;
+    const int lr = g * DH + (2 * (u >> 5) + ((u & 7) >> 2)) * 16 + 4 * ((u & 31) >> 3) + (u & 3);
+    Ws[lr * DLD + (i % DH)] = (__bf16)a.w_hh[i];
+  }
   for (int i = threadIdx.x; i < 3 * DH; i += 256) {
     tabs[0][i] = a.tab0[i]; tabs[1][i] = a.tab[i]; tabs[2][i] = a.tab[3 * DH + i];
     bh[i] = a.b_hh[i];
@@ -52,7 +70,10 @@ __global__ __launch_bounds__(256) void dur_gru_fwd_kernel(DurArgs a) {
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rl = lane & 15, ug = (lane >> 4) * 4;                        // row in tile, first unit of each fragment
+  const int rl = lane & 15, q8 = (lane >> 4) * 8;                        // row in tile; first of this lane's 8 units in every tile PAIR
+  // Pair-interleaved units: MFMA tile f of a gate is fed the W_hh rows of units 32*(f/2) + 8*(i/4) + 4*(f%2) + i%4 (i = row of the
+  // operand tile), so the accumulators h[2m][0..3], h[2m+1][0..3] of a lane are the 8 CONSECUTIVE units 32m + q8 .. +7 of its
+  // row: states and gate planes leave in 16-byte pieces (4 lanes = 64 contiguous bytes of a row) instead of 8-byte ones
   __bf16* hs = Hs[wave];
   const long tiles = (a.M + 15) / 16;
   for (long tile = (long)blockIdx.x * 4 + wave; tile < tiles; tile += (long)gridDim.x * 4) {
@@ -62,7 +83,7 @@ __global__ __launch_bounds__(256) void dur_gru_fwd_kernel(DurArgs a) {
 #pragma unroll
     for (int f = 0; f < 4; f++) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) v = *reinterpret_cast<const float4*>(a.h0 + row * a.ld_h0 + f * 16 + ug);
+      if (ok) v = *reinterpret_cast<const float4*>(a.h0 + row * a.ld_h0 + 32 * (f >> 1) + q8 + 4 * (f & 1));
       h[f][0] = v.x; h[f][1] = v.y; h[f][2] = v.z; h[f][3] = v.w;
     }
     int tok = 0;                                                        // table row: 0 = sos, 1 + idx afterwards
@@ -70,9 +91,11 @@ __global__ __launch_bounds__(256) void dur_gru_fwd_kernel(DurArgs a) {
     for (int d = 0; d < 5; d++) {
       // state -> LDS (bf16) as the MFMA operand
 #pragma unroll
-      for (int f = 0; f < 4; f++) {
-        bf16x4 p; p[0] = (__bf16)h[f][0]; p[1] = (__bf16)h[f][1]; p[2] = (__bf16)h[f][2]; p[3] = (__bf16)h[f][3];
-        *reinterpret_cast<bf16x4*>(hs + rl * DLD + f * 16 + ug) = p;
+      for (int m = 0; m < 2; m++) {
+        bf16x8 p;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { p[e] = (__bf16)h[2 * m][e]; p[4 + e] = (__bf16)h[2 * m + 1][e]; }
+        *reinterpret_cast<bf16x8*>(hs + rl * DLD + 32 * m + q8) = p;
       }
       __builtin_amdgcn_wave_barrier();
       f32x4 acc[12];
@@ -91,29 +114,34 @@ __global__ __launch_bounds__(256) void dur_gru_fwd_kernel(DurArgs a) {
       const float* gi = tabs[tok];
       float o0 = 0.f, o1 = 0.f;
 #pragma unroll
-      for (int f = 0; f < 4; f++) {
-        float r[4], z[4], n[4], hn[4];
+      for (int m = 0; m < 2; m++) {
+        float r[8], z[8], n[8], hn[8], hv[8];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const int j = f * 16 + ug + e;
-          r[e] = sigmoidf_(gi[j] + acc[f][e] + bh[j]);
-          z[e] = sigmoidf_(gi[DH + j] + acc[4 + f][e] + bh[DH + j]);
-          hn[e] = acc[8 + f][e] + bh[2 * DH + j];
-          n[e] = tanhf_(gi[2 * DH + j] + r[e] * hn[e]);
-          h[f][e] = (1.0f - z[e]) * n[e] + z[e] * h[f][e];
+        for (int e8 = 0; e8 < 8; e8++) {
+          const int f = 2 * m + (e8 >> 2), e = e8 & 3;
+          const int j = 32 * m + q8 + e8;
+          r[e8] = sigmoidf_(gi[j] + acc[f][e] + bh[j]);
+          z[e8] = sigmoidf_(gi[DH + j] + acc[4 + f][e] + bh[DH + j]);
+          hn[e8] = acc[8 + f][e] + bh[2 * DH + j];
+          n[e8] = tanhf_(gi[2 * DH + j] + r[e8] * hn[e8]);
+          h[f][e] = (1.0f - z[e8]) * n[e8] + z[e8] * h[f][e];
+          hv[e8] = h[f][e];
           o0 += wo[j] * h[f][e];
           o1 += wo[DH + j] * h[f][e];
         }
         if (ok) {
-          const long off = row * DH + f * 16 + ug;
-          if (a.hall) *reinterpret_cast<float4*>(a.hall + d * a.plane_h + off) = make_float4(h[f][0], h[f][1], h[f][2], h[f][3]);
-          if (a.hall16) st4f(a.hall16, d * a.plane_h + off, true, h[f][0], h[f][1], h[f][2], h[f][3]);
+          const long off = row * DH + 32 * m + q8;
+          if (a.hall) {
+            *reinterpret_cast<float4*>(a.hall + d * a.plane_h + off) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+            *reinterpret_cast<float4*>(a.hall + d * a.plane_h + off + 4) = make_float4(hv[4], hv[5], hv[6], hv[7]);
+          }
+          if (a.hall16) st8f(a.hall16, d * a.plane_h + off, true, hv);
           if (a.gates) {
             const long g0 = d * a.step_g + off;
-            st4f(a.gates, g0 + 0 * a.plane_g, a.gates_bf16, r[0], r[1], r[2], r[3]);
-            st4f(a.gates, g0 + 1 * a.plane_g, a.gates_bf16, z[0], z[1], z[2], z[3]);
-            st4f(a.gates, g0 + 2 * a.plane_g, a.gates_bf16, n[0], n[1], n[2], n[3]);
-            st4f(a.gates, g0 + 3 * a.plane_g, a.gates_bf16, hn[0], hn[1], hn[2], hn[3]);
+            st8f(a.gates, g0 + 0 * a.plane_g, a.gates_bf16, r);
+            st8f(a.gates, g0 + 1 * a.plane_g, a.gates_bf16, z);
+            st8f(a.gates, g0 + 2 * a.plane_g, a.gates_bf16, n);
+            st8f(a.gates, g0 + 3 * a.plane_g, a.gates_bf16, hn);
           }
         }
       }
@@ -144,7 +172,7 @@ extern "C" int ptv_dur_gru_fwd(int H, long M, const float* h0, long ld_h0, const
                                void* stream) {
   if (H != DH) return PTV_ERR_ARG;                 // callers fall back to the per-step kernels for other sizes
   if (M <= 0 || !h0 || !w_hh || !b_hh || !tab0 || !tab || !w_out || !b_out || !dur_out || !idx) return PTV_ERR_ARG;
-  if ((ld_h0 & 3) || (plane_h & 3) || (plane_g & 3) || (step_g & 3)) return PTV_ERR_ARG;
+  if ((ld_h0 & 3) || (plane_h & 7) || (plane_g & 7) || (step_g & 7)) return PTV_ERR_ARG;      // 16-byte bf16 pieces
   DurArgs a{h0, ld_h0, w_hh, b_hh, tab0, tab, w_out, b_out, hall, plane_h, (__bf16*)hall16, gates, plane_g, step_g, gates_bf16,
             dur_out, ld_out, idx, idx_stride, force, force_stride, M};
   long nb = ((M + 15) / 16 + 3) / 4; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1;
