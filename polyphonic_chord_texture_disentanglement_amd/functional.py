@@ -175,8 +175,17 @@ def _iarr(vs):
     return (ctypes.c_int * len(vs))(*[int(v) for v in vs])
 
 
-def persist_supported(NC, M, H):
+# Persistent launches take turns (two spinning grids must never be half-resident together), so a short sequence on a sibling stream
+# makes the long one next to it wait (the chord encoder's 8 steps in front of the texture encoder's 32).  Sending sequences shorter
+# than PTV_PERSIST_MIN_T to the per-step kernels instead (they co-reside with a persistent grid) measured SLOWER: 9.68 vs 9.57 ms
+# with 16 -- the step kernels cost more than the turn they free.  0 = every supported sequence runs persistent.
+PERSIST_MIN_T = int(os.environ.get('PTV_PERSIST_MIN_T', '0'))
+
+
+def persist_supported(NC, M, H, T=None):
     if str(PERSIST).lower() in ('0', 'false', 'off') or torch.cuda.is_current_stream_capturing():
+        return False
+    if T is not None and T < PERSIST_MIN_T:
         return False
     key = (NC, M, H, torch.cuda.current_device())
     if key not in _PERSIST_OK:
@@ -263,7 +272,7 @@ def gru_persist_bwd(M, H, T, chains):
 def _persist_fwd_ok(prec, M, H, T, gi, gi2, gates, gi_idx, hall16, w16, NC=1):
     return (prec == 1 and T >= 2 and hall16 is not None and gi.dtype == BF16 and (gi2 is None or gi2.dtype == BF16)
             and (gates is None or gates.dtype == BF16) and gi_idx is None and w16 is not None and w16.dtype == BF16
-            and persist_supported(NC, M, H))
+            and persist_supported(NC, M, H, T))
 
 
 def gru_fwd(prec, gi, gi_step, gi_ld, w_hh, b_hh, hall, gates, *, gi2=None, gi2_step=0, gi2_ld=0, lengths=None,
@@ -301,7 +310,7 @@ def gru_bwd(prec, hall, gates, w_hh, *, dh_ext=None, dh_last=None, lr=None, reve
     lra = (ptr(lr[0]), lr[1], lr[2], lr[3], ptr(lr[4])) if lr is not None else (None, 0, 0, 0, None)
     if dt == BF16:
         wt = _WT(w_hh, prec)                  # W_hh^T [H,3H] bf16: K-contiguous weight tiles for the BPTT products
-        if (wt is not None and lr is None and T >= 2 and gates.dtype == BF16 and persist_supported(1, M, H)
+        if (wt is not None and lr is None and T >= 2 and gates.dtype == BF16 and persist_supported(1, M, H, T)
                 and (dh_ext is None or dh_ext.stride(2) == 1)):
             gru_persist_bwd(M, H, T, [dict(hall=hall, gates=gates, wt16=wt, dh_ext=dh_ext, dh_last=dh_last, dgi=dgi, dgh=dgh,
                                            dh0=dh0, reverse=reverse)])
@@ -649,7 +658,7 @@ def _bigru_forward(prec, x3, lengths, w):
 
     adt = _act_dtype(prec, H)
     w16 = [_W(w[1], prec), _W(w[5], prec)]
-    if prec == 1 and T >= 2 and adt == BF16 and w16[0].dtype == BF16 and w16[1].dtype == BF16 and persist_supported(2, M, H):
+    if prec == 1 and T >= 2 and adt == BF16 and w16[0].dtype == BF16 and w16[1].dtype == BF16 and persist_supported(2, M, H, T):
         # both directions in ONE persistent launch (csrc/gru_persist.hip): per step the two chains share the exchange latency
         chains, saved = [], []
         for d in range(2):
@@ -727,7 +736,7 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
     wts = [_WT(w[1], prec), _WT(w[5], prec)]
     adt = _act_dtype(prec, H)
     if (T >= 2 and adt == BF16 and wts[0] is not None and wts[1] is not None and saved[0][1].dtype == BF16
-            and saved[0][2] is not None and persist_supported(2, M, H)):
+            and saved[0][2] is not None and persist_supported(2, M, H, T)):
         # BPTT of both directions in ONE persistent launch, then the weight-gradient products of the two on sibling streams
         chains = []
         for d in range(2):
