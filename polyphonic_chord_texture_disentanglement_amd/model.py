@@ -64,6 +64,8 @@ class DisentangleVAE(PytorchModel):
         # the two encoders are independent of each other and of the embedding: sibling HIP streams
         # (autograd replays each branch's backward on the stream its forward ran on).  They fork FIRST: a sibling stream waits for
         # what its parent has queued so far, and the embedding (queued on the parent next) is not their input
+        from .ptvae import _require_cuda
+        _require_cuda(x, 'DisentangleVAE.run')               # (fails loudly off-GPU before any stream is touched)
         s_chd, s_rhy = F_.Side(1), F_.Side(2)
         dist_chd = s_chd(lambda: self.chd_encoder(c), c)
         dist_rhy = s_rhy(lambda: self.rhy_encoder(pr_mat), pr_mat)
