@@ -66,6 +66,9 @@ int ptv_gemm(int prec, int transA, int transB, int M, int N, int K,
 int ptv_gemm_mtop(int prec, int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                   void* C, long ldc, const float* bias, float alpha, int accumulate, int act, int splitk, int dtypes,
                   const int* m_top, long m_unit, void* stream);
+/* plain products enqueued after this call raise their wave priority (p != 0) or run at the default one (0): host-side marker for the
+ * launches of a latency chain that share the GPU with weight-gradient products on sibling streams.  Process-wide, read at enqueue time. */
+int ptv_gemm_priority(int p);
 
 /* ------------------------------------------------------------------------------------------------
  * GRU recurrence over T steps for M independent rows (torch.nn.GRU cell semantics; replaces the

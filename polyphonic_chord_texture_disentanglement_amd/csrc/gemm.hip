@@ -140,6 +140,7 @@ struct EpiPlain {
 
 template <class CT, int BM, int BN, int WGM, int WGN, bool KA, bool KB, bool SA, bool SB>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_plain_kernel(GemmArgs g, EpiPlain::Params ep) {
+  if (g.prio) __builtin_amdgcn_s_setprio(3);
   gemm_body<CT, BM, BN, WGM, WGN, 1, KA, KB, EpiPlain, SA, SB, (BM * BN <= 64 * 64 ? 2 : PLAIN_PF_BIG(KA, KB, SA, SB))>(g, ep);
 }
 
@@ -210,6 +211,11 @@ static int gemm_dispatch(int transA, int transB, GemmArgs g, EpiPlain::Params ep
 
 }  // namespace ptv
 
+namespace ptv { int g_gemm_prio = 0; }
+// products launched from now on raise their wave priority (p != 0) / run at the default priority (0): the host marks the launches of
+// its latency chain so that they win instruction issue against the weight-gradient products on sibling streams
+extern "C" int ptv_gemm_priority(int p) { ptv::g_gemm_prio = p ? 1 : 0; return PTV_OK; }
+
 extern "C" int ptv_gemm_mtop(int prec, int transA, int transB, int M, int N, int K,
                              const void* A, long lda, const void* B, long ldb,
                              void* C, long ldc, const float* bias, float alpha,
@@ -224,7 +230,7 @@ extern "C" int ptv_gemm_mtop(int prec, int transA, int transB, int M, int N, int
   if (use_wgrad && prec == PTV_PREC_BF16 && transA && transB && !sc && !bias && act == 0 && K >= 512 && splitk <= 0)
     return ptv_wgrad(M, N, K, A, lda, B, ldb, reinterpret_cast<float*>(C), ldc, alpha, accumulate, dtypes & 3, 0, nullptr, nullptr, 0, 0, stream);
   if (m_top && (transA || m_unit <= 0)) return PTV_ERR_ARG;            // a row limit on A: A must be row-per-sample
-  ptv::GemmArgs g{A, lda, B, ldb, M, N, K, K, 0, m_top, m_unit};
+  ptv::GemmArgs g{A, lda, B, ldb, M, N, K, K, 0, m_top, m_unit, ptv::g_gemm_prio};
   ptv::EpiPlain::Params ep{C, ldc, bias, alpha, accumulate, act, 0, sc ? 1 : 0};
   hipStream_t s = (hipStream_t)stream;
   int rc;

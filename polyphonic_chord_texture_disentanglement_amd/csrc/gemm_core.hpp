@@ -71,6 +71,7 @@ struct GemmArgs {
   int k_per_split;            // K range handled by one blockIdx.z (multiple of BK); == K when no split
   long gate_stride;           // NG==3: B row of gate g, unit j is g*gate_stride + j   (N = #units)
   const int* m_top; long m_unit;   // rows of A from (*m_top + 1) * m_unit on are known to be zero (or null): those tiles skip the K loop
+  int prio;                   // plain products: raise the wave priority (a launch of the latency chain next to sibling-stream products)
 };
 
 // LDS image of a tile: [row][128 bytes], the eight 16-byte chunks of row r XOR-permuted by

@@ -76,6 +76,10 @@ def _ld(t):
     return t.stride(0)
 
 
+CHAIN_PRIO = os.environ.get('PTV_CHAIN_PRIO', '1') != '0'
+_SIDE_DEPTH = [0, 0]          # [nesting depth of Side calls on this thread, priority state last sent to the library]
+
+
 def gemm(a, b, out=None, *, ta=False, tb=False, bias=None, alpha=1.0, acc=False, act=0, prec=0, splitk=0, out_dtype=F32, m_top=None,
          m_unit=0):
     """out[M,N] = act(alpha * op(a) . op(b)^T + bias) (+ out);  see ptv_gemm in include/ptvae_hip.h.
@@ -88,6 +92,11 @@ def gemm(a, b, out=None, *, ta=False, tb=False, bias=None, alpha=1.0, acc=False,
         out = _empty(M, N, dev=a.device, dtype=out_dtype)
     assert tuple(out.shape) == (M, N), (out.shape, M, N)
     dt = _bf(a) | (_bf(b) << 1) | (_bf(out) << 2)
+    if CHAIN_PRIO:                                          # products of a latency chain (not inside a Side call) raise their wave priority
+        want = 1 if _SIDE_DEPTH[0] == 0 else 0
+        if want != _SIDE_DEPTH[1]:
+            lib().ptv_gemm_priority(want)
+            _SIDE_DEPTH[1] = want
     if m_top is not None:                                   # rows of a from (m_top + 1) * m_unit on are zero (device int)
         call('ptv_gemm_mtop', prec, int(ta), int(tb), M, N, K, ptr(a), _ld(a), ptr(b), _ld(b), ptr(out), _ld(out),
              ptr(bias), float(alpha), int(acc), int(act), int(-1 if _bf(out) else splitk), dt, ptr(m_top), int(m_unit), stream_ptr())
@@ -385,8 +394,12 @@ class Side:
         self.s.wait_stream(self.main)
         self.used = True
         self.keep.extend(keep)
-        with torch.cuda.stream(self.s):
-            r = fn()
+        _SIDE_DEPTH[0] += 1
+        try:
+            with torch.cuda.stream(self.s):
+                r = fn()
+        finally:
+            _SIDE_DEPTH[0] -= 1
         # What fn returns was allocated under the sibling stream and will be read on the parent after join(): tell the caching
         # allocator, or the block goes back to the SIBLING's pool the moment Python drops the tensor and the next allocation there
         # may overwrite it while the parent's reader is still queued (seen as partly wrong dx / gradients once in ~10 runs).
