@@ -49,6 +49,7 @@ struct DurArgs {
 };
 
 __global__ __launch_bounds__(256, 2) void dur_gru_fwd_kernel(DurArgs a) {
+  __builtin_amdgcn_s_setprio(3);                                         // a launch of the latency chain: wins instruction issue against sibling-stream products
   __shared__ __attribute__((aligned(16))) __bf16 Ws[3 * DH * DLD];       // W_hh as bf16
   __shared__ __attribute__((aligned(16))) __bf16 Hs[4][16 * DLD];        // per-wave state tile
   __shared__ float tabs[3][3 * DH];                                     // gate tables: sos, idx0, idx1

@@ -65,6 +65,7 @@ __device__ __forceinline__ void dur_load(const DurBwdArgs& a, int d, long row, i
 
 template <bool HB>
 __global__ __launch_bounds__(256, 1) void dur_gru_bwd_kernel(DurBwdArgs a) {
+  __builtin_amdgcn_s_setprio(3);                                         // a launch of the latency chain: wins instruction issue against sibling-stream products
   __shared__ __attribute__((aligned(16))) __bf16 WT[BH * WLD];          // W_hh^T: WT[unit][gate-unit]
   __shared__ __attribute__((aligned(16))) __bf16 DG[4][16 * WLD];       // per-wave dgh rows [16][192]
   __shared__ __attribute__((aligned(16))) __bf16 AT[256 * KLD];         // [dr dz dnr dn][block row]

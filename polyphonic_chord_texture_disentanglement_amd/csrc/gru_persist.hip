@@ -183,6 +183,7 @@ struct PMma {
 // =============================================================================================
 template <int FM, int KU, int LP>
 __global__ __launch_bounds__(NTHREADS, 2) void pgru_fwd_kernel(PGruFwdArgs a) {
+  __builtin_amdgcn_s_setprio(3);                                         // a launch of the latency chain: wins instruction issue against sibling-stream products
   __shared__ __attribute__((aligned(16))) char smem[PLDS];
   __bf16* Ws = reinterpret_cast<__bf16*>(smem);
   int grp, ug;
@@ -288,6 +289,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void pgru_fwd_kernel(PGruFwdArgs a) {
 // =============================================================================================
 template <int FM, int KU, int LP>
 __global__ __launch_bounds__(NTHREADS, 2) void pgru_bwd_kernel(PGruBwdArgs a) {
+  __builtin_amdgcn_s_setprio(3);                                         // a launch of the latency chain: wins instruction issue against sibling-stream products
   __shared__ __attribute__((aligned(16))) char smem[PLDS];
   __bf16* Ws = reinterpret_cast<__bf16*>(smem);
   int grp, ug;

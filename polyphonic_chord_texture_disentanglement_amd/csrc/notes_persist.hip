@@ -97,6 +97,7 @@ struct RowGruFwdArgs {
 // dec_notes_emb_gru (b_ih, optional length mask, optional reversed time, final state)
 template <int H, bool EMB>
 __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
+  __builtin_amdgcn_s_setprio(3);                                         // a launch of the latency chain: wins instruction issue against sibling-stream products
   constexpr int KBH = H / 32, NUT = H / 16, NPASS = H / 128, UTW = NUT / 4, HLD = H + 16, KT = KBH + 4;
   extern __shared__ __attribute__((aligned(16))) char nsm[];
   __bf16* h16 = reinterpret_cast<__bf16*>(nsm);                          // [2][64][HLD]
@@ -340,6 +341,7 @@ struct RowGruBwdArgs {
 // dec_notes_emb_gru (gradient arrives at the final state only: dh_last; optional reversed time)
 template <int H, bool EMB>
 __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowGruBwdArgs a) {
+  __builtin_amdgcn_s_setprio(3);                                         // a launch of the latency chain: wins instruction issue against sibling-stream products
   constexpr int KT = 3 * H / 32, NTW = H / 64, NCH = 3 * H / 8;           // k-blocks, output tiles per wave, scratch chunks
   extern __shared__ __attribute__((aligned(16))) char nsm[];
   float* dhz = reinterpret_cast<float*>(nsm);                            // [64][H] fp32: dh (x) z carried to the earlier step
