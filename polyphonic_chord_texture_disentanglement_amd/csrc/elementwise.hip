@@ -49,6 +49,7 @@ __global__ void sum_steps_kernel(float* out, const void* in, long n, int T, long
 template <bool BF>
 __global__ void sum_steps_vec_kernel(float* __restrict__ out, const void* __restrict__ in, long nvec, int T, long stride, int accumulate,
                                      const int* __restrict__ t_top) {
+  __builtin_amdgcn_s_setprio(3);                                         // always part of a latency chain
   constexpr int E = BF ? 8 : 4;
   if (t_top) T = min(T, *t_top + 1);
   for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
@@ -127,6 +128,7 @@ __global__ void colsum_kernel(float* out, const void* __restrict__ A, long lda, 
 // ---------------------------------------------------------------------------------------------
 __global__ void embed_fwd_kernel(const long* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
                                  float* __restrict__ emb, int B, int E) {
+  __builtin_amdgcn_s_setprio(3);                                         // always part of a latency chain
   extern __shared__ __attribute__((aligned(16))) float wt[];     // [135][E] transposed weight
   for (int i = threadIdx.x; i < 135 * E; i += blockDim.x) { int e = i / 135, p = i % 135; wt[p * E + e] = W[i]; }     // (coalesced reads; the transposing side is the LDS)
   __syncthreads();
@@ -279,6 +281,7 @@ extern "C" int ptv_transpose01(float* dst, const float* src, int D0, int D1, int
 
 // top = max(top, (last row block that holds a non-zero) / unit): which trailing part of a gradient matrix is all zero
 __global__ void last_nonzero_kernel(const float* __restrict__ x, long rows, int cols, long ld, long unit, int* __restrict__ top) {
+  __builtin_amdgcn_s_setprio(3);                                         // always part of a latency chain
   const long chunks = (rows + 63) / 64;
   for (long c = chunks - 1 - blockIdx.x; c >= 0; c -= gridDim.x) {
     const long r1 = min(rows, (c + 1) * 64);

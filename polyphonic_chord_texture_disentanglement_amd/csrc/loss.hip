@@ -95,6 +95,7 @@ __global__ void ce_wave_kernel(const float* __restrict__ logits, long ld, const 
 template <bool BWD>
 __global__ void ce_vec_kernel(const float* __restrict__ logits, long ld, const int* __restrict__ tgt, long rows, int C, int ignore,
                               float* __restrict__ nll_sum, const float* __restrict__ gscale, float* __restrict__ dlogits, long ldd) {
+  __builtin_amdgcn_s_setprio(3);                                         // always part of a latency chain
   __shared__ float red[8];
   const int lane = threadIdx.x & 63, sub = lane & 31, hw = threadIdx.x >> 5;       // 8 half-waves per block
   float local = 0.f;

@@ -23,6 +23,8 @@
 
 namespace ptv {
 
+extern int g_gemm_prio;            // gemm.hip: set by ptv_gemm_priority
+
 typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
 typedef short ws16x4 __attribute__((ext_vector_type(4)));
 typedef short ws16x8 __attribute__((ext_vector_type(8)));
@@ -43,6 +45,7 @@ struct WgArgs {
   float* csum;                   // [M] += column sums of A (the bias gradient that goes with this weight gradient), or null
   const int* k_top; long k_unit;  // rows from (*k_top + 1) * k_unit on are known to be zero in A (written by the kernel that produced A), or null
   int k_rev;                     // > 0: A is stored in REVERSED unit order (k_rev units): the zero part is the rows BEFORE (k_rev - *k_top - 1) * k_unit
+  int prio;                      // the launch belongs to a latency chain (ptv_gemm_priority): raised wave priority
 };
 
 // one thread's share of a stage of one operand: 2 chunks of 8 columns (chunk c: row c / 16, columns (c % 16) * 8).
@@ -147,6 +150,7 @@ __device__ __forceinline__ wbf16x8 tr_frag(const __bf16* st, int col) {
 // GUARD = false: rows 16-byte aligned, K a multiple of 32 and not reaching the operands' last row (see ptv_wgrad)
 template <bool AF32, bool BF32, bool GUARD, int NSET>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
+  if (g.prio) __builtin_amdgcn_s_setprio(3);
   __shared__ __attribute__((aligned(16))) __bf16 As[2 * WSTAGE];
   __shared__ __attribute__((aligned(16))) __bf16 Bs[2 * WSTAGE];
   const int tiles = g.tiles_m * g.tiles_n;
@@ -315,7 +319,7 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
   const int nset = (af || bf) ? 2 : (nset_env == 4 ? 4 : 2);       // 4 register sets only fit with bf16 sources
   auto launch = [&](bool guard, int k0, int kn, int want_slabs) {
     WgArgs g{static_cast<const char*>(A) + (long)k0 * lda * (af ? 4 : 2), lda, static_cast<const char*>(B) + (long)k0 * ldb * (bf ? 4 : 2), ldb,
-             C, ldc, M, N, kn, 0, cdiv(M, WBM), cdiv(N, WBN), 1, 0, alpha, colsum_a, k0 == 0 ? k_top : nullptr, k_unit, k_rev};
+             C, ldc, M, N, kn, 0, cdiv(M, WBM), cdiv(N, WBN), 1, 0, alpha, colsum_a, k0 == 0 ? k_top : nullptr, k_unit, k_rev, g_gemm_prio};
     const int tiles = g.tiles_m * g.tiles_n;
     // slab count (measured optima of scripts/bench_wgrad.py sweep on MI355X).  Every slab pays M*N atomics, and a grid that is
     // just over one block per CU leaves a tail, so: about one block per CU (never more) for the skinny, HBM-bound products;

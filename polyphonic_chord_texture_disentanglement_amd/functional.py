@@ -80,6 +80,15 @@ CHAIN_PRIO = os.environ.get('PTV_CHAIN_PRIO', '1') != '0'
 _SIDE_DEPTH = [0, 0]          # [nesting depth of Side calls on this thread, priority state last sent to the library]
 
 
+def _chain_prio():
+    """products of a latency chain (not inside a Side call) raise their wave priority: tell the library when the state changes"""
+    if CHAIN_PRIO:
+        want = 1 if _SIDE_DEPTH[0] == 0 else 0
+        if want != _SIDE_DEPTH[1]:
+            lib().ptv_gemm_priority(want)
+            _SIDE_DEPTH[1] = want
+
+
 def gemm(a, b, out=None, *, ta=False, tb=False, bias=None, alpha=1.0, acc=False, act=0, prec=0, splitk=0, out_dtype=F32, m_top=None,
          m_unit=0):
     """out[M,N] = act(alpha * op(a) . op(b)^T + bias) (+ out);  see ptv_gemm in include/ptvae_hip.h.
@@ -92,11 +101,7 @@ def gemm(a, b, out=None, *, ta=False, tb=False, bias=None, alpha=1.0, acc=False,
         out = _empty(M, N, dev=a.device, dtype=out_dtype)
     assert tuple(out.shape) == (M, N), (out.shape, M, N)
     dt = _bf(a) | (_bf(b) << 1) | (_bf(out) << 2)
-    if CHAIN_PRIO:                                          # products of a latency chain (not inside a Side call) raise their wave priority
-        want = 1 if _SIDE_DEPTH[0] == 0 else 0
-        if want != _SIDE_DEPTH[1]:
-            lib().ptv_gemm_priority(want)
-            _SIDE_DEPTH[1] = want
+    _chain_prio()
     if m_top is not None:                                   # rows of a from (m_top + 1) * m_unit on are zero (device int)
         call('ptv_gemm_mtop', prec, int(ta), int(tb), M, N, K, ptr(a), _ld(a), ptr(b), _ld(b), ptr(out), _ld(out),
              ptr(bias), float(alpha), int(acc), int(act), int(-1 if _bf(out) else splitk), dt, ptr(m_top), int(m_unit), stream_ptr())
@@ -511,6 +516,7 @@ def wgrad_bias(dy, x, gw, gb, prec, k_top=None, k_unit=0, k_rev=0):
     K = dy.shape[0]
     if (WGRAD_FUSE_BIAS and prec == 1 and K >= 512 and gw.dtype == F32 and dy.stride(1) == 1 and x.stride(1) == 1
             and os.environ.get('PTV_WGRAD', '1') != '0'):
+        _chain_prio()
         call('ptv_wgrad', dy.shape[1], x.shape[1], K, ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(gw), _ld(gw), 1.0, 1,
              _bf(dy) | (_bf(x) << 1), 0, ptr(gb), ptr(k_top), int(k_unit) if k_top is not None else 0, int(k_rev), stream_ptr())
     else:
