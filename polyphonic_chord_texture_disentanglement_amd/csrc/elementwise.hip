@@ -280,13 +280,23 @@ extern "C" int ptv_transpose01(float* dst, const float* src, int D0, int D1, int
 }
 
 // top = max(top, (last row block that holds a non-zero) / unit): which trailing part of a gradient matrix is all zero
-__global__ void last_nonzero_kernel(const float* __restrict__ x, long rows, int cols, long ld, long unit, int* __restrict__ top) {
+__global__ void last_nonzero_kernel(const float* __restrict__ x, long rows, int cols, long ld, long unit, int* __restrict__ top, int vec) {
   __builtin_amdgcn_s_setprio(3);                                         // always part of a latency chain
   const long chunks = (rows + 63) / 64;
   for (long c = chunks - 1 - blockIdx.x; c >= 0; c -= gridDim.x) {
     const long r1 = min(rows, (c + 1) * 64);
     if ((r1 - 1) / unit <= *reinterpret_cast<volatile int*>(top)) break;           // the chunk's LAST row is already covered by a report
     bool nz = false;
+    if (vec) {
+      // the chunk's rows with their padding are one contiguous span: 16-byte loads.  (Padding that is not zero can only make `top` too
+      // large, i.e. less is skipped -- never wrong.)
+      const float4* p4 = reinterpret_cast<const float4*>(x + c * 64 * ld);
+      const long n4 = (r1 - c * 64) * ld / 4;
+      for (long i = threadIdx.x; i < n4; i += blockDim.x) {
+        const float4 v = p4[i];
+        nz |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+      }
+    } else
     for (long i = c * 64 * (long)cols + threadIdx.x; i < r1 * cols; i += blockDim.x) {
       const long r = i / cols; const int q = (int)(i % cols);
       nz |= x[r * ld + q] != 0.f;
@@ -370,7 +380,9 @@ extern "C" int ptv_reparam_kl_bwd(const float* mu, const float* sd, const float*
 extern "C" int ptv_last_nonzero_unit(const float* x, long rows, int cols, long ld, long unit, int* top, void* stream) {
   if (!x || !top || rows <= 0 || cols <= 0 || ld < cols || unit <= 0) return PTV_ERR_ARG;
   long nb = (rows + 63) / 64; if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(last_nonzero_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, unit, top);
+  // whole 64-row chunks as 16-byte loads when every chunk is a 16-byte aligned span whose length is a multiple of 4 floats
+  const int vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && ((64 * ld) % 4) == 0 && ((rows * ld) % 4) == 0 && (ld % 4 == 0 || ld == cols);
+  hipLaunchKernelGGL(last_nonzero_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, unit, top, vec);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
