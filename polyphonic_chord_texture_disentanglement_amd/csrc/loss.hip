@@ -342,7 +342,7 @@ using namespace ptv;
 
 extern "C" int ptv_pianotree_targets(const long* x, int B, int step_major, int* pitch_t, int* dur_t, int* counts, void* stream) {
   if (!x || !pitch_t || !dur_t || !counts || B <= 0) return PTV_ERR_ARG;
-  hipLaunchKernelGGL(pianotree_targets_kernel, dim3(grid_rows((long)B * 480, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, B, step_major, pitch_t, dur_t, counts);
+  hipLaunchKernelGGL(pianotree_targets_kernel, dim3(grid_rows((long)B * 480, 256, 256)), dim3(256), 0, (hipStream_t)stream, x, B, step_major, pitch_t, dur_t, counts);   // (two atomics on the count words per block)
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

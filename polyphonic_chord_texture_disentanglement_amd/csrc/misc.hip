@@ -244,7 +244,7 @@ extern "C" int ptv_grad_sumsq(const float* g, long n, float* sumsq, void* stream
   if (reinterpret_cast<uintptr_t>(g) & 15) return PTV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(sumsq, 0, sizeof(float), s) != hipSuccess) return PTV_ERR_LAUNCH;
-  long nb = (n / 4 + 255) / 256; if (nb > 2048) nb = 2048; if (nb < 1) nb = 1;
+  long nb = (n / 4 + 255) / 256; if (nb > 512) nb = 512; if (nb < 1) nb = 1;       // (one atomicAdd on *sumsq per block: keep the queue on that address short)
   hipLaunchKernelGGL(sumsq_kernel, dim3((int)nb), dim3(256), 0, s, g, n, sumsq);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
