@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault('PTV_PTR_CHECKS', '1')      # full argument checks of the ctypes binding (_lib.ptr) in the test suite
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
