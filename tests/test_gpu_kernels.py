@@ -692,3 +692,49 @@ def test_note_loop_cluster_mode_is_bit_identical_to_one_workgroup_per_panel(B):
         for n, a_, b_ in zip(names, ref, got):
             assert torch.equal(a_, b_), (S, train, n, float((a_.float() - b_.float()).abs().max()))
     assert (res[1, 1][3][:, :2, 1:, 0] != 0).any()             # the decisions are not trivially constant
+
+
+def test_chain_priority_marker_changes_nothing_but_scheduling():
+    """ptv_gemm_priority: plain and weight-gradient products enqueued with the marker set raise their wave priority (s_setprio) -- same
+    arithmetic, bit-identical results"""
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    from polyphonic_chord_texture_disentanglement_amd._lib import lib
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(2)
+    a = torch.randn(700, 520, device=dev, generator=g)
+    b = torch.randn(300, 520, device=dev, generator=g)
+    dy = (torch.randn(4096, 256, device=dev, generator=g)).to(torch.bfloat16)
+    x = (torch.randn(4096, 192, device=dev, generator=g)).to(torch.bfloat16)
+    outs = []
+    for p in (0, 1, 0):
+        lib().ptv_gemm_priority(p)
+        F_._SIDE_DEPTH[1] = p
+        old, F_.CHAIN_PRIO = F_.CHAIN_PRIO, False            # (keep the wrapper from resetting the marker)
+        try:
+            c = F_.gemm(a, b, prec=1)
+            gw = torch.zeros(256, 192, device=dev)
+            F_.wgrad_bias(dy, x, gw, None, 1)                 # one K slab would be exact; several slabs add atomically: compare loosely
+        finally:
+            F_.CHAIN_PRIO = old
+        torch.cuda.synchronize()
+        outs.append((c.clone(), gw.clone()))
+    lib().ptv_gemm_priority(0)
+    F_._SIDE_DEPTH[1] = 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], outs[2][0])
+    ref = dy.float().t() @ x.float()
+    for _, gw in outs:
+        assert (gw - ref).abs().max() <= 2e-3 * ref.abs().max()
+
+
+def test_binding_rejects_host_tensors_and_checks_arguments_in_the_test_suite():
+    """_lib.ptr: a CPU tensor is always refused (there is no CPU fallback); dtype and current-device checks run under PTV_PTR_CHECKS,
+    which tests/conftest.py switches on"""
+    from polyphonic_chord_texture_disentanglement_amd import _lib
+    assert _lib.PTR_CHECKS
+    with pytest.raises(AssertionError):
+        _lib.ptr(torch.zeros(4))
+    with pytest.raises(AssertionError):
+        _lib.ptr(torch.zeros(4, device='cuda:0', dtype=torch.float64))
+    t = torch.zeros(4, device='cuda:0')
+    assert _lib.ptr(t) == t.data_ptr() and _lib.ptr(None) is None
+    assert int(_lib.stream_ptr() or 0) == int(torch.cuda.current_stream().cuda_stream)
