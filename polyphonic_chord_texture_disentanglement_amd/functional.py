@@ -493,6 +493,12 @@ WGRAD_FUSE_BIAS = os.environ.get('PTV_WGRAD_BIAS', '1') != '0'
 EMBED_MH_FWD = os.environ.get('PTV_EMBED_MH_FWD', '1') != '0'    # multi-hot operand of the note_embedding gradient built during the forward
 # decoder backward: fork the weight-gradient work BEFORE the chain queues its next dX products (no false dependency on them)?  Measured
 # 9.43 vs 9.37 ms: the products then compete with the chain's own dX products for the CUs -- the later fork is the better schedule
+# stream slot of a bi-GRU's second direction, forward / backward.  In the backward slot 7 = pool stream 3 is also the stream of the decoder's
+# deferred weight-gradient products (Side(3)): the reversed directions of the note-summary and encoder BPTTs queue behind them.  Moving
+# them to another pool stream measured SLOWER (slot 8 / 6 / 5: 9.40 / 9.39 / 9.29 vs 9.09 ms): running everything at once costs more
+# in contention than the queueing does.
+BIGRU_SLOT = int(os.environ.get('PTV_BIGRU_SLOT', '7'))
+BIGRU_SLOT_BWD = int(os.environ.get('PTV_BIGRU_SLOT_BWD', '7'))
 FORK_EARLY = os.environ.get('PTV_FORK_EARLY', '0') != '0'
 DP_INPLACE = os.environ.get('PTV_DP_INPLACE', '1') != '0'        # decoder backward accumulates into the loss node's dpitch buffer (no 134-MB copy)
 # the backward passes over work whose result is exactly zero: note steps / tiles at which no gradient arrives (the loss ignores the
@@ -713,13 +719,13 @@ def _bigru_forward(prec, x3, lengths, w):
                  ptr(lengths) if lengths is not None else None, ptr(hall), ptr(h16), ptr(gates), out.data_ptr() + 4 * d * H, 2 * H,
                  M, T, d, stream_ptr())
             return hall, gates, h16, (lengths if ZERO_SKIP else None)      # the backward must skip the same fully masked panel steps
-        side = Side(7)
+        side = Side(BIGRU_SLOT)
         rev = side(lambda: rows(1), x3, out)
         fwd = rows(0)
         side.join()
         return out, [fwd, rev]
 
-    side = Side(7)
+    side = Side(BIGRU_SLOT)
     rev = side(lambda: direction(1), xf, out)
     fwd = direction(0)
     side.join()
@@ -754,7 +760,7 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
         dx = gemm_dx(dgi2, w_ih, prec=prec, m_top=top, m_unit=M) if need_dx else None
         return [dw_ih, dw_hh, db_ih, db_hh], dx
 
-    side = Side(7)
+    side = Side(BIGRU_SLOT_BWD)
     wts = [_WT(w[1], prec), _WT(w[5], prec)]
     adt = _act_dtype(prec, H)
     if (T >= 2 and adt == BF16 and wts[0] is not None and wts[1] is not None and saved[0][1].dtype == BF16

@@ -39,7 +39,10 @@ torch.cuda.synchronize()
 acc = {}
 N = 10
 for _ in range(N):
-    step()                                   # an untraced step in flight: the traced one is enqueued while the GPU is busy, as in steady state
+    if os.environ.get('SYNC_START') == '1':
+        torch.cuda.synchronize()             # traced step starts on an idle GPU: host and GPU columns share their origin (who waits for whom?)
+    else:
+        step()                               # an untraced step in flight: the traced one is enqueued while the GPU is busy, as in steady state
     F_.TRACE = []
     step()
     torch.cuda.synchronize()
