@@ -2,6 +2,7 @@
 
     python bench.py [--gpus N --steps K --warmup W --batch 512 --precision bf16]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+    python bench.py --gpus N          (no launcher: bench.py starts the N ranks itself, one fresh process per GPU)
 
 A step = zero_grad -> model('train', x, c, pr_mat, tfr=1, beta, weights) -> backward -> RCCL
 all-reduce (N>1) -> fused global-norm clip + Adam -> MinExponentialLR.step, on synthetic batches
@@ -221,6 +222,38 @@ def _roofline(lib, B, model, args):
     return roof
 
 
+def _launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh children of this script, one per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, as `torch.distributed.run` would), BEFORE this process makes any GPU call -- it
+    never does: the parent only waits.  Rank 0 inherits stdout (its ONE JSON line is this command's output), the other ranks'
+    stdout goes to stderr.  Returns the exit code: non-zero when any rank failed (the others are then stopped).
+    Replaces nn.DataParallel's in-process replication (reference amc_dl/torch_plus/module.py:67-68)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ.get('MASTER_PORT', str(port)), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc, live = 0, list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in live:                                   # one rank died: the others would wait for it in a collective forever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -236,6 +269,8 @@ def main():
                     help="'decode' = configs[3]: free-running inference_decode samples/s")
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(_launch_ranks(args.gpus))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -250,7 +285,18 @@ def main():
         else:
             dist.init_process_group(backend)
         local_rank = local_rank % max(ndev, 1)
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or without a launcher' % (args.gpus, world, args.gpus)
+    if os.environ.get('PTV_BENCH_LAUNCH_ONLY') == '1':
+        # launch-path check without a GPU (tests/test_dist_gloo.py): rendezvous, barrier, MAX over ranks, rank 0's one JSON line
+        import torch.distributed as dist
+        t0 = time.perf_counter()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({'launch_only': True, 'n_gpus': world, 'max_over_ranks': float(t.item()), 'steps': args.steps}), flush=True)
+        dist.destroy_process_group()
+        return
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 

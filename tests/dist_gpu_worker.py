@@ -1,4 +1,4 @@
-"""One rank of the 2-process data-parallel step used by tests/test_gpu_dist.py (started as a FRESH process before anything
+"""One rank of the 2-process data-parallel step used by tests/test_gpu_zz_dist.py (started as a FRESH process before anything
 touches the GPU; gloo carries the CUDA bucket, both ranks share cuda:0 on a 1-GPU box).  Runs the product path:
 FusedClipAdam arena -> GradSync.all_reduce_grads on arena.flat -> grad_scale = 1/world inside ptv_clip_adam_step."""
 import os
@@ -46,6 +46,8 @@ def main():
         res['early.%d' % step] = early
         sync.all_reduce_grads()
         assert opt.grad_scale == 1.0 / world
+        torch.cuda.synchronize()
+        res['flat_g.%d' % step] = (opt.arena.flat.detach() * opt.grad_scale).cpu()        # the averaged bucket clip+Adam is about to read
         opt.clip_and_step(1.0)
         res['losses.%d' % step] = [float(v) for v in sync.mean_scalars(losses)]
         res['gnorm.%d' % step] = float(opt.grad_norm())

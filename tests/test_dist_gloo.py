@@ -181,3 +181,36 @@ def test_philox_oracle_known_answers_and_sharding_invariance():
     assert not np.array_equal(whole, philox_normal(64, 30, 7, 6))
     big = philox_normal(4096, 256, 7, 0)
     assert abs(big.mean()) < 5e-3 and abs(big.std() - 1) < 5e-3
+
+
+def _run_bench(args, **env):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, **env)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + args, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    return p.returncode, [json.loads(l) for l in lines], p.stderr
+
+
+def test_bench_launches_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent starts two fresh ranks (before any GPU call), they rendezvous over
+    gloo, take the MAX over ranks and rank 0 prints the ONE line (PTV_BENCH_LAUNCH_ONLY=1 stops before the model, which needs the
+    GPU; the full step through this launcher runs in tests/test_gpu_zz_dist.py)"""
+    rc, lines, err = _run_bench(['--gpus', '2', '--steps', '1', '--warmup', '0'], PTV_DIST_BACKEND='gloo', PTV_BENCH_LAUNCH_ONLY='1')
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1 and lines[0]['n_gpus'] == 2 and lines[0]['launch_only'] is True
+    assert lines[0]['max_over_ranks'] >= 1.0            # rank 1 contributed (its value carries +rank)
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    """no GPU here: without the launch-only switch every rank dies at its first device call; the launcher must return non-zero
+    and print no result line"""
+    if torch.cuda.is_available():
+        pytest.skip('needs a box without a GPU')
+    rc, lines, err = _run_bench(['--gpus', '2', '--steps', '1', '--warmup', '0', '--no-extras', '--no-cpu-baseline'], PTV_DIST_BACKEND='gloo')
+    assert rc != 0 and lines == []

@@ -13,10 +13,14 @@ import pytest
 import torch
 
 from polyphonic_chord_texture_disentanglement_amd.synthetic import synth_batch
+from helpers import ADAM_NOISE_FRAC_OF_LR, ATOMICS_RTOL
 from test_host_surface import build_reduced
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
+LR = 1e-3
+DETERMINISTIC = os.environ.get('PTV_DETERMINISTIC', '0') == '1'
+G_TOL = 0.0 if DETERMINISTIC else ATOMICS_RTOL
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -36,7 +40,7 @@ def test_rccl_group_of_one_runs_the_overlapped_exchange(tmp_path):
     got = torch.load(out + '.rank0')
     assert got['early.0'] > 0
     m = build_reduced(DEV).to(DEV)
-    opt = FusedClipAdam(m.parameters(), lr=1e-3)
+    opt = FusedClipAdam(m.parameters(), lr=LR)
     m.use_philox(seed=7, sample_offset=0)
     random.seed(7)
     x, c, pr = (torch.from_numpy(a).to(DEV) for a in synth_batch(4, 321))
@@ -47,7 +51,7 @@ def test_rccl_group_of_one_runs_the_overlapped_exchange(tmp_path):
         opt.clip_and_step(1.0)
         np.testing.assert_allclose(got['losses.%d' % step], [float(v.detach()) for v in ls], rtol=0, atol=2e-5)
         assert abs(got['gnorm.%d' % step] - float(opt.grad_norm())) <= 2e-5 * float(opt.grad_norm())
-        assert (got['flat_p.%d' % step] - opt.flat_p.cpu()).abs().max() < 2e-5
+        assert (got['flat_p.%d' % step] - opt.flat_p.cpu()).abs().max() <= LR * ADAM_NOISE_FRAC_OF_LR * (step + 1)
 
 
 @pytest.mark.parametrize('early', ['1', '0'])
@@ -71,7 +75,7 @@ def test_two_process_arena_all_reduce_matches_mean_of_shards(tmp_path, early):
 
     # the same two steps in ONE process: per shard forward/backward, gradients averaged, one clip+Adam
     m = build_reduced(DEV).to(DEV)
-    opt = FusedClipAdam(m.parameters(), lr=1e-3)
+    opt = FusedClipAdam(m.parameters(), lr=LR)
     x, c, pr = synth_batch(world * B_local, 321)
     for step in range(2):
         flats, losses = [], []
@@ -86,15 +90,45 @@ def test_two_process_arena_all_reduce_matches_mean_of_shards(tmp_path, early):
             assert opt.arena.holds_all_grads()
             flats.append(opt.arena.flat.clone())
             losses.append([float(v) for v in ls])
-        opt.arena.flat.copy_(sum(flats) / world)
+        want_g = sum(flats) / world
+        opt.arena.flat.copy_(want_g)
         opt.grad_scale = 1.0
         opt.clip_and_step(1.0)
         want_losses = np.mean(losses, axis=0)
+        want_g, gn = want_g.cpu(), float(opt.grad_norm())
+        p_tol = LR * ADAM_NOISE_FRAC_OF_LR * (step + 1)
         for r in range(world):
-            np.testing.assert_allclose(got[r]['losses.%d' % step], want_losses, rtol=0, atol=2e-6)
-            assert abs(got[r]['gnorm.%d' % step] - float(opt.grad_norm())) < 1e-5 * max(1.0, float(opt.grad_norm()))
-            assert (got[r]['flat_p.%d' % step] - opt.flat_p.cpu()).abs().max() < 2e-6
+            np.testing.assert_allclose(got[r]['losses.%d' % step], want_losses, rtol=0, atol=2e-6 if step == 0 else 2e-5)
+            if step == 0:
+                # what the exchange itself must get right, at the run-to-run noise floor of the fp32 atomics in the weight-gradient
+                # kernels (helpers.ATOMICS_RTOL; 0 under PTV_DETERMINISTIC=1): the averaged bucket, per parameter tensor
+                for p_, o in zip(opt.arena.params, opt.arena.offsets):
+                    w = want_g[o:o + p_.numel()]
+                    d = (got[r]['flat_g.0'][o:o + p_.numel()] - w).abs().max()
+                    assert d <= G_TOL * max(float(w.abs().max()), 1e-30), (o, float(d), float(w.abs().max()))
+                assert abs(got[r]['gnorm.0'] - gn) <= max(G_TOL, 1e-9) * gn
+            else:
+                assert abs(got[r]['gnorm.%d' % step] - gn) <= 1e-3 * gn      # step 2 starts from parameters that differ by Adam-amplified noise
+            # Adam's first steps are lr * g / (|g| + eps): a reordering of 1e-10 on a gradient near eps moves the parameter by
+            # ~lr * 1e-2, so parameters are held to a fraction of lr, never to the gradients' own tolerance
+            assert (got[r]['flat_p.%d' % step] - opt.flat_p.cpu()).abs().max() <= (0.0 if DETERMINISTIC and step == 0 else p_tol)
         assert torch.equal(got[0]['flat_p.%d' % step], got[1]['flat_p.%d' % step])      # replicas stay bit-identical
+
+
+def test_bench_gpus_2_launches_itself_and_reports_configs2():
+    """`python bench.py --gpus 2` with no launcher around it: two fresh ranks (gloo carries the bucket, both on cuda:0 of a 1-GPU box)
+    run the data-parallel step end to end and rank 0 prints ONE line for configs[2]"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    env['PTV_DIST_BACKEND'] = 'gloo'
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '64',
+                        '--no-extras', '--no-cpu-baseline'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    r = lines[0]
+    assert r['n_gpus'] == 2 and r['scaling'] == 'weak' and r['config']['workload'].startswith('configs[2]')
+    assert r['config']['global_batch'] == 128 and r['value'] > 0 and np.isfinite(r['final_loss'])
 
 
 def test_philox_eps_kernel_vs_oracle_and_sharding_invariance():
