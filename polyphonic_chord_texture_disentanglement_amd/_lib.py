@@ -82,21 +82,25 @@ def prec_code(p):
 
 
 _OK_DTYPES = frozenset((torch.float32, torch.bfloat16, torch.int32, torch.int64, torch.uint8))
-# full argument checks (dtype, tensor on the CURRENT device -- kernels are enqueued on the current device's stream, a tensor of another
-# device would be a wild pointer): on in the test suite (tests/conftest.py), off by default -- ptr() runs ~3000 times per train step and
-# the checks were 2 ms of its 6.6 ms of host time.  That the tensor lives on a GPU at all is always checked (no CPU fallback).
+# Always checked (ptr() runs ~3000 times per train step, so only what costs tens of nanoseconds): the tensor lives on a GPU (no CPU
+# fallback), has one of the dtypes the library takes at all, and -- in a process that sees more than one GPU -- lives on the CURRENT
+# device (kernels are enqueued on the current device's stream: a tensor of another device would be a wild pointer).
+# PTV_PTR_CHECKS=1 (the test suite, tests/conftest.py) checks the device in every process, with messages.
 PTR_CHECKS = os.environ.get('PTV_PTR_CHECKS', '0') == '1'
+_get_device = getattr(torch._C, '_cuda_getDevice', None) or torch.cuda.current_device
+_multi_dev = None
 
 
 def ptr(t):
+    global _multi_dev
     if t is None:
         return None
-    if not t.is_cuda:
-        raise AssertionError('device tensor expected, got %s %s' % (t.device, t.dtype))
-    if PTR_CHECKS:
-        assert t.dtype in _OK_DTYPES, 'device fp32/int tensor expected, got %s %s' % (t.device, t.dtype)
-        assert t.device.index == torch.cuda.current_device(), \
-            'tensor on %s but the current device is cuda:%d (torch.cuda.set_device first)' % (t.device, torch.cuda.current_device())
+    if not t.is_cuda or t.dtype not in _OK_DTYPES:
+        raise AssertionError('device fp32/bf16/int tensor expected, got %s %s' % (t.device, t.dtype))
+    if _multi_dev is None:
+        _multi_dev = torch.cuda.device_count() > 1
+    if (_multi_dev or PTR_CHECKS) and t.device.index != _get_device():
+        raise AssertionError('tensor on %s but the current device is cuda:%d (torch.cuda.set_device first)' % (t.device, _get_device()))
     return t.data_ptr()                       # (a plain int: ctypes converts it for the declared void* parameter)
 
 

@@ -202,17 +202,34 @@ class TrainingInterface:
         self._barrier()
 
     # ---- full-state checkpoints: weights + optimiser (Adam moments, step count, lr) + LR scheduler
-    # + parameter-scheduler counters + the trainer's epoch / step counters
+    # + parameter-scheduler counters + the trainer's epoch / step counters + everything that decides the NEXT batches and noise:
+    # the model's Philox key and draw counter, python's `random` state (the teacher-forcing coins, ptvae.py:395-428), torch's
+    # device generator (the default eps source) and the generators of device-resident loaders (DeviceBatcher.gen)
+    def _loader_gens(self):
+        out = {}
+        for k in ('train_loader', 'val_loader'):
+            g = getattr(getattr(self.data_loaders, k, None), 'gen', None)
+            if isinstance(g, torch.Generator):
+                out[k] = g
+        return out
+
     def save_checkpoint(self, fn):
+        import random
         opt, sch = self.opt_scheduler.optimizer, self.opt_scheduler.scheduler
-        state = {'model': self.model.state_dict(), 'optimizer': opt.state_dict(), 'lr_scheduler': sch.state_dict(),
+        m = self.model
+        rng = {'philox': getattr(m, '_philox', None), 'draws': getattr(m, '_draws', 0), 'python_random': random.getstate(),
+               'torch_cpu': torch.get_rng_state(),
+               'torch_cuda': torch.cuda.get_rng_state(self.device) if torch.cuda.is_available() and torch.device(self.device).type == 'cuda' else None,
+               'loaders': {k: g.get_state() for k, g in self._loader_gens().items()}}
+        state = {'model': m.state_dict(), 'optimizer': opt.state_dict(), 'lr_scheduler': sch.state_dict(),
                  'opt_scheduler_step': self.opt_scheduler._step, 'param_scheduler': self.param_scheduler.state_dict(),
-                 'epoch': self.epoch, 'train_step': self.train_step, 'val_step': self.val_step}
+                 'epoch': self.epoch, 'train_step': self.train_step, 'val_step': self.val_step, 'rng': rng}
         if self.is_main:
             torch.save(state, fn)
         self._barrier()
 
     def load_checkpoint(self, fn):
+        import random
         state = torch.load(fn, map_location=self.device, weights_only=False)
         self.model.load_state_dict(state['model'])
         self.opt_scheduler.optimizer.load_state_dict(state['optimizer'])
@@ -220,6 +237,19 @@ class TrainingInterface:
         self.opt_scheduler._step = state['opt_scheduler_step']
         self.param_scheduler.load_state_dict(state['param_scheduler'])
         self.epoch, self.train_step, self.val_step = state['epoch'], state['train_step'], state['val_step']
+        self._resumed = True                                   # run() continues from these counters unless told otherwise
+        rng = state.get('rng')
+        if rng is not None:
+            if hasattr(self.model, '_philox'):
+                self.model._philox, self.model._draws = rng['philox'], rng['draws']
+            random.setstate(rng['python_random'])
+            torch.set_rng_state(rng['torch_cpu'].cpu())
+            if rng.get('torch_cuda') is not None and torch.cuda.is_available():
+                torch.cuda.set_rng_state(rng['torch_cuda'].cpu(), self.device)
+            gens = self._loader_gens()
+            for k, st in rng.get('loaders', {}).items():
+                if k in gens:
+                    gens[k].set_state(st.cpu())
 
     def epoch_report(self, start_time, end_time, train_loss, valid_loss):
         mins, secs = epoch_time(start_time, end_time)
@@ -227,10 +257,14 @@ class TrainingInterface:
                      f'\t Valid. Loss: {valid_loss:.3f}'):
             print(line, flush=True)
 
-    def run(self, start_epoch=0, start_train_step=0, start_val_step=0):
+    def run(self, start_epoch=None, start_train_step=None, start_val_step=None):
         """n_epoch x (train, eval); checkpoints '<name>_epoch.pt' every epoch, '<name>_valid.pt' on a new
-        best validation loss, '<name>_final.pt' at the end (module.py:195-213)."""
-        self.epoch, self.train_step, self.val_step = start_epoch, start_train_step, start_val_step
+        best validation loss, '<name>_final.pt' at the end (module.py:195-213).  The start_* arguments are the reference's
+        (default 0 there); None = 0 on a fresh trainer, the restored counters after load_checkpoint()."""
+        keep = getattr(self, '_resumed', False)
+        self.epoch = start_epoch if start_epoch is not None else (self.epoch if keep else 0)
+        self.train_step = start_train_step if start_train_step is not None else (self.train_step if keep else 0)
+        self.val_step = start_val_step if start_val_step is not None else (self.val_step if keep else 0)
         best = float('inf')
         for _ in range(self.n_epoch):
             tic = time.time()

@@ -283,9 +283,15 @@ extern "C" int ptv_transpose01(float* dst, const float* src, int D0, int D1, int
 __global__ void last_nonzero_kernel(const float* __restrict__ x, long rows, int cols, long ld, long unit, int* __restrict__ top, int vec) {
   __builtin_amdgcn_s_setprio(3);                                         // always part of a latency chain
   const long chunks = (rows + 63) / 64;
+  __shared__ int s_top;
   for (long c = chunks - 1 - blockIdx.x; c >= 0; c -= gridDim.x) {
     const long r1 = min(rows, (c + 1) * 64);
-    if ((r1 - 1) / unit <= *reinterpret_cast<volatile int*>(top)) break;           // the chunk's LAST row is already covered by a report
+    // other blocks raise *top concurrently: ONE thread samples it per trip so that the whole block takes the same branch (a
+    // per-thread read could send some waves out of the loop and the rest into the barrier below)
+    __syncthreads();                                                               // (the previous trip's readers of s_top are done)
+    if (threadIdx.x == 0) s_top = *reinterpret_cast<volatile int*>(top);
+    __syncthreads();
+    if ((r1 - 1) / unit <= s_top) break;                                           // the chunk's LAST row is already covered by a report
     bool nz = false;
     if (vec) {
       // the chunk's rows with their padding are one contiguous span: 16-byte loads.  (Padding that is not zero can only make `top` too

@@ -10,7 +10,16 @@ starts its all-reduce the moment its last weight-gradient product is enqueued (f
 stream that waits for the producing streams), under the rest of the backward pass; `all_reduce_grads()` then reduces what is
 left (heads, CNN, embedding, chord decoder: a few per cent) and waits for the early parts.
 xGMI is point-to-point: a ring all-reduce is bound per link, so one large early message beats many small buckets here.
-`backend='nccl'` is RCCL on ROCm; the CPU tests use gloo.  PTV_EARLY_ALLREDUCE=0: one all-reduce after the backward pass."""
+`backend='nccl'` is RCCL on ROCm; the CPU tests use gloo.  PTV_EARLY_ALLREDUCE=0: one all-reduce after the backward pass.
+
+Contract of the early exchange (checked, not assumed): a slice leaves only if this step's backward holds the ONLY contribution
+to its parameters -- each weight used once per step, one backward per zero_grad().  A second contribution to a slice that is on the
+wire raises (GradArena.take); a backward that starts with gradients already present (accumulation) never starts an early part
+(`p.grad is None` at the hook sites); zero_grad() waits for and drops early parts that no all_reduce_grads() consumed; and
+all_reduce_grads() refuses early parts that were started under another zero_grad() epoch.  Every rank must issue the same
+collectives in the same order: the hook fires from the same autograd nodes everywhere because the only data-dependent branch of
+the step -- the teacher-forcing coins -- is drawn from ONE python `random` stream that all ranks seed alike (bench.py, train.py);
+all_reduce_grads() cross-checks the ranges once per step when PTV_DP_CHECK=1."""
 import os
 import weakref
 
@@ -48,7 +57,8 @@ class GradSync:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._bucket = None
-        self._early = []                                     # [((start, end), work)] all-reduces started during the backward pass
+        self._early = []                                     # [((start, end), work, arena epoch)] all-reduces started during the backward pass
+        self.check = os.environ.get('PTV_DP_CHECK', '0') == '1'
         self._comm = None
         self.early = os.environ.get('PTV_EARLY_ALLREDUCE', '1') != '0'
         # PTV_DP_FORCE=1: run the exchange on a group of ONE rank too (tests: the RCCL / stream mechanics on a 1-GPU box)
@@ -59,6 +69,25 @@ class GradSync:
                 from . import functional as F_
                 me = weakref.ref(self)
                 F_.GRAD_READY_HOOK = lambda params, streams: (me() is not None) and me().grads_ready(params, streams)
+                optimizer.arena.in_flight = lambda p: (me() is not None) and me()._in_flight(p)
+                optimizer.arena.on_zero.append(lambda: (me() is not None) and me().drop_early())
+
+    def _in_flight(self, p):
+        a = self.optimizer.arena
+        i = a._index.get(id(p))
+        if i is None:
+            return False
+        lo, hi = a.offsets[i], a.offsets[i] + p.numel()
+        return any(lo < e[0][1] and e[0][0] < hi for e in self._early)
+
+    def drop_early(self):
+        """zero_grad(): early parts nobody consumed (a backward without all_reduce_grads(), an aborted step) must finish before
+        the bucket is cleared under them, and must not be mistaken for the next step's"""
+        early, self._early = self._early, []
+        for e in early:
+            e[1].wait()
+        if early and self._comm is not None:
+            torch.cuda.current_stream().wait_stream(self._comm)
 
     def broadcast_parameters(self, src=0):
         """replica equality by construction, not by every rank happening to seed alike: rank `src`'s weights everywhere"""
@@ -116,11 +145,11 @@ class GradSync:
             with torch.cuda.stream(self._comm):
                 for r in ranges:
                     self._early.append((r, dist.all_reduce(a.flat[r[0]:min(r[1], a.total)], op=dist.ReduceOp.SUM, group=self.group,
-                                                           async_op=True)))
+                                                           async_op=True), a.epoch))
         else:
             for r in ranges:
                 self._early.append((r, dist.all_reduce(a.flat[r[0]:min(r[1], a.total)], op=dist.ReduceOp.SUM, group=self.group,
-                                                       async_op=True)))
+                                                       async_op=True), a.epoch))
         return True
 
     def all_reduce_grads(self):
@@ -128,16 +157,32 @@ class GradSync:
             return
         early, self._early = self._early, []
         flat, scatter = self._flat_bucket()
+        if early:
+            epoch = self.optimizer.arena.epoch
+            if any(e[2] != epoch for e in early):
+                for e in early:
+                    e[1].wait()
+                raise RuntimeError('GradSync: an early all-reduce from another zero_grad() epoch is still pending')
+        if self.check:
+            # every rank must have started the same early ranges (else the collectives below pair up wrongly): compare a digest
+            sig = torch.tensor(([float(len(early))] + [float(v) for e in early for v in e[0]] + [0.0] * 32)[:33], dtype=torch.float64)
+            lo, hi = sig.clone(), sig.clone()
+            if flat.is_cuda and dist.get_backend(self.group) == 'nccl':
+                lo, hi = lo.to(flat.device), hi.to(flat.device)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+            if not torch.equal(lo.cpu(), hi.cpu()):
+                raise RuntimeError('GradSync: ranks started different early all-reduce ranges (%s here)' % [e[0] for e in early])
         if early and not scatter:
             # (every rank started the same early ranges in the same order: the hook fires from the same autograd node everywhere)
             for r in complement_ranges([e[0] for e in early], flat.numel()):
                 dist.all_reduce(flat[r[0]:r[1]], op=dist.ReduceOp.SUM, group=self.group)
-            for _, w in early:
+            for _, w, _e in early:
                 w.wait()                                 # RCCL: the current stream waits; gloo: the host does
             if flat.is_cuda and self._comm is not None:
                 torch.cuda.current_stream().wait_stream(self._comm)
         else:
-            for _, w in early:
+            for _, w, _e in early:
                 w.wait()
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         opt = self.optimizer

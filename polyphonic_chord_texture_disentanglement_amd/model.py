@@ -179,8 +179,14 @@ class DisentangleVAE(PytorchModel):
             dist_chd = HipNormal(dist_chd.mean, dist_chd.scale * scale)
             dist_rhy = HipNormal(dist_rhy.mean, dist_rhy.scale * scale)
         with torch.no_grad():
-            z_chd = self._rsample('chd', dist_chd) if sample_chd else dist_chd.mean
-            z_rhy = self._rsample('rhy', dist_rhy) if sample_txt else dist_rhy.mean
+            # the reference draws BOTH latents (get_zs_from_dists(..., True), model.py:165) and then overrides the unsampled one with
+            # its mean: the generator / draw counter advances by two draws whatever the flags say, so the sampled latent sees the
+            # same noise as in the reference under a seeded generator
+            z_chd, z_rhy = self._rsample('chd', dist_chd), self._rsample('rhy', dist_rhy)
+            if not sample_chd:
+                z_chd = dist_chd.mean
+            if not sample_txt:
+                z_rhy = dist_rhy.mean
         return self.inference_decode(z_chd, z_rhy)
 
     # ---- model.py:174-184

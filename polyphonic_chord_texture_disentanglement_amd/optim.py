@@ -36,6 +36,9 @@ class GradArena:
         self.flat = torch.zeros(off, device=dev, dtype=torch.float32)
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._handed = set()
+        self.epoch = 0                  # bumped by zero(): what an in-flight early all-reduce (dist.GradSync) was started under
+        self.in_flight = None           # callable(param) -> bool set by dist.GradSync: p's range is being all-reduced right now
+        self.on_zero = []               # callables run by zero() before the bucket is cleared (GradSync drops stale early parts)
         for p in self.params:
             _ARENA_OF[id(p)] = self
 
@@ -47,11 +50,20 @@ class GradArena:
     def take(self, p):
         """zeroed gradient view for p, once per zero(); None if already handed out this step."""
         if id(p) in self._handed:
+            # a second contribution to p in this step (shared weight, two forwards before one backward, gradient accumulation):
+            # autograd will ADD it into the arena view -- which must not be on the wire already
+            if self.in_flight is not None and self.in_flight(p):
+                raise RuntimeError('GradArena: a second gradient contribution arrived for a parameter whose slice of the bucket is already '
+                                   'being all-reduced (dist.GradSync early exchange requires every weight to be used once per step and one '
+                                   'backward per zero_grad; set PTV_EARLY_ALLREDUCE=0 for shared weights or gradient accumulation)')
             return None
         self._handed.add(id(p))
         return self.view(p)
 
     def zero(self):
+        for f in self.on_zero:
+            f()
+        self.epoch += 1
         self.flat.zero_()
         self._handed.clear()
 

@@ -41,7 +41,7 @@ def main():
         losses[0].backward()
         assert opt.arena.holds_all_grads()
         # the decoder's slice of the bucket left during the backward pass (functional.GRAD_READY_HOOK -> GradSync.grads_ready)
-        early = sum(b - a for (a, b), _ in sync._early)
+        early = sum(e[0][1] - e[0][0] for e in sync._early)
         assert (early > 0) == (os.environ.get('PTV_EARLY_ALLREDUCE', '1') != '0'), (early, opt.arena.total)
         res['early.%d' % step] = early
         sync.all_reduce_grads()

@@ -105,7 +105,7 @@ def _fake_shard(rank):
 
 
 def _arena_worker(rank, world, port, out, early=False):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), PTV_DP_CHECK='1')
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.set_num_threads(2)
     params = _fake_shard(rank)
@@ -128,8 +128,19 @@ def _arena_worker(rank, world, port, out, early=False):
             ps[i].grad = v
     write(range(k0, k1))
     if early:                                                # ... and leaves while the rest is still being produced (dist.py)
+        # contract of the early exchange (dist.py docstring): parts nobody consumed are waited for and dropped by zero()
+        assert sync.grads_ready(ps[k0:k1]) and len(sync._early) > 0
+        opt.arena.zero()
+        assert sync._early == []
+        for i in range(k0, k1):
+            ps[i].grad = None
+        write(range(k0, k1))
         assert sync.grads_ready(ps[k0:k1])
         assert not sync.grads_ready(ps[k0:k1])               # not twice
+        with pytest.raises(RuntimeError, match='second gradient contribution'):
+            opt.arena.take(ps[k0])                           # a shared weight's second use while its slice is on the wire
+        assert opt.arena.take(ps[0]) is not None and opt.arena.take(ps[0]) is None     # not on the wire: plain "already handed out"
+        opt.arena._handed.discard(id(ps[0]))
     write([i for i in range(len(ps)) if not k0 <= i < k1])
     assert opt.arena.holds_all_grads()
     sync.all_reduce_grads()

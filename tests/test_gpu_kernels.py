@@ -19,7 +19,7 @@ def _dev():
 @pytest.mark.parametrize('M,N,K', [(37, 130, 512), (512, 3072, 1024), (300, 64, 642), (1000, 290, 36),
                                    (2048, 1536, 128), (16, 5, 64), (130, 135, 7)])
 def test_gemm_nt_bias(prec, M, N, K):
-    from polyphonic_chord_texture_disentanglement_amd import ops
+    import kernel_ops as ops
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     a = torch.randn(M, K, generator=g)
     w = torch.randn(N, K, generator=g) / np.sqrt(K)
@@ -32,7 +32,7 @@ def test_gemm_nt_bias(prec, M, N, K):
 
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 def test_gemm_layouts_accumulate_exp_splitk(prec):
-    from polyphonic_chord_texture_disentanglement_amd import ops
+    import kernel_ops as ops
     dev = _dev()
     g = torch.Generator().manual_seed(5)
     # NN: dX = dY . W     (asymmetric shapes catch transposes)
@@ -80,7 +80,7 @@ def _gru_oracle_seq(x, h0, w_ih, w_hh, b_ih, b_hh, lengths, reverse):
                                                     (700, 128, 128, 16, True, True), (512, 1024, 36, 4, False, True),
                                                     (2100, 512, 128, 3, False, False)])
 def test_gru_seq_fwd_bwd(prec, M, H, I, T, masked, reverse):
-    from polyphonic_chord_texture_disentanglement_amd import ops
+    import kernel_ops as ops
     dev = _dev()
     g = torch.Generator().manual_seed(M + H + T)
     k = 1.0 / np.sqrt(H)

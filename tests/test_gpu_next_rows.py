@@ -210,3 +210,107 @@ def test_optimizer_and_trainer_state_checkpoint_resumes_bit_identically(tmp_path
     # a plain FusedClipAdam.state_dict() round trip keeps the moments
     sd = opt2.state_dict()
     assert sd['exp_avg'].numel() == sum(p.numel() for p in m2.parameters()) and sd['step_count'] == 4
+
+
+def test_checkpoint_restores_noise_coin_and_loader_streams(tmp_path, monkeypatch):
+    """what decides the NEXT batches and noise is part of the checkpoint -- the model's Philox key + draw counter,
+    python's `random` state (teacher-forcing coins), the device loader's generator -- and run() continues from the restored
+    epoch / step counters.  A trainer restored from the checkpoint sees the same batches, eps and coins as the one that went on."""
+    import random
+    from polyphonic_chord_texture_disentanglement_amd.amc_dl import torch_plus as tp
+    from polyphonic_chord_texture_disentanglement_amd.dataset_loaders import MusicDataLoaders, TrainingVAE
+    from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
+    from polyphonic_chord_texture_disentanglement_amd.synthetic import synth_raw_bank
+    monkeypatch.chdir(tmp_path)
+    bank = synth_raw_bank(12, 5)
+
+    class Spy(TrainingVAE):
+        seen = None
+
+        def _batch_to_inputs(self, batch):
+            inputs = super()._batch_to_inputs(batch)
+            self.seen.append((inputs[0].sum().item(), self.model._draws, random.getstate()[1][:4]))
+            return inputs
+
+    def make():
+        m = build_reduced(DEV).to(DEV)
+        m.use_philox(seed=9, sample_offset=0)
+        opt = FusedClipAdam(m.parameters(), lr=1e-3)
+        osch = tp.OptimizerScheduler(opt, tp.MinExponentialLR(opt, gamma=0.9, minimum=1e-5), 1)
+        ps = tp.ParameterScheduler(tfr1=tp.ConstantScheduler(.5), tfr2=tp.ConstantScheduler(.5), tfr3=tp.ConstantScheduler(.5),
+                                   beta=tp.ConstantScheduler(0.1), weights=tp.ConstantScheduler([1, 0.5]))
+        loaders = MusicDataLoaders.get_loaders(11, bs_train=16, bs_val=4, device_bank=bank)
+        pm = tp.LogPathManager(None)
+        sw = tp.SummaryWriters(M.LOSS_NAMES, {'loss': None}, pm.writer_path)
+        t = Spy(torch.device(DEV), m, False, pm, loaders, sw, osch, ps, 1)
+        t.seen = []
+        return t, m
+
+    random.seed(123)
+    tr, m = make()
+    tr.run()                                                    # one epoch (train + eval), counters advance
+    assert tr.epoch == 1 and tr.train_step > 0
+    ck = str(tmp_path / 'ck.pt')
+    tr.save_checkpoint(ck)
+    steps_saved = (tr.epoch, tr.train_step, tr.val_step)
+    tr.seen = []
+    loss_a = tr.train()
+    seen_a = list(tr.seen)
+
+    random.seed(999)                                            # a fresh process would start somewhere else entirely
+    tr2, m2 = make()
+    tr2.load_checkpoint(ck)
+    assert (tr2.epoch, tr2.train_step, tr2.val_step) == steps_saved and m2._draws == seen_a[0][1] and m2._philox == (9, 0)
+    loss_b = tr2.train()
+    assert [s[0] for s in tr2.seen] == [s[0] for s in seen_a]       # same batches (loader generator restored)
+    assert [s[1] for s in tr2.seen] == [s[1] for s in seen_a]       # same Philox draw numbers
+    assert [s[2] for s in tr2.seen] == [s[2] for s in seen_a]       # same coin stream
+    assert abs(loss_a['loss'] - loss_b['loss']) <= 1e-4 * max(1.0, abs(loss_a['loss']))
+    # run() after a restore continues the counters instead of resetting them to the reference's default 0
+    n_train = tr2.train_step
+    tr2.n_epoch = 0
+    tr2.run()
+    assert tr2.train_step == n_train and tr2.epoch == steps_saved[0]
+    tr2.run(start_epoch=0, start_train_step=0, start_val_step=0)
+    assert (tr2.epoch, tr2.train_step, tr2.val_step) == (0, 0, 0)
+
+
+def test_posterior_sample_draws_both_latents_in_reference_order():
+    """model.py:150-172: get_zs_from_dists([dist_chd, dist_rhy], True) always draws chd then rhy; the unsampled latent is then
+    overridden by its mean.  So (a) the draw counter / generator advances by two whatever the flags say and (b) the sampled
+    latent sees the noise it would see with both flags on (VERDICT r2 missing #5; the f1 golden injects eps by name and cannot
+    see the order)."""
+    g = load_npz('reduced_family.npz')
+    m = build_reduced(DEV).to(DEV)
+    pr1, c1 = torch.from_numpy(g['pr1']).to(DEV), torch.from_numpy(g['c1']).to(DEV)
+    seen = []
+    real = m._rsample
+
+    def spy(name, dist):
+        z = real(name, dist)
+        seen.append((name, m._draws, z.clone()))
+        return z
+    m._rsample = spy
+    m.use_philox(seed=3, sample_offset=0)
+    m.posterior_sample(pr1, c1, scale=0.5, sample_chd=True, sample_txt=True)
+    both = list(seen)
+    for flags in ((True, False), (False, True)):
+        seen.clear()
+        m.use_philox(seed=3, sample_offset=0)
+        m.posterior_sample(pr1, c1, scale=0.5, sample_chd=flags[0], sample_txt=flags[1])
+        assert [s[0] for s in seen] == ['chd', 'rhy'] and m._draws == 2
+        for a, b in zip(seen, both):
+            assert torch.equal(a[2], b[2])                   # same draws in the same order as with both flags on
+    # torch's device generator (the default eps source, as the reference's global generator): rhy-only sampling must consume the chd
+    # draw first
+    m._philox = None
+    seen.clear()
+    torch.manual_seed(5)
+    m.posterior_sample(pr1, c1, scale=0.5, sample_chd=False, sample_txt=True)
+    z_rhy = seen[1][2]
+    torch.manual_seed(5)
+    e_chd = torch.randn(z_rhy.shape, device=DEV)
+    e_rhy = torch.randn(z_rhy.shape, device=DEV)
+    dist_chd, dist_rhy = m.inference_encode(pr1, c1)
+    want = dist_rhy.mean + 0.5 * dist_rhy.scale * e_rhy
+    assert (z_rhy - want).abs().max() < 1e-6 and (z_rhy - (dist_rhy.mean + 0.5 * dist_rhy.scale * e_chd)).abs().max() > 1e-3
