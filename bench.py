@@ -70,6 +70,54 @@ def cpu_baseline(batch=16, timed=3):
                       'oracle/ptvae_oracle.py; value = best teacher-forced step' % (timed, batch), 'cases': out}
 
 
+# ---- parity of the benched dtype against the reference-generated golden vectors (data only: expected outputs recorded from the
+# reference by tests/golden/make_golden.py).  Outside the timed region.
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def _full_params():
+    import numpy as np
+    from polyphonic_chord_texture_disentanglement_amd.synthetic import fill_state_dict
+    with np.load(os.path.join(GOLDEN, 'full_shapes.npz'), allow_pickle=False) as f:
+        shapes = {str(n): tuple(int(t) for t in s.strip('()').split(',') if t.strip()) for n, s in zip(f['names'], f['shapes'])}
+    return fill_state_dict(shapes, 1234)
+
+
+def golden_parity(precision, dev, case='full_tf1_b16', detail=False):
+    import numpy as np
+    """{max_abs_dloss, rel_gradnorm_err, worst_tensor_gradnorm_rel_err}: the full init_model() geometry, teacher-forced step of
+    `case` in `precision` against the losses / per-tensor gradient norms the reference produced on the same inputs"""
+    from polyphonic_chord_texture_disentanglement_amd.model import DisentangleVAE
+    from polyphonic_chord_texture_disentanglement_amd.synthetic import synth_batch
+    with np.load(os.path.join(GOLDEN, case + '.npz'), allow_pickle=False) as f:
+        g = {k: f[k] for k in f.files}
+    x, c, pr = (torch.from_numpy(a).to(dev) for a in synth_batch(int(g['B']), int(g['data_seed'])))
+    m = DisentangleVAE.init_model(dev)
+    m.load_state_dict(_full_params())
+    m.to(dev).set_precision(precision)
+    m.eps_source = lambda name, shape, device: torch.from_numpy(g['eps_' + name]).to(device)
+    m.zero_grad()
+    outs = m.run(x, c, pr, 1., 1., 1.)
+    losses = m.loss_function(x, c, *outs, float(g['beta']), [float(w) for w in g['weights']])
+    got = np.array([l.item() for l in losses])
+    losses[0].backward()
+    tot2, ref2, worst, worst_name = 0.0, 0.0, 0.0, None
+    for k, p in m.named_parameters():
+        gn, ref = float(p.grad.double().pow(2).sum().sqrt()), float(g['gnorm.' + k])
+        tot2 += gn * gn
+        ref2 += ref * ref
+        e = abs(gn - ref) / max(ref, 1e-30)
+        if e > worst:
+            worst, worst_name = e, k
+    res = {'fixture': 'tests/golden/%s.npz' % case, 'dtype': 'bf16' if precision == 'bf16' else 'f32',
+           'max_abs_dloss': float(np.abs(got - g['losses']).max()), 'loss': float(got[0]), 'loss_ref': float(g['losses'][0]),
+           'rel_gradnorm_err': abs(tot2 ** 0.5 - ref2 ** 0.5) / ref2 ** 0.5, 'worst_tensor_gradnorm_rel_err': worst}
+    if detail:
+        res['worst_tensor'] = worst_name
+        res['dloss'] = [float(v) for v in (got - g['losses'])]
+    return res
+
+
 def _measure(step_fn, steps, warmup):
     for i in range(warmup):
         step_fn(i)
@@ -144,6 +192,26 @@ def extras(dev, B, rank):
                                         'note': 'the <=1e-4 parity path (exact fp32 MFMA)'}
     del m, opt
     torch.cuda.empty_cache()
+    # smaller per-GPU batches, where the host (not the GPU) bounds the eager step: eagerly enqueued vs replayed from ONE captured
+    # hipGraph per step (graph_step.GraphedTrainStep: what TrainingInterface.train() uses by default for batch <= 256)
+    from polyphonic_chord_texture_disentanglement_amd.graph_step import GraphedTrainStep
+    for Bs in (128, 256):
+        torch.manual_seed(0)
+        m = DisentangleVAE.init_model(dev).to(dev).set_precision('bf16')
+        m.use_philox(7, 0)
+        opt = FusedClipAdam(m.parameters(), lr=1e-3)
+        data = [tuple(torch.from_numpy(a).to(dev) for a in synth_batch(Bs, 99 + i)) for i in range(2)]
+        te = _measure(train_fn(m, opt, data, 1.0), 8, 3)
+        gs = GraphedTrainStep(m, opt, Bs)
+        gs(*data[0])
+        t0 = time.perf_counter()
+        tg = _measure(lambda i: gs(*data[i % 2]), 12, 2)
+        out['train_teacher_forced_b%d' % Bs] = {
+            'eager': {'samples_per_s': round(Bs / te, 1), 'ms_per_step': round(te * 1e3, 2)},
+            'graph_replayed': {'samples_per_s': round(Bs / tg, 1), 'ms_per_step': round(tg * 1e3, 2)}, 'batch': Bs, 'dtype': 'bf16',
+            'note': 'whole step (zero_grad, forward, backward, clip+Adam) as one captured hipGraph per step vs ~300 eager launches'}
+        del m, opt, gs, data
+        torch.cuda.empty_cache()
     # the headline with every zero-skip switched off: the backward computes the (exactly zero) gradients of the padded note slots and
     # the note-summary GRU runs all 16 note positions of every row, as dense autograd would
     from polyphonic_chord_texture_disentanglement_amd import functional as F_
@@ -402,6 +470,12 @@ def main():
                 res['extra'] = extras(dev, B, rank)
             except Exception as e:                             # side figures must never cost the headline line
                 res['extra'] = {'error': repr(e)}
+        if world == 1 and args.mode == 'train':
+            try:
+                res['parity'] = {'benched': golden_parity(args.precision, dev), 'fp32_path': golden_parity('fp32', dev) if args.precision != 'fp32' else None,
+                                 'bar': 'north_star: losses within 1e-4 of the CPU reference in fp32; bf16 = bf16 MFMA operands + bf16-stored saved tensors'}
+            except Exception as e:
+                res['parity'] = {'error': repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res), flush=True)

@@ -429,6 +429,12 @@ int ptv_clip_adam_step(float* p, const float* g, float* m, float* v, long n, con
 int ptv_clip_adam_step_shadow(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float gscale, float clip,
                               float lr, float beta1, float beta2, float eps, int step, void* p16, void* stream);
 
+/* Per-step scalars on the device (graph-replayed train steps, graph_step.py): while dev4 is set, ptv_loss_finalize /
+ * ptv_loss_bwd_scales read beta = dev4[0] (the KL weight of train.py:56-58's schedule; only where the call's own beta is non-zero) and
+ * ptv_clip_adam_step* read lr = dev4[1], 1 - beta1^t = dev4[2], sqrt(1 - beta2^t) = dev4[3] (Adam's bias corrections,
+ * scheduler.py:69-74 + train.py:50) instead of their by-value arguments.  NULL restores by-value behaviour. */
+int ptv_step_params(const float* dev4);
+
 /* ------------------------------------------------------------------------------------------------
  * Weight-gradient product (csrc/wgrad.hip): C[M,N] (fp32, row stride ldc) (+)= alpha * sum_k A[k*lda + m] * B[k*ldb + n], i.e.
  * grad_W = grad_out^T . input as autograd forms it for every nn.Linear / nn.GRU weight (ptvae.py:16-17,23,64,116,360,396,450,461),

@@ -56,6 +56,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // ptv_zero_skip (misc.hip): the backward kernels pass over work whose result is exactly zero (note steps / tiles at which no gradient
 // arrives, panel steps beyond the longest sequence); 0 makes them run dense (timing comparisons)
 extern int g_zero_skip;
+// ptv_step_params (misc.hip): device array of per-step scalars that override by-value arguments (graph-replayed steps), or null
+extern const float* g_step_params;
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -302,8 +302,9 @@ __global__ void kl_bwd_kernel(const float* __restrict__ mu, const float* __restr
 
 // out: loss, recon, pl, dl, kl, kl_chd, kl_rhy, chord, root, chroma, bass   (train.py:54-55 order)
 __global__ void loss_finalize_kernel(const float* __restrict__ sums, const int* __restrict__ counts, float beta, float w0, float w1,
-                                     float n_kl, float n_root, float n_chroma, float* __restrict__ out) {
+                                     float n_kl, float n_root, float n_chroma, float* __restrict__ out, const float* __restrict__ sp) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (sp) beta = sp[0];                                                   // (ptv_step_params: beta of a graph-replayed step)
   float pl = sums[0] / (float)counts[0];
   float dl = sums[1] / (float)counts[1];
   float klc = sums[2] / n_kl, klr = sums[3] / n_kl;
@@ -318,8 +319,9 @@ __global__ void loss_finalize_kernel(const float* __restrict__ sums, const int* 
 
 // upstream grads of the 11 outputs (null entries = 0) -> per-component scale factors gs[7]
 __global__ void loss_bwd_scales_kernel(const float* __restrict__ g, const int* __restrict__ counts, float beta, float w0, float w1,
-                                       float n_kl, float n_root, float n_chroma, float* __restrict__ gs) {
+                                       float n_kl, float n_root, float n_chroma, float* __restrict__ gs, const float* __restrict__ sp) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (sp) beta = sp[0];
   float g_recon = g[0] + g[1];
   gs[0] = (g_recon * w0 + g[2]) / (float)counts[0];
   gs[1] = (g_recon * w1 + g[3]) / (float)counts[1];
@@ -390,14 +392,14 @@ extern "C" int ptv_kl_bwd(const float* mu, const float* sd, long n, const float*
 
 extern "C" int ptv_loss_finalize(const float* sums, const int* counts, float beta, float w0, float w1, float n_kl, float n_root, float n_chroma, float* out11, void* stream) {
   if (!sums || !counts || !out11) return PTV_ERR_ARG;
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, counts, beta, w0, w1, n_kl, n_root, n_chroma, out11);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, counts, beta, w0, w1, n_kl, n_root, n_chroma, out11, beta != 0.f ? ptv::g_step_params : nullptr);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
 
 extern "C" int ptv_loss_bwd_scales(const float* gout11, const int* counts, float beta, float w0, float w1, float n_kl, float n_root, float n_chroma, float* gs7, void* stream) {
   if (!gout11 || !counts || !gs7) return PTV_ERR_ARG;
-  hipLaunchKernelGGL(loss_bwd_scales_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gout11, counts, beta, w0, w1, n_kl, n_root, n_chroma, gs7);
+  hipLaunchKernelGGL(loss_bwd_scales_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gout11, counts, beta, w0, w1, n_kl, n_root, n_chroma, gs7, beta != 0.f ? ptv::g_step_params : nullptr);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

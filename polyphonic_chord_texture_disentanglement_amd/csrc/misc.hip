@@ -96,7 +96,9 @@ __global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restr
 
 __global__ void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
                                  const float* __restrict__ sumsq, float gscale, float clip, float lr, float b1, float b2, float eps,
-                                 float bc1, float bc2_sqrt, __bf16* __restrict__ p16) {
+                                 float bc1, float bc2_sqrt, __bf16* __restrict__ p16, const float* __restrict__ sp) {
+  // sp (ptv_step_params): the per-step scalars of a graph-replayed step live on the device -- [1] lr, [2] 1 - b1^t, [3] sqrt(1 - b2^t)
+  if (sp) { lr = sp[1]; bc1 = sp[2]; bc2_sqrt = sp[3]; }
   // grads are first scaled by gscale (1/world_size after a sum all-reduce); sumsq is of the UNSCALED buffer
   const float norm = sqrtf(sumsq[0]) * gscale;
   float coef = clip > 0.f ? clip / (norm + 1e-6f) : 1.f;
@@ -256,7 +258,7 @@ extern "C" int ptv_clip_adam_step_shadow(float* p, const float* g, float* m, flo
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   long nb = (n + 255) / 256; if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(clip_adam_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, gscale, clip, lr, beta1, beta2, eps,
-                     (float)bc1, (float)sqrt(bc2), (__bf16*)p16);
+                     (float)bc1, (float)sqrt(bc2), (__bf16*)p16, ptv::g_step_params);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
@@ -316,5 +318,11 @@ extern "C" int ptv_transpose_cast_bf16(const float* src, void* dst, int rows, in
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
+
+namespace ptv { const float* g_step_params = nullptr; }
+// Launches made from now on read their per-step scalars from this device array instead of their by-value arguments (NULL: by value
+// again): [0] beta (ptv_loss_finalize / ptv_loss_bwd_scales), [1] lr, [2] 1 - beta1^t, [3] sqrt(1 - beta2^t) (ptv_clip_adam_step*).
+// A hipGraph captured while it is set replays with whatever the host has written there since (graph_step.GraphedTrainStep).
+extern "C" int ptv_step_params(const float* dev4) { ptv::g_step_params = dev4; return PTV_OK; }
 
 extern "C" int ptv_zero_skip(int enable) { ptv::g_zero_skip = enable ? 1 : 0; return PTV_OK; }

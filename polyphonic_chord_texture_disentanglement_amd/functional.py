@@ -24,6 +24,103 @@ BF16_STORAGE = True         # bf16 precision: tensors that only feed MFMA operan
 # (csrc/gru_persist.hip) wherever the shape fits one workgroup per CU.  Measured on one box, teacher-forced train step:
 # B = 512: 28.7-30.1k samples/s with the per-step kernels, 31.7-32.9k persistent; B = 128: 14.5k -> 17.2k; B = 256: 23.1k -> 26.1k.
 PERSIST = os.environ.get('PTV_PERSIST', '1')            # '1' | '0'
+# set while graph_step.GraphedTrainStep captures a WHOLE train step (forward + backward + optimiser) into one hipGraph: every fork is
+# joined again before the capture ends, so the sibling-stream tricks and the persistent launches (ordered by captured event edges)
+# stay on.  A capture of PART of a step (the decoder forward, ptvae.py) must not leave forks open and keeps them off.
+WHOLE_STEP_CAPTURE = False
+
+
+def capturing_part():
+    """the current stream is being captured into a graph that does NOT span the whole step"""
+    return (not WHOLE_STEP_CAPTURE) and torch.cuda.is_current_stream_capturing()
+
+
+# Whole-step capture keeps the sibling streams, so its cross-stream edges must all be edges INSIDE the capture: waiting for a stream
+# or an event that carries only work from before the capture is an error there (hipErrorStreamCaptureIsolation) -- and is not needed
+# (the capture starts after a device-wide join).  Every wait of this module goes through these two helpers.
+_CAPTURE_GEN = [0]          # bumped when a whole-step capture begins: events recorded before it are never waited for inside it
+
+
+def stream_is_capturing(s):
+    with torch.cuda.stream(s):
+        return torch.cuda.is_current_stream_capturing()
+
+
+_ORIGIN = [None]            # the capturing (origin) stream of a whole-step capture
+
+
+def _via_origin(waiter, record):
+    """torch 2.10's bundled HIP runtime (7.0) recurses forever in hipStreamEndCapture when two NON-origin streams of a capture wait
+    for each other in both directions (a nested fork + join, the persistent launches' turn-taking chain); the origin stream may
+    wait and be waited for freely (scripts/micro/graph_patterns.py).  So inside a whole-step capture an edge between two sibling
+    streams is routed through the origin: origin waits for the source, the waiter waits for the origin."""
+    o = _ORIGIN[0]
+    record(o)                                                # origin <- source
+    ev = torch.cuda.Event()
+    ev.record(o)
+    waiter.wait_event(ev)                                    # waiter <- origin
+
+
+def wait_stream(waiter, waited):
+    if WHOLE_STEP_CAPTURE:
+        if not stream_is_capturing(waited):
+            return                                           # nothing captured on it: no edge to add
+        o = _ORIGIN[0]
+        if o is not None and waiter != o and waited != o:
+            return _via_origin(waiter, lambda org: org.wait_stream(waited))
+    waiter.wait_stream(waited)
+
+
+def record_event(stream=None):
+    ev = torch.cuda.Event()
+    stream = stream if stream is not None else torch.cuda.current_stream()
+    ev.record(stream)
+    ev.ptv_gen = _CAPTURE_GEN[0] if WHOLE_STEP_CAPTURE else -1
+    ev.ptv_stream = stream
+    return ev
+
+
+def wait_event(stream, ev):
+    if WHOLE_STEP_CAPTURE:
+        if getattr(ev, 'ptv_gen', -1) != _CAPTURE_GEN[0]:
+            return                                           # recorded before this capture began
+        o = _ORIGIN[0]
+        if o is not None and stream != o and getattr(ev, 'ptv_stream', o) != o:
+            if ev.ptv_stream == stream:
+                return                                       # same stream: ordered already
+            return _via_origin(stream, lambda org: org.wait_event(ev))
+    stream.wait_event(ev)
+
+
+def join_captured_streams():
+    """end of a whole-step capture: every sibling stream that was forked into the capture joins the capturing stream (a fork left
+    open -- e.g. side work whose consumer did not run in this step -- would fail the capture)"""
+    cur = torch.cuda.current_stream()
+    for s in list(_CHILD_STREAMS.values()):
+        if s != cur and stream_is_capturing(s):
+            cur.wait_stream(s)
+
+
+class whole_step_capture:
+    """with whole_step_capture(): ... inside torch.cuda.graph(...): the module's stream helpers switch to capture-safe behaviour"""
+
+    def __enter__(self):
+        global WHOLE_STEP_CAPTURE
+        WHOLE_STEP_CAPTURE = True
+        _CAPTURE_GEN[0] += 1
+        _PERSIST_LAST.clear()
+        _ORIGIN[0] = None
+        return self
+
+    def origin(self):
+        """call first thing inside torch.cuda.graph(): the current stream is the capture's origin"""
+        _ORIGIN[0] = torch.cuda.current_stream()
+
+    def __exit__(self, *exc):
+        global WHOLE_STEP_CAPTURE
+        WHOLE_STEP_CAPTURE = False
+        _ORIGIN[0] = None
+        return False
 
 
 def _empty(*shape, dev, dtype=F32):
@@ -197,7 +294,7 @@ PERSIST_MIN_T = int(os.environ.get('PTV_PERSIST_MIN_T', '0'))
 
 
 def persist_supported(NC, M, H, T=None):
-    if str(PERSIST).lower() in ('0', 'false', 'off') or torch.cuda.is_current_stream_capturing():
+    if str(PERSIST).lower() in ('0', 'false', 'off') or capturing_part():
         return False
     if T is not None and T < PERSIST_MIN_T:
         return False
@@ -214,13 +311,11 @@ class _PersistTurn:
         self.cur = torch.cuda.current_stream()
         ev = _PERSIST_LAST.get(self.cur.device.index)
         if ev is not None:
-            self.cur.wait_event(ev)
+            wait_event(self.cur, ev)
         return self
 
     def __exit__(self, *exc):
-        ev = torch.cuda.Event()
-        ev.record(self.cur)
-        _PERSIST_LAST[self.cur.device.index] = ev
+        _PERSIST_LAST[self.cur.device.index] = record_event(self.cur)
         return False
 
 
@@ -396,7 +491,7 @@ class Side:
     def __call__(self, fn, *keep):
         if not OVERLAP:
             return fn()
-        self.s.wait_stream(self.main)
+        wait_stream(self.s, self.main)
         self.used = True
         self.keep.extend(keep)
         _SIDE_DEPTH[0] += 1
@@ -414,7 +509,7 @@ class Side:
 
     def join(self):
         if self.used:
-            self.main.wait_stream(self.s)
+            wait_stream(self.main, self.s)
         self.keep.clear()
         self.used = False
 
@@ -453,7 +548,7 @@ def _join_deferred():
     mark('deferred:join_start')
     cur = torch.cuda.current_stream()
     for s, _keep in _DEFERRED:
-        cur.wait_stream(s)
+        wait_stream(cur, s)
     _DEFERRED.clear()
     mark('deferred:joined')
 
@@ -633,13 +728,11 @@ class EmbedFn(torch.autograd.Function):
         # is left to hide it behind
         ctx.mh = ctx.mh_side = None
         if (EMBED_MH_FWD and prec == 1 and E % 8 == 0 and OVERLAP and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-                and not torch.cuda.is_current_stream_capturing()):
+                and not capturing_part()):
             def build():
                 mh = _empty(B * 512, 136, dev=w.device, dtype=BF16)
                 call('ptv_multihot_bf16', ptr(x), ptr(mh), 136, B, stream_ptr())
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
-                return mh, ev
+                return mh, record_event()
             ctx.mh, ctx.mh_side = Side(7)(build, x)           # (pool stream 3: idle in the forward; streams 0 / 2 delayed the encoders)            # (mh_side: the event the backward waits for -- not the whole stream)
         return emb, lengths
 
@@ -649,7 +742,7 @@ class EmbedFn(torch.autograd.Function):
         B, E = x.shape[0], w.shape[0]
         demb2 = demb.contiguous().view(B * 512, E)
         if ctx.mh is not None:
-            torch.cuda.current_stream().wait_event(ctx.mh_side)
+            wait_event(torch.cuda.current_stream(), ctx.mh_side)
             mh, ctx.mh, ctx.mh_side = ctx.mh, None, None
             dw, db = wgrad_bias(demb2, mh[:, :135], _gbuf(w), _gbuf(b), ctx.prec)      # bias gradient inside the same pass over dy
             return None, dw, db, None

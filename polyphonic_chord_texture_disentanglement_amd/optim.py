@@ -111,7 +111,8 @@ def weight_shadow_t(p):
         return None
     opt.refresh_shadow_if_stale()
     if opt._t_event is not None:
-        torch.cuda.current_stream().wait_event(opt._t_event)
+        from . import functional as F_
+        F_.wait_event(torch.cuda.current_stream(), opt._t_event)
     return opt.flat_pT16[off:off + p.numel()].view(p.shape[1], p.shape[0])
 
 
@@ -215,13 +216,12 @@ class FusedClipAdam(torch.optim.Optimizer):
                      self._tdesc[1], stream_ptr())
             from . import functional as F_
             self._t_event = None
-            if SHADOW_T_ASYNC and F_.OVERLAP and not torch.cuda.is_current_stream_capturing():
+            if SHADOW_T_ASYNC and F_.OVERLAP and not F_.capturing_part():
                 # only the backward pass reads the transposed copies (dX products, BPTT): refresh them on a sibling stream, off the
                 # head of the step; weight_shadow_t() makes its caller's stream wait for the event
                 side = F_.Side(7)
                 side(transposes)
-                self._t_event = torch.cuda.Event()
-                self._t_event.record(side.s)
+                self._t_event = F_.record_event(side.s)
             else:
                 transposes()
         for p, buf in self._row_padded.values():

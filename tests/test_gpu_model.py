@@ -809,3 +809,94 @@ def test_sibling_streams_do_not_change_a_steady_state_training_run(prec, monkeyp
                 a, b = g0[o:o + k], g1[o:o + k]
                 tol = (1e-2 if prec == 'bf16' else 5e-4) * (step + 1)   # order of the fp32 atomics (+ bf16 roundings they flip); grows per step
                 assert (a - b).abs().max() <= tol * a.abs().max() + 1e-7, (tag, step, n, float((a - b).abs().max()), float(a.abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------
+# the whole step as one hipGraph launch (graph_step.GraphedTrainStep)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('prec,B', [('fp32', 4), ('bf16', 64)])
+def test_graph_replayed_train_steps_equal_eager_steps(prec, B):
+    """4 optimisation steps with a changing batch, Philox noise, a decaying learning rate and an annealed beta: replayed from the
+    captured graph vs enqueued eagerly (reference loop body amc_dl/torch_plus/module.py:129-150).  Same losses per step and the same
+    parameters at the end, to the run-to-run noise of the fp32 atomics (helpers); building the graph (warm-up steps + capture) must
+    leave no trace in the training state: step count, draw counter and coin stream end where the eager run's do."""
+    import random
+    from helpers import ADAM_NOISE_FRAC_OF_LR
+    from polyphonic_chord_texture_disentanglement_amd.amc_dl.torch_plus import MinExponentialLR
+    from polyphonic_chord_texture_disentanglement_amd.graph_step import GraphedTrainStep
+    from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    full = prec == 'bf16'
+    batches = [tuple(torch.from_numpy(a).to(DEV) for a in synth_batch(B, 700 + i)) for i in range(4)]
+    betas = [0.0, 0.03, 0.06, 0.1]
+    res = {}
+    for mode in ('eager', 'graph'):
+        if full:
+            m = M.DisentangleVAE.init_model(torch.device(DEV))
+            m.load_state_dict(full_params())
+            m.to(DEV).set_precision('bf16')
+        else:
+            m = build_reduced(DEV).to(DEV)
+        opt = FusedClipAdam(m.parameters(), lr=1e-3)
+        sched = MinExponentialLR(opt, gamma=0.9, minimum=1e-5)
+        m.use_philox(seed=11, sample_offset=0)
+        random.seed(5)
+        gs = GraphedTrainStep(m, opt, B) if mode == 'graph' else None
+        losses = []
+        for i, (x, c, pr) in enumerate(batches):
+            if gs is not None:
+                losses.append(gs(x, c, pr, beta=betas[i]).cpu().numpy().copy())
+            else:
+                opt.zero_grad()
+                out = m('train', x, c, pr, tfr1=1., tfr2=1., tfr3=1., beta=betas[i], weights=[1, 0.5])
+                out[0].backward()
+                opt.clip_and_step(1.0)
+                losses.append(np.array([float(o) for o in out]))
+            sched.step()
+        F_.persist_check()
+        res[mode] = (np.stack(losses), opt.flat_p.detach().cpu().clone(), opt.step_count, m._draws, random.random(), float(opt.grad_norm()))
+        del m, opt, gs
+    le, lg = res['eager'][0], res['graph'][0]
+    tol = 2e-3 if full else 2e-5
+    np.testing.assert_allclose(lg, le, rtol=0, atol=tol * np.arange(1, 5)[:, None])
+    assert abs(lg[1][0] - lg[0][0]) > 10 * tol                       # (the steps really differ: batch, beta, lr)
+    assert res['graph'][2:5] == res['eager'][2:5]                       # step count, Philox draws, position of the coin stream
+    assert abs(res['graph'][5] - res['eager'][5]) <= (2e-2 if full else 1e-3) * res['eager'][5]
+    dp = (res['graph'][1] - res['eager'][1]).abs().max()
+    assert dp <= 1e-3 * ADAM_NOISE_FRAC_OF_LR * 4 * (25 if full else 1), float(dp)
+
+
+def test_trainer_surface_with_graph_replayed_steps(tmp_path, monkeypatch):
+    """TrainingVAE.train() with graph_step = True (device batch transform -> replayed step -> schedulers -> async logging) against the
+    same epoch run eagerly: epoch losses, LR / beta schedule positions and optimiser step count"""
+    import random
+    from polyphonic_chord_texture_disentanglement_amd.amc_dl import torch_plus as tp
+    from polyphonic_chord_texture_disentanglement_amd.amc_dl.torch_plus.train_utils import kl_anealing
+    from polyphonic_chord_texture_disentanglement_amd.dataset_loaders import MusicDataLoaders, TrainingVAE
+    from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
+    from polyphonic_chord_texture_disentanglement_amd.synthetic import synth_raw_bank
+    monkeypatch.chdir(tmp_path)
+    bank = synth_raw_bank(10, 3)
+    out = {}
+    for graph in (False, True):
+        m = build_reduced(DEV).to(DEV)
+        m.use_philox(seed=2, sample_offset=0)
+        random.seed(8)
+        opt = FusedClipAdam(m.parameters(), lr=1e-3)
+        osch = tp.OptimizerScheduler(opt, tp.MinExponentialLR(opt, gamma=0.99, minimum=1e-5), 1)
+        ps = tp.ParameterScheduler(tfr1=tp.ConstantScheduler(1.), tfr2=tp.ConstantScheduler(1.), tfr3=tp.ConstantScheduler(1.),
+                                   beta=tp.TeacherForcingScheduler(0.1, 0., f=kl_anealing), weights=tp.ConstantScheduler([1, 0.5]))
+        loaders = MusicDataLoaders.get_loaders(11, bs_train=12, bs_val=4, device_bank=bank)
+        loaders.train_loader.drop_last = True
+        pm = tp.LogPathManager(None)
+        sw = tp.SummaryWriters(M.LOSS_NAMES, {'loss': None}, pm.writer_path)
+        tr = TrainingVAE(torch.device(DEV), m, False, pm, loaders, sw, osch, ps, 1, graph_step=graph)
+        dic = tr.train()
+        assert ('_graph_steps' in tr.__dict__ and len(tr._graph_steps) == 1) == graph
+        out[graph] = (dic, opt.step_count, opt.param_groups[0]['lr'], tr.train_step, opt.flat_p.detach().cpu().clone())
+    n = out[True][3]
+    assert n == out[False][3] and n >= 4 and out[True][1] == out[False][1] == n
+    assert abs(out[True][2] - out[False][2]) < 1e-15
+    for k in out[False][0]:
+        assert abs(out[True][0][k] - out[False][0][k]) <= 2e-5 * n * max(1.0, abs(out[False][0][k])), k
+    assert (out[True][4] - out[False][4]).abs().max() <= 2e-5 * n

@@ -300,7 +300,8 @@ def test_posterior_sample_draws_both_latents_in_reference_order():
         m.posterior_sample(pr1, c1, scale=0.5, sample_chd=flags[0], sample_txt=flags[1])
         assert [s[0] for s in seen] == ['chd', 'rhy'] and m._draws == 2
         for a, b in zip(seen, both):
-            assert torch.equal(a[2], b[2])                   # same draws in the same order as with both flags on
+            # same draws in the same order as with both flags on (the encoders' means carry run-to-run rounding: not bitwise)
+            assert (a[2] - b[2]).abs().max() < 1e-5
     # torch's device generator (the default eps source, as the reference's global generator): rhy-only sampling must consume the chd
     # draw first
     m._philox = None
