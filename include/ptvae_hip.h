@@ -429,6 +429,16 @@ int ptv_clip_adam_step(float* p, const float* g, float* m, float* v, long n, con
 int ptv_clip_adam_step_shadow(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float gscale, float clip,
                               float lr, float beta1, float beta2, float eps, int step, void* p16, void* stream);
 
+/* Reproducible reductions (default ON; environment PTV_WGRAD_ORDERED=0 or ptv_ordered_reductions(0) turn them off).  The
+ * reference's CPU path is run-to-run deterministic.  With the switch on, nothing on the train step ends in an fp32
+ * atomicAdd whose order depends on arrival: the K slabs of ptv_wgrad and the K splits of ptv_gemm store partial tiles into a
+ * per-stream workspace and one more launch adds them in slab order; the grid reductions (ptv_grad_sumsq, ptv_kl_fwd,
+ * ptv_reparam_kl_fwd, ptv_ce_fwd, ptv_colsum, ptv_dur_out_wgrad, ptv_txt_conv_relu_pool_bwd) park one partial per block and the last
+ * block to arrive adds them in block order.  Two runs of the same step then produce the same bits.  (Still atomic: the grouped
+ * cross-entropy of the weighted duration loss, ptv_ce_group_fwd.)  ptv_wgrad_mode switches the two product paths only. */
+int ptv_ordered_reductions(int on);
+int ptv_wgrad_mode(int ordered);
+
 /* Per-step scalars on the device (graph-replayed train steps, graph_step.py): while dev4 is set, ptv_loss_finalize /
  * ptv_loss_bwd_scales read beta = dev4[0] (the KL weight of train.py:56-58's schedule; only where the call's own beta is non-zero) and
  * ptv_clip_adam_step* read lr = dev4[1], 1 - beta1^t = dev4[2], sqrt(1 - beta2^t) = dev4[3] (Adam's bias corrections,

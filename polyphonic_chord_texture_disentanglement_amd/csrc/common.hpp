@@ -61,4 +61,49 @@ extern const float* g_step_params;
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- ordered grid reductions (ptv_wgrad_mode / PTV_WGRAD_ORDERED, default on): instead of ending in one fp32 atomicAdd per block
+// (summation order = arrival order: the last bits differ from run to run), every block parks its partial in a per-stream scratch
+// slot and the LAST block to arrive adds the partials in block order.  slots == nullptr: the atomics.
+struct OrdScratch { float* slots; unsigned* counters; };
+constexpr long ORD_SLOT_FLOATS = 1L << 20;     // 4 MB of partials per stream
+constexpr int ORD_COUNTERS = 256;
+OrdScratch ord_scratch(hipStream_t s, long need_floats, int need_counters);     // misc.hip
+
+// Every thread of the block calls it after the block's partial vector part[0..L) (LDS) is complete and visible (caller synced).
+// group = which output vector / counter, idx = this block's position among the n blocks that contribute to it.
+__device__ __forceinline__ void ordered_commit(float* out, const float* part, int L, const OrdScratch& sc, int group, int idx, int n) {
+  if (!sc.slots) {
+    for (int i = threadIdx.x; i < L; i += blockDim.x) { const float v = part[i]; if (v != 0.f) atomicAdd(out + i, v); }
+    return;
+  }
+  __shared__ int s_last;
+  __shared__ float s_red[16];
+  float* base = sc.slots + (long)group * n * L;
+  for (int i = threadIdx.x; i < L; i += blockDim.x) __hip_atomic_store(base + (long)idx * L + i, part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(sc.counters + group, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n - 1);
+  __syncthreads();
+  if (!s_last) return;
+  if (L == 1) {                                                   // a scalar: the whole block adds (fixed strides + fixed tree = fixed order)
+    float s = 0.f;
+    for (int b = threadIdx.x; b < n; b += blockDim.x) s += __hip_atomic_load(base + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int w = 0; w < (int)((blockDim.x + 63) >> 6); w++) t += s_red[w];
+      out[0] += t;
+    }
+  } else {
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+      float s = 0.f;
+      for (int b = 0; b < n; b++) s += __hip_atomic_load(base + (long)b * L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      out[i] += s;
+    }
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(sc.counters + group, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace ptv

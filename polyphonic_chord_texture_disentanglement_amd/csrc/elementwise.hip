@@ -87,8 +87,9 @@ __global__ void sum_steps_vec_kernel(float* __restrict__ out, const void* __rest
 // out[g*N + n] += sum_{rows r with (sel ? sel[r] : 0) == g} A[r*lda + n]   (G <= 2; block partial + atomics)
 // block = 256 threads = 16 column quads (64 columns, 16-byte loads) x 16 row lanes
 template <bool VEC>
-__global__ void colsum_kernel(float* out, const void* __restrict__ A, long lda, long rows, int N, const int* __restrict__ sel, int G, int bf) {
+__global__ void colsum_kernel(float* out, const void* __restrict__ A, long lda, long rows, int N, const int* __restrict__ sel, int G, int bf, OrdScratch sc) {
   __shared__ float red[2][16][64];
+  __shared__ float tot[2 * 64];
   const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
   const int n = blockIdx.x * 64 + cq * 4;
   const long rows_per_block = (rows + gridDim.y - 1) / gridDim.y;
@@ -117,7 +118,30 @@ __global__ void colsum_kernel(float* out, const void* __restrict__ A, long lda, 
     float t = 0.f;
 #pragma unroll
     for (int y = 0; y < 16; y++) t += red[g][y][c];
-    if (blockIdx.x * 64 + c < N && t != 0.f) atomicAdd(out + (long)g * N + blockIdx.x * 64 + c, t);
+    if (sc.slots) tot[i] = t;
+    else if (blockIdx.x * 64 + c < N && t != 0.f) atomicAdd(out + (long)g * N + blockIdx.x * 64 + c, t);
+  }
+  if (sc.slots) {
+    // ordered: this column block's row blocks park their [G][64] partials; the last one adds them in row-block order
+    __syncthreads();
+    __shared__ int s_last;
+    const int L = G * 64, n = gridDim.y;
+    float* base = sc.slots + (long)blockIdx.x * n * L;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) __hip_atomic_store(base + (long)blockIdx.y * L + i, tot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(sc.counters + blockIdx.x, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n - 1);
+    __syncthreads();
+    if (s_last) {
+      for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        const int g = i / 64, c = i % 64;
+        if (blockIdx.x * 64 + c >= N) continue;
+        float s2 = 0.f;
+        for (int b = 0; b < n; b++) s2 += __hip_atomic_load(base + (long)b * L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        out[(long)g * N + blockIdx.x * 64 + c] += s2;
+      }
+      if (threadIdx.x == 0) __hip_atomic_store(sc.counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -227,7 +251,7 @@ __global__ void multihot_bf16_kernel(const long* __restrict__ x, __bf16* __restr
 // reparameterisation + KL (train_utils.py:33-34,45-49):  z = mu + std*eps ; kl = mean(-log std + (std^2+mu^2)/2 - 1/2)
 // ---------------------------------------------------------------------------------------------
 __global__ void reparam_kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ sd, const float* __restrict__ eps,
-                                      float* __restrict__ z, long ldz, float* __restrict__ kl_sum, int B, int Z) {
+                                      float* __restrict__ z, long ldz, float* __restrict__ kl_sum, int B, int Z, OrdScratch sc) {
   __shared__ float red[4];
   long total = (long)B * Z;
   float s = 0.f;
@@ -240,7 +264,9 @@ __global__ void reparam_kl_fwd_kernel(const float* __restrict__ mu, const float*
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(kl_sum, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) red[0] = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  ordered_commit(kl_sum, red, 1, sc, 0, blockIdx.x, gridDim.x);
 }
 
 // dmu = dz + klw*mu ; dlv = (dz*eps + klw*(std - 1/std)) * std      (lv = log std is the Linear output)
@@ -337,8 +363,10 @@ extern "C" int ptv_colsum(float* out, const void* A, long lda, long rows, int N,
   long want = 2048 / gx; if (want < 1) want = 1;                 // ~2048 blocks in flight
   long gy = (rows + 63) / 64; if (gy > want) gy = want; if (gy < 1) gy = 1;
   const bool vec = ((lda & 3) == 0) && ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & (a_bf16 ? 7 : 15)) == 0);
-  if (vec) hipLaunchKernelGGL((colsum_kernel<true>), dim3(gx, (int)gy), dim3(256), 0, (hipStream_t)stream, out, A, lda, rows, N, sel, G, a_bf16);
-  else hipLaunchKernelGGL((colsum_kernel<false>), dim3(gx, (int)gy), dim3(256), 0, (hipStream_t)stream, out, A, lda, rows, N, sel, G, a_bf16);
+  OrdScratch sc = ord_scratch((hipStream_t)stream, (long)gx * 64 * G * 64, gx);
+  if (sc.slots && gy > 64) gy = 64;                               // (the last row block adds gy partials per column)
+  if (vec) hipLaunchKernelGGL((colsum_kernel<true>), dim3(gx, (int)gy), dim3(256), 0, (hipStream_t)stream, out, A, lda, rows, N, sel, G, a_bf16, sc);
+  else hipLaunchKernelGGL((colsum_kernel<false>), dim3(gx, (int)gy), dim3(256), 0, (hipStream_t)stream, out, A, lda, rows, N, sel, G, a_bf16, sc);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
@@ -370,7 +398,7 @@ extern "C" int ptv_multihot_bf16(const long* x, void* out, long ld, int B, void*
 
 extern "C" int ptv_reparam_kl_fwd(const float* mu, const float* sd, const float* eps, float* z, long ldz, float* kl_sum, int B, int Z, void* stream) {
   if (!mu || !sd || !z || !kl_sum || B <= 0 || Z <= 0) return PTV_ERR_ARG;
-  hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(grid_for((long)B * Z, 256, 256)), dim3(256), 0, (hipStream_t)stream, mu, sd, eps, z, ldz, kl_sum, B, Z);
+  hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(grid_for((long)B * Z, 256, 256)), dim3(256), 0, (hipStream_t)stream, mu, sd, eps, z, ldz, kl_sum, B, Z, kl_sum ? ord_scratch((hipStream_t)stream, 256, 1) : OrdScratch{nullptr, nullptr});
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

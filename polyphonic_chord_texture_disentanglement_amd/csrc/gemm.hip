@@ -1,6 +1,7 @@
 // gemm.hip -- plain dense products on the MFMA core: Linear forward (NT), dX (NN), dW (TN, split-K).
 // C-ABI entry: ptv_gemm (include/ptvae_hip.h).
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
 #include "common.hpp"
 #include "gemm_core.hpp"
@@ -18,6 +19,8 @@ struct EpiPlain {
     int act;          // 0 none, 1 exp
     int atomic;       // split-K partial sums: atomicAdd into C (C pre-initialised, fp32 only)
     int c_bf16;       // C holds bf16
+    long split_stride;   // ordered split-K: split z stores its partial at C + z * split_stride floats (C = a workspace, ldc = N);
+                         // splitk_reduce_kernel adds the partials in split order
   };
   // a row tile that lies in the declared-zero part of A (GemmArgs::m_top): accumulating or atomically adding zero changes nothing
   static __device__ __forceinline__ bool dead_is_noop(const Params& p) { return (p.accumulate || p.atomic) && p.act == 0 && p.bias == nullptr; }
@@ -28,8 +31,11 @@ struct EpiPlain {
   template <int FN> static constexpr bool staged() { return FN == 2 || FN == 4; }
   template <int FM, int FN, int NG> static constexpr int lds_bytes() { return staged<FN>() ? 4 * RowStage<1, (staged<FN>() ? FN * 16 : 64)>::WAVE_BYTES : 0; }
   template <int FM, int FN, int NG>
-  static __device__ __forceinline__ void apply(const Params& p, f32x4 (&acc)[FM][NG * FN], const Pre<FM, FN, NG>&,
+  static __device__ __forceinline__ void apply(const Params& p_in, f32x4 (&acc)[FM][NG * FN], const Pre<FM, FN, NG>&,
                                                int m0, int n0, int M, int N, int split, char* lds) {
+    Params q = p_in;
+    if (q.split_stride) q.C = reinterpret_cast<float*>(q.C) + (long)split * q.split_stride;
+    const Params& p = q;
     const bool bf = p.c_bf16 != 0;
     const bool vec = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & (bf ? 7 : 15)) == 0);
     const bool use_bias = p.bias != nullptr && split == 0;
@@ -144,6 +150,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_plain_kernel(GemmArgs g, Epi
   gemm_body<CT, BM, BN, WGM, WGN, 1, KA, KB, EpiPlain, SA, SB, (BM * BN <= 64 * 64 ? 2 : PLAIN_PF_BIG(KA, KB, SA, SB))>(g, ep);
 }
 
+// C[m][n] (+)= ws[0][m][n] + ws[1][m][n] + ... in split order (alpha and the bias are already inside the partials)
+__global__ void splitk_reduce_kernel(float* __restrict__ C, long ldc, const float* __restrict__ ws, int M, int N, int splits, int accumulate) {
+  const long total = (long)M * N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    float sum = 0.f;
+    for (int z = 0; z < splits; z++) sum += ws[(long)z * total + i];
+    float* cp = C + (i / N) * ldc + (i % N);
+    *cp = (accumulate ? *cp : 0.f) + sum;
+  }
+}
+
 __global__ void fill_rows_kernel(float* C, long ldc, int M, int N, float v) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = (long)M * N;
@@ -154,6 +171,29 @@ template <class CT, int BM, int BN, bool KA, bool KB, bool SA, bool SB>
 static void launch_plain(const GemmArgs& g, const EpiPlain::Params& ep, int splits, hipStream_t s) {
   dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), splits);
   hipLaunchKernelGGL((gemm_plain_kernel<CT, BM, BN, 2, 2, KA, KB, SA, SB>), grid, dim3(NTHREADS), 0, s, g, ep);
+}
+
+// 1 (default): split-K partials through a per-stream workspace + ordered reduction; 0: fp32 atomics into C (PTV_WGRAD_ORDERED=0,
+// ptv_wgrad_mode)
+int g_splitk_ordered = [] { const char* e = getenv("PTV_WGRAD_ORDERED"); return (e && e[0] == '0') ? 0 : 1; }();
+
+static float* splitk_workspace(hipStream_t s, size_t bytes) {
+  struct Buf { float* p; size_t bytes; };
+  static Buf pool[64]; static hipStream_t keys[64]; static int n = 0; static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  int i = 0;
+  for (; i < n; i++) if (keys[i] == s) break;
+  if (i == n) { if (n == 64) return nullptr; keys[n++] = s; pool[i] = Buf{nullptr, 0}; }
+  Buf& b = pool[i];
+  if (b.bytes < bytes) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) return nullptr;   // cannot grow inside a capture
+    if (b.p) { if (hipStreamSynchronize(s) != hipSuccess) return nullptr; (void)hipFree(b.p); }
+    const size_t want = bytes + bytes / 4;
+    if (hipMalloc(reinterpret_cast<void**>(&b.p), want) != hipSuccess) { b = Buf{nullptr, 0}; return nullptr; }
+    b.bytes = want;
+  }
+  return b.p;
 }
 
 template <class CT, bool SA, bool SB>
@@ -188,7 +228,16 @@ static int gemm_dispatch(int transA, int transB, GemmArgs g, EpiPlain::Params ep
     } else splits = s2;
   }
   g.k_per_split = kper;
-  if (splits > 1) {
+  float* ws = nullptr;
+  const EpiPlain::Params ep_user = ep;
+  if (splits > 1 && g_splitk_ordered) {
+    // ordered reduction: every split stores its partial tile-by-tile into a per-stream workspace, one more launch adds them in
+    // split order -- bit-reproducible, no fp32 atomics.  (Dead row tiles of an m_top product store zeros.)
+    ws = splitk_workspace(s, (size_t)splits * g.M * g.N * sizeof(float));
+  }
+  if (ws) {
+    ep.C = ws; ep.ldc = g.N; ep.accumulate = 0; ep.atomic = 0; ep.split_stride = (long)g.M * g.N;
+  } else if (splits > 1) {
     ep.atomic = 1;
     if (!ep.accumulate) {
       long total = (long)g.M * g.N;
@@ -206,6 +255,11 @@ static int gemm_dispatch(int transA, int transB, GemmArgs g, EpiPlain::Params ep
   else if (transA && transB) PTV_LAUNCH(true, true);
   else PTV_LAUNCH(true, false);
 #undef PTV_LAUNCH
+  if (ws) {
+    const long total = (long)g.M * g.N;
+    int nb = (int)((total + 255) / 256); if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, s, reinterpret_cast<float*>(ep_user.C), ep_user.ldc, ws, g.M, g.N, splits, ep_user.accumulate);
+  }
   return PTV_OK;
 }
 
@@ -231,7 +285,7 @@ extern "C" int ptv_gemm_mtop(int prec, int transA, int transB, int M, int N, int
     return ptv_wgrad(M, N, K, A, lda, B, ldb, reinterpret_cast<float*>(C), ldc, alpha, accumulate, dtypes & 3, 0, nullptr, nullptr, 0, 0, stream);
   if (m_top && (transA || m_unit <= 0)) return PTV_ERR_ARG;            // a row limit on A: A must be row-per-sample
   ptv::GemmArgs g{A, lda, B, ldb, M, N, K, K, 0, m_top, m_unit, ptv::g_gemm_prio};
-  ptv::EpiPlain::Params ep{C, ldc, bias, alpha, accumulate, act, 0, sc ? 1 : 0};
+  ptv::EpiPlain::Params ep{C, ldc, bias, alpha, accumulate, act, 0, sc ? 1 : 0, 0};
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (prec != PTV_PREC_BF16) rc = ptv::gemm_dispatch<ptv::F32, false, false>(transA, transB, g, ep, splitk, s);

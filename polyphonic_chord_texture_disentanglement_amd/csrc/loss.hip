@@ -55,7 +55,7 @@ __global__ void chord_targets_kernel(const float* __restrict__ c, int B, int ste
 // one wave per row, C <= 256
 template <bool BWD>
 __global__ void ce_wave_kernel(const float* __restrict__ logits, long ld, const int* __restrict__ tgt, long rows, int C, int ignore,
-                               float* __restrict__ nll_sum, const float* __restrict__ gscale, float* __restrict__ dlogits, long ldd) {
+                               float* __restrict__ nll_sum, const float* __restrict__ gscale, float* __restrict__ dlogits, long ldd, OrdScratch sc) {
   __shared__ float red[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float local = 0.f;
@@ -86,7 +86,9 @@ __global__ void ce_wave_kernel(const float* __restrict__ logits, long ld, const 
   if (!BWD) {
     if (lane == 0) red[w] = local;
     __syncthreads();
-    if (threadIdx.x == 0) { float t = red[0] + red[1] + red[2] + red[3]; if (t != 0.f) atomicAdd(nll_sum, t); }
+    if (threadIdx.x == 0) red[0] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    ordered_commit(nll_sum, red, 1, sc, 0, blockIdx.x, gridDim.x);
   }
 }
 
@@ -94,7 +96,7 @@ __global__ void ce_wave_kernel(const float* __restrict__ logits, long ld, const 
 // loads / stores, two rows per wave instruction stream.  C <= 256.  (The scalar kernel above moved 4 bytes per lane.)
 template <bool BWD>
 __global__ void ce_vec_kernel(const float* __restrict__ logits, long ld, const int* __restrict__ tgt, long rows, int C, int ignore,
-                              float* __restrict__ nll_sum, const float* __restrict__ gscale, float* __restrict__ dlogits, long ldd) {
+                              float* __restrict__ nll_sum, const float* __restrict__ gscale, float* __restrict__ dlogits, long ldd, OrdScratch sc) {
   __builtin_amdgcn_s_setprio(3);                                         // always part of a latency chain
   __shared__ float red[8];
   const int lane = threadIdx.x & 63, sub = lane & 31, hw = threadIdx.x >> 5;       // 8 half-waves per block
@@ -167,7 +169,9 @@ __global__ void ce_vec_kernel(const float* __restrict__ logits, long ld, const i
   if (!BWD) {
     if (sub == 0) red[hw] = local;
     __syncthreads();
-    if (threadIdx.x == 0) { float t = 0.f; for (int i = 0; i < 8; i++) t += red[i]; if (t != 0.f) atomicAdd(nll_sum, t); }
+    if (threadIdx.x == 0) { float t = 0.f; for (int i = 0; i < 8; i++) t += red[i]; red[0] = t; }
+    __syncthreads();
+    ordered_commit(nll_sum, red, 1, sc, 0, blockIdx.x, gridDim.x);
   }
 }
 
@@ -178,7 +182,7 @@ static inline bool ce_vec_ok(const float* p, long ld, int C) {
 // one thread per row, C <= 16 (duration bits C=2, chord heads C=12 / 2)
 template <bool BWD>
 __global__ void ce_small_kernel(const float* __restrict__ logits, long ld, const int* __restrict__ tgt, long rows, int C, int ignore,
-                                float* __restrict__ nll_sum, const float* __restrict__ gscale, float* __restrict__ dlogits, long ldd) {
+                                float* __restrict__ nll_sum, const float* __restrict__ gscale, float* __restrict__ dlogits, long ldd, OrdScratch sc) {
   __shared__ float red[4];
   float local = 0.f;
   const float gs = BWD ? gscale[0] : 0.f;
@@ -209,7 +213,9 @@ __global__ void ce_small_kernel(const float* __restrict__ logits, long ld, const
     local = wave_sum(local);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
     __syncthreads();
-    if (threadIdx.x == 0) { float t = red[0] + red[1] + red[2] + red[3]; if (t != 0.f) atomicAdd(nll_sum, t); }
+    if (threadIdx.x == 0) red[0] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    ordered_commit(nll_sum, red, 1, sc, 0, blockIdx.x, gridDim.x);
   }
 }
 
@@ -277,7 +283,7 @@ __global__ void wdur_scales_kernel(const float* __restrict__ gs1, const int* __r
   for (int d = 0; d < 5; d++) out5[d] = gs1[0] * w[d] / (float)gcnt[d];
 }
 
-__global__ void kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ sd, long n, float* __restrict__ kl_sum) {
+__global__ void kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ sd, long n, float* __restrict__ kl_sum, OrdScratch sc) {
   __shared__ float red[4];
   float s = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -287,7 +293,9 @@ __global__ void kl_fwd_kernel(const float* __restrict__ mu, const float* __restr
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(kl_sum, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) red[0] = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  ordered_commit(kl_sum, red, 1, sc, 0, blockIdx.x, gridDim.x);
 }
 
 __global__ void kl_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ sd, long n, const float* __restrict__ gscale,
@@ -359,9 +367,10 @@ extern "C" int ptv_chord_targets(const float* c, int B, int step_major, int* roo
 extern "C" int ptv_ce_fwd(const float* logits, long ld, const int* targets, long rows, int C, int ignore_index, float* nll_sum, void* stream) {
   if (!logits || !targets || !nll_sum || rows <= 0 || C <= 0 || C > 256) return PTV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (C <= 16) hipLaunchKernelGGL((ce_small_kernel<false>), dim3(grid_rows(rows, 256, 2048)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nll_sum, nullptr, nullptr, 0L);
-  else if (ce_vec_ok(logits, ld, C)) hipLaunchKernelGGL((ce_vec_kernel<false>), dim3(grid_rows(rows, 8, 2048)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nll_sum, nullptr, nullptr, 0L);   // (one atomicAdd on nll_sum per block: 16384 blocks spent 210 us queueing on that one address, 2048: 51 us)
-  else hipLaunchKernelGGL((ce_wave_kernel<false>), dim3(grid_rows(rows, 4, 2048)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nll_sum, nullptr, nullptr, 0L);
+  const OrdScratch sc = ord_scratch(s, 2048, 1);
+  if (C <= 16) hipLaunchKernelGGL((ce_small_kernel<false>), dim3(grid_rows(rows, 256, 2048)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nll_sum, nullptr, nullptr, 0L, sc);
+  else if (ce_vec_ok(logits, ld, C)) hipLaunchKernelGGL((ce_vec_kernel<false>), dim3(grid_rows(rows, 8, 2048)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nll_sum, nullptr, nullptr, 0L, sc);   // (one atomicAdd on nll_sum per block: 16384 blocks spent 210 us queueing on that one address, 2048: 51 us)
+  else hipLaunchKernelGGL((ce_wave_kernel<false>), dim3(grid_rows(rows, 4, 2048)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nll_sum, nullptr, nullptr, 0L, sc);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
@@ -369,16 +378,16 @@ extern "C" int ptv_ce_fwd(const float* logits, long ld, const int* targets, long
 extern "C" int ptv_ce_bwd(const float* logits, long ld, const int* targets, long rows, int C, int ignore_index, const float* gscale, float* dlogits, long ldd, void* stream) {
   if (!logits || !targets || !gscale || !dlogits || rows <= 0 || C <= 0 || C > 256) return PTV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (C <= 16) hipLaunchKernelGGL((ce_small_kernel<true>), dim3(grid_rows(rows, 256, 2048)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nullptr, gscale, dlogits, ldd);
-  else if (ce_vec_ok(logits, ld, C) && ce_vec_ok(dlogits, ldd, C)) hipLaunchKernelGGL((ce_vec_kernel<true>), dim3(grid_rows(rows, 8, 16384)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nullptr, gscale, dlogits, ldd);
-  else hipLaunchKernelGGL((ce_wave_kernel<true>), dim3(grid_rows(rows, 4, 16384)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nullptr, gscale, dlogits, ldd);
+  if (C <= 16) hipLaunchKernelGGL((ce_small_kernel<true>), dim3(grid_rows(rows, 256, 2048)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nullptr, gscale, dlogits, ldd, OrdScratch{nullptr, nullptr});
+  else if (ce_vec_ok(logits, ld, C) && ce_vec_ok(dlogits, ldd, C)) hipLaunchKernelGGL((ce_vec_kernel<true>), dim3(grid_rows(rows, 8, 16384)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nullptr, gscale, dlogits, ldd, OrdScratch{nullptr, nullptr});
+  else hipLaunchKernelGGL((ce_wave_kernel<true>), dim3(grid_rows(rows, 4, 16384)), dim3(256), 0, s, logits, ld, targets, rows, C, ignore_index, nullptr, gscale, dlogits, ldd, OrdScratch{nullptr, nullptr});
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
 
 extern "C" int ptv_kl_fwd(const float* mu, const float* sd, long n, float* kl_sum, void* stream) {
   if (!mu || !sd || !kl_sum || n <= 0) return PTV_ERR_ARG;
-  hipLaunchKernelGGL(kl_fwd_kernel, dim3(grid_rows(n, 256, 256)), dim3(256), 0, (hipStream_t)stream, mu, sd, n, kl_sum);
+  hipLaunchKernelGGL(kl_fwd_kernel, dim3(grid_rows(n, 256, 256)), dim3(256), 0, (hipStream_t)stream, mu, sd, n, kl_sum, ord_scratch((hipStream_t)stream, 256, 1));
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

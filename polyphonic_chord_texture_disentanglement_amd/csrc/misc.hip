@@ -1,4 +1,6 @@
 // misc.hip -- duration-head token kernel, chord-decoder token kernel, fused clip + Adam.
+#include <mutex>
+#include <stdlib.h>
 #include "common.hpp"
 #include "gemm_core.hpp"
 #include "../../include/ptvae_hip.h"
@@ -79,7 +81,7 @@ __global__ void transpose_cast_batched_kernel(const float* __restrict__ flat, __
   }
 }
 
-__global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+__global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out, OrdScratch sc) {
   __shared__ float red[4];
   float s = 0.f;
   const long n4 = n / 4;
@@ -91,7 +93,9 @@ __global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restr
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) red[0] = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  ordered_commit(out, red, 1, sc, 0, blockIdx.x, gridDim.x);
 }
 
 __global__ void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
@@ -207,8 +211,9 @@ extern "C" int ptv_dur_out_token(const float* h, int H, const float* w_out, cons
 // (5 separate [2 x 64] split-K products each re-launch and re-read; this reads the 5 bf16 state planes once).
 // block: 256 threads = 8 unit-octets (16-byte loads of 8 bf16) x 32 row lanes; LDS tree over the row lanes, atomics per block.
 __global__ void dur_out_wgrad_kernel(const float* __restrict__ ddur, long ld_dd, const __bf16* __restrict__ hall16, long plane_h,
-                                     float* __restrict__ gw, long rows, int H) {
+                                     float* __restrict__ gw, long rows, int H, OrdScratch sc) {
   __shared__ float red[32][2][64];
+  __shared__ float tot[128];
   const int uo = threadIdx.x & 7, rlane = threadIdx.x >> 3;
   float a0[8], a1[8];
 #pragma unroll
@@ -229,14 +234,18 @@ __global__ void dur_out_wgrad_kernel(const float* __restrict__ ddur, long ld_dd,
     const int c = threadIdx.x >> 6, u = threadIdx.x & 63;
     float s = 0.f;
     for (int q = 0; q < 32; q++) s += red[q][c][u];
-    atomicAdd(gw + c * H + u, s);
+    tot[c * 64 + u] = s;                                          // (H = 64: gw[c * H + u])
   }
+  __syncthreads();
+  ordered_commit(gw, tot, 128, sc, 0, blockIdx.x, gridDim.x);
 }
 
 extern "C" int ptv_dur_out_wgrad(const float* ddur, long ld_dd, const void* hall16, long plane_h, float* gw, long rows, int H, void* stream) {
   if (!ddur || !hall16 || !gw || rows <= 0 || H != 64 || (ld_dd & 1) || (plane_h & 7)) return PTV_ERR_ARG;
   long nb = (rows + 31) / 32; if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(dur_out_wgrad_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, ddur, ld_dd, (const __bf16*)hall16, plane_h, gw, rows, H);
+  OrdScratch sc = ord_scratch((hipStream_t)stream, 256L * 128, 1);
+  if (sc.slots && nb > 256) nb = 256;                                   // (the last block adds nb partials per output)
+  hipLaunchKernelGGL(dur_out_wgrad_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, ddur, ld_dd, (const __bf16*)hall16, plane_h, gw, rows, H, sc);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
@@ -247,7 +256,7 @@ extern "C" int ptv_grad_sumsq(const float* g, long n, float* sumsq, void* stream
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(sumsq, 0, sizeof(float), s) != hipSuccess) return PTV_ERR_LAUNCH;
   long nb = (n / 4 + 255) / 256; if (nb > 512) nb = 512; if (nb < 1) nb = 1;       // (one atomicAdd on *sumsq per block: keep the queue on that address short)
-  hipLaunchKernelGGL(sumsq_kernel, dim3((int)nb), dim3(256), 0, s, g, n, sumsq);
+  hipLaunchKernelGGL(sumsq_kernel, dim3((int)nb), dim3(256), 0, s, g, n, sumsq, ord_scratch(s, nb, 1));
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
@@ -319,7 +328,33 @@ extern "C" int ptv_transpose_cast_bf16(const float* src, void* dst, int rows, in
   return PTV_OK;
 }
 
-namespace ptv { const float* g_step_params = nullptr; }
+namespace ptv {
+const float* g_step_params = nullptr;
+int g_ordered = [] { const char* e = getenv("PTV_WGRAD_ORDERED"); return (e && e[0] == '0') ? 0 : 1; }();
+
+// scratch of the ordered grid reductions (common.hpp): one allocation per stream, made on the stream's first use -- outside any
+// capture when the captured step was warmed up first; inside a capture without a buffer the kernels fall back to atomics
+OrdScratch ord_scratch(hipStream_t s, long need_floats, int need_counters) {
+  OrdScratch none{nullptr, nullptr};
+  if (!g_ordered || need_floats > ORD_SLOT_FLOATS || need_counters > ORD_COUNTERS) return none;
+  static OrdScratch pool[64]; static hipStream_t keys[64]; static int n = 0; static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  int i = 0;
+  for (; i < n; i++) if (keys[i] == s) break;
+  if (i < n) return pool[i];
+  if (n == 64) return none;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) return none;
+  char* p = nullptr;
+  const size_t bytes = ORD_SLOT_FLOATS * sizeof(float) + ORD_COUNTERS * sizeof(unsigned);
+  if (hipMalloc(reinterpret_cast<void**>(&p), bytes) != hipSuccess) return none;
+  if (hipMemset(p + ORD_SLOT_FLOATS * sizeof(float), 0, ORD_COUNTERS * sizeof(unsigned)) != hipSuccess) return none;
+  keys[n] = s; pool[n] = OrdScratch{reinterpret_cast<float*>(p), reinterpret_cast<unsigned*>(p + ORD_SLOT_FLOATS * sizeof(float))};
+  return pool[n++];
+}
+}  // namespace ptv
+extern "C" int ptv_wgrad_mode(int ordered);
+extern "C" int ptv_ordered_reductions(int on) { ptv::g_ordered = on ? 1 : 0; return ptv_wgrad_mode(on); }
 // Launches made from now on read their per-step scalars from this device array instead of their by-value arguments (NULL: by value
 // again): [0] beta (ptv_loss_finalize / ptv_loss_bwd_scales), [1] lr, [2] 1 - beta1^t, [3] sqrt(1 - beta2^t) (ptv_clip_adam_step*).
 // A hipGraph captured while it is set replays with whatever the host has written there since (graph_step.GraphedTrainStep).

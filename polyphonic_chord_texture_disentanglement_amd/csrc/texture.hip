@@ -43,9 +43,28 @@ __global__ void txt_conv_fwd_kernel(const float* __restrict__ pr, const float* _
   }
 }
 
+__device__ __forceinline__ void ordered_commit_tx(float* dw, float* dbias, const float* acc, int C, const OrdScratch& sc) {
+  __shared__ int s_last;
+  const int L = C * 49, n = gridDim.x;
+  for (int i = threadIdx.x; i < L; i += blockDim.x) __hip_atomic_store(sc.slots + (long)blockIdx.x * L + i, acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(sc.counters, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n - 1);
+  __syncthreads();
+  if (!s_last) return;
+  for (int i = threadIdx.x; i < L; i += blockDim.x) {
+    float t = 0.f;
+    for (int b = 0; b < n; b++) t += __hip_atomic_load(sc.slots + (long)b * L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int c2 = i / 49, k = i % 49;
+    if (k < 48) dw[c2 * 48 + k] += t; else dbias[c2] += t;
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(sc.counters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // dW[ch,i,j] += sum dpool * [conv>0 at the arg-max q] * pr ; dbias likewise.  Conv is recomputed.
 __global__ void txt_conv_bwd_kernel(const float* __restrict__ pr, const float* __restrict__ w, const float* __restrict__ bias,
-                                    const float* __restrict__ dpooled, float* __restrict__ dw, float* __restrict__ dbias, int B, int C) {
+                                    const float* __restrict__ dpooled, float* __restrict__ dw, float* __restrict__ dbias, int B, int C, OrdScratch sc) {
+  __shared__ float stage[TX_MAXC * 29][7];
   __shared__ float rows[4][128];
   __shared__ float ws[TX_MAXC * 48 + TX_MAXC];
   __shared__ float acc[TX_MAXC * 49];
@@ -88,12 +107,28 @@ __global__ void txt_conv_bwd_kernel(const float* __restrict__ pr, const float* _
       }
     }
   }
-  __syncthreads();
-  if (o < nout) {
+  // the 29 pooled positions of a channel are 29 threads: their private gradients meet in LDS, 7 taps at a time, and ONE thread per
+  // (channel, tap) adds them in position order (LDS float atomics would add in arrival order)
 #pragma unroll
-    for (int k = 0; k < 49; k++) if (g[k] != 0.f) atomicAdd(&acc[ch * 49 + k], g[k]);
+  for (int kk = 0; kk < 7; kk++) {
+    __syncthreads();
+    if (o < nout) {
+#pragma unroll
+      for (int j = 0; j < 7; j++) stage[o][j] = g[kk * 7 + j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 7; i += blockDim.x) {
+      const int c2 = i / 7, j = i % 7;
+      float t = 0.f;
+      for (int q = 0; q < 29; q++) t += stage[c2 * 29 + q][j];
+      acc[c2 * 49 + kk * 7 + j] = t;
+    }
   }
   __syncthreads();
+  if (sc.slots) {                                                // acc [C][49] -> dw [C][48] | dbias [C]: one ordered vector of C*49
+    ordered_commit_tx(dw, dbias, acc, C, sc);
+    return;
+  }
   for (int i = threadIdx.x; i < C * 49; i += blockDim.x) {
     float v = acc[i];
     if (v == 0.f) continue;
@@ -119,7 +154,9 @@ extern "C" int ptv_txt_conv_relu_pool_bwd(const float* pr_mat, const float* w, c
   if (!pr_mat || !w || !bias || !dpooled || !dw || !dbias || B <= 0 || C <= 0 || C > TX_MAXC) return PTV_ERR_ARG;
   int nthreads = ((C * 29 + 63) / 64) * 64;       // one thread per (ch, pp)
   int grid = B * 8 < 512 ? B * 8 : 512;
-  hipLaunchKernelGGL(txt_conv_bwd_kernel, dim3(grid), dim3(nthreads), 0, (hipStream_t)stream, pr_mat, w, bias, dpooled, dw, dbias, B, C);
+  OrdScratch sc = ord_scratch((hipStream_t)stream, 128L * C * 49, 1);
+  if (sc.slots && grid > 128) grid = 128;                         // (the last block adds `grid` partials per tap)
+  hipLaunchKernelGGL(txt_conv_bwd_kernel, dim3(grid), dim3(nthreads), 0, (hipStream_t)stream, pr_mat, w, bias, dpooled, dw, dbias, B, C, sc);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

@@ -18,6 +18,7 @@
 // fp32 sources are rounded to bf16 on the way into LDS (the bf16 precision mode's MFMA operands, as in gemm_core.hpp).
 // Entry: ptv_wgrad (include/ptvae_hip.h); ptv_gemm routes its bf16 transA && transB calls here.
 #include <stdlib.h>
+#include <mutex>
 #include "common.hpp"
 #include "../../include/ptvae_hip.h"
 
@@ -46,7 +47,30 @@ struct WgArgs {
   const int* k_top; long k_unit;  // rows from (*k_top + 1) * k_unit on are known to be zero in A (written by the kernel that produced A), or null
   int k_rev;                     // > 0: A is stored in REVERSED unit order (k_rev units): the zero part is the rows BEFORE (k_rev - *k_top - 1) * k_unit
   int prio;                      // the launch belongs to a latency chain (ptv_gemm_priority): raised wave priority
+  float* ws;                     // ordered reduction (ptv_wgrad_mode 1): slab partials go to ws[(slab0 + slab) * tiles + tile][128][128] with plain
+  float* ws_csum;                // stores (ws_csum[(slab0 + slab) * M + m] for the column sums) and wgrad_reduce_kernel adds them up in slab
+  int slab0;                     // order; null: fp32 atomics into C (run-to-run rounding differs)
 };
+
+// which part of a slab's K range survives the k_top limits: shared by the product kernel and the ordered reduction (a slab that is
+// empty writes no partial and must not be read)
+__device__ __forceinline__ bool slab_range(const WgArgs& g, int slab, int& k_begin, int& k_end) {
+  k_begin = slab * g.kper;
+  int k_lim = g.K, k_from = 0;
+  if (g.k_top) {                                                  // (multiples of the 32-row stage whenever k_unit is)
+    if (g.k_rev > 0) {
+      const long lo = ((long)g.k_rev - *g.k_top - 1) * g.k_unit;
+      if (lo > 0) k_from = (int)min((long)g.K, lo);
+    } else {
+      const long lim = ((long)*g.k_top + 1) * g.k_unit;
+      if (lim < k_lim) k_lim = (int)lim;
+    }
+  }
+  if (k_begin >= k_lim || k_begin + g.kper <= k_from) return false;
+  k_end = min(k_lim, k_begin + g.kper);
+  if (k_from > k_begin) k_begin = k_from;                         // (k_from is a multiple of 32 like every slab start)
+  return true;
+}
 
 // one thread's share of a stage of one operand: 2 chunks of 8 columns (chunk c: row c / 16, columns (c % 16) * 8).
 // Columns at or beyond ncols only ever meet outputs that are not stored, so a chunk that straddles ncols may be read whole as long as
@@ -158,21 +182,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
   if (g.map == 1) { const int q = b >> 3; slab = (q / tiles) * 8 + (b & 7); tile = q % tiles; }
   else if (g.map == 2) { const int tx = tiles >> 3, q = b >> 3; tile = (b & 7) * tx + q % tx; slab = q / tx; }
   else { slab = b / tiles; tile = b % tiles; }
-  int k_begin = slab * g.kper;
-  int k_lim = g.K;
-  int k_from = 0;
-  if (g.k_top) {                                                  // (multiples of the 32-row stage whenever k_unit is)
-    if (g.k_rev > 0) {
-      const long lo = ((long)g.k_rev - *g.k_top - 1) * g.k_unit;
-      if (lo > 0) k_from = (int)min((long)g.K, lo);
-    } else {
-      const long lim = ((long)*g.k_top + 1) * g.k_unit;
-      if (lim < k_lim) k_lim = (int)lim;
-    }
-  }
-  if (k_begin >= k_lim || k_begin + g.kper <= k_from) return;
-  const int k_end = min(k_lim, k_begin + g.kper);
-  if (k_from > k_begin) k_begin = k_from;                         // (k_from is a multiple of 32 like every slab start)
+  int k_begin, k_end;
+  if (!slab_range(g, slab, k_begin, k_end)) return;
   const int m_blk = (tile / g.tiles_n) * WBM, n_blk = (tile % g.tiles_n) * WBN;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -264,8 +275,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int m = m_blk + wm + i * 16 + (lane >> 4) * 4 + r;
-        if (m < g.M) atomicAdd(g.csum + m, accs[i][r]);
+        if (m < g.M) {
+          if (g.ws_csum) g.ws_csum[(long)(g.slab0 + slab) * g.M + m] = accs[i][r];
+          else atomicAdd(g.csum + m, accs[i][r]);
+        }
       }
+  }
+  if (g.ws) {                                                    // ordered reduction: this slab's partial tile, plain stores
+    float* wt = g.ws + ((long)(g.slab0 + slab) * tiles + tile) * (WBM * WBN);
+    const int mrem = g.M - m_blk - wm - (lane >> 4) * 4, nrem = g.N - n_blk - wn - (lane & 15);      // rows / columns of C left from this lane's first cell
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (i * 16 + r < mrem && j * 16 < nrem)                  // (cells outside C are never read back)
+            wt[(wm + i * 16 + (lane >> 4) * 4 + r) * WBN + wn + j * 16 + (lane & 15)] = acc[i][j][r];
+    return;
   }
   const bool single = g.nslab == 1;
   const bool inner = m_blk + WBM <= g.M && n_blk + WBN <= g.N;
@@ -286,6 +313,81 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
   }
 }
 
+// ordered reduction of the slab partials: C[m][n] (+)= alpha * (p_0 + p_1 + ...) in slab order -- the same bits on every run.
+// ga: the fast launch's arguments (slabs 0 .. ga.nslab-1), gb: the guarded tail launch (one slab, number ga.nslab), if has_b.
+__global__ void wgrad_reduce_kernel(WgArgs ga, WgArgs gb, int has_a, int has_b, int accumulate) {
+  const int tiles = ga.tiles_m * ga.tiles_n;
+  // the live slabs of the fast launch are one contiguous range (the k_top limits cut K at one end): [s0, s1)
+  int s0 = 0, s1 = 0;
+  if (has_a) {
+    bool any = false;
+    for (int sl = 0; sl < ga.nslab; sl++) {
+      int kb, ke;
+      if (slab_range(ga, sl, kb, ke)) { if (!any) s0 = sl; s1 = sl + 1; any = true; }
+    }
+  }
+  bool live_b = false;
+  if (has_b) { int kb, ke; live_b = slab_range(gb, 0, kb, ke); }
+  const long tstride = (long)tiles * (WBM * WBN);
+  const float* wb = has_b ? gb.ws + (long)gb.slab0 * tstride : nullptr;
+  const bool vec = (ga.N & 3) == 0 && (ga.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(ga.C) & 15) == 0;
+  if (vec) {
+    const int N4 = ga.N >> 2;
+    const long total4 = (long)ga.M * N4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+      const int m = (int)(i / N4), n = (int)(i % N4) * 4;
+      const long off = (long)((m / WBM) * ga.tiles_n + n / WBN) * (WBM * WBN) + (long)(m % WBM) * WBN + (n % WBN);
+      const float* p = ga.ws + off;
+      float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+      int sl = s0;
+      for (; sl + 8 <= s1; sl += 8) {                               // eight partials in flight, added in slab order
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = *reinterpret_cast<const float4*>(p + (long)(sl + q) * tstride);
+#pragma unroll
+        for (int q = 0; q < 8; q++) { sum.x += v[q].x; sum.y += v[q].y; sum.z += v[q].z; sum.w += v[q].w; }
+      }
+      for (; sl < s1; sl++) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (long)sl * tstride);
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+      }
+      if (live_b) { const float4 v = *reinterpret_cast<const float4*>(wb + off); sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w; }
+      float4* cp = reinterpret_cast<float4*>(ga.C + (long)m * ga.ldc + n);
+      float4 c = accumulate ? *cp : make_float4(0.f, 0.f, 0.f, 0.f);
+      c.x += ga.alpha * sum.x; c.y += ga.alpha * sum.y; c.z += ga.alpha * sum.z; c.w += ga.alpha * sum.w;
+      *cp = c;
+    }
+  } else {
+    const long total = (long)ga.M * ga.N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      const int m = (int)(i / ga.N), n = (int)(i % ga.N);
+      const long off = (long)((m / WBM) * ga.tiles_n + n / WBN) * (WBM * WBN) + (long)(m % WBM) * WBN + (n % WBN);
+      float sum = 0.f;
+      const float* p = ga.ws + off;
+      int sl = s0;
+      for (; sl + 8 <= s1; sl += 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = p[(long)(sl + q) * tstride];
+#pragma unroll
+        for (int q = 0; q < 8; q++) sum += v[q];
+      }
+      for (; sl < s1; sl++) sum += p[(long)sl * tstride];
+      if (live_b) sum += wb[off];
+      float* cp = ga.C + (long)m * ga.ldc + n;
+      *cp = (accumulate ? *cp : 0.f) + ga.alpha * sum;
+    }
+  }
+  if (ga.ws_csum) {                                                 // the bias gradient (always accumulates)
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < ga.M; m += (long)gridDim.x * blockDim.x) {
+      float sum = 0.f;
+      for (int sl = s0; sl < s1; sl++) sum += ga.ws_csum[(long)sl * ga.M + m];
+      if (live_b) sum += gb.ws_csum[(long)gb.slab0 * ga.M + m];
+      ga.csum[m] += sum;
+    }
+  }
+}
+
 __global__ void wgrad_zero_kernel(float* C, long ldc, int M, int N) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)M * N;
@@ -296,18 +398,55 @@ __global__ void wgrad_zero_kernel(float* C, long ldc, int M, int N) {
 
 using namespace ptv;
 
+namespace ptv {
+// 1 (default): slab partials through a workspace + ordered reduction (bit-reproducible, and no fp32 atomics: they retire at
+// ~1e11 elements/s, a fifth of the time of the deep products); 0: atomics into C
+static int g_wgrad_mode = [] { const char* e = getenv("PTV_WGRAD_ORDERED"); return (e && e[0] == '0') ? 0 : 1; }();
+
+// grow-only workspace per stream: launches on one stream are ordered, so the next product's partials cannot overtake this one's
+// reduction; two streams never share a buffer.  (Allocation happens on a stream's first large product -- never inside a captured
+// graph if the capture was preceded by a warm-up of the same step.)
+struct WsBuf { float* p = nullptr; size_t bytes = 0; };
+static WsBuf* ws_for(hipStream_t s, size_t bytes) {
+  static WsBuf pool[64];
+  static hipStream_t keys[64];
+  static int n = 0;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  int i = 0;
+  for (; i < n; i++) if (keys[i] == s) break;
+  if (i == n) { if (n == 64) return nullptr; keys[n++] = s; pool[i] = WsBuf{}; }
+  WsBuf& b = pool[i];
+  if (b.bytes < bytes) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) return nullptr;   // cannot grow inside a capture
+    if (b.p) { if (hipStreamSynchronize(s) != hipSuccess) return nullptr; (void)hipFree(b.p); }
+    size_t want = bytes + bytes / 4;
+    if (hipMalloc(reinterpret_cast<void**>(&b.p), want) != hipSuccess) { b = WsBuf{}; return nullptr; }
+    b.bytes = want;
+  }
+  return &b;
+}
+}  // namespace ptv
+
+namespace ptv { extern int g_splitk_ordered; }
+extern "C" int ptv_wgrad_mode(int ordered) { ptv::g_wgrad_mode = ptv::g_splitk_ordered = ordered ? 1 : 0; return PTV_OK; }
+
 extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const void* B, long ldb, float* C, long ldc, float alpha,
                          int accumulate, int dtypes, int slabs, float* colsum_a, const int* k_top, long k_unit, int k_rev, void* stream) {
   if (M < 0 || N < 0 || K < 0 || !A || !B || !C) return PTV_ERR_ARG;
   if (k_top && (k_unit <= 0 || k_unit % WBK)) return PTV_ERR_ARG;
   if (M == 0 || N == 0) return PTV_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate) {
-    const long total = (long)M * N;
-    int nb = (int)((total + 255) / 256); if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(wgrad_zero_kernel, dim3(nb), dim3(256), 0, s, C, ldc, M, N);
+  if (K == 0) {
+    if (!accumulate) {
+      const long total = (long)M * N;
+      int nb = (int)((total + 255) / 256); if (nb > 2048) nb = 2048;
+      hipLaunchKernelGGL(wgrad_zero_kernel, dim3(nb), dim3(256), 0, s, C, ldc, M, N);
+    }
+    PTV_CHECK_LAUNCH();
+    return PTV_OK;
   }
-  if (K == 0) { PTV_CHECK_LAUNCH(); return PTV_OK; }
   const bool af = !(dtypes & 1), bf = !(dtypes & 2);
   const bool vec = (lda % (af ? 4 : 8) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
                    (ldb % (bf ? 4 : 8) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
@@ -317,9 +456,13 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
   const int kfast = !vec ? 0 : (odd ? ((K - 1) / WBK) * WBK : (K / WBK) * WBK);
   static const int nset_env = [] { const char* e = getenv("PTV_WGRAD_NSET"); return e ? atoi(e) : 0; }();
   const int nset = (af || bf) ? 2 : (nset_env == 4 ? 4 : 2);       // 4 register sets only fit with bf16 sources
-  auto launch = [&](bool guard, int k0, int kn, int want_slabs) {
+  WgArgs sent[2]; int nsent[2] = {0, 0};
+  float* ws = nullptr; float* ws_csum = nullptr; int ws_slabs = 0;
+  bool zeroed = false;
+  auto launch = [&](bool guard, int k0, int kn, int want_slabs, int pass) -> int {
     WgArgs g{static_cast<const char*>(A) + (long)k0 * lda * (af ? 4 : 2), lda, static_cast<const char*>(B) + (long)k0 * ldb * (bf ? 4 : 2), ldb,
-             C, ldc, M, N, kn, 0, cdiv(M, WBM), cdiv(N, WBN), 1, 0, alpha, colsum_a, k0 == 0 ? k_top : nullptr, k_unit, k_rev, g_gemm_prio};
+             C, ldc, M, N, kn, 0, cdiv(M, WBM), cdiv(N, WBN), 1, 0, alpha, colsum_a, k0 == 0 ? k_top : nullptr, k_unit, k_rev, g_gemm_prio,
+             nullptr, nullptr, 0};
     const int tiles = g.tiles_m * g.tiles_n;
     // slab count (measured optima of scripts/bench_wgrad.py sweep on MI355X).  Every slab pays M*N atomics, and a grid that is
     // just over one block per CU leaves a tail, so: about one block per CU (never more) for the skinny, HBM-bound products;
@@ -341,6 +484,18 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
     g.kper = cdiv(cdiv(kn, ns), WBK) * WBK;
     if (g.map != 1) ns = cdiv(kn, g.kper);
     g.nslab = ns;
+    if (pass == 0) {                                             // planning pass: slab counts only
+      sent[guard ? 1 : 0] = g; nsent[guard ? 1 : 0] = ns;
+      return PTV_OK;
+    }
+    if (ws) { g.ws = ws; g.ws_csum = colsum_a ? ws_csum : nullptr; g.slab0 = guard ? nsent[0] : 0; }
+    else if (!accumulate && !zeroed) {
+      const long total = (long)M * N;
+      int nb = (int)((total + 255) / 256); if (nb > 2048) nb = 2048;
+      hipLaunchKernelGGL(wgrad_zero_kernel, dim3(nb), dim3(256), 0, s, C, ldc, M, N);
+      zeroed = true;
+    }
+    sent[guard ? 1 : 0] = g;
     const dim3 grid((unsigned)(tiles * ns));
 #define WG_LAUNCH(AF, BF)                                                                                      \
     do {                                                                                                       \
@@ -353,9 +508,31 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
     else if (bf) WG_LAUNCH(false, true);
     else WG_LAUNCH(false, false);
 #undef WG_LAUNCH
+    return PTV_OK;
   };
-  if (kfast > 0) launch(false, 0, kfast, slabs);
-  if (kfast < K) launch(true, kfast, K - kfast, kfast > 0 ? 1 : slabs);
+  const bool has_a = kfast > 0, has_b = kfast < K;
+  if (has_a) launch(false, 0, kfast, slabs, 0);
+  if (has_b) launch(true, kfast, K - kfast, has_a ? 1 : slabs, 0);
+  const int total_slabs = nsent[0] + nsent[1];
+  // one slab in all: the product kernel is the only writer of every element (plain read-modify-write, already reproducible)
+  if (g_wgrad_mode == 1 && total_slabs > 1) {
+    const int tiles = cdiv(M, WBM) * cdiv(N, WBN);
+    const size_t tile_bytes = (size_t)total_slabs * tiles * WBM * WBN * sizeof(float);
+    const size_t sum_bytes = colsum_a ? (size_t)total_slabs * M * sizeof(float) : 0;
+    WsBuf* wb = ws_for(s, tile_bytes + sum_bytes);
+    if (wb) { ws = wb->p; ws_csum = colsum_a ? wb->p + tile_bytes / sizeof(float) : nullptr; ws_slabs = total_slabs; }
+  }
+  if (has_a) launch(false, 0, kfast, slabs, 1);
+  if (has_b) launch(true, kfast, K - kfast, has_a ? 1 : slabs, 1);
+  if (ws) {
+    const bool vec4 = (N & 3) == 0 && (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+    const long total = vec4 ? ((M * (long)N) >> 2) : M * (long)N;
+    int nb = (int)((total + 255) / 256); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
+    // (the guarded launch alone -- unaligned operands -- may have many slabs: it then plays the fast launch's part in the reduction)
+    if (!has_a) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, s, sent[1], sent[1], 1, 0, accumulate);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, s, sent[0], sent[1], 1, has_b ? 1 : 0, accumulate);
+  }
+  (void)ws_slabs;
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

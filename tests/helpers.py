@@ -11,7 +11,8 @@ import torch
 # max |g| per element (worst tensor: the conv bias, 49-way atomics), 2.4e-8 relative on the global norm, <= 3.8e-6 absolute on a
 # loss.  ATOMICS_RTOL is that floor with a 7x margin; tests that compare two HIP runs of the same step (not HIP vs oracle) use it.
 # bf16: reordered partial sums flip roundings of bf16-stored operands: 9.7e-4 of a tensor's max measured, ATOMICS_RTOL_BF16.
-# Under PTV_DETERMINISTIC=1 the reductions are ordered and the floor is 0.
+# That is the PTV_WGRAD_ORDERED=0 mode.  With the default ordered reductions (ptv_ordered_reductions) the floor is 0: two runs of a
+# step give the same bits (tests/test_gpu_model.py::test_two_runs_of_a_training_trace_are_bit_identical).
 ATOMICS_RTOL = 1e-5
 ATOMICS_RTOL_BF16 = 5e-3
 # One Adam step turns a gradient perturbation d into a parameter perturbation of up to lr * d / (|g| + eps): for |g| ~ eps = 1e-8 a

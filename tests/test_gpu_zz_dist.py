@@ -19,7 +19,7 @@ from test_host_surface import build_reduced
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 LR = 1e-3
-DETERMINISTIC = os.environ.get('PTV_DETERMINISTIC', '0') == '1'
+DETERMINISTIC = os.environ.get('PTV_WGRAD_ORDERED', '1') != '0'      # ordered reductions (include/ptvae_hip.h: ptv_ordered_reductions), the default
 G_TOL = 0.0 if DETERMINISTIC else ATOMICS_RTOL
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -98,20 +98,20 @@ def test_two_process_arena_all_reduce_matches_mean_of_shards(tmp_path, early):
         want_g, gn = want_g.cpu(), float(opt.grad_norm())
         p_tol = LR * ADAM_NOISE_FRAC_OF_LR * (step + 1)
         for r in range(world):
-            np.testing.assert_allclose(got[r]['losses.%d' % step], want_losses, rtol=0, atol=2e-6 if step == 0 else 2e-5)
+            np.testing.assert_allclose(got[r]['losses.%d' % step], want_losses, rtol=0, atol=2e-6 if (step == 0 or DETERMINISTIC) else 2e-5)
             if step == 0:
                 # what the exchange itself must get right, at the run-to-run noise floor of the fp32 atomics in the weight-gradient
-                # kernels (helpers.ATOMICS_RTOL; 0 under PTV_DETERMINISTIC=1): the averaged bucket, per parameter tensor
+                # kernels (helpers.ATOMICS_RTOL with PTV_WGRAD_ORDERED=0; exactly 0 with the default ordered reductions): the averaged bucket, per parameter tensor
                 for p_, o in zip(opt.arena.params, opt.arena.offsets):
                     w = want_g[o:o + p_.numel()]
                     d = (got[r]['flat_g.0'][o:o + p_.numel()] - w).abs().max()
                     assert d <= G_TOL * max(float(w.abs().max()), 1e-30), (o, float(d), float(w.abs().max()))
                 assert abs(got[r]['gnorm.0'] - gn) <= max(G_TOL, 1e-9) * gn
             else:
-                assert abs(got[r]['gnorm.%d' % step] - gn) <= 1e-3 * gn      # step 2 starts from parameters that differ by Adam-amplified noise
+                assert abs(got[r]['gnorm.%d' % step] - gn) <= (1e-6 if DETERMINISTIC else 1e-3) * gn      # (atomics: step 2 starts from parameters that differ by Adam-amplified noise)
             # Adam's first steps are lr * g / (|g| + eps): a reordering of 1e-10 on a gradient near eps moves the parameter by
             # ~lr * 1e-2, so parameters are held to a fraction of lr, never to the gradients' own tolerance
-            assert (got[r]['flat_p.%d' % step] - opt.flat_p.cpu()).abs().max() <= (0.0 if DETERMINISTIC and step == 0 else p_tol)
+            assert (got[r]['flat_p.%d' % step] - opt.flat_p.cpu()).abs().max() <= (0.0 if DETERMINISTIC else p_tol)
         assert torch.equal(got[0]['flat_p.%d' % step], got[1]['flat_p.%d' % step])      # replicas stay bit-identical
 
 
