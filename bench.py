@@ -330,6 +330,7 @@ def main():
     ap.add_argument('--batch', type=int, default=512, help='per-GPU batch (weak scaling)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true', help='skip the golden-vector parity block of the benched dtype')
     ap.add_argument('--no-extras', action='store_true', help='skip the side figures (tfr=0 train, trainer surface, fp32, decode)')
     ap.add_argument('--graph', action='store_true', help='decode mode: replay the step loop from a captured hipGraph')
     ap.add_argument('--tfr', type=float, default=1.0, help='teacher-forcing ratio (1 = configs[1]; 0 = free-running training)')
@@ -470,7 +471,7 @@ def main():
                 res['extra'] = extras(dev, B, rank)
             except Exception as e:                             # side figures must never cost the headline line
                 res['extra'] = {'error': repr(e)}
-        if world == 1 and args.mode == 'train':
+        if world == 1 and args.mode == 'train' and not args.no_parity:
             try:
                 res['parity'] = {'benched': golden_parity(args.precision, dev), 'fp32_path': golden_parity('fp32', dev) if args.precision != 'fp32' else None,
                                  'bar': 'north_star: losses within 1e-4 of the CPU reference in fp32; bf16 = bf16 MFMA operands + bf16-stored saved tensors'}

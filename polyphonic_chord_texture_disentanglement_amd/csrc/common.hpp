@@ -64,6 +64,9 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // ---- ordered grid reductions (ptv_wgrad_mode / PTV_WGRAD_ORDERED, default on): instead of ending in one fp32 atomicAdd per block
 // (summation order = arrival order: the last bits differ from run to run), every block parks its partial in a per-stream scratch
 // slot and the LAST block to arrive adds the partials in block order.  slots == nullptr: the atomics.
+// Hand-off without fences (an agent-scope release is an L2 write-back on a multi-XCD part, one per block): partials go out as
+// write-through sc1 stores, the wave waits for their acknowledgement (vmcnt), one lane bumps the counter (relaxed), and the last block
+// reads them with agent-scope loads -- the recipe of the persistent recurrences (gru_persist.hip).
 struct OrdScratch { float* slots; unsigned* counters; };
 constexpr long ORD_SLOT_FLOATS = 1L << 20;     // 4 MB of partials per stream
 constexpr int ORD_COUNTERS = 256;
@@ -80,9 +83,9 @@ __device__ __forceinline__ void ordered_commit(float* out, const float* part, in
   __shared__ float s_red[16];
   float* base = sc.slots + (long)group * n * L;
   for (int i = threadIdx.x; i < L; i += blockDim.x) __hip_atomic_store(base + (long)idx * L + i, part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the write-through (sc1) stores above are acknowledged ...
   __syncthreads();
-  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(sc.counters + group, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n - 1);
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(sc.counters + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n - 1);
   __syncthreads();
   if (!s_last) return;
   if (L == 1) {                                                   // a scalar: the whole block adds (fixed strides + fixed tree = fixed order)

@@ -128,16 +128,33 @@ __global__ void colsum_kernel(float* out, const void* __restrict__ A, long lda, 
     const int L = G * 64, n = gridDim.y;
     float* base = sc.slots + (long)blockIdx.x * n * L;
     for (int i = threadIdx.x; i < L; i += blockDim.x) __hip_atomic_store(base + (long)blockIdx.y * L + i, tot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(sc.counters + blockIdx.x, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n - 1);
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(sc.counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n - 1);
     __syncthreads();
     if (s_last) {
+      // the partials [n][G][64] are summed the way the rows were: row lane ry takes partials ry, ry + 16, ... (float4 per column quad),
+      // then the 16 lanes meet in LDS in lane order -- a fixed association, 16 loads in flight per column quad
+      for (int g = 0; g < G; g++) {
+        float a4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int b = ry; b < n; b += 16) {
+          const float* q = base + (long)b * L + g * 64 + cq * 4;      // (agent-scope loads: other XCDs' L2s wrote these)
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = __hip_atomic_load(q + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int e = 0; e < 4; e++) a4[e] += v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) red[g][ry][cq * 4 + e] = a4[e];
+      }
+      __syncthreads();
       for (int i = threadIdx.x; i < L; i += blockDim.x) {
         const int g = i / 64, c = i % 64;
         if (blockIdx.x * 64 + c >= N) continue;
         float s2 = 0.f;
-        for (int b = 0; b < n; b++) s2 += __hip_atomic_load(base + (long)b * L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int y = 0; y < 16; y++) s2 += red[g][y][c];
         out[(long)g * N + blockIdx.x * 64 + c] += s2;
       }
       if (threadIdx.x == 0) __hip_atomic_store(sc.counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -362,9 +379,10 @@ extern "C" int ptv_colsum(float* out, const void* A, long lda, long rows, int N,
   int gx = cdiv(N, 64);
   long want = 2048 / gx; if (want < 1) want = 1;                 // ~2048 blocks in flight
   long gy = (rows + 63) / 64; if (gy > want) gy = want; if (gy < 1) gy = 1;
-  const bool vec = ((lda & 3) == 0) && ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & (a_bf16 ? 7 : 15)) == 0);
-  OrdScratch sc = ord_scratch((hipStream_t)stream, (long)gx * 64 * G * 64, gx);
-  if (sc.slots && gy > 64) gy = 64;                               // (the last row block adds gy partials per column)
+  // 16-byte loads need whole column quads inside the row: N a multiple of 4, or rows padded up to one (the 130 pitch logits live in
+  // 136-float rows; whatever the padding holds only meets sums that are never stored)
+  const bool vec = ((lda & 3) == 0) && (lda >= ((N + 3) & ~3)) && ((reinterpret_cast<uintptr_t>(A) & (a_bf16 ? 7 : 15)) == 0);
+  OrdScratch sc = ord_scratch((hipStream_t)stream, (long)gx * gy * G * 64, gx);
   if (vec) hipLaunchKernelGGL((colsum_kernel<true>), dim3(gx, (int)gy), dim3(256), 0, (hipStream_t)stream, out, A, lda, rows, N, sel, G, a_bf16, sc);
   else hipLaunchKernelGGL((colsum_kernel<false>), dim3(gx, (int)gy), dim3(256), 0, (hipStream_t)stream, out, A, lda, rows, N, sel, G, a_bf16, sc);
   PTV_CHECK_LAUNCH();

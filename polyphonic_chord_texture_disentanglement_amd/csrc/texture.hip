@@ -47,9 +47,9 @@ __device__ __forceinline__ void ordered_commit_tx(float* dw, float* dbias, const
   __shared__ int s_last;
   const int L = C * 49, n = gridDim.x;
   for (int i = threadIdx.x; i < L; i += blockDim.x) __hip_atomic_store(sc.slots + (long)blockIdx.x * L + i, acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(sc.counters, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n - 1);
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(sc.counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n - 1);
   __syncthreads();
   if (!s_last) return;
   for (int i = threadIdx.x; i < L; i += blockDim.x) {

@@ -93,7 +93,7 @@ def weight_shadow(p):
     if opt is None or ent[2] != p.numel() or not p.is_contiguous():
         return None
     off = ent[1]
-    opt.refresh_shadow_if_stale()
+    opt.refresh_if_param_stale(p)
     if off in opt._row_padded:                       # rows not a multiple of 8 elements: separate row-padded copy
         return opt._row_padded[off][1][:, :p.shape[1]]
     return opt.flat_p16[off:off + p.numel()].view(p.shape)
@@ -109,7 +109,7 @@ def weight_shadow_t(p):
     off = ent[1]
     if off not in opt._mat_offsets:
         return None
-    opt.refresh_shadow_if_stale()
+    opt.refresh_if_param_stale(p)
     if opt._t_event is not None:
         from . import functional as F_
         F_.wait_event(torch.cuda.current_stream(), opt._t_event)
@@ -182,6 +182,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         self.step_count = 0
         self._dirty = 0
         self._shadow_stamp = None
+        self._fast_key, self._pver = None, {}
         self._t_event = None            # recorded after the last transposed-shadow refresh when that ran on a sibling stream
         self._plain_stamp = None        # stamp at which flat_p16 (the untransposed bf16 copy) was last written
         self.grad_scale = 1.0           # set to 1/world_size when the bucket holds a SUM over ranks
@@ -198,8 +199,20 @@ class FusedClipAdam(torch.optim.Optimizer):
         if self._shadow_stamp != self._stamp():
             self.refresh_shadow()
 
+    def refresh_if_param_stale(self, p):
+        """per-weight form of the check (runs ~60 times per step): the copies of p are current iff no optimiser step / mark_dirty()
+        happened since the last refresh AND p itself was not written in place since (its version counter; aliases share it) -- the
+        full stamp sums the version counters of all 81 parameters (8 us a time)"""
+        if self._fast_key == (self.step_count, self._dirty) and self._pver.get(p.data_ptr()) == p._version:
+            return
+        self.refresh_shadow_if_stale()
+        if self._pver.get(p.data_ptr()) != p._version:       # the stamp was unchanged but this check failed: p is an unknown alias
+            self._pver[p.data_ptr()] = p._version
+
     def refresh_shadow(self):
         self._shadow_stamp = self._stamp()
+        self._fast_key = (self.step_count, self._dirty)
+        self._pver = {q.data_ptr(): q._version for q in self.arena.params}
         st = stream_ptr()
         if self._plain_stamp != self._shadow_stamp:          # (after an optimiser step the Adam kernel has written flat_p16 already)
             call('ptv_cast_bf16', ptr(self.flat_p), ptr(self.flat_p16), self.arena.total, st)

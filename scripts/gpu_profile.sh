@@ -7,6 +7,6 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$tag
 # NSTEPS = steps + warmup of the run (for the per-step figures of the summary); default run: 5 + 2
 case " $* " in *" --steps "*) args="$*";; *) args="--steps 5 --warmup 2 $*";; esac
-timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/$tag -o r -- python3 bench.py --no-cpu-baseline $args > gpurun_out/$tag/bench.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/$tag -o r -- python3 bench.py --no-cpu-baseline --no-parity $args > gpurun_out/$tag/bench.log 2>&1
 grep '"metric"' gpurun_out/$tag/bench.log | cut -c1-330
-python3 scripts/rocpd_summary.py gpurun_out/$tag/r_results.db gpurun_out/$tag/summary.md ${NSTEPS:-7} "$tag" "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline $args" | head -34 | cut -c1-200
+python3 scripts/rocpd_summary.py gpurun_out/$tag/r_results.db gpurun_out/$tag/summary.md ${NSTEPS:-7} "$tag" "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-parity $args" | head -34 | cut -c1-200

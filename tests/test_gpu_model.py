@@ -74,6 +74,10 @@ def test_full_config_vs_reference_golden(case):
 
 
 def test_bf16_path_tracks_fp32_loss():
+    """the benched dtype against the reference-generated golden (full geometry, B = 16).  Measured with scripts/bf16_parity.py
+    (profiles/r03_bf16_parity.jsonl): max |d loss| 2.1e-5 over the 11 losses, global gradient norm 6.2e-5 relative, worst
+    per-tensor gradient norm 6.1e-4 relative -- the bf16 path (bf16 MFMA operands AND bf16-stored saved tensors) meets the
+    north-star 1e-4 loss bar on this fixture; bounds = 3x the measured values (the reductions are ordered: the values reproduce)"""
     g = load_npz('full_tf1_b16.npz')
     x, c, pr = synth_batch(int(g['B']), int(g['data_seed']))
     m = M.DisentangleVAE.init_model(torch.device(DEV))
@@ -81,11 +85,15 @@ def test_bf16_path_tracks_fp32_loss():
     m.to(DEV).set_precision('bf16')
     outs, losses = _run(m, g, x, c, pr)
     got = np.array([l.item() for l in losses])
-    np.testing.assert_allclose(got, g['losses'], rtol=0, atol=2e-2)       # bf16 operands: loss-curve tolerance
+    np.testing.assert_allclose(got, g['losses'], rtol=0, atol=1e-4)       # the north-star bar
+    np.testing.assert_allclose(got, g['losses'], rtol=0, atol=6e-5)       # 3x measured
     losses[0].backward()
     tot = sum(float(p.grad.double().pow(2).sum()) for p in m.parameters()) ** 0.5
     ref = sum(float(g['gnorm.' + k]) ** 2 for k, _ in m.named_parameters()) ** 0.5
-    assert abs(tot - ref) < 0.05 * ref
+    assert abs(tot - ref) < 2e-4 * ref
+    for k, p in m.named_parameters():
+        gn, r = float(p.grad.double().pow(2).sum().sqrt()), float(g['gnorm.' + k])
+        assert abs(gn - r) <= 1e-7 + 2e-3 * r, (k, gn, r)
 
 
 def test_fresh_batch_vs_oracle_with_weighted_outputs():
