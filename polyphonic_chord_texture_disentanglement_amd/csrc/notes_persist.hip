@@ -23,6 +23,12 @@
 
 namespace ptv {
 
+// The saved gate planes are private to this file's forward / BPTT pair and live UNIT-BLOCKED: plane[(u / 32)][row][u % 32].  A lane of the
+// epilogue owns 8 consecutive units of a row and the 4 lane groups of a wave 32 of them, so in a row-major plane a wave instruction
+// touches 16 rows x 64 bytes -- half a cache line per row; blocked it is ONE contiguous kilobyte.  Measured at R = 16384, T = 15:
+// forward 999 -> 973 us, dense BPTT 1245 -> 1090 us (scripts/bench_notes.py).
+__device__ __forceinline__ long gate_off(long row, int u, long R) { return ((long)(u >> 5) * R + row) * 32 + (u & 31); }
+
 constexpr int NE = 128, NRP = 64;                    // input (token) width, rows per workgroup
 constexpr int NT16LD = NE + 16;                      // bf16 LDS row strides (+16): conflict-free b128 fragment reads
 
@@ -87,7 +93,7 @@ struct RowGruFwdArgs {
   const float* x; long x_step;     // fed tokens fp32: x + t*x_step + row*128
   const int* lengths;              // [R] or null: row m is updated at time t iff t < lengths[m]
   float* HN; __bf16* HN16;         // [T+1][R][H]; slot 0 of HN written by the caller
-  __bf16* gates;                   // [T][4][R][H] or null
+  __bf16* gates;                   // [T][4][H/32][R][32] (unit-blocked planes, see gate_off) or null
   float* out; long out_ld;         // final state -> out[row*out_ld + unit], or null
   int R, T, reverse, dbg;
   int skip;                        // pass over the steps beyond the longest row of the panel (EMB with lengths)
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
             st_f32x8(a.HN + o, h);                                       // read back next step: default policy
             stnt_bf16x8(a.HN16 + o, h);
             if (a.gates) {
-              __bf16* gp = a.gates + (long)n * 4 * RH + grow[mh + i] * H + u;
+              __bf16* gp = a.gates + (long)n * 4 * RH + gate_off(grow[mh + i], u, R);
               stnt_bf16x8(gp, r); stnt_bf16x8(gp + RH, z); stnt_bf16x8(gp + 2 * RH, nn); stnt_bf16x8(gp + 3 * RH, hn);
             }
             }
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowG
       const int pr = it >> 2, i = it & 3;
       const int u = (wave * NTW + pr * 2) * 16 + eq * 8;
       const long base = (long)s * RH + grow[i] * H + u;
-      const __bf16* gp = a.gates + (long)s * 4 * RH + grow[i] * H + u;
+      const __bf16* gp = a.gates + (long)s * 4 * RH + gate_off(grow[i], u, R);
 #pragma unroll
       for (int q = 0; q < 4; q++) o.g[q] = ldnt_bf16x8(gp + q * RH);
       if constexpr (!EMB) o.ex = ldnt_bf16x8(a.ext + base);

@@ -868,8 +868,9 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
         gru_persist_bwd(M, H, T, chains)
         g1, dx1 = side(lambda: products(1, chains[1]['dgi'], chains[1]['dgh']), xf, dout, chains[1]['dgi'], chains[1]['dgh'])
         g0, dx0 = products(0, chains[0]['dgi'], chains[0]['dgh'])
-    elif ((row_gru_ok(prec, H, I, M, adt) or len(saved[0]) > 3) and saved[0][1].dtype == BF16 and saved[0][2] is not None):
-        # (a forward that ran on the row kernels with lengths left the gates of skipped panel steps unwritten: same kernels back)
+    elif (len(saved[0]) > 3 and saved[0][1].dtype == BF16 and saved[0][2] is not None):
+        # (a forward that ran on the row kernels -- a 4-entry saved state -- left its gates in their private unit-blocked layout, and with
+        # lengths the gates of skipped panel steps unwritten: same kernels back)
         def rows(d):
             w_ih, w_hh = w[4 * d], w[4 * d + 1]
             hall, gates, h16 = saved[d][:3]
@@ -1158,7 +1159,9 @@ class DecoderTFFn(torch.autograd.Function):
         GC = gemm(NSf_op, w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec, out_dtype=adt)      # [R, 3Hn]
         gates_n = _empty(15, 4, R, Hn, dev=dev, dtype=adt)
         HN16 = _hall16(prec, 16, R, Hn, dev)
+        gates_n_rowk = False
         if notes_persist_ok(prec, Hn, E, adt) and emb3.dtype == F32 and emb3.is_contiguous():
+            gates_n_rowk = True
             # ONE launch for the 15 note steps, 64 rows per workgroup, token product fused (csrc/notes_persist.hip)
             pk = notes_packs(P['dec_notes_gru.weight_ih_l0'], P['dec_notes_gru.weight_hh_l0'], Ht)
             call('ptv_notes_gru_persist_fwd', ptr(pk['wg_h']), ptr(pk['wg_t']), ptr(P['dec_notes_gru.bias_hh_l0']), ptr(GC), ptr(emb3),
@@ -1213,7 +1216,7 @@ class DecoderTFFn(torch.autograd.Function):
         S.save_for_backward(z, emb, *params)
         S.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in, NS16=NS16, HN16=HN16,
                     HD16=HD16,
-                    TOKS=TOKS, gates_t=gates_t, HN=HN, gates_n=gates_n, pitch=pitch, HD=HD, gates_d=gates_d, idx=idx,
+                    TOKS=TOKS, gates_t=gates_t, HN=HN, gates_n=gates_n, gates_n_rowk=gates_n_rowk, pitch=pitch, HD=HD, gates_d=gates_d, idx=idx,
                     dur16_only=bool(prec == 1 and Hd == 64 and FUSED_DUR and HD16 is not None))   # HD[1:] never written
         S.mark_non_differentiable(idx)
         return pitch.view(15, 32, B, NP), dur, idx
@@ -1356,7 +1359,8 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     mark('dec_bwd:head_dx')
     # ---- notes GRU (15 steps, batch 32*B) ----
     w_hh_n, w_ih_n = W['dec_notes_gru.weight_hh_l0'], W['dec_notes_gru.weight_ih_l0']
-    if (notes_persist_ok(prec, Hn, E, st['gates_n'].dtype) and dNSUM.dtype == BF16 and HN.dtype == F32):
+    if (st.get('gates_n_rowk') and notes_persist_ok(prec, Hn, E, st['gates_n'].dtype) and dNSUM.dtype == BF16 and HN.dtype == F32):
+        # (the forward ran on the row kernel: its gate planes are in that kernel pair's private layout)
         pk = notes_packs(w_ih_n, w_hh_n, Ht)
         dgi_n = _empty(15, R, 3 * Hn, dev=dev, dtype=BF16)
         dgh_n = _empty(15, R, Hn, dev=dev, dtype=BF16)          # n third only: the r / z thirds of dgh are dgi's

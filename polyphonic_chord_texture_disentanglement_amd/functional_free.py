@@ -336,7 +336,7 @@ class DecoderStepFn(torch.autograd.Function):
         if train:
             ctx.save_for_backward(z, emb, *params)
             ctx.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in, TOKS=TOKS,
-                          gates_t=gates_t, HN=HN, gates_n=gates_n, pitch=pitch, HD=HD, gates_d=gates_d, idx=idx, TOK=TOK,
+                          gates_t=gates_t, HN=HN, gates_n=gates_n, gates_n_rowk=bool(replay), pitch=pitch, HD=HD, gates_d=gates_d, idx=idx, TOK=TOK,
                           PRED=PRED, xhat=xhat, XH=XH, XG=XG, XH16=XH16, plen=plen, skipped=F_.ZERO_SKIP, coins=coins, has_xs=xs is not None,
                           NS16=NS16, HN16=HN16, HD16=HD16, dur16_only=HD16 is not None)
         ctx.mark_non_differentiable(xhat, idx)
