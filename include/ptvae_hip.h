@@ -56,6 +56,10 @@ int ptv_abi_version(void);
  *   transB = 0: B[n*ldb + k] (nn.Linear weight layout)   1: B[k*ldb + n]
  *   act: 0 none, 1 exp (linear_var(...).exp_(), ptvae.py:27,120)
  *   splitk: 0 auto, >0 forced number of K splits, <0 never split
+ *   dtypes: bit 0 / 1 / 2 = A / B / C hold bf16 (bf16 precision only); bit 3 (8) = C is COLUMN-BLOCKED by 32: element (m, n) lives at
+ *           ((n / 32) * M + m) * 32 + n % 32 (ldc unused, N a multiple of 32, no K split) -- the layout in which the row-partitioned
+ *           recurrences (ptv_notes_gru_persist_fwd: gc) read their per-row operands: a wave touches one contiguous kilobyte instead of
+ *           16 half cache lines
  */
 int ptv_gemm(int prec, int transA, int transB, int M, int N, int K,
              const void* A, long lda, const void* B, long ldb,
@@ -372,7 +376,8 @@ int ptv_free_resummarize(const void* const* w, const void* const* io, int B, int
  * as row-partitioned persistent kernels (csrc/notes_persist.hip): ONE launch for the whole sequence, a workgroup owns 64 rows,
  * the state stays on the CU, W_hh streams from L2 in ptv_pack_mfma_b packing, the token product is fused.  bf16 precision,
  * Hn = 512, E = 128.
- *   fwd: wg_h = pack(W_hh [1536,512]), wg_t = pack(W_ih[:, Ht:] [1536,128]); gc bf16 [R][1536] = W_ih[:, :Ht] ns + b_ih;
+ *   fwd: wg_h = pack(W_hh [1536,512]), wg_t = pack(W_ih[:, Ht:] [1536,128]); gc bf16 = W_ih[:, :Ht] ns + b_ih, the [R][1536] matrix
+ *        stored COLUMN-BLOCKED by 32 ([48][R][32]: ptv_gemm dtypes bit 3 writes it that way; read once per step, 11 % of the launch);
  *        emb fp32 [T][R][128] fed tokens; HN fp32 [T+1][R][512] (slot 0 written by the caller), HN16 bf16 same shape (all slots
  *        written here), gates bf16 [T][4] planes (r, z, n, W_hn h + b_hn) or NULL -- PRIVATE to this forward / BPTT pair: each plane is
  *        unit-blocked, plane[u / 32][row][u % 32] (whole-kilobyte wave accesses), not the [R][512] of ptv_gru_seq_fwd.

@@ -19,9 +19,14 @@ struct EpiPlain {
     int act;          // 0 none, 1 exp
     int atomic;       // split-K partial sums: atomicAdd into C (C pre-initialised, fp32 only)
     int c_bf16;       // C holds bf16
+    int c_blocked;    // C is COLUMN-BLOCKED by 32: element (m, n) at ((n / 32) * c_rows + m) * 32 + n % 32 (ldc unused) -- the layout the
+    int c_rows;       // row-partitioned recurrences read their per-row operands in (one contiguous kilobyte per wave access)
     long split_stride;   // ordered split-K: split z stores its partial at C + z * split_stride floats (C = a workspace, ldc = N);
                          // splitk_reduce_kernel adds the partials in split order
   };
+  static __device__ __forceinline__ long coff(const Params& p, int m, int n) {
+    return p.c_blocked ? ((long)(n >> 5) * p.c_rows + m) * 32 + (n & 31) : (long)m * p.ldc + n;
+  }
   // a row tile that lies in the declared-zero part of A (GemmArgs::m_top): accumulating or atomically adding zero changes nothing
   static __device__ __forceinline__ bool dead_is_noop(const Params& p) { return (p.accumulate || p.atomic) && p.act == 0 && p.bias == nullptr; }
   template <int FM, int FN, int NG> struct Pre {};
@@ -37,7 +42,7 @@ struct EpiPlain {
     if (q.split_stride) q.C = reinterpret_cast<float*>(q.C) + (long)split * q.split_stride;
     const Params& p = q;
     const bool bf = p.c_bf16 != 0;
-    const bool vec = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & (bf ? 7 : 15)) == 0);
+    const bool vec = (p.c_blocked || (p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & (bf ? 7 : 15)) == 0);
     const bool use_bias = p.bias != nullptr && split == 0;
     if constexpr (staged<FN>()) {
       using RS = RowStage<1, FN * 16>;
@@ -91,7 +96,7 @@ struct EpiPlain {
       for (int c = 0; c < RS::PASSES; c++) {
         const int row = RS::row(c);
         const f32x4 a = RS::get(st, row, u);
-        const long off = (long)(m0 + i * 16 + row) * p.ldc + n;
+        const long off = coff(p, m0 + i * 16 + row, n);
         float v0 = p.alpha * a[0] + b4.x, v1 = p.alpha * a[1] + b4.y, v2 = p.alpha * a[2] + b4.z, v3 = p.alpha * a[3] + b4.w;
         if constexpr (MODE == 1 || MODE == 4) {
           if constexpr (MODE == 4) {
@@ -120,7 +125,7 @@ struct EpiPlain {
       if (use_bias && n + e < N) v[e] += p.bias[n + e];
       if (p.act == 1) v[e] = expf(v[e]);
     }
-    const long off = (long)m * p.ldc + n;
+    const long off = coff(p, m, n);
     if (p.atomic) {
       float* c = reinterpret_cast<float*>(p.C) + off;
 #pragma unroll
@@ -279,13 +284,15 @@ extern "C" int ptv_gemm_mtop(int prec, int transA, int transB, int M, int N, int
   const bool sa = dtypes & 1, sb = dtypes & 2, sc = dtypes & 4;
   if ((sa || sb) && prec != PTV_PREC_BF16) return PTV_ERR_ARG;       // bf16 operands feed the bf16 MFMA path only
   if (sc && splitk > 1) return PTV_ERR_ARG;                          // split-K accumulates with fp32 atomics
+  if ((dtypes & 8) && ((N & 31) || splitk > 1)) return PTV_ERR_ARG;  // column-blocked C: whole 32-column blocks, one writer per element
+  if ((dtypes & 8) && splitk == 0) splitk = 1;
   // weight gradients (both operands row-per-sample): the transposing-LDS-read kernel of wgrad.hip
   static const bool use_wgrad = [] { const char* e = getenv("PTV_WGRAD"); return !(e && e[0] == '0'); }();
-  if (use_wgrad && prec == PTV_PREC_BF16 && transA && transB && !sc && !bias && act == 0 && K >= 512 && splitk <= 0)
+  if (use_wgrad && prec == PTV_PREC_BF16 && transA && transB && !sc && !(dtypes & 8) && !bias && act == 0 && K >= 512 && splitk <= 0)
     return ptv_wgrad(M, N, K, A, lda, B, ldb, reinterpret_cast<float*>(C), ldc, alpha, accumulate, dtypes & 3, 0, nullptr, nullptr, 0, 0, stream);
   if (m_top && (transA || m_unit <= 0)) return PTV_ERR_ARG;            // a row limit on A: A must be row-per-sample
   ptv::GemmArgs g{A, lda, B, ldb, M, N, K, K, 0, m_top, m_unit, ptv::g_gemm_prio};
-  ptv::EpiPlain::Params ep{C, ldc, bias, alpha, accumulate, act, 0, sc ? 1 : 0, 0};
+  ptv::EpiPlain::Params ep{C, ldc, bias, alpha, accumulate, act, 0, sc ? 1 : 0, (dtypes & 8) ? 1 : 0, M, 0};
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (prec != PTV_PREC_BF16) rc = ptv::gemm_dispatch<ptv::F32, false, false>(transA, transB, g, ep, splitk, s);

@@ -89,7 +89,7 @@ __device__ __forceinline__ void st_f32x8(float* p, const float (&v)[8]) {
 struct RowGruFwdArgs {
   const bf16x8 *w_hh, *w_x;        // pair-interleaved packing: W_hh [3H/16 tiles][H/32 kb][64], W_x [3H/16][4][64]
   const float* b_hh; const float* b_ih;   // [3H]; b_ih may be null (folded into gc)
-  const __bf16* gc;                // [R][3H] hoisted input part (b_ih included) or null
+  const __bf16* gc;                // the [R][3H] hoisted input part (b_ih included), COLUMN-BLOCKED by 32: [3H/32][R][32] (ptv_gemm dtypes bit 3), or null
   const float* x; long x_step;     // fed tokens fp32: x + t*x_step + row*128
   const int* lengths;              // [R] or null: row m is updated at time t iff t < lengths[m]
   float* HN; __bf16* HN16;         // [T+1][R][H]; slot 0 of HN written by the caller
@@ -226,9 +226,10 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
   #pragma unroll
         for (int i = 0; i < MH; i++) {
           if constexpr (!EMB) {
-            const __bf16* g = a.gc + grow[mh + i] * (3 * H) + u;
+            const __bf16* g = a.gc + gate_off(grow[mh + i], u, R);            // column-blocked by 32: [3H/32][R][32]
+            const long gstep = R * H;
   #pragma unroll
-            for (int gt = 0; gt < 3; gt++) gq[i][gt] = ldnt_bf16x8(g + gt * H);
+            for (int gt = 0; gt < 3; gt++) gq[i][gt] = ldnt_bf16x8(g + gt * gstep);
           }
           if constexpr (H != 128) {                                        // (H = 128: loaded per tile in the epilogue -- registers)
             const float* hp = a.HN + (long)n * RH + grow[mh + i] * H + u;

@@ -187,7 +187,7 @@ def _chain_prio():
 
 
 def gemm(a, b, out=None, *, ta=False, tb=False, bias=None, alpha=1.0, acc=False, act=0, prec=0, splitk=0, out_dtype=F32, m_top=None,
-         m_unit=0):
+         m_unit=0, out_blocked=False):
     """out[M,N] = act(alpha * op(a) . op(b)^T + bias) (+ out);  see ptv_gemm in include/ptvae_hip.h.
     a / b / out may be bf16 tensors (bf16 precision only)."""
     M, K = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
@@ -198,6 +198,9 @@ def gemm(a, b, out=None, *, ta=False, tb=False, bias=None, alpha=1.0, acc=False,
         out = _empty(M, N, dev=a.device, dtype=out_dtype)
     assert tuple(out.shape) == (M, N), (out.shape, M, N)
     dt = _bf(a) | (_bf(b) << 1) | (_bf(out) << 2)
+    if out_blocked:                                         # out holds the [M, N] result column-blocked by 32: [N/32][M][32] (ptv_gemm dtypes bit 3)
+        assert N % 32 == 0 and out.is_contiguous()
+        dt |= 8
     _chain_prio()
     if m_top is not None:                                   # rows of a from (m_top + 1) * m_unit on are zero (device int)
         call('ptv_gemm_mtop', prec, int(ta), int(tb), M, N, K, ptr(a), _ld(a), ptr(b), _ld(b), ptr(out), _ld(out),
@@ -1156,12 +1159,13 @@ class DecoderTFFn(torch.autograd.Function):
         gemm(NSf_op, W['dec_time_to_notes_hid.weight'], HN[0], bias=P['dec_time_to_notes_hid.bias'], prec=prec)
         w_ih_n = W['dec_notes_gru.weight_ih_l0']
         adt = _act_dtype(prec, Hn)
-        GC = gemm(NSf_op, w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec, out_dtype=adt)      # [R, 3Hn]
+        rowk = notes_persist_ok(prec, Hn, E, adt) and emb3.dtype == F32 and emb3.is_contiguous()
+        # (the row kernel reads the hoisted part column-blocked: one contiguous kilobyte per wave access instead of 16 half cache lines)
+        GC = gemm(NSf_op, w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec, out_dtype=adt, out_blocked=rowk)      # [R, 3Hn]
         gates_n = _empty(15, 4, R, Hn, dev=dev, dtype=adt)
         HN16 = _hall16(prec, 16, R, Hn, dev)
-        gates_n_rowk = False
-        if notes_persist_ok(prec, Hn, E, adt) and emb3.dtype == F32 and emb3.is_contiguous():
-            gates_n_rowk = True
+        gates_n_rowk = rowk
+        if rowk:
             # ONE launch for the 15 note steps, 64 rows per workgroup, token product fused (csrc/notes_persist.hip)
             pk = notes_packs(P['dec_notes_gru.weight_ih_l0'], P['dec_notes_gru.weight_hh_l0'], Ht)
             call('ptv_notes_gru_persist_fwd', ptr(pk['wg_h']), ptr(pk['wg_t']), ptr(P['dec_notes_gru.bias_hh_l0']), ptr(GC), ptr(emb3),

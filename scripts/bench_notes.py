@@ -16,6 +16,8 @@ g = torch.Generator(device=dev).manual_seed(1)
 rn = lambda *s: torch.randn(*s, device=dev, generator=g)
 w_hh, w_tok, b_hh = rn(3 * H, H) / H ** 0.5, rn(3 * H, E) / H ** 0.5, rn(3 * H) * 0.1
 gc, emb = (rn(R, 3 * H) * 0.5).to(bf), rn(T, R, E) * 0.5
+gc_rm = gc                                                     # row-major for the per-step kernels
+gc = gc.view(R, 3 * H // 32, 32).permute(1, 0, 2).contiguous()   # column-blocked by 32 for the row kernel (ptv_gemm dtypes bit 3)
 ext = (rn(T, R, H) * 0.1).to(bf)
 wg_h, wg_t, wt = F_.pack_mfma_b(w_hh, pairs=True), F_.pack_mfma_b(w_tok, pairs=True), F_.pack_mfma_b(w_hh.t().contiguous(), pairs=True)
 HN = torch.zeros(T + 1, R, H, device=dev); HN[0] = rn(R, H) * 0.5
@@ -53,7 +55,7 @@ def p_bwd():
 
 def s_fwd():
     GT = F_.gemm(emb.view(T * R, E), wtok16, prec=1, out_dtype=bf)
-    call('ptv_gru_seq_fwd', 1, R, H, T, ptr(GT), R * 3 * H, 3 * H, ptr(gc), 0, 3 * H, ptr(w16), ptr(b_hh), ptr(HN), ptr(HN16), ptr(gates),
+    call('ptv_gru_seq_fwd', 1, R, H, T, ptr(GT), R * 3 * H, 3 * H, ptr(gc_rm), 0, 3 * H, ptr(w16), ptr(b_hh), ptr(HN), ptr(HN16), ptr(gates),
          None, 0, None, FL, stream_ptr())
 
 

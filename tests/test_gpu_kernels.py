@@ -409,12 +409,13 @@ def test_notes_gru_persistent_kernels_vs_step_kernels_and_oracle(R, T, zero_from
             ext[zero_from - 1, 64:] = 0
     d = lambda t: t.to(dev).contiguous()
     Wd = dict(w_hh=d(w_hh), w_tok=d(w_tok), b_hh=d(b_hh), gc=d(gc), emb=d(emb), ext=d(ext))
+    gc_blocked = Wd['gc'].view(R, 3 * H // 32, 32).permute(1, 0, 2).contiguous()      # what ptv_gemm writes with dtypes bit 3
     wg_h, wg_t = F_.pack_mfma_b(Wd['w_hh'], pairs=True), F_.pack_mfma_b(Wd['w_tok'], pairs=True)
     wt = F_.pack_mfma_b(Wd['w_hh'].t().contiguous(), pairs=True)
     HN = torch.zeros(T + 1, R, H, device=dev); HN[0] = d(h0)
     HN16 = torch.zeros(T + 1, R, H, device=dev, dtype=bf)
     gates = torch.zeros(T, 4, R, H, device=dev, dtype=bf)
-    call('ptv_notes_gru_persist_fwd', ptr(wg_h), ptr(wg_t), ptr(Wd['b_hh']), ptr(Wd['gc']), ptr(Wd['emb']), ptr(HN), ptr(HN16), ptr(gates),
+    call('ptv_notes_gru_persist_fwd', ptr(wg_h), ptr(wg_t), ptr(Wd['b_hh']), ptr(gc_blocked), ptr(Wd['emb']), ptr(HN), ptr(HN16), ptr(gates),
          R, T, stream_ptr())
     dgi = torch.zeros(T, R, 3 * H, device=dev, dtype=bf); dgh = torch.zeros(T, R, H, device=dev, dtype=bf)     # dgh: n third only
     dh0 = torch.zeros(R, H, device=dev)
