@@ -381,7 +381,8 @@ int ptv_free_resummarize(const void* const* w, const void* const* io, int B, int
  *        emb fp32 [T][R][128] fed tokens; HN fp32 [T+1][R][512] (slot 0 written by the caller), HN16 bf16 same shape (all slots
  *        written here), gates bf16 [T][4] planes (r, z, n, W_hn h + b_hn) or NULL -- PRIVATE to this forward / BPTT pair: each plane is
  *        unit-blocked, plane[u / 32][row][u % 32] (whole-kilobyte wave accesses), not the [R][512] of ptv_gru_seq_fwd.
- *   bwd: wt = pack(W_hh^T [512,1536]); ext bf16 [T][R][512] = gradient arriving at the state after step s;
+ *   bwd: wt = pack(W_hh^T [512,1536]); ext bf16 = gradient arriving at the state after step s, the [T*R][512] matrix of the heads'
+ *        input-gradient products stored COLUMN-BLOCKED by 32 ([16][T*R][32], ptv_gemm dtypes bit 3);
  *        dgi bf16 [T][R][1536]; dgh bf16 [T][R][512] = the n third (dn * r) only -- the r and z thirds of dgh are dgi's, so
  *        grad W_hh[0:1024] = dgi[:, 0:1024]^T . h and grad W_hh[1024:] = dgh^T . h; dh0 fp32 [R][512] or NULL; scratch:
  *        ptv_notes_gru_persist_scratch_elems(R) bf16 elements.  The BPTT passes over the late steps of a 64-row panel at which no gradient

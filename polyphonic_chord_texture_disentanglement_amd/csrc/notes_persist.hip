@@ -28,6 +28,9 @@ namespace ptv {
 // touches 16 rows x 64 bytes -- half a cache line per row; blocked it is ONE contiguous kilobyte.  Measured at R = 16384, T = 15:
 // forward 999 -> 973 us, dense BPTT 1245 -> 1090 us (scripts/bench_notes.py).
 __device__ __forceinline__ long gate_off(long row, int u, long R) { return ((long)(u >> 5) * R + row) * 32 + (u & 31); }
+// the gradient arriving at the states, the [T*R][H] matrix of the heads' input-gradient products, column-blocked by 32 the same way
+// (ptv_gemm dtypes bit 3 over all T*R rows): element (step s, row, u)
+__device__ __forceinline__ long ext_off(int s, long row, int u, long R, int T) { return ((long)(u >> 5) * ((long)T * R) + (long)s * R + row) * 32 + (u & 31); }
 
 constexpr int NE = 128, NRP = 64;                    // input (token) width, rows per workgroup
 constexpr int NT16LD = NE + 16;                      // bf16 LDS row strides (+16): conflict-free b128 fragment reads
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
 struct RowGruBwdArgs {
   const bf16x8* wt;                // pair-interleaved packing of W_hh^T: [H/16 tiles of output units][3H/32 kb][64]
   const float* HN; const __bf16* gates;
-  const __bf16* ext;               // [T][R][H] bf16 gradient arriving at the state after step s, or null
+  const __bf16* ext;               // bf16 gradient arriving at the state after step s: the [T*R][H] matrix COLUMN-BLOCKED by 32 ([H/32][T*R][32]), or null
   const float* dh_last; long last_ld;   // gradient arriving at the final state only (rows of stride last_ld), or null
   const int* lengths;              // EMB: the lengths the forward ran with (it skipped the panel's fully masked steps), or null
   int* top_step;                   // atomicMax'ed with the last step at which a gradient arrived for any panel (!EMB) / the last time
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowG
         const int row = i / (H / 8), c8 = (i % (H / 8)) * 8;
         if (r0 + row < R) {
           typedef __attribute__((ext_vector_type(4))) unsigned u4v;
-          const u4v w = *reinterpret_cast<const u4v*>(a.ext + (long)s_top * RH + (r0 + row) * H + c8);
+          const u4v w = *reinterpret_cast<const u4v*>(a.ext + ext_off(s_top, r0 + row, c8, R, a.T));
           nz |= (w[0] | w[1] | w[2] | w[3]) & 0x7fff7fffu;                // -0.0 is zero too
         }
       }
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowG
       const __bf16* gp = a.gates + (long)s * 4 * RH + gate_off(grow[i], u, R);
 #pragma unroll
       for (int q = 0; q < 4; q++) o.g[q] = ldnt_bf16x8(gp + q * RH);
-      if constexpr (!EMB) o.ex = ldnt_bf16x8(a.ext + base);
+      if constexpr (!EMB) o.ex = ldnt_bf16x8(a.ext + ext_off(s, grow[i], u, R, a.T));
       o.hp[0] = ldnt_f4(a.HN + base); o.hp[1] = ldnt_f4(a.HN + base + 4);
     };
     if (s >= 0) { ldops(ops[0], 0); ldops(ops[1], 1); }

@@ -253,13 +253,13 @@ def _WT(p, prec):
     return None
 
 
-def gemm_dx(dy, w, cols=None, out=None, *, acc=False, prec=0, m_top=None, m_unit=0):
+def gemm_dx(dy, w, cols=None, out=None, *, acc=False, prec=0, m_top=None, m_unit=0, out_blocked=False):
     """input gradient of a Linear: dy . w[:, cols].  With a transposed bf16 shadow of w this is a K-contiguous
     (NT) product on bf16 weight tiles; otherwise the fp32 weight is read K-major."""
     wt = _WT(w, prec)
     if wt is not None:
-        return gemm(dy, wt if cols is None else wt[cols, :], out, acc=acc, prec=prec, m_top=m_top, m_unit=m_unit)
-    return gemm(dy, w if cols is None else w[:, cols], out, tb=True, acc=acc, prec=prec, m_top=m_top, m_unit=m_unit)
+        return gemm(dy, wt if cols is None else wt[cols, :], out, acc=acc, prec=prec, m_top=m_top, m_unit=m_unit, out_blocked=out_blocked)
+    return gemm(dy, w if cols is None else w[:, cols], out, tb=True, acc=acc, prec=prec, m_top=m_top, m_unit=m_unit, out_blocked=out_blocked)
 
 
 def _gru_flags(gates=None, gi=None, gi2=None, dg=None, w=None, ext=None):
@@ -1345,6 +1345,8 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     w_dh, w_p = W['dur_hid_linear.weight'], W['pitch_out_linear.weight']
     # gradient reaching the notes-GRU states: only ever an addend of the BPTT epilogue -> activation dtype
     dNSUM = _empty(M, Hn, dev=dev, dtype=_act_dtype(prec, Hn))
+    # (read by the row-partitioned BPTT kernel column-blocked by 32, like its saved gates: whole-kilobyte wave accesses)
+    rowk_bwd = bool(st.get('gates_n_rowk') and notes_persist_ok(prec, Hn, E, st['gates_n'].dtype) and dNSUM.dtype == BF16 and HN.dtype == F32)
     gemm_dx(dHD0, w_dh, slice(Hn, None), out=dP, acc=True, prec=prec, m_top=top_h, m_unit=R)         # dP complete
 
     def head_wgrads():
@@ -1355,15 +1357,15 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     # queues next would be a false dependency)
     if FORK_EARLY:
         side(head_wgrads, dHD0, dP)
-    gemm_dx(dHD0, w_dh, slice(0, Hn), out=dNSUM, prec=prec, m_top=top_h, m_unit=R)                   # [M, Hn]
-    gemm_dx(dP, w_p, out=dNSUM, acc=True, prec=prec, m_top=top_h, m_unit=R)
+    gemm_dx(dHD0, w_dh, slice(0, Hn), out=dNSUM, prec=prec, m_top=top_h, m_unit=R, out_blocked=rowk_bwd)                   # [M, Hn]
+    gemm_dx(dP, w_p, out=dNSUM, acc=True, prec=prec, m_top=top_h, m_unit=R, out_blocked=rowk_bwd)
     if not FORK_EARLY:
         side(head_wgrads, dHD0, dP)
 
     mark('dec_bwd:head_dx')
     # ---- notes GRU (15 steps, batch 32*B) ----
     w_hh_n, w_ih_n = W['dec_notes_gru.weight_hh_l0'], W['dec_notes_gru.weight_ih_l0']
-    if (st.get('gates_n_rowk') and notes_persist_ok(prec, Hn, E, st['gates_n'].dtype) and dNSUM.dtype == BF16 and HN.dtype == F32):
+    if rowk_bwd:
         # (the forward ran on the row kernel: its gate planes are in that kernel pair's private layout)
         pk = notes_packs(w_ih_n, w_hh_n, Ht)
         dgi_n = _empty(15, R, 3 * Hn, dev=dev, dtype=BF16)

@@ -1,4 +1,4 @@
-"""rocprofv3 --pmc csv files of scripts/gpu_pmc_r02.sh -> per-kernel means per launch.  HBM bytes follow MI355X_MICROARCH.md (HBM
+"""rocprofv3 --pmc csv files of scripts/gpu_pmc.sh -> per-kernel means per launch.  HBM bytes follow MI355X_MICROARCH.md (HBM
 section): FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 B,
 so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is used as reported.  MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES /
 (GRBM_GUI_ACTIVE / 8 * 1024): busy cycles are summed over the chip's 1024 SIMDs (= 16 cycles x SQ_INSTS_MFMA for the 16x16x32
@@ -35,9 +35,16 @@ for r in res:
     for name in ('row_gru_bwd_kernel<512>', 'row_gru_fwd_kernel<512>', 'row_gru_bwd_kernel<128>', 'row_gru_fwd_kernel<128>'):
         if r['kernel'].startswith(name[:-1]):          # 'row_gru_bwd_kernel<512' matches the <512, false> instantiation
             pick[name] = {k: r[k] for k in ('launches', 'read_bytes_per_launch', 'write_bytes_per_launch', 'hbm_bytes_per_launch', 'mfma_busy_frac')}
+import subprocess
+try:
+    pick['_commit'] = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()
+except Exception:
+    pick['_commit'] = None                       # (the GPU box has no .git: scripts/gpu_pmc.sh passes PTV_COMMIT)
+import os
+pick['_commit'] = os.environ.get('PTV_COMMIT') or pick['_commit']
 pick['_how'] = ('rocprofv3 --pmc (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_MFMA, three passes) '
-                '-- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras; scripts/gpu_pmc_r02.sh; corrections in '
-                'scripts/pmc_summary_r02.py')
+                '-- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-parity; scripts/gpu_pmc.sh; corrections in '
+                'scripts/pmc_summary.py')
 json.dump(pick, open('%s/row_gru_pmc.json' % d, 'w'), indent=1)
 for r in res[:30]:
     print('%-64s n=%4d rd=%8.1f MB wr=%8.1f MB mfma_busy=%s' % (r['kernel'][:64], r['launches'], r['read_bytes_per_launch'] / 1e6,

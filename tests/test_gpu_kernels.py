@@ -420,7 +420,8 @@ def test_notes_gru_persistent_kernels_vs_step_kernels_and_oracle(R, T, zero_from
     dgi = torch.zeros(T, R, 3 * H, device=dev, dtype=bf); dgh = torch.zeros(T, R, H, device=dev, dtype=bf)     # dgh: n third only
     dh0 = torch.zeros(R, H, device=dev)
     scratch = torch.empty(lib().ptv_notes_gru_persist_scratch_elems(R), device=dev, dtype=bf)
-    call('ptv_notes_gru_persist_bwd', ptr(wt), ptr(HN), ptr(gates), ptr(Wd['ext']), ptr(dgi), ptr(dgh), ptr(dh0), ptr(scratch), R, T, None, stream_ptr())
+    ext_blocked = Wd['ext'].view(T * R, H // 32, 32).permute(1, 0, 2).contiguous()        # the [T*R][H] matrix as ptv_gemm writes it with dtypes bit 3
+    call('ptv_notes_gru_persist_bwd', ptr(wt), ptr(HN), ptr(gates), ptr(ext_blocked), ptr(dgi), ptr(dgh), ptr(dh0), ptr(scratch), R, T, None, stream_ptr())
     # ---- the per-step kernels on the same operands
     GT = F_.gemm(Wd['emb'].view(T * R, E), Wd['w_tok'].to(bf), prec=1, out_dtype=bf)
     HN2 = torch.zeros_like(HN); HN2[0] = HN[0]
