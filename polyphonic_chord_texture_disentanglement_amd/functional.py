@@ -146,8 +146,43 @@ def _W(p, prec):
     return p
 
 
+# Small zero-initialised buffers (reduction targets, counters, sync words: ~40 per step, 8 bytes to 2 KB each) are slices of a chunk
+# that was cleared ONCE when it was allocated, handed out once and never reused -- one fill launch per 64 KB instead of one per
+# buffer.  One bump chunk per (stream, dtype, fill value): a slice is requested on the stream whose earlier work cleared the chunk.
+# Not inside a graph capture (the fill has to be a node of the graph) and not for anything over 4 KB.
+_ZCHUNK = {}
+_ZCHUNK_BYTES = 64 * 1024
+
+
+def _small_filled(n, dtype, value, dev):
+    if n * 4 > 4096 or torch.cuda.is_current_stream_capturing():
+        return torch.full((n,), value, device=dev, dtype=dtype)
+    key = (torch.cuda.current_stream().cuda_stream, dtype, value, str(dev))
+    ent = _ZCHUNK.get(key)
+    n4 = (n + 3) // 4 * 4                                    # 16-byte aligned slices
+    if ent is None or ent[1] + n4 > ent[0].numel():
+        ent = _ZCHUNK[key] = [torch.full((_ZCHUNK_BYTES // 4,), value, device=dev, dtype=dtype), 0]
+    out = ent[0][ent[1]:ent[1] + n]
+    ent[1] += n4
+    return out
+
+
 def _zeros(*shape, dev):
+    n = 1
+    for d_ in shape:
+        n *= d_
+    if n * 4 <= 4096:
+        return _small_filled(n, F32, 0, dev).view(*shape)
     return torch.zeros(*shape, device=dev, dtype=F32)
+
+
+def _izeros(n, dev):
+    return _small_filled(n, torch.int32, 0, dev)
+
+
+def _ineg1(dev):
+    """device int initialised to -1 (the `top` words the zero-skipping kernels raise with atomicMax)"""
+    return _small_filled(1, torch.int32, -1, dev)
 
 
 def _pad8(n):
@@ -324,7 +359,7 @@ class _PersistTurn:
 
 def _persist_sync(NC, dev):
     """zeroed sync words of one launch: word 0 = error flag, word 16*(1+g) = arrival counter of row group g"""
-    sync = torch.zeros(16 * 33, device=dev, dtype=torch.int32)
+    sync = _izeros(16 * 33, dev)
     _PERSIST_SYNC.append(sync)
     if len(_PERSIST_SYNC) > 64:
         del _PERSIST_SYNC[:32]
@@ -882,7 +917,7 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
             dgi = _empty(T, M, 3 * H, dev=x3.device, dtype=BF16)
             dgh = _empty(T, M, 3 * H, dev=x3.device, dtype=BF16)
             scratch = _empty(lib().ptv_row_gru_persist_scratch_elems(H, M), dev=x3.device, dtype=BF16)
-            top = torch.full((1,), -1, device=x3.device, dtype=torch.int32) if (lengths is not None and M % 32 == 0) else None
+            top = _ineg1(x3.device) if (lengths is not None and M % 32 == 0) else None
             call('ptv_row_gru_persist_bwd', H, ptr(pk['wt']), ptr(hall), ptr(gates), None, dout.data_ptr() + 4 * d * H, dout.stride(0),
                  ptr(lengths) if lengths is not None else None, ptr(dgi), ptr(dgh), None, ptr(scratch), M, T, d, ptr(top), stream_ptr())
             return products(d, dgi, dgh, top)
@@ -1309,7 +1344,7 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     zero_skip_sync()
     top_h = None
     if ZERO_SKIP:
-        top_h = torch.full((1,), -1, device=dev, dtype=torch.int32)
+        top_h = _ineg1(dev)
         call('ptv_last_nonzero_unit', ptr(dP), M, NP, dP.stride(0), R, ptr(top_h), stream_ptr())
         call('ptv_last_nonzero_unit', ptr(ddur), M, 10, 10, R, ptr(top_h), stream_ptr())
 
@@ -1372,7 +1407,7 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
         dgh_n = _empty(15, R, Hn, dev=dev, dtype=BF16)          # n third only: the r / z thirds of dgh are dgi's
         dHN0 = _empty(R, Hn, dev=dev)
         scratch = _empty(lib().ptv_notes_gru_persist_scratch_elems(R), dev=dev, dtype=BF16)
-        top_step = torch.full((1,), -1, device=dev, dtype=torch.int32) if ZERO_SKIP else None   # <- last note step with a gradient
+        top_step = _ineg1(dev) if ZERO_SKIP else None   # <- last note step with a gradient
         call('ptv_notes_gru_persist_bwd', ptr(pk['wt']), ptr(HN), ptr(st['gates_n']), ptr(dNSUM), ptr(dgi_n), ptr(dgh_n), ptr(dHN0),
              ptr(scratch), R, 15, ptr(top_step), stream_ptr())
     else:
@@ -1573,12 +1608,12 @@ def _pianotree_ce_fwd(pitch, dur, x, sums, st, weighted=False):
     NP = pitch.shape[-1]
     pitch_t = torch.empty(rows, device=dev, dtype=torch.int32)
     dur_t = torch.empty(rows * 5, device=dev, dtype=torch.int32)
-    counts = torch.zeros(2, device=dev, dtype=torch.int32)
+    counts = _izeros(2, dev)
     call('ptv_pianotree_targets', ptr(x), B, int(sm), ptr(pitch_t), ptr(dur_t), ptr(counts), st)
     call('ptv_ce_fwd', ptr(pitch_m), pitch_m.stride(-2), ptr(pitch_t), rows, NP, 130, ptr(sums[0:]), st)
     if weighted:                              # 5 per-bit-position means, weighted (ptvae.py:512-527)
         gsum = _zeros(5, dev=dev)
-        gcnt = torch.zeros(5, device=dev, dtype=torch.int32)
+        gcnt = _izeros(5, dev)
         call('ptv_ce_group_fwd', ptr(dur_m), 2, ptr(dur_t), rows * 5, 2, 2, 5, ptr(gsum), ptr(gcnt), st)
         call('ptv_wdur_finalize', ptr(gsum), ptr(gcnt), *WDUR, ptr(sums[1:]), ptr(counts[1:]), st)
         return pitch_m, dur_m, sm, pitch_t, dur_t, counts, gcnt
