@@ -31,6 +31,28 @@ EMB_GRU = ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0', 'weight_i
 _SOS = {}
 
 
+
+_ROUTE_MASKS = {}
+
+
+def _route_mask(key, dev):
+    """device int32 mask of a coin pattern (the backward's gradient routing): cached per pattern -- with tfr = 0 or 1 it is one
+    constant, and a host-to-device copy per step is a synchronisation point (and impossible inside a graph capture)"""
+    k = (key, str(dev))
+    m = _ROUTE_MASKS.get(k)
+    if m is None:
+        if len(_ROUTE_MASKS) > 64:
+            _ROUTE_MASKS.clear()
+        if key[0] == 'tok':
+            t_ = torch.ones(15, 32, dtype=torch.int32)
+            for t in range(32):
+                for n in range(14):
+                    t_[n + 1, t] = 1 if key[1][t][n] else 0
+        else:
+            t_ = torch.tensor([1 if c else 0 for c in key[1]] + [1], dtype=torch.int32)
+        m = _ROUTE_MASKS[k] = t_.to(dev)
+    return m
+
 def _sos_grid(dev):
     """a [1,32,16,6] grid whose every row is <sos> (ptvae.py:315-320); cached so graph capture sees no H2D copy"""
     k = str(dev)
@@ -376,17 +398,13 @@ class DecoderStepFn(torch.autograd.Function):
         # ---- route token gradients: ground-truth embedding (coin true / slot 0) vs predicted tokens
         demb = _zeros(16, R, E, dev=dev)
         dPRED = _zeros(16, R, E, dev=dev)
-        mask_tok = torch.ones(15, 32, dtype=torch.int32)
-        for t in range(32):
-            for n in range(14):
-                mask_tok[n + 1, t] = 1 if coin_notes[t][n] else 0
-        mask_tok = mask_tok.to(dev)
+        mask_tok = _route_mask(('tok', tuple(tuple(bool(v) for v in row) for row in coin_notes)), dev)
         call('ptv_route_slices', ptr(dTOK), ptr(demb), ptr(dPRED), ptr(mask_tok), B * E, 15 * 32, 0, sp)
 
         # ---- time tokens: ground-truth summaries (coin true) vs re-summarised predictions
         dxs = _zeros(32, B, 2 * He, dev=dev)
         dxsp = _zeros(32, B, 2 * He, dev=dev)
-        mask_time = torch.tensor([1 if c else 0 for c in coin_time] + [1], dtype=torch.int32).to(dev)
+        mask_time = _route_mask(('time', tuple(bool(v) for v in coin_time)), dev)
         call('ptv_route_slices', ptr(dTOKS[1:]), ptr(dxs), ptr(dxsp), ptr(mask_time), B * 2 * He, 32, 0, sp)
         if st['XH'] is not None:
             wE = [P['dec_notes_emb_gru.' + n] for n in EMB_GRU]
