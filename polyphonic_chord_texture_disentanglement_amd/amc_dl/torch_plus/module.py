@@ -171,8 +171,8 @@ class TrainingInterface:
         if any(float(t) != 1.0 for t in tfr) or 'weights' not in params:
             return None
         B = inputs[0].shape[0]
-        if mode == 'auto' and B > self.GRAPH_AUTO_MAX_BATCH:
-            return None
+        if mode == 'auto' and (B > self.GRAPH_AUTO_MAX_BATCH or (self.grad_sync is not None and self.grad_sync.active)):
+            return None                                        # (data parallel: only when asked for -- the early, overlapped exchange needs the eager step)
         gs = self.__dict__.setdefault('_graph_steps', {})
         key = (B, tuple(float(w) for w in params['weights']), float(self.opt_scheduler.clip))
         if key not in gs:

@@ -301,7 +301,8 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
           if (ok[mh + i]) {
             const long o = (long)(n + 1) * RH + grow[mh + i] * H + u;
             st_f32x8(a.HN + o, h);                                       // read back next step: default policy
-            stnt_bf16x8(a.HN16 + o, h);
+            // (HN16 is NOT written here: 16 bytes per lane are 64-byte row segments, half a cache line.  The whole bf16 state of the
+            // panel is in LDS once the step's barrier has passed -- it goes out from there in full rows, under the next step's products)
             if (a.gates) {
               __bf16* gp = a.gates + (long)n * 4 * RH + gate_off(grow[mh + i], u, R);
               stnt_bf16x8(gp, r); stnt_bf16x8(gp + RH, z); stnt_bf16x8(gp + 2 * RH, nn); stnt_bf16x8(gp + 3 * RH, hn);
@@ -313,6 +314,17 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
     }
     lds_barrier();
     slot = n + 1; cur = nxt;
+    // bf16 state after this step: LDS (complete, and stable until the step after next overwrites this buffer) -> HN16 slot n + 1, one
+    // kilobyte (H = 512) of contiguous row per 64 lanes
+    {
+      const __bf16* hs = h16 + cur * NRP * HLD;
+      for (int i = tid; i < NRP * (H / 8); i += 256) {
+        const int row = i / (H / 8), c8 = (i % (H / 8)) * 8;
+        if (r0 + row < R)
+          __builtin_nontemporal_store(*reinterpret_cast<const bf16x8*>(hs + row * HLD + c8),
+                                      reinterpret_cast<bf16x8*>(a.HN16 + (long)(n + 1) * RH + (r0 + row) * H + c8));
+      }
+    }
   }
   if constexpr (EMB) {
     if (a.out) {                                                           // final state = the last written slot

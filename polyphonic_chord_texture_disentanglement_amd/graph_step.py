@@ -127,7 +127,9 @@ class GraphedTrainStep:
         # they touch is put back afterwards, so building the graph is invisible to the run
         saved = (opt.flat_p.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_count, m._draws, random.getstate(),
                  torch.cuda.get_rng_state(self.dev), opt.grad_scale)
-        s = torch.cuda.Stream(device=self.dev)
+        # (warm-up and capture share ONE stream: the library's per-stream reduction workspaces are allocated on a stream's first use,
+        # which must not happen inside the capture)
+        s = self._stream = torch.cuda.Stream(device=self.dev)
         s.wait_stream(cur)
         with torch.cuda.stream(s):
             for _ in range(max(1, self.warmup)):
@@ -156,13 +158,13 @@ class GraphedTrainStep:
         try:
             pool = torch.cuda.graph_pool_handle()
             g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1, pool=pool):
+            with torch.cuda.graph(g1, pool=pool, stream=self._stream):
                 cap.origin()
                 out = self._body_backward(beta if beta != 0 else 1e-30)   # (a non-zero by-value beta marks the calls that read the device beta)
                 self.losses = torch.stack([o.detach().reshape(()) for o in out])
                 F_.join_captured_streams()
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=pool):
+            with torch.cuda.graph(g2, pool=pool, stream=self._stream):
                 cap.origin()
                 self._body_step()
                 F_.join_captured_streams()
