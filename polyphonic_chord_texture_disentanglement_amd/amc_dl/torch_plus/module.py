@@ -153,12 +153,13 @@ class TrainingInterface:
             self.summary_writers.write_task(task, self._write_loss_to_dic(vals), step)
 
     # ---- the step as one hipGraph launch (graph_step.GraphedTrainStep).  graph_step = 'auto' (default; PTV_GRAPH_STEP overrides):
-    # replay when the host is the wall -- per-GPU batch <= 256, where enqueueing ~300 launches takes longer than the GPU needs to run
-    # them (measured B = 128: 18.6k -> 23.0k samples/s, B = 256: 17.5k -> 37.2k; B = 512 is GPU-bound and 6 % faster eagerly);
+    # replay when the host is the wall -- per-GPU batch <= 128, where enqueueing ~300 launches (5.5 ms) takes longer than the GPU needs to
+    # run them (measured B = 64: 9.1k -> 12.4k samples/s, B = 128: 23.0k -> 23.6k; from B = 256 on the eager step wins: 40.6k vs 37.5k,
+    # B = 512 55k vs 52k -- the capture routes sibling-stream edges through the origin stream, see graph_step.py);
     # True / False force it.  Only steps whose teacher-forcing ratios are all exactly 1 can replay (coin flips pick kernels on the
     # host); every other step runs eagerly.
     graph_step = 'auto'
-    GRAPH_AUTO_MAX_BATCH = 256
+    GRAPH_AUTO_MAX_BATCH = 128
 
     def _graphed(self, inputs, params):
         import os
