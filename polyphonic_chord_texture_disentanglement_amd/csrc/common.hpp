@@ -102,7 +102,15 @@ __device__ __forceinline__ void ordered_commit(float* out, const float* part, in
   } else {
     for (int i = threadIdx.x; i < L; i += blockDim.x) {
       float s = 0.f;
-      for (int b = 0; b < n; b++) s += __hip_atomic_load(base + (long)b * L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int b = 0;
+      for (; b + 8 <= n; b += 8) {                                  // eight partials in flight, added in block order
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = __hip_atomic_load(base + (long)(b + q) * L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int q = 0; q < 8; q++) s += v[q];
+      }
+      for (; b < n; b++) s += __hip_atomic_load(base + (long)b * L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       out[i] += s;
     }
   }

@@ -54,7 +54,15 @@ __device__ __forceinline__ void ordered_commit_tx(float* dw, float* dbias, const
   if (!s_last) return;
   for (int i = threadIdx.x; i < L; i += blockDim.x) {
     float t = 0.f;
-    for (int b = 0; b < n; b++) t += __hip_atomic_load(sc.slots + (long)b * L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int b = 0;
+    for (; b + 8 <= n; b += 8) {                                    // eight partials in flight, added in block order
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) v[q] = __hip_atomic_load(sc.slots + (long)(b + q) * L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int q = 0; q < 8; q++) t += v[q];
+    }
+    for (; b < n; b++) t += __hip_atomic_load(sc.slots + (long)b * L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int c2 = i / 49, k = i % 49;
     if (k < 48) dw[c2 * 48 + k] += t; else dbias[c2] += t;
   }
