@@ -157,7 +157,7 @@ _ZCHUNK_BYTES = 64 * 1024
 def _small_filled(n, dtype, value, dev):
     if n * 4 > 4096 or torch.cuda.is_current_stream_capturing():
         return torch.full((n,), value, device=dev, dtype=dtype)
-    key = (torch.cuda.current_stream().cuda_stream, dtype, value, str(dev))
+    key = (stream_ptr(), dtype, value, dev.index if isinstance(dev, torch.device) else str(dev))
     ent = _ZCHUNK.get(key)
     n4 = (n + 3) // 4 * 4                                    # 16-byte aligned slices
     if ent is None or ent[1] + n4 > ent[0].numel():
