@@ -67,46 +67,15 @@ class DeviceBatcher:
     def __len__(self):
         return self.n // self.batch_size if self.drop_last else (self.n + self.batch_size - 1) // self.batch_size
 
-    prefetch = True       # the transform of batch i + 1 runs on a sibling HIP stream while the step of batch i runs (same batches, same order)
-
-    def _make(self, ids, i):
-        b = ids[i * self.batch_size:(i + 1) * self.batch_size]
-        index = torch.div(b, self.n_shift, rounding_mode='floor').int()
-        shift = (b % self.n_shift + self.shift_low).int()
-        return batch_transform(self.pr, self.chord, shift, index)
-
     def __iter__(self):
         dev = self.pr.device
         ids = torch.randperm(self.n, device=dev, generator=self.gen) if self.shuffle else torch.arange(self.n, device=dev)
         empty = torch.empty(0, device=dev)
-        n = len(self)
-        if not self.prefetch or n == 0 or torch.cuda.is_current_stream_capturing():
-            for i in range(n):
-                pr_mat, x, c = self._make(ids, i)
-                yield empty, empty, pr_mat, x, c, empty
-            return
-        # one batch ahead on a sibling stream: the consumer's stream waits for the batch's event only
-        main = torch.cuda.current_stream(dev)
-        from . import functional as F_
-        with torch.cuda.device(dev):
-            side = F_.pool_stream(3)                             # (the pool stream of the deferred weight-gradient products: idle when a step starts)
-        side.wait_stream(main)                               # (ids and the resident bank were produced on the caller's stream)
-
-        def produce(i):
-            with torch.cuda.stream(side):
-                out = self._make(ids, i)
-                ev = torch.cuda.Event()
-                ev.record(side)
-            return out, ev
-        nxt = produce(0)
-        for i in range(n):
-            (pr_mat, x, c), ev = nxt
-            cur = torch.cuda.current_stream(dev)
-            cur.wait_event(ev)
-            for t in (pr_mat, x, c):
-                t.record_stream(cur)                         # allocated under the sibling stream, consumed here
-            if i + 1 < n:
-                nxt = produce(i + 1)
+        for i in range(len(self)):
+            b = ids[i * self.batch_size:(i + 1) * self.batch_size]
+            index = torch.div(b, self.n_shift, rounding_mode='floor').int()
+            shift = (b % self.n_shift + self.shift_low).int()
+            pr_mat, x, c = batch_transform(self.pr, self.chord, shift, index)
             yield empty, empty, pr_mat, x, c, empty
 
 

@@ -568,13 +568,6 @@ class Side:
         self.used = False
 
 
-def pool_stream(slot):
-    """one of the pool's sibling streams (created with the others, in the fixed order) for work that is not a Side call -- the data
-    loader's one-batch-ahead transform.  A stream of its own would be a sixth one: the runtime multiplexes all streams onto 4 hardware
-    queues and every extra stream re-deals them (the step got 40 % slower with a pool of 5)."""
-    return Side(slot).s
-
-
 _DEFERRED = []
 GRAD_READY_HOOK = None      # callable(params, streams) set by dist.GradSync: the gradients of `params` are complete once `streams` drain
 
