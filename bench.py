@@ -164,7 +164,7 @@ def extras(dev, B, rank):
                                       'note': "the reference's train.py schedule from its third batch on (SURVEY 0.4)"}
     # the trainer surface: TrainingVAE.train() with the device-resident data path (raw piano-roll bank -> ptv_batch_transform),
     # train.py's schedulers, fused clip+Adam, one non-blocking 11-scalar log per batch
-    pr_bank, ch_bank = synth_raw_bank(256, 5)
+    pr_bank, ch_bank = synth_raw_bank(1024, 5)              # 12288 augmented samples: 24 batches per epoch (an epoch ends with a log flush = a sync)
     loader = DeviceBatcher(pr_bank, ch_bank, B, seed=1, device=dev, drop_last=True)
     nb = len(loader)
 
