@@ -917,7 +917,10 @@ def test_two_runs_of_a_training_trace_are_bit_identical(prec, tfr):
     order of fp32 atomics, so -- like the reference on the CPU -- two runs of the same 3-step trace give the same
     bits: every loss, the gradient norm and every parameter.  Sibling streams, persistent launches and the zero-skip stay on."""
     from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
+    import os
     import random
+    if os.environ.get('PTV_WGRAD_ORDERED', '1') == '0':
+        pytest.skip('fp32 atomics requested (PTV_WGRAD_ORDERED=0): summation order follows arrival order')
     runs = []
     for rep in range(2):
         if prec == 'fp32':
