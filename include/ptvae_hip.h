@@ -44,7 +44,7 @@ extern "C" {
 #define PTV_GRU_EXT_BF16 64     /* dh_ext (backward) holds bf16 */
 #define PTV_GRU_SKIP_CAST0 32  /* hall16 slot 0 is already valid (chained single-step calls) */
 
-/* Library / build identification ("gfx950"). */
+/* Library / build identification ("gfx950"; ABI version 2 since round 3). */
 const char* ptv_arch(void);
 int ptv_abi_version(void);
 
