@@ -205,7 +205,7 @@ template <class CT, bool SA, bool SB>
 static int gemm_dispatch(int transA, int transB, GemmArgs g, EpiPlain::Params ep, int splitk, hipStream_t s) {
   // tile choice: 128x128 when it still yields >= ~1 block per CU, else 64x64.  Weight-gradient
   // products (transA: K = rows x steps is huge, M x N small) fill the chip with K splits; the
-  // thresholds / block targets below are the measured optima of scripts/bench_tn.py on MI355X.
+  // thresholds / block targets below are the measured optima of a round-1 sweep on MI355X (scripts/bench_wgrad.py covers the same shapes).
   const long blocks_big = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
   const bool deepk = transA && g.K >= 4096;
   const bool big = blocks_big >= 192 || (deepk && g.M >= 256 && g.N >= 256);
