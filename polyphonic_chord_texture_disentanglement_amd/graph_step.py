@@ -88,8 +88,11 @@ class GraphedTrainStep:
         if self._host_events[i] is not None:
             self._host_events[i].synchronize()
         h = self._host_params[i]
+        # (the bias corrections exactly as ptv_clip_adam_step forms them: the betas arrive there as C floats and are raised in double)
+        b1 = torch.tensor(g['betas'][0], dtype=torch.float32).item()
+        b2 = torch.tensor(g['betas'][1], dtype=torch.float32).item()
         h[0], h[1] = float(beta), float(g['lr'])
-        h[2], h[3] = 1.0 - g['betas'][0] ** t, math.sqrt(1.0 - g['betas'][1] ** t)
+        h[2], h[3] = 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t)
         self.params.copy_(h, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
