@@ -193,7 +193,7 @@ static float* splitk_workspace(hipStream_t s, size_t bytes) {
   if (b.bytes < bytes) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) return nullptr;   // cannot grow inside a capture
-    if (b.p) { if (hipStreamSynchronize(s) != hipSuccess) return nullptr; (void)hipFree(b.p); }
+    // (the outgrown buffer is not freed: a captured hipGraph may hold its address)
     const size_t want = bytes + bytes / 4;
     if (hipMalloc(reinterpret_cast<void**>(&b.p), want) != hipSuccess) { b = Buf{nullptr, 0}; return nullptr; }
     b.bytes = want;
