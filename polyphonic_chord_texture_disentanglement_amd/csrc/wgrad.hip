@@ -421,7 +421,7 @@ static WsBuf* ws_for(hipStream_t s, size_t bytes) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) return nullptr;   // cannot grow inside a capture
     // (the outgrown buffer is NOT freed: a captured hipGraph may hold its address -- graph_step.py replays launches recorded on this
-    // stream -- and it is a few megabytes at most)
+    // stream -- and it is tens of megabytes at most)
     size_t want = bytes + bytes / 4;
     if (hipMalloc(reinterpret_cast<void**>(&b.p), want) != hipSuccess) { b = WsBuf{}; return nullptr; }
     b.bytes = want;
