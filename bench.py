@@ -478,6 +478,10 @@ def main():
             try:
                 res['parity'] = {'benched': golden_parity(args.precision, dev), 'fp32_path': golden_parity('fp32', dev) if args.precision != 'fp32' else None,
                                  'bar': 'north_star: losses within 1e-4 of the CPU reference in fp32; bf16 = bf16 MFMA operands + bf16-stored saved tensors'}
+                # the same at B = 4 and at the BENCHED batch (round 4: full_tf1_b512.npz, produced by the reference at B = 512)
+                res['parity']['by_batch'] = {
+                    'b%d' % b_: {p_: golden_parity(p_, dev, case='full_tf1_b%d' % b_) for p_ in dict.fromkeys((args.precision, 'fp32'))}
+                    for b_ in (4, 512)}
             except Exception as e:
                 res['parity'] = {'error': repr(e)}
         if world == 1 and not args.no_cpu_baseline:

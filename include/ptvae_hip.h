@@ -135,7 +135,7 @@ int ptv_gru_seq_bwd(int prec, int M, int H, int T,
  * All array arguments are HOST arrays of NC entries (device pointers / strides per chain).
  * `xch`: per chain a bf16 scratch tensor for the exchanged operand, (T+1)*M*H elements (forward) / T*M*3H (backward),
  *   held K-blocked [step][k/8][row][8] so that the consumers' MFMA-fragment loads are contiguous across lanes.
- * `sync`: 16 * (1 + 32) device words ZEROED by the caller on `stream` before the call: word 0 = error flag (non-zero
+ * `sync`: 16 * (1 + 32) device words (the host allocates 16 * (1 + 32 + 128): see the split-K form below) ZEROED by the caller on `stream` before the call: word 0 = error flag (non-zero
  *   after the launch = a bounded spin gave up, results invalid), word 16*(1+g) = arrival counter of row group g.
  * Returns PTV_ERR_UNSUPPORTED (-3) when the shape does not fit one workgroup per CU (H % 256, H <= 1024,
  * rows per workgroup <= 256): the caller then uses the per-step entry points.  At most ONE persistent launch may
@@ -156,6 +156,21 @@ int ptv_gru_persist_bwd(int NC, int M, int H, int T,
                         const float* const* dh_last, const long* last_ld,
                         void* const* dgi, void* const* dgh, float* const* dh0,
                         const int* reverse, void* const* xch, unsigned* sync, void* stream);
+/* The BPTT with split-K TEAMS (round 4): S = 2 or 4 consecutive workgroups share 16*S hidden units and split K = 3H, so a workgroup
+ * reads 1/S of the exchanged operand per step (the classic kernel is bound by exactly that read: 64 unit groups x M x 3H bf16 per
+ * step); the team adds its fp32 partial tiles in a fixed order (bit-reproducible).  Same arguments and results as
+ * ptv_gru_persist_bwd (summation order differs) plus
+ *   part: per chain ptv_gru_persist_part_elems(NC, M, H, S) floats of scratch (partial tiles, ring of two steps),
+ *   sync: 16 * (1 + 32 + 128) ZEROED words (row-group counters as above, then one counter per team from word 16*33 on).
+ * Up to 512 rows per workgroup: the four chains of two bi-GRUs at M = 512, H = 1024 fit ONE launch. */
+int ptv_gru_persist_splitk_supported(int NC, int M, int H, int S);
+long ptv_gru_persist_part_elems(int NC, int M, int H, int S);
+int ptv_gru_persist_bwd_splitk(int S, int NC, int M, int H, int T,
+                               const float* const* hall, const void* const* gates, const void* const* w_t16,
+                               const void* const* dh_ext, const long* ext_step, const long* ext_ld, const int* ext_bf16,
+                               const float* const* dh_last, const long* last_ld,
+                               void* const* dgi, void* const* dgh, float* const* dh0,
+                               const int* reverse, void* const* xch, float* const* part, unsigned* sync, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Streaming helpers (layout shuffles and reductions that torch would do with cat/transpose/sum).

@@ -63,6 +63,7 @@ struct PChainB {
   __bf16* dgi; __bf16* dgh; float* dh0;
   __bf16* xch;                                           // exchange scratch [T][3H/8][M][8]
   int reverse;
+  float* part;                                           // split-K teams only: fp32 partial tiles [2][RG][teams][dest][src][rows_wg][16]
 };
 struct PGruBwdArgs {
   PChainB c[PMAXC];
@@ -406,6 +407,195 @@ __global__ __launch_bounds__(NTHREADS, 2) void pgru_bwd_kernel(PGruBwdArgs a) {
   }
 }
 
+// =============================================================================================
+// BPTT, split-K teams (round 4).  The kernel above makes every workgroup read ALL K = 3H of its row group's exchanged operand per
+// step -- 64 unit groups x M x 3H bf16 = 201 MB per step and chain at M = 512, H = 1024, at the ~65 GB/s a CU gets out of a
+// handed-off tile (MI355X_MICROARCH.md, handoff-payload): 12-16 us of a 21-us step.  Here S consecutive workgroups (a TEAM, on one
+// XCD under the XCD-aware block map) share 16*S units and split K: a workgroup keeps W_hh^T[16*S units][3H/S] in LDS (the same
+// 96 KB), reads only its K range of the operand (1/S of the bytes), and the team exchanges fp32 partial tiles: workgroup ks
+// FINALISES units [16*ks, 16*ks+16) of the team -- it parks the other S-1 tiles [rows x 16] in a scratch ring (16-byte sc1
+// stores), bumps the team's counter, and adds the S-1 tiles it receives to its own IN SOURCE ORDER (fixed association: the result
+// does not depend on arrival order).  Per step and workgroup at rows = 128: 192 KB + 24 KB read instead of 768 KB, one more
+// (4-party, same-XCD) hand-off.  The epilogue operands (gates, previous state, external gradient) are requested after the
+// partials are published, while the accumulators are dead, so the kernel stays inside 256 registers at 512 rows per workgroup:
+// all four chains of the two encoder bi-GRUs fit ONE launch.  Epilogue, exchange layout, dgi / dgh outputs: as above.
+// =============================================================================================
+__device__ __forceinline__ u32x4 as_u32x4(const f32x4& v) { union { f32x4 f; u32x4 u; } x; x.f = v; return x.u; }
+__device__ __forceinline__ f32x4 as_f32x4(const u32x4& v) { union { u32x4 u; f32x4 f; } x; x.u = v; return x.f; }
+
+template <int FM, int KU, int S>
+__global__ __launch_bounds__(NTHREADS, 2) void pgru_bwd_sk_kernel(PGruBwdArgs a) {
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ __attribute__((aligned(16))) char smem[PLDS];
+  __bf16* Ws = reinterpret_cast<__bf16*>(smem);
+  int grp, idx;
+  block_map(a.NC * a.RG, a.UG, grp, idx);
+  const int ch = grp / a.RG, rg = grp - ch * a.RG;
+  const int team = idx / S, ks = idx - team * S;
+  const PChainB& c = a.c[ch];
+  const int H = a.H, M = a.M, T = a.T;
+  const long MH = (long)M * H, M3H = 3 * MH;
+  const int KS = 3 * H / S;                                   // this workgroup's K range [ks*KS, (ks+1)*KS)
+  const int uq0 = team * (PU * S), u0 = uq0 + ks * PU;       // the team's units / the 16 this workgroup finalises
+  const int TPG = a.UG / S;                                   // teams per row group
+  gu32* cnt = (gu32*)(a.sync + 16 * (1 + grp));
+  gu32* tcnt = (gu32*)(a.sync + 16 * (33 + grp * TPG + team));
+  gu32* err = (gu32*)(a.sync);
+
+  load_w_slice<PU * S>(Ws, c.w_t + (long)ks * KS, KS, [&](int r) { return (long)(uq0 + r) * 3 * H; });
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rl = lane & 15, kq = lane >> 4;
+  const int u = u0 + kq * 4;
+  const int rw0 = wave * (FM * 16);
+  const int row0 = rg * a.rows_wg + rw0;
+  int row[FM]; bool ok[FM]; unsigned rowoff[FM]; float4 dhz[FM];
+#pragma unroll
+  for (int i = 0; i < FM; i++) {
+    const int r = row0 + i * 16 + rl;
+    ok[i] = r < M; row[i] = r < M ? r : M - 1;
+    rowoff[i] = (unsigned)(((long)kq * M + row[i]) * 16);
+    dhz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  bool dead = false;
+  PMma<FM, KU, S, 0> mm;
+  mm.kstride = (unsigned)M * 64u;
+  const int xe = (kq & 1) * 4;
+  const int nkb = KS >> 5;
+  const long xks = (long)ks * KS * M;                         // this K range inside a slot of [3H/8][M][8]
+  const long ptile = (long)a.rows_wg * 16;                    // floats of one [rows x 16] partial tile
+  const long pteam = (long)S * S * ptile, pslot = (long)a.RG * TPG * pteam;
+  float* pbase = c.part + ((long)rg * TPG + team) * pteam;
+  const unsigned plane = (unsigned)(((rw0 + rl) * 16 + kq * 4) * 4);       // byte offset of this lane inside a tile (+ i*1024)
+
+  for (int step = T - 1; step >= (c.dh0 ? -1 : 0); step--) {
+    const int t = step < 0 ? 0 : (c.reverse ? T - 1 - step : step);
+    const bool last = step == T - 1;
+    f32x4 own[FM];
+#pragma unroll
+    for (int i = 0; i < FM; i++) own[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __amdgpu_buffer_rsrc_t prs = make_rsrc(pbase + ((step + 1) & 1) * pslot, pteam * 4);
+    if (!last) {
+      wait_arrivals<false>(cnt, (unsigned)(a.UG * (T - 1 - step)), err, dead);          // dgh_{step+1} of the row group is published
+      f32x4 acc[FM][S];
+#pragma unroll
+      for (int i = 0; i < FM; i++)
+#pragma unroll
+        for (int j = 0; j < S; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      mm.run(make_rsrc(c.xch + (long)(step + 1) * M3H + xks, (long)KS * M * 2), rowoff, Ws, nkb, acc);
+#pragma unroll
+      for (int j = 0; j < S; j++) {
+        if (j == ks) {
+#pragma unroll
+          for (int i = 0; i < FM; i++) own[i] = acc[i][j];
+        } else {
+#pragma unroll
+          for (int i = 0; i < FM; i++)
+            __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(acc[i][j]), prs, plane + (unsigned)i * 1024u, (unsigned)((j * S + ks) * ptile * 4), 16);
+        }
+      }
+      publish(tcnt);
+    }
+    // this lane's cells: saved gates, previous state, external gradients (all from earlier launches)
+    float4 gr[FM], gz[FM], gn[FM], gh[FM], hpv[FM], ex[FM];
+    if (step >= 0) {
+#pragma unroll
+      for (int i = 0; i < FM; i++) {
+        const long o = (long)row[i] * H + u;
+        const __bf16* gp = c.gates + (long)step * 4 * MH + o;
+        gr[i] = ld_bf16x4(gp); gz[i] = ld_bf16x4(gp + MH); gn[i] = ld_bf16x4(gp + 2 * MH); gh[i] = ld_bf16x4(gp + 3 * MH);
+        hpv[i] = *reinterpret_cast<const float4*>(c.hall + (long)step * MH + o);
+        float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c.dh_ext) {
+          const long eo = (long)step * c.ext_step + (long)row[i] * c.ext_ld + u;
+          e = c.ext_bf16 ? ld_bf16x4(reinterpret_cast<const __bf16*>(c.dh_ext) + eo) : *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(c.dh_ext) + eo);
+        }
+        if (last && c.dh_last) {
+          const float4 q = *reinterpret_cast<const float4*>(c.dh_last + (long)row[i] * c.last_ld + u);
+          e.x += q.x; e.y += q.y; e.z += q.z; e.w += q.w;
+        }
+        ex[i] = e;
+      }
+    }
+    f32x4 sum[FM];
+    if (!last) {
+      wait_arrivals<false>(tcnt, (unsigned)(S * (T - 1 - step)), err, dead);            // the team's partial tiles are parked
+      f32x4 p[S][FM];
+#pragma unroll
+      for (int q = 0; q < S; q++) {
+        if (q == ks) {
+#pragma unroll
+          for (int i = 0; i < FM; i++) p[q][i] = own[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < FM; i++)
+            p[q][i] = as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(prs, plane + (unsigned)i * 1024u, (unsigned)((ks * S + q) * ptile * 4), 16));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < FM; i++) {
+        f32x4 s_ = p[0][i];
+#pragma unroll
+        for (int q = 1; q < S; q++) s_ += p[q][i];
+        sum[i] = s_;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < FM; i++) sum[i] = own[i];
+    }
+    if (step < 0) {                                                            // dh0 = dhz_0 + dgh_0 . W_hh
+#pragma unroll
+      for (int i = 0; i < FM; i++)
+        if (ok[i]) *reinterpret_cast<float4*>(c.dh0 + (long)row[i] * H + u) =
+            make_float4(sum[i][0] + dhz[i].x, sum[i][1] + dhz[i].y, sum[i][2] + dhz[i].z, sum[i][3] + dhz[i].w);
+      break;
+    }
+    float4 dR[FM], dZ[FM], dN[FM], dNR[FM];
+#pragma unroll
+    for (int i = 0; i < FM; i++) {
+      const float dzn[4] = {dhz[i].x, dhz[i].y, dhz[i].z, dhz[i].w}, e1[4] = {ex[i].x, ex[i].y, ex[i].z, ex[i].w};
+      const float R[4] = {gr[i].x, gr[i].y, gr[i].z, gr[i].w}, Z[4] = {gz[i].x, gz[i].y, gz[i].z, gz[i].w};
+      const float N[4] = {gn[i].x, gn[i].y, gn[i].z, gn[i].w}, HN[4] = {gh[i].x, gh[i].y, gh[i].z, gh[i].w};
+      const float hP[4] = {hpv[i].x, hpv[i].y, hpv[i].z, hpv[i].w};
+      float dr[4], dz[4], dn[4], dnr[4], dq[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float dh = sum[i][e] + dzn[e] + e1[e];
+        dn[e] = dh * (1.0f - Z[e]) * (1.0f - N[e] * N[e]);
+        dz[e] = dh * (hP[e] - N[e]) * Z[e] * (1.0f - Z[e]);
+        dr[e] = dn[e] * HN[e] * R[e] * (1.0f - R[e]);
+        dnr[e] = dn[e] * R[e];
+        dq[e] = dh * Z[e];
+      }
+      dhz[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+      dR[i] = make_float4(dr[0], dr[1], dr[2], dr[3]); dZ[i] = make_float4(dz[0], dz[1], dz[2], dz[3]);
+      dN[i] = make_float4(dn[0], dn[1], dn[2], dn[3]);
+      dNR[i] = make_float4(dnr[0], dnr[1], dnr[2], dnr[3]);
+      if (ok[i]) {                                                             // exchanged operand: write-through, first and alone
+        __bf16* px = c.xch + (long)step * M3H + (long)row[i] * 8 + xe;
+        store_bf16x4_sc1(px + (long)((u) >> 3) * M * 8, dr[0], dr[1], dr[2], dr[3]);
+        store_bf16x4_sc1(px + (long)((H + u) >> 3) * M * 8, dz[0], dz[1], dz[2], dz[3]);
+        store_bf16x4_sc1(px + (long)((2 * H + u) >> 3) * M * 8, dnr[0], dnr[1], dnr[2], dnr[3]);
+      }
+    }
+    if (step > 0 || c.dh0) publish(cnt);
+#pragma unroll
+    for (int i = 0; i < FM; i++) {
+      if (ok[i]) {                                                             // dgi / dgh: read by later launches only
+        __bf16* ph = c.dgh + (long)step * M3H + (long)row[i] * 3 * H + u;
+        st_bf16x4(ph, dR[i].x, dR[i].y, dR[i].z, dR[i].w);
+        st_bf16x4(ph + H, dZ[i].x, dZ[i].y, dZ[i].z, dZ[i].w);
+        st_bf16x4(ph + 2 * H, dNR[i].x, dNR[i].y, dNR[i].z, dNR[i].w);
+        __bf16* pi = c.dgi + (long)t * M3H + (long)row[i] * 3 * H + u;
+        st_bf16x4(pi, dR[i].x, dR[i].y, dR[i].z, dR[i].w);
+        st_bf16x4(pi + H, dZ[i].x, dZ[i].y, dZ[i].z, dZ[i].w);
+        st_bf16x4(pi + 2 * H, dN[i].x, dN[i].y, dN[i].z, dN[i].w);
+      }
+    }
+  }
+}
+
 // x[(k/8)*M*8 + row*8 + k%8] = bf16(h[row*H + k]): slot 0 of the forward exchange tensor from the caller's fp32 state
 __global__ void pack_blocked_kernel(const float* __restrict__ h, __bf16* __restrict__ x, int M, int H) {
   const long n = (long)M * (H >> 3);
@@ -432,7 +622,7 @@ static int num_cu() {
 }
 
 // row groups / rows per workgroup for NC chains of M rows with UG = H/16 unit groups: one workgroup per CU at most
-static int plan(int NC, int M, int H, int& RG, int& rows_wg, int& FM) {
+static int plan(int NC, int M, int H, int& RG, int& rows_wg, int& FM, int fm_max = 4) {
   if (NC < 1 || NC > PMAXC || M <= 0 || H < 256 || H > 1024 || (H & 255)) return PTV_ERR_UNSUPPORTED;
   const int ncu = num_cu();
   const int UG = H / PU;
@@ -441,13 +631,14 @@ static int plan(int NC, int M, int H, int& RG, int& rows_wg, int& FM) {
   int p2 = 1; while (p2 * 2 <= rg) p2 *= 2;
   rg = p2;
   while (rg > 1 && (M + rg - 1) / rg < 64 && (M + rg / 2 - 1) / (rg / 2) <= 256) rg /= 2;     // no emptier than one 64-row panel
-  int rows = ((M + rg - 1) / rg + 63) / 64 * 64;
-  int fm = rows / 64;
-  if (fm == 3) { fm = 4; rows = 256; }
-  if (fm > 4) return PTV_ERR_UNSUPPORTED;
-  RG = rg; rows_wg = rows; FM = fm;
+  int fm = ((M + rg - 1) / rg + 63) / 64;
+  if (fm == 3) fm = 4;
+  if (fm > 4 && fm <= 8) fm = 8;
+  if (fm > fm_max) return PTV_ERR_UNSUPPORTED;
+  RG = rg; rows_wg = fm * 64; FM = fm;
   return PTV_OK;
 }
+static bool splitk_ok(int H, int S) { return (S == 2 || S == 4) && (H / PU) % S == 0 && (3 * H / S) % 192 == 0; }
 
 }  // namespace ptv
 
@@ -538,6 +729,56 @@ extern "C" int ptv_gru_persist_bwd(int NC, int M, int H, int T,
   if (g_load_policy == 0) PTV_PG_LAUNCH(pgru_bwd_kernel, 0, 3 * H);
   else if (g_load_policy == 1) PTV_PG_LAUNCH(pgru_bwd_kernel, 1, 3 * H);
   else PTV_PG_LAUNCH(pgru_bwd_kernel, 2, 3 * H);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+// ---- split-K teams (pgru_bwd_sk_kernel): S = 2 or 4 workgroups share 16*S units and split K = 3H
+extern "C" int ptv_gru_persist_splitk_supported(int NC, int M, int H, int S) {
+  int RG, rows, FM;
+  return splitk_ok(H, S) && plan(NC, M, H, RG, rows, FM, 8) == PTV_OK ? 1 : 0;
+}
+
+extern "C" long ptv_gru_persist_part_elems(int NC, int M, int H, int S) {
+  int RG, rows, FM;
+  if (!splitk_ok(H, S) || plan(NC, M, H, RG, rows, FM, 8) != PTV_OK) return 0;
+  return 2L * RG * rows * H * S;                               // [2][RG][H/(16 S) teams][S][S][rows][16]
+}
+
+extern "C" int ptv_gru_persist_bwd_splitk(int S, int NC, int M, int H, int T,
+                                          const float* const* hall, const void* const* gates, const void* const* w_t16,
+                                          const void* const* dh_ext, const long* ext_step, const long* ext_ld, const int* ext_bf16,
+                                          const float* const* dh_last, const long* last_ld,
+                                          void* const* dgi, void* const* dgh, float* const* dh0,
+                                          const int* reverse, void* const* xch, float* const* part, unsigned* sync, void* stream) {
+  if (T <= 0 || !hall || !gates || !w_t16 || !dgi || !dgh || !reverse || !xch || !part || !sync) return PTV_ERR_ARG;
+  if (!splitk_ok(H, S)) return PTV_ERR_UNSUPPORTED;
+  int RG, rows, FM;
+  PTV_TRY(plan(NC, M, H, RG, rows, FM, 8));
+  PGruBwdArgs a{};
+  for (int i = 0; i < NC; i++) {
+    if (!hall[i] || !gates[i] || !w_t16[i] || !dgi[i] || !dgh[i] || !xch[i] || !part[i]) return PTV_ERR_ARG;
+    const bool hext = dh_ext && dh_ext[i];
+    if (hext && ((ext_ld[i] & 3) || (ext_step[i] & 3))) return PTV_ERR_ARG;
+    const bool hl = dh_last && dh_last[i];
+    if (hl && (last_ld[i] & 3)) return PTV_ERR_ARG;
+    a.c[i] = PChainB{(const __bf16*)w_t16[i], hall[i], (const __bf16*)gates[i],
+                     hext ? dh_ext[i] : nullptr, hext ? ext_step[i] : 0, hext ? ext_ld[i] : 0, hext && ext_bf16 ? ext_bf16[i] : 0,
+                     hl ? dh_last[i] : nullptr, hl ? last_ld[i] : 0,
+                     (__bf16*)dgi[i], (__bf16*)dgh[i], dh0 ? dh0[i] : nullptr, (__bf16*)xch[i], reverse[i], part[i]};
+  }
+  a.NC = NC; a.M = M; a.H = H; a.T = T; a.RG = RG; a.UG = H / PU; a.rows_wg = rows; a.sync = sync;
+  if (NC * RG > 32 || NC * RG * (a.UG / S) > 128) return PTV_ERR_UNSUPPORTED;            // counters: 16 * (33 + 128) words
+  const dim3 grid(NC * RG * a.UG), block(NTHREADS);
+  hipStream_t s = (hipStream_t)stream;
+#define PTV_SK_LAUNCH(S_)                                                                                  \
+  do {                                                                                                     \
+    if (FM == 1) hipLaunchKernelGGL((pgru_bwd_sk_kernel<1, 3, S_>), grid, block, 0, s, a);                 \
+    else if (FM == 2) hipLaunchKernelGGL((pgru_bwd_sk_kernel<2, 3, S_>), grid, block, 0, s, a);            \
+    else if (FM == 4) hipLaunchKernelGGL((pgru_bwd_sk_kernel<4, 3, S_>), grid, block, 0, s, a);            \
+    else hipLaunchKernelGGL((pgru_bwd_sk_kernel<8, 1, S_>), grid, block, 0, s, a);                         \
+  } while (0)
+  if (S == 4) PTV_SK_LAUNCH(4); else PTV_SK_LAUNCH(2);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

@@ -438,6 +438,10 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
   if (M < 0 || N < 0 || K < 0 || !A || !B || !C) return PTV_ERR_ARG;
   if (k_top && (k_unit <= 0 || k_unit % WBK)) return PTV_ERR_ARG;
   if (M == 0 || N == 0) return PTV_OK;
+  {                                                      // timing experiment only (results invalid): PTV_WGRAD_DRY=1 skips every product
+    static const int dry = getenv("PTV_WGRAD_DRY") ? atoi(getenv("PTV_WGRAD_DRY")) : 0;
+    if (dry) return PTV_OK;
+  }
   hipStream_t s = (hipStream_t)stream;
   if (K == 0) {
     if (!accumulate) {

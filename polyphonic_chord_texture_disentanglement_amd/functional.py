@@ -147,15 +147,16 @@ def _W(p, prec):
 
 
 # Small zero-initialised buffers (reduction targets, counters, sync words: ~40 per step, 8 bytes to 2 KB each) are slices of a chunk
-# that was cleared ONCE when it was allocated, handed out once and never reused -- one fill launch per 64 KB instead of one per
+# that was cleared ONCE when it was allocated, handed out once and never reused -- one fill launch per 256 KB instead of one per
 # buffer.  One bump chunk per (stream, dtype, fill value): a slice is requested on the stream whose earlier work cleared the chunk.
-# Not inside a graph capture (the fill has to be a node of the graph) and not for anything over 4 KB.
+# Not inside a graph capture (the fill has to be a node of the graph) and not for anything over 16 KB
+# (the persistent launches' sync words are 10 KB).
 _ZCHUNK = {}
-_ZCHUNK_BYTES = 64 * 1024
+_ZCHUNK_BYTES = 256 * 1024
 
 
 def _small_filled(n, dtype, value, dev):
-    if n * 4 > 4096 or torch.cuda.is_current_stream_capturing():
+    if n * 4 > 16384 or torch.cuda.is_current_stream_capturing():
         return torch.full((n,), value, device=dev, dtype=dtype)
     key = (stream_ptr(), dtype, value, dev.index if isinstance(dev, torch.device) else str(dev))
     ent = _ZCHUNK.get(key)
@@ -359,7 +360,7 @@ class _PersistTurn:
 
 def _persist_sync(NC, dev):
     """zeroed sync words of one launch: word 0 = error flag, word 16*(1+g) = arrival counter of row group g"""
-    sync = _izeros(16 * 33, dev)
+    sync = _izeros(16 * (33 + 128), dev)       # error word, 32 row-group counters, 128 team counters (split-K BPTT)
     _PERSIST_SYNC.append(sync)
     if len(_PERSIST_SYNC) > 64:
         del _PERSIST_SYNC[:32]
@@ -395,6 +396,23 @@ def gru_persist_fwd(M, H, T, chains):
     check(rc, 'ptv_gru_persist_fwd')
 
 
+# BPTT of the persistent recurrences: split-K teams of S workgroups (csrc/gru_persist.hip, pgru_bwd_sk_kernel) read 1/S of the
+# exchanged operand per step; 0 = the round-2 kernel (every workgroup reads all of K).  Measured in scripts/bench_persist.py.
+PERSIST_SPLITK = int(os.environ.get('PTV_PERSIST_SPLITK', '4'))
+_SPLITK_OK = {}
+
+
+def persist_splitk(NC, M, H):
+    """S of the split-K BPTT for this shape, or 0"""
+    S = PERSIST_SPLITK
+    if S not in (2, 4):
+        return 0
+    key = (NC, M, H, S, torch.cuda.current_device())
+    if key not in _SPLITK_OK:
+        _SPLITK_OK[key] = bool(lib().ptv_gru_persist_splitk_supported(NC, M, H, S))
+    return S if _SPLITK_OK[key] else 0
+
+
 def gru_persist_bwd(M, H, T, chains):
     """chains: dicts with hall, gates, wt16 (bf16 W_hh^T [H,3H]), dh_ext ([T,M,H] fp32/bf16 view or None), dh_last, dgi, dgh,
     dh0 (or None), reverse"""
@@ -405,14 +423,21 @@ def gru_persist_bwd(M, H, T, chains):
     dev = chains[0]['hall'].device
     sync = _persist_sync(NC, dev)
     xch = [torch.empty(T * M * 3 * H, device=dev, dtype=BF16) for _ in chains]
+    S = persist_splitk(NC, M, H)
+    args = (NC, M, H, T, _parr(g('hall')), _parr(g('gates')), _parr(g('wt16')),
+            _parr(ext), _larr([e.stride(0) if e is not None else 0 for e in ext]),
+            _larr([e.stride(1) if e is not None else 0 for e in ext]),
+            _iarr([_bf(e) for e in ext]),
+            _parr(last), _larr([l.stride(0) if l is not None else 0 for l in last]),
+            _parr(g('dgi')), _parr(g('dgh')), _parr(g('dh0')),
+            _iarr([int(bool(c.get('reverse'))) for c in chains]), _parr(xch))
     with _PersistTurn():
-        rc = lib().ptv_gru_persist_bwd(NC, M, H, T, _parr(g('hall')), _parr(g('gates')), _parr(g('wt16')),
-                                       _parr(ext), _larr([e.stride(0) if e is not None else 0 for e in ext]),
-                                       _larr([e.stride(1) if e is not None else 0 for e in ext]),
-                                       _iarr([_bf(e) for e in ext]),
-                                       _parr(last), _larr([l.stride(0) if l is not None else 0 for l in last]),
-                                       _parr(g('dgi')), _parr(g('dgh')), _parr(g('dh0')),
-                                       _iarr([int(bool(c.get('reverse'))) for c in chains]), _parr(xch), ptr(sync), stream_ptr())
+        if S:
+            n = lib().ptv_gru_persist_part_elems(NC, M, H, S)
+            part = [torch.empty(n, device=dev) for _ in chains]
+            rc = lib().ptv_gru_persist_bwd_splitk(S, *args, _parr(part), ptr(sync), stream_ptr())
+        else:
+            rc = lib().ptv_gru_persist_bwd(*args, ptr(sync), stream_ptr())
     check(rc, 'ptv_gru_persist_bwd')
 
 
@@ -493,6 +518,27 @@ def _record_stream(obj, stream):
                 _record_stream(o, stream)
 
 
+# HIP has three stream priorities (hipDeviceGetStreamPriorityRange: 1 = low, 0 = normal, -1 = high; torch exposes only 0 / -1): the
+# command processor hands free workgroup slots to the highest-priority queue that has a ready dispatch.  PTV_POOL_PRIO gives the
+# pool streams theirs (pool stream 3 carries the decoder's deferred weight-gradient products: the bulk work that should fill the gaps
+# of the latency chains, not delay them).
+POOL_PRIO = [int(v) for v in os.environ.get('PTV_POOL_PRIO', '0,0,0,0').split(',')]
+_HIP = []
+
+
+def _new_stream(device, prio=0):
+    if prio <= 0:
+        return torch.cuda.Stream(device=device, priority=prio)
+    if not _HIP:
+        _HIP.append(ctypes.CDLL('libamdhip64.so'))
+    st = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = _HIP[0].hipStreamCreateWithPriority(ctypes.byref(st), 0, int(prio))
+    if rc != 0:
+        raise RuntimeError('hipStreamCreateWithPriority failed: %d' % rc)
+    return torch.cuda.ExternalStream(st.value, device=device)        # (never destroyed: lives as long as the process)
+
+
 class Side:
     """s = Side(slot); s(fn, *keep_alive) runs fn on the sibling stream after everything enqueued so far
     on the parent; s.join() makes the parent wait for it.  `keep_alive` tensors (or containers of tensors) stay referenced
@@ -519,7 +565,7 @@ class Side:
                 # creating them lazily in first-use order made the step time depend on which slot happened to be used first (0.4 ms)
                 order = [1, 2, 0, 3] if pool == 4 else list(range(pool))
                 for k in order:
-                    _CHILD_STREAMS.setdefault(('pool', self.main.device.index, k), torch.cuda.Stream(device=self.main.device))
+                    _CHILD_STREAMS.setdefault(('pool', self.main.device.index, k), _new_stream(self.main.device, POOL_PRIO[k % len(POOL_PRIO)]))
             else:
                 _CHILD_STREAMS[key] = torch.cuda.Stream(device=self.main.device)
         self.s = _CHILD_STREAMS[key]

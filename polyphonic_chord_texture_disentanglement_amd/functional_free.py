@@ -535,10 +535,12 @@ class GraphedDecoderStepFn(torch.autograd.Function):
 
 
 class ChordDecoderStepFn(torch.autograd.Function):
-    """(z_chd, c_sm [8,B,36] or None, coins [8] bools, prec, *params) -> root [8,B,12], chroma [8,B,24], bass [8,B,12]"""
+    """(z_chd, c_sm [8,B,36] or None, coins [8] bools, force, prec, *params) -> root [8,B,12], chroma [8,B,24], bass [8,B,12]
+    force (tests: replay mode): {'root' [8,B,12], 'chroma' [8,B,24], 'bass' [8,B,12]} logits of a recorded run whose
+    argmax decisions build the fed-back tokens instead of this run's own (a near-tie flipped by rounding changes the trajectory)"""
 
     @staticmethod
-    def forward(ctx, z, c_sm, coins, prec, *params):
+    def forward(ctx, z, c_sm, coins, force, prec, *params):
         P = dict(zip(F_.CHD_PARAM_NAMES, params))
         dev = z.device
         z = z.contiguous()
@@ -567,7 +569,8 @@ class ChordDecoderStepFn(torch.autograd.Function):
                 if coins[t] and c_sm is not None:
                     copy2d(toks[t + 1], c_sm[t])
                 else:
-                    call('ptv_chord_token', ptr(root[t]), ptr(chroma[t]), ptr(bass[t]), ptr(masks), ptr(toks[t + 1]), B,
+                    src = (force['root'], force['chroma'], force['bass']) if force else (root, chroma, bass)
+                    call('ptv_chord_token', ptr(src[0][t]), ptr(src[1][t]), ptr(src[2][t]), ptr(masks), ptr(toks[t + 1]), B,
                          stream_ptr())
         ctx.save_for_backward(z, *params)
         ctx.st = dict(hall=hall, gates=gates, toks=toks, z_in=z_in, prec=prec, T=T, B=B, H=H, I=I)
@@ -577,4 +580,4 @@ class ChordDecoderStepFn(torch.autograd.Function):
     def backward(ctx, droot, dchroma, dbass):
         # tokens are constants (ground truth or argmax one-hots): same BPTT as the teacher-forced path
         g = F_.ChordDecoderTFFn.backward(ctx, droot, dchroma, dbass)
-        return (g[0], None, None, None) + tuple(g[3:])
+        return (g[0], None, None, None, None) + tuple(g[3:])

@@ -176,6 +176,7 @@ class RnnDecoder(nn.Module, _PrecMixin):
         self.chroma_out = Linear(hidden_dim, 24)
         self.bass_out = Linear(hidden_dim, 12)
         self.num_step = num_step
+        self.force_trace = None            # {'root' [B,8,12], 'chroma' [B,8,12,2], 'bass' [B,8,12]} logits: replay mode (tests)
 
     def _params(self):
         sd = dict(self.named_parameters())
@@ -197,7 +198,12 @@ class RnnDecoder(nn.Module, _PrecMixin):
         if all(coins) and not inference:
             root, chroma, bass = F_.ChordDecoderTFFn.apply(z_chd, c_sm, self._prec, *self._params())
         else:
-            root, chroma, bass = FF_.ChordDecoderStepFn.apply(z_chd, c_sm, list(coins), self._prec, *self._params())
+            force = None
+            if self.force_trace is not None:
+                ft = self.force_trace
+                force = {'root': ft['root'].float().transpose(0, 1).contiguous(), 'bass': ft['bass'].float().transpose(0, 1).contiguous(),
+                         'chroma': ft['chroma'].float().reshape(z_chd.size(0), T, 24).transpose(0, 1).contiguous()}
+            root, chroma, bass = FF_.ChordDecoderStepFn.apply(z_chd, c_sm, list(coins), force, self._prec, *self._params())
         bs = z_chd.size(0)
         # reference shapes [B,8,12] / [B,8,12,2] / [B,8,12] as views of the step-major buffers
         return root.transpose(0, 1), chroma.view(T, bs, 12, 2).transpose(0, 1), bass.transpose(0, 1)

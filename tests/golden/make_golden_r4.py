@@ -1,0 +1,165 @@
+"""Round-4 golden vectors, produced by running the REFERENCE itself (build container only; same recipe and helper classes as
+make_golden.py: `/root/reference` imported unmodified behind the two third-party stubs).  Fixtures hold inputs' seeds and expected
+outputs only.
+
+  full_tf1_b512.npz            the BENCHED batch (BASELINE configs[1], B = 512, teacher-forced, full init_model() geometry, filler
+                               weights 1234): eps, 11 losses, 256-element logit slices + checksums, per-tensor gradient norm / sum and
+                               a 64-element slice of EVERY gradient tensor
+  full_tf1_b4_gslices.npz      the same 64-element gradient slices for the existing cases full_tf1_b4 / full_tf1_b16 (regenerated with
+  full_tf1_b16_gslices.npz     make_golden.run_case; the losses are asserted bit-identical to the committed fixtures)
+  full_train5_b16.npz          5-step full-geometry training trace, B = 16, tfr = 1: zero_grad -> model('train') -> backward ->
+                               clip_grad_norm_(1) -> Adam(1e-3) -> MinExponentialLR (module.py:129-150): per step eps, 11 losses,
+                               pre-clip global gradient norm, lr, per-tensor parameter sum / abs-sum after the update
+  full_sched4_b8.npz           configs[4]'s schedule: train.py's ParameterScheduler (tf_rates (0.6,0),(0.5,0),(0.5,0), beta 0.1 with
+                               kl_anealing: scheduler.py:28-99, train.py:23-24,59-63) for 4 training steps at B = 8: per step the
+                               scheduled tfr1/tfr2/tfr3/beta, the 487 coins, eps, the argmax decisions (pitch / duration / chord: what a
+                               reduced-precision run has to be forced to) with their top-2 margins, 11 losses,
+                               gradient norm, parameter checksums
+
+    python tests/golden/make_golden_r4.py [b512] [slices] [train5] [sched4]     # needs /root/reference; b512 takes ~5 min / ~20 GB
+"""
+import os
+import sys
+import warnings
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402
+from make_golden_r2 import top2_margin  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(HERE))
+from polyphonic_chord_texture_disentanglement_amd.synthetic import synth_batch, fill_state_dict  # noqa: E402
+
+NSLICE = 64
+
+
+def grad_slices(res, out):
+    for k, v in res.items():
+        if k.startswith('grad.'):
+            flat = v.reshape(-1)
+            idx = np.linspace(0, flat.size - 1, min(NSLICE, flat.size)).astype(np.int64)
+            out['gslice.' + k[5:] + '.idx'] = idx
+            out['gslice.' + k[5:] + '.val'] = flat[idx].astype(np.float32)
+            out['gmax.' + k[5:]] = np.float32(np.abs(flat).max())
+
+
+def full_model(ref_model):
+    torch.manual_seed(0)
+    mf = ref_model.DisentangleVAE.init_model(torch.device('cpu'))
+    mf.decoder.device = torch.device('cpu')
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in mf.state_dict().items())
+    mf.load_state_dict(fill_state_dict(shapes, seed=1234))
+    return mf
+
+
+def checksums(m):
+    return (np.array([p.detach().double().sum().item() for p in m.parameters()]),
+            np.array([p.detach().double().abs().sum().item() for p in m.parameters()]))
+
+
+def main():
+    what = set(sys.argv[1:]) or {'b512', 'slices', 'train5', 'sched4'}
+    ref_model, ref_ptvae, ref_tp = mg.import_reference()
+    from amc_dl.torch_plus.train_utils import kl_anealing
+    warnings.simplefilter('ignore')
+
+    if 'slices' in what:
+        mf = full_model(ref_model)
+        for name, B, seed in (('tf1_b4', 4, 11), ('tf1_b16', 16, 12)):
+            res = mg.run_case(mf, B, 500 + seed, seed, (1., 1., 1.))
+            old = np.load(os.path.join(HERE, 'full_%s.npz' % name))
+            assert np.array_equal(res['losses'], old['losses']), 'full_%s does not regenerate bit-identically' % name
+            out = OrderedDict(B=np.int64(B), data_seed=np.int64(500 + seed), losses=res['losses'])
+            grad_slices(res, out)
+            np.savez_compressed(os.path.join(HERE, 'full_%s_gslices.npz' % name), **out)
+            print('slices', name, len(out))
+
+    if 'b512' in what:
+        mf = full_model(ref_model)
+        B, seed = 512, 14
+        res = mg.run_case(mf, B, 500 + seed, seed, (1., 1., 1.))
+        out = mg.slim(res)
+        grad_slices(res, out)
+        del out['x'], out['c'], out['pr_mat']          # regenerated from (B, data_seed)
+        out['B'] = np.int64(B)
+        out['data_seed'] = np.int64(500 + seed)
+        np.savez_compressed(os.path.join(HERE, 'full_tf1_b512.npz'), **out)
+        print('full tf1_b512', res['losses'])
+        del res, out
+
+    if 'train5' in what:
+        mf = full_model(ref_model)
+        opt = torch.optim.Adam(mf.parameters(), lr=1e-3)
+        sched = ref_tp.MinExponentialLR(opt, gamma=0.9999, minimum=1e-5)
+        B = 16
+        tr = OrderedDict(B=np.int64(B), data_seed0=np.int64(700), names=np.array([n for n, _ in mf.named_parameters()]))
+        for step in range(5):
+            x, c, pr = (torch.from_numpy(a) for a in synth_batch(B, 700 + step))
+            opt.zero_grad()
+            torch.manual_seed(800 + step)
+            with mg.EpsRecorder() as er, mg.CoinRecorder(800 + step):
+                losses = mf('train', x, c, pr, tfr1=1., tfr2=1., tfr3=1., beta=0.1, weights=[1, 0.5])
+            losses[0].backward()
+            gn = torch.nn.utils.clip_grad_norm_(mf.parameters(), 1)
+            opt.step()
+            sched.step()
+            tr['eps_chd.%d' % step], tr['eps_rhy.%d' % step] = er.eps[0].numpy(), er.eps[1].numpy()
+            tr['losses.%d' % step] = np.array([l.item() for l in losses])
+            tr['gnorm.%d' % step] = np.float64(gn.item())
+            tr['lr.%d' % step] = np.float64(opt.param_groups[0]['lr'])
+            tr['psum.%d' % step], tr['pabs.%d' % step] = checksums(mf)
+            print('train5 step', step, tr['losses.%d' % step][:4], float(gn))
+        np.savez_compressed(os.path.join(HERE, 'full_train5_b16.npz'), **tr)
+
+    if 'sched4' in what:
+        mf = full_model(ref_model)
+        opt = torch.optim.Adam(mf.parameters(), lr=1e-3)
+        sched = ref_tp.MinExponentialLR(opt, gamma=0.9999, minimum=1e-5)
+        ps = ref_tp.ParameterScheduler(tfr1=ref_tp.TeacherForcingScheduler(0.6, 0), tfr2=ref_tp.TeacherForcingScheduler(0.5, 0),
+                                       tfr3=ref_tp.TeacherForcingScheduler(0.5, 0),
+                                       beta=ref_tp.TeacherForcingScheduler(0.1, 0., f=kl_anealing),
+                                       weights=ref_tp.ConstantScheduler([1, 0.5]))
+        ps.train()
+        B = 8
+        tr = OrderedDict(B=np.int64(B), data_seed0=np.int64(900), names=np.array([n for n, _ in mf.named_parameters()]))
+        for step in range(4):
+            x, c, pr = (torch.from_numpy(a) for a in synth_batch(B, 900 + step))
+            opt.zero_grad()
+            params = ps.step()                                    # module.py:136
+            torch.manual_seed(950 + step)
+            with mg.EpsRecorder() as er, mg.CoinRecorder(950 + step) as cr:
+                outs = mf.run(x, c, pr, params['tfr1'], params['tfr2'], params['tfr3'])
+                losses = mf.loss_function(x, c, *outs, params['beta'], params['weights'])
+            losses[0].backward()
+            gn = torch.nn.utils.clip_grad_norm_(mf.parameters(), 1)
+            opt.step()
+            sched.step()
+            po, do = outs[0].detach().numpy(), outs[1].detach().numpy()
+            s = '.%d' % step
+            tr['sched' + s] = np.array([params['tfr1'], params['tfr2'], params['tfr3'], params['beta']], dtype=np.float64)
+            tr['coins' + s] = np.array(cr.coins, dtype=np.float64)
+            tr['eps_chd' + s], tr['eps_rhy' + s] = er.eps[0].numpy(), er.eps[1].numpy()
+            tr['pitch_inds' + s] = po.argmax(-1).astype(np.int16)
+            tr['dur_inds' + s] = do.argmax(-1).astype(np.int8)
+            tr['pitch_margin' + s] = top2_margin(po)
+            tr['dur_margin' + s] = np.abs(do[..., 0] - do[..., 1]).astype(np.float32)
+            for n_, t_ in (('root', outs[4]), ('chroma', outs[5]), ('bass', outs[6])):
+                tr['recon_%s%s' % (n_, s)] = t_.detach().numpy()
+            flat = po.reshape(-1)
+            idx = np.linspace(0, flat.size - 1, 256).astype(np.int64)
+            tr['pitch_outs.idx'] = idx
+            tr['pitch_outs.val' + s] = flat[idx]
+            tr['losses' + s] = np.array([l.item() for l in losses])
+            tr['gnorm' + s] = np.float64(gn.item())
+            tr['lr' + s] = np.float64(opt.param_groups[0]['lr'])
+            tr['psum' + s], tr['pabs' + s] = checksums(mf)
+            print('sched4 step', step, tr['sched' + s], tr['losses' + s][:4], float(gn), 'coins', len(cr.coins))
+        np.savez_compressed(os.path.join(HERE, 'full_sched4_b8.npz'), **tr)
+
+
+if __name__ == '__main__':
+    main()

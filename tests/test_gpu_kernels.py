@@ -173,17 +173,24 @@ def test_gru_seq_bf16_storage_fast_path(M, H, T, use_gi2):
 @pytest.mark.parametrize('NC,M,H,T,masked,use_gi2', [(1, 512, 1024, 6, False, True), (2, 512, 1024, 4, True, False),
                                                      (1, 512, 512, 8, False, True), (1, 1024, 1024, 3, False, False),
                                                      (1, 300, 512, 5, True, False), (2, 100, 1024, 3, False, True),
-                                                     (4, 512, 1024, 3, False, False)])
-def test_gru_persistent_kernels_vs_oracle_and_step_kernels(NC, M, H, T, masked, use_gi2):
+                                                     (4, 512, 1024, 3, False, False), (4, 300, 1024, 2, True, False),
+                                                     (1, 128, 1024, 5, False, False), (2, 1024, 1024, 2, False, False)])
+@pytest.mark.parametrize('splitk', [0, 2, 4])
+def test_gru_persistent_kernels_vs_oracle_and_step_kernels(NC, M, H, T, masked, use_gi2, splitk, monkeypatch):
     """csrc/gru_persist.hip (one weight-stationary launch per sequence, state exchanged between workgroups per step)
     against the fp32 oracle cell and against the per-step kernels of csrc/gru.hip on the same bf16 operands: forward
-    states + saved gates, BPTT dgi / dgh / dh0; NC chains per launch, reversed chains, masked rows, ragged M."""
+    states + saved gates, BPTT dgi / dgh / dh0; NC chains per launch, reversed chains, masked rows, ragged M.
+    splitk: the BPTT as split-K teams of 2 / 4 workgroups (pgru_bwd_sk_kernel; up to 512 rows per workgroup: four chains
+    of 512 rows in one launch) or the round-2 kernel (0)."""
     from polyphonic_chord_texture_disentanglement_amd import functional as F_
     from polyphonic_chord_texture_disentanglement_amd._lib import call, lib, ptr, stream_ptr
     dev = _dev()
     bf = torch.bfloat16
-    if not lib().ptv_gru_persist_supported(NC, M, H):
+    monkeypatch.setattr(F_, 'PERSIST_SPLITK', splitk)
+    if splitk == 0 and not lib().ptv_gru_persist_supported(NC, M, H):
         pytest.skip('shape does not fit one workgroup per CU on this device')
+    if splitk and not lib().ptv_gru_persist_splitk_supported(NC, M, H, splitk):
+        pytest.skip('shape does not fit the split-K teams on this device')
     import os
     if 'PTV_LP' in os.environ:                       # experiment switch: how consumers read the exchanged operand
         lib().ptv_gru_persist_load_policy(int(os.environ['PTV_LP']))
@@ -225,7 +232,12 @@ def test_gru_persistent_kernels_vs_oracle_and_step_kernels(NC, M, H, T, masked, 
         bw.append(dict(hall=hall, gates=c['gates'], wt16=d(w_hh).t().contiguous().to(bf), dh_ext=de, dh_last=dl[:, :H],
                        dgi=torch.zeros(T, M, 3 * H, device=dev, dtype=bf), dgh=torch.zeros(T, M, 3 * H, device=dev, dtype=bf),
                        dh0=torch.zeros(M, H, device=dev), reverse=reverse))
-    F_.gru_persist_fwd(M, H, T, fw)
+    if lib().ptv_gru_persist_supported(NC, M, H):
+        F_.gru_persist_fwd(M, H, T, fw)
+    else:                                            # the forward takes at most 256 rows per workgroup: more launches
+        n = 2 if lib().ptv_gru_persist_supported(2, M, H) else 1
+        for i in range(0, NC, n):
+            F_.gru_persist_fwd(M, H, T, fw[i:i + n])
     F_.gru_persist_bwd(M, H, T, bw)
     F_.persist_check()
     for ci in range(NC):
