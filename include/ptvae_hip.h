@@ -204,6 +204,8 @@ int ptv_colsum(float* out, const void* A, long lda, long rows, int N, const int*
  */
 int ptv_embed_fwd(const long* x, const float* W, const float* bias, float* emb, int* lengths, int B, int E, void* stream);
 int ptv_multihot(const long* x, float* out, long ld, int B, void* stream);
+/* get_len_index_tensor alone (ptvae.py:292-297): lengths [32][B] int32 = 16 - number of <pad> pitches of each (step, sample) */
+int ptv_grid_lengths(const long* x, int* lengths, int B, void* stream);
 /* the same rows as bf16 (exact), ld >= 136 with column 135 zeroed: operand of the bf16-precision note_embedding weight gradient */
 int ptv_multihot_bf16(const long* x, void* out, long ld, int B, void* stream);
 

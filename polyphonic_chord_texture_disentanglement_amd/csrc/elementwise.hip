@@ -398,6 +398,13 @@ extern "C" int ptv_embed_fwd(const long* x, const float* W, const float* bias, f
   return PTV_OK;
 }
 
+extern "C" int ptv_grid_lengths(const long* x, int* lengths, int B, void* stream) {
+  if (!x || !lengths || B <= 0) return PTV_ERR_ARG;
+  hipLaunchKernelGGL(lengths_kernel, dim3(cdiv((long)B * 32, 256)), dim3(256), 0, (hipStream_t)stream, x, lengths, B);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
 extern "C" int ptv_multihot(const long* x, float* out, long ld, int B, void* stream) {
   if (!x || !out || B <= 0 || ld < 135) return PTV_ERR_ARG;
   long nb = ((long)B * 512 + 3) / 4; if (nb > 8192) nb = 8192;

@@ -397,14 +397,23 @@ def gru_persist_fwd(M, H, T, chains):
 
 
 # BPTT of the persistent recurrences: split-K teams of S workgroups (csrc/gru_persist.hip, pgru_bwd_sk_kernel) read 1/S of the
-# exchanged operand per step; 0 = the round-2 kernel (every workgroup reads all of K).  Measured in scripts/bench_persist.py.
-PERSIST_SPLITK = int(os.environ.get('PTV_PERSIST_SPLITK', '4'))
+# exchanged operand per step; 0 = the round-2 kernel (every workgroup reads all of K).  Measured (scripts/bench_persist.py,
+# gpurun_out/r04_bench_persist_a.txt; us per launch, S = 0 / 2 / 4): time GRU M = 512 T = 32: 429 / 402 / 382; one encoder's two
+# chains M = 512 T = 8: 213 / 172 / 178; M = 1024 T = 32: 770 / 633 / 645; M = 256: 253 / 295 / 271; M = 128: 220 / 271 / 240;
+# H = 512 M = 512: 53 / 61 / 60 -- the second hand-off of a step costs what the smaller read saves unless the read is large.  In the
+# B = 512 step (scripts/ab_step.py, same process): 9.242 / 9.173 / 9.326 ms.  'auto' = 2 where it wins (H = 1024, M >= 512), else 0.
+PERSIST_SPLITK = os.environ.get('PTV_PERSIST_SPLITK', 'auto')
+PERSIST_SPLITK = PERSIST_SPLITK if PERSIST_SPLITK == 'auto' else int(PERSIST_SPLITK)
 _SPLITK_OK = {}
 
 
 def persist_splitk(NC, M, H):
     """S of the split-K BPTT for this shape, or 0"""
     S = PERSIST_SPLITK
+    if S == 'auto':
+        S = 2 if (H >= 1024 and M >= 512) else 0
+        if not S and not persist_supported(NC, M, H):
+            S = 2                                  # only the split-K kernel takes more than 256 rows per workgroup
     if S not in (2, 4):
         return 0
     key = (NC, M, H, S, torch.cuda.current_device())

@@ -534,6 +534,97 @@ class GraphedDecoderStepFn(torch.autograd.Function):
         return (None, r[0], r[1], r[2], None) + tuple(r[7:])
 
 
+# ---------------------------------------------------------------------------------------------
+# The reference's note-level METHODS (ptvae.py:315-428) as callable entry points: forward-only helpers for reference-side code that
+# calls `decoder.decode_note(...)` / `decode_notes(...)` / the token builders directly (training goes through DecoderTFFn /
+# DecoderStepFn, which run the same kernels fused).  Rows = whatever batch the caller hands over.
+# ---------------------------------------------------------------------------------------------
+def note_token_rows(P, pitch_inds, dur_inds):
+    """pitch_dur_ind_to_note_token (ptvae.py:328-334): note_embedding(onehot(pitch) | 5 duration bits) -> [B, E]"""
+    dev = pitch_inds.device
+    B = pitch_inds.shape[0]
+    w_emb, b_emb = P['note_embedding.weight'], P['note_embedding.bias']
+    E = w_emb.shape[0]
+    NP = w_emb.shape[1] - 5
+    dummy = _zeros(B, NP, dev=dev)
+    idx = dur_inds.reshape(B, 5).t().contiguous().int()
+    pred = _empty(B, E, dev=dev)
+    xhat = torch.empty(B, 6, device=dev, dtype=torch.long)
+    plen = torch.zeros(B, device=dev, dtype=torch.int32)
+    call('ptv_note_token', ptr(dummy), NP, ptr(idx), B, ptr(w_emb), ptr(b_emb), E, ptr(pred), E, ptr(xhat), 6, ptr(plen), 1, 0,
+         ptr(pitch_inds.int().contiguous()), B, stream_ptr())
+    return pred
+
+
+def decode_note_rows(P, h, prec, force_dur=None):
+    """decode_note (ptvae.py:336-368) for B rows: h [B, Hn] -> est_pitch [B, NP], est_durs [B, 5, 2], duration argmaxes [5, B]"""
+    dev = h.device
+    B, Hn = h.shape
+    Hd = P['dec_dur_gru.weight_hh_l0'].shape[1]
+    w_dh = P['dur_hid_linear.weight']
+    w_ih_d, b_ih_d = P['dec_dur_gru.weight_ih_l0'], P['dec_dur_gru.bias_ih_l0']
+    w_hh_d, b_hh_d = P['dec_dur_gru.weight_hh_l0'], P['dec_dur_gru.bias_hh_l0']
+    pitch = gemm(h, P['pitch_out_linear.weight'], bias=P['pitch_out_linear.bias'], prec=prec)
+    HD = _empty(6, B, Hd, dev=dev)
+    gemm(h, w_dh[:, :Hn], HD[0], bias=P['dur_hid_linear.bias'], prec=prec)
+    gemm(pitch, w_dh[:, Hn:], HD[0], acc=True, prec=prec)
+    tab0 = gemm(P['dur_sos_token'].view(1, -1), w_ih_d, bias=b_ih_d, prec=0)
+    tab = gemm(_onehot2x5(dev), w_ih_d, bias=b_ih_d, prec=0)
+    idx = torch.empty(5, B, device=dev, dtype=torch.int32)
+    dur = _empty(B, 5, 2, dev=dev)
+    dur2 = dur.view(B, 10)
+    for d in range(5):
+        g_, g_ld, g_idx = (tab0, 0, None) if d == 0 else (tab, 3 * Hd, idx[d - 1])
+        gru_step(prec, HD[d], g_, g_ld, w_hh_d, b_hh_d, HD[d + 1], plane=B * Hd, gi_idx=g_idx)
+        call('ptv_dur_out_token', ptr(HD[d + 1]), Hd, ptr(P['dur_out_linear.weight']), ptr(P['dur_out_linear.bias']),
+             ptr(dur2[:, 2 * d:]), 10, ptr(idx[d]), ptr(force_dur[d]) if force_dur is not None else None, B, stream_ptr())
+    return pitch, dur, idx
+
+
+def decode_notes_rows(P, ns, notes, coins, inference, prec):
+    """decode_notes (ptvae.py:370-428) for B rows: ns [B, Ht] time-level summary, notes [B, 16, E] ground-truth embedded notes (or
+    None when `inference`), coins [14] teacher-forcing decisions -> pitch_outs [B,15,NP], dur_outs [B,15,5,2],
+    predicted_notes [B,16,E], lengths [B] float"""
+    dev = ns.device
+    B, Ht = ns.shape
+    E = P['note_embedding.weight'].shape[0]
+    Hn = P['dec_notes_gru.weight_hh_l0'].shape[1]
+    NP = P['pitch_out_linear.weight'].shape[0]
+    w_emb, b_emb = P['note_embedding.weight'], P['note_embedding.bias']
+    w_ih_n, w_hh_n, b_hh_n = P['dec_notes_gru.weight_ih_l0'], P['dec_notes_gru.weight_hh_l0'], P['dec_notes_gru.bias_hh_l0']
+    st = stream_ptr()
+    HN = _empty(16, B, Hn, dev=dev)
+    gemm(ns, P['dec_time_to_notes_hid.weight'], HN[0], bias=P['dec_time_to_notes_hid.bias'], prec=prec)
+    GC = gemm(ns, w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec)
+    TOK = _empty(15, B, E, dev=dev)
+    PRED = _zeros(16, B, E, dev=dev)
+    if inference:
+        sos = _sos_grid(dev)
+        sos_emb = _empty(16, 32, 1, E, dev=dev)
+        call('ptv_embed_fwd', ptr(sos), ptr(w_emb), ptr(b_emb), ptr(sos_emb), None, 1, E, st)
+        copy2d(TOK[0], sos_emb.view(-1, E)[0:1], lds=0)
+    else:
+        nt = notes.float().transpose(0, 1).contiguous()                  # [16, B, E]
+        copy2d(TOK[0], nt[0])
+    copy2d(PRED[0], TOK[0])
+    pitch = _empty(15, B, NP, dev=dev)
+    dur = _empty(15, B, 5, 2, dev=dev)
+    xhat = torch.full((B, 16, 6), 2, device=dev, dtype=torch.long)
+    plen = torch.zeros(B, device=dev, dtype=torch.int32)
+    for n in range(15):
+        gi_tok = gemm(TOK[n], w_ih_n[:, Ht:], prec=prec)
+        gru_step(prec, HN[n], gi_tok, 3 * Hn, w_hh_n, b_hh_n, HN[n + 1], gi2=GC, plane=B * Hn)
+        p_, d_, idx = decode_note_rows(P, HN[n + 1], prec)
+        copy2d(pitch[n], p_)
+        copy2d(dur[n].view(B, 10), d_.view(B, 10))
+        call('ptv_note_token', ptr(p_), NP, ptr(idx), B, ptr(w_emb), ptr(b_emb), E, ptr(PRED[n + 1]), E, ptr(xhat[0, n + 1]), 16 * 6,
+             ptr(plen), n + 1, int(n == 14), None, B, st)
+        if n < 14:
+            use_gt = (not inference) and coins[n]
+            copy2d(TOK[n + 1], nt[n + 1] if use_gt else PRED[n + 1])
+    return (pitch.transpose(0, 1), dur.transpose(0, 1), PRED.transpose(0, 1), plen.float())
+
+
 class ChordDecoderStepFn(torch.autograd.Function):
     """(z_chd, c_sm [8,B,36] or None, coins [8] bools, force, prec, *params) -> root [8,B,12], chroma [8,B,24], bass [8,B,12]
     force (tests: replay mode): {'root' [8,B,12], 'chroma' [8,B,24], 'bass' [8,B,12]} logits of a recorded run whose

@@ -374,6 +374,69 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
     def forward(self, z, inference, x, lengths, teacher_forcing_ratio1, teacher_forcing_ratio2, coins=None):
         return self.decoder(z, inference, x, lengths, teacher_forcing_ratio1, teacher_forcing_ratio2, coins=coins)
 
+    # ---- the reference's helper METHODS (ptvae.py:292-428), callable by reference-side code.  Forward-only entry points onto the
+    # kernels the fused path runs (`decoder()` never calls them: it runs DecoderTFFn / DecoderStepFn); results carry no autograd graph.
+    def _P(self):
+        return dict(zip(FF_.FREE_PARAM_NAMES, self._params_free()))
+
+    def get_len_index_tensor(self, ind_x):
+        """ptvae.py:292-297: lengths [B, 32] (int64) = 16 - number of <pad> pitches per step"""
+        _require_cuda(ind_x, 'PtvaeDecoder.get_len_index_tensor')
+        x = ind_x.long().contiguous()
+        B = x.size(0)
+        lengths = torch.empty(32 * B, device=x.device, dtype=torch.int32)
+        F_.call('ptv_grid_lengths', F_.ptr(x), F_.ptr(lengths), B, F_.stream_ptr())
+        return lengths.view(32, B).t().long()
+
+    def index_tensor_to_multihot_tensor(self, ind_x):
+        """ptvae.py:299-313: piano grid [B,32,16,6] -> multi-hot [B,32,16,135] (one-hot pitch of 130 | 5 duration bits); a permuted
+        view of the step-major matrix the note_embedding weight gradient multiplies"""
+        _require_cuda(ind_x, 'PtvaeDecoder.index_tensor_to_multihot_tensor')
+        x = ind_x.long().contiguous()
+        B = x.size(0)
+        out = torch.empty(16, 32, B, self.note_size, device=x.device, dtype=torch.float32)
+        F_.call('ptv_multihot', F_.ptr(x), F_.ptr(out), self.note_size, B, F_.stream_ptr())
+        return out.permute(2, 1, 0, 3)
+
+    def get_sos_token(self):
+        """ptvae.py:315-320: the <sos> note token [135] = onehot(128) | 2 2 2 2 2"""
+        dev = self.note_embedding.weight.device
+        return self.index_tensor_to_multihot_tensor(FF_._sos_grid(dev))[0, 0, 0].clone()
+
+    def dur_ind_to_dur_token(self, inds, batch_size):
+        """ptvae.py:322-326: [B] indices -> one-hot rows [B, dur_width]"""
+        dev = self.note_embedding.weight.device
+        inds = torch.as_tensor(inds, device=dev).long().view(batch_size, 1)
+        return torch.zeros(batch_size, self.dur_width, device=dev).scatter_(1, inds, 1.0)
+
+    def pitch_dur_ind_to_note_token(self, pitch_inds, dur_inds, batch_size):
+        """ptvae.py:328-334: note_embedding(onehot(pitch) | duration bits) -> [B, note_emb_size] (ptv_note_token)"""
+        dev = self.note_embedding.weight.device
+        with torch.no_grad():
+            return FF_.note_token_rows(self._P(), torch.as_tensor(pitch_inds, device=dev).view(batch_size),
+                                       torch.as_tensor(dur_inds, device=dev).view(batch_size, self.dur_width))
+
+    def decode_note(self, note_summary, batch_size):
+        """ptvae.py:336-368: note_summary [B,1,Hn] -> est_pitch [B,130], est_durs [B,5,2] (pitch head + the 5-step duration GRU
+        with argmax feedback)"""
+        _require_cuda(note_summary, 'PtvaeDecoder.decode_note')
+        with torch.no_grad():
+            p, d, _ = FF_.decode_note_rows(self._P(), note_summary.detach().reshape(batch_size, -1).float().contiguous(), self._prec)
+        return p, d
+
+    def decode_notes(self, notes_summary, batch_size, notes, inference, teacher_forcing_ratio=0.5):
+        """ptvae.py:370-428: one time step's 15 note steps.  notes_summary [B,1,Ht], notes [B,16,E] or None ->
+        pitch_outs [B,15,130], dur_outs [B,15,5,2], predicted_notes [B,16,E], lengths [B].  Coins in the reference's order
+        (one random.random() after each of the first 14 note steps)."""
+        _require_cuda(notes_summary, 'PtvaeDecoder.decode_notes')
+        if inference:
+            assert teacher_forcing_ratio == 0
+            assert notes is None
+        coins = [random.random() < teacher_forcing_ratio for _ in range(self.max_simu_note - 2)]
+        with torch.no_grad():
+            return FF_.decode_notes_rows(self._P(), notes_summary.detach().reshape(batch_size, -1).float().contiguous(),
+                                         None if notes is None else notes.detach(), coins, bool(inference), self._prec)
+
     # ---- ptvae.py:537-544
     def output_to_numpy(self, recon_pitch, recon_dur):
         est_pitch = recon_pitch.max(-1)[1].unsqueeze(-1)
@@ -452,6 +515,31 @@ class PtvaeEncoder(nn.Module, _PrecMixin):
         if (self.max_simu_note, self.num_step, self.dur_width, self.pitch_range, self.pitch_pad, self.dur_pad) != (16, 32, 5, 130, 130, 2):
             raise NotImplementedError('HIP kernels are specialised to the 32x16x(130+5) PianoTree grid '
                                       '(the reference\'s train.py:32 geometry cannot consume its own data either: SURVEY.md 0.2)')
+
+    # ---- ptvae.py:160-206: the reference's method surface
+    def get_len_index_tensor(self, ind_x):
+        return PtvaeDecoder.get_len_index_tensor(self, ind_x)
+
+    def index_tensor_to_multihot_tensor(self, ind_x):
+        return PtvaeDecoder.index_tensor_to_multihot_tensor(self, ind_x)
+
+    def encoder(self, x, lengths):
+        """ptvae.py:190-206: MULTI-HOT x [B,32,16,135] + lengths [B,32] -> (Normal, embedded [B,32,16,E]); differentiable.  forward()
+        embeds the index grid by a gather instead of multiplying the multi-hot matrix; this entry point takes what the reference's
+        takes (the embedding is then a [B*512,135] product)"""
+        _require_cuda(x, 'PtvaeEncoder.encoder')
+        self._check_grid()
+        B = x.size(0)
+        E = self.note_emb_size
+        emb_b = F_.LinearFn.apply(x.reshape(B * 512, self.note_size).float(), self.note_embedding.weight, self.note_embedding.bias,
+                                  self._prec).view(B, 32, 16, E)
+        emb = F_.Transpose01Fn.apply(emb_b.transpose(1, 2).reshape(B, 16 * 32, E)).view(16, 32, B, E)
+        len32 = lengths.t().contiguous().int().reshape(-1)
+        notes = F_.BiGruFinalFn.apply(emb.view(16, 32 * B, E), len32, self._prec, *self.enc_notes_gru.weights())
+        h = F_.BiGruFinalFn.apply(notes.view(32, B, -1), None, self._prec, *self.enc_time_gru.weights())
+        mu, sd = F_.EncoderHeadsFn.apply(h, self.linear_mu.weight, self.linear_mu.bias, self.linear_std.weight, self.linear_std.bias,
+                                         self._prec)
+        return HipNormal(mu, sd), emb_b
 
     def forward(self, x, return_iterators=False):
         _require_cuda(x, 'PtvaeEncoder')

@@ -16,7 +16,12 @@ outputs only.
                                reduced-precision run has to be forced to) with their top-2 margins, 11 losses,
                                gradient norm, parameter checksums
 
-    python tests/golden/make_golden_r4.py [b512] [slices] [train5] [sched4]     # needs /root/reference; b512 takes ~5 min / ~20 GB
+  reduced_methods.npz          the reference's helper METHODS called directly on the reduced model (ptvae.py:292-428, 190-206):
+                               get_len_index_tensor, index_tensor_to_multihot_tensor, get_sos_token, dur_ind_to_dur_token,
+                               pitch_dur_ind_to_note_token, decode_note, decode_notes (scheduled sampling with recorded coins, and
+                               inference), PtvaeEncoder.encoder on the multi-hot grid
+
+    python tests/golden/make_golden_r4.py [b512] [slices] [train5] [sched4] [methods]   # needs /root/reference; b512 takes ~5 min / ~20 GB
 """
 import os
 import sys
@@ -62,7 +67,7 @@ def checksums(m):
 
 
 def main():
-    what = set(sys.argv[1:]) or {'b512', 'slices', 'train5', 'sched4'}
+    what = set(sys.argv[1:]) or {'b512', 'slices', 'train5', 'sched4', 'methods'}
     ref_model, ref_ptvae, ref_tp = mg.import_reference()
     from amc_dl.torch_plus.train_utils import kl_anealing
     warnings.simplefilter('ignore')
@@ -159,6 +164,51 @@ def main():
             tr['psum' + s], tr['pabs' + s] = checksums(mf)
             print('sched4 step', step, tr['sched' + s], tr['losses' + s][:4], float(gn), 'coins', len(cr.coins))
         np.savez_compressed(os.path.join(HERE, 'full_sched4_b8.npz'), **tr)
+
+
+    if 'methods' in what:
+        m = mg.build_reduced(ref_model, ref_ptvae)
+        dec = m.decoder
+        dec.device = torch.device('cpu')
+        x, _, _ = synth_batch(3, 107)
+        xt = torch.from_numpy(x)
+        out = OrderedDict(x=x)
+        with torch.no_grad():
+            out['lengths'] = dec.get_len_index_tensor(xt).numpy()
+            mh = dec.index_tensor_to_multihot_tensor(xt)
+            out['multihot'] = mh.numpy()
+            out['sos'] = dec.get_sos_token().numpy()
+            out['dur_inds1'] = np.array([0, 1, 1], dtype=np.int64)
+            out['dur_token'] = dec.dur_ind_to_dur_token(torch.from_numpy(out['dur_inds1']), 3).numpy()
+            out['pitch_inds'] = np.array([5, 129, 60], dtype=np.int64)
+            out['dur_inds'] = np.array([[0, 1, 0, 1, 1], [1, 1, 1, 1, 1], [0, 0, 0, 0, 0]], dtype=np.int64)
+            out['note_token'] = dec.pitch_dur_ind_to_note_token(torch.from_numpy(out['pitch_inds']), torch.from_numpy(out['dur_inds']).float(), 3).numpy()
+            g = torch.Generator().manual_seed(17)
+            note_summary = torch.randn(3, 1, 28, generator=g)
+            out['note_summary'] = note_summary.numpy()
+            ep, ed = dec.decode_note(note_summary, 3)
+            out['decode_note.pitch'], out['decode_note.durs'] = ep.numpy(), ed.numpy()
+            notes_summary = torch.randn(3, 1, 40, generator=g)
+            out['notes_summary'] = notes_summary.numpy()
+            notes = dec.note_embedding(mh)[:, 3]                                   # ground-truth embedded notes of time step 3
+            out['notes'] = notes.numpy()
+            with mg.CoinRecorder(23) as cr:
+                po, do, pn, ln = dec.decode_notes(notes_summary, 3, notes, False, 0.5)
+            out['decode_notes.coins'] = np.array(cr.coins, dtype=np.float64)
+            out['decode_notes.pitch'], out['decode_notes.durs'] = po.numpy(), do.numpy()
+            out['decode_notes.predicted'], out['decode_notes.lengths'] = pn.numpy(), ln.numpy()
+            po, do, pn, ln = dec.decode_notes(notes_summary, 3, None, True, 0.)
+            out['decode_notes_inf.pitch'], out['decode_notes_inf.durs'] = po.numpy(), do.numpy()
+            out['decode_notes_inf.predicted'], out['decode_notes_inf.lengths'] = pn.numpy(), ln.numpy()
+        torch.manual_seed(0)
+        enc = ref_ptvae.PtvaeEncoder(torch.device('cpu'), note_emb_size=20, enc_notes_hid_size=12, enc_time_hid_size=16, z_size=8)
+        shapes = OrderedDict((k, tuple(v.shape)) for k, v in enc.state_dict().items())
+        enc.load_state_dict(fill_state_dict(shapes, seed=4321))
+        with torch.no_grad():
+            dist, emb = enc.encoder(enc.index_tensor_to_multihot_tensor(xt), enc.get_len_index_tensor(xt))
+        out['enc.mean'], out['enc.scale'], out['enc.embedded'] = dist.mean.numpy(), dist.scale.numpy(), emb.numpy()
+        np.savez_compressed(os.path.join(HERE, 'reduced_methods.npz'), **out)
+        print('methods', {k: v.shape for k, v in out.items()})
 
 
 if __name__ == '__main__':

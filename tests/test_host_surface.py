@@ -108,3 +108,15 @@ def test_path_manager_and_writers(tmp_path, monkeypatch):
     sw = tp.SummaryWriters(names, {'loss': None}, pm.writer_path)
     sw.write_task('train', {'loss': 1.0, 'recon_loss': 2.0}, 0)
     assert sw.all_tags['train'] == {'train_loss': (0, 1)}
+
+
+def test_reference_method_names_exist_on_the_decoder_and_encoder():
+    """every method of the reference's PtvaeDecoder / PtvaeEncoder (ptvae.py:125-215, 218-575) is defined under its own name"""
+    for n in ('get_len_index_tensor', 'index_tensor_to_multihot_tensor', 'get_sos_token', 'dur_ind_to_dur_token',
+              'pitch_dur_ind_to_note_token', 'decode_note', 'decode_notes', 'decoder', 'forward', 'recon_loss', 'emb_x',
+              'output_to_numpy', 'pr_to_notes', 'grid_to_pr_and_notes'):
+        assert callable(getattr(P.PtvaeDecoder, n, None)), n
+    for n in ('get_len_index_tensor', 'index_tensor_to_multihot_tensor', 'encoder', 'forward'):
+        assert callable(getattr(P.PtvaeEncoder, n, None)), n
+    with pytest.raises((AssertionError, RuntimeError)):            # no CPU fallback: the helpers refuse host tensors too
+        build_reduced().decoder.get_len_index_tensor(torch.zeros(1, 32, 16, 6, dtype=torch.long))
