@@ -386,6 +386,8 @@ def main():
     model.decoder.use_graph = args.graph
     sched = MinExponentialLR(opt, gamma=0.9999, minimum=1e-5)
     sync = GradSync(model, opt) if world > 1 else None
+    if sync is not None:
+        sync.timing = True
 
     B = args.batch
     nb = 2
@@ -437,8 +439,23 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     lib.ptv_prof_enable(0)
+    dp = None
     if world > 1:
         import torch.distributed as dist
+        # what a first N-GPU run needs to see where the time went: every rank's own step time, the part of the gradient exchange the
+        # backward pass did not hide (event-timed on the step's stream), what left early and what was left for the end
+        rep = sync.exchange_report()
+        cpu_backend = dist.get_backend() != 'nccl'
+        mine = torch.tensor([dt / args.steps * 1e3, rep['exposed_allreduce_ms'] or 0.0], dtype=torch.float64,
+                            device='cpu' if cpu_backend else dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        dp = dict(rep, per_rank_ms_per_step=[round(float(a[0]), 3) for a in allr],
+                  per_rank_exposed_allreduce_ms=[round(float(a[1]), 3) for a in allr],
+                  note='exposed_allreduce_ms = GPU time of all_reduce_grads() on the step stream per step (waits for the slices that '
+                       'left during the backward pass + the all-reduce of the remainder); a ring all-reduce of the whole bucket over '
+                       'xGMI is ~1.25 ms (SURVEY 8e)')
+        dp['exposed_allreduce_ms'] = None if rep['exposed_allreduce_ms'] is None else round(rep['exposed_allreduce_ms'], 3)
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -465,6 +482,8 @@ def main():
                           'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world},
                'step_tflops': round(value * GFLOP_PER_SAMPLE_TRAIN / 1e3, 2), 'final_loss': round(loss, 4),
                'host_enqueue_ms_per_step': round(t_host / args.steps * 1e3, 3), 'roofline': roof}
+        if dp is not None:
+            res['data_parallel'] = dp
         from polyphonic_chord_texture_disentanglement_amd.functional import persist_check
         persist_check()                                        # a persistent launch that gave up would have invalidated the run
         if world == 1 and args.mode == 'train' and not args.no_extras:

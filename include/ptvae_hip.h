@@ -142,6 +142,9 @@ int ptv_gru_seq_bwd(int prec, int M, int H, int T,
  * be in flight on the device at a time (chain them with events across streams).
  */
 int ptv_gru_persist_supported(int NC, int M, int H);
+/* CUs the persistent grids leave free (default 0 = size to every CU): a data-parallel run may set it so that RCCL's channel kernels
+ * always find a CU without a 96-KB workgroup on it (dist.GradSync, PTV_PERSIST_CU_RESERVE); the grids are sized from CUs - reserve */
+int ptv_gru_persist_cu_reserve(int cus);
 /* how consumers read the exchanged operand: 0 = sc1 loads, 1 = nt loads, 2 = plain loads behind one agent acquire per step */
 int ptv_gru_persist_load_policy(int lp);
 int ptv_gru_persist_fwd(int NC, int M, int H, int T,
@@ -462,12 +465,18 @@ int ptv_clip_adam_step_shadow(float* p, const float* g, float* m, float* v, long
  * cross-entropy of the weighted duration loss, ptv_ce_group_fwd.)  ptv_wgrad_mode switches the two product paths only. */
 int ptv_ordered_reductions(int on);
 int ptv_wgrad_mode(int ordered);
+/* reductions that ran on fp32 atomics although ordered mode is on (no workspace: first use inside a capture, > 64 streams, a need
+ * beyond the scratch); 0 after any step is what makes the step bit-reproducible.  reset != 0 clears the counter. */
+long ptv_ordered_fallbacks(int reset);
 
 /* Per-step scalars on the device (graph-replayed train steps, graph_step.py): while dev4 is set, ptv_loss_finalize /
  * ptv_loss_bwd_scales read beta = dev4[0] (the KL weight of train.py:56-58's schedule; only where the call's own beta is non-zero) and
  * ptv_clip_adam_step* read lr = dev4[1], 1 - beta1^t = dev4[2], sqrt(1 - beta2^t) = dev4[3] (Adam's bias corrections,
  * scheduler.py:69-74 + train.py:50) instead of their by-value arguments.  NULL restores by-value behaviour. */
 int ptv_step_params(const float* dev4);
+/* test / diagnosis aid: nwg idle workgroups holding lds_bytes of LDS each for usec microseconds on `stream` (a stand-in for another
+ * library's collective kernel sitting on the CUs the persistent recurrences were sized for; tests/test_gpu_zz_dist.py) */
+int ptv_debug_pin_cus(int nwg, int lds_bytes, int usec, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Weight-gradient product (csrc/wgrad.hip): C[M,N] (fp32, row stride ldc) (+)= alpha * sum_k A[k*lda + m] * B[k*ldb + n], i.e.

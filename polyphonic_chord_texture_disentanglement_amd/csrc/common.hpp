@@ -69,7 +69,10 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // reads them with agent-scope loads -- the recipe of the persistent recurrences (gru_persist.hip).
 struct OrdScratch { float* slots; unsigned* counters; };
 constexpr long ORD_SLOT_FLOATS = 1L << 20;     // 4 MB of partials per stream
-constexpr int ORD_COUNTERS = 256;
+constexpr int ORD_COUNTERS = 1024;            // (the duration GRU's partial sums are 320 column blocks wide)
+// ordered mode is on but a reduction had to fall back to fp32 atomics (no workspace: inside a capture, pool full, need too large):
+// counted, readable through ptv_ordered_fallbacks() -- bit-reproducibility is the advertised default and must not be lost silently
+extern int g_ord_fallbacks;
 OrdScratch ord_scratch(hipStream_t s, long need_floats, int need_counters);     // misc.hip
 
 // Every thread of the block calls it after the block's partial vector part[0..L) (LDS) is complete and visible (caller synced).

@@ -239,6 +239,7 @@ static int gemm_dispatch(int transA, int transB, GemmArgs g, EpiPlain::Params ep
     // ordered reduction: every split stores its partial tile-by-tile into a per-stream workspace, one more launch adds them in
     // split order -- bit-reproducible, no fp32 atomics.  (Dead row tiles of an m_top product store zeros.)
     ws = splitk_workspace(s, (size_t)splits * g.M * g.N * sizeof(float));
+    if (!ws) g_ord_fallbacks++;
   }
   if (ws) {
     ep.C = ws; ep.ldc = g.N; ep.accumulate = 0; ep.atomic = 0; ep.split_stride = (long)g.M * g.N;

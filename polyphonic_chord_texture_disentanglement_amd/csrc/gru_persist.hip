@@ -611,7 +611,7 @@ __global__ void pack_blocked_kernel(const float* __restrict__ h, __bf16* __restr
 }
 
 static int g_load_policy = 0, g_dbg = 0;
-static int g_num_cu = 0;
+static int g_num_cu = 0, g_cu_reserve = 0;
 static int num_cu() {
   if (g_num_cu == 0) {
     int dev = 0, n = 0;
@@ -624,7 +624,7 @@ static int num_cu() {
 // row groups / rows per workgroup for NC chains of M rows with UG = H/16 unit groups: one workgroup per CU at most
 static int plan(int NC, int M, int H, int& RG, int& rows_wg, int& FM, int fm_max = 4) {
   if (NC < 1 || NC > PMAXC || M <= 0 || H < 256 || H > 1024 || (H & 255)) return PTV_ERR_UNSUPPORTED;
-  const int ncu = num_cu();
+  const int ncu = num_cu() - g_cu_reserve;
   const int UG = H / PU;
   int rg = ncu / (NC * UG);
   if (rg < 1) return PTV_ERR_UNSUPPORTED;
@@ -648,6 +648,12 @@ extern "C" int ptv_gru_persist_load_policy(int lp) {
   if (lp >= 100) { ptv::g_dbg = lp - 100; return PTV_OK; }      // timing experiments only (results invalid)
   if (lp < 0 || lp > 2) return PTV_ERR_ARG;
   ptv::g_load_policy = lp;
+  return PTV_OK;
+}
+
+extern "C" int ptv_gru_persist_cu_reserve(int cus) {
+  if (cus < 0 || cus > 255) return PTV_ERR_ARG;
+  ptv::g_cu_reserve = cus;
   return PTV_OK;
 }
 

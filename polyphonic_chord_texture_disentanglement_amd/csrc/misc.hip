@@ -334,30 +334,56 @@ int g_ordered = [] { const char* e = getenv("PTV_WGRAD_ORDERED"); return (e && e
 
 // scratch of the ordered grid reductions (common.hpp): one allocation per stream, made on the stream's first use -- outside any
 // capture when the captured step was warmed up first; inside a capture without a buffer the kernels fall back to atomics
+int g_ord_fallbacks = 0;
 OrdScratch ord_scratch(hipStream_t s, long need_floats, int need_counters) {
   OrdScratch none{nullptr, nullptr};
-  if (!g_ordered || need_floats > ORD_SLOT_FLOATS || need_counters > ORD_COUNTERS) return none;
+  if (!g_ordered) return none;
   static OrdScratch pool[64]; static hipStream_t keys[64]; static int n = 0; static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
+  if (need_floats > ORD_SLOT_FLOATS || need_counters > ORD_COUNTERS) { g_ord_fallbacks++; return none; }
   int i = 0;
   for (; i < n; i++) if (keys[i] == s) break;
   if (i < n) return pool[i];
-  if (n == 64) return none;
+  if (n == 64) { g_ord_fallbacks++; return none; }
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) return none;
+  if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) { g_ord_fallbacks++; return none; }
   char* p = nullptr;
   const size_t bytes = ORD_SLOT_FLOATS * sizeof(float) + ORD_COUNTERS * sizeof(unsigned);
-  if (hipMalloc(reinterpret_cast<void**>(&p), bytes) != hipSuccess) return none;
-  if (hipMemset(p + ORD_SLOT_FLOATS * sizeof(float), 0, ORD_COUNTERS * sizeof(unsigned)) != hipSuccess) return none;
+  if (hipMalloc(reinterpret_cast<void**>(&p), bytes) != hipSuccess) { g_ord_fallbacks++; return none; }
+  if (hipMemset(p + ORD_SLOT_FLOATS * sizeof(float), 0, ORD_COUNTERS * sizeof(unsigned)) != hipSuccess) { (void)hipFree(p); g_ord_fallbacks++; return none; }
   keys[n] = s; pool[n] = OrdScratch{reinterpret_cast<float*>(p), reinterpret_cast<unsigned*>(p + ORD_SLOT_FLOATS * sizeof(float))};
   return pool[n++];
 }
 }  // namespace ptv
 extern "C" int ptv_wgrad_mode(int ordered);
 extern "C" int ptv_ordered_reductions(int on) { ptv::g_ordered = on ? 1 : 0; return ptv_wgrad_mode(on); }
+// number of reductions that ran on fp32 atomics although ordered mode was on (no workspace available); reset = 1 clears it
+extern "C" long ptv_ordered_fallbacks(int reset) { const long n = ptv::g_ord_fallbacks; if (reset) ptv::g_ord_fallbacks = 0; return n; }
 // Launches made from now on read their per-step scalars from this device array instead of their by-value arguments (NULL: by value
 // again): [0] beta (ptv_loss_finalize / ptv_loss_bwd_scales), [1] lr, [2] 1 - beta1^t, [3] sqrt(1 - beta2^t) (ptv_clip_adam_step*).
 // A hipGraph captured while it is set replays with whatever the host has written there since (graph_step.GraphedTrainStep).
 extern "C" int ptv_step_params(const float* dev4) { ptv::g_step_params = dev4; return PTV_OK; }
 
 extern "C" int ptv_zero_skip(int enable) { ptv::g_zero_skip = enable ? 1 : 0; return PTV_OK; }
+
+// Test / diagnosis aid (tests/test_gpu_zz_dist.py): nwg workgroups that each hold `lds_bytes` of LDS and 256 threads for `usec`
+// microseconds and do nothing -- what a collective kernel of another library looks like to the persistent recurrences when it sits
+// on the CUs they were sized for (include/ptvae_hip.h: at most one workgroup per CU, gru_persist.hip plan()).
+namespace ptv {
+__global__ void pin_cus_kernel(long long ticks, int* sink) {
+  extern __shared__ char pin_smem[];
+  pin_smem[threadIdx.x] = (char)threadIdx.x;
+  __syncthreads();
+  const long long t0 = wall_clock64();                          // constant 100 MHz counter
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+  if (sink && pin_smem[(threadIdx.x + 1) & 255] == 77 && ticks < 0) sink[0] = 1;      // (keeps the LDS allocation alive)
+}
+}  // namespace ptv
+extern "C" int ptv_debug_pin_cus(int nwg, int lds_bytes, int usec, void* stream) {
+  if (nwg <= 0 || lds_bytes < 256 || lds_bytes > 160 * 1024 || usec < 0 || usec > 100000) return PTV_ERR_ARG;
+  if (lds_bytes > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)ptv::pin_cus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return PTV_ERR_LAUNCH;
+  hipLaunchKernelGGL(ptv::pin_cus_kernel, dim3(nwg), dim3(256), lds_bytes, (hipStream_t)stream, (long long)usec * 100, (int*)nullptr);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}

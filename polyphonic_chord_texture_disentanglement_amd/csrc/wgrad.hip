@@ -525,6 +525,7 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
     const size_t tile_bytes = (size_t)total_slabs * tiles * WBM * WBN * sizeof(float);
     const size_t sum_bytes = colsum_a ? (size_t)total_slabs * M * sizeof(float) : 0;
     WsBuf* wb = ws_for(s, tile_bytes + sum_bytes);
+    if (!wb) g_ord_fallbacks++;
     if (wb) { ws = wb->p; ws_csum = colsum_a ? wb->p + tile_bytes / sizeof(float) : nullptr; ws_slabs = total_slabs; }
   }
   if (has_a) launch(false, 0, kfast, slabs, 1);

@@ -63,7 +63,22 @@ class GradSync:
         self.early = os.environ.get('PTV_EARLY_ALLREDUCE', '1') != '0'
         # PTV_DP_FORCE=1: run the exchange on a group of ONE rank too (tests: the RCCL / stream mechanics on a 1-GPU box)
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get('PTV_DP_FORCE') == '1')
+        # diagnosis of a multi-GPU run (bench.py --gpus N reports it): event-timed span of all_reduce_grads() on the caller's stream =
+        # the part of the exchange the backward pass did NOT hide, and the byte counts of the early slices / the remainder
+        self.timing = False
+        self._spans = []
+        self.last_early_bytes, self.last_remainder_bytes = [], 0
+        # CUs the persistent recurrences leave to RCCL's channel kernels (csrc/gru_persist.hip sizes its grids to one 96-KB workgroup
+        # per CU).  Default 0: a collective kernel co-resides with a persistent workgroup (64 KB of LDS and half the registers of a
+        # CU stay free), and if it cannot, the part of a persistent grid that is not resident yet waits for the collective to finish
+        # -- a stall bounded by the all-reduce itself (~1 ms), never a deadlock: the exchange does not depend on the launch it
+        # delays (tests/test_gpu_zz_dist.py pins CUs under a step to show it).  > 0 halves the persistent grids (row groups are a
+        # power of two): measured slower on one GPU, kept as the knob for a node where the stall shows up in `exposed_allreduce_ms`.
+        self.cu_reserve = int(os.environ.get('PTV_PERSIST_CU_RESERVE', '0'))
         if self.active:
+            if self.cu_reserve and torch.cuda.is_available():
+                from . import functional as F_
+                F_.set_persist_cu_reserve(self.cu_reserve)
             self.broadcast_parameters()
             if self.early and optimizer is not None and hasattr(optimizer, 'arena'):
                 from . import functional as F_
@@ -157,6 +172,33 @@ class GradSync:
             return
         early, self._early = self._early, []
         flat, scatter = self._flat_bucket()
+        span = None
+        if self.timing and flat.is_cuda:
+            span = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            span[0].record()
+        self.last_early_bytes = [4 * (min(e[0][1], flat.numel()) - e[0][0]) for e in early]
+        self.last_remainder_bytes = 4 * flat.numel() - sum(self.last_early_bytes)
+        try:
+            return self._all_reduce(early, flat, scatter)
+        finally:
+            if span is not None:
+                span[1].record()
+                self._spans.append(span)
+
+    def exchange_report(self):
+        """{'exposed_allreduce_ms': mean GPU time the caller's stream spent inside all_reduce_grads() per step (waiting for the early
+        parts + reducing the remainder), 'early_slices_bytes', 'remainder_bytes', ...}; synchronises"""
+        spans, self._spans = self._spans, []
+        if spans:
+            torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in spans]
+        return {'exposed_allreduce_ms': (sum(ms) / len(ms)) if ms else None, 'steps_timed': len(ms),
+                'early_slices_bytes': list(self.last_early_bytes), 'remainder_bytes': int(self.last_remainder_bytes),
+                'bucket_bytes': int(sum(self.last_early_bytes) + self.last_remainder_bytes), 'ranks': self.world,
+                'backend': dist.get_backend(self.group) if dist.is_initialized() else None, 'early_exchange': bool(self.early),
+                'persist_cu_reserve': self.cu_reserve}
+
+    def _all_reduce(self, early, flat, scatter):
         if early:
             epoch = self.optimizer.arena.epoch
             if any(e[2] != epoch for e in early):

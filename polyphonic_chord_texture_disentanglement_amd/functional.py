@@ -343,6 +343,13 @@ def persist_supported(NC, M, H, T=None):
     return _PERSIST_OK[key]
 
 
+def set_persist_cu_reserve(cus):
+    """CUs the persistent grids leave free (ptv_gru_persist_cu_reserve; dist.GradSync sets it from PTV_PERSIST_CU_RESERVE)"""
+    check(lib().ptv_gru_persist_cu_reserve(int(cus)), 'ptv_gru_persist_cu_reserve')
+    _PERSIST_OK.clear()
+    _SPLITK_OK.clear()
+
+
 class _PersistTurn:
     """with _PersistTurn(): <one persistent launch on the current stream>"""
 
@@ -365,6 +372,15 @@ def _persist_sync(NC, dev):
     if len(_PERSIST_SYNC) > 64:
         del _PERSIST_SYNC[:32]
     return sync
+
+
+ORDERED_STRICT = os.environ.get('PTV_ORDERED_STRICT', os.environ.get('PTV_PTR_CHECKS', '0')) == '1'      # (on in the test suite)
+
+
+def ordered_fallbacks(reset=False):
+    """reductions that ran on fp32 atomics although the ordered (bit-reproducible) mode is on -- 0 after any step, or the step's last
+    bits depend on arrival order (ptv_ordered_fallbacks; asserted by the determinism tests and by GraphedTrainStep after capture)"""
+    return int(lib().ptv_ordered_fallbacks(int(bool(reset))))
 
 
 def persist_check():

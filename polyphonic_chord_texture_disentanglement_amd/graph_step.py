@@ -142,6 +142,11 @@ class GraphedTrainStep:
         torch.cuda.synchronize(self.dev)
         opt.flat_p.copy_(saved[0]); opt.exp_avg.copy_(saved[1]); opt.exp_avg_sq.copy_(saved[2])
         opt.step_count, m._draws, opt.grad_scale = saved[3], saved[4], saved[7]
+        if self.sync is not None:
+            # the optimiser graph bakes grad_scale in BY VALUE: under data parallelism every replay is preceded by an all-reduce(SUM),
+            # so the captured value must be 1/world whatever the optimiser held before its first exchange (round-3 advice: a graph
+            # built before any eager step captured 1.0 and every replayed step clipped / stepped on world x the gradient)
+            opt.grad_scale = 1.0 / self.sync.world
         random.setstate(saved[5])
         torch.cuda.set_rng_state(saved[6], self.dev)
         # The captured step must record exactly what a steady-state step enqueues: the transposed bf16 shadows and the fragment-packed
@@ -153,6 +158,7 @@ class GraphedTrainStep:
         opt._plain_stamp = opt._stamp()
         opt._shadow_stamp = None
         lib().ptv_step_params(self.params.data_ptr())
+        fb0 = F_.ordered_fallbacks()
         cap = F_.whole_step_capture()
         cap.__enter__()
         early = None
@@ -177,6 +183,11 @@ class GraphedTrainStep:
             if early is not None:
                 self.sync.early = early
         self.graphs = (g1, g2)
+        # a reduction that found no workspace inside the capture fell back to fp32 atomics: the replayed step would no longer be the
+        # eager step bit for bit (the warm-up steps above exist to make every first-use allocation happen outside the capture)
+        self.capture_fallbacks = F_.ordered_fallbacks() - fb0
+        if self.capture_fallbacks and F_.ORDERED_STRICT:
+            raise RuntimeError('GraphedTrainStep: %d reductions were captured on the atomics fallback' % self.capture_fallbacks)
         # the capture pass itself executed nothing: undo its python-side bookkeeping (the first replay is the step)
         opt.step_count -= 1
         random.setstate(saved[5])
@@ -194,6 +205,10 @@ class GraphedTrainStep:
             if self.graphs is None:
                 self._write_params(beta)
                 self._capture(beta)
+            elif opt.flat_p16 is not None and getattr(self, '_replay_stamp', None) != opt._stamp():
+                # parameters were written behind the graph's back since the last replay (load_state_dict / load_checkpoint / manual
+                # edits): the captured forward reads the plain bf16 shadow the PREVIOUS Adam kernel wrote -- bring it up to date
+                call('ptv_cast_bf16', ptr(opt.flat_p), ptr(opt.flat_p16), opt.arena.total, stream_ptr())
             self._write_params(beta)
             self._fill_eps()
             self._draw_coins()
@@ -206,5 +221,6 @@ class GraphedTrainStep:
         opt.step_count += 1
         opt._opt_called = True
         opt.mark_dirty()               # python-side stamps know nothing of the replayed kernels (an eager step after this re-casts the shadows)
+        self._replay_stamp = opt._stamp()
         self.replays += 1
         return self.losses

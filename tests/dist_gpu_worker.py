@@ -35,6 +35,21 @@ def main():
     sl = slice(rank * B_local, (rank + 1) * B_local)
     xs, cs, prs = (torch.from_numpy(a[sl]).cuda() for a in (x, c, pr))
     res = {}
+    if os.environ.get('PTV_TEST_GRAPH') == '1':
+        # the same two steps replayed from the captured graphs (backward | optimiser, the all-reduce issued between them): built BEFORE
+        # any eager step, i.e. while the optimiser still holds grad_scale = 1 (round-3 advice: that value used to be baked in)
+        from polyphonic_chord_texture_disentanglement_amd.graph_step import GraphedTrainStep
+        gs = GraphedTrainStep(m, opt, B_local, grad_sync=sync)
+        for step in range(2):
+            losses = gs(xs, cs, prs, beta=0.1)
+            torch.cuda.synchronize()
+            res['losses.%d' % step] = [float(v) for v in sync.mean_scalars(list(losses.unbind(0)))]
+            res['gnorm.%d' % step] = float(opt.grad_norm())
+            res['flat_p.%d' % step] = opt.flat_p.detach().cpu().clone()
+        torch.save(res, '%s.rank%d' % (out, rank))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     for step in range(2):
         opt.zero_grad()
         losses = m('train', xs, cs, prs, tfr1=1., tfr2=1., tfr3=1., beta=0.1, weights=[1, 0.5])

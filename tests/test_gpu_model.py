@@ -936,6 +936,37 @@ def test_trainer_surface_with_graph_replayed_steps(tmp_path, monkeypatch):
         assert torch.equal(out[True][4], out[False][4])
 
 
+@pytest.mark.parametrize('B', [64, 160])
+def test_repeated_backward_passes_are_bit_identical_and_no_reduction_fell_back_to_atomics(B):
+    """Found in round 4: from B = 64 on the duration GRU's partial sums (320 column blocks) exceeded the ordered-reduction counter
+    budget and ran on fp32 atomics SILENTLY -- the B = 32 trace below never saw it.  Now the budget covers them, every fallback is
+    counted (ptv_ordered_fallbacks) and this test holds both: four backward passes of one step give the same bits, counter 0."""
+    import os
+    import random
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
+    if os.environ.get('PTV_WGRAD_ORDERED', '1') == '0':
+        pytest.skip('fp32 atomics requested')
+    m = M.DisentangleVAE.init_model(torch.device(DEV))
+    m.load_state_dict(full_params())
+    m.to(DEV).set_precision('bf16')
+    opt = FusedClipAdam(m.parameters(), lr=1e-3)
+    x, c, pr = (torch.from_numpy(a).to(DEV) for a in synth_batch(B, 55))
+    F_.ordered_fallbacks(reset=True)
+    runs = []
+    for i in range(4):
+        m.use_philox(7, 0)
+        random.seed(7)
+        opt.zero_grad()
+        ls = m('train', x, c, pr, tfr1=1., tfr2=1., tfr3=1., beta=0.1, weights=[1, 0.5])
+        ls[0].backward()
+        torch.cuda.synchronize()
+        runs.append(opt.arena.flat.detach().clone())
+    assert F_.ordered_fallbacks() == 0
+    for i in (1, 2, 3):
+        assert torch.equal(runs[0], runs[i]), (i, float((runs[0] - runs[i]).abs().max()))
+
+
 @pytest.mark.parametrize('prec,tfr', [('fp32', 1.0), ('bf16', 1.0), ('bf16', 0.0)])
 def test_two_runs_of_a_training_trace_are_bit_identical(prec, tfr):
     """Ordered reductions (include/ptvae_hip.h: ptv_ordered_reductions, the default): no result of the step depends on the arrival
