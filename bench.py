@@ -162,6 +162,23 @@ def extras(dev, B, rank):
     t = _measure(train_fn(m, opt, data, 0.0), 4, 2)
     out['train_free_running_tfr0'] = {'samples_per_s': round(B / t, 1), 'ms_per_step': round(t * 1e3, 2), 'batch': B, 'dtype': 'bf16',
                                       'note': "the reference's train.py schedule from its third batch on (SURVEY 0.4)"}
+    del m, opt, data
+    torch.cuda.empty_cache()
+    # BASELINE configs[4] names 1024 samples per GPU for this schedule: the step loop is a latency chain per 16-sample panel, so the larger
+    # batch fills the chip (64 panels x 4 cluster members = one workgroup per CU)
+    Bsave = B
+    B = 1024
+    try:
+        random.seed(7)
+        m, opt, data = train_setup('bf16')
+        t = _measure(train_fn(m, opt, data, 0.0), 4, 2)
+        out['train_free_running_tfr0_b1024'] = {'samples_per_s': round(B / t, 1), 'ms_per_step': round(t * 1e3, 2), 'batch': B, 'dtype': 'bf16',
+                                                'note': "configs[4]'s per-GPU batch on train.py's schedule from its third batch on (tfr = 0)"}
+        del m, opt, data
+    finally:
+        B = Bsave
+    torch.cuda.empty_cache()
+    m, opt, data = train_setup('bf16')
     # the trainer surface: TrainingVAE.train() with the device-resident data path (raw piano-roll bank -> ptv_batch_transform),
     # train.py's schedulers, fused clip+Adam, one non-blocking 11-scalar log per batch
     pr_bank, ch_bank = synth_raw_bank(1024, 5)              # 12288 augmented samples: 24 batches per epoch (an epoch ends with a log flush = a sync)

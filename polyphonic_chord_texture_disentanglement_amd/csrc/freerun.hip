@@ -1022,11 +1022,15 @@ extern "C" int ptv_free_note_loop(const void* const* w, const void* const* io, l
   // (47.0 -> 40.8 us).  train bit 16 / 17 force the 4-wave / 8-wave kernel.
   const int panels = (B + FP - 1) / FP;
   const bool split = (train & 0x20000) || (!(train & 0x10000) && panels >= 96);
-  // cluster mode: S members per panel, all co-resident (they wait for each other once per note step): at most half the chip
+  // cluster mode: S members per panel, all co-resident (they wait for each other once per note step): at most one member per CU
   const int S = (train >> 18) & 7;
   a.S = 1;
   if (S > 1) {
-    if ((S != 2 && S != 4) || split || !io[19] || !io[20] || panels * S > 128) return PTV_ERR_UNSUPPORTED;
+    // (round 4: up to one member per CU -- 64 panels x 4 members at B = 1024, the per-GPU batch of BASELINE configs[4]; the launch takes
+    // its turn among the persistent launches, so nothing else that spins is resident beside it)
+    static int ncu = 0;
+    if (ncu == 0) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 128; }
+    if ((S != 2 && S != 4) || split || !io[19] || !io[20] || panels * S > ncu) return PTV_ERR_UNSUPPORTED;
     a.S = S; a.xch = (__bf16*)io[19]; a.cnt = (unsigned*)io[20];
   }
   if (!split) hipLaunchKernelGGL(note_loop_kernel, dim3(a.S > 1 ? (panels + 7) / 8 * 8 * a.S : panels), dim3(256), 0, (hipStream_t)stream, a);

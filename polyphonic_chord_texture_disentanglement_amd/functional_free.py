@@ -81,9 +81,23 @@ def note_loop_cluster(B):
     panels = (B + 15) // 16
     if NOTE_LOOP_SPLIT or (NOTE_LOOP_SPLIT is None and panels >= 96):
         return 0
+    ncu = _num_cu()
     if NOTE_LOOP_CLUSTER is not None:
-        return NOTE_LOOP_CLUSTER if NOTE_LOOP_CLUSTER in (2, 4) and panels * NOTE_LOOP_CLUSTER <= 128 else 0
-    return 4 if panels <= 32 else (2 if panels <= 64 else 0)
+        return NOTE_LOOP_CLUSTER if NOTE_LOOP_CLUSTER in (2, 4) and panels * NOTE_LOOP_CLUSTER <= ncu else 0
+    # round 4: four members per panel up to ONE MEMBER PER CU (64 panels = B 1024, the per-GPU batch of BASELINE configs[4]); it was capped at
+    # half the chip.  Free-running training, same box, S = 2 -> 4: B = 640 21.4k -> 23.8k samples/s, 768 23.4k -> 26.5k, 1024 27.2k -> 30.6k
+    cap4 = NOTE_CLUSTER4_MAX_WGS if NOTE_CLUSTER4_MAX_WGS > 0 else ncu
+    return 4 if panels * 4 <= cap4 else (2 if panels * 2 <= ncu else 0)
+
+
+NOTE_CLUSTER4_MAX_WGS = int(os.environ.get('PTV_NOTE_CLUSTER4_MAX', '0'))      # 0 = the CU count
+_NCU = []
+
+
+def _num_cu():
+    if not _NCU:
+        _NCU.append(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count)
+    return _NCU[0]
 _PACKS = F_.PackCache()
 _PACK_SRC = ('dec_notes_gru.weight_hh_l0', 'dec_notes_gru.weight_ih_l0', 'pitch_out_linear.weight', 'dur_hid_linear.weight',
              'dec_dur_gru.weight_hh_l0', 'note_embedding.weight', 'dec_notes_emb_gru.weight_ih_l0', 'dec_notes_emb_gru.weight_hh_l0',
