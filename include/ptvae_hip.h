@@ -315,6 +315,21 @@ int ptv_dur_bwd_finalize(const float* S, float* g_whh, float* g_bhh, float* g_bi
                          const float* w_ih, const float* sos, int I, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The per-note heads fused (csrc/heads.hip, bf16 precision, init_model() geometry Hn = 512 / 130 classes / Hd = 64): one pass over the
+ * note summaries for decode_note's two Linears (ptvae.py:343-352) and one for their input gradients.
+ *   fwd: pitch [M][ldp] = hn16 . W_p^T + b_p (fp32);  hd0 [M][64] = hn16 . W_dh[:, :512]^T + pitch . W_dh[:, 512:]^T + b_dh
+ *        (+ bf16 copy hd16, may be NULL).  wp / wdh / wdp: ptv_pack_mfma_b of W_p [130,512], W_dh[:, :512] [64,512], W_dh[:, 512:] [64,130].
+ *   bwd: dp [M][ldp] += dhd0 . W_dh[:, 512:] (in place);  dnsum [M][512] bf16 = dp . W_p + dhd0 . W_dh[:, :512], row-major or
+ *        (blocked != 0) column-blocked by 32 ([16][M][32], what ptv_notes_gru_persist_bwd reads).  wdpT: pack of W_dh[:, 512:]^T
+ *        [130,64];  wcat: PAIR-interleaved pack of the [512][224] matrix [W_p^T (130 columns, zero-padded to 160) | W_dh[:, :512]^T].
+ *        Rows from (*m_top + 1) * m_unit on (device int, or NULL) are known to be zero: their dnsum is written as zeros.
+ */
+int ptv_heads_fwd(const void* hn16, const void* wp_packed, const void* wdh_packed, const void* wdp_packed, const float* b_p,
+                  const float* b_dh, float* pitch, long ldp, float* hd0, void* hd16, long M, void* stream);
+int ptv_heads_bwd(float* dp, long ldp, const float* dhd0, const void* wdpT_packed, const void* wcat_packed, void* dnsum16,
+                  int blocked, const int* m_top, long m_unit, long M, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Free-running tokens.
  * ptv_note_token (ptvae.py:408-416 + pitch_dur_ind_to_note_token :328-334): per row pitch argmax (first
  *   maximal index), predicted token pred[r] = note_embedding(onehot(pitch) | 5 duration bits) with
@@ -387,6 +402,9 @@ int ptv_slerp_path(const float* z1, const float* z2, float* out, int B, int D, i
  */
 long ptv_pack_mfma_b_size(int N, int K);
 int ptv_pack_mfma_b(const float* W, long ld, int N, int K, void* out, int pairs, void* stream);
+/* the same for a TRANSPOSED source (trans != 0: element (n, k) at W[k*ld + n]) and / or into the k-block sub-range [kb0, kb0 + ceil(K/32)) of
+ * a packed buffer holding NT tiles x KBtot k-blocks (two sources side by side along K; rows n >= N and columns k >= K are zero) */
+int ptv_pack_mfma_b2(const float* W, long ld, int N, int K, void* out, int pairs, int trans, int NT, int kb0, int KBtot, void* stream);
 int ptv_free_note_loop(const void* const* w, const void* const* io, long ld_pitch, int B, int t, unsigned coin_mask, int train,
                        void* stream);
 int ptv_free_resummarize(const void* const* w, const void* const* io, int B, int t, int train, void* stream);

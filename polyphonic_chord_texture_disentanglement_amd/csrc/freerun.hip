@@ -980,6 +980,35 @@ using namespace ptv;
 
 extern "C" long ptv_pack_mfma_b_size(int N, int K) { return (long)((N + 15) / 16) * ((K + 31) / 32) * 512; }
 
+// generalised: the source may be TRANSPOSED (element (n, k) at W[k*ld + n]) and the k-blocks written may be a sub-range [kb0, kb0 + ceil(K/32))
+// of a packed buffer with KBtot k-blocks per tile (two sources side by side along K: csrc/heads.hip)
+__global__ void pack_b2_kernel(const float* __restrict__ W, long ld, int N, int K, __bf16* __restrict__ out, int NT, int KB, int pairs, int trans,
+                               int kb0, int KBtot) {
+  const long total = (long)NT * KB * 64;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const long f = i >> 6;
+    const int kb = (int)(f % KB), nt = (int)(f / KB);
+    const int c = lane & 15;
+    const int n = pairs ? (nt >> 1) * 32 + (c >> 2) * 8 + (nt & 1) * 4 + (c & 3) : nt * 16 + c;
+    const int k0 = kb * 32 + (lane >> 4) * 8;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = (__bf16)((n < N && k0 + e < K) ? (trans ? W[(long)(k0 + e) * ld + n] : W[(long)n * ld + k0 + e]) : 0.f);
+    *reinterpret_cast<bf16x8*>(out + (((long)nt * KBtot + kb0 + kb) * 64 + lane) * 8) = v;
+  }
+}
+
+extern "C" int ptv_pack_mfma_b2(const float* W, long ld, int N, int K, void* out, int pairs, int trans, int NT, int kb0, int KBtot, void* stream) {
+  if (!W || !out || N <= 0 || K <= 0 || NT * 16 < N || (pairs && (NT & 1)) || kb0 < 0 || kb0 + (K + 31) / 32 > KBtot) return PTV_ERR_ARG;
+  if ((trans && ld < N) || (!trans && ld < K)) return PTV_ERR_ARG;
+  const int KB = (K + 31) / 32;
+  long nb = ((long)NT * KB * 64 + 255) / 256; if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(pack_b2_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, W, ld, N, K, (__bf16*)out, NT, KB, pairs, trans, kb0, KBtot);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
 extern "C" int ptv_pack_mfma_b(const float* W, long ld, int N, int K, void* out, int pairs, void* stream) {
   if (!W || !out || N <= 0 || K <= 0 || ld < K || (pairs && (N & 31))) return PTV_ERR_ARG;
   const int NT = (N + 15) / 16, KB = (K + 31) / 32;

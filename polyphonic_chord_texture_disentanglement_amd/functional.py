@@ -934,10 +934,23 @@ def _bigru_forward(prec, x3, lengths, w):
     return out, [fwd, rev]
 
 
-def _bigru_backward(prec, x3, w, saved, dout, need_dx):
+def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None):
+    """-> ([dw_ih, dw_hh, db_ih, db_hh] x 2 directions, dx [T,M,I] or None).
+    dx_acc ([T*M, I] fp32, or None): a gradient that already arrived at x3 from another consumer -- both directions' input-gradient
+    products ACCUMULATE into it and it is returned as dx (round 4: autograd used to add the two consumers' 134-MB gradients of the note
+    embedding with an ATen kernel, and the two directions' dx met in a copy kernel; now both are the accumulate mode of products that
+    run anyway).  The second direction's dx product runs on the caller's stream after the join (its BPTT ran on the sibling stream)."""
     T, M, I = x3.shape
     H = w[1].shape[1]
     xf = x3.reshape(T * M, I)
+    late = {}                                            # the second direction's (dgi, top) for its dx product after the join
+
+    def dx_of(d, dgi2, top, first):
+        if not need_dx:
+            return None
+        if first and dx_acc is None:
+            return gemm_dx(dgi2, w[4 * d], prec=prec, m_top=top, m_unit=M if top is not None else 0)
+        return gemm_dx(dgi2, w[4 * d], out=dx_acc if first else late['dx'], acc=True, prec=prec, m_top=top, m_unit=M if top is not None else 0)
 
     def direction(d):
         w_ih, w_hh, b_ih, b_hh = w[4 * d: 4 * d + 4]
@@ -947,8 +960,9 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
         dgi2, dgh2 = dgi.view(T * M, 3 * H), dgh.view(T * M, 3 * H)
         dw_ih, db_ih = wgrad_bias(dgi2, xf, _gbuf(w_ih), _gbuf(b_ih), prec)
         dw_hh, db_hh = wgrad_bias(dgh2, (h16 if h16 is not None else hall)[:T].view(T * M, H), _gbuf(w_hh), _gbuf(b_hh), prec)
-        dx = gemm_dx(dgi2, w_ih, prec=prec) if need_dx else None
-        return [dw_ih, dw_hh, db_ih, db_hh], dx
+        if d:
+            late['dgi'], late['top'] = dgi2, None
+        return [dw_ih, dw_hh, db_ih, db_hh], (dx_of(0, dgi2, None, True) if d == 0 else None)
 
     def products(d, dgi, dgh, top=None):
         """top (device int, from the BPTT kernel): no row is longer than top + 1, so dgi (indexed by time) is zero after that time
@@ -959,8 +973,9 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
         dw_ih, db_ih = wgrad_bias(dgi2, xf, _gbuf(w_ih), _gbuf(b_ih), prec, top, M)
         dw_hh, db_hh = wgrad_bias(dgh2, (h16 if h16 is not None else hall)[:T].view(T * M, H), _gbuf(w_hh), _gbuf(b_hh), prec, top, M,
                                   k_rev=T if d else 0)
-        dx = gemm_dx(dgi2, w_ih, prec=prec, m_top=top, m_unit=M) if need_dx else None
-        return [dw_ih, dw_hh, db_ih, db_hh], dx
+        if d:
+            late['dgi'], late['top'] = dgi2, top
+        return [dw_ih, dw_hh, db_ih, db_hh], (dx_of(0, dgi2, top, True) if d == 0 else None)
 
     side = Side(BIGRU_SLOT_BWD)
     wts = [_WT(w[1], prec), _WT(w[5], prec)]
@@ -975,7 +990,7 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
                                dgi=_empty(T, M, 3 * H, dev=x3.device, dtype=adt), dgh=_empty(T, M, 3 * H, dev=x3.device, dtype=adt),
                                dh0=None, reverse=bool(d)))
         gru_persist_bwd(M, H, T, chains)
-        g1, dx1 = side(lambda: products(1, chains[1]['dgi'], chains[1]['dgh']), xf, dout, chains[1]['dgi'], chains[1]['dgh'])
+        g1, _ = side(lambda: products(1, chains[1]['dgi'], chains[1]['dgh']), xf, dout, chains[1]['dgi'], chains[1]['dgh'])
         g0, dx0 = products(0, chains[0]['dgi'], chains[0]['dgh'])
     elif (len(saved[0]) > 3 and saved[0][1].dtype == BF16 and saved[0][2] is not None):
         # (a forward that ran on the row kernels -- a 4-entry saved state -- left its gates in their private unit-blocked layout, and with
@@ -992,15 +1007,37 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx):
             call('ptv_row_gru_persist_bwd', H, ptr(pk['wt']), ptr(hall), ptr(gates), None, dout.data_ptr() + 4 * d * H, dout.stride(0),
                  ptr(lengths) if lengths is not None else None, ptr(dgi), ptr(dgh), None, ptr(scratch), M, T, d, ptr(top), stream_ptr())
             return products(d, dgi, dgh, top)
-        g1, dx1 = side(lambda: rows(1), xf, dout)
+        g1, _ = side(lambda: rows(1), xf, dout)
         g0, dx0 = rows(0)
     else:
-        g1, dx1 = side(lambda: direction(1), xf, dout)
+        g1, _ = side(lambda: direction(1), xf, dout)
         g0, dx0 = direction(0)
     side.join()
     if need_dx:
-        copy2d(dx0, dx1, acc=True)
+        late['dx'] = dx_acc if dx_acc is not None else dx0
+        # (dgi of the second direction was allocated under the sibling stream and is read here, on the caller's: tell the caching allocator,
+        # or its block returns to the sibling's pool when `late` dies and may be overwritten while this product is still queued)
+        if side.s != side.main:
+            _record_stream([late['dgi'], late['top']], side.main)
+        dx_of(1, late['dgi'], late['top'], False)
+        dx0 = late['dx']
     return g0 + g1, (dx0.view(T, M, I) if need_dx else None)
+
+
+# The note embedding has two consumers -- the ground-truth note summaries (this bi-GRU) and the decoder's note tokens -- and autograd
+# summed their two 134-MB gradients with an ATen add at the very end of the backward pass.  The teacher-forced decoder node instead
+# parks its gradient here and returns None; the summary node (which always runs later: the decoder consumes its output) accumulates
+# its own input-gradient products into that buffer and returns it as the one gradient of the embedding.
+_EMB_LINK = {}
+EMB_LINK = os.environ.get('PTV_EMB_LINK', '1') != '0'
+
+
+def emb_link_arm(emb):
+    """called by PtvaeDecoder._summarize before it builds the summary node on `emb`"""
+    if EMB_LINK and torch.is_grad_enabled() and emb.requires_grad:
+        if len(_EMB_LINK) > 8:
+            _EMB_LINK.clear()
+        _EMB_LINK[emb.data_ptr()] = {'demb': None}
 
 
 class BiGruFinalFn(torch.autograd.Function):
@@ -1011,13 +1048,18 @@ class BiGruFinalFn(torch.autograd.Function):
         ctx.save_for_backward(x3, *w)
         ctx.saved_state = saved
         ctx.prec = prec
+        ctx.link = _EMB_LINK.get(x3.data_ptr())
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x3, *w = ctx.saved_tensors
         mark('bigru_bwd:start M=%d' % x3.shape[1])
-        grads, dx = _bigru_backward(ctx.prec, x3, w, ctx.saved_state, dout.contiguous(), ctx.needs_input_grad[0])
+        dx_acc = None
+        if ctx.link is not None and ctx.link['demb'] is not None and ctx.needs_input_grad[0]:
+            dx_acc, ctx.link['demb'] = ctx.link['demb'].view(-1, x3.shape[2]), None     # the decoder node's gradient of the same tensor
+            _EMB_LINK.pop(x3.data_ptr(), None)
+        grads, dx = _bigru_backward(ctx.prec, x3, w, ctx.saved_state, dout.contiguous(), ctx.needs_input_grad[0], dx_acc)
         mark('bigru_bwd:end M=%d' % x3.shape[1])
         ctx.saved_state = None
         if GRAD_READY_HOOK is not None:                   # data parallel: a bi-GRU's 8 gradients are final here (its side stream is joined)
@@ -1170,6 +1212,37 @@ def notes_packs(w_ih, w_hh, Ht):
     return _NOTES_PACKS.put([w_ih, w_hh], stamp, pk)
 
 
+_HEADS_PACKS = PackCache()
+HEADS_FUSED = os.environ.get('PTV_HEADS_FUSED', '1') != '0'
+
+
+def heads_ok(prec, Hn, NP, Hd, hn16, hd16):
+    """the fused per-note heads (csrc/heads.hip): bf16 precision at the init_model() geometry"""
+    return HEADS_FUSED and prec == 1 and BF16_STORAGE and (Hn, NP, Hd) == (512, 130, 64) and hn16 is not None and hd16 is not None
+
+
+def heads_packs(w_p, w_dh):
+    """fragment-major bf16 copies of pitch_out_linear / dur_hid_linear for ptv_heads_fwd / ptv_heads_bwd; cached per parameter version"""
+    stamp = param_stamp([w_p, w_dh])
+    hit = _HEADS_PACKS.get([w_p, w_dh], stamp)
+    if hit is not None:
+        return hit
+    Hn, NP, Hd = w_p.shape[1], w_p.shape[0], w_dh.shape[0]
+    dev = w_p.device
+
+    def pk2(src, N, K, NT, KBtot, kb0=0, pairs=False, trans=False, out=None):
+        out = torch.empty(NT * KBtot * 512, device=dev, dtype=BF16) if out is None else out
+        call('ptv_pack_mfma_b2', ptr(src), src.stride(0), N, K, ptr(out), int(pairs), int(trans), NT, kb0, KBtot, stream_ptr())
+        return out
+    # wcat: B operand of dNSUM = [dP' (130 -> 160) | dHD0 (64)] . [W_p ; W_dh[:, :Hn]] -- rows = the 512 units, k-blocks 0-4 from W_p^T
+    # (its rows beyond 130 zero), 5-6 from W_dh[:, :Hn]^T; straight from the fp32 masters (transposed reads), no staging tensors
+    wcat = pk2(w_p, Hn, NP, Hn // 16, 7, 0, pairs=True, trans=True)
+    pk2(w_dh, Hn, Hd, Hn // 16, 7, 5, pairs=True, trans=True, out=wcat)
+    pk = dict(wp=pk2(w_p, NP, Hn, 9, Hn // 32), wdh=pk2(w_dh, Hd, Hn, Hd // 16, Hn // 32), wdp=pk2(w_dh[:, Hn:], Hd, NP, Hd // 16, 5),
+              wdpT=pk2(w_dh[:, Hn:], NP, Hd, 9, Hd // 32, trans=True), wcat=wcat)
+    return _HEADS_PACKS.put([w_p, w_dh], stamp, pk)
+
+
 def row_gru_ok(prec, H, I, M, adt):
     """the H = 128 instance of the row-partitioned persistent GRU (dec_notes_emb_gru): worth it when the rows fill the chip"""
     return (NOTES_PERSIST and os.environ.get('PTV_ROW_GRU128', '1') != '0' and prec == 1 and BF16_STORAGE and H == 128 and I == 128
@@ -1289,12 +1362,19 @@ class DecoderTFFn(torch.autograd.Function):
         # logits rows padded to a multiple of 8 floats: 130-wide rows would put every row of this tensor (an operand of
         # four more products) off the 16-byte grid and force element-wise loads / stores
         pitch = _empty(M, _pad8(NP), dev=dev)[:, :NP]
-        gemm(NSUM_op, W['pitch_out_linear.weight'], pitch, bias=P['pitch_out_linear.bias'], prec=prec)          # [M,130]
-        w_dh = W['dur_hid_linear.weight']
         HD = _empty(6, M, Hd, dev=dev)
         HD16 = _hall16(prec, 6, M, Hd, dev)
-        gemm(NSUM_op, w_dh[:, :Hn], HD[0], bias=P['dur_hid_linear.bias'], prec=prec)
-        gemm(pitch, w_dh[:, Hn:], HD[0], acc=True, prec=prec)
+        fused_heads = heads_ok(prec, Hn, NP, Hd, HN16, HD16)
+        if fused_heads:
+            # ONE pass over the note summaries for both Linears; the logits feed the second product from LDS (csrc/heads.hip)
+            hp = heads_packs(P['pitch_out_linear.weight'], P['dur_hid_linear.weight'])
+            call('ptv_heads_fwd', ptr(NSUM_op), ptr(hp['wp']), ptr(hp['wdh']), ptr(hp['wdp']), ptr(P['pitch_out_linear.bias']),
+                 ptr(P['dur_hid_linear.bias']), ptr(pitch), pitch.stride(0), ptr(HD[0]), ptr(HD16[0]), M, stream_ptr())
+        else:
+            gemm(NSUM_op, W['pitch_out_linear.weight'], pitch, bias=P['pitch_out_linear.bias'], prec=prec)          # [M,130]
+            w_dh = W['dur_hid_linear.weight']
+            gemm(NSUM_op, w_dh[:, :Hn], HD[0], bias=P['dur_hid_linear.bias'], prec=prec)
+            gemm(pitch, w_dh[:, Hn:], HD[0], acc=True, prec=prec)
 
         mark('dec_fwd:heads')
         # --- 5-step duration GRU with argmax feedback (ptvae.py:353-367)
@@ -1312,7 +1392,7 @@ class DecoderTFFn(torch.autograd.Function):
                  None if HD16 is not None else ptr(HD[1]), M * Hd,          # fp32 states stay in registers when the bf16
                  ptr(HD16[1]) if HD16 is not None else None, ptr(gates_d), M * Hd, 4 * M * Hd, _bf(gates_d),   # copies exist
                  ptr(dur2), 10, ptr(idx), M, ptr(force_dur) if force_dur is not None else None, M, stream_ptr())
-            if HD16 is not None:
+            if HD16 is not None and not fused_heads:
                 call('ptv_cast_bf16', ptr(HD[0]), ptr(HD16[0]), M * Hd, stream_ptr())       # slot 0 of the shadow
         else:
             for d in range(5):
@@ -1324,6 +1404,8 @@ class DecoderTFFn(torch.autograd.Function):
                      stream_ptr())
 
         S.save_for_backward(z, emb, *params)
+        # (see _EMB_LINK: only when the summaries really are a function of this very embedding and will receive a gradient from this node)
+        S.emb_link = _EMB_LINK.get(emb.data_ptr()) if (S.needs_input_grad[2] and S.needs_input_grad[1] and emb.is_contiguous()) else None
         S.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in, NS16=NS16, HN16=HN16,
                     HD16=HD16,
                     TOKS=TOKS, gates_t=gates_t, HN=HN, gates_n=gates_n, gates_n_rowk=gates_n_rowk, pitch=pitch, HD=HD, gates_d=gates_d, idx=idx,
@@ -1352,7 +1434,11 @@ class DecoderTFFn(torch.autograd.Function):
         else:
             side.join()
         B, He = st['B'], st['He']
-        return (dz, demb.view(16, 32, B, E), dTOKS[1:].view(R, 2 * He), None, None) + tuple(G[n] for n in DEC_PARAM_NAMES)
+        demb_out = demb.view(16, 32, B, E)
+        if ctx.emb_link is not None and ctx.needs_input_grad[2] and demb.dtype == F32 and demb.is_contiguous():
+            ctx.emb_link['demb'] = demb                   # the summary node accumulates into it and returns it (BiGruFinalFn.backward)
+            demb_out = None
+        return (dz, demb_out, dTOKS[1:].view(R, 2 * He), None, None) + tuple(G[n] for n in DEC_PARAM_NAMES)
 
 
 def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
@@ -1453,7 +1539,15 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     dNSUM = _empty(M, Hn, dev=dev, dtype=_act_dtype(prec, Hn))
     # (read by the row-partitioned BPTT kernel column-blocked by 32, like its saved gates: whole-kilobyte wave accesses)
     rowk_bwd = bool(st.get('gates_n_rowk') and notes_persist_ok(prec, Hn, E, st['gates_n'].dtype) and dNSUM.dtype == BF16 and HN.dtype == F32)
-    gemm_dx(dHD0, w_dh, slice(Hn, None), out=dP, acc=True, prec=prec, m_top=top_h, m_unit=R)         # dP complete
+    fused_heads = (heads_ok(prec, Hn, NP, Hd, st.get('HN16'), st.get('HD16')) and dNSUM.dtype == BF16 and dP.stride(0) % 4 == 0
+                   and dP.data_ptr() % 16 == 0 and dHD0.dtype == F32 and dHD0.is_contiguous())
+    if fused_heads:
+        # dP += dHD0 . W_dh[:, Hn:] and dNSUM = dP . W_p + dHD0 . W_dh[:, :Hn] in one pass over dP / dHD0 (csrc/heads.hip)
+        hp = heads_packs(P['pitch_out_linear.weight'], P['dur_hid_linear.weight'])
+        call('ptv_heads_bwd', ptr(dP), dP.stride(0), ptr(dHD0), ptr(hp['wdpT']), ptr(hp['wcat']), ptr(dNSUM), int(rowk_bwd),
+             ptr(top_h), R if top_h is not None else 0, M, stream_ptr())
+    else:
+        gemm_dx(dHD0, w_dh, slice(Hn, None), out=dP, acc=True, prec=prec, m_top=top_h, m_unit=R)         # dP complete
 
     def head_wgrads():
         wgrad_b('dur_hid_linear.weight', 'dur_hid_linear.bias', dHD0, NSUM_op, slice(0, Hn), top_h)
@@ -1463,8 +1557,9 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     # queues next would be a false dependency)
     if FORK_EARLY:
         side(head_wgrads, dHD0, dP)
-    gemm_dx(dHD0, w_dh, slice(0, Hn), out=dNSUM, prec=prec, m_top=top_h, m_unit=R, out_blocked=rowk_bwd)                   # [M, Hn]
-    gemm_dx(dP, w_p, out=dNSUM, acc=True, prec=prec, m_top=top_h, m_unit=R, out_blocked=rowk_bwd)
+    if not fused_heads:
+        gemm_dx(dHD0, w_dh, slice(0, Hn), out=dNSUM, prec=prec, m_top=top_h, m_unit=R, out_blocked=rowk_bwd)                   # [M, Hn]
+        gemm_dx(dP, w_p, out=dNSUM, acc=True, prec=prec, m_top=top_h, m_unit=R, out_blocked=rowk_bwd)
     if not FORK_EARLY:
         side(head_wgrads, dHD0, dP)
 

@@ -311,6 +311,7 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
 
     def _summarize(self, emb, len32):
         n, t, b, e = emb.shape
+        F_.emb_link_arm(emb)
         return F_.BiGruFinalFn.apply(emb.view(n, t * b, e), len32, self._prec, *self.dec_notes_emb_gru.weights())
 
     def draw_coins(self, tfr1, tfr2):

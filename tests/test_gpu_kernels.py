@@ -755,3 +755,50 @@ def test_binding_rejects_host_tensors_and_checks_arguments_in_the_test_suite():
     t = torch.zeros(4, device='cuda:0')
     assert _lib.ptr(t) == t.data_ptr() and _lib.ptr(None) is None
     assert int(_lib.stream_ptr() or 0) == int(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize('M,top,unit', [(1000, None, 0), (4096, 1, 1024), (4096, -1, 1024), (300, 0, 96)])
+def test_fused_heads_kernels_vs_fp32_products_of_the_same_bf16_operands(M, top, unit):
+    """csrc/heads.hip: decode_note's two Linears (ptvae.py:343-352) for M note summaries in ONE pass, and their input gradients in one
+    pass -- against plain fp32 products of the bf16-rounded operands (what the three ptv_gemm calls they replace compute): logits,
+    duration state (+ its bf16 copy), dP in place, dNSUM row-major and column-blocked by 32, ragged M, the zero-row limit"""
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    from polyphonic_chord_texture_disentanglement_amd._lib import call, ptr, stream_ptr
+    dev = _dev()
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(M)
+    w_p = (torch.randn(130, 512, generator=g) * 0.05).to(dev)
+    w_dh = (torch.randn(64, 642, generator=g) * 0.05).to(dev)
+    b_p, b_dh = torch.randn(130, generator=g).to(dev) * 0.1, torch.randn(64, generator=g).to(dev) * 0.1
+    hn = (torch.randn(M, 512, generator=g) * 0.5).to(dev).to(bf)
+    hp = F_.heads_packs(w_p, w_dh)
+    r = lambda t: t.to(bf).float()
+    pitch = torch.full((M, 136), 7.0, device=dev)
+    hd0 = torch.zeros(M, 64, device=dev)
+    hd16 = torch.zeros(M, 64, device=dev, dtype=bf)
+    call('ptv_heads_fwd', ptr(hn), ptr(hp['wp']), ptr(hp['wdh']), ptr(hp['wdp']), ptr(b_p), ptr(b_dh), ptr(pitch), 136, ptr(hd0), ptr(hd16), M,
+         stream_ptr())
+    p_ref = hn.float() @ r(w_p).t() + b_p
+    h_ref = hn.float() @ r(w_dh[:, :512]).t() + r(p_ref) @ r(w_dh[:, 512:]).t() + b_dh
+    assert (pitch[:, :130] - p_ref).abs().max() < 2e-4 * max(1.0, p_ref.abs().max().item())
+    assert (pitch[:, 130:] == 7.0).all()                                  # the row padding is not touched
+    assert (hd0 - h_ref).abs().max() < 3e-3 * max(1.0, h_ref.abs().max().item())      # (a logit that rounds the other way in bf16 moves it)
+    assert torch.equal(hd16, hd0.to(bf))
+    # ---- backward
+    live = M if top is None else min(M, (top + 1) * unit)
+    dP0 = torch.randn(M, 136, generator=g).to(dev) * 0.1
+    dhd = torch.randn(M, 64, generator=g).to(dev) * 0.1
+    dP0[live:] = 0
+    dhd[live:] = 0
+    top_t = torch.tensor([top], device=dev, dtype=torch.int32) if top is not None else None
+    dp_ref = dP0[:, :130] + r(dhd) @ r(w_dh[:, 512:])
+    dn_ref = r(dp_ref) @ r(w_p) + r(dhd) @ r(w_dh[:, :512])
+    for blocked in (0, 1):
+        dP = dP0.clone()
+        dn = torch.full((M * 512,), 3.0, device=dev).to(bf)
+        call('ptv_heads_bwd', ptr(dP), 136, ptr(dhd), ptr(hp['wdpT']), ptr(hp['wcat']), ptr(dn), blocked, ptr(top_t), unit, M, stream_ptr())
+        assert (dP[:, :130] - dp_ref).abs().max() < 2e-4 * max(1.0, dp_ref.abs().max().item())
+        assert torch.equal(dP[:, 130:], dP0[:, 130:])
+        got = dn.view(16, M, 32).permute(1, 0, 2).reshape(M, 512) if blocked else dn.view(M, 512)
+        assert (got.float() - dn_ref).abs().max() < 1.5e-2 * max(1.0, dn_ref.abs().max().item())
+        assert (got[live:] == 0).all()
