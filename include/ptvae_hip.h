@@ -220,6 +220,12 @@ int ptv_multihot_bf16(const long* x, void* out, long ld, int B, void* stream);
 int ptv_txt_conv_relu_pool_fwd(const float* pr_mat, const float* w, const float* bias, float* pooled, int B, int C, void* stream);
 int ptv_txt_conv_relu_pool_bwd(const float* pr_mat, const float* w, const float* bias, const float* dpooled,
                                float* dw, float* dbias, int B, int C, void* stream);
+/* the same with the pooled map held as the rows of the reference's raw view (ptvae.py:114): feat [B*8][ld], ld >= C*29 -- element
+ * (b, ch, beat, pp) at row b*8 + f / (C*29), column f % (C*29), f = (ch*8 + beat)*29 + pp.  A 16-byte-multiple ld keeps the rows of fc1's
+ * operand aligned for the MFMA loaders; ld = C*29 is the plain tensor of the entry points above. */
+int ptv_txt_conv_relu_pool_fwd_rows(const float* pr_mat, const float* w, const float* bias, float* feat, long ld, int B, int C, void* stream);
+int ptv_txt_conv_relu_pool_bwd_rows(const float* pr_mat, const float* w, const float* bias, const float* dfeat, long ld,
+                                    float* dw, float* dbias, int B, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * reparameterize(): get_zs_from_dists / Normal.rsample (amc_dl/torch_plus/train_utils.py:33-34)
@@ -323,11 +329,13 @@ int ptv_dur_bwd_finalize(const float* S, float* g_whh, float* g_bhh, float* g_bi
  *        (blocked != 0) column-blocked by 32 ([16][M][32], what ptv_notes_gru_persist_bwd reads).  wdpT: pack of W_dh[:, 512:]^T
  *        [130,64];  wcat: PAIR-interleaved pack of the [512][224] matrix [W_p^T (130 columns, zero-padded to 160) | W_dh[:, :512]^T].
  *        Rows from (*m_top + 1) * m_unit on (device int, or NULL) are known to be zero: their dnsum is written as zeros.
+ *        dy16 (or NULL): [M][200] bf16 = [dp (130) | 0 (6) | dhd0 (64)] of the live rows -- ONE ptv_wgrad operand for the weight gradients
+ *        of both Linears over the note summaries (one pass over the [M][512] summaries instead of two).
  */
 int ptv_heads_fwd(const void* hn16, const void* wp_packed, const void* wdh_packed, const void* wdp_packed, const float* b_p,
                   const float* b_dh, float* pitch, long ldp, float* hd0, void* hd16, long M, void* stream);
 int ptv_heads_bwd(float* dp, long ldp, const float* dhd0, const void* wdpT_packed, const void* wcat_packed, void* dnsum16,
-                  int blocked, const int* m_top, long m_unit, long M, void* stream);
+                  int blocked, void* dy16, const int* m_top, long m_unit, long M, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Free-running tokens.

@@ -172,6 +172,7 @@ struct HeadsBwdArgs {
   const bf16x8 *wdpT;                          // W_dh[:, 512:]^T packed [9][2][64]   (N = 130 -> 144, K = 64)
   const bf16x8 *wcat;                          // [W_p ; W_dh[:, :512]]^T packed, PAIR-interleaved [32][7][64]: k-blocks 0-4 = the 130 (-> 160) logit rows, 5-6 = the 64 duration rows
   __bf16* dnsum; int blocked;                  // [M][512] bf16, or column-blocked by 32: [16][M][32]
+  __bf16* dy16;                                // [M][200] bf16 = [dP' (130) | 0 (6) | dHD0 (64)]: ONE operand for both heads' weight gradients, or null
   const int* m_top; long m_unit;               // rows from (*m_top + 1) * m_unit on are zero (or null)
   long M;
 };
@@ -229,6 +230,13 @@ __global__ __launch_bounds__(256, 1) void heads_bwd_kernel(HeadsBwdArgs a) {
       ad[i][k] = bf16x8{(__bf16)lo.x, (__bf16)lo.y, (__bf16)lo.z, (__bf16)lo.w, (__bf16)hi.x, (__bf16)hi.y, (__bf16)hi.z, (__bf16)hi.w};
     }
   }
+  if (a.dy16) {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+      if (r0 + i * 16 + rl < a.M)
+#pragma unroll
+        for (int k = 0; k < 2; k++) *reinterpret_cast<bf16x8*>(a.dy16 + (r0 + i * 16 + rl) * 200 + 136 + k * 32 + kq * 8) = ad[i][k];
+  }
   // ---- dP' = dP + dHD0 . W_dh[:, 512:]   (accumulators start at dP: lane (row rl, quad kq) holds columns 16 j + 4 kq .. + 3)
 #pragma unroll
   for (int i = 0; i < 2; i++) {
@@ -258,6 +266,7 @@ __global__ __launch_bounds__(256, 1) void heads_bwd_kernel(HeadsBwdArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; e++) w[e] = (__bf16)(c + e < HNP ? v[e] : 0.f);
       *reinterpret_cast<bf16x4*>(ps + (i * 16 + rl) * HPLD + c) = w;
+      if (ok && a.dy16 && c < 136) *reinterpret_cast<bf16x4*>(a.dy16 + gr * 200 + c) = w;       // (columns 130 .. 135: zeros)
       if (ok && rlive[i]) {
         float* pp = a.dp + gr * a.ldp + c;
         if (c + 4 <= HNP) *reinterpret_cast<float4*>(pp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -332,10 +341,10 @@ extern "C" int ptv_heads_fwd(const void* hn16, const void* wp_packed, const void
 }
 
 extern "C" int ptv_heads_bwd(float* dp, long ldp, const float* dhd0, const void* wdpT_packed, const void* wcat_packed, void* dnsum16,
-                             int blocked, const int* m_top, long m_unit, long M, void* stream) {
+                             int blocked, void* dy16, const int* m_top, long m_unit, long M, void* stream) {
   if (!dp || !dhd0 || !wdpT_packed || !wcat_packed || !dnsum16 || M <= 0 || ldp < HNP || (ldp & 3) || (m_top && m_unit <= 0)) return PTV_ERR_ARG;
   if (reinterpret_cast<uintptr_t>(dp) & 15) return PTV_ERR_ARG;
-  HeadsBwdArgs a{dp, ldp, dhd0, (const bf16x8*)wdpT_packed, (const bf16x8*)wcat_packed, (__bf16*)dnsum16, blocked, m_top, m_unit, M};
+  HeadsBwdArgs a{dp, ldp, dhd0, (const bf16x8*)wdpT_packed, (const bf16x8*)wcat_packed, (__bf16*)dnsum16, blocked, (__bf16*)dy16, m_top, m_unit, M};
   const int lds = 2 * HGT * HBK * 64 * 16 + 4 * 32 * HPLD * 2;            // 112 KB + 42 KB
   static bool attr = false;
   if (!attr) { if (hipFuncSetAttribute((const void*)heads_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return PTV_ERR_LAUNCH; attr = true; }

@@ -11,9 +11,17 @@ namespace ptv {
 
 constexpr int TX_MAXC = 16;
 
+// element (b, ch, beat, pp) of the pooled map [B,C,8,29] inside the reference's raw view [B*8 rows][C*29] (ptvae.py:114) held with row
+// stride ld >= C*29.  ld = C*29 is the plain contiguous tensor; a 16-byte multiple keeps the rows of fc1's operand aligned (the weight
+// gradient of fc1 ran 334 us on the element-wise path with 290-float rows, round 4)
+__device__ __forceinline__ long tx_index(int b, int ch, int beat, int pp, int C, long ld) {
+  const int W = C * 29, f = (ch * 8 + beat) * 29 + pp;
+  return ((long)b * 8 + f / W) * ld + f % W;
+}
+
 // one block iteration = one (b, beat); thread -> (ch, pp)
 __global__ void txt_conv_fwd_kernel(const float* __restrict__ pr, const float* __restrict__ w, const float* __restrict__ bias,
-                                    float* __restrict__ pooled, int B, int C) {
+                                    float* __restrict__ pooled, int B, int C, long ld) {
   __shared__ float rows[4][128];
   __shared__ float ws[TX_MAXC * 48 + TX_MAXC];
   for (int i = threadIdx.x; i < C * 48; i += blockDim.x) ws[i] = w[i];
@@ -38,7 +46,11 @@ __global__ void txt_conv_fwd_kernel(const float* __restrict__ pr, const float* _
           for (int j = 0; j < 12; j++) v += wc[i * 12 + j] * rows[i][p0 + j];
         best = fmaxf(best, v);
       }
-      pooled[(((long)b * C + ch) * 8 + beat) * 29 + pp] = best;
+      pooled[tx_index(b, ch, beat, pp, C, ld)] = best;
+    }
+    if (beat == 0 && ld > nout) {                                  // the row padding of this sample's 8 rows: finite (zero), never data
+      const int padw = (int)(ld - nout);
+      for (int i = threadIdx.x; i < 8 * padw; i += blockDim.x) pooled[((long)b * 8 + i / padw) * ld + nout + i % padw] = 0.f;
     }
   }
 }
@@ -71,9 +83,10 @@ __device__ __forceinline__ void ordered_commit_tx(float* dw, float* dbias, const
 
 // dW[ch,i,j] += sum dpool * [conv>0 at the arg-max q] * pr ; dbias likewise.  Conv is recomputed.
 __global__ void txt_conv_bwd_kernel(const float* __restrict__ pr, const float* __restrict__ w, const float* __restrict__ bias,
-                                    const float* __restrict__ dpooled, float* __restrict__ dw, float* __restrict__ dbias, int B, int C, OrdScratch sc) {
+                                    const float* __restrict__ dpooled, float* __restrict__ dw, float* __restrict__ dbias, int B, int C, long ld, OrdScratch sc) {
   __shared__ float stage[TX_MAXC * 29][7];
-  __shared__ float rows[4][128];
+  constexpr int NB = 4;                                           // (sample, beat) items per trip: their 2-KB row loads are in flight together
+  __shared__ float rows[NB][4][128];
   __shared__ float ws[TX_MAXC * 48 + TX_MAXC];
   __shared__ float acc[TX_MAXC * 49];
   for (int i = threadIdx.x; i < C * 48; i += blockDim.x) ws[i] = w[i];
@@ -86,32 +99,50 @@ __global__ void txt_conv_bwd_kernel(const float* __restrict__ pr, const float* _
   for (int k = 0; k < 49; k++) g[k] = 0.f;
   const int o = threadIdx.x;
   const int ch = o / 29, pp = o % 29;
-  for (long it = blockIdx.x; it < (long)B * 8; it += gridDim.x) {
-    const int b = (int)(it / 8), beat = (int)(it % 8);
+  // (round 4: one item per trip was a chain of 32 load -> barrier -> compute round trips per block, 207 us for a 480-weight convolution)
+  const long total = (long)B * 8;
+  for (long base = (long)blockIdx.x * NB; base < total; base += (long)gridDim.x * NB) {
     __syncthreads();
-    for (int i = threadIdx.x; i < 512; i += blockDim.x) rows[i >> 7][i & 127] = pr[((long)b * 32 + beat * 4) * 128 + i];
+    for (int i = threadIdx.x; i < NB * 512; i += blockDim.x) {
+      const long it = base + (i >> 9);
+      if (it < total) {
+        const int b = (int)(it / 8), beat = (int)(it % 8);
+        rows[i >> 9][(i >> 7) & 3][i & 127] = pr[((long)b * 32 + beat * 4) * 128 + (i & 511)];
+      }
+    }
+    // this thread's pooled gradients of the NB items: requested before the barrier, consumed after the recomputed convolutions
+    float dn[NB];
+#pragma unroll
+    for (int n = 0; n < NB; n++) {
+      const long it = base + n;
+      dn[n] = (o < nout && it < total) ? dpooled[tx_index((int)(it / 8), ch, (int)(it % 8), pp, C, ld)] : 0.f;
+    }
     __syncthreads();
     if (o < nout) {
       const float* wc = ws + ch * 48;
-      float best = 0.f; int bq = -1;
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int p0 = pp * 4 + q;
-        float v = ws[C * 48 + ch];
+      for (int n = 0; n < NB; n++) {
+        if (base + n >= total) break;
+        float best = 0.f; int bq = -1;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int q = 0; q < 4; q++) {
+          const int p0 = pp * 4 + q;
+          float v = ws[C * 48 + ch];
 #pragma unroll
-          for (int j = 0; j < 12; j++) v += wc[i * 12 + j] * rows[i][p0 + j];
-        if (v > best) { best = v; bq = q; }      // first max wins ties, as MaxPool2d does
-      }
-      if (bq >= 0) {
-        const float d = dpooled[(((long)b * C + ch) * 8 + beat) * 29 + pp];
-        const int p0 = pp * 4 + bq;
+          for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 12; j++) v += wc[i * 12 + j] * rows[n][i][p0 + j];
+          if (v > best) { best = v; bq = q; }      // first max wins ties, as MaxPool2d does
+        }
+        if (bq >= 0) {
+          const float d = dn[n];
+          const int p0 = pp * 4 + bq;
 #pragma unroll
-          for (int j = 0; j < 12; j++) g[i * 12 + j] += d * rows[i][p0 + j];
-        g[48] += d;
+          for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 12; j++) g[i * 12 + j] += d * rows[n][i][p0 + j];
+          g[48] += d;
+        }
       }
     }
   }
@@ -149,22 +180,29 @@ __global__ void txt_conv_bwd_kernel(const float* __restrict__ pr, const float* _
 
 using namespace ptv;
 
-extern "C" int ptv_txt_conv_relu_pool_fwd(const float* pr_mat, const float* w, const float* bias, float* pooled, int B, int C, void* stream) {
-  if (!pr_mat || !w || !bias || !pooled || B <= 0 || C <= 0 || C > TX_MAXC) return PTV_ERR_ARG;
+extern "C" int ptv_txt_conv_relu_pool_fwd_rows(const float* pr_mat, const float* w, const float* bias, float* feat, long ld, int B, int C, void* stream) {
+  if (!pr_mat || !w || !bias || !feat || B <= 0 || C <= 0 || C > TX_MAXC || ld < C * 29) return PTV_ERR_ARG;
   int grid = B * 8 < 2048 ? B * 8 : 2048;
-  hipLaunchKernelGGL(txt_conv_fwd_kernel, dim3(grid), dim3(320), 0, (hipStream_t)stream, pr_mat, w, bias, pooled, B, C);
+  hipLaunchKernelGGL(txt_conv_fwd_kernel, dim3(grid), dim3(320), 0, (hipStream_t)stream, pr_mat, w, bias, feat, B, C, ld);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
+extern "C" int ptv_txt_conv_relu_pool_fwd(const float* pr_mat, const float* w, const float* bias, float* pooled, int B, int C, void* stream) {
+  return ptv_txt_conv_relu_pool_fwd_rows(pr_mat, w, bias, pooled, (long)C * 29, B, C, stream);
+}
 
-extern "C" int ptv_txt_conv_relu_pool_bwd(const float* pr_mat, const float* w, const float* bias, const float* dpooled,
-                                          float* dw, float* dbias, int B, int C, void* stream) {
-  if (!pr_mat || !w || !bias || !dpooled || !dw || !dbias || B <= 0 || C <= 0 || C > TX_MAXC) return PTV_ERR_ARG;
+extern "C" int ptv_txt_conv_relu_pool_bwd_rows(const float* pr_mat, const float* w, const float* bias, const float* dfeat, long ld,
+                                               float* dw, float* dbias, int B, int C, void* stream) {
+  if (!pr_mat || !w || !bias || !dfeat || !dw || !dbias || B <= 0 || C <= 0 || C > TX_MAXC || ld < C * 29) return PTV_ERR_ARG;
   int nthreads = ((C * 29 + 63) / 64) * 64;       // one thread per (ch, pp)
-  int grid = B * 8 < 512 ? B * 8 : 512;
-  OrdScratch sc = ord_scratch((hipStream_t)stream, 128L * C * 49, 1);
-  if (sc.slots && grid > 128) grid = 128;                         // (the last block adds `grid` partials per tap)
-  hipLaunchKernelGGL(txt_conv_bwd_kernel, dim3(grid), dim3(nthreads), 0, (hipStream_t)stream, pr_mat, w, bias, dpooled, dw, dbias, B, C, sc);
+  int grid = (B * 8 + 3) / 4 < 512 ? (B * 8 + 3) / 4 : 512;       // four items per trip
+  OrdScratch sc = ord_scratch((hipStream_t)stream, 256L * C * 49, 1);
+  if (sc.slots && grid > 256) grid = 256;                         // (the last block adds `grid` partials per tap)
+  hipLaunchKernelGGL(txt_conv_bwd_kernel, dim3(grid), dim3(nthreads), 0, (hipStream_t)stream, pr_mat, w, bias, dfeat, dw, dbias, B, C, ld, sc);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
+}
+extern "C" int ptv_txt_conv_relu_pool_bwd(const float* pr_mat, const float* w, const float* bias, const float* dpooled,
+                                          float* dw, float* dbias, int B, int C, void* stream) {
+  return ptv_txt_conv_relu_pool_bwd_rows(pr_mat, w, bias, dpooled, (long)C * 29, dw, dbias, B, C, stream);
 }

@@ -1132,20 +1132,27 @@ class ReparamFn(torch.autograd.Function):
 # TextureEncoder front end: conv + relu + maxpool   (ptvae.py:95-99,112-114)
 # =============================================================================================
 class TextureFrontFn(torch.autograd.Function):
+    """pr_mat [B,32,128] -> the rows of the reference's raw view of the pooled conv map (ptvae.py:112-114): [B*8, C*29], held with a row
+    stride padded to a multiple of 8 floats (fc1's operand: aligned rows for the MFMA loaders -- its weight gradient took the
+    element-wise path at 290-float rows, 334 us at the very end of the backward pass)"""
+
     @staticmethod
     def forward(ctx, pr_mat, w, b):
         B, C = pr_mat.shape[0], w.shape[0]
         pr_mat = pr_mat.contiguous()
-        pooled = _empty(B, C, 8, 29, dev=w.device)
-        call('ptv_txt_conv_relu_pool_fwd', ptr(pr_mat), ptr(w), ptr(b), ptr(pooled), B, C, stream_ptr())
+        W = C * 29
+        feat = _empty(B * 8, _pad8(W), dev=w.device)             # (the kernel zeroes the row padding)
+        call('ptv_txt_conv_relu_pool_fwd_rows', ptr(pr_mat), ptr(w), ptr(b), ptr(feat), feat.stride(0), B, C, stream_ptr())
         ctx.save_for_backward(pr_mat, w, b)
-        return pooled
+        return feat[:, :W]
 
     @staticmethod
-    def backward(ctx, dpooled):
+    def backward(ctx, dfeat):
         pr_mat, w, b = ctx.saved_tensors
         dw, db = _gbuf(w), _gbuf(b)
-        call('ptv_txt_conv_relu_pool_bwd', ptr(pr_mat), ptr(w), ptr(b), ptr(dpooled.contiguous()), ptr(dw), ptr(db),
+        if dfeat.stride(1) != 1:
+            dfeat = dfeat.contiguous()
+        call('ptv_txt_conv_relu_pool_bwd_rows', ptr(pr_mat), ptr(w), ptr(b), ptr(dfeat), dfeat.stride(0), ptr(dw), ptr(db),
              pr_mat.shape[0], w.shape[0], stream_ptr())
         return None, dw, db
 
@@ -1214,6 +1221,7 @@ def notes_packs(w_ih, w_hh, Ht):
 
 _HEADS_PACKS = PackCache()
 HEADS_FUSED = os.environ.get('PTV_HEADS_FUSED', '1') != '0'
+HEADS_WGRAD_FUSED = os.environ.get('PTV_HEADS_WGRAD_FUSED', '1') != '0'
 
 
 def heads_ok(prec, Hn, NP, Hd, hn16, hd16):
@@ -1541,27 +1549,47 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     rowk_bwd = bool(st.get('gates_n_rowk') and notes_persist_ok(prec, Hn, E, st['gates_n'].dtype) and dNSUM.dtype == BF16 and HN.dtype == F32)
     fused_heads = (heads_ok(prec, Hn, NP, Hd, st.get('HN16'), st.get('HD16')) and dNSUM.dtype == BF16 and dP.stride(0) % 4 == 0
                    and dP.data_ptr() % 16 == 0 and dHD0.dtype == F32 and dHD0.is_contiguous())
+    dY16 = None
     if fused_heads:
         # dP += dHD0 . W_dh[:, Hn:] and dNSUM = dP . W_p + dHD0 . W_dh[:, :Hn] in one pass over dP / dHD0 (csrc/heads.hip)
         hp = heads_packs(P['pitch_out_linear.weight'], P['dur_hid_linear.weight'])
-        call('ptv_heads_bwd', ptr(dP), dP.stride(0), ptr(dHD0), ptr(hp['wdpT']), ptr(hp['wcat']), ptr(dNSUM), int(rowk_bwd),
+        dY16 = _empty(M, 200, dev=dev, dtype=BF16) if HEADS_WGRAD_FUSED else None
+        call('ptv_heads_bwd', ptr(dP), dP.stride(0), ptr(dHD0), ptr(hp['wdpT']), ptr(hp['wcat']), ptr(dNSUM), int(rowk_bwd), ptr(dY16),
              ptr(top_h), R if top_h is not None else 0, M, stream_ptr())
     else:
         gemm_dx(dHD0, w_dh, slice(Hn, None), out=dP, acc=True, prec=prec, m_top=top_h, m_unit=R)         # dP complete
 
     def head_wgrads():
+        if fused_heads and dY16 is not None:
+            # [dP | dHD0]^T . note summaries as ONE product (the summaries are read once, the gradients as bf16), then four tiny scatters
+            tmp, cs = _empty(200, Hn, dev=dev), _zeros(200, dev=dev)
+            _chain_prio()
+            call('ptv_wgrad', 200, Hn, M, ptr(dY16), 200, ptr(NSUM_op), _ld(NSUM_op), ptr(tmp), Hn, 1.0, 0, 3, 0, ptr(cs), ptr(top_h),
+                 R if top_h is not None else 0, 0, stream_ptr())
+            for name, bname, lo, hi, sub in (('pitch_out_linear.weight', 'pitch_out_linear.bias', 0, NP, None),
+                                             ('dur_hid_linear.weight', 'dur_hid_linear.bias', 136, 136 + Hd, slice(0, Hn))):
+                if G[name] is None:
+                    G[name] = _gbuf(P[name])
+                if G[bname] is None:
+                    G[bname] = _gbuf(P[bname])
+                copy2d(G[name] if sub is None else G[name][:, sub], tmp[lo:hi], acc=True)
+                copy2d(G[bname].view(1, -1), cs[lo:hi].view(1, -1), acc=True)
+            # (from the fp32 dHD0, whose dead rows are real zeros: N = 130 sends the last <= 32 rows through the guarded tail launch, which
+            # knows no row limit -- the dead rows of dY16 are never written)
+            wgrad_b('dur_hid_linear.weight', None, dHD0, st['pitch'], slice(Hn, None), top_h)
+            return
         wgrad_b('dur_hid_linear.weight', 'dur_hid_linear.bias', dHD0, NSUM_op, slice(0, Hn), top_h)
         wgrad_b('dur_hid_linear.weight', None, dHD0, st['pitch'], slice(Hn, None), top_h)
         wgrad_b('pitch_out_linear.weight', 'pitch_out_linear.bias', dP, NSUM_op, None, top_h)
     # (forked as soon as its operands exist: a sibling stream waits for everything its parent has QUEUED, so the products the chain
     # queues next would be a false dependency)
     if FORK_EARLY:
-        side(head_wgrads, dHD0, dP)
+        side(head_wgrads, dHD0, dP, dY16)
     if not fused_heads:
         gemm_dx(dHD0, w_dh, slice(0, Hn), out=dNSUM, prec=prec, m_top=top_h, m_unit=R, out_blocked=rowk_bwd)                   # [M, Hn]
         gemm_dx(dP, w_p, out=dNSUM, acc=True, prec=prec, m_top=top_h, m_unit=R, out_blocked=rowk_bwd)
     if not FORK_EARLY:
-        side(head_wgrads, dHD0, dP)
+        side(head_wgrads, dHD0, dP, dY16)
 
     mark('dec_bwd:head_dx')
     # ---- notes GRU (15 steps, batch 32*B) ----

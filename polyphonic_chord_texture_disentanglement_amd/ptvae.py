@@ -151,8 +151,7 @@ class TextureEncoder(nn.Module, _PrecMixin):
         _require_cuda(pr, 'TextureEncoder')
         bs = pr.size(0)
         conv = self.cnn[0]
-        pooled = F_.TextureFrontFn.apply(pr.float(), conv.weight, conv.bias)            # [B,C,8,29]
-        feat = pooled.view(bs * 8, -1)                                 # the reference's raw .view(bs, 8, -1)
+        feat = F_.TextureFrontFn.apply(pr.float(), conv.weight, conv.bias)              # [B*8, C*29]: the reference's raw .view(bs, 8, -1) of [B,C,8,29]
         feat = F_.LinearFn.apply(feat, self.fc1.weight, self.fc1.bias, self._prec)
         feat = F_.LinearFn.apply(feat, self.fc2.weight, self.fc2.bias, self._prec)
         x_sm = F_.Transpose01Fn.apply(feat.view(bs, 8, -1))

@@ -796,7 +796,12 @@ def test_fused_heads_kernels_vs_fp32_products_of_the_same_bf16_operands(M, top, 
     for blocked in (0, 1):
         dP = dP0.clone()
         dn = torch.full((M * 512,), 3.0, device=dev).to(bf)
-        call('ptv_heads_bwd', ptr(dP), 136, ptr(dhd), ptr(hp['wdpT']), ptr(hp['wcat']), ptr(dn), blocked, ptr(top_t), unit, M, stream_ptr())
+        dy = torch.full((M, 200), 9.0, device=dev).to(bf)
+        call('ptv_heads_bwd', ptr(dP), 136, ptr(dhd), ptr(hp['wdpT']), ptr(hp['wcat']), ptr(dn), blocked, ptr(dy), ptr(top_t), unit, M,
+             stream_ptr())
+        lv = ((live + 127) // 128) * 128                                  # (whole workgroups of dead rows write nothing)
+        assert torch.equal(dy[:live, :130], dP[:live, :130].to(bf)) and (dy[:min(lv, M), 130:136] == 0).all()
+        assert torch.equal(dy[:live, 136:], dhd[:live].to(bf))
         assert (dP[:, :130] - dp_ref).abs().max() < 2e-4 * max(1.0, dp_ref.abs().max().item())
         assert torch.equal(dP[:, 130:], dP0[:, 130:])
         got = dn.view(16, M, 32).permute(1, 0, 2).reshape(M, 512) if blocked else dn.view(M, 512)
