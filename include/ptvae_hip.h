@@ -413,6 +413,8 @@ int ptv_pack_mfma_b(const float* W, long ld, int N, int K, void* out, int pairs,
 /* the same for a TRANSPOSED source (trans != 0: element (n, k) at W[k*ld + n]) and / or into the k-block sub-range [kb0, kb0 + ceil(K/32)) of
  * a packed buffer holding NT tiles x KBtot k-blocks (two sources side by side along K; rows n >= N and columns k >= K are zero) */
 int ptv_pack_mfma_b2(const float* W, long ld, int N, int K, void* out, int pairs, int trans, int NT, int kb0, int KBtot, void* stream);
+/* up to 8 such packs in ONE launch: jobs = n rows of 10 longs {W, ld, N, K, out, pairs, trans, NT, kb0, KBtot} (host array) */
+int ptv_pack_mfma_multi(const long* jobs, int n, void* stream);
 int ptv_free_note_loop(const void* const* w, const void* const* io, long ld_pitch, int B, int t, unsigned coin_mask, int train,
                        void* stream);
 int ptv_free_resummarize(const void* const* w, const void* const* io, int B, int t, int train, void* stream);

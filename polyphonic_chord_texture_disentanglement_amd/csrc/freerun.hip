@@ -1009,6 +1009,50 @@ extern "C" int ptv_pack_mfma_b2(const float* W, long ld, int N, int K, void* out
   return PTV_OK;
 }
 
+// several packs in ONE launch (blockIdx.y = job): the per-step re-packs of a module's weights were 4-7 launches of a few microseconds each on
+// the critical path and ~100 us of host time
+struct PackJobs { const float* W[8]; long ld[8]; int N[8], K[8]; __bf16* out[8]; int pairs[8], trans[8], NT[8], kb0[8], KBtot[8]; };
+__global__ void pack_multi_kernel(PackJobs j) {
+  const int q = blockIdx.y;
+  const float* __restrict__ W = j.W[q];
+  const long ld = j.ld[q];
+  const int N = j.N[q], K = j.K[q], NT = j.NT[q], KB = (K + 31) / 32, pairs = j.pairs[q], trans = j.trans[q], kb0 = j.kb0[q], KBtot = j.KBtot[q];
+  __bf16* __restrict__ out = j.out[q];
+  const long total = (long)NT * KB * 64;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const long f = i >> 6;
+    const int kb = (int)(f % KB), nt = (int)(f / KB);
+    const int c = lane & 15;
+    const int n = pairs ? (nt >> 1) * 32 + (c >> 2) * 8 + (nt & 1) * 4 + (c & 3) : nt * 16 + c;
+    const int k0 = kb * 32 + (lane >> 4) * 8;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = (__bf16)((n < N && k0 + e < K) ? (trans ? W[(long)(k0 + e) * ld + n] : W[(long)n * ld + k0 + e]) : 0.f);
+    *reinterpret_cast<bf16x8*>(out + (((long)nt * KBtot + kb0 + kb) * 64 + lane) * 8) = v;
+  }
+}
+
+// jobs: n <= 8 rows of 10 longs {W, ld, N, K, out, pairs, trans, NT, kb0, KBtot} (ptv_pack_mfma_b2's arguments)
+extern "C" int ptv_pack_mfma_multi(const long* jobs, int n, void* stream) {
+  if (!jobs || n < 1 || n > 8) return PTV_ERR_ARG;
+  PackJobs j{};
+  long most = 0;
+  for (int q = 0; q < n; q++) {
+    const long* r = jobs + 10 * q;
+    j.W[q] = (const float*)r[0]; j.ld[q] = r[1]; j.N[q] = (int)r[2]; j.K[q] = (int)r[3]; j.out[q] = (__bf16*)r[4];
+    j.pairs[q] = (int)r[5]; j.trans[q] = (int)r[6]; j.NT[q] = (int)r[7]; j.kb0[q] = (int)r[8]; j.KBtot[q] = (int)r[9];
+    if (!j.W[q] || !j.out[q] || j.N[q] <= 0 || j.K[q] <= 0 || j.NT[q] * 16 < j.N[q] || (j.pairs[q] && (j.NT[q] & 1)) || j.kb0[q] < 0 ||
+        j.kb0[q] + (j.K[q] + 31) / 32 > j.KBtot[q] || (j.trans[q] ? j.ld[q] < j.N[q] : j.ld[q] < j.K[q])) return PTV_ERR_ARG;
+    const long t = (long)j.NT[q] * ((j.K[q] + 31) / 32) * 64;
+    if (t > most) most = t;
+  }
+  long nb = (most + 255) / 256; if (nb > 512) nb = 512;
+  hipLaunchKernelGGL(pack_multi_kernel, dim3((int)nb, n), dim3(256), 0, (hipStream_t)stream, j);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
 extern "C" int ptv_pack_mfma_b(const float* W, long ld, int N, int K, void* out, int pairs, void* stream) {
   if (!W || !out || N <= 0 || K <= 0 || ld < K || (pairs && (N & 31))) return PTV_ERR_ARG;
   const int NT = (N + 15) / 16, KB = (K + 31) / 32;

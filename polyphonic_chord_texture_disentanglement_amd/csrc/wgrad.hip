@@ -502,11 +502,14 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
     }
     sent[guard ? 1 : 0] = g;
     const dim3 grid((unsigned)(tiles * ns));
+    // experiment knob (PTV_WGRAD_LDS_PAD bytes of unused dynamic LDS per block): fewer co-resident product blocks per CU next to the
+    // latency chains
+    static const int lds_pad = getenv("PTV_WGRAD_LDS_PAD") ? atoi(getenv("PTV_WGRAD_LDS_PAD")) : 0;
 #define WG_LAUNCH(AF, BF)                                                                                      \
     do {                                                                                                       \
-      if (guard) hipLaunchKernelGGL((wgrad_kernel<AF, BF, true, 2>), grid, dim3(256), 0, s, g);                \
-      else if (nset == 2) hipLaunchKernelGGL((wgrad_kernel<AF, BF, false, 2>), grid, dim3(256), 0, s, g);      \
-      else if constexpr (!(AF) && !(BF)) hipLaunchKernelGGL((wgrad_kernel<false, false, false, 4>), grid, dim3(256), 0, s, g); \
+      if (guard) hipLaunchKernelGGL((wgrad_kernel<AF, BF, true, 2>), grid, dim3(256), lds_pad, s, g);                \
+      else if (nset == 2) hipLaunchKernelGGL((wgrad_kernel<AF, BF, false, 2>), grid, dim3(256), lds_pad, s, g);      \
+      else if constexpr (!(AF) && !(BF)) hipLaunchKernelGGL((wgrad_kernel<false, false, false, 4>), grid, dim3(256), lds_pad, s, g); \
     } while (0)
     if (af && bf) WG_LAUNCH(true, true);
     else if (af) WG_LAUNCH(true, false);

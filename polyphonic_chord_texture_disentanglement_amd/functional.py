@@ -16,6 +16,19 @@ import torch
 
 from ._lib import call, check, lib, prec_code, ptr, stream_ptr
 
+
+# torch.cuda.current_stream() costs ~10 us of python (device-index resolution, lazy-init checks) and the step asks ~60 times
+_get_cur = getattr(torch._C, '_cuda_getCurrentStream', None)
+_get_dev = getattr(torch._C, '_cuda_getDevice', None)
+_set_stream = getattr(torch._C, '_cuda_setStream', None)
+
+
+def cur_stream():
+    if _get_cur is None or _get_dev is None:
+        return torch.cuda.current_stream()
+    sid, di, dt = _get_cur(_get_dev())
+    return torch.cuda.Stream(stream_id=sid, device_index=di, device_type=dt)
+
 F32 = torch.float32
 BF16 = torch.bfloat16
 FUSED_DUR = True            # bf16 precision, H = 64: the 5-step duration GRU runs as one kernel (csrc/dur.hip)
@@ -73,7 +86,7 @@ def wait_stream(waiter, waited):
 
 def record_event(stream=None):
     ev = torch.cuda.Event()
-    stream = stream if stream is not None else torch.cuda.current_stream()
+    stream = stream if stream is not None else cur_stream()
     ev.record(stream)
     ev.ptv_gen = _CAPTURE_GEN[0] if WHOLE_STEP_CAPTURE else -1
     ev.ptv_stream = stream
@@ -95,7 +108,7 @@ def wait_event(stream, ev):
 def join_captured_streams():
     """end of a whole-step capture: every sibling stream that was forked into the capture joins the capturing stream (a fork left
     open -- e.g. side work whose consumer did not run in this step -- would fail the capture)"""
-    cur = torch.cuda.current_stream()
+    cur = cur_stream()
     for s in list(_CHILD_STREAMS.values()):
         if s != cur and stream_is_capturing(s):
             cur.wait_stream(s)
@@ -114,7 +127,7 @@ class whole_step_capture:
 
     def origin(self):
         """call first thing inside torch.cuda.graph(): the current stream is the capture's origin"""
-        _ORIGIN[0] = torch.cuda.current_stream()
+        _ORIGIN[0] = cur_stream()
 
     def __exit__(self, *exc):
         global WHOLE_STEP_CAPTURE
@@ -354,7 +367,7 @@ class _PersistTurn:
     """with _PersistTurn(): <one persistent launch on the current stream>"""
 
     def __enter__(self):
-        self.cur = torch.cuda.current_stream()
+        self.cur = cur_stream()
         ev = _PERSIST_LAST.get(self.cur.device.index)
         if ev is not None:
             wait_event(self.cur, ev)
@@ -574,7 +587,7 @@ class Side:
     instead of adopting them.)"""
 
     def __init__(self, slot=0):
-        self.main = torch.cuda.current_stream()
+        self.main = cur_stream()
         # The sibling streams are folded onto a pool of 4 (slot mod 4): the HIP runtime multiplexes all streams of a process onto 4
         # hardware queues anyway (GPU_MAX_HW_QUEUES; with 5 or more the step gets 40 % SLOWER), and which of ~10 private streams
         # end up sharing a queue -- i.e. silently serialise -- is then decided by creation order.  With the pool the sharing is
@@ -605,8 +618,16 @@ class Side:
         self.keep.extend(keep)
         _SIDE_DEPTH[0] += 1
         try:
-            with torch.cuda.stream(self.s):
-                r = fn()
+            # (torch.cuda.stream() is ~15 us of python per use; the parent stream is known)
+            if _set_stream is not None:
+                _set_stream(stream_id=self.s.stream_id, device_index=self.s.device_index, device_type=self.s.device_type)
+                try:
+                    r = fn()
+                finally:
+                    _set_stream(stream_id=self.main.stream_id, device_index=self.main.device_index, device_type=self.main.device_type)
+            else:
+                with torch.cuda.stream(self.s):
+                    r = fn()
         finally:
             _SIDE_DEPTH[0] -= 1
         # What fn returns was allocated under the sibling stream and will be read on the parent after join(): tell the caching
@@ -649,13 +670,13 @@ TRACE = None          # set to a list by scripts/trace_marks.py: (name, event on
 def mark(name):
     if TRACE is not None:
         e = torch.cuda.Event(enable_timing=True)
-        e.record(torch.cuda.current_stream())
+        e.record(cur_stream())
         TRACE.append((name, e, time.perf_counter()))
 
 
 def _join_deferred():
     mark('deferred:join_start')
-    cur = torch.cuda.current_stream()
+    cur = cur_stream()
     for s, _keep in _DEFERRED:
         wait_stream(cur, s)
     _DEFERRED.clear()
@@ -851,7 +872,7 @@ class EmbedFn(torch.autograd.Function):
         B, E = x.shape[0], w.shape[0]
         demb2 = demb.contiguous().view(B * 512, E)
         if ctx.mh is not None:
-            wait_event(torch.cuda.current_stream(), ctx.mh_side)
+            wait_event(cur_stream(), ctx.mh_side)
             mh, ctx.mh, ctx.mh_side = ctx.mh, None, None
             dw, db = wgrad_bias(demb2, mh[:, :135], _gbuf(w), _gbuf(b), ctx.prec)      # bias gradient inside the same pass over dy
             return None, dw, db, None
@@ -1199,6 +1220,12 @@ def pack_mfma_b(w2d, K=None, pairs=False):
     return out
 
 
+def pack_multi(jobs):
+    """jobs: tuples (src_ptr, ld, N, K, out_ptr, pairs, trans, NT, kb0, KBtot) -- ptv_pack_mfma_b2's arguments -- in one launch"""
+    flat = (ctypes.c_long * (10 * len(jobs)))(*[int(v) for j in jobs for v in j])
+    check(lib().ptv_pack_mfma_multi(flat, len(jobs), stream_ptr()), 'ptv_pack_mfma_multi')
+
+
 def param_stamp(params):
     """changes whenever one of `params` may have changed: in-place version counters + the fused optimiser's step count"""
     from .optim import _SHADOW_OF
@@ -1213,9 +1240,17 @@ def notes_packs(w_ih, w_hh, Ht):
     hit = _NOTES_PACKS.get([w_ih, w_hh], stamp)
     if hit is not None:
         return hit
-    wT = torch.empty(w_hh.shape[1], w_hh.shape[0], device=w_hh.device, dtype=F32)
-    call('ptv_transpose01', ptr(wT), ptr(w_hh), w_hh.shape[0], w_hh.shape[1], 1, stream_ptr())
-    pk = dict(wg_h=pack_mfma_b(w_hh, pairs=True), wg_t=pack_mfma_b(w_ih[:, Ht:], pairs=True), wt=pack_mfma_b(wT, pairs=True))
+    dev = w_hh.device
+    H3, H = w_hh.shape
+    w_x = w_ih[:, Ht:]
+    E = w_x.shape[1]
+    size = lambda N, K: lib().ptv_pack_mfma_b_size(N, K)
+    pk = dict(wg_h=torch.empty(size(H3, H), device=dev, dtype=BF16), wg_t=torch.empty(size(H3, E), device=dev, dtype=BF16),
+              wt=torch.empty(size(H, H3), device=dev, dtype=BF16))
+    # (W_hh^T is packed straight from W_hh with transposed reads: no staging transpose; one launch for the three)
+    pack_multi([(w_hh.data_ptr(), w_hh.stride(0), H3, H, pk['wg_h'].data_ptr(), 1, 0, H3 // 16, 0, (H + 31) // 32),
+                (w_x.data_ptr(), w_x.stride(0), H3, E, pk['wg_t'].data_ptr(), 1, 0, H3 // 16, 0, (E + 31) // 32),
+                (w_hh.data_ptr(), w_hh.stride(0), H, H3, pk['wt'].data_ptr(), 1, 1, H // 16, 0, (H3 + 31) // 32)])
     return _NOTES_PACKS.put([w_ih, w_hh], stamp, pk)
 
 
@@ -1237,17 +1272,22 @@ def heads_packs(w_p, w_dh):
         return hit
     Hn, NP, Hd = w_p.shape[1], w_p.shape[0], w_dh.shape[0]
     dev = w_p.device
-
-    def pk2(src, N, K, NT, KBtot, kb0=0, pairs=False, trans=False, out=None):
-        out = torch.empty(NT * KBtot * 512, device=dev, dtype=BF16) if out is None else out
-        call('ptv_pack_mfma_b2', ptr(src), src.stride(0), N, K, ptr(out), int(pairs), int(trans), NT, kb0, KBtot, stream_ptr())
-        return out
     # wcat: B operand of dNSUM = [dP' (130 -> 160) | dHD0 (64)] . [W_p ; W_dh[:, :Hn]] -- rows = the 512 units, k-blocks 0-4 from W_p^T
-    # (its rows beyond 130 zero), 5-6 from W_dh[:, :Hn]^T; straight from the fp32 masters (transposed reads), no staging tensors
-    wcat = pk2(w_p, Hn, NP, Hn // 16, 7, 0, pairs=True, trans=True)
-    pk2(w_dh, Hn, Hd, Hn // 16, 7, 5, pairs=True, trans=True, out=wcat)
-    pk = dict(wp=pk2(w_p, NP, Hn, 9, Hn // 32), wdh=pk2(w_dh, Hd, Hn, Hd // 16, Hn // 32), wdp=pk2(w_dh[:, Hn:], Hd, NP, Hd // 16, 5),
-              wdpT=pk2(w_dh[:, Hn:], NP, Hd, 9, Hd // 32, trans=True), wcat=wcat)
+    # (its rows beyond 130 zero), 5-6 from W_dh[:, :Hn]^T; straight from the fp32 masters (transposed reads), ONE launch for all six packs
+    jobs, pk = [], {}
+
+    def job(key, src, N, K, NT, KBtot, kb0=0, pairs=False, trans=False):
+        if key not in pk:
+            pk[key] = torch.empty(NT * KBtot * 512, device=dev, dtype=BF16)
+        jobs.append((src.data_ptr(), src.stride(0), N, K, pk[key].data_ptr(), int(pairs), int(trans), NT, kb0, KBtot))
+    w_dp = w_dh[:, Hn:]
+    job('wcat', w_p, Hn, NP, Hn // 16, 7, 0, True, True)
+    job('wcat', w_dh, Hn, Hd, Hn // 16, 7, 5, True, True)
+    job('wp', w_p, NP, Hn, 9, Hn // 32)
+    job('wdh', w_dh, Hd, Hn, Hd // 16, Hn // 32)
+    job('wdp', w_dp, Hd, NP, Hd // 16, 5)
+    job('wdpT', w_dp, NP, Hd, 9, Hd // 32, trans=True)
+    pack_multi(jobs)
     return _HEADS_PACKS.put([w_p, w_dh], stamp, pk)
 
 

@@ -111,8 +111,14 @@ def weight_shadow_t(p):
         return None
     opt.refresh_if_param_stale(p)
     if opt._t_event is not None:
+        # (once per stream and refresh: a stream that has waited orders everything it runs afterwards -- this was 25 event waits and
+        # current-stream lookups per step)
         from . import functional as F_
-        F_.wait_event(torch.cuda.current_stream(), opt._t_event)
+        sid = F_.stream_ptr()
+        if sid not in opt._t_waited:
+            F_.wait_event(F_.cur_stream(), opt._t_event)
+            if not F_.WHOLE_STEP_CAPTURE:
+                opt._t_waited.add(sid)
     return opt.flat_pT16[off:off + p.numel()].view(p.shape[1], p.shape[0])
 
 
@@ -184,6 +190,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         self._shadow_stamp = None
         self._fast_key, self._pver = None, {}
         self._t_event = None            # recorded after the last transposed-shadow refresh when that ran on a sibling stream
+        self._t_waited = set()          # raw streams that already wait for it
         self._plain_stamp = None        # stamp at which flat_p16 (the untransposed bf16 copy) was last written
         self.grad_scale = 1.0           # set to 1/world_size when the bucket holds a SUM over ranks
         self.refresh_shadow()
@@ -229,12 +236,14 @@ class FusedClipAdam(torch.optim.Optimizer):
                      self._tdesc[1], stream_ptr())
             from . import functional as F_
             self._t_event = None
+            self._t_waited = set()
             if SHADOW_T_ASYNC and F_.OVERLAP and not F_.capturing_part():
                 # only the backward pass reads the transposed copies (dX products, BPTT): refresh them on a sibling stream, off the
                 # head of the step; weight_shadow_t() makes its caller's stream wait for the event
                 side = F_.Side(7)
                 side(transposes)
                 self._t_event = F_.record_event(side.s)
+                self._t_waited = set()
             else:
                 transposes()
         for p, buf in self._row_padded.values():

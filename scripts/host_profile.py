@@ -34,10 +34,13 @@ for _ in range(3):
     step()
 torch.cuda.synchronize()
 pr_ = cProfile.Profile()
-pr_.enable()
-for _ in range(K):
-    step()
-pr_.disable()
+# (the backward pass runs on the autograd engine's worker thread, which cProfile does not see: keep it on this thread)
+with torch.autograd.set_multithreading_enabled(False):
+    pr_.enable()
+    for _ in range(K):
+        step()
+    pr_.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr_)
-st.sort_stats('tottime').print_stats(28)
+st.sort_stats('tottime').print_stats(34)
+st.sort_stats('cumtime').print_stats(40)
