@@ -483,6 +483,11 @@ int ptv_clip_adam_step(float* p, const float* g, float* m, float* v, long n, con
 /* the same step that also writes the bf16 operand copy p16[i] = bf16(p[i]) of the updated parameters (p16 may be NULL) */
 int ptv_clip_adam_step_shadow(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float gscale, float clip,
                               float lr, float beta1, float beta2, float eps, int step, void* p16, void* stream);
+/* SURVEY 8b's gradnorm_clip_adam_step: torch.nn.utils.clip_grad_norm_(params, clip) + Adam.step() (module.py:142-144, train.py:50) over
+ * the flat buffers in ONE call -- sumsq[0] = sum g^2 (left on the device: the pre-clip norm is sqrt(sumsq) * gscale), then the clipped
+ * update of ptv_clip_adam_step_shadow.  gscale: 1/world under data parallelism (the bucket holds a SUM over ranks). */
+int ptv_gradnorm_clip_adam_step(float* p, const float* g, float* m, float* v, long n, float* sumsq, float gscale, float clip,
+                                float lr, float beta1, float beta2, float eps, int step, void* p16, void* stream);
 
 /* Reproducible reductions (default ON; environment PTV_WGRAD_ORDERED=0 or ptv_ordered_reductions(0) turn them off).  The
  * reference's CPU path is run-to-run deterministic.  With the switch on, nothing on the train step ends in an fp32

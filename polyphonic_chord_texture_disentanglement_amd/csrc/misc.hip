@@ -272,6 +272,14 @@ extern "C" int ptv_clip_adam_step_shadow(float* p, const float* g, float* m, flo
   return PTV_OK;
 }
 
+// clip_grad_norm_(parameters, clip) + Adam.step() of the reference's loop body (module.py:142-144, train.py:50) as ONE entry point: the
+// gradient's sum of squares and the update that reads it, back to back on `stream` (gradnorm_clip_adam_step)
+extern "C" int ptv_gradnorm_clip_adam_step(float* p, const float* g, float* m, float* v, long n, float* sumsq, float gscale, float clip,
+                                           float lr, float beta1, float beta2, float eps, int step, void* p16, void* stream) {
+  PTV_TRY(ptv_grad_sumsq(g, n, sumsq, stream));
+  return ptv_clip_adam_step_shadow(p, g, m, v, n, sumsq, gscale, clip, lr, beta1, beta2, eps, step, p16, stream);
+}
+
 extern "C" int ptv_clip_adam_step(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float gscale, float clip,
                                   float lr, float beta1, float beta2, float eps, int step, void* stream) {
   return ptv_clip_adam_step_shadow(p, g, m, v, n, sumsq, gscale, clip, lr, beta1, beta2, eps, step, nullptr, stream);

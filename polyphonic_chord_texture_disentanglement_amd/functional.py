@@ -722,6 +722,7 @@ EMBED_MH_FWD = os.environ.get('PTV_EMBED_MH_FWD', '1') != '0'    # multi-hot ope
 # deferred weight-gradient products (Side(3)): the reversed directions of the note-summary and encoder BPTTs queue behind them.  Moving
 # them to another pool stream measured SLOWER (slot 8 / 6 / 5: 9.40 / 9.39 / 9.29 vs 9.09 ms): running everything at once costs more
 # in contention than the queueing does.
+DEC_SIDE2 = int(os.environ.get('PTV_DEC_SIDE2', '-1'))
 BIGRU_SLOT = int(os.environ.get('PTV_BIGRU_SLOT', '7'))
 BIGRU_SLOT_BWD = int(os.environ.get('PTV_BIGRU_SLOT_BWD', '7'))
 FORK_EARLY = os.environ.get('PTV_FORK_EARLY', '0') != '0'
@@ -1475,12 +1476,16 @@ class DecoderTFFn(torch.autograd.Function):
         # node's stream without a dependency on the side stream
         from .optim import is_arena_view
         if all(G[n] is None or (P[n].grad is None and is_arena_view(P[n], G[n])) for n in DEC_PARAM_NAMES):
-            side_stream = side.s
+            streams = (side.s,) + tuple(s2.s for s2 in side.extra)
             side.defer()
+            for s2 in side.extra:
+                s2.defer()
             if GRAD_READY_HOOK is not None:               # data parallel: this slice of the gradient bucket can leave now (dist.GradSync)
-                GRAD_READY_HOOK([P[n] for n in DEC_PARAM_NAMES if G[n] is not None], (side_stream,))
+                GRAD_READY_HOOK([P[n] for n in DEC_PARAM_NAMES if G[n] is not None], streams)
         else:
             side.join()
+            for s2 in side.extra:
+                s2.join()
         B, He = st['B'], st['He']
         demb_out = demb.view(16, 32, B, E)
         if ctx.emb_link is not None and ctx.needs_input_grad[2] and demb.dtype == F32 and demb.is_contiguous():
@@ -1712,10 +1717,16 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
         bgrad('z2dec_hid_linear.bias', dzhid)
         wgrad('z2dec_in_linear.weight', dz_in, z)
         bgrad('z2dec_in_linear.bias', dz_in)
-    side(time_wgrads, dgi_t, dgh_t, dZG, dTOKS, dzhid, dz_in, dNS)
+    # the last products of the node may go to a SECOND deferred sibling stream (PTV_DEC_SIDE2 = slot, -1 = off): the first one is the
+    # stream that finishes last in the step (the deferred join), while the other pool streams idle between the encoders' chains
+    side2 = Side(DEC_SIDE2) if DEC_SIDE2 >= 0 else side
+    side2(time_wgrads, dgi_t, dgh_t, dZG, dTOKS, dzhid, dz_in, dNS)
     # the caller defers the join to the end of the backward pass; the node's saved forward state (released when the node returns)
     # is still being read by the products queued above
     side.keep.extend((st, z, tok_op))
+    side.extra = [side2] if side2 is not side else []
+    if side.extra:
+        side2.keep.extend((st, z, tok_op))
     return dz, dtok, dTOKS, G, side
 
 

@@ -437,6 +437,8 @@ class DecoderStepFn(torch.autograd.Function):
         bgrad('note_embedding.bias', dPRED.view(16 * R, E))
 
         side.join()
+        for s2 in getattr(side, 'extra', []):
+            s2.join()
         grads = tuple(G[n] for n in FREE_PARAM_NAMES)
         return (dz, demb.view(16, 32, B, E), dxs.view(R, 2 * He) if st['has_xs'] else None, None, None, None, None) + grads
 

@@ -295,10 +295,10 @@ class FusedClipAdam(torch.optim.Optimizer):
         from . import functional as F_
         F_.mark('opt:start')
         st = stream_ptr()
-        call('ptv_grad_sumsq', ptr(a.flat), a.total, ptr(self.sumsq), st)
-        # the kernel also writes the bf16 operand copy of the updated parameters (one more 55-MB stream in a 760-MB pass) -- the next
-        # forward then only re-transposes the matrices instead of re-reading all 109 MB first
-        call('ptv_clip_adam_step_shadow', ptr(self.flat_p), ptr(a.flat), ptr(self.exp_avg), ptr(self.exp_avg_sq), a.total,
+        # one library call: global gradient norm + clipped Adam update (gradnorm_clip_adam_step).  The kernel also writes the
+        # bf16 operand copy of the updated parameters (one more 55-MB stream in a 760-MB pass) -- the next forward then only
+        # re-transposes the matrices instead of re-reading all 109 MB first
+        call('ptv_gradnorm_clip_adam_step', ptr(self.flat_p), ptr(a.flat), ptr(self.exp_avg), ptr(self.exp_avg_sq), a.total,
              ptr(self.sumsq), float(self.grad_scale), float(clip if clip is not None else 0.0), float(g['lr']),
              float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), self.step_count, ptr(self.flat_p16) if ADAM_SHADOW else None, st)
         if ADAM_SHADOW:
