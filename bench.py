@@ -277,7 +277,7 @@ def _roofline(lib, B, model, args):
     pmc = {}
     # HBM traffic of these launches from the PMC counters (separate rocprofv3 --pmc passes over this same command, scripts/gpu_pmc.sh,
     # corrected as MI355X_MICROARCH.md prescribes): read from the committed file, stamped with the commit it was taken at
-    pmc_path = os.path.join(ROOT, 'profiles', 'r03_row_gru_pmc.json')
+    pmc_path = os.path.join(ROOT, 'profiles', 'r04_row_gru_pmc.json')
     if B == 512 and args.precision == 'bf16' and os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
     out = []
@@ -295,7 +295,7 @@ def _roofline(lib, B, model, args):
         k = pmc.get(name, {})
         out.append({'bound': 'hbm', 'kernel': '%s (dec_notes_gru, R=%d rows x T=%d steps in one launch)' % (name, R, T),
                     'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
-                    'traffic': k.get('hbm_bytes_per_launch'), 'traffic_source': ('profiles/r03_row_gru_pmc.json @ %s' % pmc.get('_commit')) if k else None,
+                    'traffic': k.get('hbm_bytes_per_launch'), 'traffic_source': ('profiles/r04_row_gru_pmc.json @ %s' % pmc.get('_commit')) if k else None,
                     'algorithmic_bytes': nbytes, 'launches': cnt.value,
                     'avg_us': round(avg_s * 1e6, 1), 'total_ms': round(ms.value, 2),
                     'mfma': {'achieved': round(tfs, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(tfs / 2500.0, 4),

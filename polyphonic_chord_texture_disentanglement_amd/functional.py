@@ -505,7 +505,7 @@ def _hall16(prec, T1, M, H, dev):
     return _empty(T1, M, H, dev=dev, dtype=BF16) if _act_dtype(prec, H) == BF16 else None
 
 
-def gru_bwd(prec, hall, gates, w_hh, *, dh_ext=None, dh_last=None, lr=None, reverse=False, need_dh0=True):
+def gru_bwd(prec, hall, gates, w_hh, *, dh_ext=None, dh_last=None, lr=None, reverse=False, need_dh0=True, allow_persist=True):
     """-> dgi [T,M,3H] (time order), dgh [T,M,3H] (processing order), dh0 [M,H] or None"""
     T1, M, H = hall.shape
     T = T1 - 1
@@ -520,7 +520,7 @@ def gru_bwd(prec, hall, gates, w_hh, *, dh_ext=None, dh_last=None, lr=None, reve
     lra = (ptr(lr[0]), lr[1], lr[2], lr[3], ptr(lr[4])) if lr is not None else (None, 0, 0, 0, None)
     if dt == BF16:
         wt = _WT(w_hh, prec)                  # W_hh^T [H,3H] bf16: K-contiguous weight tiles for the BPTT products
-        if (wt is not None and lr is None and T >= 2 and gates.dtype == BF16 and persist_supported(1, M, H, T)
+        if (allow_persist and wt is not None and lr is None and T >= 2 and gates.dtype == BF16 and persist_supported(1, M, H, T)
                 and (dh_ext is None or dh_ext.stride(2) == 1)):
             gru_persist_bwd(M, H, T, [dict(hall=hall, gates=gates, wt16=wt, dh_ext=dh_ext, dh_last=dh_last, dgi=dgi, dgh=dgh,
                                            dh0=dh0, reverse=reverse)])
@@ -723,6 +723,7 @@ EMBED_MH_FWD = os.environ.get('PTV_EMBED_MH_FWD', '1') != '0'    # multi-hot ope
 # them to another pool stream measured SLOWER (slot 8 / 6 / 5: 9.40 / 9.39 / 9.29 vs 9.09 ms): running everything at once costs more
 # in contention than the queueing does.
 DEC_SIDE2 = int(os.environ.get('PTV_DEC_SIDE2', '-1'))
+CHD_BWD_PERSIST = os.environ.get('PTV_CHD_BWD_PERSIST', '1') != '0'      # (0 measured slower: 8.83 vs 8.54-8.66 ms)
 BIGRU_SLOT = int(os.environ.get('PTV_BIGRU_SLOT', '7'))
 BIGRU_SLOT_BWD = int(os.environ.get('PTV_BIGRU_SLOT_BWD', '7'))
 FORK_EARLY = os.environ.get('PTV_FORK_EARLY', '0') != '0'
@@ -1076,13 +1077,13 @@ class BiGruFinalFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x3, *w = ctx.saved_tensors
-        mark('bigru_bwd:start M=%d' % x3.shape[1])
+        mark('bigru_bwd:start M=%d @%x' % (x3.shape[1], stream_ptr() & 0xffff))
         dx_acc = None
         if ctx.link is not None and ctx.link['demb'] is not None and ctx.needs_input_grad[0]:
             dx_acc, ctx.link['demb'] = ctx.link['demb'].view(-1, x3.shape[2]), None     # the decoder node's gradient of the same tensor
             _EMB_LINK.pop(x3.data_ptr(), None)
         grads, dx = _bigru_backward(ctx.prec, x3, w, ctx.saved_state, dout.contiguous(), ctx.needs_input_grad[0], dx_acc)
-        mark('bigru_bwd:end M=%d' % x3.shape[1])
+        mark('bigru_bwd:end M=%d @%x' % (x3.shape[1], stream_ptr() & 0xffff))
         ctx.saved_state = None
         if GRAD_READY_HOOK is not None:                   # data parallel: a bi-GRU's 8 gradients are final here (its side stream is joined)
             from .optim import is_arena_view
@@ -1108,6 +1109,7 @@ class EncoderHeadsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dmu, dsd):
         h, w_mu, w_var, mu, sd, b_mu, b_var = ctx.saved_tensors
+        mark('enc_heads_bwd:start @%x' % (stream_ptr() & 0xffff))
         prec = ctx.prec
         B, Z = mu.shape
         dev = h.device
@@ -1141,6 +1143,7 @@ class ReparamFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz):
+        mark('reparam_bwd:start @%x' % (stream_ptr() & 0xffff))
         mu, sd, eps = ctx.saved_tensors
         B, Z = mu.shape
         dz = dz.contiguous()
@@ -1775,6 +1778,7 @@ class ChordDecoderTFFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, droot, dchroma, dbass):
         z, *params = ctx.saved_tensors
+        mark('chd_dec_bwd:start')
         P = dict(zip(CHD_PARAM_NAMES, params))
         st = ctx.st
         ctx.st = None
@@ -1799,7 +1803,9 @@ class ChordDecoderTFFn(torch.autograd.Function):
         if dhs is None:
             dhs = _zeros(T * B, H, dev=dev)
         w_hh, w_ih = P['gru.weight_hh_l0'], P['gru.weight_ih_l0']
-        dgi, dgh, dh0 = gru_bwd(prec, hall, st['gates'], w_hh, dh_ext=dhs.view(T, B, H))
+        # (per-step kernels, not the persistent launch: persistent launches take turns, and this short chain on its sibling stream had
+        # to wait for the decoder's 32-step time BPTT -- its dz then reached the chord encoder 0.3 ms after the decoder's own, round 4)
+        dgi, dgh, dh0 = gru_bwd(prec, hall, st['gates'], w_hh, dh_ext=dhs.view(T, B, H), allow_persist=CHD_BWD_PERSIST)
         G['gru.weight_hh_l0'] = gemm(dgh.view(T * B, 3 * H), hall[:T].view(T * B, H), _gbuf(w_hh), ta=True, tb=True, acc=True,
                                      prec=prec)
         G['gru.bias_hh_l0'] = _bgrad(P['gru.bias_hh_l0'], dgh.view(T * B, 3 * H))
@@ -1819,6 +1825,7 @@ class ChordDecoderTFFn(torch.autograd.Function):
         G['z2dec_hid.bias'] = _bgrad(P['z2dec_hid.bias'], dh0)
         G['z2dec_in.weight'] = gemm(dz_in, z, _gbuf(w_zi), ta=True, tb=True, acc=True, prec=prec)
         G['z2dec_in.bias'] = _bgrad(P['z2dec_in.bias'], dz_in)
+        mark('chd_dec_bwd:end')
         return (dz, None, None) + tuple(G[n] for n in CHD_PARAM_NAMES)
 
 

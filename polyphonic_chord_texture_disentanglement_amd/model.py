@@ -5,6 +5,8 @@ init_model :244-265): same constructor, `forward(mode, ...)` dispatch, `run` / `
 `loss_function` / `kl_loss` / `chord_loss` signatures and return tuples, same `state_dict` keys.
 All arithmetic runs in libptvae_hip.so kernels.
 """
+import os
+
 import torch
 
 from . import functional as F_
@@ -14,6 +16,11 @@ from .ptvae import HipNormal, PtvaeDecoder, RnnDecoder, RnnEncoder, TextureEncod
 
 LOSS_NAMES = ['loss', 'recon_loss', 'pl', 'dl', 'kl_loss', 'kl_chd', 'kl_rhy', 'chord_loss', 'root_loss',
               'chroma_loss', 'bass_loss']                       # train.py:54-55
+
+
+CHD_ENC_SLOT = int(os.environ.get('PTV_CHD_ENC_SLOT', '1'))
+EMB_FIRST = os.environ.get('PTV_EMB_FIRST', '0') != '0'
+EMB_SLOT = int(os.environ.get('PTV_EMB_SLOT', '4'))
 
 
 class DisentangleVAE(PytorchModel):
@@ -66,14 +73,28 @@ class DisentangleVAE(PytorchModel):
         # what its parent has queued so far, and the embedding (queued on the parent next) is not their input
         from .ptvae import _require_cuda
         _require_cuda(x, 'DisentangleVAE.run')               # (fails loudly off-GPU before any stream is touched)
-        s_chd, s_rhy = F_.Side(1), F_.Side(2)
+        s_chd, s_rhy = F_.Side(CHD_ENC_SLOT), F_.Side(2)
+        self.decoder.summaries_needed = tfr1 > 0             # with tfr1 = 0 no time step is fed a ground-truth note summary
+        s_emb = None
+        if EMB_FIRST and F_.OVERLAP:
+            # Round 4: the embedding / note-summary nodes are CREATED first (on a sibling stream, so that the gather still does not sit in
+            # front of the encoders' chains): autograd runs nodes in reverse creation order, so in the backward pass the encoders' BPTTs --
+            # the longer tail: two persistent launches, their products, fc2 / fc1, the conv -- now start right after the decoder node
+            # instead of queueing behind the note-summary BPTT
+            s_emb = F_.Side(EMB_SLOT)
+            try:
+                embedded_x, lengths = s_emb(lambda: self.decoder.emb_x(x), x)
+            finally:
+                self.decoder.summaries_needed = True
         dist_chd = s_chd(lambda: self.chd_encoder(c), c)
         dist_rhy = s_rhy(lambda: self.rhy_encoder(pr_mat), pr_mat)
-        self.decoder.summaries_needed = tfr1 > 0             # with tfr1 = 0 no time step is fed a ground-truth note summary
-        try:
-            embedded_x, lengths = self.decoder.emb_x(x)
-        finally:
-            self.decoder.summaries_needed = True
+        if s_emb is None:
+            try:
+                embedded_x, lengths = self.decoder.emb_x(x)
+            finally:
+                self.decoder.summaries_needed = True
+        else:
+            s_emb.join()
         F_.mark('run:emb_x')
         s_chd.join()
         s_rhy.join()
