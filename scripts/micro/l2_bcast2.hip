@@ -56,8 +56,9 @@ int main() {
   const long n16 = wbytes / 16, per = n16 / 64 / 4;
   const int U = 8;
   // per wave per pass: per / U groups; activations per group: (rd + wr) KB
-  for (int cfg = 0; cfg < 4; cfg++) {
-    const int rd = cfg == 0 ? 0 : 1, wr = cfg == 0 ? 0 : (cfg == 1 ? 1 : (cfg == 2 ? 2 : 3));
+  for (int cfg = 0; cfg < 7; cfg++) {
+    // cfg 4-6: stores only / loads only -- which of the two slow streams blocks the weight stream?
+    const int rd = cfg == 0 ? 0 : (cfg == 4 ? 0 : (cfg >= 5 ? cfg - 4 : 1)), wr = cfg == 0 ? 0 : (cfg <= 3 ? cfg : (cfg == 4 ? 2 : 0));
     const long groups = (per + U - 1) / U;
     const long act16_per_wave = groups * (rd + wr) * 64;
     const long act16_per_wg_pass = act16_per_wave * 4;
