@@ -211,6 +211,15 @@ int ptv_multihot(const long* x, float* out, long ld, int B, void* stream);
 int ptv_grid_lengths(const long* x, int* lengths, int B, void* stream);
 /* the same rows as bf16 (exact), ld >= 136 with column 135 zeroed: operand of the bf16-precision note_embedding weight gradient */
 int ptv_multihot_bf16(const long* x, void* out, long ld, int B, void* stream);
+/* The same three for ANY grid geometry the reference's constructors accept (ptvae.py:127-147 PtvaeEncoder, :220-241 PtvaeDecoder):
+ * S = num_step, N = max_simu_note, P = pitch_range = max_pitch - min_pitch + 3, D = dur_width (<= 8), pad = pitch_pad.
+ *   x [B,S,N,1+D] int64 -> emb step-major [N][S][B][E], lengths [S][B], multihot rows [N*S*B][P+D] (bf16 != 0: bf16 rows zero-filled to
+ *   the 8-column granule, ld >= that).  A pitch index outside [0, P) contributes no pitch column (the reference drops column P, the
+ *   <pad> column: ptvae.py:186,311).  train.py:32 constructs PtvaeEncoder(max_pitch=31): P = 34. */
+int ptv_embed_fwd_geom(const long* x, const float* W, const float* bias, float* emb, int* lengths, int B, int E,
+                       int S, int N, int P, int D, int pad, void* stream);
+int ptv_grid_lengths_geom(const long* x, int* lengths, int B, int S, int N, int D, int pad, void* stream);
+int ptv_multihot_geom(const long* x, void* out, long ld, int B, int S, int N, int P, int D, int bf16, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * TextureEncoder front end (ptvae.py:95-99,112-114): Conv2d(1,C,(4,12),stride(4,1)) + ReLU +

@@ -338,16 +338,23 @@ class Oracle:
 
 
 # ---- ptvae.py:125-215: PtvaeEncoder (params keyed like its state_dict) --------------------------
-def ptvae_encoder(p, x):
-    """x int64 [B,32,16,6] -> (mu, std, embedded [B,32,16,E], lengths [B,32])"""
+def ptvae_encoder(p, x, multihot=None, lengths=None, max_simu_note=MAX_SIMU_NOTE, num_step=32, pitch_range=PITCH_RANGE,
+                  pitch_pad=PITCH_PAD):
+    """x int64 [B,S,N,1+D] -> (mu, std, embedded [B,S,N,E], lengths [B,S]); any grid geometry the constructor accepts (:127-147).
+    With `multihot` / `lengths` given, this is encoder() itself (:190-206) on the caller's multi-hot grid."""
     o = Oracle.__new__(Oracle)
-    o.p = {'decoder.note_embedding.weight': p['note_embedding.weight'], 'decoder.note_embedding.bias': p['note_embedding.bias']}
-    o.p.update(p)
-    emb, lengths = o.emb_x(x)                                                 # :167-188 = the decoder's emb_x
-    B = x.shape[0]
+    o.p = dict(p)
+    S, N, P = num_step, max_simu_note, pitch_range
+    if multihot is None:
+        lengths = N - (x[..., 0] == pitch_pad).sum(dim=-1)                       # :167-172
+        onehot = torch.zeros(x.shape[:-1] + (P + 1,), dtype=torch.float32)       # :174-188
+        onehot.scatter_(-1, x[..., 0:1], 1.0)
+        multihot = torch.cat([onehot[..., :P], x[..., 1:].float()], dim=-1)
+    emb = linear(multihot, p['note_embedding.weight'], p['note_embedding.bias'])  # :191
+    B = multihot.shape[0]
     E = emb.shape[-1]
-    notes = o._bigru_final('enc_notes_gru', emb.reshape(B * 32, 16, E), lengths.reshape(-1))      # :193-198 packed by length
-    h = o._bigru_final('enc_time_gru', notes.reshape(B, 32, -1))                                    # :200-202
+    notes = o._bigru_final('enc_notes_gru', emb.reshape(B * S, N, E), lengths.reshape(-1))        # :193-198 packed by length
+    h = o._bigru_final('enc_time_gru', notes.reshape(B, S, -1))                                     # :200-202
     mu = linear(h, p['linear_mu.weight'], p['linear_mu.bias'])
     std = torch.exp(linear(h, p['linear_std.weight'], p['linear_std.bias']))                        # :204-205
     return mu, std, emb, lengths

@@ -164,34 +164,44 @@ __global__ void colsum_kernel(float* out, const void* __restrict__ A, long lda, 
 
 // ---------------------------------------------------------------------------------------------
 // note embedding as a gather (ptvae.py:299-313 builds a dense multi-hot and multiplies by the
-// 135 x E weight; one-hot . W is a column gather + 5 duration columns)
-//   x [B,32,16,6] int64 -> emb step-major [16][32][B][E], lengths [32][B] int32
+// (P+D) x E weight; one-hot . W is a column gather + D duration columns)
+//   x [B,S,N,1+D] int64 -> emb step-major [N][S][B][E], lengths [S][B] int32
+// Grid geometry (ptvae.py:127-147 / :220-241): S = num_step, N = max_simu_note, P = pitch_range, D = dur_width, pad = pitch_pad.
+// DEF = the 32 x 16 x (130+5) grid of init_model() with every bound a compile-time constant; the other instantiation takes them at
+// run time (train.py:32 builds PtvaeEncoder(max_pitch=31): P = 34).
 // ---------------------------------------------------------------------------------------------
+struct GridGeom { int S, N, P, D, pad; };
+constexpr int GEOM_DMAX = 8;
+
+template <bool DEF>
 __global__ void embed_fwd_kernel(const long* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
-                                 float* __restrict__ emb, int B, int E) {
+                                 float* __restrict__ emb, int B, int E, GridGeom g) {
   __builtin_amdgcn_s_setprio(3);                                         // always part of a latency chain
-  extern __shared__ __attribute__((aligned(16))) float wt[];     // [135][E] transposed weight
-  for (int i = threadIdx.x; i < 135 * E; i += blockDim.x) { int e = i / 135, p = i % 135; wt[p * E + e] = W[i]; }     // (coalesced reads; the transposing side is the LDS)
+  const int S = DEF ? 32 : g.S, N = DEF ? 16 : g.N, P = DEF ? 130 : g.P, D = DEF ? 5 : g.D;
+  constexpr int DM = DEF ? 5 : GEOM_DMAX;
+  const int C = P + D;
+  extern __shared__ __attribute__((aligned(16))) float wt[];     // [P+D][E] transposed weight
+  for (int i = threadIdx.x; i < C * E; i += blockDim.x) { int e = i / C, p = i % C; wt[p * E + e] = W[i]; }     // (coalesced reads; the transposing side is the LDS)
   __syncthreads();
-  const long notes = (long)B * 512;
+  const long notes = (long)B * S * N;
   if ((E & 3) == 0 && blockDim.x >= E / 4) {
     // 4 features per thread: 16-byte LDS reads and stores, blockDim / (E/4) notes in flight per block
     const int tpn = E / 4, per = blockDim.x / tpn;
     const int e = (threadIdx.x % tpn) * 4, sub = threadIdx.x / tpn;
     if (sub >= per) return;
     const float4 bv = *reinterpret_cast<const float4*>(bias + e);
-    // four notes per thread and trip: their index rows (6 x int64 each, one cache line apart from every neighbour) are requested
+    // four notes per thread and trip: their index rows (1+D x int64 each, one cache line apart from every neighbour) are requested
     // together -- with one note per trip the loop was a chain of exposed load latencies (8 notes in flight per block)
     const long stride = (long)gridDim.x * per;
     for (long i0 = (long)blockIdx.x * per + sub; i0 < notes; i0 += 4 * stride) {
-      long xi[4][6];
+      long xi[4][1 + DM];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const long i = min(i0 + u * stride, notes - 1);
-        const int b = (int)(i % B); const long q = i / B; const int t = (int)(q % 32), n = (int)(q / 32);
-        const long* xr = x + (((long)b * 32 + t) * 16 + n) * 6;
+        const int b = (int)(i % B); const long q = i / B; const int t = (int)(q % S), n = (int)(q / S);
+        const long* xr = x + (((long)b * S + t) * N + n) * (1 + D);
 #pragma unroll
-        for (int d = 0; d < 6; d++) xi[u][d] = xr[d];
+        for (int d = 0; d < 1 + DM; d++) xi[u][d] = d <= D ? xr[d] : 0;
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
@@ -199,11 +209,12 @@ __global__ void embed_fwd_kernel(const long* __restrict__ x, const float* __rest
         if (i >= notes) break;
         const int p = (int)xi[u][0];
         float4 v = bv;
-        if (p < 130) { const float4 w = *reinterpret_cast<const float4*>(wt + p * E + e); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+        if (p >= 0 && p < P) { const float4 w = *reinterpret_cast<const float4*>(wt + p * E + e); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
 #pragma unroll
-        for (int d = 0; d < 5; d++) {
+        for (int d = 0; d < DM; d++) {
+          if (d >= D) break;
           const float f = (float)xi[u][1 + d];
-          const float4 w = *reinterpret_cast<const float4*>(wt + (130 + d) * E + e);
+          const float4 w = *reinterpret_cast<const float4*>(wt + (P + d) * E + e);
           v.x += w.x * f; v.y += w.y * f; v.z += w.z * f; v.w += w.w * f;
         }
         *reinterpret_cast<float4*>(emb + i * E + e) = v;
@@ -216,51 +227,41 @@ __global__ void embed_fwd_kernel(const long* __restrict__ x, const float* __rest
   if (sub >= per) return;
   for (long i = (long)blockIdx.x * per + sub; i < notes; i += (long)gridDim.x * per) {
     // i indexes the OUTPUT row (n, t, b)
-    const int b = (int)(i % B); const long q = i / B; const int t = (int)(q % 32), n = (int)(q / 32);
-    const long* xr = x + (((long)b * 32 + t) * 16 + n) * 6;
+    const int b = (int)(i % B); const long q = i / B; const int t = (int)(q % S), n = (int)(q / S);
+    const long* xr = x + (((long)b * S + t) * N + n) * (1 + D);
     const int p = (int)xr[0];
     float v = bias[e];
-    if (p < 130) v += wt[p * E + e];
-#pragma unroll
-    for (int d = 0; d < 5; d++) v += wt[(130 + d) * E + e] * (float)xr[1 + d];
+    if (p >= 0 && p < P) v += wt[p * E + e];
+    for (int d = 0; d < D; d++) v += wt[(P + d) * E + e] * (float)xr[1 + d];
     emb[i * E + e] = v;
   }
 }
 
-__global__ void lengths_kernel(const long* __restrict__ x, int* __restrict__ lengths, int B) {
+__global__ void lengths_kernel(const long* __restrict__ x, int* __restrict__ lengths, int B, GridGeom g) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;       // output index t*B + b
-  if (i >= (long)B * 32) return;
+  if (i >= (long)B * g.S) return;
   int b = (int)(i % B), t = (int)(i / B);
-  const long* xr = x + ((long)b * 32 + t) * 16 * 6;
+  const long* xr = x + ((long)b * g.S + t) * g.N * (1 + g.D);
   int pad = 0;
-  for (int n = 0; n < 16; n++) pad += (xr[n * 6] == 130);
-  lengths[i] = 16 - pad;
+  for (int n = 0; n < g.N; n++) pad += (xr[n * (1 + g.D)] == g.pad);
+  lengths[i] = g.N - pad;
 }
 
-// multihot [16*32*B, 135] (row stride ld) in the embedding's step-major row order: the matrix the
+// multihot [N*S*B, P+D] (row stride ld) in the embedding's step-major row order: the matrix the
 // reference multiplies by note_embedding.weight (ptvae.py:299-313).  Only the BACKWARD uses it here:
 // dW = demb^T . multihot is a K = 262144-deep product that belongs on the MFMA (split-K) path instead of
-// on atomics.
-__global__ void multihot_kernel(const long* __restrict__ x, float* __restrict__ out, long ld, int B) {
-  const long notes = (long)B * 512;
+// on atomics.  T = float, or bf16 (0, 1 and 2 are exact: half the bytes for the bf16-precision weight-gradient product; its rows are
+// zero-filled up to `cols` >= P+D)
+template <typename T>
+__global__ void multihot_kernel(const long* __restrict__ x, T* __restrict__ out, long ld, int B, int cols, GridGeom g) {
+  const long notes = (long)B * g.S * g.N;
+  const int C = g.P + g.D;
   for (long i = (long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); i < notes; i += (long)gridDim.x * (blockDim.x / 64)) {
-    const int b = (int)(i % B); const long q = i / B; const int t = (int)(q % 32), n = (int)(q / 32);
-    const long* xr = x + (((long)b * 32 + t) * 16 + n) * 6;
+    const int b = (int)(i % B); const long q = i / B; const int t = (int)(q % g.S), n = (int)(q / g.S);
+    const long* xr = x + (((long)b * g.S + t) * g.N + n) * (1 + g.D);
     const int p = (int)xr[0];
-    float* o = out + i * ld;
-    for (int c = threadIdx.x & 63; c < 135; c += 64) o[c] = c < 130 ? (c == p ? 1.f : 0.f) : (float)xr[1 + c - 130];
-  }
-}
-
-// the same rows as bf16 (0, 1 and 2 are exact): half the bytes for the bf16-precision weight-gradient product
-__global__ void multihot_bf16_kernel(const long* __restrict__ x, __bf16* __restrict__ out, long ld, int B) {
-  const long notes = (long)B * 512;
-  for (long i = (long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); i < notes; i += (long)gridDim.x * (blockDim.x / 64)) {
-    const int b = (int)(i % B); const long q = i / B; const int t = (int)(q % 32), n = (int)(q / 32);
-    const long* xr = x + (((long)b * 32 + t) * 16 + n) * 6;
-    const int p = (int)xr[0];
-    __bf16* o = out + i * ld;
-    for (int c = threadIdx.x & 63; c < 136; c += 64) o[c] = (__bf16)(c < 130 ? (c == p ? 1.f : 0.f) : (c < 135 ? (float)xr[1 + c - 130] : 0.f));
+    T* o = out + i * ld;
+    for (int c = threadIdx.x & 63; c < cols; c += 64) o[c] = (T)(c < g.P ? (c == p ? 1.f : 0.f) : (c < C ? (float)xr[1 + c - g.P] : 0.f));
   }
 }
 
@@ -389,36 +390,62 @@ extern "C" int ptv_colsum(float* out, const void* A, long lda, long rows, int N,
   return PTV_OK;
 }
 
-extern "C" int ptv_embed_fwd(const long* x, const float* W, const float* bias, float* emb, int* lengths, int B, int E, void* stream) {
-  if (!x || !W || !bias || !emb || B <= 0 || E <= 0 || E > 256) return PTV_ERR_ARG;
+static inline bool geom_ok(int S, int N, int P, int D) { return S > 0 && N > 0 && P > 0 && D >= 0 && D <= GEOM_DMAX; }
+
+extern "C" int ptv_embed_fwd_geom(const long* x, const float* W, const float* bias, float* emb, int* lengths, int B, int E,
+                                  int S, int N, int P, int D, int pad, void* stream) {
+  if (!x || !W || !bias || !emb || B <= 0 || E <= 0 || E > 256 || !geom_ok(S, N, P, D)) return PTV_ERR_ARG;
+  if ((size_t)(P + D) * E * sizeof(float) > 150 * 1024) return PTV_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for((long)B * 512, 8, 512)), dim3(256), 135 * E * sizeof(float), s, x, W, bias, emb, B, E);   // (two 69-KB blocks per CU: one round)
-  if (lengths) hipLaunchKernelGGL(lengths_kernel, dim3(cdiv((long)B * 32, 256)), dim3(256), 0, s, x, lengths, B);
+  const GridGeom g{S, N, P, D, pad};
+  const bool def = S == 32 && N == 16 && P == 130 && D == 5;
+  const size_t lds = (size_t)(P + D) * E * sizeof(float);
+  const int grid = grid_for((long)B * S * N, 8, 512);                     // (default grid: two 69-KB blocks per CU: one round)
+  if (def) hipLaunchKernelGGL((embed_fwd_kernel<true>), dim3(grid), dim3(256), lds, s, x, W, bias, emb, B, E, g);
+  else {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)embed_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+    hipLaunchKernelGGL((embed_fwd_kernel<false>), dim3(grid), dim3(256), lds, s, x, W, bias, emb, B, E, g);
+  }
+  if (lengths) hipLaunchKernelGGL(lengths_kernel, dim3(cdiv((long)B * S, 256)), dim3(256), 0, s, x, lengths, B, g);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
+extern "C" int ptv_embed_fwd(const long* x, const float* W, const float* bias, float* emb, int* lengths, int B, int E, void* stream) {
+  return ptv_embed_fwd_geom(x, W, bias, emb, lengths, B, E, 32, 16, 130, 5, 130, stream);
+}
+
+extern "C" int ptv_grid_lengths_geom(const long* x, int* lengths, int B, int S, int N, int D, int pad, void* stream) {
+  if (!x || !lengths || B <= 0 || !geom_ok(S, N, 1, D)) return PTV_ERR_ARG;
+  hipLaunchKernelGGL(lengths_kernel, dim3(cdiv((long)B * S, 256)), dim3(256), 0, (hipStream_t)stream, x, lengths, B, GridGeom{S, N, 1, D, pad});
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
 
 extern "C" int ptv_grid_lengths(const long* x, int* lengths, int B, void* stream) {
-  if (!x || !lengths || B <= 0) return PTV_ERR_ARG;
-  hipLaunchKernelGGL(lengths_kernel, dim3(cdiv((long)B * 32, 256)), dim3(256), 0, (hipStream_t)stream, x, lengths, B);
+  return ptv_grid_lengths_geom(x, lengths, B, 32, 16, 5, 130, stream);
+}
+
+extern "C" int ptv_multihot_geom(const long* x, void* out, long ld, int B, int S, int N, int P, int D, int bf16, void* stream) {
+  if (!x || !out || B <= 0 || !geom_ok(S, N, P, D) || ld < P + D) return PTV_ERR_ARG;
+  long nb = ((long)B * S * N + 3) / 4; if (nb > 8192) nb = 8192;
+  const GridGeom g{S, N, P, D, 0};
+  if (bf16) {
+    const int cols = (int)(ld < (long)((P + D + 7) / 8 * 8) ? ld : (P + D + 7) / 8 * 8);         // zero-filled up to the 16-byte row granule
+    hipLaunchKernelGGL((multihot_kernel<__bf16>), dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)out, ld, B, cols, g);
+  } else hipLaunchKernelGGL((multihot_kernel<float>), dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, (float*)out, ld, B, P + D, g);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
 
 extern "C" int ptv_multihot(const long* x, float* out, long ld, int B, void* stream) {
-  if (!x || !out || B <= 0 || ld < 135) return PTV_ERR_ARG;
-  long nb = ((long)B * 512 + 3) / 4; if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(multihot_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, out, ld, B);
-  PTV_CHECK_LAUNCH();
-  return PTV_OK;
+  return ptv_multihot_geom(x, out, ld, B, 32, 16, 130, 5, 0, stream);
 }
 
 extern "C" int ptv_multihot_bf16(const long* x, void* out, long ld, int B, void* stream) {
-  if (!x || !out || B <= 0 || ld < 136) return PTV_ERR_ARG;
-  long nb = ((long)B * 512 + 3) / 4; if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(multihot_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)out, ld, B);
-  PTV_CHECK_LAUNCH();
-  return PTV_OK;
+  if (ld < 136) return PTV_ERR_ARG;
+  return ptv_multihot_geom(x, out, ld, B, 32, 16, 130, 5, 1, stream);
 }
 
 extern "C" int ptv_reparam_kl_fwd(const float* mu, const float* sd, const float* eps, float* z, long ldz, float* kl_sum, int B, int Z, void* stream) {

@@ -841,18 +841,24 @@ class Transpose01Fn(torch.autograd.Function):
 # =============================================================================================
 # PtvaeDecoder.emb_x  (ptvae.py:531-535)
 # =============================================================================================
+DEFAULT_GEOM = (32, 16, 130, 5, 130)                    # (num_step, max_simu_note, pitch_range, dur_width, pitch_pad) of init_model()
+
+
 class EmbedFn(torch.autograd.Function):
-    """x [B,32,16,6] int64 -> (emb step-major [16,32,B,E], lengths int32 [32*B])"""
+    """x [B,S,N,1+D] int64 -> (emb step-major [N,S,B,E], lengths int32 [S*B]); geom = (S, N, P, D, pitch_pad), default the
+    32 x 16 x (130+5) grid"""
 
     @staticmethod
-    def forward(ctx, x, w, b, prec=0):
+    def forward(ctx, x, w, b, prec=0, geom=DEFAULT_GEOM):
         B = x.shape[0]
         E = w.shape[0]
-        ctx.prec = prec
+        S, N, P, D, pad = geom
+        assert tuple(x.shape[1:]) == (S, N, 1 + D) and w.shape[1] == P + D, (tuple(x.shape), tuple(w.shape), geom)
+        ctx.prec, ctx.geom = prec, geom
         x = x.contiguous()
-        emb = _empty(16, 32, B, E, dev=w.device)
-        lengths = torch.empty(32 * B, device=w.device, dtype=torch.int32)
-        call('ptv_embed_fwd', ptr(x), ptr(w), ptr(b), ptr(emb), ptr(lengths), B, E, stream_ptr())
+        emb = _empty(N, S, B, E, dev=w.device)
+        lengths = torch.empty(S * B, device=w.device, dtype=torch.int32)
+        call('ptv_embed_fwd_geom', ptr(x), ptr(w), ptr(b), ptr(emb), ptr(lengths), B, E, S, N, P, D, pad, stream_ptr())
         ctx.save_for_backward(x, w, b)
         ctx.mark_non_differentiable(lengths)
         # The weight gradient is dy^T . multihot(x), and multihot(x) depends on the input only: in bf16 precision it is built NOW, on a
@@ -861,9 +867,11 @@ class EmbedFn(torch.autograd.Function):
         ctx.mh = ctx.mh_side = None
         if (EMBED_MH_FWD and prec == 1 and E % 8 == 0 and OVERLAP and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
                 and not capturing_part()):
+            ld = (P + D + 7) // 8 * 8
+
             def build():
-                mh = _empty(B * 512, 136, dev=w.device, dtype=BF16)
-                call('ptv_multihot_bf16', ptr(x), ptr(mh), 136, B, stream_ptr())
+                mh = _empty(B * S * N, ld, dev=w.device, dtype=BF16)
+                call('ptv_multihot_geom', ptr(x), ptr(mh), ld, B, S, N, P, D, 1, stream_ptr())
                 return mh, record_event()
             ctx.mh, ctx.mh_side = Side(7)(build, x)           # (pool stream 3: idle in the forward; streams 0 / 2 delayed the encoders)            # (mh_side: the event the backward waits for -- not the whole stream)
         return emb, lengths
@@ -872,17 +880,19 @@ class EmbedFn(torch.autograd.Function):
     def backward(ctx, demb, _dl):
         x, w, b = ctx.saved_tensors
         B, E = x.shape[0], w.shape[0]
-        demb2 = demb.contiguous().view(B * 512, E)
+        S, N, P, D, _pad = ctx.geom
+        demb2 = demb.contiguous().view(B * S * N, E)
         if ctx.mh is not None:
             wait_event(cur_stream(), ctx.mh_side)
             mh, ctx.mh, ctx.mh_side = ctx.mh, None, None
-            dw, db = wgrad_bias(demb2, mh[:, :135], _gbuf(w), _gbuf(b), ctx.prec)      # bias gradient inside the same pass over dy
-            return None, dw, db, None
-        mh = _empty(B * 512, 136, dev=w.device)
-        call('ptv_multihot', ptr(x), ptr(mh), 136, B, stream_ptr())
-        dw = gemm(demb2, mh[:, :135], _gbuf(w), ta=True, tb=True, acc=True, prec=ctx.prec)
+            dw, db = wgrad_bias(demb2, mh[:, :P + D], _gbuf(w), _gbuf(b), ctx.prec)      # bias gradient inside the same pass over dy
+            return None, dw, db, None, None
+        ld = (P + D + 7) // 8 * 8
+        mh = _empty(B * S * N, ld, dev=w.device)
+        call('ptv_multihot_geom', ptr(x), ptr(mh), ld, B, S, N, P, D, 0, stream_ptr())
+        dw = gemm(demb2, mh[:, :P + D], _gbuf(w), ta=True, tb=True, acc=True, prec=ctx.prec)
         db = _bgrad(b, demb2)
-        return None, dw, db, None
+        return None, dw, db, None, None
 
 
 # =============================================================================================
@@ -1948,6 +1958,28 @@ class VaeLossFn(torch.autograd.Function):
         if sm_c:
             droot, dchroma, dbass = (t.permute(*_chord_perm(t)) for t in (droot, dchroma, dbass))
         return (dpitch, ddur, dmu_c, dsd_c, dmu_r, dsd_r, droot, dchroma, dbass) + (None,) * 6
+
+
+class SplitScalarsFn(torch.autograd.Function):
+    """out[n] -> n scalars, like Tensor.unbind -- whose backward launches one zero fill per output that got no gradient plus a stack
+    (11 losses, `losses[0].backward()`: 10 fills + stack at the very head of the backward pass).  Here an output without gradient costs
+    nothing: the incoming scalars are copied into a pooled zero row."""
+
+    @staticmethod
+    def forward(ctx, out):
+        ctx.set_materialize_grads(False)
+        ctx.n = out.shape[0]
+        return tuple(out.detach().unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [(i, g) for i, g in enumerate(gs) if g is not None]
+        if not live:
+            return None
+        g = _zeros(ctx.n, dev=live[0][1].device)
+        for i, gi in live:
+            g[i:i + 1].copy_(gi.reshape(1))
+        return g
 
 
 class ReconLossFn(torch.autograd.Function):

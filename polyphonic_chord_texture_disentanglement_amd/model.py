@@ -120,7 +120,7 @@ class DisentangleVAE(PytorchModel):
         out = F_.VaeLossFn.apply(recon_pitch, recon_dur, dist_chd.mean, dist_chd.scale, dist_rhy.mean,
                                  dist_rhy.scale, recon_root, recon_chroma, recon_bass, x.long(), c.float(),
                                  float(beta), float(weights[0]), float(weights[1]), bool(weighted_dur))
-        return tuple(out.unbind(0))
+        return F_.SplitScalarsFn.apply(out)
 
     # ---- model.py:70-90 (stand-alone forms; loss_function computes them fused)
     def chord_loss(self, c, recon_root, recon_chroma, recon_bass):

@@ -379,23 +379,29 @@ class PtvaeDecoder(nn.Module, _PrecMixin):
     def _P(self):
         return dict(zip(FF_.FREE_PARAM_NAMES, self._params_free()))
 
+    def _geom(self):
+        return (self.num_step, self.max_simu_note, self.pitch_range, self.dur_width, self.pitch_pad)
+
     def get_len_index_tensor(self, ind_x):
-        """ptvae.py:292-297: lengths [B, 32] (int64) = 16 - number of <pad> pitches per step"""
+        """ptvae.py:292-297: lengths [B, num_step] (int64) = max_simu_note - number of <pad> pitches per step"""
         _require_cuda(ind_x, 'PtvaeDecoder.get_len_index_tensor')
         x = ind_x.long().contiguous()
         B = x.size(0)
-        lengths = torch.empty(32 * B, device=x.device, dtype=torch.int32)
-        F_.call('ptv_grid_lengths', F_.ptr(x), F_.ptr(lengths), B, F_.stream_ptr())
-        return lengths.view(32, B).t().long()
+        S, N, _P, D, pad = PtvaeDecoder._geom(self)
+        lengths = torch.empty(S * B, device=x.device, dtype=torch.int32)
+        F_.call('ptv_grid_lengths_geom', F_.ptr(x), F_.ptr(lengths), B, S, N, D, pad, F_.stream_ptr())
+        return lengths.view(S, B).t().long()
 
     def index_tensor_to_multihot_tensor(self, ind_x):
         """ptvae.py:299-313: piano grid [B,32,16,6] -> multi-hot [B,32,16,135] (one-hot pitch of 130 | 5 duration bits); a permuted
-        view of the step-major matrix the note_embedding weight gradient multiplies"""
+        view of the step-major matrix the note_embedding weight gradient multiplies.  (Any grid geometry; the reference's own
+        `view(-1, 32, ...)` fixes num_step = 32.)"""
         _require_cuda(ind_x, 'PtvaeDecoder.index_tensor_to_multihot_tensor')
         x = ind_x.long().contiguous()
         B = x.size(0)
-        out = torch.empty(16, 32, B, self.note_size, device=x.device, dtype=torch.float32)
-        F_.call('ptv_multihot', F_.ptr(x), F_.ptr(out), self.note_size, B, F_.stream_ptr())
+        S, N, P, D, _pad = PtvaeDecoder._geom(self)
+        out = torch.empty(N, S, B, self.note_size, device=x.device, dtype=torch.float32)
+        F_.call('ptv_multihot_geom', F_.ptr(x), F_.ptr(out), self.note_size, B, S, N, P, D, 0, F_.stream_ptr())
         return out.permute(2, 1, 0, 3)
 
     def get_sos_token(self):
@@ -512,9 +518,10 @@ class PtvaeEncoder(nn.Module, _PrecMixin):
         self.linear_std = Linear(2 * enc_time_hid_size, z_size)
 
     def _check_grid(self):
-        if (self.max_simu_note, self.num_step, self.dur_width, self.pitch_range, self.pitch_pad, self.dur_pad) != (16, 32, 5, 130, 130, 2):
-            raise NotImplementedError('HIP kernels are specialised to the 32x16x(130+5) PianoTree grid '
-                                      '(the reference\'s train.py:32 geometry cannot consume its own data either: SURVEY.md 0.2)')
+        """Every geometry the reference's constructor accepts runs (train.py:32 builds max_pitch = 31: pitch_range 34); the bounds are
+        those of the kernels' fixed-size staging (dur_width <= 8 index columns per note, the [P+D][E] weight in 150 KB of LDS)"""
+        if self.dur_width > 8 or (self.note_size * self.note_emb_size * 4) > 150 * 1024 or self.note_emb_size > 256:
+            raise NotImplementedError('PtvaeEncoder on HIP: dur_width <= 8, note_emb_size <= 256, note_size * note_emb_size <= 38400')
 
     # ---- ptvae.py:160-206: the reference's method surface
     def get_len_index_tensor(self, ind_x):
@@ -531,12 +538,13 @@ class PtvaeEncoder(nn.Module, _PrecMixin):
         self._check_grid()
         B = x.size(0)
         E = self.note_emb_size
-        emb_b = F_.LinearFn.apply(x.reshape(B * 512, self.note_size).float(), self.note_embedding.weight, self.note_embedding.bias,
-                                  self._prec).view(B, 32, 16, E)
-        emb = F_.Transpose01Fn.apply(emb_b.transpose(1, 2).reshape(B, 16 * 32, E)).view(16, 32, B, E)
+        S, N = self.num_step, self.max_simu_note
+        emb_b = F_.LinearFn.apply(x.reshape(B * S * N, self.note_size).float(), self.note_embedding.weight, self.note_embedding.bias,
+                                  self._prec).view(B, S, N, E)
+        emb = F_.Transpose01Fn.apply(emb_b.transpose(1, 2).reshape(B, N * S, E)).view(N, S, B, E)
         len32 = lengths.t().contiguous().int().reshape(-1)
-        notes = F_.BiGruFinalFn.apply(emb.view(16, 32 * B, E), len32, self._prec, *self.enc_notes_gru.weights())
-        h = F_.BiGruFinalFn.apply(notes.view(32, B, -1), None, self._prec, *self.enc_time_gru.weights())
+        notes = F_.BiGruFinalFn.apply(emb.view(N, S * B, E), len32, self._prec, *self.enc_notes_gru.weights())
+        h = F_.BiGruFinalFn.apply(notes.view(S, B, -1), None, self._prec, *self.enc_time_gru.weights())
         mu, sd = F_.EncoderHeadsFn.apply(h, self.linear_mu.weight, self.linear_mu.bias, self.linear_std.weight, self.linear_std.bias,
                                          self._prec)
         return HipNormal(mu, sd), emb_b
@@ -545,13 +553,14 @@ class PtvaeEncoder(nn.Module, _PrecMixin):
         _require_cuda(x, 'PtvaeEncoder')
         self._check_grid()
         B = x.size(0)
-        emb, lengths = F_.EmbedFn.apply(x.long(), self.note_embedding.weight, self.note_embedding.bias, self._prec)   # [16,32,B,E]
+        emb, lengths = F_.EmbedFn.apply(x.long(), self.note_embedding.weight, self.note_embedding.bias, self._prec,
+                                        PtvaeDecoder._geom(self))                                                      # [N,S,B,E]
         n, t, b, e = emb.shape
-        notes = F_.BiGruFinalFn.apply(emb.view(n, t * b, e), lengths, self._prec, *self.enc_notes_gru.weights())      # [32*B, 2Hn]
+        notes = F_.BiGruFinalFn.apply(emb.view(n, t * b, e), lengths, self._prec, *self.enc_notes_gru.weights())      # [S*B, 2Hn]
         h = F_.BiGruFinalFn.apply(notes.view(t, b, -1), None, self._prec, *self.enc_time_gru.weights())               # [B, 2Ht]
         mu, sd = F_.EncoderHeadsFn.apply(h, self.linear_mu.weight, self.linear_mu.bias, self.linear_std.weight,
                                          self.linear_std.bias, self._prec)
-        embedded_x = emb.permute(2, 1, 0, 3)                                # reference shape [B,32,16,E], step-major memory
+        embedded_x = emb.permute(2, 1, 0, 3)                                # reference shape [B,S,N,E], step-major memory
         if return_iterators:
             return mu, sd, embedded_x
-        return HipNormal(mu, sd), embedded_x, lengths.view(32, B).t()
+        return HipNormal(mu, sd), embedded_x, lengths.view(t, b).t()

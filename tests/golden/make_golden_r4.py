@@ -20,8 +20,15 @@ outputs only.
                                get_len_index_tensor, index_tensor_to_multihot_tensor, get_sos_token, dur_ind_to_dur_token,
                                pitch_dur_ind_to_note_token, decode_note, decode_notes (scheduled sampling with recorded coins, and
                                inference), PtvaeEncoder.encoder on the multi-hot grid
+  ptvae_encoder_geom.npz       PtvaeEncoder on grid geometries OTHER than 32 x 16 x (130+5) (ptvae.py:127-147 takes any): case `train32` =
+                               train.py:32's own construction PtvaeEncoder(z_size=256, max_pitch=31, min_pitch=0) at full widths
+                               (pitch_range 34, pad index left at 130: lengths are all 16), forward() on an index grid with pitches
+                               0..34; case `small` = max_simu_note 12, dur_width 4, pitch_range 34 with consistent sos/eos/pad
+                               32/33/34, reduced widths, forward(); case `steps24` = num_step 24, max_simu_note 10 through
+                               encoder(multihot, lengths) (the reference's index->multihot helper fixes num_step = 32).  Outputs: mean,
+                               scale, lengths, embedded (or its sum), every gradient (or norm / sum / 64-element slice)
 
-    python tests/golden/make_golden_r4.py [b512] [slices] [train5] [sched4] [methods]   # needs /root/reference; b512 takes ~5 min / ~20 GB
+    python tests/golden/make_golden_r4.py [b512] [slices] [train5] [sched4] [methods] [geom]   # needs /root/reference; b512 takes ~5 min / ~20 GB
 """
 import os
 import sys
@@ -67,7 +74,7 @@ def checksums(m):
 
 
 def main():
-    what = set(sys.argv[1:]) or {'b512', 'slices', 'train5', 'sched4', 'methods'}
+    what = set(sys.argv[1:]) or {'b512', 'slices', 'train5', 'sched4', 'methods', 'geom'}
     ref_model, ref_ptvae, ref_tp = mg.import_reference()
     from amc_dl.torch_plus.train_utils import kl_anealing
     warnings.simplefilter('ignore')
@@ -209,6 +216,68 @@ def main():
         out['enc.mean'], out['enc.scale'], out['enc.embedded'] = dist.mean.numpy(), dist.scale.numpy(), emb.numpy()
         np.savez_compressed(os.path.join(HERE, 'reduced_methods.npz'), **out)
         print('methods', {k: v.shape for k, v in out.items()})
+
+    if 'geom' in what:
+        out = OrderedDict()
+        cases = (('train32', dict(z_size=256, max_pitch=39 - 8, min_pitch=0), 3, 'forward'),
+                 ('small', dict(max_simu_note=12, max_pitch=31, min_pitch=0, pitch_sos=32, pitch_eos=33, pitch_pad=34, dur_width=4,
+                                note_emb_size=20, enc_notes_hid_size=12, enc_time_hid_size=16, z_size=8), 5, 'forward'),
+                 ('steps24', dict(max_simu_note=10, max_pitch=31, min_pitch=0, pitch_sos=32, pitch_eos=33, pitch_pad=34, num_step=24,
+                                  note_emb_size=24, enc_notes_hid_size=16, enc_time_hid_size=12, z_size=8), 4, 'encoder'))
+        for tag, kw, B, how in cases:
+            torch.manual_seed(0)
+            enc = ref_ptvae.PtvaeEncoder(torch.device('cpu'), **kw)
+            shapes = OrderedDict((k, tuple(v.shape)) for k, v in enc.state_dict().items())
+            enc.load_state_dict(fill_state_dict(shapes, seed=977))
+            S, N, D, P, pad = enc.num_step, enc.max_simu_note, enc.dur_width, enc.pitch_range, enc.pitch_pad
+            rs = np.random.RandomState(31 + B)
+            x = np.zeros((B, S, N, 1 + D), dtype=np.int64)
+            x[..., 0] = rs.randint(0, P + 1, size=(B, S, N))                      # P = the dropped column (ptvae.py:186)
+            x[..., 1:] = rs.randint(0, 2, size=(B, S, N, D))
+            if pad <= P:                                                         # consistent geometry: ragged steps, >= 1 note each
+                n_live = rs.randint(1, N + 1, size=(B, S))
+                dead = np.arange(N)[None, None, :] >= n_live[..., None]
+                x[..., 0] = np.where(dead, pad, np.minimum(x[..., 0], P - 1))
+                x[..., 1:] = np.where(dead[..., None], 2, x[..., 1:])
+            xt = torch.from_numpy(x)
+            if how == 'forward':
+                dist, emb, lengths = enc(xt)
+            else:
+                lengths = enc.get_len_index_tensor(xt)
+                oh = torch.zeros(B, S, N, P + 1).scatter_(-1, xt[..., 0:1], 1.0)       # what index_tensor_to_multihot_tensor builds (:174-188)
+                mh = torch.cat([oh[..., :P], xt[..., 1:].float()], dim=-1)
+                dist, emb = enc.encoder(mh, lengths)
+                out[tag + '.multihot'] = mh.numpy()
+            g = torch.Generator().manual_seed(3)
+            w1, w2 = torch.randn(dist.mean.shape, generator=g), torch.randn(dist.mean.shape, generator=g)
+            ((dist.mean * w1).sum() + (dist.scale * w2).sum()).backward()
+            out[tag + '.kw'] = np.array(repr(sorted(kw.items())))
+            out[tag + '.x'], out[tag + '.w1'], out[tag + '.w2'] = x, w1.numpy(), w2.numpy()
+            out[tag + '.mean'], out[tag + '.scale'] = dist.mean.detach().numpy(), dist.scale.detach().numpy()
+            out[tag + '.lengths'] = lengths.numpy()
+            out[tag + '.names'] = np.array(list(shapes.keys()))
+            out[tag + '.shapes'] = np.array([str(v) for v in shapes.values()])
+            full = tag == 'train32'
+            if full:
+                out[tag + '.embedded.sum'] = np.float64(emb.detach().double().sum().item())
+                out[tag + '.embedded.slice'] = emb.detach().reshape(-1)[::997].numpy().copy()
+            else:
+                out[tag + '.embedded'] = emb.detach().numpy()
+            res = {}
+            for n, p in enc.named_parameters():
+                if full:
+                    out[tag + '.gnorm.' + n] = np.float64(p.grad.double().pow(2).sum().sqrt().item())
+                    out[tag + '.gsum.' + n] = np.float64(p.grad.double().sum().item())
+                    res['grad.' + n] = p.grad.numpy()
+                else:
+                    out[tag + '.grad.' + n] = p.grad.numpy().copy()
+            if full:
+                sl = OrderedDict()
+                grad_slices(res, sl)
+                for k, v in sl.items():
+                    out[tag + '.' + k] = v
+            print('geom', tag, (S, N, P, D, pad), dist.mean.shape, float(dist.mean.abs().mean()), int(lengths.min()), int(lengths.max()))
+        np.savez_compressed(os.path.join(HERE, 'ptvae_encoder_geom.npz'), **out)
 
 
 if __name__ == '__main__':

@@ -103,6 +103,56 @@ def test_ptvae_encoder_vs_reference_golden(tag):
     assert torch.equal(mu, dist.mean.detach()) or (mu - dist.mean).abs().max() < 1e-6
 
 
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('tag', ['train32', 'small', 'steps24'])
+def test_ptvae_encoder_on_other_grid_geometries_vs_reference_golden(tag, prec):
+    """ptvae.py:127-147 accepts any grid geometry; `train32` is train.py:32's own PtvaeEncoder(z_size=256, max_pitch=39-8) at full
+    widths (the persistent / row kernels engage), `small` a 32 x 12 x (34+4) grid, `steps24` a 24 x 10 grid through
+    encoder(multihot, lengths).  Expected values: the reference (tests/golden/make_golden_r4.py geom)."""
+    from polyphonic_chord_texture_disentanglement_amd.ptvae import PtvaeEncoder
+    from test_oracle_vs_golden import GEOM_CASES
+    g = load_npz('ptvae_encoder_geom.npz')
+    kw = GEOM_CASES[tag]
+    enc = PtvaeEncoder(torch.device(DEV), **kw)
+    shapes = {str(n): tuple(int(t) for t in s.strip('()').split(',') if t.strip()) for n, s in zip(g[tag + '.names'], g[tag + '.shapes'])}
+    assert list(enc.state_dict().keys()) == list(shapes.keys())
+    enc.load_state_dict(fill_state_dict(shapes, 977))
+    enc.to(DEV)
+    enc.precision = prec
+    x = torch.from_numpy(g[tag + '.x']).to(DEV)
+    B, S, N = x.shape[:3]
+    tol = 2e-5 if prec == 'fp32' else 2e-2
+    if tag == 'steps24':
+        ref_len = torch.from_numpy(g[tag + '.lengths']).to(DEV)
+        assert torch.equal(enc.get_len_index_tensor(x), ref_len)
+        mh = enc.index_tensor_to_multihot_tensor(x)
+        assert np.array_equal(mh.cpu().numpy(), g[tag + '.multihot'])
+        dist, emb = enc.encoder(torch.from_numpy(g[tag + '.multihot']).to(DEV), ref_len)
+        lengths = ref_len
+    else:
+        dist, emb, lengths = enc(x)
+    assert emb.shape == (B, S, N, enc.note_emb_size) and lengths.shape == (B, S)
+    assert np.array_equal(lengths.cpu().numpy(), g[tag + '.lengths'])
+    np.testing.assert_allclose(dist.mean.detach().cpu().numpy(), g[tag + '.mean'], rtol=0, atol=tol)
+    np.testing.assert_allclose(dist.scale.detach().cpu().numpy(), g[tag + '.scale'], rtol=0, atol=tol)
+    if tag == 'train32':
+        np.testing.assert_allclose(emb.detach().reshape(-1)[::997].cpu().numpy(), g[tag + '.embedded.slice'], rtol=0, atol=tol)
+    else:
+        np.testing.assert_allclose(emb.detach().cpu().numpy(), g[tag + '.embedded'], rtol=0, atol=tol)
+    ((dist.mean * torch.from_numpy(g[tag + '.w1']).to(DEV)).sum() + (dist.scale * torch.from_numpy(g[tag + '.w2']).to(DEV)).sum()).backward()
+    gtol = 2e-4 if prec == 'fp32' else 4e-2
+    for k, p in enc.named_parameters():
+        if tag == 'train32':
+            gn, ref = float(p.grad.double().pow(2).sum().sqrt()), float(g['%s.gnorm.%s' % (tag, k)])
+            assert abs(gn - ref) <= 1e-5 + (2e-3 if prec == 'fp32' else 3e-2) * ref, (k, gn, ref)
+            idx, val, gmax = g['%s.gslice.%s.idx' % (tag, k)], g['%s.gslice.%s.val' % (tag, k)], float(g['%s.gmax.%s' % (tag, k)])
+            got = p.grad.reshape(-1)[torch.from_numpy(idx).to(DEV)].cpu().numpy()
+            np.testing.assert_allclose(got, val, rtol=0, atol=2e-6 + gtol * gmax, err_msg=k)
+        else:
+            ref = g['%s.grad.%s' % (tag, k)]
+            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=0, atol=2e-6 + gtol * np.abs(ref).max(), err_msg=k)
+
+
 # ---------------------------------------------------------------------------------------------- f1
 def _eps(g, key):
     return lambda name, shape, device: torch.from_numpy(g['%s.eps_%s' % (key, name)]).to(device)
