@@ -321,11 +321,15 @@ int ptv_dur_gru_fwd(int H, long M, const float* h0, long ld_h0, const float* w_h
  * ptv_dur_bwd_finalize folds the column-summed partial S [256 x 80] into the gradients of weight_hh, bias_hh,
  * bias_ih, weight_ih [192, I] and the <sos> token [I] (all +=).
  *   gates/hall as written by ptv_dur_gru_fwd (hall: the fp32 states or, h_bf16 = 1, their bf16 copies hall16); ddur [M, 10] = d loss / d est_dur; idx[d*idx_stride + row].
+ *   gates == NULL: RECOMPUTE mode -- the forward was called with gates = NULL (it then writes a third of the bytes) and the backward
+ *   rebuilds r, z, n, hn of each step from h_{d-1}, W_hh, b_hh and the gate tables tab0 / tab the forward was given (the forward's own
+ *   MFMA product and fp32 expressions, hence the forward's values); otherwise b_hh / tab0 / tab may be NULL.
  */
 int ptv_dur_gru_bwd_part_size(void);
 int ptv_dur_gru_bwd(int H, long M, const void* gates, long plane_g, long step_g, const void* hall, long plane_h, int h_bf16,
                     const float* ddur, long ld_dd, const float* w_hh, const float* w_out,
-                    const int* idx, long idx_stride, float* dh0, float* part, int nblocks, void* stream);
+                    const int* idx, long idx_stride, float* dh0, float* part, int nblocks,
+                    const float* b_hh, const float* tab0, const float* tab, void* stream);
 int ptv_dur_bwd_finalize(const float* S, float* g_whh, float* g_bhh, float* g_bih, float* g_wih, float* g_sos,
                          const float* w_ih, const float* sos, int I, void* stream);
 

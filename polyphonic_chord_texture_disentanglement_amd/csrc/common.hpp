@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #define PTV_OK 0
 #define PTV_ERR_ARG (-1)
@@ -31,10 +32,22 @@
 
 namespace ptv {
 
+// compute units of the current device (MI355X: 256), cached
+inline int num_cus() {
+  static int n = 0;
+  if (n == 0) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; }
+  return n;
+}
+
 // accurate (ocml) transcendentals: the epilogues are a negligible share of the step and the fp32
 // parity path must track the CPU reference through 50+ recurrent steps
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
+// bf16-precision kernels: hardware exp / reciprocal (~1 ulp each; the operands of these gates were rounded to bf16, 2^-9).  The ocml
+// forms cost ~100 VALU instructions per GRU unit and step -- the 5-step duration GRU (236 M gate evaluations at B = 512) spent its whole
+// 250 us on them (round 4: 8.3e9 lane-instructions = 240 us of the chip's VALU issue)
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

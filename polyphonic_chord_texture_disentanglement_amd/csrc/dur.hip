@@ -121,10 +121,10 @@ __global__ __launch_bounds__(256, 2) void dur_gru_fwd_kernel(DurArgs a) {
         for (int e8 = 0; e8 < 8; e8++) {
           const int f = 2 * m + (e8 >> 2), e = e8 & 3;
           const int j = 32 * m + q8 + e8;
-          r[e8] = sigmoidf_(gi[j] + acc[f][e] + bh[j]);
-          z[e8] = sigmoidf_(gi[DH + j] + acc[4 + f][e] + bh[DH + j]);
+          r[e8] = sigmoid_fast(gi[j] + acc[f][e] + bh[j]);
+          z[e8] = sigmoid_fast(gi[DH + j] + acc[4 + f][e] + bh[DH + j]);
           hn[e8] = acc[8 + f][e] + bh[2 * DH + j];
-          n[e8] = tanhf_(gi[2 * DH + j] + r[e8] * hn[e8]);
+          n[e8] = tanh_fast(gi[2 * DH + j] + r[e8] * hn[e8]);
           h[f][e] = (1.0f - z[e8]) * n[e8] + z[e8] * h[f][e];
           hv[e8] = h[f][e];
           o0 += wo[j] * h[f][e];
@@ -176,7 +176,10 @@ extern "C" int ptv_dur_gru_fwd(int H, long M, const float* h0, long ld_h0, const
   if ((ld_h0 & 3) || (plane_h & 7) || (plane_g & 7) || (step_g & 7)) return PTV_ERR_ARG;      // 16-byte bf16 pieces
   DurArgs a{h0, ld_h0, w_hh, b_hh, tab0, tab, w_out, b_out, hall, plane_h, (__bf16*)hall16, gates, plane_g, step_g, gates_bf16,
             dur_out, ld_out, idx, idx_stride, force, force_stride, M};
-  long nb = ((M + 15) / 16 + 3) / 4; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1;
+  // grid: whole rounds of resident blocks (3 per CU: 44.5 KB of LDS each) -- 1024 blocks on 256 CUs were 1 1/3 rounds, the last one a third full
+  static int cap = 0;
+  if (!cap) { const char* e = getenv("PTV_DUR_FWD_NB"); cap = e ? atoi(e) : 3 * num_cus(); if (cap < 1) cap = 1024; }
+  long nb = ((M + 15) / 16 + 3) / 4; if (nb > cap) nb = cap; if (nb < 1) nb = 1;
   hipLaunchKernelGGL(dur_gru_fwd_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, a);
   PTV_CHECK_LAUNCH();
   return PTV_OK;

@@ -16,6 +16,11 @@
 //     each block writes one [256 x 80] partial; a column-sum over blocks and ptv_dur_bwd_finalize fold them
 //     into the parameter gradients.
 // Nothing but dh0 [M, 64] and the per-block partials is written.  bf16 precision, H = 64 only.
+//
+// RC (recompute, round 4): the forward no longer writes the four gate planes of its 5 steps (629 MB at B = 512, two thirds of
+// everything it wrote); the backward rebuilds r, z, n, hn of step d from h_{d-1} -- which it reads anyway -- with the forward's own
+// 24 MFMAs per wave (same operands, same order, same fp32 expressions: the values are the forward's, before their bf16 rounding) against
+// W_hh resident in LDS.  Saved planes are still accepted (gates != null: the free-running note loop writes them).
 #include "common.hpp"
 #include "gemm_core.hpp"
 #include "../../include/ptvae_hip.h"
@@ -29,7 +34,8 @@ constexpr int PART_COLS = 80;           // 64 h units + 3 token classes + zero p
 constexpr int PART = 256 * PART_COLS;   // floats per block partial
 
 struct DurBwdArgs {
-  const __bf16* gates; long plane_g, step_g;     // gate plane p of step d at gates + d*step_g + p*plane_g (+ row*64 + unit)
+  const __bf16* gates; long plane_g, step_g;     // gate plane p of step d at gates + d*step_g + p*plane_g (+ row*64 + unit); null: recompute
+  const float* b_hh; const float* tab0; const float* tab;   // recompute mode: [192], [192] = W_i sos + b_i, [2][192] = W_i onehot + b_i
   const void* hall; long plane_h; int h_bf16;    // h_d at hall + d*plane_h (+ row*64 + unit), d = 0..4; fp32 or bf16
   const float* ddur; long ld_dd;                 // [M, 10]: d loss / d est_dur
   const float* w_hh; const float* w_out;         // [192, 64], [2, 64]
@@ -42,13 +48,15 @@ struct DurBwdArgs {
 
 struct DurOps { bf16x4 g[4][4]; float4 hp[4]; };   // [plane][fragment]
 
-template <bool HB>
+template <bool HB, bool RC>
 __device__ __forceinline__ void dur_load(const DurBwdArgs& a, int d, long row, int ug, DurOps& o) {
-  const __bf16* gp = a.gates + d * a.step_g + row * BH + ug;
+  if constexpr (!RC) {
+    const __bf16* gp = a.gates + d * a.step_g + row * BH + ug;
 #pragma unroll
-  for (int p = 0; p < 4; p++)
+    for (int p = 0; p < 4; p++)
 #pragma unroll
-    for (int f = 0; f < 4; f++) o.g[p][f] = *reinterpret_cast<const bf16x4*>(gp + p * a.plane_g + f * 16);
+      for (int f = 0; f < 4; f++) o.g[p][f] = *reinterpret_cast<const bf16x4*>(gp + p * a.plane_g + f * 16);
+  }
   if constexpr (HB) {
     const __bf16* hp = reinterpret_cast<const __bf16*>(a.hall) + d * a.plane_h + row * BH + ug;
 #pragma unroll
@@ -63,7 +71,7 @@ __device__ __forceinline__ void dur_load(const DurBwdArgs& a, int d, long row, i
   }
 }
 
-template <bool HB>
+template <bool HB, bool RC>
 __global__ __launch_bounds__(256, 1) void dur_gru_bwd_kernel(DurBwdArgs a) {
   __builtin_amdgcn_s_setprio(3);                                         // a launch of the latency chain: wins instruction issue against sibling-stream products
   __shared__ __attribute__((aligned(16))) __bf16 WT[BH * WLD];          // W_hh^T: WT[unit][gate-unit]
@@ -71,6 +79,17 @@ __global__ __launch_bounds__(256, 1) void dur_gru_bwd_kernel(DurBwdArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 AT[256 * KLD];         // [dr dz dnr dn][block row]
   __shared__ __attribute__((aligned(16))) __bf16 HT[PART_COLS * KLD];   // [h unit | class | 0][block row]
   __shared__ float wo[2 * BH];
+  __shared__ __attribute__((aligned(16))) __bf16 Wn[RC ? 3 * BH * KLD : 8];   // recompute: W_hh [gate unit][k], the forward's operand
+  __shared__ __attribute__((aligned(16))) __bf16 HP[RC ? 4 * 16 * KLD : 8];   //            per-wave h_{d-1} tile
+  __shared__ float tabs[RC ? 3 : 1][RC ? 3 * BH : 1];
+  __shared__ float bh[RC ? 3 * BH : 1];
+  if constexpr (RC) {
+    for (int i = threadIdx.x; i < 3 * BH * BH; i += 256) Wn[(i / BH) * KLD + (i % BH)] = (__bf16)a.w_hh[i];
+    for (int i = threadIdx.x; i < 3 * BH; i += 256) {
+      tabs[0][i] = a.tab0[i]; tabs[1][i] = a.tab[i]; tabs[2][i] = a.tab[3 * BH + i];
+      bh[i] = a.b_hh[i];
+    }
+  }
   for (int i = threadIdx.x; i < 3 * BH * BH; i += 256) WT[(i % BH) * WLD + (i / BH)] = (__bf16)a.w_hh[i];
   for (int i = threadIdx.x; i < (PART_COLS - BH) * KLD; i += 256) HT[BH * KLD + i] = (__bf16)0.f;
   for (int i = threadIdx.x; i < 2 * BH; i += 256) wo[i] = a.w_out[i];
@@ -121,11 +140,36 @@ __global__ __launch_bounds__(256, 1) void dur_gru_bwd_kernel(DurBwdArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; e++) carry[f][e] = 0.f;
     DurOps ops[2];
-    dur_load<HB>(a, 4, rowc, ug, ops[0]);
+    dur_load<HB, RC>(a, 4, rowc, ug, ops[0]);
 #pragma unroll
     for (int d = 4; d >= 0; d--) {
       const DurOps& o = ops[(4 - d) & 1];
-      if (d > 0) dur_load<HB>(a, d - 1, rowc, ug, ops[(5 - d) & 1]);       // next step's operands in flight under this one
+      if (d > 0) dur_load<HB, RC>(a, d - 1, rowc, ug, ops[(5 - d) & 1]);       // next step's operands in flight under this one
+      f32x4 gh[RC ? 12 : 1];
+      if constexpr (RC) {
+        // the forward's recurrent product again: gh = h_{d-1} . W_hh^T (dur.hip: same fragments, same k order)
+        __bf16* hpt = HP + wave * 16 * KLD;
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+          bf16x4 p;
+          p[0] = (__bf16)o.hp[f].x; p[1] = (__bf16)o.hp[f].y; p[2] = (__bf16)o.hp[f].z; p[3] = (__bf16)o.hp[f].w;
+          *reinterpret_cast<bf16x4*>(hpt + rl * KLD + f * 16 + ug) = p;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int n = 0; n < 12; n++) gh[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < BH; ks += 32) {
+          const bf16x8 hb = *reinterpret_cast<const bf16x8*>(hpt + rl * KLD + ks + kq * 8);
+#pragma unroll
+          for (int n = 0; n < 12; n++) {
+            const bf16x8 wb = *reinterpret_cast<const bf16x8*>(Wn + (n * 16 + rl) * KLD + ks + kq * 8);
+            gh[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, hb, gh[n], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      const float* gi = tabs[RC ? cls[d] : 0];
       float dhz[4][4];
 #pragma unroll
       for (int f = 0; f < 4; f++) {
@@ -136,7 +180,15 @@ __global__ __launch_bounds__(256, 1) void dur_gru_bwd_kernel(DurBwdArgs a) {
           const int u = f * 16 + ug + e;
           float dh = carry[f][e] + dd[2 * d] * wo[u] + dd[2 * d + 1] * wo[BH + u];
           if (!ok) dh = 0.f;
-          const float r = (float)o.g[0][f][e], z = (float)o.g[1][f][e], n = (float)o.g[2][f][e], hn = (float)o.g[3][f][e];
+          float r, z, n, hn;
+          if constexpr (RC) {
+            r = sigmoid_fast(gi[u] + gh[f][e] + bh[u]);
+            z = sigmoid_fast(gi[BH + u] + gh[4 + f][e] + bh[BH + u]);
+            hn = gh[8 + f][e] + bh[2 * BH + u];
+            n = tanh_fast(gi[2 * BH + u] + r * hn);
+          } else {
+            r = (float)o.g[0][f][e]; z = (float)o.g[1][f][e]; n = (float)o.g[2][f][e]; hn = (float)o.g[3][f][e];
+          }
           const float dn = dh * (1.0f - z) * (1.0f - n * n);
           const float dz = dh * (hp[e] - n) * z * (1.0f - z);
           const float dr = dn * hn * r * (1.0f - r);
@@ -235,13 +287,20 @@ extern "C" int ptv_dur_gru_bwd_part_size(void) { return PART; }
 
 extern "C" int ptv_dur_gru_bwd(int H, long M, const void* gates, long plane_g, long step_g, const void* hall, long plane_h, int h_bf16,
                                const float* ddur, long ld_dd, const float* w_hh, const float* w_out,
-                               const int* idx, long idx_stride, float* dh0, float* part, int nblocks, void* stream) {
+                               const int* idx, long idx_stride, float* dh0, float* part, int nblocks,
+                               const float* b_hh, const float* tab0, const float* tab, void* stream) {
   if (H != BH) return PTV_ERR_ARG;
-  if (M <= 0 || !gates || !hall || !ddur || !w_hh || !w_out || !idx || !dh0 || !part || nblocks <= 0) return PTV_ERR_ARG;
+  if (M <= 0 || !hall || !ddur || !w_hh || !w_out || !idx || !dh0 || !part || nblocks <= 0) return PTV_ERR_ARG;
+  if (!gates && (!b_hh || !tab0 || !tab)) return PTV_ERR_ARG;            // recompute mode needs what the forward's gates were built from
   if ((plane_g & 3) || (step_g & 3) || (plane_h & 3) || (ld_dd & 1)) return PTV_ERR_ARG;
-  DurBwdArgs a{(const __bf16*)gates, plane_g, step_g, hall, plane_h, h_bf16, ddur, ld_dd, w_hh, w_out, idx, idx_stride, dh0, part, M, g_zero_skip};
-  if (h_bf16) hipLaunchKernelGGL(dur_gru_bwd_kernel<true>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(dur_gru_bwd_kernel<false>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, a);
+  DurBwdArgs a{(const __bf16*)gates, plane_g, step_g, b_hh, tab0, tab, hall, plane_h, h_bf16, ddur, ld_dd, w_hh, w_out, idx, idx_stride,
+               dh0, part, M, g_zero_skip};
+  hipStream_t s = (hipStream_t)stream;
+  if (!gates) {
+    if (h_bf16) hipLaunchKernelGGL((dur_gru_bwd_kernel<true, true>), dim3(nblocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((dur_gru_bwd_kernel<false, true>), dim3(nblocks), dim3(256), 0, s, a);
+  } else if (h_bf16) hipLaunchKernelGGL((dur_gru_bwd_kernel<true, false>), dim3(nblocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((dur_gru_bwd_kernel<false, false>), dim3(nblocks), dim3(256), 0, s, a);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

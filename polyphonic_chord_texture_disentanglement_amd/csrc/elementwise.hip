@@ -404,7 +404,7 @@ extern "C" int ptv_embed_fwd_geom(const long* x, const float* W, const float* bi
   if (def) hipLaunchKernelGGL((embed_fwd_kernel<true>), dim3(grid), dim3(256), lds, s, x, W, bias, emb, B, E, g);
   else {
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)embed_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+    if (!attr) { if (hipFuncSetAttribute((const void*)embed_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return PTV_ERR_LAUNCH; attr = true; }
     hipLaunchKernelGGL((embed_fwd_kernel<false>), dim3(grid), dim3(256), lds, s, x, W, bias, emb, B, E, g);
   }
   if (lengths) hipLaunchKernelGGL(lengths_kernel, dim3(cdiv((long)B * S, 256)), dim3(256), 0, s, x, lengths, B, g);

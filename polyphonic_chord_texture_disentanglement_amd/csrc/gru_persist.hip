@@ -252,10 +252,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void pgru_fwd_kernel(PGruFwdArgs a) {
       float r[4], z[4], n[4], hn[4], h[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        r[e] = sigmoidf_(ir[e] + acc[i][0][e] + bR[e]);
-        z[e] = sigmoidf_(iz[e] + acc[i][1][e] + bZ[e]);
+        r[e] = sigmoid_fast(ir[e] + acc[i][0][e] + bR[e]);
+        z[e] = sigmoid_fast(iz[e] + acc[i][1][e] + bZ[e]);
         hn[e] = acc[i][2][e] + bN[e];
-        n[e] = tanhf_(in_[e] + r[e] * hn[e]);
+        n[e] = tanh_fast(in_[e] + r[e] * hn[e]);
         if (!live) { r[e] = 0.f; z[e] = 1.f; n[e] = 0.f; }            // masked row: h' = h, zero gate grads
         h[e] = (1.0f - z[e]) * n[e] + z[e] * hP[e];
       }

@@ -23,6 +23,8 @@
 
 namespace ptv {
 
+extern int g_gemm_prio;            // gemm.hip: set by ptv_gemm_priority (the caller is on a latency chain)
+
 // The saved gate planes are private to this file's forward / BPTT pair and live UNIT-BLOCKED: plane[(u / 32)][row][u % 32].  A lane of the
 // epilogue owns 8 consecutive units of a row and the 4 lane groups of a wave 32 of them, so in a row-major plane a wave instruction
 // touches 16 rows x 64 bytes -- half a cache line per row; blocked it is ONE contiguous kilobyte.  Measured at R = 16384, T = 15:
@@ -100,13 +102,17 @@ struct RowGruFwdArgs {
   float* out; long out_ld;         // final state -> out[row*out_ld + unit], or null
   int R, T, reverse, dbg;
   int skip;                        // pass over the steps beyond the longest row of the panel (EMB with lengths)
+  int prio;                        // EMB: raised wave priority (the launch is part of a latency chain)
 };
 
 // EMB = false: the notes GRU (hoisted input part gc, b_ih folded in, no mask, no final-state output); EMB = true: a direction of
 // dec_notes_emb_gru (b_ih, optional length mask, optional reversed time, final state)
 template <int H, bool EMB>
 __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
-  __builtin_amdgcn_s_setprio(3);                                         // a launch of the latency chain: wins instruction issue against sibling-stream products
+  // a launch of the latency chain wins instruction issue against sibling-stream products.  The ground-truth note summaries (EMB) are
+  // NOT on the chain when they run beside the encoders at the head of the step (their consumer is the time GRU, after the encoders):
+  // there the caller's priority state decides (ptv_gemm_priority, 0 inside a side-stream call)
+  if (!EMB || a.prio) __builtin_amdgcn_s_setprio(3);
   constexpr int KBH = H / 32, NUT = H / 16, NPASS = H / 128, UTW = NUT / 4, HLD = H + 16, KT = KBH + 4;
   extern __shared__ __attribute__((aligned(16))) char nsm[];
   __bf16* h16 = reinterpret_cast<__bf16*>(nsm);                          // [2][64][HLD]
@@ -582,7 +588,7 @@ extern "C" int ptv_row_gru_persist_fwd(int H, const void* w_hh, const void* w_x,
   if (!w_hh || !w_x || !b_hh || !x || !HN || !HN16 || R <= 0 || T <= 0 || (H != 512 && H != 128)) return PTV_ERR_ARG;
   if (out && (out_ld & 3)) return PTV_ERR_ARG;
   RowGruFwdArgs a{(const bf16x8*)w_hh, (const bf16x8*)w_x, b_hh, b_ih, (const __bf16*)gc, x, x_step, lengths, HN, (__bf16*)HN16,
-                  (__bf16*)gates, out, out_ld, (int)R, T & 0xff, reverse, T >> 8, g_zero_skip};
+                  (__bf16*)gates, out, out_ld, (int)R, T & 0xff, reverse, T >> 8, g_zero_skip, g_gemm_prio};
   const int pi = prof::want(3, (int)R, H) ? prof::begin((hipStream_t)stream) : -1;
   // H = 512 is the notes GRU (gc given, bias folded, dense); H = 128 the note-summary GRU (b_ih given, mask / reverse / final state)
   if (H == 512 && (!gc || b_ih || lengths || reverse || out)) return PTV_ERR_UNSUPPORTED;

@@ -7,6 +7,7 @@ sees one contiguous matrix; API tensors are converted at the boundary (Transpose
 
 Reference call sites are cited per function (paths are into /root/reference).
 """
+import contextlib
 import ctypes
 import os
 import time
@@ -586,8 +587,9 @@ class Side:
     fn writes: a second reference makes AccumulateGrad clone them -- on its own stream, before the sibling has run --
     instead of adopting them.)"""
 
-    def __init__(self, slot=0):
+    def __init__(self, slot=0, chain=False):
         self.main = cur_stream()
+        self.chain = chain          # the call IS a latency chain of the step (the encoders at its head): its products keep the raised wave priority
         # The sibling streams are folded onto a pool of 4 (slot mod 4): the HIP runtime multiplexes all streams of a process onto 4
         # hardware queues anyway (GPU_MAX_HW_QUEUES; with 5 or more the step gets 40 % SLOWER), and which of ~10 private streams
         # end up sharing a queue -- i.e. silently serialise -- is then decided by creation order.  With the pool the sharing is
@@ -616,7 +618,9 @@ class Side:
         wait_stream(self.s, self.main)
         self.used = True
         self.keep.extend(keep)
-        _SIDE_DEPTH[0] += 1
+        depth = 0 if self.chain else 1
+        _SIDE_DEPTH[0] += depth
+        _chain_prio()               # (kernels other than the products read the same library state: csrc/notes_persist.hip)
         try:
             # (torch.cuda.stream() is ~15 us of python per use; the parent stream is known)
             if _set_stream is not None:
@@ -629,7 +633,8 @@ class Side:
                 with torch.cuda.stream(self.s):
                     r = fn()
         finally:
-            _SIDE_DEPTH[0] -= 1
+            _SIDE_DEPTH[0] -= depth
+            _chain_prio()
         # What fn returns was allocated under the sibling stream and will be read on the parent after join(): tell the caching
         # allocator, or the block goes back to the SIBLING's pool the moment Python drops the tensor and the next allocation there
         # may overwrite it while the parent's reader is still queued (seen as partly wrong dx / gradients once in ~10 runs).
@@ -661,6 +666,8 @@ class Side:
 
 
 _DEFERRED = []
+_LATE = []                  # (fn, keep_alive, origin stream): bulk launches postponed to the end of the backward pass (late())
+LATE_SLOTS = [int(v) for v in os.environ.get('PTV_LATE_SLOTS', '1,0,3').split(',')]
 GRAD_READY_HOOK = None      # callable(params, streams) set by dist.GradSync: the gradients of `params` are complete once `streams` drain
 
 
@@ -674,9 +681,28 @@ def mark(name):
         TRACE.append((name, e, time.perf_counter()))
 
 
+def late(fn, *keep):
+    """run fn() -- launches that only produce parameter gradients into buffers the caller has ALREADY handed to autograd -- when the
+    backward pass ends, on sibling streams: every node's chain work is then queued in front of it on every hardware queue (a queue runs
+    its dispatches in order), and the bulk spreads over all of them instead of piling up on one.  Outside a backward pass: now."""
+    try:
+        if not _DEFERRED and not _LATE:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_deferred)
+    except RuntimeError:                      # not inside the autograd engine
+        return fn()
+    _LATE.append((fn, list(keep), cur_stream()))
+
+
 def _join_deferred():
     mark('deferred:join_start')
     cur = cur_stream()
+    for i, (fn, keep, origin) in enumerate(_LATE):
+        side = Side(LATE_SLOTS[i % len(LATE_SLOTS)])
+        if origin != side.s:
+            wait_stream(side.s, origin)           # the operands were produced on the node's stream
+        side(fn, keep)
+        _DEFERRED.append((side.s, side.keep))
+    _LATE.clear()
     for s, _keep in _DEFERRED:
         wait_stream(cur, s)
     _DEFERRED.clear()
@@ -686,6 +712,7 @@ def _join_deferred():
 def reset_deferred():
     """join whatever deferred side-stream work is still registered (a backward pass that raised never ran its end-of-pass
     callback): called by FusedClipAdam.zero_grad() and by the first node of every backward pass (VaeLossFn)"""
+    _LATE.clear()                           # (their gradients belong to the aborted pass)
     if _DEFERRED:
         _join_deferred()
 
@@ -726,6 +753,17 @@ DEC_SIDE2 = int(os.environ.get('PTV_DEC_SIDE2', '-1'))
 CHD_BWD_PERSIST = os.environ.get('PTV_CHD_BWD_PERSIST', '1') != '0'      # (0 measured slower: 8.83 vs 8.54-8.66 ms)
 BIGRU_SLOT = int(os.environ.get('PTV_BIGRU_SLOT', '7'))
 BIGRU_SLOT_BWD = int(os.environ.get('PTV_BIGRU_SLOT_BWD', '7'))
+# Round-4 scheduling experiments on the step's tail (scripts/trace_calls.py shows it launch by launch; scripts/micro/queue_map.py: pool
+# streams 2 and 3 SHARE one of the 4 hardware queues, a queue runs its dispatches in order).  All measured slower than the plain scheme
+# (each direction's products right behind its BPTT, second direction on the sibling stream): 8.43 ms per step at B = 512 against
+#   BIGRU_CHAIN_FIRST (both BPTTs + both dX products on the node's stream, all 8 parameter-gradient products deferred):   8.75
+#   + BIGRU_LATE (those products launched when the backward pass ends, spread over 3 streams: "chains first, bulk last"):  8.75-8.95
+#   ROW_TURNS (the row-partitioned summary GRUs take turns with the persistent launches whose LDS they crowd):             8.48
+# -- the bulk products overlapping the latency-bound chains is what fills the GPU; taking them out of the chains' way leaves the chains
+# no faster (they are bound by their own hand-offs) and the bulk exposed at the end.
+BIGRU_CHAIN_FIRST = os.environ.get('PTV_BIGRU_CHAIN_FIRST', '0') != '0'
+BIGRU_LATE = os.environ.get('PTV_BIGRU_LATE', '1') != '0'
+ROW_TURNS = os.environ.get('PTV_ROW_TURNS', '0') != '0'
 FORK_EARLY = os.environ.get('PTV_FORK_EARLY', '0') != '0'
 DP_INPLACE = os.environ.get('PTV_DP_INPLACE', '1') != '0'        # decoder backward accumulates into the loss node's dpitch buffer (no 134-MB copy)
 # the backward passes over work whose result is exactly zero: note steps / tiles at which no gradient arrives (the loss ignores the
@@ -759,13 +797,19 @@ def wgrad_bias(dy, x, gw, gb, prec, k_top=None, k_unit=0, k_rev=0):
     return gw, gb
 
 
+# The fused duration GRU does not write its gate planes (5 steps x 4 planes x [M, 64] bf16 = 629 MB at B = 512, 63 % of the forward
+# kernel's writes); its backward rebuilds them from the states it reads anyway (csrc/dur_bwd.hip, recompute mode).  0 = save them.
+DUR_RECOMPUTE = os.environ.get('PTV_DUR_RECOMPUTE', '1') != '0'
+
+
 def dur_bwd_fusable(prec, Hd, gates_d):
-    return prec == 1 and Hd == 64 and FUSED_DUR and gates_d.dtype == BF16
+    return prec == 1 and Hd == 64 and FUSED_DUR and (gates_d is None or gates_d.dtype == BF16)
 
 
-def dur_bwd_fused(P, G, gates_d, idx, HD, HDo, ddur, wgrad, bgrad, side):
+def dur_bwd_fused(P, G, gates_d, idx, HD, HDo, ddur, wgrad, bgrad, side, tabs=None):
     """backward of the 5-step duration GRU as one kernel (csrc/dur_bwd.hip) -> dHD0 [M, Hd]; the parameter gradients
-    come back as per-block partials that a column sum + ptv_dur_bwd_finalize fold into G on a side stream"""
+    come back as per-block partials that a column sum + ptv_dur_bwd_finalize fold into G on a side stream.
+    gates_d None: the forward did not save its gates; tabs = (tab0, tab) it was given"""
     _, M, Hd = HD.shape
     dev = HD.device
     nblk = min(256, (M + 63) // 64)
@@ -773,8 +817,9 @@ def dur_bwd_fused(P, G, gates_d, idx, HD, HDo, ddur, wgrad, bgrad, side):
     part = _empty(nblk, psz, dev=dev)
     dHD0 = _empty(M, Hd, dev=dev)
     hsrc = HDo if HDo.dtype == BF16 else HD                 # bf16 state copies when the forward kept them (half the reads)
+    rc = (ptr(P['dec_dur_gru.bias_hh_l0']), ptr(tabs[0]), ptr(tabs[1])) if gates_d is None else (None, None, None)
     call('ptv_dur_gru_bwd', Hd, M, ptr(gates_d), M * Hd, 4 * M * Hd, ptr(hsrc), M * Hd, int(hsrc.dtype == BF16), ptr(ddur), 10,
-         ptr(P['dec_dur_gru.weight_hh_l0']), ptr(P['dur_out_linear.weight']), ptr(idx), M, ptr(dHD0), ptr(part), nblk,
+         ptr(P['dec_dur_gru.weight_hh_l0']), ptr(P['dur_out_linear.weight']), ptr(idx), M, ptr(dHD0), ptr(part), nblk, *rc,
          stream_ptr())
 
     def dur_wgrads():
@@ -841,6 +886,7 @@ class Transpose01Fn(torch.autograd.Function):
 # =============================================================================================
 # PtvaeDecoder.emb_x  (ptvae.py:531-535)
 # =============================================================================================
+BIGRU_ROWS_OVERLAP = os.environ.get('PTV_BIGRU_ROWS_OVERLAP', '1') != '0'
 DEFAULT_GEOM = (32, 16, 130, 5, 130)                    # (num_step, max_simu_note, pitch_range, dur_width, pitch_pad) of init_model()
 
 
@@ -954,10 +1000,13 @@ def _bigru_forward(prec, x3, lengths, w):
                  ptr(lengths) if lengths is not None else None, ptr(hall), ptr(h16), ptr(gates), out.data_ptr() + 4 * d * H, 2 * H,
                  M, T, d, stream_ptr())
             return hall, gates, h16, (lengths if ZERO_SKIP else None)      # the backward must skip the same fully masked panel steps
-        side = Side(BIGRU_SLOT)
-        rev = side(lambda: rows(1), x3, out)
-        fwd = rows(0)
-        side.join()
+        with (_PersistTurn() if (ROW_TURNS and not capturing_part()) else contextlib.nullcontext()):
+            if not BIGRU_ROWS_OVERLAP:
+                return out, [rows(0), rows(1)]
+            side = Side(BIGRU_SLOT)
+            rev = side(lambda: rows(1), x3, out)
+            fwd = rows(0)
+            side.join()
         return out, [fwd, rev]
 
     side = Side(BIGRU_SLOT)
@@ -967,8 +1016,11 @@ def _bigru_forward(prec, x3, lengths, w):
     return out, [fwd, rev]
 
 
-def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None):
+def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None, pending=None):
     """-> ([dw_ih, dw_hh, db_ih, db_hh] x 2 directions, dx [T,M,I] or None).
+    pending (a list, or None): chain-first mode (BIGRU_CHAIN_FIRST) -- the BPTTs of both directions and both input-gradient products run on
+    the caller's stream, ALL eight parameter-gradient products go to the sibling stream, which is NOT joined: its Side handle is appended
+    to `pending` and the caller defers or joins it.
     dx_acc ([T*M, I] fp32, or None): a gradient that already arrived at x3 from another consumer -- both directions' input-gradient
     products ACCUMULATE into it and it is returned as dx (round 4: autograd used to add the two consumers' 134-MB gradients of the note
     embedding with an ATen kernel, and the two directions' dx met in a copy kernel; now both are the accumulate mode of products that
@@ -997,7 +1049,7 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None):
             late['dgi'], late['top'] = dgi2, None
         return [dw_ih, dw_hh, db_ih, db_hh], (dx_of(0, dgi2, None, True) if d == 0 else None)
 
-    def products(d, dgi, dgh, top=None):
+    def products(d, dgi, dgh, top=None, with_dx=True):
         """top (device int, from the BPTT kernel): no row is longer than top + 1, so dgi (indexed by time) is zero after that time
         and dgh (indexed by processing step) after that step -- or, in the reversed direction, BEFORE step T - top - 1"""
         w_ih, w_hh, b_ih, b_hh = w[4 * d: 4 * d + 4]
@@ -1008,7 +1060,40 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None):
                                   k_rev=T if d else 0)
         if d:
             late['dgi'], late['top'] = dgi2, top
-        return [dw_ih, dw_hh, db_ih, db_hh], (dx_of(0, dgi2, top, True) if d == 0 else None)
+        return [dw_ih, dw_hh, db_ih, db_hh], (dx_of(0, dgi2, top, True) if (d == 0 and with_dx) else None)
+
+    def chain_first(res):
+        """res[d] = (dgi, dgh, top) of the two BPTTs, produced on this stream.  The input gradient is what the rest of the backward pass
+        waits for: both of its products first, here; the eight parameter-gradient products are bulk -- handed to the caller as a closure
+        (`pending`) that fills buffers returned NOW (round 4: the second direction's BPTT and the join used to queue behind the decoder's
+        deferred weight-gradient products on the sibling stream -- 0.6 ms of the step's tail)"""
+        dx = None
+        if need_dx:
+            for d in range(2):
+                dgi2 = res[d][0].view(T * M, 3 * H)
+                top = res[d][2]
+                kw = dict(prec=prec, m_top=top, m_unit=M if top is not None else 0)
+                if d == 0 and dx_acc is None:
+                    dx = gemm_dx(dgi2, w[0], **kw)
+                else:
+                    dx = gemm_dx(dgi2, w[4 * d], out=dx_acc if d == 0 else dx, acc=True, **kw)
+        bufs = [[_gbuf(w[4 * d]), _gbuf(w[4 * d + 1]), _gbuf(w[4 * d + 2]), _gbuf(w[4 * d + 3])] for d in range(2)]   # ih, hh, b_ih, b_hh
+
+        # (the closure writes through ALIASES: a second reference to the tensors handed to autograd would make AccumulateGrad clone them
+        # -- still empty -- instead of adopting them)
+        al = [[t.view(t.shape) for t in row] for row in bufs]
+
+        def wgrads():
+            for d in range(2):
+                dgi, dgh, top = res[d]
+                hall, _gates, h16 = saved[d][:3]
+                wgrad_bias(dgi.view(T * M, 3 * H), xf, al[d][0], al[d][2], prec, top, M)
+                wgrad_bias(dgh.view(T * M, 3 * H), (h16 if h16 is not None else hall)[:T].view(T * M, H), al[d][1], al[d][3], prec, top, M,
+                           k_rev=T if d else 0)
+        # (keep-alive: everything the products read -- the saved forward state dies with the node, the BPTT outputs with this frame)
+        pending.append((wgrads, [xf, dout, saved, [r[:2] for r in res], [r[2] for r in res]]))
+        g = [bufs[0][0], bufs[0][1], bufs[0][2], bufs[0][3], bufs[1][0], bufs[1][1], bufs[1][2], bufs[1][3]]
+        return g, (dx.view(T, M, I) if need_dx else None)
 
     side = Side(BIGRU_SLOT_BWD)
     wts = [_WT(w[1], prec), _WT(w[5], prec)]
@@ -1023,6 +1108,8 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None):
                                dgi=_empty(T, M, 3 * H, dev=x3.device, dtype=adt), dgh=_empty(T, M, 3 * H, dev=x3.device, dtype=adt),
                                dh0=None, reverse=bool(d)))
         gru_persist_bwd(M, H, T, chains)
+        if pending is not None:
+            return chain_first([(c['dgi'], c['dgh'], None) for c in chains])
         g1, _ = side(lambda: products(1, chains[1]['dgi'], chains[1]['dgh']), xf, dout, chains[1]['dgi'], chains[1]['dgh'])
         g0, dx0 = products(0, chains[0]['dgi'], chains[0]['dgh'])
     elif (len(saved[0]) > 3 and saved[0][1].dtype == BF16 and saved[0][2] is not None):
@@ -1039,7 +1126,13 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None):
             top = _ineg1(x3.device) if (lengths is not None and M % 32 == 0) else None
             call('ptv_row_gru_persist_bwd', H, ptr(pk['wt']), ptr(hall), ptr(gates), None, dout.data_ptr() + 4 * d * H, dout.stride(0),
                  ptr(lengths) if lengths is not None else None, ptr(dgi), ptr(dgh), None, ptr(scratch), M, T, d, ptr(top), stream_ptr())
+            if pending is not None:
+                return dgi, dgh, top
             return products(d, dgi, dgh, top)
+        if pending is not None:
+            with (_PersistTurn() if ROW_TURNS else contextlib.nullcontext()):
+                res = [rows(0), rows(1)]
+            return chain_first(res)
         g1, _ = side(lambda: rows(1), xf, dout)
         g0, dx0 = rows(0)
     else:
@@ -1092,15 +1185,29 @@ class BiGruFinalFn(torch.autograd.Function):
         if ctx.link is not None and ctx.link['demb'] is not None and ctx.needs_input_grad[0]:
             dx_acc, ctx.link['demb'] = ctx.link['demb'].view(-1, x3.shape[2]), None     # the decoder node's gradient of the same tensor
             _EMB_LINK.pop(x3.data_ptr(), None)
-        grads, dx = _bigru_backward(ctx.prec, x3, w, ctx.saved_state, dout.contiguous(), ctx.needs_input_grad[0], dx_acc)
+        pending = [] if (BIGRU_CHAIN_FIRST and OVERLAP and not capturing_part()) else None
+        grads, dx = _bigru_backward(ctx.prec, x3, w, ctx.saved_state, dout.contiguous(), ctx.needs_input_grad[0], dx_acc, pending)
         mark('bigru_bwd:end M=%d @%x' % (x3.shape[1], stream_ptr() & 0xffff))
         ctx.saved_state = None
-        if GRAD_READY_HOOK is not None:                   # data parallel: a bi-GRU's 8 gradients are final here (its side stream is joined)
-            from .optim import is_arena_view
-            # (w is ordered by direction, the products return [ih, hh, b_ih, b_hh] per direction)
-            pairs = list(zip(w[0:4], grads[0:4])) + list(zip(w[4:8], grads[4:8]))
-            if all(p_.grad is None and is_arena_view(p_, g_) for p_, g_ in pairs):
-                GRAD_READY_HOOK([p_ for p_, _ in pairs], ())
+        from .optim import is_arena_view
+        # (w is ordered by direction, the products return [ih, hh, b_ih, b_hh] per direction)
+        pairs = list(zip(w[0:4], grads[0:4])) + list(zip(w[4:8], grads[4:8]))
+        adopted = all(p_.grad is None and is_arena_view(p_, g_) for p_, g_ in pairs)
+        streams, final = (), True
+        for fn, keep in (pending or ()):
+            # parameter gradients only: they may be computed after this node returns -- if autograd ADOPTS the buffers (DecoderTFFn.backward)
+            if adopted and BIGRU_LATE:
+                late(fn, *keep)                           # at the end of the backward pass, spread over the sibling streams
+                final = False
+            elif adopted:
+                sd = Side(BIGRU_SLOT_BWD)
+                sd(fn, *keep)
+                streams += (sd.s,)
+                sd.defer()
+            else:
+                fn()
+        if GRAD_READY_HOOK is not None and adopted and final:       # data parallel: a bi-GRU's 8 gradients are final once `streams` drain
+            GRAD_READY_HOOK([p_ for p_, _ in pairs], streams)
         return (dx, None, None) + tuple(grads)
 
 
@@ -1443,11 +1550,12 @@ class DecoderTFFn(torch.autograd.Function):
         w_ih_d, b_ih_d = W['dec_dur_gru.weight_ih_l0'], P['dec_dur_gru.bias_ih_l0']
         tab0 = gemm(P['dur_sos_token'].view(1, -1), w_ih_d, bias=b_ih_d, prec=0)       # [1, 3Hd]  (tiny: exact)
         tab = gemm(_onehot2x5(dev), w_ih_d, bias=b_ih_d, prec=0)                       # [2, 3Hd]
-        gates_d = _empty(5, 4, M, Hd, dev=dev, dtype=_act_dtype(prec, Hd))
+        fused_dur = prec == 1 and Hd == 64 and FUSED_DUR
+        gates_d = None if (fused_dur and DUR_RECOMPUTE and HD16 is not None) else _empty(5, 4, M, Hd, dev=dev, dtype=_act_dtype(prec, Hd))
         dur = _empty(M, 5, 2, dev=dev)
         idx = torch.empty(5, M, device=dev, dtype=torch.int32)
         dur2 = dur.view(M, 10)
-        if prec == 1 and Hd == 64 and FUSED_DUR:
+        if fused_dur:
             # one kernel for the 5 steps + output layer + argmax feedback (dur.hip)
             call('ptv_dur_gru_fwd', Hd, M, ptr(HD[0]), Hd, ptr(P['dec_dur_gru.weight_hh_l0']), ptr(P['dec_dur_gru.bias_hh_l0']),
                  ptr(tab0), ptr(tab), ptr(P['dur_out_linear.weight']), ptr(P['dur_out_linear.bias']),
@@ -1471,6 +1579,7 @@ class DecoderTFFn(torch.autograd.Function):
         S.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in, NS16=NS16, HN16=HN16,
                     HD16=HD16,
                     TOKS=TOKS, gates_t=gates_t, HN=HN, gates_n=gates_n, gates_n_rowk=gates_n_rowk, pitch=pitch, HD=HD, gates_d=gates_d, idx=idx,
+                    dur_tabs=(tab0, tab),
                     dur16_only=bool(prec == 1 and Hd == 64 and FUSED_DUR and HD16 is not None))   # HD[1:] never written
         S.mark_non_differentiable(idx)
         return pitch.view(15, 32, B, NP), dur, idx
@@ -1575,7 +1684,7 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     w_out = P['dur_out_linear.weight']
     w_hh_d, w_ih_d = W['dec_dur_gru.weight_hh_l0'], W['dec_dur_gru.weight_ih_l0']
     if dur_bwd_fusable(prec, Hd, st['gates_d']) or st.get('dur16_only'):
-        dHD0 = dur_bwd_fused(P, G, st['gates_d'], st['idx'], HD, HDo, ddur, wgrad, bgrad, side)
+        dHD0 = dur_bwd_fused(P, G, st['gates_d'], st['idx'], HD, HDo, ddur, wgrad, bgrad, side, tabs=st.get('dur_tabs'))
     else:
         dgi_d, dgh_d, dHD0 = gru_bwd(prec, HD, st['gates_d'], w_hh_d, lr=(ddur, 2, 10, 2, w_out))
 

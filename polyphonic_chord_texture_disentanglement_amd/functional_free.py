@@ -232,6 +232,8 @@ class DecoderStepFn(torch.autograd.Function):
         replay = (fast and train and FREE_REPLAY and F_.notes_persist_ok(prec, Hn, E) and Hd == 64 and F_.FUSED_DUR and NS16 is not None
                   and force_dur is None and force_pitch is None)
         XH = XG = None
+        if replay and F_.DUR_RECOMPUTE and HD16 is not None:
+            gates_d = None                                         # the batched recompute's duration GRU saves no gates (csrc/dur_bwd.hip rebuilds them)
         if need_resum and replay:                                # the batched recompute writes every row of every slot but slot 0
             XH = [_empty(17, R, He, dev=dev) for _ in range(2)]
             for d in range(2):
@@ -375,7 +377,7 @@ class DecoderStepFn(torch.autograd.Function):
             ctx.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in, TOKS=TOKS,
                           gates_t=gates_t, HN=HN, gates_n=gates_n, gates_n_rowk=bool(replay), pitch=pitch, HD=HD, gates_d=gates_d, idx=idx, TOK=TOK,
                           PRED=PRED, xhat=xhat, XH=XH, XG=XG, XH16=XH16, plen=plen, skipped=F_.ZERO_SKIP, coins=coins, has_xs=xs is not None,
-                          NS16=NS16, HN16=HN16, HD16=HD16, dur16_only=HD16 is not None)
+                          NS16=NS16, HN16=HN16, HD16=HD16, dur16_only=HD16 is not None, dur_tabs=(tab0, tab))
         ctx.mark_non_differentiable(xhat, idx)
         return pitch.view(15, 32, B, NP), dur, xhat, idx
 

@@ -19,8 +19,12 @@ LOSS_NAMES = ['loss', 'recon_loss', 'pl', 'dl', 'kl_loss', 'kl_chd', 'kl_rhy', '
 
 
 CHD_ENC_SLOT = int(os.environ.get('PTV_CHD_ENC_SLOT', '1'))
+RHY_ENC_SLOT = int(os.environ.get('PTV_RHY_ENC_SLOT', '2'))
 EMB_FIRST = os.environ.get('PTV_EMB_FIRST', '0') != '0'
 EMB_SLOT = int(os.environ.get('PTV_EMB_SLOT', '4'))
+# The two encoders ARE the latency chain of the head of the step (the decoder waits for z; the embedding / note summaries beside them are
+# needed later): their products keep the raised wave priority although they run inside sibling-stream calls, the note-summary GRUs drop it
+ENC_CHAIN = os.environ.get('PTV_ENC_CHAIN', '1') != '0'
 
 
 class DisentangleVAE(PytorchModel):
@@ -73,7 +77,7 @@ class DisentangleVAE(PytorchModel):
         # what its parent has queued so far, and the embedding (queued on the parent next) is not their input
         from .ptvae import _require_cuda
         _require_cuda(x, 'DisentangleVAE.run')               # (fails loudly off-GPU before any stream is touched)
-        s_chd, s_rhy = F_.Side(CHD_ENC_SLOT), F_.Side(2)
+        s_chd, s_rhy = F_.Side(CHD_ENC_SLOT, chain=ENC_CHAIN), F_.Side(RHY_ENC_SLOT, chain=ENC_CHAIN)
         self.decoder.summaries_needed = tfr1 > 0             # with tfr1 = 0 no time step is fed a ground-truth note summary
         s_emb = None
         if EMB_FIRST and F_.OVERLAP:

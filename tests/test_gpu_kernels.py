@@ -369,10 +369,32 @@ def test_fused_duration_kernels_at_the_b512_grid_caps():
     part = torch.zeros(nblk, psz, device=dev)
     dh0 = torch.empty(M, H, device=dev)
     call('ptv_dur_gru_bwd', H, M, ptr(gates), M * H, 4 * M * H, ptr(HD16), M * H, 1, ptr(Wd['ddur']), 10, ptr(Wd['w_hh']), ptr(Wd['w_out']),
-         ptr(idx), M, ptr(dh0), ptr(part), nblk, stream_ptr())
+         ptr(idx), M, ptr(dh0), ptr(part), nblk, None, None, None, stream_ptr())
     assert (dh0.cpu()[rows] - hr.grad).abs().max() < 0.05 * max(1.0, hr.grad.abs().max().item())
     assert torch.isfinite(part).all() and torch.isfinite(dh0).all()
     assert (dh0[M - 64 * 3:] == 0).all() and (dh0[M // 2 + 128: M // 2 + 64 * 49] == 0).all()
+    # RECOMPUTE mode (what the train step runs): the forward saves no gates, the backward rebuilds them from the bf16 states.  Same
+    # states / logits / decisions bit for bit; gradients at least as close to the fp32 oracle as with the bf16-rounded saved gates
+    HD16b = torch.zeros(6, M, H, device=dev, dtype=bf)
+    dur_b = torch.empty(M, 10, device=dev)
+    idx_b = torch.empty(5, M, device=dev, dtype=torch.int32)
+    call('ptv_dur_gru_fwd', H, M, ptr(h0d), H, ptr(Wd['w_hh']), ptr(Wd['b_hh']), ptr(Wd['tab0']), ptr(Wd['tab']), ptr(Wd['w_out']),
+         ptr(Wd['b_out']), None, M * H, ptr(HD16b[1]), None, M * H, 4 * M * H, 1, ptr(dur_b), 10, ptr(idx_b), M, None, M, stream_ptr())
+    call('ptv_cast_bf16', ptr(h0d), ptr(HD16b[0]), M * H, stream_ptr())
+    assert torch.equal(HD16b, HD16) and torch.equal(dur_b, dur) and torch.equal(idx_b, idx)
+    part_b = torch.zeros(nblk, psz, device=dev)
+    dh0_b = torch.empty(M, H, device=dev)
+    assert lib().ptv_dur_gru_bwd(H, M, None, M * H, 4 * M * H, ptr(HD16b), M * H, 1, ptr(Wd['ddur']), 10, ptr(Wd['w_hh']), ptr(Wd['w_out']),
+                                 ptr(idx_b), M, ptr(dh0_b), ptr(part_b), nblk, None, None, None, stream_ptr()) != 0     # tables are required
+    call('ptv_dur_gru_bwd', H, M, None, M * H, 4 * M * H, ptr(HD16b), M * H, 1, ptr(Wd['ddur']), 10, ptr(Wd['w_hh']), ptr(Wd['w_out']),
+         ptr(idx_b), M, ptr(dh0_b), ptr(part_b), nblk, ptr(Wd['b_hh']), ptr(Wd['tab0']), ptr(Wd['tab']), stream_ptr())
+    gmax = max(1.0, hr.grad.abs().max().item())
+    err_saved, err_rc = (dh0.cpu()[rows] - hr.grad).abs().max().item(), (dh0_b.cpu()[rows] - hr.grad).abs().max().item()
+    assert err_rc < 0.05 * gmax and err_rc <= err_saved * 1.25 + 1e-4, (err_saved, err_rc)
+    assert (dh0_b - dh0).abs().max() < 0.02 * gmax
+    Sa, Sb = part.sum(0), part_b.sum(0)
+    assert (Sa - Sb).abs().max() < 0.02 * max(1.0, Sa.abs().max().item())
+    assert (dh0_b[M - 64 * 3:] == 0).all() and (dh0_b[M // 2 + 128: M // 2 + 64 * 49] == 0).all()
 
 
 def test_integration_md_snippet_runs_verbatim():
