@@ -232,9 +232,13 @@ int ptv_txt_conv_relu_pool_bwd(const float* pr_mat, const float* w, const float*
 /* the same with the pooled map held as the rows of the reference's raw view (ptvae.py:114): feat [B*8][ld], ld >= C*29 -- element
  * (b, ch, beat, pp) at row b*8 + f / (C*29), column f % (C*29), f = (ch*8 + beat)*29 + pp.  A 16-byte-multiple ld keeps the rows of fc1's
  * operand aligned for the MFMA loaders; ld = C*29 is the plain tensor of the entry points above. */
-int ptv_txt_conv_relu_pool_fwd_rows(const float* pr_mat, const float* w, const float* bias, float* feat, long ld, int B, int C, void* stream);
+int ptv_txt_conv_relu_pool_fwd_rows(const float* pr_mat, const float* w, const float* bias, float* feat, long ld, int B, int C,
+                                    signed char* arg, void* stream);
+/* arg (may be NULL): int8 [B*8][C*29], written by the forward -- which of the 4 pooled positions won (-1: ReLU cut all four).  Given to the
+ * backward, the convolution is not recomputed (w / bias may then be NULL): same decisions, same gradients, a fifth of the arithmetic
+ * (this kernel is the LAST launch of the backward pass's longest chain) */
 int ptv_txt_conv_relu_pool_bwd_rows(const float* pr_mat, const float* w, const float* bias, const float* dfeat, long ld,
-                                    float* dw, float* dbias, int B, int C, void* stream);
+                                    float* dw, float* dbias, int B, int C, const signed char* arg, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * reparameterize(): get_zs_from_dists / Normal.rsample (amc_dl/torch_plus/train_utils.py:33-34)

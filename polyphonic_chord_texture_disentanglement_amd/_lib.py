@@ -81,7 +81,7 @@ def prec_code(p):
     return _PREC[p]
 
 
-_OK_DTYPES = frozenset((torch.float32, torch.bfloat16, torch.int32, torch.int64, torch.uint8))
+_OK_DTYPES = frozenset((torch.float32, torch.bfloat16, torch.int32, torch.int64, torch.uint8, torch.int8))
 # Always checked (ptr() runs ~3000 times per train step, so only what costs tens of nanoseconds): the tensor lives on a GPU (no CPU
 # fallback), has one of the dtypes the library takes at all, and -- in a process that sees more than one GPU -- lives on the CURRENT
 # device (kernels are enqueued on the current device's stream: a tensor of another device would be a wild pointer).

@@ -20,8 +20,10 @@ __device__ __forceinline__ long tx_index(int b, int ch, int beat, int pp, int C,
 }
 
 // one block iteration = one (b, beat); thread -> (ch, pp)
+// arg (optional): [B*8][C*29] int8 -- which of the 4 pooled positions won (first max, as MaxPool2d), -1 where ReLU cut all four: what the
+// backward needs of the recomputed convolution
 __global__ void txt_conv_fwd_kernel(const float* __restrict__ pr, const float* __restrict__ w, const float* __restrict__ bias,
-                                    float* __restrict__ pooled, int B, int C, long ld) {
+                                    float* __restrict__ pooled, int B, int C, long ld, signed char* __restrict__ arg) {
   __shared__ float rows[4][128];
   __shared__ float ws[TX_MAXC * 48 + TX_MAXC];
   for (int i = threadIdx.x; i < C * 48; i += blockDim.x) ws[i] = w[i];
@@ -36,6 +38,7 @@ __global__ void txt_conv_fwd_kernel(const float* __restrict__ pr, const float* _
       const int ch = o / 29, pp = o % 29;
       const float* wc = ws + ch * 48;
       float best = 0.f;                       // ReLU floor: max(relu(v_q)) = max(0, max v_q)
+      int bq = -1;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int p0 = pp * 4 + q;
@@ -44,9 +47,10 @@ __global__ void txt_conv_fwd_kernel(const float* __restrict__ pr, const float* _
         for (int i = 0; i < 4; i++)
 #pragma unroll
           for (int j = 0; j < 12; j++) v += wc[i * 12 + j] * rows[i][p0 + j];
-        best = fmaxf(best, v);
+        if (v > best) { best = v; bq = q; }      // first max wins ties, as MaxPool2d does
       }
       pooled[tx_index(b, ch, beat, pp, C, ld)] = best;
+      if (arg) arg[it * nout + o] = (signed char)bq;
     }
     if (beat == 0 && ld > nout) {                                  // the row padding of this sample's 8 rows: finite (zero), never data
       const int padw = (int)(ld - nout);
@@ -83,14 +87,17 @@ __device__ __forceinline__ void ordered_commit_tx(float* dw, float* dbias, const
 
 // dW[ch,i,j] += sum dpool * [conv>0 at the arg-max q] * pr ; dbias likewise.  Conv is recomputed.
 __global__ void txt_conv_bwd_kernel(const float* __restrict__ pr, const float* __restrict__ w, const float* __restrict__ bias,
-                                    const float* __restrict__ dpooled, float* __restrict__ dw, float* __restrict__ dbias, int B, int C, long ld, OrdScratch sc) {
+                                    const float* __restrict__ dpooled, float* __restrict__ dw, float* __restrict__ dbias, int B, int C, long ld, OrdScratch sc,
+                                    const signed char* __restrict__ arg) {
   __shared__ float stage[TX_MAXC * 29][7];
   constexpr int NB = 4;                                           // (sample, beat) items per trip: their 2-KB row loads are in flight together
   __shared__ float rows[NB][4][128];
   __shared__ float ws[TX_MAXC * 48 + TX_MAXC];
   __shared__ float acc[TX_MAXC * 49];
-  for (int i = threadIdx.x; i < C * 48; i += blockDim.x) ws[i] = w[i];
-  for (int i = threadIdx.x; i < C; i += blockDim.x) ws[C * 48 + i] = bias[i];
+  if (!arg) {
+    for (int i = threadIdx.x; i < C * 48; i += blockDim.x) ws[i] = w[i];
+    for (int i = threadIdx.x; i < C; i += blockDim.x) ws[C * 48 + i] = bias[i];
+  }
   for (int i = threadIdx.x; i < C * 49; i += blockDim.x) acc[i] = 0.f;
   const int nout = C * 29;
   // thread o = threadIdx.x (< nout) keeps a private gradient for its channel across all iterations
@@ -112,10 +119,12 @@ __global__ void txt_conv_bwd_kernel(const float* __restrict__ pr, const float* _
     }
     // this thread's pooled gradients of the NB items: requested before the barrier, consumed after the recomputed convolutions
     float dn[NB];
+    int an[NB];
 #pragma unroll
     for (int n = 0; n < NB; n++) {
       const long it = base + n;
       dn[n] = (o < nout && it < total) ? dpooled[tx_index((int)(it / 8), ch, (int)(it % 8), pp, C, ld)] : 0.f;
+      an[n] = (arg && o < nout && it < total) ? (int)arg[it * nout + o] : -1;
     }
     __syncthreads();
     if (o < nout) {
@@ -124,15 +133,18 @@ __global__ void txt_conv_bwd_kernel(const float* __restrict__ pr, const float* _
       for (int n = 0; n < NB; n++) {
         if (base + n >= total) break;
         float best = 0.f; int bq = -1;
+        if (arg) bq = an[n];                       // the forward's decision (same arithmetic, same result -- without the 192 MACs)
+        else {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int p0 = pp * 4 + q;
-          float v = ws[C * 48 + ch];
+          for (int q = 0; q < 4; q++) {
+            const int p0 = pp * 4 + q;
+            float v = ws[C * 48 + ch];
 #pragma unroll
-          for (int i = 0; i < 4; i++)
+            for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int j = 0; j < 12; j++) v += wc[i * 12 + j] * rows[n][i][p0 + j];
-          if (v > best) { best = v; bq = q; }      // first max wins ties, as MaxPool2d does
+              for (int j = 0; j < 12; j++) v += wc[i * 12 + j] * rows[n][i][p0 + j];
+            if (v > best) { best = v; bq = q; }      // first max wins ties, as MaxPool2d does
+          }
         }
         if (bq >= 0) {
           const float d = dn[n];
@@ -180,29 +192,31 @@ __global__ void txt_conv_bwd_kernel(const float* __restrict__ pr, const float* _
 
 using namespace ptv;
 
-extern "C" int ptv_txt_conv_relu_pool_fwd_rows(const float* pr_mat, const float* w, const float* bias, float* feat, long ld, int B, int C, void* stream) {
+extern "C" int ptv_txt_conv_relu_pool_fwd_rows(const float* pr_mat, const float* w, const float* bias, float* feat, long ld, int B, int C,
+                                               signed char* arg, void* stream) {
   if (!pr_mat || !w || !bias || !feat || B <= 0 || C <= 0 || C > TX_MAXC || ld < C * 29) return PTV_ERR_ARG;
   int grid = B * 8 < 2048 ? B * 8 : 2048;
-  hipLaunchKernelGGL(txt_conv_fwd_kernel, dim3(grid), dim3(320), 0, (hipStream_t)stream, pr_mat, w, bias, feat, B, C, ld);
+  hipLaunchKernelGGL(txt_conv_fwd_kernel, dim3(grid), dim3(320), 0, (hipStream_t)stream, pr_mat, w, bias, feat, B, C, ld, arg);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
 extern "C" int ptv_txt_conv_relu_pool_fwd(const float* pr_mat, const float* w, const float* bias, float* pooled, int B, int C, void* stream) {
-  return ptv_txt_conv_relu_pool_fwd_rows(pr_mat, w, bias, pooled, (long)C * 29, B, C, stream);
+  return ptv_txt_conv_relu_pool_fwd_rows(pr_mat, w, bias, pooled, (long)C * 29, B, C, nullptr, stream);
 }
 
 extern "C" int ptv_txt_conv_relu_pool_bwd_rows(const float* pr_mat, const float* w, const float* bias, const float* dfeat, long ld,
-                                               float* dw, float* dbias, int B, int C, void* stream) {
-  if (!pr_mat || !w || !bias || !dfeat || !dw || !dbias || B <= 0 || C <= 0 || C > TX_MAXC || ld < C * 29) return PTV_ERR_ARG;
+                                               float* dw, float* dbias, int B, int C, const signed char* arg, void* stream) {
+  if (!pr_mat || !dfeat || !dw || !dbias || B <= 0 || C <= 0 || C > TX_MAXC || ld < C * 29) return PTV_ERR_ARG;
+  if (!arg && (!w || !bias)) return PTV_ERR_ARG;                  // without the forward's arg-max map the convolution is recomputed
   int nthreads = ((C * 29 + 63) / 64) * 64;       // one thread per (ch, pp)
   int grid = (B * 8 + 3) / 4 < 512 ? (B * 8 + 3) / 4 : 512;       // four items per trip
   OrdScratch sc = ord_scratch((hipStream_t)stream, 256L * C * 49, 1);
   if (sc.slots && grid > 256) grid = 256;                         // (the last block adds `grid` partials per tap)
-  hipLaunchKernelGGL(txt_conv_bwd_kernel, dim3(grid), dim3(nthreads), 0, (hipStream_t)stream, pr_mat, w, bias, dfeat, dw, dbias, B, C, ld, sc);
+  hipLaunchKernelGGL(txt_conv_bwd_kernel, dim3(grid), dim3(nthreads), 0, (hipStream_t)stream, pr_mat, w, bias, dfeat, dw, dbias, B, C, ld, sc, arg);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
 extern "C" int ptv_txt_conv_relu_pool_bwd(const float* pr_mat, const float* w, const float* bias, const float* dpooled,
                                           float* dw, float* dbias, int B, int C, void* stream) {
-  return ptv_txt_conv_relu_pool_bwd_rows(pr_mat, w, bias, dpooled, (long)C * 29, dw, dbias, B, C, stream);
+  return ptv_txt_conv_relu_pool_bwd_rows(pr_mat, w, bias, dpooled, (long)C * 29, dw, dbias, B, C, nullptr, stream);
 }

@@ -750,6 +750,10 @@ EMBED_MH_FWD = os.environ.get('PTV_EMBED_MH_FWD', '1') != '0'    # multi-hot ope
 # them to another pool stream measured SLOWER (slot 8 / 6 / 5: 9.40 / 9.39 / 9.29 vs 9.09 ms): running everything at once costs more
 # in contention than the queueing does.
 DEC_SIDE2 = int(os.environ.get('PTV_DEC_SIDE2', '-1'))
+# chord decoder backward: the chain to dz first and the parameter gradients afterwards (in line, or CHD_BWD_BULK: deferred on a bulk stream)?
+# Measured SLOWER than the interleaved program order: 8.53 (in line) / 8.88 (bulk stream 3) vs 8.30 ms per step -- kept as a switch
+CHD_BWD_DZ_FIRST = os.environ.get('PTV_CHD_BWD_DZ_FIRST', '0') != '0'
+CHD_BWD_BULK = int(os.environ.get('PTV_CHD_BWD_BULK', '3'))     # stream slot of the chord decoder's parameter-gradient products (-1: in line)
 CHD_BWD_PERSIST = os.environ.get('PTV_CHD_BWD_PERSIST', '1') != '0'      # (0 measured slower: 8.83 vs 8.54-8.66 ms)
 BIGRU_SLOT = int(os.environ.get('PTV_BIGRU_SLOT', '7'))
 BIGRU_SLOT_BWD = int(os.environ.get('PTV_BIGRU_SLOT_BWD', '7'))
@@ -1273,6 +1277,9 @@ class ReparamFn(torch.autograd.Function):
 # =============================================================================================
 # TextureEncoder front end: conv + relu + maxpool   (ptvae.py:95-99,112-114)
 # =============================================================================================
+TXT_ARGMAX = os.environ.get('PTV_TXT_ARGMAX', '1') != '0'
+
+
 class TextureFrontFn(torch.autograd.Function):
     """pr_mat [B,32,128] -> the rows of the reference's raw view of the pooled conv map (ptvae.py:112-114): [B*8, C*29], held with a row
     stride padded to a multiple of 8 floats (fc1's operand: aligned rows for the MFMA loaders -- its weight gradient took the
@@ -1284,8 +1291,11 @@ class TextureFrontFn(torch.autograd.Function):
         pr_mat = pr_mat.contiguous()
         W = C * 29
         feat = _empty(B * 8, _pad8(W), dev=w.device)             # (the kernel zeroes the row padding)
-        call('ptv_txt_conv_relu_pool_fwd_rows', ptr(pr_mat), ptr(w), ptr(b), ptr(feat), feat.stride(0), B, C, stream_ptr())
+        # which pooled position won, for the backward (1 byte per output instead of recomputing the convolution there)
+        arg = torch.empty(B * 8, W, device=w.device, dtype=torch.int8) if (TXT_ARGMAX and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])) else None
+        call('ptv_txt_conv_relu_pool_fwd_rows', ptr(pr_mat), ptr(w), ptr(b), ptr(feat), feat.stride(0), B, C, ptr(arg), stream_ptr())
         ctx.save_for_backward(pr_mat, w, b)
+        ctx.arg = arg
         return feat[:, :W]
 
     @staticmethod
@@ -1294,8 +1304,9 @@ class TextureFrontFn(torch.autograd.Function):
         dw, db = _gbuf(w), _gbuf(b)
         if dfeat.stride(1) != 1:
             dfeat = dfeat.contiguous()
+        arg, ctx.arg = ctx.arg, None
         call('ptv_txt_conv_relu_pool_bwd_rows', ptr(pr_mat), ptr(w), ptr(b), ptr(dfeat), dfeat.stride(0), ptr(dw), ptr(db),
-             pr_mat.shape[0], w.shape[0], stream_ptr())
+             pr_mat.shape[0], w.shape[0], ptr(arg), stream_ptr())
         return None, dw, db
 
 
@@ -1904,46 +1915,107 @@ class ChordDecoderTFFn(torch.autograd.Function):
         prec, T, B, H, I = st['prec'], st['T'], st['B'], st['H'], st['I']
         dev = z.device
         hall, toks = st['hall'], st['toks']
-        hs = hall[1:].view(T * B, H)
-        G = {}
-        dhs = None
-        for name, dlog in (('root_out', droot), ('chroma_out', dchroma), ('bass_out', dbass)):
-            w = P[name + '.weight']
-            if dlog is None:
-                G[name + '.weight'], G[name + '.bias'] = _gbuf(w), _gbuf(P[name + '.bias'])
-                continue
-            d2 = dlog.contiguous().view(T * B, -1)
+        if not CHD_BWD_DZ_FIRST:
+            hs = hall[1:].view(T * B, H)
+            G = {}
+            dhs = None
+            for name, dlog in (('root_out', droot), ('chroma_out', dchroma), ('bass_out', dbass)):
+                w = P[name + '.weight']
+                if dlog is None:
+                    G[name + '.weight'], G[name + '.bias'] = _gbuf(w), _gbuf(P[name + '.bias'])
+                    continue
+                d2 = dlog.contiguous().view(T * B, -1)
+                if dhs is None:
+                    dhs = gemm(d2, w, tb=True, prec=prec)
+                else:
+                    gemm(d2, w, dhs, tb=True, acc=True, prec=prec)
+                G[name + '.weight'] = gemm(d2, hs, _gbuf(w), ta=True, tb=True, acc=True, prec=prec)
+                G[name + '.bias'] = _bgrad(P[name + '.bias'], d2)
             if dhs is None:
-                dhs = gemm(d2, w, tb=True, prec=prec)
+                dhs = _zeros(T * B, H, dev=dev)
+            w_hh, w_ih = P['gru.weight_hh_l0'], P['gru.weight_ih_l0']
+            # (per-step kernels, not the persistent launch: persistent launches take turns, and this short chain on its sibling stream had
+            # to wait for the decoder's 32-step time BPTT -- its dz then reached the chord encoder 0.3 ms after the decoder's own, round 4)
+            dgi, dgh, dh0 = gru_bwd(prec, hall, st['gates'], w_hh, dh_ext=dhs.view(T, B, H), allow_persist=CHD_BWD_PERSIST)
+            G['gru.weight_hh_l0'] = gemm(dgh.view(T * B, 3 * H), hall[:T].view(T * B, H), _gbuf(w_hh), ta=True, tb=True, acc=True,
+                                         prec=prec)
+            G['gru.bias_hh_l0'] = _bgrad(P['gru.bias_hh_l0'], dgh.view(T * B, 3 * H))
+            dzg = sum_steps(dgi)
+            G['gru.bias_ih_l0'] = _bgrad(P['gru.bias_ih_l0'], dzg)
+            g = _gbuf(w_ih)
+            gemm(dzg, st['z_in'], g[:, I:], ta=True, tb=True, acc=True, prec=prec)
+            gemm(dgi.view(T * B, 3 * H), toks.view(T * B, I), g[:, :I], ta=True, tb=True, acc=True, prec=prec)
+            G['gru.weight_ih_l0'] = g
+            dz_in = gemm(dzg, w_ih[:, I:], tb=True, prec=prec)
+            dtok0 = gemm(dgi[0], w_ih[:, :I], tb=True, prec=prec)                     # only the learned start token
+            G['init_input'] = _bgrad(P['init_input'], dtok0)
+            w_zh, w_zi = P['z2dec_hid.weight'], P['z2dec_in.weight']
+            dz = gemm(dh0, w_zh, tb=True, prec=prec)
+            gemm(dz_in, w_zi, dz, tb=True, acc=True, prec=prec)
+            G['z2dec_hid.weight'] = gemm(dh0, z, _gbuf(w_zh), ta=True, tb=True, acc=True, prec=prec)
+            G['z2dec_hid.bias'] = _bgrad(P['z2dec_hid.bias'], dh0)
+            G['z2dec_in.weight'] = gemm(dz_in, z, _gbuf(w_zi), ta=True, tb=True, acc=True, prec=prec)
+            G['z2dec_in.bias'] = _bgrad(P['z2dec_in.bias'], dz_in)
+        else:
+            hs = hall[1:].view(T * B, H)
+            G = {}
+            dhs = None
+            # The chain to dz first; every parameter gradient afterwards, on the bulk stream (CHD_BWD_BULK).  Round 4: the node used to interleave
+            # them in program order -- dz left 14 launches after the BPTT, the decoder's own dz had been waiting for it for 0.3 ms (the reparam
+            # node needs both), and autograd's hand-over event of this node sits behind ALL of its launches
+            bulk = []
+            for name, dlog in (('root_out', droot), ('chroma_out', dchroma), ('bass_out', dbass)):
+                w = P[name + '.weight']
+                G[name + '.weight'], G[name + '.bias'] = _gbuf(w), _gbuf(P[name + '.bias'])
+                if dlog is None:
+                    continue
+                d2 = dlog.contiguous().view(T * B, -1)
+                if dhs is None:
+                    dhs = gemm(d2, w, tb=True, prec=prec)
+                else:
+                    gemm(d2, w, dhs, tb=True, acc=True, prec=prec)
+                bulk.append((lambda d2=d2, gw=G[name + '.weight'], gb=G[name + '.bias']:
+                             (gemm(d2, hs, gw, ta=True, tb=True, acc=True, prec=prec), colsum(gb.view(1, -1), d2)), d2))
+            if dhs is None:
+                dhs = _zeros(T * B, H, dev=dev)
+            w_hh, w_ih = P['gru.weight_hh_l0'], P['gru.weight_ih_l0']
+            w_zh, w_zi = P['z2dec_hid.weight'], P['z2dec_in.weight']
+            dgi, dgh, dh0 = gru_bwd(prec, hall, st['gates'], w_hh, dh_ext=dhs.view(T, B, H), allow_persist=CHD_BWD_PERSIST)
+            dzg = sum_steps(dgi)
+            dz_in = gemm(dzg, w_ih[:, I:], tb=True, prec=prec)
+            dz = gemm(dh0, w_zh, tb=True, prec=prec)
+            gemm(dz_in, w_zi, dz, tb=True, acc=True, prec=prec)
+            for n in ('gru.weight_hh_l0', 'gru.bias_hh_l0', 'gru.bias_ih_l0', 'gru.weight_ih_l0', 'init_input', 'z2dec_hid.weight',
+                      'z2dec_hid.bias', 'z2dec_in.weight', 'z2dec_in.bias'):
+                G[n] = _gbuf(P[n])
+
+            def rest():
+                gemm(dgh.view(T * B, 3 * H), hall[:T].view(T * B, H), G['gru.weight_hh_l0'], ta=True, tb=True, acc=True, prec=prec)
+                colsum(G['gru.bias_hh_l0'].view(1, -1), dgh.view(T * B, 3 * H))
+                colsum(G['gru.bias_ih_l0'].view(1, -1), dzg)
+                g = G['gru.weight_ih_l0']
+                gemm(dzg, st['z_in'], g[:, I:], ta=True, tb=True, acc=True, prec=prec)
+                gemm(dgi.view(T * B, 3 * H), toks.view(T * B, I), g[:, :I], ta=True, tb=True, acc=True, prec=prec)
+                dtok0 = gemm(dgi[0], w_ih[:, :I], tb=True, prec=prec)                     # only the learned start token
+                colsum(G['init_input'].view(1, -1), dtok0)
+                gemm(dh0, z, G['z2dec_hid.weight'], ta=True, tb=True, acc=True, prec=prec)
+                colsum(G['z2dec_hid.bias'].view(1, -1), dh0)
+                gemm(dz_in, z, G['z2dec_in.weight'], ta=True, tb=True, acc=True, prec=prec)
+                colsum(G['z2dec_in.bias'].view(1, -1), dz_in)
+                return dtok0
+
+            def run_bulk():
+                for fn, _d2 in bulk:
+                    fn()
+                return rest()
+            from .optim import is_arena_view
+            adopted = all(P[n].grad is None and is_arena_view(P[n], G[n]) for n in CHD_PARAM_NAMES)
+            if CHD_BWD_BULK >= 0 and adopted and OVERLAP and not capturing_part():
+                side = Side(CHD_BWD_BULK)
+                side(run_bulk, hall, toks, st['z_in'], dgi, dgh, dh0, dzg, dz_in, z, [d for _f, d in bulk])
+                side.defer()                        # (these gradients travel with the final exchange under data parallelism)
             else:
-                gemm(d2, w, dhs, tb=True, acc=True, prec=prec)
-            G[name + '.weight'] = gemm(d2, hs, _gbuf(w), ta=True, tb=True, acc=True, prec=prec)
-            G[name + '.bias'] = _bgrad(P[name + '.bias'], d2)
-        if dhs is None:
-            dhs = _zeros(T * B, H, dev=dev)
-        w_hh, w_ih = P['gru.weight_hh_l0'], P['gru.weight_ih_l0']
-        # (per-step kernels, not the persistent launch: persistent launches take turns, and this short chain on its sibling stream had
-        # to wait for the decoder's 32-step time BPTT -- its dz then reached the chord encoder 0.3 ms after the decoder's own, round 4)
-        dgi, dgh, dh0 = gru_bwd(prec, hall, st['gates'], w_hh, dh_ext=dhs.view(T, B, H), allow_persist=CHD_BWD_PERSIST)
-        G['gru.weight_hh_l0'] = gemm(dgh.view(T * B, 3 * H), hall[:T].view(T * B, H), _gbuf(w_hh), ta=True, tb=True, acc=True,
-                                     prec=prec)
-        G['gru.bias_hh_l0'] = _bgrad(P['gru.bias_hh_l0'], dgh.view(T * B, 3 * H))
-        dzg = sum_steps(dgi)
-        G['gru.bias_ih_l0'] = _bgrad(P['gru.bias_ih_l0'], dzg)
-        g = _gbuf(w_ih)
-        gemm(dzg, st['z_in'], g[:, I:], ta=True, tb=True, acc=True, prec=prec)
-        gemm(dgi.view(T * B, 3 * H), toks.view(T * B, I), g[:, :I], ta=True, tb=True, acc=True, prec=prec)
-        G['gru.weight_ih_l0'] = g
-        dz_in = gemm(dzg, w_ih[:, I:], tb=True, prec=prec)
-        dtok0 = gemm(dgi[0], w_ih[:, :I], tb=True, prec=prec)                     # only the learned start token
-        G['init_input'] = _bgrad(P['init_input'], dtok0)
-        w_zh, w_zi = P['z2dec_hid.weight'], P['z2dec_in.weight']
-        dz = gemm(dh0, w_zh, tb=True, prec=prec)
-        gemm(dz_in, w_zi, dz, tb=True, acc=True, prec=prec)
-        G['z2dec_hid.weight'] = gemm(dh0, z, _gbuf(w_zh), ta=True, tb=True, acc=True, prec=prec)
-        G['z2dec_hid.bias'] = _bgrad(P['z2dec_hid.bias'], dh0)
-        G['z2dec_in.weight'] = gemm(dz_in, z, _gbuf(w_zi), ta=True, tb=True, acc=True, prec=prec)
-        G['z2dec_in.bias'] = _bgrad(P['z2dec_in.bias'], dz_in)
+                run_bulk()
         mark('chd_dec_bwd:end')
         return (dz, None, None) + tuple(G[n] for n in CHD_PARAM_NAMES)
 
@@ -2010,6 +2082,9 @@ def _pianotree_ce_bwd(pitch_m, dur_m, sm, pitch_t, dur_t, gs, st, gcnt=None):
     return dpitch, ddur
 
 
+LOSS_SIDE = os.environ.get('PTV_LOSS_SIDE', '0') != '0'          # (measured: 8.298 vs 8.302 ms -- no gain; kept as a switch)
+
+
 class VaeLossFn(torch.autograd.Function):
     """(pitch [B,32,15,130], dur [B,32,15,5,2], mu_c, sd_c, mu_r, sd_r, root [B,8,12], chroma [B,8,12,2],
     bass [B,8,12], x, c, beta, w0, w1) -> the 11 scalars of model.py:67-68 as one [11] tensor."""
@@ -2023,20 +2098,31 @@ class VaeLossFn(torch.autograd.Function):
         c = c.contiguous()
         mu_c, sd_c, mu_r, sd_r = (t.contiguous() for t in (mu_c, sd_c, mu_r, sd_r))
         sums = _zeros(8, dev=dev)
-        pitch_m, dur_m, sm_p, pitch_t, dur_t, counts, gcnt = _pianotree_ce_fwd(pitch, dur, x, sums, st, weighted_dur)
-        ctx.gcnt = gcnt
         (root_m, chroma_m, bass_m), sm_c = _mem_order([root, chroma, bass], [_chord_perm(root), _chord_perm(chroma),
                                                                               _chord_perm(bass)])
         root_t = torch.empty(B * 8, device=dev, dtype=torch.int32)
         chroma_t = torch.empty(B * 96, device=dev, dtype=torch.int32)
         bass_t = torch.empty(B * 8, device=dev, dtype=torch.int32)
-        call('ptv_chord_targets', ptr(c), B, int(sm_c), ptr(root_t), ptr(chroma_t), ptr(bass_t), st)
         Z = mu_c.shape[1]
-        call('ptv_kl_fwd', ptr(mu_c), ptr(sd_c), mu_c.numel(), ptr(sums[2:]), st)
-        call('ptv_kl_fwd', ptr(mu_r), ptr(sd_r), mu_r.numel(), ptr(sums[3:]), st)
-        call('ptv_ce_fwd', ptr(root_m), 12, ptr(root_t), B * 8, 12, -1, ptr(sums[4:]), st)
-        call('ptv_ce_fwd', ptr(chroma_m), 2, ptr(chroma_t), B * 96, 2, -1, ptr(sums[5:]), st)
-        call('ptv_ce_fwd', ptr(bass_m), 12, ptr(bass_t), B * 8, 12, -1, ptr(sums[6:]), st)
+
+        def small():
+            # the two KL terms and the three chord cross-entropies: six ~5-us launches, next to the PianoTree cross-entropy instead of behind it
+            st2 = stream_ptr()
+            call('ptv_chord_targets', ptr(c), B, int(sm_c), ptr(root_t), ptr(chroma_t), ptr(bass_t), st2)
+            call('ptv_kl_fwd', ptr(mu_c), ptr(sd_c), mu_c.numel(), ptr(sums[2:]), st2)
+            call('ptv_kl_fwd', ptr(mu_r), ptr(sd_r), mu_r.numel(), ptr(sums[3:]), st2)
+            call('ptv_ce_fwd', ptr(root_m), 12, ptr(root_t), B * 8, 12, -1, ptr(sums[4:]), st2)
+            call('ptv_ce_fwd', ptr(chroma_m), 2, ptr(chroma_t), B * 96, 2, -1, ptr(sums[5:]), st2)
+            call('ptv_ce_fwd', ptr(bass_m), 12, ptr(bass_t), B * 8, 12, -1, ptr(sums[6:]), st2)
+        side = Side(4) if (LOSS_SIDE and not capturing_part()) else None
+        if side is not None:
+            side(small, sums, root_m, chroma_m, bass_m, mu_c, sd_c, mu_r, sd_r, c)
+        pitch_m, dur_m, sm_p, pitch_t, dur_t, counts, gcnt = _pianotree_ce_fwd(pitch, dur, x, sums, st, weighted_dur)
+        ctx.gcnt = gcnt
+        if side is not None:
+            side.join()
+        else:
+            small()
         out = _empty(11, dev=dev)
         ctx.scal = (float(beta), float(w0), float(w1), float(B * Z), float(B * 8), float(B * 96))
         call('ptv_loss_finalize', ptr(sums), ptr(counts), *ctx.scal, ptr(out), st)
@@ -2055,15 +2141,25 @@ class VaeLossFn(torch.autograd.Function):
         reset_deferred()                        # first node of the backward pass: nothing may be left from an aborted one
         gs = _empty(8, dev=dev)
         call('ptv_loss_bwd_scales', ptr(gout.contiguous()), ptr(counts), *ctx.scal, ptr(gs), st)
-        dpitch, ddur = _pianotree_ce_bwd(pitch_m, dur_m, sm_p, pitch_t, dur_t, gs, st, ctx.gcnt)
         dmu_c, dsd_c = torch.empty_like(mu_c), torch.empty_like(sd_c)
         dmu_r, dsd_r = torch.empty_like(mu_r), torch.empty_like(sd_r)
-        call('ptv_kl_bwd', ptr(mu_c), ptr(sd_c), mu_c.numel(), ptr(gs[2:]), ptr(dmu_c), ptr(dsd_c), st)
-        call('ptv_kl_bwd', ptr(mu_r), ptr(sd_r), mu_r.numel(), ptr(gs[3:]), ptr(dmu_r), ptr(dsd_r), st)
         droot, dchroma, dbass = torch.empty_like(root_m), torch.empty_like(chroma_m), torch.empty_like(bass_m)
-        call('ptv_ce_bwd', ptr(root_m), 12, ptr(root_t), root_t.numel(), 12, -1, ptr(gs[4:]), ptr(droot), 12, st)
-        call('ptv_ce_bwd', ptr(chroma_m), 2, ptr(chroma_t), chroma_t.numel(), 2, -1, ptr(gs[5:]), ptr(dchroma), 2, st)
-        call('ptv_ce_bwd', ptr(bass_m), 12, ptr(bass_t), bass_t.numel(), 12, -1, ptr(gs[6:]), ptr(dbass), 12, st)
+
+        def small():
+            st2 = stream_ptr()
+            call('ptv_kl_bwd', ptr(mu_c), ptr(sd_c), mu_c.numel(), ptr(gs[2:]), ptr(dmu_c), ptr(dsd_c), st2)
+            call('ptv_kl_bwd', ptr(mu_r), ptr(sd_r), mu_r.numel(), ptr(gs[3:]), ptr(dmu_r), ptr(dsd_r), st2)
+            call('ptv_ce_bwd', ptr(root_m), 12, ptr(root_t), root_t.numel(), 12, -1, ptr(gs[4:]), ptr(droot), 12, st2)
+            call('ptv_ce_bwd', ptr(chroma_m), 2, ptr(chroma_t), chroma_t.numel(), 2, -1, ptr(gs[5:]), ptr(dchroma), 2, st2)
+            call('ptv_ce_bwd', ptr(bass_m), 12, ptr(bass_t), bass_t.numel(), 12, -1, ptr(gs[6:]), ptr(dbass), 12, st2)
+        side = Side(4) if (LOSS_SIDE and not capturing_part()) else None
+        if side is not None:
+            side(small, gs, dmu_c, dsd_c, dmu_r, dsd_r, droot, dchroma, dbass)
+        dpitch, ddur = _pianotree_ce_bwd(pitch_m, dur_m, sm_p, pitch_t, dur_t, gs, st, ctx.gcnt)
+        if side is not None:
+            side.join()
+        else:
+            small()
         if sm_c:
             droot, dchroma, dbass = (t.permute(*_chord_perm(t)) for t in (droot, dchroma, dbass))
         return (dpitch, ddur, dmu_c, dsd_c, dmu_r, dsd_r, droot, dchroma, dbass) + (None,) * 6

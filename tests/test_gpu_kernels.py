@@ -397,6 +397,44 @@ def test_fused_duration_kernels_at_the_b512_grid_caps():
     assert (dh0_b[M - 64 * 3:] == 0).all() and (dh0_b[M // 2 + 128: M // 2 + 64 * 49] == 0).all()
 
 
+@pytest.mark.parametrize('B,C', [(3, 10), (70, 10), (512, 10), (5, 16)])
+def test_texture_conv_front_end_vs_fp32_reference(B, C):
+    """TextureEncoder's Conv2d(1,C,(4,12),stride (4,1)) + ReLU + MaxPool2d((1,4)) (ptvae.py:95-99,112-114) alone: the pooled map in the
+    raw-view row layout (padded and plain), and the weight / bias gradients from (a) the recomputed convolution and (b) the forward's
+    arg-max map (what the train step runs) -- against torch's own conv / pool autograd on the CPU, and (b) == (a) bit for bit"""
+    from polyphonic_chord_texture_disentanglement_amd._lib import call, ptr, stream_ptr
+    import torch.nn.functional as TF
+    dev = _dev()
+    g = torch.Generator().manual_seed(100 + B)
+    pr = (torch.rand(B, 32, 128, generator=g) < 0.06).float() * torch.randint(1, 9, (B, 32, 128), generator=g).float()
+    w = (torch.randn(C, 1, 4, 12, generator=g) * 0.15).requires_grad_()
+    b = (torch.randn(C, generator=g) * 0.1).requires_grad_()
+    ref = TF.max_pool2d(torch.relu(TF.conv2d(pr.unsqueeze(1), w, b, stride=(4, 1))), (1, 4))           # [B,C,8,29]
+    dy = torch.randn(ref.shape, generator=g)
+    (ref * dy).sum().backward()
+    W = C * 29
+    prd, wd, bd = pr.to(dev), w.detach().reshape(C, 48).to(dev).contiguous(), b.detach().to(dev)
+    res = {}
+    for ld in (W, (W + 7) // 8 * 8):
+        feat = torch.full((B * 8, ld), float('nan'), device=dev)
+        arg = torch.empty(B * 8, W, device=dev, dtype=torch.int8)
+        call('ptv_txt_conv_relu_pool_fwd_rows', ptr(prd), ptr(wd), ptr(bd), ptr(feat), ld, B, C, ptr(arg), stream_ptr())
+        # the reference's raw view (ptvae.py:114): [B,C,8,29] memory read as [B*8, C*29] rows
+        np.testing.assert_allclose(feat[:, :W].cpu().numpy(), ref.detach().reshape(B * 8, W).numpy(), rtol=0, atol=2e-5)
+        assert torch.isfinite(feat).all()                          # row padding zeroed
+        dfeat = torch.zeros(B * 8, ld, device=dev)
+        dfeat[:, :W] = dy.reshape(B * 8, W).to(dev)
+        for mode in ('recompute', 'argmax'):
+            dw, db = torch.zeros(C, 48, device=dev), torch.zeros(C, device=dev)
+            call('ptv_txt_conv_relu_pool_bwd_rows', ptr(prd), ptr(wd) if mode == 'recompute' else None, ptr(bd) if mode == 'recompute' else None,
+                 ptr(dfeat), ld, ptr(dw), ptr(db), B, C, ptr(arg) if mode == 'argmax' else None, stream_ptr())
+            res[ld, mode] = (dw.cpu(), db.cpu())
+            tol = 2e-6 + 2e-5 * float(w.grad.abs().max()) * max(1.0, B / 16)
+            np.testing.assert_allclose(dw.cpu().numpy(), w.grad.reshape(C, 48).numpy(), rtol=0, atol=tol, err_msg='%s ld=%d' % (mode, ld))
+            np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), rtol=0, atol=tol)
+        assert torch.equal(res[ld, 'argmax'][0], res[ld, 'recompute'][0]) and torch.equal(res[ld, 'argmax'][1], res[ld, 'recompute'][1])
+
+
 def test_integration_md_snippet_runs_verbatim():
     """the ctypes example a maintainer would copy out of INTEGRATION.md, executed as written against the shipped .so"""
     import os
