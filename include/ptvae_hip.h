@@ -355,6 +355,83 @@ int ptv_heads_bwd(float* dp, long ldp, const float* dhd0, const void* wdpT_packe
                   int blocked, void* dy16, const int* m_top, long m_unit, long M, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * COMPOSITE: PtvaeDecoder.decoder, teacher-forced, FORWARD -- ptvae.py:430-496 with decode_notes (:370-428) and decode_note (:336-368)
+ * restructured to 32 + 15 + 5 sequential steps -- behind one call: the 15 launches, the persistent launch's turn (event wait /
+ * record) and every shape decision are C++ host code (csrc/composite.hip); the caller owns the tensors and hands them over as one
+ * pointer table t[PTV_DTF_COUNT] and one dimension table d[PTV_DTF_D_COUNT].  bf16 precision at the init_model() sizes only
+ * (E = 128, Hn = 512, Hd = 64, 130 pitch classes, Ht with a persistent plan): ptv_decoder_tf_supported(d) == 0 / PTV_ERR_UNSUPPORTED
+ * otherwise, before anything is launched -- the caller then sequences the entry points above itself.
+ *   rows: R = 32*B (time step, sample), M = 15*R (note, time step, sample).  Layouts as documented at the entry points it calls.
+ */
+enum PtvDtfTensor {
+  /* inputs */
+  PTV_DTF_Z = 0,          /* [B, Zs] fp32 */
+  PTV_DTF_EMB,            /* [16, R, E] fp32: the embedded ground-truth notes, step-major (ptv_embed_fwd) */
+  PTV_DTF_XS,             /* [R, 2He] fp32: ground-truth note summaries (ptvae.py:446-453) */
+  PTV_DTF_FORCE_DUR,      /* [5, M] int32 or NULL: replayed duration decisions (tests) */
+  /* fp32 parameters */
+  PTV_DTF_B_ZHID, PTV_DTF_B_ZIN, PTV_DTF_INIT_INPUT, PTV_DTF_B_IH_T, PTV_DTF_B_HH_T, PTV_DTF_B_T2N, PTV_DTF_B_IH_N, PTV_DTF_B_HH_N,
+  PTV_DTF_B_P, PTV_DTF_B_DH, PTV_DTF_W_HH_D, PTV_DTF_B_HH_D, PTV_DTF_W_IH_D, PTV_DTF_B_IH_D, PTV_DTF_SOS,
+  PTV_DTF_ONEHOT,         /* [2, 5] fp32 constant: rows onehot(0), onehot(1) */
+  PTV_DTF_W_OUT_D, PTV_DTF_B_OUT_D,
+  /* bf16 operand copies of the weights, [out, in] row-major */
+  PTV_DTF_W16_ZHID, PTV_DTF_W16_ZIN, PTV_DTF_W16_IH_T, PTV_DTF_W16_HH_T, PTV_DTF_W16_T2N, PTV_DTF_W16_IH_N,
+  /* MFMA-fragment packs (ptv_pack_mfma_multi): notes GRU W_hh / token part of W_ih; pitch_out, dur_hid[:, :Hn], dur_hid[:, Hn:] */
+  PTV_DTF_PK_NOTES_H, PTV_DTF_PK_NOTES_T, PTV_DTF_PK_WP, PTV_DTF_PK_WDH, PTV_DTF_PK_WDP,
+  /* outputs and what the backward keeps */
+  PTV_DTF_NS,             /* [33, B, Ht] fp32 time states (slot 0 = z2dec_hid(z)) */
+  PTV_DTF_NS16,           /* the same, bf16 */
+  PTV_DTF_Z_IN,           /* [B, Zi] fp32 */
+  PTV_DTF_TOKS,           /* [33, B, 2He] fp32 time-step tokens */
+  PTV_DTF_GI_T,           /* [R, 3Ht] bf16 */
+  PTV_DTF_ZG,             /* [B, 3Ht] bf16 */
+  PTV_DTF_GATES_T,        /* [32, 4, B, Ht] bf16 */
+  PTV_DTF_HN,             /* [16, R, Hn] fp32 note states */
+  PTV_DTF_HN16,           /* the same, bf16 */
+  PTV_DTF_GC,             /* [R, 3Hn] bf16, column-blocked by 32 */
+  PTV_DTF_GATES_N,        /* [15, 4, R, Hn] bf16 */
+  PTV_DTF_PITCH,          /* [M, ldp] fp32 pitch logits (130 used) */
+  PTV_DTF_HD,             /* [6, M, Hd] fp32 (slot 0 written) */
+  PTV_DTF_HD16,           /* [6, M, Hd] bf16 */
+  PTV_DTF_TAB0, PTV_DTF_TAB,    /* [1, 3Hd], [2, 3Hd] fp32 gate tables of the duration GRU */
+  PTV_DTF_GATES_D,        /* [5, 4, M, Hd] bf16, or NULL (the backward then recomputes them: ptv_dur_gru_bwd) */
+  PTV_DTF_DUR,            /* [M, 10] fp32 duration logits */
+  PTV_DTF_IDX,            /* [5, M] int32 duration decisions */
+  /* workspaces and the persistent launch's turn */
+  PTV_DTF_XCH,            /* 33*B*Ht bf16 exchange buffer of ptv_gru_persist_fwd */
+  PTV_DTF_SYNC,           /* its zeroed sync words */
+  PTV_DTF_WAIT_EVENT,     /* hipEvent_t recorded after the previous persistent launch of the process, or NULL */
+  PTV_DTF_RECORD_EVENT,   /* hipEvent_t to record after this one, or NULL */
+  PTV_DTF_COUNT
+};
+enum PtvDtfDim { PTV_DTF_D_B = 0, PTV_DTF_D_E, PTV_DTF_D_HE, PTV_DTF_D_HT, PTV_DTF_D_HN, PTV_DTF_D_HD, PTV_DTF_D_NP, PTV_DTF_D_ZS, PTV_DTF_D_ZI,
+                 PTV_DTF_D_LDP, PTV_DTF_D_COUNT };
+int ptv_decoder_tf_supported(const long* d);
+int ptv_decoder_tf_fwd(const void* const* t, const long* d, void* stream);
+
+/* COMPOSITE: RnnDecoder.forward, teacher-forced (ptvae.py:51-87 with tfr = 1), FORWARD in one call: z -> h0 / z_in, the tokens
+ * [init ; c_0 .. c_{T-2}], the hoisted input product, the T-step GRU, the three heads.  Any sizes; d[PTV_CDF_D_PREC] = 0 (fp32) / 1 (bf16
+ * MFMA operands, fp32 masters converted per tile); all tensors fp32 except GATES when d[PTV_CDF_D_GATES_BF16]. */
+enum PtvCdfTensor {
+  PTV_CDF_Z = 0,          /* [B, Z] */
+  PTV_CDF_C_SM,           /* [T, B, I] the chord steps, step-major */
+  PTV_CDF_W_ZHID, PTV_CDF_B_ZHID, PTV_CDF_W_ZIN, PTV_CDF_B_ZIN, PTV_CDF_INIT_INPUT,
+  PTV_CDF_W_IH,           /* [3H, I + Zi] */
+  PTV_CDF_B_IH, PTV_CDF_W_HH, PTV_CDF_B_HH, PTV_CDF_W_ROOT, PTV_CDF_B_ROOT, PTV_CDF_W_CHROMA, PTV_CDF_B_CHROMA, PTV_CDF_W_BASS, PTV_CDF_B_BASS,
+  PTV_CDF_HALL,           /* out [T+1, B, H] states (slot 0 = z2dec_hid(z)) */
+  PTV_CDF_Z_IN,           /* out [B, Zi] */
+  PTV_CDF_TOKS,           /* out [T, B, I] */
+  PTV_CDF_GI,             /* out [T*B, 3H] */
+  PTV_CDF_ZG,             /* out [B, 3H] */
+  PTV_CDF_GATES,          /* out [T, 4, B, H] fp32 or bf16 */
+  PTV_CDF_ROOT, PTV_CDF_CHROMA, PTV_CDF_BASS,   /* out [T*B, 12 / 24 / 12] logits */
+  PTV_CDF_COUNT
+};
+enum PtvCdfDim { PTV_CDF_D_B = 0, PTV_CDF_D_T, PTV_CDF_D_H, PTV_CDF_D_I, PTV_CDF_D_Z, PTV_CDF_D_ZI, PTV_CDF_D_PREC, PTV_CDF_D_GATES_BF16,
+                 PTV_CDF_D_NROOT, PTV_CDF_D_NCHROMA, PTV_CDF_D_NBASS, PTV_CDF_D_COUNT };
+int ptv_chord_decoder_fwd(const void* const* t, const long* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Free-running tokens.
  * ptv_note_token (ptvae.py:408-416 + pitch_dur_ind_to_note_token :328-334): per row pitch argmax (first
  *   maximal index), predicted token pred[r] = note_embedding(onehot(pitch) | 5 duration bits) with

@@ -52,6 +52,22 @@ def _parse_header(path):
     return sigs
 
 
+def header_enum(name, path=None):
+    """{enumerator: value} of a plain (0, 1, 2, ...) enum of include/ptvae_hip.h: the slot numbers of a composite entry point's tables"""
+    import re
+    src = re.sub(r'/\*.*?\*/', '', open(path or HEADER_PATH).read(), flags=re.S)
+    m = re.search(r'enum\s+%s\s*\{(.*?)\}' % name, src, flags=re.S)
+    if not m:
+        raise KeyError(name)
+    out = {}
+    for i, item in enumerate(x.strip() for x in m.group(1).split(',') if x.strip()):
+        ident = item.split('=')[0].strip()
+        if '=' in item:
+            assert int(item.split('=')[1]) == i, item
+        out[ident] = i
+    return out
+
+
 _SIGNATURES = _parse_header(HEADER_PATH)
 
 

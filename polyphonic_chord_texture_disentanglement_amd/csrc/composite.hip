@@ -1,0 +1,137 @@
+// composite.hip -- whole sub-graphs of the train step behind ONE C entry point: the launch sequence, the persistent launch's turn
+// (an event wait / record pair) and every shape decision live here in C++ host code; the caller owns the tensors.
+//
+//   ptv_decoder_tf_fwd   PtvaeDecoder.decoder, teacher-forced, forward (ptvae.py:430-496 with decode_notes :370-428 and decode_note
+//                        :336-368 restructured to 32 + 15 + 5 sequential steps): 15 launches
+//
+// bf16 precision at the init_model() sizes (the configuration every persistent / fused kernel below is specialised for); anything
+// else returns PTV_ERR_UNSUPPORTED BEFORE the first launch and the caller sequences the generic entry points itself.
+#include "common.hpp"
+#include "../../include/ptvae_hip.h"
+
+namespace {
+
+inline const void* T_(const void* const* t, int i) { return t[i]; }
+template <typename X> inline X* M_(const void* const* t, int i) { return reinterpret_cast<X*>(const_cast<void*>(t[i])); }
+
+// dtypes word of ptv_gemm: bit 0 = A bf16, bit 1 = B bf16, bit 2 = C bf16, bit 3 = C column-blocked by 32
+constexpr int A16 = 1, B16 = 2, C16 = 4, CBLK = 8;
+
+}  // namespace
+
+extern "C" int ptv_decoder_tf_supported(const long* d) {
+  if (!d) return 0;
+  const long B = d[PTV_DTF_D_B], E = d[PTV_DTF_D_E], He = d[PTV_DTF_D_HE], Ht = d[PTV_DTF_D_HT], Hn = d[PTV_DTF_D_HN], Hd = d[PTV_DTF_D_HD],
+             NP = d[PTV_DTF_D_NP];
+  if (B <= 0 || E != 128 || Hn != 512 || Hd != 64 || NP != 130 || He <= 0 || (He & 7) || (Ht & 7)) return 0;
+  return ptv_gru_persist_supported(1, (int)B, (int)Ht) ? 1 : 0;
+}
+
+extern "C" int ptv_decoder_tf_fwd(const void* const* t, const long* d, void* stream) {
+  if (!t || !d) return PTV_ERR_ARG;
+  if (!ptv_decoder_tf_supported(d)) return PTV_ERR_UNSUPPORTED;
+  for (int i = 0; i < PTV_DTF_COUNT; i++)
+    if (!t[i] && i != PTV_DTF_FORCE_DUR && i != PTV_DTF_GATES_D && i != PTV_DTF_WAIT_EVENT && i != PTV_DTF_RECORD_EVENT) return PTV_ERR_ARG;
+  const int B = (int)d[PTV_DTF_D_B], E = (int)d[PTV_DTF_D_E], He = (int)d[PTV_DTF_D_HE], Ht = (int)d[PTV_DTF_D_HT], Hn = (int)d[PTV_DTF_D_HN],
+            Hd = (int)d[PTV_DTF_D_HD], Zs = (int)d[PTV_DTF_D_ZS], Zi = (int)d[PTV_DTF_D_ZI];
+  const long ldp = d[PTV_DTF_D_LDP];
+  const int R = 32 * B;                                        // rows (time step, sample) of the notes GRU
+  const long M = 15L * R;                                      // rows (note, time step, sample) of the heads / the duration GRU
+  const int P = PTV_PREC_BF16;
+  hipStream_t s = (hipStream_t)stream;
+  float* NS = M_<float>(t, PTV_DTF_NS);
+  __bf16* NS16 = M_<__bf16>(t, PTV_DTF_NS16);
+  float* TOKS = M_<float>(t, PTV_DTF_TOKS);
+  float* HN = M_<float>(t, PTV_DTF_HN);
+  __bf16* HN16 = M_<__bf16>(t, PTV_DTF_HN16);
+  float* HD = M_<float>(t, PTV_DTF_HD);
+  __bf16* HD16 = M_<__bf16>(t, PTV_DTF_HD16);
+  const __bf16* w_ih_t = (const __bf16*)T_(t, PTV_DTF_W16_IH_T);      // [3Ht][2He + Zi]
+  const __bf16* w_ih_n = (const __bf16*)T_(t, PTV_DTF_W16_IH_N);      // [3Hn][Ht + E]
+  const long ld_t = 2L * He + Zi, ld_n = (long)Ht + E;
+
+  // ---- z -> initial time state, z_in (ptvae.py:435-437)
+  PTV_TRY(ptv_gemm(P, 0, 0, B, Ht, Zs, T_(t, PTV_DTF_Z), Zs, T_(t, PTV_DTF_W16_ZHID), Zs, NS, Ht, (const float*)T_(t, PTV_DTF_B_ZHID), 1.f, 0, 0, 0,
+                   B16, stream));
+  PTV_TRY(ptv_gemm(P, 0, 0, B, Zi, Zs, T_(t, PTV_DTF_Z), Zs, T_(t, PTV_DTF_W16_ZIN), Zs, M_<void>(t, PTV_DTF_Z_IN), Zi,
+                   (const float*)T_(t, PTV_DTF_B_ZIN), 1.f, 0, 0, 0, B16, stream));
+  // ---- time-GRU inputs: token_t = [init ; summary_{t-1}], z_in broadcast over t (ptvae.py:457-462,476-478)
+  PTV_TRY(ptv_copy2d(TOKS, 2L * He, (const float*)T_(t, PTV_DTF_INIT_INPUT), 0, B, 2 * He, 1.f, 0, stream));
+  PTV_TRY(ptv_copy2d(TOKS + (long)B * 2 * He, 2L * He, (const float*)T_(t, PTV_DTF_XS), 2L * He, R, 2 * He, 1.f, 0, stream));
+  PTV_TRY(ptv_gemm(P, 0, 0, R, 3 * Ht, 2 * He, TOKS, 2L * He, w_ih_t, ld_t, M_<void>(t, PTV_DTF_GI_T), 3L * Ht, nullptr, 1.f, 0, 0, -1,
+                   B16 | C16, stream));
+  PTV_TRY(ptv_gemm(P, 0, 0, B, 3 * Ht, Zi, T_(t, PTV_DTF_Z_IN), Zi, w_ih_t + 2 * He, ld_t, M_<void>(t, PTV_DTF_ZG), 3L * Ht,
+                   (const float*)T_(t, PTV_DTF_B_IH_T), 1.f, 0, 0, -1, B16 | C16, stream));
+  // ---- the 32 time steps: ONE persistent launch; persistent launches take turns (never two spinning grids half-resident together)
+  {
+    const void* gi[1] = {T_(t, PTV_DTF_GI_T)}; const long gi_step[1] = {(long)B * 3 * Ht}, gi_ld[1] = {3L * Ht};
+    const void* gi2[1] = {T_(t, PTV_DTF_ZG)}; const long gi2_step[1] = {0}, gi2_ld[1] = {3L * Ht};
+    const void* w16[1] = {T_(t, PTV_DTF_W16_HH_T)}; const float* bhh[1] = {(const float*)T_(t, PTV_DTF_B_HH_T)};
+    float* hall[1] = {NS}; void* hall16[1] = {NS16}; void* gates[1] = {M_<void>(t, PTV_DTF_GATES_T)};
+    const int* lengths[1] = {nullptr}; const int rev[1] = {0}; void* xch[1] = {M_<void>(t, PTV_DTF_XCH)};
+    if (t[PTV_DTF_WAIT_EVENT] && hipStreamWaitEvent(s, (hipEvent_t)const_cast<void*>(t[PTV_DTF_WAIT_EVENT]), 0) != hipSuccess) return PTV_ERR_LAUNCH;
+    PTV_TRY(ptv_gru_persist_fwd(1, B, Ht, 32, gi, gi_step, gi_ld, gi2, gi2_step, gi2_ld, w16, bhh, hall, hall16, gates, lengths, rev, xch,
+                                M_<unsigned>(t, PTV_DTF_SYNC), stream));
+    if (t[PTV_DTF_RECORD_EVENT] && hipEventRecord((hipEvent_t)const_cast<void*>(t[PTV_DTF_RECORD_EVENT]), s) != hipSuccess) return PTV_ERR_LAUNCH;
+  }
+  // ---- notes GRU: h0 = dec_time_to_notes_hid(summary_t); input [summary_t | token], summary part hoisted (ptvae.py:374-398)
+  const __bf16* nsf = NS16 + (long)B * Ht;                     // the 32 time states as rows (t, b): an MFMA operand as they are
+  PTV_TRY(ptv_gemm(P, 0, 0, R, Hn, Ht, nsf, Ht, T_(t, PTV_DTF_W16_T2N), Ht, HN, Hn, (const float*)T_(t, PTV_DTF_B_T2N), 1.f, 0, 0, 0, A16 | B16,
+                   stream));
+  PTV_TRY(ptv_gemm(P, 0, 0, R, 3 * Hn, Ht, nsf, Ht, w_ih_n, ld_n, M_<void>(t, PTV_DTF_GC), 3L * Hn, (const float*)T_(t, PTV_DTF_B_IH_N), 1.f, 0, 0,
+                   -1, A16 | B16 | C16 | CBLK, stream));
+  PTV_TRY(ptv_notes_gru_persist_fwd(T_(t, PTV_DTF_PK_NOTES_H), T_(t, PTV_DTF_PK_NOTES_T), (const float*)T_(t, PTV_DTF_B_HH_N), T_(t, PTV_DTF_GC),
+                                    (const float*)T_(t, PTV_DTF_EMB), HN, HN16, M_<void>(t, PTV_DTF_GATES_N), R, 15, stream));
+  // ---- pitch head + initial duration state in one pass over the note states (ptvae.py:343-352)
+  PTV_TRY(ptv_heads_fwd(HN16 + (long)R * Hn, T_(t, PTV_DTF_PK_WP), T_(t, PTV_DTF_PK_WDH), T_(t, PTV_DTF_PK_WDP), (const float*)T_(t, PTV_DTF_B_P),
+                        (const float*)T_(t, PTV_DTF_B_DH), M_<float>(t, PTV_DTF_PITCH), ldp, HD, HD16, M, stream));
+  // ---- 5-step duration GRU with arg-max feedback; its input is one of three vectors: gate tables (ptvae.py:353-367)
+  const int I = 5;
+  PTV_TRY(ptv_gemm(PTV_PREC_F32, 0, 0, 1, 3 * Hd, I, T_(t, PTV_DTF_SOS), I, T_(t, PTV_DTF_W_IH_D), I, M_<void>(t, PTV_DTF_TAB0), 3L * Hd,
+                   (const float*)T_(t, PTV_DTF_B_IH_D), 1.f, 0, 0, 0, 0, stream));
+  PTV_TRY(ptv_gemm(PTV_PREC_F32, 0, 0, 2, 3 * Hd, I, T_(t, PTV_DTF_ONEHOT), I, T_(t, PTV_DTF_W_IH_D), I, M_<void>(t, PTV_DTF_TAB), 3L * Hd,
+                   (const float*)T_(t, PTV_DTF_B_IH_D), 1.f, 0, 0, 0, 0, stream));
+  PTV_TRY(ptv_dur_gru_fwd(Hd, M, HD, Hd, (const float*)T_(t, PTV_DTF_W_HH_D), (const float*)T_(t, PTV_DTF_B_HH_D), (const float*)T_(t, PTV_DTF_TAB0),
+                          (const float*)T_(t, PTV_DTF_TAB), (const float*)T_(t, PTV_DTF_W_OUT_D), (const float*)T_(t, PTV_DTF_B_OUT_D), nullptr,
+                          M * Hd, HD16 + M * Hd, M_<void>(t, PTV_DTF_GATES_D), M * Hd, 4 * M * Hd, 1, M_<float>(t, PTV_DTF_DUR), 10,
+                          M_<int>(t, PTV_DTF_IDX), M, (const int*)T_(t, PTV_DTF_FORCE_DUR), M, stream));
+  return PTV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ptv_chord_decoder_fwd: RnnDecoder.forward, teacher-forced (ptvae.py:51-87 with tfr = 1: every step is fed the ground-truth chord of the
+// step before it): z -> h0 and z_in, tokens [init ; c_0 .. c_{T-2}], the input-side product hoisted out of the T steps, the GRU sequence,
+// the three heads.  Any sizes, fp32 or bf16 precision (fp32 master weights either way: the products convert per tile).  11 launches.
+// ---------------------------------------------------------------------------------------------
+extern "C" int ptv_chord_decoder_fwd(const void* const* t, const long* d, void* stream) {
+  if (!t || !d) return PTV_ERR_ARG;
+  for (int i = 0; i < PTV_CDF_COUNT; i++)
+    if (!t[i]) return PTV_ERR_ARG;
+  const int B = (int)d[PTV_CDF_D_B], T = (int)d[PTV_CDF_D_T], H = (int)d[PTV_CDF_D_H], I = (int)d[PTV_CDF_D_I], Z = (int)d[PTV_CDF_D_Z],
+            Zi = (int)d[PTV_CDF_D_ZI], P = (int)d[PTV_CDF_D_PREC], gbf = (int)d[PTV_CDF_D_GATES_BF16];
+  if (B <= 0 || T <= 0 || H <= 0 || I <= 0 || Z <= 0 || Zi <= 0 || (P != PTV_PREC_F32 && P != PTV_PREC_BF16)) return PTV_ERR_ARG;
+  float* hall = M_<float>(t, PTV_CDF_HALL);
+  float* toks = M_<float>(t, PTV_CDF_TOKS);
+  const float* w_ih = (const float*)T_(t, PTV_CDF_W_IH);
+  const long ld_ih = (long)I + Zi;
+  const long TB = (long)T * B;
+  PTV_TRY(ptv_gemm(P, 0, 0, B, H, Z, T_(t, PTV_CDF_Z), Z, T_(t, PTV_CDF_W_ZHID), Z, hall, H, (const float*)T_(t, PTV_CDF_B_ZHID), 1.f, 0, 0, 0, 0, stream));
+  PTV_TRY(ptv_gemm(P, 0, 0, B, Zi, Z, T_(t, PTV_CDF_Z), Z, T_(t, PTV_CDF_W_ZIN), Z, M_<void>(t, PTV_CDF_Z_IN), Zi, (const float*)T_(t, PTV_CDF_B_ZIN), 1.f,
+                   0, 0, 0, 0, stream));
+  PTV_TRY(ptv_copy2d(toks, I, (const float*)T_(t, PTV_CDF_INIT_INPUT), 0, B, I, 1.f, 0, stream));
+  if (T > 1) PTV_TRY(ptv_copy2d(toks + (long)B * I, I, (const float*)T_(t, PTV_CDF_C_SM), I, (long)(T - 1) * B, I, 1.f, 0, stream));
+  PTV_TRY(ptv_gemm(P, 0, 0, (int)TB, 3 * H, I, toks, I, w_ih, ld_ih, M_<void>(t, PTV_CDF_GI), 3L * H, nullptr, 1.f, 0, 0, 0, 0, stream));
+  PTV_TRY(ptv_gemm(P, 0, 0, B, 3 * H, Zi, T_(t, PTV_CDF_Z_IN), Zi, w_ih + I, ld_ih, M_<void>(t, PTV_CDF_ZG), 3L * H, (const float*)T_(t, PTV_CDF_B_IH),
+                   1.f, 0, 0, 0, 0, stream));
+  PTV_TRY(ptv_gru_seq_fwd(P, B, H, T, T_(t, PTV_CDF_GI), (long)B * 3 * H, 3L * H, T_(t, PTV_CDF_ZG), 0, 3L * H, T_(t, PTV_CDF_W_HH),
+                          (const float*)T_(t, PTV_CDF_B_HH), hall, nullptr, M_<void>(t, PTV_CDF_GATES), nullptr, 0, nullptr, gbf ? 1 : 0, stream));
+  const float* hs = hall + (long)B * H;
+  const int nr = (int)d[PTV_CDF_D_NROOT], nc = (int)d[PTV_CDF_D_NCHROMA], nb = (int)d[PTV_CDF_D_NBASS];
+  PTV_TRY(ptv_gemm(P, 0, 0, (int)TB, nr, H, hs, H, T_(t, PTV_CDF_W_ROOT), H, M_<void>(t, PTV_CDF_ROOT), nr, (const float*)T_(t, PTV_CDF_B_ROOT), 1.f, 0,
+                   0, 0, 0, stream));
+  PTV_TRY(ptv_gemm(P, 0, 0, (int)TB, nc, H, hs, H, T_(t, PTV_CDF_W_CHROMA), H, M_<void>(t, PTV_CDF_CHROMA), nc, (const float*)T_(t, PTV_CDF_B_CHROMA),
+                   1.f, 0, 0, 0, 0, stream));
+  PTV_TRY(ptv_gemm(P, 0, 0, (int)TB, nb, H, hs, H, T_(t, PTV_CDF_W_BASS), H, M_<void>(t, PTV_CDF_BASS), nb, (const float*)T_(t, PTV_CDF_B_BASS), 1.f, 0,
+                   0, 0, 0, stream));
+  return PTV_OK;
+}

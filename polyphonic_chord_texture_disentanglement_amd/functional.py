@@ -1467,6 +1467,94 @@ def _eye2(dev):
     return _CONST[key]
 
 
+# The teacher-forced decoder forward behind ONE C entry point (ptv_decoder_tf_fwd, csrc/composite.hip): launch sequence, the persistent
+# launch's turn and the shape decisions in C++; this side allocates the tensors and fills the two tables.  0 = sequence the launches here.
+DEC_COMPOSITE = os.environ.get('PTV_DEC_COMPOSITE', '1') != '0'
+CHD_COMPOSITE = os.environ.get('PTV_CHD_COMPOSITE', '1') != '0'
+_DTF = {}
+
+
+def _decoder_tf_composite(ctx, z, emb, xs, force_dur, prec, P, W, params, B, R, E, He, Ht, Hn, Hd, NP):
+    """-> True when ptv_decoder_tf_fwd ran (ctx then holds exactly what the launch-by-launch path leaves on it)"""
+    if 't' not in _DTF:
+        from ._lib import header_enum
+        _DTF['t'], _DTF['d'] = header_enum('PtvDtfTensor'), header_enum('PtvDtfDim')
+    T_, D_ = _DTF['t'], _DTF['d']
+    dev = z.device
+    emb3 = emb.view(16, R, E)
+    w16 = [W[n] for n in ('z2dec_hid_linear.weight', 'z2dec_in_linear.weight', 'dec_time_gru.weight_ih_l0', 'dec_time_gru.weight_hh_l0',
+                          'dec_time_to_notes_hid.weight', 'dec_notes_gru.weight_ih_l0')]
+    if (prec != 1 or not BF16_STORAGE or capturing_part() or any(w.dtype != BF16 for w in w16) or emb3.dtype != F32
+            or not emb3.is_contiguous() or not FUSED_DUR or not HEADS_FUSED or not NOTES_PERSIST or _act_dtype(prec, Ht) != BF16
+            or z.dtype != F32 or not persist_supported(1, B, Ht, 32)):
+        return False
+    Zs, Zi = z.shape[1], W['z2dec_in_linear.weight'].shape[0]
+    dims = [0] * D_['PTV_DTF_D_COUNT']
+    for k, v in (('B', B), ('E', E), ('HE', He), ('HT', Ht), ('HN', Hn), ('HD', Hd), ('NP', NP), ('ZS', Zs), ('ZI', Zi), ('LDP', _pad8(NP))):
+        dims[D_['PTV_DTF_D_' + k]] = v
+    darr = _larr(dims)
+    if not lib().ptv_decoder_tf_supported(darr):
+        return False
+    M = 15 * R
+    xs = xs.contiguous()
+    NS, NS16 = _empty(33, B, Ht, dev=dev), _empty(33, B, Ht, dev=dev, dtype=BF16)
+    z_in, TOKS = _empty(B, Zi, dev=dev), _empty(33, B, 2 * He, dev=dev)
+    gi_t, zg = _empty(R, 3 * Ht, dev=dev, dtype=BF16), _empty(B, 3 * Ht, dev=dev, dtype=BF16)
+    gates_t = _empty(32, 4, B, Ht, dev=dev, dtype=BF16)
+    HN, HN16 = _empty(16, R, Hn, dev=dev), _empty(16, R, Hn, dev=dev, dtype=BF16)
+    GC, gates_n = _empty(R, 3 * Hn, dev=dev, dtype=BF16), _empty(15, 4, R, Hn, dev=dev, dtype=BF16)
+    pitch = _empty(M, _pad8(NP), dev=dev)[:, :NP]
+    HD, HD16 = _empty(6, M, Hd, dev=dev), _empty(6, M, Hd, dev=dev, dtype=BF16)
+    tab0, tab = _empty(1, 3 * Hd, dev=dev), _empty(2, 3 * Hd, dev=dev)
+    gates_d = None if DUR_RECOMPUTE else _empty(5, 4, M, Hd, dev=dev, dtype=BF16)
+    dur = _empty(M, 5, 2, dev=dev)
+    idx = torch.empty(5, M, device=dev, dtype=torch.int32)
+    xch = torch.empty(33 * B * Ht, device=dev, dtype=BF16)
+    sync = _persist_sync(1, dev)
+    pk = notes_packs(P['dec_notes_gru.weight_ih_l0'], P['dec_notes_gru.weight_hh_l0'], Ht)
+    hp = heads_packs(P['pitch_out_linear.weight'], P['dur_hid_linear.weight'])
+    cur = cur_stream()
+    prev = _PERSIST_LAST.get(cur.device.index)
+    done = torch.cuda.Event()
+    tens = {'Z': z, 'EMB': emb3, 'XS': xs, 'FORCE_DUR': force_dur,
+            'B_ZHID': P['z2dec_hid_linear.bias'], 'B_ZIN': P['z2dec_in_linear.bias'], 'INIT_INPUT': P['dec_init_input'],
+            'B_IH_T': P['dec_time_gru.bias_ih_l0'], 'B_HH_T': P['dec_time_gru.bias_hh_l0'], 'B_T2N': P['dec_time_to_notes_hid.bias'],
+            'B_IH_N': P['dec_notes_gru.bias_ih_l0'], 'B_HH_N': P['dec_notes_gru.bias_hh_l0'], 'B_P': P['pitch_out_linear.bias'],
+            'B_DH': P['dur_hid_linear.bias'], 'W_HH_D': P['dec_dur_gru.weight_hh_l0'], 'B_HH_D': P['dec_dur_gru.bias_hh_l0'],
+            'W_IH_D': P['dec_dur_gru.weight_ih_l0'], 'B_IH_D': P['dec_dur_gru.bias_ih_l0'], 'SOS': P['dur_sos_token'],
+            'ONEHOT': _onehot2x5(dev), 'W_OUT_D': P['dur_out_linear.weight'], 'B_OUT_D': P['dur_out_linear.bias'],
+            'W16_ZHID': w16[0], 'W16_ZIN': w16[1], 'W16_IH_T': w16[2], 'W16_HH_T': w16[3], 'W16_T2N': w16[4], 'W16_IH_N': w16[5],
+            'PK_NOTES_H': pk['wg_h'], 'PK_NOTES_T': pk['wg_t'], 'PK_WP': hp['wp'], 'PK_WDH': hp['wdh'], 'PK_WDP': hp['wdp'],
+            'NS': NS, 'NS16': NS16, 'Z_IN': z_in, 'TOKS': TOKS, 'GI_T': gi_t, 'ZG': zg, 'GATES_T': gates_t, 'HN': HN, 'HN16': HN16, 'GC': GC,
+            'GATES_N': gates_n, 'PITCH': pitch, 'HD': HD, 'HD16': HD16, 'TAB0': tab0, 'TAB': tab, 'GATES_D': gates_d, 'DUR': dur, 'IDX': idx,
+            'XCH': xch, 'SYNC': sync}
+    slots = [None] * T_['PTV_DTF_COUNT']
+    for k, v in tens.items():
+        slots[T_['PTV_DTF_' + k]] = v.data_ptr() if v is not None else None
+    # (the two event slots carry hipEvent_t handles, not tensors: events are created lazily -- record / wait once here to have a handle)
+    if prev is not None:
+        slots[T_['PTV_DTF_WAIT_EVENT']] = prev.cuda_event
+    done.record(cur)                      # creates the handle; the library records it again after the persistent launch
+    slots[T_['PTV_DTF_RECORD_EVENT']] = done.cuda_event
+    _chain_prio()
+    mark('dec_fwd:start')
+    rc = lib().ptv_decoder_tf_fwd((ctypes.c_void_p * len(slots))(*slots), darr, stream_ptr())
+    if rc == -3:
+        return False
+    check(rc, 'ptv_decoder_tf_fwd')
+    _PERSIST_LAST[cur.device.index] = done
+    mark('dec_fwd:heads')
+    ctx.save_for_backward(z, emb, *params)
+    ctx.emb_link = _EMB_LINK.get(emb.data_ptr()) if (ctx.needs_input_grad[2] and ctx.needs_input_grad[1] and emb.is_contiguous()) else None
+    ctx.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in, NS16=NS16, HN16=HN16, HD16=HD16,
+                  TOKS=TOKS, gates_t=gates_t, HN=HN, gates_n=gates_n, gates_n_rowk=True, pitch=pitch, HD=HD, gates_d=gates_d, idx=idx,
+                  dur_tabs=(tab0, tab), dur16_only=True)
+    _DTF['calls'] = _DTF.get('calls', 0) + 1
+    ctx.mark_non_differentiable(idx)
+    ctx._outs = (pitch.view(15, 32, B, NP), dur, idx)
+    return True
+
+
 class DecoderTFFn(torch.autograd.Function):
     """(z [B,Zs], emb step-major [16,32,B,E], xs [32B, 2He] ground-truth note summaries (BiGruFinalFn over
     emb, ptvae.py:446-453), force_dur_idx or None, *params)
@@ -1487,6 +1575,9 @@ class DecoderTFFn(torch.autograd.Function):
         Hd = W['dec_dur_gru.weight_hh_l0'].shape[1]
         NP = W['pitch_out_linear.weight'].shape[0]              # 130
         S = ctx                                                  # stash everything on ctx
+
+        if DEC_COMPOSITE and _decoder_tf_composite(ctx, z, emb, xs, force_dur, prec, P, W, params, B, R, E, He, Ht, Hn, Hd, NP):
+            return ctx._outs
 
         # --- z -> initial time state, z_in  (ptvae.py:435-437)
         NS = _empty(33, B, Ht, dev=dev)
@@ -1884,6 +1975,38 @@ class ChordDecoderTFFn(torch.autograd.Function):
         T = c_sm.shape[0]
         H = P['gru.weight_hh_l0'].shape[1]
         I = c_sm.shape[2]
+        if CHD_COMPOSITE and c_sm.is_contiguous() and c_sm.dtype == F32 and z.dtype == F32 and not capturing_part():
+            # the whole forward behind ONE C call (ptv_chord_decoder_fwd, csrc/composite.hip)
+            if 'ct' not in _DTF:
+                from ._lib import header_enum
+                _DTF['ct'], _DTF['cd'] = header_enum('PtvCdfTensor'), header_enum('PtvCdfDim')
+            CT, CD = _DTF['ct'], _DTF['cd']
+            Zi = P['z2dec_in.weight'].shape[0]
+            adt = _act_dtype(prec, H)
+            hall, z_in, toks = _empty(T + 1, B, H, dev=dev), _empty(B, Zi, dev=dev), _empty(T, B, I, dev=dev)
+            gi, zg = _empty(T * B, 3 * H, dev=dev), _empty(B, 3 * H, dev=dev)
+            gates = _empty(T, 4, B, H, dev=dev, dtype=adt)
+            nr, nc, nb = (P[n + '_out.weight'].shape[0] for n in ('root', 'chroma', 'bass'))
+            root, chroma, bass = _empty(T * B, nr, dev=dev), _empty(T * B, nc, dev=dev), _empty(T * B, nb, dev=dev)
+            tens = {'Z': z, 'C_SM': c_sm, 'W_ZHID': P['z2dec_hid.weight'], 'B_ZHID': P['z2dec_hid.bias'], 'W_ZIN': P['z2dec_in.weight'],
+                    'B_ZIN': P['z2dec_in.bias'], 'INIT_INPUT': P['init_input'], 'W_IH': P['gru.weight_ih_l0'], 'B_IH': P['gru.bias_ih_l0'],
+                    'W_HH': P['gru.weight_hh_l0'], 'B_HH': P['gru.bias_hh_l0'], 'W_ROOT': P['root_out.weight'], 'B_ROOT': P['root_out.bias'],
+                    'W_CHROMA': P['chroma_out.weight'], 'B_CHROMA': P['chroma_out.bias'], 'W_BASS': P['bass_out.weight'],
+                    'B_BASS': P['bass_out.bias'], 'HALL': hall, 'Z_IN': z_in, 'TOKS': toks, 'GI': gi, 'ZG': zg, 'GATES': gates, 'ROOT': root,
+                    'CHROMA': chroma, 'BASS': bass}
+            slots = [None] * CT['PTV_CDF_COUNT']
+            for k, v in tens.items():
+                slots[CT['PTV_CDF_' + k]] = ptr(v)
+            dims = [0] * CD['PTV_CDF_D_COUNT']
+            for k, v in (('B', B), ('T', T), ('H', H), ('I', I), ('Z', z.shape[1]), ('ZI', Zi), ('PREC', prec), ('GATES_BF16', int(adt == BF16)),
+                         ('NROOT', nr), ('NCHROMA', nc), ('NBASS', nb)):
+                dims[CD['PTV_CDF_D_' + k]] = v
+            _chain_prio()
+            check(lib().ptv_chord_decoder_fwd((ctypes.c_void_p * len(slots))(*slots), _larr(dims), stream_ptr()), 'ptv_chord_decoder_fwd')
+            _DTF['chd_calls'] = _DTF.get('chd_calls', 0) + 1
+            ctx.save_for_backward(z, *params)
+            ctx.st = dict(hall=hall, gates=gates, toks=toks, z_in=z_in, prec=prec, T=T, B=B, H=H, I=I)
+            return root.view(T, B, -1), chroma.view(T, B, -1), bass.view(T, B, -1)
         hall = _empty(T + 1, B, H, dev=dev)
         gemm(z, P['z2dec_hid.weight'], hall[0], bias=P['z2dec_hid.bias'], prec=prec)
         z_in = gemm(z, P['z2dec_in.weight'], bias=P['z2dec_in.bias'], prec=prec)

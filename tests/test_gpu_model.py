@@ -96,6 +96,40 @@ def test_bf16_path_tracks_fp32_loss():
         assert abs(gn - r) <= 1e-7 + 2e-3 * r, (k, gn, r)
 
 
+def test_decoder_tf_composite_entry_point_equals_launch_by_launch_and_reference():
+    """ptv_decoder_tf_fwd and ptv_chord_decoder_fwd (csrc/composite.hip: the two teacher-forced decoder forwards as ONE C call each --
+    launch sequence, persistent turn and shape decisions in C++) against (a) the same launches sequenced from Python, bit for bit (losses and every gradient), and (b) the
+    reference's golden losses at full geometry.  bf16 with the optimiser's bf16 weight shadows, which is what the train step runs."""
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
+    g = load_npz('full_tf1_b4.npz')
+    x, c, pr = synth_batch(int(g['B']), int(g['data_seed']))
+    res = {}
+    for comp in (True, False):
+        m = M.DisentangleVAE.init_model(torch.device(DEV))
+        m.load_state_dict(full_params())
+        m.to(DEV).set_precision('bf16')
+        opt = FusedClipAdam(m.parameters(), lr=1e-3)
+        old, F_.DEC_COMPOSITE, F_.CHD_COMPOSITE = (F_.DEC_COMPOSITE, F_.CHD_COMPOSITE), comp, comp
+        calls, chd_calls = F_._DTF.get('calls', 0), F_._DTF.get('chd_calls', 0)
+        try:
+            opt.zero_grad()
+            outs, losses = _run(m, g, x, c, pr)
+            losses[0].backward()
+        finally:
+            F_.DEC_COMPOSITE, F_.CHD_COMPOSITE = old
+        assert (F_._DTF.get('calls', 0) > calls) == comp                    # the composites really ran (or really did not)
+        assert (F_._DTF.get('chd_calls', 0) > chd_calls) == comp
+        res[comp] = (np.array([l.item() for l in losses]), {k: p.grad.detach().clone() for k, p in m.named_parameters()},
+                     outs[0].detach().clone(), outs[1].detach().clone())
+        F_.persist_check()
+    np.testing.assert_allclose(res[True][0], g['losses'], rtol=0, atol=3e-4)   # (bf16 weight shadows + bf16-stored activations: the bf16 bound of test_gpu_model_wide)
+    assert np.array_equal(res[True][0], res[False][0])
+    assert torch.equal(res[True][2], res[False][2]) and torch.equal(res[True][3], res[False][3])
+    for k in res[True][1]:
+        assert torch.equal(res[True][1][k], res[False][1][k]), k
+
+
 def test_fresh_batch_vs_oracle_with_weighted_outputs():
     """Independent check on inputs no fixture holds: oracle on CPU vs HIP path, all 11 outputs given
     non-trivial upstream gradients (exercises the loss backward's scale mixing)."""
