@@ -765,7 +765,7 @@ BIGRU_SLOT_BWD = int(os.environ.get('PTV_BIGRU_SLOT_BWD', '7'))
 #   ROW_TURNS (the row-partitioned summary GRUs take turns with the persistent launches whose LDS they crowd):             8.48
 # -- the bulk products overlapping the latency-bound chains is what fills the GPU; taking them out of the chains' way leaves the chains
 # no faster (they are bound by their own hand-offs) and the bulk exposed at the end.
-BIGRU_CHAIN_FIRST = os.environ.get('PTV_BIGRU_CHAIN_FIRST', '0') != '0'
+BIGRU_CHAIN_FIRST = int(os.environ.get('PTV_BIGRU_CHAIN_FIRST', '0'))
 BIGRU_LATE = os.environ.get('PTV_BIGRU_LATE', '1') != '0'
 ROW_TURNS = os.environ.get('PTV_ROW_TURNS', '0') != '0'
 FORK_EARLY = os.environ.get('PTV_FORK_EARLY', '0') != '0'
@@ -1112,7 +1112,19 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None, pending=None
                                dgi=_empty(T, M, 3 * H, dev=x3.device, dtype=adt), dgh=_empty(T, M, 3 * H, dev=x3.device, dtype=adt),
                                dh0=None, reverse=bool(d)))
         gru_persist_bwd(M, H, T, chains)
-        if pending is not None:
+        if pending is not None and BIGRU_CHAIN_FIRST == 2:
+            # "lite": the plain schedule, except that the second direction's input-gradient product does not wait for that direction's
+            # parameter-gradient products (its operand came out of the one BPTT launch on THIS stream) and the sibling stream is handed to
+            # the caller to defer instead of being joined here
+            g1, _ = side(lambda: products(1, chains[1]['dgi'], chains[1]['dgh']), xf, dout, chains[1]['dgi'], chains[1]['dgh'], saved)
+            g0, dx0 = products(0, chains[0]['dgi'], chains[0]['dgh'])
+            if need_dx:
+                late['dx'] = dx_acc if dx_acc is not None else dx0
+                dx_of(1, chains[1]['dgi'].view(T * M, 3 * H), None, False)
+                dx0 = late['dx']
+            pending.append(side)
+            return g0 + g1, (dx0.view(T, M, I) if need_dx else None)
+        if pending is not None and BIGRU_CHAIN_FIRST == 1:
             return chain_first([(c['dgi'], c['dgh'], None) for c in chains])
         g1, _ = side(lambda: products(1, chains[1]['dgi'], chains[1]['dgh']), xf, dout, chains[1]['dgi'], chains[1]['dgh'])
         g0, dx0 = products(0, chains[0]['dgi'], chains[0]['dgh'])
@@ -1130,10 +1142,10 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None, pending=None
             top = _ineg1(x3.device) if (lengths is not None and M % 32 == 0) else None
             call('ptv_row_gru_persist_bwd', H, ptr(pk['wt']), ptr(hall), ptr(gates), None, dout.data_ptr() + 4 * d * H, dout.stride(0),
                  ptr(lengths) if lengths is not None else None, ptr(dgi), ptr(dgh), None, ptr(scratch), M, T, d, ptr(top), stream_ptr())
-            if pending is not None:
+            if pending is not None and BIGRU_CHAIN_FIRST == 1:
                 return dgi, dgh, top
             return products(d, dgi, dgh, top)
-        if pending is not None:
+        if pending is not None and BIGRU_CHAIN_FIRST == 1:
             with (_PersistTurn() if ROW_TURNS else contextlib.nullcontext()):
                 res = [rows(0), rows(1)]
             return chain_first(res)
@@ -1198,7 +1210,15 @@ class BiGruFinalFn(torch.autograd.Function):
         pairs = list(zip(w[0:4], grads[0:4])) + list(zip(w[4:8], grads[4:8]))
         adopted = all(p_.grad is None and is_arena_view(p_, g_) for p_, g_ in pairs)
         streams, final = (), True
-        for fn, keep in (pending or ()):
+        for ent in (pending or ()):
+            if isinstance(ent, Side):                     # (mode 2: the second direction's products are already queued on it)
+                if adopted:
+                    streams += (ent.s,)
+                    ent.defer()
+                else:
+                    ent.join()
+                continue
+            fn, keep = ent
             # parameter gradients only: they may be computed after this node returns -- if autograd ADOPTS the buffers (DecoderTFFn.backward)
             if adopted and BIGRU_LATE:
                 late(fn, *keep)                           # at the end of the backward pass, spread over the sibling streams
