@@ -50,6 +50,13 @@ struct WgArgs {
   float* ws;                     // ordered reduction (ptv_wgrad_mode 1): slab partials go to ws[(slab0 + slab) * tiles + tile][128][128] with plain
   float* ws_csum;                // stores (ws_csum[(slab0 + slab) * M + m] for the column sums) and wgrad_reduce_kernel adds them up in slab
   int slab0;                     // order; null: fp32 atomics into C (run-to-run rounding differs)
+  // in-kernel fix-up (round 4): the LAST block to deliver a partial of an output tile adds that tile's partials up, in slab order, and
+  // writes C -- no separate reduction launch (39 per train step).  fix_cnt: one arrival counter per tile (zero between products, reset by
+  // the reducing block), null = wgrad_reduce_kernel does it.  fix_*: the slab geometry of the PRIMARY launch (the fast one; the guarded
+  // tail launch, fix_extra, contributes one more partial at slab index fix_nslab) -- both launches count live slabs the same way
+  unsigned* fix_cnt;
+  int fix_nslab, fix_kper, fix_K, fix_extra, fix_acc;
+  const int* fix_ktop;
 };
 
 // which part of a slab's K range survives the k_top limits: shared by the product kernel and the ordered reduction (a slab that is
@@ -171,6 +178,89 @@ __device__ __forceinline__ wbf16x8 tr_frag(const __bf16* st, int col) {
   return __builtin_bit_cast(wbf16x8, w);
 }
 
+// four consecutive floats (16-byte aligned) as two agent-scope 8-byte loads: served past this CU's non-coherent caches
+__device__ __forceinline__ float4 ld4_agent(const float* p) {
+  union { unsigned long long u; float f[2]; } a, b;
+  a.u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  b.u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float4(a.f[0], a.f[1], b.f[0], b.f[1]);
+}
+
+// The calling block has stored its partial of `tile` (and of the column sums).  Release, count the arrival; the last arriver acquires
+// and reduces the tile in slab order -- the same sums in the same order as wgrad_reduce_kernel, whichever block happens to be last.
+__device__ __forceinline__ void wgrad_fixup(const WgArgs& g, int tile, int m_blk, int n_blk) {
+  // hand-off without fences (an agent-scope release / acquire pair is an L2 write-back + invalidate of the whole XCD cache per block --
+  // measured: the step went from 8.2 to 10.5 ms): the partials went out as write-through (sc1) stores, the wave waits for their
+  // acknowledgement, one lane counts the arrival (relaxed), the last block reads with agent-scope loads (common.hpp, ordered_commit)
+  __shared__ int s_fix[3];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    WgArgs p = g;                                                   // the primary launch's slab geometry
+    p.kper = g.fix_kper; p.K = g.fix_K; p.k_top = g.fix_ktop;
+    int s0 = 0, s1 = 0; bool any = false;
+    for (int sl = 0; sl < g.fix_nslab; sl++) {
+      int kb, ke;
+      if (slab_range(p, sl, kb, ke)) { if (!any) s0 = sl; s1 = sl + 1; any = true; }
+    }
+    const unsigned expected = (unsigned)(s1 - s0) + (unsigned)g.fix_extra;
+    const unsigned old = __hip_atomic_fetch_add(g.fix_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old + 1 == expected;
+    if (last) __hip_atomic_store(g.fix_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the stream's next product
+    s_fix[0] = last; s_fix[1] = s0; s_fix[2] = s1;
+  }
+  __syncthreads();
+  if (!s_fix[0]) return;
+  const int s0 = s_fix[1], s1 = s_fix[2];
+  const int tiles = g.tiles_m * g.tiles_n;
+  const long tstride = (long)tiles * (WBM * WBN);
+  const float* base = g.ws + (long)tile * (WBM * WBN);
+  const float* pb = g.fix_extra ? base + (long)g.fix_nslab * tstride : nullptr;
+  const bool vec = (g.N & 3) == 0 && (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0;
+  for (int q = threadIdx.x; q < WBM * WBN / 4; q += blockDim.x) {
+    const int ml = q / (WBN / 4), nl = (q % (WBN / 4)) * 4;
+    const int m = m_blk + ml, n = n_blk + nl;
+    if (m >= g.M || n >= g.N) continue;
+    const float* p = base + ml * WBN + nl;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    int sl = s0;
+    for (; sl + 8 <= s1; sl += 8) {                                 // eight partials in flight, added in slab order
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = ld4_agent(p + (long)(sl + u) * tstride);
+#pragma unroll
+      for (int u = 0; u < 8; u++) { sum.x += v[u].x; sum.y += v[u].y; sum.z += v[u].z; sum.w += v[u].w; }
+    }
+    for (; sl < s1; sl++) {
+      const float4 v = ld4_agent(p + (long)sl * tstride);
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    if (pb) { const float4 v = ld4_agent(pb + ml * WBN + nl); sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w; }
+    float* cp = g.C + (long)m * g.ldc + n;
+    if (vec) {                                                      // (N a multiple of 4: the four columns are inside C together)
+      float4 c = g.fix_acc ? *reinterpret_cast<float4*>(cp) : make_float4(0.f, 0.f, 0.f, 0.f);
+      c.x += g.alpha * sum.x; c.y += g.alpha * sum.y; c.z += g.alpha * sum.z; c.w += g.alpha * sum.w;
+      *reinterpret_cast<float4*>(cp) = c;
+    } else {
+      const float sv[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        if (n + e < g.N) cp[e] = (g.fix_acc ? cp[e] : 0.f) + g.alpha * sv[e];
+    }
+  }
+  if (g.ws_csum && n_blk == 0) {                                    // the bias gradient (always accumulates): this tile row's 128 sums
+    for (int ml = threadIdx.x; ml < WBM; ml += blockDim.x) {
+      const int m = m_blk + ml;
+      if (m >= g.M) continue;
+      const float* cs = g.ws_csum;                                  // (the workspace base, the same for both launches)
+      float sum = 0.f;
+      for (int sl = s0; sl < s1; sl++) sum += __hip_atomic_load(cs + (long)sl * g.M + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (g.fix_extra) sum += __hip_atomic_load(cs + (long)g.fix_nslab * g.M + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      g.csum[m] += sum;
+    }
+  }
+}
+
 // GUARD = false: rows 16-byte aligned, K a multiple of 32 and not reaching the operands' last row (see ptv_wgrad)
 template <bool AF32, bool BF32, bool GUARD, int NSET>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
@@ -276,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
       for (int r = 0; r < 4; r++) {
         const int m = m_blk + wm + i * 16 + (lane >> 4) * 4 + r;
         if (m < g.M) {
-          if (g.ws_csum) g.ws_csum[(long)(g.slab0 + slab) * g.M + m] = accs[i][r];
+          if (g.ws_csum) __hip_atomic_store(g.ws_csum + (long)(g.slab0 + slab) * g.M + m, accs[i][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           else atomicAdd(g.csum + m, accs[i][r]);
         }
       }
@@ -290,8 +380,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
       for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int r = 0; r < 4; r++)
-          if (i * 16 + r < mrem && j * 16 < nrem)                  // (cells outside C are never read back)
-            wt[(wm + i * 16 + (lane >> 4) * 4 + r) * WBN + wn + j * 16 + (lane & 15)] = acc[i][j][r];
+          if (i * 16 + r < mrem && j * 16 < nrem) {                // (cells outside C are never read back)
+            float* q = wt + (wm + i * 16 + (lane >> 4) * 4 + r) * WBN + wn + j * 16 + (lane & 15);
+            // (fix-up: write-through stores -- another CU, possibly behind another XCD's L2, reads them in this launch)
+            if (g.fix_cnt) __hip_atomic_store(q, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *q = acc[i][j][r];
+          }
+    if (g.fix_cnt) wgrad_fixup(g, tile, m_blk, n_blk);
     return;
   }
   const bool single = g.nslab == 1;
@@ -406,7 +501,8 @@ static int g_wgrad_mode = [] { const char* e = getenv("PTV_WGRAD_ORDERED"); retu
 // grow-only workspace per stream: launches on one stream are ordered, so the next product's partials cannot overtake this one's
 // reduction; two streams never share a buffer.  (Allocation happens on a stream's first large product -- never inside a captured
 // graph if the capture was preceded by a warm-up of the same step.)
-struct WsBuf { float* p = nullptr; size_t bytes = 0; };
+struct WsBuf { float* p = nullptr; size_t bytes = 0; unsigned* cnt = nullptr; };      // cnt: 4096 zeroed tile counters (in-kernel fix-up)
+constexpr int WS_CNT = 4096;
 static WsBuf* ws_for(hipStream_t s, size_t bytes) {
   static WsBuf pool[64];
   static hipStream_t keys[64];
@@ -423,8 +519,14 @@ static WsBuf* ws_for(hipStream_t s, size_t bytes) {
     // (the outgrown buffer is NOT freed: a captured hipGraph may hold its address -- graph_step.py replays launches recorded on this
     // stream -- and it is tens of megabytes at most)
     size_t want = bytes + bytes / 4;
+    unsigned* keep = b.cnt;
     if (hipMalloc(reinterpret_cast<void**>(&b.p), want) != hipSuccess) { b = WsBuf{}; return nullptr; }
     b.bytes = want;
+    b.cnt = keep;
+    if (!b.cnt) {
+      if (hipMalloc(reinterpret_cast<void**>(&b.cnt), WS_CNT * sizeof(unsigned)) != hipSuccess || hipMemset(b.cnt, 0, WS_CNT * sizeof(unsigned)) != hipSuccess)
+        b.cnt = nullptr;                                           // (no counters: the separate reduction kernel serves this stream)
+    }
   }
   return &b;
 }
@@ -463,11 +565,13 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
   const int nset = (af || bf) ? 2 : (nset_env == 4 ? 4 : 2);       // 4 register sets only fit with bf16 sources
   WgArgs sent[2]; int nsent[2] = {0, 0};
   float* ws = nullptr; float* ws_csum = nullptr; int ws_slabs = 0;
+  unsigned* fix_cnt = nullptr;
+  const bool has_a = kfast > 0, has_b = kfast < K;
   bool zeroed = false;
   auto launch = [&](bool guard, int k0, int kn, int want_slabs, int pass) -> int {
     WgArgs g{static_cast<const char*>(A) + (long)k0 * lda * (af ? 4 : 2), lda, static_cast<const char*>(B) + (long)k0 * ldb * (bf ? 4 : 2), ldb,
              C, ldc, M, N, kn, 0, cdiv(M, WBM), cdiv(N, WBN), 1, 0, alpha, colsum_a, k0 == 0 ? k_top : nullptr, k_unit, k_rev, g_gemm_prio,
-             nullptr, nullptr, 0};
+             nullptr, nullptr, 0, nullptr, 0, 0, 0, 0, 0, nullptr};
     const int tiles = g.tiles_m * g.tiles_n;
     // slab count (measured optima of scripts/bench_wgrad.py sweep on MI355X).  Every slab pays M*N atomics, and a grid that is
     // just over one block per CU leaves a tail, so: about one block per CU (never more) for the skinny, HBM-bound products;
@@ -493,7 +597,14 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
       sent[guard ? 1 : 0] = g; nsent[guard ? 1 : 0] = ns;
       return PTV_OK;
     }
-    if (ws) { g.ws = ws; g.ws_csum = colsum_a ? ws_csum : nullptr; g.slab0 = guard ? nsent[0] : 0; }
+    if (ws) {
+      g.ws = ws; g.ws_csum = colsum_a ? ws_csum : nullptr; g.slab0 = guard ? nsent[0] : 0;
+      if (fix_cnt) {                                             // in-kernel fix-up: the primary launch's geometry, for both launches
+        const WgArgs& pr = sent[has_a ? 0 : 1];                  // (planning pass)
+        g.fix_cnt = fix_cnt; g.fix_nslab = pr.nslab; g.fix_kper = pr.kper; g.fix_K = pr.K; g.fix_ktop = pr.k_top;
+        g.fix_extra = (has_a && has_b) ? 1 : 0; g.fix_acc = accumulate;
+      }
+    }
     else if (!accumulate && !zeroed) {
       const long total = (long)M * N;
       int nb = (int)((total + 255) / 256); if (nb > 2048) nb = 2048;
@@ -518,7 +629,6 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
 #undef WG_LAUNCH
     return PTV_OK;
   };
-  const bool has_a = kfast > 0, has_b = kfast < K;
   if (has_a) launch(false, 0, kfast, slabs, 0);
   if (has_b) launch(true, kfast, K - kfast, has_a ? 1 : slabs, 0);
   const int total_slabs = nsent[0] + nsent[1];
@@ -530,10 +640,18 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
     WsBuf* wb = ws_for(s, tile_bytes + sum_bytes);
     if (!wb) g_ord_fallbacks++;
     if (wb) { ws = wb->p; ws_csum = colsum_a ? wb->p + tile_bytes / sizeof(float) : nullptr; ws_slabs = total_slabs; }
+    // the last block of a tile reduces it -- unless a product that does not accumulate could find ALL its slabs dead (k_top): C must
+    // then still be cleared, which only the separate reduction does
+    // MEASURED SLOWER, off by default (PTV_WGRAD_FIXUP=1 enables it): 8.16 ms per step with the separate reduction launches against
+    // 9.26 with the fix-up (sc1 hand-off: 64 four-byte write-through stores per lane instead of cached ones, and the last block of each
+    // tile reading S x 64 KB past the caches while its CU's other work waits) and 10.5 with agent-scope fences instead (a release /
+    // acquire pair writes back and invalidates the XCD's whole L2, per block).  The 39 reduction launches per step stay.
+    static const int fix_env = [] { const char* e = getenv("PTV_WGRAD_FIXUP"); return e ? atoi(e) : 0; }();
+    if (wb && wb->cnt && fix_env && tiles <= WS_CNT && (accumulate || !k_top)) fix_cnt = wb->cnt;
   }
   if (has_a) launch(false, 0, kfast, slabs, 1);
   if (has_b) launch(true, kfast, K - kfast, has_a ? 1 : slabs, 1);
-  if (ws) {
+  if (ws && !fix_cnt) {
     const bool vec4 = (N & 3) == 0 && (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
     const long total = vec4 ? ((M * (long)N) >> 2) : M * (long)N;
     int nb = (int)((total + 255) / 256); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
