@@ -1495,7 +1495,7 @@ _DTF = {}
 
 
 def _decoder_tf_composite(ctx, z, emb, xs, force_dur, prec, P, W, params, B, R, E, He, Ht, Hn, Hd, NP):
-    """-> True when ptv_decoder_tf_fwd ran (ctx then holds exactly what the launch-by-launch path leaves on it)"""
+    """-> the node's outputs when ptv_decoder_tf_fwd ran (ctx then holds exactly what the launch-by-launch path leaves on it), else None"""
     if 't' not in _DTF:
         from ._lib import header_enum
         _DTF['t'], _DTF['d'] = header_enum('PtvDtfTensor'), header_enum('PtvDtfDim')
@@ -1504,17 +1504,19 @@ def _decoder_tf_composite(ctx, z, emb, xs, force_dur, prec, P, W, params, B, R, 
     emb3 = emb.view(16, R, E)
     w16 = [W[n] for n in ('z2dec_hid_linear.weight', 'z2dec_in_linear.weight', 'dec_time_gru.weight_ih_l0', 'dec_time_gru.weight_hh_l0',
                           'dec_time_to_notes_hid.weight', 'dec_notes_gru.weight_ih_l0')]
-    if (prec != 1 or not BF16_STORAGE or capturing_part() or any(w.dtype != BF16 for w in w16) or emb3.dtype != F32
+    # (not inside ANY graph capture: the persistent launch's turn is a raw event pair here, and an event recorded before the capture
+    # must not be waited for inside it -- the launch-by-launch path's wait_event() knows which edges a capture may keep)
+    if (prec != 1 or not BF16_STORAGE or torch.cuda.is_current_stream_capturing() or any(w.dtype != BF16 for w in w16) or emb3.dtype != F32
             or not emb3.is_contiguous() or not FUSED_DUR or not HEADS_FUSED or not NOTES_PERSIST or _act_dtype(prec, Ht) != BF16
             or z.dtype != F32 or not persist_supported(1, B, Ht, 32)):
-        return False
+        return None
     Zs, Zi = z.shape[1], W['z2dec_in_linear.weight'].shape[0]
     dims = [0] * D_['PTV_DTF_D_COUNT']
     for k, v in (('B', B), ('E', E), ('HE', He), ('HT', Ht), ('HN', Hn), ('HD', Hd), ('NP', NP), ('ZS', Zs), ('ZI', Zi), ('LDP', _pad8(NP))):
         dims[D_['PTV_DTF_D_' + k]] = v
     darr = _larr(dims)
     if not lib().ptv_decoder_tf_supported(darr):
-        return False
+        return None
     M = 15 * R
     xs = xs.contiguous()
     NS, NS16 = _empty(33, B, Ht, dev=dev), _empty(33, B, Ht, dev=dev, dtype=BF16)
@@ -1560,7 +1562,7 @@ def _decoder_tf_composite(ctx, z, emb, xs, force_dur, prec, P, W, params, B, R, 
     mark('dec_fwd:start')
     rc = lib().ptv_decoder_tf_fwd((ctypes.c_void_p * len(slots))(*slots), darr, stream_ptr())
     if rc == -3:
-        return False
+        return None
     check(rc, 'ptv_decoder_tf_fwd')
     _PERSIST_LAST[cur.device.index] = done
     mark('dec_fwd:heads')
@@ -1571,8 +1573,9 @@ def _decoder_tf_composite(ctx, z, emb, xs, force_dur, prec, P, W, params, B, R, 
                   dur_tabs=(tab0, tab), dur16_only=True)
     _DTF['calls'] = _DTF.get('calls', 0) + 1
     ctx.mark_non_differentiable(idx)
-    ctx._outs = (pitch.view(15, 32, B, NP), dur, idx)
-    return True
+    # (returned, never stored on ctx: outputs referenced from their own grad_fn are a cycle that only the garbage collector frees -- at an
+    # arbitrary later moment, e.g. inside a graph capture, where releasing blocks that other streams used records events and kills the capture)
+    return pitch.view(15, 32, B, NP), dur, idx
 
 
 class DecoderTFFn(torch.autograd.Function):
@@ -1596,8 +1599,10 @@ class DecoderTFFn(torch.autograd.Function):
         NP = W['pitch_out_linear.weight'].shape[0]              # 130
         S = ctx                                                  # stash everything on ctx
 
-        if DEC_COMPOSITE and _decoder_tf_composite(ctx, z, emb, xs, force_dur, prec, P, W, params, B, R, E, He, Ht, Hn, Hd, NP):
-            return ctx._outs
+        if DEC_COMPOSITE:
+            outs = _decoder_tf_composite(ctx, z, emb, xs, force_dur, prec, P, W, params, B, R, E, He, Ht, Hn, Hd, NP)
+            if outs is not None:
+                return outs
 
         # --- z -> initial time state, z_in  (ptvae.py:435-437)
         NS = _empty(33, B, Ht, dev=dev)
