@@ -232,6 +232,10 @@ class TrainingInterface:
         import torch.distributed as dist
         return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
 
+    def _rank(self):
+        import torch.distributed as dist
+        return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
     def _barrier(self):
         import torch.distributed as dist
         if self.parallel and dist.is_available() and dist.is_initialized():
@@ -268,6 +272,11 @@ class TrainingInterface:
                  'epoch': self.epoch, 'train_step': self.train_step, 'val_step': self.val_step, 'rng': rng}
         if self.is_main:
             torch.save(state, fn)
+        else:
+            # every other rank keeps ITS random state next to the checkpoint: the Philox sample offset (rank * per-GPU batch), the device
+            # generator and the loader generators differ by rank, and restoring rank 0's on all ranks would give every replica the same
+            # noise for different samples and the same shard of the data
+            torch.save({'rng': rng}, '%s.rng%d' % (fn, self._rank()))
         self._barrier()
 
     def load_checkpoint(self, fn):
@@ -281,6 +290,19 @@ class TrainingInterface:
         self.epoch, self.train_step, self.val_step = state['epoch'], state['train_step'], state['val_step']
         self._resumed = True                                   # run() continues from these counters unless told otherwise
         rng = state.get('rng')
+        if rng is not None and not self.is_main:
+            import os
+            own = '%s.rng%d' % (fn, self._rank())
+            if os.path.exists(own):
+                rng = torch.load(own, map_location=self.device, weights_only=False)['rng']
+            else:
+                # no per-rank block (checkpoint written by a single process): the shared parts only -- the noise seed and draw counter
+                # (this rank's own sample offset stays) and the coin stream (identical on every rank by construction)
+                if hasattr(self.model, '_philox') and rng.get('philox') is not None and self.model._philox is not None:
+                    self.model._philox = (rng['philox'][0], self.model._philox[1])
+                    self.model._draws = rng['draws']
+                random.setstate(rng['python_random'])
+                rng = None
         if rng is not None:
             if hasattr(self.model, '_philox'):
                 self.model._philox, self.model._draws = rng['philox'], rng['draws']
