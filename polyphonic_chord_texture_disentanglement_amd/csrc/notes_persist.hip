@@ -107,11 +107,6 @@ struct RowGruFwdArgs {
 
 // EMB = false: the notes GRU (hoisted input part gc, b_ih folded in, no mask, no final-state output); EMB = true: a direction of
 // dec_notes_emb_gru (b_ih, optional length mask, optional reversed time, final state)
-#ifndef PTV_FWD_PIPE
-#define PTV_FWD_PIPE 1
-#endif
-constexpr bool FWD_PIPE = PTV_FWD_PIPE != 0;
-
 template <int H, bool EMB>
 __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
   // a launch of the latency chain wins instruction issue against sibling-stream products.  The ground-truth note summaries (EMB) are
@@ -162,43 +157,6 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
   // workgroups of one XCD run in near lockstep and would all ask the L2 for the same few fragment lines at the same moment (a
   // handful of its 16 channels busy, the rest idle): each walks the passes and the k-blocks from its own starting point
   const int prot = (a.dbg & 8) ? 0 : (blockIdx.x >> 3) & (NPASS - 1), krot = (a.dbg & 8) ? 0 : (((blockIdx.x >> 5) & 7) * 2) & (KBH - 1);
-
-  // PIPE (the notes GRU, H = 512): what a pass reads from memory before it can start -- the first RD-1 weight k-blocks, the hoisted input
-  // part GC and the fp32 state of its cells -- is requested by the PREVIOUS pass, after its products and BEFORE its epilogue stores.  A
-  // wave's memory operations complete in order: requested at the start of the pass they sat behind the previous epilogue's 24 stores, and
-  // every weight block requested after the (HBM) GC loads waited for those -- two pipeline bubbles per pass, 8 per note step.
-  constexpr bool PIPE = (H != 128) && !EMB && FWD_PIPE;
-  constexpr bool PIPE_EPI = PIPE && (PTV_FWD_PIPE >= 2);             // also the epilogue operands (costs 80 registers: spills, see DESIGN)
-  constexpr int RDP = H == 128 ? 2 : 4, MHP = H == 128 ? 2 : 4;
-  bf16x8 bring[RDP][6];                                                  // the weight ring of the products (PIPE: primed across passes)
-  bf16x8 gq_n[PIPE_EPI ? MHP : 1][3]; float4 hq_n[PIPE_EPI ? MHP : 1][2];        // PIPE_EPI: the next pass's epilogue operands
-  auto pass_tiles = [&](int p, int (&tl)[6]) {
-    const int ut0 = wave * UTW + p * 2;
-    tl[0] = ut0; tl[1] = ut0 + 1; tl[2] = NUT + ut0; tl[3] = NUT + 1 + ut0; tl[4] = 2 * NUT + ut0; tl[5] = 2 * NUT + 1 + ut0;
-    return ut0;
-  };
-  auto ldw_t = [&](bf16x8 (&d)[6], const int (&tl)[6], int k) {           // k < KBH: W_hh block (k + krot) % KBH; else W_x block k - KBH
-#pragma unroll
-    for (int j = 0; j < 6; j++)
-      d[j] = k < KBH ? a.w_hh[((long)tl[j] * KBH + ((k + krot) & (KBH - 1))) * 64 + lane] : a.w_x[((long)tl[j] * 4 + (k - KBH)) * 64 + lane];
-  };
-  auto prefetch_pass = [&](int n2, int p02) {                             // everything pass (n2, p02) reads before its first product
-    int tl2[6];
-    const int p2 = (p02 + prot) & (NPASS - 1);
-    const int u2 = pass_tiles(p2, tl2) * 16 + eq * 8;
-#pragma unroll
-    for (int k = 0; k < RDP - 1; k++) ldw_t(bring[k], tl2, k);
-#pragma unroll
-    for (int i = 0; i < (PIPE_EPI ? MHP : 0); i++) {
-      const __bf16* g = a.gc + gate_off(grow[i], u2, R);
-      const long gstep = R * H;
-#pragma unroll
-      for (int gt = 0; gt < 3; gt++) gq_n[i][gt] = ldnt_bf16x8(g + gt * gstep);
-      const float* hp = a.HN + (long)n2 * RH + grow[i] * H + u2;
-      hq_n[i][0] = ldnt_f4(hp); hq_n[i][1] = ldnt_f4(hp + 4);
-    }
-  };
-  if constexpr (PIPE) { if (a.T > 0) prefetch_pass(0, 0); }
 
   // inside the step loop the waves exchange through LDS only (the fp32 state a lane re-reads from HN is its own store): lds_barrier()
   // lets a step's 117 MB of state / gate stores drain under the next step's products instead of at the step boundary
@@ -274,16 +232,8 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
         // epilogue operands of the pass (GC and the fp32 state of this lane's cells) are requested BEFORE the products: they come
         // from HBM, and waiting for them per M tile in the epilogue exposed that latency 16 times per step
         bf16x8 gq[MH][3]; float4 hq[MH][2];
-        if constexpr (PIPE_EPI) {
   #pragma unroll
-          for (int i = 0; i < MH; i++) {
-  #pragma unroll
-            for (int gt = 0; gt < 3; gt++) gq[i][gt] = gq_n[i][gt];
-            hq[i][0] = hq_n[i][0]; hq[i][1] = hq_n[i][1];
-          }
-        }
-  #pragma unroll
-        for (int i = 0; i < (PIPE_EPI ? 0 : MH); i++) {
+        for (int i = 0; i < MH; i++) {
           if constexpr (!EMB) {
             const __bf16* g = a.gc + gate_off(grow[mh + i], u, R);            // column-blocked by 32: [3H/32][R][32]
             const long gstep = R * H;
@@ -299,13 +249,15 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
         // before the MFMAs of k-block k (24 MFMAs = ~400 cycles per k-block against ~900 cycles of L2 latency)
         // (H = 128: two workgroups share a CU -- both directions of the note-summary GRU run side by side -- so half the registers:
         // a ring of 2)
-        constexpr int RD = RDP;
-        bf16x8 (&b)[RD][6] = bring;
-        auto ldw = [&](bf16x8 (&d)[6], int k) { ldw_t(d, tl, k); };
-        if constexpr (!PIPE) {
+        constexpr int RD = H == 128 ? 2 : 4;
+        bf16x8 b[RD][6];
+        auto ldw = [&](bf16x8 (&d)[6], int k) {                            // k < KBH: W_hh block (k + krot) % KBH; else W_x block k - KBH
   #pragma unroll
-          for (int k = 0; k < RD - 1; k++) ldw(b[k], k);
-        }
+          for (int j = 0; j < 6; j++)
+            d[j] = k < KBH ? a.w_hh[((long)tl[j] * KBH + ((k + krot) & (KBH - 1))) * 64 + lane] : a.w_x[((long)tl[j] * 4 + (k - KBH)) * 64 + lane];
+        };
+  #pragma unroll
+        for (int k = 0; k < RD - 1; k++) ldw(b[k], k);
   #pragma unroll
         for (int k = 0; k < KT; k++) {
           if (k + RD - 1 < KT) ldw(b[(k + RD - 1) % RD], k + RD - 1);
@@ -321,10 +273,6 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
               acc[i][slot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[k % RD][j], av, acc[i][slot], 0, 0, 0);
             }
           }
-        }
-        if constexpr (PIPE) {                                              // the next pass's first loads, ahead of this pass's stores
-          if (p0 + 1 < NPASS) prefetch_pass(n, p0 + 1);
-          else if (n + 1 < a.T) prefetch_pass(n + 1, 0);
         }
         // ---- epilogue: GRU cell on this lane's cells of the pass
   #pragma unroll
