@@ -67,6 +67,24 @@ class DisentangleVAE(PytorchModel):
             self._draws += 1
         return dist.rsample(eps=eps)
 
+    # ---- model.py:22-40: two helpers the reference defines and never calls (both call sites are commented out, model.py:44-46,102).
+    # Plain tensor glue, kept for the method surface; not part of the hot path
+    def confuse_prmat(self, pr_mat):
+        """model.py:22-29: every non-zero entry of the piano-roll is also written one semitone up or down (coin per entry, clamped to
+        0..127), in place.  Draw order = the reference's: one torch.randint(0, 2, (nnz,)) from the default CPU generator."""
+        nz = torch.nonzero(pr_mat.long())
+        eps = ((2 * torch.randint(0, 2, (nz.size(0),))) - 1).long().to(pr_mat.device)
+        tgt = torch.clamp(nz[:, 2] + eps, min=0, max=127)
+        pr_mat[nz[:, 0], nz[:, 1], tgt] = pr_mat[nz[:, 0], nz[:, 1], nz[:, 2]]
+        return pr_mat
+
+    def get_chroma(self, pr_mat):
+        """model.py:31-40: log(1 + per-beat, per-pitch-class sum of the [B,32,128] piano-roll) -> [B,8,12]"""
+        bs = pr_mat.size(0)
+        pr = torch.cat([pr_mat, torch.zeros(bs, 32, 4, device=pr_mat.device, dtype=pr_mat.dtype)], dim=-1)
+        c = pr.view(bs, 32, -1, 12).sum(dim=-2).view(bs, 8, 4, 12).sum(dim=-2).float()
+        return torch.log(c + 1)
+
     # ---- model.py:42-55
     def run(self, x, c, pr_mat, tfr1, tfr2, tfr3, confuse=True):
         F_.mark('run:start')

@@ -172,3 +172,22 @@ def test_checkpoint_keeps_each_ranks_random_state(tmp_path, monkeypatch):
     r1.load_checkpoint(fn)
     assert r1.model._philox == (9, 16) and r1.model._draws == 5   # seed + draw counter shared, sample offset kept
     assert random.getstate() == torch.load(fn, weights_only=False)['rng']['python_random']      # the coin stream is the checkpoint's
+
+
+def test_dead_helpers_of_the_reference_model_exist_and_compute_what_it_defines():
+    """model.py:22-40 (`confuse_prmat`, `get_chroma`: defined, never called -- both call sites are commented out).  Plain tensor code:
+    checked on the CPU against the reference's own expressions restated inline."""
+    m = build_reduced('cpu')
+    g = torch.Generator().manual_seed(1)
+    pr = ((torch.rand(3, 32, 128, generator=g) < 0.05).float() * torch.randint(1, 9, (3, 32, 128), generator=g).float())
+    pad = torch.zeros(3, 32, 4)
+    ref = torch.log(torch.cat([pr, pad], -1).view(3, 32, -1, 12).sum(-2).view(3, 8, 4, 12).sum(-2).float() + 1)
+    assert torch.equal(m.get_chroma(pr.clone()), ref) and ref.shape == (3, 8, 12)
+    torch.manual_seed(5)
+    out = m.confuse_prmat(pr.clone())
+    torch.manual_seed(5)
+    nz = torch.nonzero(pr.long())
+    eps = ((2 * torch.randint(0, 2, (nz.size(0),))) - 1).long()
+    exp = pr.clone()
+    exp[nz[:, 0], nz[:, 1], torch.clamp(nz[:, 2] + eps, min=0, max=127)] = exp[nz[:, 0], nz[:, 1], nz[:, 2]]
+    assert torch.equal(out, exp) and (out != pr).any()
