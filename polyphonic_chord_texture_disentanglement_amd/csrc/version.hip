@@ -3,4 +3,7 @@
 extern "C" const char* ptv_arch(void) { return "gfx950"; }
 // 2 (round 3): ptv_step_params / ptv_ordered_reductions / ptv_wgrad_mode added; ptv_gemm dtypes bit 3 (column-blocked C); the
 // row-partitioned GRU pair takes gc / ext column-blocked and keeps its gate planes unit-blocked
-extern "C" int ptv_abi_version(void) { return 2; }
+// 3 (round 4): ptv_dur_gru_bwd takes b_hh / tab0 / tab (gates may be NULL: recompute); ptv_txt_conv_relu_pool_*_rows take the arg-max
+// map; ptv_*_geom, ptv_heads_*, ptv_pack_mfma_b2 / _multi, ptv_gru_persist_bwd_splitk, ptv_gradnorm_clip_adam_step and the composites
+// ptv_decoder_tf_fwd / ptv_chord_decoder_fwd added
+extern "C" int ptv_abi_version(void) { return 3; }
