@@ -1200,6 +1200,9 @@ class BiGruFinalFn(torch.autograd.Function):
         dx_acc = None
         if ctx.link is not None and ctx.link['demb'] is not None and ctx.needs_input_grad[0]:
             dx_acc, ctx.link['demb'] = ctx.link['demb'].view(-1, x3.shape[2]), None     # the decoder node's gradient of the same tensor
+            ev = ctx.link.pop('demb_event', None)
+            if ev is not None:
+                wait_event(cur_stream(), ev)              # (its product ran on the decoder's sibling stream: not covered by autograd's edge)
             _EMB_LINK.pop(x3.data_ptr(), None)
         pending = [] if (BIGRU_CHAIN_FIRST and OVERLAP and not capturing_part()) else None
         grads, dx = _bigru_backward(ctx.prec, x3, w, ctx.saved_state, dout.contiguous(), ctx.needs_input_grad[0], dx_acc, pending)
@@ -1490,6 +1493,10 @@ def _eye2(dev):
 # The teacher-forced decoder forward behind ONE C entry point (ptv_decoder_tf_fwd, csrc/composite.hip): launch sequence, the persistent
 # launch's turn and the shape decisions in C++; this side allocates the tensors and fills the two tables.  0 = sequence the launches here.
 DEC_COMPOSITE = os.environ.get('PTV_DEC_COMPOSITE', '1') != '0'
+# the note tokens' gradient product (194 us, not an input of the time BPTT) on the sibling stream instead of in front of the BPTT on the
+# chain: MEASURED SLOWER (9.0 vs 8.38 ms per step) -- the persistent time BPTT then starts earlier and runs beside more of the bulk
+# products, and a persistent grid with company loses more than the chain gained.  Off.
+DTOK_ASYNC = os.environ.get('PTV_DTOK_ASYNC', '0') != '0'
 CHD_COMPOSITE = os.environ.get('PTV_CHD_COMPOSITE', '1') != '0'
 _DTF = {}
 
@@ -1718,7 +1725,8 @@ class DecoderTFFn(torch.autograd.Function):
         st = ctx.st
         ctx.st = None
         R, E = st['R'], st['E']
-        dz, demb, dTOKS, G, side = decoder_bwd_core(P, st, z, emb.view(16, R, E)[:15].view(15 * R, E), dpitch, ddur)
+        link_ok = ctx.emb_link is not None and ctx.needs_input_grad[2]
+        dz, demb, dTOKS, G, side = decoder_bwd_core(P, st, z, emb.view(16, R, E)[:15].view(15 * R, E), dpitch, ddur, dtok_async=link_ok)
         mark('dec_bwd:end')
         # parameter gradients only: joined when the backward pass ends -- but only if autograd ADOPTS the tensors
         # (p.grad is None and the buffer is this step's arena view); an accumulation `p.grad += g` would run on this
@@ -1739,11 +1747,14 @@ class DecoderTFFn(torch.autograd.Function):
         demb_out = demb.view(16, 32, B, E)
         if ctx.emb_link is not None and ctx.needs_input_grad[2] and demb.dtype == F32 and demb.is_contiguous():
             ctx.emb_link['demb'] = demb                   # the summary node accumulates into it and returns it (BiGruFinalFn.backward)
+            ctx.emb_link['demb_event'] = getattr(side, 'dtok_event', None)      # ... after this event, if the product ran on the sibling stream
             demb_out = None
+        elif getattr(side, 'dtok_event', None) is not None:
+            wait_event(cur_stream(), side.dtok_event)     # handed to autograd as an ordinary gradient: complete on this stream
         return (dz, demb_out, dTOKS[1:].view(R, 2 * He), None, None) + tuple(G[n] for n in DEC_PARAM_NAMES)
 
 
-def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
+def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur, dtok_async=False):
     """BPTT of the PianoTree decoder given the saved forward state `st` -- shared by the teacher-forced node (DecoderTFFn) and
     the step-loop node (functional_free.DecoderStepFn: argmax is not differentiable, so with the fed tokens recorded every
     chain is the same batched BPTT).  Chain (duration GRU -> heads -> notes GRU -> time GRU -> z) on the caller's stream; every
@@ -1904,10 +1915,19 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     mark('dec_bwd:notes_bptt')
     dGC = sum_steps(dgi_n, t_top=top_step)                                    # [R, 3Hn]
 
-    def notes_dx():
-        dtok = _empty(16, R, E, dev=dev)
-        dtok[15].zero_()
+    # dtok_async (the teacher-forced node with the embedding link armed): the gradient of the fed note tokens -- a 245760 x 128 x 1536
+    # product, 194 us -- is NOT an input of the time BPTT; it used to sit in front of it on the chain.  It runs on the sibling stream
+    # (first in its queue, ahead of this section's weight-gradient products); whoever consumes dtok waits for `side.dtok_event`
+    dtok = _empty(16, R, E, dev=dev)
+    dtok[15].zero_()
+    side.dtok_event = None
+
+    def dtok_product():
         gemm_dx(dgi_n.view(M, 3 * Hn), w_ih_n, slice(Ht, None), out=dtok[:15].view(M, E), prec=prec, m_top=top_step, m_unit=R)
+
+    def notes_dx():
+        if not (dtok_async and DTOK_ASYNC and OVERLAP and not capturing_part()):
+            dtok_product()
         dNS = gemm_dx(dGC, w_ih_n, slice(0, Ht), prec=prec)                   # [R, Ht]
         w_tn = W['dec_time_to_notes_hid.weight']
         gemm_dx(dHN0, w_tn, out=dNS, acc=True, prec=prec)
@@ -1935,6 +1955,12 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
             wgrad('dec_notes_gru.weight_ih_l0', dgi_n.view(M, 3 * Hn), tok_op, slice(Ht, None))
         wgrad('dec_time_to_notes_hid.weight', dHN0, NSf_op)
         bgrad('dec_time_to_notes_hid.bias', dHN0)
+    if dtok_async and DTOK_ASYNC and OVERLAP and not capturing_part():
+        def dtok_side():
+            dtok_product()
+            return record_event()
+        side.dtok_event = side(dtok_side, dgi_n, dtok, top_step)
+        _record_stream(dtok, side.s)
     if FORK_EARLY:
         side(notes_wgrads, dgi_n, dgh_n, dGC, dHN0, dNSUM)                   # forked before the chain's dX products are queued
     dtok, dNS = notes_dx()
