@@ -1497,6 +1497,7 @@ DEC_COMPOSITE = os.environ.get('PTV_DEC_COMPOSITE', '1') != '0'
 # chain: MEASURED SLOWER (9.0 vs 8.38 ms per step) -- the persistent time BPTT then starts earlier and runs beside more of the bulk
 # products, and a persistent grid with company loses more than the chain gained.  Off.
 DTOK_ASYNC = os.environ.get('PTV_DTOK_ASYNC', '0') != '0'
+NOTES_WGRADS_LATE = os.environ.get('PTV_NOTES_WGRADS_LATE', '0') != '0'
 CHD_COMPOSITE = os.environ.get('PTV_CHD_COMPOSITE', '1') != '0'
 _DTF = {}
 
@@ -1964,13 +1965,17 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur, dtok_async=False):
     if FORK_EARLY:
         side(notes_wgrads, dgi_n, dgh_n, dGC, dHN0, dNSUM)                   # forked before the chain's dX products are queued
     dtok, dNS = notes_dx()
-    if not FORK_EARLY:
+    if not FORK_EARLY and not NOTES_WGRADS_LATE:
         side(notes_wgrads, dgi_n, dgh_n, dGC, dHN0, dNSUM)
 
     mark('dec_bwd:notes_dx')
     # ---- time GRU (32 steps, batch B) ----
     w_hh_t, w_ih_t = W['dec_time_gru.weight_hh_l0'], W['dec_time_gru.weight_ih_l0']
     dgi_t, dgh_t, dzhid = gru_bwd(prec, NS, st['gates_t'], w_hh_t, dh_ext=dNS.view(32, B, Ht))
+    if not FORK_EARLY and NOTES_WGRADS_LATE:
+        # (forked AFTER the time BPTT is queued: a sibling stream waits for what its parent has queued, so the notes GRU's four deep
+        # weight-gradient products start when the persistent BPTT is done instead of running beside it)
+        side(notes_wgrads, dgi_n, dgh_n, dGC, dHN0, dNSUM)
     mark('dec_bwd:time_bptt')
     dZG = sum_steps(dgi_t)                                                    # [B, 3Ht]
     dz_in = gemm_dx(dZG, w_ih_t, slice(2 * He, None), prec=prec)              # [B, Zi]
