@@ -1001,6 +1001,32 @@ def test_repeated_backward_passes_are_bit_identical_and_no_reduction_fell_back_t
         assert torch.equal(runs[0], runs[i]), (i, float((runs[0] - runs[i]).abs().max()))
 
 
+def test_fp32_atomics_mode_matches_the_ordered_reductions():
+    """round-3 advice: keep the PTV_WGRAD_ORDERED=0 path (every reduction ends in fp32 atomics: arrival-order rounding) exercised.
+    Same full-geometry bf16 backward pass in both modes of ptv_ordered_reductions: losses to a few ulps, gradients equal to the
+    noise of fp32 summation order amplified by the bf16 rounding of saved tensors (1e-2 of each tensor's largest element; measured 2e-3)."""
+    from polyphonic_chord_texture_disentanglement_amd._lib import lib
+    g = load_npz('full_tf1_b4.npz')
+    x, c, pr = synth_batch(int(g['B']), int(g['data_seed']))
+    res = {}
+    try:
+        for ordered in (1, 0):
+            assert lib().ptv_ordered_reductions(ordered) == 0
+            m = M.DisentangleVAE.init_model(torch.device(DEV))
+            m.load_state_dict(full_params())
+            m.to(DEV).set_precision('bf16')
+            outs, losses = _run(m, g, x, c, pr)
+            losses[0].backward()
+            res[ordered] = (np.array([l.item() for l in losses]), {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+    finally:
+        lib().ptv_ordered_reductions(1)
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=0, atol=1e-5)      # (the loss sums are grid reductions too: a few fp32 ulps)
+    for k, a in res[1][1].items():
+        b = res[0][1][k]
+        # (bf16 saved tensors upstream: an fp32 ulp of summation noise can flip a bf16 rounding, 2^-9 relative, of what the next product reads)
+        assert float((a - b).abs().max()) <= 1e-7 + 1e-2 * float(a.abs().max()), k
+
+
 @pytest.mark.parametrize('prec,tfr', [('fp32', 1.0), ('bf16', 1.0), ('bf16', 0.0)])
 def test_two_runs_of_a_training_trace_are_bit_identical(prec, tfr):
     """Ordered reductions (include/ptvae_hip.h: ptv_ordered_reductions, the default): no result of the step depends on the arrival
