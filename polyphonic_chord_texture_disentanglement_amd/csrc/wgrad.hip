@@ -588,8 +588,18 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
     }
     const int maxs = kn / (4 * WBK) > 0 ? kn / (4 * WBK) : 1;
     if (ns > maxs) ns = maxs;
-    if (tiles % 8 == 0) g.map = 2;
-    else if (ns >= 8 && ns % 8 == 0) g.map = 1;
+    // block -> (slab, tile) so that the blocks of one XCD (dispatch is round-robin over the 8) share operand columns in ITS L2:
+    // map 2 gives an XCD a range of tiles for all slabs (B columns are then fetched by every XCD: fine when K is short), map 1 gives it
+    // whole slabs -- every K row is fetched by one XCD only (PMC on 1536 x 512 x 245760: L2 hit 29 % and 3.3x the algorithmic bytes from
+    // the fabric with map 2)
+    static const int map_env = [] { const char* e = getenv("PTV_WGRAD_MAP"); return e ? atoi(e) : -1; }();
+    const bool can1 = ns >= 8 && ns % 8 == 0, can2 = tiles % 8 == 0;
+    const bool deepk = kn >= 32768;
+    if (map_env == 1 && can1) g.map = 1;
+    else if (map_env == 2 && can2) g.map = 2;
+    else if (map_env == 0) g.map = 0;
+    else if (can1 && (deepk || !can2)) g.map = 1;
+    else if (can2) g.map = 2;
     g.kper = cdiv(cdiv(kn, ns), WBK) * WBK;
     if (g.map != 1) ns = cdiv(kn, g.kper);
     g.nslab = ns;
