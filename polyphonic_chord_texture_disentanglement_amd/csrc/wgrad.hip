@@ -594,7 +594,7 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
     // the fabric with map 2)
     static const int map_env = [] { const char* e = getenv("PTV_WGRAD_MAP"); return e ? atoi(e) : -1; }();
     const bool can1 = ns >= 8 && ns % 8 == 0, can2 = tiles % 8 == 0;
-    const bool deepk = kn >= 32768;
+    const bool deepk = kn >= 16384;
     if (map_env == 1 && can1) g.map = 1;
     else if (map_env == 2 && can2) g.map = 2;
     else if (map_env == 0) g.map = 0;
