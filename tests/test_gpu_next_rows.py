@@ -417,3 +417,41 @@ def test_reference_helper_methods_vs_reference_golden(monkeypatch):
     np.testing.assert_allclose(emb.detach().cpu().numpy(), g['enc.embedded'], rtol=0, atol=2e-5)
     dist.mean.sum().backward()                                   # the entry point is differentiable like the reference's
     assert enc.note_embedding.weight.grad is not None and float(enc.note_embedding.weight.grad.abs().sum()) > 0
+
+
+def test_new_entry_points_reject_what_they_cannot_run():
+    """error behaviour of round 4's entry points: argument errors come back as status codes before anything is launched, never as a
+    launch with wild sizes -- the geometry-general embedding (dur_width > 8, row stride too short), the composites (shape outside the
+    specialised kernels: PTV_ERR_UNSUPPORTED = -3, missing table slots: PTV_ERR_ARG = -1), the duration BPTT without its gate tables"""
+    import ctypes
+    from polyphonic_chord_texture_disentanglement_amd._lib import lib, ptr, stream_ptr, header_enum
+    L = lib()
+    x = torch.zeros(2, 4, 3, 10, device=DEV, dtype=torch.int64)
+    w, b = torch.zeros(8, 43, device=DEV), torch.zeros(8, device=DEV)
+    emb = torch.zeros(3, 4, 2, 8, device=DEV)
+    st = stream_ptr()
+    assert L.ptv_embed_fwd_geom(ptr(x), ptr(w), ptr(b), ptr(emb), None, 2, 8, 4, 3, 34, 9, 34, st) == -1        # dur_width 9 > 8
+    assert L.ptv_embed_fwd_geom(ptr(x), ptr(w), ptr(b), ptr(emb), None, 0, 8, 4, 3, 34, 5, 34, st) == -1        # empty batch
+    assert L.ptv_multihot_geom(ptr(x), ptr(emb), 10, 2, 4, 3, 34, 5, 0, st) == -1                                 # ld < P + D
+    D, T = header_enum('PtvDtfDim'), header_enum('PtvDtfTensor')
+    dims = [0] * D['PTV_DTF_D_COUNT']
+    for k, v in (('B', 4), ('E', 20), ('HE', 12), ('HT', 40), ('HN', 28), ('HD', 8), ('NP', 130), ('ZS', 16), ('ZI', 8), ('LDP', 136)):
+        dims[D['PTV_DTF_D_' + k]] = v
+    darr = (ctypes.c_long * len(dims))(*dims)
+    assert L.ptv_decoder_tf_supported(darr) == 0                                                                # reduced widths: not this kernel set
+    slots = (ctypes.c_void_p * T['PTV_DTF_COUNT'])()
+    assert L.ptv_decoder_tf_fwd(slots, darr, st) == -3
+    for k, v in (('E', 128), ('HE', 128), ('HT', 1024), ('HN', 512), ('HD', 64), ('ZS', 512), ('ZI', 256), ('B', 512)):
+        dims[D['PTV_DTF_D_' + k]] = v
+    darr = (ctypes.c_long * len(dims))(*dims)
+    assert L.ptv_decoder_tf_supported(darr) == 1
+    assert L.ptv_decoder_tf_fwd(slots, darr, st) == -1                                                          # supported shape, empty table
+    CT, CD = header_enum('PtvCdfTensor'), header_enum('PtvCdfDim')
+    assert L.ptv_chord_decoder_fwd((ctypes.c_void_p * CT['PTV_CDF_COUNT'])(), (ctypes.c_long * CD['PTV_CDF_D_COUNT'])(), st) == -1
+    M, H = 64, 64
+    z = torch.zeros(6 * M * H, device=DEV)
+    zi = torch.zeros(5 * M, device=DEV, dtype=torch.int32)
+    part = torch.zeros(L.ptv_dur_gru_bwd_part_size(), device=DEV)
+    assert L.ptv_dur_gru_bwd(H, M, None, M * H, 4 * M * H, ptr(z), M * H, 0, ptr(z), 10, ptr(z), ptr(z), ptr(zi), M, ptr(z), ptr(part), 1,
+                             None, None, None, st) == -1                                                         # recompute mode needs b_hh / tab0 / tab
+    torch.cuda.synchronize()
