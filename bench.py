@@ -118,15 +118,22 @@ def golden_parity(precision, dev, case='full_tf1_b16', detail=False):
     return res
 
 
-def _measure(step_fn, steps, warmup):
+def _measure(step_fn, steps, warmup, repeats=2):
+    """side figures (extras) only: seconds per step over `steps` steps after `warmup`, best of `repeats` timed blocks -- a block of four
+    22-ms steps is halved by ONE caching-allocator growth (hipMalloc synchronises) right after the previous workload's cache was
+    dropped; seen once as 9.2k instead of 22.8k samples/s.  The headline measurement (main()) times exactly K steps once, as the contract says."""
     for i in range(warmup):
         step_fn(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step_fn(warmup + i)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps
+    best = None
+    for r in range(repeats):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step_fn(warmup + r * steps + i)
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / steps
+        best = t if best is None else min(best, t)
+    return best
 
 
 def extras(dev, B, rank):
