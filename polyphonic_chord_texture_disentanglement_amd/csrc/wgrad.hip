@@ -57,6 +57,7 @@ struct WgArgs {
   unsigned* fix_cnt;
   int fix_nslab, fix_kper, fix_K, fix_extra, fix_acc;
   const int* fix_ktop;
+  int pairs;                     // wgrad2_kernel: blocks are decoded over (tiles_m + 1) / 2 * tiles_n tile PAIRS instead of tiles
 };
 
 // which part of a slab's K range survives the k_top limits: shared by the product kernel and the ordered reduction (a slab that is
@@ -169,14 +170,16 @@ template <> struct WStage<true> {
 
 // MFMA operand of 16 columns starting at `col`: lane (i = lane & 15, g = lane >> 4) receives rows 4g..4g+3 and 16+4g..16+4g+3 of
 // column col + i.  Supplier lane s of a 16-lane group hands in the address of row s >> 2, columns 4 (s & 3) .. +3 of the block.
-__device__ __forceinline__ wbf16x8 tr_frag(const __bf16* st, int col) {
+template <int LD>
+__device__ __forceinline__ wbf16x8 tr_frag_ld(const __bf16* st, int col) {
   const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
-  const __bf16* p = st + (g * 4 + (s >> 2)) * WLD + col + (s & 3) * 4;
+  const __bf16* p = st + (g * 4 + (s >> 2)) * LD + col + (s & 3) * 4;
   const ws16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-  const ws16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * WLD));
+  const ws16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * LD));
   const ws16x8 w = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(wbf16x8, w);
 }
+__device__ __forceinline__ wbf16x8 tr_frag(const __bf16* st, int col) { return tr_frag_ld<WLD>(st, col); }
 
 // four consecutive floats (16-byte aligned) as two agent-scope 8-byte loads: served past this CU's non-coherent caches
 __device__ __forceinline__ float4 ld4_agent(const float* p) {
@@ -408,6 +411,145 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256 x 128 block tile: TWO vertically adjacent 128 x 128 output tiles per block, sharing the B stage (round 4).  The 128 x 128 kernel
+// reads 8 operand fragments from LDS per 16 MFMAs and wave -- at the MFMA rate that is the LDS's whole 128 B/clk (PMC: SQ_WAIT_INST_LDS
+// 34 % of the wave cycles on 1536 x 512 x 245760 once the fabric traffic was fixed); a wave that owns 128 x 64 of the block reads 12 per
+// 32.  Waves 0/1 own the upper tile, 2/3 the lower one, so the partials leave in the SAME [slab][tile][128][128] workspace layout and
+// the reduction (and the guarded tail launch) are unchanged.  A bf16, unguarded fast path, two register sets of prefetch.
+// ---------------------------------------------------------------------------------------------
+constexpr int WLD2 = 272;                                       // A stage row stride: 544 B = 8 banks mod 32, like WLD
+constexpr int WSTAGE2 = WBK * WLD2;
+
+template <bool BF32>
+__global__ __launch_bounds__(256, 2) void wgrad2_kernel(WgArgs g) {
+  if (g.prio) __builtin_amdgcn_s_setprio(3);
+  __shared__ __attribute__((aligned(16))) __bf16 As[2 * WSTAGE2];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2 * WSTAGE];
+  const int tiles = g.tiles_m * g.tiles_n, pairs = g.pairs;
+  int b = blockIdx.x, slab, pair;
+  if (g.map == 1) { const int q = b >> 3; slab = (q / pairs) * 8 + (b & 7); pair = q % pairs; }
+  else if (g.map == 2) { const int tx = pairs >> 3, q = b >> 3; pair = (b & 7) * tx + q % tx; slab = q / tx; }
+  else { slab = b / pairs; pair = b % pairs; }
+  int k_begin, k_end;
+  if (!slab_range(g, slab, k_begin, k_end)) return;
+  const int pm = pair / g.tiles_n, tn = pair % g.tiles_n;
+  const int m_blk = pm * 2 * WBM, n_blk = tn * WBN;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int half = wave >> 1, wm = half * WBM, wn = (wave & 1) * 64;
+  wf32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = wf32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_sum = g.csum != nullptr && n_blk == 0 && wn == 0;
+  wf32x4 accs[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) accs[i] = wf32x4{0.f, 0.f, 0.f, 0.f};
+  wbf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; e++) ones[e] = (__bf16)1.0f;
+  const int nst = (k_end - k_begin + WBK - 1) / WBK, last = nst - 1;
+  // staging: thread -> rows r, r + 16 of the stage; A columns c, c + 128 of the block's 256; B columns c of its 128
+  const int r = threadIdx.x >> 4, c = (threadIdx.x & 15) * 8;
+  const int ca0 = m_blk + c, ca1 = ca0 + WBM, cb = n_blk + c;
+  const __bf16* pa0 = reinterpret_cast<const __bf16*>(g.A) + (long)(k_begin + r) * g.lda + (ca0 < g.M ? ca0 : 0);
+  const __bf16* pa1 = reinterpret_cast<const __bf16*>(g.A) + (long)(k_begin + r) * g.lda + (ca1 < g.M ? ca1 : 0);
+  const typename WSrc<BF32>::T* pb = reinterpret_cast<const typename WSrc<BF32>::T*>(g.B) + (long)(k_begin + r) * g.ldb + (cb < g.N ? cb : 0);
+  wbf16x8 ra[2][2][2];                                            // [set][row half][column half]
+  WStage<BF32> rb[2];
+#define W2_FETCH(set, t)                                                                                   \
+  do {                                                                                                     \
+    const long o_ = (long)(t) * WBK * g.lda;                                                               \
+    ra[set][0][0] = *reinterpret_cast<const wbf16x8*>(pa0 + o_);                                           \
+    ra[set][1][0] = *reinterpret_cast<const wbf16x8*>(pa0 + o_ + 16 * g.lda);                              \
+    ra[set][0][1] = *reinterpret_cast<const wbf16x8*>(pa1 + o_);                                           \
+    ra[set][1][1] = *reinterpret_cast<const wbf16x8*>(pa1 + o_ + 16 * g.lda);                              \
+    rb[set].load_fast(pb + (long)(t) * WBK * g.ldb, g.ldb);                                                \
+  } while (0)
+#define W2_STORE(set, buf)                                                                                 \
+  do {                                                                                                     \
+    __bf16* a_ = As + (buf) * WSTAGE2;                                                                     \
+    *reinterpret_cast<wbf16x8*>(a_ + r * WLD2 + c) = ra[set][0][0];                                        \
+    *reinterpret_cast<wbf16x8*>(a_ + (r + 16) * WLD2 + c) = ra[set][1][0];                                 \
+    *reinterpret_cast<wbf16x8*>(a_ + r * WLD2 + c + WBM) = ra[set][0][1];                                  \
+    *reinterpret_cast<wbf16x8*>(a_ + (r + 16) * WLD2 + c + WBM) = ra[set][1][1];                           \
+    rb[set].store(Bs + (buf) * WSTAGE);                                                                    \
+  } while (0)
+  // (every fetch unconditional, the stage index clamped: see wgrad_kernel)
+  W2_FETCH(0, 0);
+  W2_FETCH(1, min(1, last));
+  W2_STORE(0, 0);
+  W2_FETCH(0, min(2, last));
+  __syncthreads();
+#define W2_BODY(u, t)                                                                                      \
+  do {                                                                                                     \
+    const __bf16* as = As + ((u) & 1) * WSTAGE2;                                                           \
+    const __bf16* bs = Bs + ((u) & 1) * WSTAGE;                                                            \
+    wbf16x8 fb[4];                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 4; j++) fb[j] = tr_frag(bs, wn + j * 16);                        \
+    constexpr int nu = ((u) + 1) & 1;                                                                      \
+    W2_STORE(nu, ((u) + 1) & 1);                                                                           \
+    W2_FETCH(nu, min((t) + 3, last));                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 8; i++) {                                                        \
+      const wbf16x8 fa = tr_frag_ld<WLD2>(as, wm + i * 16);                                                \
+      _Pragma("unroll") for (int j = 0; j < 4; j++)                                                        \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);                \
+      if (do_sum) accs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, ones, accs[i], 0, 0, 0);           \
+    }                                                                                                      \
+    __syncthreads();                                                                                       \
+  } while (0)
+  int t0 = 0;
+  for (; t0 + 2 <= nst; t0 += 2) { W2_BODY(0, t0); W2_BODY(1, t0 + 1); }
+  if (t0 < nst) W2_BODY(0, t0);
+#undef W2_BODY
+#undef W2_STORE
+#undef W2_FETCH
+  const int tile = (pm * 2 + half) * g.tiles_n + tn;               // this wave's 128 x 128 output tile (the lower one may not exist)
+  const int tm_blk = m_blk + wm;                                   // its first row
+  if (tm_blk >= g.M) return;
+  if (do_sum && (lane & 15) == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const int m = tm_blk + i * 16 + (lane >> 4) * 4 + rr;
+        if (m < g.M) {
+          if (g.ws_csum) g.ws_csum[(long)(g.slab0 + slab) * g.M + m] = accs[i][rr];
+          else atomicAdd(g.csum + m, accs[i][rr]);
+        }
+      }
+  }
+  if (g.ws) {                                                    // ordered reduction: this slab's partial of the wave's tile
+    float* wt = g.ws + ((long)(g.slab0 + slab) * tiles + tile) * (WBM * WBN);
+    const int mrem = g.M - tm_blk - (lane >> 4) * 4, nrem = g.N - n_blk - wn - (lane & 15);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+          if (i * 16 + rr < mrem && j * 16 < nrem)
+            wt[(i * 16 + (lane >> 4) * 4 + rr) * WBN + wn + j * 16 + (lane & 15)] = acc[i][j][rr];
+    return;
+  }
+  const bool single = g.nslab == 1;
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int n = n_blk + wn + j * 16 + (lane & 15);
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const int m = tm_blk + i * 16 + (lane >> 4) * 4 + rr;
+        if (m >= g.M || n >= g.N) continue;
+        float* cp = g.C + (long)m * g.ldc + n;
+        if (single) *cp += g.alpha * acc[i][j][rr];
+        else atomicAdd(cp, g.alpha * acc[i][j][rr]);
+      }
+    }
+}
+
 // ordered reduction of the slab partials: C[m][n] (+)= alpha * (p_0 + p_1 + ...) in slab order -- the same bits on every run.
 // ga: the fast launch's arguments (slabs 0 .. ga.nslab-1), gb: the guarded tail launch (one slab, number ga.nslab), if has_b.
 __global__ void wgrad_reduce_kernel(WgArgs ga, WgArgs gb, int has_a, int has_b, int accumulate) {
@@ -563,6 +705,11 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
   const int kfast = !vec ? 0 : (odd ? ((K - 1) / WBK) * WBK : (K / WBK) * WBK);
   static const int nset_env = [] { const char* e = getenv("PTV_WGRAD_NSET"); return e ? atoi(e) : 0; }();
   const int nset = (af || bf) ? 2 : (nset_env == 4 ? 4 : 2);       // 4 register sets only fit with bf16 sources
+  // MEASURED SLOWER, off by default (PTV_WGRAD_TM2=1 enables it): 1536 x 512 x 245760 at its best slab count 516 us against 467 for the
+  // 128 x 128 kernel, 3072 x 1024 x 16384 154 against 133, the step's 20 shapes 2306 against 1903 us -- 249 registers leave two
+  // blocks of four waves per CU, and what the smaller LDS traffic gives is less than what the third block per CU was hiding
+  static const int tm2_env = [] { const char* e = getenv("PTV_WGRAD_TM2"); return e ? atoi(e) : 0; }();
+  const bool tm2_ok = tm2_env && !af && nset == 2 && M > WBM;       // the fast launch runs wgrad2_kernel (256 x 128 block tile)
   WgArgs sent[2]; int nsent[2] = {0, 0};
   float* ws = nullptr; float* ws_csum = nullptr; int ws_slabs = 0;
   unsigned* fix_cnt = nullptr;
@@ -571,8 +718,12 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
   auto launch = [&](bool guard, int k0, int kn, int want_slabs, int pass) -> int {
     WgArgs g{static_cast<const char*>(A) + (long)k0 * lda * (af ? 4 : 2), lda, static_cast<const char*>(B) + (long)k0 * ldb * (bf ? 4 : 2), ldb,
              C, ldc, M, N, kn, 0, cdiv(M, WBM), cdiv(N, WBN), 1, 0, alpha, colsum_a, k0 == 0 ? k_top : nullptr, k_unit, k_rev, g_gemm_prio,
-             nullptr, nullptr, 0, nullptr, 0, 0, 0, 0, 0, nullptr};
-    const int tiles = g.tiles_m * g.tiles_n;
+             nullptr, nullptr, 0, nullptr, 0, 0, 0, 0, 0, nullptr, 0};
+    // 256 x 128 block tile (wgrad2_kernel: two output tiles per block) for the fast launch of products with at least two tile rows and a
+    // bf16 A operand; PTV_WGRAD_TM2=0: the 128 x 128 kernel everywhere
+    const bool use2 = tm2_ok && !guard;
+    const int tiles = use2 ? ((g.tiles_m + 1) / 2) * g.tiles_n : g.tiles_m * g.tiles_n;     // BLOCKS per slab
+    if (use2) g.pairs = tiles;
     // slab count (measured optima of scripts/bench_wgrad.py sweep on MI355X).  Every slab pays M*N atomics, and a grid that is
     // just over one block per CU leaves a tail, so: about one block per CU (never more) for the skinny, HBM-bound products;
     // about three per CU for the MFMA-heavy ones (many tiles), where co-resident blocks hide each other's stalls; a slab is at least
@@ -623,6 +774,11 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
     }
     sent[guard ? 1 : 0] = g;
     const dim3 grid((unsigned)(tiles * ns));
+    if (use2) {
+      if (bf) hipLaunchKernelGGL((wgrad2_kernel<true>), grid, dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((wgrad2_kernel<false>), grid, dim3(256), 0, s, g);
+      return PTV_OK;
+    }
     // experiment knob (PTV_WGRAD_LDS_PAD bytes of unused dynamic LDS per block): fewer co-resident product blocks per CU next to the
     // latency chains
     static const int lds_pad = getenv("PTV_WGRAD_LDS_PAD") ? atoi(getenv("PTV_WGRAD_LDS_PAD")) : 0;
@@ -657,7 +813,7 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
     // tile reading S x 64 KB past the caches while its CU's other work waits) and 10.5 with agent-scope fences instead (a release /
     // acquire pair writes back and invalidates the XCD's whole L2, per block).  The 39 reduction launches per step stay.
     static const int fix_env = [] { const char* e = getenv("PTV_WGRAD_FIXUP"); return e ? atoi(e) : 0; }();
-    if (wb && wb->cnt && fix_env && tiles <= WS_CNT && (accumulate || !k_top)) fix_cnt = wb->cnt;
+    if (wb && wb->cnt && fix_env && tiles <= WS_CNT && (accumulate || !k_top) && !(tm2_ok && has_a)) fix_cnt = wb->cnt;
   }
   if (has_a) launch(false, 0, kfast, slabs, 1);
   if (has_b) launch(true, kfast, K - kfast, has_a ? 1 : slabs, 1);
