@@ -225,7 +225,8 @@ def extras(dev, B, rank):
         m.use_philox(7, 0)
         opt = FusedClipAdam(m.parameters(), lr=1e-3)
         data = [tuple(torch.from_numpy(a).to(dev) for a in synth_batch(Bs, 99 + i)) for i in range(2)]
-        te = _measure(train_fn(m, opt, data, 1.0), 8, 3)
+        with torch.autograd.set_multithreading_enabled(False):          # (as TrainingInterface.train() runs its backward passes)
+            te = _measure(train_fn(m, opt, data, 1.0), 8, 3)
         gs = GraphedTrainStep(m, opt, Bs)
         gs(*data[0])
         t0 = time.perf_counter()
@@ -233,7 +234,7 @@ def extras(dev, B, rank):
         out['train_teacher_forced_b%d' % Bs] = {
             'eager': {'samples_per_s': round(Bs / te, 1), 'ms_per_step': round(te * 1e3, 2)},
             'graph_replayed': {'samples_per_s': round(Bs / tg, 1), 'ms_per_step': round(tg * 1e3, 2)}, 'batch': Bs, 'dtype': 'bf16',
-            'note': 'whole step (zero_grad, forward, backward, clip+Adam) as one captured hipGraph per step vs ~300 eager launches'}
+            'note': 'whole step (zero_grad, forward, backward, clip+Adam) as one captured hipGraph per step vs ~290 eager launches (backward pass on the calling thread, as the trainer runs it)'}
         del m, opt, gs, data
         torch.cuda.empty_cache()
     # the headline with every zero-skip switched off: the backward computes the (exactly zero) gradients of the padded note slots and

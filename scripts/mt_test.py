@@ -1,0 +1,25 @@
+import os, sys, time, torch
+sys.path.insert(0, '/root/repo')
+from polyphonic_chord_texture_disentanglement_amd.model import DisentangleVAE
+from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
+from polyphonic_chord_texture_disentanglement_amd.synthetic import synth_batch
+dev = torch.device('cuda:0')
+for B in (512, 256):
+    torch.manual_seed(0)
+    m = DisentangleVAE.init_model(dev).to(dev).set_precision('bf16')
+    opt = FusedClipAdam(m.parameters(), lr=1e-3)
+    x, c, pr = (torch.from_numpy(a).to(dev) for a in synth_batch(B, 1234))
+    m.use_philox(7, 0)
+    def step():
+        opt.zero_grad()
+        out = m('train', x, c, pr, tfr1=1., tfr2=1., tfr3=1., beta=0.1, weights=[1, 0.5])
+        out[0].backward()
+        opt.clip_and_step(1.0)
+    for mt in (True, False, True, False):
+        with torch.autograd.set_multithreading_enabled(mt):
+            for _ in range(5): step()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(30): step()
+            torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 30
+        print('B=%d autograd multithreading=%s: %.3f ms/step = %.0f samples/s' % (B, mt, t * 1e3, B / t))
+    del m, opt
