@@ -259,7 +259,9 @@ int ptv_reparam_kl_bwd(const float* mu, const float* sd, const float* eps, const
  * Losses: DisentangleVAE.loss_function (model.py:57-68), PtvaeDecoder.recon_loss (ptvae.py:498-511),
  * chord_loss (model.py:70-83), kl_loss (model.py:85-90) + kl_with_normal (train_utils.py:45-49).
  *   targets: int32 arrays in the row order of the logits (step_major = 1: [15][32][B], else [B][32][15];
- *            chord: [8][B] or [B][8]); counts[0/1] += number of non-ignored pitch / duration targets
+ *            chord: [8][B] or [B][8]); counts[0/1] += number of non-ignored pitch / duration targets; counts[2] (three zero-initialised
+ *            ints) = max(counts[2], last note step 0..14 that holds any non-ignored target): an upper bound of where the logits' gradient
+ *            can be non-zero, the decoder backward's zero-skip limit (round 4; replaces two scans of the 134-MB gradient)
  *   ptv_ce_fwd: nll_sum += sum over non-ignored rows of -log softmax(logits)[target]
  *   ptv_ce_bwd: dlogits = gscale[0] * (softmax - onehot), 0 on ignored rows (gscale is a DEVICE scalar)
  *   ptv_loss_finalize: 7 sums + 2 counts -> the 11 scalars in train.py:54-55 order

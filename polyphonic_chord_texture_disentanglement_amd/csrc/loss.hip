@@ -15,9 +15,9 @@ namespace ptv {
 
 __global__ void pianotree_targets_kernel(const long* __restrict__ x, int B, int step_major,
                                          int* __restrict__ pitch_t, int* __restrict__ dur_t, int* __restrict__ counts) {
-  __shared__ int red[2][4];
+  __shared__ int red[3][4];
   const long rows = (long)B * 480;
-  int cp = 0, cd = 0;
+  int cp = 0, cd = 0, top = 0;                                           // top: the last note step that holds ANY non-ignored target
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (long)gridDim.x * blockDim.x) {
     int b, t, n;
     if (step_major) { b = (int)(i % B); long q = i / B; t = (int)(q % 32); n = (int)(q / 32); }
@@ -26,15 +26,22 @@ __global__ void pianotree_targets_kernel(const long* __restrict__ x, int B, int 
     int p = (int)xr[0];
     pitch_t[i] = p;
     cp += (p != 130);
+    int live = (p != 130);
 #pragma unroll
-    for (int d = 0; d < 5; d++) { int v = (int)xr[1 + d]; dur_t[i * 5 + d] = v; cd += (v != 2); }
+    for (int d = 0; d < 5; d++) { int v = (int)xr[1 + d]; dur_t[i * 5 + d] = v; cd += (v != 2); live |= (v != 2); }
+    if (live) top = max(top, n);
   }
-  for (int o = 32; o > 0; o >>= 1) { cp += __shfl_xor(cp, o, 64); cd += __shfl_xor(cd, o, 64); }
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = cp; red[1][threadIdx.x >> 6] = cd; }
+  for (int o = 32; o > 0; o >>= 1) { cp += __shfl_xor(cp, o, 64); cd += __shfl_xor(cd, o, 64); top = max(top, __shfl_xor(top, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = cp; red[1][threadIdx.x >> 6] = cd; red[2][threadIdx.x >> 6] = top; }
   __syncthreads();
   if (threadIdx.x == 0) {
     atomicAdd(counts + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
     atomicAdd(counts + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    // counts[2] (zero-initialised like the others): an UPPER BOUND of the last note step whose logits can receive a gradient from this
+    // loss -- the cross-entropy gradient of an ignored row is exactly zero (ptvae.py:505-510).  The decoder's backward takes it as its
+    // zero-skip limit instead of scanning the 134-MB gradient (functional.decoder_bwd_core); blocks that cannot raise it skip the atomic
+    const int bt = max(max(red[2][0], red[2][1]), max(red[2][2], red[2][3]));
+    if (bt > __hip_atomic_load(counts + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(counts + 2, bt);
   }
 }
 

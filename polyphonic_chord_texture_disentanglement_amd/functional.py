@@ -1796,6 +1796,7 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur, dtok_async=False):
             G[bname] = _gbuf(P[bname])
         wgrad_bias(dy, x, G[name] if sub is None else G[name][:, sub], G[bname] if bname is not None else None, prec, k_top, R)
 
+    hint = _LOSS_TOP.pop((dpitch.data_ptr(), ddur.data_ptr()), None) if (dpitch is not None and ddur is not None) else None
     ddur = (ddur.contiguous() if ddur is not None else _zeros(M, 5, 2, dev=dev)).view(M, 10)
     if (DP_INPLACE and dpitch is not None and dpitch.dtype == F32 and _row_dense(dpitch) and dpitch.stride(-2) == _pad8(NP)
             and dpitch.numel() == M * NP and not dpitch.requires_grad):
@@ -1815,9 +1816,12 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur, dtok_async=False):
     zero_skip_sync()
     top_h = None
     if ZERO_SKIP:
-        top_h = _ineg1(dev)
-        call('ptv_last_nonzero_unit', ptr(dP), M, NP, dP.stride(0), R, ptr(top_h), stream_ptr())
-        call('ptv_last_nonzero_unit', ptr(ddur), M, 10, 10, R, ptr(top_h), stream_ptr())
+        if hint is not None:
+            top_h = hint                         # the loss node's own bound (its gradients are zero beyond it by construction)
+        else:
+            top_h = _ineg1(dev)
+            call('ptv_last_nonzero_unit', ptr(dP), M, NP, dP.stride(0), R, ptr(top_h), stream_ptr())
+            call('ptv_last_nonzero_unit', ptr(ddur), M, 10, 10, R, ptr(top_h), stream_ptr())
 
     # ---- duration GRU (5 steps) ----
     w_out = P['dur_out_linear.weight']
@@ -2230,7 +2234,7 @@ def _pianotree_ce_fwd(pitch, dur, x, sums, st, weighted=False):
     NP = pitch.shape[-1]
     pitch_t = torch.empty(rows, device=dev, dtype=torch.int32)
     dur_t = torch.empty(rows * 5, device=dev, dtype=torch.int32)
-    counts = _izeros(2, dev)
+    counts = _izeros(3, dev)                                 # valid pitch / duration targets; last note step with any (zero-skip limit)
     call('ptv_pianotree_targets', ptr(x), B, int(sm), ptr(pitch_t), ptr(dur_t), ptr(counts), st)
     call('ptv_ce_fwd', ptr(pitch_m), pitch_m.stride(-2), ptr(pitch_t), rows, NP, 130, ptr(sums[0:]), st)
     if weighted:                              # 5 per-bit-position means, weighted (ptvae.py:512-527)
@@ -2261,6 +2265,8 @@ def _pianotree_ce_bwd(pitch_m, dur_m, sm, pitch_t, dur_t, gs, st, gcnt=None):
     return dpitch, ddur
 
 
+_LOSS_TOP = {}
+LOSS_TOP_HINT = os.environ.get('PTV_LOSS_TOP_HINT', '1') != '0'
 LOSS_SIDE = os.environ.get('PTV_LOSS_SIDE', '0') != '0'          # (measured: 8.298 vs 8.302 ms -- no gain; kept as a switch)
 
 
@@ -2341,6 +2347,11 @@ class VaeLossFn(torch.autograd.Function):
             small()
         if sm_c:
             droot, dchroma, dbass = (t.permute(*_chord_perm(t)) for t in (droot, dchroma, dbass))
+        # zero-skip limit for whoever consumes exactly these two gradients (DecoderTFFn / DecoderStepFn): the last note step with a
+        # non-ignored target bounds where they can be non-zero -- known from the forward's target pass, no scan of the gradients
+        _LOSS_TOP.clear()
+        if LOSS_TOP_HINT and sm_p:
+            _LOSS_TOP[(dpitch.data_ptr(), ddur.data_ptr())] = counts[2:3]
         return (dpitch, ddur, dmu_c, dsd_c, dmu_r, dsd_r, droot, dchroma, dbass) + (None,) * 6
 
 
