@@ -540,6 +540,17 @@ long ptv_notes_gru_persist_scratch_elems(long R);
 int ptv_notes_gru_persist_bwd(const void* wt, const float* HN, const void* gates, const void* ext, void* dgi, void* dgh,
                               float* dh0, void* scratch, long R, int T, int* top_step, void* stream);
 
+/* Round 5: the same forward with WAVE ROLES (csrc/notes_roles.hip; the step it replaces is the decode_notes loop body, ptvae.py:395-398):
+ * 8 waves per 64-row workgroup -- four PRODUCT waves stream the weights L2 -> registers and issue the MFMAs, four CELL waves move every
+ * HBM operand / result and run the gate arithmetic; accumulators pass through 16-KB LDS slots.  Same arguments as
+ * ptv_notes_gru_persist_fwd with three layout differences: wg_h / wg_t are packed with pairs = 0; gc and the gate planes are
+ * unit-blocked by 16 ([u / 16][row][16]: ptv_gemm dtypes bit 4 writes gc that way).  T: bits 0-7 = steps, bits 8-15 = debug flags,
+ * bits 16-23 = weight-ring depth (0 = default). */
+/* timing experiments: device buffer of 8 x 2048 uint64 that one workgroup of the following launches fills with per-wave event stamps */
+int ptv_debug_notes_trace(void* buf);
+int ptv_notes_gru_roles_fwd(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
+                            const float* h0, void* HN16, void* gates, long R, int T, void* stream);
+
 /* The same kernels for any GRU whose rows are many and independent; H = 512 (above) or H = 128 with 128 inputs, which is one
  * direction of dec_notes_emb_gru, the note-summary bi-GRU over the 16 notes of each of the 32*B steps (ptvae.py:446-453,480-486).
  *   fwd: w_hh = pack(W_hh [3H,H]), w_x = pack(W_ih [3H,128]) (pairs = 1); b_ih NULL when folded into gc; gc bf16 [R][3H] or NULL;
