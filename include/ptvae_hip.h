@@ -56,10 +56,10 @@ int ptv_abi_version(void);
  *   transB = 0: B[n*ldb + k] (nn.Linear weight layout)   1: B[k*ldb + n]
  *   act: 0 none, 1 exp (linear_var(...).exp_(), ptvae.py:27,120)
  *   splitk: 0 auto, >0 forced number of K splits, <0 never split
- *   dtypes: bit 0 / 1 / 2 = A / B / C hold bf16 (bf16 precision only); bit 3 (8) = C is COLUMN-BLOCKED by 32: element (m, n) lives at
- *           ((n / 32) * M + m) * 32 + n % 32 (ldc unused, N a multiple of 32, no K split) -- the layout in which the row-partitioned
- *           recurrences (ptv_notes_gru_persist_fwd: gc) read their per-row operands: a wave touches one contiguous kilobyte instead of
- *           16 half cache lines
+ *   dtypes: bit 0 / 1 / 2 = A / B / C hold bf16 (bf16 precision only); bit 3 (8) / bit 4 (16) = C is COLUMN-BLOCKED by w = 32 / 16:
+ *           element (m, n) lives at ((n / w) * M + m) * w + n % w (ldc unused, N a multiple of w, no K split) -- the layout in which the
+ *           row-partitioned recurrences (ptv_notes_gru_persist_fwd: gc, w = 16; ptv_notes_gru_persist_bwd: ext, w = 32) read their
+ *           per-row operands: a wave touches one contiguous kilobyte instead of 16 half cache lines
  */
 int ptv_gemm(int prec, int transA, int transB, int M, int N, int K,
              const void* A, long lda, const void* B, long ldb,
@@ -517,15 +517,20 @@ int ptv_free_resummarize(const void* const* w, const void* const* io, int B, int
 
 /* ------------------------------------------------------------------------------------------------
  * The teacher-forced notes GRU (dec_notes_gru over 15 note steps x 32*B rows, ptvae.py:395-398 restructured per SURVEY.md 7.1)
- * as row-partitioned persistent kernels (csrc/notes_persist.hip): ONE launch for the whole sequence, a workgroup owns 64 rows,
- * the state stays on the CU, W_hh streams from L2 in ptv_pack_mfma_b packing, the token product is fused.  bf16 precision,
- * Hn = 512, E = 128.
- *   fwd: wg_h = pack(W_hh [1536,512]), wg_t = pack(W_ih[:, Ht:] [1536,128]); gc bf16 = W_ih[:, :Ht] ns + b_ih, the [R][1536] matrix
- *        stored COLUMN-BLOCKED by 32 ([48][R][32]: ptv_gemm dtypes bit 3 writes it that way; read once per step, 11 % of the launch);
- *        emb fp32 [T][R][128] fed tokens; HN fp32 [T+1][R][512] (slot 0 written by the caller), HN16 bf16 same shape (all slots
- *        written here), gates bf16 [T][4] planes (r, z, n, W_hn h + b_hn) or NULL -- PRIVATE to this forward / BPTT pair: each plane is
- *        unit-blocked, plane[u / 32][row][u % 32] (whole-kilobyte wave accesses), not the [R][512] of ptv_gru_seq_fwd.
- *   bwd: wt = pack(W_hh^T [512,1536]); ext bf16 = gradient arriving at the state after step s, the [T*R][512] matrix of the heads'
+ * as row-partitioned persistent kernels: ONE launch for the whole sequence, a workgroup owns 64 rows, the state stays on the CU, W_hh
+ * streams from L2 in ptv_pack_mfma_b packing, the token product is fused.  bf16 precision, Hn = 512, E = 128.
+ *   fwd (csrc/notes_roles.hip, round 5): 8 waves per workgroup with ROLES -- four product waves stream the weights L2 -> registers and
+ *        issue the MFMAs, four cell waves move every HBM operand / result and run the gate arithmetic with the fp32 state of their
+ *        cells in registers for all T steps; accumulators pass through 16-KB LDS slots.
+ *        wg_h = pack(W_hh [1536,512]), wg_t = pack(W_ih[:, Ht:] [1536,128]), both with pairs = 0; gc bf16 = W_ih[:, :Ht] ns + b_ih,
+ *        the [R][1536] matrix stored COLUMN-BLOCKED by 16 ([96][R][16]: ptv_gemm dtypes bit 4 writes it that way); emb fp32 [T][R][128]
+ *        fed tokens; h0 fp32 [R][512] the initial state (read only: the fp32 states of the later steps never leave the CU); HN16 bf16
+ *        [T+1][R][512] every state, slot 0 included (the operand of the heads, the weight-gradient products and the BPTT); gates bf16
+ *        [T][4] planes (r, z, n, W_hn h + b_hn) or NULL -- PRIVATE to this forward / BPTT pair: each plane is unit-blocked by 16,
+ *        plane[u / 16][row][u % 16] (whole-kilobyte wave accesses), not the [R][512] of ptv_gru_seq_fwd.
+ *        T: bits 0-7 = steps; bits 8-15 = debug flags and bits 16-23 = weight-ring depth of the timing scripts (0 = defaults).
+ *   bwd: wt = pack(W_hh^T [512,1536]) (pairs = 1); HN16 / gates as the forward left them (the previous state enters the gate
+ *        gradients at bf16 precision); ext bf16 = gradient arriving at the state after step s, the [T*R][512] matrix of the heads'
  *        input-gradient products stored COLUMN-BLOCKED by 32 ([16][T*R][32], ptv_gemm dtypes bit 3);
  *        dgi bf16 [T][R][1536]; dgh bf16 [T][R][512] = the n third (dn * r) only -- the r and z thirds of dgh are dgi's, so
  *        grad W_hh[0:1024] = dgi[:, 0:1024]^T . h and grad W_hh[1024:] = dgh^T . h; dh0 fp32 [R][512] or NULL; scratch:
@@ -535,21 +540,13 @@ int ptv_free_resummarize(const void* const* w, const void* const* io, int B, int
  *        dgh can stop after that step's rows (ptv_wgrad k_top).
  */
 int ptv_notes_gru_persist_fwd(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
-                              float* HN, void* HN16, void* gates, long R, int T, void* stream);
+                              const float* h0, void* HN16, void* gates, long R, int T, void* stream);
 long ptv_notes_gru_persist_scratch_elems(long R);
-int ptv_notes_gru_persist_bwd(const void* wt, const float* HN, const void* gates, const void* ext, void* dgi, void* dgh,
+int ptv_notes_gru_persist_bwd(const void* wt, const void* HN16, const void* gates, const void* ext, void* dgi, void* dgh,
                               float* dh0, void* scratch, long R, int T, int* top_step, void* stream);
-
-/* Round 5: the same forward with WAVE ROLES (csrc/notes_roles.hip; the step it replaces is the decode_notes loop body, ptvae.py:395-398):
- * 8 waves per 64-row workgroup -- four PRODUCT waves stream the weights L2 -> registers and issue the MFMAs, four CELL waves move every
- * HBM operand / result and run the gate arithmetic; accumulators pass through 16-KB LDS slots.  Same arguments as
- * ptv_notes_gru_persist_fwd with three layout differences: wg_h / wg_t are packed with pairs = 0; gc and the gate planes are
- * unit-blocked by 16 ([u / 16][row][16]: ptv_gemm dtypes bit 4 writes gc that way).  T: bits 0-7 = steps, bits 8-15 = debug flags,
- * bits 16-23 = weight-ring depth (0 = default). */
-/* timing experiments: device buffer of 8 x 2048 uint64 that one workgroup of the following launches fills with per-wave event stamps */
+/* timing experiments: device buffer of 8 x 2048 uint64 that one workgroup of the following forward launches fills with per-wave event
+ * stamps (scripts/trace_notes.py), or NULL */
 int ptv_debug_notes_trace(void* buf);
-int ptv_notes_gru_roles_fwd(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
-                            const float* h0, void* HN16, void* gates, long R, int T, void* stream);
 
 /* The same kernels for any GRU whose rows are many and independent; H = 512 (above) or H = 128 with 128 inputs, which is one
  * direction of dec_notes_emb_gru, the note-summary bi-GRU over the 16 notes of each of the 32*B steps (ptvae.py:446-453,480-486).
@@ -569,7 +566,7 @@ int ptv_row_gru_persist_fwd(int H, const void* w_hh, const void* w_x, const floa
                             const float* x, long x_step, const int* lengths, float* HN, void* HN16, void* gates,
                             float* out, long out_ld, long R, int T, int reverse, void* stream);
 long ptv_row_gru_persist_scratch_elems(int H, long R);
-int ptv_row_gru_persist_bwd(int H, const void* wt, const float* HN, const void* gates, const void* ext,
+int ptv_row_gru_persist_bwd(int H, const void* wt, const void* HN, const void* gates, const void* ext,
                             const float* dh_last, long last_ld, const int* lengths, void* dgi, void* dgh, float* dh0,
                             void* scratch, long R, int T, int reverse, int* top_step, void* stream);
 

@@ -14,8 +14,8 @@ namespace {
 inline const void* T_(const void* const* t, int i) { return t[i]; }
 template <typename X> inline X* M_(const void* const* t, int i) { return reinterpret_cast<X*>(const_cast<void*>(t[i])); }
 
-// dtypes word of ptv_gemm: bit 0 = A bf16, bit 1 = B bf16, bit 2 = C bf16, bit 3 = C column-blocked by 32
-constexpr int A16 = 1, B16 = 2, C16 = 4, CBLK = 8;
+// dtypes word of ptv_gemm: bit 0 = A bf16, bit 1 = B bf16, bit 2 = C bf16, bit 4 = C column-blocked by 16
+constexpr int A16 = 1, B16 = 2, C16 = 4, CBLK16 = 16;
 
 }  // namespace
 
@@ -79,7 +79,7 @@ extern "C" int ptv_decoder_tf_fwd(const void* const* t, const long* d, void* str
   PTV_TRY(ptv_gemm(P, 0, 0, R, Hn, Ht, nsf, Ht, T_(t, PTV_DTF_W16_T2N), Ht, HN, Hn, (const float*)T_(t, PTV_DTF_B_T2N), 1.f, 0, 0, 0, A16 | B16,
                    stream));
   PTV_TRY(ptv_gemm(P, 0, 0, R, 3 * Hn, Ht, nsf, Ht, w_ih_n, ld_n, M_<void>(t, PTV_DTF_GC), 3L * Hn, (const float*)T_(t, PTV_DTF_B_IH_N), 1.f, 0, 0,
-                   -1, A16 | B16 | C16 | CBLK, stream));
+                   -1, A16 | B16 | C16 | CBLK16, stream));
   PTV_TRY(ptv_notes_gru_persist_fwd(T_(t, PTV_DTF_PK_NOTES_H), T_(t, PTV_DTF_PK_NOTES_T), (const float*)T_(t, PTV_DTF_B_HH_N), T_(t, PTV_DTF_GC),
                                     (const float*)T_(t, PTV_DTF_EMB), HN, HN16, M_<void>(t, PTV_DTF_GATES_N), R, 15, stream));
   // ---- pitch head + initial duration state in one pass over the note states (ptvae.py:343-352)

@@ -19,13 +19,13 @@ struct EpiPlain {
     int act;          // 0 none, 1 exp
     int atomic;       // split-K partial sums: atomicAdd into C (C pre-initialised, fp32 only)
     int c_bf16;       // C holds bf16
-    int c_blocked;    // C is COLUMN-BLOCKED by 32: element (m, n) at ((n / 32) * c_rows + m) * 32 + n % 32 (ldc unused) -- the layout the
+    int c_blocked;    // C is COLUMN-BLOCKED by w = 32 or 16 (log2 here, 0 = row-major): element (m, n) at ((n / w) * c_rows + m) * w + n % w (ldc unused) -- the layout the
     int c_rows;       // row-partitioned recurrences read their per-row operands in (one contiguous kilobyte per wave access)
     long split_stride;   // ordered split-K: split z stores its partial at C + z * split_stride floats (C = a workspace, ldc = N);
                          // splitk_reduce_kernel adds the partials in split order
   };
   static __device__ __forceinline__ long coff(const Params& p, int m, int n) {
-    return p.c_blocked ? ((long)(n >> 5) * p.c_rows + m) * 32 + (n & 31) : (long)m * p.ldc + n;
+    return p.c_blocked ? (((long)(n >> p.c_blocked) * p.c_rows + m) << p.c_blocked) + (n & ((1 << p.c_blocked) - 1)) : (long)m * p.ldc + n;
   }
   // a row tile that lies in the declared-zero part of A (GemmArgs::m_top): accumulating or atomically adding zero changes nothing
   static __device__ __forceinline__ bool dead_is_noop(const Params& p) { return (p.accumulate || p.atomic) && p.act == 0 && p.bias == nullptr; }
@@ -285,15 +285,17 @@ extern "C" int ptv_gemm_mtop(int prec, int transA, int transB, int M, int N, int
   const bool sa = dtypes & 1, sb = dtypes & 2, sc = dtypes & 4;
   if ((sa || sb) && prec != PTV_PREC_BF16) return PTV_ERR_ARG;       // bf16 operands feed the bf16 MFMA path only
   if (sc && splitk > 1) return PTV_ERR_ARG;                          // split-K accumulates with fp32 atomics
-  if ((dtypes & 8) && ((N & 31) || splitk > 1)) return PTV_ERR_ARG;  // column-blocked C: whole 32-column blocks, one writer per element
-  if ((dtypes & 8) && splitk == 0) splitk = 1;
+  if ((dtypes & 8) && (dtypes & 16)) return PTV_ERR_ARG;
+  if ((dtypes & 8) && ((N & 31) || splitk > 1)) return PTV_ERR_ARG;  // column-blocked C: whole 32- / 16-column blocks, one writer per element
+  if ((dtypes & 16) && ((N & 15) || splitk > 1)) return PTV_ERR_ARG;
+  if ((dtypes & 24) && splitk == 0) splitk = 1;
   // weight gradients (both operands row-per-sample): the transposing-LDS-read kernel of wgrad.hip
   static const bool use_wgrad = [] { const char* e = getenv("PTV_WGRAD"); return !(e && e[0] == '0'); }();
-  if (use_wgrad && prec == PTV_PREC_BF16 && transA && transB && !sc && !(dtypes & 8) && !bias && act == 0 && K >= 512 && splitk <= 0)
+  if (use_wgrad && prec == PTV_PREC_BF16 && transA && transB && !sc && !(dtypes & 24) && !bias && act == 0 && K >= 512 && splitk <= 0)
     return ptv_wgrad(M, N, K, A, lda, B, ldb, reinterpret_cast<float*>(C), ldc, alpha, accumulate, dtypes & 3, 0, nullptr, nullptr, 0, 0, stream);
   if (m_top && (transA || m_unit <= 0)) return PTV_ERR_ARG;            // a row limit on A: A must be row-per-sample
   ptv::GemmArgs g{A, lda, B, ldb, M, N, K, K, 0, m_top, m_unit, ptv::g_gemm_prio};
-  ptv::EpiPlain::Params ep{C, ldc, bias, alpha, accumulate, act, 0, sc ? 1 : 0, (dtypes & 8) ? 1 : 0, M, 0};
+  ptv::EpiPlain::Params ep{C, ldc, bias, alpha, accumulate, act, 0, sc ? 1 : 0, (dtypes & 8) ? 5 : ((dtypes & 16) ? 4 : 0), M, 0};
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (prec != PTV_PREC_BF16) rc = ptv::gemm_dispatch<ptv::F32, false, false>(transA, transB, g, ep, splitk, s);

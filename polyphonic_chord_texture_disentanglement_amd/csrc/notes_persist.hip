@@ -352,7 +352,9 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
 // =============================================================================================
 struct RowGruBwdArgs {
   const bf16x8* wt;                // pair-interleaved packing of W_hh^T: [H/16 tiles of output units][3H/32 kb][64]
-  const float* HN; const __bf16* gates;
+  const float* HN;                 // EMB: fp32 states [T+1][R][H]
+  const __bf16* HN16;              // !EMB (the notes GRU, whose forward keeps the fp32 state in registers): the bf16 states [T+1][R][H]
+  const __bf16* gates;             // EMB: planes unit-blocked by 32 (gate_off); !EMB: by 16 (the wave-role forward, notes_roles.hip)
   const __bf16* ext;               // bf16 gradient arriving at the state after step s: the [T*R][H] matrix COLUMN-BLOCKED by 32 ([H/32][T*R][32]), or null
   const float* dh_last; long last_ld;   // gradient arriving at the final state only (rows of stride last_ld), or null
   const int* lengths;              // EMB: the lengths the forward ran with (it skipped the panel's fully masked steps), or null
@@ -453,18 +455,22 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowG
     __bf16* scw = sc + (s & 1) * (NCH * NRP * 8);
     // HBM operands of the epilogue items (tile pairs x 4 M tiles; saved gates, previous state, external gradient) run 2 items
     // ahead of the arithmetic through a ring of 3 register sets; the first two are requested before the products
-    struct Ops { bf16x8 g[4]; bf16x8 ex; float4 hp[2]; };
+    struct Ops { bf16x8 g[4]; bf16x8 ex; float4 hp[2]; bf16x8 hp16; };
     Ops ops[3];
     constexpr int NIT = (NTW / 2) * 4;
     auto ldops = [&](Ops& o, int it) {
       const int pr = it >> 2, i = it & 3;
       const int u = (wave * NTW + pr * 2) * 16 + eq * 8;
       const long base = (long)s * RH + grow[i] * H + u;
-      const __bf16* gp = a.gates + (long)s * 4 * RH + gate_off(grow[i], u, R);
+      const __bf16* gp = a.gates + (long)s * 4 * RH + (EMB ? gate_off(grow[i], u, R) : ((long)(u >> 4) * R + grow[i]) * 16 + (u & 15));
 #pragma unroll
       for (int q = 0; q < 4; q++) o.g[q] = ldnt_bf16x8(gp + q * RH);
-      if constexpr (!EMB) o.ex = ldnt_bf16x8(a.ext + ext_off(s, grow[i], u, R, a.T));
-      o.hp[0] = ldnt_f4(a.HN + base); o.hp[1] = ldnt_f4(a.HN + base + 4);
+      if constexpr (!EMB) {
+        o.ex = ldnt_bf16x8(a.ext + ext_off(s, grow[i], u, R, a.T));
+        o.hp16 = *reinterpret_cast<const bf16x8*>(a.HN16 + base);
+      } else {
+        o.hp[0] = ldnt_f4(a.HN + base); o.hp[1] = ldnt_f4(a.HN + base + 4);
+      }
     };
     if (s >= 0) { ldops(ops[0], 0); ldops(ops[1], 1); }
     // acc[i][j]: M tile i, unit tile wave*NTW + j
@@ -519,7 +525,13 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowG
         continue;
       }
       const Ops& o = ops[it % 3];
-      const float hp[8] = {o.hp[0].x, o.hp[0].y, o.hp[0].z, o.hp[0].w, o.hp[1].x, o.hp[1].y, o.hp[1].z, o.hp[1].w};
+      float hp[8];
+      if constexpr (EMB) {
+        hp[0] = o.hp[0].x; hp[1] = o.hp[0].y; hp[2] = o.hp[0].z; hp[3] = o.hp[0].w; hp[4] = o.hp[1].x; hp[5] = o.hp[1].y; hp[6] = o.hp[1].z; hp[7] = o.hp[1].w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) hp[e] = (float)o.hp16[e];
+      }
       float lastg[8];
 #pragma unroll
       for (int e = 0; e < 8; e++) lastg[e] = 0.f;
@@ -587,13 +599,17 @@ extern "C" int ptv_row_gru_persist_fwd(int H, const void* w_hh, const void* w_x,
                                        float* out, long out_ld, long R, int T, int reverse, void* stream) {
   if (!w_hh || !w_x || !b_hh || !x || !HN || !HN16 || R <= 0 || T <= 0 || (H != 512 && H != 128)) return PTV_ERR_ARG;
   if (out && (out_ld & 3)) return PTV_ERR_ARG;
+  // H = 512 is the notes GRU (gc given, bias folded, dense): the wave-role kernel of notes_roles.hip; H = 128 the note-summary GRU (b_ih
+  // given, mask / reverse / final state)
+  if (H == 512) {
+    if (!gc || b_ih || lengths || reverse || out || x_step != R * NE) return PTV_ERR_UNSUPPORTED;
+    return ptv_notes_gru_persist_fwd(w_hh, w_x, b_hh, gc, x, HN, HN16, gates, R, T, stream);
+  }
   RowGruFwdArgs a{(const bf16x8*)w_hh, (const bf16x8*)w_x, b_hh, b_ih, (const __bf16*)gc, x, x_step, lengths, HN, (__bf16*)HN16,
                   (__bf16*)gates, out, out_ld, (int)R, T & 0xff, reverse, T >> 8, g_zero_skip, g_gemm_prio};
   const int pi = prof::want(3, (int)R, H) ? prof::begin((hipStream_t)stream) : -1;
-  // H = 512 is the notes GRU (gc given, bias folded, dense); H = 128 the note-summary GRU (b_ih given, mask / reverse / final state)
-  if (H == 512 && (!gc || b_ih || lengths || reverse || out)) return PTV_ERR_UNSUPPORTED;
-  if (H == 128 && (gc || !b_ih)) return PTV_ERR_UNSUPPORTED;
-  PTV_TRY(H == 512 ? (launch_fwd<512, false>(a, (hipStream_t)stream)) : (launch_fwd<128, true>(a, (hipStream_t)stream)));
+  if (gc || !b_ih) return PTV_ERR_UNSUPPORTED;
+  PTV_TRY((launch_fwd<128, true>(a, (hipStream_t)stream)));
   if (pi >= 0) prof::end(pi, (hipStream_t)stream, 2.0 * R * 3.0 * H * (H + NE) * (T & 0xff));
   PTV_CHECK_LAUNCH();
   return PTV_OK;
@@ -601,13 +617,13 @@ extern "C" int ptv_row_gru_persist_fwd(int H, const void* w_hh, const void* w_x,
 
 extern "C" long ptv_row_gru_persist_scratch_elems(int H, long R) { return ((R + NRP - 1) / NRP) * 2 * ((3L * H / 8) * NRP * 8); }
 
-extern "C" int ptv_row_gru_persist_bwd(int H, const void* wt, const float* HN, const void* gates, const void* ext,
+extern "C" int ptv_row_gru_persist_bwd(int H, const void* wt, const void* HN, const void* gates, const void* ext,
                                        const float* dh_last, long last_ld, const int* lengths, void* dgi, void* dgh, float* dh0,
                                        void* scratch, long R, int T, int reverse, int* top_step, void* stream) {
   if (!wt || !HN || !gates || !dgi || !dgh || !scratch || R <= 0 || T <= 0 || (H != 512 && H != 128)) return PTV_ERR_ARG;
   if (dh_last && (last_ld & 3)) return PTV_ERR_ARG;
   if (H == 512 && lengths) return PTV_ERR_UNSUPPORTED;
-  RowGruBwdArgs a{(const bf16x8*)wt, HN, (const __bf16*)gates, (const __bf16*)ext, dh_last, last_ld, lengths, top_step, (__bf16*)dgi, (__bf16*)dgh, dh0,
+  RowGruBwdArgs a{(const bf16x8*)wt, H == 512 ? nullptr : (const float*)HN, H == 512 ? (const __bf16*)HN : nullptr, (const __bf16*)gates, (const __bf16*)ext, dh_last, last_ld, lengths, top_step, (__bf16*)dgi, (__bf16*)dgh, dh0,
                   (__bf16*)scratch, (int)R, T, reverse, g_zero_skip};
   const int pi = prof::want(4, (int)R, H) ? prof::begin((hipStream_t)stream) : -1;
   if (H == 512 && (!ext || dh_last || reverse)) return PTV_ERR_UNSUPPORTED;
@@ -618,17 +634,10 @@ extern "C" int ptv_row_gru_persist_bwd(int H, const void* wt, const float* HN, c
   return PTV_OK;
 }
 
-// the notes GRU through the generic entry points (kept as named entry points of the train step's dominant recurrence)
-extern "C" int ptv_notes_gru_persist_fwd(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
-                                         float* HN, void* HN16, void* gates, long R, int T, void* stream) {
-  if (!gc) return PTV_ERR_ARG;
-  return ptv_row_gru_persist_fwd(512, wg_h, wg_t, b_hh, nullptr, gc, emb, R * NE, nullptr, HN, HN16, gates, nullptr, 0, R, T, 0, stream);
-}
-
 extern "C" long ptv_notes_gru_persist_scratch_elems(long R) { return ptv_row_gru_persist_scratch_elems(512, R); }
 
-extern "C" int ptv_notes_gru_persist_bwd(const void* wt, const float* HN, const void* gates, const void* ext, void* dgi, void* dgh,
+extern "C" int ptv_notes_gru_persist_bwd(const void* wt, const void* HN16, const void* gates, const void* ext, void* dgi, void* dgh,
                                          float* dh0, void* scratch, long R, int T, int* top_step, void* stream) {
   if (!ext) return PTV_ERR_ARG;
-  return ptv_row_gru_persist_bwd(512, wt, HN, gates, ext, nullptr, 0, nullptr, dgi, dgh, dh0, scratch, R, T, 0, top_step, stream);
+  return ptv_row_gru_persist_bwd(512, wt, HN16, gates, ext, nullptr, 0, nullptr, dgi, dgh, dh0, scratch, R, T, 0, top_step, stream);
 }

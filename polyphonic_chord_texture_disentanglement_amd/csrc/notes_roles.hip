@@ -401,7 +401,7 @@ static unsigned long long* g_notes_trace = nullptr;
 extern "C" int ptv_debug_notes_trace(void* buf) { g_notes_trace = (unsigned long long*)buf; return PTV_OK; }
 
 // T: bits 0-7 = steps, bits 8-15 = debug flags (8: no stagger), bits 16-23 = ring depth (0 = default)
-extern "C" int ptv_notes_gru_roles_fwd(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
+extern "C" int ptv_notes_gru_persist_fwd(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
                                        const float* h0, void* HN16, void* gates, long R, int T, void* stream) {
   if (!wg_h || !wg_t || !b_hh || !gc || !emb || !h0 || !HN16 || R <= 0 || (T & 0xff) <= 0) return PTV_ERR_ARG;
   nr::Args a{(const bf16x8*)wg_h, (const bf16x8*)wg_t, b_hh, (const __bf16*)gc, emb, R * nr::E, h0, (__bf16*)HN16, (__bf16*)gates,

@@ -248,9 +248,9 @@ def gemm(a, b, out=None, *, ta=False, tb=False, bias=None, alpha=1.0, acc=False,
         out = _empty(M, N, dev=a.device, dtype=out_dtype)
     assert tuple(out.shape) == (M, N), (out.shape, M, N)
     dt = _bf(a) | (_bf(b) << 1) | (_bf(out) << 2)
-    if out_blocked:                                         # out holds the [M, N] result column-blocked by 32: [N/32][M][32] (ptv_gemm dtypes bit 3)
-        assert N % 32 == 0 and out.is_contiguous()
-        dt |= 8
+    if out_blocked:                                         # out holds the [M, N] result column-blocked by w = 32 (True) or 16: [N/w][M][w] (ptv_gemm dtypes bit 3 / 4)
+        assert out_blocked in (True, 16, 32) and N % 32 == 0 and out.is_contiguous()
+        dt |= 16 if out_blocked == 16 else 8
     _chain_prio()
     if m_top is not None:                                   # rows of a from (m_top + 1) * m_unit on are zero (device int)
         call('ptv_gemm_mtop', prec, int(ta), int(tb), M, N, K, ptr(a), _ld(a), ptr(b), _ld(b), ptr(out), _ld(out),
@@ -1403,8 +1403,12 @@ def notes_packs(w_ih, w_hh, Ht):
     pk = dict(wg_h=torch.empty(size(H3, H), device=dev, dtype=BF16), wg_t=torch.empty(size(H3, E), device=dev, dtype=BF16),
               wt=torch.empty(size(H, H3), device=dev, dtype=BF16))
     # (W_hh^T is packed straight from W_hh with transposed reads: no staging transpose; one launch for the three)
-    pack_multi([(w_hh.data_ptr(), w_hh.stride(0), H3, H, pk['wg_h'].data_ptr(), 1, 0, H3 // 16, 0, (H + 31) // 32),
-                (w_x.data_ptr(), w_x.stride(0), H3, E, pk['wg_t'].data_ptr(), 1, 0, H3 // 16, 0, (E + 31) // 32),
+    # (H = 512, the notes GRU's forward: plain tiles, pairs = 0 -- the wave-role kernel hands accumulators over through LDS and picks its
+    # own lane layout there; the note-summary GRU's forward (H = 128) and both BPTTs: pair-interleaved, their epilogues run in the MFMA
+    # lane layout)
+    pf = 0 if H == 512 else 1
+    pack_multi([(w_hh.data_ptr(), w_hh.stride(0), H3, H, pk['wg_h'].data_ptr(), pf, 0, H3 // 16, 0, (H + 31) // 32),
+                (w_x.data_ptr(), w_x.stride(0), H3, E, pk['wg_t'].data_ptr(), pf, 0, H3 // 16, 0, (E + 31) // 32),
                 (w_hh.data_ptr(), w_hh.stride(0), H, H3, pk['wt'].data_ptr(), 1, 1, H // 16, 0, (H3 + 31) // 32)])
     return _NOTES_PACKS.put([w_ih, w_hh], stamp, pk)
 
@@ -1643,8 +1647,8 @@ class DecoderTFFn(torch.autograd.Function):
         w_ih_n = W['dec_notes_gru.weight_ih_l0']
         adt = _act_dtype(prec, Hn)
         rowk = notes_persist_ok(prec, Hn, E, adt) and emb3.dtype == F32 and emb3.is_contiguous()
-        # (the row kernel reads the hoisted part column-blocked: one contiguous kilobyte per wave access instead of 16 half cache lines)
-        GC = gemm(NSf_op, w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec, out_dtype=adt, out_blocked=rowk)      # [R, 3Hn]
+        # (the row kernel reads the hoisted part column-blocked by 16: one contiguous kilobyte per wave access instead of half cache lines)
+        GC = gemm(NSf_op, w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec, out_dtype=adt, out_blocked=16 if rowk else False)      # [R, 3Hn]
         gates_n = _empty(15, 4, R, Hn, dev=dev, dtype=adt)
         HN16 = _hall16(prec, 16, R, Hn, dev)
         gates_n_rowk = rowk
@@ -1912,7 +1916,7 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur, dtok_async=False):
         dHN0 = _empty(R, Hn, dev=dev)
         scratch = _empty(lib().ptv_notes_gru_persist_scratch_elems(R), dev=dev, dtype=BF16)
         top_step = _ineg1(dev) if ZERO_SKIP else None   # <- last note step with a gradient
-        call('ptv_notes_gru_persist_bwd', ptr(pk['wt']), ptr(HN), ptr(st['gates_n']), ptr(dNSUM), ptr(dgi_n), ptr(dgh_n), ptr(dHN0),
+        call('ptv_notes_gru_persist_bwd', ptr(pk['wt']), ptr(st['HN16']), ptr(st['gates_n']), ptr(dNSUM), ptr(dgi_n), ptr(dgh_n), ptr(dHN0),
              ptr(scratch), R, 15, ptr(top_step), stream_ptr())
     else:
         top_step = None

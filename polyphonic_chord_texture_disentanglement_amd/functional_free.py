@@ -353,7 +353,7 @@ class DecoderStepFn(torch.autograd.Function):
             F_.zero_skip_sync()
             # ---- recompute what the backward reads, batched over all rows (the step loop above stored decisions and tokens only)
             GC16 = gemm(NS16[1:].view(R, Ht), w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec, out_dtype=torch.bfloat16,
-                        out_blocked=True)      # (column-blocked: the layout the row kernel reads)
+                        out_blocked=16)      # (column-blocked by 16: the layout the row kernel reads)
             pkn = F_.notes_packs(w_ih_n, w_hh_n, Ht)
             call('ptv_notes_gru_persist_fwd', ptr(pkn['wg_h']), ptr(pkn['wg_t']), ptr(b_hh_n), ptr(GC16), ptr(TOK), ptr(HN), ptr(HN16),
                  ptr(gates_n), R, 15, st)

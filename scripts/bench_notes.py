@@ -17,10 +17,10 @@ rn = lambda *s: torch.randn(*s, device=dev, generator=g)
 w_hh, w_tok, b_hh = rn(3 * H, H) / H ** 0.5, rn(3 * H, E) / H ** 0.5, rn(3 * H) * 0.1
 gc, emb = (rn(R, 3 * H) * 0.5).to(bf), rn(T, R, E) * 0.5
 gc_rm = gc                                                     # row-major for the per-step kernels
-gc = gc.view(R, 3 * H // 32, 32).permute(1, 0, 2).contiguous()   # column-blocked by 32 for the row kernel (ptv_gemm dtypes bit 3)
+gc = gc.view(R, 3 * H // 16, 16).permute(1, 0, 2).contiguous()   # column-blocked by 16 for the row kernel (ptv_gemm dtypes bit 4)
 ext = (rn(T, R, H) * 0.1).to(bf)
 ext_b = ext.view(T * R, H // 32, 32).permute(1, 0, 2).contiguous()      # column-blocked for the row BPTT kernel
-wg_h, wg_t, wt = F_.pack_mfma_b(w_hh, pairs=True), F_.pack_mfma_b(w_tok, pairs=True), F_.pack_mfma_b(w_hh.t().contiguous(), pairs=True)
+wg_h, wg_t, wt = F_.pack_mfma_b(w_hh, pairs=False), F_.pack_mfma_b(w_tok, pairs=False), F_.pack_mfma_b(w_hh.t().contiguous(), pairs=True)
 HN = torch.zeros(T + 1, R, H, device=dev); HN[0] = rn(R, H) * 0.5
 HN16 = torch.zeros(T + 1, R, H, device=dev, dtype=bf)
 gates = torch.zeros(T, 4, R, H, device=dev, dtype=bf)
@@ -51,7 +51,7 @@ def p_fwd():
 
 
 def p_bwd():
-    call('ptv_notes_gru_persist_bwd', ptr(wt), ptr(HN), ptr(gates), ptr(ext_b), ptr(dgi), ptr(dgh), ptr(dh0), ptr(scratch), R, T, None, stream_ptr())
+    call('ptv_notes_gru_persist_bwd', ptr(wt), ptr(HN16), ptr(gates), ptr(ext_b), ptr(dgi), ptr(dgh), ptr(dh0), ptr(scratch), R, T, None, stream_ptr())
 
 
 def s_fwd():

@@ -456,10 +456,27 @@ def test_integration_md_snippet_runs_verbatim():
     assert (y.cpu() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize('w', [16, 32])
+def test_gemm_column_blocked_output(w):
+    """ptv_gemm dtypes bit 3 / bit 4: C written column-blocked by 32 / 16 ([N/w][M][w], the per-row operand layout of the row-partitioned
+    recurrences) holds exactly the row-major result"""
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    dev = _dev()
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(w)
+    M, N, K = 200, 96, 160
+    a, b, bias = torch.randn(M, K, generator=g).to(dev), torch.randn(N, K, generator=g).to(dev), torch.randn(N, generator=g).to(dev)
+    for dt in (bf, torch.float32):
+        ref = F_.gemm(a, b, bias=bias, prec=1, out_dtype=dt)
+        blk = F_.gemm(a, b, bias=bias, prec=1, out_dtype=dt, out_blocked=w)
+        assert torch.equal(blk.view(N // w, M, w).permute(1, 0, 2).reshape(M, N), ref)
+
+
 @pytest.mark.parametrize('R,T,zero_from', [(512, 15, None), (200, 4, None), (16384, 2, None), (512, 15, 7), (300, 6, 0)])
 def test_notes_gru_persistent_kernels_vs_step_kernels_and_oracle(R, T, zero_from):
-    """csrc/notes_persist.hip (row-partitioned: a workgroup owns 64 rows for the whole sequence, token product fused, dgh through a
-    K-blocked scratch tile) against the per-step kernels + separate token product on the same bf16 operands, and against the
+    """the row-partitioned notes GRU (a workgroup owns 64 rows for the whole sequence, token product fused) -- forward with wave roles
+    (csrc/notes_roles.hip: fp32 state in registers, only the bf16 states leave the CU), BPTT with dgh through a K-blocked scratch tile
+    (csrc/notes_persist.hip) -- against the per-step kernels + separate token product on the same bf16 operands, and against the
     fp32 oracle cell; whole / ragged last panel / the B = 512 row count / no gradient arriving at the late steps (skipped by the
     BPTT kernel, panel by panel)"""
     from polyphonic_chord_texture_disentanglement_amd import functional as F_
@@ -481,37 +498,38 @@ def test_notes_gru_persistent_kernels_vs_step_kernels_and_oracle(R, T, zero_from
             ext[zero_from - 1, 64:] = 0
     d = lambda t: t.to(dev).contiguous()
     Wd = dict(w_hh=d(w_hh), w_tok=d(w_tok), b_hh=d(b_hh), gc=d(gc), emb=d(emb), ext=d(ext))
-    gc_blocked = Wd['gc'].view(R, 3 * H // 32, 32).permute(1, 0, 2).contiguous()      # what ptv_gemm writes with dtypes bit 3
-    wg_h, wg_t = F_.pack_mfma_b(Wd['w_hh'], pairs=True), F_.pack_mfma_b(Wd['w_tok'], pairs=True)
+    gc_blocked = Wd['gc'].view(R, 3 * H // 16, 16).permute(1, 0, 2).contiguous()      # what ptv_gemm writes with dtypes bit 4
+    wg_h, wg_t = F_.pack_mfma_b(Wd['w_hh'], pairs=False), F_.pack_mfma_b(Wd['w_tok'], pairs=False)
     wt = F_.pack_mfma_b(Wd['w_hh'].t().contiguous(), pairs=True)
-    HN = torch.zeros(T + 1, R, H, device=dev); HN[0] = d(h0)
+    HN0 = d(h0)
     HN16 = torch.zeros(T + 1, R, H, device=dev, dtype=bf)
     gates = torch.zeros(T, 4, R, H, device=dev, dtype=bf)
-    call('ptv_notes_gru_persist_fwd', ptr(wg_h), ptr(wg_t), ptr(Wd['b_hh']), ptr(gc_blocked), ptr(Wd['emb']), ptr(HN), ptr(HN16), ptr(gates),
+    call('ptv_notes_gru_persist_fwd', ptr(wg_h), ptr(wg_t), ptr(Wd['b_hh']), ptr(gc_blocked), ptr(Wd['emb']), ptr(HN0), ptr(HN16), ptr(gates),
          R, T, stream_ptr())
     dgi = torch.zeros(T, R, 3 * H, device=dev, dtype=bf); dgh = torch.zeros(T, R, H, device=dev, dtype=bf)     # dgh: n third only
     dh0 = torch.zeros(R, H, device=dev)
     scratch = torch.empty(lib().ptv_notes_gru_persist_scratch_elems(R), device=dev, dtype=bf)
     ext_blocked = Wd['ext'].view(T * R, H // 32, 32).permute(1, 0, 2).contiguous()        # the [T*R][H] matrix as ptv_gemm writes it with dtypes bit 3
-    call('ptv_notes_gru_persist_bwd', ptr(wt), ptr(HN), ptr(gates), ptr(ext_blocked), ptr(dgi), ptr(dgh), ptr(dh0), ptr(scratch), R, T, None, stream_ptr())
+    call('ptv_notes_gru_persist_bwd', ptr(wt), ptr(HN16), ptr(gates), ptr(ext_blocked), ptr(dgi), ptr(dgh), ptr(dh0), ptr(scratch), R, T, None, stream_ptr())
     # ---- the per-step kernels on the same operands
     GT = F_.gemm(Wd['emb'].view(T * R, E), Wd['w_tok'].to(bf), prec=1, out_dtype=bf)
-    HN2 = torch.zeros_like(HN); HN2[0] = HN[0]
+    HN2 = torch.zeros(T + 1, R, H, device=dev); HN2[0] = HN0
     HN16_2 = torch.zeros_like(HN16); gates2 = torch.zeros_like(gates)
     FL = 1 | 2 | 4 | 8 | 16
     w16, wt16 = Wd['w_hh'].to(bf).contiguous(), Wd['w_hh'].t().contiguous().to(bf)
     call('ptv_gru_seq_fwd', 1, R, H, T, ptr(GT), R * 3 * H, 3 * H, ptr(Wd['gc']), 0, 3 * H, ptr(w16), ptr(Wd['b_hh']),
          ptr(HN2), ptr(HN16_2), ptr(gates2), None, 0, None, FL, stream_ptr())
-    assert (HN - HN2).abs().max() < 3e-2
-    assert (HN16.float() - HN).abs().max() < 1e-2
-    # (the row kernels keep their gate planes unit-blocked, [T][4][H/32][R][32]: private to the forward / BPTT pair)
-    gates_rm = gates.view(T, 4, H // 32, R, 32).permute(0, 1, 3, 2, 4).reshape(T, 4, R, H)
+    assert torch.equal(HN16[0], HN0.to(bf))
+    assert (HN16.float() - HN2).abs().max() < 3e-2
+    # (the row kernels keep their gate planes unit-blocked, [T][4][H/16][R][16]: private to the forward / BPTT pair)
+    gates_rm = gates.view(T, 4, H // 16, R, 16).permute(0, 1, 3, 2, 4).reshape(T, 4, R, H)
     assert (gates_rm.float() - gates2.float()).abs().max() < 4e-2
     dgi2 = torch.zeros_like(dgi); dgh2 = torch.zeros_like(dgi)
     dhz = torch.empty(2, R, H, device=dev); dh02 = torch.empty(R, H, device=dev)
     e = Wd['ext']
     gates_rm = gates_rm.contiguous()
-    call('ptv_gru_seq_bwd', 1, R, H, T, ptr(HN), ptr(gates_rm), ptr(wt16), ptr(e), e.stride(0), e.stride(1), None, 0, None, 0, 0, 0, None,
+    HNf = HN16.float()                                        # (the BPTT takes the previous state from the bf16 copy)
+    call('ptv_gru_seq_bwd', 1, R, H, T, ptr(HNf), ptr(gates_rm), ptr(wt16), ptr(e), e.stride(0), e.stride(1), None, 0, None, 0, 0, 0, None,
          ptr(dgi2), ptr(dgh2), ptr(dhz), ptr(dh02), 0, FL | 64, stream_ptr())
     sc = max(1.0, dgi2.float().abs().max().item())
     assert (dgi.float() - dgi2.float()).abs().max() < 0.03 * sc
@@ -531,7 +549,7 @@ def test_notes_gru_persistent_kernels_vs_step_kernels_and_oracle(R, T, zero_from
         hs.append(h)
     hs = torch.stack(hs)
     (hs * ext[:, rows].float()).sum().backward()
-    assert (HN[1:, rows.to(dev)].cpu() - hs.detach()).abs().max() < 4e-2
+    assert (HN16[1:, rows.to(dev)].float().cpu() - hs.detach()).abs().max() < 4e-2
     assert (dh0[rows.to(dev)].cpu() - hr.grad).abs().max() < 0.05 * max(1.0, hr.grad.abs().max().item())
 
 
