@@ -630,6 +630,12 @@ int ptv_debug_pin_cus(int nwg, int lds_bytes, int usec, void* stream);
  */
 int ptv_wgrad(int M, int N, int K, const void* A, long lda, const void* B, long ldb, float* C, long ldc, float alpha,
               int accumulate, int dtypes, int slabs, float* colsum_a, const int* k_top, long k_unit, int k_rev, void* stream);
+/* the same for a gradient matrix that lives in TWO arrays: C[M1 + M2, N] (+)= alpha * [A1 | A2]^T . B, rows 0 .. M1-1 of C from the columns
+ * of A1, the rest from A2 (same dtype, M1 a multiple of 128) -- one pass over B instead of two (the notes GRU's weight_hh gradient:
+ * [dgi[:, :1024] | dgh]^T . h, ptv_notes_gru_persist_bwd) */
+int ptv_wgrad_cat(int M1, const void* A1, long lda1, int M2, const void* A2, long lda2, int N, int K, const void* B, long ldb,
+                  float* C, long ldc, float alpha, int accumulate, int dtypes, int slabs, float* colsum_a, const int* k_top,
+                  long k_unit, int k_rev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optional launch timing (bench.py roofline): HIP events recorded on the launch stream around every launch of the enabled

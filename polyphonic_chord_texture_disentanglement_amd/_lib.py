@@ -16,6 +16,9 @@ PREC_F32, PREC_BF16 = 0, 1
 _PREC = {'fp32': PREC_F32, 'f32': PREC_F32, 'bf16': PREC_BF16, 0: 0, 1: 1}
 
 _lib = None
+# the C ABI this Python package was written against (csrc/version.hip): the .so is a built artefact that ships beside the sources, and a
+# stale one would load without error and silently change argument contracts (round-4 advice: counts[3] of ptv_pianotree_targets)
+EXPECTED_ABI = 4
 
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'ptvae_hip.h')
 
@@ -89,6 +92,9 @@ def lib():
             fn = getattr(l, name)           # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
+        if l.ptv_abi_version() != EXPECTED_ABI:
+            raise RuntimeError('libptvae_hip.so at %s has ABI version %d, this package expects %d: rebuild it (python -c "import '
+                               '__graft_entry__ as g; g.build()")' % (LIB_PATH, l.ptv_abi_version(), EXPECTED_ABI))
         _lib = l
     return _lib
 

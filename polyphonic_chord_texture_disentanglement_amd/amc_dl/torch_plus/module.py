@@ -239,6 +239,10 @@ class TrainingInterface:
         import torch.distributed as dist
         return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
 
+    def _world(self):
+        import torch.distributed as dist
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
     def _barrier(self):
         import torch.distributed as dist
         if self.parallel and dist.is_available() and dist.is_initialized():
@@ -273,13 +277,23 @@ class TrainingInterface:
         state = {'model': m.state_dict(), 'optimizer': opt.state_dict(), 'lr_scheduler': sch.state_dict(),
                  'opt_scheduler_step': self.opt_scheduler._step, 'param_scheduler': self.param_scheduler.state_dict(),
                  'epoch': self.epoch, 'train_step': self.train_step, 'val_step': self.val_step, 'rng': rng}
+        stamp = {'world': self._world(), 'train_step': self.train_step, 'epoch': self.epoch}
+        state['sidecar_stamp'] = stamp
         if self.is_main:
             torch.save(state, fn)
+            # sidecars of ranks that do not exist in THIS run (a checkpoint overwritten by fewer processes) must not survive beside it
+            import glob
+            import os
+            for old in glob.glob(glob.escape(fn) + '.rng*'):
+                tail = old[len(fn) + 4:]
+                if tail.isdigit() and int(tail) >= stamp['world']:
+                    os.remove(old)
         else:
             # every other rank keeps ITS random state next to the checkpoint: the Philox sample offset (rank * per-GPU batch), the device
             # generator and the loader generators differ by rank, and restoring rank 0's on all ranks would give every replica the same
-            # noise for different samples and the same shard of the data
-            torch.save({'rng': rng}, '%s.rng%d' % (fn, self._rank()))
+            # noise for different samples and the same shard of the data.  Stamped with the run it belongs to (round-4 advice): a
+            # sidecar left over from another world size / step is ignored on load
+            torch.save({'rng': rng, 'stamp': dict(stamp, rank=self._rank())}, '%s.rng%d' % (fn, self._rank()))
         self._barrier()
 
     def load_checkpoint(self, fn):
@@ -296,8 +310,10 @@ class TrainingInterface:
         if rng is not None and not self.is_main:
             import os
             own = '%s.rng%d' % (fn, self._rank())
-            if os.path.exists(own):
-                rng = torch.load(own, map_location=self.device, weights_only=False)['rng']
+            side = torch.load(own, map_location=self.device, weights_only=False) if os.path.exists(own) else None
+            want = dict(state.get('sidecar_stamp') or {}, rank=self._rank())
+            if side is not None and side.get('stamp') == want and want.get('world') == self._world():
+                rng = side['rng']
             else:
                 # no per-rank block (checkpoint written by a single process): the shared parts only -- the noise seed and draw counter
                 # (this rank's own sample offset stays) and the coin stream (identical on every rank by construction)

@@ -6,4 +6,7 @@ extern "C" const char* ptv_arch(void) { return "gfx950"; }
 // 3 (round 4): ptv_dur_gru_bwd takes b_hh / tab0 / tab (gates may be NULL: recompute); ptv_txt_conv_relu_pool_*_rows take the arg-max
 // map; ptv_*_geom, ptv_heads_*, ptv_pack_mfma_b2 / _multi, ptv_gru_persist_bwd_splitk, ptv_gradnorm_clip_adam_step and the composites
 // ptv_decoder_tf_fwd / ptv_chord_decoder_fwd added
-extern "C" int ptv_abi_version(void) { return 3; }
+// 4 (round 5): ptv_notes_gru_persist_fwd is the wave-role kernel (pairs = 0 packs, gc / gate planes unit-blocked by 16, h0 read only: no
+// fp32 states written); ptv_notes_gru_persist_bwd / ptv_row_gru_persist_bwd(H = 512) take the bf16 states; ptv_gemm dtypes bit 4 (C
+// column-blocked by 16); ptv_pianotree_targets writes counts[3] (since round 4, unversioned then); ptv_debug_notes_trace added
+extern "C" int ptv_abi_version(void) { return 4; }

@@ -58,6 +58,9 @@ struct WgArgs {
   int fix_nslab, fix_kper, fix_K, fix_extra, fix_acc;
   const int* fix_ktop;
   int pairs;                     // wgrad2_kernel: blocks are decoded over (tiles_m + 1) / 2 * tiles_n tile PAIRS instead of tiles
+  // second source of A (ptv_wgrad_cat): output rows m >= split (a multiple of 128) are the columns m - split of A2 -- two gradient
+  // matrices that meet the same B (the notes GRU's dgi[:, :1024] and dgh: one pass over the states instead of two), or null
+  const void* A2; long lda2; int split;
 };
 
 // which part of a slab's K range survives the k_top limits: shared by the product kernel and the ordered reduction (a slab that is
@@ -280,7 +283,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
   const int m_blk = (tile / g.tiles_n) * WBM, n_blk = (tile % g.tiles_n) * WBN;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  const bool veca = (g.lda % (AF32 ? 4 : 8) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+  const bool second = g.A2 != nullptr && m_blk >= g.split;
+  const void* const srcA = second ? g.A2 : g.A;
+  const long lda_ = second ? g.lda2 : g.lda;
+  const int ma0 = second ? m_blk - g.split : m_blk;               // first column of this tile row inside its source
+  const int Ma = g.A2 ? (second ? g.M - g.split : g.split) : g.M;  // columns of that source
+  const bool veca = (lda_ % (AF32 ? 4 : 8) == 0) && ((reinterpret_cast<uintptr_t>(srcA) & 15) == 0);
   const bool vecb = (g.ldb % (BF32 ? 4 : 8) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
 
   wf32x4 acc[4][4];
@@ -303,17 +311,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
   // were issued NSET iterations before that.  bf16 sources cost 4 VGPRs per chunk, fp32 sources 8.
   WStage<AF32> ra[NSET];
   WStage<BF32> rb[NSET];
-  const int cola = m_blk + (threadIdx.x & 15) * 8, colb = n_blk + (threadIdx.x & 15) * 8;
-  const bool coka = cola < g.M, cokb = colb < g.N;
-  const typename WSrc<AF32>::T* pa = reinterpret_cast<const typename WSrc<AF32>::T*>(g.A) + (long)(k_begin + (threadIdx.x >> 4)) * g.lda + (coka ? cola : 0);
+  const int cola = ma0 + (threadIdx.x & 15) * 8, colb = n_blk + (threadIdx.x & 15) * 8;
+  const bool coka = cola < Ma, cokb = colb < g.N;
+  const typename WSrc<AF32>::T* pa = reinterpret_cast<const typename WSrc<AF32>::T*>(srcA) + (long)(k_begin + (threadIdx.x >> 4)) * lda_ + (coka ? cola : 0);
   const typename WSrc<BF32>::T* pb = reinterpret_cast<const typename WSrc<BF32>::T*>(g.B) + (long)(k_begin + (threadIdx.x >> 4)) * g.ldb + (cokb ? colb : 0);
 #define WG_FETCH(set, t)                                                                            \
   do {                                                                                              \
     if constexpr (GUARD) {                                                                          \
-      ra[set].load(g.A, g.lda, k_begin + (t) * WBK, k_end, g.K - 1, cola, g.M, veca);               \
+      ra[set].load(srcA, lda_, k_begin + (t) * WBK, k_end, g.K - 1, cola, Ma, veca);                \
       rb[set].load(g.B, g.ldb, k_begin + (t) * WBK, k_end, g.K - 1, colb, g.N, vecb);               \
     } else {                                                                                        \
-      ra[set].load_fast(pa + (long)(t) * WBK * g.lda, g.lda);                                       \
+      ra[set].load_fast(pa + (long)(t) * WBK * lda_, lda_);                                         \
       rb[set].load_fast(pb + (long)(t) * WBK * g.ldb, g.ldb);                                       \
     }                                                                                               \
   } while (0)
@@ -677,8 +685,8 @@ static WsBuf* ws_for(hipStream_t s, size_t bytes) {
 namespace ptv { extern int g_splitk_ordered; }
 extern "C" int ptv_wgrad_mode(int ordered) { ptv::g_wgrad_mode = ptv::g_splitk_ordered = ordered ? 1 : 0; return PTV_OK; }
 
-extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const void* B, long ldb, float* C, long ldc, float alpha,
-                         int accumulate, int dtypes, int slabs, float* colsum_a, const int* k_top, long k_unit, int k_rev, void* stream) {
+static int wgrad_impl(int M, int N, int K, const void* A, long lda, const void* A2, long lda2, int split, const void* B, long ldb, float* C, long ldc,
+                      float alpha, int accumulate, int dtypes, int slabs, float* colsum_a, const int* k_top, long k_unit, int k_rev, void* stream) {
   if (M < 0 || N < 0 || K < 0 || !A || !B || !C) return PTV_ERR_ARG;
   if (k_top && (k_unit <= 0 || k_unit % WBK)) return PTV_ERR_ARG;
   if (M == 0 || N == 0) return PTV_OK;
@@ -698,10 +706,11 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
   }
   const bool af = !(dtypes & 1), bf = !(dtypes & 2);
   const bool vec = (lda % (af ? 4 : 8) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                   (!A2 || ((lda2 % (af ? 4 : 8) == 0) && ((reinterpret_cast<uintptr_t>(A2) & 15) == 0))) &&
                    (ldb % (bf ? 4 : 8) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
   // the unguarded kernel reads whole 8-column chunks: where a chunk straddles M or N it spills into the next row, so it stops
   // short of the operands' last row; the guarded kernel takes the remaining <= 32 rows (and everything when rows are unaligned)
-  const bool odd = (M % 8) || (N % 8);
+  const bool odd = (M % 8) || (N % 8) || (A2 && (split % 8));
   const int kfast = !vec ? 0 : (odd ? ((K - 1) / WBK) * WBK : (K / WBK) * WBK);
   static const int nset_env = [] { const char* e = getenv("PTV_WGRAD_NSET"); return e ? atoi(e) : 0; }();
   const int nset = (af || bf) ? 2 : (nset_env == 4 ? 4 : 2);       // 4 register sets only fit with bf16 sources
@@ -709,7 +718,7 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
   // 128 x 128 kernel, 3072 x 1024 x 16384 154 against 133, the step's 20 shapes 2306 against 1903 us -- 249 registers leave two
   // blocks of four waves per CU, and what the smaller LDS traffic gives is less than what the third block per CU was hiding
   static const int tm2_env = [] { const char* e = getenv("PTV_WGRAD_TM2"); return e ? atoi(e) : 0; }();
-  const bool tm2_ok = tm2_env && !af && nset == 2 && M > WBM;       // the fast launch runs wgrad2_kernel (256 x 128 block tile)
+  const bool tm2_ok = tm2_env && !af && nset == 2 && M > WBM && !A2;       // the fast launch runs wgrad2_kernel (256 x 128 block tile)
   WgArgs sent[2]; int nsent[2] = {0, 0};
   float* ws = nullptr; float* ws_csum = nullptr; int ws_slabs = 0;
   unsigned* fix_cnt = nullptr;
@@ -718,7 +727,8 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
   auto launch = [&](bool guard, int k0, int kn, int want_slabs, int pass) -> int {
     WgArgs g{static_cast<const char*>(A) + (long)k0 * lda * (af ? 4 : 2), lda, static_cast<const char*>(B) + (long)k0 * ldb * (bf ? 4 : 2), ldb,
              C, ldc, M, N, kn, 0, cdiv(M, WBM), cdiv(N, WBN), 1, 0, alpha, colsum_a, k0 == 0 ? k_top : nullptr, k_unit, k_rev, g_gemm_prio,
-             nullptr, nullptr, 0, nullptr, 0, 0, 0, 0, 0, nullptr, 0};
+             nullptr, nullptr, 0, nullptr, 0, 0, 0, 0, 0, nullptr, 0,
+             A2 ? static_cast<const char*>(A2) + (long)k0 * lda2 * (af ? 4 : 2) : nullptr, lda2, split};
     // 256 x 128 block tile (wgrad2_kernel: two output tiles per block) for the fast launch of products with at least two tile rows and a
     // bf16 A operand; PTV_WGRAD_TM2=0: the 128 x 128 kernel everywhere
     const bool use2 = tm2_ok && !guard;
@@ -828,4 +838,19 @@ extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const voi
   (void)ws_slabs;
   PTV_CHECK_LAUNCH();
   return PTV_OK;
+}
+
+extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const void* B, long ldb, float* C, long ldc, float alpha,
+                         int accumulate, int dtypes, int slabs, float* colsum_a, const int* k_top, long k_unit, int k_rev, void* stream) {
+  return wgrad_impl(M, N, K, A, lda, nullptr, 0, 0, B, ldb, C, ldc, alpha, accumulate, dtypes, slabs, colsum_a, k_top, k_unit, k_rev, stream);
+}
+
+// C[M1 + M2, N] (+)= alpha * [A1 | A2]^T . B: the column blocks of two row-per-sample matrices of the same dtype against ONE pass over B
+// (M1 a multiple of 128).  The notes GRU's weight_hh gradient is [dgi[:, :1024] | dgh_n]^T . h (the r / z thirds of the gate gradients are
+// shared with the input side, ptv_notes_gru_persist_bwd): two products read the 252-MB state matrix twice.
+extern "C" int ptv_wgrad_cat(int M1, const void* A1, long lda1, int M2, const void* A2, long lda2, int N, int K, const void* B, long ldb,
+                             float* C, long ldc, float alpha, int accumulate, int dtypes, int slabs, float* colsum_a, const int* k_top,
+                             long k_unit, int k_rev, void* stream) {
+  if (M1 <= 0 || M2 <= 0 || (M1 % WBM) || !A1 || !A2) return PTV_ERR_ARG;
+  return wgrad_impl(M1 + M2, N, K, A1, lda1, A2, lda2, M1, B, ldb, C, ldc, alpha, accumulate, dtypes, slabs, colsum_a, k_top, k_unit, k_rev, stream);
 }

@@ -624,11 +624,17 @@ class Side:
         try:
             # (torch.cuda.stream() is ~15 us of python per use; the parent stream is known)
             if _set_stream is not None:
+                # (the stream current NOW is restored afterwards: a handle may be called under another stream than it was built under)
+                if _get_cur is not None and _get_dev is not None:
+                    psid, pdi, pdt = _get_cur(_get_dev())
+                else:
+                    pm = torch.cuda.current_stream()
+                    psid, pdi, pdt = pm.stream_id, pm.device_index, pm.device_type
                 _set_stream(stream_id=self.s.stream_id, device_index=self.s.device_index, device_type=self.s.device_type)
                 try:
                     r = fn()
                 finally:
-                    _set_stream(stream_id=self.main.stream_id, device_index=self.main.device_index, device_type=self.main.device_type)
+                    _set_stream(stream_id=psid, device_index=pdi, device_type=pdt)
             else:
                 with torch.cuda.stream(self.s):
                     r = fn()
@@ -713,6 +719,7 @@ def reset_deferred():
     """join whatever deferred side-stream work is still registered (a backward pass that raised never ran its end-of-pass
     callback): called by FusedClipAdam.zero_grad() and by the first node of every backward pass (VaeLossFn)"""
     _LATE.clear()                           # (their gradients belong to the aborted pass)
+    _LOSS_TOP.clear()                       # (a zero-skip bound nobody consumed: e.g. torch.autograd.grad that stopped at the logits)
     if _DEFERRED:
         _join_deferred()
 
@@ -1800,7 +1807,7 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur, dtok_async=False):
             G[bname] = _gbuf(P[bname])
         wgrad_bias(dy, x, G[name] if sub is None else G[name][:, sub], G[bname] if bname is not None else None, prec, k_top, R)
 
-    hint = _LOSS_TOP.pop((dpitch.data_ptr(), ddur.data_ptr()), None) if (dpitch is not None and ddur is not None) else None
+    hint = _loss_top_hint(dpitch, ddur)
     ddur = (ddur.contiguous() if ddur is not None else _zeros(M, 5, 2, dev=dev)).view(M, 10)
     if (DP_INPLACE and dpitch is not None and dpitch.dtype == F32 and _row_dense(dpitch) and dpitch.stride(-2) == _pad8(NP)
             and dpitch.numel() == M * NP and not dpitch.requires_grad):
@@ -1950,6 +1957,8 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur, dtok_async=False):
                     G[name] = _gbuf(P[name])
             gw, gb, h_op = G['dec_notes_gru.weight_hh_l0'], G['dec_notes_gru.bias_hh_l0'], HNo[:15].view(M, Hn)
             # (the rows of dgi / dgh after the last step that received a gradient are zero: the products stop there)
+            # (ONE product for the whole [3Hn, Hn] gradient -- ptv_wgrad_cat, the state matrix read once -- measured 0.1 ms per step SLOWER in
+            # situ, 7.83-7.90 against 7.73-7.78 ms: the single 768-block launch crowds the time BPTT it runs beside; two launches stay)
             wgrad_bias(dgi_n.view(M, 3 * Hn)[:, :2 * Hn], h_op, gw[:2 * Hn], gb[:2 * Hn], prec, top_step, R)
             wgrad_bias(dgh_n.view(M, Hn), h_op, gw[2 * Hn:], gb[2 * Hn:], prec, top_step, R)
         else:
@@ -2270,6 +2279,22 @@ def _pianotree_ce_bwd(pitch_m, dur_m, sm, pitch_t, dur_t, gs, st, gcnt=None):
 
 
 _LOSS_TOP = {}
+
+
+def _loss_top_hint(dpitch, ddur):
+    """the loss node's zero-skip bound, valid ONLY for the very tensors it returned, unmodified: the entry holds weak references to both
+    gradient tensors and their version counters.  A gradient that autograd accumulated another contribution into (a second consumer of
+    the logits, an in-place tensor hook) has a bumped version or is another object; a recycled address of a dead tensor is another
+    object too -- in all those cases the caller scans the gradients themselves (round-4 advice: the key used to be the two addresses)."""
+    ent = _LOSS_TOP.pop('hint', None)
+    if ent is None or dpitch is None or ddur is None:
+        return None
+    rp, rd, vp, vd, top = ent
+    if rp() is dpitch and rd() is ddur and dpitch._version == vp and ddur._version == vd:
+        return top
+    return None
+
+
 LOSS_TOP_HINT = os.environ.get('PTV_LOSS_TOP_HINT', '1') != '0'
 LOSS_SIDE = os.environ.get('PTV_LOSS_SIDE', '0') != '0'          # (measured: 8.298 vs 8.302 ms -- no gain; kept as a switch)
 
@@ -2355,7 +2380,7 @@ class VaeLossFn(torch.autograd.Function):
         # non-ignored target bounds where they can be non-zero -- known from the forward's target pass, no scan of the gradients
         _LOSS_TOP.clear()
         if LOSS_TOP_HINT and sm_p:
-            _LOSS_TOP[(dpitch.data_ptr(), ddur.data_ptr())] = counts[2:3]
+            _LOSS_TOP['hint'] = (weakref.ref(dpitch), weakref.ref(ddur), dpitch._version, ddur._version, counts[2:3])
         return (dpitch, ddur, dmu_c, dsd_c, dmu_r, dsd_r, droot, dchroma, dbass) + (None,) * 6
 
 

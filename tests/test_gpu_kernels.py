@@ -606,6 +606,42 @@ def test_row_gru_h128_bidirectional_with_lengths_vs_step_kernels_and_oracle(M, T
     assert (o1[0] == 0).all()                                   # a row of length 0 never leaves the zero state
 
 
+@pytest.mark.parametrize('M1,M2,N,K,bdt,pad', [(256, 128, 128, 4096, 1, 0), (1024, 512, 512, 2080, 1, 0), (128, 72, 130, 999, 0, 6)])
+def test_wgrad_two_source_product_equals_the_two_products(M1, M2, N, K, bdt, pad):
+    """ptv_wgrad_cat: C[M1 + M2, N] += [A1 | A2]^T B with the two column blocks in different arrays (the notes GRU's weight_hh gradient:
+    dgi's r / z columns and dgh) -- the same slabs, the same tiles, the same order of additions as one ptv_wgrad per block, so the result
+    and the fused bias gradient are bit-identical to the two calls; k_top included; and both agree with a float64 product"""
+    from polyphonic_chord_texture_disentanglement_amd._lib import call, ptr, stream_ptr
+    dev = _dev()
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(M1 + M2 + K)
+    A1 = torch.randn(K, 3 * M1 // 2, generator=g).to(bf).to(dev)[:, :M1]            # (a column block of a wider matrix: lda > M1)
+    A2 = torch.randn(K, M2 + pad, generator=g).to(bf).to(dev)[:, :M2]
+    B = torch.randn(K, N + pad, generator=g)
+    Bd = (B.to(bf) if bdt else B).to(dev)[:, :N]
+    C0, b0 = torch.randn(M1 + M2, N, generator=g).to(dev), torch.randn(M1 + M2, generator=g).to(dev)
+    unit = 32
+    ktop = torch.tensor([(K // unit) // 2], device=dev, dtype=torch.int32)
+    for kt in (None, ktop):
+        Az1, Az2 = A1.clone(), A2.clone()
+        if kt is not None:
+            Az1[(int(kt) + 1) * unit:] = 0; Az2[(int(kt) + 1) * unit:] = 0
+        Ca, ba = C0.clone(), b0.clone()
+        call('ptv_wgrad_cat', M1, ptr(Az1), Az1.stride(0), M2, ptr(Az2), Az2.stride(0), N, K, ptr(Bd), Bd.stride(0), ptr(Ca), Ca.stride(0), 1.0, 1,
+             1 | (bdt << 1), 0, ptr(ba), ptr(kt), unit if kt is not None else 0, 0, stream_ptr())
+        Cb, bb = C0.clone(), b0.clone()
+        for A_, lo, hi in ((Az1, 0, M1), (Az2, M1, M1 + M2)):
+            call('ptv_wgrad', hi - lo, N, K, ptr(A_), A_.stride(0), ptr(Bd), Bd.stride(0), ptr(Cb[lo:hi]), Cb.stride(0), 1.0, 1, 1 | (bdt << 1), 0,
+                 ptr(bb[lo:hi]), ptr(kt), unit if kt is not None else 0, 0, stream_ptr())
+        torch.cuda.synchronize()
+        want = C0.cpu().double() + torch.cat([Az1, Az2], 1).cpu().double().t() @ Bd.cpu().to(bf).double()
+        assert (Ca.cpu().double() - want).abs().max() < 2e-5 * max(1.0, want.abs().max().item())
+        if M1 % 128 == 0 and M2 % 128 == 0:                      # (same tile decomposition in both routes: not one bit apart)
+            assert torch.equal(Ca, Cb) and torch.equal(ba, bb)
+        else:
+            assert (Ca - Cb).abs().max() < 2e-5 * max(1.0, want.abs().max().item()) and (ba - bb).abs().max() < 1e-3
+
+
 @pytest.mark.parametrize('M,N,K,dt,pad', [(384, 128, 4096, 3, 0), (130, 512, 2000, 2, 6), (1536, 128, 1056, 1, 0), (64, 130, 999, 0, 6),
                                           (128, 135, 640, 0, 1), (3072, 36, 512, 1, 4), (12, 512, 4100, 0, 0), (256, 1000, 8192, 3, 0)])
 def test_wgrad_kernel_vs_fp64_product_and_column_sums(M, N, K, dt, pad):
