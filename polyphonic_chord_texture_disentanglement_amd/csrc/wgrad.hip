@@ -267,6 +267,60 @@ __device__ __forceinline__ void wgrad_fixup(const WgArgs& g, int tile, int m_blk
   }
 }
 
+// what a block does with its finished 128 x 128 partial (shared by the register-staged and the LDS-DMA kernel)
+__device__ __forceinline__ void wgrad_store(const WgArgs& g, wf32x4 (&acc)[4][4], wf32x4 (&accs)[4], bool do_sum, int slab, int tile, int tiles,
+                                            int m_blk, int n_blk, int wm, int wn, int lane) {
+  // acc[i][j]: lane holds C[m = wm + 16 i + 4 (lane >> 4) + r][n = wn + 16 j + (lane & 15)], r = 0..3: one atomic instruction of the
+  // wave covers 4 rows x 16 consecutive columns (4 cache lines; the other operand order would touch 16)
+  if (do_sum && (lane & 15) == 0) {                              // every column of accs holds the same sums
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int m = m_blk + wm + i * 16 + (lane >> 4) * 4 + r;
+        if (m < g.M) {
+          if (g.ws_csum) __hip_atomic_store(g.ws_csum + (long)(g.slab0 + slab) * g.M + m, accs[i][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else atomicAdd(g.csum + m, accs[i][r]);
+        }
+      }
+  }
+  if (g.ws) {                                                    // ordered reduction: this slab's partial tile, plain stores
+    float* wt = g.ws + ((long)(g.slab0 + slab) * tiles + tile) * (WBM * WBN);
+    const int mrem = g.M - m_blk - wm - (lane >> 4) * 4, nrem = g.N - n_blk - wn - (lane & 15);      // rows / columns of C left from this lane's first cell
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (i * 16 + r < mrem && j * 16 < nrem) {                // (cells outside C are never read back)
+            float* q = wt + (wm + i * 16 + (lane >> 4) * 4 + r) * WBN + wn + j * 16 + (lane & 15);
+            // (fix-up: write-through stores -- another CU, possibly behind another XCD's L2, reads them in this launch)
+            if (g.fix_cnt) __hip_atomic_store(q, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *q = acc[i][j][r];
+          }
+    if (g.fix_cnt) wgrad_fixup(g, tile, m_blk, n_blk);
+    return;
+  }
+  const bool single = g.nslab == 1;
+  const bool inner = m_blk + WBM <= g.M && n_blk + WBN <= g.N;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int n = n_blk + wn + j * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int m = m_blk + wm + i * 16 + (lane >> 4) * 4 + r;
+        if (!inner && (m >= g.M || n >= g.N)) continue;
+        float* cp = g.C + (long)m * g.ldc + n;
+        if (single) *cp += g.alpha * acc[i][j][r];              // the only writer of this element: plain read-modify-write
+        else atomicAdd(cp, g.alpha * acc[i][j][r]);
+      }
+    }
+  }
+}
+
 // GUARD = false: rows 16-byte aligned, K a multiple of 32 and not reaching the operands' last row (see ptv_wgrad)
 template <bool AF32, bool BF32, bool GUARD, int NSET>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
@@ -368,55 +422,121 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
   }
 #undef WG_BODY
 #undef WG_FETCH
-  // acc[i][j]: lane holds C[m = wm + 16 i + 4 (lane >> 4) + r][n = wn + 16 j + (lane & 15)], r = 0..3: one atomic instruction of the
-  // wave covers 4 rows x 16 consecutive columns (4 cache lines; the other operand order would touch 16)
-  if (do_sum && (lane & 15) == 0) {                              // every column of accs holds the same sums
+  wgrad_store(g, acc, accs, do_sum, slab, tile, tiles, m_blk, n_blk, wm, wn, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant (round 5) for bf16 x bf16 operands on the unguarded fast path: the 32-row stages go HBM -> LDS directly
+// (global_load_lds_dwordx4: no staging registers, no ds_write pass), three stage buffers, two stages in flight across ONE raw barrier per
+// stage with counted vmcnt -- the register-staged kernel waits for its prefetch at every __syncthreads.  The deep products of the step
+// (1024 / 512 / 200 x 512 x 245760, 3072 x 1024 x 16384) sat at 0.27 of the MFMA peak and 0.3 of the CU's 64 B/clk load path: latency.
+// A DMA instruction writes 64 lanes x 16 bytes CONTIGUOUSLY (four 256-byte rows), so rows cannot be padded; the 16-byte chunks of a row are
+// XOR-swizzled instead -- on the SOURCE address, the LDS image stays linear -- such that the eight rows a 32-lane transposing read touches
+// land in eight different 32-byte bank groups.
+// ---------------------------------------------------------------------------------------------
+constexpr int DSTAGE = WBK * WBM;                                // elements of one operand's stage: 32 rows x 128 columns, unpadded
+constexpr int DNBUF = 3;
+__device__ __forceinline__ int dma_swz(int row) { return ((row & 3) << 1) ^ (((row >> 2) & 1) << 3); }    // chunk index XOR of a row
+
+// MFMA operand of 16 columns starting at `col` (a multiple of 16) out of a swizzled, unpadded stage: as tr_frag_ld
+__device__ __forceinline__ wbf16x8 tr_frag_swz(const __bf16* st, int col) {
+  const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
+  const int row = g * 4 + (s >> 2);
+  const int chunk = ((col >> 3) + ((s & 3) >> 1)) ^ dma_swz(row);            // (row + 16 has the same swizzle)
+  const __bf16* p = st + row * WBM + chunk * 8 + (s & 1) * 4;
+  const ws16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const ws16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * WBM));
+  const ws16x8 w = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(wbf16x8, w);
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgArgs g) {
+  if (g.prio) __builtin_amdgcn_s_setprio(3);
+  __shared__ __attribute__((aligned(1024))) __bf16 S[2 * DNBUF * DSTAGE];        // [buffer][A | B][32][128]: ONE array (a second LDS object makes
+  const int tiles = g.tiles_m * g.tiles_n;                                        // hipcc wait vmcnt(0) in front of every ds_read)
+  int b = blockIdx.x, slab, tile;
+  if (g.map == 1) { const int q = b >> 3; slab = (q / tiles) * 8 + (b & 7); tile = q % tiles; }
+  else if (g.map == 2) { const int tx = tiles >> 3, q = b >> 3; tile = (b & 7) * tx + q % tx; slab = q / tx; }
+  else { slab = b / tiles; tile = b % tiles; }
+  int k_begin, k_end;
+  if (!slab_range(g, slab, k_begin, k_end)) return;
+  const int m_blk = (tile / g.tiles_n) * WBM, n_blk = (tile % g.tiles_n) * WBN;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const bool second = g.A2 != nullptr && m_blk >= g.split;
+  const __bf16* const srcA = reinterpret_cast<const __bf16*>(second ? g.A2 : g.A);
+  const long lda_ = second ? g.lda2 : g.lda;
+  const int ma0 = second ? m_blk - g.split : m_blk;
+  const int Ma = g.A2 ? (second ? g.M - g.split : g.split) : g.M;
+
+  wf32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = wf32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_sum = g.csum != nullptr && n_blk == 0 && wn == 0;
+  wf32x4 accs[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) accs[i] = wf32x4{0.f, 0.f, 0.f, 0.f};
+  wbf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; e++) ones[e] = (__bf16)1.0f;
+  const int nst = (k_end - k_begin + WBK - 1) / WBK, last = nst - 1;
+
+  // this wave's share of a stage: DMA instructions 2 wave, 2 wave + 1 of each operand (instruction j = rows 4j .. 4j+3).  Lane l lands at
+  // LDS offset l * 16 of the instruction's kilobyte = (row 4j + l / 16, chunk position l % 16), and fetches the chunk that belongs there
+  const __bf16* pa[2]; const __bf16* pb[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int row = (2 * wave + q) * 4 + (lane >> 4), chunk = (lane & 15) ^ dma_swz(row);
+    const int ca = ma0 + chunk * 8, cb = n_blk + chunk * 8;
+    pa[q] = srcA + (long)(k_begin + row) * lda_ + (ca < Ma ? ca : 0);                      // (columns beyond M / N only meet outputs that are never stored)
+    pb[q] = reinterpret_cast<const __bf16*>(g.B) + (long)(k_begin + row) * g.ldb + (cb < g.N ? cb : 0);
+  }
+  // (inline asm, not __builtin_amdgcn_global_load_lds: hipcc knows the builtin writes LDS and puts s_waitcnt vmcnt(0) in front of the
+  // stage's first ds_read -- the very wait this kernel exists to avoid.  The asm is invisible to its counters: the waits are the explicit
+  // ones below.  M0 carries the wave-uniform LDS address and is restored in the same statement.)
+  typedef __attribute__((address_space(3))) const void* lptr_t;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)S;
+  auto glds = [&](const __bf16* src, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+  };
+  auto fetch = [&](int t) {                                                               // stage t -> buffer t % 3 (clamped: a redundant stage is never read)
+    const int tt = t < last ? t : last;
+    const unsigned buf = lds0 + (unsigned)((t % DNBUF) * (2 * DSTAGE) * 2);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      glds(pa[q] + (long)tt * WBK * lda_, buf + (unsigned)((2 * wave + q) * 1024));
+      glds(pb[q] + (long)tt * WBK * g.ldb, buf + (unsigned)(DSTAGE * 2 + (2 * wave + q) * 1024));
+    }
+  };
+  fetch(0); fetch(1);
+  for (int t = 0; t < nst; t++) {
+    // stage t has landed for THIS wave's requests (two stages = 8 requests are outstanding at most; the 4 of stage t + 1 may stay) ...
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // ... and for everyone's; and every wave is done reading buffer (t - 1) % 3
+    asm volatile("" ::: "memory");
+    fetch(t + 2);                                                  // (into the buffer the barrier has just freed)
+    const __bf16* as = S + (t % DNBUF) * (2 * DSTAGE);
+    const __bf16* bs = as + DSTAGE;
+    wbf16x8 fa[4], fb[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) fa[i] = tr_frag_swz(as, wm + i * 16);
+#pragma unroll
+    for (int j = 0; j < 4; j++) fb[j] = tr_frag_swz(bs, wn + j * 16);
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int m = m_blk + wm + i * 16 + (lane >> 4) * 4 + r;
-        if (m < g.M) {
-          if (g.ws_csum) __hip_atomic_store(g.ws_csum + (long)(g.slab0 + slab) * g.M + m, accs[i][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else atomicAdd(g.csum + m, accs[i][r]);
-        }
-      }
-  }
-  if (g.ws) {                                                    // ordered reduction: this slab's partial tile, plain stores
-    float* wt = g.ws + ((long)(g.slab0 + slab) * tiles + tile) * (WBM * WBN);
-    const int mrem = g.M - m_blk - wm - (lane >> 4) * 4, nrem = g.N - n_blk - wn - (lane & 15);      // rows / columns of C left from this lane's first cell
+      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    if (do_sum) {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          if (i * 16 + r < mrem && j * 16 < nrem) {                // (cells outside C are never read back)
-            float* q = wt + (wm + i * 16 + (lane >> 4) * 4 + r) * WBN + wn + j * 16 + (lane & 15);
-            // (fix-up: write-through stores -- another CU, possibly behind another XCD's L2, reads them in this launch)
-            if (g.fix_cnt) __hip_atomic_store(q, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else *q = acc[i][j][r];
-          }
-    if (g.fix_cnt) wgrad_fixup(g, tile, m_blk, n_blk);
-    return;
-  }
-  const bool single = g.nslab == 1;
-  const bool inner = m_blk + WBM <= g.M && n_blk + WBN <= g.N;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int n = n_blk + wn + j * 16 + (lane & 15);
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int m = m_blk + wm + i * 16 + (lane >> 4) * 4 + r;
-        if (!inner && (m >= g.M || n >= g.N)) continue;
-        float* cp = g.C + (long)m * g.ldc + n;
-        if (single) *cp += g.alpha * acc[i][j][r];              // the only writer of this element: plain read-modify-write
-        else atomicAdd(cp, g.alpha * acc[i][j][r]);
-      }
+      for (int i = 0; i < 4; i++) accs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accs[i], 0, 0, 0);
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (the two redundant stages: nothing may land in LDS after the block has left)
+  wgrad_store(g, acc, accs, do_sum, slab, tile, tiles, m_blk, n_blk, wm, wn, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -798,6 +918,8 @@ static int wgrad_impl(int M, int N, int K, const void* A, long lda, const void* 
       else if (nset == 2) hipLaunchKernelGGL((wgrad_kernel<AF, BF, false, 2>), grid, dim3(256), lds_pad, s, g);      \
       else if constexpr (!(AF) && !(BF)) hipLaunchKernelGGL((wgrad_kernel<false, false, false, 4>), grid, dim3(256), lds_pad, s, g); \
     } while (0)
+    static const int dma_env = [] { const char* e = getenv("PTV_WGRAD_DMA"); return e ? atoi(e) : 1; }();
+    if (!af && !bf && !guard && dma_env && (kn % WBK) == 0) { hipLaunchKernelGGL(wgrad_dma_kernel, grid, dim3(256), 0, s, g); return PTV_OK; }
     if (af && bf) WG_LAUNCH(true, true);
     else if (af) WG_LAUNCH(true, false);
     else if (bf) WG_LAUNCH(false, true);
