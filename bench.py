@@ -268,53 +268,81 @@ def extras(dev, B, rank):
     return out
 
 
-def _roofline(lib, B, model, args):
+def _roofline(lib, B, model, args, ms_per_step=None):
     """roofline of the dominant kernels, measured live (HIP events on the launch stream, ptv_prof_*): the notes GRU of the
-    teacher-forced decoder as ONE row-partitioned persistent launch per direction of time (csrc/notes_persist.hip), forward
-    (tag 3) and BPTT (tag 4).  Algorithmic bytes per launch (DESIGN.md section 6, R = 32*B rows, H = 512, E = 128, T = 15 steps):
-      fwd  per step: GC bf16 R*3H*2 (hoisted input part) + fed token fp32 R*E*4 read; state fp32 R*H*4 + bf16 R*H*2 and the four
-           saved gate planes bf16 4*R*H*2 written; once: W_hh and W_ih[:, Ht:] bf16, b_hh, the initial state.
-      bwd  per step: gates 4*R*H*2 + gradient arriving at the state R*H*2 + previous state fp32 R*H*4 read; dgi bf16 R*3H*2 and
-           the n third of dgh R*H*2 written (its r / z thirds are dgi's); once: W_hh^T bf16, dh0 fp32.
-    Intensity is ~180 FLOP/B, below the MI355X balance point (2.5 PFLOP/s / 8 TB/s = 312): HBM bounds both; the MFMA fraction is
-    reported beside it."""
+    teacher-forced decoder as ONE row-partitioned launch per direction of time -- forward with wave roles (csrc/notes_roles.hip, tag 3),
+    BPTT (csrc/notes_persist.hip, tag 4).  Algorithmic bytes per launch (DESIGN.md section 4, R = 32*B rows, H = 512, E = 128, T = 15):
+      fwd  per step: GC bf16 R*3H*2 (hoisted input part) + fed token fp32 R*E*4 read; state bf16 R*H*2 and the four saved gate planes
+           bf16 4*R*H*2 written (round 5: the fp32 state stays in registers -- no per-step fp32 state store + read-back); once: W_hh and
+           W_ih[:, Ht:] bf16, b_hh, the initial state.  min_bytes = the same without the gate planes (what a forward that saved
+           nothing for its backward would move).
+      bwd  per step: gates 4*R*H*2 + gradient arriving at the state R*H*2 + previous state bf16 R*H*2 read; dgi bf16 R*3H*2 and the n
+           third of dgh R*H*2 written (its r / z thirds are dgi's); once: W_hh^T bf16, dh0 fp32.
+    Intensity is ~225 FLOP/B, below the MI355X balance point (2.5 PFLOP/s / 8 TB/s = 312): the HBM roofline is the one that prices the
+    launch; what actually BOUNDS it is reported as measured (`bound`, `bound_evidence`): the per-CU vector-memory path, on which an HBM miss
+    of ANY wave delays the L2 hits of the weight stream behind it (scripts/micro/tcp_order.hip), not the HBM pins."""
     import ctypes
     R, H, E, T = 32 * B, model.decoder.dec_notes_hid_size, 128, 15
-    fwd_bytes = T * (R * 3 * H * 2 + R * E * 4 + R * H * 4 + R * H * 2 + 4 * R * H * 2) + 3 * H * (H + E) * 2 + 3 * H * 4 + R * H * 4
-    bwd_bytes = T * (4 * R * H * 2 + R * H * 2 + R * H * 4 + R * 3 * H * 2 + R * H * 2) + 3 * H * H * 2 + R * H * 4
+    once_f = 3 * H * (H + E) * 2 + 3 * H * 4 + R * H * 4
+    fwd_bytes = T * (R * 3 * H * 2 + R * E * 4 + R * H * 2 + 4 * R * H * 2) + once_f
+    fwd_min = T * (R * 3 * H * 2 + R * E * 4 + R * H * 2) + once_f
+    bwd_bytes = T * (4 * R * H * 2 + R * H * 2 + R * H * 2 + R * 3 * H * 2 + R * H * 2) + 3 * H * H * 2 + R * H * 4
     pmc = {}
     # HBM traffic of these launches from the PMC counters (separate rocprofv3 --pmc passes over this same command, scripts/gpu_pmc.sh,
     # corrected as MI355X_MICROARCH.md prescribes): read from the committed file, stamped with the commit it was taken at
-    pmc_path = os.path.join(ROOT, 'profiles', 'r04_row_gru_pmc.json')
+    pmc_file = 'profiles/r05_row_gru_pmc.json'
+    pmc_path = os.path.join(ROOT, pmc_file)
     if B == 512 and args.precision == 'bf16' and os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
     out = []
     from polyphonic_chord_texture_disentanglement_amd import functional as F_
-    kernels = [(3, 'row_gru_fwd_kernel<512>', fwd_bytes)]
-    if not F_.ZERO_SKIP:                                    # with the zero-skip on, the BPTT launch moves a data-dependent share of
-        kernels.insert(0, (4, 'row_gru_bwd_kernel<512>', bwd_bytes))   # these bytes (late note steps without gradient are passed over)
-    for tag, name, nbytes in kernels:
+
+    def read(tag):
         cnt, ms, fl = ctypes.c_long(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
         lib.ptv_prof_read_tag(tag, ctypes.byref(cnt), ctypes.byref(ms), ctypes.byref(fl))
-        if cnt.value == 0:
+        return cnt.value, ms.value, fl.value
+
+    kernels = [(3, 'notes_fwd_kernel', fwd_bytes, fwd_min)]
+    if not F_.ZERO_SKIP:                                    # with the zero-skip on, the BPTT launch moves a data-dependent share of
+        kernels.insert(0, (4, 'row_gru_bwd_kernel<512>', bwd_bytes, bwd_bytes))   # these bytes (late note steps without gradient are passed over)
+    for tag, name, nbytes, nmin in kernels:
+        cnt, ms, fl = read(tag)
+        if cnt == 0:
             continue
-        avg_s = ms.value / cnt.value * 1e-3
-        gbs, tfs = nbytes / avg_s / 1e9, fl.value / cnt.value / avg_s / 1e12
+        avg_s = ms / cnt * 1e-3
+        gbs, tfs = nbytes / avg_s / 1e9, fl / cnt / avg_s / 1e12
         k = pmc.get(name, {})
         out.append({'bound': 'hbm', 'kernel': '%s (dec_notes_gru, R=%d rows x T=%d steps in one launch)' % (name, R, T),
                     'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
-                    'traffic': k.get('hbm_bytes_per_launch'), 'traffic_source': ('profiles/r04_row_gru_pmc.json @ %s' % pmc.get('_commit')) if k else None,
-                    'algorithmic_bytes': nbytes, 'launches': cnt.value,
-                    'avg_us': round(avg_s * 1e6, 1), 'total_ms': round(ms.value, 2),
+                    'traffic': k.get('hbm_bytes_per_launch'), 'traffic_source': ('%s @ %s' % (pmc_file, pmc.get('_commit'))) if k else None,
+                    'algorithmic_bytes': nbytes, 'min_bytes': nmin, 'frac_on_min_bytes': round(nmin / avg_s / 1e9 / 8000.0, 4),
+                    'launches': cnt, 'avg_us': round(avg_s * 1e6, 1), 'total_ms': round(ms, 2),
                     'mfma': {'achieved': round(tfs, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(tfs / 2500.0, 4),
                              'busy_frac_pmc': k.get('mfma_busy_frac')},
-                    'flop_per_byte': round(fl.value / cnt.value / nbytes, 1), 'balance_flop_per_byte': 312.5,
+                    'flop_per_byte': round(fl / cnt / nbytes, 1), 'balance_flop_per_byte': 312.5,
+                    'bound_measured': 'per-CU vector-memory path (in-order across waves), neither HBM pins nor MFMA',
+                    'bound_evidence': 'profiles/r05_notes_roles_ablation.txt (no weights / no activation streams / neither), '
+                                      'profiles/r05_tcp_order.txt (one HBM-missing wave slows the CU\'s L2-hit stream 1.46x, four 3.6x)',
                     'note': 'in situ: the launch shares the GPU with the weight-gradient products on sibling streams'})
     if not out:
         return None
     out.sort(key=lambda r: -r['total_ms'])
     roof = out[0]
     roof['also'] = out[1:]
+    # the other families the step spends its time in, on the roofline that prices them (MFMA): summed algorithmic FLOPs / summed time
+    for tag, name, what in ((5, 'wgrad family (ptv_wgrad: wgrad_kernel / wgrad_dma_kernel + wgrad_reduce_kernel)',
+                             '2*M*N*K summed over the step\'s weight-gradient products (full K: zero-skipped rows counted)'),
+                            (6, 'pgru_bwd_sk_kernel / pgru_bwd_kernel (BPTT of the small-M persistent recurrences)', '2*chains*M*3H*H*T')):
+        cnt, ms, fl = read(tag)
+        if cnt:
+            tfs = fl / (ms * 1e-3) / 1e12
+            roof['also'].append({'bound': 'mfma', 'kernel': name, 'achieved': round(tfs, 1), 'peak': 2500.0, 'unit': 'TFLOP/s',
+                                 'frac': round(tfs / 2500.0, 4), 'launches': cnt, 'total_ms': round(ms, 2), 'flops': what,
+                                 'note': 'event-timed per call on its own stream, in situ (calls overlap each other and the chains)'})
+    if ms_per_step:
+        tfs = 6.15e9 * B / (ms_per_step * 1e-3) / 1e12
+        roof['also'].append({'bound': 'mfma', 'kernel': 'whole train step (6.15 GFLOP per sample, SURVEY.md 8d)', 'achieved': round(tfs, 1),
+                             'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(tfs / 2500.0, 4)})
     return roof
 
 
@@ -456,7 +484,7 @@ def main():
     barrier()
     lib.ptv_prof_reset()
     lib.ptv_prof_config(32 * B, model.decoder.dec_notes_hid_size)
-    lib.ptv_prof_enable(4 | 8)                             # tags 3, 4: the row-partitioned notes GRU, forward and BPTT
+    lib.ptv_prof_enable(4 | 8 | 16 | 32)                   # tags 3, 4: the row-partitioned notes GRU, forward and BPTT; 5: weight-gradient products; 6: small-M BPTT
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i)
@@ -521,7 +549,8 @@ def main():
         if world == 1 and args.mode == 'train' and not args.no_parity:
             try:
                 res['parity'] = {'benched': golden_parity(args.precision, dev), 'fp32_path': golden_parity('fp32', dev) if args.precision != 'fp32' else None,
-                                 'bar': 'north_star: losses within 1e-4 of the CPU reference in fp32; bf16 = bf16 MFMA operands + bf16-stored saved tensors'}
+                                 'bar': 'north_star: losses within 1e-4 of the CPU reference -- held by the fp32 path (fp32_path / by_batch.*.fp32); the benched bf16 dtype '
+                                        '(bf16 MFMA operands + bf16-stored saved tensors) is held to 3e-4 by the tests (tests/test_gpu_model_wide.py), observed 2e-5 .. 1e-4'}
                 # the same at B = 4 and at the BENCHED batch (round 4: full_tf1_b512.npz, produced by the reference at B = 512)
                 res['parity']['by_batch'] = {
                     'b%d' % b_: {p_: golden_parity(p_, dev, case='full_tf1_b%d' % b_) for p_ in dict.fromkeys((args.precision, 'fp32'))}

@@ -640,8 +640,9 @@ int ptv_wgrad_cat(int M1, const void* A1, long lda1, int M2, const void* A2, lon
 /* ------------------------------------------------------------------------------------------------
  * Optional launch timing (bench.py roofline): HIP events recorded on the launch stream around every launch of the enabled
  * kernel families.  Tags: 1 = GRU forward step, 2 = GRU backward step (csrc/gru.hip), 3 = row-partitioned persistent GRU forward,
- * 4 = its BPTT (csrc/notes_persist.hip; M = rows R).  ptv_prof_enable takes a bit mask (bit tag-1), ptv_prof_config restricts to
- * launches with the given (M, H) (0 = any).  ptv_prof_read_tag waits for the recorded events and returns the number of launches of
+ * 4 = its BPTT (csrc/notes_roles.hip / notes_persist.hip; M = rows R), 5 = weight-gradient products (ptv_wgrad / ptv_wgrad_cat: product +
+ * reduction launches of one call), 6 = BPTT of the persistent small-M recurrences (ptv_gru_persist_bwd*).  ptv_prof_enable takes a bit mask
+ * (bit tag-1), ptv_prof_config restricts tags 1-4 to launches with the given (M, H) (0 = any).  ptv_prof_read_tag waits for the recorded events and returns the number of launches of
  * one tag (0 = all), their summed duration and their summed algorithmic MFMA FLOPs.
  */
 int ptv_prof_enable(int mask);

@@ -177,8 +177,7 @@ extern "C" int ptv_dur_gru_fwd(int H, long M, const float* h0, long ld_h0, const
   DurArgs a{h0, ld_h0, w_hh, b_hh, tab0, tab, w_out, b_out, hall, plane_h, (__bf16*)hall16, gates, plane_g, step_g, gates_bf16,
             dur_out, ld_out, idx, idx_stride, force, force_stride, M};
   // grid: whole rounds of resident blocks (3 per CU: 44.5 KB of LDS each) -- 1024 blocks on 256 CUs were 1 1/3 rounds, the last one a third full
-  static int cap = 0;
-  if (!cap) { const char* e = getenv("PTV_DUR_FWD_NB"); cap = e ? atoi(e) : 3 * num_cus(); if (cap < 1) cap = 1024; }
+  const int cap = 3 * num_cus();                               // (512 / 768 / 1024 / 2048 blocks: 247 / 276 / 247 / 251 us -- it does not matter)
   long nb = ((M + 15) / 16 + 3) / 4; if (nb > cap) nb = cap; if (nb < 1) nb = 1;
   hipLaunchKernelGGL(dur_gru_fwd_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, a);
   PTV_CHECK_LAUNCH();

@@ -290,8 +290,7 @@ extern "C" int ptv_gemm_mtop(int prec, int transA, int transB, int M, int N, int
   if ((dtypes & 16) && ((N & 15) || splitk > 1)) return PTV_ERR_ARG;
   if ((dtypes & 24) && splitk == 0) splitk = 1;
   // weight gradients (both operands row-per-sample): the transposing-LDS-read kernel of wgrad.hip
-  static const bool use_wgrad = [] { const char* e = getenv("PTV_WGRAD"); return !(e && e[0] == '0'); }();
-  if (use_wgrad && prec == PTV_PREC_BF16 && transA && transB && !sc && !(dtypes & 24) && !bias && act == 0 && K >= 512 && splitk <= 0)
+  if (prec == PTV_PREC_BF16 && transA && transB && !sc && !(dtypes & 24) && !bias && act == 0 && K >= 512 && splitk <= 0)
     return ptv_wgrad(M, N, K, A, lda, B, ldb, reinterpret_cast<float*>(C), ldc, alpha, accumulate, dtypes & 3, 0, nullptr, nullptr, 0, 0, stream);
   if (m_top && (transA || m_unit <= 0)) return PTV_ERR_ARG;            // a row limit on A: A must be row-per-sample
   ptv::GemmArgs g{A, lda, B, ldb, M, N, K, K, 0, m_top, m_unit, ptv::g_gemm_prio};

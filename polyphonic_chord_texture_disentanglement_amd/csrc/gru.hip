@@ -394,7 +394,8 @@ static int slot_tag[MAXEV];
 static double slot_flops[MAXEV];
 static int created = 0, used = 0, cur_tag = 0;
 bool want(int tag, int M, int H) {
-  const bool ok = (enabled & (1 << (tag - 1))) && (filt_M == 0 || filt_M == M) && (filt_H == 0 || filt_H == H) && used < MAXEV;
+  // (tags 5 = weight-gradient products, 6 = BPTT of the persistent small-M recurrences: whole families, no shape filter)
+  const bool ok = (enabled & (1 << (tag - 1))) && (tag >= 5 || ((filt_M == 0 || filt_M == M) && (filt_H == 0 || filt_H == H))) && used < MAXEV;
   if (ok) cur_tag = tag;
   return ok;
 }

@@ -27,6 +27,7 @@
 // half-resident grids could wait on each other): the Python host chains them with events (functional.py).
 // bf16 precision with bf16 storage only; other shapes/precisions use the per-step kernels of gru.hip.
 #include "common.hpp"
+#include "prof.hpp"
 #include "gemm_core.hpp"
 #include "../../include/ptvae_hip.h"
 
@@ -732,9 +733,11 @@ extern "C" int ptv_gru_persist_bwd(int NC, int M, int H, int T,
   a.NC = NC; a.M = M; a.H = H; a.T = T; a.RG = RG; a.UG = H / PU; a.rows_wg = rows; a.sync = sync;
   const dim3 grid(NC * RG * a.UG), block(NTHREADS);
   hipStream_t s = (hipStream_t)stream;
+  const int pi = prof::want(6, M, H) ? prof::begin(s) : -1;
   if (g_load_policy == 0) PTV_PG_LAUNCH(pgru_bwd_kernel, 0, 3 * H);
   else if (g_load_policy == 1) PTV_PG_LAUNCH(pgru_bwd_kernel, 1, 3 * H);
   else PTV_PG_LAUNCH(pgru_bwd_kernel, 2, 3 * H);
+  if (pi >= 0) prof::end(pi, s, 2.0 * NC * M * 3.0 * H * H * T);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
@@ -784,7 +787,9 @@ extern "C" int ptv_gru_persist_bwd_splitk(int S, int NC, int M, int H, int T,
     else if (FM == 4) hipLaunchKernelGGL((pgru_bwd_sk_kernel<4, 3, S_>), grid, block, 0, s, a);            \
     else hipLaunchKernelGGL((pgru_bwd_sk_kernel<8, 1, S_>), grid, block, 0, s, a);                         \
   } while (0)
+  const int pi = prof::want(6, M, H) ? prof::begin(s) : -1;
   if (S == 4) PTV_SK_LAUNCH(4); else PTV_SK_LAUNCH(2);
+  if (pi >= 0) prof::end(pi, s, 2.0 * NC * M * 3.0 * H * H * T);
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <mutex>
 #include "common.hpp"
+#include "prof.hpp"
 #include "../../include/ptvae_hip.h"
 
 namespace ptv {
@@ -50,14 +51,6 @@ struct WgArgs {
   float* ws;                     // ordered reduction (ptv_wgrad_mode 1): slab partials go to ws[(slab0 + slab) * tiles + tile][128][128] with plain
   float* ws_csum;                // stores (ws_csum[(slab0 + slab) * M + m] for the column sums) and wgrad_reduce_kernel adds them up in slab
   int slab0;                     // order; null: fp32 atomics into C (run-to-run rounding differs)
-  // in-kernel fix-up (round 4): the LAST block to deliver a partial of an output tile adds that tile's partials up, in slab order, and
-  // writes C -- no separate reduction launch (39 per train step).  fix_cnt: one arrival counter per tile (zero between products, reset by
-  // the reducing block), null = wgrad_reduce_kernel does it.  fix_*: the slab geometry of the PRIMARY launch (the fast one; the guarded
-  // tail launch, fix_extra, contributes one more partial at slab index fix_nslab) -- both launches count live slabs the same way
-  unsigned* fix_cnt;
-  int fix_nslab, fix_kper, fix_K, fix_extra, fix_acc;
-  const int* fix_ktop;
-  int pairs;                     // wgrad2_kernel: blocks are decoded over (tiles_m + 1) / 2 * tiles_n tile PAIRS instead of tiles
   // second source of A (ptv_wgrad_cat): output rows m >= split (a multiple of 128) are the columns m - split of A2 -- two gradient
   // matrices that meet the same B (the notes GRU's dgi[:, :1024] and dgh: one pass over the states instead of two), or null
   const void* A2; long lda2; int split;
@@ -184,88 +177,9 @@ __device__ __forceinline__ wbf16x8 tr_frag_ld(const __bf16* st, int col) {
 }
 __device__ __forceinline__ wbf16x8 tr_frag(const __bf16* st, int col) { return tr_frag_ld<WLD>(st, col); }
 
-// four consecutive floats (16-byte aligned) as two agent-scope 8-byte loads: served past this CU's non-coherent caches
-__device__ __forceinline__ float4 ld4_agent(const float* p) {
-  union { unsigned long long u; float f[2]; } a, b;
-  a.u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  b.u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return make_float4(a.f[0], a.f[1], b.f[0], b.f[1]);
-}
-
-// The calling block has stored its partial of `tile` (and of the column sums).  Release, count the arrival; the last arriver acquires
-// and reduces the tile in slab order -- the same sums in the same order as wgrad_reduce_kernel, whichever block happens to be last.
-__device__ __forceinline__ void wgrad_fixup(const WgArgs& g, int tile, int m_blk, int n_blk) {
-  // hand-off without fences (an agent-scope release / acquire pair is an L2 write-back + invalidate of the whole XCD cache per block --
-  // measured: the step went from 8.2 to 10.5 ms): the partials went out as write-through (sc1) stores, the wave waits for their
-  // acknowledgement, one lane counts the arrival (relaxed), the last block reads with agent-scope loads (common.hpp, ordered_commit)
-  __shared__ int s_fix[3];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    WgArgs p = g;                                                   // the primary launch's slab geometry
-    p.kper = g.fix_kper; p.K = g.fix_K; p.k_top = g.fix_ktop;
-    int s0 = 0, s1 = 0; bool any = false;
-    for (int sl = 0; sl < g.fix_nslab; sl++) {
-      int kb, ke;
-      if (slab_range(p, sl, kb, ke)) { if (!any) s0 = sl; s1 = sl + 1; any = true; }
-    }
-    const unsigned expected = (unsigned)(s1 - s0) + (unsigned)g.fix_extra;
-    const unsigned old = __hip_atomic_fetch_add(g.fix_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = old + 1 == expected;
-    if (last) __hip_atomic_store(g.fix_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the stream's next product
-    s_fix[0] = last; s_fix[1] = s0; s_fix[2] = s1;
-  }
-  __syncthreads();
-  if (!s_fix[0]) return;
-  const int s0 = s_fix[1], s1 = s_fix[2];
-  const int tiles = g.tiles_m * g.tiles_n;
-  const long tstride = (long)tiles * (WBM * WBN);
-  const float* base = g.ws + (long)tile * (WBM * WBN);
-  const float* pb = g.fix_extra ? base + (long)g.fix_nslab * tstride : nullptr;
-  const bool vec = (g.N & 3) == 0 && (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0;
-  for (int q = threadIdx.x; q < WBM * WBN / 4; q += blockDim.x) {
-    const int ml = q / (WBN / 4), nl = (q % (WBN / 4)) * 4;
-    const int m = m_blk + ml, n = n_blk + nl;
-    if (m >= g.M || n >= g.N) continue;
-    const float* p = base + ml * WBN + nl;
-    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-    int sl = s0;
-    for (; sl + 8 <= s1; sl += 8) {                                 // eight partials in flight, added in slab order
-      float4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = ld4_agent(p + (long)(sl + u) * tstride);
-#pragma unroll
-      for (int u = 0; u < 8; u++) { sum.x += v[u].x; sum.y += v[u].y; sum.z += v[u].z; sum.w += v[u].w; }
-    }
-    for (; sl < s1; sl++) {
-      const float4 v = ld4_agent(p + (long)sl * tstride);
-      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-    }
-    if (pb) { const float4 v = ld4_agent(pb + ml * WBN + nl); sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w; }
-    float* cp = g.C + (long)m * g.ldc + n;
-    if (vec) {                                                      // (N a multiple of 4: the four columns are inside C together)
-      float4 c = g.fix_acc ? *reinterpret_cast<float4*>(cp) : make_float4(0.f, 0.f, 0.f, 0.f);
-      c.x += g.alpha * sum.x; c.y += g.alpha * sum.y; c.z += g.alpha * sum.z; c.w += g.alpha * sum.w;
-      *reinterpret_cast<float4*>(cp) = c;
-    } else {
-      const float sv[4] = {sum.x, sum.y, sum.z, sum.w};
-#pragma unroll
-      for (int e = 0; e < 4; e++)
-        if (n + e < g.N) cp[e] = (g.fix_acc ? cp[e] : 0.f) + g.alpha * sv[e];
-    }
-  }
-  if (g.ws_csum && n_blk == 0) {                                    // the bias gradient (always accumulates): this tile row's 128 sums
-    for (int ml = threadIdx.x; ml < WBM; ml += blockDim.x) {
-      const int m = m_blk + ml;
-      if (m >= g.M) continue;
-      const float* cs = g.ws_csum;                                  // (the workspace base, the same for both launches)
-      float sum = 0.f;
-      for (int sl = s0; sl < s1; sl++) sum += __hip_atomic_load(cs + (long)sl * g.M + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (g.fix_extra) sum += __hip_atomic_load(cs + (long)g.fix_nslab * g.M + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      g.csum[m] += sum;
-    }
-  }
-}
+// (Round 4's in-kernel fix-up -- the LAST block to deliver a partial of an output tile adds the tile's partials up in slab order, no separate
+// reduction launch -- measured 9.26 ms per step against 8.16 with the 39 reduction launches (write-through hand-off: 64 four-byte sc1 stores
+// per lane, and the last block of each tile reading S x 64 KB past the caches) and was removed in round 5.)
 
 // what a block does with its finished 128 x 128 partial (shared by the register-staged and the LDS-DMA kernel)
 __device__ __forceinline__ void wgrad_store(const WgArgs& g, wf32x4 (&acc)[4][4], wf32x4 (&accs)[4], bool do_sum, int slab, int tile, int tiles,
@@ -295,11 +209,8 @@ __device__ __forceinline__ void wgrad_store(const WgArgs& g, wf32x4 (&acc)[4][4]
         for (int r = 0; r < 4; r++)
           if (i * 16 + r < mrem && j * 16 < nrem) {                // (cells outside C are never read back)
             float* q = wt + (wm + i * 16 + (lane >> 4) * 4 + r) * WBN + wn + j * 16 + (lane & 15);
-            // (fix-up: write-through stores -- another CU, possibly behind another XCD's L2, reads them in this launch)
-            if (g.fix_cnt) __hip_atomic_store(q, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else *q = acc[i][j][r];
+            *q = acc[i][j][r];
           }
-    if (g.fix_cnt) wgrad_fixup(g, tile, m_blk, n_blk);
     return;
   }
   const bool single = g.nslab == 1;
@@ -539,144 +450,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgArgs g) {
   wgrad_store(g, acc, accs, do_sum, slab, tile, tiles, m_blk, n_blk, wm, wn, lane);
 }
 
-// ---------------------------------------------------------------------------------------------
-// 256 x 128 block tile: TWO vertically adjacent 128 x 128 output tiles per block, sharing the B stage (round 4).  The 128 x 128 kernel
-// reads 8 operand fragments from LDS per 16 MFMAs and wave -- at the MFMA rate that is the LDS's whole 128 B/clk (PMC: SQ_WAIT_INST_LDS
-// 34 % of the wave cycles on 1536 x 512 x 245760 once the fabric traffic was fixed); a wave that owns 128 x 64 of the block reads 12 per
-// 32.  Waves 0/1 own the upper tile, 2/3 the lower one, so the partials leave in the SAME [slab][tile][128][128] workspace layout and
-// the reduction (and the guarded tail launch) are unchanged.  A bf16, unguarded fast path, two register sets of prefetch.
-// ---------------------------------------------------------------------------------------------
-constexpr int WLD2 = 272;                                       // A stage row stride: 544 B = 8 banks mod 32, like WLD
-constexpr int WSTAGE2 = WBK * WLD2;
-
-template <bool BF32>
-__global__ __launch_bounds__(256, 2) void wgrad2_kernel(WgArgs g) {
-  if (g.prio) __builtin_amdgcn_s_setprio(3);
-  __shared__ __attribute__((aligned(16))) __bf16 As[2 * WSTAGE2];
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[2 * WSTAGE];
-  const int tiles = g.tiles_m * g.tiles_n, pairs = g.pairs;
-  int b = blockIdx.x, slab, pair;
-  if (g.map == 1) { const int q = b >> 3; slab = (q / pairs) * 8 + (b & 7); pair = q % pairs; }
-  else if (g.map == 2) { const int tx = pairs >> 3, q = b >> 3; pair = (b & 7) * tx + q % tx; slab = q / tx; }
-  else { slab = b / pairs; pair = b % pairs; }
-  int k_begin, k_end;
-  if (!slab_range(g, slab, k_begin, k_end)) return;
-  const int pm = pair / g.tiles_n, tn = pair % g.tiles_n;
-  const int m_blk = pm * 2 * WBM, n_blk = tn * WBN;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int half = wave >> 1, wm = half * WBM, wn = (wave & 1) * 64;
-  wf32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = wf32x4{0.f, 0.f, 0.f, 0.f};
-  const bool do_sum = g.csum != nullptr && n_blk == 0 && wn == 0;
-  wf32x4 accs[8];
-#pragma unroll
-  for (int i = 0; i < 8; i++) accs[i] = wf32x4{0.f, 0.f, 0.f, 0.f};
-  wbf16x8 ones;
-#pragma unroll
-  for (int e = 0; e < 8; e++) ones[e] = (__bf16)1.0f;
-  const int nst = (k_end - k_begin + WBK - 1) / WBK, last = nst - 1;
-  // staging: thread -> rows r, r + 16 of the stage; A columns c, c + 128 of the block's 256; B columns c of its 128
-  const int r = threadIdx.x >> 4, c = (threadIdx.x & 15) * 8;
-  const int ca0 = m_blk + c, ca1 = ca0 + WBM, cb = n_blk + c;
-  const __bf16* pa0 = reinterpret_cast<const __bf16*>(g.A) + (long)(k_begin + r) * g.lda + (ca0 < g.M ? ca0 : 0);
-  const __bf16* pa1 = reinterpret_cast<const __bf16*>(g.A) + (long)(k_begin + r) * g.lda + (ca1 < g.M ? ca1 : 0);
-  const typename WSrc<BF32>::T* pb = reinterpret_cast<const typename WSrc<BF32>::T*>(g.B) + (long)(k_begin + r) * g.ldb + (cb < g.N ? cb : 0);
-  wbf16x8 ra[2][2][2];                                            // [set][row half][column half]
-  WStage<BF32> rb[2];
-#define W2_FETCH(set, t)                                                                                   \
-  do {                                                                                                     \
-    const long o_ = (long)(t) * WBK * g.lda;                                                               \
-    ra[set][0][0] = *reinterpret_cast<const wbf16x8*>(pa0 + o_);                                           \
-    ra[set][1][0] = *reinterpret_cast<const wbf16x8*>(pa0 + o_ + 16 * g.lda);                              \
-    ra[set][0][1] = *reinterpret_cast<const wbf16x8*>(pa1 + o_);                                           \
-    ra[set][1][1] = *reinterpret_cast<const wbf16x8*>(pa1 + o_ + 16 * g.lda);                              \
-    rb[set].load_fast(pb + (long)(t) * WBK * g.ldb, g.ldb);                                                \
-  } while (0)
-#define W2_STORE(set, buf)                                                                                 \
-  do {                                                                                                     \
-    __bf16* a_ = As + (buf) * WSTAGE2;                                                                     \
-    *reinterpret_cast<wbf16x8*>(a_ + r * WLD2 + c) = ra[set][0][0];                                        \
-    *reinterpret_cast<wbf16x8*>(a_ + (r + 16) * WLD2 + c) = ra[set][1][0];                                 \
-    *reinterpret_cast<wbf16x8*>(a_ + r * WLD2 + c + WBM) = ra[set][0][1];                                  \
-    *reinterpret_cast<wbf16x8*>(a_ + (r + 16) * WLD2 + c + WBM) = ra[set][1][1];                           \
-    rb[set].store(Bs + (buf) * WSTAGE);                                                                    \
-  } while (0)
-  // (every fetch unconditional, the stage index clamped: see wgrad_kernel)
-  W2_FETCH(0, 0);
-  W2_FETCH(1, min(1, last));
-  W2_STORE(0, 0);
-  W2_FETCH(0, min(2, last));
-  __syncthreads();
-#define W2_BODY(u, t)                                                                                      \
-  do {                                                                                                     \
-    const __bf16* as = As + ((u) & 1) * WSTAGE2;                                                           \
-    const __bf16* bs = Bs + ((u) & 1) * WSTAGE;                                                            \
-    wbf16x8 fb[4];                                                                                         \
-    _Pragma("unroll") for (int j = 0; j < 4; j++) fb[j] = tr_frag(bs, wn + j * 16);                        \
-    constexpr int nu = ((u) + 1) & 1;                                                                      \
-    W2_STORE(nu, ((u) + 1) & 1);                                                                           \
-    W2_FETCH(nu, min((t) + 3, last));                                                                      \
-    _Pragma("unroll") for (int i = 0; i < 8; i++) {                                                        \
-      const wbf16x8 fa = tr_frag_ld<WLD2>(as, wm + i * 16);                                                \
-      _Pragma("unroll") for (int j = 0; j < 4; j++)                                                        \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);                \
-      if (do_sum) accs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, ones, accs[i], 0, 0, 0);           \
-    }                                                                                                      \
-    __syncthreads();                                                                                       \
-  } while (0)
-  int t0 = 0;
-  for (; t0 + 2 <= nst; t0 += 2) { W2_BODY(0, t0); W2_BODY(1, t0 + 1); }
-  if (t0 < nst) W2_BODY(0, t0);
-#undef W2_BODY
-#undef W2_STORE
-#undef W2_FETCH
-  const int tile = (pm * 2 + half) * g.tiles_n + tn;               // this wave's 128 x 128 output tile (the lower one may not exist)
-  const int tm_blk = m_blk + wm;                                   // its first row
-  if (tm_blk >= g.M) return;
-  if (do_sum && (lane & 15) == 0) {
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-      for (int rr = 0; rr < 4; rr++) {
-        const int m = tm_blk + i * 16 + (lane >> 4) * 4 + rr;
-        if (m < g.M) {
-          if (g.ws_csum) g.ws_csum[(long)(g.slab0 + slab) * g.M + m] = accs[i][rr];
-          else atomicAdd(g.csum + m, accs[i][rr]);
-        }
-      }
-  }
-  if (g.ws) {                                                    // ordered reduction: this slab's partial of the wave's tile
-    float* wt = g.ws + ((long)(g.slab0 + slab) * tiles + tile) * (WBM * WBN);
-    const int mrem = g.M - tm_blk - (lane >> 4) * 4, nrem = g.N - n_blk - wn - (lane & 15);
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++)
-          if (i * 16 + rr < mrem && j * 16 < nrem)
-            wt[(i * 16 + (lane >> 4) * 4 + rr) * WBN + wn + j * 16 + (lane & 15)] = acc[i][j][rr];
-    return;
-  }
-  const bool single = g.nslab == 1;
-#pragma unroll
-  for (int i = 0; i < 8; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int n = n_blk + wn + j * 16 + (lane & 15);
-#pragma unroll
-      for (int rr = 0; rr < 4; rr++) {
-        const int m = tm_blk + i * 16 + (lane >> 4) * 4 + rr;
-        if (m >= g.M || n >= g.N) continue;
-        float* cp = g.C + (long)m * g.ldc + n;
-        if (single) *cp += g.alpha * acc[i][j][rr];
-        else atomicAdd(cp, g.alpha * acc[i][j][rr]);
-      }
-    }
-}
+// (Round 4's 256 x 128 block tile -- two vertically adjacent output tiles per block sharing the B stage, 12 fragment reads per 32 MFMAs
+// instead of 8 per 16 -- measured SLOWER and was removed in round 5: 1536 x 512 x 245760 516 us at its best slab count against 467, the
+// step's 20 shapes 2306 against 1903 us; its 249 registers left two blocks per CU, and the third block was hiding more latency than the
+// LDS relief bought.  profiles/r04_wgrad_xcd_map.txt.)
 
 // ordered reduction of the slab partials: C[m][n] (+)= alpha * (p_0 + p_1 + ...) in slab order -- the same bits on every run.
 // ga: the fast launch's arguments (slabs 0 .. ga.nslab-1), gb: the guarded tail launch (one slab, number ga.nslab), if has_b.
@@ -771,8 +548,7 @@ static int g_wgrad_mode = [] { const char* e = getenv("PTV_WGRAD_ORDERED"); retu
 // grow-only workspace per stream: launches on one stream are ordered, so the next product's partials cannot overtake this one's
 // reduction; two streams never share a buffer.  (Allocation happens on a stream's first large product -- never inside a captured
 // graph if the capture was preceded by a warm-up of the same step.)
-struct WsBuf { float* p = nullptr; size_t bytes = 0; unsigned* cnt = nullptr; };      // cnt: 4096 zeroed tile counters (in-kernel fix-up)
-constexpr int WS_CNT = 4096;
+struct WsBuf { float* p = nullptr; size_t bytes = 0; };
 static WsBuf* ws_for(hipStream_t s, size_t bytes) {
   static WsBuf pool[64];
   static hipStream_t keys[64];
@@ -789,14 +565,8 @@ static WsBuf* ws_for(hipStream_t s, size_t bytes) {
     // (the outgrown buffer is NOT freed: a captured hipGraph may hold its address -- graph_step.py replays launches recorded on this
     // stream -- and it is tens of megabytes at most)
     size_t want = bytes + bytes / 4;
-    unsigned* keep = b.cnt;
     if (hipMalloc(reinterpret_cast<void**>(&b.p), want) != hipSuccess) { b = WsBuf{}; return nullptr; }
     b.bytes = want;
-    b.cnt = keep;
-    if (!b.cnt) {
-      if (hipMalloc(reinterpret_cast<void**>(&b.cnt), WS_CNT * sizeof(unsigned)) != hipSuccess || hipMemset(b.cnt, 0, WS_CNT * sizeof(unsigned)) != hipSuccess)
-        b.cnt = nullptr;                                           // (no counters: the separate reduction kernel serves this stream)
-    }
   }
   return &b;
 }
@@ -832,28 +602,17 @@ static int wgrad_impl(int M, int N, int K, const void* A, long lda, const void* 
   // short of the operands' last row; the guarded kernel takes the remaining <= 32 rows (and everything when rows are unaligned)
   const bool odd = (M % 8) || (N % 8) || (A2 && (split % 8));
   const int kfast = !vec ? 0 : (odd ? ((K - 1) / WBK) * WBK : (K / WBK) * WBK);
-  static const int nset_env = [] { const char* e = getenv("PTV_WGRAD_NSET"); return e ? atoi(e) : 0; }();
-  const int nset = (af || bf) ? 2 : (nset_env == 4 ? 4 : 2);       // 4 register sets only fit with bf16 sources
-  // MEASURED SLOWER, off by default (PTV_WGRAD_TM2=1 enables it): 1536 x 512 x 245760 at its best slab count 516 us against 467 for the
-  // 128 x 128 kernel, 3072 x 1024 x 16384 154 against 133, the step's 20 shapes 2306 against 1903 us -- 249 registers leave two
-  // blocks of four waves per CU, and what the smaller LDS traffic gives is less than what the third block per CU was hiding
-  static const int tm2_env = [] { const char* e = getenv("PTV_WGRAD_TM2"); return e ? atoi(e) : 0; }();
-  const bool tm2_ok = tm2_env && !af && nset == 2 && M > WBM && !A2;       // the fast launch runs wgrad2_kernel (256 x 128 block tile)
+  const int nset = 2;                                              // (4 register sets of prefetch, bf16 sources only: 2028 vs 2011 us over the step's shapes)
   WgArgs sent[2]; int nsent[2] = {0, 0};
   float* ws = nullptr; float* ws_csum = nullptr; int ws_slabs = 0;
-  unsigned* fix_cnt = nullptr;
   const bool has_a = kfast > 0, has_b = kfast < K;
   bool zeroed = false;
   auto launch = [&](bool guard, int k0, int kn, int want_slabs, int pass) -> int {
     WgArgs g{static_cast<const char*>(A) + (long)k0 * lda * (af ? 4 : 2), lda, static_cast<const char*>(B) + (long)k0 * ldb * (bf ? 4 : 2), ldb,
              C, ldc, M, N, kn, 0, cdiv(M, WBM), cdiv(N, WBN), 1, 0, alpha, colsum_a, k0 == 0 ? k_top : nullptr, k_unit, k_rev, g_gemm_prio,
-             nullptr, nullptr, 0, nullptr, 0, 0, 0, 0, 0, nullptr, 0,
+             nullptr, nullptr, 0,
              A2 ? static_cast<const char*>(A2) + (long)k0 * lda2 * (af ? 4 : 2) : nullptr, lda2, split};
-    // 256 x 128 block tile (wgrad2_kernel: two output tiles per block) for the fast launch of products with at least two tile rows and a
-    // bf16 A operand; PTV_WGRAD_TM2=0: the 128 x 128 kernel everywhere
-    const bool use2 = tm2_ok && !guard;
-    const int tiles = use2 ? ((g.tiles_m + 1) / 2) * g.tiles_n : g.tiles_m * g.tiles_n;     // BLOCKS per slab
-    if (use2) g.pairs = tiles;
+    const int tiles = g.tiles_m * g.tiles_n;     // BLOCKS per slab
     // slab count (measured optima of scripts/bench_wgrad.py sweep on MI355X).  Every slab pays M*N atomics, and a grid that is
     // just over one block per CU leaves a tail, so: about one block per CU (never more) for the skinny, HBM-bound products;
     // about three per CU for the MFMA-heavy ones (many tiles), where co-resident blocks hide each other's stalls; a slab is at least
@@ -873,13 +632,9 @@ static int wgrad_impl(int M, int N, int K, const void* A, long lda, const void* 
     // map 2 gives an XCD a range of tiles for all slabs (B columns are then fetched by every XCD: fine when K is short), map 1 gives it
     // whole slabs -- every K row is fetched by one XCD only (PMC on 1536 x 512 x 245760: L2 hit 29 % and 3.3x the algorithmic bytes from
     // the fabric with map 2)
-    static const int map_env = [] { const char* e = getenv("PTV_WGRAD_MAP"); return e ? atoi(e) : -1; }();
     const bool can1 = ns >= 8 && ns % 8 == 0, can2 = tiles % 8 == 0;
     const bool deepk = kn >= 16384;
-    if (map_env == 1 && can1) g.map = 1;
-    else if (map_env == 2 && can2) g.map = 2;
-    else if (map_env == 0) g.map = 0;
-    else if (can1 && (deepk || !can2)) g.map = 1;
+    if (can1 && (deepk || !can2)) g.map = 1;
     else if (can2) g.map = 2;
     g.kper = cdiv(cdiv(kn, ns), WBK) * WBK;
     if (g.map != 1) ns = cdiv(kn, g.kper);
@@ -890,11 +645,6 @@ static int wgrad_impl(int M, int N, int K, const void* A, long lda, const void* 
     }
     if (ws) {
       g.ws = ws; g.ws_csum = colsum_a ? ws_csum : nullptr; g.slab0 = guard ? nsent[0] : 0;
-      if (fix_cnt) {                                             // in-kernel fix-up: the primary launch's geometry, for both launches
-        const WgArgs& pr = sent[has_a ? 0 : 1];                  // (planning pass)
-        g.fix_cnt = fix_cnt; g.fix_nslab = pr.nslab; g.fix_kper = pr.kper; g.fix_K = pr.K; g.fix_ktop = pr.k_top;
-        g.fix_extra = (has_a && has_b) ? 1 : 0; g.fix_acc = accumulate;
-      }
     }
     else if (!accumulate && !zeroed) {
       const long total = (long)M * N;
@@ -904,14 +654,7 @@ static int wgrad_impl(int M, int N, int K, const void* A, long lda, const void* 
     }
     sent[guard ? 1 : 0] = g;
     const dim3 grid((unsigned)(tiles * ns));
-    if (use2) {
-      if (bf) hipLaunchKernelGGL((wgrad2_kernel<true>), grid, dim3(256), 0, s, g);
-      else hipLaunchKernelGGL((wgrad2_kernel<false>), grid, dim3(256), 0, s, g);
-      return PTV_OK;
-    }
-    // experiment knob (PTV_WGRAD_LDS_PAD bytes of unused dynamic LDS per block): fewer co-resident product blocks per CU next to the
-    // latency chains
-    static const int lds_pad = getenv("PTV_WGRAD_LDS_PAD") ? atoi(getenv("PTV_WGRAD_LDS_PAD")) : 0;
+    constexpr int lds_pad = 0;       // (unused dynamic LDS per block to keep product blocks off the CUs of the latency chains: no change, round 4)
 #define WG_LAUNCH(AF, BF)                                                                                      \
     do {                                                                                                       \
       if (guard) hipLaunchKernelGGL((wgrad_kernel<AF, BF, true, 2>), grid, dim3(256), lds_pad, s, g);                \
@@ -938,18 +681,11 @@ static int wgrad_impl(int M, int N, int K, const void* A, long lda, const void* 
     WsBuf* wb = ws_for(s, tile_bytes + sum_bytes);
     if (!wb) g_ord_fallbacks++;
     if (wb) { ws = wb->p; ws_csum = colsum_a ? wb->p + tile_bytes / sizeof(float) : nullptr; ws_slabs = total_slabs; }
-    // the last block of a tile reduces it -- unless a product that does not accumulate could find ALL its slabs dead (k_top): C must
-    // then still be cleared, which only the separate reduction does
-    // MEASURED SLOWER, off by default (PTV_WGRAD_FIXUP=1 enables it): 8.16 ms per step with the separate reduction launches against
-    // 9.26 with the fix-up (sc1 hand-off: 64 four-byte write-through stores per lane instead of cached ones, and the last block of each
-    // tile reading S x 64 KB past the caches while its CU's other work waits) and 10.5 with agent-scope fences instead (a release /
-    // acquire pair writes back and invalidates the XCD's whole L2, per block).  The 39 reduction launches per step stay.
-    static const int fix_env = [] { const char* e = getenv("PTV_WGRAD_FIXUP"); return e ? atoi(e) : 0; }();
-    if (wb && wb->cnt && fix_env && tiles <= WS_CNT && (accumulate || !k_top) && !(tm2_ok && has_a)) fix_cnt = wb->cnt;
   }
+  const int pi = prof::want(5, M, N) ? prof::begin(s) : -1;        // bench.py's roofline block: the family's launches, product + reduction
   if (has_a) launch(false, 0, kfast, slabs, 1);
   if (has_b) launch(true, kfast, K - kfast, has_a ? 1 : slabs, 1);
-  if (ws && !fix_cnt) {
+  if (ws) {
     const bool vec4 = (N & 3) == 0 && (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
     const long total = vec4 ? ((M * (long)N) >> 2) : M * (long)N;
     int nb = (int)((total + 255) / 256); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
@@ -958,6 +694,7 @@ static int wgrad_impl(int M, int N, int K, const void* A, long lda, const void* 
     else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, s, sent[0], sent[1], 1, has_b ? 1 : 0, accumulate);
   }
   (void)ws_slabs;
+  if (pi >= 0) prof::end(pi, s, 2.0 * M * N * K);                  // (full K: a k_top limit is a device value)
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

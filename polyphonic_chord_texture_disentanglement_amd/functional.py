@@ -37,7 +37,7 @@ BF16_STORAGE = True         # bf16 precision: tensors that only feed MFMA operan
 # bf16 precision: small-M recurrences (time GRU, encoder bi-GRUs; forward and BPTT) as ONE persistent launch per sequence
 # (csrc/gru_persist.hip) wherever the shape fits one workgroup per CU.  Measured on one box, teacher-forced train step:
 # B = 512: 28.7-30.1k samples/s with the per-step kernels, 31.7-32.9k persistent; B = 128: 14.5k -> 17.2k; B = 256: 23.1k -> 26.1k.
-PERSIST = os.environ.get('PTV_PERSIST', '1')            # '1' | '0'
+PERSIST = '1'            # '1' | '0'
 # set while graph_step.GraphedTrainStep captures a WHOLE train step (forward + backward + optimiser) into one hipGraph: every fork is
 # joined again before the capture ends, so the sibling-stream tricks and the persistent launches (ordered by captured event edges)
 # stay on.  A capture of PART of a step (the decoder forward, ptvae.py) must not leave forks open and keeps them off.
@@ -223,7 +223,7 @@ def _ld(t):
     return t.stride(0)
 
 
-CHAIN_PRIO = os.environ.get('PTV_CHAIN_PRIO', '1') != '0'
+CHAIN_PRIO = True
 _SIDE_DEPTH = [0, 0]          # [nesting depth of Side calls on this thread, priority state last sent to the library]
 
 
@@ -340,16 +340,13 @@ def _iarr(vs):
 
 
 # Persistent launches take turns (two spinning grids must never be half-resident together), so a short sequence on a sibling stream
-# makes the long one next to it wait (the chord encoder's 8 steps in front of the texture encoder's 32).  Sending sequences shorter
-# than PTV_PERSIST_MIN_T to the per-step kernels instead (they co-reside with a persistent grid) measured SLOWER: 9.68 vs 9.57 ms
-# with 16 -- the step kernels cost more than the turn they free.  0 = every supported sequence runs persistent.
-PERSIST_MIN_T = int(os.environ.get('PTV_PERSIST_MIN_T', '0'))
+# makes the long one next to it wait (the chord encoder's 8 steps in front of the texture encoder's 32).  Sending the short sequences
+# to the per-step kernels instead (they co-reside with a persistent grid) measured SLOWER, 9.68 vs 9.57 ms: every supported sequence
+# runs persistent.
 
 
 def persist_supported(NC, M, H, T=None):
     if str(PERSIST).lower() in ('0', 'false', 'off') or capturing_part():
-        return False
-    if T is not None and T < PERSIST_MIN_T:
         return False
     key = (NC, M, H, torch.cuda.current_device())
     if key not in _PERSIST_OK:
@@ -557,25 +554,8 @@ def _record_stream(obj, stream):
                 _record_stream(o, stream)
 
 
-# HIP has three stream priorities (hipDeviceGetStreamPriorityRange: 1 = low, 0 = normal, -1 = high; torch exposes only 0 / -1): the
-# command processor hands free workgroup slots to the highest-priority queue that has a ready dispatch.  PTV_POOL_PRIO gives the
-# pool streams theirs (pool stream 3 carries the decoder's deferred weight-gradient products: the bulk work that should fill the gaps
-# of the latency chains, not delay them).
-POOL_PRIO = [int(v) for v in os.environ.get('PTV_POOL_PRIO', '0,0,0,0').split(',')]
-_HIP = []
-
-
-def _new_stream(device, prio=0):
-    if prio <= 0:
-        return torch.cuda.Stream(device=device, priority=prio)
-    if not _HIP:
-        _HIP.append(ctypes.CDLL('libamdhip64.so'))
-    st = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        rc = _HIP[0].hipStreamCreateWithPriority(ctypes.byref(st), 0, int(prio))
-    if rc != 0:
-        raise RuntimeError('hipStreamCreateWithPriority failed: %d' % rc)
-    return torch.cuda.ExternalStream(st.value, device=device)        # (never destroyed: lives as long as the process)
+# (HIP stream priorities on the pool streams -- the command processor hands free workgroup slots to the highest-priority queue -- measured
+# 13.3-19.2 ms per step for ANY non-default value, the same cliff as a fifth hardware queue: every pool stream is a default-priority stream.)
 
 
 class Side:
@@ -593,21 +573,13 @@ class Side:
         # The sibling streams are folded onto a pool of 4 (slot mod 4): the HIP runtime multiplexes all streams of a process onto 4
         # hardware queues anyway (GPU_MAX_HW_QUEUES; with 5 or more the step gets 40 % SLOWER), and which of ~10 private streams
         # end up sharing a queue -- i.e. silently serialise -- is then decided by creation order.  With the pool the sharing is
-        # explicit; measured 9.67 vs 9.94 ms per step (pool sizes 2 / 3 / 5 / 7: 10.0 / 9.8 / 10.3 / 10.3).  0 = private streams.
-        pool = int(os.environ.get('PTV_SIDE_POOL', '4'))
-        if pool > 0:
-            key = ('pool', self.main.device.index, slot % pool)
-        else:
-            key = (self.main.cuda_stream, self.main.device.index, slot)
+        # explicit; measured 9.67 vs 9.94 ms per step (pool sizes 2 / 3 / 5 / 7: 10.0 / 9.8 / 10.3 / 10.3).
+        key = ('pool', self.main.device.index, slot % 4)
         if key not in _CHILD_STREAMS:
-            if pool > 0:
-                # all pool streams at once, in a FIXED order: which hardware queue a stream lands on follows creation order, and
-                # creating them lazily in first-use order made the step time depend on which slot happened to be used first (0.4 ms)
-                order = [1, 2, 0, 3] if pool == 4 else list(range(pool))
-                for k in order:
-                    _CHILD_STREAMS.setdefault(('pool', self.main.device.index, k), _new_stream(self.main.device, POOL_PRIO[k % len(POOL_PRIO)]))
-            else:
-                _CHILD_STREAMS[key] = torch.cuda.Stream(device=self.main.device)
+            # all pool streams at once, in a FIXED order: which hardware queue a stream lands on follows creation order, and
+            # creating them lazily in first-use order made the step time depend on which slot happened to be used first (0.4 ms)
+            for k in (1, 2, 0, 3):
+                _CHILD_STREAMS.setdefault(('pool', self.main.device.index, k), torch.cuda.Stream(device=self.main.device))
         self.s = _CHILD_STREAMS[key]
         self.keep = []
         self.used = False
@@ -672,8 +644,6 @@ class Side:
 
 
 _DEFERRED = []
-_LATE = []                  # (fn, keep_alive, origin stream): bulk launches postponed to the end of the backward pass (late())
-LATE_SLOTS = [int(v) for v in os.environ.get('PTV_LATE_SLOTS', '1,0,3').split(',')]
 GRAD_READY_HOOK = None      # callable(params, streams) set by dist.GradSync: the gradients of `params` are complete once `streams` drain
 
 
@@ -687,28 +657,9 @@ def mark(name):
         TRACE.append((name, e, time.perf_counter()))
 
 
-def late(fn, *keep):
-    """run fn() -- launches that only produce parameter gradients into buffers the caller has ALREADY handed to autograd -- when the
-    backward pass ends, on sibling streams: every node's chain work is then queued in front of it on every hardware queue (a queue runs
-    its dispatches in order), and the bulk spreads over all of them instead of piling up on one.  Outside a backward pass: now."""
-    try:
-        if not _DEFERRED and not _LATE:
-            torch.autograd.Variable._execution_engine.queue_callback(_join_deferred)
-    except RuntimeError:                      # not inside the autograd engine
-        return fn()
-    _LATE.append((fn, list(keep), cur_stream()))
-
-
 def _join_deferred():
     mark('deferred:join_start')
     cur = cur_stream()
-    for i, (fn, keep, origin) in enumerate(_LATE):
-        side = Side(LATE_SLOTS[i % len(LATE_SLOTS)])
-        if origin != side.s:
-            wait_stream(side.s, origin)           # the operands were produced on the node's stream
-        side(fn, keep)
-        _DEFERRED.append((side.s, side.keep))
-    _LATE.clear()
     for s, _keep in _DEFERRED:
         wait_stream(cur, s)
     _DEFERRED.clear()
@@ -718,7 +669,6 @@ def _join_deferred():
 def reset_deferred():
     """join whatever deferred side-stream work is still registered (a backward pass that raised never ran its end-of-pass
     callback): called by FusedClipAdam.zero_grad() and by the first node of every backward pass (VaeLossFn)"""
-    _LATE.clear()                           # (their gradients belong to the aborted pass)
     _LOSS_TOP.clear()                       # (a zero-skip bound nobody consumed: e.g. torch.autograd.grad that stopped at the logits)
     if _DEFERRED:
         _join_deferred()
@@ -748,35 +698,21 @@ def _bgrad_hh(b_hh, dgh2, gb_ih):
     return g
 
 
-WGRAD_FUSE_BIAS = os.environ.get('PTV_WGRAD_BIAS', '1') != '0'
-EMBED_MH_FWD = os.environ.get('PTV_EMBED_MH_FWD', '1') != '0'    # multi-hot operand of the note_embedding gradient built during the forward
+WGRAD_FUSE_BIAS = True
+EMBED_MH_FWD = True    # multi-hot operand of the note_embedding gradient built during the forward
 # decoder backward: fork the weight-gradient work BEFORE the chain queues its next dX products (no false dependency on them)?  Measured
 # 9.43 vs 9.37 ms: the products then compete with the chain's own dX products for the CUs -- the later fork is the better schedule
 # stream slot of a bi-GRU's second direction, forward / backward.  In the backward slot 7 = pool stream 3 is also the stream of the decoder's
 # deferred weight-gradient products (Side(3)): the reversed directions of the note-summary and encoder BPTTs queue behind them.  Moving
 # them to another pool stream measured SLOWER (slot 8 / 6 / 5: 9.40 / 9.39 / 9.29 vs 9.09 ms): running everything at once costs more
 # in contention than the queueing does.
-DEC_SIDE2 = int(os.environ.get('PTV_DEC_SIDE2', '-1'))
-# chord decoder backward: the chain to dz first and the parameter gradients afterwards (in line, or CHD_BWD_BULK: deferred on a bulk stream)?
-# Measured SLOWER than the interleaved program order: 8.53 (in line) / 8.88 (bulk stream 3) vs 8.30 ms per step -- kept as a switch
-CHD_BWD_DZ_FIRST = os.environ.get('PTV_CHD_BWD_DZ_FIRST', '0') != '0'
-CHD_BWD_BULK = int(os.environ.get('PTV_CHD_BWD_BULK', '3'))     # stream slot of the chord decoder's parameter-gradient products (-1: in line)
-CHD_BWD_PERSIST = os.environ.get('PTV_CHD_BWD_PERSIST', '1') != '0'      # (0 measured slower: 8.83 vs 8.54-8.66 ms)
-BIGRU_SLOT = int(os.environ.get('PTV_BIGRU_SLOT', '7'))
-BIGRU_SLOT_BWD = int(os.environ.get('PTV_BIGRU_SLOT_BWD', '7'))
-# Round-4 scheduling experiments on the step's tail (scripts/trace_calls.py shows it launch by launch; scripts/micro/queue_map.py: pool
-# streams 2 and 3 SHARE one of the 4 hardware queues, a queue runs its dispatches in order).  All measured slower than the plain scheme
-# (each direction's products right behind its BPTT, second direction on the sibling stream): 8.43 ms per step at B = 512 against
-#   BIGRU_CHAIN_FIRST (both BPTTs + both dX products on the node's stream, all 8 parameter-gradient products deferred):   8.75
-#   + BIGRU_LATE (those products launched when the backward pass ends, spread over 3 streams: "chains first, bulk last"):  8.75-8.95
-#   ROW_TURNS (the row-partitioned summary GRUs take turns with the persistent launches whose LDS they crowd):             8.48
-# -- the bulk products overlapping the latency-bound chains is what fills the GPU; taking them out of the chains' way leaves the chains
-# no faster (they are bound by their own hand-offs) and the bulk exposed at the end.
-BIGRU_CHAIN_FIRST = int(os.environ.get('PTV_BIGRU_CHAIN_FIRST', '0'))
-BIGRU_LATE = os.environ.get('PTV_BIGRU_LATE', '1') != '0'
-ROW_TURNS = os.environ.get('PTV_ROW_TURNS', '0') != '0'
-FORK_EARLY = os.environ.get('PTV_FORK_EARLY', '0') != '0'
-DP_INPLACE = os.environ.get('PTV_DP_INPLACE', '1') != '0'        # decoder backward accumulates into the loss node's dpitch buffer (no 134-MB copy)
+BIGRU_SLOT = 7
+BIGRU_SLOT_BWD = 7
+# (Round-4 scheduling experiments on the step's tail -- chain-first bi-GRU backward, parameter-gradient products launched when the backward
+# pass ends, row kernels taking turns with the persistent launches, forks before / after the chain's dX products -- all measured slower
+# than this plain scheme, 8.43 ms per step against 8.48-8.95; their numbers are in DESIGN.md section 4 and profiles/r04_ab_*.txt, their
+# code paths were removed in round 5.)
+DP_INPLACE = True        # decoder backward accumulates into the loss node's dpitch buffer (no 134-MB copy)
 # the backward passes over work whose result is exactly zero: note steps / tiles at which no gradient arrives (the loss ignores the
 # padded note slots), panel steps beyond the longest packed note sequence.  Decided on the gradients / lengths themselves, so the
 # results do not change; PTV_ZERO_SKIP=0 runs everything dense (bench.py reports that figure next to the headline)
@@ -797,7 +733,7 @@ def wgrad_bias(dy, x, gw, gb, prec, k_top=None, k_unit=0, k_rev=0):
     k_top (device int) / k_unit: the rows of dy from (k_top + 1) * k_unit on are zero (ptv_wgrad)"""
     K = dy.shape[0]
     if (WGRAD_FUSE_BIAS and prec == 1 and K >= 512 and gw.dtype == F32 and dy.stride(1) == 1 and x.stride(1) == 1
-            and os.environ.get('PTV_WGRAD', '1') != '0'):
+            and True):
         _chain_prio()
         call('ptv_wgrad', dy.shape[1], x.shape[1], K, ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(gw), _ld(gw), 1.0, 1,
              _bf(dy) | (_bf(x) << 1), 0, ptr(gb), ptr(k_top), int(k_unit) if k_top is not None else 0, int(k_rev), stream_ptr())
@@ -897,7 +833,6 @@ class Transpose01Fn(torch.autograd.Function):
 # =============================================================================================
 # PtvaeDecoder.emb_x  (ptvae.py:531-535)
 # =============================================================================================
-BIGRU_ROWS_OVERLAP = os.environ.get('PTV_BIGRU_ROWS_OVERLAP', '1') != '0'
 DEFAULT_GEOM = (32, 16, 130, 5, 130)                    # (num_step, max_simu_note, pitch_range, dur_width, pitch_pad) of init_model()
 
 
@@ -1011,13 +946,10 @@ def _bigru_forward(prec, x3, lengths, w):
                  ptr(lengths) if lengths is not None else None, ptr(hall), ptr(h16), ptr(gates), out.data_ptr() + 4 * d * H, 2 * H,
                  M, T, d, stream_ptr())
             return hall, gates, h16, (lengths if ZERO_SKIP else None)      # the backward must skip the same fully masked panel steps
-        with (_PersistTurn() if (ROW_TURNS and not capturing_part()) else contextlib.nullcontext()):
-            if not BIGRU_ROWS_OVERLAP:
-                return out, [rows(0), rows(1)]
-            side = Side(BIGRU_SLOT)
-            rev = side(lambda: rows(1), x3, out)
-            fwd = rows(0)
-            side.join()
+        side = Side(BIGRU_SLOT)
+        rev = side(lambda: rows(1), x3, out)
+        fwd = rows(0)
+        side.join()
         return out, [fwd, rev]
 
     side = Side(BIGRU_SLOT)
@@ -1027,11 +959,8 @@ def _bigru_forward(prec, x3, lengths, w):
     return out, [fwd, rev]
 
 
-def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None, pending=None):
+def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None):
     """-> ([dw_ih, dw_hh, db_ih, db_hh] x 2 directions, dx [T,M,I] or None).
-    pending (a list, or None): chain-first mode (BIGRU_CHAIN_FIRST) -- the BPTTs of both directions and both input-gradient products run on
-    the caller's stream, ALL eight parameter-gradient products go to the sibling stream, which is NOT joined: its Side handle is appended
-    to `pending` and the caller defers or joins it.
     dx_acc ([T*M, I] fp32, or None): a gradient that already arrived at x3 from another consumer -- both directions' input-gradient
     products ACCUMULATE into it and it is returned as dx (round 4: autograd used to add the two consumers' 134-MB gradients of the note
     embedding with an ATen kernel, and the two directions' dx met in a copy kernel; now both are the accumulate mode of products that
@@ -1073,39 +1002,6 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None, pending=None
             late['dgi'], late['top'] = dgi2, top
         return [dw_ih, dw_hh, db_ih, db_hh], (dx_of(0, dgi2, top, True) if (d == 0 and with_dx) else None)
 
-    def chain_first(res):
-        """res[d] = (dgi, dgh, top) of the two BPTTs, produced on this stream.  The input gradient is what the rest of the backward pass
-        waits for: both of its products first, here; the eight parameter-gradient products are bulk -- handed to the caller as a closure
-        (`pending`) that fills buffers returned NOW (round 4: the second direction's BPTT and the join used to queue behind the decoder's
-        deferred weight-gradient products on the sibling stream -- 0.6 ms of the step's tail)"""
-        dx = None
-        if need_dx:
-            for d in range(2):
-                dgi2 = res[d][0].view(T * M, 3 * H)
-                top = res[d][2]
-                kw = dict(prec=prec, m_top=top, m_unit=M if top is not None else 0)
-                if d == 0 and dx_acc is None:
-                    dx = gemm_dx(dgi2, w[0], **kw)
-                else:
-                    dx = gemm_dx(dgi2, w[4 * d], out=dx_acc if d == 0 else dx, acc=True, **kw)
-        bufs = [[_gbuf(w[4 * d]), _gbuf(w[4 * d + 1]), _gbuf(w[4 * d + 2]), _gbuf(w[4 * d + 3])] for d in range(2)]   # ih, hh, b_ih, b_hh
-
-        # (the closure writes through ALIASES: a second reference to the tensors handed to autograd would make AccumulateGrad clone them
-        # -- still empty -- instead of adopting them)
-        al = [[t.view(t.shape) for t in row] for row in bufs]
-
-        def wgrads():
-            for d in range(2):
-                dgi, dgh, top = res[d]
-                hall, _gates, h16 = saved[d][:3]
-                wgrad_bias(dgi.view(T * M, 3 * H), xf, al[d][0], al[d][2], prec, top, M)
-                wgrad_bias(dgh.view(T * M, 3 * H), (h16 if h16 is not None else hall)[:T].view(T * M, H), al[d][1], al[d][3], prec, top, M,
-                           k_rev=T if d else 0)
-        # (keep-alive: everything the products read -- the saved forward state dies with the node, the BPTT outputs with this frame)
-        pending.append((wgrads, [xf, dout, saved, [r[:2] for r in res], [r[2] for r in res]]))
-        g = [bufs[0][0], bufs[0][1], bufs[0][2], bufs[0][3], bufs[1][0], bufs[1][1], bufs[1][2], bufs[1][3]]
-        return g, (dx.view(T, M, I) if need_dx else None)
-
     side = Side(BIGRU_SLOT_BWD)
     wts = [_WT(w[1], prec), _WT(w[5], prec)]
     adt = _act_dtype(prec, H)
@@ -1119,20 +1015,6 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None, pending=None
                                dgi=_empty(T, M, 3 * H, dev=x3.device, dtype=adt), dgh=_empty(T, M, 3 * H, dev=x3.device, dtype=adt),
                                dh0=None, reverse=bool(d)))
         gru_persist_bwd(M, H, T, chains)
-        if pending is not None and BIGRU_CHAIN_FIRST == 2:
-            # "lite": the plain schedule, except that the second direction's input-gradient product does not wait for that direction's
-            # parameter-gradient products (its operand came out of the one BPTT launch on THIS stream) and the sibling stream is handed to
-            # the caller to defer instead of being joined here
-            g1, _ = side(lambda: products(1, chains[1]['dgi'], chains[1]['dgh']), xf, dout, chains[1]['dgi'], chains[1]['dgh'], saved)
-            g0, dx0 = products(0, chains[0]['dgi'], chains[0]['dgh'])
-            if need_dx:
-                late['dx'] = dx_acc if dx_acc is not None else dx0
-                dx_of(1, chains[1]['dgi'].view(T * M, 3 * H), None, False)
-                dx0 = late['dx']
-            pending.append(side)
-            return g0 + g1, (dx0.view(T, M, I) if need_dx else None)
-        if pending is not None and BIGRU_CHAIN_FIRST == 1:
-            return chain_first([(c['dgi'], c['dgh'], None) for c in chains])
         g1, _ = side(lambda: products(1, chains[1]['dgi'], chains[1]['dgh']), xf, dout, chains[1]['dgi'], chains[1]['dgh'])
         g0, dx0 = products(0, chains[0]['dgi'], chains[0]['dgh'])
     elif (len(saved[0]) > 3 and saved[0][1].dtype == BF16 and saved[0][2] is not None):
@@ -1149,13 +1031,7 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None, pending=None
             top = _ineg1(x3.device) if (lengths is not None and M % 32 == 0) else None
             call('ptv_row_gru_persist_bwd', H, ptr(pk['wt']), ptr(hall), ptr(gates), None, dout.data_ptr() + 4 * d * H, dout.stride(0),
                  ptr(lengths) if lengths is not None else None, ptr(dgi), ptr(dgh), None, ptr(scratch), M, T, d, ptr(top), stream_ptr())
-            if pending is not None and BIGRU_CHAIN_FIRST == 1:
-                return dgi, dgh, top
             return products(d, dgi, dgh, top)
-        if pending is not None and BIGRU_CHAIN_FIRST == 1:
-            with (_PersistTurn() if ROW_TURNS else contextlib.nullcontext()):
-                res = [rows(0), rows(1)]
-            return chain_first(res)
         g1, _ = side(lambda: rows(1), xf, dout)
         g0, dx0 = rows(0)
     else:
@@ -1178,7 +1054,7 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None, pending=None
 # parks its gradient here and returns None; the summary node (which always runs later: the decoder consumes its output) accumulates
 # its own input-gradient products into that buffer and returns it as the one gradient of the embedding.
 _EMB_LINK = {}
-EMB_LINK = os.environ.get('PTV_EMB_LINK', '1') != '0'
+EMB_LINK = True
 
 
 def emb_link_arm(emb):
@@ -1207,41 +1083,15 @@ class BiGruFinalFn(torch.autograd.Function):
         dx_acc = None
         if ctx.link is not None and ctx.link['demb'] is not None and ctx.needs_input_grad[0]:
             dx_acc, ctx.link['demb'] = ctx.link['demb'].view(-1, x3.shape[2]), None     # the decoder node's gradient of the same tensor
-            ev = ctx.link.pop('demb_event', None)
-            if ev is not None:
-                wait_event(cur_stream(), ev)              # (its product ran on the decoder's sibling stream: not covered by autograd's edge)
             _EMB_LINK.pop(x3.data_ptr(), None)
-        pending = [] if (BIGRU_CHAIN_FIRST and OVERLAP and not capturing_part()) else None
-        grads, dx = _bigru_backward(ctx.prec, x3, w, ctx.saved_state, dout.contiguous(), ctx.needs_input_grad[0], dx_acc, pending)
+        grads, dx = _bigru_backward(ctx.prec, x3, w, ctx.saved_state, dout.contiguous(), ctx.needs_input_grad[0], dx_acc)
         mark('bigru_bwd:end M=%d @%x' % (x3.shape[1], stream_ptr() & 0xffff))
         ctx.saved_state = None
         from .optim import is_arena_view
         # (w is ordered by direction, the products return [ih, hh, b_ih, b_hh] per direction)
         pairs = list(zip(w[0:4], grads[0:4])) + list(zip(w[4:8], grads[4:8]))
-        adopted = all(p_.grad is None and is_arena_view(p_, g_) for p_, g_ in pairs)
-        streams, final = (), True
-        for ent in (pending or ()):
-            if isinstance(ent, Side):                     # (mode 2: the second direction's products are already queued on it)
-                if adopted:
-                    streams += (ent.s,)
-                    ent.defer()
-                else:
-                    ent.join()
-                continue
-            fn, keep = ent
-            # parameter gradients only: they may be computed after this node returns -- if autograd ADOPTS the buffers (DecoderTFFn.backward)
-            if adopted and BIGRU_LATE:
-                late(fn, *keep)                           # at the end of the backward pass, spread over the sibling streams
-                final = False
-            elif adopted:
-                sd = Side(BIGRU_SLOT_BWD)
-                sd(fn, *keep)
-                streams += (sd.s,)
-                sd.defer()
-            else:
-                fn()
-        if GRAD_READY_HOOK is not None and adopted and final:       # data parallel: a bi-GRU's 8 gradients are final once `streams` drain
-            GRAD_READY_HOOK([p_ for p_, _ in pairs], streams)
+        if GRAD_READY_HOOK is not None and all(p_.grad is None and is_arena_view(p_, g_) for p_, g_ in pairs):
+            GRAD_READY_HOOK([p_ for p_, _ in pairs], ())        # data parallel: a bi-GRU's 8 gradients are final (all queued on this stream)
         return (dx, None, None) + tuple(grads)
 
 
@@ -1307,7 +1157,7 @@ class ReparamFn(torch.autograd.Function):
 # =============================================================================================
 # TextureEncoder front end: conv + relu + maxpool   (ptvae.py:95-99,112-114)
 # =============================================================================================
-TXT_ARGMAX = os.environ.get('PTV_TXT_ARGMAX', '1') != '0'
+TXT_ARGMAX = True
 
 
 class TextureFrontFn(torch.autograd.Function):
@@ -1347,7 +1197,7 @@ class TextureFrontFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # row-partitioned persistent notes GRU (csrc/notes_persist.hip)
 # ---------------------------------------------------------------------------------------------
-NOTES_PERSIST = os.environ.get('PTV_NOTES_PERSIST', '1') not in ('0', 'false', 'off')
+NOTES_PERSIST = True
 class PackCache:
     """packed weight copies keyed by the source parameters' addresses, valid while (a) the stamp -- in-place version counters, the
     fused optimiser's step count -- is unchanged and (b) the tensors that were packed are still alive: an address alone can come
@@ -1421,8 +1271,8 @@ def notes_packs(w_ih, w_hh, Ht):
 
 
 _HEADS_PACKS = PackCache()
-HEADS_FUSED = os.environ.get('PTV_HEADS_FUSED', '1') != '0'
-HEADS_WGRAD_FUSED = os.environ.get('PTV_HEADS_WGRAD_FUSED', '1') != '0'
+HEADS_FUSED = True
+HEADS_WGRAD_FUSED = True
 
 
 def heads_ok(prec, Hn, NP, Hd, hn16, hd16):
@@ -1459,7 +1309,7 @@ def heads_packs(w_p, w_dh):
 
 def row_gru_ok(prec, H, I, M, adt):
     """the H = 128 instance of the row-partitioned persistent GRU (dec_notes_emb_gru): worth it when the rows fill the chip"""
-    return (NOTES_PERSIST and os.environ.get('PTV_ROW_GRU128', '1') != '0' and prec == 1 and BF16_STORAGE and H == 128 and I == 128
+    return (NOTES_PERSIST and True and prec == 1 and BF16_STORAGE and H == 128 and I == 128
             and adt == BF16 and M >= 4096)
 
 
@@ -1503,13 +1353,11 @@ def _eye2(dev):
 
 # The teacher-forced decoder forward behind ONE C entry point (ptv_decoder_tf_fwd, csrc/composite.hip): launch sequence, the persistent
 # launch's turn and the shape decisions in C++; this side allocates the tensors and fills the two tables.  0 = sequence the launches here.
-DEC_COMPOSITE = os.environ.get('PTV_DEC_COMPOSITE', '1') != '0'
+DEC_COMPOSITE = True
 # the note tokens' gradient product (194 us, not an input of the time BPTT) on the sibling stream instead of in front of the BPTT on the
 # chain: MEASURED SLOWER (9.0 vs 8.38 ms per step) -- the persistent time BPTT then starts earlier and runs beside more of the bulk
 # products, and a persistent grid with company loses more than the chain gained.  Off.
-DTOK_ASYNC = os.environ.get('PTV_DTOK_ASYNC', '0') != '0'
-NOTES_WGRADS_LATE = os.environ.get('PTV_NOTES_WGRADS_LATE', '0') != '0'
-CHD_COMPOSITE = os.environ.get('PTV_CHD_COMPOSITE', '1') != '0'
+CHD_COMPOSITE = True
 _DTF = {}
 
 
@@ -1737,36 +1585,28 @@ class DecoderTFFn(torch.autograd.Function):
         st = ctx.st
         ctx.st = None
         R, E = st['R'], st['E']
-        link_ok = ctx.emb_link is not None and ctx.needs_input_grad[2]
-        dz, demb, dTOKS, G, side = decoder_bwd_core(P, st, z, emb.view(16, R, E)[:15].view(15 * R, E), dpitch, ddur, dtok_async=link_ok)
+        dz, demb, dTOKS, G, side = decoder_bwd_core(P, st, z, emb.view(16, R, E)[:15].view(15 * R, E), dpitch, ddur)
         mark('dec_bwd:end')
         # parameter gradients only: joined when the backward pass ends -- but only if autograd ADOPTS the tensors
         # (p.grad is None and the buffer is this step's arena view); an accumulation `p.grad += g` would run on this
         # node's stream without a dependency on the side stream
         from .optim import is_arena_view
         if all(G[n] is None or (P[n].grad is None and is_arena_view(P[n], G[n])) for n in DEC_PARAM_NAMES):
-            streams = (side.s,) + tuple(s2.s for s2 in side.extra)
+            streams = (side.s,)
             side.defer()
-            for s2 in side.extra:
-                s2.defer()
             if GRAD_READY_HOOK is not None:               # data parallel: this slice of the gradient bucket can leave now (dist.GradSync)
                 GRAD_READY_HOOK([P[n] for n in DEC_PARAM_NAMES if G[n] is not None], streams)
         else:
             side.join()
-            for s2 in side.extra:
-                s2.join()
         B, He = st['B'], st['He']
         demb_out = demb.view(16, 32, B, E)
         if ctx.emb_link is not None and ctx.needs_input_grad[2] and demb.dtype == F32 and demb.is_contiguous():
             ctx.emb_link['demb'] = demb                   # the summary node accumulates into it and returns it (BiGruFinalFn.backward)
-            ctx.emb_link['demb_event'] = getattr(side, 'dtok_event', None)      # ... after this event, if the product ran on the sibling stream
             demb_out = None
-        elif getattr(side, 'dtok_event', None) is not None:
-            wait_event(cur_stream(), side.dtok_event)     # handed to autograd as an ordinary gradient: complete on this stream
         return (dz, demb_out, dTOKS[1:].view(R, 2 * He), None, None) + tuple(G[n] for n in DEC_PARAM_NAMES)
 
 
-def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur, dtok_async=False):
+def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     """BPTT of the PianoTree decoder given the saved forward state `st` -- shared by the teacher-forced node (DecoderTFFn) and
     the step-loop node (functional_free.DecoderStepFn: argmax is not differentiable, so with the fed tokens recorded every
     chain is the same batched BPTT).  Chain (duration GRU -> heads -> notes GRU -> time GRU -> z) on the caller's stream; every
@@ -1902,15 +1742,12 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur, dtok_async=False):
         wgrad_b('dur_hid_linear.weight', 'dur_hid_linear.bias', dHD0, NSUM_op, slice(0, Hn), top_h)
         wgrad_b('dur_hid_linear.weight', None, dHD0, st['pitch'], slice(Hn, None), top_h)
         wgrad_b('pitch_out_linear.weight', 'pitch_out_linear.bias', dP, NSUM_op, None, top_h)
-    # (forked as soon as its operands exist: a sibling stream waits for everything its parent has QUEUED, so the products the chain
-    # queues next would be a false dependency)
-    if FORK_EARLY:
-        side(head_wgrads, dHD0, dP, dY16)
     if not fused_heads:
         gemm_dx(dHD0, w_dh, slice(0, Hn), out=dNSUM, prec=prec, m_top=top_h, m_unit=R, out_blocked=rowk_bwd)                   # [M, Hn]
         gemm_dx(dP, w_p, out=dNSUM, acc=True, prec=prec, m_top=top_h, m_unit=R, out_blocked=rowk_bwd)
-    if not FORK_EARLY:
-        side(head_wgrads, dHD0, dP, dY16)
+    # (forked after the chain's dX products are queued: forking as soon as the operands exist removes a false dependency and measured 0.06 ms
+    # SLOWER -- the products then compete with the chain for CUs)
+    side(head_wgrads, dHD0, dP, dY16)
 
     mark('dec_bwd:head_dx')
     # ---- notes GRU (15 steps, batch 32*B) ----
@@ -1931,19 +1768,13 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur, dtok_async=False):
     mark('dec_bwd:notes_bptt')
     dGC = sum_steps(dgi_n, t_top=top_step)                                    # [R, 3Hn]
 
-    # dtok_async (the teacher-forced node with the embedding link armed): the gradient of the fed note tokens -- a 245760 x 128 x 1536
-    # product, 194 us -- is NOT an input of the time BPTT; it used to sit in front of it on the chain.  It runs on the sibling stream
-    # (first in its queue, ahead of this section's weight-gradient products); whoever consumes dtok waits for `side.dtok_event`
+    # (the gradient of the fed note tokens -- a 245760 x 128 x 1536 product, not an input of the time BPTT -- stays in front of it on the
+    # chain: on the sibling stream it measured 9.0 against 8.38 ms per step, profiles/r04_ab_slots.txt)
     dtok = _empty(16, R, E, dev=dev)
     dtok[15].zero_()
-    side.dtok_event = None
-
-    def dtok_product():
-        gemm_dx(dgi_n.view(M, 3 * Hn), w_ih_n, slice(Ht, None), out=dtok[:15].view(M, E), prec=prec, m_top=top_step, m_unit=R)
 
     def notes_dx():
-        if not (dtok_async and DTOK_ASYNC and OVERLAP and not capturing_part()):
-            dtok_product()
+        gemm_dx(dgi_n.view(M, 3 * Hn), w_ih_n, slice(Ht, None), out=dtok[:15].view(M, E), prec=prec, m_top=top_step, m_unit=R)
         dNS = gemm_dx(dGC, w_ih_n, slice(0, Ht), prec=prec)                   # [R, Ht]
         w_tn = W['dec_time_to_notes_hid.weight']
         gemm_dx(dHN0, w_tn, out=dNS, acc=True, prec=prec)
@@ -1973,26 +1804,15 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur, dtok_async=False):
             wgrad('dec_notes_gru.weight_ih_l0', dgi_n.view(M, 3 * Hn), tok_op, slice(Ht, None))
         wgrad('dec_time_to_notes_hid.weight', dHN0, NSf_op)
         bgrad('dec_time_to_notes_hid.bias', dHN0)
-    if dtok_async and DTOK_ASYNC and OVERLAP and not capturing_part():
-        def dtok_side():
-            dtok_product()
-            return record_event()
-        side.dtok_event = side(dtok_side, dgi_n, dtok, top_step)
-        _record_stream(dtok, side.s)
-    if FORK_EARLY:
-        side(notes_wgrads, dgi_n, dgh_n, dGC, dHN0, dNSUM)                   # forked before the chain's dX products are queued
     dtok, dNS = notes_dx()
-    if not FORK_EARLY and not NOTES_WGRADS_LATE:
-        side(notes_wgrads, dgi_n, dgh_n, dGC, dHN0, dNSUM)
+    # (forked BEFORE the time BPTT is queued: forking after it -- the four deep products then start when the persistent launch is done
+    # instead of running beside it -- measured 8.48 against 8.18 ms per step)
+    side(notes_wgrads, dgi_n, dgh_n, dGC, dHN0, dNSUM)
 
     mark('dec_bwd:notes_dx')
     # ---- time GRU (32 steps, batch B) ----
     w_hh_t, w_ih_t = W['dec_time_gru.weight_hh_l0'], W['dec_time_gru.weight_ih_l0']
     dgi_t, dgh_t, dzhid = gru_bwd(prec, NS, st['gates_t'], w_hh_t, dh_ext=dNS.view(32, B, Ht))
-    if not FORK_EARLY and NOTES_WGRADS_LATE:
-        # (forked AFTER the time BPTT is queued: a sibling stream waits for what its parent has queued, so the notes GRU's four deep
-        # weight-gradient products start when the persistent BPTT is done instead of running beside it)
-        side(notes_wgrads, dgi_n, dgh_n, dGC, dHN0, dNSUM)
     mark('dec_bwd:time_bptt')
     dZG = sum_steps(dgi_t)                                                    # [B, 3Ht]
     dz_in = gemm_dx(dZG, w_ih_t, slice(2 * He, None), prec=prec)              # [B, Zi]
@@ -2014,16 +1834,10 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur, dtok_async=False):
         bgrad('z2dec_hid_linear.bias', dzhid)
         wgrad('z2dec_in_linear.weight', dz_in, z)
         bgrad('z2dec_in_linear.bias', dz_in)
-    # the last products of the node may go to a SECOND deferred sibling stream (PTV_DEC_SIDE2 = slot, -1 = off): the first one is the
-    # stream that finishes last in the step (the deferred join), while the other pool streams idle between the encoders' chains
-    side2 = Side(DEC_SIDE2) if DEC_SIDE2 >= 0 else side
-    side2(time_wgrads, dgi_t, dgh_t, dZG, dTOKS, dzhid, dz_in, dNS)
+    side(time_wgrads, dgi_t, dgh_t, dZG, dTOKS, dzhid, dz_in, dNS)
     # the caller defers the join to the end of the backward pass; the node's saved forward state (released when the node returns)
     # is still being read by the products queued above
     side.keep.extend((st, z, tok_op))
-    side.extra = [side2] if side2 is not side else []
-    if side.extra:
-        side2.keep.extend((st, z, tok_op))
     return dz, dtok, dTOKS, G, side
 
 
@@ -2111,107 +1925,48 @@ class ChordDecoderTFFn(torch.autograd.Function):
         prec, T, B, H, I = st['prec'], st['T'], st['B'], st['H'], st['I']
         dev = z.device
         hall, toks = st['hall'], st['toks']
-        if not CHD_BWD_DZ_FIRST:
-            hs = hall[1:].view(T * B, H)
-            G = {}
-            dhs = None
-            for name, dlog in (('root_out', droot), ('chroma_out', dchroma), ('bass_out', dbass)):
-                w = P[name + '.weight']
-                if dlog is None:
-                    G[name + '.weight'], G[name + '.bias'] = _gbuf(w), _gbuf(P[name + '.bias'])
-                    continue
-                d2 = dlog.contiguous().view(T * B, -1)
-                if dhs is None:
-                    dhs = gemm(d2, w, tb=True, prec=prec)
-                else:
-                    gemm(d2, w, dhs, tb=True, acc=True, prec=prec)
-                G[name + '.weight'] = gemm(d2, hs, _gbuf(w), ta=True, tb=True, acc=True, prec=prec)
-                G[name + '.bias'] = _bgrad(P[name + '.bias'], d2)
-            if dhs is None:
-                dhs = _zeros(T * B, H, dev=dev)
-            w_hh, w_ih = P['gru.weight_hh_l0'], P['gru.weight_ih_l0']
-            # (per-step kernels, not the persistent launch: persistent launches take turns, and this short chain on its sibling stream had
-            # to wait for the decoder's 32-step time BPTT -- its dz then reached the chord encoder 0.3 ms after the decoder's own, round 4)
-            dgi, dgh, dh0 = gru_bwd(prec, hall, st['gates'], w_hh, dh_ext=dhs.view(T, B, H), allow_persist=CHD_BWD_PERSIST)
-            G['gru.weight_hh_l0'] = gemm(dgh.view(T * B, 3 * H), hall[:T].view(T * B, H), _gbuf(w_hh), ta=True, tb=True, acc=True,
-                                         prec=prec)
-            G['gru.bias_hh_l0'] = _bgrad(P['gru.bias_hh_l0'], dgh.view(T * B, 3 * H))
-            dzg = sum_steps(dgi)
-            G['gru.bias_ih_l0'] = _bgrad(P['gru.bias_ih_l0'], dzg)
-            g = _gbuf(w_ih)
-            gemm(dzg, st['z_in'], g[:, I:], ta=True, tb=True, acc=True, prec=prec)
-            gemm(dgi.view(T * B, 3 * H), toks.view(T * B, I), g[:, :I], ta=True, tb=True, acc=True, prec=prec)
-            G['gru.weight_ih_l0'] = g
-            dz_in = gemm(dzg, w_ih[:, I:], tb=True, prec=prec)
-            dtok0 = gemm(dgi[0], w_ih[:, :I], tb=True, prec=prec)                     # only the learned start token
-            G['init_input'] = _bgrad(P['init_input'], dtok0)
-            w_zh, w_zi = P['z2dec_hid.weight'], P['z2dec_in.weight']
-            dz = gemm(dh0, w_zh, tb=True, prec=prec)
-            gemm(dz_in, w_zi, dz, tb=True, acc=True, prec=prec)
-            G['z2dec_hid.weight'] = gemm(dh0, z, _gbuf(w_zh), ta=True, tb=True, acc=True, prec=prec)
-            G['z2dec_hid.bias'] = _bgrad(P['z2dec_hid.bias'], dh0)
-            G['z2dec_in.weight'] = gemm(dz_in, z, _gbuf(w_zi), ta=True, tb=True, acc=True, prec=prec)
-            G['z2dec_in.bias'] = _bgrad(P['z2dec_in.bias'], dz_in)
-        else:
-            hs = hall[1:].view(T * B, H)
-            G = {}
-            dhs = None
-            # The chain to dz first; every parameter gradient afterwards, on the bulk stream (CHD_BWD_BULK).  Round 4: the node used to interleave
-            # them in program order -- dz left 14 launches after the BPTT, the decoder's own dz had been waiting for it for 0.3 ms (the reparam
-            # node needs both), and autograd's hand-over event of this node sits behind ALL of its launches
-            bulk = []
-            for name, dlog in (('root_out', droot), ('chroma_out', dchroma), ('bass_out', dbass)):
-                w = P[name + '.weight']
+        hs = hall[1:].view(T * B, H)
+        G = {}
+        dhs = None
+        for name, dlog in (('root_out', droot), ('chroma_out', dchroma), ('bass_out', dbass)):
+            w = P[name + '.weight']
+            if dlog is None:
                 G[name + '.weight'], G[name + '.bias'] = _gbuf(w), _gbuf(P[name + '.bias'])
-                if dlog is None:
-                    continue
-                d2 = dlog.contiguous().view(T * B, -1)
-                if dhs is None:
-                    dhs = gemm(d2, w, tb=True, prec=prec)
-                else:
-                    gemm(d2, w, dhs, tb=True, acc=True, prec=prec)
-                bulk.append((lambda d2=d2, gw=G[name + '.weight'], gb=G[name + '.bias']:
-                             (gemm(d2, hs, gw, ta=True, tb=True, acc=True, prec=prec), colsum(gb.view(1, -1), d2)), d2))
+                continue
+            d2 = dlog.contiguous().view(T * B, -1)
             if dhs is None:
-                dhs = _zeros(T * B, H, dev=dev)
-            w_hh, w_ih = P['gru.weight_hh_l0'], P['gru.weight_ih_l0']
-            w_zh, w_zi = P['z2dec_hid.weight'], P['z2dec_in.weight']
-            dgi, dgh, dh0 = gru_bwd(prec, hall, st['gates'], w_hh, dh_ext=dhs.view(T, B, H), allow_persist=CHD_BWD_PERSIST)
-            dzg = sum_steps(dgi)
-            dz_in = gemm(dzg, w_ih[:, I:], tb=True, prec=prec)
-            dz = gemm(dh0, w_zh, tb=True, prec=prec)
-            gemm(dz_in, w_zi, dz, tb=True, acc=True, prec=prec)
-            for n in ('gru.weight_hh_l0', 'gru.bias_hh_l0', 'gru.bias_ih_l0', 'gru.weight_ih_l0', 'init_input', 'z2dec_hid.weight',
-                      'z2dec_hid.bias', 'z2dec_in.weight', 'z2dec_in.bias'):
-                G[n] = _gbuf(P[n])
-
-            def rest():
-                gemm(dgh.view(T * B, 3 * H), hall[:T].view(T * B, H), G['gru.weight_hh_l0'], ta=True, tb=True, acc=True, prec=prec)
-                colsum(G['gru.bias_hh_l0'].view(1, -1), dgh.view(T * B, 3 * H))
-                colsum(G['gru.bias_ih_l0'].view(1, -1), dzg)
-                g = G['gru.weight_ih_l0']
-                gemm(dzg, st['z_in'], g[:, I:], ta=True, tb=True, acc=True, prec=prec)
-                gemm(dgi.view(T * B, 3 * H), toks.view(T * B, I), g[:, :I], ta=True, tb=True, acc=True, prec=prec)
-                dtok0 = gemm(dgi[0], w_ih[:, :I], tb=True, prec=prec)                     # only the learned start token
-                colsum(G['init_input'].view(1, -1), dtok0)
-                gemm(dh0, z, G['z2dec_hid.weight'], ta=True, tb=True, acc=True, prec=prec)
-                colsum(G['z2dec_hid.bias'].view(1, -1), dh0)
-                gemm(dz_in, z, G['z2dec_in.weight'], ta=True, tb=True, acc=True, prec=prec)
-                colsum(G['z2dec_in.bias'].view(1, -1), dz_in)
-                return dtok0
-
-            def run_bulk():
-                for fn, _d2 in bulk:
-                    fn()
-                return rest()
-            from .optim import is_arena_view
-            adopted = all(P[n].grad is None and is_arena_view(P[n], G[n]) for n in CHD_PARAM_NAMES)
-            if CHD_BWD_BULK >= 0 and adopted and OVERLAP and not capturing_part():
-                side = Side(CHD_BWD_BULK)
-                side(run_bulk, hall, toks, st['z_in'], dgi, dgh, dh0, dzg, dz_in, z, [d for _f, d in bulk])
-                side.defer()                        # (these gradients travel with the final exchange under data parallelism)
+                dhs = gemm(d2, w, tb=True, prec=prec)
             else:
-                run_bulk()
+                gemm(d2, w, dhs, tb=True, acc=True, prec=prec)
+            G[name + '.weight'] = gemm(d2, hs, _gbuf(w), ta=True, tb=True, acc=True, prec=prec)
+            G[name + '.bias'] = _bgrad(P[name + '.bias'], d2)
+        if dhs is None:
+            dhs = _zeros(T * B, H, dev=dev)
+        w_hh, w_ih = P['gru.weight_hh_l0'], P['gru.weight_ih_l0']
+        # (per-step kernels, not the persistent launch: persistent launches take turns, and this short chain on its sibling stream had
+        # to wait for the decoder's 32-step time BPTT -- its dz then reached the chord encoder 0.3 ms after the decoder's own, round 4)
+        dgi, dgh, dh0 = gru_bwd(prec, hall, st['gates'], w_hh, dh_ext=dhs.view(T, B, H), allow_persist=True)
+        G['gru.weight_hh_l0'] = gemm(dgh.view(T * B, 3 * H), hall[:T].view(T * B, H), _gbuf(w_hh), ta=True, tb=True, acc=True,
+                                     prec=prec)
+        G['gru.bias_hh_l0'] = _bgrad(P['gru.bias_hh_l0'], dgh.view(T * B, 3 * H))
+        dzg = sum_steps(dgi)
+        G['gru.bias_ih_l0'] = _bgrad(P['gru.bias_ih_l0'], dzg)
+        g = _gbuf(w_ih)
+        gemm(dzg, st['z_in'], g[:, I:], ta=True, tb=True, acc=True, prec=prec)
+        gemm(dgi.view(T * B, 3 * H), toks.view(T * B, I), g[:, :I], ta=True, tb=True, acc=True, prec=prec)
+        G['gru.weight_ih_l0'] = g
+        dz_in = gemm(dzg, w_ih[:, I:], tb=True, prec=prec)
+        dtok0 = gemm(dgi[0], w_ih[:, :I], tb=True, prec=prec)                     # only the learned start token
+        G['init_input'] = _bgrad(P['init_input'], dtok0)
+        w_zh, w_zi = P['z2dec_hid.weight'], P['z2dec_in.weight']
+        dz = gemm(dh0, w_zh, tb=True, prec=prec)
+        gemm(dz_in, w_zi, dz, tb=True, acc=True, prec=prec)
+        G['z2dec_hid.weight'] = gemm(dh0, z, _gbuf(w_zh), ta=True, tb=True, acc=True, prec=prec)
+        G['z2dec_hid.bias'] = _bgrad(P['z2dec_hid.bias'], dh0)
+        G['z2dec_in.weight'] = gemm(dz_in, z, _gbuf(w_zi), ta=True, tb=True, acc=True, prec=prec)
+        G['z2dec_in.bias'] = _bgrad(P['z2dec_in.bias'], dz_in)
+        # (the chain to dz first and every parameter gradient afterwards -- in line or on a bulk stream -- measured 8.53 / 8.88 against 8.30 ms
+        # per step: the interleaved program order stays)
         mark('chd_dec_bwd:end')
         return (dz, None, None) + tuple(G[n] for n in CHD_PARAM_NAMES)
 
@@ -2295,8 +2050,7 @@ def _loss_top_hint(dpitch, ddur):
     return None
 
 
-LOSS_TOP_HINT = os.environ.get('PTV_LOSS_TOP_HINT', '1') != '0'
-LOSS_SIDE = os.environ.get('PTV_LOSS_SIDE', '0') != '0'          # (measured: 8.298 vs 8.302 ms -- no gain; kept as a switch)
+LOSS_TOP_HINT = True
 
 
 class VaeLossFn(torch.autograd.Function):
@@ -2328,15 +2082,9 @@ class VaeLossFn(torch.autograd.Function):
             call('ptv_ce_fwd', ptr(root_m), 12, ptr(root_t), B * 8, 12, -1, ptr(sums[4:]), st2)
             call('ptv_ce_fwd', ptr(chroma_m), 2, ptr(chroma_t), B * 96, 2, -1, ptr(sums[5:]), st2)
             call('ptv_ce_fwd', ptr(bass_m), 12, ptr(bass_t), B * 8, 12, -1, ptr(sums[6:]), st2)
-        side = Side(4) if (LOSS_SIDE and not capturing_part()) else None
-        if side is not None:
-            side(small, sums, root_m, chroma_m, bass_m, mu_c, sd_c, mu_r, sd_r, c)
         pitch_m, dur_m, sm_p, pitch_t, dur_t, counts, gcnt = _pianotree_ce_fwd(pitch, dur, x, sums, st, weighted_dur)
         ctx.gcnt = gcnt
-        if side is not None:
-            side.join()
-        else:
-            small()
+        small()                                   # (on a sibling stream beside the PianoTree cross-entropy: 8.298 against 8.302 ms -- in line)
         out = _empty(11, dev=dev)
         ctx.scal = (float(beta), float(w0), float(w1), float(B * Z), float(B * 8), float(B * 96))
         call('ptv_loss_finalize', ptr(sums), ptr(counts), *ctx.scal, ptr(out), st)
@@ -2366,14 +2114,8 @@ class VaeLossFn(torch.autograd.Function):
             call('ptv_ce_bwd', ptr(root_m), 12, ptr(root_t), root_t.numel(), 12, -1, ptr(gs[4:]), ptr(droot), 12, st2)
             call('ptv_ce_bwd', ptr(chroma_m), 2, ptr(chroma_t), chroma_t.numel(), 2, -1, ptr(gs[5:]), ptr(dchroma), 2, st2)
             call('ptv_ce_bwd', ptr(bass_m), 12, ptr(bass_t), bass_t.numel(), 12, -1, ptr(gs[6:]), ptr(dbass), 12, st2)
-        side = Side(4) if (LOSS_SIDE and not capturing_part()) else None
-        if side is not None:
-            side(small, gs, dmu_c, dsd_c, dmu_r, dsd_r, droot, dchroma, dbass)
         dpitch, ddur = _pianotree_ce_bwd(pitch_m, dur_m, sm_p, pitch_t, dur_t, gs, st, ctx.gcnt)
-        if side is not None:
-            side.join()
-        else:
-            small()
+        small()
         if sm_c:
             droot, dchroma, dbass = (t.permute(*_chord_perm(t)) for t in (droot, dchroma, dbass))
         # zero-skip limit for whoever consumes exactly these two gradients (DecoderTFFn / DecoderStepFn): the last note step with a

@@ -65,10 +65,10 @@ def _sos_grid(dev):
 # row-partitioned persistent kernels for the step loop (csrc/freerun.hip): one launch per time step walks all 15 note steps of
 # a 16-sample panel, one more re-summarises the predicted notes.  bf16 precision, init_model() geometry.
 # ---------------------------------------------------------------------------------------------
-FREE_PERSIST = os.environ.get('PTV_FREE_PERSIST', '1') not in ('0', 'false', 'off')
+FREE_PERSIST = True
 # training forward of the step loop: the panels store only decisions, logits and fed tokens; states and gates the backward needs are
 # recomputed afterwards for all 480*B rows at once by the teacher-forced kernels (same tokens, same decisions forced)
-FREE_REPLAY = os.environ.get('PTV_FREE_REPLAY', '1') not in ('0', 'false', 'off')
+FREE_REPLAY = True
 # note-loop kernel: None = by panel count (csrc/freerun.hip), True / False = force the producers-heads split / the 4-wave kernel
 NOTE_LOOP_SPLIT = None
 # cluster mode of the 4-wave kernel: S workgroups per 16-sample panel, each streaming 1/S of the notes-GRU gate weights (bound by ONE
@@ -90,7 +90,7 @@ def note_loop_cluster(B):
     return 4 if panels * 4 <= cap4 else (2 if panels * 2 <= ncu else 0)
 
 
-NOTE_CLUSTER4_MAX_WGS = int(os.environ.get('PTV_NOTE_CLUSTER4_MAX', '0'))      # 0 = the CU count
+NOTE_CLUSTER4_MAX_WGS = 0      # 0 = the CU count
 _NCU = []
 
 

@@ -18,8 +18,8 @@ import torch
 from ._lib import call, ptr, stream_ptr
 
 _ARENA_OF = {}          # id(param) -> GradArena
-SHADOW_T_ASYNC = os.environ.get('PTV_SHADOW_T_ASYNC', '1') != '0'  # transposed bf16 shadows refreshed on a sibling stream (read by the backward only)
-ADAM_SHADOW = os.environ.get('PTV_ADAM_SHADOW', '1') != '0'      # the Adam kernel also writes the bf16 operand copy of the parameters
+SHADOW_T_ASYNC = True  # transposed bf16 shadows refreshed on a sibling stream (read by the backward only)
+ADAM_SHADOW = True      # the Adam kernel also writes the bf16 operand copy of the parameters
 _SHADOW_OF = {}         # param data_ptr -> (FusedClipAdam, offset, numel): bf16 copies of the flat parameter buffer
 
 

@@ -21,7 +21,7 @@ from . import functional_free as FF_
 from ._lib import prec_code
 
 # stream slot of the ground-truth note summaries (functional.Side; autograd replays their BPTT on the same stream): -1 = the caller's
-SUMMARY_SLOT = int(os.environ.get('PTV_SUMMARY_SLOT', '5'))
+SUMMARY_SLOT = 5
 
 
 # ---------------------------------------------------------------------------------------------

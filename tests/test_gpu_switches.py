@@ -1,0 +1,27 @@
+"""Every environment switch the package keeps (each one is either a diagnostic or a supported alternative, not a parked
+experiment) runs the full-geometry teacher-forced step against the reference golden `full_tf1_b16`: a fresh process per setting (the
+switches are read at import), losses and gradient norms within the bf16 bound under each of them."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+PROBE = ("import json, sys, torch; sys.path.insert(0, %r); import bench; "
+         "print('PARITY ' + json.dumps(bench.golden_parity('bf16', torch.device('cuda:0'))))") % ROOT
+
+
+@pytest.mark.parametrize('env', [{}, {'PTV_ZERO_SKIP': '0'}, {'PTV_DUR_RECOMPUTE': '0'}, {'PTV_PERSIST_SPLITK': '0'}, {'PTV_PERSIST_SPLITK': '4'},
+                                 {'PTV_WGRAD_ORDERED': '0'}, {'PTV_WGRAD_DMA': '0'}, {'PTV_ORDERED_STRICT': '1', 'PTV_PTR_CHECKS': '1'}],
+                         ids=lambda e: ','.join('%s=%s' % kv for kv in e.items()) or 'defaults')
+def test_step_under_each_kept_switch_vs_reference_golden(env):
+    out = subprocess.run([sys.executable, '-c', PROBE], env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('PARITY ')][-1]
+    r = json.loads(line[7:])
+    assert r['max_abs_dloss'] < 3e-4, r
+    assert r['rel_gradnorm_err'] < 5e-3 and r['worst_tensor_gradnorm_rel_err'] < 2e-2, r
