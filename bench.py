@@ -338,7 +338,7 @@ def _roofline(lib, B, model, args, ms_per_step=None):
             tfs = fl / (ms * 1e-3) / 1e12
             roof['also'].append({'bound': 'mfma', 'kernel': name, 'achieved': round(tfs, 1), 'peak': 2500.0, 'unit': 'TFLOP/s',
                                  'frac': round(tfs / 2500.0, 4), 'launches': cnt, 'total_ms': round(ms, 2), 'flops': what,
-                                 'note': 'event-timed per call on its own stream, in situ (calls overlap each other and the chains)'})
+                                 'note': 'event-timed per call on its own stream over 3 extra steps after the timed region, in situ (calls overlap each other and the chains)'})
     if ms_per_step:
         tfs = 6.15e9 * B / (ms_per_step * 1e-3) / 1e12
         roof['also'].append({'bound': 'mfma', 'kernel': 'whole train step (6.15 GFLOP per sample, SURVEY.md 8d)', 'achieved': round(tfs, 1),
@@ -484,7 +484,7 @@ def main():
     barrier()
     lib.ptv_prof_reset()
     lib.ptv_prof_config(32 * B, model.decoder.dec_notes_hid_size)
-    lib.ptv_prof_enable(4 | 8 | 16 | 32)                   # tags 3, 4: the row-partitioned notes GRU, forward and BPTT; 5: weight-gradient products; 6: small-M BPTT
+    lib.ptv_prof_enable(4 | 8)                             # tags 3, 4: the row-partitioned notes GRU, forward and BPTT (two event pairs per step)
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i)
@@ -492,6 +492,14 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     lib.ptv_prof_enable(0)
+    if rank == 0 and args.mode == 'train' and args.tfr >= 1.0:
+        # the families of roofline.also (tags 5, 6: ~45 event pairs per step on the sibling streams) are timed over three EXTRA steps
+        # outside the timed region, so that their bookkeeping cannot touch the headline
+        lib.ptv_prof_enable(16 | 32)
+        for i in range(3):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        lib.ptv_prof_enable(0)
     dp = None
     if world > 1:
         import torch.distributed as dist

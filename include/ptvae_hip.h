@@ -602,6 +602,9 @@ int ptv_gradnorm_clip_adam_step(float* p, const float* g, float* m, float* v, lo
  * cross-entropy of the weighted duration loss, ptv_ce_group_fwd.)  ptv_wgrad_mode switches the two product paths only. */
 int ptv_ordered_reductions(int on);
 int ptv_wgrad_mode(int ordered);
+/* bf16 x bf16 weight-gradient products through the LDS-DMA kernel (global_load_lds staging, three stage buffers; default 0 = register-staged:
+ * faster standalone, slower beside the persistent recurrences -- csrc/wgrad.hip); process-wide, PTV_WGRAD_DMA sets the initial value */
+int ptv_wgrad_dma(int enable);
 /* reductions that ran on fp32 atomics although ordered mode is on (no workspace: first use inside a capture, > 64 streams, a need
  * beyond the scratch); 0 after any step is what makes the step bit-reproducible.  reset != 0 clears the counter. */
 long ptv_ordered_fallbacks(int reset);

@@ -543,6 +543,7 @@ using namespace ptv;
 namespace ptv {
 // 1 (default): slab partials through a workspace + ordered reduction (bit-reproducible, and no fp32 atomics: they retire at
 // ~1e11 elements/s, a fifth of the time of the deep products); 0: atomics into C
+static int g_wgrad_dma = [] { const char* e = getenv("PTV_WGRAD_DMA"); return e ? atoi(e) : 0; }();
 static int g_wgrad_mode = [] { const char* e = getenv("PTV_WGRAD_ORDERED"); return (e && e[0] == '0') ? 0 : 1; }();
 
 // grow-only workspace per stream: launches on one stream are ordered, so the next product's partials cannot overtake this one's
@@ -573,6 +574,7 @@ static WsBuf* ws_for(hipStream_t s, size_t bytes) {
 }  // namespace ptv
 
 namespace ptv { extern int g_splitk_ordered; }
+extern "C" int ptv_wgrad_dma(int enable) { ptv::g_wgrad_dma = enable ? 1 : 0; return PTV_OK; }
 extern "C" int ptv_wgrad_mode(int ordered) { ptv::g_wgrad_mode = ptv::g_splitk_ordered = ordered ? 1 : 0; return PTV_OK; }
 
 static int wgrad_impl(int M, int N, int K, const void* A, long lda, const void* A2, long lda2, int split, const void* B, long ldb, float* C, long ldc,
@@ -661,8 +663,10 @@ static int wgrad_impl(int M, int N, int K, const void* A, long lda, const void* 
       else if (nset == 2) hipLaunchKernelGGL((wgrad_kernel<AF, BF, false, 2>), grid, dim3(256), lds_pad, s, g);      \
       else if constexpr (!(AF) && !(BF)) hipLaunchKernelGGL((wgrad_kernel<false, false, false, 4>), grid, dim3(256), lds_pad, s, g); \
     } while (0)
-    static const int dma_env = [] { const char* e = getenv("PTV_WGRAD_DMA"); return e ? atoi(e) : 1; }();
-    if (!af && !bf && !guard && dma_env && (kn % WBK) == 0) { hipLaunchKernelGGL(wgrad_dma_kernel, grid, dim3(256), 0, s, g); return PTV_OK; }
+    // (default OFF: standalone the LDS-DMA kernel is 5-12 % faster on the deep products -- 1536 x 512 x 245760 571 -> 544 us -- but in the
+    // step it measured 7.82-7.98 ms against 7.72-7.75: its 48 KB of LDS per block co-reside worse with the persistent recurrences' 96-KB
+    // workgroups than the register-staged kernel's 36 KB.  PTV_WGRAD_DMA=1 enables it; tests/test_gpu_switches.py runs the step on it.)
+    if (!af && !bf && !guard && g_wgrad_dma && (kn % WBK) == 0) { hipLaunchKernelGGL(wgrad_dma_kernel, grid, dim3(256), 0, s, g); return PTV_OK; }
     if (af && bf) WG_LAUNCH(true, true);
     else if (af) WG_LAUNCH(true, false);
     else if (bf) WG_LAUNCH(false, true);

@@ -661,14 +661,19 @@ def test_wgrad_kernel_vs_fp64_product_and_column_sums(M, N, K, dt, pad):
     b0 = torch.randn(M, generator=g)
     want = C0.double() + 0.5 * (A64.t() @ B64)
     want_b = b0.double() + A64.sum(0)
-    for slabs in (0, 1, 3, 8):
+    for slabs, dma in ((0, 0), (1, 0), (3, 0), (8, 0), (0, 1), (3, 1)):          # dma: the LDS-DMA kernel (bf16 x bf16 operands only; else a no-op)
         C = C0.to(dev).clone()
         bias = b0.to(dev).clone()
-        call('ptv_wgrad', M, N, K, ptr(Ad), Ad.stride(0), ptr(Bd), Bd.stride(0), ptr(C), C.stride(0), 0.5, 1, dt, slabs, ptr(bias), None, 0, 0, stream_ptr())
-        torch.cuda.synchronize()
+        call('ptv_wgrad_dma', dma)
+        try:
+            call('ptv_wgrad', M, N, K, ptr(Ad), Ad.stride(0), ptr(Bd), Bd.stride(0), ptr(C), C.stride(0), 0.5, 1, dt, slabs, ptr(bias), None, 0, 0,
+                 stream_ptr())
+            torch.cuda.synchronize()
+        finally:
+            call('ptv_wgrad_dma', 0)
         sc = max(1.0, want.abs().max().item())
-        assert (C.cpu().double() - want).abs().max() < 2e-5 * sc, slabs
-        assert (bias.cpu().double() - want_b).abs().max() < 2e-5 * max(1.0, want_b.abs().max().item()), slabs
+        assert (C.cpu().double() - want).abs().max() < 2e-5 * sc, (slabs, dma)
+        assert (bias.cpu().double() - want_b).abs().max() < 2e-5 * max(1.0, want_b.abs().max().item()), (slabs, dma)
     # k_top: the caller knows the rows from (k_top + 1) * k_unit on are zero -- same result on an operand where they are
     if K >= 128:
         unit, top = 32, (K // 32) // 2 - 1
