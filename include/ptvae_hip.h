@@ -544,6 +544,10 @@ int ptv_notes_gru_persist_fwd(const void* wg_h, const void* wg_t, const float* b
 long ptv_notes_gru_persist_scratch_elems(long R);
 int ptv_notes_gru_persist_bwd(const void* wt, const void* HN16, const void* gates, const void* ext, void* dgi, void* dgh,
                               float* dh0, void* scratch, long R, int T, int* top_step, void* stream);
+/* which kernel ptv_notes_gru_persist_bwd runs: 1 (default) = 8 waves per workgroup, the A operand LDS-resident, the carry dh (x) z in registers
+ * (csrc/notes_roles.hip), 0 = the 4-wave kernel of rounds 2-4 (csrc/notes_persist.hip); same arguments, same results to rounding.
+ * Process-wide. */
+int ptv_notes_bwd_variant(int eight_waves);
 /* timing experiments: device buffer of 8 x 2048 uint64 that one workgroup of the following forward launches fills with per-wave event
  * stamps (scripts/trace_notes.py), or NULL */
 int ptv_debug_notes_trace(void* buf);

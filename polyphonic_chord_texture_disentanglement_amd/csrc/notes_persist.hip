@@ -594,6 +594,12 @@ static int launch_bwd(const RowGruBwdArgs& a, hipStream_t s) {
 
 using namespace ptv;
 
+extern "C" int ptv_notes_bwd8(const void* wt, const void* HN16, const void* gates, const void* ext, void* dgi, void* dgh, float* dh0, void* scratch,
+                              long R, int T, int* top_step, void* stream);
+// the notes GRU's BPTT: 1 = the 8-wave kernel of notes_roles.hip (LDS-resident operand, carry in registers), 0 = the 4-wave kernel of this file
+static int g_notes_bwd8 = 1;
+extern "C" int ptv_notes_bwd_variant(int eight_waves) { g_notes_bwd8 = eight_waves ? 1 : 0; return PTV_OK; }
+
 extern "C" int ptv_row_gru_persist_fwd(int H, const void* w_hh, const void* w_x, const float* b_hh, const float* b_ih, const void* gc,
                                        const float* x, long x_step, const int* lengths, float* HN, void* HN16, void* gates,
                                        float* out, long out_ld, long R, int T, int reverse, void* stream) {
@@ -639,5 +645,6 @@ extern "C" long ptv_notes_gru_persist_scratch_elems(long R) { return ptv_row_gru
 extern "C" int ptv_notes_gru_persist_bwd(const void* wt, const void* HN16, const void* gates, const void* ext, void* dgi, void* dgh,
                                          float* dh0, void* scratch, long R, int T, int* top_step, void* stream) {
   if (!ext) return PTV_ERR_ARG;
+  if (g_notes_bwd8) return ptv_notes_bwd8(wt, HN16, gates, ext, dgi, dgh, dh0, scratch, R, T, top_step, stream);
   return ptv_row_gru_persist_bwd(512, wt, HN16, gates, ext, nullptr, 0, nullptr, dgi, dgh, dh0, scratch, R, T, 0, top_step, stream);
 }

@@ -423,3 +423,252 @@ extern "C" int ptv_notes_gru_persist_fwd(const void* wg_h, const void* wg_t, con
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
+
+// =============================================================================================================================
+// BPTT of the notes GRU, round 5: 8 waves per 64-row workgroup (two per SIMD), every wave owns 64 output units for both phases of a step
+//   products  dh = dgh_{s+1} . W_hh (K = 1536): the weight stream L2 -> registers (a ring of 3 k-blocks x 4 tiles); the A operand -- the gate
+//             gradients the workgroup itself produced one step earlier -- comes out of LDS for its first 1152 k (144 KB, K-blocked:
+//             chunk of 8 k x 64 rows) and out of a K-blocked global scratch for the rest (48 KB per step: LDS holds 160 KB)
+//   cells     in the MFMA lane layout (pair-interleaved tiles: 8 consecutive units of a row per lane): saved gates (unit-blocked by 16),
+//             arriving gradient (blocked by 32), previous state (the bf16 copy) requested one item ahead; the carry dh (x) z lives in
+//             REGISTERS (64 per lane) -- it took 128 KB of LDS in the 4-wave kernel, which is what makes room for the A operand
+// The 4-wave kernel (notes_persist.hip) re-read the whole A operand from L2 in every wave (768 KB per CU and step next to the 1.5 MB of
+// weights) and ran one wave per SIMD; products and cells cannot overlap across the step boundary (every product of step s - 1 needs every
+// gate gradient of step s), so the step is the sum of a weight-bound and an HBM-bound phase: what the second wave per SIMD and the
+// LDS-resident operand buy is a cleaner version of each.
+// =============================================================================================================================
+namespace ptv {
+namespace nb {
+
+constexpr int H = 512, ROWS = 64, KT = 3 * H / 32, KL = 36;           // k-blocks: all / held in LDS
+constexpr int LDS_A = KL * 4 * ROWS * 16;                             // 147456 bytes
+constexpr int SCR_CH = (KT - KL) * 4;                                 // chunks per step that go through the global scratch: 48
+constexpr int DW = 3;                                                  // weight ring depth in k-blocks
+
+typedef __attribute__((ext_vector_type(4))) float f4v;
+typedef __attribute__((ext_vector_type(4))) unsigned u4v;
+
+struct Args {
+  const bf16x8* wt;                // pair-interleaved packing of W_hh^T: [32 tiles of output units][48 kb][64]
+  const __bf16* HN16;              // [T + 1][R][512] bf16 states
+  const __bf16* gates;             // [T][4][32][R][16]
+  const __bf16* ext;               // [16][T * R][32]: gradient arriving at the state after step s, column-blocked by 32
+  __bf16* dgi; __bf16* dgh;        // [T][R][1536], [T][R][512] (the n third)
+  float* dh0;                      // [R][512] or null
+  __bf16* scratch;                 // [grid][2][48][64][8]
+  int* top_step;
+  int R, T, skip;
+};
+
+__device__ __forceinline__ float bfv(const u4v& v, int e) { const unsigned w = v[e >> 1]; return __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16)); }
+__device__ __forceinline__ unsigned pk2b(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  bf16x2 v; v[0] = (__bf16)a; v[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ u4v pk8(const float (&v)[8]) { return u4v{pk2b(v[0], v[1]), pk2b(v[2], v[3]), pk2b(v[4], v[5]), pk2b(v[6], v[7])}; }
+
+template <int ABL>                 // timing experiments (scripts/bench_notes.py): 2 = no products, 4 = no cell loads / stores
+__global__ __launch_bounds__(512, 2) void notes_bwd_kernel(Args a) {
+  __builtin_amdgcn_s_setprio(3);
+  extern __shared__ __attribute__((aligned(16))) char bsm[];           // A operand chunks 0 .. 143: (chunk * 64 + row) * 16 bytes
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rl = lane & 15, q = lane >> 4;                              // fragment / epilogue coordinates: row in tile, k quad = unit octet
+  const long R = a.R, RH = R * H, R3H = 3 * RH;
+  const long r0 = (long)blockIdx.x * ROWS;
+  const int T = a.T;
+  __bf16* sc = a.scratch + (long)blockIdx.x * 2 * (SCR_CH * ROWS * 8);
+  long grow[4]; bool ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { ok[i] = r0 + i * 16 + rl < R; grow[i] = min(r0 + i * 16 + rl, R - 1); }
+
+  // ---- zero-skip: steps at which no gradient arrives for any of the 64 rows, with nothing arriving from later steps either, produce exact
+  // zeros (the loss ignores the padded note slots, ptvae.py:498-511): tested on the arriving gradient itself, panel by panel
+  int s_top = T - 1;
+  for (; a.skip && s_top >= 0; s_top--) {
+    unsigned nz = 0;
+    for (int i = tid; i < ROWS * (H / 8); i += 512) {
+      const int row = i / (H / 8), c8 = (i % (H / 8)) * 8;
+      if (r0 + row < R) {
+        const u4v w = *reinterpret_cast<const u4v*>(a.ext + ((long)(c8 >> 5) * ((long)T * R) + (long)s_top * R + r0 + row) * 32 + (c8 & 31));
+        nz |= (w[0] | w[1] | w[2] | w[3]) & 0x7fff7fffu;                // -0.0 is zero too
+      }
+    }
+    if (__syncthreads_or(nz != 0)) break;
+    for (int i = tid; i < ROWS * (H / 8); i += 512) {
+      const int row = i / (H / 8), c8 = (i % (H / 8)) * 8;
+      if (r0 + row < R) {
+        const u4v zz = {0u, 0u, 0u, 0u};
+        __bf16* pi = a.dgi + (long)s_top * R3H + (r0 + row) * (3 * H) + c8;
+        *reinterpret_cast<u4v*>(pi) = zz; *reinterpret_cast<u4v*>(pi + H) = zz; *reinterpret_cast<u4v*>(pi + 2 * H) = zz;
+        *reinterpret_cast<u4v*>(a.dgh + (long)s_top * RH + (r0 + row) * H + c8) = zz;
+      }
+    }
+  }
+  if (a.top_step && tid == 0 && s_top >= 0) atomicMax(a.top_step, s_top);    // consumers of dgi / dgh may stop after this step's rows
+
+  // ONE lane offset per M tile and operand family (the unit-tile part of every address is a scalar offset of the buffer instruction)
+  unsigned g_off[4], e_off[4], h_off[4], d_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    g_off[i] = (unsigned)(grow[i] * 32 + (q & 1) * 16 + (long)(q >> 1) * R * 32);      // unit-blocked by 16: [u / 16][R][16] bf16
+    e_off[i] = (unsigned)(grow[i] * 64 + q * 16);                                       // column-blocked by 32
+    h_off[i] = (unsigned)(grow[i] * (H * 2) + q * 16);                                  // row-major [R][512] bf16 (HN16, dgh)
+    d_off[i] = (unsigned)(grow[i] * (3 * H * 2) + q * 16);                              // row-major [R][1536] bf16 (dgi)
+  }
+  // acc[M tile][unit tile]: the accumulators of the products START each step at the carry dh (x) z the cells left in them (same lane
+  // layout: a cell's carry is its own accumulator element) -- d = carry + dgh . W_hh comes out of the MFMAs, and the carry costs no
+  // registers of its own (it took 128 KB of LDS in the 4-wave kernel, 64 registers in the first version of this one: 118 spills)
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // this wave's 4 tiles of W_hh^T through a buffer descriptor: tile j, k-block kb at byte (j * KT + kb) * 1024 + lane * 16 -- a scalar
+  // offset per fragment and ONE lane register (flat addresses: hipcc hoists the 192 lane addresses of a step out of the step loop, 280 spills)
+  const __amdgpu_buffer_rsrc_t rs_w = nr::rsrc(a.wt + (long)(wave * 4) * KT * 64, 4L * KT * 1024);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const unsigned plane = (unsigned)(RH * 2);
+  bool first = true;                                                     // no later step has handed a dgh over yet
+
+  for (int s = s_top; s >= (a.dh0 ? -1 : 0); s--) {
+    const __bf16* scr = sc + ((s + 1) & 1) * (SCR_CH * ROWS * 8);        // dgh_{s+1} chunks 144 .. 191, written one iteration ago
+    __bf16* scw = sc + (s & 1) * (SCR_CH * ROWS * 8);
+    // (the operands of the first two cell items are requested inside the LAST two k-blocks of the products, as the weight ring drains: in
+    // front of the products they would be 48 more live registers for the whole k-loop -- 484 spills)
+    struct Ops { u4v g[4]; u4v ex; u4v hp; };
+    Ops ops[2];                                                          // (a ring of 3 -- two items ahead -- spills: 866 vs 810 us)
+    const __amdgpu_buffer_rsrc_t rs_g = nr::rsrc(a.gates + (long)(s < 0 ? 0 : s) * 4 * RH, 4L * RH * 2);
+    const __amdgpu_buffer_rsrc_t rs_e = nr::rsrc(a.ext, (long)T * RH * 2);
+    const __amdgpu_buffer_rsrc_t rs_h = nr::rsrc(a.HN16 + (long)(s < 0 ? 0 : s) * RH, RH * 2);
+    auto ldops = [&](Ops& o, int it) {
+      const int pr = it >> 2, i = it & 3;
+      if constexpr (ABL & 4) return;
+      const unsigned ut = (unsigned)(wave * 4 + pr * 2);                  // first unit tile of the item (scalar)
+#pragma unroll
+      for (int p = 0; p < 4; p++) o.g[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, g_off[i], (unsigned)p * plane + ut * (unsigned)(R * 32), 2);
+      o.ex = __builtin_amdgcn_raw_buffer_load_b128(rs_e, e_off[i], (unsigned)(((long)(ut >> 1) * ((long)T * R) + (long)s * R) * 64), 2);
+      o.hp = __builtin_amdgcn_raw_buffer_load_b128(rs_h, h_off[i], ut * 32u, 0);
+    };
+    if ((first || (ABL & 2)) && s >= 0) { ldops(ops[0], 0); ldops(ops[1], 1); }
+    const __amdgpu_buffer_rsrc_t rs_scr = nr::rsrc(scr, (long)SCR_CH * ROWS * 16);
+    const __amdgpu_buffer_rsrc_t rs_di = nr::rsrc(a.dgi + (long)(s < 0 ? 0 : s) * R3H, R3H * 2), rs_dh = nr::rsrc(a.dgh + (long)(s < 0 ? 0 : s) * RH, RH * 2);
+    if (!first && !(ABL & 2)) {
+      // ---- dh = dgh_{s+1} . W_hh: 48 k-blocks, this wave's 4 unit tiles x 4 M tiles
+      bf16x8 bw[DW][4], aw[2][4];
+      auto ldw = [&](int kb) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) bw[kb % DW][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane16, (unsigned)((j * KT + kb) * 1024), 0));
+      };
+      auto lda_ = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          if (kb < KL) aw[kb & 1][i] = *reinterpret_cast<const bf16x8*>(bsm + (((kb * 4 + q) * ROWS) + i * 16 + rl) * 16);
+          else aw[kb & 1][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_scr, (unsigned)((q * ROWS + i * 16 + rl) * 16), (unsigned)((kb - KL) * 4 * ROWS * 16), 0));
+        }
+      };
+#pragma unroll
+      for (int kb = 0; kb < DW - 1; kb++) ldw(kb);
+      lda_(0);
+#pragma unroll
+      for (int kb = 0; kb < KT; kb++) {
+        if (kb + DW - 1 < KT) ldw(kb + DW - 1);
+        if (kb + 1 < KT) lda_(kb + 1);
+        if (kb == KT - 2 && s >= 0) ldops(ops[0], 0);
+        if (kb == KT - 1 && s >= 0) ldops(ops[1], 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[kb % DW][j], aw[kb & 1][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    lds_barrier();                                                        // every wave is done with dgh_{s+1} in LDS: the cells may overwrite it
+    first = false;
+    // ---- cells: 8 items of 16 rows x 32 units, MFMA lane layout
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int pr = it >> 2, i = it & 3;
+      const int u = (wave * 4 + pr * 2) * 16 + q * 8;
+      if (s < 0) {                                                        // dh0 = carry + dgh_0 . W_hh
+        if (ok[i]) {
+          float* p = a.dh0 + grow[i] * H + u;
+          *reinterpret_cast<f32x4*>(p) = acc[i][2 * pr];
+          *reinterpret_cast<f32x4*>(p + 4) = acc[i][2 * pr + 1];
+        }
+        continue;
+      }
+      Ops& o = ops[it & 1];
+      // two halves of 4 units (half the live values: the wave carries 128 registers of accumulators and carry through this loop)
+      u4v pr_, pz_, pn_, pq_;
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++) {
+        float dr[4], dzz[4], dn[4], dnr[4];
+        f4v cz;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; e4++) {
+          const int e = 4 * hf + e4;
+          const float gr = bfv(o.g[0], e), gz = bfv(o.g[1], e), gn = bfv(o.g[2], e), gh = bfv(o.g[3], e), hp = bfv(o.hp, e);
+          const float d = acc[i][2 * pr + hf][e4] + bfv(o.ex, e);
+          dn[e4] = d * (1.0f - gz) * (1.0f - gn * gn);
+          dzz[e4] = d * (hp - gn) * gz * (1.0f - gz);
+          dr[e4] = dn[e4] * gh * gr * (1.0f - gr);
+          dnr[e4] = dn[e4] * gr;
+          cz[e4] = d * gz;
+        }
+        asm volatile("" : "+v"(cz));                                     // (4-register tuples: scalar pieces fragment the register file)
+        acc[i][2 * pr + hf] = f32x4{cz[0], cz[1], cz[2], cz[3]};
+        pr_[2 * hf] = pk2b(dr[0], dr[1]); pr_[2 * hf + 1] = pk2b(dr[2], dr[3]);
+        pz_[2 * hf] = pk2b(dzz[0], dzz[1]); pz_[2 * hf + 1] = pk2b(dzz[2], dzz[3]);
+        pn_[2 * hf] = pk2b(dn[0], dn[1]); pn_[2 * hf + 1] = pk2b(dn[2], dn[3]);
+        pq_[2 * hf] = pk2b(dnr[0], dnr[1]); pq_[2 * hf + 1] = pk2b(dnr[2], dnr[3]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (it + 2 < 8) ldops(ops[it & 1], it + 2);                          // (this item's operands are consumed: request the one after next)
+      // the next step's A operand: chunk (gate * 512 + u) / 8 of this row -- LDS for chunks 0 .. 143, the scratch beyond
+      const int row = i * 16 + rl, ch = u >> 3;
+      *reinterpret_cast<u4v*>(bsm + ((ch * ROWS) + row) * 16) = pr_;
+      *reinterpret_cast<u4v*>(bsm + (((64 + ch) * ROWS) + row) * 16) = pz_;
+      if (128 + ch < KL * 4) *reinterpret_cast<u4v*>(bsm + (((128 + ch) * ROWS) + row) * 16) = pq_;
+      else *reinterpret_cast<u4v*>(scw + ((long)(128 + ch - KL * 4) * ROWS + row) * 8) = pq_;
+      if (ok[i] && !(ABL & 4)) {
+        const unsigned so = (unsigned)((wave * 4 + pr * 2) * 32);
+        __builtin_amdgcn_raw_buffer_store_b128(pr_, rs_di, d_off[i], so, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(pz_, rs_di, d_off[i], so + H * 2, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(pn_, rs_di, d_off[i], so + 2 * H * 2, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(pq_, rs_dh, h_off[i], so, 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                                      // dgh_s complete (LDS and scratch) before the next products
+  }
+}
+
+}  // namespace nb
+}  // namespace ptv
+
+extern "C" int ptv_notes_bwd8(const void* wt, const void* HN16, const void* gates, const void* ext, void* dgi, void* dgh, float* dh0, void* scratch,
+                              long R, int T, int* top_step, void* stream) {
+  if (!wt || !HN16 || !gates || !ext || !dgi || !dgh || !scratch || R <= 0 || (T & 0xff) <= 0) return PTV_ERR_ARG;
+  nb::Args a{(const bf16x8*)wt, (const __bf16*)HN16, (const __bf16*)gates, (const __bf16*)ext, (__bf16*)dgi, (__bf16*)dgh, dh0, (__bf16*)scratch,
+             top_step, (int)R, T & 0xff, g_zero_skip};
+  const int abl = (T >> 8) & 6;
+  const int pi = prof::want(4, (int)R, 512) ? prof::begin((hipStream_t)stream) : -1;
+  const dim3 grid((unsigned)((R + nb::ROWS - 1) / nb::ROWS));
+#define NB_LAUNCH(A_)                                                                                                                   \
+  do {                                                                                                                                  \
+    static bool attr = false;                                                                                                           \
+    if (!attr) {                                                                                                                        \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(nb::notes_bwd_kernel<A_>), hipFuncAttributeMaxDynamicSharedMemorySize, nb::LDS_A) != hipSuccess) return PTV_ERR_LAUNCH; \
+      attr = true;                                                                                                                      \
+    }                                                                                                                                   \
+    hipLaunchKernelGGL(nb::notes_bwd_kernel<A_>, grid, dim3(512), nb::LDS_A, (hipStream_t)stream, a);                                   \
+  } while (0)
+  if (abl == 2) NB_LAUNCH(2); else if (abl == 4) NB_LAUNCH(4); else if (abl == 6) NB_LAUNCH(6); else NB_LAUNCH(0);
+#undef NB_LAUNCH
+  if (pi >= 0) prof::end(pi, (hipStream_t)stream, 2.0 * R * 3.0 * 512 * 512 * ((T & 0xff) - 1 + (dh0 ? 1 : 0)));
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}

@@ -65,10 +65,32 @@ def s_bwd():
          ptr(dgi), ptr(dgh_steps), ptr(dhz), ptr(dh0), 0, FL | 64, stream_ptr())
 
 
+def p_bwd4():
+    call('ptv_notes_bwd_variant', 0)
+    p_bwd()
+    call('ptv_notes_bwd_variant', 1)
+
+
+# the two BPTT kernels against each other (same operands): dgi / dgh / dh0
+p_fwd(); p_bwd(); torch.cuda.synchronize()
+r8 = (dgi.clone(), dgh.clone(), dh0.clone())
+p_bwd4(); torch.cuda.synchronize()
+for nm, x8, x4 in zip(('dgi', 'dgh', 'dh0'), r8, (dgi, dgh, dh0)):
+    d = (x8.float() - x4.float()).abs()
+    print('BPTT 8-wave vs 4-wave  %-4s max |d| %.3e  (max |x| %.3e)  differing %.3f %%' % (nm, d.max().item(), x4.float().abs().max().item(), 100.0 * (d > 0).float().mean().item()))
+
 for name, fn in (('forward  per-step kernels + token product', s_fwd), ('forward  persistent', p_fwd),
-                 ('backward per-step kernels', s_bwd), ('backward persistent', p_bwd)):
+                 ('backward per-step kernels', s_bwd), ('backward persistent (8 waves)', p_bwd), ('backward persistent (4 waves)', p_bwd4),
+                 ('backward persistent (8 waves)', p_bwd)):
     t = timeit(fn)
     print('R=%d T=%d  %-42s %8.1f us  (%.1f us per step)' % (R, T, name, t, t / T), flush=True)
+
+if os.environ.get('ABL'):
+    def p_bwd_abl(bits):
+        call('ptv_notes_gru_persist_bwd', ptr(wt), ptr(HN16), ptr(gates), ptr(ext_b), ptr(dgi), ptr(dgh), ptr(dh0), ptr(scratch), R, T | (bits << 8), None, stream_ptr())
+    for bits, what in ((2, 'no products'), (4, 'no cell loads / stores'), (6, 'neither')):
+        t = timeit(lambda: p_bwd_abl(bits))
+        print('R=%d T=%d  BPTT 8 waves, ABLATION %-28s %8.1f us  (%.1f us per step)' % (R, T, what, t, t / T), flush=True)
 
 for name, dbg in (('fwd persistent: default', 0), ('fwd persistent: no stagger of pass / k order', 8)):
     def f(dbg=dbg):

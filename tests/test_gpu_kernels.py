@@ -511,6 +511,18 @@ def test_notes_gru_persistent_kernels_vs_step_kernels_and_oracle(R, T, zero_from
     scratch = torch.empty(lib().ptv_notes_gru_persist_scratch_elems(R), device=dev, dtype=bf)
     ext_blocked = Wd['ext'].view(T * R, H // 32, 32).permute(1, 0, 2).contiguous()        # the [T*R][H] matrix as ptv_gemm writes it with dtypes bit 3
     call('ptv_notes_gru_persist_bwd', ptr(wt), ptr(HN16), ptr(gates), ptr(ext_blocked), ptr(dgi), ptr(dgh), ptr(dh0), ptr(scratch), R, T, None, stream_ptr())
+    # (the 4-wave BPTT kernel of rounds 2-4 behind the same entry point: same results to the rounding of a re-associated fp32 sum)
+    dgi4, dgh4, dh04 = torch.zeros_like(dgi), torch.zeros_like(dgh), torch.zeros_like(dh0)
+    call('ptv_notes_bwd_variant', 0)
+    try:
+        call('ptv_notes_gru_persist_bwd', ptr(wt), ptr(HN16), ptr(gates), ptr(ext_blocked), ptr(dgi4), ptr(dgh4), ptr(dh04), ptr(scratch), R, T, None,
+             stream_ptr())
+        torch.cuda.synchronize()
+    finally:
+        call('ptv_notes_bwd_variant', 1)
+    assert (dgi.float() - dgi4.float()).abs().max() < 1e-2 * max(1.0, dgi4.float().abs().max().item())
+    assert (dgh.float() - dgh4.float()).abs().max() < 1e-2 * max(1.0, dgh4.float().abs().max().item())
+    assert (dh0 - dh04).abs().max() < 2e-3 * max(1.0, dh04.abs().max().item())
     # ---- the per-step kernels on the same operands
     GT = F_.gemm(Wd['emb'].view(T * R, E), Wd['w_tok'].to(bf), prec=1, out_dtype=bf)
     HN2 = torch.zeros(T + 1, R, H, device=dev); HN2[0] = HN0
