@@ -271,7 +271,7 @@ def extras(dev, B, rank):
 def _roofline(lib, B, model, args, ms_per_step=None):
     """roofline of the dominant kernels, measured live (HIP events on the launch stream, ptv_prof_*): the notes GRU of the
     teacher-forced decoder as ONE row-partitioned launch per direction of time -- forward with wave roles (csrc/notes_roles.hip, tag 3),
-    BPTT (csrc/notes_persist.hip, tag 4).  Algorithmic bytes per launch (DESIGN.md section 4, R = 32*B rows, H = 512, E = 128, T = 15):
+    BPTT with 8 waves per workgroup (csrc/notes_roles.hip, tag 4).  Algorithmic bytes per launch (DESIGN.md section 4, R = 32*B rows, H = 512, E = 128, T = 15):
       fwd  per step: GC bf16 R*3H*2 (hoisted input part) + fed token fp32 R*E*4 read; state bf16 R*H*2 and the four saved gate planes
            bf16 4*R*H*2 written (round 5: the fp32 state stays in registers -- no per-step fp32 state store + read-back); once: W_hh and
            W_ih[:, Ht:] bf16, b_hh, the initial state.  min_bytes = the same without the gate planes (what a forward that saved
@@ -304,7 +304,7 @@ def _roofline(lib, B, model, args, ms_per_step=None):
 
     kernels = [(3, 'notes_fwd_kernel', fwd_bytes, fwd_min)]
     if not F_.ZERO_SKIP:                                    # with the zero-skip on, the BPTT launch moves a data-dependent share of
-        kernels.insert(0, (4, 'row_gru_bwd_kernel<512>', bwd_bytes, bwd_bytes))   # these bytes (late note steps without gradient are passed over)
+        kernels.insert(0, (4, 'notes_bwd_kernel', bwd_bytes, bwd_bytes))   # these bytes (late note steps without gradient are passed over)
     for tag, name, nbytes, nmin in kernels:
         cnt, ms, fl = read(tag)
         if cnt == 0:

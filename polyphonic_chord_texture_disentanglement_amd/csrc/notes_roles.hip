@@ -525,6 +525,7 @@ __global__ __launch_bounds__(512, 2) void notes_bwd_kernel(Args a) {
   for (int i = 0; i < 4; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int lds_w = ((wave * 8 + q) * ROWS + rl) * 16;                  // this lane's place in the A operand: chunk wave * 8 + q, row rl
   // this wave's 4 tiles of W_hh^T through a buffer descriptor: tile j, k-block kb at byte (j * KT + kb) * 1024 + lane * 16 -- a scalar
   // offset per fragment and ONE lane register (flat addresses: hipcc hoists the 192 lane addresses of a step out of the step loop, 280 spills)
   const __amdgpu_buffer_rsrc_t rs_w = nr::rsrc(a.wt + (long)(wave * 4) * KT * 64, 4L * KT * 1024);
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(512, 2) void notes_bwd_kernel(Args a) {
       o.hp = __builtin_amdgcn_raw_buffer_load_b128(rs_h, h_off[i], ut * 32u, 0);
     };
     if ((first || (ABL & 2)) && s >= 0) { ldops(ops[0], 0); ldops(ops[1], 1); }
-    const __amdgpu_buffer_rsrc_t rs_scr = nr::rsrc(scr, (long)SCR_CH * ROWS * 16);
+    const __amdgpu_buffer_rsrc_t rs_scr = nr::rsrc(scr, (long)SCR_CH * ROWS * 16), rs_scw = nr::rsrc(scw, (long)SCR_CH * ROWS * 16);
     const __amdgpu_buffer_rsrc_t rs_di = nr::rsrc(a.dgi + (long)(s < 0 ? 0 : s) * R3H, R3H * 2), rs_dh = nr::rsrc(a.dgh + (long)(s < 0 ? 0 : s) * RH, RH * 2);
     if (!first && !(ABL & 2)) {
       // ---- dh = dgh_{s+1} . W_hh: 48 k-blocks, this wave's 4 unit tiles x 4 M tiles
@@ -628,11 +629,13 @@ __global__ __launch_bounds__(512, 2) void notes_bwd_kernel(Args a) {
       }
       if (it + 2 < 8) ldops(ops[it & 1], it + 2);                          // (this item's operands are consumed: request the one after next)
       // the next step's A operand: chunk (gate * 512 + u) / 8 of this row -- LDS for chunks 0 .. 143, the scratch beyond
-      const int row = i * 16 + rl, ch = u >> 3;
-      *reinterpret_cast<u4v*>(bsm + ((ch * ROWS) + row) * 16) = pr_;
-      *reinterpret_cast<u4v*>(bsm + (((64 + ch) * ROWS) + row) * 16) = pz_;
-      if (128 + ch < KL * 4) *reinterpret_cast<u4v*>(bsm + (((128 + ch) * ROWS) + row) * 16) = pq_;
-      else *reinterpret_cast<u4v*>(scw + ((long)(128 + ch - KL * 4) * ROWS + row) * 8) = pq_;
+      // (chunk = wave * 8 + pr * 4 + q, row = i * 16 + rl: ONE lane address per gate, the item's part is an immediate; the dn (x) r chunks of
+      // waves 2 .. 7 lie beyond the LDS-resident 144)
+      char* la = bsm + lds_w + (pr * 4 * ROWS + i * 16) * 16;
+      *reinterpret_cast<u4v*>(la) = pr_;
+      *reinterpret_cast<u4v*>(la + 64 * ROWS * 16) = pz_;
+      if (wave < 2) *reinterpret_cast<u4v*>(la + 128 * ROWS * 16) = pq_;
+      else __builtin_amdgcn_raw_buffer_store_b128(pq_, rs_scw, (unsigned)((q * ROWS + rl) * 16), (unsigned)(((wave * 8 + pr * 4 - 16) * ROWS + i * 16) * 16), 0);
       if (ok[i] && !(ABL & 4)) {
         const unsigned so = (unsigned)((wave * 4 + pr * 2) * 32);
         __builtin_amdgcn_raw_buffer_store_b128(pr_, rs_di, d_off[i], so, 2);

@@ -19,7 +19,7 @@ for f in glob.glob('%s/*_counter_collection.csv' % d):
 kern = collections.defaultdict(dict)
 for (k, c), v in per.items():
     kern[k][c] = (sum(v.values()) / len(v), len(v))
-short = lambda n: re.sub(r'\(.*', '', n.replace('void ptv::', '').replace('ptv::', '').replace('nr::', ''))
+short = lambda n: re.sub(r'\(.*', '', n.replace('void ptv::', '').replace('ptv::', '').replace('nr::', '').replace('nb::', ''))
 res = []
 for k, v in kern.items():
     g = lambda c: v.get(c, (0.0, 0))[0]
@@ -32,7 +32,7 @@ res.sort(key=lambda r: -r['hbm_bytes_per_launch'] * max(1, r['launches']))
 json.dump(res, open('%s/pmc_by_kernel.json' % d, 'w'), indent=1)
 pick = {}
 for r in res:
-    for name in ('row_gru_bwd_kernel<512>', 'notes_fwd_kernel', 'row_gru_bwd_kernel<128>', 'row_gru_fwd_kernel<128>', 'wgrad_dma_kernel', 'pgru_bwd_sk_kernel<2'):
+    for name in ('notes_bwd_kernel', 'notes_fwd_kernel', 'row_gru_bwd_kernel<128>', 'row_gru_fwd_kernel<128>', 'wgrad_dma_kernel', 'pgru_bwd_sk_kernel<2'):
         if r['kernel'].startswith(name[:-1] if name.endswith('>') else name):          # 'row_gru_bwd_kernel<512' matches the <512, false> instantiation; 'nr::notes_fwd_kernel' below
             pick[name] = {k: r[k] for k in ('launches', 'read_bytes_per_launch', 'write_bytes_per_launch', 'hbm_bytes_per_launch', 'mfma_busy_frac')}
 import subprocess
