@@ -492,10 +492,12 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     lib.ptv_prof_enable(0)
-    if rank == 0 and args.mode == 'train' and args.tfr >= 1.0:
+    if args.mode == 'train' and args.tfr >= 1.0:
         # the families of roofline.also (tags 5, 6: ~45 event pairs per step on the sibling streams) are timed over three EXTRA steps
-        # outside the timed region, so that their bookkeeping cannot touch the headline
-        lib.ptv_prof_enable(16 | 32)
+        # outside the timed region, so that their bookkeeping cannot touch the headline.  EVERY rank runs them (a step holds the
+        # gradient exchange: rank 0 alone would wait for its peers forever); only rank 0 keeps the events.
+        if rank == 0:
+            lib.ptv_prof_enable(16 | 32)
         for i in range(3):
             step(args.warmup + args.steps + i)
         torch.cuda.synchronize()
