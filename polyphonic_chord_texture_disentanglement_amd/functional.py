@@ -584,10 +584,14 @@ class Side:
         self.keep = []
         self.used = False
 
-    def __call__(self, fn, *keep):
+    def __call__(self, fn, *keep, after=None):
+        """after: an event -- the sibling waits for IT instead of for everything the parent has queued so far"""
         if not OVERLAP:
             return fn()
-        wait_stream(self.s, self.main)
+        if after is not None:
+            wait_event(self.s, after)
+        else:
+            wait_stream(self.s, self.main)
         self.used = True
         self.keep.extend(keep)
         depth = 0 if self.chain else 1
@@ -880,12 +884,31 @@ class EmbedFn(torch.autograd.Function):
         x, w, b = ctx.saved_tensors
         B, E = x.shape[0], w.shape[0]
         S, N, P, D, _pad = ctx.geom
+        slot = _EMB_FAMILY.pop(demb.data_ptr(), None)
         demb2 = demb.contiguous().view(B * S * N, E)
         if ctx.mh is not None:
-            wait_event(cur_stream(), ctx.mh_side)
-            mh, ctx.mh, ctx.mh_side = ctx.mh, None, None
-            dw, db = wgrad_bias(demb2, mh[:, :P + D], _gbuf(w), _gbuf(b), ctx.prec)      # bias gradient inside the same pass over dy
+            mh, ev_mh, ctx.mh, ctx.mh_side = ctx.mh, ctx.mh_side, None, None
+
+            def product():
+                wait_event(cur_stream(), ev_mh)
+                return wgrad_bias(demb2, mh[:, :P + D], _gbuf(w), _gbuf(b), ctx.prec)     # bias gradient inside the same pass over dy
+            from .optim import is_arena_view
+            if slot is not None and demb.is_contiguous() and w.grad is None and b.grad is None:
+                # the gradient was produced by the note-summary family on a pool stream: the product queues behind it THERE (same slot =
+                # same stream: ordered) and joins with it when the backward pass ends
+                fam = Side(slot)
+                dw, db = fam(product, demb, demb2, mh, x, w, b, after=ev_mh)
+                if is_arena_view(w, dw) and is_arena_view(b, db):
+                    fam.defer()
+                else:
+                    fam.join()
+                return None, dw, db, None, None
+            if slot is not None:
+                wait_stream(cur_stream(), _CHILD_STREAMS[('pool', cur_stream().device.index, slot % 4)])
+            dw, db = product()
             return None, dw, db, None, None
+        if slot is not None:
+            wait_stream(cur_stream(), _CHILD_STREAMS[('pool', cur_stream().device.index, slot % 4)])
         ld = (P + D + 7) // 8 * 8
         mh = _empty(B * S * N, ld, dev=w.device)
         call('ptv_multihot_geom', ptr(x), ptr(mh), ld, B, S, N, P, D, 0, stream_ptr())
@@ -966,7 +989,7 @@ def _bigru_forward(prec, x3, lengths, w):
     return out, [fwd, rev]
 
 
-def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None):
+def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None, rev_slot=None):
     """-> ([dw_ih, dw_hh, db_ih, db_hh] x 2 directions, dx [T,M,I] or None).
     dx_acc ([T*M, I] fp32, or None): a gradient that already arrived at x3 from another consumer -- both directions' input-gradient
     products ACCUMULATE into it and it is returned as dx (round 4: autograd used to add the two consumers' 134-MB gradients of the note
@@ -1009,7 +1032,7 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None):
             late['dgi'], late['top'] = dgi2, top
         return [dw_ih, dw_hh, db_ih, db_hh], (dx_of(0, dgi2, top, True) if (d == 0 and with_dx) else None)
 
-    side = Side(BIGRU_SLOT_BWD)
+    side = Side(BIGRU_SLOT_BWD if rev_slot is None else rev_slot)
     wts = [_WT(w[1], prec), _WT(w[5], prec)]
     adt = _act_dtype(prec, H)
     if (T >= 2 and adt == BF16 and wts[0] is not None and wts[1] is not None and saved[0][1].dtype == BF16
@@ -1062,6 +1085,16 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None):
 # its own input-gradient products into that buffer and returns it as the one gradient of the embedding.
 _EMB_LINK = {}
 EMB_LINK = True
+# The note-summary BPTT as a stream family of its own (BiGruFinalFn.backward): pool slot, or -1 = on the stream autograd gives the node.
+# Round 5, same-box A/B (profiles/r05_ab_runs.txt): the family starts 0.4 ms earlier (at the decoder node's event instead of behind the
+# chord decoder's join and the reparametrisation node, which autograd happens to run first) and the tail after dec_bwd:end shrinks from
+# 2.65 to 2.3 ms in the trace marks -- but the STEP gets slower, 7.73-7.94 against 7.62-7.65 ms for every placement of its two
+# directions (pool 0 / 0, 0 / 3, 0 / 2, 0 / 1): beside the summary kernels the encoders' persistent BPTTs and the deferred deep
+# products slow down by more than the earlier start buys.  Off by default; kept as the measured answer to "run the families at once".
+SUMMARY_FAMILY_SLOT = int(os.environ.get('PTV_SUMMARY_FAMILY', '-1'))
+SUMMARY_FAMILY_REV = 4
+_SUMMARY_EV = {}      # data_ptr of the decoder node's note-summary gradient -> event after which it is final
+_EMB_FAMILY = {}      # data_ptr of the embedding gradient the family produced -> its pool slot (EmbedFn.backward queues behind it)
 
 
 def emb_link_arm(emb):
@@ -1091,14 +1124,42 @@ class BiGruFinalFn(torch.autograd.Function):
         if ctx.link is not None and ctx.link['demb'] is not None and ctx.needs_input_grad[0]:
             dx_acc, ctx.link['demb'] = ctx.link['demb'].view(-1, x3.shape[2]), None     # the decoder node's gradient of the same tensor
             _EMB_LINK.pop(x3.data_ptr(), None)
-        grads, dx = _bigru_backward(ctx.prec, x3, w, ctx.saved_state, dout.contiguous(), ctx.needs_input_grad[0], dx_acc)
+        from .optim import is_arena_view
+        ev = _SUMMARY_EV.pop(dout.data_ptr(), None)
+        if ev is not None and (dx_acc is None or not dout.is_contiguous()):
+            ev = None               # (only in the train step's own structure: the decoder node parked its embedding gradient with this node)
+        fam = None
+        if ev is not None:
+            # The note-summary BPTT (the decoder node produced `dout`): a family of its own.  Autograd runs this node on the stream of
+            # its forward -- the one the chord encoder's BPTT will want next -- and behind whatever the pass queued there since; the
+            # family instead takes a pool stream that is free by now (the chord decoder's), starts from the decoder node's event and
+            # is joined when the backward pass ends: it ends in parameter gradients and the embedding's (EmbedFn follows it there).
+            fam = Side(SUMMARY_FAMILY_SLOT)
+            state = ctx.saved_state
+            grads, dx = fam(lambda: _bigru_backward(ctx.prec, x3, w, state, dout, ctx.needs_input_grad[0], dx_acc, SUMMARY_FAMILY_REV),
+                            x3, dout, dx_acc, state, *w, after=ev)
+        else:
+            grads, dx = _bigru_backward(ctx.prec, x3, w, ctx.saved_state, dout.contiguous(), ctx.needs_input_grad[0], dx_acc)
         mark('bigru_bwd:end M=%d @%x' % (x3.shape[1], stream_ptr() & 0xffff))
         ctx.saved_state = None
-        from .optim import is_arena_view
         # (w is ordered by direction, the products return [ih, hh, b_ih, b_hh] per direction)
         pairs = list(zip(w[0:4], grads[0:4])) + list(zip(w[4:8], grads[4:8]))
-        if GRAD_READY_HOOK is not None and all(p_.grad is None and is_arena_view(p_, g_) for p_, g_ in pairs):
-            GRAD_READY_HOOK([p_ for p_, _ in pairs], ())        # data parallel: a bi-GRU's 8 gradients are final (all queued on this stream)
+        adopted = all(p_.grad is None and is_arena_view(p_, g_) for p_, g_ in pairs)
+        if fam is not None:
+            streams = (fam.s,)
+            if adopted:
+                fam.defer()
+                if dx is not None:
+                    if len(_EMB_FAMILY) > 8:
+                        _EMB_FAMILY.clear()
+                    _EMB_FAMILY[dx.data_ptr()] = SUMMARY_FAMILY_SLOT
+            else:
+                fam.join()
+                streams = ()
+        else:
+            streams = ()
+        if GRAD_READY_HOOK is not None and adopted:
+            GRAD_READY_HOOK([p_ for p_, _ in pairs], streams)   # data parallel: a bi-GRU's 8 gradients are final once these streams drain
         return (dx, None, None) + tuple(grads)
 
 
@@ -1606,6 +1667,10 @@ class DecoderTFFn(torch.autograd.Function):
         else:
             side.join()
         B, He = st['B'], st['He']
+        if st.get('ev_dtoks') is not None:
+            if len(_SUMMARY_EV) > 8:
+                _SUMMARY_EV.clear()
+            _SUMMARY_EV[dTOKS[1:].data_ptr()] = st['ev_dtoks']
         demb_out = demb.view(16, 32, B, E)
         if ctx.emb_link is not None and ctx.needs_input_grad[2] and demb.dtype == F32 and demb.is_contiguous():
             ctx.emb_link['demb'] = demb                   # the summary node accumulates into it and returns it (BiGruFinalFn.backward)
@@ -1826,6 +1891,9 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     dTOKS = _empty(33, B, 2 * He, dev=dev)
     dTOKS[32].zero_()
     gemm_dx(dgi_t.view(R, 3 * Ht), w_ih_t, slice(0, 2 * He), out=dTOKS[:32].view(R, 2 * He), prec=prec)
+    # (the note-summary node's two inputs -- this gradient and, queued earlier on this stream, the parked embedding gradient -- are final
+    # HERE: its BPTT family starts from this event, not from the end of whatever else the step has queued by then)
+    st['ev_dtoks'] = record_event() if SUMMARY_FAMILY_SLOT >= 0 and OVERLAP else None
     w_zh, w_zi = W['z2dec_hid_linear.weight'], W['z2dec_in_linear.weight']
     dz = gemm_dx(dzhid, w_zh, prec=prec)
     gemm_dx(dz_in, w_zi, out=dz, acc=True, prec=prec)
