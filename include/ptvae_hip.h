@@ -573,6 +573,23 @@ long ptv_row_gru_persist_scratch_elems(int H, long R);
 int ptv_row_gru_persist_bwd(int H, const void* wt, const void* HN, const void* gates, const void* ext,
                             const float* dh_last, long last_ld, const int* lengths, void* dgi, void* dgh, float* dh0,
                             void* scratch, long R, int T, int reverse, int* top_step, void* stream);
+/* The same with a ROW PERMUTATION (H = 128): panel position p works on row perm[p] of x / lengths / out (forward) and of dh_last / lengths
+ * / dgi (backward); the kernels' private tensors HN / HN16 / gates and dgh are indexed by position (dgh pairs with HN16[:T], dgi with x in
+ * the weight-gradient products, as before).  With perm = ptv_rows_by_length(lengths) a 64-row panel holds rows of (almost) one length, so
+ * the passing-over of a panel's masked steps -- what pack_padded_sequence does for the reference, ptvae.py:446-453 -- removes the masked
+ * work itself instead of only the steps beyond the LONGEST of 64 unrelated rows.  perm NULL = the entry points above.  dh0 unsupported. */
+int ptv_row_gru_persist_fwd_perm(int H, const void* w_hh, const void* w_x, const float* b_hh, const float* b_ih, const void* gc,
+                                 const float* x, long x_step, const int* lengths, const int* perm, float* HN, void* HN16,
+                                 void* gates, float* out, long out_ld, long R, int T, int reverse, void* stream);
+int ptv_row_gru_persist_bwd_perm(int H, const void* wt, const void* HN, const void* gates, const void* ext,
+                                 const float* dh_last, long last_ld, const int* lengths, const int* perm, void* dgi, void* dgh,
+                                 float* dh0, void* scratch, long R, int T, int reverse, int* top_step, void* stream);
+/* perm [R] = the rows in order of DESCENDING lengths[row] (0 <= length <= max_len <= 38), ties in row order: a stable counting sort in one
+ * workgroup (deterministic: the order of the K rows of the weight-gradient products depends on it) */
+int ptv_rows_by_length(const int* lengths, int* perm, long R, int max_len, void* stream);
+/* launches with perm and at least two panels per CU: two panels per workgroup -- workgroup b runs panel b, then panel G-1-b, a long one
+ * and a short one, so that the launch is not as long as its longest panel (1, default) / one panel per workgroup (0) */
+int ptv_row_gru_pair(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * clip_grad_norm_ (module.py:142-143) + torch.optim.Adam.step (train.py:50, scheduler.py:69-74) over

@@ -18,7 +18,7 @@ _PREC = {'fp32': PREC_F32, 'f32': PREC_F32, 'bf16': PREC_BF16, 0: 0, 1: 1}
 _lib = None
 # the C ABI this Python package was written against (csrc/version.hip): the .so is a built artefact that ships beside the sources, and a
 # stale one would load without error and silently change argument contracts (round-4 advice: counts[3] of ptv_pianotree_targets)
-EXPECTED_ABI = 4
+EXPECTED_ABI = 5
 
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'ptvae_hip.h')
 

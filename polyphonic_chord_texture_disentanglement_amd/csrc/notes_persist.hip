@@ -103,25 +103,22 @@ struct RowGruFwdArgs {
   int R, T, reverse, dbg;
   int skip;                        // pass over the steps beyond the longest row of the panel (EMB with lengths)
   int prio;                        // EMB: raised wave priority (the launch is part of a latency chain)
+  const int* perm;                 // EMB, or null: panel position p works on row perm[p] of x / lengths / out (rows sorted by length: a panel's
+                                   // longest row is then close to all of its rows); HN / HN16 / gates are indexed by POSITION
 };
 
 // EMB = false: the notes GRU (hoisted input part gc, b_ih folded in, no mask, no final-state output); EMB = true: a direction of
 // dec_notes_emb_gru (b_ih, optional length mask, optional reversed time, final state)
 template <int H, bool EMB>
-__global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
-  // a launch of the latency chain wins instruction issue against sibling-stream products.  The ground-truth note summaries (EMB) are
-  // NOT on the chain when they run beside the encoders at the head of the step (their consumer is the time GRU, after the encoders):
-  // there the caller's priority state decides (ptv_gemm_priority, 0 inside a side-stream call)
-  if (!EMB || a.prio) __builtin_amdgcn_s_setprio(3);
+__device__ __forceinline__ void row_gru_fwd_body(const RowGruFwdArgs& a, const long panel, char* nsm) {
   constexpr int KBH = H / 32, NUT = H / 16, NPASS = H / 128, UTW = NUT / 4, HLD = H + 16, KT = KBH + 4;
-  extern __shared__ __attribute__((aligned(16))) char nsm[];
   __bf16* h16 = reinterpret_cast<__bf16*>(nsm);                          // [2][64][HLD]
   __bf16* tok16 = h16 + 2 * NRP * HLD;                                   // [64][NT16LD]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rl = lane & 15, kq = (lane >> 4) * 8;                        // fragment coordinates
   const int erow = lane & 15, eq = lane >> 4;                            // epilogue coordinates = the MFMA C layout (pair-interleaved tiles)
   const long R = a.R;
-  const long r0 = (long)blockIdx.x * NRP;
+  const long r0 = panel * NRP;
   const long RH = R * H;
 
   // ---- initial state: bf16 operand copy -> LDS and HN16 slot 0
@@ -134,12 +131,18 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
     if (r0 + row < R) st_bf16x8(a.HN16 + gr * H + c8, v);
   }
   long grow[4]; bool ok[4]; int len[4];
+  long tnat[4];                                                          // the rows whose tokens this thread stages each step
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     ok[i] = r0 + i * 16 + erow < R; grow[i] = min(r0 + i * 16 + erow, R - 1);
     len[i] = 0x7fffffff;
-    if constexpr (EMB) { if (a.lengths) len[i] = a.lengths[grow[i]]; }
+    tnat[i] = min(r0 + (tid >> 4) + i * 16, R - 1);
+    if constexpr (EMB) {
+      if (a.perm) tnat[i] = a.perm[tnat[i]];
+      if (a.lengths) len[i] = a.lengths[a.perm ? (long)a.perm[grow[i]] : grow[i]];
+    }
   }
+  static_assert(NE == 128, "token staging: 16 chunks per row, 4 rows per thread");
   // EMB with lengths: a (panel, time) pair beyond the longest row of the panel is the identity for all 64 rows (the reference packs
   // the sequences, ptvae.py:446-453: on this data the mean length is 3.7 of 16 notes) -- such steps only pass the state on
   int pmax = a.T;
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
       int* misc = reinterpret_cast<int*>(tok16 + NRP * NT16LD);
       if (tid == 0) misc[0] = 0;
       __syncthreads();
-      if (tid < NRP && r0 + tid < R) atomicMax(misc, a.lengths[r0 + tid]);
+      if (tid < NRP && r0 + tid < R) atomicMax(misc, a.lengths[a.perm ? (long)a.perm[r0 + tid] : r0 + tid]);
       __syncthreads();
       pmax = min(misc[0], a.T);
     }
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
   int slot = 0, cur = 0;                                                   // HN slot holding the current fp32 state; current bf16 LDS buffer
   // workgroups of one XCD run in near lockstep and would all ask the L2 for the same few fragment lines at the same moment (a
   // handful of its 16 channels busy, the rest idle): each walks the passes and the k-blocks from its own starting point
-  const int prot = (a.dbg & 8) ? 0 : (blockIdx.x >> 3) & (NPASS - 1), krot = (a.dbg & 8) ? 0 : (((blockIdx.x >> 5) & 7) * 2) & (KBH - 1);
+  const int prot = (a.dbg & 8) ? 0 : ((int)panel >> 3) & (NPASS - 1), krot = (a.dbg & 8) ? 0 : ((((int)panel >> 5) & 7) * 2) & (KBH - 1);
 
   // inside the step loop the waves exchange through LDS only (the fp32 state a lane re-reads from HN is its own store): lds_barrier()
   // lets a step's 117 MB of state / gate stores drain under the next step's products instead of at the step boundary
@@ -184,10 +187,11 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
     const __bf16* hc = h16 + cur * NRP * HLD;
     __bf16* hn_ = h16 + nxt * NRP * HLD;
     // ---- this step's fed tokens -> LDS (bf16 MFMA operand)
-    for (int i = tid; i < NRP * (NE / 8); i += 256) {
-      const int row = i / (NE / 8), c8 = (i % (NE / 8)) * 8;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int row = (tid >> 4) + k * 16, c8 = (tid & 15) * 8;
       float v[8];
-      ld_f32x8(a.x + (long)tt * a.x_step + min(r0 + row, R - 1) * NE + c8, v);
+      ld_f32x8(a.x + (long)tt * a.x_step + tnat[k] * NE + c8, v);
       st_bf16x8(tok16 + row * NT16LD + c8, v);
     }
     lds_barrier();
@@ -340,11 +344,24 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowG
         if (r0 + row < R) {
           float v[8];
           ld_f32x8(a.HN + (long)slot * RH + (r0 + row) * H + c8, v);
-          st_f32x8(a.out + (r0 + row) * a.out_ld + c8, v);
+          st_f32x8(a.out + (a.perm ? (long)a.perm[r0 + row] : r0 + row) * a.out_ld + c8, v);
         }
       }
     }
   }
+}
+
+template <int H, bool EMB>
+__global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_fwd_kernel(RowGruFwdArgs a) {
+  // a launch of the latency chain wins instruction issue against sibling-stream products.  The ground-truth note summaries (EMB) are
+  // NOT on the chain when they run beside the encoders at the head of the step (their consumer is the time GRU, after the encoders):
+  // there the caller's priority state decides (ptv_gemm_priority, 0 inside a side-stream call)
+  if (!EMB || a.prio) __builtin_amdgcn_s_setprio(3);
+  extern __shared__ __attribute__((aligned(16))) char nsm[];
+  // (Measured and removed, round 5: with the rows sorted by length, HALF the panels as the grid and workgroup b running panel b, then panel
+  // G-1-b -- a long one and a short one, equal work per workgroup.  The launch is latency-bound per step, not throughput-bound: twice the
+  // sequential steps per workgroup made the step 0.3 ms slower, 8.08-8.10 against 7.75-7.88 ms; profiles/r05_ab_runs.txt)
+  row_gru_fwd_body<H, EMB>(a, blockIdx.x, nsm);
 }
 
 // =============================================================================================
@@ -365,26 +382,31 @@ struct RowGruBwdArgs {
   __bf16* scratch;                 // [grid][2][3H/8 chunks][64 rows][8]: dgh of the workgroup's rows, K-blocked (A operand of the next step)
   int R, T, reverse;
   int skip;                        // pass over steps whose result is exactly zero
+  const int* perm;                 // EMB, or null: the forward's row permutation -- dh_last, lengths and dgi (operand of products against the
+                                   // forward's INPUT rows) by row perm[p], HN / gates / dgh (against the forward's states) by position p
 };
 
 // EMB = false: the notes GRU (gradient arrives at every state: ext; forward time order; dh0 wanted); EMB = true: a direction of
 // dec_notes_emb_gru (gradient arrives at the final state only: dh_last; optional reversed time)
 template <int H, bool EMB>
-__global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowGruBwdArgs a) {
-  __builtin_amdgcn_s_setprio(3);                                         // a launch of the latency chain: wins instruction issue against sibling-stream products
+__device__ __forceinline__ void row_gru_bwd_body(const RowGruBwdArgs& a, const long panel, char* nsm) {
   constexpr int KT = 3 * H / 32, NTW = H / 64, NCH = 3 * H / 8;           // k-blocks, output tiles per wave, scratch chunks
-  extern __shared__ __attribute__((aligned(16))) char nsm[];
   float* dhz = reinterpret_cast<float*>(nsm);                            // [64][H] fp32: dh (x) z carried to the earlier step
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rl = lane & 15, kqi = lane >> 4;
   const int erow = lane & 15, eq = lane >> 4;
   const long R = a.R;
-  const long r0 = (long)blockIdx.x * NRP;
+  const long r0 = panel * NRP;
   const long RH = R * H, R3H = 3 * RH;
   __bf16* sc = a.scratch + (long)blockIdx.x * 2 * (NCH * NRP * 8);
   long grow[4]; bool ok[4];
+  long gnat[4];                                                          // the same rows in the order of the forward's INPUT (EMB with perm)
 #pragma unroll
-  for (int i = 0; i < 4; i++) { ok[i] = r0 + i * 16 + erow < R; grow[i] = min(r0 + i * 16 + erow, R - 1); }
+  for (int i = 0; i < 4; i++) {
+    ok[i] = r0 + i * 16 + erow < R; grow[i] = min(r0 + i * 16 + erow, R - 1);
+    gnat[i] = grow[i];
+    if constexpr (EMB) { if (a.perm) gnat[i] = a.perm[grow[i]]; }
+  }
   int pmax = a.T;
   if constexpr (EMB) {
     if (a.lengths) {                                                     // given iff the forward skipped: must match it
@@ -394,7 +416,7 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowG
       int* misc = reinterpret_cast<int*>(dhz);
       if (tid == 0) misc[0] = 0;
       __syncthreads();
-      if (tid < NRP && r0 + tid < R) atomicMax(misc, a.lengths[r0 + tid]);
+      if (tid < NRP && r0 + tid < R) atomicMax(misc, a.lengths[a.perm ? (long)a.perm[r0 + tid] : r0 + tid]);
       __syncthreads();
       pmax = min(misc[0], a.T);
       if (a.top_step && tid == 0 && pmax > 0) atomicMax(a.top_step, pmax - 1);   // last TIME index with a live row in any panel
@@ -443,7 +465,7 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowG
           if (r0 + row < R) {
             const bf16x8 zz = {};
             *reinterpret_cast<bf16x8*>(a.dgh + (long)s * R3H + (r0 + row) * (3 * H) + c8) = zz;
-            *reinterpret_cast<bf16x8*>(a.dgi + (long)tt * R3H + (r0 + row) * (3 * H) + c8) = zz;
+            *reinterpret_cast<bf16x8*>(a.dgi + (long)tt * R3H + (a.perm ? (long)a.perm[r0 + row] : r0 + row) * (3 * H) + c8) = zz;
           }
         }
         continue;
@@ -535,7 +557,7 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowG
       float lastg[8];
 #pragma unroll
       for (int e = 0; e < 8; e++) lastg[e] = 0.f;
-      if constexpr (EMB) { if (last && a.dh_last) ld_f32x8(a.dh_last + grow[i] * a.last_ld + u, lastg); }
+      if constexpr (EMB) { if (last && a.dh_last) ld_f32x8(a.dh_last + gnat[i] * a.last_ld + u, lastg); }
       float dr[8], dz[8], dn[8], dnr[8], dq[8];
 #pragma unroll
       for (int e = 0; e < 8; e++) {
@@ -559,12 +581,19 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowG
           // forward time order: the r and z thirds of dgh ARE dgi's (same rows, same step) -- only the n third (dn * r) goes out
           stnt_bf16x8(a.dgh + (long)s * RH + grow[i] * H + u, dnr);
         }
-        __bf16* pi = a.dgi + (long)tt * R3H + grow[i] * (3 * H) + u;
+        __bf16* pi = a.dgi + (long)tt * R3H + gnat[i] * (3 * H) + u;
         stnt_bf16x8(pi, dr); stnt_bf16x8(pi + H, dz); stnt_bf16x8(pi + 2 * H, dn);
       }
     }
     __syncthreads();                                                     // scratch + dhz of this step complete before the next products
   }
+}
+
+template <int H, bool EMB>
+__global__ __launch_bounds__(256, H == 128 ? 2 : 1) void row_gru_bwd_kernel(RowGruBwdArgs a) {
+  __builtin_amdgcn_s_setprio(3);                                         // a launch of the latency chain: wins instruction issue against sibling-stream products
+  extern __shared__ __attribute__((aligned(16))) char nsm[];
+  row_gru_bwd_body<H, EMB>(a, blockIdx.x, nsm);
 }
 
 template <int H, bool EMB>
@@ -590,9 +619,65 @@ static int launch_bwd(const RowGruBwdArgs& a, hipStream_t s) {
   return PTV_OK;
 }
 
+// perm = the rows ordered by DESCENDING length, ties in row order (a stable counting sort: one workgroup, each thread owns a contiguous
+// chunk of rows; cnt[bin][thread] -> exclusive scan in (bin descending, thread ascending) order -> positions).  lengths in [0, nb - 1].
+__global__ __launch_bounds__(1024) void rows_by_length_kernel(const int* __restrict__ lengths, int* __restrict__ perm, long R, int nb) {
+  extern __shared__ int cnt[];                                           // [nb][1024] + [nb][16] wave totals + [nb] bin bases
+  int* wtot = cnt + nb * 1024;
+  int* base = wtot + nb * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long chunk = (R + 1023) / 1024, r0 = tid * chunk, r1 = min(R, r0 + chunk);
+  for (int b = 0; b < nb; b++) cnt[b * 1024 + tid] = 0;
+  for (long r = r0; r < r1; r++) cnt[min(max(lengths[r], 0), nb - 1) * 1024 + tid]++;
+  // per bin: exclusive scan over the 1024 threads (wave scan by shuffles, wave totals through LDS)
+  for (int b = 0; b < nb; b++) {
+    const int v = cnt[b * 1024 + tid];
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wtot[b * 16 + wave] = incl;
+    cnt[b * 1024 + tid] = incl - v;                                      // exclusive within the wave
+  }
+  __syncthreads();
+  if (tid < nb) {                                                        // bin tid: its waves' offsets, its total
+    int run = 0;
+    for (int w = 0; w < 16; w++) { const int t = wtot[tid * 16 + w]; wtot[tid * 16 + w] = run; run += t; }
+    base[tid] = run;
+  }
+  __syncthreads();
+  if (tid == 0) {                                                        // bins in descending order of length
+    int run = 0;
+    for (int b = nb - 1; b >= 0; b--) { const int t = base[b]; base[b] = run; run += t; }
+  }
+  __syncthreads();
+  for (long r = r0; r < r1; r++) {
+    const int b = min(max(lengths[r], 0), nb - 1);
+    const int pos = base[b] + wtot[b * 16 + wave] + cnt[b * 1024 + tid]++;
+    perm[pos] = (int)r;
+  }
+}
+
 }  // namespace ptv
 
 using namespace ptv;
+
+extern "C" int ptv_rows_by_length(const int* lengths, int* perm, long R, int max_len, void* stream) {
+  if (!lengths || !perm || R <= 0 || R > 0x7fffffffL || max_len < 0) return PTV_ERR_ARG;
+  const int nb = max_len + 1;
+  const size_t lds = (size_t)(nb * 1024 + nb * 16 + nb) * sizeof(int);
+  if (lds > 160 * 1024) return PTV_ERR_UNSUPPORTED;                       // lengths up to 38
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rows_by_length_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return PTV_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(rows_by_length_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, lengths, perm, R, nb);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
 
 extern "C" int ptv_notes_bwd8(const void* wt, const void* HN16, const void* gates, const void* ext, void* dgi, void* dgh, float* dh0, void* scratch,
                               long R, int T, int* top_step, void* stream);
@@ -600,19 +685,28 @@ extern "C" int ptv_notes_bwd8(const void* wt, const void* HN16, const void* gate
 static int g_notes_bwd8 = 1;
 extern "C" int ptv_notes_bwd_variant(int eight_waves) { g_notes_bwd8 = eight_waves ? 1 : 0; return PTV_OK; }
 
+extern "C" int ptv_row_gru_persist_fwd_perm(int H, const void* w_hh, const void* w_x, const float* b_hh, const float* b_ih, const void* gc,
+                                            const float* x, long x_step, const int* lengths, const int* perm, float* HN, void* HN16,
+                                            void* gates, float* out, long out_ld, long R, int T, int reverse, void* stream);
 extern "C" int ptv_row_gru_persist_fwd(int H, const void* w_hh, const void* w_x, const float* b_hh, const float* b_ih, const void* gc,
                                        const float* x, long x_step, const int* lengths, float* HN, void* HN16, void* gates,
                                        float* out, long out_ld, long R, int T, int reverse, void* stream) {
+  return ptv_row_gru_persist_fwd_perm(H, w_hh, w_x, b_hh, b_ih, gc, x, x_step, lengths, nullptr, HN, HN16, gates, out, out_ld, R, T, reverse, stream);
+}
+
+extern "C" int ptv_row_gru_persist_fwd_perm(int H, const void* w_hh, const void* w_x, const float* b_hh, const float* b_ih, const void* gc,
+                                            const float* x, long x_step, const int* lengths, const int* perm, float* HN, void* HN16,
+                                            void* gates, float* out, long out_ld, long R, int T, int reverse, void* stream) {
   if (!w_hh || !w_x || !b_hh || !x || !HN || !HN16 || R <= 0 || T <= 0 || (H != 512 && H != 128)) return PTV_ERR_ARG;
   if (out && (out_ld & 3)) return PTV_ERR_ARG;
   // H = 512 is the notes GRU (gc given, bias folded, dense): the wave-role kernel of notes_roles.hip; H = 128 the note-summary GRU (b_ih
   // given, mask / reverse / final state)
   if (H == 512) {
-    if (!gc || b_ih || lengths || reverse || out || x_step != R * NE) return PTV_ERR_UNSUPPORTED;
+    if (!gc || b_ih || lengths || perm || reverse || out || x_step != R * NE) return PTV_ERR_UNSUPPORTED;
     return ptv_notes_gru_persist_fwd(w_hh, w_x, b_hh, gc, x, HN, HN16, gates, R, T, stream);
   }
   RowGruFwdArgs a{(const bf16x8*)w_hh, (const bf16x8*)w_x, b_hh, b_ih, (const __bf16*)gc, x, x_step, lengths, HN, (__bf16*)HN16,
-                  (__bf16*)gates, out, out_ld, (int)R, T & 0xff, reverse, T >> 8, g_zero_skip, g_gemm_prio};
+                  (__bf16*)gates, out, out_ld, (int)R, T & 0xff, reverse, T >> 8, g_zero_skip, g_gemm_prio, perm};
   const int pi = prof::want(3, (int)R, H) ? prof::begin((hipStream_t)stream) : -1;
   if (gc || !b_ih) return PTV_ERR_UNSUPPORTED;
   PTV_TRY((launch_fwd<128, true>(a, (hipStream_t)stream)));
@@ -623,14 +717,24 @@ extern "C" int ptv_row_gru_persist_fwd(int H, const void* w_hh, const void* w_x,
 
 extern "C" long ptv_row_gru_persist_scratch_elems(int H, long R) { return ((R + NRP - 1) / NRP) * 2 * ((3L * H / 8) * NRP * 8); }
 
+extern "C" int ptv_row_gru_persist_bwd_perm(int H, const void* wt, const void* HN, const void* gates, const void* ext,
+                                            const float* dh_last, long last_ld, const int* lengths, const int* perm, void* dgi, void* dgh,
+                                            float* dh0, void* scratch, long R, int T, int reverse, int* top_step, void* stream);
 extern "C" int ptv_row_gru_persist_bwd(int H, const void* wt, const void* HN, const void* gates, const void* ext,
                                        const float* dh_last, long last_ld, const int* lengths, void* dgi, void* dgh, float* dh0,
                                        void* scratch, long R, int T, int reverse, int* top_step, void* stream) {
+  return ptv_row_gru_persist_bwd_perm(H, wt, HN, gates, ext, dh_last, last_ld, lengths, nullptr, dgi, dgh, dh0, scratch, R, T, reverse, top_step, stream);
+}
+
+extern "C" int ptv_row_gru_persist_bwd_perm(int H, const void* wt, const void* HN, const void* gates, const void* ext,
+                                            const float* dh_last, long last_ld, const int* lengths, const int* perm, void* dgi, void* dgh,
+                                            float* dh0, void* scratch, long R, int T, int reverse, int* top_step, void* stream) {
   if (!wt || !HN || !gates || !dgi || !dgh || !scratch || R <= 0 || T <= 0 || (H != 512 && H != 128)) return PTV_ERR_ARG;
   if (dh_last && (last_ld & 3)) return PTV_ERR_ARG;
-  if (H == 512 && lengths) return PTV_ERR_UNSUPPORTED;
+  if (H == 512 && (lengths || perm)) return PTV_ERR_UNSUPPORTED;
+  if (perm && dh0) return PTV_ERR_UNSUPPORTED;                            // (dh0 would be indexed by position)
   RowGruBwdArgs a{(const bf16x8*)wt, H == 512 ? nullptr : (const float*)HN, H == 512 ? (const __bf16*)HN : nullptr, (const __bf16*)gates, (const __bf16*)ext, dh_last, last_ld, lengths, top_step, (__bf16*)dgi, (__bf16*)dgh, dh0,
-                  (__bf16*)scratch, (int)R, T, reverse, g_zero_skip};
+                  (__bf16*)scratch, (int)R, T, reverse, g_zero_skip, perm};
   const int pi = prof::want(4, (int)R, H) ? prof::begin((hipStream_t)stream) : -1;
   if (H == 512 && (!ext || dh_last || reverse)) return PTV_ERR_UNSUPPORTED;
   if (H == 128 && ext) return PTV_ERR_UNSUPPORTED;

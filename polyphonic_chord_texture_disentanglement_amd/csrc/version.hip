@@ -9,4 +9,5 @@ extern "C" const char* ptv_arch(void) { return "gfx950"; }
 // 4 (round 5): ptv_notes_gru_persist_fwd is the wave-role kernel (pairs = 0 packs, gc / gate planes unit-blocked by 16, h0 read only: no
 // fp32 states written); ptv_notes_gru_persist_bwd / ptv_row_gru_persist_bwd(H = 512) take the bf16 states; ptv_gemm dtypes bit 4 (C
 // column-blocked by 16); ptv_pianotree_targets writes counts[3] (since round 4, unversioned then); ptv_debug_notes_trace added
-extern "C" int ptv_abi_version(void) { return 4; }
+// 5 (round 5): ptv_row_gru_persist_{fwd,bwd}_perm and ptv_rows_by_length added (panels of rows sorted by length)
+extern "C" int ptv_abi_version(void) { return 5; }

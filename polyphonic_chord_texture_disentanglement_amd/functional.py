@@ -719,6 +719,9 @@ EMBED_MH_FWD = True    # multi-hot operand of the note_embedding gradient built 
 # in contention than the queueing does.
 BIGRU_SLOT = 7
 BIGRU_SLOT_BWD = 7
+SORT_ROWS = os.environ.get('PTV_SORT_ROWS', '1') != '0'      # note-summary bi-GRU: panels of rows sorted by length (0: row order)
+if os.environ.get('PTV_ROW_PAIR'):
+    lib().ptv_row_gru_pair(int(os.environ['PTV_ROW_PAIR']))
 # (Round-4 scheduling experiments on the step's tail -- chain-first bi-GRU backward, parameter-gradient products launched when the backward
 # pass ends, row kernels taking turns with the persistent launches, forks before / after the chain's dX products -- all measured slower
 # than this plain scheme, 8.43 ms per step against 8.48-8.95; their numbers are in DESIGN.md section 4 and profiles/r04_ab_*.txt, their
@@ -965,6 +968,14 @@ def _bigru_forward(prec, x3, lengths, w):
     if row_gru_ok(prec, H, I, M, adt) and x3.dtype == F32:
         # many short independent rows (dec_notes_emb_gru: 32*B rows x 16 notes): row-partitioned persistent kernels, one launch per
         # direction for the whole sequence (csrc/notes_persist.hip), input product fused; the directions overlap on sibling streams
+        # Rows sorted by length (one tiny launch): a 64-row panel then holds rows of (almost) one length and passes over the steps that
+        # are masked for ALL of them -- in row order a panel's longest row is nearly always the longest of the batch (here 8 of 16 note
+        # slots against a mean of 3.8).  What the reference gets from pack_padded_sequence (ptvae.py:446-453).
+        perm = None
+        if lengths is not None and ZERO_SKIP and SORT_ROWS and T <= 38:
+            perm = torch.empty(M, device=dev, dtype=torch.int32)
+            call('ptv_rows_by_length', ptr(lengths), ptr(perm), M, T, stream_ptr())
+
         def rows(d):
             w_ih, w_hh, b_ih, b_hh = w[4 * d: 4 * d + 4]
             pk = notes_packs(w_ih, w_hh, 0)
@@ -972,10 +983,11 @@ def _bigru_forward(prec, x3, lengths, w):
             hall[0].zero_()
             h16 = _empty(T + 1, M, H, dev=dev, dtype=BF16)
             gates = _empty(T, 4, M, H, dev=dev, dtype=BF16)
-            call('ptv_row_gru_persist_fwd', H, ptr(pk['wg_h']), ptr(pk['wg_t']), ptr(b_hh), ptr(b_ih), None, ptr(x3), M * I,
-                 ptr(lengths) if lengths is not None else None, ptr(hall), ptr(h16), ptr(gates), out.data_ptr() + 4 * d * H, 2 * H,
-                 M, T, d, stream_ptr())
-            return hall, gates, h16, (lengths if ZERO_SKIP else None)      # the backward must skip the same fully masked panel steps
+            call('ptv_row_gru_persist_fwd_perm', H, ptr(pk['wg_h']), ptr(pk['wg_t']), ptr(b_hh), ptr(b_ih), None, ptr(x3), M * I,
+                 ptr(lengths) if lengths is not None else None, ptr(perm), ptr(hall), ptr(h16), ptr(gates), out.data_ptr() + 4 * d * H,
+                 2 * H, M, T, d, stream_ptr())
+            # (the backward must skip the same fully masked panel steps, with the same row order)
+            return hall, gates, h16, (lengths if ZERO_SKIP else None), perm
         side = Side(BIGRU_SLOT)
         rev = side(lambda: rows(1), x3, out)
         fwd = rows(0)
@@ -1054,13 +1066,15 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None, rev_slot=Non
             w_ih, w_hh = w[4 * d], w[4 * d + 1]
             hall, gates, h16 = saved[d][:3]
             lengths = saved[d][3] if len(saved[d]) > 3 else None
+            perm = saved[d][4] if len(saved[d]) > 4 else None
             pk = notes_packs(w_ih, w_hh, 0)
             dgi = _empty(T, M, 3 * H, dev=x3.device, dtype=BF16)
             dgh = _empty(T, M, 3 * H, dev=x3.device, dtype=BF16)
             scratch = _empty(lib().ptv_row_gru_persist_scratch_elems(H, M), dev=x3.device, dtype=BF16)
             top = _ineg1(x3.device) if (lengths is not None and M % 32 == 0) else None
-            call('ptv_row_gru_persist_bwd', H, ptr(pk['wt']), ptr(hall), ptr(gates), None, dout.data_ptr() + 4 * d * H, dout.stride(0),
-                 ptr(lengths) if lengths is not None else None, ptr(dgi), ptr(dgh), None, ptr(scratch), M, T, d, ptr(top), stream_ptr())
+            call('ptv_row_gru_persist_bwd_perm', H, ptr(pk['wt']), ptr(hall), ptr(gates), None, dout.data_ptr() + 4 * d * H, dout.stride(0),
+                 ptr(lengths) if lengths is not None else None, ptr(perm), ptr(dgi), ptr(dgh), None, ptr(scratch), M, T, d, ptr(top),
+                 stream_ptr())
             return products(d, dgi, dgh, top)
         g1, _ = side(lambda: rows(1), xf, dout)
         g0, dx0 = rows(0)

@@ -565,8 +565,24 @@ def test_notes_gru_persistent_kernels_vs_step_kernels_and_oracle(R, T, zero_from
     assert (dh0[rows.to(dev)].cpu() - hr.grad).abs().max() < 0.05 * max(1.0, hr.grad.abs().max().item())
 
 
+@pytest.mark.parametrize('R,maxlen', [(16384, 16), (4100, 5), (70000, 38), (7, 3), (1024, 0)])
+def test_rows_by_length_is_a_stable_descending_sort(R, maxlen):
+    """ptv_rows_by_length (the row order of the note-summary bi-GRU's panels): a permutation, lengths non-increasing along it, ties in
+    row order -- i.e. exactly torch's stable descending sort"""
+    from polyphonic_chord_texture_disentanglement_amd._lib import call, ptr, stream_ptr
+    dev = _dev()
+    g = torch.Generator().manual_seed(R)
+    lengths = torch.randint(0, maxlen + 1, (R,), generator=g, dtype=torch.int32).to(dev)
+    perm = torch.full((R,), -1, device=dev, dtype=torch.int32)
+    call('ptv_rows_by_length', ptr(lengths), ptr(perm), R, maxlen, stream_ptr())
+    torch.cuda.synchronize()
+    want = torch.sort(lengths.cpu().long(), descending=True, stable=True)[1]
+    assert torch.equal(perm.cpu().long(), want)
+
+
+@pytest.mark.parametrize('sort_rows', [True, False])
 @pytest.mark.parametrize('M,T,maxlen', [(4096, 16, 16), (4100, 5, 5), (4200, 16, 6), (4096, 16, 0)])
-def test_row_gru_h128_bidirectional_with_lengths_vs_step_kernels_and_oracle(M, T, maxlen, monkeypatch):
+def test_row_gru_h128_bidirectional_with_lengths_vs_step_kernels_and_oracle(M, T, maxlen, sort_rows, monkeypatch):
     """dec_notes_emb_gru through the H = 128 instance of csrc/notes_persist.hip (lengths mask, reversed direction, final state into
     its half of the summary, gradient arriving at the final state only) against the per-step path on the same operands and the
     fp32 oracle's packed-sequence bi-GRU (oracle _bigru_final, ptvae.py:446-453); short sequences (panels whose late steps are skipped
@@ -575,6 +591,7 @@ def test_row_gru_h128_bidirectional_with_lengths_vs_step_kernels_and_oracle(M, T
     from oracle.ptvae_oracle import Oracle
     dev = _dev()
     H = I = 128
+    monkeypatch.setattr(F_, 'SORT_ROWS', sort_rows)             # panels of rows sorted by length (the default) / in row order
     g = torch.Generator().manual_seed(M + T)
     k = 1.0 / np.sqrt(H)
     U = lambda *s: ((torch.rand(*s, generator=g) * 2 - 1) * k)
