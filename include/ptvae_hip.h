@@ -587,9 +587,6 @@ int ptv_row_gru_persist_bwd_perm(int H, const void* wt, const void* HN, const vo
 /* perm [R] = the rows in order of DESCENDING lengths[row] (0 <= length <= max_len <= 38), ties in row order: a stable counting sort in one
  * workgroup (deterministic: the order of the K rows of the weight-gradient products depends on it) */
 int ptv_rows_by_length(const int* lengths, int* perm, long R, int max_len, void* stream);
-/* launches with perm and at least two panels per CU: two panels per workgroup -- workgroup b runs panel b, then panel G-1-b, a long one
- * and a short one, so that the launch is not as long as its longest panel (1, default) / one panel per workgroup (0) */
-int ptv_row_gru_pair(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * clip_grad_norm_ (module.py:142-143) + torch.optim.Adam.step (train.py:50, scheduler.py:69-74) over

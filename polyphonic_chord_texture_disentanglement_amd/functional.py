@@ -719,9 +719,11 @@ EMBED_MH_FWD = True    # multi-hot operand of the note_embedding gradient built 
 # in contention than the queueing does.
 BIGRU_SLOT = 7
 BIGRU_SLOT_BWD = 7
-SORT_ROWS = os.environ.get('PTV_SORT_ROWS', '1') != '0'      # note-summary bi-GRU: panels of rows sorted by length (0: row order)
-if os.environ.get('PTV_ROW_PAIR'):
-    lib().ptv_row_gru_pair(int(os.environ['PTV_ROW_PAIR']))
+# note-summary bi-GRU: panels of rows sorted by length (ptv_rows_by_length + the *_perm entry points).  Measured, round 5 (profiles/
+# r05_ab_runs.txt): the launches do half the work (mean length 3.8 against a panel maximum of 8) but stay as long as their longest panel --
+# 225 / 242 us against 210 / 233 us in situ, step 7.69-7.71 against 7.64-7.67 ms: they are latency-bound per step, and what they leave
+# free nobody needs at that moment.  Off; the capability stays (it is the sequence packing of pack_padded_sequence, ptvae.py:446-453).
+SORT_ROWS = os.environ.get('PTV_SORT_ROWS', '0') == '1'
 # (Round-4 scheduling experiments on the step's tail -- chain-first bi-GRU backward, parameter-gradient products launched when the backward
 # pass ends, row kernels taking turns with the persistent launches, forks before / after the chain's dX products -- all measured slower
 # than this plain scheme, 8.43 ms per step against 8.48-8.95; their numbers are in DESIGN.md section 4 and profiles/r04_ab_*.txt, their
@@ -968,9 +970,8 @@ def _bigru_forward(prec, x3, lengths, w):
     if row_gru_ok(prec, H, I, M, adt) and x3.dtype == F32:
         # many short independent rows (dec_notes_emb_gru: 32*B rows x 16 notes): row-partitioned persistent kernels, one launch per
         # direction for the whole sequence (csrc/notes_persist.hip), input product fused; the directions overlap on sibling streams
-        # Rows sorted by length (one tiny launch): a 64-row panel then holds rows of (almost) one length and passes over the steps that
-        # are masked for ALL of them -- in row order a panel's longest row is nearly always the longest of the batch (here 8 of 16 note
-        # slots against a mean of 3.8).  What the reference gets from pack_padded_sequence (ptvae.py:446-453).
+        # (optional) rows sorted by length: a 64-row panel then holds rows of (almost) one length and passes over the steps that are masked
+        # for ALL of them -- in row order a panel's longest row is nearly always the longest of the batch
         perm = None
         if lengths is not None and ZERO_SKIP and SORT_ROWS and T <= 38:
             perm = torch.empty(M, device=dev, dtype=torch.int32)
