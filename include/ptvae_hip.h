@@ -316,6 +316,15 @@ int ptv_dur_gru_fwd(int H, long M, const float* h0, long ld_h0, const float* w_h
                     float* hall, long plane_h, void* hall16, void* gates, long plane_g, long step_g, int gates_bf16,
                     float* dur_out, long ld_out, int* idx, long idx_stride, const int* force, long force_stride,
                     void* stream);
+/* the same with a LIVE-ROW LIMIT: m_top (device int32, or NULL = all rows) and m_unit (a multiple of 16) -- only the rows below
+ * (*m_top + 1) * m_unit are computed; the other rows of hall / hall16 / gates / dur_out / idx stay unwritten.  For callers whose loss
+ * ignores the padded note slots (ptvae.py:498-511): rows are ordered [note step][32 B], m_unit = 32 B, *m_top = the last note step with a
+ * target. */
+int ptv_dur_gru_fwd_top(int H, long M, const float* h0, long ld_h0, const float* w_hh, const float* b_hh,
+                        const float* tab0, const float* tab, const float* w_out, const float* b_out,
+                        float* hall, long plane_h, void* hall16, void* gates, long plane_g, long step_g, int gates_bf16,
+                        float* dur_out, long ld_out, int* idx, long idx_stride, const int* force, long force_stride,
+                        const int* m_top, long m_unit, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Backward of the 5-step duration GRU (autograd of ptvae.py:353-367) in ONE kernel (bf16 gates, H = 64): dh
@@ -353,6 +362,10 @@ int ptv_dur_bwd_finalize(const float* S, float* g_whh, float* g_bhh, float* g_bi
  */
 int ptv_heads_fwd(const void* hn16, const void* wp_packed, const void* wdh_packed, const void* wdp_packed, const float* b_p,
                   const float* b_dh, float* pitch, long ldp, float* hd0, void* hd16, long M, void* stream);
+/* the same with the live-row limit of ptv_dur_gru_fwd_top (m_unit a multiple of 128): later rows of pitch / hd0 / hd16 stay unwritten */
+int ptv_heads_fwd_top(const void* hn16, const void* wp_packed, const void* wdh_packed, const void* wdp_packed, const float* b_p,
+                      const float* b_dh, float* pitch, long ldp, float* hd0, void* hd16, long M, const int* m_top, long m_unit,
+                      void* stream);
 int ptv_heads_bwd(float* dp, long ldp, const float* dhd0, const void* wdpT_packed, const void* wcat_packed, void* dnsum16,
                   int blocked, void* dy16, const int* m_top, long m_unit, long M, void* stream);
 
@@ -404,6 +417,9 @@ enum PtvDtfTensor {
   PTV_DTF_SYNC,           /* its zeroed sync words */
   PTV_DTF_WAIT_EVENT,     /* hipEvent_t recorded after the previous persistent launch of the process, or NULL */
   PTV_DTF_RECORD_EVENT,   /* hipEvent_t to record after this one, or NULL */
+  PTV_DTF_LIVE_TOP,       /* device int32 or NULL: the caller uses the outputs of the note steps 0 .. *LIVE_TOP only (a loss that ignores the
+                           * padded note slots, ptvae.py:498-511): the notes GRU, the heads and the duration GRU leave the later steps' rows of
+                           * HN16 / GATES_N / PITCH / HD / HD16 / GATES_D / DUR / IDX unwritten */
   PTV_DTF_COUNT
 };
 enum PtvDtfDim { PTV_DTF_D_B = 0, PTV_DTF_D_E, PTV_DTF_D_HE, PTV_DTF_D_HT, PTV_DTF_D_HN, PTV_DTF_D_HD, PTV_DTF_D_NP, PTV_DTF_D_ZS, PTV_DTF_D_ZI,
@@ -541,6 +557,10 @@ int ptv_free_resummarize(const void* const* w, const void* const* io, int B, int
  */
 int ptv_notes_gru_persist_fwd(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
                               const float* h0, void* HN16, void* gates, long R, int T, void* stream);
+/* the same with a live-step limit: live_top (device int32, or NULL) -- only the note steps 0 .. *live_top run; the later slots of HN16 and
+ * planes of gates stay unwritten (the BPTT must then be given a top_step limit <= *live_top: ptv_notes_gru_persist_bwd) */
+int ptv_notes_gru_persist_fwd_top(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
+                                  const float* h0, void* HN16, void* gates, long R, int T, const int* live_top, void* stream);
 long ptv_notes_gru_persist_scratch_elems(long R);
 int ptv_notes_gru_persist_bwd(const void* wt, const void* HN16, const void* gates, const void* ext, void* dgi, void* dgh,
                               float* dh0, void* scratch, long R, int T, int* top_step, void* stream);

@@ -31,7 +31,8 @@ extern "C" int ptv_decoder_tf_fwd(const void* const* t, const long* d, void* str
   if (!t || !d) return PTV_ERR_ARG;
   if (!ptv_decoder_tf_supported(d)) return PTV_ERR_UNSUPPORTED;
   for (int i = 0; i < PTV_DTF_COUNT; i++)
-    if (!t[i] && i != PTV_DTF_FORCE_DUR && i != PTV_DTF_GATES_D && i != PTV_DTF_WAIT_EVENT && i != PTV_DTF_RECORD_EVENT) return PTV_ERR_ARG;
+    if (!t[i] && i != PTV_DTF_FORCE_DUR && i != PTV_DTF_GATES_D && i != PTV_DTF_WAIT_EVENT && i != PTV_DTF_RECORD_EVENT && i != PTV_DTF_LIVE_TOP)
+      return PTV_ERR_ARG;
   const int B = (int)d[PTV_DTF_D_B], E = (int)d[PTV_DTF_D_E], He = (int)d[PTV_DTF_D_HE], Ht = (int)d[PTV_DTF_D_HT], Hn = (int)d[PTV_DTF_D_HN],
             Hd = (int)d[PTV_DTF_D_HD], Zs = (int)d[PTV_DTF_D_ZS], Zi = (int)d[PTV_DTF_D_ZI];
   const long ldp = d[PTV_DTF_D_LDP];
@@ -80,21 +81,24 @@ extern "C" int ptv_decoder_tf_fwd(const void* const* t, const long* d, void* str
                    stream));
   PTV_TRY(ptv_gemm(P, 0, 0, R, 3 * Hn, Ht, nsf, Ht, w_ih_n, ld_n, M_<void>(t, PTV_DTF_GC), 3L * Hn, (const float*)T_(t, PTV_DTF_B_IH_N), 1.f, 0, 0,
                    -1, A16 | B16 | C16 | CBLK16, stream));
-  PTV_TRY(ptv_notes_gru_persist_fwd(T_(t, PTV_DTF_PK_NOTES_H), T_(t, PTV_DTF_PK_NOTES_T), (const float*)T_(t, PTV_DTF_B_HH_N), T_(t, PTV_DTF_GC),
-                                    (const float*)T_(t, PTV_DTF_EMB), HN, HN16, M_<void>(t, PTV_DTF_GATES_N), R, 15, stream));
+  // (LIVE_TOP, device int or NULL: the caller wants the outputs of the note steps 0 .. *LIVE_TOP only -- a loss that ignores the padded
+  // note slots; the three launches below then leave the later steps' rows of their outputs unwritten)
+  const int* live = (const int*)T_(t, PTV_DTF_LIVE_TOP);
+  PTV_TRY(ptv_notes_gru_persist_fwd_top(T_(t, PTV_DTF_PK_NOTES_H), T_(t, PTV_DTF_PK_NOTES_T), (const float*)T_(t, PTV_DTF_B_HH_N), T_(t, PTV_DTF_GC),
+                                        (const float*)T_(t, PTV_DTF_EMB), HN, HN16, M_<void>(t, PTV_DTF_GATES_N), R, 15, live, stream));
   // ---- pitch head + initial duration state in one pass over the note states (ptvae.py:343-352)
-  PTV_TRY(ptv_heads_fwd(HN16 + (long)R * Hn, T_(t, PTV_DTF_PK_WP), T_(t, PTV_DTF_PK_WDH), T_(t, PTV_DTF_PK_WDP), (const float*)T_(t, PTV_DTF_B_P),
-                        (const float*)T_(t, PTV_DTF_B_DH), M_<float>(t, PTV_DTF_PITCH), ldp, HD, HD16, M, stream));
+  PTV_TRY(ptv_heads_fwd_top(HN16 + (long)R * Hn, T_(t, PTV_DTF_PK_WP), T_(t, PTV_DTF_PK_WDH), T_(t, PTV_DTF_PK_WDP), (const float*)T_(t, PTV_DTF_B_P),
+                            (const float*)T_(t, PTV_DTF_B_DH), M_<float>(t, PTV_DTF_PITCH), ldp, HD, HD16, M, live, R, stream));
   // ---- 5-step duration GRU with arg-max feedback; its input is one of three vectors: gate tables (ptvae.py:353-367)
   const int I = 5;
   PTV_TRY(ptv_gemm(PTV_PREC_F32, 0, 0, 1, 3 * Hd, I, T_(t, PTV_DTF_SOS), I, T_(t, PTV_DTF_W_IH_D), I, M_<void>(t, PTV_DTF_TAB0), 3L * Hd,
                    (const float*)T_(t, PTV_DTF_B_IH_D), 1.f, 0, 0, 0, 0, stream));
   PTV_TRY(ptv_gemm(PTV_PREC_F32, 0, 0, 2, 3 * Hd, I, T_(t, PTV_DTF_ONEHOT), I, T_(t, PTV_DTF_W_IH_D), I, M_<void>(t, PTV_DTF_TAB), 3L * Hd,
                    (const float*)T_(t, PTV_DTF_B_IH_D), 1.f, 0, 0, 0, 0, stream));
-  PTV_TRY(ptv_dur_gru_fwd(Hd, M, HD, Hd, (const float*)T_(t, PTV_DTF_W_HH_D), (const float*)T_(t, PTV_DTF_B_HH_D), (const float*)T_(t, PTV_DTF_TAB0),
+  PTV_TRY(ptv_dur_gru_fwd_top(Hd, M, HD, Hd, (const float*)T_(t, PTV_DTF_W_HH_D), (const float*)T_(t, PTV_DTF_B_HH_D), (const float*)T_(t, PTV_DTF_TAB0),
                           (const float*)T_(t, PTV_DTF_TAB), (const float*)T_(t, PTV_DTF_W_OUT_D), (const float*)T_(t, PTV_DTF_B_OUT_D), nullptr,
                           M * Hd, HD16 + M * Hd, M_<void>(t, PTV_DTF_GATES_D), M * Hd, 4 * M * Hd, 1, M_<float>(t, PTV_DTF_DUR), 10,
-                          M_<int>(t, PTV_DTF_IDX), M, (const int*)T_(t, PTV_DTF_FORCE_DUR), M, stream));
+                              M_<int>(t, PTV_DTF_IDX), M, (const int*)T_(t, PTV_DTF_FORCE_DUR), M, live, R, stream));
   return PTV_OK;
 }
 

@@ -36,9 +36,11 @@ struct HeadsFwdArgs {
   float* pitch; long ldp;                      // [M][ldp] fp32
   float* hd0; __bf16* hd16;                    // [M][64] fp32, bf16 copy or null
   long M;
+  const int* m_top; long m_unit;               // or null: only the rows below (*m_top + 1) * m_unit are wanted; the others stay unwritten
 };
 
 __global__ __launch_bounds__(256, 1) void heads_fwd_kernel(HeadsFwdArgs a) {
+  if (a.m_top && (long)blockIdx.x * 128 >= (long)(max(*a.m_top, 0) + 1) * a.m_unit) return;
   extern __shared__ __attribute__((aligned(16))) char hsm[];
   bf16x8* Bs = reinterpret_cast<bf16x8*>(hsm);                       // [2][HCH][HNT][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -326,12 +328,22 @@ __global__ __launch_bounds__(256, 1) void heads_bwd_kernel(HeadsBwdArgs a) {
 
 using namespace ptv;
 
+extern "C" int ptv_heads_fwd_top(const void* hn16, const void* wp_packed, const void* wdh_packed, const void* wdp_packed, const float* b_p,
+                                 const float* b_dh, float* pitch, long ldp, float* hd0, void* hd16, long M, const int* m_top, long m_unit,
+                                 void* stream);
 extern "C" int ptv_heads_fwd(const void* hn16, const void* wp_packed, const void* wdh_packed, const void* wdp_packed, const float* b_p,
                              const float* b_dh, float* pitch, long ldp, float* hd0, void* hd16, long M, void* stream) {
+  return ptv_heads_fwd_top(hn16, wp_packed, wdh_packed, wdp_packed, b_p, b_dh, pitch, ldp, hd0, hd16, M, nullptr, 0, stream);
+}
+
+extern "C" int ptv_heads_fwd_top(const void* hn16, const void* wp_packed, const void* wdh_packed, const void* wdp_packed, const float* b_p,
+                                 const float* b_dh, float* pitch, long ldp, float* hd0, void* hd16, long M, const int* m_top, long m_unit,
+                                 void* stream) {
+  if (m_top && (m_unit <= 0 || (m_unit & 127))) return PTV_ERR_ARG;        // (whole 128-row blocks on either side of the limit)
   if (!hn16 || !wp_packed || !wdh_packed || !wdp_packed || !b_p || !b_dh || !pitch || !hd0 || M <= 0 || ldp < HNP || (ldp & 3)) return PTV_ERR_ARG;
   if ((reinterpret_cast<uintptr_t>(pitch) & 15) || (reinterpret_cast<uintptr_t>(hn16) & 15)) return PTV_ERR_ARG;
   HeadsFwdArgs a{(const __bf16*)hn16, (const bf16x8*)wp_packed, (const bf16x8*)wdh_packed, (const bf16x8*)wdp_packed, b_p, b_dh,
-                 pitch, ldp, hd0, (__bf16*)hd16, M};
+                 pitch, ldp, hd0, (__bf16*)hd16, M, m_top, m_unit};
   const int lds = 2 * HCH * HNT * 64 * 16;                                // 104 KB (the staged logits, 42 KB, reuse it)
   static bool attr = false;
   if (!attr) { if (hipFuncSetAttribute((const void*)heads_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return PTV_ERR_LAUNCH; attr = true; }

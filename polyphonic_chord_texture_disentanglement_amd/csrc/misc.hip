@@ -222,6 +222,9 @@ __global__ void dur_out_wgrad_kernel(const float* __restrict__ ddur, long ld_dd,
 #pragma unroll
     for (int d = 0; d < 5; d++) {
       const float2 g = *reinterpret_cast<const float2*>(ddur + r * ld_dd + 2 * d);
+      // an ignored target's gradient is exactly zero (more than half of the rows): its state is not read -- and need not have been
+      // written (a forward that stopped at the batch's last live note step leaves the later rows of hall16 as they were)
+      if (g.x == 0.f && g.y == 0.f) continue;
       const bf16x8 h = *reinterpret_cast<const bf16x8*>(hall16 + (d + 1) * plane_h + r * H + uo * 8);
 #pragma unroll
       for (int e = 0; e < 8; e++) { const float hv = (float)h[e]; a0[e] += g.x * hv; a1[e] += g.y * hv; }

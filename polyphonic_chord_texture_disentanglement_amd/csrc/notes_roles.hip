@@ -85,6 +85,8 @@ struct Args {
   __bf16* gates;                   // [T][4][32][R][16] (r, z, n, W_hn h + b_hn) or null
   int R, T, dbg;
   unsigned long long* trace;       // timing experiments: per-wave event stamps of workgroup 0 (s_memtime), or null
+  const int* live_top;             // or null: device int -- only the note steps 0 .. *live_top are wanted by the caller; later HN16 slots
+                                   // and gate planes stay unwritten
 };
 
 // slot address of the 16-byte chunk j (units 4j .. 4j+3) of (gate, row): chunks are XOR-swizzled so that both the product wave's
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void notes_fwd_kernel(Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long R = a.R, RH = R * H;
   const long r0 = (long)blockIdx.x * ROWS;
-  const int T = a.T;
+  const int T = a.live_top ? min(a.T, max(__builtin_amdgcn_readfirstlane(*a.live_top), 0) + 1) : a.T;
   // workgroups of one XCD run in near lockstep and would ask the L2 for the same fragment lines at the same moment: each walks its
   // mini-passes from its own starting point (a k-block rotation on top measured nothing and costs 80 address registers)
   const int rot = (a.dbg & 8) ? 0 : (blockIdx.x >> 3) & (MPS - 1);
@@ -400,12 +402,19 @@ static unsigned long long* g_notes_trace = nullptr;
 // timing experiments (scripts/trace_notes.py): device buffer of 8 x 2048 uint64 that workgroup 8 of the next launches fills with event stamps
 extern "C" int ptv_debug_notes_trace(void* buf) { g_notes_trace = (unsigned long long*)buf; return PTV_OK; }
 
-// T: bits 0-7 = steps, bits 8-15 = debug flags (8: no stagger), bits 16-23 = ring depth (0 = default)
+extern "C" int ptv_notes_gru_persist_fwd_top(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
+                                             const float* h0, void* HN16, void* gates, long R, int T, const int* live_top, void* stream);
 extern "C" int ptv_notes_gru_persist_fwd(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
                                        const float* h0, void* HN16, void* gates, long R, int T, void* stream) {
+  return ptv_notes_gru_persist_fwd_top(wg_h, wg_t, b_hh, gc, emb, h0, HN16, gates, R, T, nullptr, stream);
+}
+
+// T: bits 0-7 = steps, bits 8-15 = debug flags (8: no stagger), bits 16-23 = ring depth (0 = default)
+extern "C" int ptv_notes_gru_persist_fwd_top(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
+                                             const float* h0, void* HN16, void* gates, long R, int T, const int* live_top, void* stream) {
   if (!wg_h || !wg_t || !b_hh || !gc || !emb || !h0 || !HN16 || R <= 0 || (T & 0xff) <= 0) return PTV_ERR_ARG;
   nr::Args a{(const bf16x8*)wg_h, (const bf16x8*)wg_t, b_hh, (const __bf16*)gc, emb, R * nr::E, h0, (__bf16*)HN16, (__bf16*)gates,
-             (int)R, T & 0xff, (T >> 8) & 0xff, g_notes_trace};
+             (int)R, T & 0xff, (T >> 8) & 0xff, g_notes_trace, live_top};
   const int depth = (T >> 16) & 0xff, abl = a.dbg & 7;
   const int pi = prof::want(3, (int)R, nr::H) ? prof::begin((hipStream_t)stream) : -1;
   hipStream_t s = (hipStream_t)stream;

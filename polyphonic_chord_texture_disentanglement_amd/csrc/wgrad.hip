@@ -54,6 +54,7 @@ struct WgArgs {
   // second source of A (ptv_wgrad_cat): output rows m >= split (a multiple of 128) are the columns m - split of A2 -- two gradient
   // matrices that meet the same B (the notes GRU's dgi[:, :1024] and dgh: one pass over the states instead of two), or null
   const void* A2; long lda2; int split;
+  int k_base;                    // this launch's first row in the numbering of the k_top limits (the guarded tail launch starts at kfast)
 };
 
 // which part of a slab's K range survives the k_top limits: shared by the product kernel and the ordered reduction (a slab that is
@@ -63,10 +64,10 @@ __device__ __forceinline__ bool slab_range(const WgArgs& g, int slab, int& k_beg
   int k_lim = g.K, k_from = 0;
   if (g.k_top) {                                                  // (multiples of the 32-row stage whenever k_unit is)
     if (g.k_rev > 0) {
-      const long lo = ((long)g.k_rev - *g.k_top - 1) * g.k_unit;
+      const long lo = ((long)g.k_rev - *g.k_top - 1) * g.k_unit - g.k_base;
       if (lo > 0) k_from = (int)min((long)g.K, lo);
     } else {
-      const long lim = ((long)*g.k_top + 1) * g.k_unit;
+      const long lim = max(((long)*g.k_top + 1) * g.k_unit - g.k_base, 0L);
       if (lim < k_lim) k_lim = (int)lim;
     }
   }
@@ -611,9 +612,11 @@ static int wgrad_impl(int M, int N, int K, const void* A, long lda, const void* 
   bool zeroed = false;
   auto launch = [&](bool guard, int k0, int kn, int want_slabs, int pass) -> int {
     WgArgs g{static_cast<const char*>(A) + (long)k0 * lda * (af ? 4 : 2), lda, static_cast<const char*>(B) + (long)k0 * ldb * (bf ? 4 : 2), ldb,
-             C, ldc, M, N, kn, 0, cdiv(M, WBM), cdiv(N, WBN), 1, 0, alpha, colsum_a, k0 == 0 ? k_top : nullptr, k_unit, k_rev, g_gemm_prio,
+             C, ldc, M, N, kn, 0, cdiv(M, WBM), cdiv(N, WBN), 1, 0, alpha, colsum_a, k_top, k_unit, k_rev, g_gemm_prio,
              nullptr, nullptr, 0,
-             A2 ? static_cast<const char*>(A2) + (long)k0 * lda2 * (af ? 4 : 2) : nullptr, lda2, split};
+             A2 ? static_cast<const char*>(A2) + (long)k0 * lda2 * (af ? 4 : 2) : nullptr, lda2, split, k0};
+    // (the guarded tail launch takes the limits too, shifted by its first row: the rows a limit declares zero may never have been WRITTEN by
+    // whoever produced the other operand -- a forward that stopped at the batch's last live note step)
     const int tiles = g.tiles_m * g.tiles_n;     // BLOCKS per slab
     // slab count (measured optima of scripts/bench_wgrad.py sweep on MI355X).  Every slab pays M*N atomics, and a grid that is
     // just over one block per CU leaves a tail, so: about one block per CU (never more) for the skinny, HBM-bound products;

@@ -1500,9 +1500,13 @@ def _decoder_tf_composite(ctx, z, emb, xs, force_dur, prec, P, W, params, B, R, 
             'NS': NS, 'NS16': NS16, 'Z_IN': z_in, 'TOKS': TOKS, 'GI_T': gi_t, 'ZG': zg, 'GATES_T': gates_t, 'HN': HN, 'HN16': HN16, 'GC': GC,
             'GATES_N': gates_n, 'PITCH': pitch, 'HD': HD, 'HD16': HD16, 'TAB0': tab0, 'TAB': tab, 'GATES_D': gates_d, 'DUR': dur, 'IDX': idx,
             'XCH': xch, 'SYNC': sync}
+    live = live_top_for(dev)
+    if live is not None and POISON_DEAD_STEPS:
+        _poison(HN16, gates_n, pitch, HD, HD16, gates_d, dur, idx)
     slots = [None] * T_['PTV_DTF_COUNT']
     for k, v in tens.items():
         slots[T_['PTV_DTF_' + k]] = v.data_ptr() if v is not None else None
+    slots[T_['PTV_DTF_LIVE_TOP']] = live.data_ptr() if live is not None else None
     # (the two event slots carry hipEvent_t handles, not tensors: events are created lazily -- record / wait once here to have a handle)
     if prev is not None:
         slots[T_['PTV_DTF_WAIT_EVENT']] = prev.cuda_event
@@ -1520,7 +1524,7 @@ def _decoder_tf_composite(ctx, z, emb, xs, force_dur, prec, P, W, params, B, R, 
     ctx.emb_link = _EMB_LINK.get(emb.data_ptr()) if (ctx.needs_input_grad[2] and ctx.needs_input_grad[1] and emb.is_contiguous()) else None
     ctx.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in, NS16=NS16, HN16=HN16, HD16=HD16,
                   TOKS=TOKS, gates_t=gates_t, HN=HN, gates_n=gates_n, gates_n_rowk=True, pitch=pitch, HD=HD, gates_d=gates_d, idx=idx,
-                  dur_tabs=(tab0, tab), dur16_only=True)
+                  dur_tabs=(tab0, tab), dur16_only=True, live_top=live)
     _DTF['calls'] = _DTF.get('calls', 0) + 1
     ctx.mark_non_differentiable(idx)
     # (returned, never stored on ctx: outputs referenced from their own grad_fn are a cycle that only the garbage collector frees -- at an
@@ -1593,9 +1597,13 @@ class DecoderTFFn(torch.autograd.Function):
         if rowk:
             # ONE launch for the 15 note steps, 64 rows per workgroup, token product fused (csrc/notes_persist.hip)
             pk = notes_packs(P['dec_notes_gru.weight_ih_l0'], P['dec_notes_gru.weight_hh_l0'], Ht)
-            call('ptv_notes_gru_persist_fwd', ptr(pk['wg_h']), ptr(pk['wg_t']), ptr(P['dec_notes_gru.bias_hh_l0']), ptr(GC), ptr(emb3),
-                 ptr(HN), ptr(HN16), ptr(gates_n), R, 15, stream_ptr())
+            live = live_top_for(dev)
+            if live is not None and POISON_DEAD_STEPS:
+                _poison(HN16, gates_n)
+            call('ptv_notes_gru_persist_fwd_top', ptr(pk['wg_h']), ptr(pk['wg_t']), ptr(P['dec_notes_gru.bias_hh_l0']), ptr(GC), ptr(emb3),
+                 ptr(HN), ptr(HN16), ptr(gates_n), R, 15, ptr(live), stream_ptr())
         else:
+            live = None
             GT = gemm(emb3[:15].view(15 * R, E), w_ih_n[:, Ht:], prec=prec, out_dtype=adt)                    # [15R, 3Hn]
             gru_fwd(prec, GT, R * 3 * Hn, 3 * Hn, W['dec_notes_gru.weight_hh_l0'], P['dec_notes_gru.bias_hh_l0'], HN,
                     gates_n, gi2=GC, gi2_step=0, gi2_ld=3 * Hn, hall16=HN16)
@@ -1614,8 +1622,10 @@ class DecoderTFFn(torch.autograd.Function):
         if fused_heads:
             # ONE pass over the note summaries for both Linears; the logits feed the second product from LDS (csrc/heads.hip)
             hp = heads_packs(P['pitch_out_linear.weight'], P['dur_hid_linear.weight'])
-            call('ptv_heads_fwd', ptr(NSUM_op), ptr(hp['wp']), ptr(hp['wdh']), ptr(hp['wdp']), ptr(P['pitch_out_linear.bias']),
-                 ptr(P['dur_hid_linear.bias']), ptr(pitch), pitch.stride(0), ptr(HD[0]), ptr(HD16[0]), M, stream_ptr())
+            if live is not None and POISON_DEAD_STEPS:
+                _poison(pitch, HD, HD16)
+            call('ptv_heads_fwd_top', ptr(NSUM_op), ptr(hp['wp']), ptr(hp['wdh']), ptr(hp['wdp']), ptr(P['pitch_out_linear.bias']),
+                 ptr(P['dur_hid_linear.bias']), ptr(pitch), pitch.stride(0), ptr(HD[0]), ptr(HD16[0]), M, ptr(live), R, stream_ptr())
         else:
             gemm(NSUM_op, W['pitch_out_linear.weight'], pitch, bias=P['pitch_out_linear.bias'], prec=prec)          # [M,130]
             w_dh = W['dur_hid_linear.weight']
@@ -1634,11 +1644,14 @@ class DecoderTFFn(torch.autograd.Function):
         dur2 = dur.view(M, 10)
         if fused_dur:
             # one kernel for the 5 steps + output layer + argmax feedback (dur.hip)
-            call('ptv_dur_gru_fwd', Hd, M, ptr(HD[0]), Hd, ptr(P['dec_dur_gru.weight_hh_l0']), ptr(P['dec_dur_gru.bias_hh_l0']),
+            live_d = live if fused_heads else None          # (the generic heads wrote every row: keep the duration GRU dense beside them)
+            if live_d is not None and POISON_DEAD_STEPS:
+                _poison(gates_d, dur, idx)
+            call('ptv_dur_gru_fwd_top', Hd, M, ptr(HD[0]), Hd, ptr(P['dec_dur_gru.weight_hh_l0']), ptr(P['dec_dur_gru.bias_hh_l0']),
                  ptr(tab0), ptr(tab), ptr(P['dur_out_linear.weight']), ptr(P['dur_out_linear.bias']),
                  None if HD16 is not None else ptr(HD[1]), M * Hd,          # fp32 states stay in registers when the bf16
                  ptr(HD16[1]) if HD16 is not None else None, ptr(gates_d), M * Hd, 4 * M * Hd, _bf(gates_d),   # copies exist
-                 ptr(dur2), 10, ptr(idx), M, ptr(force_dur) if force_dur is not None else None, M, stream_ptr())
+                 ptr(dur2), 10, ptr(idx), M, ptr(force_dur) if force_dur is not None else None, M, ptr(live_d), R, stream_ptr())
             if HD16 is not None and not fused_heads:
                 call('ptv_cast_bf16', ptr(HD[0]), ptr(HD16[0]), M * Hd, stream_ptr())       # slot 0 of the shadow
         else:
@@ -1656,7 +1669,7 @@ class DecoderTFFn(torch.autograd.Function):
         S.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in, NS16=NS16, HN16=HN16,
                     HD16=HD16,
                     TOKS=TOKS, gates_t=gates_t, HN=HN, gates_n=gates_n, gates_n_rowk=gates_n_rowk, pitch=pitch, HD=HD, gates_d=gates_d, idx=idx,
-                    dur_tabs=(tab0, tab),
+                    dur_tabs=(tab0, tab), live_top=live,
                     dur16_only=bool(prec == 1 and Hd == 64 and FUSED_DUR and HD16 is not None))   # HD[1:] never written
         S.mark_non_differentiable(idx)
         return pitch.view(15, 32, B, NP), dur, idx
@@ -1754,7 +1767,12 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     zero_skip_sync()
     top_h = None
     if ZERO_SKIP:
-        if hint is not None:
+        if st.get('live_top') is not None:
+            # the forward stopped at this note step (DisentangleVAE.loss(): the loss ignores everything after it, its gradient there is
+            # exactly zero): the limit of everything below -- a scan may report MORE (row padding that is not zero), and the forward
+            # tensors hold nothing beyond it
+            top_h = st['live_top']
+        elif hint is not None:
             top_h = hint                         # the loss node's own bound (its gradients are zero beyond it by construction)
         else:
             top_h = _ineg1(dev)
@@ -2090,10 +2108,14 @@ def _pianotree_ce_fwd(pitch, dur, x, sums, st, weighted=False):
     B = x.shape[0]
     rows = B * 480
     NP = pitch.shape[-1]
-    pitch_t = torch.empty(rows, device=dev, dtype=torch.int32)
-    dur_t = torch.empty(rows * 5, device=dev, dtype=torch.int32)
-    counts = _izeros(3, dev)                                 # valid pitch / duration targets; last note step with any (zero-skip limit)
-    call('ptv_pianotree_targets', ptr(x), B, int(sm), ptr(pitch_t), ptr(dur_t), ptr(counts), st)
+    cached = _cached_targets(x, sm)                          # (DisentangleVAE.loss() computed them before the decoder ran)
+    if cached is not None:
+        pitch_t, dur_t, counts = cached
+    else:
+        pitch_t = torch.empty(rows, device=dev, dtype=torch.int32)
+        dur_t = torch.empty(rows * 5, device=dev, dtype=torch.int32)
+        counts = _izeros(3, dev)                             # valid pitch / duration targets; last note step with any (zero-skip limit)
+        call('ptv_pianotree_targets', ptr(x), B, int(sm), ptr(pitch_t), ptr(dur_t), ptr(counts), st)
     call('ptv_ce_fwd', ptr(pitch_m), pitch_m.stride(-2), ptr(pitch_t), rows, NP, 130, ptr(sums[0:]), st)
     if weighted:                              # 5 per-bit-position means, weighted (ptvae.py:512-527)
         gsum = _zeros(5, dev=dev)
@@ -2125,19 +2147,86 @@ def _pianotree_ce_bwd(pitch_m, dur_m, sm, pitch_t, dur_t, gs, st, gcnt=None):
 
 _LOSS_TOP = {}
 
+# ---- dead note steps of the forward --------------------------------------------------------------------------------------------
+# The loss ignores the padded note slots (CrossEntropyLoss(ignore_index), ptvae.py:498-511): the decoder outputs of the note steps after
+# the last one that holds ANY target of the batch are dead values when the caller only wants the loss.  DisentangleVAE.loss() -- run +
+# loss_function in one call, nothing of run()'s outputs returned -- computes the targets before the decoder (they depend on x only) and
+# arms `live_top`; the teacher-forced decoder node then runs its notes GRU, heads and duration GRU for the live steps only (device-side
+# limit: no host sync) and the loss node reuses the targets.  run() itself always computes every step (its outputs ARE the result).
+# The backward's zero-skip limit is the same number, so nothing reads the unwritten rows (tests poison them with NaN: POISON_DEAD_STEPS).
+DEAD_STEPS = os.environ.get('PTV_DEAD_STEPS', '1') != '0'
+POISON_DEAD_STEPS = False
+_LIVE = {}
+
+
+def pianotree_targets(x, step_major):
+    """-> (pitch_t [480 B] int32, dur_t [2400 B] int32, counts int32 [3]: valid pitch / duration targets, last note step with any)"""
+    B = x.shape[0]
+    dev = x.device
+    pitch_t = torch.empty(B * 480, device=dev, dtype=torch.int32)
+    dur_t = torch.empty(B * 2400, device=dev, dtype=torch.int32)
+    counts = _izeros(3, dev)
+    call('ptv_pianotree_targets', ptr(x), B, int(step_major), ptr(pitch_t), ptr(dur_t), ptr(counts), stream_ptr())
+    return pitch_t, dur_t, counts
+
+
+def arm_live_top(x):
+    """called by DisentangleVAE.loss() before run(): targets of x now (step-major: the teacher-forced decoder's layout), kept for the loss
+    node; the decoder node of THIS forward may stop at counts[2].  -> token for disarm_live_top"""
+    if not (DEAD_STEPS and ZERO_SKIP and x.is_cuda and x.dtype == torch.int64 and x.is_contiguous()):
+        return None
+    pt, dt, counts = pianotree_targets(x, True)
+    _LIVE['x'] = (weakref.ref(x), x.data_ptr(), x._version, True, pt, dt, counts)
+    _LIVE['top'] = counts[2:3]
+    return counts
+
+
+def disarm_live_top():
+    _LIVE.pop('top', None)
+
+
+def live_top_for(dev):
+    t = _LIVE.get('top')
+    return t if (t is not None and t.device == dev) else None
+
+
+def _cached_targets(x, sm):
+    ent = _LIVE.get('x')
+    if ent is None:
+        return None
+    ref, p, ver, sm0, pt, dt, counts = ent
+    if ref() is x and x.data_ptr() == p and x._version == ver and bool(sm) == sm0:
+        _LIVE.pop('x', None)
+        return pt, dt, counts
+    return None
+
+
+def _poison(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if t.dtype.is_floating_point:
+            t.fill_(float('nan'))
+        else:
+            t.fill_(0x3fffffff)
+
 
 def _loss_top_hint(dpitch, ddur):
-    """the loss node's zero-skip bound, valid ONLY for the very tensors it returned, unmodified: the entry holds weak references to both
-    gradient tensors and their version counters.  A gradient that autograd accumulated another contribution into (a second consumer of
-    the logits, an in-place tensor hook) has a bumped version or is another object; a recycled address of a dead tensor is another
-    object too -- in all those cases the caller scans the gradients themselves (round-4 advice: the key used to be the two addresses)."""
+    """the loss node's zero-skip bound, valid ONLY for the very tensors it returned, unmodified.  The entry holds the two gradient tensors
+    themselves (so their memory cannot be handed to another tensor while the entry lives) with their version counters: what arrives must
+    have the same storage address, shape, strides and version.  A gradient that autograd accumulated another contribution into (a second
+    consumer of the logits) is a new allocation; an in-place tensor hook bumps the version -- in those cases the caller scans the
+    gradients themselves.  (Round-4 advice: the key used to be the two addresses alone.  Object identity does not work: the engine hands a
+    node's result to the next node through C++, and the Python wrapper it arrives in is a new object.)"""
     ent = _LOSS_TOP.pop('hint', None)
     if ent is None or dpitch is None or ddur is None:
         return None
-    rp, rd, vp, vd, top = ent
-    if rp() is dpitch and rd() is ddur and dpitch._version == vp and ddur._version == vd:
-        return top
-    return None
+    gp, gd, vp, vd, top = ent
+
+    def same(a, b, v):
+        return (a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride() and a.dtype == b.dtype
+                and b._version == v and a._version == v)
+    return top if (same(gp, dpitch, vp) and same(gd, ddur, vd)) else None
 
 
 LOSS_TOP_HINT = True
@@ -2212,7 +2301,7 @@ class VaeLossFn(torch.autograd.Function):
         # non-ignored target bounds where they can be non-zero -- known from the forward's target pass, no scan of the gradients
         _LOSS_TOP.clear()
         if LOSS_TOP_HINT and sm_p:
-            _LOSS_TOP['hint'] = (weakref.ref(dpitch), weakref.ref(ddur), dpitch._version, ddur._version, counts[2:3])
+            _LOSS_TOP['hint'] = (dpitch, ddur, dpitch._version, ddur._version, counts[2:3])
         return (dpitch, ddur, dmu_c, dsd_c, dmu_r, dsd_r, droot, dchroma, dbass) + (None,) * 6
 
 

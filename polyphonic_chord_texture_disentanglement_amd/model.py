@@ -159,7 +159,14 @@ class DisentangleVAE(PytorchModel):
             if k not in p:
                 raise TypeError("loss() got an unexpected keyword argument '%s'" % k)
             p[k] = v
-        outputs = self.run(x, c, pr_mat, p['tfr1'], p['tfr2'], p['tfr3'])
+        # run()'s outputs go nowhere but into the loss, which ignores the padded note slots: the teacher-forced decoder may leave the note
+        # steps after the batch's last target uncomputed (functional.arm_live_top; run() on its own always computes all of them)
+        armed = F_.arm_live_top(x) if (torch.is_grad_enabled() and p['tfr1'] >= 1. and p['tfr2'] >= 1.) else None
+        try:
+            outputs = self.run(x, c, pr_mat, p['tfr1'], p['tfr2'], p['tfr3'])
+        finally:
+            if armed is not None:
+                F_.disarm_live_top()
         return self.loss_function(x, c, *outputs, p['beta'], p['weights'])
 
     # ---- model.py:117-122
