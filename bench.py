@@ -249,12 +249,25 @@ def extras(dev, B, rank):
         t = _measure(train_fn(m, opt, data, 1.0), 6, 3)
         out['train_teacher_forced_dense_backward'] = {
             'samples_per_s': round(B / t, 1), 'ms_per_step': round(t * 1e3, 2), 'batch': B, 'dtype': 'bf16',
-            'note': 'PTV_ZERO_SKIP=0: same results; the headline passes over note steps / tiles whose gradient is exactly zero (decided on '
-                    'the gradients themselves) and over packed-sequence padding'}
+            'note': 'PTV_ZERO_SKIP=0: same results, EVERYTHING dense -- the headline (i) passes over note steps / tiles whose gradient is '
+                    'exactly zero (decided on the gradients themselves) and over packed-sequence padding in the backward, and (ii) in '
+                    'loss() stops the decoder forward at the batch\'s last note step that holds a target (the loss ignores the rest)'}
         del m, opt
     finally:
         F_.ZERO_SKIP = True
         F_.zero_skip_sync()
+    torch.cuda.empty_cache()
+    # ... and with only the forward dense (every note step computed, as run() on its own does), the backward zero-skipping
+    F_.DEAD_STEPS = False
+    try:
+        m, opt, data = train_setup('bf16')
+        t = _measure(train_fn(m, opt, data, 1.0), 6, 3)
+        out['train_teacher_forced_full_forward'] = {
+            'samples_per_s': round(B / t, 1), 'ms_per_step': round(t * 1e3, 2), 'batch': B, 'dtype': 'bf16',
+            'note': 'PTV_DEAD_STEPS=0: the decoder forward computes all 15 note steps although loss() uses only those up to the last target'}
+        del m, opt
+    finally:
+        F_.DEAD_STEPS = True
     torch.cuda.empty_cache()
     torch.manual_seed(0)
     m = DisentangleVAE.init_model(dev).to(dev).set_precision('bf16')
@@ -286,9 +299,13 @@ def _roofline(lib, B, model, args, ms_per_step=None):
     of ANY wave delays the L2 hits of the weight stream behind it (scripts/micro/tcp_order.hip), not the HBM pins."""
     import ctypes
     R, H, E, T = 32 * B, model.decoder.dec_notes_hid_size, 128, 15
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    # loss() stops the forward launch at the batch's last note step that holds a target: bytes and FLOPs of the launch scale with it
+    last = F_._LIVE.get('last_counts')
+    Tl = min(T, int(last[2].item()) + 1) if (last is not None and F_.DEAD_STEPS and F_.ZERO_SKIP) else T
     once_f = 3 * H * (H + E) * 2 + 3 * H * 4 + R * H * 4
-    fwd_bytes = T * (R * 3 * H * 2 + R * E * 4 + R * H * 2 + 4 * R * H * 2) + once_f
-    fwd_min = T * (R * 3 * H * 2 + R * E * 4 + R * H * 2) + once_f
+    fwd_bytes = Tl * (R * 3 * H * 2 + R * E * 4 + R * H * 2 + 4 * R * H * 2) + once_f
+    fwd_min = Tl * (R * 3 * H * 2 + R * E * 4 + R * H * 2) + once_f
     bwd_bytes = T * (4 * R * H * 2 + R * H * 2 + R * H * 2 + R * 3 * H * 2 + R * H * 2) + 3 * H * H * 2 + R * H * 4
     pmc = {}
     # HBM traffic of these launches from the PMC counters (separate rocprofv3 --pmc passes over this same command, scripts/gpu_pmc.sh,
@@ -298,7 +315,6 @@ def _roofline(lib, B, model, args, ms_per_step=None):
     if B == 512 and args.precision == 'bf16' and os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
     out = []
-    from polyphonic_chord_texture_disentanglement_amd import functional as F_
 
     def read(tag):
         cnt, ms, fl = ctypes.c_long(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
@@ -312,10 +328,13 @@ def _roofline(lib, B, model, args, ms_per_step=None):
         cnt, ms, fl = read(tag)
         if cnt == 0:
             continue
+        steps_run = Tl if tag == 3 else T
+        fl *= steps_run / T                                  # (the library counts the launch's FLOPs for all T steps)
         avg_s = ms / cnt * 1e-3
         gbs, tfs = nbytes / avg_s / 1e9, fl / cnt / avg_s / 1e12
         k = pmc.get(name, {})
-        out.append({'bound': 'hbm', 'kernel': '%s (dec_notes_gru, R=%d rows x T=%d steps in one launch)' % (name, R, T),
+        out.append({'bound': 'hbm', 'kernel': '%s (dec_notes_gru, R=%d rows x %d of T=%d steps in one launch%s)' % (
+                        name, R, steps_run, T, ': loss() stops at the last note step with a target' if steps_run < T else ''),
                     'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
                     'traffic': k.get('hbm_bytes_per_launch'), 'traffic_source': ('%s @ %s' % (pmc_file, pmc.get('_commit'))) if k else None,
                     'algorithmic_bytes': nbytes, 'min_bytes': nmin, 'frac_on_min_bytes': round(nmin / avg_s / 1e9 / 8000.0, 4),
@@ -439,6 +458,8 @@ def main():
     torch.manual_seed(0)                                   # identical weights on every rank
     model = DisentangleVAE.init_model(dev).to(dev).set_precision(args.precision)
     opt = FusedClipAdam(model.parameters(), lr=1e-3)
+    from polyphonic_chord_texture_disentanglement_amd.optim import reserve_step_memory
+    reserve_step_memory(args.batch, dev)                       # allocator warm-up (setup): no hipMalloc -- a device-wide sync -- inside the steps
     model.decoder.use_graph = args.graph
     sched = MinExponentialLR(opt, gamma=0.9999, minimum=1e-5)
     sync = GradSync(model, opt) if world > 1 else None
@@ -561,7 +582,7 @@ def main():
                 res['extra'] = {'error': repr(e)}
         if world == 1 and args.mode == 'train' and not args.no_parity:
             try:
-                res['parity'] = {'benched': golden_parity(args.precision, dev), 'fp32_path': golden_parity('fp32', dev) if args.precision != 'fp32' else None,
+                res['parity'] = {'benched': golden_parity(args.precision, dev, via_loss=True), 'run_then_loss_function': golden_parity(args.precision, dev), 'fp32_path': golden_parity('fp32', dev) if args.precision != 'fp32' else None,
                                  'bar': 'north_star: losses within 1e-4 of the CPU reference -- held by the fp32 path (fp32_path / by_batch.*.fp32); the benched bf16 dtype '
                                         '(bf16 MFMA operands + bf16-stored saved tensors) is held to 3e-4 by the tests (tests/test_gpu_model_wide.py), observed 2e-5 .. 1e-4'}
                 # the same at B = 4 and at the BENCHED batch (round 4: full_tf1_b512.npz, produced by the reference at B = 512)

@@ -156,6 +156,31 @@ def grad_buffer(p):
     return torch.zeros_like(p, memory_format=torch.contiguous_format)
 
 
+def reserve_step_memory(batch, device=None, gb_per_512=(12.0, 3.0)):
+    """Warm the caching allocator for train steps of `batch` samples: one large block on the current stream and one on each sibling pool
+    stream (functional.Side), allocated and released -- they stay cached per stream and later requests are carved out of them.  Without it
+    the allocator grows by hipMalloc (a device-wide synchronisation, ~70 ms) for as long as the step's working set keeps changing: measured
+    at B = 512 a step around the seventh takes 77 ms instead of 7 (the first full garbage collection frees reference cycles that held
+    blocks until then).  Sizes: the steady state at B = 512 holds 5.6 GB on the step's stream and <= 1.7 GB per pool stream; HBM is 288 GB.
+    Returns the bytes reserved."""
+    from . import functional as F_
+    dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+    scale = max(batch, 64) / 512.0
+    main = F_.cur_stream()
+    F_.Side(0)                                               # (creates the pool streams in their fixed order)
+    total = 0
+    streams = [(main, gb_per_512[0])] + [(st, gb_per_512[1]) for key, st in sorted(F_._CHILD_STREAMS.items(), key=lambda kv: str(kv[0]))
+                                         if key[0] == 'pool' and key[1] == dev.index]
+    for st, gb in streams:
+        with torch.cuda.stream(st):
+            n = int(gb * scale * 2 ** 30)
+            big = torch.empty(n, dtype=torch.uint8, device=dev)
+            small = [torch.empty(512 * 1024, dtype=torch.uint8, device=dev) for _ in range(128)]      # the small-block pool (2-MB segments)
+            total += n + 128 * 512 * 1024
+            del big, small
+    return total
+
+
 class FusedClipAdam(torch.optim.Optimizer):
     """Adam with global-norm clipping fused in (`clip_and_step(clip)`); `step()` alone = no clipping."""
 

@@ -1,0 +1,48 @@
+"""which host event stalls a step now and then?  per-step host wall time over 120 steps with the allocator's device-malloc counter and the
+garbage collector's runs logged next to every slow step"""
+import gc, os, random, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from polyphonic_chord_texture_disentanglement_amd import functional as F_
+from polyphonic_chord_texture_disentanglement_amd.model import DisentangleVAE
+from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
+from polyphonic_chord_texture_disentanglement_amd.synthetic import synth_batch
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+m = DisentangleVAE.init_model(dev).to(dev).set_precision('bf16'); m.use_philox(7, 0); random.seed(7)
+opt = FusedClipAdam(m.parameters(), lr=1e-3)
+from polyphonic_chord_texture_disentanglement_amd.optim import reserve_step_memory
+if os.environ.get("RESERVE"): reserve_step_memory(512, dev)
+data = [tuple(torch.from_numpy(t).to(dev) for t in synth_batch(512, 1234 + i)) for i in range(2)]
+gcs = []
+gc.callbacks.append(lambda phase, info: gcs.append((phase, info.get('generation'), info.get('collected'), time.perf_counter())))
+def step(i):
+    x, c, pr = data[i % 2]
+    opt.zero_grad()
+    o = m('train', x, c, pr, tfr1=1., tfr2=1., tfr3=1., beta=0.1, weights=[1, 0.5])
+    o[0].backward()
+    opt.clip_and_step(1.0)
+for i in range(5): step(i)
+torch.cuda.synchronize()
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+prev = time.perf_counter(); ms0 = torch.cuda.memory_stats()
+times = []
+for i in range(N):
+    step(i)
+    if i % 4 == 3: torch.cuda.synchronize()
+    now = time.perf_counter(); times.append(now - prev); prev = now
+ms1 = torch.cuda.memory_stats()
+print('device allocs', ms1['num_device_alloc'] - ms0['num_device_alloc'], 'frees', ms1['num_device_free'] - ms0['num_device_free'], 'retries', ms1['num_alloc_retries'] - ms0['num_alloc_retries'])
+med = sorted(times)[len(times) // 2]
+print('median step host %.2f ms' % (med * 1e3))
+t_acc = 0
+for i, t in enumerate(times):
+    if t > 3 * med + 0.01:
+        print('slow step', i, '%.1f ms' % (t * 1e3))
+print('gc runs', [(p, g, c) for p, g, c, _ in gcs if p == 'stop'][:40])
+print('reserved GB %.2f  allocated GB %.2f  max allocated GB %.2f' % (torch.cuda.memory_reserved() / 2**30, torch.cuda.memory_allocated() / 2**30, torch.cuda.max_memory_allocated() / 2**30))
+seg = torch.cuda.memory_snapshot()
+by = {}
+for s_ in seg:
+    by.setdefault(s_['stream'], [0, 0]); by[s_['stream']][0] += s_['total_size']; by[s_['stream']][1] += 1
+print('segments by stream (GB, count):', {k: (round(v[0] / 2**30, 2), v[1]) for k, v in by.items()})
