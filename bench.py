@@ -516,6 +516,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     lib.ptv_prof_enable(0)
+    rep = sync.exchange_report() if world > 1 else None        # (the exchange figures of the TIMED steps: taken before the extra ones below)
     if args.mode == 'train' and args.tfr >= 1.0:
         # the families of roofline.also (tags 5, 6: ~45 event pairs per step on the sibling streams) are timed over three EXTRA steps
         # outside the timed region, so that their bookkeeping cannot touch the headline.  EVERY rank runs them (a step holds the
@@ -531,7 +532,6 @@ def main():
         import torch.distributed as dist
         # what a first N-GPU run needs to see where the time went: every rank's own step time, the part of the gradient exchange the
         # backward pass did not hide (event-timed on the step's stream), what left early and what was left for the end
-        rep = sync.exchange_report()
         cpu_backend = dist.get_backend() != 'nccl'
         mine = torch.tensor([dt / args.steps * 1e3, rep['exposed_allreduce_ms'] or 0.0], dtype=torch.float64,
                             device='cpu' if cpu_backend else dev)
