@@ -88,7 +88,9 @@ __global__ void sum_steps_vec_kernel(float* __restrict__ out, const void* __rest
 // block = 256 threads = 16 column quads (64 columns, 16-byte loads) x 16 row lanes
 template <bool VEC>
 __global__ void colsum_kernel(float* out, const void* __restrict__ A, long lda, long rows, int N, const int* __restrict__ sel, int G, int bf, OrdScratch sc) {
-  __shared__ float red[2][16][64];
+  // (2.6 KB of LDS, not 8.7: a bias-gradient launch on a sibling stream then fits beside the 148-158-KB workgroups of the chain's row / head
+  // kernels instead of waiting for a CU to drain -- round 5 saw such launches take 100-650 us for microseconds of work)
+  __shared__ float red[4][2][64];
   __shared__ float tot[2 * 64];
   const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
   const int n = blockIdx.x * 64 + cq * 4;
@@ -109,15 +111,26 @@ __global__ void colsum_kernel(float* out, const void* __restrict__ A, long lda, 
       else if (g == 1) { s[1][0] += v.x; s[1][1] += v.y; s[1][2] += v.z; s[1][3] += v.w; }
     }
   }
-  for (int g = 0; g < G; g++)
+  // a wave holds 4 row lanes x 16 column quads (lane = (ry & 3) * 16 + cq): the row lanes meet by shuffles, the 4 waves through LDS
 #pragma unroll
-    for (int e = 0; e < 4; e++) red[g][ry][cq * 4 + e] = s[g][e];
+  for (int g = 0; g < 2; g++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      float v = s[g][e];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      s[g][e] = v;
+    }
+  if ((threadIdx.x & 63) < 16)
+    for (int g = 0; g < G; g++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) red[threadIdx.x >> 6][g][cq * 4 + e] = s[g][e];
   __syncthreads();
   for (int i = threadIdx.x; i < G * 64; i += blockDim.x) {
     const int g = i / 64, c = i % 64;
     float t = 0.f;
 #pragma unroll
-    for (int y = 0; y < 16; y++) t += red[g][y][c];
+    for (int y = 0; y < 4; y++) t += red[y][g][c];
     if (sc.slots) tot[i] = t;
     else if (blockIdx.x * 64 + c < N && t != 0.f) atomicAdd(out + (long)g * N + blockIdx.x * 64 + c, t);
   }
@@ -134,7 +147,7 @@ __global__ void colsum_kernel(float* out, const void* __restrict__ A, long lda, 
     __syncthreads();
     if (s_last) {
       // the partials [n][G][64] are summed the way the rows were: row lane ry takes partials ry, ry + 16, ... (float4 per column quad),
-      // then the 16 lanes meet in LDS in lane order -- a fixed association, 16 loads in flight per column quad
+      // then the 16 lanes meet (shuffles inside a wave, LDS across the waves) -- a fixed association, 16 loads in flight per column quad
       for (int g = 0; g < G; g++) {
         float a4[4] = {0.f, 0.f, 0.f, 0.f};
         for (int b = ry; b < n; b += 16) {
@@ -146,7 +159,12 @@ __global__ void colsum_kernel(float* out, const void* __restrict__ A, long lda, 
           for (int e = 0; e < 4; e++) a4[e] += v[e];
         }
 #pragma unroll
-        for (int e = 0; e < 4; e++) red[g][ry][cq * 4 + e] = a4[e];
+        for (int e = 0; e < 4; e++) {                                 // the wave's 4 row lanes by shuffles, the waves through LDS (as above)
+          float v = a4[e];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          if ((threadIdx.x & 63) < 16) red[threadIdx.x >> 6][g][cq * 4 + e] = v;
+        }
       }
       __syncthreads();
       for (int i = threadIdx.x; i < L; i += blockDim.x) {
@@ -154,7 +172,7 @@ __global__ void colsum_kernel(float* out, const void* __restrict__ A, long lda, 
         if (blockIdx.x * 64 + c >= N) continue;
         float s2 = 0.f;
 #pragma unroll
-        for (int y = 0; y < 16; y++) s2 += red[g][y][c];
+        for (int y = 0; y < 4; y++) s2 += red[y][g][c];
         out[(long)g * N + blockIdx.x * 64 + c] += s2;
       }
       if (threadIdx.x == 0) __hip_atomic_store(sc.counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -212,7 +212,7 @@ extern "C" int ptv_dur_out_token(const float* h, int H, const float* w_out, cons
 // block: 256 threads = 8 unit-octets (16-byte loads of 8 bf16) x 32 row lanes; LDS tree over the row lanes, atomics per block.
 __global__ void dur_out_wgrad_kernel(const float* __restrict__ ddur, long ld_dd, const __bf16* __restrict__ hall16, long plane_h,
                                      float* __restrict__ gw, long rows, int H, OrdScratch sc) {
-  __shared__ float red[32][2][64];
+  __shared__ float red[4][2][64];                                  // (2.5 KB, not 16.9: the launch fits beside the chain's 148-158-KB workgroups)
   __shared__ float tot[128];
   const int uo = threadIdx.x & 7, rlane = threadIdx.x >> 3;
   float a0[8], a1[8];
@@ -230,13 +230,19 @@ __global__ void dur_out_wgrad_kernel(const float* __restrict__ ddur, long ld_dd,
       for (int e = 0; e < 8; e++) { const float hv = (float)h[e]; a0[e] += g.x * hv; a1[e] += g.y * hv; }
     }
   }
+  // a wave holds 8 row lanes x 8 unit octets (lane = (rlane & 7) * 8 + uo): the row lanes meet by shuffles, the 4 waves through LDS
 #pragma unroll
-  for (int e = 0; e < 8; e++) { red[rlane][0][uo * 8 + e] = a0[e]; red[rlane][1][uo * 8 + e] = a1[e]; }
+  for (int e = 0; e < 8; e++) {
+    float v0 = a0[e], v1 = a1[e];
+#pragma unroll
+    for (int d = 8; d < 64; d <<= 1) { v0 += __shfl_xor(v0, d, 64); v1 += __shfl_xor(v1, d, 64); }
+    if ((threadIdx.x & 63) < 8) { red[threadIdx.x >> 6][0][uo * 8 + e] = v0; red[threadIdx.x >> 6][1][uo * 8 + e] = v1; }
+  }
   __syncthreads();
   if (threadIdx.x < 128) {
     const int c = threadIdx.x >> 6, u = threadIdx.x & 63;
     float s = 0.f;
-    for (int q = 0; q < 32; q++) s += red[q][c][u];
+    for (int q = 0; q < 4; q++) s += red[q][c][u];
     tot[c * 64 + u] = s;                                          // (H = 64: gw[c * H + u])
   }
   __syncthreads();

@@ -328,6 +328,23 @@ class FusedClipAdam(torch.optim.Optimizer):
              float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), self.step_count, ptr(self.flat_p16) if ADAM_SHADOW else None, st)
         if ADAM_SHADOW:
             self._plain_stamp = self._stamp()
+        self._throttle()
+
+    # The host enqueues a step in 5.5 ms, the GPU runs it in 7: a loop that never synchronises runs further and further ahead, and every
+    # block that crossed streams (record_stream) stays unusable until the GPU has passed it -- the allocator then grows by hipMalloc, a
+    # device-wide synchronisation (36 of them in 120 steps, one ~60-ms stall every ~40 steps: scripts/probe_stall.py).  So the host waits for
+    # the step before the previous one to finish before it enqueues the next: never a bubble (two whole steps stay queued), bounded memory.
+    MAX_STEPS_IN_FLIGHT = 2
+
+    def _throttle(self):
+        if torch.cuda.is_current_stream_capturing():
+            return
+        q = self.__dict__.setdefault('_inflight', [])
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        q.append(ev)
+        while len(q) > self.MAX_STEPS_IN_FLIGHT:
+            q.pop(0).synchronize()
 
     def step(self, closure=None):
         assert closure is None

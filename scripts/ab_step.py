@@ -39,6 +39,8 @@ def main():
     m.use_philox(7, 0)
     random.seed(7)
     opt = FusedClipAdam(m.parameters(), lr=1e-3)
+    from polyphonic_chord_texture_disentanglement_amd.optim import reserve_step_memory
+    reserve_step_memory(a.batch, dev)                          # (no hipMalloc -- a 70-ms device-wide sync -- inside a timed round)
     data = [tuple(torch.from_numpy(t).to(dev) for t in synth_batch(a.batch, 1234 + i)) for i in range(2)]
 
     def step(i):
