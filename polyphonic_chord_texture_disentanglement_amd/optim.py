@@ -343,8 +343,12 @@ class FusedClipAdam(torch.optim.Optimizer):
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         q.append(ev)
-        while len(q) > self.MAX_STEPS_IN_FLIGHT:
-            q.pop(0).synchronize()
+        if len(q) > self.MAX_STEPS_IN_FLIGHT:
+            import time
+            t0 = time.perf_counter()
+            while len(q) > self.MAX_STEPS_IN_FLIGHT:
+                q.pop(0).synchronize()
+            self.throttle_wait_s = getattr(self, 'throttle_wait_s', 0.0) + (time.perf_counter() - t0)     # (bench.py: host time that is waiting, not work)
 
     def step(self, closure=None):
         assert closure is None
