@@ -449,6 +449,36 @@ enum PtvCdfDim { PTV_CDF_D_B = 0, PTV_CDF_D_T, PTV_CDF_D_H, PTV_CDF_D_I, PTV_CDF
                  PTV_CDF_D_NROOT, PTV_CDF_D_NCHROMA, PTV_CDF_D_NBASS, PTV_CDF_D_COUNT };
 int ptv_chord_decoder_fwd(const void* const* t, const long* d, void* stream);
 
+/* ptv_chord_decoder_bwd: autograd through RnnDecoder.forward, teacher-forced (ptvae.py:51-87) -- what ChordDecoderTFFn.backward sequences:
+ * the three heads' input / weight / bias gradients, the GRU's BPTT (one persistent launch with its event turn when d[PTV_CDB_D_PERSIST],
+ * S = d[PTV_CDB_D_SPLITK] teams; else the per-step kernels), the weight / bias gradients of the GRU, of the start token and of the two
+ * z projections, and dz.  26 launches.  Every G_* slot is the parameter's gradient buffer and is ACCUMULATED into (the caller zeroes it
+ * once per step); a NULL D* slot = that head received no gradient.  fp32 tensors except GATES / DGI / DGH (bf16 when d[PTV_CDB_D_ACT_BF16])
+ * and WT16 / XCH.  Same arithmetic, launch by launch, as the Python sequencing it replaces (bit-identical results). */
+enum PtvCdbTensor {
+  PTV_CDB_Z = 0,          /* [B, Z] */
+  PTV_CDB_W_ZHID, PTV_CDB_W_ZIN, PTV_CDB_W_IH, PTV_CDB_W_HH, PTV_CDB_W_ROOT, PTV_CDB_W_CHROMA, PTV_CDB_W_BASS,   /* fp32 masters */
+  PTV_CDB_WT16_HH,        /* bf16 W_hh^T [H, 3H] (persistent BPTT and the bf16 per-step kernels), or NULL: fp32 W_hh */
+  PTV_CDB_HALL, PTV_CDB_GATES, PTV_CDB_TOKS, PTV_CDB_Z_IN,                                 /* saved by the forward */
+  PTV_CDB_DROOT, PTV_CDB_DCHROMA, PTV_CDB_DBASS,                                           /* in: [T*B, n] or NULL */
+  PTV_CDB_DZ,             /* out [B, Z] */
+  PTV_CDB_G_INIT_INPUT, PTV_CDB_G_W_ZHID, PTV_CDB_G_B_ZHID, PTV_CDB_G_W_ZIN, PTV_CDB_G_B_ZIN, PTV_CDB_G_W_IH, PTV_CDB_G_B_IH, PTV_CDB_G_W_HH,
+  PTV_CDB_G_B_HH, PTV_CDB_G_W_ROOT, PTV_CDB_G_B_ROOT, PTV_CDB_G_W_CHROMA, PTV_CDB_G_B_CHROMA, PTV_CDB_G_W_BASS, PTV_CDB_G_B_BASS,
+  PTV_CDB_DHS,            /* scratch [T*B, H] fp32 */
+  PTV_CDB_DGI, PTV_CDB_DGH,      /* scratch [T, B, 3H] */
+  PTV_CDB_DHZ,            /* scratch [2, B, H] fp32 (per-step kernels) or NULL */
+  PTV_CDB_DH0,            /* scratch [B, H] */
+  PTV_CDB_DZG,            /* scratch [B, 3H] fp32 */
+  PTV_CDB_DZ_IN,          /* scratch [B, Zi] */
+  PTV_CDB_DTOK0,          /* scratch [B, I] */
+  PTV_CDB_XCH, PTV_CDB_PART, PTV_CDB_SYNC,   /* persistent launch: exchange buffer T*B*3H bf16, split-K partials or NULL, zeroed sync words */
+  PTV_CDB_WAIT_EVENT, PTV_CDB_RECORD_EVENT,  /* hipEvent_t of the previous persistent launch of the process / to record after this one, or NULL */
+  PTV_CDB_COUNT
+};
+enum PtvCdbDim { PTV_CDB_D_B = 0, PTV_CDB_D_T, PTV_CDB_D_H, PTV_CDB_D_I, PTV_CDB_D_Z, PTV_CDB_D_ZI, PTV_CDB_D_PREC, PTV_CDB_D_ACT_BF16,
+                 PTV_CDB_D_NROOT, PTV_CDB_D_NCHROMA, PTV_CDB_D_NBASS, PTV_CDB_D_PERSIST, PTV_CDB_D_SPLITK, PTV_CDB_D_COUNT };
+int ptv_chord_decoder_bwd(const void* const* tensors, const long* dims, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Free-running tokens.
  * ptv_note_token (ptvae.py:408-416 + pitch_dur_ind_to_note_token :328-334): per row pitch argmax (first

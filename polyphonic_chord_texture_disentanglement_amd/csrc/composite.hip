@@ -139,3 +139,87 @@ extern "C" int ptv_chord_decoder_fwd(const void* const* t, const long* d, void* 
                    0, 0, 0, stream));
   return PTV_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// ptv_chord_decoder_bwd: the backward of the above (ChordDecoderTFFn.backward's launch sequence, bit-identical to it)
+// ---------------------------------------------------------------------------------------------
+extern "C" int ptv_chord_decoder_bwd(const void* const* t, const long* d, void* stream) {
+  if (!t || !d) return PTV_ERR_ARG;
+  const int B = (int)d[PTV_CDB_D_B], T = (int)d[PTV_CDB_D_T], H = (int)d[PTV_CDB_D_H], I = (int)d[PTV_CDB_D_I], Z = (int)d[PTV_CDB_D_Z],
+            Zi = (int)d[PTV_CDB_D_ZI], P = (int)d[PTV_CDB_D_PREC], abf = d[PTV_CDB_D_ACT_BF16] ? 1 : 0, persist = (int)d[PTV_CDB_D_PERSIST],
+            S = (int)d[PTV_CDB_D_SPLITK];
+  if (B <= 0 || T <= 0 || H <= 0 || I <= 0 || Z <= 0 || Zi <= 0 || (P != PTV_PREC_F32 && P != PTV_PREC_BF16)) return PTV_ERR_ARG;
+  for (int i = 0; i < PTV_CDB_COUNT; i++) {
+    const bool optional = i == PTV_CDB_WT16_HH || i == PTV_CDB_DROOT || i == PTV_CDB_DCHROMA || i == PTV_CDB_DBASS || i == PTV_CDB_DHZ ||
+                          i == PTV_CDB_XCH || i == PTV_CDB_PART || i == PTV_CDB_SYNC || i == PTV_CDB_WAIT_EVENT || i == PTV_CDB_RECORD_EVENT;
+    if (!t[i] && !optional) return PTV_ERR_ARG;
+  }
+  if (persist && (!t[PTV_CDB_WT16_HH] || !t[PTV_CDB_XCH] || !t[PTV_CDB_SYNC] || !abf || (S && !t[PTV_CDB_PART]))) return PTV_ERR_ARG;
+  if (!persist && !t[PTV_CDB_DHZ]) return PTV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const long TB = (long)T * B, ld_ih = (long)I + Zi;
+  const float* hall = (const float*)T_(t, PTV_CDB_HALL);
+  const float* hs = hall + (long)B * H;
+  float* dhs = M_<float>(t, PTV_CDB_DHS);
+  // ---- the three heads: dhs = sum_k dlog_k . W_k;  dW_k += dlog_k^T . hs;  db_k += column sums of dlog_k
+  const int heads[3][4] = {{PTV_CDB_DROOT, PTV_CDB_W_ROOT, PTV_CDB_G_W_ROOT, PTV_CDB_G_B_ROOT},
+                           {PTV_CDB_DCHROMA, PTV_CDB_W_CHROMA, PTV_CDB_G_W_CHROMA, PTV_CDB_G_B_CHROMA},
+                           {PTV_CDB_DBASS, PTV_CDB_W_BASS, PTV_CDB_G_W_BASS, PTV_CDB_G_B_BASS}};
+  const int ncls[3] = {(int)d[PTV_CDB_D_NROOT], (int)d[PTV_CDB_D_NCHROMA], (int)d[PTV_CDB_D_NBASS]};
+  bool have = false;
+  for (int k = 0; k < 3; k++) {
+    const void* dl = T_(t, heads[k][0]);
+    if (!dl) continue;
+    const int n = ncls[k];
+    PTV_TRY(ptv_gemm(P, 0, 1, (int)TB, H, n, dl, n, T_(t, heads[k][1]), H, dhs, H, nullptr, 1.f, have ? 1 : 0, 0, 0, 0, stream));
+    have = true;
+    PTV_TRY(ptv_gemm(P, 1, 1, n, H, (int)TB, dl, n, hs, H, M_<void>(t, heads[k][2]), H, nullptr, 1.f, 1, 0, 0, 0, stream));
+    PTV_TRY(ptv_colsum(M_<float>(t, heads[k][3]), dl, n, TB, n, nullptr, 1, 0, stream));
+  }
+  if (!have && hipMemsetAsync(dhs, 0, sizeof(float) * TB * H, s) != hipSuccess) return PTV_ERR_LAUNCH;
+  // ---- BPTT
+  void* dgi = M_<void>(t, PTV_CDB_DGI); void* dgh = M_<void>(t, PTV_CDB_DGH);
+  float* dh0 = M_<float>(t, PTV_CDB_DH0);
+  if (persist) {
+    const float* hall_[1] = {hall}; const void* gates_[1] = {T_(t, PTV_CDB_GATES)}; const void* wt_[1] = {T_(t, PTV_CDB_WT16_HH)};
+    const void* ext_[1] = {dhs}; const long ext_step[1] = {(long)B * H}, ext_ld[1] = {(long)H}; const int ext_bf[1] = {0};
+    const float* last_[1] = {nullptr}; const long last_ld[1] = {0};
+    void* dgi_[1] = {dgi}; void* dgh_[1] = {dgh}; float* dh0_[1] = {dh0}; const int rev[1] = {0};
+    void* xch_[1] = {M_<void>(t, PTV_CDB_XCH)}; float* part_[1] = {M_<float>(t, PTV_CDB_PART)};
+    if (t[PTV_CDB_WAIT_EVENT] && hipStreamWaitEvent(s, (hipEvent_t)const_cast<void*>(t[PTV_CDB_WAIT_EVENT]), 0) != hipSuccess) return PTV_ERR_LAUNCH;
+    if (S) PTV_TRY(ptv_gru_persist_bwd_splitk(S, 1, B, H, T, hall_, gates_, wt_, ext_, ext_step, ext_ld, ext_bf, last_, last_ld, dgi_, dgh_, dh0_, rev,
+                                              xch_, part_, M_<unsigned>(t, PTV_CDB_SYNC), stream));
+    else PTV_TRY(ptv_gru_persist_bwd(1, B, H, T, hall_, gates_, wt_, ext_, ext_step, ext_ld, ext_bf, last_, last_ld, dgi_, dgh_, dh0_, rev, xch_,
+                                     M_<unsigned>(t, PTV_CDB_SYNC), stream));
+    if (t[PTV_CDB_RECORD_EVENT] && hipEventRecord((hipEvent_t)const_cast<void*>(t[PTV_CDB_RECORD_EVENT]), s) != hipSuccess) return PTV_ERR_LAUNCH;
+  } else {
+    const void* w = t[PTV_CDB_WT16_HH] ? T_(t, PTV_CDB_WT16_HH) : T_(t, PTV_CDB_W_HH);
+    const int flags = abf | (abf << 3) | ((t[PTV_CDB_WT16_HH] ? 1 : 0) << 4);     // gates bf16, gate gradients bf16, weight operand bf16 (ptv_gru_seq_bwd)
+    PTV_TRY(ptv_gru_seq_bwd(P, B, H, T, hall, T_(t, PTV_CDB_GATES), w, dhs, (long)B * H, H, nullptr, 0, nullptr, 0, 0, 0, nullptr, dgi, dgh,
+                            M_<float>(t, PTV_CDB_DHZ), dh0, 0, flags, stream));
+  }
+  // ---- the GRU's parameters
+  const int A = abf ? A16 : 0;
+  PTV_TRY(ptv_gemm(P, 1, 1, 3 * H, H, (int)TB, dgh, 3L * H, hall, H, M_<void>(t, PTV_CDB_G_W_HH), H, nullptr, 1.f, 1, 0, 0, A, stream));
+  PTV_TRY(ptv_colsum(M_<float>(t, PTV_CDB_G_B_HH), dgh, 3L * H, TB, 3 * H, nullptr, 1, abf, stream));
+  float* dzg = M_<float>(t, PTV_CDB_DZG);
+  PTV_TRY(ptv_sum_steps_top(dzg, dgi, (long)B * 3 * H, T, (long)B * 3 * H, 0, abf, nullptr, stream));
+  PTV_TRY(ptv_colsum(M_<float>(t, PTV_CDB_G_B_IH), dzg, 3L * H, B, 3 * H, nullptr, 1, 0, stream));
+  float* g_ih = M_<float>(t, PTV_CDB_G_W_IH);
+  PTV_TRY(ptv_gemm(P, 1, 1, 3 * H, Zi, B, dzg, 3L * H, T_(t, PTV_CDB_Z_IN), Zi, g_ih + I, ld_ih, nullptr, 1.f, 1, 0, 0, 0, stream));
+  PTV_TRY(ptv_gemm(P, 1, 1, 3 * H, I, (int)TB, dgi, 3L * H, T_(t, PTV_CDB_TOKS), I, g_ih, ld_ih, nullptr, 1.f, 1, 0, 0, A, stream));
+  const float* w_ih = (const float*)T_(t, PTV_CDB_W_IH);
+  float* dz_in = M_<float>(t, PTV_CDB_DZ_IN); float* dtok0 = M_<float>(t, PTV_CDB_DTOK0);
+  PTV_TRY(ptv_gemm(P, 0, 1, B, Zi, 3 * H, dzg, 3L * H, w_ih + I, ld_ih, dz_in, Zi, nullptr, 1.f, 0, 0, 0, 0, stream));
+  PTV_TRY(ptv_gemm(P, 0, 1, B, I, 3 * H, dgi, 3L * H, w_ih, ld_ih, dtok0, I, nullptr, 1.f, 0, 0, 0, A, stream));     // only the learned start token
+  PTV_TRY(ptv_colsum(M_<float>(t, PTV_CDB_G_INIT_INPUT), dtok0, I, B, I, nullptr, 1, 0, stream));
+  // ---- the two z projections
+  float* dz = M_<float>(t, PTV_CDB_DZ);
+  PTV_TRY(ptv_gemm(P, 0, 1, B, Z, H, dh0, H, T_(t, PTV_CDB_W_ZHID), Z, dz, Z, nullptr, 1.f, 0, 0, 0, 0, stream));
+  PTV_TRY(ptv_gemm(P, 0, 1, B, Z, Zi, dz_in, Zi, T_(t, PTV_CDB_W_ZIN), Z, dz, Z, nullptr, 1.f, 1, 0, 0, 0, stream));
+  PTV_TRY(ptv_gemm(P, 1, 1, H, Z, B, dh0, H, T_(t, PTV_CDB_Z), Z, M_<void>(t, PTV_CDB_G_W_ZHID), Z, nullptr, 1.f, 1, 0, 0, 0, stream));
+  PTV_TRY(ptv_colsum(M_<float>(t, PTV_CDB_G_B_ZHID), dh0, H, B, H, nullptr, 1, 0, stream));
+  PTV_TRY(ptv_gemm(P, 1, 1, Zi, Z, B, dz_in, Zi, T_(t, PTV_CDB_Z), Z, M_<void>(t, PTV_CDB_G_W_ZIN), Z, nullptr, 1.f, 1, 0, 0, 0, stream));
+  PTV_TRY(ptv_colsum(M_<float>(t, PTV_CDB_G_B_ZIN), dz_in, Zi, B, Zi, nullptr, 1, 0, stream));
+  return PTV_OK;
+}

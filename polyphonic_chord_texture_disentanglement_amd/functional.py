@@ -1958,6 +1958,80 @@ CHD_PARAM_NAMES = ['init_input', 'z2dec_hid.weight', 'z2dec_hid.bias', 'z2dec_in
                    'bass_out.weight', 'bass_out.bias']
 
 
+CHD_BWD_COMPOSITE = True      # ChordDecoderTFFn.backward through ptv_chord_decoder_bwd (one C call: 26 launches + the persistent launch's turn)
+_CDB = {}
+
+
+def _chord_decoder_bwd_composite(P, st, z, droot, dchroma, dbass):
+    """-> (dz, {name: gradient}) when ptv_chord_decoder_bwd ran, else None (the caller sequences the launches itself: same bits)"""
+    if 't' not in _CDB:
+        from ._lib import header_enum
+        _CDB['t'], _CDB['d'] = header_enum('PtvCdbTensor'), header_enum('PtvCdbDim')
+    T_, D_ = _CDB['t'], _CDB['d']
+    prec, T, B, H, I = st['prec'], st['T'], st['B'], st['H'], st['I']
+    dev = z.device
+    hall, gates, toks, z_in = st['hall'], st['gates'], st['toks'], st['z_in']
+    dls = []
+    for dl in (droot, dchroma, dbass):
+        if dl is not None:
+            dl = dl.contiguous()
+            if dl.dtype != F32:
+                return None
+        dls.append(dl)
+    adt = _act_dtype(prec, H)
+    if (torch.cuda.is_current_stream_capturing() or hall.dtype != F32 or gates.dtype != adt or z.dtype != F32 or not z.is_contiguous()
+            or not hall.is_contiguous() or not gates.is_contiguous() or not toks.is_contiguous() or not z_in.is_contiguous()):
+        return None                      # (inside a capture the persistent launch's turn must go through wait_event(): the Python path)
+    w_hh = P['gru.weight_hh_l0']
+    wt = _WT(w_hh, prec) if adt == BF16 else None
+    persist = bool(adt == BF16 and wt is not None and T >= 2 and persist_supported(1, B, H, T))
+    S = persist_splitk(1, B, H) if persist else 0
+    Z, Zi = z.shape[1], z_in.shape[1]
+    dims = [0] * D_['PTV_CDB_D_COUNT']
+    for k, v in (('B', B), ('T', T), ('H', H), ('I', I), ('Z', Z), ('ZI', Zi), ('PREC', prec), ('ACT_BF16', int(adt == BF16)),
+                 ('NROOT', P['root_out.weight'].shape[0]), ('NCHROMA', P['chroma_out.weight'].shape[0]), ('NBASS', P['bass_out.weight'].shape[0]),
+                 ('PERSIST', int(persist)), ('SPLITK', S)):
+        dims[D_['PTV_CDB_D_' + k]] = v
+    G = {n: _gbuf(P[n]) for n in CHD_PARAM_NAMES}
+    dz = _empty(B, Z, dev=dev)
+    tens = {'Z': z, 'W_ZHID': P['z2dec_hid.weight'], 'W_ZIN': P['z2dec_in.weight'], 'W_IH': P['gru.weight_ih_l0'], 'W_HH': w_hh,
+            'W_ROOT': P['root_out.weight'], 'W_CHROMA': P['chroma_out.weight'], 'W_BASS': P['bass_out.weight'], 'WT16_HH': wt,
+            'HALL': hall, 'GATES': gates, 'TOKS': toks, 'Z_IN': z_in, 'DROOT': dls[0], 'DCHROMA': dls[1], 'DBASS': dls[2], 'DZ': dz,
+            'G_INIT_INPUT': G['init_input'], 'G_W_ZHID': G['z2dec_hid.weight'], 'G_B_ZHID': G['z2dec_hid.bias'], 'G_W_ZIN': G['z2dec_in.weight'],
+            'G_B_ZIN': G['z2dec_in.bias'], 'G_W_IH': G['gru.weight_ih_l0'], 'G_B_IH': G['gru.bias_ih_l0'], 'G_W_HH': G['gru.weight_hh_l0'],
+            'G_B_HH': G['gru.bias_hh_l0'], 'G_W_ROOT': G['root_out.weight'], 'G_B_ROOT': G['root_out.bias'], 'G_W_CHROMA': G['chroma_out.weight'],
+            'G_B_CHROMA': G['chroma_out.bias'], 'G_W_BASS': G['bass_out.weight'], 'G_B_BASS': G['bass_out.bias'],
+            'DHS': _empty(T * B, H, dev=dev), 'DGI': _empty(T, B, 3 * H, dev=dev, dtype=adt), 'DGH': _empty(T, B, 3 * H, dev=dev, dtype=adt),
+            'DHZ': None if persist else _empty(2, B, H, dev=dev), 'DH0': _empty(B, H, dev=dev), 'DZG': _empty(B, 3 * H, dev=dev),
+            'DZ_IN': _empty(B, Zi, dev=dev), 'DTOK0': _empty(B, I, dev=dev),
+            'XCH': torch.empty(T * B * 3 * H, device=dev, dtype=BF16) if persist else None,
+            'PART': torch.empty(lib().ptv_gru_persist_part_elems(1, B, H, S), device=dev) if S else None,
+            'SYNC': _persist_sync(1, dev) if persist else None}
+    slots = [None] * T_['PTV_CDB_COUNT']
+    for k, v in tens.items():
+        slots[T_['PTV_CDB_' + k]] = ptr(v)
+    cur = cur_stream()
+    done = None
+    if persist:
+        prev = _PERSIST_LAST.get(cur.device.index)
+        done = torch.cuda.Event()
+        if prev is not None:
+            slots[T_['PTV_CDB_WAIT_EVENT']] = prev.cuda_event
+        done.record(cur)                  # creates the handle; the library records it again after the persistent launch
+        slots[T_['PTV_CDB_RECORD_EVENT']] = done.cuda_event
+    _chain_prio()
+    rc = lib().ptv_chord_decoder_bwd((ctypes.c_void_p * len(slots))(*slots), _larr(dims), stream_ptr())
+    if rc == -3:
+        return None
+    check(rc, 'ptv_chord_decoder_bwd')
+    if done is not None:
+        _PERSIST_LAST[cur.device.index] = done
+    _CDB['calls'] = _CDB.get('calls', 0) + 1
+    # (the scratch tensors die here while the launches are only queued: the caching allocator reuses a block in stream order; the gradient
+    # views must NOT be kept anywhere -- a second reference makes AccumulateGrad clone instead of adopt them)
+    return dz, G
+
+
 class ChordDecoderTFFn(torch.autograd.Function):
     """(z_chd [B,Z], c_sm [8,B,36] step-major, *params) -> root [8,B,12], chroma [8,B,24], bass [8,B,12]"""
 
@@ -2033,6 +2107,11 @@ class ChordDecoderTFFn(torch.autograd.Function):
         prec, T, B, H, I = st['prec'], st['T'], st['B'], st['H'], st['I']
         dev = z.device
         hall, toks = st['hall'], st['toks']
+        if CHD_BWD_COMPOSITE:
+            res = _chord_decoder_bwd_composite(P, st, z, droot, dchroma, dbass)
+            if res is not None:
+                mark('chd_dec_bwd:end')
+                return (res[0], None, None) + tuple(res[1][n] for n in CHD_PARAM_NAMES)
         hs = hall[1:].view(T * B, H)
         G = {}
         dhs = None

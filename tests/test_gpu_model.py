@@ -110,16 +110,17 @@ def test_decoder_tf_composite_entry_point_equals_launch_by_launch_and_reference(
         m.load_state_dict(full_params())
         m.to(DEV).set_precision('bf16')
         opt = FusedClipAdam(m.parameters(), lr=1e-3)
-        old, F_.DEC_COMPOSITE, F_.CHD_COMPOSITE = (F_.DEC_COMPOSITE, F_.CHD_COMPOSITE), comp, comp
-        calls, chd_calls = F_._DTF.get('calls', 0), F_._DTF.get('chd_calls', 0)
+        old, F_.DEC_COMPOSITE, F_.CHD_COMPOSITE, F_.CHD_BWD_COMPOSITE = (F_.DEC_COMPOSITE, F_.CHD_COMPOSITE, F_.CHD_BWD_COMPOSITE), comp, comp, comp
+        calls, chd_calls, bwd_calls = F_._DTF.get('calls', 0), F_._DTF.get('chd_calls', 0), F_._CDB.get('calls', 0)
         try:
             opt.zero_grad()
             outs, losses = _run(m, g, x, c, pr)
             losses[0].backward()
         finally:
-            F_.DEC_COMPOSITE, F_.CHD_COMPOSITE = old
+            F_.DEC_COMPOSITE, F_.CHD_COMPOSITE, F_.CHD_BWD_COMPOSITE = old
         assert (F_._DTF.get('calls', 0) > calls) == comp                    # the composites really ran (or really did not)
         assert (F_._DTF.get('chd_calls', 0) > chd_calls) == comp
+        assert (F_._CDB.get('calls', 0) > bwd_calls) == comp                # ... ptv_chord_decoder_bwd too
         res[comp] = (np.array([l.item() for l in losses]), {k: p.grad.detach().clone() for k, p in m.named_parameters()},
                      outs[0].detach().clone(), outs[1].detach().clone())
         F_.persist_check()
@@ -128,6 +129,35 @@ def test_decoder_tf_composite_entry_point_equals_launch_by_launch_and_reference(
     assert torch.equal(res[True][2], res[False][2]) and torch.equal(res[True][3], res[False][3])
     for k in res[True][1]:
         assert torch.equal(res[True][1][k], res[False][1][k]), k
+
+
+@pytest.mark.parametrize('prec,B', [('bf16', 512), ('bf16', 24), ('fp32', 8)])
+def test_chord_decoder_bwd_composite_equals_python_sequencing(prec, B):
+    """ptv_chord_decoder_bwd (one C call: the heads' gradients, the BPTT -- persistent launch with its event turn at B = 512, the per-step
+    kernels otherwise --, every parameter gradient, dz) against ChordDecoderTFFn.backward's own launch sequence: every gradient of the step
+    bit for bit, bf16 and fp32 precision"""
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    x, c, pr = (torch.from_numpy(a).to(DEV) for a in synth_batch(B, 77))
+    res = {}
+    for comp in (True, False):
+        m = M.DisentangleVAE.init_model(torch.device(DEV))
+        m.load_state_dict(full_params())
+        m.to(DEV).set_precision(prec)
+        m.use_philox(11, 0)
+        old, F_.CHD_BWD_COMPOSITE = F_.CHD_BWD_COMPOSITE, comp
+        n0 = F_._CDB.get('calls', 0)
+        try:
+            m.zero_grad()
+            losses = m.loss(x, c, pr, 1., 1., 1., 0.1, [1, 0.5])
+            losses[0].backward()
+            torch.cuda.synchronize()
+        finally:
+            F_.CHD_BWD_COMPOSITE = old
+        assert (F_._CDB.get('calls', 0) > n0) == comp
+        res[comp] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        F_.persist_check()
+    for k in res[True]:
+        assert torch.equal(res[True][k], res[False][k]), k
 
 
 def test_fresh_batch_vs_oracle_with_weighted_outputs():
