@@ -479,6 +479,62 @@ enum PtvCdbDim { PTV_CDB_D_B = 0, PTV_CDB_D_T, PTV_CDB_D_H, PTV_CDB_D_I, PTV_CDB
                  PTV_CDB_D_NROOT, PTV_CDB_D_NCHROMA, PTV_CDB_D_NBASS, PTV_CDB_D_PERSIST, PTV_CDB_D_SPLITK, PTV_CDB_D_COUNT };
 int ptv_chord_decoder_bwd(const void* const* tensors, const long* dims, void* stream);
 
+/* ptv_decoder_tf_bwd: autograd through PtvaeDecoder.decoder, teacher-forced (ptvae.py:430-496) -- what functional.decoder_bwd_core sequences
+ * on its fused bf16 path at the init_model() sizes: the chain  duration-GRU BPTT -> heads -> notes-GRU BPTT -> note-token / time-state
+ * gradients -> time-GRU BPTT (persistent, split-K teams, event turn) -> dTOKS, dz  on `stream`, and the four groups of weight / bias
+ * gradient products on the SIDE stream, each forked (event record / wait) where the Python sequencing forks it.  The caller joins the side
+ * stream (or defers the join) and keeps every tensor of the table alive until then.  ~50 launches, the same arithmetic launch by launch
+ * (bit-identical results).  Every G_* slot is the parameter's gradient buffer and is ACCUMULATED into.  TOP_H: device int, the last note
+ * step whose gradient is non-zero (zero-skip limit of the head / duration products), or NULL = dense. */
+enum PtvDtbTensor {
+  /* inputs */
+  PTV_DTB_Z = 0,          /* [B, Zs] fp32 */
+  PTV_DTB_TOK_OP,         /* [15 R, E] fp32: the note tokens fed to the notes GRU */
+  PTV_DTB_DP,             /* [M, ldp] fp32: gradient of the pitch logits; ACCUMULATED into (dP += dHD0 . W_dh[:, Hn:]) */
+  PTV_DTB_DDUR,           /* [M, 10] fp32 */
+  PTV_DTB_TOP_H,
+  /* parameters (fp32 masters) and their packed / transposed bf16 forms */
+  PTV_DTB_W_HH_D, PTV_DTB_B_HH_D, PTV_DTB_W_IH_D, PTV_DTB_W_OUT_D, PTV_DTB_SOS,
+  PTV_DTB_PK_WDPT, PTV_DTB_PK_WCAT,                      /* heads_packs: 'wdpT', 'wcat' */
+  PTV_DTB_PK_NOTES_WT,                                   /* notes_packs: 'wt' */
+  PTV_DTB_WT_IH_N, PTV_DTB_WT_T2N, PTV_DTB_WT_IH_T, PTV_DTB_WT_HH_T, PTV_DTB_WT_ZHID, PTV_DTB_WT_ZIN,   /* transposed bf16 shadows [in, out] */
+  /* saved by the forward */
+  PTV_DTB_NS, PTV_DTB_NS16, PTV_DTB_Z_IN, PTV_DTB_TOKS, PTV_DTB_GATES_T, PTV_DTB_HN16, PTV_DTB_GATES_N, PTV_DTB_PITCH, PTV_DTB_HD16,
+  PTV_DTB_TAB0, PTV_DTB_TAB, PTV_DTB_IDX,
+  /* outputs */
+  PTV_DTB_DZ,             /* [B, Zs] */
+  PTV_DTB_DTOK,           /* [16, R, E] (slot 15 zeroed here) */
+  PTV_DTB_DTOKS,          /* [33, B, 2He] (slot 32 zeroed here) */
+  /* gradient buffers, DEC_PARAM_NAMES order */
+  PTV_DTB_G_W_ZHID, PTV_DTB_G_B_ZHID, PTV_DTB_G_W_ZIN, PTV_DTB_G_B_ZIN, PTV_DTB_G_INIT_INPUT,
+  PTV_DTB_G_W_IH_T, PTV_DTB_G_W_HH_T, PTV_DTB_G_B_IH_T, PTV_DTB_G_B_HH_T,
+  PTV_DTB_G_W_T2N, PTV_DTB_G_B_T2N,
+  PTV_DTB_G_W_IH_N, PTV_DTB_G_W_HH_N, PTV_DTB_G_B_IH_N, PTV_DTB_G_B_HH_N,
+  PTV_DTB_G_W_P, PTV_DTB_G_B_P, PTV_DTB_G_W_DH, PTV_DTB_G_B_DH, PTV_DTB_G_W_OUT_D, PTV_DTB_G_B_OUT_D,
+  PTV_DTB_G_W_IH_D, PTV_DTB_G_W_HH_D, PTV_DTB_G_B_IH_D, PTV_DTB_G_B_HH_D, PTV_DTB_G_SOS,
+  /* scratch */
+  PTV_DTB_DHD0,           /* [M, Hd] fp32 */
+  PTV_DTB_PART,           /* [NBLK, ptv_dur_gru_bwd_part_size()] fp32 */
+  PTV_DTB_S,              /* [part_size] fp32, ZEROED by the caller */
+  PTV_DTB_TMP64,          /* [64] fp32, ZEROED */
+  PTV_DTB_DNSUM,          /* [M, Hn] bf16 */
+  PTV_DTB_DY16,           /* [M, 200] bf16 */
+  PTV_DTB_TMP200,         /* [200, Hn] fp32 */
+  PTV_DTB_CS200,          /* [200] fp32, ZEROED */
+  PTV_DTB_DGI_N, PTV_DTB_DGH_N, PTV_DTB_DHN0, PTV_DTB_SCRATCH_N,
+  PTV_DTB_TOP_STEP,       /* device int initialised to -1 */
+  PTV_DTB_DGC, PTV_DTB_DNS,
+  PTV_DTB_DGI_T, PTV_DTB_DGH_T, PTV_DTB_DZHID, PTV_DTB_DZG, PTV_DTB_DZ_IN,
+  PTV_DTB_XCH, PTV_DTB_PART_T, PTV_DTB_SYNC,             /* the time GRU's persistent BPTT */
+  PTV_DTB_WAIT_EVENT, PTV_DTB_RECORD_EVENT,              /* hipEvent_t: persistent launches take turns */
+  PTV_DTB_SIDE_STREAM,    /* hipStream_t of the sibling stream */
+  PTV_DTB_FORK_EVENT0, PTV_DTB_FORK_EVENT1, PTV_DTB_FORK_EVENT2, PTV_DTB_FORK_EVENT3,   /* hipEvent_t, one per fork */
+  PTV_DTB_COUNT
+};
+enum PtvDtbDim { PTV_DTB_D_B = 0, PTV_DTB_D_E, PTV_DTB_D_HE, PTV_DTB_D_HT, PTV_DTB_D_HN, PTV_DTB_D_HD, PTV_DTB_D_NP, PTV_DTB_D_ZS, PTV_DTB_D_ZI,
+                 PTV_DTB_D_LDP, PTV_DTB_D_NBLK, PTV_DTB_D_SPLITK, PTV_DTB_D_COUNT };
+int ptv_decoder_tf_bwd(const void* const* tensors, const long* dims, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Free-running tokens.
  * ptv_note_token (ptvae.py:408-416 + pitch_dur_ind_to_note_token :328-334): per row pitch argmax (first

@@ -223,3 +223,147 @@ extern "C" int ptv_chord_decoder_bwd(const void* const* t, const long* d, void* 
   PTV_TRY(ptv_colsum(M_<float>(t, PTV_CDB_G_B_ZIN), dz_in, Zi, B, Zi, nullptr, 1, 0, stream));
   return PTV_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// ptv_decoder_tf_bwd: the backward of ptv_decoder_tf_fwd (functional.decoder_bwd_core's launch sequence on its fused bf16 path, bit-identical
+// to it).  Chain on `stream`; the parameter-gradient products on the side stream, forked where the Python sequencing forks them.
+// ---------------------------------------------------------------------------------------------
+extern "C" int ptv_decoder_tf_bwd(const void* const* t, const long* d, void* stream) {
+  if (!t || !d) return PTV_ERR_ARG;
+  for (int i = 0; i < PTV_DTB_COUNT; i++)
+    if (!t[i] && i != PTV_DTB_TOP_H && i != PTV_DTB_PART_T && i != PTV_DTB_WAIT_EVENT && i != PTV_DTB_RECORD_EVENT) return PTV_ERR_ARG;
+  const int B = (int)d[PTV_DTB_D_B], E = (int)d[PTV_DTB_D_E], He = (int)d[PTV_DTB_D_HE], Ht = (int)d[PTV_DTB_D_HT], Hn = (int)d[PTV_DTB_D_HN],
+            Hd = (int)d[PTV_DTB_D_HD], NP = (int)d[PTV_DTB_D_NP], Zs = (int)d[PTV_DTB_D_ZS], Zi = (int)d[PTV_DTB_D_ZI], nblk = (int)d[PTV_DTB_D_NBLK],
+            S = (int)d[PTV_DTB_D_SPLITK];
+  const long ldp = d[PTV_DTB_D_LDP];
+  if (B <= 0 || E != 128 || Hn != 512 || Hd != 64 || NP != 130 || ldp < NP || nblk <= 0 || (S && !t[PTV_DTB_PART_T])) return PTV_ERR_UNSUPPORTED;
+  const int R = 32 * B;
+  const long M = 15L * R;
+  const int P = PTV_PREC_BF16;
+  hipStream_t s = (hipStream_t)stream, side = (hipStream_t)const_cast<void*>(t[PTV_DTB_SIDE_STREAM]);
+  void* sside = (void*)side;
+  const int psz = ptv_dur_gru_bwd_part_size();
+  const int* top_h = (const int*)T_(t, PTV_DTB_TOP_H);
+  const long top_unit = top_h ? R : 0;
+  auto fork = [&](int k) -> int {                       // the side stream waits for everything queued on `stream` so far
+    hipEvent_t e = (hipEvent_t)const_cast<void*>(t[PTV_DTB_FORK_EVENT0 + k]);
+    if (hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return PTV_ERR_LAUNCH;
+    return PTV_OK;
+  };
+  float* G_ = nullptr; (void)G_;
+#define GB(i) M_<float>(t, i)
+
+  // ================= duration GRU (5 steps): one kernel; its parameter gradients come back as per-block partials
+  float* ddur = GB(PTV_DTB_DDUR); float* dHD0 = GB(PTV_DTB_DHD0); float* part = GB(PTV_DTB_PART);
+  const void* HD16 = T_(t, PTV_DTB_HD16);
+  ptv_gemm_priority(1);
+  PTV_TRY(ptv_dur_gru_bwd(Hd, M, nullptr, M * Hd, 4 * M * Hd, HD16, M * Hd, 1, ddur, 10, (const float*)T_(t, PTV_DTB_W_HH_D),
+                          (const float*)T_(t, PTV_DTB_W_OUT_D), (const int*)T_(t, PTV_DTB_IDX), M, dHD0, part, nblk,
+                          (const float*)T_(t, PTV_DTB_B_HH_D), (const float*)T_(t, PTV_DTB_TAB0), (const float*)T_(t, PTV_DTB_TAB), stream));
+  PTV_TRY(fork(0));
+  ptv_gemm_priority(0);
+  PTV_TRY(ptv_dur_out_wgrad(ddur, 10, HD16, M * Hd, GB(PTV_DTB_G_W_OUT_D), M, Hd, sside));
+  PTV_TRY(ptv_colsum(GB(PTV_DTB_TMP64), ddur, 64, M * 10 / 64, 64, nullptr, 1, 0, sside));      // bias of a 2-column matrix: a 64-column stream, folded
+  PTV_TRY(ptv_colsum(GB(PTV_DTB_G_B_OUT_D), GB(PTV_DTB_TMP64), 2, 32, 2, nullptr, 1, 0, sside));
+  PTV_TRY(ptv_colsum(GB(PTV_DTB_S), part, psz, nblk, psz, nullptr, 1, 0, sside));
+  PTV_TRY(ptv_dur_bwd_finalize(GB(PTV_DTB_S), GB(PTV_DTB_G_W_HH_D), GB(PTV_DTB_G_B_HH_D), GB(PTV_DTB_G_B_IH_D), GB(PTV_DTB_G_W_IH_D), GB(PTV_DTB_G_SOS),
+                               (const float*)T_(t, PTV_DTB_W_IH_D), (const float*)T_(t, PTV_DTB_SOS), 5, sside));
+
+  // ================= the two per-note heads: dP += dHD0 . W_dh[:, Hn:], dNSUM = dP . W_p + dHD0 . W_dh[:, :Hn] in one pass
+  float* dP = GB(PTV_DTB_DP);
+  void* dNSUM = M_<void>(t, PTV_DTB_DNSUM); void* dY16 = M_<void>(t, PTV_DTB_DY16);
+  ptv_gemm_priority(1);
+  PTV_TRY(ptv_heads_bwd(dP, ldp, dHD0, T_(t, PTV_DTB_PK_WDPT), T_(t, PTV_DTB_PK_WCAT), dNSUM, 1, dY16, top_h, top_unit, M, stream));
+  PTV_TRY(fork(1));
+  ptv_gemm_priority(0);
+  {
+    const __bf16* HN16 = (const __bf16*)T_(t, PTV_DTB_HN16);
+    const __bf16* nsum = HN16 + (long)R * Hn;                       // the note summaries = states 1 .. 15
+    float* tmp = GB(PTV_DTB_TMP200); float* cs = GB(PTV_DTB_CS200);
+    PTV_TRY(ptv_wgrad(200, Hn, (int)M, dY16, 200, nsum, Hn, tmp, Hn, 1.f, 0, 3, 0, cs, top_h, top_unit, 0, sside));
+    PTV_TRY(ptv_copy2d(GB(PTV_DTB_G_W_P), Hn, tmp, Hn, NP, Hn, 1.f, 1, sside));
+    PTV_TRY(ptv_copy2d(GB(PTV_DTB_G_B_P), NP, cs, NP, 1, NP, 1.f, 1, sside));
+    PTV_TRY(ptv_copy2d(GB(PTV_DTB_G_W_DH), (long)Hn + NP, tmp + 136L * Hn, Hn, Hd, Hn, 1.f, 1, sside));
+    PTV_TRY(ptv_copy2d(GB(PTV_DTB_G_B_DH), Hd, cs + 136, Hd, 1, Hd, 1.f, 1, sside));
+    PTV_TRY(ptv_wgrad(Hd, NP, (int)M, dHD0, Hd, T_(t, PTV_DTB_PITCH), ldp, GB(PTV_DTB_G_W_DH) + Hn, (long)Hn + NP, 1.f, 1, 0, 0, nullptr, top_h,
+                      top_unit, 0, sside));
+  }
+
+  // ================= notes GRU (15 steps x 32 B rows): BPTT, then the gradients of the fed tokens and of the time states
+  void* dgi_n = M_<void>(t, PTV_DTB_DGI_N); void* dgh_n = M_<void>(t, PTV_DTB_DGH_N);
+  float* dHN0 = GB(PTV_DTB_DHN0); int* top_step = M_<int>(t, PTV_DTB_TOP_STEP);
+  float* dGC = GB(PTV_DTB_DGC); float* dNS = GB(PTV_DTB_DNS); float* dtok = GB(PTV_DTB_DTOK);
+  const __bf16* wt_ih_n = (const __bf16*)T_(t, PTV_DTB_WT_IH_N);   // [Ht + E, 3Hn]
+  ptv_gemm_priority(1);
+  PTV_TRY(ptv_notes_gru_persist_bwd(T_(t, PTV_DTB_PK_NOTES_WT), T_(t, PTV_DTB_HN16), T_(t, PTV_DTB_GATES_N), dNSUM, dgi_n, dgh_n, dHN0,
+                                    M_<void>(t, PTV_DTB_SCRATCH_N), R, 15, top_step, stream));
+  PTV_TRY(ptv_sum_steps_top(dGC, dgi_n, (long)R * 3 * Hn, 15, (long)R * 3 * Hn, 0, 1, top_step, stream));
+  if (hipMemsetAsync(dtok + 15L * R * E, 0, sizeof(float) * R * E, s) != hipSuccess) return PTV_ERR_LAUNCH;
+  PTV_TRY(ptv_gemm_mtop(P, 0, 0, (int)M, E, 3 * Hn, dgi_n, 3L * Hn, wt_ih_n + (long)Ht * 3 * Hn, 3L * Hn, dtok, E, nullptr, 1.f, 0, 0, 0, A16 | B16,
+                        top_step, R, stream));
+  PTV_TRY(ptv_gemm(P, 0, 0, R, Ht, 3 * Hn, dGC, 3L * Hn, wt_ih_n, 3L * Hn, dNS, Ht, nullptr, 1.f, 0, 0, 0, B16, stream));
+  PTV_TRY(ptv_gemm(P, 0, 0, R, Ht, Hn, dHN0, Hn, T_(t, PTV_DTB_WT_T2N), Hn, dNS, Ht, nullptr, 1.f, 1, 0, 0, B16, stream));
+  PTV_TRY(fork(2));
+  ptv_gemm_priority(0);
+  {
+    const __bf16* HN16 = (const __bf16*)T_(t, PTV_DTB_HN16);      // states 0 .. 14: the operand of the W_hh gradient
+    const __bf16* NSf = (const __bf16*)T_(t, PTV_DTB_NS16) + (long)B * Ht;
+    float* gw = GB(PTV_DTB_G_W_HH_N); float* gb = GB(PTV_DTB_G_B_HH_N); float* gih = GB(PTV_DTB_G_W_IH_N);
+    PTV_TRY(ptv_wgrad(2 * Hn, Hn, (int)M, dgi_n, 3L * Hn, HN16, Hn, gw, Hn, 1.f, 1, 3, 0, gb, top_step, R, 0, sside));
+    PTV_TRY(ptv_wgrad(Hn, Hn, (int)M, dgh_n, Hn, HN16, Hn, gw + 2L * Hn * Hn, Hn, 1.f, 1, 3, 0, gb + 2 * Hn, top_step, R, 0, sside));
+    PTV_TRY(ptv_colsum(GB(PTV_DTB_G_B_IH_N), dGC, 3L * Hn, R, 3 * Hn, nullptr, 1, 0, sside));
+    PTV_TRY(ptv_gemm(P, 1, 1, 3 * Hn, Ht, R, dGC, 3L * Hn, NSf, Ht, gih, (long)Ht + E, nullptr, 1.f, 1, 0, 0, B16, sside));
+    PTV_TRY(ptv_wgrad(3 * Hn, E, (int)M, dgi_n, 3L * Hn, T_(t, PTV_DTB_TOK_OP), E, gih + Ht, (long)Ht + E, 1.f, 1, 1, 0, nullptr, top_step, R, 0, sside));
+    PTV_TRY(ptv_gemm(P, 1, 1, Hn, Ht, R, dHN0, Hn, NSf, Ht, GB(PTV_DTB_G_W_T2N), Ht, nullptr, 1.f, 1, 0, 0, B16, sside));
+    PTV_TRY(ptv_colsum(GB(PTV_DTB_G_B_T2N), dHN0, Hn, R, Hn, nullptr, 1, 0, sside));
+  }
+
+  // ================= time GRU (32 steps x B rows): one persistent launch, split-K teams; then dTOKS and dz
+  void* dgi_t = M_<void>(t, PTV_DTB_DGI_T); void* dgh_t = M_<void>(t, PTV_DTB_DGH_T);
+  float* dzhid = GB(PTV_DTB_DZHID); float* dZG = GB(PTV_DTB_DZG); float* dz_in = GB(PTV_DTB_DZ_IN); float* dTOKS = GB(PTV_DTB_DTOKS);
+  float* dz = GB(PTV_DTB_DZ);
+  const __bf16* wt_ih_t = (const __bf16*)T_(t, PTV_DTB_WT_IH_T);   // [2He + Zi, 3Ht]
+  ptv_gemm_priority(1);
+  {
+    const float* hall_[1] = {(const float*)T_(t, PTV_DTB_NS)}; const void* gates_[1] = {T_(t, PTV_DTB_GATES_T)};
+    const void* wt_[1] = {T_(t, PTV_DTB_WT_HH_T)};
+    const void* ext_[1] = {dNS}; const long ext_step[1] = {(long)B * Ht}, ext_ld[1] = {(long)Ht}; const int ext_bf[1] = {0};
+    const float* last_[1] = {nullptr}; const long last_ld[1] = {0};
+    void* dgi_[1] = {dgi_t}; void* dgh_[1] = {dgh_t}; float* dh0_[1] = {dzhid}; const int rev[1] = {0};
+    void* xch_[1] = {M_<void>(t, PTV_DTB_XCH)}; float* part_[1] = {M_<float>(t, PTV_DTB_PART_T)};
+    if (t[PTV_DTB_WAIT_EVENT] && hipStreamWaitEvent(s, (hipEvent_t)const_cast<void*>(t[PTV_DTB_WAIT_EVENT]), 0) != hipSuccess) return PTV_ERR_LAUNCH;
+    if (S) PTV_TRY(ptv_gru_persist_bwd_splitk(S, 1, B, Ht, 32, hall_, gates_, wt_, ext_, ext_step, ext_ld, ext_bf, last_, last_ld, dgi_, dgh_, dh0_,
+                                              rev, xch_, part_, M_<unsigned>(t, PTV_DTB_SYNC), stream));
+    else PTV_TRY(ptv_gru_persist_bwd(1, B, Ht, 32, hall_, gates_, wt_, ext_, ext_step, ext_ld, ext_bf, last_, last_ld, dgi_, dgh_, dh0_, rev, xch_,
+                                     M_<unsigned>(t, PTV_DTB_SYNC), stream));
+    if (t[PTV_DTB_RECORD_EVENT] && hipEventRecord((hipEvent_t)const_cast<void*>(t[PTV_DTB_RECORD_EVENT]), s) != hipSuccess) return PTV_ERR_LAUNCH;
+  }
+  PTV_TRY(ptv_sum_steps_top(dZG, dgi_t, (long)B * 3 * Ht, 32, (long)B * 3 * Ht, 0, 1, nullptr, stream));
+  PTV_TRY(ptv_gemm(P, 0, 0, B, Zi, 3 * Ht, dZG, 3L * Ht, wt_ih_t + 2L * He * 3 * Ht, 3L * Ht, dz_in, Zi, nullptr, 1.f, 0, 0, 0, B16, stream));
+  if (hipMemsetAsync(dTOKS + 32L * B * 2 * He, 0, sizeof(float) * B * 2 * He, s) != hipSuccess) return PTV_ERR_LAUNCH;
+  PTV_TRY(ptv_gemm(P, 0, 0, R, 2 * He, 3 * Ht, dgi_t, 3L * Ht, wt_ih_t, 3L * Ht, dTOKS, 2L * He, nullptr, 1.f, 0, 0, 0, A16 | B16, stream));
+  PTV_TRY(ptv_gemm(P, 0, 0, B, Zs, Ht, dzhid, Ht, T_(t, PTV_DTB_WT_ZHID), Ht, dz, Zs, nullptr, 1.f, 0, 0, 0, B16, stream));
+  PTV_TRY(ptv_gemm(P, 0, 0, B, Zs, Zi, dz_in, Zi, T_(t, PTV_DTB_WT_ZIN), Zi, dz, Zs, nullptr, 1.f, 1, 0, 0, B16, stream));
+  PTV_TRY(fork(3));
+  ptv_gemm_priority(0);
+  {
+    const __bf16* NS16 = (const __bf16*)T_(t, PTV_DTB_NS16);
+    float* g_ih = GB(PTV_DTB_G_W_IH_T); float* gb_ih = GB(PTV_DTB_G_B_IH_T); float* gb_hh = GB(PTV_DTB_G_B_HH_T);
+    const long ld_t = 2L * He + Zi;
+    PTV_TRY(ptv_gemm(P, 1, 1, 3 * Ht, Ht, R, dgh_t, 3L * Ht, NS16, Ht, GB(PTV_DTB_G_W_HH_T), Ht, nullptr, 1.f, 1, 0, 0, A16 | B16, sside));
+    PTV_TRY(ptv_colsum(gb_ih, dZG, 3L * Ht, B, 3 * Ht, nullptr, 1, 0, sside));
+    // bias_hh: dgi and dgh share their r and z thirds (the column sums are copied), only the n third is summed
+    PTV_TRY(ptv_copy2d(gb_hh, 3L * Ht, gb_ih, 3L * Ht, 1, 2 * Ht, 1.f, 1, sside));
+    PTV_TRY(ptv_colsum(gb_hh + 2 * Ht, (const __bf16*)dgh_t + 2 * Ht, 3L * Ht, R, Ht, nullptr, 1, 1, sside));
+    PTV_TRY(ptv_gemm(P, 1, 1, 3 * Ht, Zi, B, dZG, 3L * Ht, T_(t, PTV_DTB_Z_IN), Zi, g_ih + 2 * He, ld_t, nullptr, 1.f, 1, 0, 0, 0, sside));
+    PTV_TRY(ptv_gemm(P, 1, 1, 3 * Ht, 2 * He, R, dgi_t, 3L * Ht, T_(t, PTV_DTB_TOKS), 2L * He, g_ih, ld_t, nullptr, 1.f, 1, 0, 0, A16, sside));
+    PTV_TRY(ptv_colsum(GB(PTV_DTB_G_INIT_INPUT), dTOKS, 2L * He, B, 2 * He, nullptr, 1, 0, sside));
+    PTV_TRY(ptv_gemm(P, 1, 1, Ht, Zs, B, dzhid, Ht, T_(t, PTV_DTB_Z), Zs, GB(PTV_DTB_G_W_ZHID), Zs, nullptr, 1.f, 1, 0, 0, 0, sside));
+    PTV_TRY(ptv_colsum(GB(PTV_DTB_G_B_ZHID), dzhid, Ht, B, Ht, nullptr, 1, 0, sside));
+    PTV_TRY(ptv_gemm(P, 1, 1, Zi, Zs, B, dz_in, Zi, T_(t, PTV_DTB_Z), Zs, GB(PTV_DTB_G_W_ZIN), Zs, nullptr, 1.f, 1, 0, 0, 0, sside));
+    PTV_TRY(ptv_colsum(GB(PTV_DTB_G_B_ZIN), dz_in, Zi, B, Zi, nullptr, 1, 0, sside));
+  }
+  ptv_gemm_priority(1);
+#undef GB
+  return PTV_OK;
+}

@@ -1706,6 +1706,113 @@ class DecoderTFFn(torch.autograd.Function):
         return (dz, demb_out, dTOKS[1:].view(R, 2 * He), None, None) + tuple(G[n] for n in DEC_PARAM_NAMES)
 
 
+DEC_BWD_COMPOSITE = True      # decoder_bwd_core's fused bf16 path through ptv_decoder_tf_bwd (one C call: ~50 launches, four forks, the persistent turn)
+_DTB = {}
+_DTB_G = (('W_ZHID', 'z2dec_hid_linear.weight'), ('B_ZHID', 'z2dec_hid_linear.bias'), ('W_ZIN', 'z2dec_in_linear.weight'),
+          ('B_ZIN', 'z2dec_in_linear.bias'), ('INIT_INPUT', 'dec_init_input'), ('W_IH_T', 'dec_time_gru.weight_ih_l0'),
+          ('W_HH_T', 'dec_time_gru.weight_hh_l0'), ('B_IH_T', 'dec_time_gru.bias_ih_l0'), ('B_HH_T', 'dec_time_gru.bias_hh_l0'),
+          ('W_T2N', 'dec_time_to_notes_hid.weight'), ('B_T2N', 'dec_time_to_notes_hid.bias'), ('W_IH_N', 'dec_notes_gru.weight_ih_l0'),
+          ('W_HH_N', 'dec_notes_gru.weight_hh_l0'), ('B_IH_N', 'dec_notes_gru.bias_ih_l0'), ('B_HH_N', 'dec_notes_gru.bias_hh_l0'),
+          ('W_P', 'pitch_out_linear.weight'), ('B_P', 'pitch_out_linear.bias'), ('W_DH', 'dur_hid_linear.weight'),
+          ('B_DH', 'dur_hid_linear.bias'), ('W_OUT_D', 'dur_out_linear.weight'), ('B_OUT_D', 'dur_out_linear.bias'),
+          ('W_IH_D', 'dec_dur_gru.weight_ih_l0'), ('W_HH_D', 'dec_dur_gru.weight_hh_l0'), ('B_IH_D', 'dec_dur_gru.bias_ih_l0'),
+          ('B_HH_D', 'dec_dur_gru.bias_hh_l0'), ('SOS', 'dur_sos_token'))
+
+
+def _decoder_bwd_composite(P, st, z, tok_op, dP, ddur, top_h, side, G):
+    """-> decoder_bwd_core's result tuple when ptv_decoder_tf_bwd ran the whole sequence, else None (the caller sequences it: same bits)"""
+    if 't' not in _DTB:
+        from ._lib import header_enum
+        _DTB['t'], _DTB['d'] = header_enum('PtvDtbTensor'), header_enum('PtvDtbDim')
+    T_, D_ = _DTB['t'], _DTB['d']
+    B, R, E, He, Ht, Hn, Hd, NP, prec = (st[k] for k in ('B', 'R', 'E', 'He', 'Ht', 'Hn', 'Hd', 'NP', 'prec'))
+    dev = z.device
+    M = 15 * R
+    HN16, HD16, NS16, gates_n, gates_t = st.get('HN16'), st.get('HD16'), st.get('NS16'), st['gates_n'], st['gates_t']
+    if (prec != 1 or not ZERO_SKIP or not OVERLAP or SUMMARY_FAMILY_SLOT >= 0 or torch.cuda.is_current_stream_capturing()
+            or not st.get('dur16_only') or st['gates_d'] is not None or st.get('dur_tabs') is None or HD16 is None or HN16 is None
+            or NS16 is None or not st.get('gates_n_rowk') or gates_n.dtype != BF16 or gates_t.dtype != BF16 or not HEADS_WGRAD_FUSED
+            or not heads_ok(prec, Hn, NP, Hd, HN16, HD16) or not notes_persist_ok(prec, Hn, E, BF16)
+            or dP.stride(0) != _pad8(NP) or dP.data_ptr() % 16 or not ddur.is_contiguous() or ddur.dtype != F32
+            or tok_op.dtype != F32 or not tok_op.is_contiguous() or z.dtype != F32 or not z.is_contiguous()
+            or not persist_supported(1, B, Ht, 32) or side.s == side.main):
+        return None
+    wts = [_WT(P[n], prec) for n in ('dec_notes_gru.weight_ih_l0', 'dec_time_to_notes_hid.weight', 'dec_time_gru.weight_ih_l0',
+                                      'dec_time_gru.weight_hh_l0', 'z2dec_hid_linear.weight', 'z2dec_in_linear.weight')]
+    if any(w is None for w in wts):
+        return None
+    Zs, Zi = z.shape[1], st['z_in'].shape[1]
+    S = persist_splitk(1, B, Ht)
+    nblk = min(256, (M + 63) // 64)
+    psz = lib().ptv_dur_gru_bwd_part_size()
+    dims = [0] * D_['PTV_DTB_D_COUNT']
+    for k, v in (('B', B), ('E', E), ('HE', He), ('HT', Ht), ('HN', Hn), ('HD', Hd), ('NP', NP), ('ZS', Zs), ('ZI', Zi), ('LDP', _pad8(NP)),
+                 ('NBLK', nblk), ('SPLITK', S)):
+        dims[D_['PTV_DTB_D_' + k]] = v
+    hp = heads_packs(P['pitch_out_linear.weight'], P['dur_hid_linear.weight'])
+    pk = notes_packs(P['dec_notes_gru.weight_ih_l0'], P['dec_notes_gru.weight_hh_l0'], Ht)
+    for _, n in _DTB_G:
+        G[n] = _gbuf(P[n])
+    dz, dtok, dTOKS = _empty(B, Zs, dev=dev), _empty(16, R, E, dev=dev), _empty(33, B, 2 * He, dev=dev)
+    tab0, tab = st['dur_tabs']
+    tens = {'Z': z, 'TOK_OP': tok_op, 'DP': dP, 'DDUR': ddur, 'TOP_H': top_h,
+            'W_HH_D': P['dec_dur_gru.weight_hh_l0'], 'B_HH_D': P['dec_dur_gru.bias_hh_l0'], 'W_IH_D': P['dec_dur_gru.weight_ih_l0'],
+            'W_OUT_D': P['dur_out_linear.weight'], 'SOS': P['dur_sos_token'], 'PK_WDPT': hp['wdpT'], 'PK_WCAT': hp['wcat'],
+            'PK_NOTES_WT': pk['wt'], 'WT_IH_N': wts[0], 'WT_T2N': wts[1], 'WT_IH_T': wts[2], 'WT_HH_T': wts[3], 'WT_ZHID': wts[4],
+            'WT_ZIN': wts[5], 'NS': st['NS'], 'NS16': NS16, 'Z_IN': st['z_in'], 'TOKS': st['TOKS'], 'GATES_T': gates_t, 'HN16': HN16,
+            'GATES_N': gates_n, 'PITCH': st['pitch'], 'HD16': HD16, 'TAB0': tab0, 'TAB': tab, 'IDX': st['idx'],
+            'DZ': dz, 'DTOK': dtok, 'DTOKS': dTOKS,
+            'DHD0': _empty(M, Hd, dev=dev), 'PART': _empty(nblk, psz, dev=dev), 'S': _zeros(1, psz, dev=dev), 'TMP64': _zeros(1, 64, dev=dev),
+            'DNSUM': _empty(M, Hn, dev=dev, dtype=BF16), 'DY16': _empty(M, 200, dev=dev, dtype=BF16), 'TMP200': _empty(200, Hn, dev=dev),
+            'CS200': _zeros(200, dev=dev), 'DGI_N': _empty(15, R, 3 * Hn, dev=dev, dtype=BF16), 'DGH_N': _empty(15, R, Hn, dev=dev, dtype=BF16),
+            'DHN0': _empty(R, Hn, dev=dev), 'SCRATCH_N': _empty(lib().ptv_notes_gru_persist_scratch_elems(R), dev=dev, dtype=BF16),
+            'TOP_STEP': _ineg1(dev), 'DGC': _empty(R, 3 * Hn, dev=dev), 'DNS': _empty(R, Ht, dev=dev),
+            'DGI_T': _empty(32, B, 3 * Ht, dev=dev, dtype=BF16), 'DGH_T': _empty(32, B, 3 * Ht, dev=dev, dtype=BF16),
+            'DZHID': _empty(B, Ht, dev=dev), 'DZG': _empty(B, 3 * Ht, dev=dev), 'DZ_IN': _empty(B, Zi, dev=dev),
+            'XCH': torch.empty(32 * B * 3 * Ht, device=dev, dtype=BF16),
+            'PART_T': torch.empty(lib().ptv_gru_persist_part_elems(1, B, Ht, S), device=dev) if S else None,
+            'SYNC': _persist_sync(1, dev)}
+    if st['pitch'].stride(0) != _pad8(NP) or st['idx'].dtype != torch.int32:
+        return None
+    slots = [None] * T_['PTV_DTB_COUNT']
+    for k, v in tens.items():
+        slots[T_['PTV_DTB_' + k]] = ptr(v)
+    for k, n in _DTB_G:
+        slots[T_['PTV_DTB_G_' + k]] = ptr(G[n])
+    cur = cur_stream()
+    evs = _DTB.get(('ev', cur.device.index))
+    if evs is None:                                   # the four fork events, created once (a wait takes the record that precedes it)
+        evs = [torch.cuda.Event() for _ in range(4)]
+        for e in evs:
+            e.record(cur)
+        _DTB[('ev', cur.device.index)] = evs
+    for i, e in enumerate(evs):
+        slots[T_['PTV_DTB_FORK_EVENT%d' % i]] = e.cuda_event
+    slots[T_['PTV_DTB_SIDE_STREAM']] = side.s.cuda_stream
+    prev = _PERSIST_LAST.get(cur.device.index)
+    done = torch.cuda.Event()
+    if prev is not None:
+        slots[T_['PTV_DTB_WAIT_EVENT']] = prev.cuda_event
+    done.record(cur)                      # creates the handle; the library records it again after the persistent launch
+    slots[T_['PTV_DTB_RECORD_EVENT']] = done.cuda_event
+    mark('dec_bwd:composite')
+    rc = lib().ptv_decoder_tf_bwd((ctypes.c_void_p * len(slots))(*slots), _larr(dims), stream_ptr())
+    _SIDE_DEPTH[1] = 1                    # (the library's priority state as the call leaves it)
+    if os.environ.get('PTV_DEBUG_DTB'):
+        print('ptv_decoder_tf_bwd rc', rc, 'S', S, 'nblk', nblk, flush=True)
+    if rc == -3:
+        return None
+    check(rc, 'ptv_decoder_tf_bwd')
+    _PERSIST_LAST[cur.device.index] = done
+    _DTB['calls'] = _DTB.get('calls', 0) + 1
+    st['ev_dtoks'] = None
+    # the sibling stream's products are queued, not run: everything they read or write stays referenced until the join (the caller defers
+    # it to the end of the backward pass) -- EXCEPT the gradient buffers (a second reference makes AccumulateGrad clone them)
+    side.used = True
+    side.keep.extend([v for k, v in tens.items() if v is not None] + [st, z, tok_op])
+    return dz, dtok, dTOKS, G, side
+
+
 def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     """BPTT of the PianoTree decoder given the saved forward state `st` -- shared by the teacher-forced node (DecoderTFFn) and
     the step-loop node (functional_free.DecoderStepFn: argmax is not differentiable, so with the fed tokens recorded every
@@ -1778,6 +1885,11 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
             top_h = _ineg1(dev)
             call('ptv_last_nonzero_unit', ptr(dP), M, NP, dP.stride(0), R, ptr(top_h), stream_ptr())
             call('ptv_last_nonzero_unit', ptr(ddur), M, 10, 10, R, ptr(top_h), stream_ptr())
+
+    if DEC_BWD_COMPOSITE:
+        res = _decoder_bwd_composite(P, st, z, tok_op, dP, ddur, top_h, side, G)
+        if res is not None:
+            return res
 
     # ---- duration GRU (5 steps) ----
     w_out = P['dur_out_linear.weight']

@@ -131,12 +131,15 @@ def test_decoder_tf_composite_entry_point_equals_launch_by_launch_and_reference(
         assert torch.equal(res[True][1][k], res[False][1][k]), k
 
 
-@pytest.mark.parametrize('prec,B', [('bf16', 512), ('bf16', 24), ('fp32', 8)])
-def test_chord_decoder_bwd_composite_equals_python_sequencing(prec, B):
-    """ptv_chord_decoder_bwd (one C call: the heads' gradients, the BPTT -- persistent launch with its event turn at B = 512, the per-step
-    kernels otherwise --, every parameter gradient, dz) against ChordDecoderTFFn.backward's own launch sequence: every gradient of the step
-    bit for bit, bf16 and fp32 precision"""
+@pytest.mark.parametrize('prec,B,via_loss', [('bf16', 512, True), ('bf16', 24, True), ('bf16', 16, False), ('fp32', 8, True)])
+def test_backward_composites_equal_python_sequencing(prec, B, via_loss):
+    """ptv_chord_decoder_bwd and ptv_decoder_tf_bwd (one C call each: the chord decoder's / the PianoTree decoder's whole backward -- chain,
+    the forks of the weight-gradient groups onto the sibling stream, the persistent launches with their event turn) against the launch
+    sequences of ChordDecoderTFFn.backward / decoder_bwd_core: every gradient of the step bit for bit.  bf16 at B = 512 (persistent BPTTs,
+    split-K teams) and small batches, through loss() (the decoder stops at the last live note step) and through run() + loss_function()
+    (all 15 steps); fp32 (the chord decoder's composite takes it, the PianoTree decoder's declines: still the Python path)"""
     from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
     x, c, pr = (torch.from_numpy(a).to(DEV) for a in synth_batch(B, 77))
     res = {}
     for comp in (True, False):
@@ -144,19 +147,25 @@ def test_chord_decoder_bwd_composite_equals_python_sequencing(prec, B):
         m.load_state_dict(full_params())
         m.to(DEV).set_precision(prec)
         m.use_philox(11, 0)
-        old, F_.CHD_BWD_COMPOSITE = F_.CHD_BWD_COMPOSITE, comp
-        n0 = F_._CDB.get('calls', 0)
+        opt = FusedClipAdam(m.parameters(), lr=1e-3)        # (the bf16 weight shadows the composites read are the optimiser's)
+        old, F_.CHD_BWD_COMPOSITE, F_.DEC_BWD_COMPOSITE = (F_.CHD_BWD_COMPOSITE, F_.DEC_BWD_COMPOSITE), comp, comp
+        n0, n1 = F_._CDB.get('calls', 0), F_._DTB.get('calls', 0)
         try:
-            m.zero_grad()
-            losses = m.loss(x, c, pr, 1., 1., 1., 0.1, [1, 0.5])
+            opt.zero_grad()
+            if via_loss:
+                losses = m.loss(x, c, pr, 1., 1., 1., 0.1, [1, 0.5])
+            else:
+                losses = m.loss_function(x, c, *m.run(x, c, pr, 1., 1., 1.), 0.1, [1, 0.5])
             losses[0].backward()
             torch.cuda.synchronize()
         finally:
-            F_.CHD_BWD_COMPOSITE = old
+            F_.CHD_BWD_COMPOSITE, F_.DEC_BWD_COMPOSITE = old
         assert (F_._CDB.get('calls', 0) > n0) == comp
+        assert (F_._DTB.get('calls', 0) > n1) == (comp and prec == 'bf16')
         res[comp] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
         F_.persist_check()
     for k in res[True]:
+        assert torch.isfinite(res[True][k]).all(), k
         assert torch.equal(res[True][k], res[False][k]), k
 
 
