@@ -1706,7 +1706,9 @@ class DecoderTFFn(torch.autograd.Function):
         return (dz, demb_out, dTOKS[1:].view(R, 2 * He), None, None) + tuple(G[n] for n in DEC_PARAM_NAMES)
 
 
-DEC_BWD_COMPOSITE = True      # decoder_bwd_core's fused bf16 path through ptv_decoder_tf_bwd (one C call: ~50 launches, four forks, the persistent turn)
+# decoder_bwd_core's fused bf16 path through ptv_decoder_tf_bwd (one C call: ~50 launches, four forks, the persistent turn);
+# PTV_BWD_COMPOSITES=0: both backward composites off -- the same launches sequenced from Python (bit-identical)
+DEC_BWD_COMPOSITE = os.environ.get('PTV_BWD_COMPOSITES', '1') != '0'
 _DTB = {}
 _DTB_G = (('W_ZHID', 'z2dec_hid_linear.weight'), ('B_ZHID', 'z2dec_hid_linear.bias'), ('W_ZIN', 'z2dec_in_linear.weight'),
           ('B_ZIN', 'z2dec_in_linear.bias'), ('INIT_INPUT', 'dec_init_input'), ('W_IH_T', 'dec_time_gru.weight_ih_l0'),
@@ -1798,8 +1800,6 @@ def _decoder_bwd_composite(P, st, z, tok_op, dP, ddur, top_h, side, G):
     mark('dec_bwd:composite')
     rc = lib().ptv_decoder_tf_bwd((ctypes.c_void_p * len(slots))(*slots), _larr(dims), stream_ptr())
     _SIDE_DEPTH[1] = 1                    # (the library's priority state as the call leaves it)
-    if os.environ.get('PTV_DEBUG_DTB'):
-        print('ptv_decoder_tf_bwd rc', rc, 'S', S, 'nblk', nblk, flush=True)
     if rc == -3:
         return None
     check(rc, 'ptv_decoder_tf_bwd')
@@ -2070,7 +2070,7 @@ CHD_PARAM_NAMES = ['init_input', 'z2dec_hid.weight', 'z2dec_hid.bias', 'z2dec_in
                    'bass_out.weight', 'bass_out.bias']
 
 
-CHD_BWD_COMPOSITE = True      # ChordDecoderTFFn.backward through ptv_chord_decoder_bwd (one C call: 26 launches + the persistent launch's turn)
+CHD_BWD_COMPOSITE = os.environ.get('PTV_BWD_COMPOSITES', '1') != '0'     # ChordDecoderTFFn.backward through ptv_chord_decoder_bwd (one C call: 26 launches + the persistent launch's turn)
 _CDB = {}
 
 
