@@ -535,6 +535,27 @@ enum PtvDtbDim { PTV_DTB_D_B = 0, PTV_DTB_D_E, PTV_DTB_D_HE, PTV_DTB_D_HT, PTV_D
                  PTV_DTB_D_LDP, PTV_DTB_D_NBLK, PTV_DTB_D_SPLITK, PTV_DTB_D_COUNT };
 int ptv_decoder_tf_bwd(const void* const* tensors, const long* dims, void* stream);
 
+/* ptv_bigru_final_bwd: autograd through a bidirectional GRU whose final states are its output (RnnEncoder / TextureEncoder, ptvae.py:23-31,
+ * 116-122), bf16 precision, both directions' BPTT in ONE persistent launch (event turn in here), then per direction the weight / bias
+ * gradients dW_ih += dgi^T . x, dW_hh += dgh^T . h (bias sums fused) -- the reversed direction's on the side stream, forked and joined in
+ * here -- and, with DX, the input gradient dx (+)= dgi_0 . W_ih_0 + dgi_1 . W_ih_1.  What functional._bigru_backward sequences on its
+ * persistent branch, bit-identical to it.  G_* slots are accumulated into. */
+enum PtvBgbTensor {
+  PTV_BGB_X = 0,          /* [T*M, I] the forward's input rows (fp32, or bf16 with d[PTV_BGB_D_X_BF16]) */
+  PTV_BGB_DOUT,           /* [M, 2H] fp32: gradient of the two final states */
+  PTV_BGB_HALL0, PTV_BGB_H16_0, PTV_BGB_GATES0, PTV_BGB_WT_HH0, PTV_BGB_WT_IH0,   /* forward direction: fp32 / bf16 states [T+1, M, H], gate planes,
+                                                                                   * bf16 W_hh^T [H, 3H], bf16 W_ih^T [I, 3H] (NULL without DX) */
+  PTV_BGB_HALL1, PTV_BGB_H16_1, PTV_BGB_GATES1, PTV_BGB_WT_HH1, PTV_BGB_WT_IH1,   /* reversed direction */
+  PTV_BGB_G_W_IH0, PTV_BGB_G_W_HH0, PTV_BGB_G_B_IH0, PTV_BGB_G_B_HH0, PTV_BGB_G_W_IH1, PTV_BGB_G_W_HH1, PTV_BGB_G_B_IH1, PTV_BGB_G_B_HH1,
+  PTV_BGB_DX,             /* out [T*M, I] fp32, or NULL: no input gradient wanted */
+  PTV_BGB_DGI0, PTV_BGB_DGH0, PTV_BGB_DGI1, PTV_BGB_DGH1,                        /* scratch [T, M, 3H] bf16 */
+  PTV_BGB_XCH0, PTV_BGB_XCH1, PTV_BGB_PART0, PTV_BGB_PART1, PTV_BGB_SYNC,        /* persistent launch (PART*: split-K partials or NULL) */
+  PTV_BGB_WAIT_EVENT, PTV_BGB_RECORD_EVENT, PTV_BGB_SIDE_STREAM, PTV_BGB_FORK_EVENT, PTV_BGB_JOIN_EVENT,
+  PTV_BGB_COUNT
+};
+enum PtvBgbDim { PTV_BGB_D_M = 0, PTV_BGB_D_T, PTV_BGB_D_H, PTV_BGB_D_I, PTV_BGB_D_X_BF16, PTV_BGB_D_DX_ACC, PTV_BGB_D_SPLITK, PTV_BGB_D_COUNT };
+int ptv_bigru_final_bwd(const void* const* tensors, const long* dims, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Free-running tokens.
  * ptv_note_token (ptvae.py:408-416 + pitch_dur_ind_to_note_token :328-334): per row pitch argmax (first

@@ -367,3 +367,67 @@ extern "C" int ptv_decoder_tf_bwd(const void* const* t, const long* d, void* str
 #undef GB
   return PTV_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// ptv_bigru_final_bwd: functional._bigru_backward's persistent branch (the two encoders' bi-GRUs) as one call
+// ---------------------------------------------------------------------------------------------
+extern "C" int ptv_bigru_final_bwd(const void* const* t, const long* d, void* stream) {
+  if (!t || !d) return PTV_ERR_ARG;
+  const int M = (int)d[PTV_BGB_D_M], T = (int)d[PTV_BGB_D_T], H = (int)d[PTV_BGB_D_H], I = (int)d[PTV_BGB_D_I], xbf = d[PTV_BGB_D_X_BF16] ? 1 : 0,
+            dx_acc = d[PTV_BGB_D_DX_ACC] ? 1 : 0, S = (int)d[PTV_BGB_D_SPLITK];
+  if (M <= 0 || T < 2 || H <= 0 || I <= 0) return PTV_ERR_ARG;
+  const bool want_dx = t[PTV_BGB_DX] != nullptr;
+  for (int i = 0; i < PTV_BGB_COUNT; i++) {
+    const bool optional = i == PTV_BGB_WT_IH0 || i == PTV_BGB_WT_IH1 || i == PTV_BGB_DX || i == PTV_BGB_PART0 || i == PTV_BGB_PART1 ||
+                          i == PTV_BGB_WAIT_EVENT || i == PTV_BGB_RECORD_EVENT;
+    if (!t[i] && !optional) return PTV_ERR_ARG;
+  }
+  if ((want_dx && (!t[PTV_BGB_WT_IH0] || !t[PTV_BGB_WT_IH1])) || (S && (!t[PTV_BGB_PART0] || !t[PTV_BGB_PART1]))) return PTV_ERR_ARG;
+  const int P = PTV_PREC_BF16;
+  hipStream_t s = (hipStream_t)stream, side = (hipStream_t)const_cast<void*>(t[PTV_BGB_SIDE_STREAM]);
+  void* sside = (void*)side;
+  const long TM = (long)T * M;
+  const float* dout = (const float*)T_(t, PTV_BGB_DOUT);
+  void* dgi[2] = {M_<void>(t, PTV_BGB_DGI0), M_<void>(t, PTV_BGB_DGI1)};
+  void* dgh[2] = {M_<void>(t, PTV_BGB_DGH0), M_<void>(t, PTV_BGB_DGH1)};
+  ptv_gemm_priority(1);
+  {
+    const float* hall_[2] = {(const float*)T_(t, PTV_BGB_HALL0), (const float*)T_(t, PTV_BGB_HALL1)};
+    const void* gates_[2] = {T_(t, PTV_BGB_GATES0), T_(t, PTV_BGB_GATES1)};
+    const void* wt_[2] = {T_(t, PTV_BGB_WT_HH0), T_(t, PTV_BGB_WT_HH1)};
+    const void* ext_[2] = {nullptr, nullptr}; const long ext_step[2] = {0, 0}, ext_ld[2] = {0, 0}; const int ext_bf[2] = {0, 0};
+    const float* last_[2] = {dout, dout + H}; const long last_ld[2] = {2L * H, 2L * H};
+    float* dh0_[2] = {nullptr, nullptr}; const int rev[2] = {0, 1};
+    void* xch_[2] = {M_<void>(t, PTV_BGB_XCH0), M_<void>(t, PTV_BGB_XCH1)};
+    float* part_[2] = {M_<float>(t, PTV_BGB_PART0), M_<float>(t, PTV_BGB_PART1)};
+    if (t[PTV_BGB_WAIT_EVENT] && hipStreamWaitEvent(s, (hipEvent_t)const_cast<void*>(t[PTV_BGB_WAIT_EVENT]), 0) != hipSuccess) return PTV_ERR_LAUNCH;
+    if (S) PTV_TRY(ptv_gru_persist_bwd_splitk(S, 2, M, H, T, hall_, gates_, wt_, ext_, ext_step, ext_ld, ext_bf, last_, last_ld, dgi, dgh, dh0_, rev,
+                                              xch_, part_, M_<unsigned>(t, PTV_BGB_SYNC), stream));
+    else PTV_TRY(ptv_gru_persist_bwd(2, M, H, T, hall_, gates_, wt_, ext_, ext_step, ext_ld, ext_bf, last_, last_ld, dgi, dgh, dh0_, rev, xch_,
+                                     M_<unsigned>(t, PTV_BGB_SYNC), stream));
+    if (t[PTV_BGB_RECORD_EVENT] && hipEventRecord((hipEvent_t)const_cast<void*>(t[PTV_BGB_RECORD_EVENT]), s) != hipSuccess) return PTV_ERR_LAUNCH;
+  }
+  const void* x = T_(t, PTV_BGB_X);
+  const int dt_x = 1 | (xbf << 1);                                   // dgi / dgh bf16, x fp32 or bf16
+  auto products = [&](int dir, void* st) -> int {
+    const int o = dir ? 4 : 0;
+    PTV_TRY(ptv_wgrad(3 * H, I, (int)TM, dgi[dir], 3L * H, x, I, M_<float>(t, PTV_BGB_G_W_IH0 + o), I, 1.f, 1, dt_x, 0,
+                      M_<float>(t, PTV_BGB_G_B_IH0 + o), nullptr, 0, 0, st));
+    PTV_TRY(ptv_wgrad(3 * H, H, (int)TM, dgh[dir], 3L * H, T_(t, dir ? PTV_BGB_H16_1 : PTV_BGB_H16_0), H, M_<float>(t, PTV_BGB_G_W_HH0 + o), H, 1.f, 1,
+                      3, 0, M_<float>(t, PTV_BGB_G_B_HH0 + o), nullptr, 0, dir ? T : 0, st));
+    return PTV_OK;
+  };
+  // the reversed direction's products on the side stream ...
+  hipEvent_t ef = (hipEvent_t)const_cast<void*>(t[PTV_BGB_FORK_EVENT]), ej = (hipEvent_t)const_cast<void*>(t[PTV_BGB_JOIN_EVENT]);
+  if (hipEventRecord(ef, s) != hipSuccess || hipStreamWaitEvent(side, ef, 0) != hipSuccess) return PTV_ERR_LAUNCH;
+  ptv_gemm_priority(0);
+  PTV_TRY(products(1, sside));
+  // ... the forward direction's (and its share of dx) on this one
+  ptv_gemm_priority(1);
+  PTV_TRY(products(0, stream));
+  float* dx = M_<float>(t, PTV_BGB_DX);
+  if (want_dx) PTV_TRY(ptv_gemm(P, 0, 0, (int)TM, I, 3 * H, dgi[0], 3L * H, T_(t, PTV_BGB_WT_IH0), 3L * H, dx, I, nullptr, 1.f, dx_acc, 0, 0, A16 | B16, stream));
+  if (hipEventRecord(ej, side) != hipSuccess || hipStreamWaitEvent(s, ej, 0) != hipSuccess) return PTV_ERR_LAUNCH;
+  if (want_dx) PTV_TRY(ptv_gemm(P, 0, 0, (int)TM, I, 3 * H, dgi[1], 3L * H, T_(t, PTV_BGB_WT_IH1), 3L * H, dx, I, nullptr, 1.f, 1, 0, 0, A16 | B16, stream));
+  return PTV_OK;
+}

@@ -1002,6 +1002,72 @@ def _bigru_forward(prec, x3, lengths, w):
     return out, [fwd, rev]
 
 
+BIGRU_BWD_COMPOSITE = os.environ.get('PTV_BWD_COMPOSITES', '1') != '0'    # the encoders' bi-GRU backward through ptv_bigru_final_bwd (one C call)
+_BGB = {}
+
+
+def _bigru_bwd_composite(prec, x3, xf, w, saved, dout, need_dx, dx_acc, wts, side, T, M, I, H):
+    """-> _bigru_backward's result when ptv_bigru_final_bwd ran its persistent branch, else None"""
+    if 't' not in _BGB:
+        from ._lib import header_enum
+        _BGB['t'], _BGB['d'] = header_enum('PtvBgbTensor'), header_enum('PtvBgbDim')
+    T_, D_ = _BGB['t'], _BGB['d']
+    dev = x3.device
+    if (T * M < 512 or not OVERLAP or side.s == side.main or torch.cuda.is_current_stream_capturing() or xf.stride(1) != 1
+            or xf.stride(0) != I or xf.dtype not in (F32, BF16) or dout.dtype != F32 or dout.stride(1) != 1 or dout.stride(0) != 2 * H
+            or any(sv[0].dtype != F32 or sv[2] is None or sv[1].dtype != BF16 for sv in saved[:2])):
+        return None
+    wt_ih = [_WT(w[0], prec), _WT(w[4], prec)] if need_dx else [None, None]
+    if need_dx and (wt_ih[0] is None or wt_ih[1] is None):
+        return None
+    S = persist_splitk(2, M, H)
+    dims = [0] * D_['PTV_BGB_D_COUNT']
+    for k, v in (('M', M), ('T', T), ('H', H), ('I', I), ('X_BF16', _bf(xf)), ('DX_ACC', int(dx_acc is not None)), ('SPLITK', S)):
+        dims[D_['PTV_BGB_D_' + k]] = v
+    G = [_gbuf(p_) for p_ in w]                           # (w_ih, w_hh, b_ih, b_hh) x 2 directions
+    dx = None
+    if need_dx:
+        dx = dx_acc if dx_acc is not None else _empty(T * M, I, dev=dev)
+    n_part = lib().ptv_gru_persist_part_elems(2, M, H, S) if S else 0
+    tens = {'X': xf, 'DOUT': dout, 'DX': dx, 'SYNC': _persist_sync(2, dev)}
+    for d_ in range(2):
+        hall, gates, h16 = saved[d_][:3]
+        tens.update({'HALL%d' % d_: hall, 'H16_%d' % d_: h16, 'GATES%d' % d_: gates, 'WT_HH%d' % d_: wts[d_], 'WT_IH%d' % d_: wt_ih[d_],
+                     'DGI%d' % d_: _empty(T, M, 3 * H, dev=dev, dtype=BF16), 'DGH%d' % d_: _empty(T, M, 3 * H, dev=dev, dtype=BF16),
+                     'XCH%d' % d_: torch.empty(T * M * 3 * H, device=dev, dtype=BF16),
+                     'PART%d' % d_: torch.empty(n_part, device=dev) if S else None})
+    slots = [None] * T_['PTV_BGB_COUNT']
+    for k, v in tens.items():
+        slots[T_['PTV_BGB_' + k]] = ptr(v)
+    for d_ in range(2):
+        for j, nm in enumerate(('W_IH', 'W_HH', 'B_IH', 'B_HH')):
+            slots[T_['PTV_BGB_G_%s%d' % (nm, d_)]] = ptr(G[4 * d_ + j])
+    cur = cur_stream()
+    evs = _BGB.get(('ev', cur.device.index, stream_ptr()))
+    if evs is None:                                   # fork / join events of this stream, created once
+        evs = [torch.cuda.Event(), torch.cuda.Event()]
+        for e in evs:
+            e.record(cur)
+        _BGB[('ev', cur.device.index, stream_ptr())] = evs
+    slots[T_['PTV_BGB_FORK_EVENT']], slots[T_['PTV_BGB_JOIN_EVENT']] = evs[0].cuda_event, evs[1].cuda_event
+    slots[T_['PTV_BGB_SIDE_STREAM']] = side.s.cuda_stream
+    prev = _PERSIST_LAST.get(cur.device.index)
+    done = torch.cuda.Event()
+    if prev is not None:
+        slots[T_['PTV_BGB_WAIT_EVENT']] = prev.cuda_event
+    done.record(cur)
+    slots[T_['PTV_BGB_RECORD_EVENT']] = done.cuda_event
+    rc = lib().ptv_bigru_final_bwd((ctypes.c_void_p * len(slots))(*slots), _larr(dims), stream_ptr())
+    _SIDE_DEPTH[1] = 1
+    if rc == -3:
+        return None
+    check(rc, 'ptv_bigru_final_bwd')
+    _PERSIST_LAST[cur.device.index] = done
+    _BGB['calls'] = _BGB.get('calls', 0) + 1
+    # (the side stream was joined inside the call: what it read may be released in this stream's order)
+    return G[0:4] + G[4:8], (dx.view(T, M, I) if need_dx else None)
+
+
 def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None, rev_slot=None):
     """-> ([dw_ih, dw_hh, db_ih, db_hh] x 2 directions, dx [T,M,I] or None).
     dx_acc ([T*M, I] fp32, or None): a gradient that already arrived at x3 from another consumer -- both directions' input-gradient
@@ -1051,6 +1117,10 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None, rev_slot=Non
     if (T >= 2 and adt == BF16 and wts[0] is not None and wts[1] is not None and saved[0][1].dtype == BF16
             and saved[0][2] is not None and persist_supported(2, M, H, T)):
         # BPTT of both directions in ONE persistent launch, then the weight-gradient products of the two on sibling streams
+        if BIGRU_BWD_COMPOSITE:
+            res = _bigru_bwd_composite(prec, x3, xf, w, saved, dout, need_dx, dx_acc, wts, side, T, M, I, H)
+            if res is not None:
+                return res
         chains = []
         for d in range(2):
             hall, gates, h16 = saved[d][:3]

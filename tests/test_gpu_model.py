@@ -131,9 +131,10 @@ def test_decoder_tf_composite_entry_point_equals_launch_by_launch_and_reference(
         assert torch.equal(res[True][1][k], res[False][1][k]), k
 
 
-@pytest.mark.parametrize('prec,B,via_loss', [('bf16', 512, True), ('bf16', 24, True), ('bf16', 16, False), ('fp32', 8, True)])
+@pytest.mark.parametrize('prec,B,via_loss', [('bf16', 512, True), ('bf16', 64, True), ('bf16', 24, True), ('bf16', 16, False), ('fp32', 8, True)])
 def test_backward_composites_equal_python_sequencing(prec, B, via_loss):
-    """ptv_chord_decoder_bwd and ptv_decoder_tf_bwd (one C call each: the chord decoder's / the PianoTree decoder's whole backward -- chain,
+    """ptv_chord_decoder_bwd, ptv_decoder_tf_bwd and ptv_bigru_final_bwd (one C call each: the chord decoder's / the PianoTree decoder's / an
+    encoder bi-GRU's whole backward -- chain,
     the forks of the weight-gradient groups onto the sibling stream, the persistent launches with their event turn) against the launch
     sequences of ChordDecoderTFFn.backward / decoder_bwd_core: every gradient of the step bit for bit.  bf16 at B = 512 (persistent BPTTs,
     split-K teams) and small batches, through loss() (the decoder stops at the last live note step) and through run() + loss_function()
@@ -148,8 +149,8 @@ def test_backward_composites_equal_python_sequencing(prec, B, via_loss):
         m.to(DEV).set_precision(prec)
         m.use_philox(11, 0)
         opt = FusedClipAdam(m.parameters(), lr=1e-3)        # (the bf16 weight shadows the composites read are the optimiser's)
-        old, F_.CHD_BWD_COMPOSITE, F_.DEC_BWD_COMPOSITE = (F_.CHD_BWD_COMPOSITE, F_.DEC_BWD_COMPOSITE), comp, comp
-        n0, n1 = F_._CDB.get('calls', 0), F_._DTB.get('calls', 0)
+        old, F_.CHD_BWD_COMPOSITE, F_.DEC_BWD_COMPOSITE, F_.BIGRU_BWD_COMPOSITE = (F_.CHD_BWD_COMPOSITE, F_.DEC_BWD_COMPOSITE, F_.BIGRU_BWD_COMPOSITE), comp, comp, comp
+        n0, n1, n2 = F_._CDB.get('calls', 0), F_._DTB.get('calls', 0), F_._BGB.get('calls', 0)
         try:
             opt.zero_grad()
             if via_loss:
@@ -159,9 +160,10 @@ def test_backward_composites_equal_python_sequencing(prec, B, via_loss):
             losses[0].backward()
             torch.cuda.synchronize()
         finally:
-            F_.CHD_BWD_COMPOSITE, F_.DEC_BWD_COMPOSITE = old
+            F_.CHD_BWD_COMPOSITE, F_.DEC_BWD_COMPOSITE, F_.BIGRU_BWD_COMPOSITE = old
         assert (F_._CDB.get('calls', 0) > n0) == comp
         assert (F_._DTB.get('calls', 0) > n1) == (comp and prec == 'bf16')
+        assert (F_._BGB.get('calls', 0) - n2) == (2 if (comp and prec == 'bf16' and 8 * B >= 512) else 0)      # the two encoders' bi-GRUs
         res[comp] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
         F_.persist_check()
     for k in res[True]:
