@@ -556,6 +556,21 @@ enum PtvBgbTensor {
 enum PtvBgbDim { PTV_BGB_D_M = 0, PTV_BGB_D_T, PTV_BGB_D_H, PTV_BGB_D_I, PTV_BGB_D_X_BF16, PTV_BGB_D_DX_ACC, PTV_BGB_D_SPLITK, PTV_BGB_D_COUNT };
 int ptv_bigru_final_bwd(const void* const* tensors, const long* dims, void* stream);
 
+/* ptv_bigru_final_fwd: the forward of the above (functional._bigru_forward's persistent branch): per direction the input product
+ * gi = x . W_ih^T + b_ih (bf16 out), the zero initial state, both recurrences in ONE persistent launch (event turn in here), the two final
+ * states copied into OUT [M, 2H].  Saved for the backward: HALL / H16 / GATES.  bf16 precision; lengths (packed sequences) or NULL. */
+enum PtvBgfTensor {
+  PTV_BGF_X = 0,          /* [T*M, I] fp32 (or bf16 with d[PTV_BGF_D_X_BF16]) */
+  PTV_BGF_LENGTHS,        /* [M] int32 or NULL */
+  PTV_BGF_W16_IH0, PTV_BGF_B_IH0, PTV_BGF_W16_HH0, PTV_BGF_B_HH0, PTV_BGF_W16_IH1, PTV_BGF_B_IH1, PTV_BGF_W16_HH1, PTV_BGF_B_HH1,   /* bf16 weight shadows, fp32 biases */
+  PTV_BGF_OUT,            /* out [M, 2H] fp32 */
+  PTV_BGF_GI0, PTV_BGF_HALL0, PTV_BGF_H16_0, PTV_BGF_GATES0, PTV_BGF_GI1, PTV_BGF_HALL1, PTV_BGF_H16_1, PTV_BGF_GATES1,
+  PTV_BGF_XCH0, PTV_BGF_XCH1, PTV_BGF_SYNC, PTV_BGF_WAIT_EVENT, PTV_BGF_RECORD_EVENT,
+  PTV_BGF_COUNT
+};
+enum PtvBgfDim { PTV_BGF_D_M = 0, PTV_BGF_D_T, PTV_BGF_D_H, PTV_BGF_D_I, PTV_BGF_D_X_BF16, PTV_BGF_D_COUNT };
+int ptv_bigru_final_fwd(const void* const* tensors, const long* dims, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Free-running tokens.
  * ptv_note_token (ptvae.py:408-416 + pitch_dur_ind_to_note_token :328-334): per row pitch argmax (first

@@ -431,3 +431,43 @@ extern "C" int ptv_bigru_final_bwd(const void* const* t, const long* d, void* st
   if (want_dx) PTV_TRY(ptv_gemm(P, 0, 0, (int)TM, I, 3 * H, dgi[1], 3L * H, T_(t, PTV_BGB_WT_IH1), 3L * H, dx, I, nullptr, 1.f, 1, 0, 0, A16 | B16, stream));
   return PTV_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// ptv_bigru_final_fwd: functional._bigru_forward's persistent branch as one call
+// ---------------------------------------------------------------------------------------------
+extern "C" int ptv_bigru_final_fwd(const void* const* t, const long* d, void* stream) {
+  if (!t || !d) return PTV_ERR_ARG;
+  const int M = (int)d[PTV_BGF_D_M], T = (int)d[PTV_BGF_D_T], H = (int)d[PTV_BGF_D_H], I = (int)d[PTV_BGF_D_I], xbf = d[PTV_BGF_D_X_BF16] ? 1 : 0;
+  if (M <= 0 || T < 2 || H <= 0 || I <= 0) return PTV_ERR_ARG;
+  for (int i = 0; i < PTV_BGF_COUNT; i++)
+    if (!t[i] && i != PTV_BGF_LENGTHS && i != PTV_BGF_WAIT_EVENT && i != PTV_BGF_RECORD_EVENT) return PTV_ERR_ARG;
+  const int P = PTV_PREC_BF16;
+  hipStream_t s = (hipStream_t)stream;
+  const long TM = (long)T * M;
+  const int gi_slot[2] = {PTV_BGF_GI0, PTV_BGF_GI1}, hall_slot[2] = {PTV_BGF_HALL0, PTV_BGF_HALL1};
+  const int wih_slot[2] = {PTV_BGF_W16_IH0, PTV_BGF_W16_IH1}, bih_slot[2] = {PTV_BGF_B_IH0, PTV_BGF_B_IH1};
+  for (int dir = 0; dir < 2; dir++) {
+    PTV_TRY(ptv_gemm(P, 0, 0, (int)TM, 3 * H, I, T_(t, PTV_BGF_X), I, T_(t, wih_slot[dir]), I, M_<void>(t, gi_slot[dir]), 3L * H,
+                     (const float*)T_(t, bih_slot[dir]), 1.f, 0, 0, -1, (xbf ? A16 : 0) | B16 | C16, stream));
+    if (hipMemsetAsync(M_<void>(t, hall_slot[dir]), 0, sizeof(float) * M * H, s) != hipSuccess) return PTV_ERR_LAUNCH;
+  }
+  {
+    const void* gi[2] = {T_(t, PTV_BGF_GI0), T_(t, PTV_BGF_GI1)}; const long gi_step[2] = {(long)M * 3 * H, (long)M * 3 * H}, gi_ld[2] = {3L * H, 3L * H};
+    const void* gi2[2] = {nullptr, nullptr}; const long z2[2] = {0, 0};
+    const void* w16[2] = {T_(t, PTV_BGF_W16_HH0), T_(t, PTV_BGF_W16_HH1)};
+    const float* bhh[2] = {(const float*)T_(t, PTV_BGF_B_HH0), (const float*)T_(t, PTV_BGF_B_HH1)};
+    float* hall[2] = {M_<float>(t, PTV_BGF_HALL0), M_<float>(t, PTV_BGF_HALL1)};
+    void* h16[2] = {M_<void>(t, PTV_BGF_H16_0), M_<void>(t, PTV_BGF_H16_1)};
+    void* gates[2] = {M_<void>(t, PTV_BGF_GATES0), M_<void>(t, PTV_BGF_GATES1)};
+    const int* len[2] = {(const int*)T_(t, PTV_BGF_LENGTHS), (const int*)T_(t, PTV_BGF_LENGTHS)}; const int rev[2] = {0, 1};
+    void* xch[2] = {M_<void>(t, PTV_BGF_XCH0), M_<void>(t, PTV_BGF_XCH1)};
+    if (t[PTV_BGF_WAIT_EVENT] && hipStreamWaitEvent(s, (hipEvent_t)const_cast<void*>(t[PTV_BGF_WAIT_EVENT]), 0) != hipSuccess) return PTV_ERR_LAUNCH;
+    PTV_TRY(ptv_gru_persist_fwd(2, M, H, T, gi, gi_step, gi_ld, gi2, z2, z2, w16, bhh, hall, h16, gates, len, rev, xch, M_<unsigned>(t, PTV_BGF_SYNC),
+                                stream));
+    if (t[PTV_BGF_RECORD_EVENT] && hipEventRecord((hipEvent_t)const_cast<void*>(t[PTV_BGF_RECORD_EVENT]), s) != hipSuccess) return PTV_ERR_LAUNCH;
+  }
+  float* out = M_<float>(t, PTV_BGF_OUT);
+  for (int dir = 0; dir < 2; dir++)
+    PTV_TRY(ptv_copy2d(out + (long)dir * H, 2L * H, M_<float>(t, hall_slot[dir]) + (long)T * M * H, H, M, H, 1.f, 0, stream));
+  return PTV_OK;
+}

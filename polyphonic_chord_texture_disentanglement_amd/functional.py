@@ -925,6 +925,51 @@ class EmbedFn(torch.autograd.Function):
 # =============================================================================================
 # bidirectional GRU, final states only  (RnnEncoder / TextureEncoder / dec_notes_emb_gru)
 # =============================================================================================
+_BGF = {}
+
+
+def _bigru_fwd_composite(prec, xf, lengths, w, w16, out, T, M, I, H, dev):
+    """-> _bigru_forward's result when ptv_bigru_final_fwd ran its persistent branch, else None"""
+    if 't' not in _BGF:
+        from ._lib import header_enum
+        _BGF['t'], _BGF['d'] = header_enum('PtvBgfTensor'), header_enum('PtvBgfDim')
+    T_, D_ = _BGF['t'], _BGF['d']
+    wih16 = [_W(w[0], prec), _W(w[4], prec)]
+    if (torch.cuda.is_current_stream_capturing() or xf.dtype not in (F32, BF16) or xf.stride(1) != 1 or xf.stride(0) != I
+            or wih16[0].dtype != BF16 or wih16[1].dtype != BF16 or not wih16[0].is_contiguous() or not wih16[1].is_contiguous()):
+        return None
+    dims = [0] * D_['PTV_BGF_D_COUNT']
+    for k, v in (('M', M), ('T', T), ('H', H), ('I', I), ('X_BF16', _bf(xf))):
+        dims[D_['PTV_BGF_D_' + k]] = v
+    saved = []
+    tens = {'X': xf, 'LENGTHS': lengths, 'OUT': out, 'SYNC': _persist_sync(2, dev)}
+    for d_ in range(2):
+        hall, h16 = _empty(T + 1, M, H, dev=dev), _empty(T + 1, M, H, dev=dev, dtype=BF16)
+        gates = _empty(T, 4, M, H, dev=dev, dtype=BF16)
+        saved.append((hall, gates, h16))
+        tens.update({'W16_IH%d' % d_: wih16[d_], 'B_IH%d' % d_: w[4 * d_ + 2], 'W16_HH%d' % d_: w16[d_], 'B_HH%d' % d_: w[4 * d_ + 3],
+                     'GI%d' % d_: _empty(T * M, 3 * H, dev=dev, dtype=BF16), 'HALL%d' % d_: hall, 'H16_%d' % d_: h16, 'GATES%d' % d_: gates,
+                     'XCH%d' % d_: torch.empty((T + 1) * M * H, device=dev, dtype=BF16)})
+    slots = [None] * T_['PTV_BGF_COUNT']
+    for k, v in tens.items():
+        slots[T_['PTV_BGF_' + k]] = ptr(v)
+    cur = cur_stream()
+    prev = _PERSIST_LAST.get(cur.device.index)
+    done = torch.cuda.Event()
+    if prev is not None:
+        slots[T_['PTV_BGF_WAIT_EVENT']] = prev.cuda_event
+    done.record(cur)
+    slots[T_['PTV_BGF_RECORD_EVENT']] = done.cuda_event
+    _chain_prio()
+    rc = lib().ptv_bigru_final_fwd((ctypes.c_void_p * len(slots))(*slots), _larr(dims), stream_ptr())
+    if rc == -3:
+        return None
+    check(rc, 'ptv_bigru_final_fwd')
+    _PERSIST_LAST[cur.device.index] = done
+    _BGF['calls'] = _BGF.get('calls', 0) + 1
+    return out, saved
+
+
 def _bigru_forward(prec, x3, lengths, w):
     """x3 [T,M,I] step-major.  w = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r).
     Returns out [M,2H] and the saved state for backward.  The two directions are independent
@@ -950,6 +995,10 @@ def _bigru_forward(prec, x3, lengths, w):
     w16 = [_W(w[1], prec), _W(w[5], prec)]
     if prec == 1 and T >= 2 and adt == BF16 and w16[0].dtype == BF16 and w16[1].dtype == BF16 and persist_supported(2, M, H, T):
         # both directions in ONE persistent launch (csrc/gru_persist.hip): per step the two chains share the exchange latency
+        if BIGRU_BWD_COMPOSITE:
+            res = _bigru_fwd_composite(prec, xf, lengths, w, w16, out, T, M, I, H, dev)
+            if res is not None:
+                return res
         chains, saved = [], []
         for d in range(2):
             w_ih, w_hh, b_ih, b_hh = w[4 * d: 4 * d + 4]

@@ -150,7 +150,7 @@ def test_backward_composites_equal_python_sequencing(prec, B, via_loss):
         m.use_philox(11, 0)
         opt = FusedClipAdam(m.parameters(), lr=1e-3)        # (the bf16 weight shadows the composites read are the optimiser's)
         old, F_.CHD_BWD_COMPOSITE, F_.DEC_BWD_COMPOSITE, F_.BIGRU_BWD_COMPOSITE = (F_.CHD_BWD_COMPOSITE, F_.DEC_BWD_COMPOSITE, F_.BIGRU_BWD_COMPOSITE), comp, comp, comp
-        n0, n1, n2 = F_._CDB.get('calls', 0), F_._DTB.get('calls', 0), F_._BGB.get('calls', 0)
+        n0, n1, n2, n3 = F_._CDB.get('calls', 0), F_._DTB.get('calls', 0), F_._BGB.get('calls', 0), F_._BGF.get('calls', 0)
         try:
             opt.zero_grad()
             if via_loss:
@@ -164,6 +164,8 @@ def test_backward_composites_equal_python_sequencing(prec, B, via_loss):
         assert (F_._CDB.get('calls', 0) > n0) == comp
         assert (F_._DTB.get('calls', 0) > n1) == (comp and prec == 'bf16')
         assert (F_._BGB.get('calls', 0) - n2) == (2 if (comp and prec == 'bf16' and 8 * B >= 512) else 0)      # the two encoders' bi-GRUs
+        # ... and the texture encoder's forward (the chord encoder's 36-wide input weight has no bf16 shadow: that one stays launch by launch)
+        assert (F_._BGF.get('calls', 0) - n3) == (1 if (comp and prec == 'bf16') else 0)
         res[comp] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
         F_.persist_check()
     for k in res[True]:
