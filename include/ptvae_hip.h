@@ -571,6 +571,35 @@ enum PtvBgfTensor {
 enum PtvBgfDim { PTV_BGF_D_M = 0, PTV_BGF_D_T, PTV_BGF_D_H, PTV_BGF_D_I, PTV_BGF_D_X_BF16, PTV_BGF_D_COUNT };
 int ptv_bigru_final_fwd(const void* const* tensors, const long* dims, void* stream);
 
+/* ptv_bigru_rows_fwd / ptv_bigru_rows_bwd: the same pair for a bi-GRU over MANY short independent rows (dec_notes_emb_gru, the ground-truth
+ * note summaries, ptvae.py:446-453: 32 B rows x 16 notes, H = 128) on the row-partitioned kernels -- one launch per direction for the whole
+ * sequence, the input product fused, the reversed direction on the side stream (forked and joined in here).  What functional._bigru_forward
+ * / _bigru_backward sequence on their row-kernel branch, bit-identical to it.  LENGTHS / PERM as ptv_row_gru_persist_fwd_perm; TOP0 / TOP1:
+ * device ints initialised to -1 (the BPTT reports the last live time index; the products stop there), NULL = no limit. */
+enum PtvBrfTensor {
+  PTV_BRF_X = 0,          /* [T, M, I] fp32 */
+  PTV_BRF_LENGTHS, PTV_BRF_PERM,           /* int32 [M] or NULL */
+  PTV_BRF_PK_WG_H0, PTV_BRF_PK_WG_T0, PTV_BRF_B_HH0, PTV_BRF_B_IH0, PTV_BRF_PK_WG_H1, PTV_BRF_PK_WG_T1, PTV_BRF_B_HH1, PTV_BRF_B_IH1,
+  PTV_BRF_OUT,            /* out [M, 2H] */
+  PTV_BRF_HALL0, PTV_BRF_H16_0, PTV_BRF_GATES0, PTV_BRF_HALL1, PTV_BRF_H16_1, PTV_BRF_GATES1,
+  PTV_BRF_SIDE_STREAM, PTV_BRF_FORK_EVENT, PTV_BRF_JOIN_EVENT,
+  PTV_BRF_COUNT
+};
+enum PtvBrfDim { PTV_BRF_D_M = 0, PTV_BRF_D_T, PTV_BRF_D_H, PTV_BRF_D_I, PTV_BRF_D_COUNT };
+int ptv_bigru_rows_fwd(const void* const* tensors, const long* dims, void* stream);
+enum PtvBrbTensor {
+  PTV_BRB_X = 0, PTV_BRB_DOUT, PTV_BRB_LENGTHS, PTV_BRB_PERM,
+  PTV_BRB_PK_WT0, PTV_BRB_HALL0, PTV_BRB_H16_0, PTV_BRB_GATES0, PTV_BRB_WT_IH0,       /* WT_IH*: bf16 W_ih^T [I, 3H], NULL without DX */
+  PTV_BRB_PK_WT1, PTV_BRB_HALL1, PTV_BRB_H16_1, PTV_BRB_GATES1, PTV_BRB_WT_IH1,
+  PTV_BRB_G_W_IH0, PTV_BRB_G_W_HH0, PTV_BRB_G_B_IH0, PTV_BRB_G_B_HH0, PTV_BRB_G_W_IH1, PTV_BRB_G_W_HH1, PTV_BRB_G_B_IH1, PTV_BRB_G_B_HH1,
+  PTV_BRB_DX,             /* out [T*M, I] fp32 or NULL */
+  PTV_BRB_DGI0, PTV_BRB_DGH0, PTV_BRB_SCRATCH0, PTV_BRB_TOP0, PTV_BRB_DGI1, PTV_BRB_DGH1, PTV_BRB_SCRATCH1, PTV_BRB_TOP1,
+  PTV_BRB_SIDE_STREAM, PTV_BRB_FORK_EVENT, PTV_BRB_JOIN_EVENT,
+  PTV_BRB_COUNT
+};
+enum PtvBrbDim { PTV_BRB_D_M = 0, PTV_BRB_D_T, PTV_BRB_D_H, PTV_BRB_D_I, PTV_BRB_D_DX_ACC, PTV_BRB_D_DOUT_LD, PTV_BRB_D_COUNT };
+int ptv_bigru_rows_bwd(const void* const* tensors, const long* dims, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Free-running tokens.
  * ptv_note_token (ptvae.py:408-416 + pitch_dur_ind_to_note_token :328-334): per row pitch argmax (first

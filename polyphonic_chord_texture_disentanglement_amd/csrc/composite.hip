@@ -471,3 +471,82 @@ extern "C" int ptv_bigru_final_fwd(const void* const* t, const long* d, void* st
     PTV_TRY(ptv_copy2d(out + (long)dir * H, 2L * H, M_<float>(t, hall_slot[dir]) + (long)T * M * H, H, M, H, 1.f, 0, stream));
   return PTV_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// ptv_bigru_rows_fwd / ptv_bigru_rows_bwd: functional._bigru_forward / _bigru_backward's row-kernel branch (the note-summary bi-GRU)
+// ---------------------------------------------------------------------------------------------
+extern "C" int ptv_bigru_rows_fwd(const void* const* t, const long* d, void* stream) {
+  if (!t || !d) return PTV_ERR_ARG;
+  const int M = (int)d[PTV_BRF_D_M], T = (int)d[PTV_BRF_D_T], H = (int)d[PTV_BRF_D_H], I = (int)d[PTV_BRF_D_I];
+  if (M <= 0 || T <= 0 || H != 128 || I != 128) return PTV_ERR_UNSUPPORTED;
+  for (int i = 0; i < PTV_BRF_COUNT; i++)
+    if (!t[i] && i != PTV_BRF_LENGTHS && i != PTV_BRF_PERM) return PTV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream, side = (hipStream_t)const_cast<void*>(t[PTV_BRF_SIDE_STREAM]);
+  hipEvent_t ef = (hipEvent_t)const_cast<void*>(t[PTV_BRF_FORK_EVENT]), ej = (hipEvent_t)const_cast<void*>(t[PTV_BRF_JOIN_EVENT]);
+  float* out = M_<float>(t, PTV_BRF_OUT);
+  auto rows = [&](int dir, hipStream_t st) -> int {
+    const int o = dir ? 4 : 0, q = dir ? 3 : 0;
+    float* hall = M_<float>(t, PTV_BRF_HALL0 + q);
+    if (hipMemsetAsync(hall, 0, sizeof(float) * M * H, st) != hipSuccess) return PTV_ERR_LAUNCH;
+    return ptv_row_gru_persist_fwd_perm(H, T_(t, PTV_BRF_PK_WG_H0 + o), T_(t, PTV_BRF_PK_WG_T0 + o), (const float*)T_(t, PTV_BRF_B_HH0 + o),
+                                        (const float*)T_(t, PTV_BRF_B_IH0 + o), nullptr, (const float*)T_(t, PTV_BRF_X), (long)M * I,
+                                        (const int*)T_(t, PTV_BRF_LENGTHS), (const int*)T_(t, PTV_BRF_PERM), hall, M_<void>(t, PTV_BRF_H16_0 + q),
+                                        M_<void>(t, PTV_BRF_GATES0 + q), out + (long)dir * H, 2L * H, M, T, dir, (void*)st);
+  };
+  if (hipEventRecord(ef, s) != hipSuccess || hipStreamWaitEvent(side, ef, 0) != hipSuccess) return PTV_ERR_LAUNCH;
+  PTV_TRY(rows(1, side));
+  PTV_TRY(rows(0, s));
+  if (hipEventRecord(ej, side) != hipSuccess || hipStreamWaitEvent(s, ej, 0) != hipSuccess) return PTV_ERR_LAUNCH;
+  return PTV_OK;
+}
+
+extern "C" int ptv_bigru_rows_bwd(const void* const* t, const long* d, void* stream) {
+  if (!t || !d) return PTV_ERR_ARG;
+  const int M = (int)d[PTV_BRB_D_M], T = (int)d[PTV_BRB_D_T], H = (int)d[PTV_BRB_D_H], I = (int)d[PTV_BRB_D_I], dx_acc = d[PTV_BRB_D_DX_ACC] ? 1 : 0;
+  const long dout_ld = d[PTV_BRB_D_DOUT_LD];
+  if (M <= 0 || T <= 0 || H != 128 || I != 128) return PTV_ERR_UNSUPPORTED;
+  const bool want_dx = t[PTV_BRB_DX] != nullptr;
+  for (int i = 0; i < PTV_BRB_COUNT; i++) {
+    const bool optional = i == PTV_BRB_LENGTHS || i == PTV_BRB_PERM || i == PTV_BRB_WT_IH0 || i == PTV_BRB_WT_IH1 || i == PTV_BRB_DX ||
+                          i == PTV_BRB_TOP0 || i == PTV_BRB_TOP1;
+    if (!t[i] && !optional) return PTV_ERR_ARG;
+  }
+  if (want_dx && (!t[PTV_BRB_WT_IH0] || !t[PTV_BRB_WT_IH1])) return PTV_ERR_ARG;
+  const int P = PTV_PREC_BF16;
+  hipStream_t s = (hipStream_t)stream, side = (hipStream_t)const_cast<void*>(t[PTV_BRB_SIDE_STREAM]);
+  hipEvent_t ef = (hipEvent_t)const_cast<void*>(t[PTV_BRB_FORK_EVENT]), ej = (hipEvent_t)const_cast<void*>(t[PTV_BRB_JOIN_EVENT]);
+  const long TM = (long)T * M;
+  const float* dout = (const float*)T_(t, PTV_BRB_DOUT);
+  const void* x = T_(t, PTV_BRB_X);
+  float* dx = M_<float>(t, PTV_BRB_DX);
+  auto rows = [&](int dir, hipStream_t st) -> int {
+    const int o = dir ? 5 : 0, g = dir ? 4 : 0, q = dir ? 4 : 0;
+    void* dgi = M_<void>(t, PTV_BRB_DGI0 + q); void* dgh = M_<void>(t, PTV_BRB_DGH0 + q);
+    int* top = M_<int>(t, PTV_BRB_TOP0 + q);
+    PTV_TRY(ptv_row_gru_persist_bwd_perm(H, T_(t, PTV_BRB_PK_WT0 + o), T_(t, PTV_BRB_HALL0 + o), T_(t, PTV_BRB_GATES0 + o), nullptr, dout + (long)dir * H,
+                                         dout_ld, (const int*)T_(t, PTV_BRB_LENGTHS), (const int*)T_(t, PTV_BRB_PERM), dgi, dgh, nullptr,
+                                         M_<void>(t, PTV_BRB_SCRATCH0 + q), M, T, dir, top, (void*)st));
+    PTV_TRY(ptv_wgrad(3 * H, I, (int)TM, dgi, 3L * H, x, I, M_<float>(t, PTV_BRB_G_W_IH0 + g), I, 1.f, 1, 1, 0, M_<float>(t, PTV_BRB_G_B_IH0 + g), top,
+                      top ? M : 0, 0, (void*)st));
+    PTV_TRY(ptv_wgrad(3 * H, H, (int)TM, dgh, 3L * H, T_(t, PTV_BRB_H16_0 + o), H, M_<float>(t, PTV_BRB_G_W_HH0 + g), H, 1.f, 1, 3, 0,
+                      M_<float>(t, PTV_BRB_G_B_HH0 + g), top, top ? M : 0, dir ? T : 0, (void*)st));
+    return PTV_OK;
+  };
+  auto dx_of = [&](int dir, int acc) -> int {
+    const int o = dir ? 5 : 0, q = dir ? 4 : 0;
+    const int* top = (const int*)T_(t, PTV_BRB_TOP0 + q);
+    if (top) return ptv_gemm_mtop(P, 0, 0, (int)TM, I, 3 * H, T_(t, PTV_BRB_DGI0 + q), 3L * H, T_(t, PTV_BRB_WT_IH0 + o), 3L * H, dx, I, nullptr, 1.f, acc,
+                                  0, 0, A16 | B16, top, M, stream);
+    return ptv_gemm(P, 0, 0, (int)TM, I, 3 * H, T_(t, PTV_BRB_DGI0 + q), 3L * H, T_(t, PTV_BRB_WT_IH0 + o), 3L * H, dx, I, nullptr, 1.f, acc, 0, 0,
+                    A16 | B16, stream);
+  };
+  if (hipEventRecord(ef, s) != hipSuccess || hipStreamWaitEvent(side, ef, 0) != hipSuccess) return PTV_ERR_LAUNCH;
+  ptv_gemm_priority(0);
+  PTV_TRY(rows(1, side));
+  ptv_gemm_priority(1);
+  PTV_TRY(rows(0, s));
+  if (want_dx) PTV_TRY(dx_of(0, dx_acc));
+  if (hipEventRecord(ej, side) != hipSuccess || hipStreamWaitEvent(s, ej, 0) != hipSuccess) return PTV_ERR_LAUNCH;
+  if (want_dx) PTV_TRY(dx_of(1, 1));
+  return PTV_OK;
+}

@@ -926,6 +926,105 @@ class EmbedFn(torch.autograd.Function):
 # bidirectional GRU, final states only  (RnnEncoder / TextureEncoder / dec_notes_emb_gru)
 # =============================================================================================
 _BGF = {}
+_BRF, _BRB = {}, {}
+
+
+def _fork_events(cache, n=2):
+    """per (device, stream): the fork / join events a composite call needs, created once"""
+    cur = cur_stream()
+    key = ('ev', cur.device.index, stream_ptr())
+    evs = cache.get(key)
+    if evs is None:
+        evs = [torch.cuda.Event() for _ in range(n)]
+        for e in evs:
+            e.record(cur)
+        cache[key] = evs
+    return evs
+
+
+def _bigru_rows_fwd_composite(x3, lengths, perm, w, out, side, T, M, I, H, dev):
+    """-> _bigru_forward's result when ptv_bigru_rows_fwd ran its row-kernel branch, else None"""
+    if 't' not in _BRF:
+        from ._lib import header_enum
+        _BRF['t'], _BRF['d'] = header_enum('PtvBrfTensor'), header_enum('PtvBrfDim')
+    T_, D_ = _BRF['t'], _BRF['d']
+    if (not OVERLAP or side.s == side.main or torch.cuda.is_current_stream_capturing() or not x3.is_contiguous() or x3.dtype != F32
+            or H != 128 or I != 128):
+        return None
+    dims = [0] * D_['PTV_BRF_D_COUNT']
+    for k, v in (('M', M), ('T', T), ('H', H), ('I', I)):
+        dims[D_['PTV_BRF_D_' + k]] = v
+    tens = {'X': x3, 'LENGTHS': lengths, 'PERM': perm, 'OUT': out}
+    saved = []
+    for d_ in range(2):
+        w_ih, w_hh, b_ih, b_hh = w[4 * d_: 4 * d_ + 4]
+        pk = notes_packs(w_ih, w_hh, 0)
+        hall, h16 = _empty(T + 1, M, H, dev=dev), _empty(T + 1, M, H, dev=dev, dtype=BF16)
+        gates = _empty(T, 4, M, H, dev=dev, dtype=BF16)
+        saved.append((hall, gates, h16, (lengths if ZERO_SKIP else None), perm))
+        tens.update({'PK_WG_H%d' % d_: pk['wg_h'], 'PK_WG_T%d' % d_: pk['wg_t'], 'B_HH%d' % d_: b_hh, 'B_IH%d' % d_: b_ih,
+                     'HALL%d' % d_: hall, 'H16_%d' % d_: h16, 'GATES%d' % d_: gates})
+    slots = [None] * T_['PTV_BRF_COUNT']
+    for k, v in tens.items():
+        slots[T_['PTV_BRF_' + k]] = ptr(v)
+    evs = _fork_events(_BRF)
+    slots[T_['PTV_BRF_FORK_EVENT']], slots[T_['PTV_BRF_JOIN_EVENT']] = evs[0].cuda_event, evs[1].cuda_event
+    slots[T_['PTV_BRF_SIDE_STREAM']] = side.s.cuda_stream
+    rc = lib().ptv_bigru_rows_fwd((ctypes.c_void_p * len(slots))(*slots), _larr(dims), stream_ptr())
+    if rc == -3:
+        return None
+    check(rc, 'ptv_bigru_rows_fwd')
+    _BRF['calls'] = _BRF.get('calls', 0) + 1
+    return out, saved
+
+
+def _bigru_rows_bwd_composite(prec, x3, xf, w, saved, dout, need_dx, dx_acc, side, T, M, I, H):
+    """-> _bigru_backward's result when ptv_bigru_rows_bwd ran its row-kernel branch, else None"""
+    if 't' not in _BRB:
+        from ._lib import header_enum
+        _BRB['t'], _BRB['d'] = header_enum('PtvBrbTensor'), header_enum('PtvBrbDim')
+    T_, D_ = _BRB['t'], _BRB['d']
+    dev = x3.device
+    if (prec != 1 or not OVERLAP or side.s == side.main or torch.cuda.is_current_stream_capturing() or H != 128 or I != 128 or T * M < 512
+            or xf.dtype != F32 or xf.stride(1) != 1 or xf.stride(0) != I or dout.dtype != F32 or dout.stride(1) != 1):
+        return None
+    wt_ih = [_WT(w[0], prec), _WT(w[4], prec)] if need_dx else [None, None]
+    if need_dx and (wt_ih[0] is None or wt_ih[1] is None):
+        return None
+    lengths = saved[0][3] if len(saved[0]) > 3 else None
+    perm = saved[0][4] if len(saved[0]) > 4 else None
+    dims = [0] * D_['PTV_BRB_D_COUNT']
+    for k, v in (('M', M), ('T', T), ('H', H), ('I', I), ('DX_ACC', int(dx_acc is not None)), ('DOUT_LD', dout.stride(0))):
+        dims[D_['PTV_BRB_D_' + k]] = v
+    G = [_gbuf(p_) for p_ in w]
+    dx = None
+    if need_dx:
+        dx = dx_acc if dx_acc is not None else _empty(T * M, I, dev=dev)
+    tens = {'X': xf, 'DOUT': dout, 'LENGTHS': lengths, 'PERM': perm, 'DX': dx}
+    n_scr = lib().ptv_row_gru_persist_scratch_elems(H, M)
+    for d_ in range(2):
+        hall, gates, h16 = saved[d_][:3]
+        pk = notes_packs(w[4 * d_], w[4 * d_ + 1], 0)
+        tens.update({'PK_WT%d' % d_: pk['wt'], 'HALL%d' % d_: hall, 'H16_%d' % d_: h16, 'GATES%d' % d_: gates, 'WT_IH%d' % d_: wt_ih[d_],
+                     'DGI%d' % d_: _empty(T, M, 3 * H, dev=dev, dtype=BF16), 'DGH%d' % d_: _empty(T, M, 3 * H, dev=dev, dtype=BF16),
+                     'SCRATCH%d' % d_: _empty(n_scr, dev=dev, dtype=BF16),
+                     'TOP%d' % d_: _ineg1(dev) if (lengths is not None and M % 32 == 0) else None})
+    slots = [None] * T_['PTV_BRB_COUNT']
+    for k, v in tens.items():
+        slots[T_['PTV_BRB_' + k]] = ptr(v)
+    for d_ in range(2):
+        for j, nm in enumerate(('W_IH', 'W_HH', 'B_IH', 'B_HH')):
+            slots[T_['PTV_BRB_G_%s%d' % (nm, d_)]] = ptr(G[4 * d_ + j])
+    evs = _fork_events(_BRB)
+    slots[T_['PTV_BRB_FORK_EVENT']], slots[T_['PTV_BRB_JOIN_EVENT']] = evs[0].cuda_event, evs[1].cuda_event
+    slots[T_['PTV_BRB_SIDE_STREAM']] = side.s.cuda_stream
+    rc = lib().ptv_bigru_rows_bwd((ctypes.c_void_p * len(slots))(*slots), _larr(dims), stream_ptr())
+    _SIDE_DEPTH[1] = 1
+    if rc == -3:
+        return None
+    check(rc, 'ptv_bigru_rows_bwd')
+    _BRB['calls'] = _BRB.get('calls', 0) + 1
+    return G[0:4] + G[4:8], (dx.view(T, M, I) if need_dx else None)
 
 
 def _bigru_fwd_composite(prec, xf, lengths, w, w16, out, T, M, I, H, dev):
@@ -1039,6 +1138,10 @@ def _bigru_forward(prec, x3, lengths, w):
             # (the backward must skip the same fully masked panel steps, with the same row order)
             return hall, gates, h16, (lengths if ZERO_SKIP else None), perm
         side = Side(BIGRU_SLOT)
+        if BIGRU_BWD_COMPOSITE:
+            res = _bigru_rows_fwd_composite(x3, lengths, perm, w, out, side, T, M, I, H, dev)
+            if res is not None:
+                return res
         rev = side(lambda: rows(1), x3, out)
         fwd = rows(0)
         side.join()
@@ -1182,6 +1285,11 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None, rev_slot=Non
     elif (len(saved[0]) > 3 and saved[0][1].dtype == BF16 and saved[0][2] is not None):
         # (a forward that ran on the row kernels -- a 4-entry saved state -- left its gates in their private unit-blocked layout, and with
         # lengths the gates of skipped panel steps unwritten: same kernels back)
+        if BIGRU_BWD_COMPOSITE:
+            res = _bigru_rows_bwd_composite(prec, x3, xf, w, saved, dout, need_dx, dx_acc, side, T, M, I, H)
+            if res is not None:
+                return res
+
         def rows(d):
             w_ih, w_hh = w[4 * d], w[4 * d + 1]
             hall, gates, h16 = saved[d][:3]

@@ -151,6 +151,7 @@ def test_backward_composites_equal_python_sequencing(prec, B, via_loss):
         opt = FusedClipAdam(m.parameters(), lr=1e-3)        # (the bf16 weight shadows the composites read are the optimiser's)
         old, F_.CHD_BWD_COMPOSITE, F_.DEC_BWD_COMPOSITE, F_.BIGRU_BWD_COMPOSITE = (F_.CHD_BWD_COMPOSITE, F_.DEC_BWD_COMPOSITE, F_.BIGRU_BWD_COMPOSITE), comp, comp, comp
         n0, n1, n2, n3 = F_._CDB.get('calls', 0), F_._DTB.get('calls', 0), F_._BGB.get('calls', 0), F_._BGF.get('calls', 0)
+        n4, n5 = F_._BRF.get('calls', 0), F_._BRB.get('calls', 0)
         try:
             opt.zero_grad()
             if via_loss:
@@ -166,6 +167,10 @@ def test_backward_composites_equal_python_sequencing(prec, B, via_loss):
         assert (F_._BGB.get('calls', 0) - n2) == (2 if (comp and prec == 'bf16' and 8 * B >= 512) else 0)      # the two encoders' bi-GRUs
         # ... and the texture encoder's forward (the chord encoder's 36-wide input weight has no bf16 shadow: that one stays launch by launch)
         assert (F_._BGF.get('calls', 0) - n3) == (1 if (comp and prec == 'bf16') else 0)
+        # ... and the note-summary bi-GRU (row kernels), forward and backward
+        rows_branch = prec == 'bf16' and F_.row_gru_ok(1, 128, 128, 32 * B, torch.bfloat16)        # (many rows: the row kernels run it)
+        assert (F_._BRF.get('calls', 0) - n4) == (1 if (comp and rows_branch) else 0)
+        assert (F_._BRB.get('calls', 0) - n5) == (1 if (comp and rows_branch) else 0)
         res[comp] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
         F_.persist_check()
     for k in res[True]:
