@@ -1,5 +1,6 @@
 """Where the backward of the teacher-forced B=512 step spends its time on the MAIN stream, unprofiled: functional.mark() events.
-python scripts/trace_marks.py"""
+PTV_BWD_COMPOSITES=0 python scripts/trace_marks.py    (the marks inside the two decoders' backward passes exist on the launch-by-launch path
+only; with the one-call C entry points -- the default -- a node is a single mark)"""
 import os
 import random
 import sys
