@@ -600,6 +600,27 @@ enum PtvBrbTensor {
 enum PtvBrbDim { PTV_BRB_D_M = 0, PTV_BRB_D_T, PTV_BRB_D_H, PTV_BRB_D_I, PTV_BRB_D_DX_ACC, PTV_BRB_D_DOUT_LD, PTV_BRB_D_COUNT };
 int ptv_bigru_rows_bwd(const void* const* tensors, const long* dims, void* stream);
 
+/* ptv_vae_loss_fwd / ptv_vae_loss_bwd: DisentangleVAE.loss_function (model.py:57-68: PianoTree reconstruction CE x2 with ignore_index, the
+ * two KL terms, the three chord CEs, the 11 output scalars) and its backward, one call each -- what functional.VaeLossFn sequences (12 / 9
+ * launches).  scal = {beta, w0, w1, B * Z, 8 B, 96 B} as doubles.  PITCH_T / DUR_T / COUNTS: the targets of ptv_pianotree_targets; with
+ * d[PTV_VL_D_HAVE_TARGETS] they were computed by the caller already (DisentangleVAE.loss() does, before the decoder). */
+enum PtvVlTensor {
+  PTV_VL_X = 0, PTV_VL_C,                                    /* int64 [B,32,16,6], fp32 [B,8,36] */
+  PTV_VL_PITCH, PTV_VL_DUR,                                  /* logits in memory order: [480 B, ldp], [2400 B, 2] */
+  PTV_VL_MU_C, PTV_VL_SD_C, PTV_VL_MU_R, PTV_VL_SD_R,        /* [B, Z] */
+  PTV_VL_ROOT, PTV_VL_CHROMA, PTV_VL_BASS,                   /* [8 B, 12], [96 B, 2], [8 B, 12] */
+  PTV_VL_PITCH_T, PTV_VL_DUR_T, PTV_VL_COUNTS, PTV_VL_ROOT_T, PTV_VL_CHROMA_T, PTV_VL_BASS_T,   /* int32 targets / counts[3] */
+  PTV_VL_SUMS,            /* fwd: [8] fp32 ZEROED */
+  PTV_VL_OUT,             /* fwd out: [11] */
+  PTV_VL_GOUT,            /* bwd in: [11] */
+  PTV_VL_GS,              /* bwd scratch: [8] */
+  PTV_VL_DPITCH, PTV_VL_DDUR, PTV_VL_DMU_C, PTV_VL_DSD_C, PTV_VL_DMU_R, PTV_VL_DSD_R, PTV_VL_DROOT, PTV_VL_DCHROMA, PTV_VL_DBASS,   /* bwd out */
+  PTV_VL_COUNT
+};
+enum PtvVlDim { PTV_VL_D_B = 0, PTV_VL_D_Z, PTV_VL_D_NP, PTV_VL_D_LDP, PTV_VL_D_SM_P, PTV_VL_D_SM_C, PTV_VL_D_HAVE_TARGETS, PTV_VL_D_COUNT };
+int ptv_vae_loss_fwd(const void* const* tensors, const long* dims, const double* scal, void* stream);
+int ptv_vae_loss_bwd(const void* const* tensors, const long* dims, const double* scal, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Free-running tokens.
  * ptv_note_token (ptvae.py:408-416 + pitch_dur_ind_to_note_token :328-334): per row pitch argmax (first

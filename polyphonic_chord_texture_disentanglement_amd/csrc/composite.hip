@@ -550,3 +550,59 @@ extern "C" int ptv_bigru_rows_bwd(const void* const* t, const long* d, void* str
   if (want_dx) PTV_TRY(dx_of(1, 1));
   return PTV_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// ptv_vae_loss_fwd / ptv_vae_loss_bwd: functional.VaeLossFn's two launch sequences
+// ---------------------------------------------------------------------------------------------
+extern "C" int ptv_vae_loss_fwd(const void* const* t, const long* d, const double* sc, void* stream) {
+  if (!t || !d || !sc) return PTV_ERR_ARG;
+  const int B = (int)d[PTV_VL_D_B], Z = (int)d[PTV_VL_D_Z], NP = (int)d[PTV_VL_D_NP], sm_p = (int)d[PTV_VL_D_SM_P], sm_c = (int)d[PTV_VL_D_SM_C];
+  const long ldp = d[PTV_VL_D_LDP];
+  const int need[] = {PTV_VL_X, PTV_VL_C, PTV_VL_PITCH, PTV_VL_DUR, PTV_VL_MU_C, PTV_VL_SD_C, PTV_VL_MU_R, PTV_VL_SD_R, PTV_VL_ROOT, PTV_VL_CHROMA,
+                      PTV_VL_BASS, PTV_VL_PITCH_T, PTV_VL_DUR_T, PTV_VL_COUNTS, PTV_VL_ROOT_T, PTV_VL_CHROMA_T, PTV_VL_BASS_T, PTV_VL_SUMS, PTV_VL_OUT};
+  for (int i : need) if (!t[i]) return PTV_ERR_ARG;
+  if (B <= 0 || Z <= 0 || NP <= 0 || ldp < NP) return PTV_ERR_ARG;
+  const long rows = (long)B * 480;
+  float* sums = M_<float>(t, PTV_VL_SUMS);
+  int* pitch_t = M_<int>(t, PTV_VL_PITCH_T); int* dur_t = M_<int>(t, PTV_VL_DUR_T); int* counts = M_<int>(t, PTV_VL_COUNTS);
+  if (!d[PTV_VL_D_HAVE_TARGETS]) PTV_TRY(ptv_pianotree_targets((const long*)T_(t, PTV_VL_X), B, sm_p, pitch_t, dur_t, counts, stream));
+  PTV_TRY(ptv_ce_fwd((const float*)T_(t, PTV_VL_PITCH), ldp, pitch_t, rows, NP, 130, sums + 0, stream));
+  PTV_TRY(ptv_ce_fwd((const float*)T_(t, PTV_VL_DUR), 2, dur_t, rows * 5, 2, 2, sums + 1, stream));
+  int* root_t = M_<int>(t, PTV_VL_ROOT_T); int* chroma_t = M_<int>(t, PTV_VL_CHROMA_T); int* bass_t = M_<int>(t, PTV_VL_BASS_T);
+  PTV_TRY(ptv_chord_targets((const float*)T_(t, PTV_VL_C), B, sm_c, root_t, chroma_t, bass_t, stream));
+  PTV_TRY(ptv_kl_fwd((const float*)T_(t, PTV_VL_MU_C), (const float*)T_(t, PTV_VL_SD_C), (long)B * Z, sums + 2, stream));
+  PTV_TRY(ptv_kl_fwd((const float*)T_(t, PTV_VL_MU_R), (const float*)T_(t, PTV_VL_SD_R), (long)B * Z, sums + 3, stream));
+  PTV_TRY(ptv_ce_fwd((const float*)T_(t, PTV_VL_ROOT), 12, root_t, (long)B * 8, 12, -1, sums + 4, stream));
+  PTV_TRY(ptv_ce_fwd((const float*)T_(t, PTV_VL_CHROMA), 2, chroma_t, (long)B * 96, 2, -1, sums + 5, stream));
+  PTV_TRY(ptv_ce_fwd((const float*)T_(t, PTV_VL_BASS), 12, bass_t, (long)B * 8, 12, -1, sums + 6, stream));
+  return ptv_loss_finalize(sums, counts, (float)sc[0], (float)sc[1], (float)sc[2], (float)sc[3], (float)sc[4], (float)sc[5], M_<float>(t, PTV_VL_OUT),
+                           stream);
+}
+
+extern "C" int ptv_vae_loss_bwd(const void* const* t, const long* d, const double* sc, void* stream) {
+  if (!t || !d || !sc) return PTV_ERR_ARG;
+  const int B = (int)d[PTV_VL_D_B], Z = (int)d[PTV_VL_D_Z], NP = (int)d[PTV_VL_D_NP];
+  const long ldp = d[PTV_VL_D_LDP];
+  const int need[] = {PTV_VL_PITCH, PTV_VL_DUR, PTV_VL_MU_C, PTV_VL_SD_C, PTV_VL_MU_R, PTV_VL_SD_R, PTV_VL_ROOT, PTV_VL_CHROMA, PTV_VL_BASS, PTV_VL_PITCH_T,
+                      PTV_VL_DUR_T, PTV_VL_COUNTS, PTV_VL_ROOT_T, PTV_VL_CHROMA_T, PTV_VL_BASS_T, PTV_VL_GOUT, PTV_VL_GS, PTV_VL_DPITCH, PTV_VL_DDUR,
+                      PTV_VL_DMU_C, PTV_VL_DSD_C, PTV_VL_DMU_R, PTV_VL_DSD_R, PTV_VL_DROOT, PTV_VL_DCHROMA, PTV_VL_DBASS};
+  for (int i : need) if (!t[i]) return PTV_ERR_ARG;
+  if (B <= 0 || Z <= 0 || NP <= 0 || ldp < NP) return PTV_ERR_ARG;
+  const long rows = (long)B * 480;
+  float* gs = M_<float>(t, PTV_VL_GS);
+  PTV_TRY(ptv_loss_bwd_scales((const float*)T_(t, PTV_VL_GOUT), (const int*)T_(t, PTV_VL_COUNTS), (float)sc[0], (float)sc[1], (float)sc[2], (float)sc[3],
+                              (float)sc[4], (float)sc[5], gs, stream));
+  PTV_TRY(ptv_ce_bwd((const float*)T_(t, PTV_VL_PITCH), ldp, (const int*)T_(t, PTV_VL_PITCH_T), rows, NP, 130, gs + 0, M_<float>(t, PTV_VL_DPITCH), ldp,
+                     stream));
+  PTV_TRY(ptv_ce_bwd((const float*)T_(t, PTV_VL_DUR), 2, (const int*)T_(t, PTV_VL_DUR_T), rows * 5, 2, 2, gs + 1, M_<float>(t, PTV_VL_DDUR), 2, stream));
+  PTV_TRY(ptv_kl_bwd((const float*)T_(t, PTV_VL_MU_C), (const float*)T_(t, PTV_VL_SD_C), (long)B * Z, gs + 2, M_<float>(t, PTV_VL_DMU_C),
+                     M_<float>(t, PTV_VL_DSD_C), stream));
+  PTV_TRY(ptv_kl_bwd((const float*)T_(t, PTV_VL_MU_R), (const float*)T_(t, PTV_VL_SD_R), (long)B * Z, gs + 3, M_<float>(t, PTV_VL_DMU_R),
+                     M_<float>(t, PTV_VL_DSD_R), stream));
+  PTV_TRY(ptv_ce_bwd((const float*)T_(t, PTV_VL_ROOT), 12, (const int*)T_(t, PTV_VL_ROOT_T), (long)B * 8, 12, -1, gs + 4, M_<float>(t, PTV_VL_DROOT), 12,
+                     stream));
+  PTV_TRY(ptv_ce_bwd((const float*)T_(t, PTV_VL_CHROMA), 2, (const int*)T_(t, PTV_VL_CHROMA_T), (long)B * 96, 2, -1, gs + 5, M_<float>(t, PTV_VL_DCHROMA),
+                     2, stream));
+  return ptv_ce_bwd((const float*)T_(t, PTV_VL_BASS), 12, (const int*)T_(t, PTV_VL_BASS_T), (long)B * 8, 12, -1, gs + 6, M_<float>(t, PTV_VL_DBASS), 12,
+                    stream);
+}

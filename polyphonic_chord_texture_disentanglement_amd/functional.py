@@ -2651,6 +2651,75 @@ def _loss_top_hint(dpitch, ddur):
 LOSS_TOP_HINT = True
 
 
+LOSS_COMPOSITE = os.environ.get('PTV_BWD_COMPOSITES', '1') != '0'     # VaeLossFn through ptv_vae_loss_fwd / ptv_vae_loss_bwd (one C call each)
+_VL = {}
+
+
+def _vl_tables():
+    if 't' not in _VL:
+        from ._lib import header_enum
+        _VL['t'], _VL['d'] = header_enum('PtvVlTensor'), header_enum('PtvVlDim')
+    return _VL['t'], _VL['d']
+
+
+def _vl_ok(*ts):
+    return all(t.is_cuda and t.dtype == F32 and t.is_contiguous() for t in ts)
+
+
+def _vae_loss_fwd_composite(pitch, dur, x, c, mu_c, sd_c, mu_r, sd_r, root_m, chroma_m, bass_m, sm_c, root_t, chroma_t, bass_t, sums, out, scal, st):
+    """-> (pitch_m, dur_m, sm_p, pitch_t, dur_t, counts) when ptv_vae_loss_fwd ran, else None"""
+    T_, D_ = _vl_tables()
+    (pitch_m, dur_m), sm_p = _mem_order([pitch, dur], [_PERM[4], _PERM[5]])
+    B = x.shape[0]
+    NP = pitch.shape[-1]
+    if (x.dtype != torch.int64 or not _vl_ok(c, mu_c, sd_c, mu_r, sd_r, root_m, chroma_m, bass_m) or pitch_m.dtype != F32 or dur_m.dtype != F32
+            or not dur_m.is_contiguous() or not _row_dense(pitch_m) or pitch_m.numel() != B * 480 * NP or dur_m.numel() != B * 4800):
+        return None
+    dev = pitch.device
+    cached = _cached_targets(x, sm_p)
+    if cached is not None:
+        pitch_t, dur_t, counts = cached
+    else:
+        pitch_t = torch.empty(B * 480, device=dev, dtype=torch.int32)
+        dur_t = torch.empty(B * 2400, device=dev, dtype=torch.int32)
+        counts = _izeros(3, dev)
+    dims = [0] * D_['PTV_VL_D_COUNT']
+    for k, v in (('B', B), ('Z', mu_c.shape[1]), ('NP', NP), ('LDP', pitch_m.stride(-2)), ('SM_P', int(sm_p)), ('SM_C', int(sm_c)),
+                 ('HAVE_TARGETS', int(cached is not None))):
+        dims[D_['PTV_VL_D_' + k]] = v
+    slots = [None] * T_['PTV_VL_COUNT']
+    for k, v in (('X', x), ('C', c), ('PITCH', pitch_m), ('DUR', dur_m), ('MU_C', mu_c), ('SD_C', sd_c), ('MU_R', mu_r), ('SD_R', sd_r),
+                 ('ROOT', root_m), ('CHROMA', chroma_m), ('BASS', bass_m), ('PITCH_T', pitch_t), ('DUR_T', dur_t), ('COUNTS', counts),
+                 ('ROOT_T', root_t), ('CHROMA_T', chroma_t), ('BASS_T', bass_t), ('SUMS', sums), ('OUT', out)):
+        slots[T_['PTV_VL_' + k]] = ptr(v)
+    rc = lib().ptv_vae_loss_fwd((ctypes.c_void_p * len(slots))(*slots), _larr(dims), (ctypes.c_double * 6)(*scal), st)
+    check(rc, 'ptv_vae_loss_fwd')
+    _VL['calls'] = _VL.get('calls', 0) + 1
+    return pitch_m, dur_m, sm_p, pitch_t, dur_t, counts
+
+
+def _vae_loss_bwd_composite(gout, gs, pitch_m, dur_m, mu_c, sd_c, mu_r, sd_r, root_m, chroma_m, bass_m, pitch_t, dur_t, counts, root_t, chroma_t,
+                            bass_t, dpitch, ddur, dmu_c, dsd_c, dmu_r, dsd_r, droot, dchroma, dbass, scal, st):
+    T_, D_ = _vl_tables()
+    B = root_t.numel() // 8
+    NP = pitch_m.shape[-1]
+    if gout.dtype != F32 or not _row_dense(pitch_m) or not dur_m.is_contiguous():
+        return False
+    dims = [0] * D_['PTV_VL_D_COUNT']
+    for k, v in (('B', B), ('Z', mu_c.shape[1]), ('NP', NP), ('LDP', pitch_m.stride(-2))):
+        dims[D_['PTV_VL_D_' + k]] = v
+    slots = [None] * T_['PTV_VL_COUNT']
+    for k, v in (('PITCH', pitch_m), ('DUR', dur_m), ('MU_C', mu_c), ('SD_C', sd_c), ('MU_R', mu_r), ('SD_R', sd_r), ('ROOT', root_m),
+                 ('CHROMA', chroma_m), ('BASS', bass_m), ('PITCH_T', pitch_t), ('DUR_T', dur_t), ('COUNTS', counts), ('ROOT_T', root_t),
+                 ('CHROMA_T', chroma_t), ('BASS_T', bass_t), ('GOUT', gout), ('GS', gs), ('DPITCH', dpitch), ('DDUR', ddur), ('DMU_C', dmu_c),
+                 ('DSD_C', dsd_c), ('DMU_R', dmu_r), ('DSD_R', dsd_r), ('DROOT', droot), ('DCHROMA', dchroma), ('DBASS', dbass)):
+        slots[T_['PTV_VL_' + k]] = ptr(v)
+    rc = lib().ptv_vae_loss_bwd((ctypes.c_void_p * len(slots))(*slots), _larr(dims), (ctypes.c_double * 6)(*scal), st)
+    check(rc, 'ptv_vae_loss_bwd')
+    _VL['bwd_calls'] = _VL.get('bwd_calls', 0) + 1
+    return True
+
+
 class VaeLossFn(torch.autograd.Function):
     """(pitch [B,32,15,130], dur [B,32,15,5,2], mu_c, sd_c, mu_r, sd_r, root [B,8,12], chroma [B,8,12,2],
     bass [B,8,12], x, c, beta, w0, w1) -> the 11 scalars of model.py:67-68 as one [11] tensor."""
@@ -2680,12 +2749,20 @@ class VaeLossFn(torch.autograd.Function):
             call('ptv_ce_fwd', ptr(root_m), 12, ptr(root_t), B * 8, 12, -1, ptr(sums[4:]), st2)
             call('ptv_ce_fwd', ptr(chroma_m), 2, ptr(chroma_t), B * 96, 2, -1, ptr(sums[5:]), st2)
             call('ptv_ce_fwd', ptr(bass_m), 12, ptr(bass_t), B * 8, 12, -1, ptr(sums[6:]), st2)
-        pitch_m, dur_m, sm_p, pitch_t, dur_t, counts, gcnt = _pianotree_ce_fwd(pitch, dur, x, sums, st, weighted_dur)
-        ctx.gcnt = gcnt
-        small()                                   # (on a sibling stream beside the PianoTree cross-entropy: 8.298 against 8.302 ms -- in line)
         out = _empty(11, dev=dev)
         ctx.scal = (float(beta), float(w0), float(w1), float(B * Z), float(B * 8), float(B * 96))
-        call('ptv_loss_finalize', ptr(sums), ptr(counts), *ctx.scal, ptr(out), st)
+        comp = None
+        if LOSS_COMPOSITE and not weighted_dur:
+            comp = _vae_loss_fwd_composite(pitch, dur, x, c, mu_c, sd_c, mu_r, sd_r, root_m, chroma_m, bass_m, sm_c, root_t, chroma_t, bass_t,
+                                           sums, out, ctx.scal, st)
+        if comp is not None:
+            pitch_m, dur_m, sm_p, pitch_t, dur_t, counts = comp
+            ctx.gcnt = None
+        else:
+            pitch_m, dur_m, sm_p, pitch_t, dur_t, counts, gcnt = _pianotree_ce_fwd(pitch, dur, x, sums, st, weighted_dur)
+            ctx.gcnt = gcnt
+            small()                               # (on a sibling stream beside the PianoTree cross-entropy: 8.298 against 8.302 ms -- in line)
+            call('ptv_loss_finalize', ptr(sums), ptr(counts), *ctx.scal, ptr(out), st)
         ctx.save_for_backward(pitch_m, dur_m, mu_c, sd_c, mu_r, sd_r, root_m, chroma_m, bass_m, pitch_t, dur_t, counts,
                               root_t, chroma_t, bass_t)
         ctx.sm = (sm_p, sm_c)
@@ -2700,10 +2777,22 @@ class VaeLossFn(torch.autograd.Function):
         st = stream_ptr()
         reset_deferred()                        # first node of the backward pass: nothing may be left from an aborted one
         gs = _empty(8, dev=dev)
-        call('ptv_loss_bwd_scales', ptr(gout.contiguous()), ptr(counts), *ctx.scal, ptr(gs), st)
         dmu_c, dsd_c = torch.empty_like(mu_c), torch.empty_like(sd_c)
         dmu_r, dsd_r = torch.empty_like(mu_r), torch.empty_like(sd_r)
         droot, dchroma, dbass = torch.empty_like(root_m), torch.empty_like(chroma_m), torch.empty_like(bass_m)
+        done = False
+        if LOSS_COMPOSITE and ctx.gcnt is None:
+            NP = pitch_m.shape[-1]
+            ld = pitch_m.stride(-2)
+            dpitch = torch.empty(pitch_t.numel(), ld, device=dev)[:, :NP].as_strided(pitch_m.shape, pitch_m.stride())
+            ddur = torch.empty_like(dur_m)
+            done = _vae_loss_bwd_composite(gout.contiguous(), gs, pitch_m, dur_m, mu_c, sd_c, mu_r, sd_r, root_m, chroma_m, bass_m, pitch_t, dur_t,
+                                           counts, root_t, chroma_t, bass_t, dpitch, ddur, dmu_c, dsd_c, dmu_r, dsd_r, droot, dchroma, dbass,
+                                           ctx.scal, st)
+            if done and sm_p:
+                dpitch, ddur = dpitch.permute(*_PERM[4]), ddur.permute(*_PERM[5])
+        if not done:
+            call('ptv_loss_bwd_scales', ptr(gout.contiguous()), ptr(counts), *ctx.scal, ptr(gs), st)
 
         def small():
             st2 = stream_ptr()
@@ -2712,8 +2801,9 @@ class VaeLossFn(torch.autograd.Function):
             call('ptv_ce_bwd', ptr(root_m), 12, ptr(root_t), root_t.numel(), 12, -1, ptr(gs[4:]), ptr(droot), 12, st2)
             call('ptv_ce_bwd', ptr(chroma_m), 2, ptr(chroma_t), chroma_t.numel(), 2, -1, ptr(gs[5:]), ptr(dchroma), 2, st2)
             call('ptv_ce_bwd', ptr(bass_m), 12, ptr(bass_t), bass_t.numel(), 12, -1, ptr(gs[6:]), ptr(dbass), 12, st2)
-        dpitch, ddur = _pianotree_ce_bwd(pitch_m, dur_m, sm_p, pitch_t, dur_t, gs, st, ctx.gcnt)
-        small()
+        if not done:
+            dpitch, ddur = _pianotree_ce_bwd(pitch_m, dur_m, sm_p, pitch_t, dur_t, gs, st, ctx.gcnt)
+            small()
         if sm_c:
             droot, dchroma, dbass = (t.permute(*_chord_perm(t)) for t in (droot, dchroma, dbass))
         # zero-skip limit for whoever consumes exactly these two gradients (DecoderTFFn / DecoderStepFn): the last note step with a

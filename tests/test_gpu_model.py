@@ -150,6 +150,8 @@ def test_backward_composites_equal_python_sequencing(prec, B, via_loss):
         m.use_philox(11, 0)
         opt = FusedClipAdam(m.parameters(), lr=1e-3)        # (the bf16 weight shadows the composites read are the optimiser's)
         old, F_.CHD_BWD_COMPOSITE, F_.DEC_BWD_COMPOSITE, F_.BIGRU_BWD_COMPOSITE = (F_.CHD_BWD_COMPOSITE, F_.DEC_BWD_COMPOSITE, F_.BIGRU_BWD_COMPOSITE), comp, comp, comp
+        old_l, F_.LOSS_COMPOSITE = F_.LOSS_COMPOSITE, comp
+        n6, n7 = F_._VL.get('calls', 0), F_._VL.get('bwd_calls', 0)
         n0, n1, n2, n3 = F_._CDB.get('calls', 0), F_._DTB.get('calls', 0), F_._BGB.get('calls', 0), F_._BGF.get('calls', 0)
         n4, n5 = F_._BRF.get('calls', 0), F_._BRB.get('calls', 0)
         try:
@@ -162,6 +164,8 @@ def test_backward_composites_equal_python_sequencing(prec, B, via_loss):
             torch.cuda.synchronize()
         finally:
             F_.CHD_BWD_COMPOSITE, F_.DEC_BWD_COMPOSITE, F_.BIGRU_BWD_COMPOSITE = old
+            F_.LOSS_COMPOSITE = old_l
+        assert (F_._VL.get('calls', 0) - n6) == int(comp) and (F_._VL.get('bwd_calls', 0) - n7) == int(comp)      # the loss node, both ways
         assert (F_._CDB.get('calls', 0) > n0) == comp
         assert (F_._DTB.get('calls', 0) > n1) == (comp and prec == 'bf16')
         assert (F_._BGB.get('calls', 0) - n2) == (2 if (comp and prec == 'bf16' and 8 * B >= 512) else 0)      # the two encoders' bi-GRUs
@@ -172,6 +176,7 @@ def test_backward_composites_equal_python_sequencing(prec, B, via_loss):
         assert (F_._BRF.get('calls', 0) - n4) == (1 if (comp and rows_branch) else 0)
         assert (F_._BRB.get('calls', 0) - n5) == (1 if (comp and rows_branch) else 0)
         res[comp] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        res[comp]['_losses'] = torch.stack([l.detach() for l in losses]).clone()
         F_.persist_check()
     for k in res[True]:
         assert torch.isfinite(res[True][k]).all(), k
