@@ -568,7 +568,9 @@ enum PtvBgfTensor {
   PTV_BGF_XCH0, PTV_BGF_XCH1, PTV_BGF_SYNC, PTV_BGF_WAIT_EVENT, PTV_BGF_RECORD_EVENT,
   PTV_BGF_COUNT
 };
-enum PtvBgfDim { PTV_BGF_D_M = 0, PTV_BGF_D_T, PTV_BGF_D_H, PTV_BGF_D_I, PTV_BGF_D_X_BF16, PTV_BGF_D_COUNT };
+enum PtvBgfDim { PTV_BGF_D_M = 0, PTV_BGF_D_T, PTV_BGF_D_H, PTV_BGF_D_I, PTV_BGF_D_X_BF16,
+                 PTV_BGF_D_WIH_F32,   /* W16_IH* are the fp32 masters (an input width that is no multiple of 8 has no bf16 shadow) */
+                 PTV_BGF_D_COUNT };
 int ptv_bigru_final_fwd(const void* const* tensors, const long* dims, void* stream);
 
 /* ptv_bigru_rows_fwd / ptv_bigru_rows_bwd: the same pair for a bi-GRU over MANY short independent rows (dec_notes_emb_gru, the ground-truth

@@ -448,7 +448,7 @@ extern "C" int ptv_bigru_final_fwd(const void* const* t, const long* d, void* st
   const int wih_slot[2] = {PTV_BGF_W16_IH0, PTV_BGF_W16_IH1}, bih_slot[2] = {PTV_BGF_B_IH0, PTV_BGF_B_IH1};
   for (int dir = 0; dir < 2; dir++) {
     PTV_TRY(ptv_gemm(P, 0, 0, (int)TM, 3 * H, I, T_(t, PTV_BGF_X), I, T_(t, wih_slot[dir]), I, M_<void>(t, gi_slot[dir]), 3L * H,
-                     (const float*)T_(t, bih_slot[dir]), 1.f, 0, 0, -1, (xbf ? A16 : 0) | B16 | C16, stream));
+                     (const float*)T_(t, bih_slot[dir]), 1.f, 0, 0, -1, (xbf ? A16 : 0) | (d[PTV_BGF_D_WIH_F32] ? 0 : B16) | C16, stream));
     if (hipMemsetAsync(M_<void>(t, hall_slot[dir]), 0, sizeof(float) * M * H, s) != hipSuccess) return PTV_ERR_LAUNCH;
   }
   {

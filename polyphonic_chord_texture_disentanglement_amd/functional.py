@@ -1035,10 +1035,10 @@ def _bigru_fwd_composite(prec, xf, lengths, w, w16, out, T, M, I, H, dev):
     T_, D_ = _BGF['t'], _BGF['d']
     wih16 = [_W(w[0], prec), _W(w[4], prec)]
     if (torch.cuda.is_current_stream_capturing() or xf.dtype not in (F32, BF16) or xf.stride(1) != 1 or xf.stride(0) != I
-            or wih16[0].dtype != BF16 or wih16[1].dtype != BF16 or not wih16[0].is_contiguous() or not wih16[1].is_contiguous()):
+            or wih16[0].dtype != wih16[1].dtype or not wih16[0].is_contiguous() or not wih16[1].is_contiguous()):
         return None
     dims = [0] * D_['PTV_BGF_D_COUNT']
-    for k, v in (('M', M), ('T', T), ('H', H), ('I', I), ('X_BF16', _bf(xf))):
+    for k, v in (('M', M), ('T', T), ('H', H), ('I', I), ('X_BF16', _bf(xf)), ('WIH_F32', int(wih16[0].dtype == F32))):
         dims[D_['PTV_BGF_D_' + k]] = v
     saved = []
     tens = {'X': xf, 'LENGTHS': lengths, 'OUT': out, 'SYNC': _persist_sync(2, dev)}
