@@ -572,6 +572,14 @@ def main():
                'step_tflops': round(value * GFLOP_PER_SAMPLE_TRAIN / 1e3, 2), 'final_loss': round(loss, 4),
                'host_enqueue_ms_per_step': round((t_host - t_wait) / args.steps * 1e3, 3),
                'host_wait_ms_per_step': round(t_wait / args.steps * 1e3, 3), 'roofline': roof}
+        if args.mode == 'train' and args.tfr >= 1.0:
+            from polyphonic_chord_texture_disentanglement_amd import functional as F_
+            res['exact_work_elision'] = {
+                'zero_skip_backward': bool(F_.ZERO_SKIP), 'dead_note_steps_forward': bool(F_.DEAD_STEPS and F_.ZERO_SKIP),
+                'note': 'same losses / gradients / parameter updates as the dense step: the backward passes over work whose result is '
+                        'exactly zero, and loss() does not compute decoder outputs that the loss ignores (padded note slots after the batch\'s '
+                        'last target); extra.train_teacher_forced_full_forward = forward dense, extra.train_teacher_forced_dense_backward '
+                        '= everything dense (DESIGN.md section 4)'}
         if dp is not None:
             res['data_parallel'] = dp
         from polyphonic_chord_texture_disentanglement_amd.functional import persist_check
