@@ -191,3 +191,46 @@ def test_dead_helpers_of_the_reference_model_exist_and_compute_what_it_defines()
     exp = pr.clone()
     exp[nz[:, 0], nz[:, 1], torch.clamp(nz[:, 2] + eps, min=0, max=127)] = exp[nz[:, 0], nz[:, 1], nz[:, 2]]
     assert torch.equal(out, exp) and (out != pr).any()
+
+
+def test_loss_node_zero_skip_hint_matches_only_the_very_tensors():
+    """functional._loss_top_hint: the loss node's zero-skip bound must be honoured for exactly the gradient tensors it produced -- the same
+    storage, shape, strides and version, whatever Python wrapper they arrive in (the engine hands them over through C++) -- and for nothing
+    else: not a copy, not an in-place modified tensor, not a view with another shape.  (Round 5: an identity-based key never matched and the
+    decoder silently scanned the gradients every step.)"""
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    dp, dd, top = torch.zeros(6, 8), torch.zeros(6, 10), torch.tensor([3], dtype=torch.int32)
+
+    def arm():
+        F_._LOSS_TOP.clear()
+        F_._LOSS_TOP['hint'] = (dp, dd, dp._version, dd._version, top)
+    arm()
+    assert F_._loss_top_hint(dp.view(6, 8), dd.view(6, 10)) is top          # new wrapper objects of the same tensors: accepted
+    assert F_._loss_top_hint(dp, dd) is None                                 # consumed: one use
+    arm()
+    assert F_._loss_top_hint(dp.clone(), dd) is None                         # a copy (autograd accumulated another contribution)
+    arm()
+    dp.add_(0)
+    assert F_._loss_top_hint(dp, dd) is None                                 # modified in place (a tensor hook): version bumped
+    arm()
+    assert F_._loss_top_hint(dp.view(8, 6), dd) is None                      # same storage, other shape
+    arm()
+    assert F_._loss_top_hint(None, dd) is None
+    F_._LOSS_TOP.clear()
+
+
+def test_grad_arena_views_are_fresh_objects_over_the_bucket():
+    """optim.GradArena.view: a new tensor object per call (autograd adopts a gradient only when nothing else references it) that aliases
+    the parameter's 16-byte aligned range of the flat bucket with the parameter's shape"""
+    from polyphonic_chord_texture_disentanglement_amd.optim import GradArena
+    ps = [torch.nn.Parameter(torch.randn(3, 5)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 3, 4))]
+    a = GradArena(ps)
+    for i, p in enumerate(ps):
+        v1, v2 = a.view(p), a.view(p)
+        assert v1 is not v2 and v1.shape == p.shape and v1.is_contiguous()
+        assert v1.data_ptr() == a.flat.data_ptr() + 4 * a.offsets[i] and a.offsets[i] % 8 == 0
+        v1.fill_(i + 1)
+        assert float(a.flat[a.offsets[i]:a.offsets[i] + p.numel()].sum()) == (i + 1) * p.numel()
+    assert a.take(ps[0]) is not None and a.take(ps[0]) is None               # handed out once per zero()
+    a.zero()
+    assert float(a.flat.abs().sum()) == 0 and a.take(ps[0]) is not None
