@@ -505,6 +505,9 @@ def main():
         if rank == 0:
             torch.cuda.synchronize()
             print('[bench] warmup step %d done' % i, file=sys.stderr, flush=True)
+    import gc
+    gc.collect()                                           # a full collection (~100 ms: it walks the whole module tree) must not fall into
+    gc.freeze()                                            # the timed steps; what is alive now moves to the permanent generation
     barrier()
     lib.ptv_prof_reset()
     lib.ptv_prof_config(32 * B, model.decoder.dec_notes_hid_size)
@@ -585,7 +588,9 @@ def main():
         from polyphonic_chord_texture_disentanglement_amd.functional import persist_check
         persist_check()                                        # a persistent launch that gave up would have invalidated the run
         if world == 1 and args.mode == 'train' and not args.no_extras:
+            gc.unfreeze()                                      # (the headline model may be collected again: the side figures build their own)
             del model, opt
+            gc.collect()
             torch.cuda.empty_cache()
             try:
                 res['extra'] = extras(dev, B, rank)

@@ -337,8 +337,18 @@ class FusedClipAdam(torch.optim.Optimizer):
     # device-wide synchronisation (36 of them in 120 steps, one ~60-ms stall every ~40 steps: scripts/probe_stall.py).  So the host waits for
     # the step before the previous one to finish before it enqueues the next: never a bubble (two whole steps stay queued), bounded memory.
     MAX_STEPS_IN_FLIGHT = 2
+    # A FULL garbage collection walks every tracked Python object of the process (the module tree, the autograd closures, torch's own
+    # registries): ~100 ms, and the first one falls around the 20th step -- measured as one 15-18 ms "step" average per 12-step round,
+    # 3 runs of 3 (scripts/ab_step.py), gone in 3 of 3 once everything alive after the third step is frozen (moved to the permanent
+    # generation: later collections only walk what was created since).  None = leave the collector alone.
+    GC_FREEZE_AT_STEP = 3
 
     def _throttle(self):
+        if self.GC_FREEZE_AT_STEP is not None and self.step_count == self.GC_FREEZE_AT_STEP and not self.__dict__.get('_gc_frozen'):
+            import gc
+            gc.collect()
+            gc.freeze()
+            self._gc_frozen = True
         if torch.cuda.is_current_stream_capturing():
             return
         q = self.__dict__.setdefault('_inflight', [])
