@@ -714,11 +714,12 @@ EMBED_MH_FWD = True    # multi-hot operand of the note_embedding gradient built 
 # decoder backward: fork the weight-gradient work BEFORE the chain queues its next dX products (no false dependency on them)?  Measured
 # 9.43 vs 9.37 ms: the products then compete with the chain's own dX products for the CUs -- the later fork is the better schedule
 # stream slot of a bi-GRU's second direction, forward / backward.  In the backward slot 7 = pool stream 3 is also the stream of the decoder's
-# deferred weight-gradient products (Side(3)): the reversed directions of the note-summary and encoder BPTTs queue behind them.  Moving
-# them to another pool stream measured SLOWER (slot 8 / 6 / 5: 9.40 / 9.39 / 9.29 vs 9.09 ms): running everything at once costs more
-# in contention than the queueing does.
+# deferred weight-gradient products (Side(3)): until round 5 the reversed directions of the note-summary and encoder BPTTs queued behind
+# them there (moving them measured SLOWER in round 4: slot 8 / 6 / 5: 9.40 / 9.39 / 9.29 vs 9.09 ms).  Measured again at the end of round 5
+# -- shorter forward, shorter host, the chord encoder itself on stream 3 (model.CHD_ENC_SLOT) -- slot 4 (pool stream 0, the chord decoder's,
+# idle in the tail) wins: 7.32-7.43 against 7.49-7.68 ms alone, 6.97-7.15 with the encoder move; slots 5 / 6 the same within noise.
 BIGRU_SLOT = 7
-BIGRU_SLOT_BWD = 7
+BIGRU_SLOT_BWD = 4
 # note-summary bi-GRU: panels of rows sorted by length (ptv_rows_by_length + the *_perm entry points).  Measured, round 5 (profiles/
 # r05_ab_runs.txt): the launches do half the work (mean length 3.8 against a panel maximum of 8) but stay as long as their longest panel --
 # 225 / 242 us against 210 / 233 us in situ, step 7.69-7.71 against 7.64-7.67 ms: they are latency-bound per step, and what they leave

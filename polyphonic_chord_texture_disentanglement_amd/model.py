@@ -18,7 +18,13 @@ LOSS_NAMES = ['loss', 'recon_loss', 'pl', 'dl', 'kl_loss', 'kl_chd', 'kl_rhy', '
               'chroma_loss', 'bass_loss']                       # train.py:54-55
 
 
-CHD_ENC_SLOT = 1
+# Stream slots of the two encoders (pool stream = slot mod 4; autograd replays a branch's backward on the stream of its forward).  Round 5,
+# after loss() stopped computing the dead note steps and the backward passes moved behind the C ABI, the schedule was measured again
+# (scripts/ab_combo.py, 5-6 interleaved rounds per setting, profiles/r05_ab_runs.txt): the chord encoder on pool stream 3 -- the stream of
+# the decoder's deferred weight-gradient products, so its BPTT runs AFTER them in the tail instead of beside them -- with the bi-GRUs'
+# reversed-direction products on pool stream 0 (functional.BIGRU_SLOT_BWD = 4): 6.97-7.15 ms per step against 7.49-7.68 (slots 1 / 7);
+# both encoders on stream 3: 7.47-7.56 (their forwards serialise); the texture encoder on 1 instead of 2: the same.
+CHD_ENC_SLOT = 3
 RHY_ENC_SLOT = 2
 # The two encoders ARE the latency chain of the head of the step (the decoder waits for z; the embedding / note summaries beside them are
 # needed later): their products keep the raised wave priority although they run inside sibling-stream calls, the note-summary GRUs drop it
