@@ -720,6 +720,7 @@ EMBED_MH_FWD = True    # multi-hot operand of the note_embedding gradient built 
 # idle in the tail) wins: 7.32-7.43 against 7.49-7.68 ms alone, 6.97-7.15 with the encoder move; slots 5 / 6 the same within noise.
 BIGRU_SLOT = 7
 BIGRU_SLOT_BWD = 4
+DEC_WGRAD_SLOT = 3      # pool stream of the decoder's deferred weight-gradient products
 # note-summary bi-GRU: panels of rows sorted by length (ptv_rows_by_length + the *_perm entry points).  Measured, round 5 (profiles/
 # r05_ab_runs.txt): the launches do half the work (mean length 3.8 against a panel maximum of 8) but stay as long as their longest panel --
 # 225 / 242 us against 210 / 233 us in situ, step 7.69-7.71 against 7.64-7.67 ms: they are latency-bound per step, and what they leave
@@ -2061,7 +2062,7 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     HNo = st['HN16'] if st.get('HN16') is not None else HN
     HDo = st['HD16'] if st.get('HD16') is not None else HD
     NSf_op, NSUM_op = NSo[1:].view(R, Ht), HNo[1:].view(M, Hn)
-    side = Side(3)
+    side = Side(DEC_WGRAD_SLOT)
 
     def wgrad(name, dy, x, sub=None):
         """G[name][:, sub] += dy^T . x"""

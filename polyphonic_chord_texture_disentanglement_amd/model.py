@@ -26,6 +26,7 @@ LOSS_NAMES = ['loss', 'recon_loss', 'pl', 'dl', 'kl_loss', 'kl_chd', 'kl_rhy', '
 # both encoders on stream 3: 7.47-7.56 (their forwards serialise); the texture encoder on 1 instead of 2: the same.
 CHD_ENC_SLOT = 3
 RHY_ENC_SLOT = 2
+CHD_DEC_SLOT = 4        # the chord decoder beside the PianoTree decoder
 # The two encoders ARE the latency chain of the head of the step (the decoder waits for z; the embedding / note summaries beside them are
 # needed later): their products keep the raised wave priority although they run inside sibling-stream calls, the note-summary GRUs drop it
 ENC_CHAIN = True
@@ -121,7 +122,7 @@ class DisentangleVAE(PytorchModel):
         # on the host in that order, then enqueue.
         dec_coins = self.decoder.draw_coins(tfr1, tfr2)
         chd_coins = self.chd_decoder.draw_coins(tfr3)
-        s_cd = F_.Side(4)
+        s_cd = F_.Side(CHD_DEC_SLOT)
         recon_root, recon_chroma, recon_bass = s_cd(
             lambda: self.chd_decoder(z_chd, False, tfr3, c, coins=chd_coins), z_chd, c)
         pitch_outs, dur_outs = self.decoder(dec_z, False, embedded_x, lengths, tfr1, tfr2, coins=dec_coins)
