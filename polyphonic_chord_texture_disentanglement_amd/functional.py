@@ -721,6 +721,8 @@ EMBED_MH_FWD = True    # multi-hot operand of the note_embedding gradient built 
 BIGRU_SLOT = 7
 BIGRU_SLOT_BWD = 4
 DEC_WGRAD_SLOT = 3      # pool stream of the decoder's deferred weight-gradient products
+EMBED_MH_SLOT = 7       # pool stream on which the embedding's multi-hot operand is built during the forward
+SHADOW_T_SLOT = 7       # pool stream of the transposed bf16 weight shadows' refresh (optim.refresh_weight_shadows)
 # note-summary bi-GRU: panels of rows sorted by length (ptv_rows_by_length + the *_perm entry points).  Measured, round 5 (profiles/
 # r05_ab_runs.txt): the launches do half the work (mean length 3.8 against a panel maximum of 8) but stay as long as their longest panel --
 # 225 / 242 us against 210 / 233 us in situ, step 7.69-7.71 against 7.64-7.67 ms: they are latency-bound per step, and what they leave
@@ -883,7 +885,7 @@ class EmbedFn(torch.autograd.Function):
                 mh = _empty(B * S * N, ld, dev=w.device, dtype=BF16)
                 call('ptv_multihot_geom', ptr(x), ptr(mh), ld, B, S, N, P, D, 1, stream_ptr())
                 return mh, record_event()
-            ctx.mh, ctx.mh_side = Side(7)(build, x)           # (pool stream 3: idle in the forward; streams 0 / 2 delayed the encoders)            # (mh_side: the event the backward waits for -- not the whole stream)
+            ctx.mh, ctx.mh_side = Side(EMBED_MH_SLOT)(build, x)           # (mh_side: the event the backward waits for -- not the whole stream)
         return emb, lengths
 
     @staticmethod

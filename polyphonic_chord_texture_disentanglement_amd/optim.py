@@ -267,7 +267,7 @@ class FusedClipAdam(torch.optim.Optimizer):
             if SHADOW_T_ASYNC and F_.OVERLAP and not F_.capturing_part():
                 # only the backward pass reads the transposed copies (dX products, BPTT): refresh them on a sibling stream, off the
                 # head of the step; weight_shadow_t() makes its caller's stream wait for the event
-                side = F_.Side(7)
+                side = F_.Side(F_.SHADOW_T_SLOT)
                 side(transposes)
                 self._t_event = F_.record_event(side.s)
                 self._t_waited = set()
