@@ -558,6 +558,9 @@ def _record_stream(obj, stream):
 # 13.3-19.2 ms per step for ANY non-default value, the same cliff as a fifth hardware queue: every pool stream is a default-priority stream.)
 
 
+POOL_MAP = (0, 1, 2, 3)       # pool stream of slot % 4 (experiments: merging two pool streams)
+
+
 class Side:
     """s = Side(slot); s(fn, *keep_alive) runs fn on the sibling stream after everything enqueued so far
     on the parent; s.join() makes the parent wait for it.  `keep_alive` tensors (or containers of tensors) stay referenced
@@ -574,7 +577,7 @@ class Side:
         # hardware queues anyway (GPU_MAX_HW_QUEUES; with 5 or more the step gets 40 % SLOWER), and which of ~10 private streams
         # end up sharing a queue -- i.e. silently serialise -- is then decided by creation order.  With the pool the sharing is
         # explicit; measured 9.67 vs 9.94 ms per step (pool sizes 2 / 3 / 5 / 7: 10.0 / 9.8 / 10.3 / 10.3).
-        key = ('pool', self.main.device.index, slot % 4)
+        key = ('pool', self.main.device.index, POOL_MAP[slot % 4])
         if key not in _CHILD_STREAMS:
             # all pool streams at once, in a FIXED order: which hardware queue a stream lands on follows creation order, and
             # creating them lazily in first-use order made the step time depend on which slot happened to be used first (0.4 ms)
