@@ -558,7 +558,10 @@ def _record_stream(obj, stream):
 # 13.3-19.2 ms per step for ANY non-default value, the same cliff as a fifth hardware queue: every pool stream is a default-priority stream.)
 
 
-POOL_MAP = (0, 1, 2, 3)       # pool stream of slot % 4 (experiments: merging two pool streams)
+# pool stream of slot % 4.  Merging streams measured at the end of round 5 (scripts/ab_combo.py, 6 interleaved rounds): the note summaries
+# and the texture encoder on ONE stream ((0, 2, 2, 3) or (0, 1, 1, 3): four streams with the step's own, one per hardware queue) 7.04-7.12 ms
+# per step, the same as five (7.05-7.15); the chord decoder's stream merged into another one 7.57-7.60.
+POOL_MAP = (0, 1, 2, 3)
 
 
 class Side:

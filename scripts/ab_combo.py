@@ -13,7 +13,8 @@ for arg in sys.argv[1:]:
     c = []
     for kv in arg.split(','):
         k, v = kv.split('='); mod, name = k.split('.')
-        c.append((importlib.import_module(PK + mod), name, eval(v)))
+        val = tuple(int(ch) for ch in v[1:]) if v.startswith('t') and v[1:].isdigit() else eval(v)      # t0123 = the tuple (0, 1, 2, 3)
+        c.append((importlib.import_module(PK + mod), name, val))
     combos.append((arg, c))
 dev = torch.device('cuda:0'); torch.manual_seed(0)
 m = DisentangleVAE.init_model(dev).to(dev).set_precision('bf16'); m.use_philox(7, 0); random.seed(7)
