@@ -344,13 +344,13 @@ class FusedClipAdam(torch.optim.Optimizer):
     GC_FREEZE_AT_STEP = 3
 
     def _throttle(self):
-        if self.GC_FREEZE_AT_STEP is not None and self.step_count == self.GC_FREEZE_AT_STEP and not self.__dict__.get('_gc_frozen'):
+        if torch.cuda.is_current_stream_capturing():
+            return                                  # (inside a graph capture: no host waits, and no collection -- releasing blocks there kills it)
+        if self.GC_FREEZE_AT_STEP is not None and self.step_count >= self.GC_FREEZE_AT_STEP and not self.__dict__.get('_gc_frozen'):
             import gc
             gc.collect()
             gc.freeze()
             self._gc_frozen = True
-        if torch.cuda.is_current_stream_capturing():
-            return
         q = self.__dict__.setdefault('_inflight', [])
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
