@@ -2601,7 +2601,8 @@ def pianotree_targets(x, step_major):
 def arm_live_top(x):
     """called by DisentangleVAE.loss() before run(): targets of x now (step-major: the teacher-forced decoder's layout), kept for the loss
     node; the decoder node of THIS forward may stop at counts[2].  -> token for disarm_live_top"""
-    if not (DEAD_STEPS and ZERO_SKIP and x.is_cuda and x.dtype == torch.int64 and x.is_contiguous()):
+    # (B a multiple of 4: the heads kernel's 128-row blocks must not straddle the limit -- a note step holds 32 B rows)
+    if not (DEAD_STEPS and ZERO_SKIP and x.is_cuda and x.dtype == torch.int64 and x.is_contiguous() and x.shape[0] % 4 == 0):
         return None
     pt, dt, counts = pianotree_targets(x, True)
     _LIVE['x'] = (weakref.ref(x), x.data_ptr(), x._version, True, pt, dt, counts)

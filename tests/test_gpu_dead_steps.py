@@ -78,6 +78,28 @@ def test_live_steps_equal_the_last_target_and_run_stays_dense(monkeypatch):
     assert seen.get('t') is None
 
 
+@pytest.mark.parametrize('B', [6, 3])
+def test_batches_that_do_not_fill_whole_head_blocks_run_every_step(B):
+    """a note step holds 32 B rows and the fused heads work in 128-row blocks: with B not a multiple of 4 loss() keeps the decoder dense
+    (same results as run() + loss_function())"""
+    x, c, pr = (torch.from_numpy(a).to(DEV) for a in synth_batch(B, 3))
+    m = _model()
+    m.use_philox(9, 0)
+    m.zero_grad()
+    l1 = m.loss(x, c, pr, 1., 1., 1., 0.1, [1, 0.5])
+    l1[0].backward()
+    g1 = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    m.use_philox(9, 0)
+    m.zero_grad()
+    l0 = m.loss_function(x, c, *m.run(x, c, pr, 1., 1., 1.), 0.1, [1, 0.5])
+    l0[0].backward()
+    torch.cuda.synchronize()
+    for a, b in zip(l0, l1):
+        assert torch.equal(a, b)
+    for k, p in m.named_parameters():
+        assert torch.equal(p.grad, g1[k]), k
+
+
 @pytest.mark.parametrize('case', ['full_tf1_b16', 'full_tf1_b512'])
 def test_loss_entry_point_vs_reference_golden(case):
     import bench
