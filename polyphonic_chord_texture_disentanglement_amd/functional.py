@@ -1974,7 +1974,7 @@ def _decoder_bwd_composite(P, st, z, tok_op, dP, ddur, top_h, side, G):
             or not heads_ok(prec, Hn, NP, Hd, HN16, HD16) or not notes_persist_ok(prec, Hn, E, BF16)
             or dP.stride(0) != _pad8(NP) or dP.data_ptr() % 16 or not ddur.is_contiguous() or ddur.dtype != F32
             or tok_op.dtype != F32 or not tok_op.is_contiguous() or z.dtype != F32 or not z.is_contiguous()
-            or not persist_supported(1, B, Ht, 32) or side.s == side.main):
+            or not persist_supported(1, B, Ht, 32) or side.s == side.main or M * 5 < 4096):       # (M * 5 >= 4096: _bgrad's 64-column path, as in C)
         return None
     wts = [_WT(P[n], prec) for n in ('dec_notes_gru.weight_ih_l0', 'dec_time_to_notes_hid.weight', 'dec_time_gru.weight_ih_l0',
                                       'dec_time_gru.weight_hh_l0', 'z2dec_hid_linear.weight', 'z2dec_in_linear.weight')]
