@@ -220,9 +220,9 @@ def extras(dev, B, rank):
     del m, opt
     torch.cuda.empty_cache()
     # smaller per-GPU batches, where the host (not the GPU) bounds the eager step: eagerly enqueued vs replayed from ONE captured
-    # hipGraph per step (graph_step.GraphedTrainStep: what TrainingInterface.train() uses by default for batch <= 256)
+    # hipGraph per step (graph_step.GraphedTrainStep: what TrainingInterface.train() uses by default for batch <= GRAPH_AUTO_MAX_BATCH = 64)
     from polyphonic_chord_texture_disentanglement_amd.graph_step import GraphedTrainStep
-    for Bs in (128, 256):
+    for Bs in (64, 128, 256):
         torch.manual_seed(0)
         m = DisentangleVAE.init_model(dev).to(dev).set_precision('bf16')
         m.use_philox(7, 0)
@@ -506,8 +506,9 @@ def main():
             torch.cuda.synchronize()
             print('[bench] warmup step %d done' % i, file=sys.stderr, flush=True)
     import gc
-    gc.collect()                                           # a full collection (~100 ms: it walks the whole module tree) must not fall into
-    gc.freeze()                                            # the timed steps; what is alive now moves to the permanent generation
+    from polyphonic_chord_texture_disentanglement_amd.optim import freeze_gc, unfreeze_gc
+    freeze_gc()                                            # a full collection (~100 ms: it walks the whole module tree) must not fall into
+                                                           # the timed steps; what is alive now moves to the permanent generation
     barrier()
     lib.ptv_prof_reset()
     lib.ptv_prof_config(32 * B, model.decoder.dec_notes_hid_size)
@@ -588,7 +589,7 @@ def main():
         from polyphonic_chord_texture_disentanglement_amd.functional import persist_check
         persist_check()                                        # a persistent launch that gave up would have invalidated the run
         if world == 1 and args.mode == 'train' and not args.no_extras:
-            gc.unfreeze()                                      # (the headline model may be collected again: the side figures build their own)
+            unfreeze_gc()                                      # (the headline model may be collected again: the side figures build their own)
             del model, opt
             gc.collect()
             torch.cuda.empty_cache()

@@ -153,13 +153,17 @@ class TrainingInterface:
             self.summary_writers.write_task(task, self._write_loss_to_dic(vals), step)
 
     # ---- the step as one hipGraph launch (graph_step.GraphedTrainStep).  graph_step = 'auto' (default; PTV_GRAPH_STEP overrides):
-    # replay when the host is the wall -- per-GPU batch <= 128, where enqueueing ~300 launches (5.5 ms) takes longer than the GPU needs to
-    # run them (measured B = 64: 9.1k -> 12.4k samples/s, B = 128: 23.0k -> 23.6k; from B = 256 on the eager step wins: 40.6k vs 37.5k,
-    # B = 512 55k vs 52k -- the capture routes sibling-stream edges through the origin stream, see graph_step.py);
-    # True / False force it.  Only steps whose teacher-forcing ratios are all exactly 1 can replay (coin flips pick kernels on the
-    # host); every other step runs eagerly.
+    # replay only where it was MEASURED faster than the eager step.  Round 3 that was per-GPU batch <= 128; since the backward passes
+    # moved behind one C call each (round 5) the eager step wins at 128 and above (BENCH_r05: B = 128 eager 4.10 ms vs replayed 4.36,
+    # B = 256 4.94 vs 5.40, B = 512 7.06 vs 7.66 -- the capture routes sibling-stream edges through the origin stream, see
+    # graph_step.py), so the crossover sits below 128: the default replays at B <= 64 only (bench.py reports the eager / replayed pair
+    # at 64, 128 and 256 every round: `extra.train_teacher_forced_b*`).  True / False force it.  Only steps whose teacher-forcing
+    # ratios are all exactly 1 can replay (coin flips pick kernels on the host); every other step runs eagerly.
     graph_step = 'auto'
-    GRAPH_AUTO_MAX_BATCH = 128
+    GRAPH_AUTO_MAX_BATCH = 64
+    # the training LOOP (not the optimiser) opts into optim.freeze_gc() once its working set exists: the first generation-2 collection
+    # otherwise lands around the 20th step as a ~100-ms stall.  Process-wide, idempotent, undone by optim.unfreeze_gc(); None = never.
+    freeze_gc_after_steps = 3
 
     def _graphed(self, inputs, params):
         import os
@@ -211,6 +215,9 @@ class TrainingInterface:
             self._clip_and_step()
             self._log('train', outputs, epoch_loss_dic, self.train_step)
             self.train_step += 1
+            if self.freeze_gc_after_steps is not None and self.train_step == self.freeze_gc_after_steps:
+                from ...optim import freeze_gc
+                freeze_gc()
         self._flush_logs()
         return epoch_loss_dic
 

@@ -1834,7 +1834,11 @@ class DecoderTFFn(torch.autograd.Function):
         if rowk:
             # ONE launch for the 15 note steps, 64 rows per workgroup, token product fused (csrc/notes_persist.hip)
             pk = notes_packs(P['dec_notes_gru.weight_ih_l0'], P['dec_notes_gru.weight_hh_l0'], Ht)
-            live = live_top_for(dev)
+            # the dead-step limit is taken only when EVERY later stage of the chain honours it (fused heads, fused duration GRU with
+            # recomputed gates, and their backward halves): the generic heads / per-step duration GRU and their weight-gradient sums
+            # read every row, so rows this launch leaves unwritten would meet zero gradients as NaN bit patterns (round-5 advice)
+            chain_live = heads_ok(prec, Hn, NP, Hd, HN16, _act_dtype(prec, Hd) == BF16 or None) and prec == 1 and Hd == 64 and FUSED_DUR
+            live = live_top_for(dev) if chain_live else None
             if live is not None and POISON_DEAD_STEPS:
                 _poison(HN16, gates_n)
             call('ptv_notes_gru_persist_fwd_top', ptr(pk['wg_h']), ptr(pk['wg_t']), ptr(P['dec_notes_gru.bias_hh_l0']), ptr(GC), ptr(emb3),
@@ -1881,7 +1885,7 @@ class DecoderTFFn(torch.autograd.Function):
         dur2 = dur.view(M, 10)
         if fused_dur:
             # one kernel for the 5 steps + output layer + argmax feedback (dur.hip)
-            live_d = live if fused_heads else None          # (the generic heads wrote every row: keep the duration GRU dense beside them)
+            live_d = live                                   # (None unless the fused heads took the limit too: chain_live above)
             if live_d is not None and POISON_DEAD_STEPS:
                 _poison(gates_d, dur, idx)
             call('ptv_dur_gru_fwd_top', Hd, M, ptr(HD[0]), Hd, ptr(P['dec_dur_gru.weight_hh_l0']), ptr(P['dec_dur_gru.bias_hh_l0']),

@@ -158,6 +158,30 @@ def grad_buffer(p):
     return torch.zeros_like(p, memory_format=torch.contiguous_format)
 
 
+_GC_FROZEN = False
+
+
+def freeze_gc():
+    """One full collection, then move everything alive to the permanent generation (gc.freeze()): later collections walk only what was
+    created since, so no ~100-ms generation-2 pass lands inside a training loop.  Process-wide and idempotent (a second call is a no-op
+    until unfreeze_gc()); cyclic garbage among the objects frozen now is not collected until then."""
+    global _GC_FROZEN
+    if _GC_FROZEN:
+        return False
+    import gc
+    gc.collect()
+    gc.freeze()
+    _GC_FROZEN = True
+    return True
+
+
+def unfreeze_gc():
+    global _GC_FROZEN
+    import gc
+    gc.unfreeze()
+    _GC_FROZEN = False
+
+
 def reserve_step_memory(batch, device=None, gb_per_512=(12.0, 3.0)):
     """Warm the caching allocator for train steps of `batch` samples: one large block on the current stream and one on each sibling pool
     stream (functional.Side), allocated and released -- they stay cached per stream and later requests are carved out of them.  Without it
@@ -186,9 +210,14 @@ def reserve_step_memory(batch, device=None, gb_per_512=(12.0, 3.0)):
 class FusedClipAdam(torch.optim.Optimizer):
     """Adam with global-norm clipping fused in (`clip_and_step(clip)`); `step()` alone = no clipping."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_steps_in_flight=2, gc_freeze_at_step=None):
         params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        # host-side pacing, both explicit (round-5 advice): at most `max_steps_in_flight` optimiser steps queued ahead of the GPU (None: never
+        # wait); `gc_freeze_at_step` = n calls optim.freeze_gc() -- process-wide, once -- after the n-th step (None, the default: the
+        # collector is left alone; a training script that wants steady step times calls optim.freeze_gc() itself after its warm-up)
+        self.MAX_STEPS_IN_FLIGHT = max_steps_in_flight
+        self.GC_FREEZE_AT_STEP = gc_freeze_at_step
         ps = [p for g in self.param_groups for p in g['params']]
         assert len(self.param_groups) == 1 and all(p.is_cuda and p.dtype == torch.float32 for p in ps), \
             'FusedClipAdam: one group of fp32 cuda parameters expected (move the model to the GPU first)'
@@ -339,18 +368,18 @@ class FusedClipAdam(torch.optim.Optimizer):
     MAX_STEPS_IN_FLIGHT = 2
     # A FULL garbage collection walks every tracked Python object of the process (the module tree, the autograd closures, torch's own
     # registries): ~100 ms, and the first one falls around the 20th step -- measured as one 15-18 ms "step" average per 12-step round,
-    # 3 runs of 3 (scripts/ab_step.py), gone in 3 of 3 once everything alive after the third step is frozen (moved to the permanent
-    # generation: later collections only walk what was created since).  None = leave the collector alone.
-    GC_FREEZE_AT_STEP = 3
+    # 3 runs of 3 (scripts/ab_step.py).  optim.freeze_gc() (explicit, process-wide, idempotent; optim.unfreeze_gc() undoes it) moves what
+    # is alive to the permanent generation: later collections only walk what was created since.  The optimiser does NOT do that behind
+    # the caller's back: `gc_freeze_at_step` (constructor) opts in, bench.py and TrainingInterface.train() call freeze_gc() themselves.
+    GC_FREEZE_AT_STEP = None
 
     def _throttle(self):
         if torch.cuda.is_current_stream_capturing():
             return                                  # (inside a graph capture: no host waits, and no collection -- releasing blocks there kills it)
-        if self.GC_FREEZE_AT_STEP is not None and self.step_count >= self.GC_FREEZE_AT_STEP and not self.__dict__.get('_gc_frozen'):
-            import gc
-            gc.collect()
-            gc.freeze()
-            self._gc_frozen = True
+        if self.GC_FREEZE_AT_STEP is not None and self.step_count >= self.GC_FREEZE_AT_STEP:
+            freeze_gc()
+        if self.MAX_STEPS_IN_FLIGHT is None:
+            return
         q = self.__dict__.setdefault('_inflight', [])
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())

@@ -54,6 +54,32 @@ def test_dead_note_steps_are_never_read(B, composite, monkeypatch):
         assert torch.equal(g0[k], g1[k]), (k, (g0[k] - g1[k]).abs().max())
 
 
+@pytest.mark.parametrize('switch', ['HEADS_FUSED', 'FUSED_DUR'])
+def test_a_chain_that_is_not_limit_aware_end_to_end_stays_dense(switch, monkeypatch):
+    """round-5 advice: with the generic heads (HEADS_FUSED off) or the per-step duration GRU (FUSED_DUR off) the launch-by-launch forward
+    must not take the dead-step limit -- those stages and their weight-gradient sums read every row.  With the poison armed, loss() then
+    poisons nothing and gives finite gradients that equal the DEAD_STEPS-off run bit for bit."""
+    B = 16
+    x, c, pr = (torch.from_numpy(a).to(DEV) for a in synth_batch(B, 99))
+    monkeypatch.setattr(F_, 'DEC_COMPOSITE', False)
+    monkeypatch.setattr(F_, switch, False)
+    m = _model()
+    monkeypatch.setattr(F_, 'DEAD_STEPS', False)
+    l0, g0 = _step(m, x, c, pr, 5)
+    monkeypatch.setattr(F_, 'DEAD_STEPS', True)
+    monkeypatch.setattr(F_, 'POISON_DEAD_STEPS', True)
+    poisoned = []
+    orig = F_._poison
+    monkeypatch.setattr(F_, '_poison', lambda *t: (poisoned.append(len(t)), orig(*t)))
+    l1, g1 = _step(m, x, c, pr, 5)
+    assert not poisoned, 'a chain with a dense stage took the live-step limit'
+    for a, b in zip(l0, l1):
+        assert torch.equal(a, b), (a, b)
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), k
+        assert torch.equal(g0[k], g1[k]), k
+
+
 def test_live_steps_equal_the_last_target_and_run_stays_dense(monkeypatch):
     B = 16
     x, c, pr = (torch.from_numpy(a).to(DEV) for a in synth_batch(B, 7))
