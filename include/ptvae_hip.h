@@ -47,6 +47,9 @@ extern "C" {
 /* Library / build identification ("gfx950"; ABI version 2 since round 3). */
 const char* ptv_arch(void);
 int ptv_abi_version(void);
+/* first 16 hex digits of sha256(ptvae_hip.h || ptvae_hip_debug.h) as they were when the library was built (csrc/Makefile); a loader that
+ * binds from these headers compares it with its own hash of them and refuses a stale library */
+const char* ptv_header_hash(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense product  C[M,N] = act(alpha * A.B^T + bias) (+ C)      -- every nn.Linear forward
@@ -742,9 +745,6 @@ int ptv_notes_gru_persist_bwd(const void* wt, const void* HN16, const void* gate
  * (csrc/notes_roles.hip), 0 = the 4-wave kernel of rounds 2-4 (csrc/notes_persist.hip); same arguments, same results to rounding.
  * Process-wide. */
 int ptv_notes_bwd_variant(int eight_waves);
-/* timing experiments: device buffer of 8 x 2048 uint64 that one workgroup of the following forward launches fills with per-wave event
- * stamps (scripts/trace_notes.py), or NULL */
-int ptv_debug_notes_trace(void* buf);
 
 /* The same kernels for any GRU whose rows are many and independent; H = 512 (above) or H = 128 with 128 inputs, which is one
  * direction of dec_notes_emb_gru, the note-summary bi-GRU over the 16 notes of each of the 32*B steps (ptvae.py:446-453,480-486).
@@ -826,9 +826,6 @@ long ptv_ordered_fallbacks(int reset);
  * ptv_clip_adam_step* read lr = dev4[1], 1 - beta1^t = dev4[2], sqrt(1 - beta2^t) = dev4[3] (Adam's bias corrections,
  * scheduler.py:69-74 + train.py:50) instead of their by-value arguments.  NULL restores by-value behaviour. */
 int ptv_step_params(const float* dev4);
-/* test / diagnosis aid: nwg idle workgroups holding lds_bytes of LDS each for usec microseconds on `stream` (a stand-in for another
- * library's collective kernel sitting on the CUs the persistent recurrences were sized for; tests/test_gpu_zz_dist.py) */
-int ptv_debug_pin_cus(int nwg, int lds_bytes, int usec, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Weight-gradient product (csrc/wgrad.hip): C[M,N] (fp32, row stride ldc) (+)= alpha * sum_k A[k*lda + m] * B[k*ldb + n], i.e.
@@ -852,19 +849,6 @@ int ptv_wgrad_cat(int M1, const void* A1, long lda1, int M2, const void* A2, lon
                   float* C, long ldc, float alpha, int accumulate, int dtypes, int slabs, float* colsum_a, const int* k_top,
                   long k_unit, int k_rev, void* stream);
 
-/* ------------------------------------------------------------------------------------------------
- * Optional launch timing (bench.py roofline): HIP events recorded on the launch stream around every launch of the enabled
- * kernel families.  Tags: 1 = GRU forward step, 2 = GRU backward step (csrc/gru.hip), 3 = row-partitioned persistent GRU forward,
- * 4 = its BPTT (csrc/notes_roles.hip / notes_persist.hip; M = rows R), 5 = weight-gradient products (ptv_wgrad / ptv_wgrad_cat: product +
- * reduction launches of one call), 6 = BPTT of the persistent small-M recurrences (ptv_gru_persist_bwd*).  ptv_prof_enable takes a bit mask
- * (bit tag-1), ptv_prof_config restricts tags 1-4 to launches with the given (M, H) (0 = any).  ptv_prof_read_tag waits for the recorded events and returns the number of launches of
- * one tag (0 = all), their summed duration and their summed algorithmic MFMA FLOPs.
- */
-int ptv_prof_enable(int mask);
-int ptv_prof_config(int M, int H);
-int ptv_prof_reset(void);
-int ptv_prof_read_tag(int tag, long* count, double* total_ms, double* flops);
-int ptv_prof_read(long* count, double* total_ms, double* flops);
 
 #ifdef __cplusplus
 }

@@ -18,9 +18,11 @@ _PREC = {'fp32': PREC_F32, 'f32': PREC_F32, 'bf16': PREC_BF16, 0: 0, 1: 1}
 _lib = None
 # the C ABI this Python package was written against (csrc/version.hip): the .so is a built artefact that ships beside the sources, and a
 # stale one would load without error and silently change argument contracts (round-4 advice: counts[3] of ptv_pianotree_targets)
-EXPECTED_ABI = 5
+EXPECTED_ABI = 6
 
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'ptvae_hip.h')
+# instrumentation / test aids (ptv_prof_*, ptv_debug_*): bound too, but not part of the product ABI
+DEBUG_HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'ptvae_hip_debug.h')
 
 
 def _parse_header(path):
@@ -72,6 +74,16 @@ def header_enum(name, path=None):
 
 
 _SIGNATURES = _parse_header(HEADER_PATH)
+_SIGNATURES.update(_parse_header(DEBUG_HEADER_PATH))
+
+
+def header_hash():
+    """what csrc/Makefile stamps into the library: sha256 over both headers, first 16 hex digits"""
+    import hashlib
+    h = hashlib.sha256()
+    for p in (HEADER_PATH, DEBUG_HEADER_PATH):
+        h.update(open(p, 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def exported_symbols():
@@ -95,6 +107,10 @@ def lib():
         if l.ptv_abi_version() != EXPECTED_ABI:
             raise RuntimeError('libptvae_hip.so at %s has ABI version %d, this package expects %d: rebuild it (python -c "import '
                                '__graft_entry__ as g; g.build()")' % (LIB_PATH, l.ptv_abi_version(), EXPECTED_ABI))
+        got = l.ptv_header_hash().decode()
+        if got != header_hash():
+            raise RuntimeError('libptvae_hip.so at %s was built from other headers (hash %s, include/*.h now %s): rebuild it (python -c '
+                               '"import __graft_entry__ as g; g.build()")' % (LIB_PATH, got, header_hash()))
         _lib = l
     return _lib
 

@@ -10,6 +10,7 @@
 #include "gemm_core.hpp"
 #include "prof.hpp"
 #include "../../include/ptvae_hip.h"
+#include "../../include/ptvae_hip_debug.h"
 
 namespace ptv {
 

@@ -4,6 +4,7 @@
 #include "common.hpp"
 #include "gemm_core.hpp"
 #include "../../include/ptvae_hip.h"
+#include "../../include/ptvae_hip_debug.h"
 
 namespace ptv {
 int g_zero_skip = 1;

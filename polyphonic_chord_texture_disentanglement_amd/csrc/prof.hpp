@@ -1,4 +1,4 @@
-// prof.hpp -- optional launch timing (ptv_prof_* in include/ptvae_hip.h): HIP events on the launch stream around the launches of
+// prof.hpp -- optional launch timing (ptv_prof_* in include/ptvae_hip_debug.h): HIP events on the launch stream around the launches of
 // one kernel family.  Defined in gru.hip.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -10,4 +10,11 @@ extern "C" const char* ptv_arch(void) { return "gfx950"; }
 // fp32 states written); ptv_notes_gru_persist_bwd / ptv_row_gru_persist_bwd(H = 512) take the bf16 states; ptv_gemm dtypes bit 4 (C
 // column-blocked by 16); ptv_pianotree_targets writes counts[3] (since round 4, unversioned then); ptv_debug_notes_trace added
 // 5 (round 5): ptv_row_gru_persist_{fwd,bwd}_perm and ptv_rows_by_length added (panels of rows sorted by length)
-extern "C" int ptv_abi_version(void) { return 5; }
+// 6 (round 6): the ptv_*_top entry points / PTV_DTF_LIVE_TOP (round 5, unversioned then), the bwd / loss / bigru composites, row limits in
+// ptv_wgrad's guarded tail and ptv_dur_out_wgrad, PTV_BGF_D_W_IH_F32; debug / profiling entry points moved to ptvae_hip_debug.h;
+// ptv_header_hash added (the loader compares it with the headers it binds from)
+extern "C" int ptv_abi_version(void) { return 6; }
+#ifndef PTV_HEADER_HASH
+#define PTV_HEADER_HASH "unknown"
+#endif
+extern "C" const char* ptv_header_hash(void) { return PTV_HEADER_HASH; }

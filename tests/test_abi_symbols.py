@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared():
-    src = open(os.path.join(ROOT, 'include', 'ptvae_hip.h')).read()
+    src = ''.join(open(os.path.join(ROOT, 'include', h)).read() for h in ('ptvae_hip.h', 'ptvae_hip_debug.h'))
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     return sorted(set(re.findall(r'\b(ptv_[a-z0-9_]+)\s*\(', src)))
 
@@ -30,6 +30,12 @@ def test_identification_calls_work_without_gpu():
     assert l.ptv_arch() == b'gfx950'
     from polyphonic_chord_texture_disentanglement_amd._lib import EXPECTED_ABI
     assert l.ptv_abi_version() == EXPECTED_ABI
+    assert l.ptv_header_hash().decode() == _lib.header_hash()                  # the library was built from the headers in the tree
+
+
+def test_product_header_carries_no_debug_hooks():
+    src = open(os.path.join(ROOT, 'include', 'ptvae_hip.h')).read()
+    assert not re.search(r'\bptv_(debug|prof)_[a-z0-9_]+\s*\(', src)
 
 
 def integration_snippet():
