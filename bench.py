@@ -65,7 +65,13 @@ def cpu_baseline(batch=16, timed=3):
         out['tfr=%g' % tfr] = {'s_per_step_min': round(min(times), 3), 's_per_step_median': round(statistics.median(times), 3),
                                'samples_per_s_best': round(batch / min(times), 2)}
     best = out['tfr=1']
+    ref_itself = None
+    try:                                                    # the reference's own train.py step, timed in the build container (8 vCPU): read beside the port
+        ref_itself = json.load(open(os.path.join(ROOT, 'profiles', 'r02_reference_cpu_timing.json')))
+    except Exception:
+        pass
     return {'value': best['samples_per_s_best'], 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+            'reference_itself_build_container': ref_itself,
             'sample': '1 warm-up + %d timed train steps (fwd+bwd+clip+Adam) each at tfr=1 and tfr=0, batch %d, fp32, torch CPU '
                       'oracle/ptvae_oracle.py; value = best teacher-forced step' % (timed, batch), 'cases': out}
 
@@ -284,43 +290,81 @@ def extras(dev, B, rank):
     return out
 
 
+PMC_FILE = 'profiles/r06_pmc_pick.json'
+
+
 def _roofline(lib, B, model, args, ms_per_step=None):
-    """roofline of the dominant kernels, measured live (HIP events on the launch stream, ptv_prof_*): the notes GRU of the
-    teacher-forced decoder as ONE row-partitioned launch per direction of time -- forward with wave roles (csrc/notes_roles.hip, tag 3),
-    BPTT with 8 waves per workgroup (csrc/notes_roles.hip, tag 4).  Algorithmic bytes per launch (DESIGN.md section 4, R = 32*B rows, H = 512, E = 128, T = 15):
-      fwd  per step: GC bf16 R*3H*2 (hoisted input part) + fed token fp32 R*E*4 read; state bf16 R*H*2 and the four saved gate planes
-           bf16 4*R*H*2 written (round 5: the fp32 state stays in registers -- no per-step fp32 state store + read-back); once: W_hh and
-           W_ih[:, Ht:] bf16, b_hh, the initial state.  min_bytes = the same without the gate planes (what a forward that saved
-           nothing for its backward would move).
-      bwd  per step: gates 4*R*H*2 + gradient arriving at the state R*H*2 + previous state bf16 R*H*2 read; dgi bf16 R*3H*2 and the n
-           third of dgh R*H*2 written (its r / z thirds are dgi's); once: W_hh^T bf16, dh0 fp32.
-    Intensity is ~225 FLOP/B, below the MI355X balance point (2.5 PFLOP/s / 8 TB/s = 312): the HBM roofline is the one that prices the
-    launch; what actually BOUNDS it is reported as measured (`bound`, `bound_evidence`): the per-CU vector-memory path, on which an HBM miss
-    of ANY wave delays the L2 hits of the weight stream behind it (scripts/micro/tcp_order.hip), not the HBM pins."""
+    """roofline of the step's dominant kernel FAMILY, measured live: HIP events on each launch's own stream (ptv_prof_*,
+    include/ptvae_hip_debug.h) over the timed region.  Candidates: the weight-gradient family (ptv_wgrad / ptv_wgrad_batch: product +
+    reduction launches; MFMA roofline), the notes GRU of the teacher-forced decoder as one row-partitioned launch per direction of time
+    (csrc/notes_roles.hip; HBM roofline), the BPTT of the persistent small-M recurrences (MFMA).  The top-level record is the candidate
+    with the most summed launch time per step (round-5 review: it used to be the notes forward whatever its share); the rest follow in
+    `also`, then the whole step on nominal and on EXECUTED FLOPs.
+
+    Weight-gradient family: algorithmic FLOPs of a launch = sum over its products of 2*M*N*K_live, K_live = the rows below the
+    product's device-side limit (ptv_wgrad's k_top: note steps / note positions at which no gradient arrives are exact zeros and are
+    passed over); the library reports the limited part separately and the live fraction of the benchmark batch is applied here
+    (`k_live`).  `achieved` = those FLOPs / the summed launch durations.
+
+    Notes GRU, algorithmic bytes per launch (DESIGN.md section 4, R = 32*B rows, H = 512, E = 128, T = 15):
+      fwd  per step: GC bf16 R*3H*2 + fed token fp32 R*E*4 read; state bf16 R*H*2 + four gate planes bf16 4*R*H*2 written; once: W_hh,
+           W_ih[:, Ht:] bf16, b_hh, the initial state.  min_bytes = the same without the gate planes.
+      bwd  per step: gates 4*R*H*2 + arriving gradient R*H*2 + previous state bf16 R*H*2 read; dgi bf16 R*3H*2 + the n third of dgh
+           R*H*2 written; once: W_hh^T bf16, dh0 fp32."""
     import ctypes
     R, H, E, T = 32 * B, model.decoder.dec_notes_hid_size, 128, 15
     from polyphonic_chord_texture_disentanglement_amd import functional as F_
     # loss() stops the forward launch at the batch's last note step that holds a target: bytes and FLOPs of the launch scale with it
     last = F_._LIVE.get('last_counts')
-    Tl = min(T, int(last[2].item()) + 1) if (last is not None and F_.DEAD_STEPS and F_.ZERO_SKIP) else T
+    skip = F_.DEAD_STEPS and F_.ZERO_SKIP
+    Tl = min(T, int(last[2].item()) + 1) if (last is not None and skip) else T
     once_f = 3 * H * (H + E) * 2 + 3 * H * 4 + R * H * 4
     fwd_bytes = Tl * (R * 3 * H * 2 + R * E * 4 + R * H * 2 + 4 * R * H * 2) + once_f
     fwd_min = Tl * (R * 3 * H * 2 + R * E * 4 + R * H * 2) + once_f
     bwd_bytes = T * (4 * R * H * 2 + R * H * 2 + R * H * 2 + R * 3 * H * 2 + R * H * 2) + 3 * H * H * 2 + R * H * 4
     pmc = {}
-    # HBM traffic of these launches from the PMC counters (separate rocprofv3 --pmc passes over this same command, scripts/gpu_pmc.sh,
-    # corrected as MI355X_MICROARCH.md prescribes): read from the committed file, stamped with the commit it was taken at
-    pmc_file = 'profiles/r05_row_gru_pmc.json'
-    pmc_path = os.path.join(ROOT, pmc_file)
+    # HBM traffic / executed MFMA instructions from the PMC counters (separate rocprofv3 --pmc passes over this same command,
+    # scripts/gpu_pmc.sh, corrected as MI355X_MICROARCH.md prescribes): read from the committed file, stamped with its commit
+    pmc_path = os.path.join(ROOT, PMC_FILE)
     if B == 512 and args.precision == 'bf16' and os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
-    out = []
+    src = ('%s @ %s' % (PMC_FILE, pmc.get('_commit'))) if pmc else None
+    steps = max(1, args.steps)
 
     def read(tag):
         cnt, ms, fl = ctypes.c_long(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
         lib.ptv_prof_read_tag(tag, ctypes.byref(cnt), ctypes.byref(ms), ctypes.byref(fl))
         return cnt.value, ms.value, fl.value
 
+    out = []
+    # ---- weight-gradient family (MFMA roofline)
+    cnt, ms, fl = read(5)
+    if cnt:
+        l15, l16 = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        lib.ptv_prof_read_limited(5, ctypes.byref(l15), ctypes.byref(l16))
+        # live fractions of this batch: decoder products stop at the last note step with a target (Tl of 15); the note-summary GRU's
+        # products at the longest note list of the batch (lengths = targets per (sample, step) + 1 for the <sos> slot, capped at 16)
+        f15 = Tl / float(T) if F_.ZERO_SKIP else 1.0
+        f16 = min(16, Tl + 1) / 16.0 if F_.ZERO_SKIP else 1.0
+        fl_live = fl - l15.value * (1.0 - f15) - l16.value * (1.0 - f16)
+        tfs, tfs_nom = fl_live / (ms * 1e-3) / 1e12, fl / (ms * 1e-3) / 1e12
+        k = pmc.get('wgrad_family', {})
+        out.append({'bound': 'mfma', 'kernel': 'weight-gradient family: wgrad_kernel / wgrad_batch_kernel + wgrad_reduce(_batch)_kernel (ptv_wgrad, '
+                                               'ptv_wgrad_batch; every grad_W = grad_out^T . input of the step, bias sums fused)',
+                    'achieved': round(tfs, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(tfs / 2500.0, 4),
+                    'traffic': k.get('hbm_bytes_per_step'), 'traffic_unit': 'HBM bytes per step, all launches of the family (PMC)',
+                    'traffic_source': src if k else None,
+                    'algorithmic_flops_per_step': round(fl_live / steps), 'nominal_flops_per_step': round(fl / steps),
+                    'k_live': {'decoder_note_steps': '%d of %d' % (Tl, T), 'frac15': round(f15, 4), 'frac16': round(f16, 4)},
+                    'achieved_on_nominal_flops': round(tfs_nom, 1),
+                    'launches_per_step': round(cnt / steps, 1), 'avg_us': round(ms / cnt * 1e3, 1), 'total_ms': round(ms, 2),
+                    'ms_per_step': round(ms / steps, 3),
+                    'executed_mfma_tflop_per_step_pmc': k.get('executed_tflop_per_step'), 'mfma_busy_frac_pmc': k.get('mfma_busy_frac'),
+                    'operand_bytes_note': 'products with M or N <= 135 are HBM-bound (3-4.4 TB/s standalone, profiles/r05_bench_wgrad.txt); the '
+                                          'family figure is FLOP-weighted and dominated by the deep products',
+                    'note': 'event-timed per call (a batch = one product launch + one reduction launch) on its own stream inside the timed region, '
+                            'in situ: the calls overlap each other and the latency chains, so the summed time exceeds their share of the step'})
+    # ---- notes GRU (HBM roofline)
     kernels = [(3, 'notes_fwd_kernel', fwd_bytes, fwd_min)]
     if not F_.ZERO_SKIP:                                    # with the zero-skip on, the BPTT launch moves a data-dependent share of
         kernels.insert(0, (4, 'notes_bwd_kernel', bwd_bytes, bwd_bytes))   # these bytes (late note steps without gradient are passed over)
@@ -336,9 +380,9 @@ def _roofline(lib, B, model, args, ms_per_step=None):
         out.append({'bound': 'hbm', 'kernel': '%s (dec_notes_gru, R=%d rows x %d of T=%d steps in one launch%s)' % (
                         name, R, steps_run, T, ': loss() stops at the last note step with a target' if steps_run < T else ''),
                     'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
-                    'traffic': k.get('hbm_bytes_per_launch'), 'traffic_source': ('%s @ %s' % (pmc_file, pmc.get('_commit'))) if k else None,
+                    'traffic': k.get('hbm_bytes_per_launch'), 'traffic_source': src if k else None,
                     'algorithmic_bytes': nbytes, 'min_bytes': nmin, 'frac_on_min_bytes': round(nmin / avg_s / 1e9 / 8000.0, 4),
-                    'launches': cnt, 'avg_us': round(avg_s * 1e6, 1), 'total_ms': round(ms, 2),
+                    'launches': cnt, 'avg_us': round(avg_s * 1e6, 1), 'total_ms': round(ms, 2), 'ms_per_step': round(ms / steps, 3),
                     'mfma': {'achieved': round(tfs, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(tfs / 2500.0, 4),
                              'busy_frac_pmc': k.get('mfma_busy_frac')},
                     'flop_per_byte': round(fl / cnt / nbytes, 1), 'balance_flop_per_byte': 312.5,
@@ -346,25 +390,31 @@ def _roofline(lib, B, model, args, ms_per_step=None):
                     'bound_evidence': 'profiles/r05_notes_roles_ablation.txt (no weights / no activation streams / neither), '
                                       'profiles/r05_tcp_order.txt (one HBM-missing wave slows the CU\'s L2-hit stream 1.46x, four 3.6x)',
                     'note': 'in situ: the launch shares the GPU with the weight-gradient products on sibling streams'})
+    # ---- BPTT of the persistent small-M recurrences (MFMA roofline by FLOPs; bound by its per-step hand-offs)
+    cnt, ms, fl = read(6)
+    if cnt:
+        tfs = fl / (ms * 1e-3) / 1e12
+        out.append({'bound': 'mfma', 'kernel': 'pgru_bwd_sk_kernel / pgru_bwd_kernel (BPTT of the small-M persistent recurrences)',
+                    'achieved': round(tfs, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(tfs / 2500.0, 4), 'traffic': None,
+                    'launches': cnt, 'total_ms': round(ms, 2), 'ms_per_step': round(ms / steps, 3), 'flops': '2*chains*M*3H*H*T',
+                    'bound_measured': 'hand-off latency (two L2 exchanges per recurrent step), DESIGN.md section 4'})
     if not out:
         return None
     out.sort(key=lambda r: -r['total_ms'])
     roof = out[0]
+    roof['selected_by'] = 'largest summed launch time per step among the event-timed families'
     roof['also'] = out[1:]
-    # the other families the step spends its time in, on the roofline that prices them (MFMA): summed algorithmic FLOPs / summed time
-    for tag, name, what in ((5, 'wgrad family (ptv_wgrad: wgrad_kernel / wgrad_dma_kernel + wgrad_reduce_kernel)',
-                             '2*M*N*K summed over the step\'s weight-gradient products (full K: zero-skipped rows counted)'),
-                            (6, 'pgru_bwd_sk_kernel / pgru_bwd_kernel (BPTT of the small-M persistent recurrences)', '2*chains*M*3H*H*T')):
-        cnt, ms, fl = read(tag)
-        if cnt:
-            tfs = fl / (ms * 1e-3) / 1e12
-            roof['also'].append({'bound': 'mfma', 'kernel': name, 'achieved': round(tfs, 1), 'peak': 2500.0, 'unit': 'TFLOP/s',
-                                 'frac': round(tfs / 2500.0, 4), 'launches': cnt, 'total_ms': round(ms, 2), 'flops': what,
-                                 'note': 'event-timed per call on its own stream over 3 extra steps after the timed region, in situ (calls overlap each other and the chains)'})
     if ms_per_step:
-        tfs = 6.15e9 * B / (ms_per_step * 1e-3) / 1e12
-        roof['also'].append({'bound': 'mfma', 'kernel': 'whole train step (6.15 GFLOP per sample, SURVEY.md 8d)', 'achieved': round(tfs, 1),
+        tfs = GFLOP_PER_SAMPLE_TRAIN * 1e9 * B / (ms_per_step * 1e-3) / 1e12
+        roof['also'].append({'bound': 'mfma', 'kernel': 'whole train step, NOMINAL work (6.15 GFLOP per sample, SURVEY.md 8d: the exactly-zero work '
+                                                        'the step passes over is counted)', 'achieved': round(tfs, 1),
                              'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(tfs / 2500.0, 4)})
+        ex = pmc.get('_step', {}).get('executed_tflop_per_step')
+        if ex:
+            tfs = ex * 1e12 / (ms_per_step * 1e-3) / 1e12
+            roof['also'].append({'bound': 'mfma', 'kernel': 'whole train step, EXECUTED MFMA work (sum of SQ_INSTS_MFMA x 16384 FLOP over the step\'s '
+                                                            'kernels, PMC)', 'achieved': round(tfs, 1), 'peak': 2500.0,
+                                 'unit': 'TFLOP/s', 'frac': round(tfs / 2500.0, 4), 'executed_tflop_per_step': ex, 'traffic_source': src})
     return roof
 
 
@@ -512,7 +562,9 @@ def main():
     barrier()
     lib.ptv_prof_reset()
     lib.ptv_prof_config(32 * B, model.decoder.dec_notes_hid_size)
-    lib.ptv_prof_enable(4 | 8)                             # tags 3, 4: the row-partitioned notes GRU, forward and BPTT (two event pairs per step)
+    # tags 3, 4: the row-partitioned notes GRU, forward and BPTT; 5: the weight-gradient family (~20 calls per step since the products are
+    # batched); 6: BPTT of the persistent recurrences -- all event-timed on their own streams INSIDE the timed region
+    lib.ptv_prof_enable(4 | 8 | 16 | 32)
     opt.throttle_wait_s = 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -523,16 +575,6 @@ def main():
     dt = time.perf_counter() - t0
     lib.ptv_prof_enable(0)
     rep = sync.exchange_report() if world > 1 else None        # (the exchange figures of the TIMED steps: taken before the extra ones below)
-    if args.mode == 'train' and args.tfr >= 1.0:
-        # the families of roofline.also (tags 5, 6: ~45 event pairs per step on the sibling streams) are timed over three EXTRA steps
-        # outside the timed region, so that their bookkeeping cannot touch the headline.  EVERY rank runs them (a step holds the
-        # gradient exchange: rank 0 alone would wait for its peers forever); only rank 0 keeps the events.
-        if rank == 0:
-            lib.ptv_prof_enable(16 | 32)
-        for i in range(3):
-            step(args.warmup + args.steps + i)
-        torch.cuda.synchronize()
-        lib.ptv_prof_enable(0)
     dp = None
     if world > 1:
         import torch.distributed as dist
@@ -558,7 +600,7 @@ def main():
         import ctypes
         ms_per_step = dt / args.steps * 1e3
         value = world * B * args.steps / dt
-        roof = _roofline(lib, B, model, args) if args.mode == 'train' and args.tfr >= 1.0 else None
+        roof = _roofline(lib, B, model, args, ms_per_step) if args.mode == 'train' and args.tfr >= 1.0 else None
         if args.mode == 'decode':
             workload = 'configs[3]: free-running PtvaeDecoder sampling (inference_decode), batch=%d, 32x15x(1+5) step loop' % B
         elif args.tfr >= 1.0:
@@ -573,7 +615,10 @@ def main():
                'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
                'config': {'workload': workload,
                           'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world},
-               'step_tflops': round(value * GFLOP_PER_SAMPLE_TRAIN / 1e3, 2), 'final_loss': round(loss, 4),
+               'step_tflops': round(value * GFLOP_PER_SAMPLE_TRAIN / 1e3, 2),
+               'step_tflops_note': 'NOMINAL: 6.15 GFLOP per sample x samples/s (work the step passes over as exactly zero is counted); the executed '
+                                   'rate is roofline.also[whole train step, EXECUTED MFMA work]',
+               'final_loss': round(loss, 4),
                'host_enqueue_ms_per_step': round((t_host - t_wait) / args.steps * 1e3, 3),
                'host_wait_ms_per_step': round(t_wait / args.steps * 1e3, 3), 'roofline': roof}
         if args.mode == 'train' and args.tfr >= 1.0:

@@ -848,6 +848,21 @@ int ptv_wgrad(int M, int N, int K, const void* A, long lda, const void* B, long 
 int ptv_wgrad_cat(int M1, const void* A1, long lda1, int M2, const void* A2, long lda2, int N, int K, const void* B, long ldb,
                   float* C, long ldc, float alpha, int accumulate, int dtypes, int slabs, float* colsum_a, const int* k_top,
                   long k_unit, int k_rev, void* stream);
+/* Several weight-gradient products in ONE launch (plus one launch for their ordered reductions): the parameter gradients that become ready
+ * at the same point of a backward pass -- a GRU's W_ih / W_hh with their bias sums, a decoder's z projections (ptvae.py:16-17,23,64,116,
+ * 360,396,450,461 as above).  Each job has exactly the meaning of one ptv_wgrad call with the same fields, and gives the same bits as that
+ * call would (same slab plan, same reduction order); the jobs' outputs (C, colsum_a) must not overlap.  HOST array of jobs. */
+typedef struct ptv_wgrad_job {
+  int M, N, K;
+  const void* A; long lda;
+  const void* B; long ldb;
+  float* C; long ldc;
+  float alpha;
+  int accumulate, dtypes, slabs;
+  float* colsum_a;
+  const int* k_top; long k_unit; int k_rev;
+} ptv_wgrad_job;
+int ptv_wgrad_batch(const ptv_wgrad_job* jobs, int njobs, void* stream);
 
 
 #ifdef __cplusplus

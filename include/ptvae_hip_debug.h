@@ -30,6 +30,9 @@ int ptv_prof_config(int M, int H);
 int ptv_prof_reset(void);
 int ptv_prof_read_tag(int tag, long* count, double* total_ms, double* flops);
 int ptv_prof_read(long* count, double* total_ms, double* flops);
+/* of a tag's summed FLOPs, the part that runs under a device-side row limit (ptv_wgrad's k_top): products over the decoder's 15 note steps
+ * (lim15) and over the note-summary GRU's 16 note positions (lim16) -- what bench.py scales by the batch's live fraction */
+int ptv_prof_read_limited(int tag, double* lim15, double* lim16);
 
 #ifdef __cplusplus
 }

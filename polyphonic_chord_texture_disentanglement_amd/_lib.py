@@ -115,6 +115,28 @@ def lib():
     return _lib
 
 
+class WgradJob(ctypes.Structure):
+    """ptv_wgrad_job of include/ptvae_hip.h (one product of a ptv_wgrad_batch call)"""
+    _fields_ = [('M', ctypes.c_int), ('N', ctypes.c_int), ('K', ctypes.c_int), ('A', ctypes.c_void_p), ('lda', ctypes.c_long),
+                ('B', ctypes.c_void_p), ('ldb', ctypes.c_long), ('C', ctypes.c_void_p), ('ldc', ctypes.c_long), ('alpha', ctypes.c_float),
+                ('accumulate', ctypes.c_int), ('dtypes', ctypes.c_int), ('slabs', ctypes.c_int), ('colsum_a', ctypes.c_void_p),
+                ('k_top', ctypes.c_void_p), ('k_unit', ctypes.c_long), ('k_rev', ctypes.c_int)]
+
+
+def wgrad_batch(jobs, stream=None):
+    """jobs: dicts with the fields of ptv_wgrad_job (tensors for the pointers) -> one ptv_wgrad_batch call on `stream` (default: current)"""
+    arr = (WgradJob * len(jobs))()
+    for q, j in zip(arr, jobs):
+        A, B, C = j['A'], j['B'], j['C']
+        q.M, q.N, q.K = j['M'], j['N'], j['K']
+        q.A, q.lda, q.B, q.ldb, q.C, q.ldc = ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), C.stride(0)
+        q.alpha, q.accumulate, q.slabs = j.get('alpha', 1.0), j.get('accumulate', 1), j.get('slabs', 0)
+        q.dtypes = (1 if A.dtype == torch.bfloat16 else 0) | (2 if B.dtype == torch.bfloat16 else 0)
+        q.colsum_a, q.k_top = ptr(j.get('colsum_a')), ptr(j.get('k_top'))
+        q.k_unit, q.k_rev = j.get('k_unit', 0), j.get('k_rev', 0)
+    check(lib().ptv_wgrad_batch(arr, len(jobs), stream if stream is not None else stream_ptr()), 'ptv_wgrad_batch')
+
+
 def prec_code(p):
     return _PREC[p]
 

@@ -17,6 +17,32 @@ template <typename X> inline X* M_(const void* const* t, int i) { return reinter
 // dtypes word of ptv_gemm: bit 0 = A bf16, bit 1 = B bf16, bit 2 = C bf16, bit 4 = C column-blocked by 16
 constexpr int A16 = 1, B16 = 2, C16 = 4, CBLK16 = 16;
 
+// The parameter-gradient products that become ready at one point of a backward pass, as ONE ptv_wgrad_batch call (one product launch + one
+// reduction launch) with every bias gradient taken from the A tiles while they are in LDS (colsum_a) instead of a second pass over the
+// gradient matrix.  add(): C[M,N] += A^T B (A [K,M], B [K,N] row-per-sample), csum (or NULL) [M] += column sums of A.  Products the
+// weight-gradient kernel does not take (fp32 precision, K < 512: ptv_gemm's own rule) run at once as ptv_gemm + ptv_colsum, as before.
+// The Python sequencing (functional.py) makes the same calls one by one: ptv_wgrad with the same colsum_a -- the same bits.
+struct WgradGroup {
+  ptv_wgrad_job jobs[8]; int n = 0; int P; void* stream;
+  WgradGroup(int prec, void* st) : P(prec), stream(st) {}
+  int add(int M, int N, long K, const void* A, long lda, int a_bf16, const void* B, long ldb, int b_bf16, float* C, long ldc, float* csum,
+          const int* k_top = nullptr, long k_unit = 0, int k_rev = 0, int accumulate = 1) {
+    if (P == PTV_PREC_BF16 && K >= 512) {
+      if (n == 8) PTV_TRY(flush());
+      jobs[n++] = ptv_wgrad_job{M, N, (int)K, A, lda, B, ldb, C, ldc, 1.f, accumulate, (a_bf16 ? 1 : 0) | (b_bf16 ? 2 : 0), 0, csum, k_top, k_unit, k_rev};
+      return PTV_OK;
+    }
+    if (k_top) return PTV_ERR_ARG;
+    PTV_TRY(ptv_gemm(P, 1, 1, M, N, (int)K, A, lda, B, ldb, C, ldc, nullptr, 1.f, accumulate, 0, 0, (a_bf16 ? A16 : 0) | (b_bf16 ? B16 : 0), stream));
+    if (csum) PTV_TRY(ptv_colsum(csum, A, lda, K, M, nullptr, 1, a_bf16, stream));
+    return PTV_OK;
+  }
+  int flush() {
+    if (n) { const int q = n; n = 0; return ptv_wgrad_batch(jobs, q, stream); }
+    return PTV_OK;
+  }
+};
+
 }  // namespace
 
 extern "C" int ptv_decoder_tf_supported(const long* d) {
@@ -167,15 +193,16 @@ extern "C" int ptv_chord_decoder_bwd(const void* const* t, const long* d, void* 
                            {PTV_CDB_DBASS, PTV_CDB_W_BASS, PTV_CDB_G_W_BASS, PTV_CDB_G_B_BASS}};
   const int ncls[3] = {(int)d[PTV_CDB_D_NROOT], (int)d[PTV_CDB_D_NCHROMA], (int)d[PTV_CDB_D_NBASS]};
   bool have = false;
+  WgradGroup wg(P, stream);
   for (int k = 0; k < 3; k++) {
     const void* dl = T_(t, heads[k][0]);
     if (!dl) continue;
     const int n = ncls[k];
     PTV_TRY(ptv_gemm(P, 0, 1, (int)TB, H, n, dl, n, T_(t, heads[k][1]), H, dhs, H, nullptr, 1.f, have ? 1 : 0, 0, 0, 0, stream));
     have = true;
-    PTV_TRY(ptv_gemm(P, 1, 1, n, H, (int)TB, dl, n, hs, H, M_<void>(t, heads[k][2]), H, nullptr, 1.f, 1, 0, 0, 0, stream));
-    PTV_TRY(ptv_colsum(M_<float>(t, heads[k][3]), dl, n, TB, n, nullptr, 1, 0, stream));
+    PTV_TRY(wg.add(n, H, TB, dl, n, 0, hs, H, 0, M_<float>(t, heads[k][2]), H, M_<float>(t, heads[k][3])));
   }
+  PTV_TRY(wg.flush());
   if (!have && hipMemsetAsync(dhs, 0, sizeof(float) * TB * H, s) != hipSuccess) return PTV_ERR_LAUNCH;
   // ---- BPTT
   void* dgi = M_<void>(t, PTV_CDB_DGI); void* dgh = M_<void>(t, PTV_CDB_DGH);
@@ -198,29 +225,26 @@ extern "C" int ptv_chord_decoder_bwd(const void* const* t, const long* d, void* 
     PTV_TRY(ptv_gru_seq_bwd(P, B, H, T, hall, T_(t, PTV_CDB_GATES), w, dhs, (long)B * H, H, nullptr, 0, nullptr, 0, 0, 0, nullptr, dgi, dgh,
                             M_<float>(t, PTV_CDB_DHZ), dh0, 0, flags, stream));
   }
-  // ---- the GRU's parameters
+  // ---- the GRU's parameters and the two z projections: the chain to dz first, then every parameter gradient as one batch (the bias sums
+  // ride inside the products)
   const int A = abf ? A16 : 0;
-  PTV_TRY(ptv_gemm(P, 1, 1, 3 * H, H, (int)TB, dgh, 3L * H, hall, H, M_<void>(t, PTV_CDB_G_W_HH), H, nullptr, 1.f, 1, 0, 0, A, stream));
-  PTV_TRY(ptv_colsum(M_<float>(t, PTV_CDB_G_B_HH), dgh, 3L * H, TB, 3 * H, nullptr, 1, abf, stream));
   float* dzg = M_<float>(t, PTV_CDB_DZG);
   PTV_TRY(ptv_sum_steps_top(dzg, dgi, (long)B * 3 * H, T, (long)B * 3 * H, 0, abf, nullptr, stream));
-  PTV_TRY(ptv_colsum(M_<float>(t, PTV_CDB_G_B_IH), dzg, 3L * H, B, 3 * H, nullptr, 1, 0, stream));
   float* g_ih = M_<float>(t, PTV_CDB_G_W_IH);
-  PTV_TRY(ptv_gemm(P, 1, 1, 3 * H, Zi, B, dzg, 3L * H, T_(t, PTV_CDB_Z_IN), Zi, g_ih + I, ld_ih, nullptr, 1.f, 1, 0, 0, 0, stream));
-  PTV_TRY(ptv_gemm(P, 1, 1, 3 * H, I, (int)TB, dgi, 3L * H, T_(t, PTV_CDB_TOKS), I, g_ih, ld_ih, nullptr, 1.f, 1, 0, 0, A, stream));
   const float* w_ih = (const float*)T_(t, PTV_CDB_W_IH);
   float* dz_in = M_<float>(t, PTV_CDB_DZ_IN); float* dtok0 = M_<float>(t, PTV_CDB_DTOK0);
   PTV_TRY(ptv_gemm(P, 0, 1, B, Zi, 3 * H, dzg, 3L * H, w_ih + I, ld_ih, dz_in, Zi, nullptr, 1.f, 0, 0, 0, 0, stream));
   PTV_TRY(ptv_gemm(P, 0, 1, B, I, 3 * H, dgi, 3L * H, w_ih, ld_ih, dtok0, I, nullptr, 1.f, 0, 0, 0, A, stream));     // only the learned start token
-  PTV_TRY(ptv_colsum(M_<float>(t, PTV_CDB_G_INIT_INPUT), dtok0, I, B, I, nullptr, 1, 0, stream));
-  // ---- the two z projections
   float* dz = M_<float>(t, PTV_CDB_DZ);
   PTV_TRY(ptv_gemm(P, 0, 1, B, Z, H, dh0, H, T_(t, PTV_CDB_W_ZHID), Z, dz, Z, nullptr, 1.f, 0, 0, 0, 0, stream));
   PTV_TRY(ptv_gemm(P, 0, 1, B, Z, Zi, dz_in, Zi, T_(t, PTV_CDB_W_ZIN), Z, dz, Z, nullptr, 1.f, 1, 0, 0, 0, stream));
-  PTV_TRY(ptv_gemm(P, 1, 1, H, Z, B, dh0, H, T_(t, PTV_CDB_Z), Z, M_<void>(t, PTV_CDB_G_W_ZHID), Z, nullptr, 1.f, 1, 0, 0, 0, stream));
-  PTV_TRY(ptv_colsum(M_<float>(t, PTV_CDB_G_B_ZHID), dh0, H, B, H, nullptr, 1, 0, stream));
-  PTV_TRY(ptv_gemm(P, 1, 1, Zi, Z, B, dz_in, Zi, T_(t, PTV_CDB_Z), Z, M_<void>(t, PTV_CDB_G_W_ZIN), Z, nullptr, 1.f, 1, 0, 0, 0, stream));
-  PTV_TRY(ptv_colsum(M_<float>(t, PTV_CDB_G_B_ZIN), dz_in, Zi, B, Zi, nullptr, 1, 0, stream));
+  PTV_TRY(wg.add(3 * H, H, TB, dgh, 3L * H, abf, hall, H, 0, M_<float>(t, PTV_CDB_G_W_HH), H, M_<float>(t, PTV_CDB_G_B_HH)));
+  PTV_TRY(wg.add(3 * H, Zi, B, dzg, 3L * H, 0, T_(t, PTV_CDB_Z_IN), Zi, 0, g_ih + I, ld_ih, M_<float>(t, PTV_CDB_G_B_IH)));
+  PTV_TRY(wg.add(3 * H, I, TB, dgi, 3L * H, abf, T_(t, PTV_CDB_TOKS), I, 0, g_ih, ld_ih, nullptr));
+  PTV_TRY(wg.add(H, Z, B, dh0, H, 0, T_(t, PTV_CDB_Z), Z, 0, M_<float>(t, PTV_CDB_G_W_ZHID), Z, M_<float>(t, PTV_CDB_G_B_ZHID)));
+  PTV_TRY(wg.add(Zi, Z, B, dz_in, Zi, 0, T_(t, PTV_CDB_Z), Z, 0, M_<float>(t, PTV_CDB_G_W_ZIN), Z, M_<float>(t, PTV_CDB_G_B_ZIN)));
+  PTV_TRY(wg.flush());
+  PTV_TRY(ptv_colsum(M_<float>(t, PTV_CDB_G_INIT_INPUT), dtok0, I, B, I, nullptr, 1, 0, stream));
   return PTV_OK;
 }
 
@@ -280,13 +304,14 @@ extern "C" int ptv_decoder_tf_bwd(const void* const* t, const long* d, void* str
     const __bf16* HN16 = (const __bf16*)T_(t, PTV_DTB_HN16);
     const __bf16* nsum = HN16 + (long)R * Hn;                       // the note summaries = states 1 .. 15
     float* tmp = GB(PTV_DTB_TMP200); float* cs = GB(PTV_DTB_CS200);
-    PTV_TRY(ptv_wgrad(200, Hn, (int)M, dY16, 200, nsum, Hn, tmp, Hn, 1.f, 0, 3, 0, cs, top_h, top_unit, 0, sside));
+    WgradGroup wg(P, sside);                                       // both head products in one launch
+    PTV_TRY(wg.add(200, Hn, M, dY16, 200, 1, nsum, Hn, 1, tmp, Hn, cs, top_h, top_unit, 0, 0));
+    PTV_TRY(wg.add(Hd, NP, M, dHD0, Hd, 0, T_(t, PTV_DTB_PITCH), ldp, 0, GB(PTV_DTB_G_W_DH) + Hn, (long)Hn + NP, nullptr, top_h, top_unit, 0));
+    PTV_TRY(wg.flush());
     PTV_TRY(ptv_copy2d(GB(PTV_DTB_G_W_P), Hn, tmp, Hn, NP, Hn, 1.f, 1, sside));
     PTV_TRY(ptv_copy2d(GB(PTV_DTB_G_B_P), NP, cs, NP, 1, NP, 1.f, 1, sside));
     PTV_TRY(ptv_copy2d(GB(PTV_DTB_G_W_DH), (long)Hn + NP, tmp + 136L * Hn, Hn, Hd, Hn, 1.f, 1, sside));
     PTV_TRY(ptv_copy2d(GB(PTV_DTB_G_B_DH), Hd, cs + 136, Hd, 1, Hd, 1.f, 1, sside));
-    PTV_TRY(ptv_wgrad(Hd, NP, (int)M, dHD0, Hd, T_(t, PTV_DTB_PITCH), ldp, GB(PTV_DTB_G_W_DH) + Hn, (long)Hn + NP, 1.f, 1, 0, 0, nullptr, top_h,
-                      top_unit, 0, sside));
   }
 
   // ================= notes GRU (15 steps x 32 B rows): BPTT, then the gradients of the fed tokens and of the time states
@@ -309,13 +334,15 @@ extern "C" int ptv_decoder_tf_bwd(const void* const* t, const long* d, void* str
     const __bf16* HN16 = (const __bf16*)T_(t, PTV_DTB_HN16);      // states 0 .. 14: the operand of the W_hh gradient
     const __bf16* NSf = (const __bf16*)T_(t, PTV_DTB_NS16) + (long)B * Ht;
     float* gw = GB(PTV_DTB_G_W_HH_N); float* gb = GB(PTV_DTB_G_B_HH_N); float* gih = GB(PTV_DTB_G_W_IH_N);
-    PTV_TRY(ptv_wgrad(2 * Hn, Hn, (int)M, dgi_n, 3L * Hn, HN16, Hn, gw, Hn, 1.f, 1, 3, 0, gb, top_step, R, 0, sside));
-    PTV_TRY(ptv_wgrad(Hn, Hn, (int)M, dgh_n, Hn, HN16, Hn, gw + 2L * Hn * Hn, Hn, 1.f, 1, 3, 0, gb + 2 * Hn, top_step, R, 0, sside));
-    PTV_TRY(ptv_colsum(GB(PTV_DTB_G_B_IH_N), dGC, 3L * Hn, R, 3 * Hn, nullptr, 1, 0, sside));
-    PTV_TRY(ptv_gemm(P, 1, 1, 3 * Hn, Ht, R, dGC, 3L * Hn, NSf, Ht, gih, (long)Ht + E, nullptr, 1.f, 1, 0, 0, B16, sside));
-    PTV_TRY(ptv_wgrad(3 * Hn, E, (int)M, dgi_n, 3L * Hn, T_(t, PTV_DTB_TOK_OP), E, gih + Ht, (long)Ht + E, 1.f, 1, 1, 0, nullptr, top_step, R, 0, sside));
-    PTV_TRY(ptv_gemm(P, 1, 1, Hn, Ht, R, dHN0, Hn, NSf, Ht, GB(PTV_DTB_G_W_T2N), Ht, nullptr, 1.f, 1, 0, 0, B16, sside));
-    PTV_TRY(ptv_colsum(GB(PTV_DTB_G_B_T2N), dHN0, Hn, R, Hn, nullptr, 1, 0, sside));
+    // the five parameter gradients of the notes GRU and of dec_time_to_notes_hid: ONE product launch + ONE reduction launch; the four bias
+    // gradients are column sums taken from the A tiles in LDS (round 5: five products, five reductions, two column-sum passes over dGC / dHN0)
+    WgradGroup wg(P, sside);
+    PTV_TRY(wg.add(2 * Hn, Hn, M, dgi_n, 3L * Hn, 1, HN16, Hn, 1, gw, Hn, gb, top_step, R, 0));
+    PTV_TRY(wg.add(Hn, Hn, M, dgh_n, Hn, 1, HN16, Hn, 1, gw + 2L * Hn * Hn, Hn, gb + 2 * Hn, top_step, R, 0));
+    PTV_TRY(wg.add(3 * Hn, Ht, R, dGC, 3L * Hn, 0, NSf, Ht, 1, gih, (long)Ht + E, GB(PTV_DTB_G_B_IH_N)));
+    PTV_TRY(wg.add(3 * Hn, E, M, dgi_n, 3L * Hn, 1, T_(t, PTV_DTB_TOK_OP), E, 0, gih + Ht, (long)Ht + E, nullptr, top_step, R, 0));
+    PTV_TRY(wg.add(Hn, Ht, R, dHN0, Hn, 0, NSf, Ht, 1, GB(PTV_DTB_G_W_T2N), Ht, GB(PTV_DTB_G_B_T2N)));
+    PTV_TRY(wg.flush());
   }
 
   // ================= time GRU (32 steps x B rows): one persistent launch, split-K teams; then dTOKS and dz
@@ -350,18 +377,17 @@ extern "C" int ptv_decoder_tf_bwd(const void* const* t, const long* d, void* str
     const __bf16* NS16 = (const __bf16*)T_(t, PTV_DTB_NS16);
     float* g_ih = GB(PTV_DTB_G_W_IH_T); float* gb_ih = GB(PTV_DTB_G_B_IH_T); float* gb_hh = GB(PTV_DTB_G_B_HH_T);
     const long ld_t = 2L * He + Zi;
-    PTV_TRY(ptv_gemm(P, 1, 1, 3 * Ht, Ht, R, dgh_t, 3L * Ht, NS16, Ht, GB(PTV_DTB_G_W_HH_T), Ht, nullptr, 1.f, 1, 0, 0, A16 | B16, sside));
-    PTV_TRY(ptv_colsum(gb_ih, dZG, 3L * Ht, B, 3 * Ht, nullptr, 1, 0, sside));
-    // bias_hh: dgi and dgh share their r and z thirds (the column sums are copied), only the n third is summed
-    PTV_TRY(ptv_copy2d(gb_hh, 3L * Ht, gb_ih, 3L * Ht, 1, 2 * Ht, 1.f, 1, sside));
-    PTV_TRY(ptv_colsum(gb_hh + 2 * Ht, (const __bf16*)dgh_t + 2 * Ht, 3L * Ht, R, Ht, nullptr, 1, 1, sside));
-    PTV_TRY(ptv_gemm(P, 1, 1, 3 * Ht, Zi, B, dZG, 3L * Ht, T_(t, PTV_DTB_Z_IN), Zi, g_ih + 2 * He, ld_t, nullptr, 1.f, 1, 0, 0, 0, sside));
-    PTV_TRY(ptv_gemm(P, 1, 1, 3 * Ht, 2 * He, R, dgi_t, 3L * Ht, T_(t, PTV_DTB_TOKS), 2L * He, g_ih, ld_t, nullptr, 1.f, 1, 0, 0, A16, sside));
+    // the time GRU's and the two z projections' parameter gradients as one batch.  bias_hh = column sums of dgh over all (t, b) rows, taken
+    // inside the W_hh product (round 5: r / z thirds copied from bias_ih, n third summed by a second pass over dgh); bias_ih = column sums
+    // of dZG = sum_t dgi_t inside the z_in product.  Only the learned start token's gradient (row block 0 of dTOKS) keeps its own column sum.
+    WgradGroup wg(P, sside);
+    PTV_TRY(wg.add(3 * Ht, Ht, R, dgh_t, 3L * Ht, 1, NS16, Ht, 1, GB(PTV_DTB_G_W_HH_T), Ht, gb_hh));
+    PTV_TRY(wg.add(3 * Ht, Zi, B, dZG, 3L * Ht, 0, T_(t, PTV_DTB_Z_IN), Zi, 0, g_ih + 2 * He, ld_t, gb_ih));
+    PTV_TRY(wg.add(3 * Ht, 2 * He, R, dgi_t, 3L * Ht, 1, T_(t, PTV_DTB_TOKS), 2L * He, 0, g_ih, ld_t, nullptr));
+    PTV_TRY(wg.add(Ht, Zs, B, dzhid, Ht, 0, T_(t, PTV_DTB_Z), Zs, 0, GB(PTV_DTB_G_W_ZHID), Zs, GB(PTV_DTB_G_B_ZHID)));
+    PTV_TRY(wg.add(Zi, Zs, B, dz_in, Zi, 0, T_(t, PTV_DTB_Z), Zs, 0, GB(PTV_DTB_G_W_ZIN), Zs, GB(PTV_DTB_G_B_ZIN)));
+    PTV_TRY(wg.flush());
     PTV_TRY(ptv_colsum(GB(PTV_DTB_G_INIT_INPUT), dTOKS, 2L * He, B, 2 * He, nullptr, 1, 0, sside));
-    PTV_TRY(ptv_gemm(P, 1, 1, Ht, Zs, B, dzhid, Ht, T_(t, PTV_DTB_Z), Zs, GB(PTV_DTB_G_W_ZHID), Zs, nullptr, 1.f, 1, 0, 0, 0, sside));
-    PTV_TRY(ptv_colsum(GB(PTV_DTB_G_B_ZHID), dzhid, Ht, B, Ht, nullptr, 1, 0, sside));
-    PTV_TRY(ptv_gemm(P, 1, 1, Zi, Zs, B, dz_in, Zi, T_(t, PTV_DTB_Z), Zs, GB(PTV_DTB_G_W_ZIN), Zs, nullptr, 1.f, 1, 0, 0, 0, sside));
-    PTV_TRY(ptv_colsum(GB(PTV_DTB_G_B_ZIN), dz_in, Zi, B, Zi, nullptr, 1, 0, sside));
   }
   ptv_gemm_priority(1);
 #undef GB
@@ -408,14 +434,13 @@ extern "C" int ptv_bigru_final_bwd(const void* const* t, const long* d, void* st
     if (t[PTV_BGB_RECORD_EVENT] && hipEventRecord((hipEvent_t)const_cast<void*>(t[PTV_BGB_RECORD_EVENT]), s) != hipSuccess) return PTV_ERR_LAUNCH;
   }
   const void* x = T_(t, PTV_BGB_X);
-  const int dt_x = 1 | (xbf << 1);                                   // dgi / dgh bf16, x fp32 or bf16
   auto products = [&](int dir, void* st) -> int {
     const int o = dir ? 4 : 0;
-    PTV_TRY(ptv_wgrad(3 * H, I, (int)TM, dgi[dir], 3L * H, x, I, M_<float>(t, PTV_BGB_G_W_IH0 + o), I, 1.f, 1, dt_x, 0,
-                      M_<float>(t, PTV_BGB_G_B_IH0 + o), nullptr, 0, 0, st));
-    PTV_TRY(ptv_wgrad(3 * H, H, (int)TM, dgh[dir], 3L * H, T_(t, dir ? PTV_BGB_H16_1 : PTV_BGB_H16_0), H, M_<float>(t, PTV_BGB_G_W_HH0 + o), H, 1.f, 1,
-                      3, 0, M_<float>(t, PTV_BGB_G_B_HH0 + o), nullptr, 0, dir ? T : 0, st));
-    return PTV_OK;
+    WgradGroup wg(P, st);                                          // a direction's W_ih / W_hh gradients (and both bias sums): one launch
+    PTV_TRY(wg.add(3 * H, I, TM, dgi[dir], 3L * H, 1, x, I, xbf, M_<float>(t, PTV_BGB_G_W_IH0 + o), I, M_<float>(t, PTV_BGB_G_B_IH0 + o)));
+    PTV_TRY(wg.add(3 * H, H, TM, dgh[dir], 3L * H, 1, T_(t, dir ? PTV_BGB_H16_1 : PTV_BGB_H16_0), H, 1, M_<float>(t, PTV_BGB_G_W_HH0 + o), H,
+                   M_<float>(t, PTV_BGB_G_B_HH0 + o), nullptr, 0, dir ? T : 0));
+    return wg.flush();
   };
   // the reversed direction's products on the side stream ...
   hipEvent_t ef = (hipEvent_t)const_cast<void*>(t[PTV_BGB_FORK_EVENT]), ej = (hipEvent_t)const_cast<void*>(t[PTV_BGB_JOIN_EVENT]);
@@ -526,11 +551,11 @@ extern "C" int ptv_bigru_rows_bwd(const void* const* t, const long* d, void* str
     PTV_TRY(ptv_row_gru_persist_bwd_perm(H, T_(t, PTV_BRB_PK_WT0 + o), T_(t, PTV_BRB_HALL0 + o), T_(t, PTV_BRB_GATES0 + o), nullptr, dout + (long)dir * H,
                                          dout_ld, (const int*)T_(t, PTV_BRB_LENGTHS), (const int*)T_(t, PTV_BRB_PERM), dgi, dgh, nullptr,
                                          M_<void>(t, PTV_BRB_SCRATCH0 + q), M, T, dir, top, (void*)st));
-    PTV_TRY(ptv_wgrad(3 * H, I, (int)TM, dgi, 3L * H, x, I, M_<float>(t, PTV_BRB_G_W_IH0 + g), I, 1.f, 1, 1, 0, M_<float>(t, PTV_BRB_G_B_IH0 + g), top,
-                      top ? M : 0, 0, (void*)st));
-    PTV_TRY(ptv_wgrad(3 * H, H, (int)TM, dgh, 3L * H, T_(t, PTV_BRB_H16_0 + o), H, M_<float>(t, PTV_BRB_G_W_HH0 + g), H, 1.f, 1, 3, 0,
-                      M_<float>(t, PTV_BRB_G_B_HH0 + g), top, top ? M : 0, dir ? T : 0, (void*)st));
-    return PTV_OK;
+    WgradGroup wg(P, (void*)st);
+    PTV_TRY(wg.add(3 * H, I, TM, dgi, 3L * H, 1, x, I, 0, M_<float>(t, PTV_BRB_G_W_IH0 + g), I, M_<float>(t, PTV_BRB_G_B_IH0 + g), top, top ? M : 0, 0));
+    PTV_TRY(wg.add(3 * H, H, TM, dgh, 3L * H, 1, T_(t, PTV_BRB_H16_0 + o), H, 1, M_<float>(t, PTV_BRB_G_W_HH0 + g), H,
+                   M_<float>(t, PTV_BRB_G_B_HH0 + g), top, top ? M : 0, dir ? T : 0));
+    return wg.flush();
   };
   auto dx_of = [&](int dir, int acc) -> int {
     const int o = dir ? 5 : 0, q = dir ? 4 : 0;

@@ -392,7 +392,7 @@ constexpr int MAXEV = 8192;
 static int enabled = 0, filt_M = 0, filt_H = 0;          // enabled: bit (tag-1) set = record launches of that family
 static hipEvent_t ev0[MAXEV], ev1[MAXEV];
 static int slot_tag[MAXEV];
-static double slot_flops[MAXEV];
+static double slot_flops[MAXEV], slot_aux[MAXEV][2];
 static int created = 0, used = 0, cur_tag = 0;
 bool want(int tag, int M, int H) {
   // (tags 5 = weight-gradient products, 6 = BPTT of the persistent small-M recurrences: whole families, no shape filter)
@@ -412,8 +412,10 @@ int begin(hipStream_t s) {
 void end(int i, hipStream_t s, double fl) {
   (void)hipEventRecord(ev1[i], s);
   slot_flops[i] = fl;
+  slot_aux[i][0] = slot_aux[i][1] = 0.0;
   used = i + 1;
 }
+void aux(int i, double a, double b) { slot_aux[i][0] = a; slot_aux[i][1] = b; }
 }  // namespace prof
 
 template <class CT, bool SA, bool SB, int FAST>
@@ -584,6 +586,19 @@ extern "C" int ptv_prof_read_tag(int tag, long* count, double* total_ms, double*
   if (count) *count = n;
   if (total_ms) *total_ms = tot;
   if (flops) *flops = fl;
+  return PTV_OK;
+}
+// the part of a tag's FLOPs that is subject to a device-side row limit (ptv_wgrad's k_top), by the number of units the limit counts in:
+// lim15 = products over the 15 note steps of the decoder, lim16 = over the 16 note positions of the note-summary GRU.  bench.py scales
+// them by the live fraction of the benchmark batch to report EXECUTED next to nominal FLOPs.
+extern "C" int ptv_prof_read_limited(int tag, double* lim15, double* lim16) {
+  double a = 0.0, b = 0.0;
+  for (int i = 0; i < ptv::prof::used; i++) {
+    if (tag != 0 && ptv::prof::slot_tag[i] != tag) continue;
+    a += ptv::prof::slot_aux[i][0]; b += ptv::prof::slot_aux[i][1];
+  }
+  if (lim15) *lim15 = a;
+  if (lim16) *lim16 = b;
   return PTV_OK;
 }
 extern "C" int ptv_prof_read(long* count, double* total_ms, double* flops) { return ptv_prof_read_tag(0, count, total_ms, flops); }

@@ -233,14 +233,15 @@ __device__ __forceinline__ void wgrad_store(const WgArgs& g, wf32x4 (&acc)[4][4]
   }
 }
 
-// GUARD = false: rows 16-byte aligned, K a multiple of 32 and not reaching the operands' last row (see ptv_wgrad)
-template <bool AF32, bool BF32, bool GUARD, int NSET>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
+// one block's share of a product: block number b of the launch that `g` describes (a slab of K for one 128 x 128 output tile).
+// GUARD = false: rows 16-byte aligned, K a multiple of 32 and not reaching the operands' last row (see ptv_wgrad).
+// Shared by the one-product kernel and the batched one (wgrad_batch_kernel): the same plan gives the same bits either way.
+template <bool AF32, bool BF32, bool GUARD>
+__device__ __forceinline__ void wgrad_block(const WgArgs& g, int b, __bf16* As, __bf16* Bs) {
+  constexpr int NSET = 2;            // register sets of prefetch (4, bf16 sources only, measured 2028 vs 2011 us over the step's shapes: removed)
   if (g.prio) __builtin_amdgcn_s_setprio(3);
-  __shared__ __attribute__((aligned(16))) __bf16 As[2 * WSTAGE];
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[2 * WSTAGE];
   const int tiles = g.tiles_m * g.tiles_n;
-  int b = blockIdx.x, slab, tile;
+  int slab, tile;
   if (g.map == 1) { const int q = b >> 3; slab = (q / tiles) * 8 + (b & 7); tile = q % tiles; }
   else if (g.map == 2) { const int tx = tiles >> 3, q = b >> 3; tile = (b & 7) * tx + q % tx; slab = q / tx; }
   else { slab = b / tiles; tile = b % tiles; }
@@ -324,17 +325,55 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
   for (; t0 + NSET <= nst; t0 += NSET) {
     WG_BODY(0, t0);
     WG_BODY(1, t0 + 1);
-    if constexpr (NSET == 4) { WG_BODY(2, t0 + 2); WG_BODY(3, t0 + 3); }
   }
-  if (t0 < nst) {
-    WG_BODY(0, t0);
-    if constexpr (NSET == 4) {
-      if (t0 + 1 < nst) { WG_BODY(1, t0 + 1); if (t0 + 2 < nst) WG_BODY(2, t0 + 2); }
-    }
-  }
+  if (t0 < nst) WG_BODY(0, t0);
 #undef WG_BODY
 #undef WG_FETCH
   wgrad_store(g, acc, accs, do_sum, slab, tile, tiles, m_blk, n_blk, wm, wn, lane);
+}
+
+template <bool AF32, bool BF32, bool GUARD>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs g) {
+  __shared__ __attribute__((aligned(16))) __bf16 As[2 * WSTAGE];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2 * WSTAGE];
+  wgrad_block<AF32, BF32, GUARD>(g, blockIdx.x, As, Bs);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Several products in ONE launch (ptv_wgrad_batch): the parameter-gradient products that become ready at the same point of a backward
+// pass -- a GRU's W_ih / W_hh / bias gradients, a decoder's z projections -- are each a few dozen to a few hundred blocks; launched one
+// by one every small product leaves most of the chip idle for its ramp-up and tail, and each is followed by its own reduction launch.
+// The table holds one entry per (product, fast | guarded part); a block finds its entry by its number and runs wgrad_block on it.
+// ---------------------------------------------------------------------------------------------
+constexpr int WG_MAX_ENT = 16;          // entries per launch (8 products with a guarded tail each)
+struct WgBatch {
+  WgArgs g[WG_MAX_ENT];
+  int first[WG_MAX_ENT + 1];            // entry e owns blocks first[e] .. first[e + 1] - 1
+  unsigned char kind[WG_MAX_ENT];       // bit 0: A fp32, bit 1: B fp32, bit 2: guarded
+  int n;
+};
+
+template <bool HAS_F32, bool HAS_GUARD>
+__global__ __launch_bounds__(256, 2) void wgrad_batch_kernel(WgBatch bt) {
+  __shared__ __attribute__((aligned(16))) __bf16 As[2 * WSTAGE];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2 * WSTAGE];
+  int e = 0;
+  while (e + 1 < bt.n && (int)blockIdx.x >= bt.first[e + 1]) e++;
+  e = __builtin_amdgcn_readfirstlane(e);
+  const WgArgs& g = bt.g[e];
+  const int b = (int)blockIdx.x - bt.first[e];
+  const int kind = bt.kind[e];
+  if (!HAS_F32 && !HAS_GUARD) { wgrad_block<false, false, false>(g, b, As, Bs); return; }
+  switch (kind) {
+    case 0: wgrad_block<false, false, false>(g, b, As, Bs); break;
+    case 1: if constexpr (HAS_F32) wgrad_block<true, false, false>(g, b, As, Bs); break;
+    case 2: if constexpr (HAS_F32) wgrad_block<false, true, false>(g, b, As, Bs); break;
+    case 3: if constexpr (HAS_F32) wgrad_block<true, true, false>(g, b, As, Bs); break;
+    case 4: if constexpr (HAS_GUARD) wgrad_block<false, false, true>(g, b, As, Bs); break;
+    case 5: if constexpr (HAS_F32 && HAS_GUARD) wgrad_block<true, false, true>(g, b, As, Bs); break;
+    case 6: if constexpr (HAS_F32 && HAS_GUARD) wgrad_block<false, true, true>(g, b, As, Bs); break;
+    default: if constexpr (HAS_F32 && HAS_GUARD) wgrad_block<true, true, true>(g, b, As, Bs); break;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -458,7 +497,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgArgs g) {
 
 // ordered reduction of the slab partials: C[m][n] (+)= alpha * (p_0 + p_1 + ...) in slab order -- the same bits on every run.
 // ga: the fast launch's arguments (slabs 0 .. ga.nslab-1), gb: the guarded tail launch (one slab, number ga.nslab), if has_b.
-__global__ void wgrad_reduce_kernel(WgArgs ga, WgArgs gb, int has_a, int has_b, int accumulate) {
+// bi / nb: this block's number among the nb blocks that work on this product (grid-stride over its elements).
+__device__ __forceinline__ void wgrad_reduce_block(const WgArgs& ga, const WgArgs& gb, int has_a, int has_b, int accumulate, int bi, int nb) {
   const int tiles = ga.tiles_m * ga.tiles_n;
   // the live slabs of the fast launch are one contiguous range (the k_top limits cut K at one end): [s0, s1)
   int s0 = 0, s1 = 0;
@@ -474,10 +514,11 @@ __global__ void wgrad_reduce_kernel(WgArgs ga, WgArgs gb, int has_a, int has_b, 
   const long tstride = (long)tiles * (WBM * WBN);
   const float* wb = has_b ? gb.ws + (long)gb.slab0 * tstride : nullptr;
   const bool vec = (ga.N & 3) == 0 && (ga.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(ga.C) & 15) == 0;
+  const long gstride = (long)nb * blockDim.x, gstart = (long)bi * blockDim.x + threadIdx.x;
   if (vec) {
     const int N4 = ga.N >> 2;
     const long total4 = (long)ga.M * N4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    for (long i = gstart; i < total4; i += gstride) {
       const int m = (int)(i / N4), n = (int)(i % N4) * 4;
       const long off = (long)((m / WBM) * ga.tiles_n + n / WBN) * (WBM * WBN) + (long)(m % WBM) * WBN + (n % WBN);
       const float* p = ga.ws + off;
@@ -502,7 +543,7 @@ __global__ void wgrad_reduce_kernel(WgArgs ga, WgArgs gb, int has_a, int has_b, 
     }
   } else {
     const long total = (long)ga.M * ga.N;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = gstart; i < total; i += gstride) {
       const int m = (int)(i / ga.N), n = (int)(i % ga.N);
       const long off = (long)((m / WBM) * ga.tiles_n + n / WBN) * (WBM * WBN) + (long)(m % WBM) * WBN + (n % WBN);
       float sum = 0.f;
@@ -522,13 +563,32 @@ __global__ void wgrad_reduce_kernel(WgArgs ga, WgArgs gb, int has_a, int has_b, 
     }
   }
   if (ga.ws_csum) {                                                 // the bias gradient (always accumulates)
-    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < ga.M; m += (long)gridDim.x * blockDim.x) {
+    for (long m = gstart; m < ga.M; m += gstride) {
       float sum = 0.f;
       for (int sl = s0; sl < s1; sl++) sum += ga.ws_csum[(long)sl * ga.M + m];
       if (live_b) sum += gb.ws_csum[(long)gb.slab0 * ga.M + m];
       ga.csum[m] += sum;
     }
   }
+}
+
+__global__ void wgrad_reduce_kernel(WgArgs ga, WgArgs gb, int has_a, int has_b, int accumulate) {
+  wgrad_reduce_block(ga, gb, has_a, has_b, accumulate, blockIdx.x, gridDim.x);
+}
+
+// the reductions of a batch in one launch: product j owns blocks first[j] .. first[j + 1] - 1
+constexpr int WG_MAX_JOBS = 8;
+struct WgRedBatch {
+  WgArgs ga[WG_MAX_JOBS], gb[WG_MAX_JOBS];
+  int first[WG_MAX_JOBS + 1];
+  unsigned char has_a[WG_MAX_JOBS], has_b[WG_MAX_JOBS], acc[WG_MAX_JOBS];
+  int n;
+};
+__global__ void wgrad_reduce_batch_kernel(WgRedBatch rb) {
+  int j = 0;
+  while (j + 1 < rb.n && (int)blockIdx.x >= rb.first[j + 1]) j++;
+  j = __builtin_amdgcn_readfirstlane(j);
+  wgrad_reduce_block(rb.ga[j], rb.gb[j], rb.has_a[j], rb.has_b[j], rb.acc[j], (int)blockIdx.x - rb.first[j], rb.first[j + 1] - rb.first[j]);
 }
 
 __global__ void wgrad_zero_kernel(float* C, long ldc, int M, int N) {
@@ -578,46 +638,40 @@ namespace ptv { extern int g_splitk_ordered; }
 extern "C" int ptv_wgrad_dma(int enable) { ptv::g_wgrad_dma = enable ? 1 : 0; return PTV_OK; }
 extern "C" int ptv_wgrad_mode(int ordered) { ptv::g_wgrad_mode = ptv::g_splitk_ordered = ordered ? 1 : 0; return PTV_OK; }
 
-static int wgrad_impl(int M, int N, int K, const void* A, long lda, const void* A2, long lda2, int split, const void* B, long ldb, float* C, long ldc,
-                      float alpha, int accumulate, int dtypes, int slabs, float* colsum_a, const int* k_top, long k_unit, int k_rev, void* stream) {
-  if (M < 0 || N < 0 || K < 0 || !A || !B || !C) return PTV_ERR_ARG;
-  if (k_top && (k_unit <= 0 || k_unit % WBK)) return PTV_ERR_ARG;
-  if (M == 0 || N == 0) return PTV_OK;
-  {                                                      // timing experiment only (results invalid): PTV_WGRAD_DRY=1 skips every product
-    static const int dry = getenv("PTV_WGRAD_DRY") ? atoi(getenv("PTV_WGRAD_DRY")) : 0;
-    if (dry) return PTV_OK;
-  }
-  hipStream_t s = (hipStream_t)stream;
-  if (K == 0) {
-    if (!accumulate) {
-      const long total = (long)M * N;
-      int nb = (int)((total + 255) / 256); if (nb > 2048) nb = 2048;
-      hipLaunchKernelGGL(wgrad_zero_kernel, dim3(nb), dim3(256), 0, s, C, ldc, M, N);
-    }
-    PTV_CHECK_LAUNCH();
-    return PTV_OK;
-  }
-  const bool af = !(dtypes & 1), bf = !(dtypes & 2);
-  const bool vec = (lda % (af ? 4 : 8) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
-                   (!A2 || ((lda2 % (af ? 4 : 8) == 0) && ((reinterpret_cast<uintptr_t>(A2) & 15) == 0))) &&
-                   (ldb % (bf ? 4 : 8) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+namespace {
+// one product of a call: what the caller asked for (ptv_wgrad_job + the two-source form of ptv_wgrad_cat) ...
+struct Job {
+  int M, N, K; const void* A; long lda; const void* A2; long lda2; int split; const void* B; long ldb; float* C; long ldc;
+  float alpha; int accumulate, dtypes, slabs; float* colsum_a; const int* k_top; long k_unit; int k_rev;
+};
+// ... and how it runs: the fast (unguarded) launch over rows [0, kfast) and the guarded one over the rest, each cut into K slabs.
+// A pure function of the job (shapes, alignment) and of the process-wide mode: one product planned alone or inside a batch runs the
+// same blocks on the same slabs and reduces them in the same order -- the same bits.
+struct Plan {
+  WgArgs part[2]; bool has[2]; int nslab[2]; int tiles; bool af, bf; int total_slabs;
+  size_t tile_floats, sum_floats;           // workspace need when the reduction is ordered (total_slabs > 1)
+};
+
+int plan_job(const Job& j, Plan& p) {
+  const bool af = !(j.dtypes & 1), bf = !(j.dtypes & 2);
+  p.af = af; p.bf = bf;
+  const bool vec = (j.lda % (af ? 4 : 8) == 0) && ((reinterpret_cast<uintptr_t>(j.A) & 15) == 0) &&
+                   (!j.A2 || ((j.lda2 % (af ? 4 : 8) == 0) && ((reinterpret_cast<uintptr_t>(j.A2) & 15) == 0))) &&
+                   (j.ldb % (bf ? 4 : 8) == 0) && ((reinterpret_cast<uintptr_t>(j.B) & 15) == 0);
   // the unguarded kernel reads whole 8-column chunks: where a chunk straddles M or N it spills into the next row, so it stops
   // short of the operands' last row; the guarded kernel takes the remaining <= 32 rows (and everything when rows are unaligned)
-  const bool odd = (M % 8) || (N % 8) || (A2 && (split % 8));
-  const int kfast = !vec ? 0 : (odd ? ((K - 1) / WBK) * WBK : (K / WBK) * WBK);
-  const int nset = 2;                                              // (4 register sets of prefetch, bf16 sources only: 2028 vs 2011 us over the step's shapes)
-  WgArgs sent[2]; int nsent[2] = {0, 0};
-  float* ws = nullptr; float* ws_csum = nullptr; int ws_slabs = 0;
-  const bool has_a = kfast > 0, has_b = kfast < K;
-  bool zeroed = false;
-  auto launch = [&](bool guard, int k0, int kn, int want_slabs, int pass) -> int {
-    WgArgs g{static_cast<const char*>(A) + (long)k0 * lda * (af ? 4 : 2), lda, static_cast<const char*>(B) + (long)k0 * ldb * (bf ? 4 : 2), ldb,
-             C, ldc, M, N, kn, 0, cdiv(M, WBM), cdiv(N, WBN), 1, 0, alpha, colsum_a, k_top, k_unit, k_rev, g_gemm_prio,
+  const bool odd = (j.M % 8) || (j.N % 8) || (j.A2 && (j.split % 8));
+  const int kfast = !vec ? 0 : (odd ? ((j.K - 1) / WBK) * WBK : (j.K / WBK) * WBK);
+  p.has[0] = kfast > 0; p.has[1] = kfast < j.K;
+  p.tiles = cdiv(j.M, WBM) * cdiv(j.N, WBN);
+  auto part = [&](bool guard, int k0, int kn, int want_slabs) {
+    WgArgs g{static_cast<const char*>(j.A) + (long)k0 * j.lda * (af ? 4 : 2), j.lda, static_cast<const char*>(j.B) + (long)k0 * j.ldb * (bf ? 4 : 2), j.ldb,
+             j.C, j.ldc, j.M, j.N, kn, 0, cdiv(j.M, WBM), cdiv(j.N, WBN), 1, 0, j.alpha, j.colsum_a, j.k_top, j.k_unit, j.k_rev, g_gemm_prio,
              nullptr, nullptr, 0,
-             A2 ? static_cast<const char*>(A2) + (long)k0 * lda2 * (af ? 4 : 2) : nullptr, lda2, split, k0};
+             j.A2 ? static_cast<const char*>(j.A2) + (long)k0 * j.lda2 * (af ? 4 : 2) : nullptr, j.lda2, j.split, k0};
     // (the guarded tail launch takes the limits too, shifted by its first row: the rows a limit declares zero may never have been WRITTEN by
     // whoever produced the other operand -- a forward that stopped at the batch's last live note step)
-    const int tiles = g.tiles_m * g.tiles_n;     // BLOCKS per slab
+    const int tiles = p.tiles;     // BLOCKS per slab
     // slab count (measured optima of scripts/bench_wgrad.py sweep on MI355X).  Every slab pays M*N atomics, and a grid that is
     // just over one block per CU leaves a tail, so: about one block per CU (never more) for the skinny, HBM-bound products;
     // about three per CU for the MFMA-heavy ones (many tiles), where co-resident blocks hide each other's stalls; a slab is at least
@@ -644,71 +698,166 @@ static int wgrad_impl(int M, int N, int K, const void* A, long lda, const void* 
     g.kper = cdiv(cdiv(kn, ns), WBK) * WBK;
     if (g.map != 1) ns = cdiv(kn, g.kper);
     g.nslab = ns;
-    if (pass == 0) {                                             // planning pass: slab counts only
-      sent[guard ? 1 : 0] = g; nsent[guard ? 1 : 0] = ns;
-      return PTV_OK;
-    }
-    if (ws) {
-      g.ws = ws; g.ws_csum = colsum_a ? ws_csum : nullptr; g.slab0 = guard ? nsent[0] : 0;
-    }
-    else if (!accumulate && !zeroed) {
-      const long total = (long)M * N;
-      int nb = (int)((total + 255) / 256); if (nb > 2048) nb = 2048;
-      hipLaunchKernelGGL(wgrad_zero_kernel, dim3(nb), dim3(256), 0, s, C, ldc, M, N);
-      zeroed = true;
-    }
-    sent[guard ? 1 : 0] = g;
-    const dim3 grid((unsigned)(tiles * ns));
-    constexpr int lds_pad = 0;       // (unused dynamic LDS per block to keep product blocks off the CUs of the latency chains: no change, round 4)
-#define WG_LAUNCH(AF, BF)                                                                                      \
-    do {                                                                                                       \
-      if (guard) hipLaunchKernelGGL((wgrad_kernel<AF, BF, true, 2>), grid, dim3(256), lds_pad, s, g);                \
-      else if (nset == 2) hipLaunchKernelGGL((wgrad_kernel<AF, BF, false, 2>), grid, dim3(256), lds_pad, s, g);      \
-      else if constexpr (!(AF) && !(BF)) hipLaunchKernelGGL((wgrad_kernel<false, false, false, 4>), grid, dim3(256), lds_pad, s, g); \
-    } while (0)
-    // (default OFF: standalone the LDS-DMA kernel is 5-12 % faster on the deep products -- 1536 x 512 x 245760 571 -> 544 us -- but in the
-    // step it measured 7.82-7.98 ms against 7.72-7.75: its 48 KB of LDS per block co-reside worse with the persistent recurrences' 96-KB
-    // workgroups than the register-staged kernel's 36 KB.  PTV_WGRAD_DMA=1 enables it; tests/test_gpu_switches.py runs the step on it.)
-    if (!af && !bf && !guard && g_wgrad_dma && (kn % WBK) == 0) { hipLaunchKernelGGL(wgrad_dma_kernel, grid, dim3(256), 0, s, g); return PTV_OK; }
-    if (af && bf) WG_LAUNCH(true, true);
-    else if (af) WG_LAUNCH(true, false);
-    else if (bf) WG_LAUNCH(false, true);
-    else WG_LAUNCH(false, false);
-#undef WG_LAUNCH
-    return PTV_OK;
+    p.part[guard ? 1 : 0] = g; p.nslab[guard ? 1 : 0] = ns;
   };
-  if (has_a) launch(false, 0, kfast, slabs, 0);
-  if (has_b) launch(true, kfast, K - kfast, has_a ? 1 : slabs, 0);
-  const int total_slabs = nsent[0] + nsent[1];
-  // one slab in all: the product kernel is the only writer of every element (plain read-modify-write, already reproducible)
-  if (g_wgrad_mode == 1 && total_slabs > 1) {
-    const int tiles = cdiv(M, WBM) * cdiv(N, WBN);
-    const size_t tile_bytes = (size_t)total_slabs * tiles * WBM * WBN * sizeof(float);
-    const size_t sum_bytes = colsum_a ? (size_t)total_slabs * M * sizeof(float) : 0;
-    WsBuf* wb = ws_for(s, tile_bytes + sum_bytes);
-    if (!wb) g_ord_fallbacks++;
-    if (wb) { ws = wb->p; ws_csum = colsum_a ? wb->p + tile_bytes / sizeof(float) : nullptr; ws_slabs = total_slabs; }
-  }
-  const int pi = prof::want(5, M, N) ? prof::begin(s) : -1;        // bench.py's roofline block: the family's launches, product + reduction
-  if (has_a) launch(false, 0, kfast, slabs, 1);
-  if (has_b) launch(true, kfast, K - kfast, has_a ? 1 : slabs, 1);
-  if (ws) {
-    const bool vec4 = (N & 3) == 0 && (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
-    const long total = vec4 ? ((M * (long)N) >> 2) : M * (long)N;
-    int nb = (int)((total + 255) / 256); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
-    // (the guarded launch alone -- unaligned operands -- may have many slabs: it then plays the fast launch's part in the reduction)
-    if (!has_a) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, s, sent[1], sent[1], 1, 0, accumulate);
-    else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, s, sent[0], sent[1], 1, has_b ? 1 : 0, accumulate);
-  }
-  (void)ws_slabs;
-  if (pi >= 0) prof::end(pi, s, 2.0 * M * N * K);                  // (full K: a k_top limit is a device value)
-  PTV_CHECK_LAUNCH();
+  p.nslab[0] = p.nslab[1] = 0;
+  if (p.has[0]) part(false, 0, kfast, j.slabs);
+  if (p.has[1]) part(true, kfast, j.K - kfast, p.has[0] ? 1 : j.slabs);
+  p.total_slabs = p.nslab[0] + p.nslab[1];
+  p.tile_floats = (size_t)p.total_slabs * p.tiles * WBM * WBN;
+  p.sum_floats = j.colsum_a ? (size_t)p.total_slabs * j.M : 0;
   return PTV_OK;
 }
 
+void zero_c(const Job& j, hipStream_t s) {
+  const long total = (long)j.M * j.N;
+  int nb = (int)((total + 255) / 256); if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(wgrad_zero_kernel, dim3(nb), dim3(256), 0, s, j.C, j.ldc, j.M, j.N);
+}
+
+int reduce_blocks(const Job& j) {
+  const bool vec4 = (j.N & 3) == 0 && (j.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(j.C) & 15) == 0;
+  const long total = vec4 ? ((j.M * (long)j.N) >> 2) : j.M * (long)j.N;
+  int nb = (int)((total + 255) / 256); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
+  return nb;
+}
+
+// the products of `jobs` (disjoint outputs), as one product launch + one reduction launch when there are several
+int wgrad_run(const Job* jobs, int njobs, hipStream_t s) {
+  if (njobs <= 0) return PTV_OK;
+  if (njobs > WG_MAX_JOBS) {                                       // more than a table holds: in chunks
+    for (int i = 0; i < njobs; i += WG_MAX_JOBS) PTV_TRY(wgrad_run(jobs + i, njobs - i < WG_MAX_JOBS ? njobs - i : WG_MAX_JOBS, s));
+    return PTV_OK;
+  }
+  {                                                      // timing experiment only (results invalid): PTV_WGRAD_DRY=1 skips every product
+    static const int dry = getenv("PTV_WGRAD_DRY") ? atoi(getenv("PTV_WGRAD_DRY")) : 0;
+    if (dry) return PTV_OK;
+  }
+  Job live[WG_MAX_JOBS]; Plan plan[WG_MAX_JOBS]; int n = 0;
+  double flops = 0.0, lim15 = 0.0, lim16 = 0.0; int pm = 0, pn = 0;
+  for (int i = 0; i < njobs; i++) {
+    const Job& j = jobs[i];
+    if (j.M < 0 || j.N < 0 || j.K < 0 || !j.A || !j.B || !j.C) return PTV_ERR_ARG;
+    if (j.k_top && (j.k_unit <= 0 || j.k_unit % WBK)) return PTV_ERR_ARG;
+    if (j.M == 0 || j.N == 0) continue;
+    if (j.K == 0) { if (!j.accumulate) zero_c(j, s); continue; }
+    live[n] = j; PTV_TRY(plan_job(j, plan[n]));
+    flops += 2.0 * j.M * j.N * j.K; pm = j.M; pn = j.N;
+    if (j.k_top && j.k_unit > 0) {
+      const long units = j.k_rev > 0 ? j.k_rev : j.K / j.k_unit;
+      if (units == 15) lim15 += 2.0 * j.M * j.N * j.K; else if (units == 16) lim16 += 2.0 * j.M * j.N * j.K;
+    }
+    n++;
+  }
+  if (n == 0) { PTV_CHECK_LAUNCH(); return PTV_OK; }
+  // workspace of the ordered reductions: one region per product that has more than one slab in all (a single slab is the only writer of
+  // every element: plain read-modify-write, already reproducible)
+  float* wsp[WG_MAX_JOBS]; float* wsc[WG_MAX_JOBS];
+  for (int i = 0; i < n; i++) wsp[i] = wsc[i] = nullptr;
+  if (g_wgrad_mode == 1) {
+    size_t need = 0;
+    for (int i = 0; i < n; i++) if (plan[i].total_slabs > 1) need += plan[i].tile_floats + ((plan[i].sum_floats + 3) & ~(size_t)3);
+    if (need) {
+      WsBuf* wb = ws_for(s, need * sizeof(float));
+      if (!wb) g_ord_fallbacks++;
+      else {
+        float* q = wb->p;
+        for (int i = 0; i < n; i++) if (plan[i].total_slabs > 1) {
+          wsp[i] = q; q += plan[i].tile_floats;
+          if (live[i].colsum_a) { wsc[i] = q; q += (plan[i].sum_floats + 3) & ~(size_t)3; }
+        }
+      }
+    }
+  }
+  const int pi = prof::want(5, pm, pn) ? prof::begin(s) : -1;       // bench.py's roofline block: the family's launches, product + reduction
+  for (int i = 0; i < n; i++) {
+    for (int k = 0; k < 2; k++) if (plan[i].has[k]) {
+      WgArgs& g = plan[i].part[k];
+      if (wsp[i]) { g.ws = wsp[i]; g.ws_csum = wsc[i]; g.slab0 = k ? plan[i].nslab[0] : 0; }
+    }
+    if (!wsp[i] && !live[i].accumulate) zero_c(live[i], s);          // (atomics / single slab: the product adds into C)
+  }
+  if (n == 1) {
+    const Plan& p = plan[0];
+    for (int k = 0; k < 2; k++) if (p.has[k]) {
+      const WgArgs& g = p.part[k];
+      const dim3 grid((unsigned)(p.tiles * p.nslab[k]));
+      const bool guard = k == 1;
+#define WG_LAUNCH(AF, BF)                                                                                      \
+      do {                                                                                                     \
+        if (guard) hipLaunchKernelGGL((wgrad_kernel<AF, BF, true>), grid, dim3(256), 0, s, g);                 \
+        else hipLaunchKernelGGL((wgrad_kernel<AF, BF, false>), grid, dim3(256), 0, s, g);                      \
+      } while (0)
+      // (default OFF: standalone the LDS-DMA kernel is 5-12 % faster on the deep products -- 1536 x 512 x 245760 571 -> 544 us -- but in the
+      // step it measured 7.82-7.98 ms against 7.72-7.75: its 48 KB of LDS per block co-reside worse with the persistent recurrences' 96-KB
+      // workgroups than the register-staged kernel's 36 KB.  PTV_WGRAD_DMA=1 enables it; tests/test_gpu_switches.py runs the step on it.)
+      if (!p.af && !p.bf && !guard && g_wgrad_dma && (g.K % WBK) == 0) { hipLaunchKernelGGL(wgrad_dma_kernel, grid, dim3(256), 0, s, g); continue; }
+      if (p.af && p.bf) WG_LAUNCH(true, true);
+      else if (p.af) WG_LAUNCH(true, false);
+      else if (p.bf) WG_LAUNCH(false, true);
+      else WG_LAUNCH(false, false);
+#undef WG_LAUNCH
+    }
+    if (wsp[0]) {
+      // (the guarded launch alone -- unaligned operands -- may have many slabs: it then plays the fast launch's part in the reduction)
+      const int nb = reduce_blocks(live[0]);
+      if (!p.has[0]) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, s, p.part[1], p.part[1], 1, 0, live[0].accumulate);
+      else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, s, p.part[0], p.part[1], 1, p.has[1] ? 1 : 0, live[0].accumulate);
+    }
+  } else {
+    // ---- one product launch: the entries in order of decreasing work (the long blocks start first), every entry's first block a
+    // multiple of 8 so that the block -> XCD relation the slab / tile maps count on (block b runs on XCD b % 8) holds inside the entry
+    WgBatch bt; bt.n = 0;
+    int order[2 * WG_MAX_JOBS]; double work[2 * WG_MAX_JOBS]; int ne = 0;
+    for (int i = 0; i < n; i++) for (int k = 0; k < 2; k++) if (plan[i].has[k]) {
+      order[ne] = i * 2 + k; work[ne] = (double)plan[i].part[k].kper * (k ? 4.0 : 1.0); ne++;       // (a block's time ~ its slab depth; guarded rows cost more)
+    }
+    for (int a = 1; a < ne; a++) {                                   // insertion sort by work, stable
+      const int o = order[a]; const double w = work[a]; int b = a - 1;
+      while (b >= 0 && work[b] < w) { order[b + 1] = order[b]; work[b + 1] = work[b]; b--; }
+      order[b + 1] = o; work[b + 1] = w;
+    }
+    bool any_f32 = false, any_guard = false;
+    int nblk = 0;
+    for (int a = 0; a < ne; a++) {
+      const int i = order[a] >> 1, k = order[a] & 1;
+      const Plan& p = plan[i];
+      bt.g[a] = p.part[k];
+      bt.kind[a] = (unsigned char)((p.af ? 1 : 0) | (p.bf ? 2 : 0) | (k ? 4 : 0));
+      any_f32 |= p.af || p.bf; any_guard |= k == 1;
+      bt.first[a] = nblk;
+      nblk += (p.tiles * p.nslab[k] + 7) / 8 * 8;                  // (surplus blocks find their slab beyond K and return)
+    }
+    bt.first[ne] = nblk; bt.n = ne;
+    for (int a = ne + 1; a <= WG_MAX_ENT; a++) bt.first[a] = nblk;
+    const dim3 grid((unsigned)nblk);
+    if (any_f32 && any_guard) hipLaunchKernelGGL((wgrad_batch_kernel<true, true>), grid, dim3(256), 0, s, bt);
+    else if (any_f32) hipLaunchKernelGGL((wgrad_batch_kernel<true, false>), grid, dim3(256), 0, s, bt);
+    else if (any_guard) hipLaunchKernelGGL((wgrad_batch_kernel<false, true>), grid, dim3(256), 0, s, bt);
+    else hipLaunchKernelGGL((wgrad_batch_kernel<false, false>), grid, dim3(256), 0, s, bt);
+    // ---- one reduction launch for the products that went through the workspace
+    WgRedBatch rb; rb.n = 0; int rblk = 0;
+    for (int i = 0; i < n; i++) if (wsp[i]) {
+      const Plan& p = plan[i];
+      const int q = rb.n++;
+      if (!p.has[0]) { rb.ga[q] = p.part[1]; rb.gb[q] = p.part[1]; rb.has_a[q] = 1; rb.has_b[q] = 0; }
+      else { rb.ga[q] = p.part[0]; rb.gb[q] = p.has[1] ? p.part[1] : p.part[0]; rb.has_a[q] = 1; rb.has_b[q] = p.has[1] ? 1 : 0; }
+      rb.acc[q] = (unsigned char)(live[i].accumulate ? 1 : 0);
+      rb.first[q] = rblk; rblk += reduce_blocks(live[i]);
+    }
+    for (int q = rb.n; q <= WG_MAX_JOBS; q++) rb.first[q] = rblk;
+    if (rb.n) hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(rblk), dim3(256), 0, s, rb);
+  }
+  if (pi >= 0) { prof::end(pi, s, flops); prof::aux(pi, lim15, lim16); }    // (full K: a k_top limit is a device value; the limited part separately)
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+}  // namespace
+
 extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const void* B, long ldb, float* C, long ldc, float alpha,
                          int accumulate, int dtypes, int slabs, float* colsum_a, const int* k_top, long k_unit, int k_rev, void* stream) {
-  return wgrad_impl(M, N, K, A, lda, nullptr, 0, 0, B, ldb, C, ldc, alpha, accumulate, dtypes, slabs, colsum_a, k_top, k_unit, k_rev, stream);
+  const Job j{M, N, K, A, lda, nullptr, 0, 0, B, ldb, C, ldc, alpha, accumulate, dtypes, slabs, colsum_a, k_top, k_unit, k_rev};
+  return wgrad_run(&j, 1, (hipStream_t)stream);
 }
 
 // C[M1 + M2, N] (+)= alpha * [A1 | A2]^T . B: the column blocks of two row-per-sample matrices of the same dtype against ONE pass over B
@@ -718,5 +867,19 @@ extern "C" int ptv_wgrad_cat(int M1, const void* A1, long lda1, int M2, const vo
                              float* C, long ldc, float alpha, int accumulate, int dtypes, int slabs, float* colsum_a, const int* k_top,
                              long k_unit, int k_rev, void* stream) {
   if (M1 <= 0 || M2 <= 0 || (M1 % WBM) || !A1 || !A2) return PTV_ERR_ARG;
-  return wgrad_impl(M1 + M2, N, K, A1, lda1, A2, lda2, M1, B, ldb, C, ldc, alpha, accumulate, dtypes, slabs, colsum_a, k_top, k_unit, k_rev, stream);
+  const Job j{M1 + M2, N, K, A1, lda1, A2, lda2, M1, B, ldb, C, ldc, alpha, accumulate, dtypes, slabs, colsum_a, k_top, k_unit, k_rev};
+  return wgrad_run(&j, 1, (hipStream_t)stream);
+}
+
+// several products, one launch (+ one reduction launch): include/ptvae_hip.h
+extern "C" int ptv_wgrad_batch(const ptv_wgrad_job* jobs, int njobs, void* stream) {
+  if (njobs < 0 || (njobs > 0 && !jobs)) return PTV_ERR_ARG;
+  if (njobs > 64) return PTV_ERR_ARG;
+  Job js[64];
+  for (int i = 0; i < njobs; i++) {
+    const ptv_wgrad_job& q = jobs[i];
+    js[i] = Job{q.M, q.N, q.K, q.A, q.lda, nullptr, 0, 0, q.B, q.ldb, q.C, q.ldc, q.alpha, q.accumulate, q.dtypes, q.slabs, q.colsum_a, q.k_top,
+                q.k_unit, q.k_rev};
+  }
+  return wgrad_run(js, njobs, (hipStream_t)stream);
 }

@@ -705,16 +705,6 @@ def _bgrad(b, a):
     return g
 
 
-def _bgrad_hh(b_hh, dgh2, gb_ih):
-    """bias_hh gradient of a GRU from dgh [rows, 3H] given the finished bias_ih gradient: dgi and dgh share their r and z
-    thirds (only the n third differs: dn vs dn*r), so those column sums are copied and only the last third is summed"""
-    g = _gbuf(b_hh)
-    H = b_hh.numel() // 3
-    copy2d(g.view(1, -1)[:, :2 * H], gb_ih.view(1, -1)[:, :2 * H], acc=True)
-    colsum(g.view(1, -1)[:, 2 * H:], dgh2[:, 2 * H:])
-    return g
-
-
 WGRAD_FUSE_BIAS = True
 EMBED_MH_FWD = True    # multi-hot operand of the note_embedding gradient built during the forward
 # decoder backward: fork the weight-gradient work BEFORE the chain queues its next dX products (no false dependency on them)?  Measured
@@ -768,6 +758,20 @@ def wgrad_bias(dy, x, gw, gb, prec, k_top=None, k_unit=0, k_rev=0):
         if gb is not None:
             colsum(gb.view(1, -1), dy)
     return gw, gb
+
+
+def wgrad_bias_batch(items, prec):
+    """[(dy, x, gw, gb or None), ...] -> every gw += dy^T . x, gb += column sums of dy, as ONE ptv_wgrad_batch call (one product launch + one
+    reduction launch) when the weight-gradient kernel takes them all; the same bits as wgrad_bias() item by item"""
+    ok = WGRAD_FUSE_BIAS and prec == 1 and all(dy.shape[0] >= 512 and gw.dtype == F32 and dy.stride(1) == 1 and x.stride(1) == 1
+                                               for dy, x, gw, gb in items)
+    if not ok or len(items) < 2:
+        for dy, x, gw, gb in items:
+            wgrad_bias(dy, x, gw, gb, prec)
+        return
+    from ._lib import wgrad_batch
+    _chain_prio()
+    wgrad_batch([dict(M=dy.shape[1], N=x.shape[1], K=dy.shape[0], A=dy, B=x, C=gw, colsum_a=gb) for dy, x, gw, gb in items])
 
 
 # The fused duration GRU does not write its gate planes (5 steps x 4 planes x [M, 64] bf16 = 629 MB at B = 512, 63 % of the forward
@@ -1441,10 +1445,9 @@ class EncoderHeadsFn(torch.autograd.Function):
              B, Z, stream_ptr())
         dh = gemm_dx(gmu, w_mu, prec=prec)
         gemm_dx(glv, w_var, out=dh, acc=True, prec=prec)
-        dw_mu = gemm(gmu, h, _gbuf(w_mu), ta=True, tb=True, acc=True, prec=prec)
-        dw_var = gemm(glv, h, _gbuf(w_var), ta=True, tb=True, acc=True, prec=prec)
-        db_mu = _bgrad(b_mu, gmu)
-        db_var = _bgrad(b_var, glv)
+        # both heads' weight and bias gradients: one product launch + one reduction launch (six launches until round 5)
+        dw_mu, dw_var, db_mu, db_var = _gbuf(w_mu), _gbuf(w_var), _gbuf(b_mu), _gbuf(b_var)
+        wgrad_bias_batch([(gmu, h, dw_mu, db_mu), (glv, h, dw_var, db_var)], prec)
         return dh, dw_mu, db_mu, dw_var, db_var, None
 
 
@@ -2252,16 +2255,16 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
             wgrad_bias(dgh_n.view(M, Hn), h_op, gw[2 * Hn:], gb[2 * Hn:], prec, top_step, R)
         else:
             wgrad_b('dec_notes_gru.weight_hh_l0', 'dec_notes_gru.bias_hh_l0', dgh_n.view(M, 3 * Hn), HNo[:15].view(M, Hn))
-        bgrad('dec_notes_gru.bias_ih_l0', dGC)
-        wgrad('dec_notes_gru.weight_ih_l0', dGC, NSf_op, slice(0, Ht))
+        # (bias gradients as column sums INSIDE the products that read the same gradient matrix -- ptv_wgrad's colsum_a, as
+        # ptv_decoder_tf_bwd's batch does: no second pass over dGC / dHN0)
+        wgrad_b('dec_notes_gru.weight_ih_l0', 'dec_notes_gru.bias_ih_l0', dGC, NSf_op, slice(0, Ht))
         if top_step is not None:
             if G['dec_notes_gru.weight_ih_l0'] is None:
                 G['dec_notes_gru.weight_ih_l0'] = _gbuf(P['dec_notes_gru.weight_ih_l0'])
             wgrad_bias(dgi_n.view(M, 3 * Hn), tok_op, G['dec_notes_gru.weight_ih_l0'][:, Ht:], None, prec, top_step, R)
         else:
             wgrad('dec_notes_gru.weight_ih_l0', dgi_n.view(M, 3 * Hn), tok_op, slice(Ht, None))
-        wgrad('dec_time_to_notes_hid.weight', dHN0, NSf_op)
-        bgrad('dec_time_to_notes_hid.bias', dHN0)
+        wgrad_b('dec_time_to_notes_hid.weight', 'dec_time_to_notes_hid.bias', dHN0, NSf_op)
     dtok, dNS = notes_dx()
     # (forked BEFORE the time BPTT is queued: forking after it -- the four deep products then start when the persistent launch is done
     # instead of running beside it -- measured 8.48 against 8.18 ms per step)
@@ -2285,16 +2288,15 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     gemm_dx(dz_in, w_zi, out=dz, acc=True, prec=prec)
 
     def time_wgrads():
-        wgrad('dec_time_gru.weight_hh_l0', dgh_t.view(R, 3 * Ht), NSo[:32].view(R, Ht))
-        bgrad('dec_time_gru.bias_ih_l0', dZG)
-        G['dec_time_gru.bias_hh_l0'] = _bgrad_hh(P['dec_time_gru.bias_hh_l0'], dgh_t.view(R, 3 * Ht), G['dec_time_gru.bias_ih_l0'])
-        wgrad('dec_time_gru.weight_ih_l0', dZG, st['z_in'], slice(2 * He, None))
+        # bias_hh = column sums of dgh over all (t, b) rows, inside the W_hh product; bias_ih = column sums of dZG = sum_t dgi_t inside the
+        # z_in product (the same folds as ptv_decoder_tf_bwd's batch; products the weight-gradient kernel does not take -- fp32 precision,
+        # K = B < 512 -- fall back to product + column-sum kernel inside wgrad_bias, as the library's WgradGroup does)
+        wgrad_b('dec_time_gru.weight_hh_l0', 'dec_time_gru.bias_hh_l0', dgh_t.view(R, 3 * Ht), NSo[:32].view(R, Ht))
+        wgrad_b('dec_time_gru.weight_ih_l0', 'dec_time_gru.bias_ih_l0', dZG, st['z_in'], slice(2 * He, None))
         wgrad('dec_time_gru.weight_ih_l0', dgi_t.view(R, 3 * Ht), TOKS[:32].view(R, 2 * He), slice(0, 2 * He))
+        wgrad_b('z2dec_hid_linear.weight', 'z2dec_hid_linear.bias', dzhid, z)
+        wgrad_b('z2dec_in_linear.weight', 'z2dec_in_linear.bias', dz_in, z)
         bgrad('dec_init_input', dTOKS[0])
-        wgrad('z2dec_hid_linear.weight', dzhid, z)
-        bgrad('z2dec_hid_linear.bias', dzhid)
-        wgrad('z2dec_in_linear.weight', dz_in, z)
-        bgrad('z2dec_in_linear.bias', dz_in)
     side(time_wgrads, dgi_t, dgh_t, dZG, dTOKS, dzhid, dz_in, dNS)
     # the caller defers the join to the end of the backward pass; the node's saved forward state (released when the node returns)
     # is still being read by the products queued above
@@ -2478,21 +2480,19 @@ class ChordDecoderTFFn(torch.autograd.Function):
                 dhs = gemm(d2, w, tb=True, prec=prec)
             else:
                 gemm(d2, w, dhs, tb=True, acc=True, prec=prec)
-            G[name + '.weight'] = gemm(d2, hs, _gbuf(w), ta=True, tb=True, acc=True, prec=prec)
-            G[name + '.bias'] = _bgrad(P[name + '.bias'], d2)
+            # (weight and bias gradient in one pass over the logits' gradient: ptv_wgrad's colsum_a, as ptv_chord_decoder_bwd's batch does)
+            G[name + '.weight'], G[name + '.bias'] = wgrad_bias(d2, hs, _gbuf(w), _gbuf(P[name + '.bias']), prec)
         if dhs is None:
             dhs = _zeros(T * B, H, dev=dev)
         w_hh, w_ih = P['gru.weight_hh_l0'], P['gru.weight_ih_l0']
         # (per-step kernels, not the persistent launch: persistent launches take turns, and this short chain on its sibling stream had
         # to wait for the decoder's 32-step time BPTT -- its dz then reached the chord encoder 0.3 ms after the decoder's own, round 4)
         dgi, dgh, dh0 = gru_bwd(prec, hall, st['gates'], w_hh, dh_ext=dhs.view(T, B, H), allow_persist=True)
-        G['gru.weight_hh_l0'] = gemm(dgh.view(T * B, 3 * H), hall[:T].view(T * B, H), _gbuf(w_hh), ta=True, tb=True, acc=True,
-                                     prec=prec)
-        G['gru.bias_hh_l0'] = _bgrad(P['gru.bias_hh_l0'], dgh.view(T * B, 3 * H))
+        G['gru.weight_hh_l0'], G['gru.bias_hh_l0'] = wgrad_bias(dgh.view(T * B, 3 * H), hall[:T].view(T * B, H), _gbuf(w_hh),
+                                                                _gbuf(P['gru.bias_hh_l0']), prec)
         dzg = sum_steps(dgi)
-        G['gru.bias_ih_l0'] = _bgrad(P['gru.bias_ih_l0'], dzg)
         g = _gbuf(w_ih)
-        gemm(dzg, st['z_in'], g[:, I:], ta=True, tb=True, acc=True, prec=prec)
+        _, G['gru.bias_ih_l0'] = wgrad_bias(dzg, st['z_in'], g[:, I:], _gbuf(P['gru.bias_ih_l0']), prec)
         gemm(dgi.view(T * B, 3 * H), toks.view(T * B, I), g[:, :I], ta=True, tb=True, acc=True, prec=prec)
         G['gru.weight_ih_l0'] = g
         dz_in = gemm(dzg, w_ih[:, I:], tb=True, prec=prec)
@@ -2501,12 +2501,8 @@ class ChordDecoderTFFn(torch.autograd.Function):
         w_zh, w_zi = P['z2dec_hid.weight'], P['z2dec_in.weight']
         dz = gemm(dh0, w_zh, tb=True, prec=prec)
         gemm(dz_in, w_zi, dz, tb=True, acc=True, prec=prec)
-        G['z2dec_hid.weight'] = gemm(dh0, z, _gbuf(w_zh), ta=True, tb=True, acc=True, prec=prec)
-        G['z2dec_hid.bias'] = _bgrad(P['z2dec_hid.bias'], dh0)
-        G['z2dec_in.weight'] = gemm(dz_in, z, _gbuf(w_zi), ta=True, tb=True, acc=True, prec=prec)
-        G['z2dec_in.bias'] = _bgrad(P['z2dec_in.bias'], dz_in)
-        # (the chain to dz first and every parameter gradient afterwards -- in line or on a bulk stream -- measured 8.53 / 8.88 against 8.30 ms
-        # per step: the interleaved program order stays)
+        G['z2dec_hid.weight'], G['z2dec_hid.bias'] = wgrad_bias(dh0, z, _gbuf(w_zh), _gbuf(P['z2dec_hid.bias']), prec)
+        G['z2dec_in.weight'], G['z2dec_in.bias'] = wgrad_bias(dz_in, z, _gbuf(w_zi), _gbuf(P['z2dec_in.bias']), prec)
         mark('chd_dec_bwd:end')
         return (dz, None, None) + tuple(G[n] for n in CHD_PARAM_NAMES)
 

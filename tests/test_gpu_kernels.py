@@ -671,6 +671,47 @@ def test_wgrad_two_source_product_equals_the_two_products(M1, M2, N, K, bdt, pad
             assert (Ca - Cb).abs().max() < 2e-5 * max(1.0, want.abs().max().item()) and (ba - bb).abs().max() < 1e-3
 
 
+def test_wgrad_batch_equals_the_single_calls_bit_for_bit():
+    """ptv_wgrad_batch: several products behind ONE product launch and ONE reduction launch.  Every job keeps the slab plan and the
+    reduction order of its own ptv_wgrad call, so outputs and fused bias sums are bit-identical to the calls made one by one: mixed operand
+    dtypes, a guarded (unaligned) product, a single-slab product, one with a k_top limit, accumulate on and off; and vs float64."""
+    from polyphonic_chord_texture_disentanglement_amd._lib import call, ptr, stream_ptr, wgrad_batch
+    dev = _dev()
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    # (M, N, K, A bf16, B bf16, pad, bias, k_top, accumulate)
+    specs = [(1024, 512, 8192, 1, 1, 0, True, False, 1), (512, 512, 8192, 1, 1, 0, True, True, 1), (1536, 1024, 2048, 0, 1, 0, True, False, 1),
+             (130, 512, 2000, 0, 1, 6, False, False, 0), (64, 130, 999, 0, 0, 6, True, False, 1), (12, 512, 512, 0, 0, 0, True, False, 1),
+             (3072, 256, 512, 0, 0, 0, True, False, 1), (384, 128, 16384, 1, 0, 0, True, True, 1), (256, 64, 96, 1, 1, 0, False, False, 1)]
+    jobs, singles, wants = [], [], []
+    unit = 32
+    for M, N, K, abf, bbf, pad, bias, kt, acc in specs:
+        A = torch.randn(K, M + pad, generator=g); B = torch.randn(K, N + pad, generator=g)
+        top = (K // unit) // 2 - 1
+        if kt:
+            A[(top + 1) * unit:] = 0
+        Ad = (A.to(bf) if abf else A).to(dev)[:, :M]; Bd = (B.to(bf) if bbf else B).to(dev)[:, :N]
+        C0 = torch.randn(M, N, generator=g).to(dev); b0 = torch.randn(M, generator=g).to(dev)
+        ktop = torch.tensor([top], device=dev, dtype=torch.int32) if kt else None
+        Ca, ba, Cb, bb = C0.clone(), b0.clone(), C0.clone(), b0.clone()
+        jobs.append(dict(M=M, N=N, K=K, A=Ad, B=Bd, C=Ca, alpha=0.5, accumulate=acc, colsum_a=ba if bias else None, k_top=ktop,
+                         k_unit=unit if kt else 0))
+        singles.append((M, N, K, Ad, Bd, Cb, acc, abf | (bbf << 1), bb if bias else None, ktop, unit if kt else 0))
+        want = (C0.cpu().double() if acc else 0) + 0.5 * (A[:, :M].to(bf).double().t() @ B[:, :N].to(bf).double())
+        wants.append((Ca, ba, Cb, bb, want, b0.cpu().double() + A[:, :M].to(bf).double().sum(0), bias))
+    wgrad_batch(jobs)                                             # 9 jobs: two tables (8 + 1)
+    for M, N, K, Ad, Bd, Cb, acc, dt, bb, ktop, ku in singles:
+        call('ptv_wgrad', M, N, K, ptr(Ad), Ad.stride(0), ptr(Bd), Bd.stride(0), ptr(Cb), Cb.stride(0), 0.5, acc, dt, 0, ptr(bb), ptr(ktop), ku, 0,
+             stream_ptr())
+    torch.cuda.synchronize()
+    for i, (Ca, ba, Cb, bb, want, want_b, bias) in enumerate(wants):
+        assert torch.equal(Ca, Cb), (i, (Ca - Cb).abs().max())
+        assert torch.equal(ba, bb), i
+        assert (Ca.cpu().double() - want).abs().max() < 2e-5 * max(1.0, want.abs().max().item()), i
+        if bias:
+            assert (ba.cpu().double() - want_b).abs().max() < 2e-5 * max(1.0, want_b.abs().max().item()), i
+
+
 @pytest.mark.parametrize('M,N,K,dt,pad', [(384, 128, 4096, 3, 0), (130, 512, 2000, 2, 6), (1536, 128, 1056, 1, 0), (64, 130, 999, 0, 6),
                                           (128, 135, 640, 0, 1), (3072, 36, 512, 1, 4), (12, 512, 4100, 0, 0), (256, 1000, 8192, 3, 0)])
 def test_wgrad_kernel_vs_fp64_product_and_column_sums(M, N, K, dt, pad):
