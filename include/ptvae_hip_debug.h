@@ -34,6 +34,10 @@ int ptv_prof_read(long* count, double* total_ms, double* flops);
  * (lim15) and over the note-summary GRU's 16 note positions (lim16) -- what bench.py scales by the batch's live fraction */
 int ptv_prof_read_limited(int tag, double* lim15, double* lim16);
 
+/* A/B aid: 0 = ptv_wgrad_batch issues its products one by one (same bits, one product + one reduction launch each); 1 (default) = batched.
+ * Process-wide; PTV_WGRAD_BATCH=0 sets it at load. */
+int ptv_wgrad_batch_mode(int batched);
+
 #ifdef __cplusplus
 }
 #endif

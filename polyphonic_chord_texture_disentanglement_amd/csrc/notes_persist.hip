@@ -145,7 +145,7 @@ __device__ __forceinline__ void row_gru_fwd_body(const RowGruFwdArgs& a, const l
   static_assert(NE == 128, "token staging: 16 chunks per row, 4 rows per thread");
   // EMB with lengths: a (panel, time) pair beyond the longest row of the panel is the identity for all 64 rows (the reference packs
   // the sequences, ptvae.py:446-453: on this data the mean length is 3.7 of 16 notes) -- such steps only pass the state on
-  int pmax = a.T;
+  int pmax = a.T, gmax = a.T;
   if constexpr (EMB) {
     if (a.lengths && a.skip) {
       int* misc = reinterpret_cast<int*>(tok16 + NRP * NT16LD);
@@ -154,6 +154,20 @@ __device__ __forceinline__ void row_gru_fwd_body(const RowGruFwdArgs& a, const l
       if (tid < NRP && r0 + tid < R) atomicMax(misc, a.lengths[a.perm ? (long)a.perm[r0 + tid] : r0 + tid]);
       __syncthreads();
       pmax = min(misc[0], a.T);
+      // ... and a time index beyond the longest row of the WHOLE launch is dead for every panel: nothing downstream reads its state slots
+      // (the BPTT stops at its own panel limit; the weight-gradient products and the dX product stop at the launch-wide limit the BPTT
+      // reports, top_step = gmax - 1, which exists when R % 32 == 0).  Every workgroup finds gmax itself: R ints from L2, ~1 us --
+      // the per-step copies it saves were a quarter of this launch's HBM traffic (round 6; PMC in profiles/r06_pmc_by_kernel.json)
+      if ((R & 31) == 0) {
+        int g = 0;
+        for (long i = tid; i < R; i += 256) g = max(g, a.lengths[i]);
+        if (tid == 0) misc[0] = 0;
+        __syncthreads();
+        atomicMax(misc, g);
+        __syncthreads();
+        gmax = min(misc[0], a.T);
+        __syncthreads();
+      }
     }
   }
   int slot = 0, cur = 0;                                                   // HN slot holding the current fp32 state; current bf16 LDS buffer
@@ -166,6 +180,24 @@ __device__ __forceinline__ void row_gru_fwd_body(const RowGruFwdArgs& a, const l
   for (int n = 0; n < a.T; n++) {
     const int tt = (EMB && a.reverse) ? a.T - 1 - n : n;
     if constexpr (EMB) {
+      if (tt >= gmax) continue;                                            // dead for every row of the launch: the state stays in `slot`, nobody reads slot n + 1
+      if (slot != n) {
+        // the first step after a launch-wide dead PREFIX (the reversed direction): the state before this step is read as slot n by the
+        // BPTT and by the weight_hh gradient product (whose k_rev limit starts exactly here) -- materialise it once instead of once per dead step
+        __syncthreads();
+        for (int i = tid; i < NRP * (H / 8); i += 256) {
+          const int row = i / (H / 8), c8 = (i % (H / 8)) * 8;
+          if (r0 + row < R) {
+            const long gr = r0 + row;
+            *reinterpret_cast<bf16x8*>(a.HN16 + (long)n * RH + gr * H + c8) = *reinterpret_cast<const bf16x8*>(h16 + cur * NRP * HLD + row * HLD + c8);
+            float v[8];
+            ld_f32x8(a.HN + (long)slot * RH + gr * H + c8, v);
+            st_f32x8(a.HN + (long)n * RH + gr * H + c8, v);
+          }
+        }
+        __syncthreads();
+        slot = n;
+      }
       if (tt >= pmax) {                                                    // whole panel masked: h' = h
         __syncthreads();                                                   // the previous step's state stores (other lanes' mapping) are complete
         for (int i = tid; i < NRP * (H / 8); i += 256) {
@@ -407,7 +439,7 @@ __device__ __forceinline__ void row_gru_bwd_body(const RowGruBwdArgs& a, const l
     gnat[i] = grow[i];
     if constexpr (EMB) { if (a.perm) gnat[i] = a.perm[grow[i]]; }
   }
-  int pmax = a.T;
+  int pmax = a.T, gmax = a.T;
   if constexpr (EMB) {
     if (a.lengths) {                                                     // given iff the forward skipped: must match it
       // (the scratch word is the first word of dhz, zeroed afterwards: the kernel's LDS is exactly 64*H*4 bytes -- at H = 128 two of
@@ -421,6 +453,18 @@ __device__ __forceinline__ void row_gru_bwd_body(const RowGruBwdArgs& a, const l
       pmax = min(misc[0], a.T);
       if (a.top_step && tid == 0 && pmax > 0) atomicMax(a.top_step, pmax - 1);   // last TIME index with a live row in any panel
       __syncthreads();
+      // the launch-wide limit the consumers of dgi / dgh will be given (top_step = gmax - 1 once every panel has reported): the zero rows
+      // of time indices at or beyond gmax are never read -- not written (200 of this launch's 570 MB of stores, round 6)
+      if (a.top_step && (R & 31) == 0) {
+        int g = 0;
+        for (long i = tid; i < R; i += 256) g = max(g, a.lengths[i]);
+        if (tid == 0) misc[0] = 0;
+        __syncthreads();
+        atomicMax(misc, g);
+        __syncthreads();
+        gmax = min(misc[0], a.T);
+        __syncthreads();
+      }
     }
   }
   for (int i = tid; i < NRP * H; i += 256) dhz[i] = 0.f;
@@ -459,6 +503,7 @@ __device__ __forceinline__ void row_gru_bwd_body(const RowGruBwdArgs& a, const l
   for (int s = s_top; s >= (a.dh0 ? -1 : 0); s--) {
     const int tt = s < 0 ? 0 : ((EMB && a.reverse) ? a.T - 1 - s : s);
     if constexpr (EMB) {
+      if (s >= 0 && tt >= gmax) continue;                                  // beyond the launch-wide limit: rows nobody reads
       if (s >= 0 && tt >= pmax) {                                          // the forward passed the state through: zero gate gradients
         for (int i = tid; i < NRP * (3 * H / 8); i += 256) {
           const int row = i / (3 * H / 8), c8 = (i % (3 * H / 8)) * 8;

@@ -605,6 +605,11 @@ namespace ptv {
 // 1 (default): slab partials through a workspace + ordered reduction (bit-reproducible, and no fp32 atomics: they retire at
 // ~1e11 elements/s, a fifth of the time of the deep products); 0: atomics into C
 static int g_wgrad_dma = [] { const char* e = getenv("PTV_WGRAD_DMA"); return e ? atoi(e) : 0; }();
+// how ptv_wgrad_batch issues its products (ptv_wgrad_batch_mode / PTV_WGRAD_BATCH; same bits in every mode).  Measured in the B = 512 step,
+// same process, alternating (profiles/r06_ab_runs.txt): 0 = one call each 6.98-7.01 ms, 1 = ONE launch for everything 7.26-7.33 (the mixed
+// launch runs every product at the register budget of its fp32-source variant and five operand streams thrash each XCD's L2), 2 = single
+// product launches + one reduction launch 6.98-7.09, 3 = small products batched, deep ones alone, one reduction launch 6.93-7.03: the default
+static int g_wgrad_batch = [] { const char* e = getenv("PTV_WGRAD_BATCH"); return e ? atoi(e) : 3; }();
 static int g_wgrad_mode = [] { const char* e = getenv("PTV_WGRAD_ORDERED"); return (e && e[0] == '0') ? 0 : 1; }();
 
 // grow-only workspace per stream: launches on one stream are ordered, so the next product's partials cannot overtake this one's
@@ -635,6 +640,7 @@ static WsBuf* ws_for(hipStream_t s, size_t bytes) {
 }  // namespace ptv
 
 namespace ptv { extern int g_splitk_ordered; }
+extern "C" int ptv_wgrad_batch_mode(int mode) { if (mode < 0 || mode > 3) return PTV_ERR_ARG; ptv::g_wgrad_batch = mode; return PTV_OK; }
 extern "C" int ptv_wgrad_dma(int enable) { ptv::g_wgrad_dma = enable ? 1 : 0; return PTV_OK; }
 extern "C" int ptv_wgrad_mode(int ordered) { ptv::g_wgrad_mode = ptv::g_splitk_ordered = ordered ? 1 : 0; return PTV_OK; }
 
@@ -725,6 +731,10 @@ int reduce_blocks(const Job& j) {
 // the products of `jobs` (disjoint outputs), as one product launch + one reduction launch when there are several
 int wgrad_run(const Job* jobs, int njobs, hipStream_t s) {
   if (njobs <= 0) return PTV_OK;
+  if (!g_wgrad_batch && njobs > 1) {
+    for (int i = 0; i < njobs; i++) PTV_TRY(wgrad_run(jobs + i, 1, s));
+    return PTV_OK;
+  }
   if (njobs > WG_MAX_JOBS) {                                       // more than a table holds: in chunks
     for (int i = 0; i < njobs; i += WG_MAX_JOBS) PTV_TRY(wgrad_run(jobs + i, njobs - i < WG_MAX_JOBS ? njobs - i : WG_MAX_JOBS, s));
     return PTV_OK;
@@ -777,8 +787,13 @@ int wgrad_run(const Job* jobs, int njobs, hipStream_t s) {
     }
     if (!wsp[i] && !live[i].accumulate) zero_c(live[i], s);          // (atomics / single slab: the product adds into C)
   }
-  if (n == 1) {
-    const Plan& p = plan[0];
+  // how a call with several products runs (g_wgrad_batch; same bits in every mode):
+  //   1  ONE product launch for all of them (wgrad_batch_kernel) + ONE reduction launch
+  //   2  one product launch each (the kernel specialised for its operand dtypes), ONE reduction launch for all
+  //   3  the small products (<= SMALL_BLOCKS blocks) in one launch, the others one launch each, ONE reduction launch
+  // (0: every product its own call -- handled above)
+  constexpr int SMALL_BLOCKS = 160;
+  auto launch_single = [&](const Plan& p) {
     for (int k = 0; k < 2; k++) if (p.has[k]) {
       const WgArgs& g = p.part[k];
       const dim3 grid((unsigned)(p.tiles * p.nslab[k]));
@@ -798,6 +813,10 @@ int wgrad_run(const Job* jobs, int njobs, hipStream_t s) {
       else WG_LAUNCH(false, false);
 #undef WG_LAUNCH
     }
+  };
+  if (n == 1) {
+    const Plan& p = plan[0];
+    launch_single(p);
     if (wsp[0]) {
       // (the guarded launch alone -- unaligned operands -- may have many slabs: it then plays the fast launch's part in the reduction)
       const int nb = reduce_blocks(live[0]);
@@ -805,36 +824,46 @@ int wgrad_run(const Job* jobs, int njobs, hipStream_t s) {
       else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, s, p.part[0], p.part[1], 1, p.has[1] ? 1 : 0, live[0].accumulate);
     }
   } else {
-    // ---- one product launch: the entries in order of decreasing work (the long blocks start first), every entry's first block a
+    // ---- product launches.  Batched entries go in order of decreasing work (the long blocks start first), every entry's first block a
     // multiple of 8 so that the block -> XCD relation the slab / tile maps count on (block b runs on XCD b % 8) holds inside the entry
-    WgBatch bt; bt.n = 0;
-    int order[2 * WG_MAX_JOBS]; double work[2 * WG_MAX_JOBS]; int ne = 0;
-    for (int i = 0; i < n; i++) for (int k = 0; k < 2; k++) if (plan[i].has[k]) {
-      order[ne] = i * 2 + k; work[ne] = (double)plan[i].part[k].kper * (k ? 4.0 : 1.0); ne++;       // (a block's time ~ its slab depth; guarded rows cost more)
+    bool batched[WG_MAX_JOBS]; int nbat = 0;
+    for (int i = 0; i < n; i++) {
+      const int blocks = plan[i].tiles * (plan[i].nslab[0] + plan[i].nslab[1]);
+      batched[i] = g_wgrad_batch == 1 || (g_wgrad_batch == 3 && blocks <= SMALL_BLOCKS);
+      nbat += batched[i] ? 1 : 0;
     }
-    for (int a = 1; a < ne; a++) {                                   // insertion sort by work, stable
-      const int o = order[a]; const double w = work[a]; int b = a - 1;
-      while (b >= 0 && work[b] < w) { order[b + 1] = order[b]; work[b + 1] = work[b]; b--; }
-      order[b + 1] = o; work[b + 1] = w;
+    if (nbat == 1) { for (int i = 0; i < n; i++) batched[i] = false; nbat = 0; }
+    for (int i = 0; i < n; i++) if (!batched[i]) launch_single(plan[i]);
+    if (nbat) {
+      WgBatch bt; bt.n = 0;
+      int order[2 * WG_MAX_JOBS]; double work[2 * WG_MAX_JOBS]; int ne = 0;
+      for (int i = 0; i < n; i++) for (int k = 0; k < 2; k++) if (batched[i] && plan[i].has[k]) {
+        order[ne] = i * 2 + k; work[ne] = (double)plan[i].part[k].kper * (k ? 4.0 : 1.0); ne++;       // (a block's time ~ its slab depth; guarded rows cost more)
+      }
+      for (int a = 1; a < ne; a++) {                                   // insertion sort by work, stable
+        const int o = order[a]; const double w = work[a]; int b = a - 1;
+        while (b >= 0 && work[b] < w) { order[b + 1] = order[b]; work[b + 1] = work[b]; b--; }
+        order[b + 1] = o; work[b + 1] = w;
+      }
+      bool any_f32 = false, any_guard = false;
+      int nblk = 0;
+      for (int a = 0; a < ne; a++) {
+        const int i = order[a] >> 1, k = order[a] & 1;
+        const Plan& p = plan[i];
+        bt.g[a] = p.part[k];
+        bt.kind[a] = (unsigned char)((p.af ? 1 : 0) | (p.bf ? 2 : 0) | (k ? 4 : 0));
+        any_f32 |= p.af || p.bf; any_guard |= k == 1;
+        bt.first[a] = nblk;
+        nblk += (p.tiles * p.nslab[k] + 7) / 8 * 8;                  // (surplus blocks find their slab beyond K and return)
+      }
+      bt.first[ne] = nblk; bt.n = ne;
+      for (int a = ne + 1; a <= WG_MAX_ENT; a++) bt.first[a] = nblk;
+      const dim3 grid((unsigned)nblk);
+      if (any_f32 && any_guard) hipLaunchKernelGGL((wgrad_batch_kernel<true, true>), grid, dim3(256), 0, s, bt);
+      else if (any_f32) hipLaunchKernelGGL((wgrad_batch_kernel<true, false>), grid, dim3(256), 0, s, bt);
+      else if (any_guard) hipLaunchKernelGGL((wgrad_batch_kernel<false, true>), grid, dim3(256), 0, s, bt);
+      else hipLaunchKernelGGL((wgrad_batch_kernel<false, false>), grid, dim3(256), 0, s, bt);
     }
-    bool any_f32 = false, any_guard = false;
-    int nblk = 0;
-    for (int a = 0; a < ne; a++) {
-      const int i = order[a] >> 1, k = order[a] & 1;
-      const Plan& p = plan[i];
-      bt.g[a] = p.part[k];
-      bt.kind[a] = (unsigned char)((p.af ? 1 : 0) | (p.bf ? 2 : 0) | (k ? 4 : 0));
-      any_f32 |= p.af || p.bf; any_guard |= k == 1;
-      bt.first[a] = nblk;
-      nblk += (p.tiles * p.nslab[k] + 7) / 8 * 8;                  // (surplus blocks find their slab beyond K and return)
-    }
-    bt.first[ne] = nblk; bt.n = ne;
-    for (int a = ne + 1; a <= WG_MAX_ENT; a++) bt.first[a] = nblk;
-    const dim3 grid((unsigned)nblk);
-    if (any_f32 && any_guard) hipLaunchKernelGGL((wgrad_batch_kernel<true, true>), grid, dim3(256), 0, s, bt);
-    else if (any_f32) hipLaunchKernelGGL((wgrad_batch_kernel<true, false>), grid, dim3(256), 0, s, bt);
-    else if (any_guard) hipLaunchKernelGGL((wgrad_batch_kernel<false, true>), grid, dim3(256), 0, s, bt);
-    else hipLaunchKernelGGL((wgrad_batch_kernel<false, false>), grid, dim3(256), 0, s, bt);
     // ---- one reduction launch for the products that went through the workspace
     WgRedBatch rb; rb.n = 0; int rblk = 0;
     for (int i = 0; i < n; i++) if (wsp[i]) {

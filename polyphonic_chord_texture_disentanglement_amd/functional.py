@@ -706,6 +706,14 @@ def _bgrad(b, a):
 
 
 WGRAD_FUSE_BIAS = True
+WGRAD_BATCH = 3            # ptv_wgrad_batch_mode (scripts/ab_step.py): 0 = products one by one, 1 = one launch, 2 = single launches + one reduction, 3 = small ones batched
+
+
+def _apply_switches():
+    """hand module-level switches that live in the library to it (scripts/ab_step.py calls this after every setattr)"""
+    lib().ptv_wgrad_batch_mode(int(WGRAD_BATCH))
+
+
 EMBED_MH_FWD = True    # multi-hot operand of the note_embedding gradient built during the forward
 # decoder backward: fork the weight-gradient work BEFORE the chain queues its next dX products (no false dependency on them)?  Measured
 # 9.43 vs 9.37 ms: the products then compete with the chain's own dX products for the CUs -- the later fork is the better schedule

@@ -51,10 +51,16 @@ def main():
         opt.clip_and_step(1.0)
         return o
 
+    for i in range(4):                                         # warm-up, then no full garbage collection inside a timed round (optim.freeze_gc)
+        step(i)
+    from polyphonic_chord_texture_disentanglement_amd.optim import freeze_gc
+    freeze_gc()
     res = {v: [] for v in vals}
     for r in range(a.rounds):
         for v in vals:
             setattr(mod, name, v)
+            if hasattr(mod, '_apply_switches'):
+                mod._apply_switches()
             for i in range(3):
                 o = step(i)
             torch.cuda.synchronize()

@@ -21,6 +21,11 @@ with open(out, 'w') as f:
     f.write('# %s\n\nCommand: `%s`\n\n' % (title, cmd))
     f.write('%d train steps in the trace.  Total kernel time %.1f ms over %d dispatches = **%.2f ms/step**, '
             '%d launches/step.\n\n' % (steps, T / 1e6, len(rows), T / 1e6 / steps, len(rows) // steps))
+    fam = lambda pred: (sum(t for n, t in tot.items() if pred(n)) / 1e6 / steps, sum(c for n, c in cnt.items() if pred(n)) / steps)
+    wg, wgn = fam(lambda n: 'wgrad_' in n)
+    cs, csn = fam(lambda n: 'colsum_kernel' in n)
+    f.write('Weight-gradient family (`wgrad_kernel*` + `wgrad_batch_kernel*` + `wgrad_reduce*`): **%.3f ms/step**, %.1f launches/step; '
+            '`colsum_kernel*`: %.3f ms/step, %.1f launches/step.\n\n' % (wg, wgn, cs, csn))
     f.write('| kernel | calls | ms/step | avg us | % | vgpr | agpr | lds |\n|---|---|---|---|---|---|---|---|\n')
     for n, t in sorted(tot.items(), key=lambda x: -x[1])[:32]:
         v, a, l = meta[n]

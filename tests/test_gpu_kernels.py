@@ -581,7 +581,7 @@ def test_rows_by_length_is_a_stable_descending_sort(R, maxlen):
 
 
 @pytest.mark.parametrize('sort_rows', [True, False])
-@pytest.mark.parametrize('M,T,maxlen', [(4096, 16, 16), (4100, 5, 5), (4200, 16, 6), (4096, 16, 0)])
+@pytest.mark.parametrize('M,T,maxlen', [(4096, 16, 16), (4100, 5, 5), (4200, 16, 6), (4096, 16, 0), (8192, 16, -7), (4096, 16, -1)])
 def test_row_gru_h128_bidirectional_with_lengths_vs_step_kernels_and_oracle(M, T, maxlen, sort_rows, monkeypatch):
     """dec_notes_emb_gru through the H = 128 instance of csrc/notes_persist.hip (lengths mask, reversed direction, final state into
     its half of the summary, gradient arriving at the final state only) against the per-step path on the same operands and the
@@ -602,13 +602,26 @@ def test_row_gru_h128_bidirectional_with_lengths_vs_step_kernels_and_oracle(M, T
     x = torch.randn(T, M, I, generator=g) * 0.7
     # maxlen < T: whole 64-row panels have nothing to do at the late note positions (the kernels pass over those steps); one panel
     # keeps a full-length row, one row is empty
+    # maxlen < 0: NO row longer than -maxlen (M a multiple of 32): the time indices beyond the longest row of the whole launch are dead
+    # for every panel -- the kernels neither copy states nor write zero gradients there (round 6), so every buffer of the persistent run
+    # is handed out NaN-filled: whatever read an unwritten slot would poison the results
+    full_row = maxlen > 0
+    maxlen = abs(maxlen)
     lengths = torch.randint(0, maxlen + 1, (M,), generator=g, dtype=torch.int32)
-    if maxlen > 0:
+    if full_row:
         lengths[:3] = torch.tensor([0, T, 1], dtype=torch.int32)
+    elif maxlen > 0:
+        lengths[:3] = torch.tensor([0, maxlen, 1], dtype=torch.int32)
     dout = torch.randn(M, 2 * H, generator=g) * 0.3
+    plain_empty = F_._empty
+
+    def nan_empty(*shape, dev, dtype=torch.float32):
+        t = plain_empty(*shape, dev=dev, dtype=dtype)
+        return t.fill_(float('nan')) if t.dtype.is_floating_point else t
 
     def run(persist):
         monkeypatch.setattr(F_, 'NOTES_PERSIST', persist)
+        monkeypatch.setattr(F_, '_empty', nan_empty if persist else plain_empty)
         w = [cpu_w[n].to(dev).requires_grad_() for n in order]
         xd = x.to(dev).requires_grad_()
         assert F_.row_gru_ok(1, H, I, M, torch.bfloat16) == persist
