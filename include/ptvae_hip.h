@@ -359,7 +359,8 @@ int ptv_dur_bwd_finalize(const float* S, float* g_whh, float* g_bhh, float* g_bi
  *   bwd: dp [M][ldp] += dhd0 . W_dh[:, 512:] (in place);  dnsum [M][512] bf16 = dp . W_p + dhd0 . W_dh[:, :512], row-major or
  *        (blocked != 0) column-blocked by 32 ([16][M][32], what ptv_notes_gru_persist_bwd reads).  wdpT: pack of W_dh[:, 512:]^T
  *        [130,64];  wcat: PAIR-interleaved pack of the [512][224] matrix [W_p^T (130 columns, zero-padded to 160) | W_dh[:, :512]^T].
- *        Rows from (*m_top + 1) * m_unit on (device int, or NULL) are known to be zero: their dnsum is written as zeros.
+ *        Rows from (*m_top + 1) * m_unit on (device int, or NULL) are known to be zero: their dnsum is written as zeros -- or, with bit 1 of
+ *        `blocked` set (blocked = 3), left unwritten: the consumer is ptv_notes_gru_persist_bwd_top with the same limit as its bound.
  *        dy16 (or NULL): [M][200] bf16 = [dp (130) | 0 (6) | dhd0 (64)] of the live rows -- ONE ptv_wgrad operand for the weight gradients
  *        of both Linears over the note summaries (one pass over the [M][512] summaries instead of two).
  */
@@ -741,6 +742,12 @@ int ptv_notes_gru_persist_fwd_top(const void* wg_h, const void* wg_t, const floa
 long ptv_notes_gru_persist_scratch_elems(long R);
 int ptv_notes_gru_persist_bwd(const void* wt, const void* HN16, const void* gates, const void* ext, void* dgi, void* dgh,
                               float* dh0, void* scratch, long R, int T, int* top_step, void* stream);
+/* the same with a caller-given bound (device int, or NULL = the call above): no gradient arrives after note step *bound -- the forward
+ * stopped there (ptv_notes_gru_persist_fwd_top) or the loss says so -- and every consumer of dgi / dgh stops at top_step (<= *bound,
+ * required non-NULL then).  The note steps beyond the bound are not touched: neither is `ext` read there (it may be unwritten) nor are
+ * zero rows of dgi / dgh written (without the bound: 64 KB read and 256 KB of zeros written per 64-row panel and dead step). */
+int ptv_notes_gru_persist_bwd_top(const void* wt, const void* HN16, const void* gates, const void* ext, void* dgi, void* dgh,
+                                  float* dh0, void* scratch, long R, int T, const int* bound, int* top_step, void* stream);
 /* which kernel ptv_notes_gru_persist_bwd runs: 1 (default) = 8 waves per workgroup, the A operand LDS-resident, the carry dh (x) z in registers
  * (csrc/notes_roles.hip), 0 = the 4-wave kernel of rounds 2-4 (csrc/notes_persist.hip); same arguments, same results to rounding.
  * Process-wide. */

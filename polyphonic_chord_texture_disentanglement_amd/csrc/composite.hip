@@ -297,7 +297,8 @@ extern "C" int ptv_decoder_tf_bwd(const void* const* t, const long* d, void* str
   float* dP = GB(PTV_DTB_DP);
   void* dNSUM = M_<void>(t, PTV_DTB_DNSUM); void* dY16 = M_<void>(t, PTV_DTB_DY16);
   ptv_gemm_priority(1);
-  PTV_TRY(ptv_heads_bwd(dP, ldp, dHD0, T_(t, PTV_DTB_PK_WDPT), T_(t, PTV_DTB_PK_WCAT), dNSUM, 1, dY16, top_h, top_unit, M, stream));
+  // (blocked = 3 with a limit: dNSUM's dead rows stay unwritten -- the BPTT below gets the same limit as its bound and never reads them)
+  PTV_TRY(ptv_heads_bwd(dP, ldp, dHD0, T_(t, PTV_DTB_PK_WDPT), T_(t, PTV_DTB_PK_WCAT), dNSUM, top_h ? 3 : 1, dY16, top_h, top_unit, M, stream));
   PTV_TRY(fork(1));
   ptv_gemm_priority(0);
   {
@@ -320,8 +321,8 @@ extern "C" int ptv_decoder_tf_bwd(const void* const* t, const long* d, void* str
   float* dGC = GB(PTV_DTB_DGC); float* dNS = GB(PTV_DTB_DNS); float* dtok = GB(PTV_DTB_DTOK);
   const __bf16* wt_ih_n = (const __bf16*)T_(t, PTV_DTB_WT_IH_N);   // [Ht + E, 3Hn]
   ptv_gemm_priority(1);
-  PTV_TRY(ptv_notes_gru_persist_bwd(T_(t, PTV_DTB_PK_NOTES_WT), T_(t, PTV_DTB_HN16), T_(t, PTV_DTB_GATES_N), dNSUM, dgi_n, dgh_n, dHN0,
-                                    M_<void>(t, PTV_DTB_SCRATCH_N), R, 15, top_step, stream));
+  PTV_TRY(ptv_notes_gru_persist_bwd_top(T_(t, PTV_DTB_PK_NOTES_WT), T_(t, PTV_DTB_HN16), T_(t, PTV_DTB_GATES_N), dNSUM, dgi_n, dgh_n, dHN0,
+                                        M_<void>(t, PTV_DTB_SCRATCH_N), R, 15, top_h, top_step, stream));
   PTV_TRY(ptv_sum_steps_top(dGC, dgi_n, (long)R * 3 * Hn, 15, (long)R * 3 * Hn, 0, 1, top_step, stream));
   if (hipMemsetAsync(dtok + 15L * R * E, 0, sizeof(float) * R * E, s) != hipSuccess) return PTV_ERR_LAUNCH;
   PTV_TRY(ptv_gemm_mtop(P, 0, 0, (int)M, E, 3 * Hn, dgi_n, 3L * Hn, wt_ih_n + (long)Ht * 3 * Hn, 3L * Hn, dtok, E, nullptr, 1.f, 0, 0, 0, A16 | B16,

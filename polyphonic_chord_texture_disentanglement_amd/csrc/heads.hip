@@ -188,9 +188,10 @@ __global__ __launch_bounds__(256, 1) void heads_bwd_kernel(HeadsBwdArgs a) {
   long live = a.M;
   if (a.m_top) live = min(a.M, ((long)*a.m_top + 1) * a.m_unit);
   if (rb >= live) {                                                       // nothing arrived at these rows: dNSUM = 0, dP stays (zero)
+    if (a.blocked & 2) return;                                            // ... and the consumer knows the limit too: the rows stay unwritten
     const bf16x8 z = bf16x8{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
     for (int i = tid; i < 128 * (HHN / 8); i += 256) {
-      if (a.blocked) {
+      if (a.blocked & 1) {
         const int blk = i / (128 * 4), r = (i / 4) % 128, q = i % 4;
         if (rb + r < a.M) *reinterpret_cast<bf16x8*>(a.dnsum + ((long)blk * a.M + rb + r) * 32 + q * 8) = z;
       } else {
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void heads_bwd_kernel(HeadsBwdArgs a) {
           const f32x4 lo = acc[i][j], hi = acc[i][j + 1];
           const bf16x8 o = bf16x8{(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3], (__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
           const int ub = g * 4 + (j >> 1);                                 // 32-unit block
-          if (a.blocked) *reinterpret_cast<bf16x8*>(a.dnsum + ((long)ub * a.M + gr) * 32 + kq * 8) = o;
+          if (a.blocked & 1) *reinterpret_cast<bf16x8*>(a.dnsum + ((long)ub * a.M + gr) * 32 + kq * 8) = o;
           else *reinterpret_cast<bf16x8*>(a.dnsum + gr * HHN + ub * 32 + kq * 8) = o;
         }
       }

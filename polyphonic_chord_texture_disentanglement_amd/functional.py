@@ -2026,6 +2026,8 @@ def _decoder_bwd_composite(P, st, z, tok_op, dP, ddur, top_h, side, G):
             'XCH': torch.empty(32 * B * 3 * Ht, device=dev, dtype=BF16),
             'PART_T': torch.empty(lib().ptv_gru_persist_part_elems(1, B, Ht, S), device=dev) if S else None,
             'SYNC': _persist_sync(1, dev)}
+    if POISON_DEAD_STEPS and top_h is not None and st.get('live_top') is not None:        # (tests: whatever reads a dead row of these gets NaN -- heads_bwd / the BPTT leave them unwritten)
+        _poison(tens['DNSUM'], tens['DGI_N'], tens['DGH_N'], tens['DY16'])
     if st['pitch'].stride(0) != _pad8(NP) or st['idx'].dtype != torch.int32:
         return None
     slots = [None] * T_['PTV_DTB_COUNT']
@@ -2175,6 +2177,8 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
     w_dh, w_p = W['dur_hid_linear.weight'], W['pitch_out_linear.weight']
     # gradient reaching the notes-GRU states: only ever an addend of the BPTT epilogue -> activation dtype
     dNSUM = _empty(M, Hn, dev=dev, dtype=_act_dtype(prec, Hn))
+    if POISON_DEAD_STEPS and top_h is not None and st.get('live_top') is not None:
+        _poison(dNSUM)
     # (read by the row-partitioned BPTT kernel column-blocked by 32, like its saved gates: whole-kilobyte wave accesses)
     rowk_bwd = bool(st.get('gates_n_rowk') and notes_persist_ok(prec, Hn, E, st['gates_n'].dtype) and dNSUM.dtype == BF16 and HN.dtype == F32)
     fused_heads = (heads_ok(prec, Hn, NP, Hd, st.get('HN16'), st.get('HD16')) and dNSUM.dtype == BF16 and dP.stride(0) % 4 == 0
@@ -2184,8 +2188,10 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
         # dP += dHD0 . W_dh[:, Hn:] and dNSUM = dP . W_p + dHD0 . W_dh[:, :Hn] in one pass over dP / dHD0 (csrc/heads.hip)
         hp = heads_packs(P['pitch_out_linear.weight'], P['dur_hid_linear.weight'])
         dY16 = _empty(M, 200, dev=dev, dtype=BF16) if HEADS_WGRAD_FUSED else None
-        call('ptv_heads_bwd', ptr(dP), dP.stride(0), ptr(dHD0), ptr(hp['wdpT']), ptr(hp['wcat']), ptr(dNSUM), int(rowk_bwd), ptr(dY16),
-             ptr(top_h), R if top_h is not None else 0, M, stream_ptr())
+        # (with a limit and the row BPTT as the consumer -- it gets the same limit as its bound -- dNSUM's dead rows stay unwritten: bit 1)
+        bound_n = top_h if (rowk_bwd and ZERO_SKIP) else None
+        call('ptv_heads_bwd', ptr(dP), dP.stride(0), ptr(dHD0), ptr(hp['wdpT']), ptr(hp['wcat']), ptr(dNSUM),
+             int(rowk_bwd) | (2 if bound_n is not None else 0), ptr(dY16), ptr(top_h), R if top_h is not None else 0, M, stream_ptr())
     else:
         gemm_dx(dHD0, w_dh, slice(Hn, None), out=dP, acc=True, prec=prec, m_top=top_h, m_unit=R)         # dP complete
 
@@ -2226,11 +2232,13 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
         pk = notes_packs(w_ih_n, w_hh_n, Ht)
         dgi_n = _empty(15, R, 3 * Hn, dev=dev, dtype=BF16)
         dgh_n = _empty(15, R, Hn, dev=dev, dtype=BF16)          # n third only: the r / z thirds of dgh are dgi's
+        if POISON_DEAD_STEPS and top_h is not None and st.get('live_top') is not None:
+            _poison(dgi_n, dgh_n)
         dHN0 = _empty(R, Hn, dev=dev)
         scratch = _empty(lib().ptv_notes_gru_persist_scratch_elems(R), dev=dev, dtype=BF16)
         top_step = _ineg1(dev) if ZERO_SKIP else None   # <- last note step with a gradient
-        call('ptv_notes_gru_persist_bwd', ptr(pk['wt']), ptr(st['HN16']), ptr(st['gates_n']), ptr(dNSUM), ptr(dgi_n), ptr(dgh_n), ptr(dHN0),
-             ptr(scratch), R, 15, ptr(top_step), stream_ptr())
+        call('ptv_notes_gru_persist_bwd_top', ptr(pk['wt']), ptr(st['HN16']), ptr(st['gates_n']), ptr(dNSUM), ptr(dgi_n), ptr(dgh_n), ptr(dHN0),
+             ptr(scratch), R, 15, ptr(bound_n if fused_heads else None), ptr(top_step), stream_ptr())
     else:
         top_step = None
         dgi_n, dgh_n, dHN0 = gru_bwd(prec, HN, st['gates_n'], w_hh_n, dh_ext=dNSUM.view(15, R, Hn))
