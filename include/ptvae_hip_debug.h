@@ -10,7 +10,7 @@ extern "C" {
 #endif
 
 /* timing experiments: device buffer of 8 x 2048 uint64 that one workgroup of the following forward launches fills with per-wave event
- * stamps (scripts/trace_notes.py), or NULL */
+ * stamps (timing probe of round 5), or NULL */
 int ptv_debug_notes_trace(void* buf);
 
 /* test / diagnosis aid: nwg idle workgroups holding lds_bytes of LDS each for usec microseconds on `stream` (a stand-in for another

@@ -1089,7 +1089,7 @@ extern "C" int ptv_free_note_loop(const void* const* w, const void* const* io, l
   a.dbg_out = (train >> 8) & 64 ? (long*)io[17] : nullptr;
   a.B = B; a.t = t; a.R = 32 * B; a.M = 15 * 32 * B; a.coin_mask = coin_mask; a.train = (train & 3) == 1; a.tok_store = (train & 3) != 0; a.dbg = (train >> 8) & 0xff;
   // two kernels: 4 waves walking the phases one after the other, or producers / heads split over 8 waves (the state products of
-  // the next note step under the heads of the current one).  Measured (scripts/bench_freerun3.py): with few panels (B = 512: 32
+  // the next note step under the heads of the current one).  Measured (round 3, profiles/LOG.md): with few panels (B = 512: 32
   // workgroups) a note step is bound by ONE CU's L2 port either way and the heads' small dependent loads queue behind the producers'
   // deep prefetch (30.4 vs 32.0 us per note step); with many panels (B = 2048) the chip's L2 is the limit and the overlap wins
   // (47.0 -> 40.8 us).  train bit 16 / 17 force the 4-wave / 8-wave kernel.

@@ -400,7 +400,7 @@ static int launch(const Args& a, hipStream_t s) {
 using namespace ptv;
 
 static unsigned long long* g_notes_trace = nullptr;
-// timing experiments (scripts/trace_notes.py): device buffer of 8 x 2048 uint64 that workgroup 8 of the next launches fills with event stamps
+// timing experiments (round-5 probe, retired): device buffer of 8 x 2048 uint64 that workgroup 8 of the next launches fills with event stamps
 extern "C" int ptv_debug_notes_trace(void* buf) { g_notes_trace = (unsigned long long*)buf; return PTV_OK; }
 
 extern "C" int ptv_notes_gru_persist_fwd_top(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,

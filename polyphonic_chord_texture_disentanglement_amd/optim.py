@@ -363,7 +363,7 @@ class FusedClipAdam(torch.optim.Optimizer):
 
     # The host enqueues a step in 5.5 ms, the GPU runs it in 7: a loop that never synchronises runs further and further ahead, and every
     # block that crossed streams (record_stream) stays unusable until the GPU has passed it -- the allocator then grows by hipMalloc, a
-    # device-wide synchronisation (36 of them in 120 steps, one ~60-ms stall every ~40 steps: scripts/probe_stall.py).  So the host waits for
+    # device-wide synchronisation (36 of them in 120 steps, one ~60-ms stall every ~40 steps: round-5 probe, profiles/r05_allocator_stall.txt).  So the host waits for
     # the step before the previous one to finish before it enqueues the next: never a bubble (two whole steps stay queued), bounded memory.
     MAX_STEPS_IN_FLIGHT = 2
     # A FULL garbage collection walks every tracked Python object of the process (the module tree, the autograd closures, torch's own

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 # Run-to-run noise of the weight gradients: every dW ends in fp32 atomicAdd of K-slab partials (wgrad.hip, gemm.hip split-K,
-# texture.hip), so two runs of the same step differ in summation order.  Measured on MI355X with scripts/measure_atomics_noise.py
+# texture.hip), so two runs of the same step differ in summation order.  Measured on MI355X (round 3; the probe script was retired in round 6, its result is kept:
 # (profiles/r03_atomics_noise.jsonl; fp32 path, reduced B=6 and full geometry B=16, 6-8 repeats): <= 1.36e-6 of a tensor's
 # max |g| per element (worst tensor: the conv bias, 49-way atomics), 2.4e-8 relative on the global norm, <= 3.8e-6 absolute on a
 # loss.  ATOMICS_RTOL is that floor with a 7x margin; tests that compare two HIP runs of the same step (not HIP vs oracle) use it.

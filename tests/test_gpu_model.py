@@ -658,6 +658,35 @@ def test_bf16_loss_curve_tracks_fp32_over_20_steps():
     assert abs((bf[-1, 0] - bf[0, 0]) - (fp[-1, 0] - fp[0, 0])) < 1e-2
 
 
+def test_bf16_training_horizon_200_steps_tracks_fp32():
+    """round-5 review: at the benched batch the bf16 path's global gradient-norm error is 1e-3 -- does it show over a training HORIZON?
+    200 teacher-forced optimiser steps at B = 64 from the same weights, data, Philox noise and optimiser in both dtypes.  Trajectories of
+    two correct implementations separate (Adam's early +-lr steps amplify sign flips of near-zero gradients), so the test holds what
+    matters for training: the bf16 run trains as far as the fp32 run does (loss decrease within 3 %), the per-step total loss stays within
+    a band that does not widen over the run, and nothing is ever non-finite.  Measured on MI355X (profiles/r06_bf16_horizon.txt): mean
+    |d loss| 0.016 over steps 0-99 and 0.012 over 100-199, max 0.054 / 0.044, loss decrease 5.153 (fp32) vs 5.149 (bf16); bounds = 3x measured."""
+    bf, _ = _train_steps(('bf16', 'bf16'), 200, 64, schedule=False)
+    fp, _ = _train_steps(('fp32', 'fp32'), 200, 64, schedule=False)
+    assert np.isfinite(bf).all() and np.isfinite(fp).all()
+    d = np.abs(bf[:, 0] - fp[:, 0])
+    import os
+    rep = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(rep):
+        with open(os.path.join(rep, 'bf16_horizon.txt'), 'w') as f:
+            f.write('bf16 vs fp32, 200 teacher-forced steps, B = 64, full geometry\n')
+            f.write('step  loss_fp32  loss_bf16  |d|\n')
+            for i in list(range(0, 200, 10)) + [199]:
+                f.write('%4d  %9.4f  %9.4f  %.4f\n' % (i, fp[i, 0], bf[i, 0], d[i]))
+            f.write('mean |d| steps 0-99: %.4f   100-199: %.4f   max 0-99: %.4f   100-199: %.4f\n'
+                    % (d[:100].mean(), d[100:].mean(), d[:100].max(), d[100:].max()))
+            f.write('decrease fp32 %.4f  bf16 %.4f\n' % (fp[0, 0] - fp[-10:, 0].mean(), bf[0, 0] - bf[-10:, 0].mean()))
+    dec_fp, dec_bf = fp[0, 0] - fp[-10:, 0].mean(), bf[0, 0] - bf[-10:, 0].mean()
+    assert dec_fp > 1.0                                                             # 200 Adam steps train visibly
+    assert abs(dec_bf - dec_fp) < 0.03 * dec_fp + 0.05
+    assert d[100:].mean() < 0.04 and d.max() < 0.17
+    assert d[100:].mean() < 3 * d[:100].mean() + 0.01                               # the band does not widen over the horizon
+
+
 def test_full_batch_512_bf16_step_on_the_benched_code_paths():
     """B = 512, bf16: the kernel variants bench.py runs (128x128 BPTT tile, grid-stride duration kernels, 16-byte CE / embed
     kernels) produce the fp32 path's losses within the bf16 tolerance and every gradient lands in the flat arena"""
