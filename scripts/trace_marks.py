@@ -37,6 +37,8 @@ def step():
 for _ in range(5):
     step()
 torch.cuda.synchronize()
+from polyphonic_chord_texture_disentanglement_amd.optim import freeze_gc  # noqa: E402
+freeze_gc()                                  # (no full garbage collection inside a traced step)
 acc = {}
 N = 10
 for _ in range(N):
