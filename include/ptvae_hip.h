@@ -710,6 +710,63 @@ int ptv_free_note_loop(const void* const* w, const void* const* io, long ld_pitc
 int ptv_free_resummarize(const void* const* w, const void* const* io, int B, int t, int train, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * ptv_decoder_free_fwd (COMPOSITE, round 6; SURVEY.md 8b's decoder_free_fwd): the forward of the free-running / scheduled-sampling
+ * PianoTree decoder as ONE call -- PtvaeDecoder.decoder with teacher-forcing coins (ptvae.py:430-496), decode_notes / decode_note
+ * (:336-428) and the re-summarisation of the predicted notes (:476-486): what train.py's schedule runs from its third batch on
+ * (scheduler.py:48-54, train.py:23-24,59-63) and what inference_decode always runs (model.py:124-131).  The launch sequence of
+ * functional_free.DecoderStepFn.forward's persistent path, bit-identical to it:
+ *   prologue   z -> initial time state, z_in, its gate contribution; first time token; first note token
+ *   32 x       time-GRU input product, time-GRU cell (ptv_gru_step_fwd), [initial notes state | hoisted input part] in one product,
+ *              ptv_free_note_loop (all 15 note steps of the time step), then the next time token: the ground-truth summary (time coin) or
+ *              ptv_free_resummarize over the predicted notes
+ *   recompute  (training, D_REPLAY) what the batched backward reads, for all 480*B rows at once by the teacher-forced kernels on the
+ *              recorded tokens with the stored duration decisions forced: hoisted input part, notes GRU (ptv_notes_gru_persist_fwd),
+ *              dur_hid, the duration GRU (ptv_dur_gru_fwd), and the re-summarisation bi-GRU (ptv_row_gru_persist_fwd x 2)
+ * bf16 precision at the init_model() sizes (E = 128, He = 128, Hn = 512, Hd = 64, 130 pitches): anything else returns
+ * PTV_ERR_UNSUPPORTED before the first launch.  t: pointer table (enum PtvDffTensor; the caller owns every tensor), d: dimension table
+ * (enum PtvDffDim).  wl / io: the HOST pointer arrays of ptv_free_note_loop (io[18] = the H0GC scratch), wr / ior: those of
+ * ptv_free_resummarize (ior[6] is overwritten per time step with TOKS[t + 1]).  note_mask: HOST [32] -- bit n of word t = note coin n of
+ * time step t (ptvae.py:420); time_coin: HOST [31] bytes -- time step t + 1 is fed the ground-truth summary (ptvae.py:476).
+ * The autograd backward of this node is ptv_decoder_tf_bwd on the recorded tokens plus the routing of the token gradients
+ * (ptv_route_slices) and ptv_bigru_rows_bwd over the predicted notes: functional_free.DecoderStepFn.backward.
+ */
+enum PtvDffTensor {
+  PTV_DFF_Z = 0,            /* [B, Zs] fp32 */
+  PTV_DFF_XS,               /* [32 B, 2He] fp32 ground-truth note summaries, or NULL (inference / no time coin set) */
+  PTV_DFF_TOK0_SRC,         /* first note token of every time step: [R, E] rows (the embedded ground-truth slot 0) or ONE row (<sos>, D_TOK0_LDS = 0) */
+  /* parameters (fp32) and their operand copies */
+  PTV_DFF_W_ZHID, PTV_DFF_B_ZHID, PTV_DFF_W_ZIN, PTV_DFF_B_ZIN, PTV_DFF_W_IH_T, PTV_DFF_B_IH_T, PTV_DFF_INIT_INPUT, PTV_DFF_B_HH_T,
+  PTV_DFF_W_IH_T_OP,        /* dec_time_gru.weight_ih_l0 as the per-step product's operand: bf16 shadow (D_W_IH_T_BF16) or the fp32 weight */
+  PTV_DFF_W_HH_T_OP,        /* dec_time_gru.weight_hh_l0 likewise (D_W_HH_T_BF16) */
+  PTV_DFF_W_CAT, PTV_DFF_B_CAT,   /* [dec_time_to_notes_hid ; dec_notes_gru.weight_ih[:, :Ht]] bf16 [Hn + 3Hn, Ht] and its bias fp32 */
+  /* recompute block (D_REPLAY): fp32 weights + packs */
+  PTV_DFF_W_IH_N, PTV_DFF_B_IH_N, PTV_DFF_B_HH_N, PTV_DFF_W_DH, PTV_DFF_B_DH, PTV_DFF_W_HH_D, PTV_DFF_B_HH_D, PTV_DFF_TAB0, PTV_DFF_TAB,
+  PTV_DFF_W_OUT_D, PTV_DFF_B_OUT_D, PTV_DFF_PK_NOTES_H, PTV_DFF_PK_NOTES_T,
+  PTV_DFF_PK_E_H0, PTV_DFF_PK_E_T0, PTV_DFF_B_HH_E0, PTV_DFF_B_IH_E0, PTV_DFF_PK_E_H1, PTV_DFF_PK_E_T1, PTV_DFF_B_HH_E1, PTV_DFF_B_IH_E1,
+  /* state / outputs */
+  PTV_DFF_NS, PTV_DFF_NS16, PTV_DFF_Z_IN, PTV_DFF_ZG, PTV_DFF_TOKS, PTV_DFF_GATES_T,
+  PTV_DFF_GI, PTV_DFF_H0GC,          /* scratch [B, 3Ht] / [B, Hn + 3Hn] fp32, reused by every time step */
+  PTV_DFF_TOK, PTV_DFF_PRED, PTV_DFF_PITCH, PTV_DFF_HN, PTV_DFF_HN16, PTV_DFF_GATES_N, PTV_DFF_HD, PTV_DFF_HD16, PTV_DFF_GATES_D,
+  PTV_DFF_IDX, PTV_DFF_PLEN, PTV_DFF_GC16, PTV_DFF_DUR_SCR, PTV_DFF_IDX_SCR,
+  PTV_DFF_XH0, PTV_DFF_XH1, PTV_DFF_XH16_0, PTV_DFF_XH16_1, PTV_DFF_XG0, PTV_DFF_XG1,
+  PTV_DFF_WAIT_EVENT, PTV_DFF_RECORD_EVENT,   /* hipEvent_t or NULL: the persistent-launch turn around the cluster-mode note loops */
+  PTV_DFF_COUNT
+};
+enum PtvDffDim {
+  PTV_DFF_D_B = 0, PTV_DFF_D_ZS, PTV_DFF_D_ZI, PTV_DFF_D_HE, PTV_DFF_D_HT, PTV_DFF_D_HN, PTV_DFF_D_HD, PTV_DFF_D_E, PTV_DFF_D_NP,
+  PTV_DFF_D_LDP,            /* row stride of the pitch logits */
+  PTV_DFF_D_TRAIN, PTV_DFF_D_REPLAY, PTV_DFF_D_INFERENCE,
+  PTV_DFF_D_LOOP_FLAGS,     /* the `train` word of ptv_free_note_loop (mode, kernel choice, cluster size) */
+  PTV_DFF_D_CLUSTER,        /* != 0: the note loops take the persistent-launch turn (WAIT / RECORD events) */
+  PTV_DFF_D_RESUM_TRAIN,    /* the `train` word of ptv_free_resummarize */
+  PTV_DFF_D_TOK0_LDS,       /* row stride of TOK0_SRC (0 = one row for all) */
+  PTV_DFF_D_W_IH_T_BF16, PTV_DFF_D_W_HH_T_BF16,
+  PTV_DFF_D_COUNT
+};
+int ptv_decoder_free_fwd(const void* const* t, const long* d, const void* const* wl, const void* const* io, const void* const* wr,
+                         const void* const* ior, const unsigned* note_mask, const unsigned char* time_coin, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * The teacher-forced notes GRU (dec_notes_gru over 15 note steps x 32*B rows, ptvae.py:395-398 restructured per SURVEY.md 7.1)
  * as row-partitioned persistent kernels: ONE launch for the whole sequence, a workgroup owns 64 rows, the state stays on the CU, W_hh
  * streams from L2 in ptv_pack_mfma_b packing, the token product is fused.  bf16 precision, Hn = 512, E = 128.

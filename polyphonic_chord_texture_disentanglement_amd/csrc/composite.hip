@@ -578,6 +578,127 @@ extern "C" int ptv_bigru_rows_bwd(const void* const* t, const long* d, void* str
 }
 
 // ---------------------------------------------------------------------------------------------
+// ptv_decoder_free_fwd: functional_free.DecoderStepFn.forward's persistent path as one call (include/ptvae_hip.h: SURVEY.md 8b's
+// decoder_free_fwd).  The same launches with the same arguments in the same order as the Python sequencing -- the same bits; the two
+// per-time-step scratch matrices (gi, H0GC) are reused by every step (one stream: a step's consumers are queued before the next step's
+// producer).
+// ---------------------------------------------------------------------------------------------
+extern "C" int ptv_decoder_free_fwd(const void* const* t, const long* d, const void* const* wl, const void* const* io, const void* const* wr,
+                                    const void* const* ior, const unsigned* note_mask, const unsigned char* time_coin, void* stream) {
+  if (!t || !d || !wl || !io || !note_mask || !time_coin) return PTV_ERR_ARG;
+  const int B = (int)d[PTV_DFF_D_B], Zs = (int)d[PTV_DFF_D_ZS], Zi = (int)d[PTV_DFF_D_ZI], He = (int)d[PTV_DFF_D_HE], Ht = (int)d[PTV_DFF_D_HT],
+            Hn = (int)d[PTV_DFF_D_HN], Hd = (int)d[PTV_DFF_D_HD], E = (int)d[PTV_DFF_D_E], NP = (int)d[PTV_DFF_D_NP];
+  const long ldp = d[PTV_DFF_D_LDP];
+  const bool train = d[PTV_DFF_D_TRAIN] != 0, replay = d[PTV_DFF_D_REPLAY] != 0, inference = d[PTV_DFF_D_INFERENCE] != 0;
+  if (B <= 0 || E != 128 || He != 128 || Hn != 512 || Hd != 64 || NP != 130 || Ht <= 0 || (Ht & 7) || Zs <= 0 || Zi <= 0 || ldp < NP)
+    return PTV_ERR_UNSUPPORTED;
+  if (replay && !train) return PTV_ERR_ARG;
+  bool need_resum = inference;
+  for (int i = 0; i < 31 && !need_resum; i++) need_resum = !time_coin[i];
+  {
+    const int always[] = {PTV_DFF_Z, PTV_DFF_TOK0_SRC, PTV_DFF_W_ZHID, PTV_DFF_B_ZHID, PTV_DFF_W_ZIN, PTV_DFF_B_ZIN, PTV_DFF_W_IH_T, PTV_DFF_B_IH_T,
+                          PTV_DFF_INIT_INPUT, PTV_DFF_B_HH_T, PTV_DFF_W_IH_T_OP, PTV_DFF_W_HH_T_OP, PTV_DFF_W_CAT, PTV_DFF_B_CAT, PTV_DFF_NS, PTV_DFF_NS16,
+                          PTV_DFF_Z_IN, PTV_DFF_ZG, PTV_DFF_TOKS, PTV_DFF_GI, PTV_DFF_H0GC, PTV_DFF_TOK, PTV_DFF_PRED};
+    for (int i : always) if (!t[i]) return PTV_ERR_ARG;
+    if (train && !t[PTV_DFF_GATES_T]) return PTV_ERR_ARG;
+    if (need_resum && (!wr || !ior)) return PTV_ERR_ARG;
+    if (replay) {
+      const int rp[] = {PTV_DFF_W_IH_N, PTV_DFF_B_IH_N, PTV_DFF_B_HH_N, PTV_DFF_W_DH, PTV_DFF_B_DH, PTV_DFF_W_HH_D, PTV_DFF_B_HH_D, PTV_DFF_TAB0, PTV_DFF_TAB,
+                        PTV_DFF_W_OUT_D, PTV_DFF_B_OUT_D, PTV_DFF_PK_NOTES_H, PTV_DFF_PK_NOTES_T, PTV_DFF_PITCH, PTV_DFF_HN, PTV_DFF_HN16, PTV_DFF_GATES_N,
+                        PTV_DFF_HD, PTV_DFF_HD16, PTV_DFF_IDX, PTV_DFF_GC16, PTV_DFF_DUR_SCR, PTV_DFF_IDX_SCR};
+      for (int i : rp) if (!t[i]) return PTV_ERR_ARG;
+      if (need_resum)
+        for (int i : {PTV_DFF_PK_E_H0, PTV_DFF_PK_E_T0, PTV_DFF_B_HH_E0, PTV_DFF_B_IH_E0, PTV_DFF_PK_E_H1, PTV_DFF_PK_E_T1, PTV_DFF_B_HH_E1, PTV_DFF_B_IH_E1,
+                      PTV_DFF_PLEN, PTV_DFF_XH0, PTV_DFF_XH1, PTV_DFF_XH16_0, PTV_DFF_XH16_1, PTV_DFF_XG0, PTV_DFF_XG1})
+          if (!t[i]) return PTV_ERR_ARG;
+    }
+  }
+  const int P = PTV_PREC_BF16;
+  hipStream_t s = (hipStream_t)stream;
+  const int R = 32 * B;
+  const long M = 15L * R;
+  float* NS = M_<float>(t, PTV_DFF_NS);
+  __bf16* NS16 = M_<__bf16>(t, PTV_DFF_NS16);
+  float* TOKS = M_<float>(t, PTV_DFF_TOKS);
+  float* TOK = M_<float>(t, PTV_DFF_TOK);
+  float* PRED = M_<float>(t, PTV_DFF_PRED);
+  float* zg = M_<float>(t, PTV_DFF_ZG);
+  const long ld_t = 2L * He + Zi;
+  const float* w_ih_t = (const float*)T_(t, PTV_DFF_W_IH_T);
+  // ---- prologue (ptvae.py:435-437,457-462)
+  PTV_TRY(ptv_gemm(P, 0, 0, B, Ht, Zs, T_(t, PTV_DFF_Z), Zs, T_(t, PTV_DFF_W_ZHID), Zs, NS, Ht, (const float*)T_(t, PTV_DFF_B_ZHID), 1.f, 0, 0, 0, 0, stream));
+  PTV_TRY(ptv_gemm(P, 0, 0, B, Zi, Zs, T_(t, PTV_DFF_Z), Zs, T_(t, PTV_DFF_W_ZIN), Zs, M_<void>(t, PTV_DFF_Z_IN), Zi, (const float*)T_(t, PTV_DFF_B_ZIN), 1.f, 0,
+                   0, 0, 0, stream));
+  PTV_TRY(ptv_gemm(P, 0, 0, B, 3 * Ht, Zi, T_(t, PTV_DFF_Z_IN), Zi, w_ih_t + 2 * He, ld_t, zg, 3L * Ht, (const float*)T_(t, PTV_DFF_B_IH_T), 1.f, 0, 0, 0, 0,
+                   stream));
+  PTV_TRY(ptv_copy2d(TOKS, 2L * He, (const float*)T_(t, PTV_DFF_INIT_INPUT), 0, B, 2 * He, 1.f, 0, stream));
+  PTV_TRY(ptv_cast_bf16(NS, NS16, (long)B * Ht, stream));
+  // the first note token of every time step: the <sos> embedding / the embedded ground-truth slot 0 (ptvae.py:388-392)
+  PTV_TRY(ptv_copy2d(TOK, E, (const float*)T_(t, PTV_DFF_TOK0_SRC), d[PTV_DFF_D_TOK0_LDS], R, E, 1.f, 0, stream));
+  PTV_TRY(ptv_copy2d(PRED, E, TOK, E, R, E, 1.f, 0, stream));
+  // ---- the step loop
+  const int wih_bf = d[PTV_DFF_D_W_IH_T_BF16] ? 1 : 0, whh_bf = d[PTV_DFF_D_W_HH_T_BF16] ? 1 : 0;
+  float* gi = M_<float>(t, PTV_DFF_GI);
+  float* h0gc = M_<float>(t, PTV_DFF_H0GC);
+  if (io[18] != (const void*)h0gc) return PTV_ERR_ARG;
+  __bf16* gates_t = M_<__bf16>(t, PTV_DFF_GATES_T);
+  const int loop_flags = (int)d[PTV_DFF_D_LOOP_FLAGS], cluster = (int)d[PTV_DFF_D_CLUSTER];
+  const void* ior_[7];
+  if (need_resum) for (int i = 0; i < 7; i++) ior_[i] = ior[i];
+  if (cluster && t[PTV_DFF_WAIT_EVENT] && hipStreamWaitEvent(s, (hipEvent_t)const_cast<void*>(t[PTV_DFF_WAIT_EVENT]), 0) != hipSuccess) return PTV_ERR_LAUNCH;
+  for (int ts = 0; ts < 32; ts++) {
+    const float* tok_t = TOKS + (long)ts * B * 2 * He;
+    PTV_TRY(ptv_gemm(P, 0, 0, B, 3 * Ht, 2 * He, tok_t, 2L * He, T_(t, PTV_DFF_W_IH_T_OP), ld_t, gi, 3L * Ht, nullptr, 1.f, 0, 0, 0, wih_bf ? B16 : 0, stream));
+    // flags of ptv_gru_step_fwd: bit 0 gates bf16, bit 2 gi2 (zg: fp32 here), bit 4 weight bf16
+    PTV_TRY(ptv_gru_step_fwd(P, B, Ht, NS + (long)ts * B * Ht, Ht, NS16 + (long)ts * B * Ht, NS16 + (long)(ts + 1) * B * Ht, gi, 3L * Ht, zg, 3L * Ht,
+                             T_(t, PTV_DFF_W_HH_T_OP), (const float*)T_(t, PTV_DFF_B_HH_T), NS + (long)(ts + 1) * B * Ht, Ht,
+                             train ? (void*)(gates_t + (long)ts * 4 * B * Ht) : nullptr, (long)B * Ht, nullptr, 0, nullptr,
+                             (train ? 1 : 0) | (whh_bf << 4), stream));
+    PTV_TRY(ptv_gemm(P, 0, 0, B, 4 * Hn, Ht, NS16 + (long)(ts + 1) * B * Ht, Ht, T_(t, PTV_DFF_W_CAT), Ht, h0gc, 4L * Hn, (const float*)T_(t, PTV_DFF_B_CAT), 1.f,
+                     0, 0, 0, A16 | B16, stream));
+    PTV_TRY(ptv_free_note_loop(wl, io, ldp, B, ts, inference ? 0u : note_mask[ts], loop_flags, stream));
+    if (ts == 31) break;
+    float* tok_next = TOKS + (long)(ts + 1) * B * 2 * He;
+    if (!inference && time_coin[ts]) {
+      if (!t[PTV_DFF_XS]) return PTV_ERR_ARG;
+      PTV_TRY(ptv_copy2d(tok_next, 2L * He, (const float*)T_(t, PTV_DFF_XS) + (long)ts * B * 2 * He, 2L * He, B, 2 * He, 1.f, 0, stream));
+    } else {
+      ior_[6] = tok_next;
+      PTV_TRY(ptv_free_resummarize(wr, ior_, B, ts, (int)d[PTV_DFF_D_RESUM_TRAIN], stream));
+    }
+  }
+  if (cluster && t[PTV_DFF_RECORD_EVENT] && hipEventRecord((hipEvent_t)const_cast<void*>(t[PTV_DFF_RECORD_EVENT]), s) != hipSuccess) return PTV_ERR_LAUNCH;
+  if (!replay) return PTV_OK;
+  // ---- recompute what the backward reads, batched over all rows (the step loop stored decisions and tokens only)
+  const float* w_ih_n = (const float*)T_(t, PTV_DFF_W_IH_N);
+  const float* w_dh = (const float*)T_(t, PTV_DFF_W_DH);
+  __bf16* HN16 = M_<__bf16>(t, PTV_DFF_HN16);
+  float* HD = M_<float>(t, PTV_DFF_HD);
+  __bf16* HD16 = M_<__bf16>(t, PTV_DFF_HD16);
+  PTV_TRY(ptv_gemm(P, 0, 0, R, 3 * Hn, Ht, NS16 + (long)B * Ht, Ht, w_ih_n, (long)Ht + E, M_<void>(t, PTV_DFF_GC16), 3L * Hn, (const float*)T_(t, PTV_DFF_B_IH_N),
+                   1.f, 0, 0, -1, A16 | C16 | CBLK16, stream));
+  PTV_TRY(ptv_notes_gru_persist_fwd(T_(t, PTV_DFF_PK_NOTES_H), T_(t, PTV_DFF_PK_NOTES_T), (const float*)T_(t, PTV_DFF_B_HH_N), T_(t, PTV_DFF_GC16), TOK,
+                                    M_<float>(t, PTV_DFF_HN), HN16, M_<void>(t, PTV_DFF_GATES_N), R, 15, stream));
+  PTV_TRY(ptv_gemm(P, 0, 0, (int)M, Hd, Hn, HN16 + (long)R * Hn, Hn, w_dh, (long)Hn + NP, HD, Hd, (const float*)T_(t, PTV_DFF_B_DH), 1.f, 0, 0, 0, A16, stream));
+  PTV_TRY(ptv_gemm(P, 0, 0, (int)M, Hd, NP, T_(t, PTV_DFF_PITCH), ldp, w_dh + Hn, (long)Hn + NP, HD, Hd, nullptr, 1.f, 1, 0, 0, 0, stream));
+  PTV_TRY(ptv_dur_gru_fwd(Hd, M, HD, Hd, (const float*)T_(t, PTV_DFF_W_HH_D), (const float*)T_(t, PTV_DFF_B_HH_D), (const float*)T_(t, PTV_DFF_TAB0),
+                          (const float*)T_(t, PTV_DFF_TAB), (const float*)T_(t, PTV_DFF_W_OUT_D), (const float*)T_(t, PTV_DFF_B_OUT_D), nullptr, M * Hd,
+                          HD16 + M * Hd, M_<void>(t, PTV_DFF_GATES_D), M * Hd, 4 * M * Hd, 1, M_<float>(t, PTV_DFF_DUR_SCR), 10, M_<int>(t, PTV_DFF_IDX_SCR), M,
+                          (const int*)T_(t, PTV_DFF_IDX), M, stream));
+  PTV_TRY(ptv_cast_bf16(HD, HD16, M * Hd, stream));
+  if (need_resum) {
+    for (int dir = 0; dir < 2; dir++) {
+      const int o = dir ? 4 : 0;
+      PTV_TRY(ptv_row_gru_persist_fwd(He, T_(t, PTV_DFF_PK_E_H0 + o), T_(t, PTV_DFF_PK_E_T0 + o), (const float*)T_(t, PTV_DFF_B_HH_E0 + o),
+                                      (const float*)T_(t, PTV_DFF_B_IH_E0 + o), nullptr, PRED, (long)R * E, (const int*)T_(t, PTV_DFF_PLEN),
+                                      M_<float>(t, dir ? PTV_DFF_XH1 : PTV_DFF_XH0), M_<void>(t, dir ? PTV_DFF_XH16_1 : PTV_DFF_XH16_0),
+                                      M_<void>(t, dir ? PTV_DFF_XG1 : PTV_DFF_XG0), nullptr, 0, R, 16, dir, stream));
+    }
+  }
+  return PTV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // ptv_vae_loss_fwd / ptv_vae_loss_bwd: functional.VaeLossFn's two launch sequences
 // ---------------------------------------------------------------------------------------------
 extern "C" int ptv_vae_loss_fwd(const void* const* t, const long* d, const double* sc, void* stream) {

@@ -66,6 +66,10 @@ def _sos_grid(dev):
 # a 16-sample panel, one more re-summarises the predicted notes.  bf16 precision, init_model() geometry.
 # ---------------------------------------------------------------------------------------------
 FREE_PERSIST = True
+# the persistent path of DecoderStepFn.forward behind ONE C call (ptv_decoder_free_fwd, csrc/composite.hip: ~170 launches -- prologue, the
+# 32-step loop, the batched recompute); PTV_FREE_COMPOSITE=0: the same launches sequenced from here (bit-identical)
+FREE_COMPOSITE = os.environ.get('PTV_FREE_COMPOSITE', '1') != '0'
+_DFF = {}
 # training forward of the step loop: the panels store only decisions, logits and fed tokens; states and gates the backward needs are
 # recomputed afterwards for all 480*B rows at once by the teacher-forced kernels (same tokens, same decisions forced)
 FREE_REPLAY = True
@@ -152,6 +156,77 @@ def gru_step(prec, hprev, gi, gi_ld, w_hh, b_hh, hout, *, gi2=None, gates=None, 
          ptr(lengths), t, ptr(gi_idx), F_._gru_flags(gates, gi, gi2, w=w_hh), stream_ptr())
 
 
+def _decoder_free_fwd_composite(P, z, xs, tok0_src, tok0_lds, pk, wl, wr, io_of, ior, dims, tens, coins, w_hh_t, w_ih_t16, prec, dev, M, R):
+    """DecoderStepFn.forward's persistent path through ptv_decoder_free_fwd (one C call); True when it ran"""
+    import ctypes
+    if 't' not in _DFF:
+        from ._lib import header_enum
+        _DFF['t'], _DFF['d'] = header_enum('PtvDffTensor'), header_enum('PtvDffDim')
+    T_, D_ = _DFF['t'], _DFF['d']
+    B, He, Ht, Hn, Hd, E = (dims[k] for k in ('B', 'He', 'Ht', 'Hn', 'Hd', 'E'))
+    replay, need_resum = bool(dims['replay']), ior is not None
+    w_ih_n, w_hh_n = P['dec_notes_gru.weight_ih_l0'], P['dec_notes_gru.weight_hh_l0']
+    t = dict(tens)
+    t.update(Z=z, XS=xs, TOK0_SRC=tok0_src, W_ZHID=P['z2dec_hid_linear.weight'], B_ZHID=P['z2dec_hid_linear.bias'],
+             W_ZIN=P['z2dec_in_linear.weight'], B_ZIN=P['z2dec_in_linear.bias'], W_IH_T=P['dec_time_gru.weight_ih_l0'],
+             B_IH_T=P['dec_time_gru.bias_ih_l0'], INIT_INPUT=P['dec_init_input'], B_HH_T=P['dec_time_gru.bias_hh_l0'], W_IH_T_OP=w_ih_t16,
+             W_HH_T_OP=w_hh_t, W_CAT=pk['w_cat'], B_CAT=pk['b_cat'], GI=_empty(B, 3 * Ht, dev=dev), H0GC=_empty(B, 4 * Hn, dev=dev))
+    if replay:
+        F_.zero_skip_sync()
+        pkn = F_.notes_packs(w_ih_n, w_hh_n, Ht)
+        t.update(W_IH_N=w_ih_n, B_IH_N=P['dec_notes_gru.bias_ih_l0'], B_HH_N=P['dec_notes_gru.bias_hh_l0'], W_DH=P['dur_hid_linear.weight'],
+                 B_DH=P['dur_hid_linear.bias'], W_HH_D=P['dec_dur_gru.weight_hh_l0'], B_HH_D=P['dec_dur_gru.bias_hh_l0'],
+                 W_OUT_D=P['dur_out_linear.weight'], B_OUT_D=P['dur_out_linear.bias'], PK_NOTES_H=pkn['wg_h'], PK_NOTES_T=pkn['wg_t'],
+                 GC16=_empty(R, 3 * Hn, dev=dev, dtype=torch.bfloat16), DUR_SCR=_empty(M, 10, dev=dev),
+                 IDX_SCR=torch.empty(5, M, device=dev, dtype=torch.int32))
+        if need_resum:
+            wE = [P['dec_notes_emb_gru.' + n] for n in EMB_GRU]
+            for d_ in range(2):
+                w_ih_e, w_hh_e, b_ih_e, b_hh_e = wE[4 * d_: 4 * d_ + 4]
+                pke = F_.notes_packs(w_ih_e, w_hh_e, 0)
+                t.update({'PK_E_H%d' % d_: pke['wg_h'], 'PK_E_T%d' % d_: pke['wg_t'], 'B_HH_E%d' % d_: b_hh_e, 'B_IH_E%d' % d_: b_ih_e})
+    slots = [None] * T_['PTV_DFF_COUNT']
+    for k, v in t.items():
+        if v is not None:
+            slots[T_['PTV_DFF_' + k]] = v.data_ptr()
+    dvals = [0] * D_['PTV_DFF_D_COUNT']
+    for k, v in (('B', B), ('ZS', dims['Zs']), ('ZI', dims['Zi']), ('HE', He), ('HT', Ht), ('HN', Hn), ('HD', Hd), ('E', E), ('NP', dims['NP']),
+                 ('LDP', dims['ldp']), ('TRAIN', dims['train']), ('REPLAY', dims['replay']), ('INFERENCE', dims['inference']),
+                 ('LOOP_FLAGS', dims['loop_flags']), ('CLUSTER', dims['cluster']), ('RESUM_TRAIN', dims['resum_train']), ('TOK0_LDS', tok0_lds),
+                 ('W_IH_T_BF16', int(w_ih_t16.dtype == torch.bfloat16)), ('W_HH_T_BF16', int(w_hh_t.dtype == torch.bfloat16))):
+        dvals[D_['PTV_DFF_D_' + k]] = int(v)
+    coin_notes, coin_time = coins
+    masks = (ctypes.c_uint * 32)()
+    tc = (ctypes.c_ubyte * 31)()
+    if not dims['inference']:
+        for ts in range(32):
+            m_ = 0
+            for n in range(14):
+                m_ |= int(bool(coin_notes[ts][n])) << n
+            masks[ts] = m_
+        for ts in range(31):
+            tc[ts] = int(bool(coin_time[ts]))
+    cur = F_.cur_stream()
+    done_ev = None
+    if dims['cluster']:                                     # the cluster-mode note loops take the persistent-launch turn (functional._PersistTurn)
+        prev = F_._PERSIST_LAST.get(cur.device.index)
+        done_ev = torch.cuda.Event()
+        if prev is not None:
+            slots[T_['PTV_DFF_WAIT_EVENT']] = prev.cuda_event
+        done_ev.record(cur)                                 # creates the handle; the library records it again after the last note loop
+        slots[T_['PTV_DFF_RECORD_EVENT']] = done_ev.cuda_event
+    F_._chain_prio()
+    rc = lib().ptv_decoder_free_fwd((ctypes.c_void_p * len(slots))(*slots), F_._larr(dvals), wl, io_of(t['H0GC']), wr, ior, masks, tc, stream_ptr())
+    if rc == -3:
+        return False
+    F_.check(rc, 'ptv_decoder_free_fwd')
+    if done_ev is not None:
+        F_._PERSIST_LAST[cur.device.index] = done_ev
+    _DFF['calls'] = _DFF.get('calls', 0) + 1
+    _DFF['keep'] = (t, masks, tc)                           # (the scratch tensors stay referenced until the next call: their launches are queued, not run)
+    return True
+
+
 class DecoderStepFn(torch.autograd.Function):
     """(z, emb [16,32,B,E] or None, xs [32B,2He] or None, coins, inference, force, prec, *params)
     -> pitch [15,32,B,130], dur [15*32*B,5,2], xhat int64 [B,32,16,6] (predicted grid), dur idx"""
@@ -176,12 +251,19 @@ class DecoderStepFn(torch.autograd.Function):
         st = stream_ptr()
 
         NS = _empty(33, B, Ht, dev=dev)
-        gemm(z, P['z2dec_hid_linear.weight'], NS[0], bias=P['z2dec_hid_linear.bias'], prec=prec)
-        z_in = gemm(z, P['z2dec_in_linear.weight'], bias=P['z2dec_in_linear.bias'], prec=prec)
         w_ih_t = P['dec_time_gru.weight_ih_l0']
-        zg = gemm(z_in, w_ih_t[:, 2 * He:], bias=P['dec_time_gru.bias_ih_l0'], prec=prec)
+        Zi = P['z2dec_in_linear.weight'].shape[0]
         TOKS = _empty(33, B, 2 * He, dev=dev)
-        copy2d(TOKS[0], P['dec_init_input'].view(1, -1), lds=0)
+        # the persistent path as ONE library call (ptv_decoder_free_fwd): then nothing is launched from here before that call
+        comp = (FREE_COMPOSITE and free_persist_ok(prec, E, He, Hn, Hd, NP) and Ht % 8 == 0
+                and (not train or F_._act_dtype(prec, Hn) == torch.bfloat16) and z.dtype == torch.float32)
+        if comp:
+            z_in, zg = _empty(B, Zi, dev=dev), _empty(B, 3 * Ht, dev=dev)
+        else:
+            gemm(z, P['z2dec_hid_linear.weight'], NS[0], bias=P['z2dec_hid_linear.bias'], prec=prec)
+            z_in = gemm(z, P['z2dec_in_linear.weight'], bias=P['z2dec_in_linear.bias'], prec=prec)
+            zg = gemm(z_in, w_ih_t[:, 2 * He:], bias=P['dec_time_gru.bias_ih_l0'], prec=prec)
+            copy2d(TOKS[0], P['dec_init_input'].view(1, -1), lds=0)
         gates_t = _empty(32, 4, B, Ht, dev=dev, dtype=F_._act_dtype(prec, Ht)) if train else None
 
         HN = _empty(16, R, Hn, dev=dev)
@@ -224,7 +306,8 @@ class DecoderStepFn(torch.autograd.Function):
             HD16 = _empty(6, M, Hd, dev=dev, dtype=torch.bfloat16)
         if fast and Ht % 8 == 0:                                 # ... and of the time GRU / the per-step products in the loop
             NS16 = _empty(33, B, Ht, dev=dev, dtype=torch.bfloat16)
-            call('ptv_cast_bf16', ptr(NS[0]), ptr(NS16[0]), B * Ht, st)
+            if not comp:
+                call('ptv_cast_bf16', ptr(NS[0]), ptr(NS16[0]), B * Ht, st)
         # per time step the loop runs four M = B products whose cost is reading the weights: their bf16 shadows halve it
         w_hh_t = F_._W(P['dec_time_gru.weight_hh_l0'], prec) if NS16 is not None else P['dec_time_gru.weight_hh_l0']
         w_ih_t16, w_tn16, w_ih_n16 = (F_._W(w_ih_t, prec), F_._W(P['dec_time_to_notes_hid.weight'], prec), F_._W(w_ih_n, prec)) if fast \
@@ -261,13 +344,35 @@ class DecoderStepFn(torch.autograd.Function):
                            P['dur_hid_linear.bias'], b_hh_d, tab0, tab, P['dur_out_linear.weight'], P['dur_out_linear.bias'],
                            pk['w_embT'], b_emb])
             wr = F_._parr([pk['e_ih'], pk['e_hh'], pk['e_ih_r'], pk['e_hh_r'], wE[2], wE[3], wE[6], wE[7]])
+        XH16 = [None, None]
+        done = False
+        if comp:
+            assert fast and NS16 is not None
+            if replay and need_resum:
+                XH16 = [_empty(17, R, He, dev=dev, dtype=torch.bfloat16) for _ in range(2)]
+            done = _decoder_free_fwd_composite(
+                P, z, xs, sos_row if inference else emb3[0], 0 if inference else E, pk, wl, wr, io_of=lambda h0gc: F_._parr(
+                    [None, emb3, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, force_pitch, force_dur, HN16, HD16, None, h0gc,
+                     xch, xcnt]),
+                ior=F_._parr([PRED, plen, XH[0], XH[1], XG[0], XG[1], None]) if need_resum else None,
+                dims=dict(B=B, Zs=z.shape[1], Zi=Zi, He=He, Ht=Ht, Hn=Hn, Hd=Hd, E=E, NP=NP, ldp=pitch.stride(0), train=int(train), replay=int(bool(replay)),
+                          inference=int(bool(inference)), cluster=int(cluster and not capturing),
+                          loop_flags=(2 if replay else int(train)) | (0 if NOTE_LOOP_SPLIT is None else (0x20000 if NOTE_LOOP_SPLIT else 0x10000))
+                          | (cluster << 18), resum_train=int(train and not replay)),
+                tens=dict(NS=NS, NS16=NS16, Z_IN=z_in, ZG=zg, TOKS=TOKS, GATES_T=gates_t, TOK=TOK, PRED=PRED, PITCH=pitch, HN=HN, HN16=HN16,
+                          GATES_N=gates_n, HD=HD, HD16=HD16, GATES_D=gates_d, IDX=idx, PLEN=plen, XH0=XH[0] if XH else None,
+                          XH1=XH[1] if XH else None, XH16_0=XH16[0], XH16_1=XH16[1], XG0=XG[0] if XG else None, XG1=XG[1] if XG else None,
+                          TAB0=tab0, TAB=tab),
+                coins=(coin_notes, coin_time), w_hh_t=w_hh_t, w_ih_t16=w_ih_t16, prec=prec, dev=dev, M=M, R=R)
+            assert done, 'ptv_decoder_free_fwd declined a configuration free_persist_ok() accepted'
         # the first note token of every time step is the <sos> embedding (ptvae.py:388-392): one copy for all 32 steps
-        if inference:
-            copy2d(TOK[0], sos_row, lds=0)
-        else:
-            copy2d(TOK[0], emb3[0])
-        copy2d(PRED[0], TOK[0])
-        for t in range(32):
+        if not done:
+            if inference:
+                copy2d(TOK[0], sos_row, lds=0)
+            else:
+                copy2d(TOK[0], emb3[0])
+            copy2d(PRED[0], TOK[0])
+        for t in range(0 if not done else 32, 32):
             rows = slice(t * B, (t + 1) * B)
             gi = gemm(TOKS[t], w_ih_t16[:, :2 * He], prec=prec)
             gru_step(prec, NS[t], gi, 3 * Ht, w_hh_t, P['dec_time_gru.bias_hh_l0'], NS[t + 1], gi2=zg,
@@ -348,8 +453,7 @@ class DecoderStepFn(torch.autograd.Function):
                                  gates=XG[d][s_][:, rows] if train else None, plane=R * He, lengths=plen[rows], t=tt)
                     copy2d(TOKS[t + 1][:, d * He:(d + 1) * He], XH[d][16][rows])
 
-        XH16 = [None, None]
-        if replay:
+        if replay and not done:
             F_.zero_skip_sync()
             # ---- recompute what the backward reads, batched over all rows (the step loop above stored decisions and tokens only)
             GC16 = gemm(NS16[1:].view(R, Ht), w_ih_n[:, :Ht], bias=P['dec_notes_gru.bias_ih_l0'], prec=prec, out_dtype=torch.bfloat16,

@@ -823,6 +823,48 @@ def test_free_running_training_batched_recompute_equals_streamed_states(monkeypa
         assert (g1[n] - g0[n]).abs().max() <= 0.04 * g0[n].abs().max() + 1e-6, n
 
 
+@pytest.mark.parametrize('B,tfr', [(40, 0.0), (24, 0.5), (64, 0.0)])
+def test_decoder_free_composite_entry_point_equals_python_sequencing(B, tfr, monkeypatch):
+    """ptv_decoder_free_fwd (csrc/composite.hip; SURVEY 8b's decoder_free_fwd): the free-running / scheduled-sampling decoder forward --
+    prologue, the 32-step loop (time-GRU cell, note loop, re-summarisation or the ground-truth summary by the time coins), the batched
+    recompute -- as ONE C call makes the same launches as functional_free.DecoderStepFn's own sequencing: losses, the predicted grid and
+    every gradient bit-identical; a ragged last panel, cluster mode, mixed coins (tfr = 0.5: both token routes), and inference_decode"""
+    import random
+    from polyphonic_chord_texture_disentanglement_amd import functional_free as FF_
+    m = M.DisentangleVAE.init_model(torch.device(DEV))
+    m.load_state_dict(full_params())
+    m.to(DEV).set_precision('bf16')
+    x, c, pr = synth_batch(B, 77)
+    xt, ct, prt = (torch.from_numpy(a).to(DEV) for a in (x, c, pr))
+    eps = {n: torch.randn(B, 256, generator=torch.Generator().manual_seed(i)).to(DEV) for i, n in enumerate(('chd', 'rhy'))}
+    res = {}
+    for comp in (False, True):
+        monkeypatch.setattr(FF_, 'FREE_COMPOSITE', comp)
+        FF_._DFF.pop('calls', None)
+        random.seed(3)
+        m.eps_source = lambda name, shape, device: eps[name]
+        m.zero_grad()
+        outs = m.run(xt, ct, prt, tfr, tfr, tfr)
+        losses = m.loss_function(xt, ct, *outs, 0.1, [1, 0.5])
+        losses[0].backward()
+        torch.cuda.synchronize()
+        assert bool(FF_._DFF.get('calls')) == comp                 # the composite ran exactly when asked to
+        with torch.no_grad():
+            z = torch.cat([outs[2].mean, outs[3].mean], -1).detach()
+            est = m.inference_decode(z[:, :256], z[:, 256:])
+        res[comp] = ([l.detach().clone() for l in losses], m.decoder.last_xhat.clone(), est,
+                     {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    (l0, x0, e0, g0), (l1, x1, e1, g1) = res[False], res[True]
+    for a, b in zip(l0, l1):
+        assert torch.equal(a, b), (a, b)
+    assert torch.equal(x0, x1) and (e0 == e1).all()
+    assert set(g0) == set(g1)
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), (n, (g0[n] - g1[n]).abs().max())
+    from polyphonic_chord_texture_disentanglement_amd.functional import persist_check
+    persist_check()
+
+
 def test_note_loop_producer_head_split_kernel_equals_four_wave_kernel(monkeypatch):
     """csrc/freerun.hip has two note-loop kernels (4 waves phase by phase / producers + heads over 8 waves, chosen by panel count):
     same decisions and logits from both, in inference and in a free-running training step (full geometry)"""
