@@ -766,6 +766,32 @@ enum PtvDffDim {
 int ptv_decoder_free_fwd(const void* const* t, const long* d, const void* const* wl, const void* const* io, const void* const* wr,
                          const void* const* ior, const unsigned* note_mask, const unsigned char* time_coin, void* stream);
 
+/* ptv_decoder_free_bwd (COMPOSITE, round 6; SURVEY.md 8b's decoder_free_bwd): autograd through the node above (argmax is not
+ * differentiable: with the fed tokens recorded every chain is the batched BPTT of the teacher-forced path) as ONE call --
+ *   ptv_decoder_tf_bwd(t_tf, d_tf)            the decoder's whole backward on the recorded tokens (tables of that entry point)
+ *   ptv_route_slices x 2                      token gradients to the ground-truth embedding (coin set / slot 0) or to the predicted
+ *                                             tokens; time-token gradients to the ground-truth summaries or to the re-summarised ones
+ *   ptv_bigru_rows_bwd(t_rows, d_rows)        (t_rows != NULL) BPTT of the re-summarisation bi-GRU over the predicted notes
+ *                                             (ptvae.py:480-486), its input gradient added to the predicted tokens' gradient
+ *   slot 0 of the predicted tokens is the ground-truth <sos> embedding: its gradient moves over; then the predicted tokens ->
+ *   note_embedding: multi-hot operand of the predicted grid (ptv_multihot) and grad_W / grad_b in one ptv_wgrad pass
+ * -- functional_free.DecoderStepFn.backward's launch sequence, bit-identical to it.  t: enum PtvDfbTensor, d: enum PtvDfbDim. */
+enum PtvDfbTensor {
+  PTV_DFB_DTOK = 0,         /* [15, R, E] fp32 (slot 15 of the [16, R, E] buffer unused): gradient w.r.t. the fed note tokens (out of t_tf) */
+  PTV_DFB_DTOKS,            /* [33, B, 2He] fp32: gradient w.r.t. the time-step tokens (out of t_tf) */
+  PTV_DFB_DEMB, PTV_DFB_DPRED,   /* [16, R, E] fp32, zero on entry: gradient of the ground-truth embedding / of the predicted tokens */
+  PTV_DFB_DXS, PTV_DFB_DXSP,     /* [32, B, 2He] fp32, zero on entry: gradient of the ground-truth / re-summarised time tokens */
+  PTV_DFB_MASK_TOK, PTV_DFB_MASK_TIME,   /* int32 [15 * 32] / [32] routing masks of the coins */
+  PTV_DFB_DX_PRED,          /* [16 R, E] fp32: the input gradient t_rows produces (its PTV_BRB_DX), or NULL without t_rows */
+  PTV_DFB_XHAT,             /* [B, 32, 16, 6] int64 predicted grid */
+  PTV_DFB_MH,               /* [16 R, 136] fp32 scratch: its multi-hot rows */
+  PTV_DFB_G_W_EMB, PTV_DFB_G_B_EMB,     /* note_embedding gradients [E, 135] / [E], accumulated into */
+  PTV_DFB_COUNT
+};
+enum PtvDfbDim { PTV_DFB_D_B = 0, PTV_DFB_D_E, PTV_DFB_D_HE, PTV_DFB_D_COUNT };
+int ptv_decoder_free_bwd(const void* const* t_tf, const long* d_tf, const void* const* t_rows, const long* d_rows, const void* const* t,
+                         const long* d, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * The teacher-forced notes GRU (dec_notes_gru over 15 note steps x 32*B rows, ptvae.py:395-398 restructured per SURVEY.md 7.1)
  * as row-partitioned persistent kernels: ONE launch for the whole sequence, a workgroup owns 64 rows, the state stays on the CU, W_hh

@@ -699,6 +699,40 @@ extern "C" int ptv_decoder_free_fwd(const void* const* t, const long* d, const v
 }
 
 // ---------------------------------------------------------------------------------------------
+// ptv_decoder_free_bwd: functional_free.DecoderStepFn.backward as one call (include/ptvae_hip.h)
+// ---------------------------------------------------------------------------------------------
+extern "C" int ptv_decoder_free_bwd(const void* const* t_tf, const long* d_tf, const void* const* t_rows, const long* d_rows, const void* const* t,
+                                    const long* d, void* stream) {
+  if (!t_tf || !d_tf || !t || !d || (t_rows && !d_rows)) return PTV_ERR_ARG;
+  const int B = (int)d[PTV_DFB_D_B], E = (int)d[PTV_DFB_D_E], He = (int)d[PTV_DFB_D_HE];
+  if (B <= 0 || E <= 0 || He <= 0) return PTV_ERR_ARG;
+  for (int i = 0; i < PTV_DFB_COUNT; i++)
+    if (!t[i] && i != PTV_DFB_DX_PRED) return PTV_ERR_ARG;
+  if ((t_rows != nullptr) != (t[PTV_DFB_DX_PRED] != nullptr)) return PTV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const long R = 32L * B;
+  float* demb = M_<float>(t, PTV_DFB_DEMB); float* dPRED = M_<float>(t, PTV_DFB_DPRED);
+  // ---- duration GRU, heads, notes GRU, time GRU: the batched BPTT of the teacher-forced path on the recorded fed tokens
+  PTV_TRY(ptv_decoder_tf_bwd(t_tf, d_tf, stream));
+  // ---- route the token gradients: ground-truth embedding (coin set / slot 0) vs predicted tokens; time tokens likewise
+  PTV_TRY(ptv_route_slices((const float*)T_(t, PTV_DFB_DTOK), demb, dPRED, (const int*)T_(t, PTV_DFB_MASK_TOK), (long)B * E, 15 * 32, 0, stream));
+  PTV_TRY(ptv_route_slices((const float*)T_(t, PTV_DFB_DTOKS) + (long)B * 2 * He, M_<float>(t, PTV_DFB_DXS), M_<float>(t, PTV_DFB_DXSP),
+                           (const int*)T_(t, PTV_DFB_MASK_TIME), (long)B * 2 * He, 32, 0, stream));
+  if (t_rows) {
+    PTV_TRY(ptv_bigru_rows_bwd(t_rows, d_rows, stream));
+    PTV_TRY(ptv_copy2d(dPRED, E, (const float*)T_(t, PTV_DFB_DX_PRED), E, 16 * R, E, 1.f, 1, stream));
+  }
+  // ---- slot 0 of the predicted tokens is the ground-truth <sos> embedding; the rest -> note_embedding
+  PTV_TRY(ptv_copy2d(demb, E, dPRED, E, R, E, 1.f, 1, stream));
+  if (hipMemsetAsync(dPRED, 0, sizeof(float) * R * E, s) != hipSuccess) return PTV_ERR_LAUNCH;
+  float* mh = M_<float>(t, PTV_DFB_MH);
+  PTV_TRY(ptv_multihot((const long*)T_(t, PTV_DFB_XHAT), mh, 136, B, stream));
+  WgradGroup wg(PTV_PREC_BF16, stream);
+  PTV_TRY(wg.add(E, 135, 16 * R, dPRED, E, 0, mh, 136, 0, M_<float>(t, PTV_DFB_G_W_EMB), 135, M_<float>(t, PTV_DFB_G_B_EMB)));
+  return wg.flush();
+}
+
+// ---------------------------------------------------------------------------------------------
 // ptv_vae_loss_fwd / ptv_vae_loss_bwd: functional.VaeLossFn's two launch sequences
 // ---------------------------------------------------------------------------------------------
 extern "C" int ptv_vae_loss_fwd(const void* const* t, const long* d, const double* sc, void* stream) {

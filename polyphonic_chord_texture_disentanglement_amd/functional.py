@@ -322,6 +322,30 @@ def _gru_flags(gates=None, gi=None, gi2=None, dg=None, w=None, ext=None):
 # the same time: every launch waits for the event of the previous one, whatever stream that ran on.
 # ---------------------------------------------------------------------------------------------
 _PERSIST_LAST = {}          # device index -> event recorded after the last persistent launch
+# A backward node that is itself one C entry point made of other composites (functional_free.DecoderStepFn.backward ->
+# ptv_decoder_free_bwd) COLLECTS its stages instead of launching them: while _DEFER is a list, every stage appends (kind, payload, thunk)
+# -- payload = the C tables (and the tensors they point to, kept alive), thunk = the launch as it would have run here.  A stage that cannot
+# go behind the C ABI flushes first (the thunks run, in order, and collecting stops): nothing is ever reordered.
+_DEFER = None
+
+
+def _defer_or_run(kind, payload, thunk):
+    if _DEFER is not None:
+        _DEFER.append((kind, payload, thunk))
+        return 0
+    return thunk()
+
+
+def _defer_flush():
+    """run what was collected so far, in order, and stop collecting"""
+    global _DEFER
+    items, _DEFER = _DEFER, None
+    for kind, payload, thunk in items or ():
+        rc = thunk()
+        if isinstance(rc, int):
+            check(rc, 'deferred ' + kind)
+
+
 _PERSIST_SYNC = []          # (sync words, error index) of recent launches, for persist_check()
 _CLUSTER_SYNC = []          # arrival counters + error word (last) of recent cluster-mode step loops (functional_free), for persist_check()
 _PERSIST_OK = {}
@@ -1009,9 +1033,11 @@ def _bigru_rows_bwd_composite(prec, x3, xf, w, saved, dout, need_dx, dx_acc, sid
     dev = x3.device
     if (prec != 1 or not OVERLAP or side.s == side.main or torch.cuda.is_current_stream_capturing() or H != 128 or I != 128 or T * M < 512
             or xf.dtype != F32 or xf.stride(1) != 1 or xf.stride(0) != I or dout.dtype != F32 or dout.stride(1) != 1):
+        _defer_flush()
         return None
     wt_ih = [_WT(w[0], prec), _WT(w[4], prec)] if need_dx else [None, None]
     if need_dx and (wt_ih[0] is None or wt_ih[1] is None):
+        _defer_flush()
         return None
     lengths = saved[0][3] if len(saved[0]) > 3 else None
     perm = saved[0][4] if len(saved[0]) > 4 else None
@@ -1040,7 +1066,8 @@ def _bigru_rows_bwd_composite(prec, x3, xf, w, saved, dout, need_dx, dx_acc, sid
     evs = _fork_events(_BRB)
     slots[T_['PTV_BRB_FORK_EVENT']], slots[T_['PTV_BRB_JOIN_EVENT']] = evs[0].cuda_event, evs[1].cuda_event
     slots[T_['PTV_BRB_SIDE_STREAM']] = side.s.cuda_stream
-    rc = lib().ptv_bigru_rows_bwd((ctypes.c_void_p * len(slots))(*slots), _larr(dims), stream_ptr())
+    arr_, darr_, sp_ = (ctypes.c_void_p * len(slots))(*slots), _larr(dims), stream_ptr()
+    rc = _defer_or_run('rows_bwd', (arr_, darr_, (tens, G, saved, dout, xf)), lambda: lib().ptv_bigru_rows_bwd(arr_, darr_, sp_))
     _SIDE_DEPTH[1] = 1
     if rc == -3:
         return None
@@ -1288,6 +1315,10 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None, rev_slot=Non
     side = Side(BIGRU_SLOT_BWD if rev_slot is None else rev_slot)
     wts = [_WT(w[1], prec), _WT(w[5], prec)]
     adt = _act_dtype(prec, H)
+    rows_branch = len(saved[0]) > 3 and saved[0][1].dtype == BF16 and saved[0][2] is not None
+    if _DEFER is not None and not (rows_branch and BIGRU_BWD_COMPOSITE and not (
+            T >= 2 and adt == BF16 and wts[0] is not None and wts[1] is not None and persist_supported(2, M, H, T))):
+        _defer_flush()                    # (only the row-kernel composite can be collected: everything else below launches at once)
     if (T >= 2 and adt == BF16 and wts[0] is not None and wts[1] is not None and saved[0][1].dtype == BF16
             and saved[0][2] is not None and persist_supported(2, M, H, T)):
         # BPTT of both directions in ONE persistent launch, then the weight-gradient products of the two on sibling streams
@@ -1990,10 +2021,12 @@ def _decoder_bwd_composite(P, st, z, tok_op, dP, ddur, top_h, side, G):
             or dP.stride(0) != _pad8(NP) or dP.data_ptr() % 16 or not ddur.is_contiguous() or ddur.dtype != F32
             or tok_op.dtype != F32 or not tok_op.is_contiguous() or z.dtype != F32 or not z.is_contiguous()
             or not persist_supported(1, B, Ht, 32) or side.s == side.main or M * 5 < 4096):       # (M * 5 >= 4096: _bgrad's 64-column path, as in C)
+        _defer_flush()
         return None
     wts = [_WT(P[n], prec) for n in ('dec_notes_gru.weight_ih_l0', 'dec_time_to_notes_hid.weight', 'dec_time_gru.weight_ih_l0',
                                       'dec_time_gru.weight_hh_l0', 'z2dec_hid_linear.weight', 'z2dec_in_linear.weight')]
     if any(w is None for w in wts):
+        _defer_flush()
         return None
     Zs, Zi = z.shape[1], st['z_in'].shape[1]
     S = persist_splitk(1, B, Ht)
@@ -2029,6 +2062,7 @@ def _decoder_bwd_composite(P, st, z, tok_op, dP, ddur, top_h, side, G):
     if POISON_DEAD_STEPS and top_h is not None and st.get('live_top') is not None:        # (tests: whatever reads a dead row of these gets NaN -- heads_bwd / the BPTT leave them unwritten)
         _poison(tens['DNSUM'], tens['DGI_N'], tens['DGH_N'], tens['DY16'])
     if st['pitch'].stride(0) != _pad8(NP) or st['idx'].dtype != torch.int32:
+        _defer_flush()
         return None
     slots = [None] * T_['PTV_DTB_COUNT']
     for k, v in tens.items():
@@ -2052,7 +2086,8 @@ def _decoder_bwd_composite(P, st, z, tok_op, dP, ddur, top_h, side, G):
     done.record(cur)                      # creates the handle; the library records it again after the persistent launch
     slots[T_['PTV_DTB_RECORD_EVENT']] = done.cuda_event
     mark('dec_bwd:composite')
-    rc = lib().ptv_decoder_tf_bwd((ctypes.c_void_p * len(slots))(*slots), _larr(dims), stream_ptr())
+    arr_, darr_, sp_ = (ctypes.c_void_p * len(slots))(*slots), _larr(dims), stream_ptr()
+    rc = _defer_or_run('tf_bwd', (arr_, darr_, tens), lambda: lib().ptv_decoder_tf_bwd(arr_, darr_, sp_))
     _SIDE_DEPTH[1] = 1                    # (the library's priority state as the call leaves it)
     if rc == -3:
         return None
@@ -2144,6 +2179,7 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
         res = _decoder_bwd_composite(P, st, z, tok_op, dP, ddur, top_h, side, G)
         if res is not None:
             return res
+    _defer_flush()                        # (the launch-by-launch sequencing below runs at once)
 
     # ---- duration GRU (5 steps) ----
     w_out = P['dur_out_linear.weight']

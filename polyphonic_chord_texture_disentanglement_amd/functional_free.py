@@ -227,6 +227,32 @@ def _decoder_free_fwd_composite(P, z, xs, tok0_src, tok0_lds, pk, wl, wr, io_of,
     return True
 
 
+def _decoder_free_bwd_call(items, dTOK, dTOKS, demb, dPRED, dxs, dxsp, mask_tok, mask_time, dx_pred, xhat, mh, gw, gb, B, E, He):
+    """the collected stages of DecoderStepFn.backward through ptv_decoder_free_bwd (one C call); True when it ran"""
+    import ctypes
+    if 'bt' not in _DFF:
+        from ._lib import header_enum
+        _DFF['bt'], _DFF['bd'] = header_enum('PtvDfbTensor'), header_enum('PtvDfbDim')
+    T_, D_ = _DFF['bt'], _DFF['bd']
+    tf = [p for k, p, _ in items if k == 'tf_bwd'][0]
+    rows = [p for k, p, _ in items if k == 'rows_bwd']
+    slots = [None] * T_['PTV_DFB_COUNT']
+    for k, v in (('DTOK', dTOK), ('DTOKS', dTOKS), ('DEMB', demb), ('DPRED', dPRED), ('DXS', dxs), ('DXSP', dxsp), ('MASK_TOK', mask_tok),
+                 ('MASK_TIME', mask_time), ('DX_PRED', dx_pred), ('XHAT', xhat), ('MH', mh), ('G_W_EMB', gw), ('G_B_EMB', gb)):
+        if v is not None:
+            slots[T_['PTV_DFB_' + k]] = v.data_ptr()
+    dvals = [0] * D_['PTV_DFB_D_COUNT']
+    dvals[D_['PTV_DFB_D_B']], dvals[D_['PTV_DFB_D_E']], dvals[D_['PTV_DFB_D_HE']] = B, E, He
+    if dx_pred is not None and not dx_pred.is_contiguous():
+        return False
+    F_._chain_prio()
+    rc = lib().ptv_decoder_free_bwd(tf[0], tf[1], rows[0][0] if rows else None, rows[0][1] if rows else None,
+                                    (ctypes.c_void_p * len(slots))(*slots), F_._larr(dvals), stream_ptr())
+    F_.check(rc, 'ptv_decoder_free_bwd')
+    _DFF['bcalls'] = _DFF.get('bcalls', 0) + 1
+    return True
+
+
 class DecoderStepFn(torch.autograd.Function):
     """(z, emb [16,32,B,E] or None, xs [32B,2He] or None, coins, inference, force, prec, *params)
     -> pitch [15,32,B,130], dur [15*32*B,5,2], xhat int64 [B,32,16,6] (predicted grid), dur idx"""
@@ -498,49 +524,69 @@ class DecoderStepFn(torch.autograd.Function):
         PRED = st['PRED']
         coin_notes, coin_time = st['coins']
         sp = stream_ptr()
-        # ---- duration GRU, heads, notes GRU, time GRU: the batched BPTT of the teacher-forced path on the recorded fed tokens
-        dz, dTOK, dTOKS, G0, side = F_.decoder_bwd_core(P, st, z, st['TOK'].view(M, E), dpitch, ddur)
-        G = {n: None for n in FREE_PARAM_NAMES}
-        G.update(G0)
+        # ---- the node behind ONE C entry point (ptv_decoder_free_bwd): its stages are COLLECTED (functional._DEFER) instead of launched -- the
+        # decoder's composite backward, the two routings, the re-summarisation bi-GRU's composite backward, the note_embedding gradients --
+        # and go out as one call; a stage that cannot go behind the C ABI flushes what was collected and the rest launches at once (same
+        # order, same bits either way)
+        collect = (FREE_COMPOSITE and prec == 1 and F_.DEC_BWD_COMPOSITE and F_.BIGRU_BWD_COMPOSITE and F_.WGRAD_FUSE_BIAS
+                   and not torch.cuda.is_current_stream_capturing() and F_._DEFER is None)
+        if collect:
+            F_._DEFER = []
+        try:
+            # ---- duration GRU, heads, notes GRU, time GRU: the batched BPTT of the teacher-forced path on the recorded fed tokens
+            dz, dTOK, dTOKS, G0, side = F_.decoder_bwd_core(P, st, z, st['TOK'].view(M, E), dpitch, ddur)
+            G = {n: None for n in FREE_PARAM_NAMES}
+            G.update(G0)
 
-        def wgrad(name, dy, x, sub=None):
-            if G[name] is None:
-                G[name] = _gbuf(P[name])
-            out = G[name] if sub is None else G[name][:, sub]
-            gemm(dy, x, out, ta=True, tb=True, acc=True, prec=prec)
+            # ---- route token gradients: ground-truth embedding (coin true / slot 0) vs predicted tokens
+            demb = _zeros(16, R, E, dev=dev)
+            dPRED = _zeros(16, R, E, dev=dev)
+            mask_tok = _route_mask(('tok', tuple(tuple(bool(v) for v in row) for row in coin_notes)), dev)
+            F_._defer_or_run('route', None, lambda: call('ptv_route_slices', ptr(dTOK), ptr(demb), ptr(dPRED), ptr(mask_tok), B * E, 15 * 32, 0, sp))
 
-        def bgrad(name, a):
-            if G[name] is None:
-                G[name] = _bgrad(P[name], a)
-            else:
-                colsum(G[name].view(1, -1), a)
+            # ---- time tokens: ground-truth summaries (coin true) vs re-summarised predictions
+            dxs = _zeros(32, B, 2 * He, dev=dev)
+            dxsp = _zeros(32, B, 2 * He, dev=dev)
+            mask_time = _route_mask(('time', tuple(bool(v) for v in coin_time)), dev)
+            F_._defer_or_run('route', None, lambda: call('ptv_route_slices', ptr(dTOKS[1:]), ptr(dxs), ptr(dxsp), ptr(mask_time), B * 2 * He, 32, 0, sp))
+            dx_pred = None
+            if st['XH'] is not None:
+                wE = [P['dec_notes_emb_gru.' + n] for n in EMB_GRU]
+                saved = [(st['XH'][d_], st['XG'][d_], st['XH16'][d_]) + ((st['plen'] if st['skipped'] else None,) if st['XH16'][d_] is not None else ()) for d_ in range(2)]
+                ge, dx_pred = _bigru_backward(prec, PRED, wE, saved, dxsp.view(R, 2 * He), True)
+                for n, gg in zip(EMB_GRU, ge):
+                    G['dec_notes_emb_gru.' + n] = gg
+                F_._defer_or_run('copy', None, lambda: copy2d(dPRED.view(16 * R, E), dx_pred.view(16 * R, E), acc=True))
 
-        # ---- route token gradients: ground-truth embedding (coin true / slot 0) vs predicted tokens
-        demb = _zeros(16, R, E, dev=dev)
-        dPRED = _zeros(16, R, E, dev=dev)
-        mask_tok = _route_mask(('tok', tuple(tuple(bool(v) for v in row) for row in coin_notes)), dev)
-        call('ptv_route_slices', ptr(dTOK), ptr(demb), ptr(dPRED), ptr(mask_tok), B * E, 15 * 32, 0, sp)
+            # ---- predicted tokens -> note_embedding (slot 0 is the ground-truth <sos> embedding); weight and bias gradient in ONE pass
+            # over the gradient matrix (ptv_wgrad's colsum_a)
+            mh = _empty(B * 512, 136, dev=dev)
+            for n in ('note_embedding.weight', 'note_embedding.bias'):
+                if G[n] is None:
+                    G[n] = _gbuf(P[n])
 
-        # ---- time tokens: ground-truth summaries (coin true) vs re-summarised predictions
-        dxs = _zeros(32, B, 2 * He, dev=dev)
-        dxsp = _zeros(32, B, 2 * He, dev=dev)
-        mask_time = _route_mask(('time', tuple(bool(v) for v in coin_time)), dev)
-        call('ptv_route_slices', ptr(dTOKS[1:]), ptr(dxs), ptr(dxsp), ptr(mask_time), B * 2 * He, 32, 0, sp)
-        if st['XH'] is not None:
-            wE = [P['dec_notes_emb_gru.' + n] for n in EMB_GRU]
-            saved = [(st['XH'][d_], st['XG'][d_], st['XH16'][d_]) + ((st['plen'] if st['skipped'] else None,) if st['XH16'][d_] is not None else ()) for d_ in range(2)]
-            ge, dx_pred = _bigru_backward(prec, PRED, wE, saved, dxsp.view(R, 2 * He), True)
-            for n, gg in zip(EMB_GRU, ge):
-                G['dec_notes_emb_gru.' + n] = gg
-            copy2d(dPRED.view(16 * R, E), dx_pred.view(16 * R, E), acc=True)
-
-        # ---- predicted tokens -> note_embedding (slot 0 is the ground-truth <sos> embedding)
-        copy2d(demb[0], dPRED[0], acc=True)
-        dPRED[0].zero_()
-        mh = _empty(B * 512, 136, dev=dev)
-        call('ptv_multihot', ptr(st['xhat']), ptr(mh), 136, B, sp)
-        wgrad('note_embedding.weight', dPRED.view(16 * R, E), mh[:, :135])
-        bgrad('note_embedding.bias', dPRED.view(16 * R, E))
+            def tail():
+                copy2d(demb[0], dPRED[0], acc=True)
+                dPRED[0].zero_()
+                call('ptv_multihot', ptr(st['xhat']), ptr(mh), 136, B, sp)
+                F_.wgrad_bias(dPRED.view(16 * R, E), mh[:, :135], G['note_embedding.weight'], G['note_embedding.bias'], prec)
+            F_._defer_or_run('tail', None, tail)
+            items = F_._DEFER
+            if items is None and collect:
+                _DFF['bflush'] = 'a stage flushed'
+            if items is not None:
+                F_._DEFER = None
+                kinds = [k for k, _, _ in items]
+                want = ['tf_bwd', 'route', 'route'] + (['rows_bwd', 'copy'] if dx_pred is not None else []) + ['tail']
+                if kinds == want and _decoder_free_bwd_call(items, dTOK, dTOKS, demb, dPRED, dxs, dxsp, mask_tok, mask_time, dx_pred, st['xhat'], mh,
+                                                            G['note_embedding.weight'], G['note_embedding.bias'], B, E, He):
+                    pass
+                else:                                       # (not the whole pattern: the collected stages run as they are, in order)
+                    _DFF['bflush'] = kinds
+                    F_._DEFER = items
+                    F_._defer_flush()
+        finally:
+            F_._DEFER = None
 
         side.join()
         for s2 in getattr(side, 'extra', []):

@@ -823,17 +823,21 @@ def test_free_running_training_batched_recompute_equals_streamed_states(monkeypa
         assert (g1[n] - g0[n]).abs().max() <= 0.04 * g0[n].abs().max() + 1e-6, n
 
 
-@pytest.mark.parametrize('B,tfr', [(40, 0.0), (24, 0.5), (64, 0.0)])
-def test_decoder_free_composite_entry_point_equals_python_sequencing(B, tfr, monkeypatch):
-    """ptv_decoder_free_fwd (csrc/composite.hip; SURVEY 8b's decoder_free_fwd): the free-running / scheduled-sampling decoder forward --
+@pytest.mark.parametrize('B,tfr,bwd_call', [(40, 0.0, None), (24, 0.5, None), (512, 0.0, True), (512, 0.5, True)])
+def test_decoder_free_composite_entry_point_equals_python_sequencing(B, tfr, bwd_call, monkeypatch):
+    """ptv_decoder_free_fwd / ptv_decoder_free_bwd (csrc/composite.hip; SURVEY 8b's decoder_free_{fwd,bwd}): the free-running /
+    scheduled-sampling decoder node as ONE C call per direction.  Forward --
     prologue, the 32-step loop (time-GRU cell, note loop, re-summarisation or the ground-truth summary by the time coins), the batched
     recompute -- as ONE C call makes the same launches as functional_free.DecoderStepFn's own sequencing: losses, the predicted grid and
-    every gradient bit-identical; a ragged last panel, cluster mode, mixed coins (tfr = 0.5: both token routes), and inference_decode"""
+    every gradient bit-identical; a ragged last panel, cluster mode, mixed coins (tfr = 0.5: both token routes), the benched batch, and
+    inference_decode"""
     import random
     from polyphonic_chord_texture_disentanglement_amd import functional_free as FF_
+    from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
     m = M.DisentangleVAE.init_model(torch.device(DEV))
     m.load_state_dict(full_params())
     m.to(DEV).set_precision('bf16')
+    opt = FusedClipAdam(m.parameters(), lr=1e-3)            # (the bf16 weight shadows the backward composites read are the optimiser's)
     x, c, pr = synth_batch(B, 77)
     xt, ct, prt = (torch.from_numpy(a).to(DEV) for a in (x, c, pr))
     eps = {n: torch.randn(B, 256, generator=torch.Generator().manual_seed(i)).to(DEV) for i, n in enumerate(('chd', 'rhy'))}
@@ -841,14 +845,18 @@ def test_decoder_free_composite_entry_point_equals_python_sequencing(B, tfr, mon
     for comp in (False, True):
         monkeypatch.setattr(FF_, 'FREE_COMPOSITE', comp)
         FF_._DFF.pop('calls', None)
+        FF_._DFF.pop('bcalls', None)
         random.seed(3)
         m.eps_source = lambda name, shape, device: eps[name]
-        m.zero_grad()
+        opt.zero_grad()
         outs = m.run(xt, ct, prt, tfr, tfr, tfr)
         losses = m.loss_function(xt, ct, *outs, 0.1, [1, 0.5])
         losses[0].backward()
         torch.cuda.synchronize()
-        assert bool(FF_._DFF.get('calls')) == comp                 # the composite ran exactly when asked to
+        assert bool(FF_._DFF.get('calls')) == comp                 # the composites ran exactly when asked to: forward ...
+        if bwd_call:                                               # ... and backward (ptv_decoder_free_bwd: when every stage of the node has its
+            assert bool(FF_._DFF.get('bcalls')) == comp            # composite -- at small batches the re-summarisation BPTT runs on the persistent
+                                                                   # kernels, launched from Python: the collected stages then run as they are)
         with torch.no_grad():
             z = torch.cat([outs[2].mean, outs[3].mean], -1).detach()
             est = m.inference_decode(z[:, :256], z[:, 256:])
