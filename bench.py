@@ -173,11 +173,37 @@ def extras(dev, B, rank):
             opt.clip_and_step(1.0)
         return fn
 
+    import ctypes
+    from polyphonic_chord_texture_disentanglement_amd._lib import lib as _lib_
+    L = _lib_()
+
+    def note_loop_record(rows):
+        """the free-running note loop (ptv_free_note_loop: 15 note steps of every 16-sample panel per launch, 32 launches per forward) on the
+        MFMA roofline by its algorithmic FLOPs -- and as what it is: a latency chain, microseconds per dependent note step"""
+        cnt, ms, fl = ctypes.c_long(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        L.ptv_prof_read_tag(7, ctypes.byref(cnt), ctypes.byref(ms), ctypes.byref(fl))
+        if not cnt.value:
+            return None
+        tfs = fl.value / (ms.value * 1e-3) / 1e12
+        return {'bound': 'mfma', 'kernel': 'note_loop_kernel / note_loop2_kernel (csrc/freerun.hip), B = %d rows' % rows, 'achieved': round(tfs, 2),
+                'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(tfs / 2500.0, 5), 'launches': cnt.value, 'avg_us': round(ms.value / cnt.value * 1e3, 1),
+                'us_per_note_step': round(ms.value / cnt.value * 1e3 / 15, 2),
+                'bound_measured': 'latency: 480 dependent note steps per forward (gate products -> state all-gather -> pitch head -> argmax -> '
+                                  'dur_hid -> 5 duration steps -> token embedding), weights streamed from L2 per panel'}
+
+    def timed_with_note_loop(fn, steps, warm, rows):
+        t_ = _measure(fn, steps, warm)
+        L.ptv_prof_reset(); L.ptv_prof_enable(64)            # tag 7, two more steps outside the timing
+        fn(0); fn(1)
+        torch.cuda.synchronize()
+        L.ptv_prof_enable(0)
+        return t_, note_loop_record(rows)
+
     random.seed(7)
     m, opt, data = train_setup('bf16')
-    t = _measure(train_fn(m, opt, data, 0.0), 4, 2)
+    t, nl = timed_with_note_loop(train_fn(m, opt, data, 0.0), 4, 2, B)
     out['train_free_running_tfr0'] = {'samples_per_s': round(B / t, 1), 'ms_per_step': round(t * 1e3, 2), 'batch': B, 'dtype': 'bf16',
-                                      'note': "the reference's train.py schedule from its third batch on (SURVEY 0.4)"}
+                                      'note': "the reference's train.py schedule from its third batch on (SURVEY 0.4)", 'roofline_note_loop': nl}
     del m, opt, data
     torch.cuda.empty_cache()
     # BASELINE configs[4] names 1024 samples per GPU for this schedule: the step loop is a latency chain per 16-sample panel, so the larger
@@ -187,9 +213,10 @@ def extras(dev, B, rank):
     try:
         random.seed(7)
         m, opt, data = train_setup('bf16')
-        t = _measure(train_fn(m, opt, data, 0.0), 4, 2)
+        t, nl = timed_with_note_loop(train_fn(m, opt, data, 0.0), 4, 2, B)
         out['train_free_running_tfr0_b1024'] = {'samples_per_s': round(B / t, 1), 'ms_per_step': round(t * 1e3, 2), 'batch': B, 'dtype': 'bf16',
-                                                'note': "configs[4]'s per-GPU batch on train.py's schedule from its third batch on (tfr = 0)"}
+                                                'note': "configs[4]'s per-GPU batch on train.py's schedule from its third batch on (tfr = 0)",
+                                                'roofline_note_loop': nl}
         del m, opt, data
     finally:
         B = Bsave
@@ -285,8 +312,14 @@ def extras(dev, B, rank):
         with torch.no_grad():
             m.decoder(z, True, None, None, 0., 0.)
     t = _measure(dec, 3, 2)
+    m.decoder.use_graph = False                              # (the note loop's events are recorded on eager launches)
+    L.ptv_prof_reset(); L.ptv_prof_enable(64)
+    dec(0)
+    torch.cuda.synchronize()
+    L.ptv_prof_enable(0)
     out['decode_free_running_b2048_graph'] = {'samples_per_s': round(Bd / t, 1), 'ms_per_decode': round(t * 1e3, 2), 'batch': Bd,
-                                              'note': 'configs[3]: inference_decode step loop replayed from a hipGraph'}
+                                              'note': 'configs[3]: inference_decode step loop replayed from a hipGraph',
+                                              'roofline_note_loop': note_loop_record(Bd)}
     return out
 
 

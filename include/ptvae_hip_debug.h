@@ -21,7 +21,7 @@ int ptv_debug_pin_cus(int nwg, int lds_bytes, int usec, void* stream);
  * Optional launch timing (bench.py roofline): HIP events recorded on the launch stream around every launch of the enabled
  * kernel families.  Tags: 1 = GRU forward step, 2 = GRU backward step (csrc/gru.hip), 3 = row-partitioned persistent GRU forward,
  * 4 = its BPTT (csrc/notes_roles.hip / notes_persist.hip; M = rows R), 5 = weight-gradient products (ptv_wgrad / ptv_wgrad_cat: product +
- * reduction launches of one call), 6 = BPTT of the persistent small-M recurrences (ptv_gru_persist_bwd*).  ptv_prof_enable takes a bit mask
+ * reduction launches of one call), 6 = BPTT of the persistent small-M recurrences (ptv_gru_persist_bwd*), 7 = the free-running note loop (ptv_free_note_loop: 15 note steps per launch).  ptv_prof_enable takes a bit mask
  * (bit tag-1), ptv_prof_config restricts tags 1-4 to launches with the given (M, H) (0 = any).  ptv_prof_read_tag waits for the recorded events and returns the number of launches of
  * one tag (0 = all), their summed duration and their summed algorithmic MFMA FLOPs.
  */

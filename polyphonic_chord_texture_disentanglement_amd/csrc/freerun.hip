@@ -20,6 +20,7 @@
 // Specialised to the init_model() geometry (E = 128, Hn = 512, Hd = 64, He = 128, 130 pitches), bf16 MFMA operands, fp32
 // state / logits -- the bf16 precision policy of the teacher-forced path.  Other configurations use the step loop.
 #include "common.hpp"
+#include "prof.hpp"
 #include "gemm_core.hpp"
 #include "../../include/ptvae_hip.h"
 
@@ -1106,8 +1107,12 @@ extern "C" int ptv_free_note_loop(const void* const* w, const void* const* io, l
     if ((S != 2 && S != 4) || split || !io[19] || !io[20] || panels * S > ncu) return PTV_ERR_UNSUPPORTED;
     a.S = S; a.xch = (__bf16*)io[19]; a.cnt = (unsigned*)io[20];
   }
+  // bench.py's roofline record of the step loop (tag 7): 15 note steps per launch; algorithmic MFMA work of a launch = 15 note steps x B rows x
+  // (gate products 2*3Hn*(Hn+E) + pitch head 2*130*Hn + dur_hid 2*64*(Hn+130) + 5 duration steps 2*3*64*64 + token embedding 2*128*135)
+  const int pi = prof::want(7, B, FHN) ? prof::begin((hipStream_t)stream) : -1;
   if (!split) hipLaunchKernelGGL(note_loop_kernel, dim3(a.S > 1 ? (panels + 7) / 8 * 8 * a.S : panels), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(note_loop2_kernel, dim3(panels), dim3(512), 0, (hipStream_t)stream, a);
+  if (pi >= 0) prof::end(pi, (hipStream_t)stream, 15.0 * B * (2.0 * 3 * FHN * (FHN + 128) + 2.0 * 130 * FHN + 2.0 * 64 * (FHN + 130) + 5 * 2.0 * 3 * 64 * 64 + 2.0 * 128 * 135));
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
