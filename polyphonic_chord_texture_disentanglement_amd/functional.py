@@ -1069,8 +1069,8 @@ def _bigru_rows_bwd_composite(prec, x3, xf, w, saved, dout, need_dx, dx_acc, sid
     arr_, darr_, sp_ = (ctypes.c_void_p * len(slots))(*slots), _larr(dims), stream_ptr()
     rc = _defer_or_run('rows_bwd', (arr_, darr_, (tens, G, saved, dout, xf)), lambda: lib().ptv_bigru_rows_bwd(arr_, darr_, sp_))
     _SIDE_DEPTH[1] = 1
-    if rc == -3:
-        return None
+    if rc == -3:                          # (H = I = 128 was checked above: ptv_bigru_rows_bwd's only refusal)
+        raise RuntimeError('ptv_bigru_rows_bwd refused a configuration its Python-side checks accepted')
     check(rc, 'ptv_bigru_rows_bwd')
     _BRB['calls'] = _BRB.get('calls', 0) + 1
     return G[0:4] + G[4:8], (dx.view(T, M, I) if need_dx else None)
@@ -1260,8 +1260,8 @@ def _bigru_bwd_composite(prec, x3, xf, w, saved, dout, need_dx, dx_acc, wts, sid
     slots[T_['PTV_BGB_RECORD_EVENT']] = done.cuda_event
     rc = lib().ptv_bigru_final_bwd((ctypes.c_void_p * len(slots))(*slots), _larr(dims), stream_ptr())
     _SIDE_DEPTH[1] = 1
-    if rc == -3:
-        return None
+    if rc == -3:                          # (persist_supported() was asked before the arena views were taken)
+        raise RuntimeError('ptv_bigru_final_bwd refused a configuration its Python-side checks accepted')
     check(rc, 'ptv_bigru_final_bwd')
     _PERSIST_LAST[cur.device.index] = done
     _BGB['calls'] = _BGB.get('calls', 0) + 1
@@ -2025,7 +2025,9 @@ def _decoder_bwd_composite(P, st, z, tok_op, dP, ddur, top_h, side, G):
         return None
     wts = [_WT(P[n], prec) for n in ('dec_notes_gru.weight_ih_l0', 'dec_time_to_notes_hid.weight', 'dec_time_gru.weight_ih_l0',
                                       'dec_time_gru.weight_hh_l0', 'z2dec_hid_linear.weight', 'z2dec_in_linear.weight')]
-    if any(w is None for w in wts):
+    # (every reason to decline is checked HERE, before a gradient buffer is taken from the arena: GradArena.take hands a view out once per
+    # step, a fallback after it would get fresh non-arena buffers and the deferred join would turn into a join -- round-5 advice)
+    if any(w is None for w in wts) or st['pitch'].stride(0) != _pad8(NP) or st['idx'].dtype != torch.int32:
         _defer_flush()
         return None
     Zs, Zi = z.shape[1], st['z_in'].shape[1]
@@ -2061,9 +2063,6 @@ def _decoder_bwd_composite(P, st, z, tok_op, dP, ddur, top_h, side, G):
             'SYNC': _persist_sync(1, dev)}
     if POISON_DEAD_STEPS and top_h is not None and st.get('live_top') is not None:        # (tests: whatever reads a dead row of these gets NaN -- heads_bwd / the BPTT leave them unwritten)
         _poison(tens['DNSUM'], tens['DGI_N'], tens['DGH_N'], tens['DY16'])
-    if st['pitch'].stride(0) != _pad8(NP) or st['idx'].dtype != torch.int32:
-        _defer_flush()
-        return None
     slots = [None] * T_['PTV_DTB_COUNT']
     for k, v in tens.items():
         slots[T_['PTV_DTB_' + k]] = ptr(v)
@@ -2087,10 +2086,12 @@ def _decoder_bwd_composite(P, st, z, tok_op, dP, ddur, top_h, side, G):
     slots[T_['PTV_DTB_RECORD_EVENT']] = done.cuda_event
     mark('dec_bwd:composite')
     arr_, darr_, sp_ = (ctypes.c_void_p * len(slots))(*slots), _larr(dims), stream_ptr()
-    rc = _defer_or_run('tf_bwd', (arr_, darr_, tens), lambda: lib().ptv_decoder_tf_bwd(arr_, darr_, sp_))
+    # (payload: the tables AND everything they point to that nothing else keeps alive until a collected call runs -- the tensors, and the
+    # previous persistent launch's event, which _PERSIST_LAST drops below: a destroyed hipEvent_t in the table was a segfault)
+    rc = _defer_or_run('tf_bwd', (arr_, darr_, tens, prev, done, evs), lambda: lib().ptv_decoder_tf_bwd(arr_, darr_, sp_))
     _SIDE_DEPTH[1] = 1                    # (the library's priority state as the call leaves it)
-    if rc == -3:
-        return None
+    if rc == -3:                          # (the checks above mirror ptv_decoder_tf_bwd's: a late refusal would leave taken arena views behind)
+        raise RuntimeError('ptv_decoder_tf_bwd refused a configuration its Python-side checks accepted')
     check(rc, 'ptv_decoder_tf_bwd')
     _PERSIST_LAST[cur.device.index] = done
     _DTB['calls'] = _DTB.get('calls', 0) + 1
@@ -2428,8 +2429,8 @@ def _chord_decoder_bwd_composite(P, st, z, droot, dchroma, dbass):
         slots[T_['PTV_CDB_RECORD_EVENT']] = done.cuda_event
     _chain_prio()
     rc = lib().ptv_chord_decoder_bwd((ctypes.c_void_p * len(slots))(*slots), _larr(dims), stream_ptr())
-    if rc == -3:
-        return None
+    if rc == -3:                          # (persist_supported() was asked before the arena views were taken)
+        raise RuntimeError('ptv_chord_decoder_bwd refused a configuration its Python-side checks accepted')
     check(rc, 'ptv_chord_decoder_bwd')
     if done is not None:
         _PERSIST_LAST[cur.device.index] = done

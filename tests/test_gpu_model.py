@@ -823,7 +823,7 @@ def test_free_running_training_batched_recompute_equals_streamed_states(monkeypa
         assert (g1[n] - g0[n]).abs().max() <= 0.04 * g0[n].abs().max() + 1e-6, n
 
 
-@pytest.mark.parametrize('B,tfr,bwd_call', [(40, 0.0, None), (24, 0.5, None), (512, 0.0, True), (512, 0.5, True)])
+@pytest.mark.parametrize('B,tfr,bwd_call', [(8, 0.5, None), (8, 0.0, None), (40, 0.0, None), (24, 0.5, None), (512, 0.0, True), (512, 0.5, True)])
 def test_decoder_free_composite_entry_point_equals_python_sequencing(B, tfr, bwd_call, monkeypatch):
     """ptv_decoder_free_fwd / ptv_decoder_free_bwd (csrc/composite.hip; SURVEY 8b's decoder_free_{fwd,bwd}): the free-running /
     scheduled-sampling decoder node as ONE C call per direction.  Forward --
