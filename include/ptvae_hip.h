@@ -271,6 +271,15 @@ int ptv_reparam_kl_bwd(const float* mu, const float* sd, const float* eps, const
  *   ptv_loss_bwd_scales: upstream grads of the 11 scalars -> 7 per-component scale factors (device)
  */
 int ptv_pianotree_targets(const long* x, int B, int step_major, int* pitch_t, int* dur_t, int* counts, void* stream);
+/* the same + row_live (int32 [32 B], ZEROED by the caller, or NULL): row (t, b)'s number of live note steps = 1 + the last note step at
+ * which it holds a target (what the teacher-forced decoder needs of that row when only the loss consumes it) */
+int ptv_pianotree_targets_rows(const long* x, int B, int step_major, int* pitch_t, int* dur_t, int* counts, int* row_live, void* stream);
+/* rows by index, `planes` planes of `rows` rows of row_words 4-byte words: gather dst[pl][p] = src[pl][idx[p]], scatter dst[pl][idx[p]] =
+ * src[pl][p] (plane strides in words).  The decoder's rows in length-sorted order and back. */
+int ptv_gather_rows(void* dst, const void* src, const int* idx, long rows, int row_words, long src_plane_words, long dst_plane_words, int planes,
+                    void* stream);
+int ptv_scatter_rows(void* dst, const void* src, const int* idx, long rows, int row_words, long src_plane_words, long dst_plane_words, int planes,
+                     void* stream);
 int ptv_chord_targets(const float* c, int B, int step_major, int* root_t, int* chroma_t, int* bass_t, void* stream);
 int ptv_ce_fwd(const float* logits, long ld, const int* targets, long rows, int C, int ignore_index, float* nll_sum, void* stream);
 int ptv_ce_bwd(const float* logits, long ld, const int* targets, long rows, int C, int ignore_index, const float* gscale,
@@ -328,6 +337,13 @@ int ptv_dur_gru_fwd_top(int H, long M, const float* h0, long ld_h0, const float*
                         float* hall, long plane_h, void* hall16, void* gates, long plane_g, long step_g, int gates_bf16,
                         float* dur_out, long ld_out, int* idx, long idx_stride, const int* force, long force_stride,
                         const int* m_top, long m_unit, void* stream);
+/* ... and with the rows of every note step sorted by descending length (row_len int32 [m_unit]): 16-row tiles whose first row has no target
+ * at their note step are passed over (outputs unwritten) */
+int ptv_dur_gru_fwd_rows(int H, long M, const float* h0, long ld_h0, const float* w_hh, const float* b_hh,
+                         const float* tab0, const float* tab, const float* w_out, const float* b_out,
+                         float* hall, long plane_h, void* hall16, void* gates, long plane_g, long step_g, int gates_bf16,
+                         float* dur_out, long ld_out, int* idx, long idx_stride, const int* force, long force_stride,
+                         const int* m_top, long m_unit, const int* row_len, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Backward of the 5-step duration GRU (autograd of ptvae.py:353-367) in ONE kernel (bf16 gates, H = 64): dh
@@ -372,6 +388,14 @@ int ptv_heads_fwd_top(const void* hn16, const void* wp_packed, const void* wdh_p
                       void* stream);
 int ptv_heads_bwd(float* dp, long ldp, const float* dhd0, const void* wdpT_packed, const void* wcat_packed, void* dnsum16,
                   int blocked, void* dy16, const int* m_top, long m_unit, long M, void* stream);
+/* ... with the rows of every note step sorted by descending length (row_len int32 [m_unit], needs m_top): 128-row blocks whose first row
+ * has no target at their note step are passed over -- forward: their logits are written as zeros (finite operands of a weight-gradient
+ * product), hd0 / hd16 stay unwritten; backward: their dy16 rows are zeros, their dnsum rows unwritten */
+int ptv_heads_fwd_rows(const void* hn16, const void* wp_packed, const void* wdh_packed, const void* wdp_packed, const float* b_p,
+                       const float* b_dh, float* pitch, long ldp, float* hd0, void* hd16, long M, const int* m_top, long m_unit,
+                       const int* row_len, void* stream);
+int ptv_heads_bwd_rows(float* dp, long ldp, const float* dhd0, const void* wdpT_packed, const void* wcat_packed, void* dnsum16,
+                       int blocked, void* dy16, const int* m_top, long m_unit, const int* row_len, long M, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * COMPOSITE: PtvaeDecoder.decoder, teacher-forced, FORWARD -- ptvae.py:430-496 with decode_notes (:370-428) and decode_note (:336-368)
@@ -424,6 +448,13 @@ enum PtvDtfTensor {
   PTV_DTF_LIVE_TOP,       /* device int32 or NULL: the caller uses the outputs of the note steps 0 .. *LIVE_TOP only (a loss that ignores the
                            * padded note slots, ptvae.py:498-511): the notes GRU, the heads and the duration GRU leave the later steps' rows of
                            * HN16 / GATES_N / PITCH / HD / HD16 / GATES_D / DUR / IDX unwritten */
+  /* rows sorted by length (round 6: per-row dead work; all four or none).  With them the notes GRU, the heads and the duration GRU work on
+   * the decoder's rows in the order PERM -- row p of their tensors is row PERM[p] of the time states / tokens -- and pass over the
+   * (note step, 64-row panel) pairs whose longest row has no target there; the loss must be given its targets in the same order. */
+  PTV_DTF_PERM,           /* int32 [R]: rows by descending ROW_LEN (ptv_rows_by_length), or NULL */
+  PTV_DTF_ROW_LEN,        /* int32 [R]: live note steps of the row at position p (ptv_pianotree_targets_rows, gathered by PERM) */
+  PTV_DTF_NS16S,          /* out [R, Ht] bf16: the time states NS16[1:] gathered by PERM (operand of the hoisted products, kept for the backward) */
+  PTV_DTF_TOK_S,          /* out [15, R, E] fp32: the fed tokens EMB[:15] gathered by PERM */
   PTV_DTF_COUNT
 };
 enum PtvDtfDim { PTV_DTF_D_B = 0, PTV_DTF_D_E, PTV_DTF_D_HE, PTV_DTF_D_HT, PTV_DTF_D_HN, PTV_DTF_D_HD, PTV_DTF_D_NP, PTV_DTF_D_ZS, PTV_DTF_D_ZI,
@@ -533,6 +564,12 @@ enum PtvDtbTensor {
   PTV_DTB_WAIT_EVENT, PTV_DTB_RECORD_EVENT,              /* hipEvent_t: persistent launches take turns */
   PTV_DTB_SIDE_STREAM,    /* hipStream_t of the sibling stream */
   PTV_DTB_FORK_EVENT0, PTV_DTB_FORK_EVENT1, PTV_DTB_FORK_EVENT2, PTV_DTB_FORK_EVENT3,   /* hipEvent_t, one per fork */
+  /* the forward ran on rows sorted by length (PTV_DTF_PERM ...): all or none.  NS16 / TOK_OP are then the gathered copies the forward left
+   * (NS16: slot 0 unused, rows from NS16S - B*Ht ... the table holds NS16S itself in PTV_DTB_NS16S), DNS / DTOK come out in natural row order */
+  PTV_DTB_PERM, PTV_DTB_ROW_LEN,
+  PTV_DTB_NS16S,          /* [R, Ht] bf16 gathered time states (operand of the weight_ih / time_to_notes gradients) */
+  PTV_DTB_DNS_S,          /* scratch [R, Ht] fp32: the gradient of the time states in sorted row order, scattered into DNS */
+  PTV_DTB_DTOK_S,         /* scratch [15, R, E] fp32: the token gradient in sorted row order, scattered into DTOK */
   PTV_DTB_COUNT
 };
 enum PtvDtbDim { PTV_DTB_D_B = 0, PTV_DTB_D_E, PTV_DTB_D_HE, PTV_DTB_D_HT, PTV_DTB_D_HN, PTV_DTB_D_HD, PTV_DTB_D_NP, PTV_DTB_D_ZS, PTV_DTB_D_ZI,
@@ -831,6 +868,15 @@ int ptv_notes_gru_persist_bwd(const void* wt, const void* HN16, const void* gate
  * zero rows of dgi / dgh written (without the bound: 64 KB read and 256 KB of zeros written per 64-row panel and dead step). */
 int ptv_notes_gru_persist_bwd_top(const void* wt, const void* HN16, const void* gates, const void* ext, void* dgi, void* dgh,
                                   float* dh0, void* scratch, long R, int T, const int* bound, int* top_step, void* stream);
+/* both with the rows sorted by descending length (row_len int32 [R] = live note steps of the row at each position, or NULL): a 64-row panel
+ * runs the steps its first (= longest) row has.  Forward: the HN16 slots of a panel's dead steps up to *live_top are zero-filled, their gate
+ * planes unwritten.  Backward (needs bound): `ext` is not read at a panel's dead steps; dgi / dgh get zero rows there up to *bound. */
+int ptv_notes_gru_persist_fwd_rows(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
+                                   const float* h0, void* HN16, void* gates, long R, int T, const int* live_top, const int* row_len,
+                                   void* stream);
+int ptv_notes_gru_persist_bwd_rows(const void* wt, const void* HN16, const void* gates, const void* ext, void* dgi, void* dgh,
+                                   float* dh0, void* scratch, long R, int T, const int* bound, const int* row_len, int* top_step,
+                                   void* stream);
 /* which kernel ptv_notes_gru_persist_bwd runs: 1 (default) = 8 waves per workgroup, the A operand LDS-resident, the carry dh (x) z in registers
  * (csrc/notes_roles.hip), 0 = the 4-wave kernel of rounds 2-4 (csrc/notes_persist.hip); same arguments, same results to rounding.
  * Process-wide. */

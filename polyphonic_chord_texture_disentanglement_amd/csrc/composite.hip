@@ -57,8 +57,14 @@ extern "C" int ptv_decoder_tf_fwd(const void* const* t, const long* d, void* str
   if (!t || !d) return PTV_ERR_ARG;
   if (!ptv_decoder_tf_supported(d)) return PTV_ERR_UNSUPPORTED;
   for (int i = 0; i < PTV_DTF_COUNT; i++)
-    if (!t[i] && i != PTV_DTF_FORCE_DUR && i != PTV_DTF_GATES_D && i != PTV_DTF_WAIT_EVENT && i != PTV_DTF_RECORD_EVENT && i != PTV_DTF_LIVE_TOP)
+    if (!t[i] && i != PTV_DTF_FORCE_DUR && i != PTV_DTF_GATES_D && i != PTV_DTF_WAIT_EVENT && i != PTV_DTF_RECORD_EVENT && i != PTV_DTF_LIVE_TOP &&
+        i != PTV_DTF_PERM && i != PTV_DTF_ROW_LEN && i != PTV_DTF_NS16S && i != PTV_DTF_TOK_S)
       return PTV_ERR_ARG;
+  // rows sorted by length: all four slots or none, and only with a live-step limit (the consumers of the unwritten rows need one)
+  const bool sorted = t[PTV_DTF_PERM] != nullptr;
+  if (sorted != (t[PTV_DTF_ROW_LEN] != nullptr) || sorted != (t[PTV_DTF_NS16S] != nullptr) || sorted != (t[PTV_DTF_TOK_S] != nullptr) ||
+      (sorted && !t[PTV_DTF_LIVE_TOP]))
+    return PTV_ERR_ARG;
   const int B = (int)d[PTV_DTF_D_B], E = (int)d[PTV_DTF_D_E], He = (int)d[PTV_DTF_D_HE], Ht = (int)d[PTV_DTF_D_HT], Hn = (int)d[PTV_DTF_D_HN],
             Hd = (int)d[PTV_DTF_D_HD], Zs = (int)d[PTV_DTF_D_ZS], Zi = (int)d[PTV_DTF_D_ZI];
   const long ldp = d[PTV_DTF_D_LDP];
@@ -103,6 +109,17 @@ extern "C" int ptv_decoder_tf_fwd(const void* const* t, const long* d, void* str
   }
   // ---- notes GRU: h0 = dec_time_to_notes_hid(summary_t); input [summary_t | token], summary part hoisted (ptvae.py:374-398)
   const __bf16* nsf = NS16 + (long)B * Ht;                     // the 32 time states as rows (t, b): an MFMA operand as they are
+  const float* tok = (const float*)T_(t, PTV_DTF_EMB);
+  const int* perm = (const int*)T_(t, PTV_DTF_PERM);
+  const int* row_len = (const int*)T_(t, PTV_DTF_ROW_LEN);
+  if (sorted) {
+    // the decoder's rows from here on in the order PERM (descending number of live note steps): time states and fed tokens are gathered
+    // once, everything below is row-wise and does not care which (t, b) a row is
+    PTV_TRY(ptv_gather_rows(M_<void>(t, PTV_DTF_NS16S), nsf, perm, R, Ht / 2, 0, 0, 1, stream));
+    PTV_TRY(ptv_gather_rows(M_<void>(t, PTV_DTF_TOK_S), tok, perm, R, E, (long)R * E, (long)R * E, 15, stream));
+    nsf = (const __bf16*)T_(t, PTV_DTF_NS16S);
+    tok = (const float*)T_(t, PTV_DTF_TOK_S);
+  }
   PTV_TRY(ptv_gemm(P, 0, 0, R, Hn, Ht, nsf, Ht, T_(t, PTV_DTF_W16_T2N), Ht, HN, Hn, (const float*)T_(t, PTV_DTF_B_T2N), 1.f, 0, 0, 0, A16 | B16,
                    stream));
   PTV_TRY(ptv_gemm(P, 0, 0, R, 3 * Hn, Ht, nsf, Ht, w_ih_n, ld_n, M_<void>(t, PTV_DTF_GC), 3L * Hn, (const float*)T_(t, PTV_DTF_B_IH_N), 1.f, 0, 0,
@@ -110,21 +127,21 @@ extern "C" int ptv_decoder_tf_fwd(const void* const* t, const long* d, void* str
   // (LIVE_TOP, device int or NULL: the caller wants the outputs of the note steps 0 .. *LIVE_TOP only -- a loss that ignores the padded
   // note slots; the three launches below then leave the later steps' rows of their outputs unwritten)
   const int* live = (const int*)T_(t, PTV_DTF_LIVE_TOP);
-  PTV_TRY(ptv_notes_gru_persist_fwd_top(T_(t, PTV_DTF_PK_NOTES_H), T_(t, PTV_DTF_PK_NOTES_T), (const float*)T_(t, PTV_DTF_B_HH_N), T_(t, PTV_DTF_GC),
-                                        (const float*)T_(t, PTV_DTF_EMB), HN, HN16, M_<void>(t, PTV_DTF_GATES_N), R, 15, live, stream));
+  PTV_TRY(ptv_notes_gru_persist_fwd_rows(T_(t, PTV_DTF_PK_NOTES_H), T_(t, PTV_DTF_PK_NOTES_T), (const float*)T_(t, PTV_DTF_B_HH_N), T_(t, PTV_DTF_GC),
+                                         tok, HN, HN16, M_<void>(t, PTV_DTF_GATES_N), R, 15, live, row_len, stream));
   // ---- pitch head + initial duration state in one pass over the note states (ptvae.py:343-352)
-  PTV_TRY(ptv_heads_fwd_top(HN16 + (long)R * Hn, T_(t, PTV_DTF_PK_WP), T_(t, PTV_DTF_PK_WDH), T_(t, PTV_DTF_PK_WDP), (const float*)T_(t, PTV_DTF_B_P),
-                            (const float*)T_(t, PTV_DTF_B_DH), M_<float>(t, PTV_DTF_PITCH), ldp, HD, HD16, M, live, R, stream));
+  PTV_TRY(ptv_heads_fwd_rows(HN16 + (long)R * Hn, T_(t, PTV_DTF_PK_WP), T_(t, PTV_DTF_PK_WDH), T_(t, PTV_DTF_PK_WDP), (const float*)T_(t, PTV_DTF_B_P),
+                             (const float*)T_(t, PTV_DTF_B_DH), M_<float>(t, PTV_DTF_PITCH), ldp, HD, HD16, M, live, R, row_len, stream));
   // ---- 5-step duration GRU with arg-max feedback; its input is one of three vectors: gate tables (ptvae.py:353-367)
   const int I = 5;
   PTV_TRY(ptv_gemm(PTV_PREC_F32, 0, 0, 1, 3 * Hd, I, T_(t, PTV_DTF_SOS), I, T_(t, PTV_DTF_W_IH_D), I, M_<void>(t, PTV_DTF_TAB0), 3L * Hd,
                    (const float*)T_(t, PTV_DTF_B_IH_D), 1.f, 0, 0, 0, 0, stream));
   PTV_TRY(ptv_gemm(PTV_PREC_F32, 0, 0, 2, 3 * Hd, I, T_(t, PTV_DTF_ONEHOT), I, T_(t, PTV_DTF_W_IH_D), I, M_<void>(t, PTV_DTF_TAB), 3L * Hd,
                    (const float*)T_(t, PTV_DTF_B_IH_D), 1.f, 0, 0, 0, 0, stream));
-  PTV_TRY(ptv_dur_gru_fwd_top(Hd, M, HD, Hd, (const float*)T_(t, PTV_DTF_W_HH_D), (const float*)T_(t, PTV_DTF_B_HH_D), (const float*)T_(t, PTV_DTF_TAB0),
+  PTV_TRY(ptv_dur_gru_fwd_rows(Hd, M, HD, Hd, (const float*)T_(t, PTV_DTF_W_HH_D), (const float*)T_(t, PTV_DTF_B_HH_D), (const float*)T_(t, PTV_DTF_TAB0),
                           (const float*)T_(t, PTV_DTF_TAB), (const float*)T_(t, PTV_DTF_W_OUT_D), (const float*)T_(t, PTV_DTF_B_OUT_D), nullptr,
                           M * Hd, HD16 + M * Hd, M_<void>(t, PTV_DTF_GATES_D), M * Hd, 4 * M * Hd, 1, M_<float>(t, PTV_DTF_DUR), 10,
-                              M_<int>(t, PTV_DTF_IDX), M, (const int*)T_(t, PTV_DTF_FORCE_DUR), M, live, R, stream));
+                              M_<int>(t, PTV_DTF_IDX), M, (const int*)T_(t, PTV_DTF_FORCE_DUR), M, live, R, row_len, stream));
   return PTV_OK;
 }
 
@@ -255,7 +272,17 @@ extern "C" int ptv_chord_decoder_bwd(const void* const* t, const long* d, void* 
 extern "C" int ptv_decoder_tf_bwd(const void* const* t, const long* d, void* stream) {
   if (!t || !d) return PTV_ERR_ARG;
   for (int i = 0; i < PTV_DTB_COUNT; i++)
-    if (!t[i] && i != PTV_DTB_TOP_H && i != PTV_DTB_PART_T && i != PTV_DTB_WAIT_EVENT && i != PTV_DTB_RECORD_EVENT) return PTV_ERR_ARG;
+    if (!t[i] && i != PTV_DTB_TOP_H && i != PTV_DTB_PART_T && i != PTV_DTB_WAIT_EVENT && i != PTV_DTB_RECORD_EVENT && i != PTV_DTB_PERM &&
+        i != PTV_DTB_ROW_LEN && i != PTV_DTB_NS16S && i != PTV_DTB_DNS_S && i != PTV_DTB_DTOK_S)
+      return PTV_ERR_ARG;
+  // the forward ran on rows sorted by length: every per-row tensor here is in that order; the two gradients that leave the node for
+  // row-order-aware consumers (the time states', the fed tokens') are scattered back
+  const bool sorted = t[PTV_DTB_PERM] != nullptr;
+  if (sorted != (t[PTV_DTB_ROW_LEN] != nullptr) || sorted != (t[PTV_DTB_NS16S] != nullptr) || sorted != (t[PTV_DTB_DNS_S] != nullptr) ||
+      sorted != (t[PTV_DTB_DTOK_S] != nullptr) || (sorted && !t[PTV_DTB_TOP_H]))
+    return PTV_ERR_ARG;
+  const int* perm = (const int*)T_(t, PTV_DTB_PERM);
+  const int* row_len = (const int*)T_(t, PTV_DTB_ROW_LEN);
   const int B = (int)d[PTV_DTB_D_B], E = (int)d[PTV_DTB_D_E], He = (int)d[PTV_DTB_D_HE], Ht = (int)d[PTV_DTB_D_HT], Hn = (int)d[PTV_DTB_D_HN],
             Hd = (int)d[PTV_DTB_D_HD], NP = (int)d[PTV_DTB_D_NP], Zs = (int)d[PTV_DTB_D_ZS], Zi = (int)d[PTV_DTB_D_ZI], nblk = (int)d[PTV_DTB_D_NBLK],
             S = (int)d[PTV_DTB_D_SPLITK];
@@ -298,7 +325,8 @@ extern "C" int ptv_decoder_tf_bwd(const void* const* t, const long* d, void* str
   void* dNSUM = M_<void>(t, PTV_DTB_DNSUM); void* dY16 = M_<void>(t, PTV_DTB_DY16);
   ptv_gemm_priority(1);
   // (blocked = 3 with a limit: dNSUM's dead rows stay unwritten -- the BPTT below gets the same limit as its bound and never reads them)
-  PTV_TRY(ptv_heads_bwd(dP, ldp, dHD0, T_(t, PTV_DTB_PK_WDPT), T_(t, PTV_DTB_PK_WCAT), dNSUM, top_h ? 3 : 1, dY16, top_h, top_unit, M, stream));
+  PTV_TRY(ptv_heads_bwd_rows(dP, ldp, dHD0, T_(t, PTV_DTB_PK_WDPT), T_(t, PTV_DTB_PK_WCAT), dNSUM, top_h ? 3 : 1, dY16, top_h, top_unit, row_len, M,
+                             stream));
   PTV_TRY(fork(1));
   ptv_gemm_priority(0);
   {
@@ -318,22 +346,29 @@ extern "C" int ptv_decoder_tf_bwd(const void* const* t, const long* d, void* str
   // ================= notes GRU (15 steps x 32 B rows): BPTT, then the gradients of the fed tokens and of the time states
   void* dgi_n = M_<void>(t, PTV_DTB_DGI_N); void* dgh_n = M_<void>(t, PTV_DTB_DGH_N);
   float* dHN0 = GB(PTV_DTB_DHN0); int* top_step = M_<int>(t, PTV_DTB_TOP_STEP);
-  float* dGC = GB(PTV_DTB_DGC); float* dNS = GB(PTV_DTB_DNS); float* dtok = GB(PTV_DTB_DTOK);
+  float* dGC = GB(PTV_DTB_DGC);
+  float* dNS_out = GB(PTV_DTB_DNS); float* dtok_out = GB(PTV_DTB_DTOK);     // what leaves the node, natural row order
+  float* dNS = sorted ? GB(PTV_DTB_DNS_S) : dNS_out;                       // what the products below write
+  float* dtok = sorted ? GB(PTV_DTB_DTOK_S) : dtok_out;
   const __bf16* wt_ih_n = (const __bf16*)T_(t, PTV_DTB_WT_IH_N);   // [Ht + E, 3Hn]
   ptv_gemm_priority(1);
-  PTV_TRY(ptv_notes_gru_persist_bwd_top(T_(t, PTV_DTB_PK_NOTES_WT), T_(t, PTV_DTB_HN16), T_(t, PTV_DTB_GATES_N), dNSUM, dgi_n, dgh_n, dHN0,
-                                        M_<void>(t, PTV_DTB_SCRATCH_N), R, 15, top_h, top_step, stream));
+  PTV_TRY(ptv_notes_gru_persist_bwd_rows(T_(t, PTV_DTB_PK_NOTES_WT), T_(t, PTV_DTB_HN16), T_(t, PTV_DTB_GATES_N), dNSUM, dgi_n, dgh_n, dHN0,
+                                         M_<void>(t, PTV_DTB_SCRATCH_N), R, 15, top_h, row_len, top_step, stream));
   PTV_TRY(ptv_sum_steps_top(dGC, dgi_n, (long)R * 3 * Hn, 15, (long)R * 3 * Hn, 0, 1, top_step, stream));
-  if (hipMemsetAsync(dtok + 15L * R * E, 0, sizeof(float) * R * E, s) != hipSuccess) return PTV_ERR_LAUNCH;
+  if (hipMemsetAsync(dtok_out + 15L * R * E, 0, sizeof(float) * R * E, s) != hipSuccess) return PTV_ERR_LAUNCH;
   PTV_TRY(ptv_gemm_mtop(P, 0, 0, (int)M, E, 3 * Hn, dgi_n, 3L * Hn, wt_ih_n + (long)Ht * 3 * Hn, 3L * Hn, dtok, E, nullptr, 1.f, 0, 0, 0, A16 | B16,
                         top_step, R, stream));
   PTV_TRY(ptv_gemm(P, 0, 0, R, Ht, 3 * Hn, dGC, 3L * Hn, wt_ih_n, 3L * Hn, dNS, Ht, nullptr, 1.f, 0, 0, 0, B16, stream));
   PTV_TRY(ptv_gemm(P, 0, 0, R, Ht, Hn, dHN0, Hn, T_(t, PTV_DTB_WT_T2N), Hn, dNS, Ht, nullptr, 1.f, 1, 0, 0, B16, stream));
+  if (sorted) {
+    PTV_TRY(ptv_scatter_rows(dNS_out, dNS, perm, R, Ht, 0, 0, 1, stream));
+    PTV_TRY(ptv_scatter_rows(dtok_out, dtok, perm, R, E, (long)R * E, (long)R * E, 15, stream));
+  }
   PTV_TRY(fork(2));
   ptv_gemm_priority(0);
   {
     const __bf16* HN16 = (const __bf16*)T_(t, PTV_DTB_HN16);      // states 0 .. 14: the operand of the W_hh gradient
-    const __bf16* NSf = (const __bf16*)T_(t, PTV_DTB_NS16) + (long)B * Ht;
+    const __bf16* NSf = sorted ? (const __bf16*)T_(t, PTV_DTB_NS16S) : (const __bf16*)T_(t, PTV_DTB_NS16) + (long)B * Ht;
     float* gw = GB(PTV_DTB_G_W_HH_N); float* gb = GB(PTV_DTB_G_B_HH_N); float* gih = GB(PTV_DTB_G_W_IH_N);
     // the five parameter gradients of the notes GRU and of dec_time_to_notes_hid: ONE product launch + ONE reduction launch; the four bias
     // gradients are column sums taken from the A tiles in LDS (round 5: five products, five reductions, two column-sum passes over dGC / dHN0)
@@ -355,7 +390,7 @@ extern "C" int ptv_decoder_tf_bwd(const void* const* t, const long* d, void* str
   {
     const float* hall_[1] = {(const float*)T_(t, PTV_DTB_NS)}; const void* gates_[1] = {T_(t, PTV_DTB_GATES_T)};
     const void* wt_[1] = {T_(t, PTV_DTB_WT_HH_T)};
-    const void* ext_[1] = {dNS}; const long ext_step[1] = {(long)B * Ht}, ext_ld[1] = {(long)Ht}; const int ext_bf[1] = {0};
+    const void* ext_[1] = {dNS_out}; const long ext_step[1] = {(long)B * Ht}, ext_ld[1] = {(long)Ht}; const int ext_bf[1] = {0};
     const float* last_[1] = {nullptr}; const long last_ld[1] = {0};
     void* dgi_[1] = {dgi_t}; void* dgh_[1] = {dgh_t}; float* dh0_[1] = {dzhid}; const int rev[1] = {0};
     void* xch_[1] = {M_<void>(t, PTV_DTB_XCH)}; float* part_[1] = {M_<float>(t, PTV_DTB_PART_T)};

@@ -47,6 +47,8 @@ struct DurArgs {
   const int* force; long force_stride; // replay mode (tests), may be null
   long M;
   const int* m_top; long m_unit;       // or null: only the rows below (*m_top + 1) * m_unit are wanted; the others stay unwritten
+  const int* row_len;                  // or null (needs m_top): rows of a step sorted by descending length, [m_unit] live note steps per row -- a
+                                       // tile inside a 128-row block whose first row has no target at its note step is passed over
 };
 
 __global__ __launch_bounds__(256, 2) void dur_gru_fwd_kernel(DurArgs a) {
@@ -80,6 +82,7 @@ __global__ __launch_bounds__(256, 2) void dur_gru_fwd_kernel(DurArgs a) {
   const long m_live = a.m_top ? min(a.M, (long)(max(*a.m_top, 0) + 1) * a.m_unit) : a.M;
   const long tiles = (m_live + 15) / 16;
   for (long tile = (long)blockIdx.x * 4 + wave; tile < tiles; tile += (long)gridDim.x * 4) {
+    if (a.row_len) { const long rb = tile * 16 / 128 * 128; if (a.row_len[rb % a.m_unit] <= rb / a.m_unit) continue; }     // (deadness per 128-row block, as the heads)
     const long row = tile * 16 + rl;
     const bool ok = row < a.M;
     float h[4][4];                                                      // h[f][e]: unit f*16 + ug + e
@@ -182,17 +185,31 @@ extern "C" int ptv_dur_gru_fwd(int H, long M, const float* h0, long ld_h0, const
                              dur_out, ld_out, idx, idx_stride, force, force_stride, nullptr, 0, stream);
 }
 
+extern "C" int ptv_dur_gru_fwd_rows(int H, long M, const float* h0, long ld_h0, const float* w_hh, const float* b_hh,
+                                    const float* tab0, const float* tab, const float* w_out, const float* b_out,
+                                    float* hall, long plane_h, void* hall16, void* gates, long plane_g, long step_g, int gates_bf16,
+                                    float* dur_out, long ld_out, int* idx, long idx_stride, const int* force, long force_stride,
+                                    const int* m_top, long m_unit, const int* row_len, void* stream);
 extern "C" int ptv_dur_gru_fwd_top(int H, long M, const float* h0, long ld_h0, const float* w_hh, const float* b_hh,
                                    const float* tab0, const float* tab, const float* w_out, const float* b_out,
                                    float* hall, long plane_h, void* hall16, void* gates, long plane_g, long step_g, int gates_bf16,
                                    float* dur_out, long ld_out, int* idx, long idx_stride, const int* force, long force_stride,
                                    const int* m_top, long m_unit, void* stream) {
+  return ptv_dur_gru_fwd_rows(H, M, h0, ld_h0, w_hh, b_hh, tab0, tab, w_out, b_out, hall, plane_h, hall16, gates, plane_g, step_g, gates_bf16,
+                              dur_out, ld_out, idx, idx_stride, force, force_stride, m_top, m_unit, nullptr, stream);
+}
+extern "C" int ptv_dur_gru_fwd_rows(int H, long M, const float* h0, long ld_h0, const float* w_hh, const float* b_hh,
+                                   const float* tab0, const float* tab, const float* w_out, const float* b_out,
+                                   float* hall, long plane_h, void* hall16, void* gates, long plane_g, long step_g, int gates_bf16,
+                                   float* dur_out, long ld_out, int* idx, long idx_stride, const int* force, long force_stride,
+                                   const int* m_top, long m_unit, const int* row_len, void* stream) {
+  if (row_len && (!m_top || (m_unit & 127))) return PTV_ERR_ARG;          // (deadness per 128-row block)
   if (m_top && (m_unit <= 0 || (m_unit & 15))) return PTV_ERR_ARG;         // (whole 16-row tiles on either side of the limit)
   if (H != DH) return PTV_ERR_ARG;                 // callers fall back to the per-step kernels for other sizes
   if (M <= 0 || !h0 || !w_hh || !b_hh || !tab0 || !tab || !w_out || !b_out || !dur_out || !idx) return PTV_ERR_ARG;
   if ((ld_h0 & 3) || (plane_h & 7) || (plane_g & 7) || (step_g & 7)) return PTV_ERR_ARG;      // 16-byte bf16 pieces
   DurArgs a{h0, ld_h0, w_hh, b_hh, tab0, tab, w_out, b_out, hall, plane_h, (__bf16*)hall16, gates, plane_g, step_g, gates_bf16,
-            dur_out, ld_out, idx, idx_stride, force, force_stride, M, m_top, m_unit};
+            dur_out, ld_out, idx, idx_stride, force, force_stride, M, m_top, m_unit, row_len};
   // grid: whole rounds of resident blocks (3 per CU: 44.5 KB of LDS each) -- 1024 blocks on 256 CUs were 1 1/3 rounds, the last one a third full
   const int cap = 3 * num_cus();                               // (512 / 768 / 1024 / 2048 blocks: 247 / 276 / 247 / 251 us -- it does not matter)
   long nb = ((M + 15) / 16 + 3) / 4; if (nb > cap) nb = cap; if (nb < 1) nb = 1;

@@ -490,3 +490,47 @@ extern "C" int ptv_last_nonzero_unit(const float* x, long rows, int cols, long l
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// rows by index: dst[plane][p][:] = src[plane][idx[p]][:] (gather) / dst[plane][idx[p]][:] = src[plane][p][:] (scatter), rows of `w4`
+// 4-byte words (16-byte pieces when w4 % 4 == 0 and everything is aligned).  The decoder's rows in length-sorted order (round 6:
+// per-row dead work): time states and fed tokens are gathered into it, the gradients of both scattered back.
+// ---------------------------------------------------------------------------------------------
+template <bool SCATTER, bool VEC>
+__global__ void rows_by_index_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src, const int* __restrict__ idx, long rows, int w4,
+                                     long src_plane, long dst_plane, int planes) {
+  const int per = VEC ? w4 / 4 : w4;                                     // pieces per row
+  const long total = rows * per * planes;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % per);
+    const long q = i / per;
+    const long p = q % rows;
+    const int pl = (int)(q / rows);
+    const long r = idx[p];
+    const long so = (long)pl * src_plane + (SCATTER ? p : r) * w4, dof = (long)pl * dst_plane + (SCATTER ? r : p) * w4;
+    if (VEC) reinterpret_cast<uint4*>(dst + dof)[c] = reinterpret_cast<const uint4*>(src + so)[c];
+    else dst[dof + c] = src[so + c];
+  }
+}
+static int rows_by_index(bool scatter, void* dst, const void* src, const int* idx, long rows, int w4, long src_plane, long dst_plane, int planes, void* stream) {
+  if (!dst || !src || !idx || rows < 0 || w4 <= 0 || planes <= 0) return PTV_ERR_ARG;
+  if (rows == 0) return PTV_OK;
+  const bool vec = (w4 % 4 == 0) && (src_plane % 4 == 0) && (dst_plane % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+  const long total = rows * (vec ? w4 / 4 : w4) * planes;
+  int nb = (int)((total + 255) / 256); if (nb > 8192) nb = 8192; if (nb < 1) nb = 1;
+  unsigned* d_ = (unsigned*)dst; const unsigned* s_ = (const unsigned*)src;
+  if (scatter) { if (vec) hipLaunchKernelGGL((rows_by_index_kernel<true, true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, d_, s_, idx, rows, w4, src_plane, dst_plane, planes);
+                 else hipLaunchKernelGGL((rows_by_index_kernel<true, false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, d_, s_, idx, rows, w4, src_plane, dst_plane, planes); }
+  else { if (vec) hipLaunchKernelGGL((rows_by_index_kernel<false, true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, d_, s_, idx, rows, w4, src_plane, dst_plane, planes);
+         else hipLaunchKernelGGL((rows_by_index_kernel<false, false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, d_, s_, idx, rows, w4, src_plane, dst_plane, planes); }
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+extern "C" int ptv_gather_rows(void* dst, const void* src, const int* idx, long rows, int row_words, long src_plane_words, long dst_plane_words,
+                               int planes, void* stream) {
+  return rows_by_index(false, dst, src, idx, rows, row_words, src_plane_words, dst_plane_words, planes, stream);
+}
+extern "C" int ptv_scatter_rows(void* dst, const void* src, const int* idx, long rows, int row_words, long src_plane_words, long dst_plane_words,
+                                int planes, void* stream) {
+  return rows_by_index(true, dst, src, idx, rows, row_words, src_plane_words, dst_plane_words, planes, stream);
+}

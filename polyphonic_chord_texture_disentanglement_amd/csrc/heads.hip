@@ -37,10 +37,23 @@ struct HeadsFwdArgs {
   float* hd0; __bf16* hd16;                    // [M][64] fp32, bf16 copy or null
   long M;
   const int* m_top; long m_unit;               // or null: only the rows below (*m_top + 1) * m_unit are wanted; the others stay unwritten
+  const int* row_len;                          // or null (needs m_top): [m_unit] live note steps per row, rows of a step sorted by descending length
 };
 
 __global__ __launch_bounds__(256, 1) void heads_fwd_kernel(HeadsFwdArgs a) {
   if (a.m_top && (long)blockIdx.x * 128 >= (long)(max(*a.m_top, 0) + 1) * a.m_unit) return;
+  if (a.row_len) {
+    // rows sorted by length: a block whose FIRST row has no target at this note step holds only dead rows.  Its logits are an operand of a
+    // weight-gradient product that knows only the launch-wide limit: zero rows (finite), nothing else is written
+    const long rb = (long)blockIdx.x * 128, n = rb / a.m_unit, r = rb % a.m_unit;
+    if (a.row_len[r] <= n) {
+      for (int i = threadIdx.x; i < 128 * (int)(a.ldp / 4); i += 256) {
+        const long row = rb + i / (a.ldp / 4);
+        if (row < a.M) reinterpret_cast<float4*>(a.pitch + row * a.ldp)[i % (a.ldp / 4)] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      return;
+    }
+  }
   extern __shared__ __attribute__((aligned(16))) char hsm[];
   bf16x8* Bs = reinterpret_cast<bf16x8*>(hsm);                       // [2][HCH][HNT][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -177,6 +190,7 @@ struct HeadsBwdArgs {
   __bf16* dy16;                                // [M][200] bf16 = [dP' (130) | 0 (6) | dHD0 (64)]: ONE operand for both heads' weight gradients, or null
   const int* m_top; long m_unit;               // rows from (*m_top + 1) * m_unit on are zero (or null)
   long M;
+  const int* row_len;                          // or null (needs m_top): rows of a step sorted by descending length, [m_unit] live note steps per row
 };
 
 __global__ __launch_bounds__(256, 1) void heads_bwd_kernel(HeadsBwdArgs a) {
@@ -187,6 +201,22 @@ __global__ __launch_bounds__(256, 1) void heads_bwd_kernel(HeadsBwdArgs a) {
   const long r0 = rb + wave * 32;
   long live = a.M;
   if (a.m_top) live = min(a.M, ((long)*a.m_top + 1) * a.m_unit);
+  if (a.row_len && rb < live) {
+    // rows sorted by length: a block whose first row has no target at this note step received nothing.  Its dNSUM rows stay unwritten (the
+    // BPTT has the same row lengths as its per-panel bound); its rows of dy16 -- an operand of the heads' weight-gradient product, which
+    // knows only the launch-wide limit -- are written as zeros
+    const long n = rb / a.m_unit, r = rb % a.m_unit;
+    if (a.row_len[r] <= n) {
+      if (a.dy16) {
+        const bf16x8 z = bf16x8{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        for (int i = tid; i < 128 * 25; i += 256) {
+          const long row = rb + i / 25;
+          if (row < a.M) *reinterpret_cast<bf16x8*>(a.dy16 + row * 200 + (i % 25) * 8) = z;
+        }
+      }
+      return;
+    }
+  }
   if (rb >= live) {                                                       // nothing arrived at these rows: dNSUM = 0, dP stays (zero)
     if (a.blocked & 2) return;                                            // ... and the consumer knows the limit too: the rows stay unwritten
     const bf16x8 z = bf16x8{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
@@ -337,14 +367,23 @@ extern "C" int ptv_heads_fwd(const void* hn16, const void* wp_packed, const void
   return ptv_heads_fwd_top(hn16, wp_packed, wdh_packed, wdp_packed, b_p, b_dh, pitch, ldp, hd0, hd16, M, nullptr, 0, stream);
 }
 
+extern "C" int ptv_heads_fwd_rows(const void* hn16, const void* wp_packed, const void* wdh_packed, const void* wdp_packed, const float* b_p,
+                                  const float* b_dh, float* pitch, long ldp, float* hd0, void* hd16, long M, const int* m_top, long m_unit,
+                                  const int* row_len, void* stream);
 extern "C" int ptv_heads_fwd_top(const void* hn16, const void* wp_packed, const void* wdh_packed, const void* wdp_packed, const float* b_p,
                                  const float* b_dh, float* pitch, long ldp, float* hd0, void* hd16, long M, const int* m_top, long m_unit,
                                  void* stream) {
+  return ptv_heads_fwd_rows(hn16, wp_packed, wdh_packed, wdp_packed, b_p, b_dh, pitch, ldp, hd0, hd16, M, m_top, m_unit, nullptr, stream);
+}
+extern "C" int ptv_heads_fwd_rows(const void* hn16, const void* wp_packed, const void* wdh_packed, const void* wdp_packed, const float* b_p,
+                                  const float* b_dh, float* pitch, long ldp, float* hd0, void* hd16, long M, const int* m_top, long m_unit,
+                                  const int* row_len, void* stream) {
+  if (row_len && !m_top) return PTV_ERR_ARG;
   if (m_top && (m_unit <= 0 || (m_unit & 127))) return PTV_ERR_ARG;        // (whole 128-row blocks on either side of the limit)
   if (!hn16 || !wp_packed || !wdh_packed || !wdp_packed || !b_p || !b_dh || !pitch || !hd0 || M <= 0 || ldp < HNP || (ldp & 3)) return PTV_ERR_ARG;
   if ((reinterpret_cast<uintptr_t>(pitch) & 15) || (reinterpret_cast<uintptr_t>(hn16) & 15)) return PTV_ERR_ARG;
   HeadsFwdArgs a{(const __bf16*)hn16, (const bf16x8*)wp_packed, (const bf16x8*)wdh_packed, (const bf16x8*)wdp_packed, b_p, b_dh,
-                 pitch, ldp, hd0, (__bf16*)hd16, M, m_top, m_unit};
+                 pitch, ldp, hd0, (__bf16*)hd16, M, m_top, m_unit, row_len};
   const int lds = 2 * HCH * HNT * 64 * 16;                                // 104 KB (the staged logits, 42 KB, reuse it)
   static bool attr = false;
   if (!attr) { if (hipFuncSetAttribute((const void*)heads_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return PTV_ERR_LAUNCH; attr = true; }
@@ -353,11 +392,18 @@ extern "C" int ptv_heads_fwd_top(const void* hn16, const void* wp_packed, const 
   return PTV_OK;
 }
 
+extern "C" int ptv_heads_bwd_rows(float* dp, long ldp, const float* dhd0, const void* wdpT_packed, const void* wcat_packed, void* dnsum16,
+                                  int blocked, void* dy16, const int* m_top, long m_unit, const int* row_len, long M, void* stream);
 extern "C" int ptv_heads_bwd(float* dp, long ldp, const float* dhd0, const void* wdpT_packed, const void* wcat_packed, void* dnsum16,
                              int blocked, void* dy16, const int* m_top, long m_unit, long M, void* stream) {
+  return ptv_heads_bwd_rows(dp, ldp, dhd0, wdpT_packed, wcat_packed, dnsum16, blocked, dy16, m_top, m_unit, nullptr, M, stream);
+}
+extern "C" int ptv_heads_bwd_rows(float* dp, long ldp, const float* dhd0, const void* wdpT_packed, const void* wcat_packed, void* dnsum16,
+                                  int blocked, void* dy16, const int* m_top, long m_unit, const int* row_len, long M, void* stream) {
+  if (row_len && (!m_top || (m_unit & 127))) return PTV_ERR_ARG;
   if (!dp || !dhd0 || !wdpT_packed || !wcat_packed || !dnsum16 || M <= 0 || ldp < HNP || (ldp & 3) || (m_top && m_unit <= 0)) return PTV_ERR_ARG;
   if (reinterpret_cast<uintptr_t>(dp) & 15) return PTV_ERR_ARG;
-  HeadsBwdArgs a{dp, ldp, dhd0, (const bf16x8*)wdpT_packed, (const bf16x8*)wcat_packed, (__bf16*)dnsum16, blocked, (__bf16*)dy16, m_top, m_unit, M};
+  HeadsBwdArgs a{dp, ldp, dhd0, (const bf16x8*)wdpT_packed, (const bf16x8*)wcat_packed, (__bf16*)dnsum16, blocked, (__bf16*)dy16, m_top, m_unit, M, row_len};
   const int lds = 2 * HGT * HBK * 64 * 16 + 4 * 32 * HPLD * 2;            // 112 KB + 42 KB
   static bool attr = false;
   if (!attr) { if (hipFuncSetAttribute((const void*)heads_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return PTV_ERR_LAUNCH; attr = true; }

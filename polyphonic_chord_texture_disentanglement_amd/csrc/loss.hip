@@ -14,7 +14,7 @@ namespace ptv {
 // counts: 0 valid pitch targets, 1 valid dur targets
 
 __global__ void pianotree_targets_kernel(const long* __restrict__ x, int B, int step_major,
-                                         int* __restrict__ pitch_t, int* __restrict__ dur_t, int* __restrict__ counts) {
+                                         int* __restrict__ pitch_t, int* __restrict__ dur_t, int* __restrict__ counts, int* __restrict__ row_live) {
   __shared__ int red[3][4];
   const long rows = (long)B * 480;
   int cp = 0, cd = 0, top = 0;                                           // top: the last note step that holds ANY non-ignored target
@@ -30,6 +30,7 @@ __global__ void pianotree_targets_kernel(const long* __restrict__ x, int B, int 
 #pragma unroll
     for (int d = 0; d < 5; d++) { int v = (int)xr[1 + d]; dur_t[i * 5 + d] = v; cd += (v != 2); live |= (v != 2); }
     if (live) top = max(top, n);
+    if (live && row_live) atomicMax(row_live + (long)t * B + b, n + 1);     // row (t, b): its live note steps are 0 .. row_live - 1
   }
   for (int o = 32; o > 0; o >>= 1) { cp += __shfl_xor(cp, o, 64); cd += __shfl_xor(cd, o, 64); top = max(top, __shfl_xor(top, o, 64)); }
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = cp; red[1][threadIdx.x >> 6] = cd; red[2][threadIdx.x >> 6] = top; }
@@ -357,9 +358,13 @@ static inline int grid_rows(long n, int per_block, int cap = 8192) {
 
 using namespace ptv;
 
+extern "C" int ptv_pianotree_targets_rows(const long* x, int B, int step_major, int* pitch_t, int* dur_t, int* counts, int* row_live, void* stream);
 extern "C" int ptv_pianotree_targets(const long* x, int B, int step_major, int* pitch_t, int* dur_t, int* counts, void* stream) {
+  return ptv_pianotree_targets_rows(x, B, step_major, pitch_t, dur_t, counts, nullptr, stream);
+}
+extern "C" int ptv_pianotree_targets_rows(const long* x, int B, int step_major, int* pitch_t, int* dur_t, int* counts, int* row_live, void* stream) {
   if (!x || !pitch_t || !dur_t || !counts || B <= 0) return PTV_ERR_ARG;
-  hipLaunchKernelGGL(pianotree_targets_kernel, dim3(grid_rows((long)B * 480, 256, 256)), dim3(256), 0, (hipStream_t)stream, x, B, step_major, pitch_t, dur_t, counts);   // (two atomics on the count words per block)
+  hipLaunchKernelGGL(pianotree_targets_kernel, dim3(grid_rows((long)B * 480, 256, 256)), dim3(256), 0, (hipStream_t)stream, x, B, step_major, pitch_t, dur_t, counts, row_live);   // (two atomics on the count words per block)
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }

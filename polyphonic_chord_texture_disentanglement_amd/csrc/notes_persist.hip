@@ -417,6 +417,7 @@ struct RowGruBwdArgs {
   const int* perm;                 // EMB, or null: the forward's row permutation -- dh_last, lengths and dgi (operand of products against the
                                    // forward's INPUT rows) by row perm[p], HN / gates / dgh (against the forward's states) by position p
   const int* bound;                // !EMB, or null: no gradient arrives after step *bound and nobody reads dgi / dgh beyond top_step <= *bound
+  const int* row_len;              // !EMB, or null (needs bound): rows sorted by descending length -- the panel's own last live step is row_len[first row] - 1
 };
 
 // EMB = false: the notes GRU (gradient arrives at every state: ext; forward time order; dh0 wanted); EMB = true: a direction of
@@ -478,8 +479,10 @@ __device__ __forceinline__ void row_gru_bwd_body(const RowGruBwdArgs& a, const l
     // steps of every row -- on this data 8 of the 15.  Tested on the arriving gradient itself (one 64-KB read per step), so it holds
     // for whatever loss produced it.  The BPTT proper starts at the last step that has something.
     if (a.skip && a.bound) s_top = min(a.T - 1, max(*a.bound, -1));         // (steps beyond a caller-given bound are not touched at all)
+    const int s_panel = (a.skip && a.bound && a.row_len) ? min(s_top, a.row_len[r0 & ~127L] - 1) : s_top;     // (deadness per 128-row block, as the heads)
     for (; a.skip && s_top >= 0; s_top--) {
       unsigned nz = 0;
+      if (s_top <= s_panel)
       for (int i = tid; i < NRP * (H / 8); i += 256) {
         const int row = i / (H / 8), c8 = (i % (H / 8)) * 8;
         if (r0 + row < R) {
@@ -727,7 +730,7 @@ extern "C" int ptv_rows_by_length(const int* lengths, int* perm, long R, int max
 }
 
 extern "C" int ptv_notes_bwd8(const void* wt, const void* HN16, const void* gates, const void* ext, void* dgi, void* dgh, float* dh0, void* scratch,
-                              long R, int T, const int* bound, int* top_step, void* stream);
+                              long R, int T, const int* bound, const int* row_len, int* top_step, void* stream);
 // the notes GRU's BPTT: 1 = the 8-wave kernel of notes_roles.hip (LDS-resident operand, carry in registers), 0 = the 4-wave kernel of this file
 static int g_notes_bwd8 = 1;
 extern "C" int ptv_notes_bwd_variant(int eight_waves) { g_notes_bwd8 = eight_waves ? 1 : 0; return PTV_OK; }
@@ -769,7 +772,7 @@ extern "C" int ptv_row_gru_persist_bwd_perm(int H, const void* wt, const void* H
                                             float* dh0, void* scratch, long R, int T, int reverse, int* top_step, void* stream);
 static int row_gru_bwd_any(int H, const void* wt, const void* HN, const void* gates, const void* ext, const float* dh_last, long last_ld,
                            const int* lengths, const int* perm, void* dgi, void* dgh, float* dh0, void* scratch, long R, int T, int reverse,
-                           const int* bound, int* top_step, void* stream);
+                           const int* bound, const int* row_len, int* top_step, void* stream);
 extern "C" int ptv_row_gru_persist_bwd(int H, const void* wt, const void* HN, const void* gates, const void* ext,
                                        const float* dh_last, long last_ld, const int* lengths, void* dgi, void* dgh, float* dh0,
                                        void* scratch, long R, int T, int reverse, int* top_step, void* stream) {
@@ -779,18 +782,18 @@ extern "C" int ptv_row_gru_persist_bwd(int H, const void* wt, const void* HN, co
 extern "C" int ptv_row_gru_persist_bwd_perm(int H, const void* wt, const void* HN, const void* gates, const void* ext,
                                             const float* dh_last, long last_ld, const int* lengths, const int* perm, void* dgi, void* dgh,
                                             float* dh0, void* scratch, long R, int T, int reverse, int* top_step, void* stream) {
-  return row_gru_bwd_any(H, wt, HN, gates, ext, dh_last, last_ld, lengths, perm, dgi, dgh, dh0, scratch, R, T, reverse, nullptr, top_step, stream);
+  return row_gru_bwd_any(H, wt, HN, gates, ext, dh_last, last_ld, lengths, perm, dgi, dgh, dh0, scratch, R, T, reverse, nullptr, nullptr, top_step, stream);
 }
 
 static int row_gru_bwd_any(int H, const void* wt, const void* HN, const void* gates, const void* ext, const float* dh_last, long last_ld,
                            const int* lengths, const int* perm, void* dgi, void* dgh, float* dh0, void* scratch, long R, int T, int reverse,
-                           const int* bound, int* top_step, void* stream) {
+                           const int* bound, const int* row_len, int* top_step, void* stream) {
   if (!wt || !HN || !gates || !dgi || !dgh || !scratch || R <= 0 || T <= 0 || (H != 512 && H != 128)) return PTV_ERR_ARG;
   if (dh_last && (last_ld & 3)) return PTV_ERR_ARG;
   if (H == 512 && (lengths || perm)) return PTV_ERR_UNSUPPORTED;
   if (perm && dh0) return PTV_ERR_UNSUPPORTED;                            // (dh0 would be indexed by position)
   RowGruBwdArgs a{(const bf16x8*)wt, H == 512 ? nullptr : (const float*)HN, H == 512 ? (const __bf16*)HN : nullptr, (const __bf16*)gates, (const __bf16*)ext, dh_last, last_ld, lengths, top_step, (__bf16*)dgi, (__bf16*)dgh, dh0,
-                  (__bf16*)scratch, (int)R, T, reverse, g_zero_skip, perm, bound};
+                  (__bf16*)scratch, (int)R, T, reverse, g_zero_skip, perm, bound, row_len};
   const int pi = prof::want(4, (int)R, H) ? prof::begin((hipStream_t)stream) : -1;
   if (H == 512 && (!ext || dh_last || reverse)) return PTV_ERR_UNSUPPORTED;
   if (H == 128 && ext) return PTV_ERR_UNSUPPORTED;
@@ -802,11 +805,16 @@ static int row_gru_bwd_any(int H, const void* wt, const void* HN, const void* ga
 
 extern "C" long ptv_notes_gru_persist_scratch_elems(long R) { return ptv_row_gru_persist_scratch_elems(512, R); }
 
+extern "C" int ptv_notes_gru_persist_bwd_rows(const void* wt, const void* HN16, const void* gates, const void* ext, void* dgi, void* dgh,
+                                              float* dh0, void* scratch, long R, int T, const int* bound, const int* row_len, int* top_step,
+                                              void* stream) {
+  if (!ext || (bound && !top_step) || (row_len && !bound)) return PTV_ERR_ARG;
+  if (g_notes_bwd8) return ptv_notes_bwd8(wt, HN16, gates, ext, dgi, dgh, dh0, scratch, R, T, bound, row_len, top_step, stream);
+  return row_gru_bwd_any(512, wt, HN16, gates, ext, nullptr, 0, nullptr, nullptr, dgi, dgh, dh0, scratch, R, T, 0, bound, row_len, top_step, stream);
+}
 extern "C" int ptv_notes_gru_persist_bwd_top(const void* wt, const void* HN16, const void* gates, const void* ext, void* dgi, void* dgh,
                                              float* dh0, void* scratch, long R, int T, const int* bound, int* top_step, void* stream) {
-  if (!ext || (bound && !top_step)) return PTV_ERR_ARG;
-  if (g_notes_bwd8) return ptv_notes_bwd8(wt, HN16, gates, ext, dgi, dgh, dh0, scratch, R, T, bound, top_step, stream);
-  return row_gru_bwd_any(512, wt, HN16, gates, ext, nullptr, 0, nullptr, nullptr, dgi, dgh, dh0, scratch, R, T, 0, bound, top_step, stream);
+  return ptv_notes_gru_persist_bwd_rows(wt, HN16, gates, ext, dgi, dgh, dh0, scratch, R, T, bound, nullptr, top_step, stream);
 }
 extern "C" int ptv_notes_gru_persist_bwd(const void* wt, const void* HN16, const void* gates, const void* ext, void* dgi, void* dgh,
                                          float* dh0, void* scratch, long R, int T, int* top_step, void* stream) {

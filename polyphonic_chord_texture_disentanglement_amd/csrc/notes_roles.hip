@@ -88,6 +88,9 @@ struct Args {
   unsigned long long* trace;       // timing experiments: per-wave event stamps of workgroup 0 (s_memtime), or null
   const int* live_top;             // or null: device int -- only the note steps 0 .. *live_top are wanted by the caller; later HN16 slots
                                    // and gate planes stay unwritten
+  const int* row_len;              // or null: [R] live note steps per row, rows sorted by DESCENDING length (ptv_rows_by_length): a panel runs the
+                                   // steps its longest (= first) row has; the HN16 slots of its dead steps up to the launch-wide limit are
+                                   // zero-filled (finite operands for the weight-gradient products), their gate planes stay unwritten
 };
 
 // slot address of the 16-byte chunk j (units 4j .. 4j+3) of (gate, row): chunks are XOR-swizzled so that both the product wave's
@@ -104,7 +107,11 @@ __global__ __launch_bounds__(512, 2) void notes_fwd_kernel(Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long R = a.R, RH = R * H;
   const long r0 = (long)blockIdx.x * ROWS;
-  const int T = a.live_top ? min(a.T, max(__builtin_amdgcn_readfirstlane(*a.live_top), 0) + 1) : a.T;
+  const int Tg = a.live_top ? min(a.T, max(__builtin_amdgcn_readfirstlane(*a.live_top), 0) + 1) : a.T;      // launch-wide
+  // this panel: the steps the first row of its 128-row BLOCK has -- one granularity of deadness for every kernel of the chain (the heads
+  // work on 128-row blocks): inside a live block every row is computed (finite values meet the zero gradients of its shorter rows),
+  // a dead block is read by nobody
+  const int T = a.row_len ? min(Tg, max(__builtin_amdgcn_readfirstlane(a.row_len[r0 & ~127L]), 0)) : Tg;
   // workgroups of one XCD run in near lockstep and would ask the L2 for the same fragment lines at the same moment: each walks its
   // mini-passes from its own starting point (a k-block rotation on top measured nothing and costs 80 address registers)
   const int rot = (a.dbg & 8) ? 0 : (blockIdx.x >> 3) & (MPS - 1);
@@ -381,6 +388,16 @@ __global__ __launch_bounds__(512, 2) void notes_fwd_kernel(Args a) {
                                     reinterpret_cast<bf16x8*>(a.HN16 + (long)T * RH + (r0 + row) * H + c8));
     }
   }
+  // (rows sorted by length) the panel's dead steps below the launch-wide limit: zero states -- the weight_hh gradient product meets them
+  // with exactly-zero gate gradients, and 0 x whatever-the-allocator-left is not 0
+  for (int n = T; n < Tg; n++)
+    for (int i = tid; i < ROWS * (H / 8); i += 512) {
+      const int row = i / (H / 8), c8 = (i % (H / 8)) * 8;
+      if (r0 + row < R) {
+        const bf16x8 z8 = bf16x8{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        *reinterpret_cast<bf16x8*>(a.HN16 + (long)(n + 1) * RH + (r0 + row) * H + c8) = z8;
+      }
+    }
 }
 
 template <int DF, int ABL>
@@ -411,11 +428,19 @@ extern "C" int ptv_notes_gru_persist_fwd(const void* wg_h, const void* wg_t, con
 }
 
 // T: bits 0-7 = steps, bits 8-15 = debug flags (8: no stagger), bits 16-23 = ring depth (0 = default)
+extern "C" int ptv_notes_gru_persist_fwd_rows(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
+                                              const float* h0, void* HN16, void* gates, long R, int T, const int* live_top, const int* row_len,
+                                              void* stream);
 extern "C" int ptv_notes_gru_persist_fwd_top(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
                                              const float* h0, void* HN16, void* gates, long R, int T, const int* live_top, void* stream) {
+  return ptv_notes_gru_persist_fwd_rows(wg_h, wg_t, b_hh, gc, emb, h0, HN16, gates, R, T, live_top, nullptr, stream);
+}
+extern "C" int ptv_notes_gru_persist_fwd_rows(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
+                                              const float* h0, void* HN16, void* gates, long R, int T, const int* live_top, const int* row_len,
+                                              void* stream) {
   if (!wg_h || !wg_t || !b_hh || !gc || !emb || !h0 || !HN16 || R <= 0 || (T & 0xff) <= 0) return PTV_ERR_ARG;
   nr::Args a{(const bf16x8*)wg_h, (const bf16x8*)wg_t, b_hh, (const __bf16*)gc, emb, R * nr::E, h0, (__bf16*)HN16, (__bf16*)gates,
-             (int)R, T & 0xff, (T >> 8) & 0xff, g_notes_trace, live_top};
+             (int)R, T & 0xff, (T >> 8) & 0xff, g_notes_trace, live_top, row_len};
   const int depth = (T >> 16) & 0xff, abl = a.dbg & 7;
   const int pi = prof::want(3, (int)R, nr::H) ? prof::begin((hipStream_t)stream) : -1;
   hipStream_t s = (hipStream_t)stream;
@@ -470,6 +495,9 @@ struct Args {
   int R, T, skip;
   const int* bound;                // or null: device int, NO gradient arrives after note step *bound (the caller knows: the forward stopped there /
                                    // the loss says so) and the consumers of dgi / dgh stop at top_step <= *bound -- steps beyond it are not touched
+  const int* row_len;              // or null (needs bound): [R] live note steps per row, rows sorted by DESCENDING length: no gradient arrives at
+                                   // this panel after step row_len[first row] - 1 -- `ext` is not read there (it may be unwritten), the steps
+                                   // between that and *bound get zero rows of dgi / dgh (their consumers know only the launch-wide limit)
 };
 
 __device__ __forceinline__ float bfv(const u4v& v, int e) { const unsigned w = v[e >> 1]; return __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16)); }
@@ -501,8 +529,10 @@ __global__ __launch_bounds__(512, 2) void notes_bwd_kernel(Args a) {
   // steps of the benchmark batch -- 0.13 GB read, 0.52 GB written per launch for rows nobody reads, a third of the launch's time)
   int s_top = T - 1;
   if (a.skip && a.bound) s_top = min(T - 1, max(*a.bound, -1));
+  const int s_panel = (a.skip && a.bound && a.row_len) ? min(s_top, a.row_len[r0 & ~127L] - 1) : s_top;     // (sorted rows: the last live step of the panel's 128-row block)
   for (; a.skip && s_top >= 0; s_top--) {
     unsigned nz = 0;
+    if (s_top <= s_panel)
     for (int i = tid; i < ROWS * (H / 8); i += 512) {
       const int row = i / (H / 8), c8 = (i % (H / 8)) * 8;
       if (r0 + row < R) {
@@ -668,11 +698,11 @@ __global__ __launch_bounds__(512, 2) void notes_bwd_kernel(Args a) {
 }  // namespace ptv
 
 extern "C" int ptv_notes_bwd8(const void* wt, const void* HN16, const void* gates, const void* ext, void* dgi, void* dgh, float* dh0, void* scratch,
-                              long R, int T, const int* bound, int* top_step, void* stream) {
+                              long R, int T, const int* bound, const int* row_len, int* top_step, void* stream) {
   if (!wt || !HN16 || !gates || !ext || !dgi || !dgh || !scratch || R <= 0 || (T & 0xff) <= 0) return PTV_ERR_ARG;
-  if (bound && !top_step) return PTV_ERR_ARG;                    // (rows beyond the bound stay unwritten: the consumers need the limit)
+  if ((bound && !top_step) || (row_len && !bound)) return PTV_ERR_ARG;   // (rows beyond the bound stay unwritten: the consumers need the limit)
   nb::Args a{(const bf16x8*)wt, (const __bf16*)HN16, (const __bf16*)gates, (const __bf16*)ext, (__bf16*)dgi, (__bf16*)dgh, dh0, (__bf16*)scratch,
-             top_step, (int)R, T & 0xff, g_zero_skip, bound};
+             top_step, (int)R, T & 0xff, g_zero_skip, bound, row_len};
   const int abl = (T >> 8) & 6;
   const int pi = prof::want(4, (int)R, 512) ? prof::begin((hipStream_t)stream) : -1;
   const dim3 grid((unsigned)((R + nb::ROWS - 1) / nb::ROWS));

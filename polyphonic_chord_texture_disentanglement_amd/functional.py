@@ -730,6 +730,10 @@ def _bgrad(b, a):
 
 
 WGRAD_FUSE_BIAS = True
+# per-row dead work (round 6): inside loss() the teacher-forced decoder works on its rows (t, b) in the order of descending number of live
+# note steps and passes over the (note step, 64-row panel) pairs that hold no target; PTV_SORT_DEC_ROWS=0 = rows in (t, b) order, only
+# the batch-wide limit (PTV_DEAD_STEPS).  Needs both decoder composites (it is implemented behind the C ABI only).
+SORT_DEC_ROWS = os.environ.get('PTV_SORT_DEC_ROWS', '1') != '0'
 WGRAD_BATCH = 3            # ptv_wgrad_batch_mode (scripts/ab_step.py): 0 = products one by one, 1 = one launch, 2 = single launches + one reduction, 3 = small ones batched
 
 
@@ -1780,6 +1784,11 @@ def _decoder_tf_composite(ctx, z, emb, xs, force_dur, prec, P, W, params, B, R, 
             'GATES_N': gates_n, 'PITCH': pitch, 'HD': HD, 'HD16': HD16, 'TAB0': tab0, 'TAB': tab, 'GATES_D': gates_d, 'DUR': dur, 'IDX': idx,
             'XCH': xch, 'SYNC': sync}
     live = live_top_for(dev)
+    srt = _LIVE.get('sort') if live is not None else None
+    if srt is not None and not (force_dur is None and decoder_bwd_composite_static_ok(prec, B, Ht, Hn, NP, Hd, E, P)):
+        srt = None                                            # (the backward composite is the only un-sorter: no sorted forward without it)
+    if srt is not None:
+        tens.update(PERM=srt['perm'], ROW_LEN=srt['len'], NS16S=_empty(R, Ht, dev=dev, dtype=BF16), TOK_S=_empty(15, R, E, dev=dev))
     if live is not None and POISON_DEAD_STEPS:
         _poison(HN16, gates_n, pitch, HD, HD16, gates_d, dur, idx)
     slots = [None] * T_['PTV_DTF_COUNT']
@@ -1804,6 +1813,10 @@ def _decoder_tf_composite(ctx, z, emb, xs, force_dur, prec, P, W, params, B, R, 
     ctx.st = dict(B=B, R=R, E=E, He=He, Ht=Ht, Hn=Hn, Hd=Hd, NP=NP, prec=prec, NS=NS, z_in=z_in, NS16=NS16, HN16=HN16, HD16=HD16,
                   TOKS=TOKS, gates_t=gates_t, HN=HN, gates_n=gates_n, gates_n_rowk=True, pitch=pitch, HD=HD, gates_d=gates_d, idx=idx,
                   dur_tabs=(tab0, tab), dur16_only=True, live_top=live)
+    if srt is not None:
+        srt['used'] = True                # (the loss node now takes the targets in the same row order: _cached_targets)
+        ctx.st['sorted'] = dict(perm=srt['perm'], len=srt['len'], NS16S=tens['NS16S'], TOK_S=tens['TOK_S'])
+        _DTF['sorted_calls'] = _DTF.get('sorted_calls', 0) + 1
     _DTF['calls'] = _DTF.get('calls', 0) + 1
     ctx.mark_non_differentiable(idx)
     # (returned, never stored on ctx: outputs referenced from their own grad_fn are a cycle that only the garbage collector frees -- at an
@@ -2004,6 +2017,17 @@ _DTB_G = (('W_ZHID', 'z2dec_hid_linear.weight'), ('B_ZHID', 'z2dec_hid_linear.bi
           ('B_HH_D', 'dec_dur_gru.bias_hh_l0'), ('SOS', 'dur_sos_token'))
 
 
+def decoder_bwd_composite_static_ok(prec, B, Ht, Hn, NP, Hd, E, P=None):
+    """what _decoder_bwd_composite will ask of the configuration (not of the gradients it is handed): a forward on length-sorted rows
+    commits the backward to the composite -- the only place that scatters the row order back"""
+    return (prec == 1 and ZERO_SKIP and OVERLAP and SUMMARY_FAMILY_SLOT < 0 and DEC_BWD_COMPOSITE and not torch.cuda.is_current_stream_capturing()
+            and DUR_RECOMPUTE and HEADS_WGRAD_FUSED and HEADS_FUSED and BF16_STORAGE and (Hn, NP, Hd) == (512, 130, 64)
+            and notes_persist_ok(prec, Hn, E, BF16) and persist_supported(1, B, Ht, 32) and 15 * 32 * B * 5 >= 4096 and DP_INPLACE
+            and (P is None or all(_WT(P[n], prec) is not None for n in (
+                'dec_notes_gru.weight_ih_l0', 'dec_time_to_notes_hid.weight', 'dec_time_gru.weight_ih_l0', 'dec_time_gru.weight_hh_l0',
+                'z2dec_hid_linear.weight', 'z2dec_in_linear.weight'))))
+
+
 def _decoder_bwd_composite(P, st, z, tok_op, dP, ddur, top_h, side, G):
     """-> decoder_bwd_core's result tuple when ptv_decoder_tf_bwd ran the whole sequence, else None (the caller sequences it: same bits)"""
     if 't' not in _DTB:
@@ -2061,6 +2085,10 @@ def _decoder_bwd_composite(P, st, z, tok_op, dP, ddur, top_h, side, G):
             'XCH': torch.empty(32 * B * 3 * Ht, device=dev, dtype=BF16),
             'PART_T': torch.empty(lib().ptv_gru_persist_part_elems(1, B, Ht, S), device=dev) if S else None,
             'SYNC': _persist_sync(1, dev)}
+    srt = st.get('sorted')
+    if srt is not None:                                   # the forward ran on length-sorted rows: operands in that order, dNS / dtok scattered back
+        tens.update(PERM=srt['perm'], ROW_LEN=srt['len'], NS16S=srt['NS16S'], TOK_OP=srt['TOK_S'].view(M, E), DNS_S=_empty(R, Ht, dev=dev),
+                    DTOK_S=_empty(15, R, E, dev=dev))
     if POISON_DEAD_STEPS and top_h is not None and st.get('live_top') is not None:        # (tests: whatever reads a dead row of these gets NaN -- heads_bwd / the BPTT leave them unwritten)
         _poison(tens['DNSUM'], tens['DGI_N'], tens['DGH_N'], tens['DY16'])
     slots = [None] * T_['PTV_DTB_COUNT']
@@ -2180,6 +2208,9 @@ def decoder_bwd_core(P, st, z, tok_op, dpitch, ddur):
         res = _decoder_bwd_composite(P, st, z, tok_op, dP, ddur, top_h, side, G)
         if res is not None:
             return res
+    if st.get('sorted') is not None:
+        raise RuntimeError('the decoder forward ran on length-sorted rows (PTV_SORT_DEC_ROWS) but ptv_decoder_tf_bwd, the only place that '
+                           'restores the row order, declined this backward pass')
     _defer_flush()                        # (the launch-by-launch sequencing below runs at once)
 
     # ---- duration GRU (5 steps) ----
@@ -2657,7 +2688,28 @@ def arm_live_top(x):
     # (B a multiple of 4: the heads kernel's 128-row blocks must not straddle the limit -- a note step holds 32 B rows)
     if not (DEAD_STEPS and ZERO_SKIP and x.is_cuda and x.dtype == torch.int64 and x.is_contiguous() and x.shape[0] % 4 == 0):
         return None
-    pt, dt, counts = pianotree_targets(x, True)
+    B = x.shape[0]
+    R = 32 * B
+    sort = SORT_DEC_ROWS and DEC_COMPOSITE and DEC_BWD_COMPOSITE and not torch.cuda.is_current_stream_capturing()
+    row_live = _izeros(R, x.device) if sort else None
+    pitch_t = torch.empty(B * 480, device=x.device, dtype=torch.int32)
+    dur_t = torch.empty(B * 2400, device=x.device, dtype=torch.int32)
+    counts = _izeros(3, x.device)
+    call('ptv_pianotree_targets_rows', ptr(x), B, 1, ptr(pitch_t), ptr(dur_t), ptr(counts), ptr(row_live), stream_ptr())
+    pt, dt = pitch_t, dur_t
+    _LIVE.pop('sort', None)
+    if sort:
+        # per-row dead work (round 6): the decoder's rows (t, b) in the order of DESCENDING number of live note steps.  Here: the
+        # permutation, the lengths and the loss targets in that order; the decoder node takes them up if its composite runs
+        # (_decoder_tf_composite) and then marks them used -- the loss node picks the targets that match the logits it is given
+        perm = torch.empty(R, device=x.device, dtype=torch.int32)
+        call('ptv_rows_by_length', ptr(row_live), ptr(perm), R, 15, stream_ptr())
+        len_s = torch.empty(R, device=x.device, dtype=torch.int32)
+        call('ptv_gather_rows', ptr(len_s), ptr(row_live), ptr(perm), R, 1, 0, 0, 1, stream_ptr())
+        pt_s, dt_s = torch.empty_like(pitch_t), torch.empty_like(dur_t)
+        call('ptv_gather_rows', ptr(pt_s), ptr(pitch_t), ptr(perm), R, 1, R, R, 15, stream_ptr())
+        call('ptv_gather_rows', ptr(dt_s), ptr(dur_t), ptr(perm), R, 5, 5 * R, 5 * R, 15, stream_ptr())
+        _LIVE['sort'] = dict(perm=perm, len=len_s, pt=pt_s, dt=dt_s, used=False, x=x.data_ptr())
     _LIVE['x'] = (weakref.ref(x), x.data_ptr(), x._version, True, pt, dt, counts)
     _LIVE['top'] = counts[2:3]
     _LIVE['last_counts'] = counts                               # (bench.py's roofline record: how many note steps the launches ran)
@@ -2680,6 +2732,9 @@ def _cached_targets(x, sm):
     ref, p, ver, sm0, pt, dt, counts = ent
     if ref() is x and x.data_ptr() == p and x._version == ver and bool(sm) == sm0:
         _LIVE.pop('x', None)
+        srt = _LIVE.pop('sort', None)
+        if srt is not None and srt['used'] and srt['x'] == p:      # the decoder node ran on length-sorted rows: its logits are in that order
+            return srt['pt'], srt['dt'], counts
         return pt, dt, counts
     return None
 

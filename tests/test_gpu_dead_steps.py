@@ -33,6 +33,7 @@ def _step(m, x, c, pr, seed):
 
 @pytest.mark.parametrize('B,composite', [(16, True), (16, False), (64, True)])
 def test_dead_note_steps_are_never_read(B, composite, monkeypatch):
+    monkeypatch.setattr(F_, 'SORT_DEC_ROWS', False)              # (rows in (t, b) order: bit-identity with the dense path; sorted rows: next test)
     x, c, pr = (torch.from_numpy(a).to(DEV) for a in synth_batch(B, 99))
     top = int(((x[..., 1:, 0] != 130) | (x[..., 1:, 1:] != 2).any(-1)).any(0).any(0).nonzero().max())
     assert top < 14                                              # (the synthetic data holds at most 8 of 16 note slots: there ARE dead steps)
@@ -52,6 +53,38 @@ def test_dead_note_steps_are_never_read(B, composite, monkeypatch):
     for k in g0:
         assert torch.isfinite(g1[k]).all(), k
         assert torch.equal(g0[k], g1[k]), (k, (g0[k] - g1[k]).abs().max())
+
+
+@pytest.mark.parametrize('B', [16, 64, 512])
+def test_length_sorted_rows_skip_dead_blocks_and_change_nothing(B, monkeypatch):
+    """round 6, per-row dead work: inside loss() the decoder works on its rows (t, b) sorted by the number of live note steps and passes over
+    the (note step, 128-row block) pairs without a target; the loss gets its targets in the same order, the gradients of the time states
+    and of the fed tokens are scattered back.  With EVERY buffer the skipped blocks leave unwritten poisoned with NaN: losses equal to the
+    unsorted step's to fp32 summation order (1e-6), every gradient finite and equal to it within the reordering of the K-deep sums"""
+    from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
+    x, c, pr = (torch.from_numpy(a).to(DEV) for a in synth_batch(B, 99))
+    m = _model()
+    opt = FusedClipAdam(m.parameters(), lr=1e-3)                 # (the backward composite reads the optimiser's transposed weight shadows)
+    res = {}
+    for srt in (False, True):
+        monkeypatch.setattr(F_, 'SORT_DEC_ROWS', srt)
+        monkeypatch.setattr(F_, 'POISON_DEAD_STEPS', srt)
+        n0 = F_._DTF.get('sorted_calls', 0)
+        m.use_philox(5, 0)
+        opt.zero_grad()
+        losses = m.loss(x, c, pr, 1., 1., 1., 0.1, [1, 0.5])
+        losses[0].backward()
+        torch.cuda.synchronize()
+        assert (F_._DTF.get('sorted_calls', 0) - n0 == 1) == srt    # the sorted path ran exactly when asked to
+        res[srt] = ([l.detach().clone() for l in losses], {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+    (l0, g0), (l1, g1) = res[False], res[True]
+    for a, b in zip(l0, l1):
+        assert abs(a.item() - b.item()) <= 2e-6 * max(1.0, abs(a.item())), (a, b)
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), k
+        sc = max(g0[k].abs().max().item(), 1e-12)
+        assert (g0[k] - g1[k]).abs().max().item() <= 2e-3 * sc, (k, (g0[k] - g1[k]).abs().max().item() / sc)
+    F_.persist_check()
 
 
 @pytest.mark.parametrize('switch', ['HEADS_FUSED', 'FUSED_DUR'])

@@ -132,7 +132,7 @@ def test_decoder_tf_composite_entry_point_equals_launch_by_launch_and_reference(
 
 
 @pytest.mark.parametrize('prec,B,via_loss', [('bf16', 512, True), ('bf16', 64, True), ('bf16', 24, True), ('bf16', 16, False), ('fp32', 8, True)])
-def test_backward_composites_equal_python_sequencing(prec, B, via_loss):
+def test_backward_composites_equal_python_sequencing(prec, B, via_loss, monkeypatch):
     """ptv_chord_decoder_bwd, ptv_decoder_tf_bwd and ptv_bigru_final_bwd (one C call each: the chord decoder's / the PianoTree decoder's / an
     encoder bi-GRU's whole backward -- chain,
     the forks of the weight-gradient groups onto the sibling stream, the persistent launches with their event turn) against the launch
@@ -142,6 +142,7 @@ def test_backward_composites_equal_python_sequencing(prec, B, via_loss):
     from polyphonic_chord_texture_disentanglement_amd import functional as F_
     from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam
     x, c, pr = (torch.from_numpy(a).to(DEV) for a in synth_batch(B, 77))
+    monkeypatch.setattr(F_, 'SORT_DEC_ROWS', False)             # (length-sorted rows exist behind the C ABI only: the Python sequencing is the (t, b) order)
     res = {}
     for comp in (True, False):
         m = M.DisentangleVAE.init_model(torch.device(DEV))
