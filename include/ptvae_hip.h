@@ -731,6 +731,8 @@ int ptv_slerp_path(const float* z1, const float* z2, float* out, int B, int D, i
  *     new bf16 state is all-gathered through xch once per note step (8-byte agent-scope stores / loads, one arrival counter per
  *     panel; the launches of t = 0..31 must follow each other in order on one stream), heads / duration GRU / embedding are computed
  *     redundantly by all members and written by member 0.  cnt[ceil(B/16)] != 0 afterwards: a member gave up waiting (results void).
+ *     Bit 21 of train: the 4-wave kernel streams the head weights from L2 every note step instead of keeping them in registers / LDS
+ *     for the whole launch (the kernel before round 6; timing comparisons, bit-identical results).
  *   ptv_free_resummarize: w = { pack(W_ih), pack(W_hh), pack(W_ih_reverse), pack(W_hh_reverse), b_ih, b_hh, b_ih_r, b_hh_r } of
  *     dec_notes_emb_gru; io = { PRED, plen, XH fwd [17][R][128] (slot 0 zero), XH bwd, XG fwd [16][4][R][128] bf16, XG bwd,
  *     tok_next = TOKS[t+1] [B][256] }.

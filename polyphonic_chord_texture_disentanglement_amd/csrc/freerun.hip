@@ -167,7 +167,38 @@ struct NoteLoopArgs {
   unsigned* cnt;                   // [panels] arrival counters (zeroed by the caller before t = 0) + [1] error word
 };
 
+// lane-exchange helpers of the RES = 1 kernel (VALU, no LDS round trip; same operands and the same order of additions as the __shfl_xor forms)
+// (inline asm: hipcc 7.2 miscompiles __builtin_amdgcn_permlane16_swap / 32_swap -- it reads the FIRST result for both elements of the
+// returned pair, scripts/micro/permlane_swap.hip; the s_nop covers the VALU-write -> permlane-read hazard the compiler cannot see)
+__device__ __forceinline__ float xor16_sum(float x) {           // x[l] + x[l ^ 16]: swap the odd 16-lane rows of a with the even rows of b
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float xor32_sum(float x) {           // x[l] + x[l ^ 32]: swap the upper half of a with the lower half of b
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+template <int N> __device__ __forceinline__ int row_ror(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x120 + N, 0xf, 0xf, false); }
+// (value, index) maximum over the 16 lanes of a DPP row, first maximal index on ties; every lane ends with the result
+template <int N> __device__ __forceinline__ void argmax_ror(float& best, int& bi) {
+  const float ov = __builtin_bit_cast(float, row_ror<N>(__builtin_bit_cast(int, best)));
+  const int oi = row_ror<N>(bi);
+  const bool take = ov > best || (ov == best && oi < bi);
+  best = take ? ov : best; bi = take ? oi : bi;
+}
+
+// RES = 1 (round 6): the weights of the HEAD phases never change over the 15 x 32 note steps, and a wave is alone on its SIMD (512
+// registers): the two pitch-head tiles of a wave stay in registers for the whole launch, the third tile of wave 0 (columns 128 / 129
+// only: 2 KB) and the logits part of dur_hid_linear (20 KB) in LDS, the state part of dur_hid_linear is requested when the head
+// phase begins and consumed two phases later, the predicted token's embedding row right after the argmax.  The head phases then
+// hold no exposed L2 round trip (RES = 0 had 8 + 1 + 1 of them per note step on wave 0).  Same products, same k order: bit-identical.
+template <int RES>
 __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16x8 wp8[RES ? 16 * 4 * 2 : 1];   // pitch-head tile 8, rows 128 / 129 only: [kb][quad][row]
+  __shared__ __attribute__((aligned(16))) bf16x8 wdp[RES ? 4 * 5 * 64 : 1];   // dur_hid_linear, logits part (4 tiles x 5 k-blocks)
+  __shared__ __attribute__((aligned(16))) float embc[RES ? 6 : 1][FE];        // note_embedding: bias + the 5 duration columns
   __shared__ __attribute__((aligned(16))) float hf[FP][FHN];                   // notes-GRU state, fp32
   __shared__ __attribute__((aligned(16))) __bf16 h16[2][FP][H16LD];            // its bf16 MFMA-operand copy (double buffered)
   __shared__ __attribute__((aligned(16))) __bf16 tok16[FP][T16LD];             // current input token
@@ -183,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
   __shared__ int pidx[FP];
   __shared__ int bits[FP][5];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: branches on it are not divergent)
   const long t_begin = a.dbg_out ? (long)__builtin_amdgcn_s_memtime() : 0;
   const int crow = lane & 15, ckq = lane >> 4;                // accumulator (C) layout
   const int erow = lane >> 2, eq = lane & 3;                  // epilogue layout
@@ -230,11 +261,45 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
   }
   for (int i = tid; i < FP * (P16LD - FNP); i += 256) pit16[i / (P16LD - FNP)][FNP + i % (P16LD - FNP)] = (__bf16)0.f;   // K padding of the logits operand
   if (tid < FP) pidx[tid] = 0;
+  bf16x8 rp[2][16];                                             // RES: pitch-head tiles `wave` and `wave + 4`, resident
+  if constexpr (RES) {
+    for (int i = tid; i < 16 * 4 * 2; i += 256) {
+      const int r = i & 1, quad = (i >> 1) & 3, kb = i >> 3;
+      wp8[i] = a.wp[((long)8 * 16 + kb) * 64 + quad * 16 + r];
+    }
+    for (int i = tid; i < 4 * 5 * 64; i += 256) wdp[i] = a.wd_p[i];
+    for (int i = tid; i < 6 * FE; i += 256) embc[i / FE][i % FE] = i < FE ? a.b_emb[i] : a.w_embT[(long)(FNP + i / FE - 1) * FE + i % FE];
+#pragma unroll
+    for (int kb = 0; kb < 16; kb++) {
+      rp[0][kb] = a.wp[((long)wave * 16 + kb) * 64 + lane];
+      rp[1][kb] = a.wp[((long)(wave + 4) * 16 + kb) * 64 + lane];
+    }
+  }
+  float bp_r[3][4] = {};                                        // RES: the biases of this lane's head columns (a global load between the head's MFMAs
+  float4 bdh_r = make_float4(0.f, 0.f, 0.f, 0.f);               //      and its LDS stores is a whole L2 round trip on the chain, every note step)
+  if constexpr (RES) {
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int c = (j == 2 ? 8 : wave + 4 * j) * 16 + ckq * 4 + e;
+        bp_r[j][e] = c < FNP ? a.b_p[c] : 0.f;
+      }
+    bdh_r = *reinterpret_cast<const float4*>(a.b_dh + wave * 16 + ckq * 4);
+  }
+  float4 ew0 = make_float4(0.f, 0.f, 0.f, 0.f), ew1 = ew0, eg0 = ew0, eg1 = ew0;   // RES: embedding row of the decision / ground-truth token, requested in P3
+  // timing experiments (dbg_out): 100-MHz ticks wave 0 spends per phase, summed over the 15 note steps -> dbg_out[3 * grid + 8 * block + i],
+  // i = 0 cell (products + epilogue), 1 barrier + state exchange, 2 pitch head, 3 argmax + dur_hid, 4 duration GRU, 5 token embedding
+  long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+  auto PH = [&](int i) {
+    if (a.dbg_out) { const long now = (long)__builtin_amdgcn_s_memrealtime(); if (i >= 0) tph[i] += now - tlast; tlast = now; }
+  };
 
   __syncthreads();
 
   // waves exchange through LDS only inside the loop (every global store is an output nobody here reads back from another
   // wave): lds_barrier() keeps the training-mode stores of states and gates in flight across the 14 barriers of a note step
+  PH(-1);
   for (int n = 0; n < 15; n++) {
     const int cur = n & 1, nxt = cur ^ 1;
     // ================= P1: notes-GRU cell.  wave w owns units [w*128, w*128+128) = 8 tiles of 16, two per pass =================
@@ -292,6 +357,12 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
         }
       }
     }
+    bf16x8 wdh[16];                                              // RES: this wave's tile of dur_hid_linear's state part -- requested here, in
+    if constexpr (RES) {                                         // flight across the state exchange, consumed in the head phase
+#pragma unroll
+      for (int kb = 0; kb < 16; kb++) wdh[kb] = a.wd_h[((long)wave * 16 + kb) * 64 + lane];
+    }
+    PH(0);
     lds_barrier();
     if (S > 1) {
       // ---- all-gather of the new bf16 state: own slices (4/S passes x 4 waves x 32 units x 16 rows) out with write-through (sc1)
@@ -324,13 +395,53 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
       }
       lds_barrier();
     }
+    PH(1);
     // ================= P2: pitch head (9 tiles over 4 waves) + the state part of dur_hid_linear (one tile per wave) =================
     f32x4 accD[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-    {
+    if constexpr (RES) {
+      if (!(a.dbg & 4)) {
+        // operands first, all at once (left to the scheduler -- at this register pressure -- every LDS read is issued right before the MFMA
+        // that consumes it and its latency is paid 16 times), then the MFMAs back to back
+        const int rl = lane & 15, kq = (lane >> 4) * 8;
+        f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int k0 = 0; k0 < 16; k0 += 8) {                       // (two halves: 64 registers of operands instead of 128)
+          bf16x8 av[8], b8[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) av[q] = *reinterpret_cast<const bf16x8*>(&h16[nxt][rl][(k0 + q) * 32 + kq]);
+#pragma unroll
+          for (int q = 0; q < 8; q++) b8[q] = wp8[((k0 + q) * 4 + (lane >> 4)) * 2 + (rl & 1)];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rp[0][k0 + q], av[q], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rp[1][k0 + q], av[q], acc[1], 0, 0, 0);
+            // tile 8 is wave 0's, but every wave runs it: wave 0 is the longest chain either way, and a branch between the MFMAs makes the
+            // compiler copy the accumulators around it
+            if (rl >= 2) b8[q] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b8[q], av[q], acc[2], 0, 0, 0);
+            accD[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdh[k0 + q], av[q], accD[0], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          if (j == 2 && wave != 0) break;
+          const int c0 = (j == 2 ? 8 : wave + 4 * j) * 16 + ckq * 4;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const int c = c0 + e;
+            const float v = c < FNP ? acc[j][e] + bp_r[j][e] : 0.f;
+            pit[crow][c] = v;
+            pit16[crow][c] = (__bf16)v;
+          }
+        }
+      }
+    } else {
       const int tl[1] = {wave};
       panel_mma<1, 16, 8>(a.wd_h, tl, &h16[nxt][0][0], H16LD, accD);
     }
-    for (int nt = wave; nt < ((a.dbg & 4) ? 0 : 9); nt += 4) {
+    for (int nt = wave; nt < ((a.dbg & 4) || RES ? 0 : 9); nt += 4) {
       f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
       const int tl[1] = {nt};
       panel_mma<1, 16, 8>(a.wp, tl, &h16[nxt][0][0], H16LD, acc);
@@ -344,12 +455,30 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
       }
     }
     lds_barrier();
+    PH(2);
     // ================= P3: argmax over the 130 logits (16 lanes per row, first maximal index) + logits out =================
     {
       const int row = tid >> 4, j = tid & 15;
       float best = -INFINITY; int bi = 0x7fffffff;
       const long pr = (long)n * R + (long)t * B + min(r0 + row, B - 1);
       const bool ok = r0 + row < B && lead;
+      if constexpr (RES) {
+        float pv[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) pv[k] = pit[row][j + 16 * k];              // (columns 130..143 of the row exist and hold zeros)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+          const int c = j + 16 * k;
+          const bool take = c < FNP && pv[k] > best;
+          best = take ? pv[k] : best; bi = take ? c : bi;
+        }
+        argmax_ror<8>(best, bi); argmax_ror<4>(best, bi); argmax_ror<2>(best, bi); argmax_ror<1>(best, bi);
+        if (ok) {
+#pragma unroll
+          for (int k = 0; k < 9; k++) if (j + 16 * k < FNP) a.pitch[pr * a.ld_pitch + j + 16 * k] = pv[k];
+        }
+      } else {
 #pragma unroll
       for (int k = 0; k < 9; k++) {
         const int c = j + 16 * k;
@@ -364,15 +493,37 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
         const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
         if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
       }
+      }
       if (a.force_pitch) bi = a.force_pitch[(long)n * R + (long)t * B + min(r0 + row, B - 1)];
       if (j == 0) pidx[row] = bi;
+      if constexpr (RES) {                                        // (every lane of the row holds the decision; P6 maps threads the same way)
+        const float* wr_ = a.w_embT + (long)bi * FE + j * 8;
+        ew0 = *reinterpret_cast<const float4*>(wr_); ew1 = *reinterpret_cast<const float4*>(wr_ + 4);
+        if (n < 14 && ((a.coin_mask >> n) & 1u)) {
+          const float* gp = a.emb + ((long)(n + 1) * R + (long)t * B + min(r0 + row, B - 1)) * FE + j * 8;
+          eg0 = *reinterpret_cast<const float4*>(gp); eg1 = *reinterpret_cast<const float4*>(gp + 4);
+        }
+      }
     }
     // ================= P4: dur_hid_linear([h | logits]) -> initial duration state (wave w = units w*16..) =================
     {
-      const int tl[1] = {wave};
-      panel_mma<1, 5, 8>(a.wd_p, tl, &pit16[0][0], P16LD, accD);               // + the logits part (K = 130 padded to 160)
+      if constexpr (RES) {
+        const int rl = lane & 15, kq = (lane >> 4) * 8;
+        bf16x8 pv16[5], wv[5];
+#pragma unroll
+        for (int kb = 0; kb < 5; kb++) {
+          pv16[kb] = *reinterpret_cast<const bf16x8*>(&pit16[rl][kb * 32 + kq]);
+          wv[kb] = wdp[(wave * 5 + kb) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < 5; kb++) accD[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[kb], pv16[kb], accD[0], 0, 0, 0);
+      } else {
+        const int tl[1] = {wave};
+        panel_mma<1, 5, 8>(a.wd_p, tl, &pit16[0][0], P16LD, accD);             // + the logits part (K = 130 padded to 160)
+      }
       const int u = wave * 16 + ckq * 4;
-      const float4 b4 = *reinterpret_cast<const float4*>(a.b_dh + u);
+      const float4 b4 = RES ? bdh_r : *reinterpret_cast<const float4*>(a.b_dh + u);
       const float h[4] = {accD[0][0] + b4.x, accD[0][1] + b4.y, accD[0][2] + b4.z, accD[0][3] + b4.w};
       *reinterpret_cast<float4*>(&hdf[crow][u]) = make_float4(h[0], h[1], h[2], h[3]);
       st_bf16x4_lds(&hd16[0][crow][u], h[0], h[1], h[2], h[3]);
@@ -382,6 +533,7 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
       }
     }
     lds_barrier();
+    PH(3);
     // ================= P5: 5-step duration GRU, argmax feedback (wave w = units w*16..w*16+15) =================
     {
       const long prC = (long)n * R + wrowC;
@@ -425,8 +577,11 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
           st_bf16x4_lds(gp + 2 * pl, nn[0], nn[1], nn[2], nn[3]);
           st_bf16x4_lds(gp + 3 * pl, hn[0], hn[1], hn[2], hn[3]);
         }
-        o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64);
-        o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64);
+        if constexpr (RES) { o0 = xor16_sum(o0); o1 = xor16_sum(o1); o0 = xor32_sum(o0); o1 = xor32_sum(o1); }
+        else {
+          o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64);
+          o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64);
+        }
         if (lane < 16) { part[dc][wave][lane][0] = o0; part[dc][wave][lane][1] = o1; }
         lds_barrier();
         // every lane forms the two logits of ITS row from the four waves' partial sums and takes the decision itself (no second
@@ -448,6 +603,7 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
       }
     }
     lds_barrier();                                                             // bits[] of the last duration step
+    PH(4);
     // ================= P6: predicted token = note_embedding(onehot(pitch) | 5 duration bits); next input token =================
     {
       const int row = tid >> 4, e0 = (tid & 15) * 8;
@@ -455,13 +611,21 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
       const long wr = (long)t * B + min(r0 + row, B - 1);
       const int pch = pidx[row];
       float v[8];
-      const float4 b0 = *reinterpret_cast<const float4*>(a.b_emb + e0), b1 = *reinterpret_cast<const float4*>(a.b_emb + e0 + 4);
-      const float4 w0 = *reinterpret_cast<const float4*>(a.w_embT + (long)pch * FE + e0), w1 = *reinterpret_cast<const float4*>(a.w_embT + (long)pch * FE + e0 + 4);
+      float4 b0, b1, w0, w1;
+      if constexpr (RES) {
+        b0 = *reinterpret_cast<const float4*>(&embc[0][e0]); b1 = *reinterpret_cast<const float4*>(&embc[0][e0 + 4]);
+        w0 = ew0; w1 = ew1;
+      } else {
+        b0 = *reinterpret_cast<const float4*>(a.b_emb + e0); b1 = *reinterpret_cast<const float4*>(a.b_emb + e0 + 4);
+        w0 = *reinterpret_cast<const float4*>(a.w_embT + (long)pch * FE + e0); w1 = *reinterpret_cast<const float4*>(a.w_embT + (long)pch * FE + e0 + 4);
+      }
       v[0] = b0.x + w0.x; v[1] = b0.y + w0.y; v[2] = b0.z + w0.z; v[3] = b0.w + w0.w;
       v[4] = b1.x + w1.x; v[5] = b1.y + w1.y; v[6] = b1.z + w1.z; v[7] = b1.w + w1.w;
 #pragma unroll
       for (int d = 0; d < 5; d++) {
-        const float4 q0 = *reinterpret_cast<const float4*>(a.w_embT + (long)(FNP + d) * FE + e0), q1 = *reinterpret_cast<const float4*>(a.w_embT + (long)(FNP + d) * FE + e0 + 4);
+        float4 q0, q1;
+        if constexpr (RES) { q0 = *reinterpret_cast<const float4*>(&embc[1 + d][e0]); q1 = *reinterpret_cast<const float4*>(&embc[1 + d][e0 + 4]); }
+        else { q0 = *reinterpret_cast<const float4*>(a.w_embT + (long)(FNP + d) * FE + e0); q1 = *reinterpret_cast<const float4*>(a.w_embT + (long)(FNP + d) * FE + e0 + 4); }
         const float f = (float)bits[row][d];
         v[0] += f * q0.x; v[1] += f * q0.y; v[2] += f * q0.z; v[3] += f * q0.w;
         v[4] += f * q1.x; v[5] += f * q1.y; v[6] += f * q1.z; v[7] += f * q1.w;
@@ -474,7 +638,9 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
       if (n < 14) {
         if ((a.coin_mask >> n) & 1u) {                                          // teacher forcing: the ground-truth note n+1
           const float* gp = a.emb + ((long)(n + 1) * R + wr) * FE + e0;
-          const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
+          float4 g0, g1;
+          if constexpr (RES) { g0 = eg0; g1 = eg1; }
+          else { g0 = *reinterpret_cast<const float4*>(gp); g1 = *reinterpret_cast<const float4*>(gp + 4); }
           v[0] = g0.x; v[1] = g0.y; v[2] = g0.z; v[3] = g0.w; v[4] = g1.x; v[5] = g1.y; v[6] = g1.z; v[7] = g1.w;
         }
         if (a.tok_store && ok) {
@@ -499,8 +665,10 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
       }
     }
     lds_barrier();
+    PH(5);
   }
   if (a.dbg_out && tid == 0) {
+    for (int i = 0; i < 6; i++) a.dbg_out[3L * gridDim.x + 8L * blockIdx.x + i] = tph[i];
     unsigned xcc, hwid;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -1110,7 +1278,11 @@ extern "C" int ptv_free_note_loop(const void* const* w, const void* const* io, l
   // bench.py's roofline record of the step loop (tag 7): 15 note steps per launch; algorithmic MFMA work of a launch = 15 note steps x B rows x
   // (gate products 2*3Hn*(Hn+E) + pitch head 2*130*Hn + dur_hid 2*64*(Hn+130) + 5 duration steps 2*3*64*64 + token embedding 2*128*135)
   const int pi = prof::want(7, B, FHN) ? prof::begin((hipStream_t)stream) : -1;
-  if (!split) hipLaunchKernelGGL(note_loop_kernel, dim3(a.S > 1 ? (panels + 7) / 8 * 8 * a.S : panels), dim3(256), 0, (hipStream_t)stream, a);
+  if (!split) {
+    const dim3 grid(a.S > 1 ? (panels + 7) / 8 * 8 * a.S : panels);
+    if (train & 0x200000) hipLaunchKernelGGL(note_loop_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);   // bit 21: head weights streamed (timing comparisons)
+    else hipLaunchKernelGGL(note_loop_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  }
   else hipLaunchKernelGGL(note_loop2_kernel, dim3(panels), dim3(512), 0, (hipStream_t)stream, a);
   if (pi >= 0) prof::end(pi, (hipStream_t)stream, 15.0 * B * (2.0 * 3 * FHN * (FHN + 128) + 2.0 * 130 * FHN + 2.0 * 64 * (FHN + 130) + 5 * 2.0 * 3 * 64 * 64 + 2.0 * 128 * 135));
   PTV_CHECK_LAUNCH();
