@@ -718,7 +718,7 @@ int ptv_slerp_path(const float* z1, const float* z2, float* out, int B, int D, i
  *            xhat [B][32][16][6] int64, plen [R] int32 (zeroed), force_pitch [15][R] or NULL, force_dur [5][M] or NULL,
  *            HN16 [16][R][512] bf16 or NULL, HD16 [6][M][64] bf16 or NULL (bf16 state copies for the backward; HD16 replaces HD[1..5]) }
  *     io[17] = NULL (timing experiments), io[18] = NULL or fp32 [B][2048] = [initial state | gc] of this time step (then io[0] is
- *     ignored and slot 0 of HN is written by the kernel); io[19] = xch, bf16 [ceil(B/16)][2][16][512], io[20] = cnt, uint32
+ *     ignored and slot 0 of HN is written by the kernel); io[19] = xch, 8-byte words [ceil(B/16)][2][16][256], io[20] = cnt, uint32
  *     [ceil(B/16) + 1] ZEROED by the caller before the launch of t = 0 (cluster mode below; else NULL): io has 21 entries;
  *     with R = 32*B, M = 15*R; the rows of time step t are [t*B, (t+1)*B).  coin_mask bit n = feed the ground-truth note n+1
  *     (teacher-forcing coin, ptvae.py:420).  train = 0 skips what only the backward reads (HN, gates, HD, TOK); train = 2 stores only
@@ -728,9 +728,11 @@ int ptv_slerp_path(const float* z1, const float* z2, float* out, int B, int D, i
  *     products under the head phases of the current one (default: by panel count).
  *     Bits 18-20 of train = S in {2, 4}: cluster mode of the 4-wave kernel -- S workgroups (co-resident: ceil(B/16) * S <= 128, else
  *     PTV_ERR_UNSUPPORTED) share a panel: each streams 1/S of the notes-GRU gate weights (the product bound by one CU's L2 port), the
- *     new bf16 state is all-gathered through xch once per note step (8-byte agent-scope stores / loads, one arrival counter per
- *     panel; the launches of t = 0..31 must follow each other in order on one stream), heads / duration GRU / embedding are computed
- *     redundantly by all members and written by member 0.  cnt[ceil(B/16)] != 0 afterwards: a member gave up waiting (results void).
+ *     new bf16 state is all-gathered through xch once per note step as 8-byte words {2 units, step tag} that the readers poll
+ *     (agent-scope stores / loads; xch = ceil(B/16) x 2 x 16 x 256 words = 64 KB per panel, ZEROED by the caller before t = 0; cnt counts
+ *     arrivals for diagnostics; the launches of t = 0..31 must follow each other in order on one stream), heads / duration GRU /
+ *     embedding are computed redundantly by all members and written by member 0.  cnt[ceil(B/16)] != 0 afterwards: a member gave up
+ *     waiting (results void).
  *     Bit 21 of train: the 4-wave kernel streams the head weights from L2 every note step instead of keeping them in registers / LDS
  *     for the whole launch (the kernel before round 6; timing comparisons, bit-identical results).
  *   ptv_free_resummarize: w = { pack(W_ih), pack(W_hh), pack(W_ih_reverse), pack(W_hh_reverse), b_ih, b_hh, b_ih_r, b_hh_r } of

@@ -143,6 +143,7 @@ __global__ void pack_b_kernel(const float* __restrict__ W, long ld, int N, int K
 // =============================================================================================
 typedef __attribute__((address_space(1))) unsigned gu32;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 struct NoteLoopArgs {
   const bf16x8 *wg_h, *wg_t, *wp, *wd_h, *wd_p, *wdur;
@@ -302,6 +303,10 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
   PH(-1);
   for (int n = 0; n < 15; n++) {
     const int cur = n & 1, nxt = cur ^ 1;
+    // cluster mode: exchange buffer of this note step (double buffered) as 16 x 256 8-byte words {2 bf16 units, step tag}
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(S > 1 ? (void*)(a.xch + ((long)panel * 2 + (n & 1)) * (FP * FHN * 2)) : nullptr, 0,
+                                                                        S > 1 ? FP * FHN * 4 : 0, 0x00020000);
+    const unsigned xseq = (unsigned)(t * 15 + n + 1);
     // ================= P1: notes-GRU cell.  wave w owns units [w*128, w*128+128) = 8 tiles of 16, two per pass =================
 #pragma unroll 1
     for (int p = p_lo; p < ((a.dbg & 2) ? 0 : p_hi); p++) {
@@ -345,6 +350,13 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
         }
         *reinterpret_cast<float4*>(&hf[erow][u]) = make_float4(h[0], h[1], h[2], h[3]);
         st_bf16x4_lds(&h16[nxt][erow][u], h[0], h[1], h[2], h[3]);
+        if (S > 1) {                                              // cluster mode: the new state leaves for the other members right here
+          bf16x4 hv; hv[0] = (__bf16)h[0]; hv[1] = (__bf16)h[1]; hv[2] = (__bf16)h[2]; hv[3] = (__bf16)h[3];
+          const u32x2 d2 = __builtin_bit_cast(u32x2, hv);
+          const int wofs = (erow * FHN + u) * 4;                  // byte offset of the 8-byte word {2 units, step tag} of units u, u + 1
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{d2[0], xseq}, xr, wofs, 0, 16);        // sc1
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{d2[1], xseq}, xr, wofs + 8, 0, 16);
+        }
         if (a.train && okE) {
           *reinterpret_cast<float4*>(a.HN + ((long)(n + 1) * R + wrowE) * FHN + u) = make_float4(h[0], h[1], h[2], h[3]);
           if (a.HN16) st_bf16x4_lds(a.HN16 + ((long)(n + 1) * R + wrowE) * FHN + u, h[0], h[1], h[2], h[3]);
@@ -363,35 +375,56 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
       for (int kb = 0; kb < 16; kb++) wdh[kb] = a.wd_h[((long)wave * 16 + kb) * 64 + lane];
     }
     PH(0);
-    lds_barrier();
+    if (S == 1) lds_barrier();
     if (S > 1) {
-      // ---- all-gather of the new bf16 state: own slices (4/S passes x 4 waves x 32 units x 16 rows) out with write-through (sc1)
-      // stores, one arrival per member, the other members' slices in with sc1 loads (16-byte pieces: 8 units of a row)
-      __bf16* xb = a.xch + ((long)panel * 2 + (n & 1)) * (FP * FHN);
-      const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xb, 0, FP * FHN * 2, 0x00020000);
-      const int npo = 4 / S;
-      for (int i = tid; i < 256 * npo; i += 256) {
-        const int piece = i & 3, row = (i >> 2) & 15, wp = i >> 6;               // wp: (wave, owned pass)
-        const int u = (wp / npo) * 128 + (p_lo + wp % npo) * 32 + piece * 8;
-        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&h16[nxt][row][u]), xr, (row * FHN + u) * 2, 0, 16);   // sc1
+      // ---- all-gather of the new bf16 state (round 6: flag-in-data).  Every member has written its units as 8-byte words {2 units, step
+      // tag} straight from the cell epilogue (single-copy atomic, sc1 = agent scope); a reader polls the WORDS it needs until they carry
+      // this step's tag -- no arrival counter to bump and poll, no store acknowledgement to wait for: one L2 round trip after the last
+      // member's stores land instead of four.  The caller zeroes xch before t = 0 (tag 0 never matches); a buffer is rewritten two
+      // note steps later, which its writer can only reach after every reader has sent the step in between.
+      const int nfo = 4 - 4 / S, npo = 4 / S;                    // foreign / own passes per wave
+      unsigned pend = 0;
+      int wofs[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int i2 = tid + 256 * q, piece = i2 & 3, row = (i2 >> 2) & 15, wp = i2 >> 6;   // wp: (wave, foreign pass)
+        const int fp = wp % nfo, pass = fp < p_lo ? fp : fp + npo;
+        const int u = (wp / nfo) * 128 + pass * 32 + piece * 8;
+        wofs[q] = (row * FHN + u) * 4;
+        if (q < nfo) pend |= 0xfu << (4 * q);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) {
-        __hip_atomic_fetch_add(xcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned target = (unsigned)(t * 15 + n + 1) * S;
-        unsigned spins = 0;
-        while (!dead && __hip_atomic_load(xcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1u << 24)) { __hip_atomic_store(xerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; }
-        }
+      if (tid == 0) __hip_atomic_fetch_add(xcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (diagnostics only: nobody waits on it)
+      unsigned spins = 0;
+      // throttle: wave 0 first watches ONE word per foreign pass (a late one: row 15, last units of wave 3's tile) with a sleep between
+      // looks -- 256 lanes x 12 words of polling per workgroup slowed the weight streams of the members still in their cell (B = 1024:
+      // +1 us per note step); the words themselves are still checked one by one below
+      while (!dead && wave == 0) {
+        bool all = true;
+#pragma unroll
+        for (int fp = 0; fp < 3; fp++)
+          if (fp < nfo) {
+            const int pass = fp < p_lo ? fp : fp + npo;
+            const u32x2 sv = __builtin_amdgcn_raw_buffer_load_b64(xr, (15 * FHN + 3 * 128 + pass * 32 + 30) * 4, 0, 16);
+            all = all && sv[1] == xseq;
+          }
+        if (all) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 22)) { __hip_atomic_store(xerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; }
       }
-      __syncthreads();
-      for (int i = tid; i < 256 * (4 - npo); i += 256) {
-        const int piece = i & 3, row = (i >> 2) & 15, wp = i >> 6;               // wp: (wave, foreign pass)
-        const int fp = wp % (4 - npo), pass = fp < p_lo ? fp : fp + npo;
-        const int u = (wp / (4 - npo)) * 128 + pass * 32 + piece * 8;
-        *reinterpret_cast<u32x4*>(&h16[nxt][row][u]) = __builtin_amdgcn_raw_buffer_load_b128(xr, (row * FHN + u) * 2, 0, 16);            // sc1
+      lds_barrier();                                              // (wave 0 watched for the other three)
+      while (pend && !dead) {
+        u32x2 v[12];
+#pragma unroll
+        for (int w = 0; w < 12; w++)
+          if ((pend >> w) & 1u) v[w] = __builtin_amdgcn_raw_buffer_load_b64(xr, wofs[w >> 2] + 8 * (w & 3), 0, 16);                     // sc1
+#pragma unroll
+        for (int w = 0; w < 12; w++)
+          if (((pend >> w) & 1u) && v[w][1] == xseq) {
+            const int o = wofs[w >> 2] >> 2;                     // = row * 512 + u
+            *reinterpret_cast<unsigned*>(&h16[nxt][o >> 9][(o & 511) + 2 * (w & 3)]) = v[w][0];
+            pend &= ~(1u << w);
+          }
+        if (pend && ++spins > (1u << 22)) { __hip_atomic_store(xerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; }
       }
       lds_barrier();
     }

@@ -359,7 +359,7 @@ class DecoderStepFn(torch.autograd.Function):
                 cluster = 0          # a captured training forward replays next to other streams' persistent launches, unordered with them
             if cluster:
                 global LAST_CLUSTER_COUNTERS
-                xch = _empty((B + 15) // 16 * 2 * 16 * Hn, dev=dev, dtype=torch.bfloat16)
+                xch = torch.zeros((B + 15) // 16 * 2 * 16 * Hn * 2, device=dev, dtype=torch.bfloat16)   # 8-byte words {2 units, step tag}: tag 0 = nothing sent yet
                 xcnt = torch.zeros((B + 15) // 16 + 1, device=dev, dtype=torch.int32)    # arrival counters of t = 0..31 + error word
                 LAST_CLUSTER_COUNTERS = xcnt             # (tests: every panel counts 32 * 15 * S arrivals, the error word stays 0)
                 F_._CLUSTER_SYNC.append(xcnt)

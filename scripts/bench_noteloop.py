@@ -1,7 +1,8 @@
 """Standalone timing of ptv_free_note_loop (the free-running decoder's step loop, freerun.hip): 32 launches (one per time step) of 15
 note steps each, the configuration functional_free uses for training (replay mode: train word 2, cluster S = 4 up to 64 panels).
 Prints us per dependent note step for the head-weights-resident kernel and the streamed one (train bit 21), and with phases skipped
-(dbg bits: 1 gate MFMAs, 2 whole cell, 4 pitch head, 8 duration GRU -- results invalid, timing only).
+(dbg bits: 1 gate MFMAs, 4 pitch head, 8 duration GRU -- results invalid, timing only; bit 2 = no cell would stop the cluster's state
+exchange, which leaves from the cell epilogue), and the per-phase timers of wave 0.
 usage: python scripts/bench_noteloop.py [B ...]"""
 import sys
 import torch
@@ -42,7 +43,7 @@ def main():
         PRED = torch.zeros(16, R, 128, device=dev)
         xhat = torch.zeros(B, 32, 16, 6, device=dev, dtype=torch.long)
         plen = torch.zeros(R, device=dev, dtype=torch.int32)
-        xch = torch.empty(panels * 2 * 16 * 512, device=dev, dtype=bf)
+        xch = torch.zeros(panels * 2 * 16 * 512 * 2, device=dev, dtype=bf)
         cnt = torch.zeros(panels + 1, device=dev, dtype=torch.int32)
         io = F_._parr([GC[0], emb, HN, None, pitch, None, None, dur, idx, TOK, PRED, xhat, plen, None, None, None, None, None, None,
                        xch if S > 1 else None, cnt if S > 1 else None])
@@ -51,13 +52,12 @@ def main():
         del io
         print(f'B = {B}: {panels} panels x S = {S}')
         for name, extra in (('resident heads', 0), ('streamed heads (bit 21)', 0x200000),
-                            ('resident, no gate MFMAs', 1 << 8), ('resident, no cell', 2 << 8), ('resident, no pitch head', 4 << 8),
-                            ('resident, no duration GRU', 8 << 8), ('resident, no cell/pitch/dur', (2 | 4 | 8) << 8),
-                            ('streamed, no pitch head', 0x200000 | (4 << 8)), ('resident heads', 0), ('streamed heads (bit 21)', 0x200000)):
+                            ('resident, no gate MFMAs', 1 << 8), ('resident, no pitch head', 4 << 8), ('resident, no duration GRU', 8 << 8),
+                            ('resident heads', 0), ('streamed heads (bit 21)', 0x200000)):
             flags = 2 | 0x10000 | ((S if S > 1 else 0) << 18) | extra
             best = 1e9
             for rep in range(4):
-                cnt.zero_(); plen.zero_()
+                cnt.zero_(); plen.zero_(); xch.zero_()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for t in range(32):
@@ -73,7 +73,7 @@ def main():
         for name, extra in (('resident', 0), ('streamed', 0x200000)):
             iod = F_._parr([GC[5], emb, HN, None, pitch, None, None, dur, idx, TOK, PRED, xhat, plen, None, None, None, None, dbg, None,
                             xch if S > 1 else None, cnt if S > 1 else None])
-            cnt.zero_()
+            cnt.zero_(); xch.zero_()
             for t in range(6):
                 call('ptv_free_note_loop', wl, iod if t == 5 else ios[t], 136, B, t, 0, 2 | 0x10000 | ((S if S > 1 else 0) << 18) | extra | ((64 << 8) if t == 5 else 0), stream_ptr())
             torch.cuda.synchronize()

@@ -894,7 +894,7 @@ def test_note_loop_cluster_mode_is_bit_identical_to_one_workgroup_per_panel(B):
             PRED = torch.zeros(16, R, 128, device=dev)
             xhat = torch.zeros(B, 32, 16, 6, device=dev, dtype=torch.long)
             plen = torch.zeros(R, device=dev, dtype=torch.int32)
-            xch = torch.empty(panels * 2 * 16 * 512, device=dev, dtype=bf)
+            xch = torch.zeros(panels * 2 * 16 * 512 * 2, device=dev, dtype=bf)
             cnt = torch.zeros(panels + 1, device=dev, dtype=torch.int32)
             for t in (0, 1):
                 io = F_._parr([GC[t], emb, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, None, None, None, None, None, None,
