@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
   __shared__ float tabs[3][3 * FHD];
   __shared__ float bhd[3 * FHD];
   __shared__ float wo[2 * FHD + 2];
-  __shared__ float part[2][4][FP][2];                                          // double buffered: one barrier per duration step
+  __shared__ __attribute__((aligned(8))) float part[2][4][FP][2];              // double buffered: one barrier per duration step
   __shared__ int pidx[FP];
   __shared__ int bits[FP][5];
 
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
       }
     bdh_r = *reinterpret_cast<const float4*>(a.b_dh + wave * 16 + ckq * 4);
   }
-  float4 ew0 = make_float4(0.f, 0.f, 0.f, 0.f), ew1 = ew0, eg0 = ew0, eg1 = ew0;   // RES: embedding row of the decision / ground-truth token, requested in P3
+  float4 ew0 = make_float4(0.f, 0.f, 0.f, 0.f), ew1 = ew0;      // RES: embedding row of the decision, requested in P3
   // timing experiments (dbg_out): 100-MHz ticks wave 0 spends per phase, summed over the 15 note steps -> dbg_out[3 * grid + 8 * block + i],
   // i = 0 cell (products + epilogue), 1 barrier + state exchange, 2 pitch head, 3 argmax + dur_hid, 4 duration GRU, 5 token embedding
   long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
@@ -532,10 +532,6 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
       if constexpr (RES) {                                        // (every lane of the row holds the decision; P6 maps threads the same way)
         const float* wr_ = a.w_embT + (long)bi * FE + j * 8;
         ew0 = *reinterpret_cast<const float4*>(wr_); ew1 = *reinterpret_cast<const float4*>(wr_ + 4);
-        if (n < 14 && ((a.coin_mask >> n) & 1u)) {
-          const float* gp = a.emb + ((long)(n + 1) * R + (long)t * B + min(r0 + row, B - 1)) * FE + j * 8;
-          eg0 = *reinterpret_cast<const float4*>(gp); eg1 = *reinterpret_cast<const float4*>(gp + 4);
-        }
       }
     }
     // ================= P4: dur_hid_linear([h | logits]) -> initial duration state (wave w = units w*16..) =================
@@ -568,7 +564,107 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
     lds_barrier();
     PH(3);
     // ================= P5: 5-step duration GRU, argmax feedback (wave w = units w*16..w*16+15) =================
-    {
+    if constexpr (RES) {
+      // The five steps unrolled with every invariant of the phase in registers (weight fragments, the three possible input rows, biases,
+      // this lane's fp32 state) and the LDS reads that follow a barrier issued together: the chain of a step is barrier -> {partial
+      // logits, state operand} in ONE LDS round trip -> decision (VALU) beside the MFMAs -> cell.  Before: the input row was looked up in
+      // LDS AFTER the decision and the four partial sums were read one round trip each (0.85 us per step).  Same arithmetic, same order.
+      const long prC = (long)n * R + wrowC;
+      const int u = wave * 16 + ckq * 4;
+      if (!(a.dbg & 8)) {
+        float4 tb[3][3], bh[3];
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+#pragma unroll
+          for (int tk = 0; tk < 3; tk++) tb[tk][g] = *reinterpret_cast<const float4*>(&tabs[tk][g * FHD + u]);
+          bh[g] = *reinterpret_cast<const float4*>(&bhd[g * FHD + u]);
+        }
+        const float4 wo0 = *reinterpret_cast<const float4*>(&wo[u]), wo1 = *reinterpret_cast<const float4*>(&wo[FHD + u]);
+        const float wb0 = wo[2 * FHD], wb1 = wo[2 * FHD + 1];
+        bf16x8 wd[3][2];
+#pragma unroll
+        for (int g = 0; g < 3; g++)
+#pragma unroll
+          for (int kb = 0; kb < 2; kb++) wd[g][kb] = wdl[((g * 4 + wave) * 2 + kb) * 64 + lane];
+        const float4 hp0 = *reinterpret_cast<const float4*>(&hdf[crow][u]);     // (this lane wrote it in P4)
+        float hp[4] = {hp0.x, hp0.y, hp0.z, hp0.w};
+        bf16x8 av[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) av[kb] = *reinterpret_cast<const bf16x8*>(&hd16[0][crow][kb * 32 + ckq * 8]);
+        float2 q[4] = {};
+        int dtk = 0;                                                           // this lane's row: 0 = <sos>, 1 + previous decision
+        auto decide = [&](int d) {                                             // logits and decision of duration step d from the four waves' partial sums
+          const float e0 = q[0].x + q[1].x + q[2].x + q[3].x + wb0;
+          const float e1 = q[0].y + q[1].y + q[2].y + q[3].y + wb1;
+          int id = e1 > e0 ? 1 : 0;                                             // first max wins ties (torch.max)
+          if (a.force_dur) id = a.force_dur[(long)d * M + prC];
+          dtk = 1 + id;
+          if (tid < FP) {                                                      // wave 0, lanes 0..15: crow == tid
+            if (okC) {
+              a.dur[prC * 10 + 2 * d] = e0; a.dur[prC * 10 + 2 * d + 1] = e1;
+              a.idx[(long)d * M + prC] = id;
+            }
+            bits[tid][d] = id;
+          }
+        };
+#pragma unroll
+        for (int d = 0; d < 5; d++) {
+          const int dc = d & 1, dn = dc ^ 1;
+          __builtin_amdgcn_sched_barrier(0);
+          if (d > 0) decide(d - 1);
+          f32x4 acc[3];
+#pragma unroll
+          for (int g = 0; g < 3; g++) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int g = 0; g < 3; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd[g][kb], av[kb], acc[g], 0, 0, 0);
+          float gi[3][4];
+#pragma unroll
+          for (int g = 0; g < 3; g++) {
+            const float4 t0 = d == 0 ? tb[0][g] : tb[1][g], t1 = d == 0 ? tb[0][g] : tb[2][g];
+            const bool two = dtk == 2;
+            gi[g][0] = two ? t1.x : t0.x; gi[g][1] = two ? t1.y : t0.y; gi[g][2] = two ? t1.z : t0.z; gi[g][3] = two ? t1.w : t0.w;
+          }
+          const float bR[4] = {bh[0].x, bh[0].y, bh[0].z, bh[0].w}, bZ[4] = {bh[1].x, bh[1].y, bh[1].z, bh[1].w}, bN[4] = {bh[2].x, bh[2].y, bh[2].z, bh[2].w};
+          const float w0v[4] = {wo0.x, wo0.y, wo0.z, wo0.w}, w1v[4] = {wo1.x, wo1.y, wo1.z, wo1.w};
+          float r[4], z[4], nn[4], hn[4], h[4], o0 = 0.f, o1 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            r[e] = fsig(gi[0][e] + acc[0][e] + bR[e]);
+            z[e] = fsig(gi[1][e] + acc[1][e] + bZ[e]);
+            hn[e] = acc[2][e] + bN[e];
+            nn[e] = ftanh(gi[2][e] + r[e] * hn[e]);
+            h[e] = (1.0f - z[e]) * nn[e] + z[e] * hp[e];
+            o0 += w0v[e] * h[e]; o1 += w1v[e] * h[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; e++) hp[e] = h[e];
+          st_bf16x4_lds(&hd16[dn][crow][u], h[0], h[1], h[2], h[3]);
+          if (a.train && okC) {
+            if (a.HD16) st_bf16x4_lds(a.HD16 + ((long)(d + 1) * M + prC) * FHD + u, h[0], h[1], h[2], h[3]);
+            else *reinterpret_cast<float4*>(a.HD + ((long)(d + 1) * M + prC) * FHD + u) = make_float4(h[0], h[1], h[2], h[3]);
+            __bf16* gp = a.gates_d + (((long)d * 4) * M + prC) * FHD + u;
+            const long pl = M * FHD;
+            st_bf16x4_lds(gp, r[0], r[1], r[2], r[3]);
+            st_bf16x4_lds(gp + pl, z[0], z[1], z[2], z[3]);
+            st_bf16x4_lds(gp + 2 * pl, nn[0], nn[1], nn[2], nn[3]);
+            st_bf16x4_lds(gp + 3 * pl, hn[0], hn[1], hn[2], hn[3]);
+          }
+          o0 = xor16_sum(o0); o1 = xor16_sum(o1); o0 = xor32_sum(o0); o1 = xor32_sum(o1);
+          if (lane < 16) *reinterpret_cast<float2*>(&part[dc][wave][lane][0]) = make_float2(o0, o1);
+          lds_barrier();
+#pragma unroll
+          for (int w = 0; w < 4; w++) q[w] = *reinterpret_cast<const float2*>(&part[dc][w][crow][0]);
+          if (d < 4) {
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++) av[kb] = *reinterpret_cast<const bf16x8*>(&hd16[dn][crow][kb * 32 + ckq * 8]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        decide(4);
+      }
+    } else {
       const long prC = (long)n * R + wrowC;
       const int u = wave * 16 + ckq * 4;
       int dtk = 0;                                                             // this lane's row: 0 = <sos>, 1 + previous decision
@@ -620,8 +716,18 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
         // every lane forms the two logits of ITS row from the four waves' partial sums and takes the decision itself (no second
         // barrier to pass the token around); the panel's first 16 threads also publish them
         {
-          const float e0 = part[dc][0][crow][0] + part[dc][1][crow][0] + part[dc][2][crow][0] + part[dc][3][crow][0] + wo[2 * FHD];
-          const float e1 = part[dc][0][crow][1] + part[dc][1][crow][1] + part[dc][2][crow][1] + part[dc][3][crow][1] + wo[2 * FHD + 1];
+          float e0, e1;
+          if constexpr (RES) {                                                  // (the four reads in flight together; same order of additions)
+            const float2 q0 = *reinterpret_cast<const float2*>(&part[dc][0][crow][0]), q1 = *reinterpret_cast<const float2*>(&part[dc][1][crow][0]);
+            const float2 q2 = *reinterpret_cast<const float2*>(&part[dc][2][crow][0]), q3 = *reinterpret_cast<const float2*>(&part[dc][3][crow][0]);
+            const float w0_ = wo[2 * FHD], w1_ = wo[2 * FHD + 1];
+            __builtin_amdgcn_sched_barrier(0);
+            e0 = q0.x + q1.x + q2.x + q3.x + w0_;
+            e1 = q0.y + q1.y + q2.y + q3.y + w1_;
+          } else {
+            e0 = part[dc][0][crow][0] + part[dc][1][crow][0] + part[dc][2][crow][0] + part[dc][3][crow][0] + wo[2 * FHD];
+            e1 = part[dc][0][crow][1] + part[dc][1][crow][1] + part[dc][2][crow][1] + part[dc][3][crow][1] + wo[2 * FHD + 1];
+          }
           int id = e1 > e0 ? 1 : 0;                                             // first max wins ties (torch.max)
           if (a.force_dur) id = a.force_dur[(long)d * M + prC];
           dtk = 1 + id;
@@ -671,9 +777,7 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
       if (n < 14) {
         if ((a.coin_mask >> n) & 1u) {                                          // teacher forcing: the ground-truth note n+1
           const float* gp = a.emb + ((long)(n + 1) * R + wr) * FE + e0;
-          float4 g0, g1;
-          if constexpr (RES) { g0 = eg0; g1 = eg1; }
-          else { g0 = *reinterpret_cast<const float4*>(gp); g1 = *reinterpret_cast<const float4*>(gp + 4); }
+          const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
           v[0] = g0.x; v[1] = g0.y; v[2] = g0.z; v[3] = g0.w; v[4] = g1.x; v[5] = g1.y; v[6] = g1.z; v[7] = g1.w;
         }
         if (a.tok_store && ok) {
