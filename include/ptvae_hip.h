@@ -737,7 +737,8 @@ int ptv_slerp_path(const float* z1, const float* z2, float* out, int B, int D, i
  *     for the whole launch (the kernel before round 6; timing comparisons, bit-identical results).
  *   ptv_free_resummarize: w = { pack(W_ih), pack(W_hh), pack(W_ih_reverse), pack(W_hh_reverse), b_ih, b_hh, b_ih_r, b_hh_r } of
  *     dec_notes_emb_gru; io = { PRED, plen, XH fwd [17][R][128] (slot 0 zero), XH bwd, XG fwd [16][4][R][128] bf16, XG bwd,
- *     tok_next = TOKS[t+1] [B][256] }.
+ *     tok_next = TOKS[t+1] [B][256] }.  train bit 0: save states and gates (XH, XG) for the backward; bit 1: stream the weights from L2
+ *     every step instead of keeping a wave's 48 fragments in registers for the launch (timing comparisons, bit-identical).
  */
 long ptv_pack_mfma_b_size(int N, int K);
 int ptv_pack_mfma_b(const float* W, long ld, int N, int K, void* out, int pairs, void* stream);

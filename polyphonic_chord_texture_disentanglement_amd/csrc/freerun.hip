@@ -1230,15 +1230,44 @@ __global__ __launch_bounds__(256, 1) void resum_kernel(ResumArgs a) {
     bI[j] = *reinterpret_cast<const float4*>(a.b_ih[dir] + 2 * FHE + u);
     bH[j] = *reinterpret_cast<const float4*>(a.b_hh[dir] + 2 * FHE + u);
   }
+  // round 6: the weights of the 16 steps are the same 48 fragments per wave (192 registers; a wave is alone on its SIMD): loaded ONCE
+  // instead of streamed from L2 every step (48 KB per wave and step was 1.9 of a step's 3.2 us); the A operands of a step are read
+  // from LDS in one batch ahead of the MFMAs.  Same products in the same k order as gate_products<4, 4>: bit-identical.
+  const int ut0 = wave * 2;
+  const int tl[6] = {ut0, ut0 + 1, 8 + ut0, 9 + ut0, 16 + ut0, 17 + ut0};
+  bf16x8 wih[6][4], whh[6][4];
+#pragma unroll
+  for (int j = 0; j < 6; j++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      wih[j][q] = a.w_ih[dir][((long)tl[j] * 4 + q) * 64 + lane];
+      whh[j][q] = a.w_hh[dir][((long)tl[j] * 4 + q) * 64 + lane];
+    }
   __syncthreads();
   for (int s = 0; s < 16; s++) {
     const int tt = dir ? 15 - s : s, cur = s & 1, nxt = cur ^ 1;
     f32x4 accX[6], accH[6];                                     // (r0, r1, z0, z1, n0, n1): x . W_ih^T and h . W_hh^T
 #pragma unroll
     for (int j = 0; j < 6; j++) accX[j] = accH[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ut0 = wave * 2;
-    const int tl[6] = {ut0, ut0 + 1, 8 + ut0, 9 + ut0, 16 + ut0, 17 + ut0};
-    gate_products<4, 4>(a.w_ih[dir], a.w_hh[dir], tl, &x16[tt][0][0], T16LD, &h16[cur][0][0], T16LD, accX, accH);
+    if (a.train & 2) gate_products<4, 4>(a.w_ih[dir], a.w_hh[dir], tl, &x16[tt][0][0], T16LD, &h16[cur][0][0], T16LD, accX, accH);   // (timing comparisons)
+    else {
+      const int rl = lane & 15, kq = (lane >> 4) * 8;
+      bf16x8 ax[4], ah[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        ax[q] = *reinterpret_cast<const bf16x8*>(&x16[tt][rl][q * 32 + kq]);
+        ah[q] = *reinterpret_cast<const bf16x8*>(&h16[cur][rl][q * 32 + kq]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) accX[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wih[j][q], ax[q], accX[j], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) accH[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whh[j][q], ah[q], accH[j], 0, 0, 0);
+    }
     const bool live = tt < len;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
@@ -1264,7 +1293,7 @@ __global__ __launch_bounds__(256, 1) void resum_kernel(ResumArgs a) {
       *reinterpret_cast<float4*>(&hf[erow][u]) = make_float4(h[0], h[1], h[2], h[3]);
       st_bf16x4_lds(&h16[nxt][erow][u], h[0], h[1], h[2], h[3]);
       if (okE) {
-        if (a.train) {
+        if (a.train & 1) {
           *reinterpret_cast<float4*>(a.XH[dir] + ((long)(s + 1) * R + wrowE) * FHE + u) = make_float4(h[0], h[1], h[2], h[3]);
           __bf16* gp = a.XG[dir] + (((long)s * 4) * R + wrowE) * FHE + u;
           const long pl = (long)R * FHE;
@@ -1431,7 +1460,7 @@ extern "C" int ptv_free_resummarize(const void* const* w, const void* const* io,
   if (!w || !io || B <= 0 || t < 0 || t >= 32) return PTV_ERR_ARG;
   for (int i = 0; i < 8; i++) if (!w[i]) return PTV_ERR_ARG;
   if (!io[0] || !io[1] || !io[6]) return PTV_ERR_ARG;
-  if (train && (!io[2] || !io[3] || !io[4] || !io[5])) return PTV_ERR_ARG;
+  if ((train & 1) && (!io[2] || !io[3] || !io[4] || !io[5])) return PTV_ERR_ARG;
   ResumArgs a{};
   a.w_ih[0] = (const bf16x8*)w[0]; a.w_hh[0] = (const bf16x8*)w[1]; a.w_ih[1] = (const bf16x8*)w[2]; a.w_hh[1] = (const bf16x8*)w[3];
   a.b_ih[0] = (const float*)w[4]; a.b_hh[0] = (const float*)w[5]; a.b_ih[1] = (const float*)w[6]; a.b_hh[1] = (const float*)w[7];

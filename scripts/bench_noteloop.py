@@ -28,6 +28,8 @@ def main():
                    P['pitch_out_linear.bias'], P['dur_hid_linear.bias'], P['dec_dur_gru.bias_hh_l0'], tab0, tab,
                    P['dur_out_linear.weight'], P['dur_out_linear.bias'], pk['w_embT'], P['note_embedding.bias']])
     bf = torch.bfloat16
+    wE = [P['dec_notes_emb_gru.' + n] for n in FF_.EMB_GRU]
+    wr = F_._parr([pk['e_ih'], pk['e_hh'], pk['e_ih_r'], pk['e_hh_r'], wE[2], wE[3], wE[6], wE[7]])
     for B in Bs:
         R, M = 32 * B, 15 * 32 * B
         panels = (B + 15) // 16
@@ -67,6 +69,22 @@ def main():
                 best = min(best, e0.elapsed_time(e1))
             err = int(cnt[-1]) if S > 1 else 0
             print(f'  {name:34s} {best:7.3f} ms per forward   {best * 1e3 / (32 * 15):6.2f} us per note step   err={err}')
+        # the re-summarisation of the predicted notes (ptv_free_resummarize): one launch per time step, 16 dependent bi-GRU steps each
+        toks = torch.zeros(33, B, 256, device=dev)
+        plen.fill_(9)
+        ior = [F_._parr([PRED, plen, None, None, None, None, toks[t + 1]]) for t in range(32)]
+        for name, fl in (('weights resident', 0), ('weights streamed (train bit 1)', 2)):
+            best = 1e9
+            toks.zero_()
+            for rep in range(4):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for t in range(32):
+                    call('ptv_free_resummarize', wr, ior[t], B, t, fl, stream_ptr())
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            print(f'  re-summarisation, {name:30s} {best:7.3f} ms per forward   {best * 1e3 / 32:6.2f} us per launch   {best * 1e3 / (32 * 16):6.2f} us per GRU step   checksum {float(toks.double().abs().sum()):.9f}')
         # per-phase time of wave 0 (100-MHz ticks summed over a launch's 15 note steps), one launch at t = 5, member 0 of panel 0 .. 3 and a foreign member
         grid = (panels + 7) // 8 * 8 * S if S > 1 else panels
         dbg = torch.zeros(3 * grid + 8 * grid, device=dev, dtype=torch.long)
