@@ -1429,9 +1429,9 @@ extern "C" int ptv_free_note_loop(const void* const* w, const void* const* io, l
   // deep prefetch (30.4 vs 32.0 us per note step); with many panels (B = 2048) the chip's L2 is the limit and the overlap wins
   // (47.0 -> 40.8 us).  train bit 16 / 17 force the 4-wave / 8-wave kernel.
   const int panels = (B + FP - 1) / FP;
-  const bool split = (train & 0x20000) || (!(train & 0x10000) && panels >= 96);
   // cluster mode: S members per panel, all co-resident (they wait for each other once per note step): at most one member per CU
   const int S = (train >> 18) & 7;
+  const bool split = (train & 0x20000) || (!(train & 0x10000) && panels >= 96 && S <= 1);      // (a cluster request means the 4-wave kernel)
   a.S = 1;
   if (S > 1) {
     // (round 4: up to one member per CU -- 64 panels x 4 members at B = 1024, the per-GPU batch of BASELINE configs[4]; the launch takes

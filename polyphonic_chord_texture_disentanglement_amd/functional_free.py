@@ -83,9 +83,11 @@ NOTE_LOOP_CLUSTER = None if os.environ.get('PTV_NOTE_CLUSTER') is None else int(
 
 def note_loop_cluster(B):
     panels = (B + 15) // 16
-    if NOTE_LOOP_SPLIT or (NOTE_LOOP_SPLIT is None and panels >= 96):
-        return 0
     ncu = _num_cu()
+    # round 6: from 96 panels on the 8-wave producer / head kernel used to take over; with the head weights resident and the state exchange
+    # flag-in-data, two members per panel on the 4-wave kernel win up to one member per CU (B = 2048: 34.9 vs 41.7 us per note step)
+    if NOTE_LOOP_SPLIT or (NOTE_LOOP_SPLIT is None and panels >= 96 and panels * 2 > ncu):
+        return 0
     if NOTE_LOOP_CLUSTER is not None:
         return NOTE_LOOP_CLUSTER if NOTE_LOOP_CLUSTER in (2, 4) and panels * NOTE_LOOP_CLUSTER <= ncu else 0
     # round 4: four members per panel up to ONE MEMBER PER CU (64 panels = B 1024, the per-GPU batch of BASELINE configs[4]); it was capped at

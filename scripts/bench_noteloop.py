@@ -55,8 +55,12 @@ def main():
         print(f'B = {B}: {panels} panels x S = {S}')
         for name, extra in (('resident heads', 0), ('streamed heads (bit 21)', 0x200000),
                             ('resident, no gate MFMAs', 1 << 8), ('resident, no pitch head', 4 << 8), ('resident, no duration GRU', 8 << 8),
-                            ('resident heads', 0), ('streamed heads (bit 21)', 0x200000)):
+                            ('resident heads', 0), ('streamed heads (bit 21)', 0x200000), ('8-wave kernel, no cluster', -1), ('4-wave resident, no cluster', -2)):
             flags = 2 | 0x10000 | ((S if S > 1 else 0) << 18) | extra
+            if extra == -1:
+                flags = 2 | 0x20000                      # the 8-wave producer / head kernel, one workgroup per panel
+            if extra == -2:
+                flags = 2 | 0x10000                      # the 4-wave kernel, one workgroup per panel
             best = 1e9
             for rep in range(4):
                 cnt.zero_(); plen.zero_(); xch.zero_()

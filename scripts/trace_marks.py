@@ -13,7 +13,8 @@ from polyphonic_chord_texture_disentanglement_amd.model import DisentangleVAE  #
 from polyphonic_chord_texture_disentanglement_amd.optim import FusedClipAdam  # noqa: E402
 from polyphonic_chord_texture_disentanglement_amd.synthetic import synth_batch  # noqa: E402
 
-B = 512
+B = int(os.environ.get('BATCH', '512'))
+TFR = float(os.environ.get('TFR', '1'))          # 0 = free-running training (train.py's schedule from its third batch on)
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
 random.seed(7)
@@ -26,7 +27,7 @@ data = tuple(torch.from_numpy(a).to(dev) for a in synth_batch(B, 99))
 def step():
     opt.zero_grad()
     F_.mark('step:start')
-    o = m('train', *data, tfr1=1.0, tfr2=1.0, tfr3=1.0, beta=0.1, weights=[1, 0.5])
+    o = m('train', *data, tfr1=TFR, tfr2=TFR, tfr3=TFR, beta=0.1, weights=[1, 0.5])
     F_.mark('fwd:end')
     o[0].backward()
     F_.mark('bwd:end')
