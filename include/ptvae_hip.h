@@ -570,6 +570,8 @@ enum PtvDtbTensor {
   PTV_DTB_NS16S,          /* [R, Ht] bf16 gathered time states (operand of the weight_ih / time_to_notes gradients) */
   PTV_DTB_DNS_S,          /* scratch [R, Ht] fp32: the gradient of the time states in sorted row order, scattered into DNS */
   PTV_DTB_DTOK_S,         /* scratch [15, R, E] fp32: the token gradient in sorted row order, scattered into DTOK */
+  PTV_DTB_SEG_N,          /* int32 [15] (ptv_rows_seg_counts of ROW_LEN) or NULL: the weight-gradient products over (note step, row) skip the dead
+                             blocks of every step (sorted mode only) */
   PTV_DTB_COUNT
 };
 enum PtvDtbDim { PTV_DTB_D_B = 0, PTV_DTB_D_E, PTV_DTB_D_HE, PTV_DTB_D_HT, PTV_DTB_D_HN, PTV_DTB_D_HD, PTV_DTB_D_NP, PTV_DTB_D_ZS, PTV_DTB_D_ZI,
@@ -1002,8 +1004,17 @@ typedef struct ptv_wgrad_job {
   int accumulate, dtypes, slabs;
   float* colsum_a;
   const int* k_top; long k_unit; int k_rev;
+  /* round 6, K SEGMENTS (or seg_n = NULL): K runs over units of seg_unit rows (a note step's R decoder rows in length order); of unit q only the
+   * first seg_n[q % seg_period] rows (device ints, multiples of 32) hold anything -- the rest of A is zero and the rest of B may never have
+   * been written.  The product skips them (slabs never straddle a unit: seg_unit must be a power of two >= 256 that divides K), and so does
+   * the ordered reduction; against the same product without segments the result is bit-identical when the skipped rows of A are zero. */
+  const int* seg_n; long seg_unit; int seg_period;
 } ptv_wgrad_job;
 int ptv_wgrad_batch(const ptv_wgrad_job* jobs, int njobs, void* stream);
+/* seg_n[s] = 128 * #{128-row blocks whose FIRST row has row_len > s}, s < steps: the live prefix of every note step when the decoder's rows run
+ * in descending length order (ptv_rows_by_length) and a block is dead beyond its first row's length -- what the *_rows kernels of the decoder
+ * skip and ptv_wgrad_batch's segments clip.  R a multiple of 128. */
+int ptv_rows_seg_counts(const int* row_len, long R, int steps, int* seg_n, void* stream);
 
 
 #ifdef __cplusplus

@@ -33,6 +33,8 @@ int ptv_prof_read(long* count, double* total_ms, double* flops);
 /* of a tag's summed FLOPs, the part that runs under a device-side row limit (ptv_wgrad's k_top): products over the decoder's 15 note steps
  * (lim15) and over the note-summary GRU's 16 note positions (lim16) -- what bench.py scales by the batch's live fraction */
 int ptv_prof_read_limited(int tag, double* lim15, double* lim16);
+/* the part of lim15 whose products also skip the dead 128-row blocks of every note step (ptv_wgrad_job.seg_n) */
+int ptv_prof_read_segmented(int tag, double* seg);
 
 /* A/B aid: 0 = ptv_wgrad_batch issues its products one by one (same bits, one product + one reduction launch each); 1 (default) = batched.
  * Process-wide; PTV_WGRAD_BATCH=0 sets it at load. */

@@ -120,7 +120,8 @@ class WgradJob(ctypes.Structure):
     _fields_ = [('M', ctypes.c_int), ('N', ctypes.c_int), ('K', ctypes.c_int), ('A', ctypes.c_void_p), ('lda', ctypes.c_long),
                 ('B', ctypes.c_void_p), ('ldb', ctypes.c_long), ('C', ctypes.c_void_p), ('ldc', ctypes.c_long), ('alpha', ctypes.c_float),
                 ('accumulate', ctypes.c_int), ('dtypes', ctypes.c_int), ('slabs', ctypes.c_int), ('colsum_a', ctypes.c_void_p),
-                ('k_top', ctypes.c_void_p), ('k_unit', ctypes.c_long), ('k_rev', ctypes.c_int)]
+                ('k_top', ctypes.c_void_p), ('k_unit', ctypes.c_long), ('k_rev', ctypes.c_int),
+                ('seg_n', ctypes.c_void_p), ('seg_unit', ctypes.c_long), ('seg_period', ctypes.c_int)]
 
 
 def wgrad_batch(jobs, stream=None):
@@ -134,6 +135,7 @@ def wgrad_batch(jobs, stream=None):
         q.dtypes = (1 if A.dtype == torch.bfloat16 else 0) | (2 if B.dtype == torch.bfloat16 else 0)
         q.colsum_a, q.k_top = ptr(j.get('colsum_a')), ptr(j.get('k_top'))
         q.k_unit, q.k_rev = j.get('k_unit', 0), j.get('k_rev', 0)
+        q.seg_n, q.seg_unit, q.seg_period = ptr(j.get('seg_n')), j.get('seg_unit', 0), j.get('seg_period', 0)
     check(lib().ptv_wgrad_batch(arr, len(jobs), stream if stream is not None else stream_ptr()), 'ptv_wgrad_batch')
 
 

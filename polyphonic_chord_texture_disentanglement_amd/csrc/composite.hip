@@ -26,10 +26,12 @@ struct WgradGroup {
   ptv_wgrad_job jobs[8]; int n = 0; int P; void* stream;
   WgradGroup(int prec, void* st) : P(prec), stream(st) {}
   int add(int M, int N, long K, const void* A, long lda, int a_bf16, const void* B, long ldb, int b_bf16, float* C, long ldc, float* csum,
-          const int* k_top = nullptr, long k_unit = 0, int k_rev = 0, int accumulate = 1) {
+          const int* k_top = nullptr, long k_unit = 0, int k_rev = 0, int accumulate = 1, const int* seg_n = nullptr, long seg_unit = 0,
+          int seg_period = 0) {
     if (P == PTV_PREC_BF16 && K >= 512) {
       if (n == 8) PTV_TRY(flush());
-      jobs[n++] = ptv_wgrad_job{M, N, (int)K, A, lda, B, ldb, C, ldc, 1.f, accumulate, (a_bf16 ? 1 : 0) | (b_bf16 ? 2 : 0), 0, csum, k_top, k_unit, k_rev};
+      jobs[n++] = ptv_wgrad_job{M, N, (int)K, A, lda, B, ldb, C, ldc, 1.f, accumulate, (a_bf16 ? 1 : 0) | (b_bf16 ? 2 : 0), 0, csum, k_top, k_unit, k_rev,
+                                seg_n, seg_n ? seg_unit : 0, seg_n ? seg_period : 0};
       return PTV_OK;
     }
     if (k_top) return PTV_ERR_ARG;
@@ -273,7 +275,7 @@ extern "C" int ptv_decoder_tf_bwd(const void* const* t, const long* d, void* str
   if (!t || !d) return PTV_ERR_ARG;
   for (int i = 0; i < PTV_DTB_COUNT; i++)
     if (!t[i] && i != PTV_DTB_TOP_H && i != PTV_DTB_PART_T && i != PTV_DTB_WAIT_EVENT && i != PTV_DTB_RECORD_EVENT && i != PTV_DTB_PERM &&
-        i != PTV_DTB_ROW_LEN && i != PTV_DTB_NS16S && i != PTV_DTB_DNS_S && i != PTV_DTB_DTOK_S)
+        i != PTV_DTB_ROW_LEN && i != PTV_DTB_NS16S && i != PTV_DTB_DNS_S && i != PTV_DTB_DTOK_S && i != PTV_DTB_SEG_N)
       return PTV_ERR_ARG;
   // the forward ran on rows sorted by length: every per-row tensor here is in that order; the two gradients that leave the node for
   // row-order-aware consumers (the time states', the fed tokens') are scattered back
@@ -283,12 +285,15 @@ extern "C" int ptv_decoder_tf_bwd(const void* const* t, const long* d, void* str
     return PTV_ERR_ARG;
   const int* perm = (const int*)T_(t, PTV_DTB_PERM);
   const int* row_len = (const int*)T_(t, PTV_DTB_ROW_LEN);
+
   const int B = (int)d[PTV_DTB_D_B], E = (int)d[PTV_DTB_D_E], He = (int)d[PTV_DTB_D_HE], Ht = (int)d[PTV_DTB_D_HT], Hn = (int)d[PTV_DTB_D_HN],
             Hd = (int)d[PTV_DTB_D_HD], NP = (int)d[PTV_DTB_D_NP], Zs = (int)d[PTV_DTB_D_ZS], Zi = (int)d[PTV_DTB_D_ZI], nblk = (int)d[PTV_DTB_D_NBLK],
             S = (int)d[PTV_DTB_D_SPLITK];
   const long ldp = d[PTV_DTB_D_LDP];
   if (B <= 0 || E != 128 || Hn != 512 || Hd != 64 || NP != 130 || ldp < NP || nblk <= 0 || (S && !t[PTV_DTB_PART_T])) return PTV_ERR_UNSUPPORTED;
   const int R = 32 * B;
+  // K segments of the weight-gradient products over (note step, sorted row): the dead blocks of every step are neither read nor multiplied
+  const int* seg_n = t[PTV_DTB_PERM] && !(R & (R - 1)) && R >= 256 ? (const int*)T_(t, PTV_DTB_SEG_N) : nullptr;
   const long M = 15L * R;
   const int P = PTV_PREC_BF16;
   hipStream_t s = (hipStream_t)stream, side = (hipStream_t)const_cast<void*>(t[PTV_DTB_SIDE_STREAM]);
@@ -334,8 +339,8 @@ extern "C" int ptv_decoder_tf_bwd(const void* const* t, const long* d, void* str
     const __bf16* nsum = HN16 + (long)R * Hn;                       // the note summaries = states 1 .. 15
     float* tmp = GB(PTV_DTB_TMP200); float* cs = GB(PTV_DTB_CS200);
     WgradGroup wg(P, sside);                                       // both head products in one launch
-    PTV_TRY(wg.add(200, Hn, M, dY16, 200, 1, nsum, Hn, 1, tmp, Hn, cs, top_h, top_unit, 0, 0));
-    PTV_TRY(wg.add(Hd, NP, M, dHD0, Hd, 0, T_(t, PTV_DTB_PITCH), ldp, 0, GB(PTV_DTB_G_W_DH) + Hn, (long)Hn + NP, nullptr, top_h, top_unit, 0));
+    PTV_TRY(wg.add(200, Hn, M, dY16, 200, 1, nsum, Hn, 1, tmp, Hn, cs, top_h, top_unit, 0, 0, seg_n, R, 15));
+    PTV_TRY(wg.add(Hd, NP, M, dHD0, Hd, 0, T_(t, PTV_DTB_PITCH), ldp, 0, GB(PTV_DTB_G_W_DH) + Hn, (long)Hn + NP, nullptr, top_h, top_unit, 0, 1, seg_n, R, 15));
     PTV_TRY(wg.flush());
     PTV_TRY(ptv_copy2d(GB(PTV_DTB_G_W_P), Hn, tmp, Hn, NP, Hn, 1.f, 1, sside));
     PTV_TRY(ptv_copy2d(GB(PTV_DTB_G_B_P), NP, cs, NP, 1, NP, 1.f, 1, sside));
@@ -373,10 +378,10 @@ extern "C" int ptv_decoder_tf_bwd(const void* const* t, const long* d, void* str
     // the five parameter gradients of the notes GRU and of dec_time_to_notes_hid: ONE product launch + ONE reduction launch; the four bias
     // gradients are column sums taken from the A tiles in LDS (round 5: five products, five reductions, two column-sum passes over dGC / dHN0)
     WgradGroup wg(P, sside);
-    PTV_TRY(wg.add(2 * Hn, Hn, M, dgi_n, 3L * Hn, 1, HN16, Hn, 1, gw, Hn, gb, top_step, R, 0));
-    PTV_TRY(wg.add(Hn, Hn, M, dgh_n, Hn, 1, HN16, Hn, 1, gw + 2L * Hn * Hn, Hn, gb + 2 * Hn, top_step, R, 0));
+    PTV_TRY(wg.add(2 * Hn, Hn, M, dgi_n, 3L * Hn, 1, HN16, Hn, 1, gw, Hn, gb, top_step, R, 0, 1, seg_n, R, 15));
+    PTV_TRY(wg.add(Hn, Hn, M, dgh_n, Hn, 1, HN16, Hn, 1, gw + 2L * Hn * Hn, Hn, gb + 2 * Hn, top_step, R, 0, 1, seg_n, R, 15));
     PTV_TRY(wg.add(3 * Hn, Ht, R, dGC, 3L * Hn, 0, NSf, Ht, 1, gih, (long)Ht + E, GB(PTV_DTB_G_B_IH_N)));
-    PTV_TRY(wg.add(3 * Hn, E, M, dgi_n, 3L * Hn, 1, T_(t, PTV_DTB_TOK_OP), E, 0, gih + Ht, (long)Ht + E, nullptr, top_step, R, 0));
+    PTV_TRY(wg.add(3 * Hn, E, M, dgi_n, 3L * Hn, 1, T_(t, PTV_DTB_TOK_OP), E, 0, gih + Ht, (long)Ht + E, nullptr, top_step, R, 0, 1, seg_n, R, 15));
     PTV_TRY(wg.add(Hn, Ht, R, dHN0, Hn, 0, NSf, Ht, 1, GB(PTV_DTB_G_W_T2N), Ht, GB(PTV_DTB_G_B_T2N)));
     PTV_TRY(wg.flush());
   }

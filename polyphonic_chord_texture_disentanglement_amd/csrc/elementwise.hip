@@ -526,6 +526,25 @@ static int rows_by_index(bool scatter, void* dst, const void* src, const int* id
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
+// live prefix of every note step when the rows run in descending length order and deadness goes by 128-row blocks (include/ptvae_hip.h)
+__global__ void rows_seg_counts_kernel(const int* __restrict__ row_len, int nblk, int steps, int* __restrict__ seg_n) {
+  __shared__ int cnt[64];
+  for (int i = threadIdx.x; i < steps; i += blockDim.x) cnt[i] = 0;
+  __syncthreads();
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
+    const int len = row_len[(long)b * 128];
+    for (int s_ = 0; s_ < steps && s_ < len; s_++) atomicAdd(&cnt[s_], 128);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < steps; i += blockDim.x) seg_n[i] = cnt[i];
+}
+extern "C" int ptv_rows_seg_counts(const int* row_len, long R, int steps, int* seg_n, void* stream) {
+  if (!row_len || !seg_n || R <= 0 || (R & 127) || steps <= 0 || steps > 64) return PTV_ERR_ARG;
+  hipLaunchKernelGGL(rows_seg_counts_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_len, (int)(R >> 7), steps, seg_n);
+  PTV_CHECK_LAUNCH();
+  return PTV_OK;
+}
+
 extern "C" int ptv_gather_rows(void* dst, const void* src, const int* idx, long rows, int row_words, long src_plane_words, long dst_plane_words,
                                int planes, void* stream) {
   return rows_by_index(false, dst, src, idx, rows, row_words, src_plane_words, dst_plane_words, planes, stream);

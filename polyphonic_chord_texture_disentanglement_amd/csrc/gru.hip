@@ -392,7 +392,7 @@ constexpr int MAXEV = 8192;
 static int enabled = 0, filt_M = 0, filt_H = 0;          // enabled: bit (tag-1) set = record launches of that family
 static hipEvent_t ev0[MAXEV], ev1[MAXEV];
 static int slot_tag[MAXEV];
-static double slot_flops[MAXEV], slot_aux[MAXEV][2];
+static double slot_flops[MAXEV], slot_aux[MAXEV][3];
 static int created = 0, used = 0, cur_tag = 0;
 bool want(int tag, int M, int H) {
   // (tags 5 = weight-gradient products, 6 = BPTT of the persistent small-M recurrences: whole families, no shape filter)
@@ -412,10 +412,10 @@ int begin(hipStream_t s) {
 void end(int i, hipStream_t s, double fl) {
   (void)hipEventRecord(ev1[i], s);
   slot_flops[i] = fl;
-  slot_aux[i][0] = slot_aux[i][1] = 0.0;
+  slot_aux[i][0] = slot_aux[i][1] = slot_aux[i][2] = 0.0;
   used = i + 1;
 }
-void aux(int i, double a, double b) { slot_aux[i][0] = a; slot_aux[i][1] = b; }
+void aux(int i, double a, double b, double c) { slot_aux[i][0] = a; slot_aux[i][1] = b; slot_aux[i][2] = c; }
 }  // namespace prof
 
 template <class CT, bool SA, bool SB, int FAST>
@@ -599,6 +599,16 @@ extern "C" int ptv_prof_read_limited(int tag, double* lim15, double* lim16) {
   }
   if (lim15) *lim15 = a;
   if (lim16) *lim16 = b;
+  return PTV_OK;
+}
+// ... and the part of lim15 whose products also clip K segments (ptv_wgrad_job.seg_n: the dead blocks of every note step)
+extern "C" int ptv_prof_read_segmented(int tag, double* seg) {
+  double c = 0.0;
+  for (int i = 0; i < ptv::prof::used; i++) {
+    if (tag != 0 && ptv::prof::slot_tag[i] != tag) continue;
+    c += ptv::prof::slot_aux[i][2];
+  }
+  if (seg) *seg = c;
   return PTV_OK;
 }
 extern "C" int ptv_prof_read(long* count, double* total_ms, double* flops) { return ptv_prof_read_tag(0, count, total_ms, flops); }

@@ -55,6 +55,7 @@ struct WgArgs {
   // matrices that meet the same B (the notes GRU's dgi[:, :1024] and dgh: one pass over the states instead of two), or null
   const void* A2; long lda2; int split;
   int k_base;                    // this launch's first row in the numbering of the k_top limits (the guarded tail launch starts at kfast)
+  const int* seg_n; int seg_unit, seg_period;   // K segments (ptv_wgrad_job): of unit q = row / seg_unit only the first seg_n[q % seg_period] rows are live
 };
 
 // which part of a slab's K range survives the k_top limits: shared by the product kernel and the ordered reduction (a slab that is
@@ -74,6 +75,13 @@ __device__ __forceinline__ bool slab_range(const WgArgs& g, int slab, int& k_beg
   if (k_begin >= k_lim || k_begin + g.kper <= k_from) return false;
   k_end = min(k_lim, k_begin + g.kper);
   if (k_from > k_begin) k_begin = k_from;                         // (k_from is a multiple of 32 like every slab start)
+  if (g.seg_n) {                                                  // (kper divides seg_unit: a slab lies inside one unit)
+    const long row = (long)k_begin + g.k_base;
+    const int q = (int)(row / g.seg_unit), r0 = (int)(row - (long)q * g.seg_unit);
+    const int live = g.seg_n[q % g.seg_period] - r0;             // live rows from the slab's first row on
+    if (live <= 0) return false;
+    if (k_end - k_begin > live) k_end = k_begin + live;
+  }
   return true;
 }
 
@@ -500,15 +508,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgArgs g) {
 // bi / nb: this block's number among the nb blocks that work on this product (grid-stride over its elements).
 __device__ __forceinline__ void wgrad_reduce_block(const WgArgs& ga, const WgArgs& gb, int has_a, int has_b, int accumulate, int bi, int nb) {
   const int tiles = ga.tiles_m * ga.tiles_n;
-  // the live slabs of the fast launch are one contiguous range (the k_top limits cut K at one end): [s0, s1)
+  // the live slabs of the fast launch are one contiguous range (the k_top limits cut K at one end): [s0, s1) -- or, with K segments, a list
+  // (one thread per slab finds out, a ballot keeps them in slab order: at most 256 slabs, wgrad_run)
+  __shared__ unsigned short lst[256];
+  __shared__ int wtot[4];
+  const bool listed = ga.seg_n != nullptr;
   int s0 = 0, s1 = 0;
-  if (has_a) {
+  if (has_a && listed) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int kb, ke;
+    const bool lv = tid < ga.nslab && slab_range(ga, tid, kb, ke);
+    const unsigned long long m = __ballot(lv);
+    if (lane == 0) wtot[wv] = __popcll(m);
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; w++) base += wtot[w];
+    if (lv) lst[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)tid;
+    s1 = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    __syncthreads();
+  } else if (has_a) {
     bool any = false;
     for (int sl = 0; sl < ga.nslab; sl++) {
       int kb, ke;
       if (slab_range(ga, sl, kb, ke)) { if (!any) s0 = sl; s1 = sl + 1; any = true; }
     }
   }
+  auto SL = [&](int i) { return listed ? (long)lst[i] : (long)i; };
   bool live_b = false;
   if (has_b) { int kb, ke; live_b = slab_range(gb, 0, kb, ke); }
   const long tstride = (long)tiles * (WBM * WBN);
@@ -527,12 +552,12 @@ __device__ __forceinline__ void wgrad_reduce_block(const WgArgs& ga, const WgArg
       for (; sl + 8 <= s1; sl += 8) {                               // eight partials in flight, added in slab order
         float4 v[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = *reinterpret_cast<const float4*>(p + (long)(sl + q) * tstride);
+        for (int q = 0; q < 8; q++) v[q] = *reinterpret_cast<const float4*>(p + SL(sl + q) * tstride);
 #pragma unroll
         for (int q = 0; q < 8; q++) { sum.x += v[q].x; sum.y += v[q].y; sum.z += v[q].z; sum.w += v[q].w; }
       }
       for (; sl < s1; sl++) {
-        const float4 v = *reinterpret_cast<const float4*>(p + (long)sl * tstride);
+        const float4 v = *reinterpret_cast<const float4*>(p + SL(sl) * tstride);
         sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
       }
       if (live_b) { const float4 v = *reinterpret_cast<const float4*>(wb + off); sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w; }
@@ -552,11 +577,11 @@ __device__ __forceinline__ void wgrad_reduce_block(const WgArgs& ga, const WgArg
       for (; sl + 8 <= s1; sl += 8) {
         float v[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = p[(long)(sl + q) * tstride];
+        for (int q = 0; q < 8; q++) v[q] = p[SL(sl + q) * tstride];
 #pragma unroll
         for (int q = 0; q < 8; q++) sum += v[q];
       }
-      for (; sl < s1; sl++) sum += p[(long)sl * tstride];
+      for (; sl < s1; sl++) sum += p[SL(sl) * tstride];
       if (live_b) sum += wb[off];
       float* cp = ga.C + (long)m * ga.ldc + n;
       *cp = (accumulate ? *cp : 0.f) + ga.alpha * sum;
@@ -565,7 +590,7 @@ __device__ __forceinline__ void wgrad_reduce_block(const WgArgs& ga, const WgArg
   if (ga.ws_csum) {                                                 // the bias gradient (always accumulates)
     for (long m = gstart; m < ga.M; m += gstride) {
       float sum = 0.f;
-      for (int sl = s0; sl < s1; sl++) sum += ga.ws_csum[(long)sl * ga.M + m];
+      for (int sl = s0; sl < s1; sl++) sum += ga.ws_csum[SL(sl) * ga.M + m];
       if (live_b) sum += gb.ws_csum[(long)gb.slab0 * ga.M + m];
       ga.csum[m] += sum;
     }
@@ -649,6 +674,7 @@ namespace {
 struct Job {
   int M, N, K; const void* A; long lda; const void* A2; long lda2; int split; const void* B; long ldb; float* C; long ldc;
   float alpha; int accumulate, dtypes, slabs; float* colsum_a; const int* k_top; long k_unit; int k_rev;
+  const int* seg_n = nullptr; long seg_unit = 0; int seg_period = 0;
 };
 // ... and how it runs: the fast (unguarded) launch over rows [0, kfast) and the guarded one over the rest, each cut into K slabs.
 // A pure function of the job (shapes, alignment) and of the process-wide mode: one product planned alone or inside a batch runs the
@@ -674,7 +700,8 @@ int plan_job(const Job& j, Plan& p) {
     WgArgs g{static_cast<const char*>(j.A) + (long)k0 * j.lda * (af ? 4 : 2), j.lda, static_cast<const char*>(j.B) + (long)k0 * j.ldb * (bf ? 4 : 2), j.ldb,
              j.C, j.ldc, j.M, j.N, kn, 0, cdiv(j.M, WBM), cdiv(j.N, WBN), 1, 0, j.alpha, j.colsum_a, j.k_top, j.k_unit, j.k_rev, g_gemm_prio,
              nullptr, nullptr, 0,
-             j.A2 ? static_cast<const char*>(j.A2) + (long)k0 * j.lda2 * (af ? 4 : 2) : nullptr, j.lda2, j.split, k0};
+             j.A2 ? static_cast<const char*>(j.A2) + (long)k0 * j.lda2 * (af ? 4 : 2) : nullptr, j.lda2, j.split, k0,
+             j.seg_n, (int)j.seg_unit, j.seg_period};
     // (the guarded tail launch takes the limits too, shifted by its first row: the rows a limit declares zero may never have been WRITTEN by
     // whoever produced the other operand -- a forward that stopped at the batch's last live note step)
     const int tiles = p.tiles;     // BLOCKS per slab
@@ -697,6 +724,21 @@ int plan_job(const Job& j, Plan& p) {
     // map 2 gives an XCD a range of tiles for all slabs (B columns are then fetched by every XCD: fine when K is short), map 1 gives it
     // whole slabs -- every K row is fetched by one XCD only (PMC on 1536 x 512 x 245760: L2 hit 29 % and 3.3x the algorithmic bytes from
     // the fabric with map 2)
+    if (j.seg_n) {
+      // K segments: a slab must lie inside one unit -- kper = the largest power of two <= the wanted depth that divides seg_unit (>= 128 rows);
+      // at most 256 slabs (the reduction lists the live ones with one thread per slab)
+      int kper = 128;
+      const int want = cdiv(kn, ns);
+      while (kper * 2 <= want && kper * 2 <= (int)j.seg_unit) kper *= 2;
+      while (cdiv(kn, kper) > 256 && kper * 2 <= (int)j.seg_unit) kper *= 2;
+      g.kper = kper; ns = cdiv(kn, kper);
+      const bool can1 = ns >= 8 && ns % 8 == 0, can2 = tiles % 8 == 0;
+      if (can1 && (kn >= 16384 || !can2)) g.map = 1;
+      else if (can2) g.map = 2;
+      g.nslab = ns;
+      p.part[guard ? 1 : 0] = g; p.nslab[guard ? 1 : 0] = ns;
+      return;
+    }
     const bool can1 = ns >= 8 && ns % 8 == 0, can2 = tiles % 8 == 0;
     const bool deepk = kn >= 16384;
     if (can1 && (deepk || !can2)) g.map = 1;
@@ -744,11 +786,14 @@ int wgrad_run(const Job* jobs, int njobs, hipStream_t s) {
     if (dry) return PTV_OK;
   }
   Job live[WG_MAX_JOBS]; Plan plan[WG_MAX_JOBS]; int n = 0;
-  double flops = 0.0, lim15 = 0.0, lim16 = 0.0; int pm = 0, pn = 0;
+  double flops = 0.0, lim15 = 0.0, lim16 = 0.0, seg = 0.0; int pm = 0, pn = 0;
   for (int i = 0; i < njobs; i++) {
     const Job& j = jobs[i];
     if (j.M < 0 || j.N < 0 || j.K < 0 || !j.A || !j.B || !j.C) return PTV_ERR_ARG;
     if (j.k_top && (j.k_unit <= 0 || j.k_unit % WBK)) return PTV_ERR_ARG;
+    if (j.seg_n && (j.seg_unit < 256 || (j.seg_unit & (j.seg_unit - 1)) || j.seg_period <= 0 || (j.K % j.seg_unit) || j.A2 ||
+                    (long)j.K / 128 > 256L * (j.seg_unit / 128)))
+      return PTV_ERR_ARG;
     if (j.M == 0 || j.N == 0) continue;
     if (j.K == 0) { if (!j.accumulate) zero_c(j, s); continue; }
     live[n] = j; PTV_TRY(plan_job(j, plan[n]));
@@ -757,6 +802,7 @@ int wgrad_run(const Job* jobs, int njobs, hipStream_t s) {
       const long units = j.k_rev > 0 ? j.k_rev : j.K / j.k_unit;
       if (units == 15) lim15 += 2.0 * j.M * j.N * j.K; else if (units == 16) lim16 += 2.0 * j.M * j.N * j.K;
     }
+    if (j.seg_n) seg += 2.0 * j.M * j.N * j.K;
     n++;
   }
   if (n == 0) { PTV_CHECK_LAUNCH(); return PTV_OK; }
@@ -877,7 +923,7 @@ int wgrad_run(const Job* jobs, int njobs, hipStream_t s) {
     for (int q = rb.n; q <= WG_MAX_JOBS; q++) rb.first[q] = rblk;
     if (rb.n) hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(rblk), dim3(256), 0, s, rb);
   }
-  if (pi >= 0) { prof::end(pi, s, flops); prof::aux(pi, lim15, lim16); }    // (full K: a k_top limit is a device value; the limited part separately)
+  if (pi >= 0) { prof::end(pi, s, flops); prof::aux(pi, lim15, lim16, seg); }    // (full K: a k_top limit is a device value; the limited part separately)
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
@@ -908,7 +954,7 @@ extern "C" int ptv_wgrad_batch(const ptv_wgrad_job* jobs, int njobs, void* strea
   for (int i = 0; i < njobs; i++) {
     const ptv_wgrad_job& q = jobs[i];
     js[i] = Job{q.M, q.N, q.K, q.A, q.lda, nullptr, 0, 0, q.B, q.ldb, q.C, q.ldc, q.alpha, q.accumulate, q.dtypes, q.slabs, q.colsum_a, q.k_top,
-                q.k_unit, q.k_rev};
+                q.k_unit, q.k_rev, q.seg_n, q.seg_unit, q.seg_period};
   }
   return wgrad_run(js, njobs, (hipStream_t)stream);
 }

@@ -734,6 +734,9 @@ WGRAD_FUSE_BIAS = True
 # note steps and passes over the (note step, 64-row panel) pairs that hold no target; PTV_SORT_DEC_ROWS=0 = rows in (t, b) order, only
 # the batch-wide limit (PTV_DEAD_STEPS).  Needs both decoder composites (it is implemented behind the C ABI only).
 SORT_DEC_ROWS = os.environ.get('PTV_SORT_DEC_ROWS', '1') != '0'
+# ... stage 2: the weight-gradient products over (note step, sorted row) skip the dead 128-row blocks of every note step too (K segments of
+# ptv_wgrad_batch); PTV_WGRAD_SEG=0 = they multiply the zero rows (bit-identical results)
+WGRAD_SEG = os.environ.get('PTV_WGRAD_SEG', '1') != '0'
 WGRAD_BATCH = 3            # ptv_wgrad_batch_mode (scripts/ab_step.py): 0 = products one by one, 1 = one launch, 2 = single launches + one reduction, 3 = small ones batched
 
 

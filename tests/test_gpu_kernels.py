@@ -725,6 +725,63 @@ def test_wgrad_batch_equals_the_single_calls_bit_for_bit():
             assert (ba.cpu().double() - want_b).abs().max() < 2e-5 * max(1.0, want_b.abs().max().item()), i
 
 
+def test_wgrad_batch_k_segments_skip_the_dead_rows_of_every_unit_bit_for_bit():
+    """ptv_wgrad_job.seg_n (round 6): K runs over 15 units of `unit` rows (a note step's decoder rows in length order) of which only a
+    prefix is live.  With the dead rows of A zero, a clipped call equals -- bit for bit -- the call that multiplies everything (same slab
+    plan: seg_n = unit everywhere), although its B holds NaN in every dead row (never read); also with a k_top limit on top, with a fused
+    bias sum, for an unaligned product (guarded tail launch), accumulate on and off; and against float64.  ptv_rows_seg_counts: the
+    prefixes of a sorted length vector by 128-row blocks."""
+    from polyphonic_chord_texture_disentanglement_amd._lib import call, ptr, stream_ptr, wgrad_batch
+    dev = _dev()
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(23)
+    unit, T = 1024, 15
+    K = unit * T
+    # lengths in descending order -> seg_n through the library's own kernel
+    lens = torch.sort(torch.randint(0, 12, (unit,), generator=g), descending=True).values.to(torch.int32)
+    lens_d = lens.to(dev)
+    seg = torch.empty(T, device=dev, dtype=torch.int32)
+    call('ptv_rows_seg_counts', ptr(lens_d), unit, T, ptr(seg), stream_ptr())
+    want_seg = torch.tensor([128 * int((lens[::128] > s_).sum()) for s_ in range(T)], dtype=torch.int32)
+    assert torch.equal(seg.cpu(), want_seg), (seg.cpu(), want_seg)
+    assert 0 < int(want_seg[5]) < unit and int(want_seg[-1]) == 0           # the case is not trivial
+    full = torch.full((T,), unit, device=dev, dtype=torch.int32)
+    live = torch.zeros(K, dtype=torch.bool)
+    for s_ in range(T):
+        live[s_ * unit: s_ * unit + int(want_seg[s_])] = True
+    top = 8                                                        # a k_top limit below the last live unit (units 9.. are declared zero too)
+    ktop = torch.tensor([top], device=dev, dtype=torch.int32)
+    # (M, N, A bf16, B bf16, pad, bias, k_top, accumulate)
+    specs = [(1024, 512, 1, 1, 0, True, False, 1), (512, 128, 1, 0, 0, False, True, 1), (64, 130, 0, 0, 6, False, False, 0), (200, 512, 1, 1, 0, True, True, 0)]
+    jobs_c, jobs_f, chk = [], [], []
+    for M, N, abf, bbf, pad, bias, kt, acc in specs:
+        A = torch.randn(K, M + pad, generator=g); B = torch.randn(K, N + pad, generator=g)
+        lv = live.clone()
+        if kt:
+            lv[(top + 1) * unit:] = False
+        A[~lv] = 0
+        Bn = B.clone(); Bn[~live] = float('nan')                   # what a forward that skipped the dead blocks leaves behind
+        Ad = (A.to(bf) if abf else A).to(dev)[:, :M]
+        Bd_nan = (Bn.to(bf) if bbf else Bn).to(dev)[:, :N]; Bd = (B.to(bf) if bbf else B).to(dev)[:, :N]
+        C0 = torch.randn(M, N, generator=g).to(dev); b0 = torch.randn(M, generator=g).to(dev)
+        Cc, bc, Cf, bfull = C0.clone(), b0.clone(), C0.clone(), b0.clone()
+        common = dict(M=M, N=N, K=K, alpha=0.5, accumulate=acc, k_top=ktop if kt else None, k_unit=unit if kt else 0, seg_unit=unit, seg_period=T)
+        jobs_c.append(dict(common, A=Ad, B=Bd_nan, C=Cc, colsum_a=bc if bias else None, seg_n=seg))
+        jobs_f.append(dict(common, A=Ad, B=Bd, C=Cf, colsum_a=bfull if bias else None, seg_n=full))
+        want = (C0.cpu().double() if acc else 0) + 0.5 * (A[:, :M].to(bf).double().t() @ B[:, :N].to(bf).double())
+        chk.append((Cc, bc, Cf, bfull, want, b0.cpu().double() + A[:, :M].to(bf).double().sum(0), bias))
+    wgrad_batch(jobs_c)
+    wgrad_batch(jobs_f)
+    torch.cuda.synchronize()
+    for i, (Cc, bc, Cf, bfull, want, want_b, bias) in enumerate(chk):
+        assert torch.isfinite(Cc).all(), i
+        assert torch.equal(Cc, Cf), (i, (Cc - Cf).abs().max())
+        assert (Cc.cpu().double() - want).abs().max() < 2e-5 * max(1.0, want.abs().max().item()), i
+        if bias:
+            assert torch.equal(bc, bfull), i
+            assert (bc.cpu().double() - want_b).abs().max() < 2e-5 * max(1.0, want_b.abs().max().item()), i
+
+
 @pytest.mark.parametrize('M,N,K,dt,pad', [(384, 128, 4096, 3, 0), (130, 512, 2000, 2, 6), (1536, 128, 1056, 1, 0), (64, 130, 999, 0, 6),
                                           (128, 135, 640, 0, 1), (3072, 36, 512, 1, 4), (12, 512, 4100, 0, 0), (256, 1000, 8192, 3, 0)])
 def test_wgrad_kernel_vs_fp64_product_and_column_sums(M, N, K, dt, pad):
