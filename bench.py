@@ -379,7 +379,14 @@ def _roofline(lib, B, model, args, ms_per_step=None):
         # products at the longest note list of the batch (lengths = targets per (sample, step) + 1 for the <sos> slot, capped at 16)
         f15 = Tl / float(T) if F_.ZERO_SKIP else 1.0
         f16 = min(16, Tl + 1) / 16.0 if F_.ZERO_SKIP else 1.0
-        fl_live = fl - l15.value * (1.0 - f15) - l16.value * (1.0 - f16)
+        # ... and, of those, the products over (note step, length-sorted row) also skip the dead 128-row blocks of every live step
+        # (ptv_wgrad_job.seg_n): live fraction = sum of the steps' live prefixes / (15 R), from the same device array the products read
+        lseg = ctypes.c_double(0.0)
+        lib.ptv_prof_read_segmented(5, ctypes.byref(lseg))
+        fseg, seg_t = f15, (getattr(F_, '_LAST_SEG_N', None) if F_.ZERO_SKIP else None)
+        if lseg.value > 0 and seg_t is not None:
+            fseg = float(seg_t.sum().item()) / (T * R)
+        fl_live = fl - (l15.value - lseg.value) * (1.0 - f15) - lseg.value * (1.0 - fseg) - l16.value * (1.0 - f16)
         tfs, tfs_nom = fl_live / (ms * 1e-3) / 1e12, fl / (ms * 1e-3) / 1e12
         k = pmc.get('wgrad_family', {})
         out.append({'bound': 'mfma', 'kernel': 'weight-gradient family: wgrad_kernel / wgrad_batch_kernel + wgrad_reduce(_batch)_kernel (ptv_wgrad, '
@@ -388,7 +395,8 @@ def _roofline(lib, B, model, args, ms_per_step=None):
                     'traffic': k.get('hbm_bytes_per_step'), 'traffic_unit': 'HBM bytes per step, all launches of the family (PMC)',
                     'traffic_source': src if k else None,
                     'algorithmic_flops_per_step': round(fl_live / steps), 'nominal_flops_per_step': round(fl / steps),
-                    'k_live': {'decoder_note_steps': '%d of %d' % (Tl, T), 'frac15': round(f15, 4), 'frac16': round(f16, 4)},
+                    'k_live': {'decoder_note_steps': '%d of %d' % (Tl, T), 'frac15': round(f15, 4), 'frac16': round(f16, 4),
+                               'frac_segmented': round(fseg, 4), 'segmented_share_of_nominal': round(lseg.value / fl, 4) if fl else None},
                     'achieved_on_nominal_flops': round(tfs_nom, 1),
                     'launches_per_step': round(cnt / steps, 1), 'avg_us': round(ms / cnt * 1e3, 1), 'total_ms': round(ms, 2),
                     'ms_per_step': round(ms / steps, 3),

@@ -737,6 +737,7 @@ SORT_DEC_ROWS = os.environ.get('PTV_SORT_DEC_ROWS', '1') != '0'
 # ... stage 2: the weight-gradient products over (note step, sorted row) skip the dead 128-row blocks of every note step too (K segments of
 # ptv_wgrad_batch); PTV_WGRAD_SEG=0 = they multiply the zero rows (bit-identical results)
 WGRAD_SEG = os.environ.get('PTV_WGRAD_SEG', '1') != '0'
+_LAST_SEG_N = None
 WGRAD_BATCH = 3            # ptv_wgrad_batch_mode (scripts/ab_step.py): 0 = products one by one, 1 = one launch, 2 = single launches + one reduction, 3 = small ones batched
 
 
@@ -1818,7 +1819,7 @@ def _decoder_tf_composite(ctx, z, emb, xs, force_dur, prec, P, W, params, B, R, 
                   dur_tabs=(tab0, tab), dur16_only=True, live_top=live)
     if srt is not None:
         srt['used'] = True                # (the loss node now takes the targets in the same row order: _cached_targets)
-        ctx.st['sorted'] = dict(perm=srt['perm'], len=srt['len'], NS16S=tens['NS16S'], TOK_S=tens['TOK_S'])
+        ctx.st['sorted'] = dict(perm=srt['perm'], len=srt['len'], NS16S=tens['NS16S'], TOK_S=tens['TOK_S'], seg_n=srt.get('seg_n'))
         _DTF['sorted_calls'] = _DTF.get('sorted_calls', 0) + 1
     _DTF['calls'] = _DTF.get('calls', 0) + 1
     ctx.mark_non_differentiable(idx)
@@ -2091,7 +2092,7 @@ def _decoder_bwd_composite(P, st, z, tok_op, dP, ddur, top_h, side, G):
     srt = st.get('sorted')
     if srt is not None:                                   # the forward ran on length-sorted rows: operands in that order, dNS / dtok scattered back
         tens.update(PERM=srt['perm'], ROW_LEN=srt['len'], NS16S=srt['NS16S'], TOK_OP=srt['TOK_S'].view(M, E), DNS_S=_empty(R, Ht, dev=dev),
-                    DTOK_S=_empty(15, R, E, dev=dev))
+                    DTOK_S=_empty(15, R, E, dev=dev), SEG_N=srt.get('seg_n'))
     if POISON_DEAD_STEPS and top_h is not None and st.get('live_top') is not None:        # (tests: whatever reads a dead row of these gets NaN -- heads_bwd / the BPTT leave them unwritten)
         _poison(tens['DNSUM'], tens['DGI_N'], tens['DGH_N'], tens['DY16'])
     slots = [None] * T_['PTV_DTB_COUNT']
@@ -2712,7 +2713,14 @@ def arm_live_top(x):
         pt_s, dt_s = torch.empty_like(pitch_t), torch.empty_like(dur_t)
         call('ptv_gather_rows', ptr(pt_s), ptr(pitch_t), ptr(perm), R, 1, R, R, 15, stream_ptr())
         call('ptv_gather_rows', ptr(dt_s), ptr(dur_t), ptr(perm), R, 5, 5 * R, 5 * R, 15, stream_ptr())
-        _LIVE['sort'] = dict(perm=perm, len=len_s, pt=pt_s, dt=dt_s, used=False, x=x.data_ptr())
+        seg_n = None
+        if WGRAD_SEG and R % 128 == 0:
+            # ... and the live prefix of every note step in that order (128-row blocks): the weight-gradient products over (note step, row) clip to it
+            seg_n = torch.empty(15, device=x.device, dtype=torch.int32)
+            call('ptv_rows_seg_counts', ptr(len_s), R, 15, ptr(seg_n), stream_ptr())
+            global _LAST_SEG_N
+            _LAST_SEG_N = seg_n                                  # (bench.py's roofline record: the live fraction of the segmented products)
+        _LIVE['sort'] = dict(perm=perm, len=len_s, pt=pt_s, dt=dt_s, used=False, x=x.data_ptr(), seg_n=seg_n)
     _LIVE['x'] = (weakref.ref(x), x.data_ptr(), x._version, True, pt, dt, counts)
     _LIVE['top'] = counts[2:3]
     _LIVE['last_counts'] = counts                               # (bench.py's roofline record: how many note steps the launches ran)
