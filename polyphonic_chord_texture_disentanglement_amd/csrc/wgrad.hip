@@ -728,7 +728,8 @@ int plan_job(const Job& j, Plan& p) {
       // K segments: a slab must lie inside one unit -- kper = the largest power of two <= the wanted depth that divides seg_unit (>= 128 rows);
       // at most 256 slabs (the reduction lists the live ones with one thread per slab)
       int kper = 128;
-      const int want = cdiv(kn, ns);
+      int want = cdiv(kn, ns);
+      if (want_slabs <= 0 && want > 4096) want = 4096;           // (measured, scripts/bench_wgrad_seg.py: the clipped slabs of a unit balance better when a unit holds >= 4 of them)
       while (kper * 2 <= want && kper * 2 <= (int)j.seg_unit) kper *= 2;
       while (cdiv(kn, kper) > 256 && kper * 2 <= (int)j.seg_unit) kper *= 2;
       g.kper = kper; ns = cdiv(kn, kper);

@@ -30,8 +30,11 @@ Cs = [torch.zeros(1024, 512, device=dev), torch.zeros(512, 512, device=dev), tor
 bs = [torch.zeros(1024, device=dev), torch.zeros(512, device=dev)]
 
 
+SLABS = 0
+
+
 def jobs(sg):
-    c = dict(K=K, k_top=top, k_unit=R)
+    c = dict(K=K, k_top=top, k_unit=R, slabs=SLABS)
     if sg is not None:
         c.update(seg_n=sg, seg_unit=R, seg_period=T)
     return [dict(c, M=1024, N=512, A=dgi[:, :1024], B=HN, C=Cs[0], colsum_a=bs[0]), dict(c, M=512, N=512, A=dgh, B=HN, C=Cs[1], colsum_a=bs[1]),
@@ -46,3 +49,11 @@ for name, sg in (('no segments (round-5 plan)', None), ('segments = R (same plan
         e0.record(); wgrad_batch(jobs(sg)); e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1))
     print('%-46s %8.1f us' % (name, best * 1e3))
+
+for SLABS in (16, 30, 60, 120, 240):
+    best = 1e9
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); wgrad_batch(jobs(seg)); e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    print('segments clipped, slabs wanted = %3d            %8.1f us' % (SLABS, best * 1e3))
