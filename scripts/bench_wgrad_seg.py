@@ -57,3 +57,19 @@ for SLABS in (16, 30, 60, 120, 240):
         e0.record(); wgrad_batch(jobs(seg)); e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1))
     print('segments clipped, slabs wanted = %3d            %8.1f us' % (SLABS, best * 1e3))
+
+# the note-summary bi-GRU's products of one direction (K = 16 positions x 16384 rows, 8 live): the default slab plan against finer ones
+K2 = 16 * R
+dgi2 = torch.randn(K2, 384, device=dev, generator=g).to(bf); dgh2 = torch.randn(K2, 384, device=dev, generator=g).to(bf)
+x2 = torch.randn(K2, 128, device=dev, generator=g); h2 = torch.randn(K2, 128, device=dev, generator=g).to(bf)
+C2 = [torch.zeros(384, 128, device=dev), torch.zeros(384, 128, device=dev)]; b2 = [torch.zeros(384, device=dev), torch.zeros(384, device=dev)]
+top2 = torch.tensor([7], device=dev, dtype=torch.int32)
+for SL in (0, 16, 32, 64, 128, 256):
+    js = [dict(M=384, N=128, K=K2, A=dgi2, B=x2, C=C2[0], colsum_a=b2[0], k_top=top2, k_unit=R, slabs=SL),
+          dict(M=384, N=128, K=K2, A=dgh2, B=h2, C=C2[1], colsum_a=b2[1], k_top=top2, k_unit=R, slabs=SL)]
+    best = 1e9
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); wgrad_batch(js); e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    print('note-summary products (384 x 128 x 262144, 8 of 16 positions live), slabs wanted = %3d   %8.1f us' % (SL, best * 1e3))
