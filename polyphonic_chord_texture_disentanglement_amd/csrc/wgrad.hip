@@ -733,8 +733,11 @@ int plan_job(const Job& j, Plan& p) {
       while (kper * 2 <= want && kper * 2 <= (int)j.seg_unit) kper *= 2;
       while (cdiv(kn, kper) > 256 && kper * 2 <= (int)j.seg_unit) kper *= 2;
       g.kper = kper; ns = cdiv(kn, kper);
-      const bool can1 = ns >= 8 && ns % 8 == 0, can2 = tiles % 8 == 0;
-      if (can1 && (kn >= 16384 || !can2)) g.map = 1;
+      // whole slabs per XCD (map 1: every K row is fetched into ONE L2) wants a multiple of 8 slabs: pad with slabs beyond K (they find
+      // no rows and leave).  With tile ranges per XCD (map 2) every XCD fetched every row of both operands: PMC, +0.1 GB per step
+      // instead of -0.6 for the clipped products
+      const bool can2 = tiles % 8 == 0;
+      if (ns >= 8 && (kn >= 16384 || !can2) && (ns + 7) / 8 * 8 <= 256) { ns = (ns + 7) / 8 * 8; g.map = 1; }
       else if (can2) g.map = 2;
       g.nslab = ns;
       p.part[guard ? 1 : 0] = g; p.nslab[guard ? 1 : 0] = ns;
