@@ -73,6 +73,12 @@ int ptv_gemm(int prec, int transA, int transB, int M, int N, int K,
 int ptv_gemm_mtop(int prec, int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                   void* C, long ldc, const float* bias, float alpha, int accumulate, int act, int splitk, int dtypes,
                   const int* m_top, long m_unit, void* stream);
+/* ... and with ROW SEGMENTS of A (round 6; seg_n or NULL): the rows of A are units of seg_unit rows (a multiple of 128: a note step's decoder rows
+ * in length order) of which only the first seg_n[unit % seg_period] (device ints, multiples of 128) hold anything -- the other row tiles are
+ * treated like the ones beyond m_top (no K loop; C = bias / zero / unchanged) */
+int ptv_gemm_mtop_seg(int prec, int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
+                      void* C, long ldc, const float* bias, float alpha, int accumulate, int act, int splitk, int dtypes,
+                      const int* m_top, long m_unit, const int* seg_n, long seg_unit, int seg_period, void* stream);
 /* plain products enqueued after this call raise their wave priority (p != 0) or run at the default one (0): host-side marker for the
  * launches of a latency chain that share the GPU with weight-gradient products on sibling streams.  Process-wide, read at enqueue time. */
 int ptv_gemm_priority(int p);
@@ -197,6 +203,10 @@ int ptv_zero_skip(int enable);
 int ptv_last_nonzero_unit(const float* x, long rows, int cols, long ld, long unit, int* top, void* stream);
 int ptv_sum_steps_top(float* out, const void* in, long n, int T, long stride, int accumulate, int in_bf16, const int* t_top,
                       void* stream);
+/* ... and with ROW SEGMENTS (round 6; seg_n or NULL): the planes are note steps over length-sorted rows of row_elems elements each, plane t holds
+ * something in its first seg_n[t] rows only (device ints, not growing with t: ptv_rows_seg_counts) -- the rest is zero and is not read */
+int ptv_sum_steps_seg(float* out, const void* in, long n, int T, long stride, int accumulate, int in_bf16, const int* t_top,
+                      const int* seg_n, long row_elems, void* stream);
 /* out[g*N + n] += sum over rows r with (sel ? sel[r] : 0) == g of A[r*lda + n]   (bias gradients;
  * with sel: the duration GRU's W_ih gradient, whose inputs are one-hot tokens) */
 int ptv_colsum(float* out, const void* A, long lda, long rows, int N, const int* sel, int G, int a_bf16, void* stream);

@@ -47,13 +47,21 @@ __global__ void sum_steps_kernel(float* out, const void* in, long n, int T, long
 
 // vector form: 16-byte loads (8 bf16 / 4 fp32 per thread), the T planes of one element group requested together
 template <bool BF>
-__global__ void sum_steps_vec_kernel(float* __restrict__ out, const void* __restrict__ in, long nvec, int T, long stride, int accumulate,
-                                     const int* __restrict__ t_top) {
+__global__ void sum_steps_vec_kernel(float* __restrict__ out, const void* __restrict__ in, long nvec, int T_, long stride, int accumulate,
+                                     const int* __restrict__ t_top, const int* __restrict__ seg_n, int row_elems) {
   __builtin_amdgcn_s_setprio(3);                                         // always part of a latency chain
   constexpr int E = BF ? 8 : 4;
-  if (t_top) T = min(T, *t_top + 1);
+  if (t_top) T_ = min(T_, *t_top + 1);
   for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
     const long i = v * E;
+    // row segments (ptv_sum_steps_seg): plane t holds something in its first seg_n[t] rows only, and seg_n does not grow with t -- the planes
+    // that hold this element's row are a prefix
+    int T = T_;
+    if (seg_n) {
+      const int row = (int)(i / row_elems);
+      T = 0;
+      while (T < T_ && seg_n[T] > row) T++;
+    }
     float s[E];
 #pragma unroll
     for (int e = 0; e < E; e++) s[e] = accumulate ? out[i + e] : 0.f;
@@ -378,11 +386,17 @@ __global__ void last_nonzero_kernel(const float* __restrict__ x, long rows, int 
 
 extern "C" int ptv_sum_steps_top(float* out, const void* in, long n, int T, long stride, int accumulate, int in_bf16, const int* t_top,
                                  void* stream) {
+  return ptv_sum_steps_seg(out, in, n, T, stride, accumulate, in_bf16, t_top, nullptr, 0, stream);
+}
+
+extern "C" int ptv_sum_steps_seg(float* out, const void* in, long n, int T, long stride, int accumulate, int in_bf16, const int* t_top,
+                                 const int* seg_n, long row_elems, void* stream) {
   if (!out || !in || n <= 0 || T <= 0) return PTV_ERR_ARG;
   const int E = in_bf16 ? 8 : 4;
   const bool vec = (n % E) == 0 && (stride % E) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-  if (vec && in_bf16) hipLaunchKernelGGL(sum_steps_vec_kernel<true>, dim3(grid_for(n / E)), dim3(256), 0, (hipStream_t)stream, out, in, n / E, T, stride, accumulate, t_top);
-  else if (vec) hipLaunchKernelGGL(sum_steps_vec_kernel<false>, dim3(grid_for(n / E)), dim3(256), 0, (hipStream_t)stream, out, in, n / E, T, stride, accumulate, t_top);
+  if (seg_n && (!vec || row_elems <= 0 || (row_elems % E))) return PTV_ERR_ARG;
+  if (vec && in_bf16) hipLaunchKernelGGL(sum_steps_vec_kernel<true>, dim3(grid_for(n / E)), dim3(256), 0, (hipStream_t)stream, out, in, n / E, T, stride, accumulate, t_top, seg_n, (int)row_elems);
+  else if (vec) hipLaunchKernelGGL(sum_steps_vec_kernel<false>, dim3(grid_for(n / E)), dim3(256), 0, (hipStream_t)stream, out, in, n / E, T, stride, accumulate, t_top, seg_n, (int)row_elems);
   else hipLaunchKernelGGL(sum_steps_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, in, n, T, stride, accumulate, in_bf16, t_top);
   PTV_CHECK_LAUNCH();
   return PTV_OK;

@@ -280,6 +280,15 @@ extern "C" int ptv_gemm_mtop(int prec, int transA, int transB, int M, int N, int
                              const void* A, long lda, const void* B, long ldb,
                              void* C, long ldc, const float* bias, float alpha,
                              int accumulate, int act, int splitk, int dtypes, const int* m_top, long m_unit, void* stream) {
+  return ptv_gemm_mtop_seg(prec, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, alpha, accumulate, act, splitk, dtypes, m_top, m_unit, nullptr, 0, 0,
+                           stream);
+}
+
+extern "C" int ptv_gemm_mtop_seg(int prec, int transA, int transB, int M, int N, int K,
+                                 const void* A, long lda, const void* B, long ldb,
+                                 void* C, long ldc, const float* bias, float alpha,
+                                 int accumulate, int act, int splitk, int dtypes, const int* m_top, long m_unit,
+                                 const int* seg_n, long seg_unit, int seg_period, void* stream) {
   if (M < 0 || N < 0 || K < 0 || !A || !B || !C) return PTV_ERR_ARG;
   if (M == 0 || N == 0) return PTV_OK;
   const bool sa = dtypes & 1, sb = dtypes & 2, sc = dtypes & 4;
@@ -293,7 +302,8 @@ extern "C" int ptv_gemm_mtop(int prec, int transA, int transB, int M, int N, int
   if (prec == PTV_PREC_BF16 && transA && transB && !sc && !(dtypes & 24) && !bias && act == 0 && K >= 512 && splitk <= 0)
     return ptv_wgrad(M, N, K, A, lda, B, ldb, reinterpret_cast<float*>(C), ldc, alpha, accumulate, dtypes & 3, 0, nullptr, nullptr, 0, 0, stream);
   if (m_top && (transA || m_unit <= 0)) return PTV_ERR_ARG;            // a row limit on A: A must be row-per-sample
-  ptv::GemmArgs g{A, lda, B, ldb, M, N, K, K, 0, m_top, m_unit, ptv::g_gemm_prio};
+  if (seg_n && (transA || seg_unit <= 0 || (seg_unit & 127) || seg_period <= 0)) return PTV_ERR_ARG;   // (row tiles are 64 or 128 rows: whole tiles dead or live)
+  ptv::GemmArgs g{A, lda, B, ldb, M, N, K, K, 0, m_top, m_unit, ptv::g_gemm_prio, seg_n, (int)seg_unit, seg_period};
   ptv::EpiPlain::Params ep{C, ldc, bias, alpha, accumulate, act, 0, sc ? 1 : 0, (dtypes & 8) ? 5 : ((dtypes & 16) ? 4 : 0), M, 0};
   hipStream_t s = (hipStream_t)stream;
   int rc;

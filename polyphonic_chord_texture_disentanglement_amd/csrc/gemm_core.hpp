@@ -72,6 +72,9 @@ struct GemmArgs {
   long gate_stride;           // NG==3: B row of gate g, unit j is g*gate_stride + j   (N = #units)
   const int* m_top; long m_unit;   // rows of A from (*m_top + 1) * m_unit on are known to be zero (or null): those tiles skip the K loop
   int prio;                   // plain products: raise the wave priority (a launch of the latency chain next to sibling-stream products)
+  // row segments of A (or null): the rows are units of seg_unit rows (a note step's decoder rows in length order) of which only the first
+  // seg_n[unit % seg_period] (device ints, multiples of 128) hold anything -- the other row tiles are dead like the ones beyond m_top
+  const int* seg_n = nullptr; int seg_unit = 0, seg_period = 0;
 };
 
 // LDS image of a tile: [row][128 bytes], the eight 16-byte chunks of row r XOR-permuted by
@@ -440,7 +443,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const typename Epi:
   const int kbeg = split * g.k_per_split;
   // a row tile that lies in the part of A its producer declared zero contributes nothing: empty K range, the epilogue still runs
   // (C = bias / unchanged)
-  const bool dead = g.m_top != nullptr && m_blk >= ((long)*g.m_top + 1) * g.m_unit;
+  const bool dead = (g.m_top != nullptr && m_blk >= ((long)*g.m_top + 1) * g.m_unit) ||
+                    (g.seg_n != nullptr && (m_blk % g.seg_unit) >= g.seg_n[(m_blk / g.seg_unit) % g.seg_period]);
   if (dead && Epi::dead_is_noop(ep)) return;                    // C += 0: nothing to read or write (block-uniform, before any barrier)
   const int kend = dead ? kbeg : min(g.K, kbeg + g.k_per_split);
   const int wave = threadIdx.x >> 6;
