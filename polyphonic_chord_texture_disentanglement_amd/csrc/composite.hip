@@ -358,7 +358,7 @@ extern "C" int ptv_decoder_tf_bwd(const void* const* t, const long* d, void* str
   const __bf16* wt_ih_n = (const __bf16*)T_(t, PTV_DTB_WT_IH_N);   // [Ht + E, 3Hn]
   ptv_gemm_priority(1);
   PTV_TRY(ptv_notes_gru_persist_bwd_rows(T_(t, PTV_DTB_PK_NOTES_WT), T_(t, PTV_DTB_HN16), T_(t, PTV_DTB_GATES_N), dNSUM, dgi_n, dgh_n, dHN0,
-                                         M_<void>(t, PTV_DTB_SCRATCH_N), R, 15, top_h, row_len, top_step, stream));
+                                         M_<void>(t, PTV_DTB_SCRATCH_N), R, 15 | (seg_n ? 0x10000 : 0), top_h, row_len, top_step, stream));
   PTV_TRY(ptv_sum_steps_seg(dGC, dgi_n, (long)R * 3 * Hn, 15, (long)R * 3 * Hn, 0, 1, top_step, seg_n, 3L * Hn, stream));
   if (hipMemsetAsync(dtok_out + 15L * R * E, 0, sizeof(float) * R * E, s) != hipSuccess) return PTV_ERR_LAUNCH;
   PTV_TRY(ptv_gemm_mtop_seg(P, 0, 0, (int)M, E, 3 * Hn, dgi_n, 3L * Hn, wt_ih_n + (long)Ht * 3 * Hn, 3L * Hn, dtok, E, nullptr, 1.f, 0, 0, 0, A16 | B16,

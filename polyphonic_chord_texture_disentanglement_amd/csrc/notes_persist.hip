@@ -810,7 +810,8 @@ extern "C" int ptv_notes_gru_persist_bwd_rows(const void* wt, const void* HN16, 
                                               void* stream) {
   if (!ext || (bound && !top_step) || (row_len && !bound)) return PTV_ERR_ARG;
   if (g_notes_bwd8) return ptv_notes_bwd8(wt, HN16, gates, ext, dgi, dgh, dh0, scratch, R, T, bound, row_len, top_step, stream);
-  return row_gru_bwd_any(512, wt, HN16, gates, ext, nullptr, 0, nullptr, nullptr, dgi, dgh, dh0, scratch, R, T, 0, bound, row_len, top_step, stream);
+  return row_gru_bwd_any(512, wt, HN16, gates, ext, nullptr, 0, nullptr, nullptr, dgi, dgh, dh0, scratch, R, T & 0xffff, 0, bound, row_len, top_step,
+                         stream);                                 // (this kernel always writes the zero rows: T bit 16 is a permission, not an order)
 }
 extern "C" int ptv_notes_gru_persist_bwd_top(const void* wt, const void* HN16, const void* gates, const void* ext, void* dgi, void* dgh,
                                              float* dh0, void* scratch, long R, int T, const int* bound, int* top_step, void* stream) {

@@ -498,6 +498,8 @@ struct Args {
   const int* row_len;              // or null (needs bound): [R] live note steps per row, rows sorted by DESCENDING length: no gradient arrives at
                                    // this panel after step row_len[first row] - 1 -- `ext` is not read there (it may be unwritten), the steps
                                    // between that and *bound get zero rows of dgi / dgh (their consumers know only the launch-wide limit)
+  int nofill;                      // (T bit 16) ... unless the caller's consumers clip to the same 128-row segments (ptv_wgrad_job.seg_n,
+                                   // ptv_sum_steps_seg, ptv_gemm_mtop_seg): then those rows stay unwritten
 };
 
 __device__ __forceinline__ float bfv(const u4v& v, int e) { const unsigned w = v[e >> 1]; return __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16)); }
@@ -541,6 +543,7 @@ __global__ __launch_bounds__(512, 2) void notes_bwd_kernel(Args a) {
       }
     }
     if (__syncthreads_or(nz != 0)) break;
+    if (a.nofill && s_top > s_panel) continue;                    // (block-uniform) a dead block of a segment-aware caller: nobody reads these rows
     for (int i = tid; i < ROWS * (H / 8); i += 512) {
       const int row = i / (H / 8), c8 = (i % (H / 8)) * 8;
       if (r0 + row < R) {
@@ -702,7 +705,7 @@ extern "C" int ptv_notes_bwd8(const void* wt, const void* HN16, const void* gate
   if (!wt || !HN16 || !gates || !ext || !dgi || !dgh || !scratch || R <= 0 || (T & 0xff) <= 0) return PTV_ERR_ARG;
   if ((bound && !top_step) || (row_len && !bound)) return PTV_ERR_ARG;   // (rows beyond the bound stay unwritten: the consumers need the limit)
   nb::Args a{(const bf16x8*)wt, (const __bf16*)HN16, (const __bf16*)gates, (const __bf16*)ext, (__bf16*)dgi, (__bf16*)dgh, dh0, (__bf16*)scratch,
-             top_step, (int)R, T & 0xff, g_zero_skip, bound, row_len};
+             top_step, (int)R, T & 0xff, g_zero_skip, bound, row_len, (T >> 16) & 1};
   const int abl = (T >> 8) & 6;
   const int pi = prof::want(4, (int)R, 512) ? prof::begin((hipStream_t)stream) : -1;
   const dim3 grid((unsigned)((R + nb::ROWS - 1) / nb::ROWS));
