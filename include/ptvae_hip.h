@@ -290,6 +290,13 @@ int ptv_gather_rows(void* dst, const void* src, const int* idx, long rows, int r
                     void* stream);
 int ptv_scatter_rows(void* dst, const void* src, const int* idx, long rows, int row_words, long src_plane_words, long dst_plane_words, int planes,
                      void* stream);
+/* ... with ROW SEGMENTS (round 6; seg_n int32 [planes] or NULL = the calls above): of plane q only the first seg_n[q] rows IN SORTED ORDER hold
+ * anything (ptv_rows_seg_counts).  The gather leaves the other rows of dst unwritten (its readers clip to the same segments); the scatter
+ * writes zeros to their places in dst without reading src. */
+int ptv_gather_rows_seg(void* dst, const void* src, const int* idx, long rows, int row_words, long src_plane_words, long dst_plane_words,
+                        int planes, const int* seg_n, void* stream);
+int ptv_scatter_rows_seg(void* dst, const void* src, const int* idx, long rows, int row_words, long src_plane_words, long dst_plane_words,
+                         int planes, const int* seg_n, void* stream);
 int ptv_chord_targets(const float* c, int B, int step_major, int* root_t, int* chroma_t, int* bass_t, void* stream);
 int ptv_ce_fwd(const float* logits, long ld, const int* targets, long rows, int C, int ignore_index, float* nll_sum, void* stream);
 int ptv_ce_bwd(const float* logits, long ld, const int* targets, long rows, int C, int ignore_index, const float* gscale,
@@ -465,6 +472,8 @@ enum PtvDtfTensor {
   PTV_DTF_ROW_LEN,        /* int32 [R]: live note steps of the row at position p (ptv_pianotree_targets_rows, gathered by PERM) */
   PTV_DTF_NS16S,          /* out [R, Ht] bf16: the time states NS16[1:] gathered by PERM (operand of the hoisted products, kept for the backward) */
   PTV_DTF_TOK_S,          /* out [15, R, E] fp32: the fed tokens EMB[:15] gathered by PERM */
+  PTV_DTF_SEG_N,          /* int32 [15] (ptv_rows_seg_counts) or NULL, sorted mode only: TOK_S is gathered for the live blocks of every note step only -- the
+                             backward must then be given PTV_DTB_SEG_N (its products never read the other rows) */
   PTV_DTF_COUNT
 };
 enum PtvDtfDim { PTV_DTF_D_B = 0, PTV_DTF_D_E, PTV_DTF_D_HE, PTV_DTF_D_HT, PTV_DTF_D_HN, PTV_DTF_D_HD, PTV_DTF_D_NP, PTV_DTF_D_ZS, PTV_DTF_D_ZI,

@@ -60,7 +60,7 @@ extern "C" int ptv_decoder_tf_fwd(const void* const* t, const long* d, void* str
   if (!ptv_decoder_tf_supported(d)) return PTV_ERR_UNSUPPORTED;
   for (int i = 0; i < PTV_DTF_COUNT; i++)
     if (!t[i] && i != PTV_DTF_FORCE_DUR && i != PTV_DTF_GATES_D && i != PTV_DTF_WAIT_EVENT && i != PTV_DTF_RECORD_EVENT && i != PTV_DTF_LIVE_TOP &&
-        i != PTV_DTF_PERM && i != PTV_DTF_ROW_LEN && i != PTV_DTF_NS16S && i != PTV_DTF_TOK_S)
+        i != PTV_DTF_PERM && i != PTV_DTF_ROW_LEN && i != PTV_DTF_NS16S && i != PTV_DTF_TOK_S && i != PTV_DTF_SEG_N)
       return PTV_ERR_ARG;
   // rows sorted by length: all four slots or none, and only with a live-step limit (the consumers of the unwritten rows need one)
   const bool sorted = t[PTV_DTF_PERM] != nullptr;
@@ -118,7 +118,7 @@ extern "C" int ptv_decoder_tf_fwd(const void* const* t, const long* d, void* str
     // the decoder's rows from here on in the order PERM (descending number of live note steps): time states and fed tokens are gathered
     // once, everything below is row-wise and does not care which (t, b) a row is
     PTV_TRY(ptv_gather_rows(M_<void>(t, PTV_DTF_NS16S), nsf, perm, R, Ht / 2, 0, 0, 1, stream));
-    PTV_TRY(ptv_gather_rows(M_<void>(t, PTV_DTF_TOK_S), tok, perm, R, E, (long)R * E, (long)R * E, 15, stream));
+    PTV_TRY(ptv_gather_rows_seg(M_<void>(t, PTV_DTF_TOK_S), tok, perm, R, E, (long)R * E, (long)R * E, 15, (const int*)T_(t, PTV_DTF_SEG_N), stream));
     nsf = (const __bf16*)T_(t, PTV_DTF_NS16S);
     tok = (const float*)T_(t, PTV_DTF_TOK_S);
   }
@@ -367,7 +367,7 @@ extern "C" int ptv_decoder_tf_bwd(const void* const* t, const long* d, void* str
   PTV_TRY(ptv_gemm(P, 0, 0, R, Ht, Hn, dHN0, Hn, T_(t, PTV_DTB_WT_T2N), Hn, dNS, Ht, nullptr, 1.f, 1, 0, 0, B16, stream));
   if (sorted) {
     PTV_TRY(ptv_scatter_rows(dNS_out, dNS, perm, R, Ht, 0, 0, 1, stream));
-    PTV_TRY(ptv_scatter_rows(dtok_out, dtok, perm, R, E, (long)R * E, (long)R * E, 15, stream));
+    PTV_TRY(ptv_scatter_rows_seg(dtok_out, dtok, perm, R, E, (long)R * E, (long)R * E, 15, seg_n, stream));
   }
   PTV_TRY(fork(2));
   ptv_gemm_priority(0);

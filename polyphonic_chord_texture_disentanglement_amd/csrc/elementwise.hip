@@ -512,7 +512,7 @@ extern "C" int ptv_last_nonzero_unit(const float* x, long rows, int cols, long l
 // ---------------------------------------------------------------------------------------------
 template <bool SCATTER, bool VEC>
 __global__ void rows_by_index_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src, const int* __restrict__ idx, long rows, int w4,
-                                     long src_plane, long dst_plane, int planes) {
+                                     long src_plane, long dst_plane, int planes, const int* __restrict__ seg) {
   const int per = VEC ? w4 / 4 : w4;                                     // pieces per row
   const long total = rows * per * planes;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -522,21 +522,28 @@ __global__ void rows_by_index_kernel(unsigned* __restrict__ dst, const unsigned*
     const int pl = (int)(q / rows);
     const long r = idx[p];
     const long so = (long)pl * src_plane + (SCATTER ? p : r) * w4, dof = (long)pl * dst_plane + (SCATTER ? r : p) * w4;
+    // row segments (ptv_gather_rows_seg / ptv_scatter_rows_seg): of plane pl only the first seg[pl] SORTED rows hold anything -- a gather
+    // leaves the others unwritten (nobody reads them), a scatter writes zeros without reading the source
+    if (seg && p >= seg[pl]) {
+      if (SCATTER) { if (VEC) reinterpret_cast<uint4*>(dst + dof)[c] = make_uint4(0u, 0u, 0u, 0u); else dst[dof + c] = 0u; }
+      continue;
+    }
     if (VEC) reinterpret_cast<uint4*>(dst + dof)[c] = reinterpret_cast<const uint4*>(src + so)[c];
     else dst[dof + c] = src[so + c];
   }
 }
-static int rows_by_index(bool scatter, void* dst, const void* src, const int* idx, long rows, int w4, long src_plane, long dst_plane, int planes, void* stream) {
+static int rows_by_index(bool scatter, void* dst, const void* src, const int* idx, long rows, int w4, long src_plane, long dst_plane, int planes, const int* seg,
+                         void* stream) {
   if (!dst || !src || !idx || rows < 0 || w4 <= 0 || planes <= 0) return PTV_ERR_ARG;
   if (rows == 0) return PTV_OK;
   const bool vec = (w4 % 4 == 0) && (src_plane % 4 == 0) && (dst_plane % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
   const long total = rows * (vec ? w4 / 4 : w4) * planes;
   int nb = (int)((total + 255) / 256); if (nb > 8192) nb = 8192; if (nb < 1) nb = 1;
   unsigned* d_ = (unsigned*)dst; const unsigned* s_ = (const unsigned*)src;
-  if (scatter) { if (vec) hipLaunchKernelGGL((rows_by_index_kernel<true, true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, d_, s_, idx, rows, w4, src_plane, dst_plane, planes);
-                 else hipLaunchKernelGGL((rows_by_index_kernel<true, false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, d_, s_, idx, rows, w4, src_plane, dst_plane, planes); }
-  else { if (vec) hipLaunchKernelGGL((rows_by_index_kernel<false, true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, d_, s_, idx, rows, w4, src_plane, dst_plane, planes);
-         else hipLaunchKernelGGL((rows_by_index_kernel<false, false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, d_, s_, idx, rows, w4, src_plane, dst_plane, planes); }
+  if (scatter) { if (vec) hipLaunchKernelGGL((rows_by_index_kernel<true, true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, d_, s_, idx, rows, w4, src_plane, dst_plane, planes, seg);
+                 else hipLaunchKernelGGL((rows_by_index_kernel<true, false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, d_, s_, idx, rows, w4, src_plane, dst_plane, planes, seg); }
+  else { if (vec) hipLaunchKernelGGL((rows_by_index_kernel<false, true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, d_, s_, idx, rows, w4, src_plane, dst_plane, planes, seg);
+         else hipLaunchKernelGGL((rows_by_index_kernel<false, false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, d_, s_, idx, rows, w4, src_plane, dst_plane, planes, seg); }
   PTV_CHECK_LAUNCH();
   return PTV_OK;
 }
@@ -561,9 +568,17 @@ extern "C" int ptv_rows_seg_counts(const int* row_len, long R, int steps, int* s
 
 extern "C" int ptv_gather_rows(void* dst, const void* src, const int* idx, long rows, int row_words, long src_plane_words, long dst_plane_words,
                                int planes, void* stream) {
-  return rows_by_index(false, dst, src, idx, rows, row_words, src_plane_words, dst_plane_words, planes, stream);
+  return rows_by_index(false, dst, src, idx, rows, row_words, src_plane_words, dst_plane_words, planes, nullptr, stream);
+}
+extern "C" int ptv_gather_rows_seg(void* dst, const void* src, const int* idx, long rows, int row_words, long src_plane_words, long dst_plane_words,
+                                   int planes, const int* seg_n, void* stream) {
+  return rows_by_index(false, dst, src, idx, rows, row_words, src_plane_words, dst_plane_words, planes, seg_n, stream);
+}
+extern "C" int ptv_scatter_rows_seg(void* dst, const void* src, const int* idx, long rows, int row_words, long src_plane_words, long dst_plane_words,
+                                    int planes, const int* seg_n, void* stream) {
+  return rows_by_index(true, dst, src, idx, rows, row_words, src_plane_words, dst_plane_words, planes, seg_n, stream);
 }
 extern "C" int ptv_scatter_rows(void* dst, const void* src, const int* idx, long rows, int row_words, long src_plane_words, long dst_plane_words,
                                 int planes, void* stream) {
-  return rows_by_index(true, dst, src, idx, rows, row_words, src_plane_words, dst_plane_words, planes, stream);
+  return rows_by_index(true, dst, src, idx, rows, row_words, src_plane_words, dst_plane_words, planes, nullptr, stream);
 }

@@ -1792,9 +1792,11 @@ def _decoder_tf_composite(ctx, z, emb, xs, force_dur, prec, P, W, params, B, R, 
     if srt is not None and not (force_dur is None and decoder_bwd_composite_static_ok(prec, B, Ht, Hn, NP, Hd, E, P)):
         srt = None                                            # (the backward composite is the only un-sorter: no sorted forward without it)
     if srt is not None:
-        tens.update(PERM=srt['perm'], ROW_LEN=srt['len'], NS16S=_empty(R, Ht, dev=dev, dtype=BF16), TOK_S=_empty(15, R, E, dev=dev))
+        tens.update(PERM=srt['perm'], ROW_LEN=srt['len'], NS16S=_empty(R, Ht, dev=dev, dtype=BF16), TOK_S=_empty(15, R, E, dev=dev), SEG_N=srt.get('seg_n'))
     if live is not None and POISON_DEAD_STEPS:
         _poison(HN16, gates_n, pitch, HD, HD16, gates_d, dur, idx)
+        if srt is not None and srt.get('seg_n') is not None:
+            _poison(tens['TOK_S'])                            # (gathered for the live blocks only: nobody may read the rest)
     slots = [None] * T_['PTV_DTF_COUNT']
     for k, v in tens.items():
         slots[T_['PTV_DTF_' + k]] = v.data_ptr() if v is not None else None
@@ -2714,7 +2716,7 @@ def arm_live_top(x):
         call('ptv_gather_rows', ptr(pt_s), ptr(pitch_t), ptr(perm), R, 1, R, R, 15, stream_ptr())
         call('ptv_gather_rows', ptr(dt_s), ptr(dur_t), ptr(perm), R, 5, 5 * R, 5 * R, 15, stream_ptr())
         seg_n = None
-        if WGRAD_SEG and R % 128 == 0:
+        if WGRAD_SEG and R >= 256 and not (R & (R - 1)):            # (a note step's rows: a power of two, so that slabs of the products never straddle a step)
             # ... and the live prefix of every note step in that order (128-row blocks): the weight-gradient products over (note step, row) clip to it
             seg_n = torch.empty(15, device=x.device, dtype=torch.int32)
             call('ptv_rows_seg_counts', ptr(len_s), R, 15, ptr(seg_n), stream_ptr())
