@@ -747,7 +747,7 @@ int ptv_slerp_path(const float* z1, const float* z2, float* out, int B, int D, i
  *     ptv_dur_gru_fwd with the stored decisions forced), cheaper than 16-row panels streaming them out note step by note step.
  *     Bits 16 / 17 of train force the 4-wave kernel / the 8-wave kernel whose producer waves stream the next note step's state
  *     products under the head phases of the current one (default: by panel count).
- *     Bits 18-20 of train = S in {2, 4}: cluster mode of the 4-wave kernel -- S workgroups (co-resident: ceil(B/16) * S <= the CU count, else
+ *     Bits 18-20 of train = S in {2, 4}, or bit 22 = eight members: cluster mode of the 4-wave kernel -- S workgroups (co-resident: ceil(B/16) * S <= the CU count, else
  *     PTV_ERR_UNSUPPORTED) share a panel: each streams 1/S of the notes-GRU gate weights (the product bound by one CU's L2 port), the
  *     new bf16 state is all-gathered through xch once per note step as 8-byte words {2 units, step tag} that the readers poll
  *     (agent-scope stores / loads; xch = ceil(B/16) x 2 x 16 x 256 words = 64 KB per panel, ZEROED by the caller before t = 0; cnt counts

@@ -19,6 +19,7 @@
 // the chip-wide step kernels of gru.hip.
 // Specialised to the init_model() geometry (E = 128, Hn = 512, Hd = 64, He = 128, 130 pitches), bf16 MFMA operands, fp32
 // state / logits -- the bf16 precision policy of the teacher-forced path.  Other configurations use the step loop.
+#include <type_traits>
 #include "common.hpp"
 #include "prof.hpp"
 #include "gemm_core.hpp"
@@ -108,6 +109,49 @@ __device__ __forceinline__ void gate_products(const bf16x8* __restrict__ wh, con
   mm(b[NG & 1], At, ldt, 0, accT);
 }
 
+// the same stream for NT tiles in groups of G k-blocks (the 16 k-blocks of h . W_hh^T and the 4 of token . W_ih^T as one sequence of 20):
+// <3, 4, 3> is the half pass of an 8-member cluster -- one unit tile x 3 gates, 24 fragment loads in flight per wave like <6, 4>'s, in
+// a ring of three groups (two groups of 8 k-blocks spilled).  Every
+// accumulator still adds its k-blocks in ascending order: bit-identical to gate_products.
+template <int NT, int G, int D>
+__device__ __forceinline__ void gate_products_g(const bf16x8* __restrict__ wh, const bf16x8* __restrict__ wt, const int (&tile)[NT],
+                                                const __bf16* Ah, int ldh, const __bf16* At, int ldt, f32x4 (&accH)[NT], f32x4 (&accT)[NT]) {
+  constexpr int KBH = 16, KBT = 4, NV = KBH + KBT, NGR = (NV + G - 1) / G;
+  const int lane = threadIdx.x & 63, rl = lane & 15, kq = (lane >> 4) * 8;
+  bf16x8 b[D][G][NT];                                             // ring of D groups: D - 1 groups of loads in flight under the MFMAs of one
+  auto ld = [&](bf16x8 (&d)[G][NT], int g) {
+#pragma unroll
+    for (int q = 0; q < G; q++) {
+      const int vk = g * G + q;
+      if (vk < NV) {
+#pragma unroll
+        for (int j = 0; j < NT; j++) d[q][j] = vk < KBH ? wh[((long)tile[j] * KBH + vk) * 64 + lane] : wt[((long)tile[j] * KBT + vk - KBH) * 64 + lane];
+      }
+    }
+  };
+  auto mm = [&](const bf16x8 (&d)[G][NT], int g) {
+#pragma unroll
+    for (int q = 0; q < G; q++) {
+      const int vk = g * G + q;
+      if (vk < NV) {
+        const bf16x8 av = vk < KBH ? *reinterpret_cast<const bf16x8*>(Ah + rl * ldh + vk * 32 + kq) : *reinterpret_cast<const bf16x8*>(At + rl * ldt + (vk - KBH) * 32 + kq);
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+          if (vk < KBH) accH[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d[q][j], av, accH[j], 0, 0, 0);
+          else accT[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d[q][j], av, accT[j], 0, 0, 0);
+        }
+      }
+    }
+  };
+#pragma unroll
+  for (int g = 0; g < D - 1 && g < NGR; g++) ld(b[g % D], g);
+#pragma unroll
+  for (int g = 0; g < NGR; g++) {
+    if (g + D - 1 < NGR) ld(b[(g + D - 1) % D], g + D - 1);
+    mm(b[g % D], g);
+  }
+}
+
 __device__ __forceinline__ void st_bf16x4_lds(__bf16* p, float a, float b, float c, float d) {
   bf16x4 v; v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
   *reinterpret_cast<bf16x4*>(p) = v;
@@ -195,7 +239,7 @@ template <int N> __device__ __forceinline__ void argmax_ror(float& best, int& bi
 // only: 2 KB) and the logits part of dur_hid_linear (20 KB) in LDS, the state part of dur_hid_linear is requested when the head
 // phase begins and consumed two phases later, the predicted token's embedding row right after the argmax.  The head phases then
 // hold no exposed L2 round trip (RES = 0 had 8 + 1 + 1 of them per note step on wave 0).  Same products, same k order: bit-identical.
-template <int RES>
+template <int RES, int NUK = 2>                                  // NUK = 1: the eight-member cluster's kernel (one unit tile per wave and note step)
 __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
   __shared__ __attribute__((aligned(16))) bf16x8 wp8[RES ? 16 * 4 * 2 : 1];   // pitch-head tile 8, rows 128 / 129 only: [kb][quad][row]
   __shared__ __attribute__((aligned(16))) bf16x8 wdp[RES ? 4 * 5 * 64 : 1];   // dur_hid_linear, logits part (4 tiles x 5 k-blocks)
@@ -308,32 +352,37 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
                                                                         S > 1 ? FP * FHN * 4 : 0, 0x00020000);
     const unsigned xseq = (unsigned)(t * 15 + n + 1);
     // ================= P1: notes-GRU cell.  wave w owns units [w*128, w*128+128) = 8 tiles of 16, two per pass =================
-#pragma unroll 1
-    for (int p = p_lo; p < ((a.dbg & 2) ? 0 : p_hi); p++) {
-      const int ut0 = wave * 8 + p * 2;
+    // one pass = NU unit tiles (of 16 units) x 3 gates of this wave: two for 1 / 2 / 4 members per panel, ONE for eight (member m: tile m of the wave's 8)
+    auto cell_pass = [&](auto nu_c, const int ut0) {
+      constexpr int NU = decltype(nu_c)::value;
       // per-lane constants in the epilogue layout (4 adjacent lanes = 16 units of one row): the hoisted input part GC (b_ih
       // included) and b_hh, requested before the products
-      float4 gR[2], gZ[2], gN[2], bR[2], bZ[2], bN[2];
+      float4 gR[NU], gZ[NU], gN[NU], bR[NU], bZ[NU], bN[NU];
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
+      for (int j = 0; j < NU; j++) {
         const int u = (ut0 + j) * 16 + eq * 4;
         const float* g = a.gc + (long)rE * a.ld_gc;
         gR[j] = *reinterpret_cast<const float4*>(g + u); gZ[j] = *reinterpret_cast<const float4*>(g + FHN + u); gN[j] = *reinterpret_cast<const float4*>(g + 2 * FHN + u);
         bR[j] = *reinterpret_cast<const float4*>(a.b_hh_n + u); bZ[j] = *reinterpret_cast<const float4*>(a.b_hh_n + FHN + u);
         bN[j] = *reinterpret_cast<const float4*>(a.b_hh_n + 2 * FHN + u);
       }
-      f32x4 accH[6], accT[6];                                   // (r0, r1, z0, z1, n0, n1): h . W_hh^T and token . W_ih[:, Ht:]^T
+      f32x4 accH[3 * NU], accT[3 * NU];                         // (r.., z.., n..): h . W_hh^T and token . W_ih[:, Ht:]^T
 #pragma unroll
-      for (int j = 0; j < 6; j++) accH[j] = accT[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int tl[6] = {ut0, ut0 + 1, 32 + ut0, 33 + ut0, 64 + ut0, 65 + ut0};
-      if (!(a.dbg & 1)) gate_products<16, 4>(a.wg_h, a.wg_t, tl, &h16[cur][0][0], H16LD, &tok16[0][0], T16LD, accH, accT);
+      for (int j = 0; j < 3 * NU; j++) accH[j] = accT[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      int tl[3 * NU];
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
+      for (int j = 0; j < NU; j++) { tl[j] = ut0 + j; tl[NU + j] = 32 + ut0 + j; tl[2 * NU + j] = 64 + ut0 + j; }
+      if (!(a.dbg & 1)) {
+        if constexpr (NU == 2) gate_products<16, 4>(a.wg_h, a.wg_t, tl, &h16[cur][0][0], H16LD, &tok16[0][0], T16LD, accH, accT);
+        else gate_products_g<3, 4, 3>(a.wg_h, a.wg_t, tl, &h16[cur][0][0], H16LD, &tok16[0][0], T16LD, accH, accT);
+      }
+#pragma unroll
+      for (int j = 0; j < NU; j++) {
         const int u = (ut0 + j) * 16 + eq * 4;
         f32x4 sR, sZ;
 #pragma unroll
-        for (int e = 0; e < 4; e++) { sR[e] = accH[j][e] + accT[j][e]; sZ[e] = accH[2 + j][e] + accT[2 + j][e]; }
-        const f32x4 aR = to_rowmajor_lanes(sR), aZ = to_rowmajor_lanes(sZ), aI = to_rowmajor_lanes(accT[4 + j]), aH = to_rowmajor_lanes(accH[4 + j]);
+        for (int e = 0; e < 4; e++) { sR[e] = accH[j][e] + accT[j][e]; sZ[e] = accH[NU + j][e] + accT[NU + j][e]; }
+        const f32x4 aR = to_rowmajor_lanes(sR), aZ = to_rowmajor_lanes(sZ), aI = to_rowmajor_lanes(accT[2 * NU + j]), aH = to_rowmajor_lanes(accH[2 * NU + j]);
         const float4 hp4 = *reinterpret_cast<const float4*>(&hf[erow][u]);
         const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
         const float kR[4] = {gR[j].x + bR[j].x, gR[j].y + bR[j].y, gR[j].z + bR[j].z, gR[j].w + bR[j].w};
@@ -368,6 +417,19 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
           st_bf16x4_lds(gp + 3 * pl, hn[0], hn[1], hn[2], hn[3]);
         }
       }
+    };
+    if (!(a.dbg & 2)) {
+      if constexpr (NUK == 1) {
+        // (opaque per note step: the 60 fragment addresses of the pass are loop-invariant otherwise, and hipcc hoists them out of the note loop --
+        // 120 registers, 220 bytes of spills; the two-tile kernels are safe behind their runtime pass loop)
+        int ut = wave * 8 + mem;
+        asm volatile("" : "+s"(ut));
+        cell_pass(std::integral_constant<int, 1>{}, ut);
+      }
+      else {
+#pragma unroll 1
+        for (int p = p_lo; p < p_hi; p++) cell_pass(std::integral_constant<int, 2>{}, wave * 8 + p * 2);
+      }
     }
     bf16x8 wdh[16];                                              // RES: this wave's tile of dur_hid_linear's state part -- requested here, in
     if constexpr (RES) {                                         // flight across the state exchange, consumed in the head phase
@@ -382,29 +444,33 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
       // this step's tag -- no arrival counter to bump and poll, no store acknowledgement to wait for: one L2 round trip after the last
       // member's stores land instead of four.  The caller zeroes xch before t = 0 (tag 0 never matches); a buffer is rewritten two
       // note steps later, which its writer can only reach after every reader has sent the step in between.
-      const int nfo = 4 - 4 / S, npo = 4 / S;                    // foreign / own passes per wave
+      // a wave's 128 units are 4 groups of 32 (a pass; 1, 2 or 4 members: NUK = 2) or 8 groups of 16 (eight members: NUK = 1); a thread fetches
+      // NQ pieces of PW words: piece = a quarter of a group's units of one row
+      constexpr int PW = NUK == 2 ? 4 : 2, NQ = NUK == 2 ? 3 : 7, GU = NUK == 2 ? 32 : 16;
+      const int nfg = NUK == 2 ? 4 - 4 / S : 7;                  // foreign groups per wave
+      const int own0 = NUK == 2 ? p_lo : mem, nown = NUK == 2 ? 4 / S : 1;
       unsigned pend = 0;
-      int wofs[3];
+      int wofs[NQ];
 #pragma unroll
-      for (int q = 0; q < 3; q++) {
-        const int i2 = tid + 256 * q, piece = i2 & 3, row = (i2 >> 2) & 15, wp = i2 >> 6;   // wp: (wave, foreign pass)
-        const int fp = wp % nfo, pass = fp < p_lo ? fp : fp + npo;
-        const int u = (wp / nfo) * 128 + pass * 32 + piece * 8;
+      for (int q = 0; q < NQ; q++) {
+        const int i2 = tid + 256 * q, piece = i2 & 3, row = (i2 >> 2) & 15, wg = i2 >> 6;   // wg: (wave, foreign group)
+        const int fg = wg % nfg, g = fg < own0 ? fg : fg + nown;
+        const int u = (wg / nfg) * 128 + g * GU + piece * (2 * PW);
         wofs[q] = (row * FHN + u) * 4;
-        if (q < nfo) pend |= 0xfu << (4 * q);
+        if (q < nfg) pend |= ((1u << PW) - 1u) << (PW * q);
       }
       if (tid == 0) __hip_atomic_fetch_add(xcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (diagnostics only: nobody waits on it)
       unsigned spins = 0;
-      // throttle: wave 0 first watches ONE word per foreign pass (a late one: row 15, last units of wave 3's tile) with a sleep between
+      // throttle: wave 0 first watches ONE word per foreign group (a late one: row 15, last units of wave 3's tile) with a sleep between
       // looks -- 256 lanes x 12 words of polling per workgroup slowed the weight streams of the members still in their cell (B = 1024:
       // +1 us per note step); the words themselves are still checked one by one below
       while (!dead && wave == 0) {
         bool all = true;
 #pragma unroll
-        for (int fp = 0; fp < 3; fp++)
-          if (fp < nfo) {
-            const int pass = fp < p_lo ? fp : fp + npo;
-            const u32x2 sv = __builtin_amdgcn_raw_buffer_load_b64(xr, (15 * FHN + 3 * 128 + pass * 32 + 30) * 4, 0, 16);
+        for (int fg = 0; fg < 7; fg++)
+          if (fg < nfg) {
+            const int g = fg < own0 ? fg : fg + nown;
+            const u32x2 sv = __builtin_amdgcn_raw_buffer_load_b64(xr, (15 * FHN + 3 * 128 + g * GU + GU - 2) * 4, 0, 16);
             all = all && sv[1] == xseq;
           }
         if (all) break;
@@ -413,15 +479,15 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
       }
       lds_barrier();                                              // (wave 0 watched for the other three)
       while (pend && !dead) {
-        u32x2 v[12];
+        u32x2 v[NQ * PW];
 #pragma unroll
-        for (int w = 0; w < 12; w++)
-          if ((pend >> w) & 1u) v[w] = __builtin_amdgcn_raw_buffer_load_b64(xr, wofs[w >> 2] + 8 * (w & 3), 0, 16);                     // sc1
+        for (int w = 0; w < NQ * PW; w++)
+          if ((pend >> w) & 1u) v[w] = __builtin_amdgcn_raw_buffer_load_b64(xr, wofs[w / PW] + 8 * (w % PW), 0, 16);                    // sc1
 #pragma unroll
-        for (int w = 0; w < 12; w++)
+        for (int w = 0; w < NQ * PW; w++)
           if (((pend >> w) & 1u) && v[w][1] == xseq) {
-            const int o = wofs[w >> 2] >> 2;                     // = row * 512 + u
-            *reinterpret_cast<unsigned*>(&h16[nxt][o >> 9][(o & 511) + 2 * (w & 3)]) = v[w][0];
+            const int o = wofs[w / PW] >> 2;                     // = row * 512 + u
+            *reinterpret_cast<unsigned*>(&h16[nxt][o >> 9][(o & 511) + 2 * (w % PW)]) = v[w][0];
             pend &= ~(1u << w);
           }
         if (pend && ++spins > (1u << 22)) { __hip_atomic_store(xerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; }
@@ -1430,7 +1496,7 @@ extern "C" int ptv_free_note_loop(const void* const* w, const void* const* io, l
   // (47.0 -> 40.8 us).  train bit 16 / 17 force the 4-wave / 8-wave kernel.
   const int panels = (B + FP - 1) / FP;
   // cluster mode: S members per panel, all co-resident (they wait for each other once per note step): at most one member per CU
-  const int S = (train >> 18) & 7;
+  const int S = (train & 0x400000) ? 8 : ((train >> 18) & 7);     // (bit 22: eight members)
   const bool split = (train & 0x20000) || (!(train & 0x10000) && panels >= 96 && S <= 1);      // (a cluster request means the 4-wave kernel)
   a.S = 1;
   if (S > 1) {
@@ -1438,7 +1504,7 @@ extern "C" int ptv_free_note_loop(const void* const* w, const void* const* io, l
     // its turn among the persistent launches, so nothing else that spins is resident beside it)
     static int ncu = 0;
     if (ncu == 0) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 128; }
-    if ((S != 2 && S != 4) || split || !io[19] || !io[20] || panels * S > ncu) return PTV_ERR_UNSUPPORTED;
+    if ((S != 2 && S != 4 && S != 8) || split || !io[19] || !io[20] || panels * S > ncu) return PTV_ERR_UNSUPPORTED;
     a.S = S; a.xch = (__bf16*)io[19]; a.cnt = (unsigned*)io[20];
   }
   // bench.py's roofline record of the step loop (tag 7): 15 note steps per launch; algorithmic MFMA work of a launch = 15 note steps x B rows x
@@ -1446,8 +1512,9 @@ extern "C" int ptv_free_note_loop(const void* const* w, const void* const* io, l
   const int pi = prof::want(7, B, FHN) ? prof::begin((hipStream_t)stream) : -1;
   if (!split) {
     const dim3 grid(a.S > 1 ? (panels + 7) / 8 * 8 * a.S : panels);
-    if (train & 0x200000) hipLaunchKernelGGL(note_loop_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);   // bit 21: head weights streamed (timing comparisons)
-    else hipLaunchKernelGGL(note_loop_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (a.S == 8) hipLaunchKernelGGL((note_loop_kernel<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (train & 0x200000) hipLaunchKernelGGL((note_loop_kernel<0, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);   // bit 21: head weights streamed (timing comparisons)
+    else hipLaunchKernelGGL((note_loop_kernel<1, 2>), grid, dim3(256), 0, (hipStream_t)stream, a);
   }
   else hipLaunchKernelGGL(note_loop2_kernel, dim3(panels), dim3(512), 0, (hipStream_t)stream, a);
   if (pi >= 0) prof::end(pi, (hipStream_t)stream, 15.0 * B * (2.0 * 3 * FHN * (FHN + 128) + 2.0 * 130 * FHN + 2.0 * 64 * (FHN + 130) + 5 * 2.0 * 3 * 64 * 64 + 2.0 * 128 * 135));

@@ -89,7 +89,9 @@ def note_loop_cluster(B):
     if NOTE_LOOP_SPLIT or (NOTE_LOOP_SPLIT is None and panels >= 96 and panels * 2 > ncu):
         return 0
     if NOTE_LOOP_CLUSTER is not None:
-        return NOTE_LOOP_CLUSTER if NOTE_LOOP_CLUSTER in (2, 4) and panels * NOTE_LOOP_CLUSTER <= ncu else 0
+        return NOTE_LOOP_CLUSTER if NOTE_LOOP_CLUSTER in (2, 4, 8) and panels * NOTE_LOOP_CLUSTER <= ncu else 0
+    if NOTE_CLUSTER8 and panels * 8 <= ncu:
+        return 8                 # round 6: eight members per panel (B <= 512 on 256 CUs): each streams an eighth of the gate weights
     # round 4: four members per panel up to ONE MEMBER PER CU (64 panels = B 1024, the per-GPU batch of BASELINE configs[4]); it was capped at
     # half the chip.  Free-running training, same box, S = 2 -> 4: B = 640 21.4k -> 23.8k samples/s, 768 23.4k -> 26.5k, 1024 27.2k -> 30.6k
     cap4 = NOTE_CLUSTER4_MAX_WGS if NOTE_CLUSTER4_MAX_WGS > 0 else ncu
@@ -97,6 +99,12 @@ def note_loop_cluster(B):
 
 
 NOTE_CLUSTER4_MAX_WGS = 0      # 0 = the CU count
+NOTE_CLUSTER8 = os.environ.get('PTV_NOTE_CLUSTER8', '1') != '0'
+
+
+def cluster_bits(c):
+    """the cluster size in ptv_free_note_loop's `train` word: bits 18-20 = 2 / 4, bit 22 = eight members"""
+    return 0x400000 if c == 8 else (c << 18)
 _NCU = []
 
 
@@ -386,7 +394,7 @@ class DecoderStepFn(torch.autograd.Function):
                 dims=dict(B=B, Zs=z.shape[1], Zi=Zi, He=He, Ht=Ht, Hn=Hn, Hd=Hd, E=E, NP=NP, ldp=pitch.stride(0), train=int(train), replay=int(bool(replay)),
                           inference=int(bool(inference)), cluster=int(cluster and not capturing),
                           loop_flags=(2 if replay else int(train)) | (0 if NOTE_LOOP_SPLIT is None else (0x20000 if NOTE_LOOP_SPLIT else 0x10000))
-                          | (cluster << 18), resum_train=int(train and not replay)),
+                          | cluster_bits(cluster), resum_train=int(train and not replay)),
                 tens=dict(NS=NS, NS16=NS16, Z_IN=z_in, ZG=zg, TOKS=TOKS, GATES_T=gates_t, TOK=TOK, PRED=PRED, PITCH=pitch, HN=HN, HN16=HN16,
                           GATES_N=gates_n, HD=HD, HD16=HD16, GATES_D=gates_d, IDX=idx, PLEN=plen, XH0=XH[0] if XH else None,
                           XH1=XH[1] if XH else None, XH16_0=XH16[0], XH16_1=XH16[1], XG0=XG[0] if XG else None, XG1=XG[1] if XG else None,
@@ -428,7 +436,7 @@ class DecoderStepFn(torch.autograd.Function):
                 with (F_._PersistTurn() if cluster and not capturing else contextlib.nullcontext()):
                     call('ptv_free_note_loop', wl, io, pitch.stride(0), B, t, mask,
                          (2 if replay else int(train)) | (0 if NOTE_LOOP_SPLIT is None else (0x20000 if NOTE_LOOP_SPLIT else 0x10000))
-                         | (cluster << 18), st)
+                         | cluster_bits(cluster), st)
                 if t == 31:
                     break
                 if (not inference) and coin_time[t]:

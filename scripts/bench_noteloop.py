@@ -33,7 +33,8 @@ def main():
     for B in Bs:
         R, M = 32 * B, 15 * 32 * B
         panels = (B + 15) // 16
-        S = 4 if panels * 4 <= 256 else (2 if panels * 2 <= 256 else 1)
+        S = 8 if panels * 8 <= 256 else (4 if panels * 4 <= 256 else (2 if panels * 2 <= 256 else 1))
+        sbits = 0x400000 if S == 8 else ((S if S > 1 else 0) << 18)
         g = torch.Generator(device=dev).manual_seed(5)
         GC = torch.randn(32, B, 1536, device=dev, generator=g) * 0.6
         emb = torch.randn(16, R, 128, device=dev, generator=g) * 0.5
@@ -55,10 +56,14 @@ def main():
         print(f'B = {B}: {panels} panels x S = {S}')
         for name, extra in (('resident heads', 0), ('streamed heads (bit 21)', 0x200000),
                             ('resident, no gate MFMAs', 1 << 8), ('resident, no pitch head', 4 << 8), ('resident, no duration GRU', 8 << 8),
-                            ('resident heads', 0), ('streamed heads (bit 21)', 0x200000), ('8-wave kernel, no cluster', -1), ('4-wave resident, no cluster', -2)):
-            flags = 2 | 0x10000 | ((S if S > 1 else 0) << 18) | extra
+                            ('resident heads', 0), ('streamed heads (bit 21)', 0x200000), ('8-wave kernel, no cluster', -1), ('4-wave resident, no cluster', -2), ('four members per panel', -3)):
+            flags = 2 | 0x10000 | sbits | extra
             if extra == -1:
                 flags = 2 | 0x20000                      # the 8-wave producer / head kernel, one workgroup per panel
+            if extra == -3:
+                flags = 2 | 0x10000 | (4 << 18)          # four members per panel (the default before the eight-member kernel)
+                if panels * 4 > 256:
+                    continue
             if extra == -2:
                 flags = 2 | 0x10000                      # the 4-wave kernel, one workgroup per panel
             best = 1e9
@@ -97,7 +102,7 @@ def main():
                             xch if S > 1 else None, cnt if S > 1 else None])
             cnt.zero_(); xch.zero_()
             for t in range(6):
-                call('ptv_free_note_loop', wl, iod if t == 5 else ios[t], 136, B, t, 0, 2 | 0x10000 | ((S if S > 1 else 0) << 18) | extra | ((64 << 8) if t == 5 else 0), stream_ptr())
+                call('ptv_free_note_loop', wl, iod if t == 5 else ios[t], 136, B, t, 0, 2 | 0x10000 | sbits | extra | ((64 << 8) if t == 5 else 0), stream_ptr())
             torch.cuda.synchronize()
             ph = dbg[3 * grid:].view(grid, 8)[:, :6].float().cpu() * 10.0 / 15.0 / 1e3          # us per note step
             live = ph.sum(1) > 0

@@ -936,7 +936,7 @@ def test_note_loop_cluster_mode_is_bit_identical_to_one_workgroup_per_panel(B):
     res = {}
     # S = -1: one workgroup per panel with the head weights STREAMED from L2 every note step (train bit 21: the kernel before round 6
     # kept nothing resident) -- same products in the same k order, so also bit-equal
-    for S in (1, -1, 2, 4):
+    for S in (1, -1, 2, 4, 8):
         if panels * S > torch.cuda.get_device_properties(dev).multi_processor_count:       # (one member per CU at most: B = 1000 -> 63 x 4 = 252)
             continue
         for train in (0, 1):
@@ -957,7 +957,7 @@ def test_note_loop_cluster_mode_is_bit_identical_to_one_workgroup_per_panel(B):
                 io = F_._parr([GC[t], emb, HN, gates_n, pitch, HD, gates_d, dur, idx, TOK, PRED, xhat, plen, None, None, None, None, None, None,
                                xch if S > 1 else None, cnt if S > 1 else None])
                 call('ptv_free_note_loop', wl, io, 136, B, t, 0x15a5 if train else 0,
-                     train | 0x10000 | ((S if S > 1 else 0) << 18) | (0x200000 if S < 0 else 0), stream_ptr())
+                     train | 0x10000 | (0x400000 if S == 8 else ((S if S > 1 else 0) << 18)) | (0x200000 if S < 0 else 0), stream_ptr())
             torch.cuda.synchronize()
             if S > 1:
                 c = cnt.cpu()
