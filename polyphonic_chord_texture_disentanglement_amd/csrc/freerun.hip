@@ -464,7 +464,9 @@ __global__ __launch_bounds__(256, 1) void note_loop_kernel(NoteLoopArgs a) {
       // throttle: wave 0 first watches ONE word per foreign group (a late one: row 15, last units of wave 3's tile) with a sleep between
       // looks -- 256 lanes x 12 words of polling per workgroup slowed the weight streams of the members still in their cell (B = 1024:
       // +1 us per note step); the words themselves are still checked one by one below
-      while (!dead && wave == 0) {
+      // (eight members: their cells are short and in step -- every lane polls its own words from the start, 13.8 -> 13.2 us; with four
+      // members at B = 1024 the same costs 20.2 -> 22.0: dbg 16 switches the watch phase off there for timing)
+      while (!dead && wave == 0 && NUK == 2 && !(a.dbg & 16)) {
         bool all = true;
 #pragma unroll
         for (int fg = 0; fg < 7; fg++)

@@ -56,7 +56,7 @@ def main():
         print(f'B = {B}: {panels} panels x S = {S}')
         for name, extra in (('resident heads', 0), ('streamed heads (bit 21)', 0x200000),
                             ('resident, no gate MFMAs', 1 << 8), ('resident, no pitch head', 4 << 8), ('resident, no duration GRU', 8 << 8),
-                            ('resident heads', 0), ('streamed heads (bit 21)', 0x200000), ('8-wave kernel, no cluster', -1), ('4-wave resident, no cluster', -2), ('four members per panel', -3)):
+                            ('resident heads', 0), ('streamed heads (bit 21)', 0x200000), ('8-wave kernel, no cluster', -1), ('4-wave resident, no cluster', -2), ('four members per panel', -3), ('resident, no watch phase (dbg 16)', 16 << 8)):
             flags = 2 | 0x10000 | sbits | extra
             if extra == -1:
                 flags = 2 | 0x20000                      # the 8-wave producer / head kernel, one workgroup per panel
