@@ -782,6 +782,97 @@ def test_wgrad_batch_k_segments_skip_the_dead_rows_of_every_unit_bit_for_bit():
             assert (bc.cpu().double() - want_b).abs().max() < 2e-5 * max(1.0, want_b.abs().max().item()), i
 
 
+def test_row_segment_variants_of_step_sum_row_product_gather_and_scatter():
+    """round 6: the other walkers of (note step, length-sorted row) take the live prefixes too (ptv_rows_seg_counts).  ptv_sum_steps_seg and
+    ptv_gemm_mtop_seg on operands whose dead rows hold NaN (they are not read) equal the plain calls on operands whose dead rows are zero,
+    bit for bit; ptv_gather_rows_seg leaves the dead rows of its output untouched, ptv_scatter_rows_seg writes zeros there without
+    reading its (NaN) source."""
+    from polyphonic_chord_texture_disentanglement_amd._lib import call, ptr, stream_ptr
+    dev = _dev()
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(29)
+    R, T, W = 1024, 15, 96                                        # rows per step, steps, row width
+    seg = torch.tensor([1024, 896, 640, 640, 384, 128, 128, 0, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int32)
+    live = torch.zeros(T, R, dtype=torch.bool)
+    for s_ in range(T):
+        live[s_, :int(seg[s_])] = True
+    seg_d = seg.to(dev)
+    top = torch.tensor([6], device=dev, dtype=torch.int32)
+    # ---- step sum: out[r] = sum_s in[s][r]
+    x = torch.randn(T, R, W, generator=g).to(bf)
+    x0 = x.clone(); x0[~live] = 0
+    xn = x.clone(); xn[~live] = float('nan')
+    a_, b_ = torch.empty(R, W, device=dev), torch.empty(R, W, device=dev)
+    x0d, xnd = x0.to(dev), xn.to(dev)
+    call('ptv_sum_steps_top', ptr(a_), ptr(x0d), R * W, T, R * W, 0, 1, ptr(top), stream_ptr())
+    call('ptv_sum_steps_seg', ptr(b_), ptr(xnd), R * W, T, R * W, 0, 1, ptr(top), ptr(seg_d), W, stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.isfinite(b_).all() and torch.equal(a_, b_)
+    assert (a_.cpu().double() - x0.double().sum(0)).abs().max() < 1e-4
+    # ---- row product: C[(s, r)] = A[(s, r)] . B^T, dead row tiles store zeros without reading A
+    K, N = 192, 128
+    A = torch.randn(T * R, K, generator=g).to(bf); Wt = torch.randn(N, K, generator=g).to(bf)
+    A0 = A.clone(); A0[~live.view(-1)] = 0
+    An = A.clone(); An[~live.view(-1)] = float('nan')
+    C0 = torch.full((T * R, N), 7.0, device=dev); C1 = torch.full((T * R, N), 7.0, device=dev)
+    A0d, And, Wd = A0.to(dev), An.to(dev), Wt.to(dev)
+    call('ptv_gemm_mtop', 1, 0, 1, T * R, N, K, ptr(A0d), K, ptr(Wd), K, ptr(C0), N, None, 1.0, 0, 0, 0, 3, ptr(top), R, stream_ptr())
+    call('ptv_gemm_mtop_seg', 1, 0, 1, T * R, N, K, ptr(And), K, ptr(Wd), K, ptr(C1), N, None, 1.0, 0, 0, 0, 3, ptr(top), R, ptr(seg_d), R, T, stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.isfinite(C1).all() and torch.equal(C0, C1)
+    assert (C1.view(T, R, N)[~live.to(dev)] == 0).all()
+    # ---- gather / scatter by a permutation
+    perm = torch.randperm(R, generator=g).to(torch.int32).to(dev)
+    src = torch.randn(T, R, W, generator=g).to(dev)
+    dst = torch.full((T, R, W), -3.0, device=dev)
+    call('ptv_gather_rows_seg', ptr(dst), ptr(src), ptr(perm), R, W, R * W, R * W, T, ptr(seg_d), stream_ptr())
+    torch.cuda.synchronize()
+    want = src[:, perm.long()]
+    lv = live.to(dev)
+    assert torch.equal(dst[lv], want[lv]) and (dst[~lv] == -3.0).all()
+    srcn = want.clone(); srcn[~lv] = float('nan')                  # sorted order, dead rows poisoned
+    back = torch.full((T, R, W), -3.0, device=dev)
+    call('ptv_scatter_rows_seg', ptr(back), ptr(srcn), ptr(perm), R, W, R * W, R * W, T, ptr(seg_d), stream_ptr())
+    torch.cuda.synchronize()
+    expect = torch.zeros(T, R, W, device=dev)
+    expect[:, perm.long()] = torch.where(lv.unsqueeze(-1), want, torch.zeros_like(want))
+    assert torch.equal(back, expect)
+
+
+@pytest.mark.parametrize('B', [24, 512])
+def test_resummarize_with_resident_weights_is_bit_identical_to_the_streamed_kernel(B):
+    """ptv_free_resummarize (round 6): a wave keeps its 48 weight fragments in registers for the 16 steps of a launch; train bit 1 selects the
+    former path that streams them from L2 every step -- same products in the same k order: next tokens, saved states and gates bit-equal"""
+    from polyphonic_chord_texture_disentanglement_amd import functional as F_
+    from polyphonic_chord_texture_disentanglement_amd import functional_free as FF_
+    from polyphonic_chord_texture_disentanglement_amd._lib import call, stream_ptr
+    from polyphonic_chord_texture_disentanglement_amd.model import DisentangleVAE
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    m = DisentangleVAE.init_model(dev).to(dev)
+    P = dict(m.decoder.named_parameters())
+    pk = FF_._free_packs(P, 1024)
+    wE = [P['dec_notes_emb_gru.' + n] for n in FF_.EMB_GRU]
+    wr = F_._parr([pk['e_ih'], pk['e_hh'], pk['e_ih_r'], pk['e_hh_r'], wE[2], wE[3], wE[6], wE[7]])
+    R = 32 * B
+    g = torch.Generator(device=dev).manual_seed(9)
+    PRED = torch.randn(16, R, 128, device=dev, generator=g) * 0.5
+    plen = torch.randint(1, 16, (R,), device=dev, generator=g).to(torch.int32)
+    outs = []
+    for fl in (1, 3, 0, 2):
+        XH = [torch.zeros(17, R, 128, device=dev) for _ in range(2)]
+        XG = [torch.zeros(16, 4, R, 128, device=dev, dtype=torch.bfloat16) for _ in range(2)]
+        tok = torch.zeros(B, 256, device=dev)
+        io = F_._parr([PRED, plen, XH[0], XH[1], XG[0], XG[1], tok])
+        call('ptv_free_resummarize', wr, io, B, 3, fl, stream_ptr())
+        torch.cuda.synchronize()
+        outs.append([tok] + XH + XG)
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a_, b_)
+    assert torch.equal(outs[2][0], outs[3][0]) and torch.equal(outs[0][0], outs[2][0])
+    assert outs[0][0].abs().sum() > 0 and outs[0][1][1:, 3 * B:4 * B].abs().sum() > 0
+
+
 @pytest.mark.parametrize('M,N,K,dt,pad', [(384, 128, 4096, 3, 0), (130, 512, 2000, 2, 6), (1536, 128, 1056, 1, 0), (64, 130, 999, 0, 6),
                                           (128, 135, 640, 0, 1), (3072, 36, 512, 1, 4), (12, 512, 4100, 0, 0), (256, 1000, 8192, 3, 0)])
 def test_wgrad_kernel_vs_fp64_product_and_column_sums(M, N, K, dt, pad):
