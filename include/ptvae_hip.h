@@ -895,8 +895,8 @@ int ptv_notes_gru_persist_bwd(const void* wt, const void* HN16, const void* gate
 int ptv_notes_gru_persist_bwd_top(const void* wt, const void* HN16, const void* gates, const void* ext, void* dgi, void* dgh,
                                   float* dh0, void* scratch, long R, int T, const int* bound, int* top_step, void* stream);
 /* both with the rows sorted by descending length (row_len int32 [R] = live note steps of the row at each position, or NULL): a 64-row panel
- * runs the steps its first (= longest) row has.  Forward: the HN16 slots of a panel's dead steps up to *live_top are zero-filled, their gate
- * planes unwritten.  Backward (needs bound): `ext` is not read at a panel's dead steps; dgi / dgh get zero rows there up to *bound -- unless
+ * runs the steps its first (= longest) row has.  Forward: the HN16 slots of a panel's dead steps up to *live_top are zero-filled (not with
+ * bit 24 of T: the caller's products clip to the same segments), their gate planes unwritten.  Backward (needs bound): `ext` is not read at a panel's dead steps; dgi / dgh get zero rows there up to *bound -- unless
  * bit 16 of T is set (round 6): the caller's consumers clip to the same 128-row segments (ptv_wgrad_job.seg_n, ptv_sum_steps_seg,
  * ptv_gemm_mtop_seg) and the rows may stay unwritten. */
 int ptv_notes_gru_persist_fwd_rows(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,

@@ -130,7 +130,7 @@ extern "C" int ptv_decoder_tf_fwd(const void* const* t, const long* d, void* str
   // note slots; the three launches below then leave the later steps' rows of their outputs unwritten)
   const int* live = (const int*)T_(t, PTV_DTF_LIVE_TOP);
   PTV_TRY(ptv_notes_gru_persist_fwd_rows(T_(t, PTV_DTF_PK_NOTES_H), T_(t, PTV_DTF_PK_NOTES_T), (const float*)T_(t, PTV_DTF_B_HH_N), T_(t, PTV_DTF_GC),
-                                         tok, HN, HN16, M_<void>(t, PTV_DTF_GATES_N), R, 15, live, row_len, stream));
+                                         tok, HN, HN16, M_<void>(t, PTV_DTF_GATES_N), R, 15 | (sorted && t[PTV_DTF_SEG_N] ? (1 << 24) : 0), live, row_len, stream));
   // ---- pitch head + initial duration state in one pass over the note states (ptvae.py:343-352)
   PTV_TRY(ptv_heads_fwd_rows(HN16 + (long)R * Hn, T_(t, PTV_DTF_PK_WP), T_(t, PTV_DTF_PK_WDH), T_(t, PTV_DTF_PK_WDP), (const float*)T_(t, PTV_DTF_B_P),
                              (const float*)T_(t, PTV_DTF_B_DH), M_<float>(t, PTV_DTF_PITCH), ldp, HD, HD16, M, live, R, row_len, stream));

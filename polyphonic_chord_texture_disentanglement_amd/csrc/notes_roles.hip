@@ -91,6 +91,7 @@ struct Args {
   const int* row_len;              // or null: [R] live note steps per row, rows sorted by DESCENDING length (ptv_rows_by_length): a panel runs the
                                    // steps its longest (= first) row has; the HN16 slots of its dead steps up to the launch-wide limit are
                                    // zero-filled (finite operands for the weight-gradient products), their gate planes stay unwritten
+  int nofill;                      // (T bit 24) ... unless the caller's products clip to the same 128-row segments (ptv_wgrad_job.seg_n): unwritten too
 };
 
 // slot address of the 16-byte chunk j (units 4j .. 4j+3) of (gate, row): chunks are XOR-swizzled so that both the product wave's
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void notes_fwd_kernel(Args a) {
   }
   // (rows sorted by length) the panel's dead steps below the launch-wide limit: zero states -- the weight_hh gradient product meets them
   // with exactly-zero gate gradients, and 0 x whatever-the-allocator-left is not 0
-  for (int n = T; n < Tg; n++)
+  for (int n = T; n < Tg && !a.nofill; n++)
     for (int i = tid; i < ROWS * (H / 8); i += 512) {
       const int row = i / (H / 8), c8 = (i % (H / 8)) * 8;
       if (r0 + row < R) {
@@ -427,7 +428,8 @@ extern "C" int ptv_notes_gru_persist_fwd(const void* wg_h, const void* wg_t, con
   return ptv_notes_gru_persist_fwd_top(wg_h, wg_t, b_hh, gc, emb, h0, HN16, gates, R, T, nullptr, stream);
 }
 
-// T: bits 0-7 = steps, bits 8-15 = debug flags (8: no stagger), bits 16-23 = ring depth (0 = default)
+// T: bits 0-7 = steps, bits 8-15 = debug flags (8: no stagger), bits 16-23 = ring depth (0 = default), bit 24 = leave the HN16 slots of a
+// panel's dead steps unwritten (rows variant: the caller's products clip to the same segments)
 extern "C" int ptv_notes_gru_persist_fwd_rows(const void* wg_h, const void* wg_t, const float* b_hh, const void* gc, const float* emb,
                                               const float* h0, void* HN16, void* gates, long R, int T, const int* live_top, const int* row_len,
                                               void* stream);
@@ -440,7 +442,7 @@ extern "C" int ptv_notes_gru_persist_fwd_rows(const void* wg_h, const void* wg_t
                                               void* stream) {
   if (!wg_h || !wg_t || !b_hh || !gc || !emb || !h0 || !HN16 || R <= 0 || (T & 0xff) <= 0) return PTV_ERR_ARG;
   nr::Args a{(const bf16x8*)wg_h, (const bf16x8*)wg_t, b_hh, (const __bf16*)gc, emb, R * nr::E, h0, (__bf16*)HN16, (__bf16*)gates,
-             (int)R, T & 0xff, (T >> 8) & 0xff, g_notes_trace, live_top, row_len};
+             (int)R, T & 0xff, (T >> 8) & 0xff, g_notes_trace, live_top, row_len, (T >> 24) & 1};
   const int depth = (T >> 16) & 0xff, abl = a.dbg & 7;
   const int pi = prof::want(3, (int)R, nr::H) ? prof::begin((hipStream_t)stream) : -1;
   hipStream_t s = (hipStream_t)stream;
