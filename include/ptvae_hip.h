@@ -1027,11 +1027,14 @@ typedef struct ptv_wgrad_job {
   const int* k_top; long k_unit; int k_rev;
   /* round 6, K SEGMENTS (or seg_n = NULL): K runs over units of seg_unit rows (a note step's R decoder rows in length order); of unit q only the
    * first seg_n[q % seg_period] rows (device ints, multiples of 32) hold anything -- the rest of A is zero and the rest of B may never have
-   * been written.  The product skips them (slabs never straddle a unit: seg_unit must be a power of two >= 256 that divides K), and so does
+   * been written.  The product skips them (slabs never straddle a unit: ptv_wgrad_seg_supported(K, seg_unit)), and so does
    * the ordered reduction; against the same product without segments the result is bit-identical when the skipped rows of A are zero. */
   const int* seg_n; long seg_unit; int seg_period;
 } ptv_wgrad_job;
 int ptv_wgrad_batch(const ptv_wgrad_job* jobs, int njobs, void* stream);
+/* 1 if a product of depth K can take segments of seg_unit rows: seg_unit a multiple of 128 that divides K, and K cut into at most 248 slabs of
+ * the largest power of two that divides seg_unit (B = 512: 16384-row units; 3 * 2^k units work too; 128 * 129 rows do not) */
+int ptv_wgrad_seg_supported(long K, long seg_unit);
 /* seg_n[s] = 128 * #{128-row blocks whose FIRST row has row_len > s}, s < steps: the live prefix of every note step when the decoder's rows run
  * in descending length order (ptv_rows_by_length) and a block is dead beyond its first row's length -- what the *_rows kernels of the decoder
  * skip and ptv_wgrad_batch's segments clip.  R a multiple of 128. */

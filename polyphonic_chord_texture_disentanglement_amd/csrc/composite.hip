@@ -293,7 +293,8 @@ extern "C" int ptv_decoder_tf_bwd(const void* const* t, const long* d, void* str
   if (B <= 0 || E != 128 || Hn != 512 || Hd != 64 || NP != 130 || ldp < NP || nblk <= 0 || (S && !t[PTV_DTB_PART_T])) return PTV_ERR_UNSUPPORTED;
   const int R = 32 * B;
   // K segments of the weight-gradient products over (note step, sorted row): the dead blocks of every step are neither read nor multiplied
-  const int* seg_n = t[PTV_DTB_PERM] && !(R & (R - 1)) && R >= 256 ? (const int*)T_(t, PTV_DTB_SEG_N) : nullptr;
+  const int* seg_n = t[PTV_DTB_PERM] ? (const int*)T_(t, PTV_DTB_SEG_N) : nullptr;
+  if (seg_n && !ptv_wgrad_seg_supported(15L * R, R)) return PTV_ERR_ARG;    // (the caller asks ptv_wgrad_seg_supported before it sets the slot)
   const long M = 15L * R;
   const int P = PTV_PREC_BF16;
   hipStream_t s = (hipStream_t)stream, side = (hipStream_t)const_cast<void*>(t[PTV_DTB_SIDE_STREAM]);

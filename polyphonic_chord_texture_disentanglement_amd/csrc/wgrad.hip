@@ -669,6 +669,7 @@ extern "C" int ptv_wgrad_batch_mode(int mode) { if (mode < 0 || mode > 3) return
 extern "C" int ptv_wgrad_dma(int enable) { ptv::g_wgrad_dma = enable ? 1 : 0; return PTV_OK; }
 extern "C" int ptv_wgrad_mode(int ordered) { ptv::g_wgrad_mode = ptv::g_splitk_ordered = ordered ? 1 : 0; return PTV_OK; }
 
+extern "C" int ptv_wgrad_seg_supported(long K, long seg_unit);
 namespace {
 // one product of a call: what the caller asked for (ptv_wgrad_job + the two-source form of ptv_wgrad_cat) ...
 struct Job {
@@ -730,8 +731,8 @@ int plan_job(const Job& j, Plan& p) {
       int kper = 128;
       int want = cdiv(kn, ns);
       if (want_slabs <= 0 && want > 4096) want = 4096;           // (measured, scripts/bench_wgrad_seg.py: the clipped slabs of a unit balance better when a unit holds >= 4 of them)
-      while (kper * 2 <= want && kper * 2 <= (int)j.seg_unit) kper *= 2;
-      while (cdiv(kn, kper) > 256 && kper * 2 <= (int)j.seg_unit) kper *= 2;
+      while (kper * 2 <= want && (j.seg_unit % (kper * 2)) == 0) kper *= 2;
+      while (cdiv(kn, kper) > 248 && (j.seg_unit % (kper * 2)) == 0) kper *= 2;
       g.kper = kper; ns = cdiv(kn, kper);
       // whole slabs per XCD (map 1: every K row is fetched into ONE L2) wants a multiple of 8 slabs: pad with slabs beyond K (they find
       // no rows and leave).  With tile ranges per XCD (map 2) every XCD fetched every row of both operands: PMC, +0.1 GB per step
@@ -795,9 +796,7 @@ int wgrad_run(const Job* jobs, int njobs, hipStream_t s) {
     const Job& j = jobs[i];
     if (j.M < 0 || j.N < 0 || j.K < 0 || !j.A || !j.B || !j.C) return PTV_ERR_ARG;
     if (j.k_top && (j.k_unit <= 0 || j.k_unit % WBK)) return PTV_ERR_ARG;
-    if (j.seg_n && (j.seg_unit < 256 || (j.seg_unit & (j.seg_unit - 1)) || j.seg_period <= 0 || (j.K % j.seg_unit) || j.A2 ||
-                    (long)j.K / 128 > 256L * (j.seg_unit / 128)))
-      return PTV_ERR_ARG;
+    if (j.seg_n && (j.seg_period <= 0 || j.A2 || !ptv_wgrad_seg_supported(j.K, j.seg_unit))) return PTV_ERR_ARG;
     if (j.M == 0 || j.N == 0) continue;
     if (j.K == 0) { if (!j.accumulate) zero_c(j, s); continue; }
     live[n] = j; PTV_TRY(plan_job(j, plan[n]));
@@ -932,6 +931,15 @@ int wgrad_run(const Job* jobs, int njobs, hipStream_t s) {
   return PTV_OK;
 }
 }  // namespace
+
+// K segments need slabs that never straddle a unit -- a power of two (>= 128 rows) that divides seg_unit -- and at most 256 of them (the
+// reduction lists the live ones with one thread per slab; 8 are kept for the padding to whole slabs per XCD and the guarded tail)
+extern "C" int ptv_wgrad_seg_supported(long K, long seg_unit) {
+  if (K <= 0 || seg_unit < 128 || (seg_unit & 127) || (K % seg_unit)) return 0;
+  long kper = 128;
+  while ((seg_unit % (kper * 2)) == 0) kper *= 2;
+  return (K + kper - 1) / kper <= 248 ? 1 : 0;
+}
 
 extern "C" int ptv_wgrad(int M, int N, int K, const void* A, long lda, const void* B, long ldb, float* C, long ldc, float alpha,
                          int accumulate, int dtypes, int slabs, float* colsum_a, const int* k_top, long k_unit, int k_rev, void* stream) {

@@ -2716,7 +2716,7 @@ def arm_live_top(x):
         call('ptv_gather_rows', ptr(pt_s), ptr(pitch_t), ptr(perm), R, 1, R, R, 15, stream_ptr())
         call('ptv_gather_rows', ptr(dt_s), ptr(dur_t), ptr(perm), R, 5, 5 * R, 5 * R, 15, stream_ptr())
         seg_n = None
-        if WGRAD_SEG and R >= 256 and not (R & (R - 1)):            # (a note step's rows: a power of two, so that slabs of the products never straddle a step)
+        if WGRAD_SEG and R % 128 == 0 and lib().ptv_wgrad_seg_supported(15 * R, R):    # (slabs of the products must not straddle a note step)
             # ... and the live prefix of every note step in that order (128-row blocks): the weight-gradient products over (note step, row) clip to it
             seg_n = torch.empty(15, device=x.device, dtype=torch.int32)
             call('ptv_rows_seg_counts', ptr(len_s), R, 15, ptr(seg_n), stream_ptr())

@@ -55,7 +55,7 @@ def test_dead_note_steps_are_never_read(B, composite, monkeypatch):
         assert torch.equal(g0[k], g1[k]), (k, (g0[k] - g1[k]).abs().max())
 
 
-@pytest.mark.parametrize('B', [16, 64, 512])
+@pytest.mark.parametrize('B', [16, 64, 512, 48, 20])          # (48, 20: note steps of 1536 / 640 rows -- segments of 3 / 5 x a power of two)
 def test_length_sorted_rows_skip_dead_blocks_and_change_nothing(B, monkeypatch):
     """round 6, per-row dead work: inside loss() the decoder works on its rows (t, b) sorted by the number of live note steps and passes over
     the (note step, 128-row block) pairs without a target; the loss gets its targets in the same order, the gradients of the time states
@@ -70,12 +70,14 @@ def test_length_sorted_rows_skip_dead_blocks_and_change_nothing(B, monkeypatch):
         monkeypatch.setattr(F_, 'SORT_DEC_ROWS', srt)
         monkeypatch.setattr(F_, 'POISON_DEAD_STEPS', srt)
         n0 = F_._DTF.get('sorted_calls', 0)
+        F_._LAST_SEG_N = None
         m.use_philox(5, 0)
         opt.zero_grad()
         losses = m.loss(x, c, pr, 1., 1., 1., 0.1, [1, 0.5])
         losses[0].backward()
         torch.cuda.synchronize()
         assert (F_._DTF.get('sorted_calls', 0) - n0 == 1) == srt    # the sorted path ran exactly when asked to
+        assert (F_._LAST_SEG_N is not None) == srt                  # ... with the row segments of stage 2
         res[srt] = ([l.detach().clone() for l in losses], {k: p.grad.detach().clone() for k, p in m.named_parameters()})
     (l0, g0), (l1, g1) = res[False], res[True]
     for a, b in zip(l0, l1):
