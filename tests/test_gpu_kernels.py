@@ -816,10 +816,13 @@ def test_row_segment_variants_of_step_sum_row_product_gather_and_scatter():
     An = A.clone(); An[~live.view(-1)] = float('nan')
     C0 = torch.full((T * R, N), 7.0, device=dev); C1 = torch.full((T * R, N), 7.0, device=dev)
     A0d, And, Wd = A0.to(dev), An.to(dev), Wt.to(dev)
-    call('ptv_gemm_mtop', 1, 0, 1, T * R, N, K, ptr(A0d), K, ptr(Wd), K, ptr(C0), N, None, 1.0, 0, 0, 0, 3, ptr(top), R, stream_ptr())
-    call('ptv_gemm_mtop_seg', 1, 0, 1, T * R, N, K, ptr(And), K, ptr(Wd), K, ptr(C1), N, None, 1.0, 0, 0, 0, 3, ptr(top), R, ptr(seg_d), R, T, stream_ptr())
+    # (transB = 0: B in the nn.Linear weight layout [N][K])
+    call('ptv_gemm_mtop', 1, 0, 0, T * R, N, K, ptr(A0d), K, ptr(Wd), K, ptr(C0), N, None, 1.0, 0, 0, 0, 3, ptr(top), R, stream_ptr())
+    call('ptv_gemm_mtop_seg', 1, 0, 0, T * R, N, K, ptr(And), K, ptr(Wd), K, ptr(C1), N, None, 1.0, 0, 0, 0, 3, ptr(top), R, ptr(seg_d), R, T, stream_ptr())
     torch.cuda.synchronize()
     assert torch.isfinite(C1).all() and torch.equal(C0, C1)
+    wantC = A0.double() @ Wt.double().t()
+    assert (C1.cpu().double() - wantC).abs().max() < 2e-5 * max(1.0, wantC.abs().max().item())
     assert (C1.view(T, R, N)[~live.to(dev)] == 0).all()
     # ---- gather / scatter by a permutation
     perm = torch.randperm(R, generator=g).to(torch.int32).to(dev)
