@@ -659,6 +659,8 @@ enum PtvBrbTensor {
   PTV_BRB_DX,             /* out [T*M, I] fp32 or NULL */
   PTV_BRB_DGI0, PTV_BRB_DGH0, PTV_BRB_SCRATCH0, PTV_BRB_TOP0, PTV_BRB_DGI1, PTV_BRB_DGH1, PTV_BRB_SCRATCH1, PTV_BRB_TOP1,
   PTV_BRB_SIDE_STREAM, PTV_BRB_FORK_EVENT, PTV_BRB_JOIN_EVENT,
+  PTV_BRB_SEG,            /* int32 [T] or NULL, with PERM = ptv_rows_by_length(LENGTHS) only: ptv_rows_seg_counts of the lengths in that order -- the
+                             weight_hh products (operands indexed by position) skip the dead 128-row blocks of every step */
   PTV_BRB_COUNT
 };
 enum PtvBrbDim { PTV_BRB_D_M = 0, PTV_BRB_D_T, PTV_BRB_D_H, PTV_BRB_D_I, PTV_BRB_D_DX_ACC, PTV_BRB_D_DOUT_LD, PTV_BRB_D_COUNT };
@@ -1026,7 +1028,8 @@ typedef struct ptv_wgrad_job {
   float* colsum_a;
   const int* k_top; long k_unit; int k_rev;
   /* round 6, K SEGMENTS (or seg_n = NULL): K runs over units of seg_unit rows (a note step's R decoder rows in length order); of unit q only the
-   * first seg_n[q % seg_period] rows (device ints, multiples of 32) hold anything -- the rest of A is zero and the rest of B may never have
+   * first seg_n[q % seg_period] rows (seg_period < 0: seg_n[|seg_period| - 1 - q % |seg_period|], units in reversed order; device ints,
+   * multiples of 32) hold anything -- the rest of A is zero and the rest of B may never have
    * been written.  The product skips them (slabs never straddle a unit: ptv_wgrad_seg_supported(K, seg_unit)), and so does
    * the ordered reduction; against the same product without segments the result is bit-identical when the skipped rows of A are zero. */
   const int* seg_n; long seg_unit; int seg_period;

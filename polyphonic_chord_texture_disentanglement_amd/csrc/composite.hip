@@ -575,7 +575,7 @@ extern "C" int ptv_bigru_rows_bwd(const void* const* t, const long* d, void* str
   const bool want_dx = t[PTV_BRB_DX] != nullptr;
   for (int i = 0; i < PTV_BRB_COUNT; i++) {
     const bool optional = i == PTV_BRB_LENGTHS || i == PTV_BRB_PERM || i == PTV_BRB_WT_IH0 || i == PTV_BRB_WT_IH1 || i == PTV_BRB_DX ||
-                          i == PTV_BRB_TOP0 || i == PTV_BRB_TOP1;
+                          i == PTV_BRB_TOP0 || i == PTV_BRB_TOP1 || i == PTV_BRB_SEG;
     if (!t[i] && !optional) return PTV_ERR_ARG;
   }
   if (want_dx && (!t[PTV_BRB_WT_IH0] || !t[PTV_BRB_WT_IH1])) return PTV_ERR_ARG;
@@ -595,8 +595,11 @@ extern "C" int ptv_bigru_rows_bwd(const void* const* t, const long* d, void* str
                                          M_<void>(t, PTV_BRB_SCRATCH0 + q), M, T, dir, top, (void*)st));
     WgradGroup wg(P, (void*)st);
     PTV_TRY(wg.add(3 * H, I, TM, dgi, 3L * H, 1, x, I, 0, M_<float>(t, PTV_BRB_G_W_IH0 + g), I, M_<float>(t, PTV_BRB_G_B_IH0 + g), top, top ? M : 0, 0));
+    // (rows sorted by length: dgh and the states are indexed by POSITION -- the dead 128-row blocks of every step are skipped; the reversed
+    // direction indexes its steps by processing order, so its segments run backwards)
+    const int* seg = t[PTV_BRB_PERM] && top ? (const int*)T_(t, PTV_BRB_SEG) : nullptr;
     PTV_TRY(wg.add(3 * H, H, TM, dgh, 3L * H, 1, T_(t, PTV_BRB_H16_0 + o), H, 1, M_<float>(t, PTV_BRB_G_W_HH0 + g), H,
-                   M_<float>(t, PTV_BRB_G_B_HH0 + g), top, top ? M : 0, dir ? T : 0));
+                   M_<float>(t, PTV_BRB_G_B_HH0 + g), top, top ? M : 0, dir ? T : 0, 1, seg, M, dir ? -T : T));
     return wg.flush();
   };
   auto dx_of = [&](int dir, int acc) -> int {

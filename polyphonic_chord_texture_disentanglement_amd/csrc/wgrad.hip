@@ -78,7 +78,9 @@ __device__ __forceinline__ bool slab_range(const WgArgs& g, int slab, int& k_beg
   if (g.seg_n) {                                                  // (kper divides seg_unit: a slab lies inside one unit)
     const long row = (long)k_begin + g.k_base;
     const int q = (int)(row / g.seg_unit), r0 = (int)(row - (long)q * g.seg_unit);
-    const int live = g.seg_n[q % g.seg_period] - r0;             // live rows from the slab's first row on
+    // (a negative period: the units run in REVERSED order -- the reversed direction of a GRU indexes its rows by processing step)
+    const int qi = g.seg_period > 0 ? q % g.seg_period : -g.seg_period - 1 - q % (-g.seg_period);
+    const int live = g.seg_n[qi] - r0;                            // live rows from the slab's first row on
     if (live <= 0) return false;
     if (k_end - k_begin > live) k_end = k_begin + live;
   }
@@ -796,7 +798,7 @@ int wgrad_run(const Job* jobs, int njobs, hipStream_t s) {
     const Job& j = jobs[i];
     if (j.M < 0 || j.N < 0 || j.K < 0 || !j.A || !j.B || !j.C) return PTV_ERR_ARG;
     if (j.k_top && (j.k_unit <= 0 || j.k_unit % WBK)) return PTV_ERR_ARG;
-    if (j.seg_n && (j.seg_period <= 0 || j.A2 || !ptv_wgrad_seg_supported(j.K, j.seg_unit))) return PTV_ERR_ARG;
+    if (j.seg_n && (j.seg_period == 0 || j.A2 || !ptv_wgrad_seg_supported(j.K, j.seg_unit))) return PTV_ERR_ARG;
     if (j.M == 0 || j.N == 0) continue;
     if (j.K == 0) { if (!j.accumulate) zero_c(j, s); continue; }
     live[n] = j; PTV_TRY(plan_job(j, plan[n]));

@@ -763,7 +763,7 @@ SHADOW_T_SLOT = 7       # pool stream of the transposed bf16 weight shadows' ref
 # r05_ab_runs.txt): the launches do half the work (mean length 3.8 against a panel maximum of 8) but stay as long as their longest panel --
 # 225 / 242 us against 210 / 233 us in situ, step 7.69-7.71 against 7.64-7.67 ms: they are latency-bound per step, and what they leave
 # free nobody needs at that moment.  Off; the capability stays (it is the sequence packing of pack_padded_sequence, ptvae.py:446-453).
-SORT_ROWS = os.environ.get('PTV_SORT_ROWS', '0') == '1'
+SORT_ROWS = os.environ.get('PTV_SORT_ROWS', '1') == '1'
 # (Round-4 scheduling experiments on the step's tail -- chain-first bi-GRU backward, parameter-gradient products launched when the backward
 # pass ends, row kernels taking turns with the persistent launches, forks before / after the chain's dX products -- all measured slower
 # than this plain scheme, 8.43 ms per step against 8.48-8.95; their numbers are in DESIGN.md section 4 and profiles/r04_ab_*.txt, their
@@ -783,14 +783,20 @@ def zero_skip_sync():
         _ZERO_SKIP_SET[:] = [ZERO_SKIP]
 
 
-def wgrad_bias(dy, x, gw, gb, prec, k_top=None, k_unit=0, k_rev=0):
+def wgrad_bias(dy, x, gw, gb, prec, k_top=None, k_unit=0, k_rev=0, seg=None, seg_period=0):
     """gw [N_out, N_in] += dy^T . x and gb [N_out] (or None) += column sums of dy: a layer's weight and bias gradient in one pass
     over dy (ptv_wgrad's colsum_a) where the weight-gradient kernel applies; otherwise the product and a column-sum kernel.
-    k_top (device int) / k_unit: the rows of dy from (k_top + 1) * k_unit on are zero (ptv_wgrad)"""
+    k_top (device int) / k_unit: the rows of dy from (k_top + 1) * k_unit on are zero (ptv_wgrad); seg (device ints) / seg_period: K segments
+    of k_unit rows (ptv_wgrad_job.seg_n)"""
     K = dy.shape[0]
     if (WGRAD_FUSE_BIAS and prec == 1 and K >= 512 and gw.dtype == F32 and dy.stride(1) == 1 and x.stride(1) == 1
             and True):
         _chain_prio()
+        if seg is not None:                                  # (the job form carries the segments; same bits as the composite's batch of two)
+            from ._lib import wgrad_batch
+            wgrad_batch([dict(M=dy.shape[1], N=x.shape[1], K=K, A=dy, B=x, C=gw, colsum_a=gb, k_top=k_top, k_unit=int(k_unit) if k_top is not None else 0,
+                              k_rev=int(k_rev), seg_n=seg, seg_unit=int(k_unit), seg_period=int(seg_period))])
+            return gw, gb
         call('ptv_wgrad', dy.shape[1], x.shape[1], K, ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(gw), _ld(gw), 1.0, 1,
              _bf(dy) | (_bf(x) << 1), 0, ptr(gb), ptr(k_top), int(k_unit) if k_top is not None else 0, int(k_rev), stream_ptr())
     else:
@@ -996,7 +1002,7 @@ def _fork_events(cache, n=2):
     return evs
 
 
-def _bigru_rows_fwd_composite(x3, lengths, perm, w, out, side, T, M, I, H, dev):
+def _bigru_rows_fwd_composite(x3, lengths, perm, w, out, side, T, M, I, H, dev, seg=None):
     """-> _bigru_forward's result when ptv_bigru_rows_fwd ran its row-kernel branch, else None"""
     if 't' not in _BRF:
         from ._lib import header_enum
@@ -1015,7 +1021,7 @@ def _bigru_rows_fwd_composite(x3, lengths, perm, w, out, side, T, M, I, H, dev):
         pk = notes_packs(w_ih, w_hh, 0)
         hall, h16 = _empty(T + 1, M, H, dev=dev), _empty(T + 1, M, H, dev=dev, dtype=BF16)
         gates = _empty(T, 4, M, H, dev=dev, dtype=BF16)
-        saved.append((hall, gates, h16, (lengths if ZERO_SKIP else None), perm))
+        saved.append((hall, gates, h16, (lengths if ZERO_SKIP else None), perm, seg))
         tens.update({'PK_WG_H%d' % d_: pk['wg_h'], 'PK_WG_T%d' % d_: pk['wg_t'], 'B_HH%d' % d_: b_hh, 'B_IH%d' % d_: b_ih,
                      'HALL%d' % d_: hall, 'H16_%d' % d_: h16, 'GATES%d' % d_: gates})
     slots = [None] * T_['PTV_BRF_COUNT']
@@ -1056,7 +1062,7 @@ def _bigru_rows_bwd_composite(prec, x3, xf, w, saved, dout, need_dx, dx_acc, sid
     dx = None
     if need_dx:
         dx = dx_acc if dx_acc is not None else _empty(T * M, I, dev=dev)
-    tens = {'X': xf, 'DOUT': dout, 'LENGTHS': lengths, 'PERM': perm, 'DX': dx}
+    tens = {'X': xf, 'DOUT': dout, 'LENGTHS': lengths, 'PERM': perm, 'DX': dx, 'SEG': saved[0][5] if len(saved[0]) > 5 else None}
     n_scr = lib().ptv_row_gru_persist_scratch_elems(H, M)
     for d_ in range(2):
         hall, gates, h16 = saved[d_][:3]
@@ -1177,10 +1183,16 @@ def _bigru_forward(prec, x3, lengths, w):
         # direction for the whole sequence (csrc/notes_persist.hip), input product fused; the directions overlap on sibling streams
         # (optional) rows sorted by length: a 64-row panel then holds rows of (almost) one length and passes over the steps that are masked
         # for ALL of them -- in row order a panel's longest row is nearly always the longest of the batch
-        perm = None
+        perm, seg = None, None
         if lengths is not None and ZERO_SKIP and SORT_ROWS and T <= 38:
             perm = torch.empty(M, device=dev, dtype=torch.int32)
             call('ptv_rows_by_length', ptr(lengths), ptr(perm), M, T, stream_ptr())
+            if WGRAD_SEG and M % 128 == 0 and lib().ptv_wgrad_seg_supported(T * M, M):
+                # (round 6) ... and the live prefix of every position in that order: the weight_hh products clip to it (ptv_bigru_rows_bwd)
+                len_s = torch.empty(M, device=dev, dtype=torch.int32)
+                call('ptv_gather_rows', ptr(len_s), ptr(lengths), ptr(perm), M, 1, 0, 0, 1, stream_ptr())
+                seg = torch.empty(T, device=dev, dtype=torch.int32)
+                call('ptv_rows_seg_counts', ptr(len_s), M, T, ptr(seg), stream_ptr())
 
         def rows(d):
             w_ih, w_hh, b_ih, b_hh = w[4 * d: 4 * d + 4]
@@ -1193,10 +1205,10 @@ def _bigru_forward(prec, x3, lengths, w):
                  ptr(lengths) if lengths is not None else None, ptr(perm), ptr(hall), ptr(h16), ptr(gates), out.data_ptr() + 4 * d * H,
                  2 * H, M, T, d, stream_ptr())
             # (the backward must skip the same fully masked panel steps, with the same row order)
-            return hall, gates, h16, (lengths if ZERO_SKIP else None), perm
+            return hall, gates, h16, (lengths if ZERO_SKIP else None), perm, seg
         side = Side(BIGRU_SLOT)
         if BIGRU_BWD_COMPOSITE:
-            res = _bigru_rows_fwd_composite(x3, lengths, perm, w, out, side, T, M, I, H, dev)
+            res = _bigru_rows_fwd_composite(x3, lengths, perm, w, out, side, T, M, I, H, dev, seg)
             if res is not None:
                 return res
         rev = side(lambda: rows(1), x3, out)
@@ -1314,8 +1326,9 @@ def _bigru_backward(prec, x3, w, saved, dout, need_dx, dx_acc=None, rev_slot=Non
         hall, gates, h16 = saved[d][:3]
         dgi2, dgh2 = dgi.view(T * M, 3 * H), dgh.view(T * M, 3 * H)
         dw_ih, db_ih = wgrad_bias(dgi2, xf, _gbuf(w_ih), _gbuf(b_ih), prec, top, M)
+        seg = saved[d][5] if (len(saved[d]) > 5 and top is not None and h16 is not None and saved[d][4] is not None) else None
         dw_hh, db_hh = wgrad_bias(dgh2, (h16 if h16 is not None else hall)[:T].view(T * M, H), _gbuf(w_hh), _gbuf(b_hh), prec, top, M,
-                                  k_rev=T if d else 0)
+                                  k_rev=T if d else 0, seg=seg, seg_period=-T if d else T)
         if d:
             late['dgi'], late['top'] = dgi2, top
         return [dw_ih, dw_hh, db_ih, db_hh], (dx_of(0, dgi2, top, True) if (d == 0 and with_dx) else None)

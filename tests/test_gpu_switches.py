@@ -18,7 +18,7 @@ PROBE = ("import json, sys, torch; sys.path.insert(0, %r); import bench; "
 
 
 @pytest.mark.parametrize('env', [{}, {'PTV_ZERO_SKIP': '0'}, {'PTV_DUR_RECOMPUTE': '0'}, {'PTV_PERSIST_SPLITK': '0'}, {'PTV_PERSIST_SPLITK': '4'},
-                                 {'PTV_WGRAD_ORDERED': '0'}, {'PTV_WGRAD_DMA': '1'}, {'PTV_SUMMARY_FAMILY': '4'}, {'PTV_SORT_ROWS': '1'}, {'PTV_DEAD_STEPS': '0'}, {'PTV_SORT_DEC_ROWS': '0'}, {'PTV_BWD_COMPOSITES': '0'}, {'PTV_ORDERED_STRICT': '1', 'PTV_PTR_CHECKS': '1'}],
+                                 {'PTV_WGRAD_ORDERED': '0'}, {'PTV_WGRAD_DMA': '1'}, {'PTV_SUMMARY_FAMILY': '4'}, {'PTV_SORT_ROWS': '0'}, {'PTV_DEAD_STEPS': '0'}, {'PTV_SORT_DEC_ROWS': '0'}, {'PTV_BWD_COMPOSITES': '0'}, {'PTV_ORDERED_STRICT': '1', 'PTV_PTR_CHECKS': '1'}],
                          ids=lambda e: ','.join('%s=%s' % kv for kv in e.items()) or 'defaults')
 def test_step_under_each_kept_switch_vs_reference_golden(env):
     out = subprocess.run([sys.executable, '-c', PROBE], env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=600)
