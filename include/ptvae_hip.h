@@ -821,7 +821,7 @@ enum PtvDffDim {
   PTV_DFF_D_B = 0, PTV_DFF_D_ZS, PTV_DFF_D_ZI, PTV_DFF_D_HE, PTV_DFF_D_HT, PTV_DFF_D_HN, PTV_DFF_D_HD, PTV_DFF_D_E, PTV_DFF_D_NP,
   PTV_DFF_D_LDP,            /* row stride of the pitch logits */
   PTV_DFF_D_TRAIN, PTV_DFF_D_REPLAY, PTV_DFF_D_INFERENCE,
-  PTV_DFF_D_LOOP_FLAGS,     /* the `train` word of ptv_free_note_loop (mode, kernel choice, cluster size) */
+  PTV_DFF_D_LOOP_FLAGS,     /* the `train` word of ptv_free_note_loop (mode, kernel choice, cluster size); in cluster mode the call zeroes io[19] / io[20] itself */
   PTV_DFF_D_CLUSTER,        /* != 0: the note loops take the persistent-launch turn (WAIT / RECORD events) */
   PTV_DFF_D_RESUM_TRAIN,    /* the `train` word of ptv_free_resummarize */
   PTV_DFF_D_TOK0_LDS,       /* row stride of TOK0_SRC (0 = one row for all) */

@@ -690,6 +690,15 @@ extern "C" int ptv_decoder_free_fwd(const void* const* t, const long* d, const v
   const void* ior_[7];
   if (need_resum) for (int i = 0; i < 7; i++) ior_[i] = ior[i];
   if (cluster && t[PTV_DFF_WAIT_EVENT] && hipStreamWaitEvent(s, (hipEvent_t)const_cast<void*>(t[PTV_DFF_WAIT_EVENT]), 0) != hipSuccess) return PTV_ERR_LAUNCH;
+  if (cluster) {
+    // the members' exchange words carry (time step, note step) tags that repeat from one forward pass to the next: whatever the caller did with
+    // the buffer, this pass starts from tag 0 (64 KB per panel; the arrival counters likewise)
+    if (!io[19] || !io[20]) return PTV_ERR_ARG;
+    const long panels = (B + 15) / 16;
+    if (hipMemsetAsync(const_cast<void*>(io[19]), 0, (size_t)panels * 65536, s) != hipSuccess ||
+        hipMemsetAsync(const_cast<void*>(io[20]), 0, sizeof(unsigned) * (size_t)(panels + 1), s) != hipSuccess)
+      return PTV_ERR_LAUNCH;
+  }
   for (int ts = 0; ts < 32; ts++) {
     const float* tok_t = TOKS + (long)ts * B * 2 * He;
     PTV_TRY(ptv_gemm(P, 0, 0, B, 3 * Ht, 2 * He, tok_t, 2L * He, T_(t, PTV_DFF_W_IH_T_OP), ld_t, gi, 3L * Ht, nullptr, 1.f, 0, 0, 0, wih_bf ? B16 : 0, stream));
