@@ -55,7 +55,7 @@ def test_dead_note_steps_are_never_read(B, composite, monkeypatch):
         assert torch.equal(g0[k], g1[k]), (k, (g0[k] - g1[k]).abs().max())
 
 
-@pytest.mark.parametrize('B', [16, 64, 512, 48, 20])          # (48, 20: note steps of 1536 / 640 rows -- segments of 3 / 5 x a power of two)
+@pytest.mark.parametrize('B', [16, 64, 512, 48, 20, 4])       # (48, 20: note steps of 1536 / 640 rows -- segments of 3 / 5 x a power of two; 4: one block)
 def test_length_sorted_rows_skip_dead_blocks_and_change_nothing(B, monkeypatch):
     """round 6, per-row dead work: inside loss() the decoder works on its rows (t, b) sorted by the number of live note steps and passes over
     the (note step, 128-row block) pairs without a target; the loss gets its targets in the same order, the gradients of the time states
