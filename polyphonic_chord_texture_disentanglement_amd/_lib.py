@@ -176,8 +176,14 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+ERROR_HOOKS = []     # callables run before a failed call raises (functional: a composite that returns early leaves the library's wave-priority marker
+                     # wherever it was -- the host's record of it is dropped, so the next product re-sends the state)
+
+
 def check(rc, what):
     if rc != 0:
+        for f in ERROR_HOOKS:
+            f()
         raise RuntimeError('libptvae_hip: %s failed with status %d' % (what, rc))
 
 

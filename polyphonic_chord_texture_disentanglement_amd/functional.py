@@ -15,6 +15,7 @@ import weakref
 
 import torch
 
+from . import _lib as _libmod
 from ._lib import call, check, lib, prec_code, ptr, stream_ptr
 
 
@@ -225,6 +226,14 @@ def _ld(t):
 
 CHAIN_PRIO = True
 _SIDE_DEPTH = [0, 0]          # [nesting depth of Side calls on this thread, priority state last sent to the library]
+
+
+def _forget_prio():
+    _SIDE_DEPTH[1] = -1          # (unknown: _chain_prio sends the wanted state again)
+
+
+if _forget_prio not in _libmod.ERROR_HOOKS:
+    _libmod.ERROR_HOOKS.append(_forget_prio)
 
 
 def _chain_prio():
